@@ -1,0 +1,88 @@
+"""Input definitions of the golden cases.  Inputs are regenerated from seeds
+(auncel_amd.synth); the expected outputs in tests/golden/<case>.npz were produced by the
+compiled reference through oracle/_ref/ref_harness (see make_golden.py)."""
+import numpy as np
+
+from auncel_amd import synth
+
+METRIC_IP, METRIC_L2 = 0, 1  # reference MetricType values (Auncel/Index.h:49-52)
+
+
+def _fixed(xb, xq, nlist, nprobe, ks, metric=METRIC_L2, nshard=0, max_codes=0, cseed=99):
+    cen = synth.sample_centroids(xb, nlist, seed=cseed)
+    return dict(kind="fixed", d=xb.shape[1], nlist=nlist, nprobe=nprobe, metric=metric,
+                centroids=cen, xb=xb, xq=xq, ks=np.array(ks, dtype=np.int64), nshard=nshard,
+                max_codes=max_codes)
+
+
+def fixed_sift_l2():
+    xb, xq = synth.sift_like(20000, 64, d=128, nblobs=40, sigma=30.0, seed=11)
+    return _fixed(xb, xq, 32, 4, [10, 1, 100], nshard=3, max_codes=900)
+
+
+def fixed_gauss_l2_d96():
+    xb, xq = synth.gauss_like(20000, 64, d=96, nblobs=200, sigma=0.6, seed=12)
+    return _fixed(xb, xq, 256, 16, [10, 100], nshard=2)
+
+
+def fixed_deep_ip_d96():
+    xb, xq = synth.deep_like(20000, 64, d=96, nblobs=100, sigma=0.5, seed=13)
+    return _fixed(xb, xq, 64, 8, [100, 10], metric=METRIC_IP, nshard=2)
+
+
+def fixed_gist_l2_d960():
+    xb, xq = synth.gist_like(4000, 32, d=960, nblobs=20, sigma=0.06, seed=14)
+    return _fixed(xb, xq, 32, 8, [10])
+
+
+def fixed_odd_d30():
+    # d % 4 != 0: masked tail in fvec_L2sqr (utils_simd.cpp:405-411); integer data keeps the
+    # BLAS coarse path exact
+    xb, xq = synth.sift_like(6000, 40, d=30, nblobs=30, sigma=25.0, seed=15)
+    return _fixed(xb, xq, 16, 5, [10])
+
+
+def fixed_ragged():
+    # more lists than most vectors can fill, k larger than the candidate count, nprobe > nlist
+    # (coarse keys padded with -1: Heap.h:317-320)
+    xb, xq = synth.sift_like(300, 40, d=16, nblobs=5, sigma=20.0, seed=16)
+    return _fixed(xb, xq, 8, 12, [100, 10], nshard=2)
+
+
+def fixed_dups():
+    # heavy exact ties: few distinct values per dimension and duplicated rows
+    rs = np.random.RandomState(17)
+    base = rs.randint(0, 4, size=(500, 16)).astype(np.float32)
+    xb = base[rs.randint(0, 500, size=8000)]
+    xq = base[rs.randint(0, 500, size=48)] + (rs.randint(0, 2, size=(48, 16))).astype(np.float32)
+    return _fixed(xb, xq, 16, 6, [10, 100], nshard=2)
+
+
+def _auncel(xb, xq, ts, ses, runs, metric=METRIC_L2, nlist=1024, K=100, niter=10):
+    return dict(kind="auncel", d=xb.shape[1], nlist=nlist, metric=metric, max_topk=K,
+                train_num=ts, test_num=ses, xb=xb, xq=xq, kmeans_niter=niter,
+                topks=np.array([r[0] for r in runs], dtype=np.int64),
+                require_acc=np.array([r[1] for r in runs], dtype=np.float32),
+                multipler=np.array([r[2] for r in runs], dtype=np.float32),
+                std_m=np.array([r[3] for r in runs], dtype=np.float32))
+
+
+def auncel_sift_d32():
+    xb, xq = synth.sift_like(100000, 400, d=32, nblobs=300, sigma=40.0, seed=21)
+    return _auncel(xb, xq, 200, 200, [(10, 0.9, 2.0, 1.0), (100, 0.95, 1.5, 2.0), (50, 0.99, 1.0, 0.5)])
+
+
+def auncel_gauss_d64():
+    xb, xq = synth.gauss_like(120000, 300, d=64, nblobs=400, sigma=0.8, seed=22)
+    return _auncel(xb, xq, 200, 100, [(10, 0.9, 1.7, 1.0), (100, 0.9, 1.2, 3.0)])
+
+
+CASES = {f.__name__: f for f in [fixed_sift_l2, fixed_gauss_l2_d96, fixed_deep_ip_d96, fixed_gist_l2_d960,
+                                  fixed_odd_d30, fixed_ragged, fixed_dups, auncel_sift_d32, auncel_gauss_d64]}
+
+
+def input_sha(case):
+    arrs = [case[k] for k in ("xb", "xq") if k in case]
+    if "centroids" in case:
+        arrs.append(case["centroids"])
+    return synth.sha(*arrs)

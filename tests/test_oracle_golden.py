@@ -1,0 +1,167 @@
+"""Pins the CPU restatement (oracle/ivf_oracle.cpp) against outputs of the compiled reference
+(tests/golden/*.npz, made by tests/golden/make_golden.py through oracle/_ref/ref_harness).
+Bit-exact on ids AND distances for every pinned path."""
+import numpy as np
+import pytest
+
+from util import AUNCEL, FIXED, load_case, traces_from_gold
+
+
+def _lists(oracle, case, gold, cen=None):
+    cen = case["centroids"] if cen is None else cen
+    return oracle.Lists(case["metric"], cen, case["xb"], gold["assign"])
+
+
+@pytest.mark.parametrize("name", FIXED)
+def test_coarse_exact_and_assign(oracle, name):
+    case, gold = load_case(name)
+    if case["d"] % 4 != 0:
+        pytest.skip("reference takes the BLAS path when d % 4 != 0")
+    D, I = oracle.knn(case["metric"], case["xq"], case["centroids"], case["nprobe"])
+    assert np.array_equal(I, gold["coarse_keys_sse"])
+    assert np.array_equal(D.view(np.uint32), gold["coarse_dis_sse"].view(np.uint32))
+    # add(): every vector goes to its nearest centroid (k=1 through the same code)
+    _, a = oracle.knn(case["metric"], case["xb"][:2000], case["centroids"], 1, gemm=False)
+    exact = case["name"] if "name" in case else None
+    # the reference assigns with nx >= 20 -> BLAS; on integer data that is exact
+    if name in ("fixed_sift_l2", "fixed_ragged", "fixed_dups"):
+        assert np.array_equal(a[:, 0], gold["assign"][:2000])
+
+
+@pytest.mark.parametrize("name", FIXED)
+def test_coarse_gemm_path_integer_data(oracle, name):
+    case, gold = load_case(name)
+    if name not in ("fixed_sift_l2", "fixed_odd_d30", "fixed_ragged"):
+        pytest.skip("float data: BLAS summation order is unpinned")
+    D, I = oracle.knn(case["metric"], case["xq"], case["centroids"], case["nprobe"], gemm=True)
+    assert np.array_equal(D, gold["coarse_dis_blas"])
+    # ids can differ only inside groups of exactly equal distances
+    assert np.array_equal(np.sort(I, axis=1) if False else I, gold["coarse_keys_blas"]) or _ties_only(D, I, gold["coarse_keys_blas"])
+
+
+def _ties_only(D, I, Iref):
+    bad = np.nonzero(I != Iref)
+    for q, j in zip(*bad):
+        same = D[q] == D[q, j]
+        if set(I[q][same]) != set(Iref[q][same]):
+            return False
+    return True
+
+
+@pytest.mark.parametrize("name", FIXED)
+def test_search_preassigned(oracle, name):
+    case, gold = load_case(name)
+    lists = _lists(oracle, case, gold)
+    assert np.array_equal(lists.sizes, gold["list_sizes"])
+    for k in case["ks"]:
+        for pairs in (False, True):
+            suf = f"_k{k}" + ("_pairs" if pairs else "")
+            D, I, st = oracle.search_preassigned(lists, case["xq"], int(k), gold["coarse_keys_sse"],
+                                                 gold["coarse_dis_sse"], store_pairs=pairs)
+            assert np.array_equal(I, gold["I" + suf]), suf
+            assert np.array_equal(D.view(np.uint32), gold["D" + suf].view(np.uint32)), suf
+            assert np.array_equal(st, gold["stats" + suf]), suf
+        if case["max_codes"]:
+            D, I, _ = oracle.search_preassigned(lists, case["xq"], int(k), gold["coarse_keys_sse"],
+                                                gold["coarse_dis_sse"], max_codes=case["max_codes"])
+            assert np.array_equal(I, gold[f"I_k{k}_maxcodes"])
+            assert np.array_equal(D.view(np.uint32), gold[f"D_k{k}_maxcodes"].view(np.uint32))
+
+
+@pytest.mark.parametrize("name", FIXED)
+def test_scanner_raw_heap(oracle, name):
+    case, gold = load_case(name)
+    lists = _lists(oracle, case, gold)
+    k = int(case["ks"][0])
+    ns = gold["scan_heap_D"].shape[0]
+    is_l2 = case["metric"] == 1
+    for i in range(ns):
+        simi = np.full(k, np.finfo(np.float32).max if is_l2 else -np.finfo(np.float32).max, dtype=np.float32)
+        idxi = np.full(k, -1, dtype=np.int64)
+        for p in range(case["nprobe"]):
+            key = int(gold["coarse_keys_sse"][i, p])
+            if key < 0:
+                continue
+            b, e = int(lists.off[key]), int(lists.off[key + 1])
+            if e == b:
+                continue
+            nup = oracle.scan_codes(case["metric"], case["xq"][i], lists.codes[b:e], lists.ids[b:e], key, False, simi, idxi)
+            assert nup == gold["scan_nup"][i, p]
+            d0 = (oracle.lib().orc_fvec_L2sqr if is_l2 else oracle.lib().orc_fvec_inner_product)(
+                oracle._f(oracle.f32(case["xq"][i])), oracle._f(lists.codes[b:b + 1]), oracle.C.c_size_t(case["d"]))
+            assert np.float32(d0) == gold["scan_dist_to_code"][i, p]
+        assert np.array_equal(simi.view(np.uint32), gold["scan_heap_D"][i].view(np.uint32))
+        assert np.array_equal(idxi, gold["scan_heap_I"][i])
+
+
+@pytest.mark.parametrize("name", [n for n in FIXED if n not in ("fixed_gist_l2_d960", "fixed_odd_d30")])
+def test_shards_merge(oracle, name):
+    case, gold = load_case(name)
+    nshard = case["nshard"]
+    a = gold["assign"]
+    for k in case["ks"]:
+        allD, allI = [], []
+        for s in range(nshard):
+            sub = oracle.Lists(case["metric"], case["centroids"], case["xb"], np.where(a % nshard == s, a, -1))
+            D, I, _ = oracle.search_preassigned(sub, case["xq"], int(k), gold["coarse_keys_sse"], gold["coarse_dis_sse"])
+            allD.append(D)
+            allI.append(I)
+        D, I = oracle.merge_tables(case["metric"], np.stack(allD), np.stack(allI))
+        assert np.array_equal(I, gold[f"I_shards_k{k}"])
+        assert np.array_equal(D.view(np.uint32), gold[f"D_shards_k{k}"].view(np.uint32))
+
+
+@pytest.mark.parametrize("name", AUNCEL)
+def test_auncel_offline(oracle, name):
+    case, gold = load_case(name)
+    K, ts = case["max_topk"], case["train_num"]
+    cen = gold["centroids"]
+    assert np.array_equal(oracle.interdis(case["metric"], cen).view(np.uint32), gold["interdis_cem"].view(np.uint32))
+    assert np.array_equal(oracle.arcos_table().view(np.uint32), gold["arcos_list"].view(np.uint32))
+    lists = _lists(oracle, case, gold, cen)
+    ntr = len(traces_from_gold(gold))
+    raw = [np.full((ts * (K // 4), 2), -1, dtype=np.float32) for _ in range(ntr)]
+    # the reference trains in 10 batches through the BLAS coarse path: feed its coarse output
+    D, I = oracle.train_samples(lists, case["xq"][:ts], K, gold["coarse_keys_blas_train"], gold["coarse_dis_blas_train"],
+                                gold["interdis_cem"], gold["arcos_list"], gold["gtD"], 0, ts, raw)
+    assert np.array_equal(I, gold["train_I"])
+    assert np.array_equal(D.view(np.uint32), gold["train_D"].view(np.uint32))
+    for i in range(ntr):
+        assert np.array_equal(raw[i].view(np.uint32), gold[f"raw_trace{i}"].view(np.uint32)), i
+        x, y, s = oracle.trace_sb(gold[f"raw_trace{i}"])
+        assert np.array_equal(x.view(np.uint32), gold[f"sb_trace{i}"][:, 0].view(np.uint32)), i
+        assert np.array_equal(y.view(np.uint32), gold[f"sb_trace{i}"][:, 1].view(np.uint32)), i
+        assert np.array_equal(s.view(np.uint32), gold[f"sb_stds{i}"].view(np.uint32)), i
+
+
+@pytest.mark.parametrize("name", AUNCEL)
+def test_auncel_set_online(oracle, name):
+    case, gold = load_case(name)
+    ts, nlist = case["train_num"], case["nlist"]
+    for i in range(0, case["test_num"], 7):
+        dtb, c2c = oracle.set_online(case["metric"], nlist, gold["coarse_dis_sse"][ts + i], gold["coarse_keys_sse"][ts + i],
+                                     gold["interdis_cem"], gold["arcos_list"])
+        assert np.array_equal(dtb.view(np.uint32), gold["disToBoundary"][i].view(np.uint32))
+        assert np.array_equal(c2c.view(np.uint32), gold["cenTocen"][i].view(np.uint32))
+
+
+@pytest.mark.parametrize("name", AUNCEL)
+def test_auncel_online(oracle, name):
+    case, gold = load_case(name)
+    K, ts, ses = case["max_topk"], case["train_num"], case["test_num"]
+    lists = _lists(oracle, case, gold, gold["centroids"])
+    traces = traces_from_gold(gold)
+    for r in range(len(case["topks"])):
+        for prof in (False, True):
+            tun = oracle.Tuner(gold["interdis_cem"], traces, K, ts + ses, arcos=gold["arcos_list"])
+            req = np.full(ts + ses, case["require_acc"][r], dtype=np.float32)
+            st = tun.struct(int(case["topks"][r]), req, float(case["multipler"][r]), float(case["std_m"][r]),
+                            gt_D=gold["gtD"], profile=prof)
+            D, I, stats = oracle.search_preassigned(lists, case["xq"][ts:], K, gold["coarse_keys_sse"][ts:],
+                                                    gold["coarse_dis_sse"][ts:], tuner=st, offset=ts)
+            suf = f"_r{r}" + ("_prof" if prof else "")
+            assert np.array_equal(tun.my_nprobe[ts:].astype(np.uint64), gold["my_nprobe" + suf]), suf
+            assert np.array_equal(I, gold["I" + suf]), suf
+            assert np.array_equal(D.view(np.uint32), gold["D" + suf].view(np.uint32)), suf
+            assert np.array_equal(tun.t_recalls[ts:].view(np.uint32), gold["t_recalls" + suf].view(np.uint32)), suf
+            assert np.array_equal(stats, gold["stats" + suf]), suf
