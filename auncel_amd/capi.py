@@ -1,0 +1,256 @@
+"""ctypes binding of include/auncel_amd.h (the C-ABI drop-in boundary).
+
+Fails loudly when libauncel_amd.so is missing: there is no CPU path in this package."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+METRIC_IP, METRIC_L2 = 0, 1
+
+_f32p = C.POINTER(C.c_float)
+_i64p = C.POINTER(C.c_int64)
+_u64p = C.POINTER(C.c_uint64)
+_szp = C.POINTER(C.c_size_t)
+_LIB = None
+
+SYMBOLS = [
+    "amd_ivf_last_error", "amd_ivf_device_count", "amd_ivf_create", "amd_ivf_destroy", "amd_ivf_set_centroids",
+    "amd_ivf_set_lists", "amd_ivf_add", "amd_ivf_ntotal", "amd_ivf_list_size", "amd_ivf_get_list", "amd_ivf_coarse",
+    "amd_ivf_search_preassigned", "amd_ivf_search", "amd_ivf_scan_codes", "amd_ivf_distance_to_code", "amd_ivf_stats",
+    "amd_ivf_set_queries", "amd_ivf_search_resident", "amd_ivf_set_interdis", "amd_ivf_get_interdis",
+    "amd_ivf_set_tuner", "amd_ivf_search_adaptive", "amd_ivf_train_samples", "amd_ivf_merge_tables",
+    "amd_ivf_last_timing",
+]
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"auncel_amd error {code}: {msg}")
+        self.code = code
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_build.LIB):
+            raise ImportError(f"{_build.LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950).  auncel_amd has no CPU fallback.")
+        L = C.CDLL(_build.LIB)
+        L.amd_ivf_last_error.restype = C.c_char_p
+        for s in SYMBOLS[1:]:
+            getattr(L, s).restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+def _chk(rc):
+    if rc != 0:
+        raise EngineError(rc, lib().amd_ivf_last_error().decode())
+
+
+def _f(a):
+    return a.ctypes.data_as(_f32p) if a is not None else None
+
+
+def _i(a):
+    return a.ctypes.data_as(_i64p) if a is not None else None
+
+
+def f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def device_count():
+    n = C.c_int(0)
+    _chk(lib().amd_ivf_device_count(C.byref(n)))
+    return n.value
+
+
+def merge_tables(metric, all_D, all_I):
+    all_D, all_I = f32(all_D), i64(all_I)
+    nshard, n, k = all_D.shape
+    D = np.empty((n, k), np.float32)
+    I = np.empty((n, k), np.int64)
+    _chk(lib().amd_ivf_merge_tables(metric, C.c_size_t(n), C.c_size_t(k), C.c_size_t(nshard), _f(all_D), _i(all_I), _f(D), _i(I)))
+    return D, I
+
+
+class Handle:
+    """thin owner of an amd_ivf_t*"""
+
+    def __init__(self, d, nlist, metric=METRIC_L2, device=0):
+        self.d, self.nlist, self.metric, self.device = int(d), int(nlist), int(metric), int(device)
+        self._h = C.c_void_p()
+        _chk(lib().amd_ivf_create(self.d, C.c_size_t(self.nlist), self.metric, self.device, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().amd_ivf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- contents
+    def set_centroids(self, c):
+        c = f32(c)
+        assert c.shape == (self.nlist, self.d)
+        _chk(lib().amd_ivf_set_centroids(self._h, _f(c)))
+
+    def set_lists(self, sizes, codes, ids):
+        sizes = np.ascontiguousarray(sizes, dtype=np.uintp)
+        codes = [f32(c) for c in codes]
+        ids = [i64(i) for i in ids]
+        cp = (_f32p * self.nlist)(*[_f(c) for c in codes])
+        ip = (_i64p * self.nlist)(*[_i(i) for i in ids])
+        _chk(lib().amd_ivf_set_lists(self._h, sizes.ctypes.data_as(_szp), cp, ip))
+
+    def set_lists_from_assign(self, xb, assign, ids=None):
+        """lists as IndexIVFFlat::add_core builds them: database order inside every list"""
+        assign = np.asarray(assign, dtype=np.int64)
+        gid = np.arange(len(assign), dtype=np.int64) if ids is None else np.asarray(ids, dtype=np.int64)
+        keep = np.nonzero(assign >= 0)[0]
+        order = keep[np.argsort(assign[keep], kind="stable")]
+        sizes = np.bincount(assign[keep], minlength=self.nlist)
+        off = np.concatenate([[0], np.cumsum(sizes)])
+        xs, gs = f32(xb)[order], gid[order]
+        self.set_lists(sizes, [xs[off[l]:off[l + 1]] for l in range(self.nlist)],
+                       [gs[off[l]:off[l + 1]] for l in range(self.nlist)])
+
+    def add(self, x, xids=None, precomputed_idx=None):
+        x = f32(x)
+        xi = i64(xids) if xids is not None else None
+        pi = i64(precomputed_idx) if precomputed_idx is not None else None
+        _chk(lib().amd_ivf_add(self._h, C.c_size_t(x.shape[0]), _f(x), _i(xi), _i(pi)))
+
+    @property
+    def ntotal(self):
+        n = C.c_size_t(0)
+        _chk(lib().amd_ivf_ntotal(self._h, C.byref(n)))
+        return n.value
+
+    def list_size(self, l):
+        n = C.c_size_t(0)
+        _chk(lib().amd_ivf_list_size(self._h, C.c_size_t(l), C.byref(n)))
+        return n.value
+
+    def get_list(self, l):
+        n = self.list_size(l)
+        codes = np.empty((n, self.d), np.float32)
+        ids = np.empty(n, np.int64)
+        _chk(lib().amd_ivf_get_list(self._h, C.c_size_t(l), _f(codes), _i(ids)))
+        return codes, ids
+
+    # ---- search
+    def coarse(self, x, nprobe, mode=0):
+        x = f32(x)
+        n = x.shape[0]
+        D = np.empty((n, nprobe), np.float32)
+        I = np.empty((n, nprobe), np.int64)
+        _chk(lib().amd_ivf_coarse(self._h, C.c_size_t(n), _f(x), C.c_size_t(nprobe), _f(D), _i(I), mode))
+        return D, I
+
+    def search_preassigned(self, x, k, keys, coarse_dis=None, store_pairs=False, max_codes=0):
+        x, keys = f32(x), i64(keys)
+        n, nprobe = keys.shape
+        cd = f32(coarse_dis) if coarse_dis is not None else None
+        D = np.empty((n, k), np.float32)
+        I = np.empty((n, k), np.int64)
+        _chk(lib().amd_ivf_search_preassigned(self._h, C.c_size_t(n), _f(x), C.c_size_t(k), C.c_size_t(nprobe), _i(keys),
+                                              _f(cd), _f(D), _i(I), int(store_pairs), C.c_size_t(max_codes)))
+        return D, I
+
+    def search(self, x, k, nprobe, coarse_mode=0):
+        x = f32(x)
+        n = x.shape[0]
+        D = np.empty((n, k), np.float32)
+        I = np.empty((n, k), np.int64)
+        _chk(lib().amd_ivf_search(self._h, C.c_size_t(n), _f(x), C.c_size_t(k), C.c_size_t(nprobe), coarse_mode, _f(D), _i(I)))
+        return D, I
+
+    def scan_codes(self, query, list_no, simi, idxi, store_pairs=False):
+        query = f32(query)
+        nup = C.c_size_t(0)
+        _chk(lib().amd_ivf_scan_codes(self._h, _f(query), C.c_size_t(list_no), int(store_pairs), C.c_size_t(simi.shape[0]),
+                                      _f(simi), _i(idxi), C.byref(nup)))
+        return nup.value
+
+    def distance_to_code(self, query, list_no, offset):
+        query = f32(query)
+        out = C.c_float(0)
+        _chk(lib().amd_ivf_distance_to_code(self._h, _f(query), C.c_size_t(list_no), C.c_size_t(offset), C.byref(out)))
+        return np.float32(out.value)
+
+    def stats(self, reset=False):
+        st = (C.c_size_t * 4)()
+        _chk(lib().amd_ivf_stats(self._h, st, int(reset)))
+        return dict(nq=st[0], nlist=st[1], ndis=st[2], nheap_updates=st[3])
+
+    def set_queries(self, x):
+        x = f32(x)
+        _chk(lib().amd_ivf_set_queries(self._h, C.c_size_t(x.shape[0]), _f(x)))
+
+    def search_resident(self, start, n, k, nprobe, coarse_mode=0):
+        D = np.empty((n, k), np.float32)
+        I = np.empty((n, k), np.int64)
+        _chk(lib().amd_ivf_search_resident(self._h, C.c_size_t(start), C.c_size_t(n), C.c_size_t(k), C.c_size_t(nprobe),
+                                           coarse_mode, _f(D), _i(I)))
+        return D, I
+
+    # ---- Auncel
+    def set_interdis(self, table=None):
+        t = f32(table) if table is not None else None
+        _chk(lib().amd_ivf_set_interdis(self._h, _f(t)))
+
+    def get_interdis(self):
+        t = np.empty(self.nlist * (self.nlist - 1) // 2, np.float32)
+        _chk(lib().amd_ivf_get_interdis(self._h, _f(t)))
+        return t
+
+    def set_tuner(self, max_topk, traces, arcos):
+        """traces: list of (x, y, std)"""
+        n = len(traces)
+        lens = np.array([len(t[0]) for t in traces], dtype=np.uintp)
+        xs, ys, ss = [f32(t[0]) for t in traces], [f32(t[1]) for t in traces], [f32(t[2]) for t in traces]
+        arcos = f32(arcos)
+        _chk(lib().amd_ivf_set_tuner(self._h, C.c_size_t(max_topk), C.c_size_t(n), lens.ctypes.data_as(_szp),
+                                     (_f32p * n)(*[_f(a) for a in xs]), (_f32p * n)(*[_f(a) for a in ys]),
+                                     (_f32p * n)(*[_f(a) for a in ss]), _f(arcos)))
+        self.max_topk = max_topk
+
+    def search_adaptive(self, start, n, query_topk, multipler, std_m, require_acc, my_nprobe, t_recalls, gt_D=None,
+                        profile=False, coarse_mode=0):
+        req = f32(require_acc)
+        gt = f32(gt_D) if gt_D is not None else None
+        assert my_nprobe.dtype == np.uint64 and t_recalls.dtype == np.float32
+        K = self.max_topk
+        D = np.empty((n, K), np.float32)
+        I = np.empty((n, K), np.int64)
+        _chk(lib().amd_ivf_search_adaptive(self._h, C.c_size_t(start), C.c_size_t(n), C.c_size_t(query_topk),
+                                           C.c_float(multipler), C.c_float(std_m), _f(req), _f(gt), int(profile), coarse_mode,
+                                           my_nprobe.ctypes.data_as(_u64p), _f(t_recalls), _f(D), _i(I)))
+        return D, I
+
+    def train_samples(self, start, n, max_topk, gt_D, train_num, raw, coarse_mode=0):
+        gt = f32(gt_D)
+        D = np.empty((n, max_topk), np.float32)
+        I = np.empty((n, max_topk), np.int64)
+        ptrs = (_f32p * len(raw))(*[_f(r) for r in raw])
+        _chk(lib().amd_ivf_train_samples(self._h, C.c_size_t(start), C.c_size_t(n), C.c_size_t(max_topk), _f(gt),
+                                         C.c_size_t(train_num), coarse_mode, ptrs, _f(D), _i(I)))
+        return D, I
+
+    def last_timing(self):
+        t = (C.c_double * 6)()
+        lib().amd_ivf_last_timing(self._h, t)
+        return dict(coarse_ms=t[0], scan_ms=t[1], select_ms=t[2], total_ms=t[3], scan_launches=t[4], scan_bytes=t[5])

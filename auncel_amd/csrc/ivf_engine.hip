@@ -1,0 +1,1340 @@
+// Host side of the gfx950 IVF-Flat engine: device-resident index, work-list construction,
+// round scheduling for the adaptive (Auncel) search, and the extern "C" boundary declared in
+// include/auncel_amd.h.  No CPU compute path exists here: distances and selection always run in
+// the kernels of ivf_kernels.hip.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/auncel_amd.h"
+#include "ivf_kernels.h"
+
+using namespace amdivf;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct EngineError : std::runtime_error {  // what the reference raises as FaissException
+    using std::runtime_error::runtime_error;
+};
+
+#define HIP_CHECK(expr)                                                                              \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess)                                                                        \
+            throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " at " #expr); \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    void ensure(size_t bytes) {
+        if (bytes <= cap) return;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        HIP_CHECK(hipMalloc(&p, want));
+        cap = want;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    ~DevBuf() { release(); }
+};
+
+struct PinnedBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    void ensure(size_t bytes) {
+        if (bytes <= cap) return;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
+        cap = want;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+    ~PinnedBuf() {
+        if (p) (void)hipHostFree(p);
+    }
+};
+
+struct EventTimer {
+    struct Span {
+        hipEvent_t a, b;
+        int cat;
+    };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get() {
+        if (!pool.empty()) {
+            hipEvent_t e = pool.back();
+            pool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreate(&e));
+        return e;
+    }
+    size_t begin(int cat, hipStream_t s) {
+        Span sp{get(), get(), cat};
+        HIP_CHECK(hipEventRecord(sp.a, s));
+        spans.push_back(sp);
+        return spans.size() - 1;
+    }
+    void end(size_t i, hipStream_t s) { HIP_CHECK(hipEventRecord(spans[i].b, s)); }
+    // call after the stream has been synchronised
+    void collect(double* ms_by_cat, int ncat, double* launches_by_cat) {
+        for (int c = 0; c < ncat; c++) ms_by_cat[c] = 0, launches_by_cat[c] = 0;
+        for (auto& sp : spans) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+                ms_by_cat[sp.cat] += ms;
+                launches_by_cat[sp.cat] += 1;
+            }
+            pool.push_back(sp.a);
+            pool.push_back(sp.b);
+        }
+        spans.clear();
+    }
+    ~EventTimer() {
+        for (auto& sp : spans) {
+            (void)hipEventDestroy(sp.a);
+            (void)hipEventDestroy(sp.b);
+        }
+        for (auto e : pool) (void)hipEventDestroy(e);
+    }
+};
+
+enum { CAT_COARSE = 0, CAT_SCAN = 1, CAT_SELECT = 2, NCAT = 3 };
+
+}  // namespace
+
+struct amd_ivf {
+    int d = 0, dpad = 0, metric = METRIC_L2, device = 0;
+    size_t nlist = 0, ntotal = 0;
+    hipStream_t stream = nullptr;
+
+    // host mirror of the inverted lists (ArrayInvertedLists layout) + device CSR copy
+    std::vector<std::vector<float>> h_codes;  // rows padded to dpad
+    std::vector<std::vector<int64_t>> h_ids;
+    std::vector<uint64_t> h_list_off;
+    bool lists_dirty = true;
+    DevBuf d_codes, d_ids, d_list_off, d_centroids;
+    std::vector<float> h_centroids;  // nlist x dpad
+    bool have_centroids = false;
+
+    // resident queries
+    DevBuf d_resident;
+    size_t n_resident = 0;
+
+    // Auncel state
+    DevBuf d_interdis;
+    bool have_interdis = false;
+    DevBuf d_arcos, d_trace_off, d_trace_x, d_trace_y, d_trace_std;
+    size_t tuner_max_topk = 0, tuner_ntraces = 0;
+    bool have_tuner = false;
+
+    // workspaces (grow only)
+    DevBuf w_x, w_dist, w_items, w_pair_query, w_pair_out, w_seg_off, w_seg_list, w_seg_count, w_qsel;
+    DevBuf w_heap_val, w_heap_ref, w_stage, w_nscan, w_done, w_pre_val, w_stoped, w_dtb, w_D, w_I;
+    DevBuf w_cdis, w_ckeys, w_stats, w_error, w_misc, w_misc2, w_misc3, w_rawptrs;
+    DevBuf c_heap_val, c_heap_ref, c_stage, c_nscan, c_done, c_seg_off, c_seg_list, c_seg_count;
+    PinnedBuf p_items, p_pair_query, p_pair_out, p_seg_off, p_seg_list, p_seg_count, p_qsel;
+
+    size_t dist_budget_floats = (size_t)768 << 20;  // 3 GiB of distances per scan launch
+    size_t stats_host[4] = {0, 0, 0, 0};
+    double timing[6] = {0, 0, 0, 0, 0, 0};
+    double scan_bytes = 0;
+    EventTimer timer;
+
+    ~amd_ivf() {
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+void use_device(const amd_ivf* h) { HIP_CHECK(hipSetDevice(h->device)); }
+
+// ------------------------------------------------------------------------------------ lists
+void upload_lists(amd_ivf* h) {
+    if (!h->lists_dirty) return;
+    use_device(h);
+    h->h_list_off.assign(h->nlist + 1, 0);
+    for (size_t l = 0; l < h->nlist; l++) h->h_list_off[l + 1] = h->h_list_off[l] + h->h_ids[l].size();
+    size_t nt = h->h_list_off[h->nlist];
+    h->d_codes.ensure(std::max<size_t>(nt, 1) * h->dpad * sizeof(float));
+    h->d_ids.ensure(std::max<size_t>(nt, 1) * sizeof(int64_t));
+    h->d_list_off.ensure((h->nlist + 1) * sizeof(uint64_t));
+    for (size_t l = 0; l < h->nlist; l++) {
+        size_t n = h->h_ids[l].size();
+        if (!n) continue;
+        HIP_CHECK(hipMemcpyAsync(h->d_codes.as<float>() + h->h_list_off[l] * h->dpad, h->h_codes[l].data(),
+                                 n * h->dpad * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HIP_CHECK(hipMemcpyAsync(h->d_ids.as<int64_t>() + h->h_list_off[l], h->h_ids[l].data(), n * sizeof(int64_t),
+                                 hipMemcpyHostToDevice, h->stream));
+    }
+    HIP_CHECK(hipMemcpyAsync(h->d_list_off.p, h->h_list_off.data(), (h->nlist + 1) * sizeof(uint64_t),
+                             hipMemcpyHostToDevice, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->lists_dirty = false;
+}
+
+// copy n x d host rows into a device matrix with row stride dpad (zero padded)
+void upload_rows(amd_ivf* h, float* dst, const float* src, size_t n) {
+    if (n == 0) return;
+    if (h->d == h->dpad) {
+        HIP_CHECK(hipMemcpyAsync(dst, src, n * h->d * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    } else {
+        HIP_CHECK(hipMemsetAsync(dst, 0, n * h->dpad * sizeof(float), h->stream));
+        HIP_CHECK(hipMemcpy2DAsync(dst, h->dpad * sizeof(float), src, h->d * sizeof(float), h->d * sizeof(float), n,
+                                   hipMemcpyHostToDevice, h->stream));
+    }
+}
+
+// ------------------------------------------------------------------------------------ state
+struct State {  // per query slot
+    float* heap_val;
+    int64_t* heap_ref;
+    uint32_t* stage;
+    unsigned long long* nscan;
+    uint32_t* done;
+};
+
+void init_state(amd_ivf* h, size_t n, size_t k, bool tune_or_train) {
+    h->w_heap_val.ensure(n * k * sizeof(float));
+    h->w_heap_ref.ensure(n * k * sizeof(int64_t));
+    h->w_stage.ensure(n * 4);
+    h->w_nscan.ensure(n * 8);
+    h->w_done.ensure(n * 4);
+    h->w_pre_val.ensure(n * 4);
+    h->w_stoped.ensure(n * 4);
+    h->w_D.ensure(n * k * sizeof(float));
+    h->w_I.ensure(n * k * sizeof(int64_t));
+    h->w_stats.ensure(3 * 8);
+    h->w_error.ensure(4);
+    launch_fill_f32(h->w_heap_val.as<float>(), n * k, h->metric == METRIC_L2 ? FLT_MAX : -FLT_MAX, h->stream);
+    launch_fill_i64(h->w_heap_ref.as<int64_t>(), n * k, -1, h->stream);
+    HIP_CHECK(hipMemsetAsync(h->w_stage.p, 0, n * 4, h->stream));
+    HIP_CHECK(hipMemsetAsync(h->w_nscan.p, 0, n * 8, h->stream));
+    HIP_CHECK(hipMemsetAsync(h->w_done.p, 0, n * 4, h->stream));
+    HIP_CHECK(hipMemsetAsync(h->w_pre_val.p, 0, n * 4, h->stream));
+    HIP_CHECK(hipMemsetAsync(h->w_stoped.p, 0, n * 4, h->stream));
+    HIP_CHECK(hipMemsetAsync(h->w_stats.p, 0, 24, h->stream));
+    HIP_CHECK(hipMemsetAsync(h->w_error.p, 0, 4, h->stream));
+    if (tune_or_train) h->w_dtb.ensure(n * (h->nlist / 8 + 20) * sizeof(float));
+}
+
+// ------------------------------------------------------------------------------------ rounds
+struct RoundSpec {
+    // participating query slots and, for each, the probes [p0, p0+cnt) to run this round
+    std::vector<uint32_t> slot;
+    std::vector<uint32_t> p0, cnt;
+    const int64_t* keys = nullptr;  // host, [.. x key_stride], row = slot
+    size_t key_stride = 0;
+    int k = 0;
+    int store_pairs = 0;
+    size_t max_codes = 0;
+    int finalize_all = 0;
+    uint32_t total_nprobe = 0;
+    uint64_t id_offset = 0;
+    const float* d_x = nullptr;  // device queries, row = slot
+    TunerDev tuner{};
+    TrainDev train{};
+    const float* d_cdis = nullptr;     // device coarse arrays for set_online (row = slot)
+    const int64_t* d_ckeys = nullptr;
+    uint32_t coarse_stride = 0;
+    int raw_heap_out = 0;
+};
+
+void exec_round(amd_ivf* h, const RoundSpec& r) {
+    const size_t m = r.slot.size();
+    if (m == 0) return;
+    const size_t nlist = h->nlist;
+    const std::vector<uint64_t>& off = h->h_list_off;
+    size_t q0 = 0;
+    std::vector<uint32_t> lcount(nlist + 1);
+    while (q0 < m) {
+        // ---- sub-batch [q0, q1) bounded by the distance-buffer budget
+        size_t q1 = q0, total = 0;
+        uint32_t rp = 0;
+        while (q1 < m) {
+            size_t need = 0;
+            for (uint32_t p = 0; p < r.cnt[q1]; p++) {
+                int64_t key = r.keys[(size_t)r.slot[q1] * r.key_stride + r.p0[q1] + p];
+                if (key < 0) continue;
+                if ((size_t)key >= nlist) throw EngineError("Invalid key=" + std::to_string(key) + " nlist=" + std::to_string(nlist));
+                need += off[key + 1] - off[key];
+            }
+            if (q1 > q0 && total + need > h->dist_budget_floats) break;
+            total += need;
+            rp = std::max(rp, r.cnt[q1]);
+            q1++;
+        }
+        const size_t mb = q1 - q0;
+        if (rp == 0) rp = 1;
+        // ---- segments (query-major distance rows) and pairs grouped by list
+        h->p_seg_off.ensure(mb * rp * 8);
+        h->p_seg_list.ensure(mb * rp * 4);
+        h->p_seg_count.ensure(mb * 4);
+        h->p_qsel.ensure(mb * 4);
+        uint64_t* seg_off = h->p_seg_off.as<uint64_t>();
+        int32_t* seg_list = h->p_seg_list.as<int32_t>();
+        uint32_t* seg_count = h->p_seg_count.as<uint32_t>();
+        uint32_t* qsel = h->p_qsel.as<uint32_t>();
+        std::fill(lcount.begin(), lcount.end(), 0u);
+        size_t npairs = 0;
+        uint64_t cursor = 0;
+        double bytes = 0;
+        for (size_t i = 0; i < mb; i++) {
+            const size_t qi = q0 + i;
+            seg_count[i] = r.cnt[qi];
+            qsel[i] = r.slot[qi];
+            for (uint32_t p = 0; p < rp; p++) {
+                int64_t key = -1;
+                if (p < r.cnt[qi]) key = r.keys[(size_t)r.slot[qi] * r.key_stride + r.p0[qi] + p];
+                seg_list[i * rp + p] = (int32_t)key;
+                seg_off[i * rp + p] = cursor;
+                if (key >= 0) {
+                    size_t sz = off[key + 1] - off[key];
+                    if (sz) {
+                        lcount[key + 1]++;
+                        npairs++;
+                        cursor += sz;
+                        bytes += (double)sz * h->d * 4.0;
+                    }
+                }
+            }
+        }
+        h->scan_bytes += bytes;
+        for (size_t l = 0; l < nlist; l++) lcount[l + 1] += lcount[l];
+        h->p_pair_query.ensure(std::max<size_t>(npairs, 1) * 4);
+        h->p_pair_out.ensure(std::max<size_t>(npairs, 1) * 8);
+        uint32_t* pair_query = h->p_pair_query.as<uint32_t>();
+        uint64_t* pair_out = h->p_pair_out.as<uint64_t>();
+        {
+            std::vector<uint32_t> fill(lcount.begin(), lcount.end() - 1);
+            for (size_t i = 0; i < mb; i++) {
+                const size_t qi = q0 + i;
+                for (uint32_t p = 0; p < r.cnt[qi]; p++) {
+                    int32_t key = seg_list[i * rp + p];
+                    if (key < 0 || off[key + 1] == off[key]) continue;
+                    uint32_t pos = fill[key]++;
+                    pair_query[pos] = r.slot[qi];
+                    pair_out[pos] = seg_off[i * rp + p];
+                }
+            }
+        }
+        // ---- tiles
+        size_t nitems = 0;
+        for (size_t l = 0; l < nlist; l++) {
+            uint32_t c = lcount[l + 1] - lcount[l];
+            if (!c) continue;
+            uint32_t qg = c <= SCAN_RQ ? 1 : c <= 2 * SCAN_RQ ? 2 : 4;
+            size_t tv = (4 / qg) * SCAN_WAVE_VECS, sz = off[l + 1] - off[l];
+            nitems += ((c + qg * SCAN_RQ - 1) / (qg * SCAN_RQ)) * ((sz + tv - 1) / tv);
+        }
+        h->p_items.ensure(std::max<size_t>(nitems, 1) * sizeof(ScanItem));
+        ScanItem* items = h->p_items.as<ScanItem>();
+        size_t ni = 0;
+        for (size_t l = 0; l < nlist; l++) {
+            uint32_t c = lcount[l + 1] - lcount[l];
+            if (!c) continue;
+            uint32_t qg = c <= SCAN_RQ ? 1 : c <= 2 * SCAN_RQ ? 2 : 4;
+            uint32_t tv = (4 / qg) * SCAN_WAVE_VECS, sz = (uint32_t)(off[l + 1] - off[l]);
+            for (uint32_t vb = 0; vb < sz; vb += tv)
+                for (uint32_t qb = 0; qb < c; qb += qg * SCAN_RQ) {
+                    ScanItem& it = items[ni++];
+                    it.vec_base = off[l] + vb;
+                    it.nvec = std::min(tv, sz - vb);
+                    it.vec_off = vb;
+                    it.pair_begin = lcount[l] + qb;
+                    it.npair = std::min<uint32_t>(qg * SCAN_RQ, c - qb);
+                    it.qg = qg;
+                    it.pad = 0;
+                }
+        }
+        // ---- upload + launch
+        h->w_dist.ensure(std::max<uint64_t>(cursor, 1) * sizeof(float));
+        h->w_seg_off.ensure(mb * rp * 8);
+        h->w_seg_list.ensure(mb * rp * 4);
+        h->w_seg_count.ensure(mb * 4);
+        h->w_qsel.ensure(mb * 4);
+        h->w_pair_query.ensure(std::max<size_t>(npairs, 1) * 4);
+        h->w_pair_out.ensure(std::max<size_t>(npairs, 1) * 8);
+        h->w_items.ensure(std::max<size_t>(nitems, 1) * sizeof(ScanItem));
+        hipStream_t s = h->stream;
+        HIP_CHECK(hipMemcpyAsync(h->w_seg_off.p, seg_off, mb * rp * 8, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(h->w_seg_list.p, seg_list, mb * rp * 4, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(h->w_seg_count.p, seg_count, mb * 4, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(h->w_qsel.p, qsel, mb * 4, hipMemcpyHostToDevice, s));
+        if (npairs) {
+            HIP_CHECK(hipMemcpyAsync(h->w_pair_query.p, pair_query, npairs * 4, hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipMemcpyAsync(h->w_pair_out.p, pair_out, npairs * 8, hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipMemcpyAsync(h->w_items.p, items, nitems * sizeof(ScanItem), hipMemcpyHostToDevice, s));
+        }
+        ScanArgs sa{};
+        sa.codes = h->d_codes.as<float>();
+        sa.queries = r.d_x;
+        sa.items = h->w_items.as<ScanItem>();
+        sa.pair_query = h->w_pair_query.as<uint32_t>();
+        sa.pair_out = h->w_pair_out.as<uint64_t>();
+        sa.dist = h->w_dist.as<float>();
+        sa.d = h->dpad;
+        sa.metric = h->metric;
+        if (nitems) {
+            size_t t = h->timer.begin(CAT_SCAN, s);
+            launch_scan(sa, nitems, s);
+            h->timer.end(t, s);
+        }
+        ReplayArgs ra{};
+        ra.metric = h->metric;
+        ra.k = r.k;
+        ra.nlist = (uint32_t)nlist;
+        ra.nq = (uint32_t)mb;
+        ra.qsel = h->w_qsel.as<uint32_t>();
+        ra.total_nprobe = r.total_nprobe;
+        ra.round_probes = rp;
+        ra.id_offset = r.id_offset;
+        ra.dist = h->w_dist.as<float>();
+        ra.seg_off = h->w_seg_off.as<uint64_t>();
+        ra.seg_list = h->w_seg_list.as<int32_t>();
+        ra.seg_count = h->w_seg_count.as<uint32_t>();
+        ra.list_off = h->d_list_off.as<uint64_t>();
+        ra.ids = h->d_ids.as<int64_t>();
+        ra.store_pairs = r.store_pairs;
+        ra.identity_ids = 0;
+        ra.max_codes = r.max_codes;
+        ra.finalize_all = r.finalize_all;
+        ra.heap_val = h->w_heap_val.as<float>();
+        ra.heap_ref = h->w_heap_ref.as<int64_t>();
+        ra.stage = h->w_stage.as<uint32_t>();
+        ra.nscan = h->w_nscan.as<unsigned long long>();
+        ra.done = h->w_done.as<uint32_t>();
+        ra.pre_val = h->w_pre_val.as<float>();
+        ra.stoped = h->w_stoped.as<uint32_t>();
+        ra.dtb = h->w_dtb.as<float>();
+        ra.coarse_dis = r.d_cdis;
+        ra.coarse_keys = r.d_ckeys;
+        ra.coarse_stride = r.coarse_stride;
+        ra.D = h->w_D.as<float>();
+        ra.I = h->w_I.as<int64_t>();
+        ra.stats = h->w_stats.as<unsigned long long>();
+        ra.error = h->w_error.as<uint32_t>();
+        ra.raw_heap_out = r.raw_heap_out;
+        ra.tuner = r.tuner;
+        ra.train = r.train;
+        {
+            size_t t = h->timer.begin(CAT_SELECT, s);
+            launch_replay(ra, s);
+            h->timer.end(t, s);
+        }
+        // the pinned staging buffers are reused by the next sub-batch
+        HIP_CHECK(hipStreamSynchronize(s));
+        q0 = q1;
+    }
+}
+
+void check_device_error(amd_ivf* h) {
+    uint32_t err = 0;
+    HIP_CHECK(hipMemcpyAsync(&err, h->w_error.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (err == ERR_ARCOS_DOMAIN) throw EngineError("arcos's domain definition is [-1, 1]");
+    if (err == ERR_COSINE_PRECOND) throw EngineError("cosine theorem's prerequisites");
+    if (err == ERR_INVALID_KEY) throw EngineError("Invalid key");
+    if (err) throw EngineError("device-side error " + std::to_string(err));
+}
+
+void fold_stats(amd_ivf* h, size_t nq) {
+    unsigned long long st[3];
+    HIP_CHECK(hipMemcpyAsync(st, h->w_stats.p, 24, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->stats_host[0] += nq;
+    h->stats_host[1] += st[0];
+    h->stats_host[2] += st[1];
+    h->stats_host[3] += st[2];
+}
+
+void finish_timing(amd_ivf* h, double wall_ms) {
+    double ms[NCAT], ln[NCAT];
+    h->timer.collect(ms, NCAT, ln);
+    h->timing[0] = ms[CAT_COARSE];
+    h->timing[1] = ms[CAT_SCAN];
+    h->timing[2] = ms[CAT_SELECT];
+    h->timing[3] = wall_ms;
+    h->timing[4] = ln[CAT_SCAN];
+    h->timing[5] = h->scan_bytes;
+}
+
+struct WallClock {
+    hipEvent_t a = nullptr, b = nullptr;
+    hipStream_t s;
+    explicit WallClock(hipStream_t st) : s(st) {
+        HIP_CHECK(hipEventCreate(&a));
+        HIP_CHECK(hipEventCreate(&b));
+        HIP_CHECK(hipEventRecord(a, s));
+    }
+    double stop() {
+        HIP_CHECK(hipEventRecord(b, s));
+        HIP_CHECK(hipEventSynchronize(b));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+        return ms;
+    }
+    ~WallClock() {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+};
+
+// ------------------------------------------------------------------------------------ coarse
+// distances of n device queries (row stride dpad) to every centroid -> sorted top-nprobe on device
+void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode, float* d_out_dis, int64_t* d_out_keys) {
+    if (!h->have_centroids) throw EngineError("quantizer has no centroids");
+    (void)mode;  // TODO(round 2): mode 1 = MFMA |x|^2+|y|^2-2xy path; the exact kernel serves both for now
+    const size_t nlist = h->nlist;
+    hipStream_t s = h->stream;
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>(n, h->dist_budget_floats / std::max<size_t>(nlist, 1)));
+    const bool use_heap = nprobe <= 128;
+    for (size_t c0 = 0; c0 < n; c0 += chunk) {
+        const size_t m = std::min(chunk, n - c0);
+        // pairs: every query of the chunk against the single "list" = centroid table
+        const uint32_t qg = m <= SCAN_RQ ? 1 : m <= 2 * SCAN_RQ ? 2 : 4;
+        const uint32_t tv = (4 / qg) * SCAN_WAVE_VECS;
+        const size_t nitems = ((m + qg * SCAN_RQ - 1) / (qg * SCAN_RQ)) * ((nlist + tv - 1) / tv);
+        h->p_pair_query.ensure(m * 4);
+        h->p_pair_out.ensure(m * 8);
+        h->p_items.ensure(nitems * sizeof(ScanItem));
+        uint32_t* pq = h->p_pair_query.as<uint32_t>();
+        uint64_t* po = h->p_pair_out.as<uint64_t>();
+        ScanItem* items = h->p_items.as<ScanItem>();
+        for (size_t i = 0; i < m; i++) {
+            pq[i] = (uint32_t)(c0 + i);
+            po[i] = (uint64_t)i * nlist;
+        }
+        size_t ni = 0;
+        for (uint32_t vb = 0; vb < nlist; vb += tv)
+            for (uint32_t qb = 0; qb < m; qb += qg * SCAN_RQ) {
+                ScanItem& it = items[ni++];
+                it.vec_base = vb;
+                it.nvec = std::min<uint32_t>(tv, (uint32_t)nlist - vb);
+                it.vec_off = vb;
+                it.pair_begin = qb;
+                it.npair = std::min<uint32_t>(qg * SCAN_RQ, (uint32_t)m - qb);
+                it.qg = qg;
+                it.pad = 0;
+            }
+        h->w_dist.ensure(m * nlist * sizeof(float));
+        h->w_pair_query.ensure(m * 4);
+        h->w_pair_out.ensure(m * 8);
+        h->w_items.ensure(nitems * sizeof(ScanItem));
+        HIP_CHECK(hipMemcpyAsync(h->w_pair_query.p, pq, m * 4, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(h->w_pair_out.p, po, m * 8, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(h->w_items.p, items, nitems * sizeof(ScanItem), hipMemcpyHostToDevice, s));
+        ScanArgs sa{};
+        sa.codes = h->d_centroids.as<float>();
+        sa.queries = d_x;
+        sa.items = h->w_items.as<ScanItem>();
+        sa.pair_query = h->w_pair_query.as<uint32_t>();
+        sa.pair_out = h->w_pair_out.as<uint64_t>();
+        sa.dist = h->w_dist.as<float>();
+        sa.d = h->dpad;
+        sa.metric = h->metric;
+        size_t t = h->timer.begin(CAT_COARSE, s);
+        launch_scan(sa, nitems, s);
+        if (use_heap) {
+            // the reference's own selection: a heap of nprobe over centroids 0..nlist-1 (utils.cpp:454-490)
+            const size_t k = nprobe;
+            h->c_heap_val.ensure(m * k * 4);
+            h->c_heap_ref.ensure(m * k * 8);
+            h->c_stage.ensure(m * 4);
+            h->c_nscan.ensure(m * 8);
+            h->c_done.ensure(m * 4);
+            h->c_seg_off.ensure(m * 8);
+            h->c_seg_list.ensure(m * 4);
+            h->c_seg_count.ensure(m * 4);
+            h->w_misc.ensure(32);
+            h->p_seg_off.ensure(m * 8);
+            h->p_seg_list.ensure(m * 4);
+            h->p_seg_count.ensure(m * 4);
+            for (size_t i = 0; i < m; i++) {
+                h->p_seg_off.as<uint64_t>()[i] = (uint64_t)i * nlist;
+                h->p_seg_list.as<int32_t>()[i] = 0;
+                h->p_seg_count.as<uint32_t>()[i] = 1;
+            }
+            HIP_CHECK(hipMemcpyAsync(h->c_seg_off.p, h->p_seg_off.p, m * 8, hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipMemcpyAsync(h->c_seg_list.p, h->p_seg_list.p, m * 4, hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipMemcpyAsync(h->c_seg_count.p, h->p_seg_count.p, m * 4, hipMemcpyHostToDevice, s));
+            launch_fill_f32(h->c_heap_val.as<float>(), m * k, h->metric == METRIC_L2 ? FLT_MAX : -FLT_MAX, s);
+            launch_fill_i64(h->c_heap_ref.as<int64_t>(), m * k, -1, s);
+            HIP_CHECK(hipMemsetAsync(h->c_stage.p, 0, m * 4, s));
+            HIP_CHECK(hipMemsetAsync(h->c_nscan.p, 0, m * 8, s));
+            HIP_CHECK(hipMemsetAsync(h->c_done.p, 0, m * 4, s));
+            HIP_CHECK(hipMemsetAsync(h->w_misc.p, 0, 32, s));
+            ReplayArgs ra{};
+            ra.metric = h->metric;
+            ra.k = (int)k;
+            ra.nlist = (uint32_t)nlist;
+            ra.nq = (uint32_t)m;
+            ra.round_probes = 1;
+            ra.dist = h->w_dist.as<float>();
+            ra.seg_off = h->c_seg_off.as<uint64_t>();
+            ra.seg_list = h->c_seg_list.as<int32_t>();
+            ra.seg_count = h->c_seg_count.as<uint32_t>();
+            ra.identity_ids = 1;
+            ra.finalize_all = 1;
+            ra.heap_val = h->c_heap_val.as<float>();
+            ra.heap_ref = h->c_heap_ref.as<int64_t>();
+            ra.stage = h->c_stage.as<uint32_t>();
+            ra.nscan = h->c_nscan.as<unsigned long long>();
+            ra.done = h->c_done.as<uint32_t>();
+            ra.D = d_out_dis + c0 * nprobe;
+            ra.I = d_out_keys + c0 * nprobe;
+            ra.stats = h->w_misc.as<unsigned long long>();
+            ra.error = reinterpret_cast<uint32_t*>(h->w_misc.as<unsigned long long>() + 3);
+            launch_replay(ra, s);
+        } else {
+            launch_sort_rows(h->w_dist.as<float>(), (uint32_t)m, (uint32_t)nlist, (uint32_t)nprobe, h->metric,
+                             d_out_dis + c0 * nprobe, d_out_keys + c0 * nprobe, s);
+        }
+        h->timer.end(t, s);
+        HIP_CHECK(hipStreamSynchronize(s));
+    }
+}
+
+// ------------------------------------------------------------------------------------ searches
+void search_fixed_core(amd_ivf* h, const float* d_x, size_t n, size_t k, size_t nprobe, const int64_t* keys, float* D,
+                       int64_t* I, int store_pairs, size_t max_codes) {
+    upload_lists(h);
+    init_state(h, n, k, false);
+    RoundSpec r;
+    r.slot.resize(n);
+    r.p0.assign(n, 0);
+    r.cnt.assign(n, (uint32_t)nprobe);
+    for (size_t i = 0; i < n; i++) r.slot[i] = (uint32_t)i;
+    if (max_codes) {
+        // the probe loop stops after the list that brings the visited codes to max_codes (IndexIVF.cpp:541)
+        for (size_t i = 0; i < n; i++) {
+            size_t nscan = 0;
+            for (size_t p = 0; p < nprobe; p++) {
+                int64_t key = keys[i * nprobe + p];
+                if (key >= 0 && (size_t)key < h->nlist) nscan += h->h_list_off[key + 1] - h->h_list_off[key];
+                if (nscan >= max_codes) {
+                    r.cnt[i] = (uint32_t)(p + 1);
+                    break;
+                }
+            }
+        }
+    }
+    r.keys = keys;
+    r.key_stride = nprobe;
+    r.k = (int)k;
+    r.store_pairs = store_pairs;
+    r.max_codes = max_codes;
+    r.finalize_all = 1;
+    r.d_x = d_x;
+    exec_round(h, r);
+    check_device_error(h);
+    HIP_CHECK(hipMemcpyAsync(D, h->w_D.p, n * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipMemcpyAsync(I, h->w_I.p, n * k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    fold_stats(h, n);
+}
+
+void search_full(amd_ivf* h, const float* d_x, size_t n, size_t k, size_t nprobe, int coarse_mode, float* D, int64_t* I) {
+    h->w_cdis.ensure(n * nprobe * 4);
+    h->w_ckeys.ensure(n * nprobe * 8);
+    coarse_dev(h, d_x, n, nprobe, coarse_mode, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>());
+    std::vector<int64_t> keys(n * nprobe);
+    HIP_CHECK(hipMemcpyAsync(keys.data(), h->w_ckeys.p, n * nprobe * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    search_fixed_core(h, d_x, n, k, nprobe, keys.data(), D, I, 0, 0);
+}
+
+TunerDev make_tuner(amd_ivf* h, size_t query_topk, float multipler, float std_m, const float* d_req, const float* d_gt,
+                    unsigned long long* d_np, float* d_tr, int profile) {
+    TunerDev t{};
+    t.enabled = 1;
+    t.profile = profile;
+    t.max_topk = (uint32_t)h->tuner_max_topk;
+    t.query_topk = (uint32_t)query_topk;
+    t.ntraces = (uint32_t)h->tuner_ntraces;
+    t.multipler = multipler;
+    t.std_m = std_m;
+    t.interdis = h->d_interdis.as<float>();
+    t.arcos = h->d_arcos.as<float>();
+    t.trace_off = h->d_trace_off.as<uint32_t>();
+    t.trace_x = h->d_trace_x.as<float>();
+    t.trace_y = h->d_trace_y.as<float>();
+    t.trace_std = h->d_trace_std.as<float>();
+    t.require_acc = d_req;
+    t.gt_D = d_gt;
+    t.my_nprobe = d_np;
+    t.t_recalls = d_tr;
+    return t;
+}
+
+// multi-round driver shared by the adaptive search and the trace training
+void run_rounds(amd_ivf* h, RoundSpec& base, size_t n, size_t first_round, size_t total_nprobe,
+                const unsigned long long* d_np_abs /* may be null */, size_t start) {
+    // keys for probes [0, have) of every slot are kept on the host and extended on demand
+    size_t have = 0;
+    std::vector<int64_t> hkeys;
+    size_t stride = 0;
+    std::vector<uint32_t> stage(n, 0), done(n, 0);
+    std::vector<unsigned long long> np(n, 0);
+    size_t round_len = first_round;
+    for (;;) {
+        // plan: every unfinished query runs either up to its known my_nprobe or one more block of round_len
+        std::vector<uint32_t> slot, p0, cnt;
+        size_t need_cols = 0;
+        for (size_t i = 0; i < n; i++) {
+            if (done[i]) continue;
+            size_t target = stage[i] + round_len;
+            if (np[i] != 0) target = std::max<size_t>(np[i], stage[i] + 1);
+            target = std::min(target, total_nprobe);
+            if (target <= stage[i]) target = std::min<size_t>(stage[i] + 1, total_nprobe);
+            slot.push_back((uint32_t)i);
+            p0.push_back(stage[i]);
+            cnt.push_back((uint32_t)(target - stage[i]));
+            need_cols = std::max(need_cols, target);
+        }
+        if (slot.empty()) break;
+        if (need_cols > have) {
+            size_t new_have = std::min(total_nprobe, std::max(need_cols, have * 2));
+            std::vector<int64_t> nk(n * new_have);
+            HIP_CHECK(hipMemcpy2DAsync(nk.data(), new_have * 8, base.d_ckeys, (size_t)base.coarse_stride * 8, new_have * 8, n,
+                                       hipMemcpyDeviceToHost, h->stream));
+            HIP_CHECK(hipStreamSynchronize(h->stream));
+            hkeys.swap(nk);
+            have = new_have;
+            stride = new_have;
+        }
+        RoundSpec r = base;
+        r.slot = slot;
+        r.p0 = p0;
+        r.cnt = cnt;
+        r.keys = hkeys.data();
+        r.key_stride = stride;
+        r.total_nprobe = (uint32_t)total_nprobe;
+        exec_round(h, r);
+        check_device_error(h);
+        HIP_CHECK(hipMemcpyAsync(stage.data(), h->w_stage.p, n * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipMemcpyAsync(done.data(), h->w_done.p, n * 4, hipMemcpyDeviceToHost, h->stream));
+        if (d_np_abs)
+            HIP_CHECK(hipMemcpyAsync(np.data(), d_np_abs + start, n * 8, hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        round_len = std::min<size_t>(round_len * 2, 64);
+    }
+}
+
+}  // namespace
+
+// ============================================================================================
+// extern "C" boundary
+// ============================================================================================
+#define API_BEGIN try {
+#define API_END                                  \
+    return 0;                                    \
+    }                                            \
+    catch (const EngineError& e) {               \
+        g_last_error = e.what();                 \
+        return -2;                               \
+    }                                            \
+    catch (const std::exception& e) {            \
+        g_last_error = e.what();                 \
+        return -4;                               \
+    }                                            \
+    catch (...) {                                \
+        g_last_error = "unknown error";          \
+        return -1;                               \
+    }
+
+extern "C" {
+
+const char* amd_ivf_last_error(void) { return g_last_error.c_str(); }
+
+int amd_ivf_device_count(int* count) {
+    API_BEGIN
+    HIP_CHECK(hipGetDeviceCount(count));
+    API_END
+}
+
+int amd_ivf_create(int d, size_t nlist, int metric, int device, amd_ivf_t** out) {
+    API_BEGIN
+    if (d <= 0 || nlist == 0) throw EngineError("bad dimension / nlist");
+    if (metric != METRIC_L2 && metric != METRIC_IP) throw EngineError("unsupported metric");
+    int ndev = 0;
+    HIP_CHECK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) throw std::runtime_error("no such HIP device (this engine has no CPU path)");
+    std::unique_ptr<amd_ivf> h(new amd_ivf);
+    h->d = d;
+    h->dpad = (d + 3) & ~3;
+    h->nlist = nlist;
+    h->metric = metric;
+    h->device = device;
+    HIP_CHECK(hipSetDevice(device));
+    HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->h_codes.resize(nlist);
+    h->h_ids.resize(nlist);
+    h->h_list_off.assign(nlist + 1, 0);
+    *out = h.release();
+    API_END
+}
+
+int amd_ivf_destroy(amd_ivf_t* h) {
+    API_BEGIN
+    if (h) {
+        use_device(h);
+        delete h;
+    }
+    API_END
+}
+
+int amd_ivf_set_centroids(amd_ivf_t* h, const float* centroids) {
+    API_BEGIN
+    use_device(h);
+    h->h_centroids.assign(h->nlist * h->dpad, 0.f);
+    for (size_t i = 0; i < h->nlist; i++) memcpy(&h->h_centroids[i * h->dpad], centroids + i * h->d, h->d * sizeof(float));
+    h->d_centroids.ensure(h->nlist * h->dpad * sizeof(float));
+    HIP_CHECK(hipMemcpyAsync(h->d_centroids.p, h->h_centroids.data(), h->nlist * h->dpad * sizeof(float),
+                             hipMemcpyHostToDevice, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->have_centroids = true;
+    h->have_interdis = false;
+    API_END
+}
+
+int amd_ivf_set_lists(amd_ivf_t* h, const size_t* sizes, const float* const* codes, const int64_t* const* ids) {
+    API_BEGIN
+    size_t nt = 0;
+    for (size_t l = 0; l < h->nlist; l++) {
+        size_t n = sizes[l];
+        h->h_codes[l].assign(n * h->dpad, 0.f);
+        for (size_t j = 0; j < n; j++) memcpy(&h->h_codes[l][j * h->dpad], codes[l] + j * h->d, h->d * sizeof(float));
+        h->h_ids[l].assign(ids[l], ids[l] + n);
+        nt += n;
+    }
+    h->ntotal = nt;
+    h->lists_dirty = true;
+    upload_lists(h);
+    API_END
+}
+
+int amd_ivf_add(amd_ivf_t* h, size_t n, const float* x, const int64_t* xids, const int64_t* precomputed_idx) {
+    API_BEGIN
+    use_device(h);
+    std::vector<int64_t> assign;
+    const int64_t* idx = precomputed_idx;
+    if (!idx) {
+        // quantizer->assign(n, x, idx): nearest centroid with the exact kernel, in blocks
+        assign.resize(n);
+        const size_t bs = 1 << 18;
+        h->w_x.ensure(std::min(bs, n) * h->dpad * sizeof(float));
+        h->w_cdis.ensure(std::min(bs, n) * 4);
+        h->w_ckeys.ensure(std::min(bs, n) * 8);
+        for (size_t i0 = 0; i0 < n; i0 += bs) {
+            size_t m = std::min(bs, n - i0);
+            upload_rows(h, h->w_x.as<float>(), x + i0 * h->d, m);
+            coarse_dev(h, h->w_x.as<float>(), m, 1, 0, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>());
+            HIP_CHECK(hipMemcpyAsync(assign.data() + i0, h->w_ckeys.p, m * 8, hipMemcpyDeviceToHost, h->stream));
+            HIP_CHECK(hipStreamSynchronize(h->stream));
+        }
+        idx = assign.data();
+        double ms[NCAT], ln[NCAT];
+        h->timer.collect(ms, NCAT, ln);
+    }
+    for (size_t i = 0; i < n; i++) {
+        int64_t id = xids ? xids[i] : (int64_t)(h->ntotal + i);
+        int64_t l = idx[i];
+        if (l < 0) continue;
+        if ((size_t)l >= h->nlist) throw EngineError("Invalid list number in add");
+        std::vector<float>& c = h->h_codes[l];
+        size_t o = c.size();
+        c.resize(o + h->dpad, 0.f);
+        memcpy(&c[o], x + i * h->d, h->d * sizeof(float));
+        h->h_ids[l].push_back(id);
+    }
+    h->ntotal += n;
+    h->lists_dirty = true;
+    API_END
+}
+
+int amd_ivf_ntotal(const amd_ivf_t* h, size_t* ntotal) {
+    *ntotal = h->ntotal;
+    return 0;
+}
+
+int amd_ivf_list_size(const amd_ivf_t* h, size_t list_no, size_t* size) {
+    API_BEGIN
+    if (list_no >= h->nlist) throw EngineError("Invalid list number");
+    *size = h->h_ids[list_no].size();
+    API_END
+}
+
+int amd_ivf_get_list(const amd_ivf_t* hc, size_t list_no, float* codes, int64_t* ids) {
+    API_BEGIN
+    amd_ivf* h = const_cast<amd_ivf*>(hc);
+    if (list_no >= h->nlist) throw EngineError("Invalid list number");
+    upload_lists(h);
+    size_t n = h->h_list_off[list_no + 1] - h->h_list_off[list_no];
+    if (n) {
+        // read back from HBM (the device copy is the one the kernels scan)
+        HIP_CHECK(hipMemcpy2DAsync(codes, h->d * sizeof(float), h->d_codes.as<float>() + h->h_list_off[list_no] * h->dpad,
+                                   h->dpad * sizeof(float), h->d * sizeof(float), n, hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipMemcpyAsync(ids, h->d_ids.as<int64_t>() + h->h_list_off[list_no], n * 8, hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+    }
+    API_END
+}
+
+int amd_ivf_coarse(amd_ivf_t* h, size_t n, const float* x, size_t nprobe, float* coarse_dis, int64_t* keys, int mode) {
+    API_BEGIN
+    use_device(h);
+    if (n == 0) return 0;
+    WallClock wc(h->stream);
+    h->scan_bytes = 0;
+    h->w_x.ensure(n * h->dpad * sizeof(float));
+    upload_rows(h, h->w_x.as<float>(), x, n);
+    h->w_cdis.ensure(n * nprobe * 4);
+    h->w_ckeys.ensure(n * nprobe * 8);
+    coarse_dev(h, h->w_x.as<float>(), n, nprobe, mode, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>());
+    HIP_CHECK(hipMemcpyAsync(coarse_dis, h->w_cdis.p, n * nprobe * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipMemcpyAsync(keys, h->w_ckeys.p, n * nprobe * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    finish_timing(h, wc.stop());
+    API_END
+}
+
+int amd_ivf_search_preassigned(amd_ivf_t* h, size_t n, const float* x, size_t k, size_t nprobe, const int64_t* keys,
+                               const float* coarse_dis, float* D, int64_t* I, int store_pairs, size_t max_codes) {
+    API_BEGIN
+    (void)coarse_dis;  // IVF-Flat codes are not residuals: the scanner ignores it (IndexIVFFlat.cpp:106)
+    use_device(h);
+    if (n == 0 || k == 0) return 0;
+    WallClock wc(h->stream);
+    h->scan_bytes = 0;
+    h->w_x.ensure(n * h->dpad * sizeof(float));
+    upload_rows(h, h->w_x.as<float>(), x, n);
+    search_fixed_core(h, h->w_x.as<float>(), n, k, nprobe, keys, D, I, store_pairs, max_codes);
+    finish_timing(h, wc.stop());
+    API_END
+}
+
+int amd_ivf_search(amd_ivf_t* h, size_t n, const float* x, size_t k, size_t nprobe, int coarse_mode, float* D, int64_t* I) {
+    API_BEGIN
+    use_device(h);
+    if (n == 0 || k == 0) return 0;
+    WallClock wc(h->stream);
+    h->scan_bytes = 0;
+    h->w_x.ensure(n * h->dpad * sizeof(float));
+    upload_rows(h, h->w_x.as<float>(), x, n);
+    search_full(h, h->w_x.as<float>(), n, k, nprobe, coarse_mode, D, I);
+    finish_timing(h, wc.stop());
+    API_END
+}
+
+int amd_ivf_set_queries(amd_ivf_t* h, size_t n, const float* x) {
+    API_BEGIN
+    use_device(h);
+    h->d_resident.ensure(std::max<size_t>(n, 1) * h->dpad * sizeof(float));
+    upload_rows(h, h->d_resident.as<float>(), x, n);
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->n_resident = n;
+    API_END
+}
+
+int amd_ivf_search_resident(amd_ivf_t* h, size_t start, size_t n, size_t k, size_t nprobe, int coarse_mode, float* D, int64_t* I) {
+    API_BEGIN
+    use_device(h);
+    if (start + n > h->n_resident) throw EngineError("resident query range out of bounds");
+    if (n == 0 || k == 0) return 0;
+    WallClock wc(h->stream);
+    h->scan_bytes = 0;
+    search_full(h, h->d_resident.as<float>() + start * h->dpad, n, k, nprobe, coarse_mode, D, I);
+    finish_timing(h, wc.stop());
+    API_END
+}
+
+int amd_ivf_scan_codes(amd_ivf_t* h, const float* query, size_t list_no, int store_pairs, size_t k, float* simi,
+                       int64_t* idxi, size_t* nup) {
+    API_BEGIN
+    use_device(h);
+    if (list_no >= h->nlist) throw EngineError("Invalid key");
+    upload_lists(h);
+    h->w_x.ensure(h->dpad * sizeof(float));
+    upload_rows(h, h->w_x.as<float>(), query, 1);
+    init_state(h, 1, k, false);
+    // import the caller's heap as the starting state
+    HIP_CHECK(hipMemcpyAsync(h->w_heap_val.p, simi, k * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_CHECK(hipMemcpyAsync(h->w_heap_ref.p, idxi, k * 8, hipMemcpyHostToDevice, h->stream));
+    int64_t key = (int64_t)list_no;
+    RoundSpec r;
+    r.slot = {0};
+    r.p0 = {0};
+    r.cnt = {1};
+    r.keys = &key;
+    r.key_stride = 1;
+    r.k = (int)k;
+    r.store_pairs = store_pairs;
+    r.finalize_all = 1;
+    r.raw_heap_out = 1;
+    r.d_x = h->w_x.as<float>();
+    exec_round(h, r);
+    check_device_error(h);
+    HIP_CHECK(hipMemcpyAsync(simi, h->w_D.p, k * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipMemcpyAsync(idxi, h->w_I.p, k * 8, hipMemcpyDeviceToHost, h->stream));
+    unsigned long long st[3];
+    HIP_CHECK(hipMemcpyAsync(st, h->w_stats.p, 24, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (nup) *nup = st[2];
+    double ms[NCAT], ln[NCAT];
+    h->timer.collect(ms, NCAT, ln);
+    API_END
+}
+
+int amd_ivf_distance_to_code(amd_ivf_t* h, const float* query, size_t list_no, size_t offset, float* dis) {
+    API_BEGIN
+    use_device(h);
+    if (list_no >= h->nlist) throw EngineError("Invalid key");
+    upload_lists(h);
+    if (offset >= h->h_list_off[list_no + 1] - h->h_list_off[list_no]) throw EngineError("offset beyond list size");
+    h->w_x.ensure(h->dpad * sizeof(float));
+    upload_rows(h, h->w_x.as<float>(), query, 1);
+    h->w_dist.ensure(4);
+    h->w_items.ensure(sizeof(ScanItem));
+    h->w_pair_query.ensure(4);
+    h->w_pair_out.ensure(8);
+    ScanItem it{h->h_list_off[list_no] + offset, 1, 0, 0, 1, 1, 0};
+    uint32_t pq = 0;
+    uint64_t po = 0;
+    HIP_CHECK(hipMemcpyAsync(h->w_items.p, &it, sizeof(it), hipMemcpyHostToDevice, h->stream));
+    HIP_CHECK(hipMemcpyAsync(h->w_pair_query.p, &pq, 4, hipMemcpyHostToDevice, h->stream));
+    HIP_CHECK(hipMemcpyAsync(h->w_pair_out.p, &po, 8, hipMemcpyHostToDevice, h->stream));
+    ScanArgs sa{h->d_codes.as<float>(), h->w_x.as<float>(), h->w_items.as<ScanItem>(), h->w_pair_query.as<uint32_t>(),
+                h->w_pair_out.as<uint64_t>(), h->w_dist.as<float>(), h->dpad, h->metric};
+    launch_scan(sa, 1, h->stream);
+    HIP_CHECK(hipMemcpyAsync(dis, h->w_dist.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    API_END
+}
+
+int amd_ivf_stats(amd_ivf_t* h, size_t stats[4], int reset) {
+    for (int i = 0; i < 4; i++) stats[i] = h->stats_host[i];
+    if (reset)
+        for (int i = 0; i < 4; i++) h->stats_host[i] = 0;
+    return 0;
+}
+
+int amd_ivf_set_interdis(amd_ivf_t* h, const float* table) {
+    API_BEGIN
+    use_device(h);
+    const size_t nl = h->nlist, sz = nl * (nl - 1) / 2;
+    h->d_interdis.ensure(std::max<size_t>(sz, 1) * 4);
+    if (table) {
+        HIP_CHECK(hipMemcpyAsync(h->d_interdis.p, table, sz * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+    } else {
+        if (!h->have_centroids) throw EngineError("quantizer has no centroids");
+        // all-pairs centroid distances with the scan kernel, then pack the upper triangle
+        std::vector<float> cq(h->h_centroids);
+        if (h->metric == METRIC_IP) {
+            // reference quirk (IndexIVF.cpp:102-107): centroid 0 is renormalised nlist times, the others never
+            for (size_t i = 0; i < nl; i++) {
+                float s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+                for (int c = 0; c < h->dpad; c += 4) {
+                    s0 += cq[c] * cq[c];
+                    s1 += cq[c + 1] * cq[c + 1];
+                    s2 += cq[c + 2] * cq[c + 2];
+                    s3 += cq[c + 3] * cq[c + 3];
+                }
+                float norm = sqrtf((s0 + s1) + (s2 + s3));
+                for (int c = 0; c < h->d; c++) cq[c] /= norm;
+            }
+        }
+        DevBuf d_cq, d_full;
+        d_cq.ensure(nl * h->dpad * 4);
+        d_full.ensure(nl * nl * 4);
+        HIP_CHECK(hipMemcpyAsync(d_cq.p, cq.data(), nl * h->dpad * 4, hipMemcpyHostToDevice, h->stream));
+        const uint32_t qg = 4, tv = SCAN_WAVE_VECS;
+        std::vector<ScanItem> items;
+        std::vector<uint32_t> pq(nl);
+        std::vector<uint64_t> po(nl);
+        for (size_t i = 0; i < nl; i++) {
+            pq[i] = (uint32_t)i;
+            po[i] = (uint64_t)i * nl;
+        }
+        for (uint32_t vb = 0; vb < nl; vb += tv)
+            for (uint32_t qb = 0; qb < nl; qb += qg * SCAN_RQ)
+                items.push_back(ScanItem{vb, std::min<uint32_t>(tv, (uint32_t)nl - vb), vb, qb,
+                                         std::min<uint32_t>(qg * SCAN_RQ, (uint32_t)nl - qb), qg, 0});
+        h->w_items.ensure(items.size() * sizeof(ScanItem));
+        h->w_pair_query.ensure(nl * 4);
+        h->w_pair_out.ensure(nl * 8);
+        HIP_CHECK(hipMemcpyAsync(h->w_items.p, items.data(), items.size() * sizeof(ScanItem), hipMemcpyHostToDevice, h->stream));
+        HIP_CHECK(hipMemcpyAsync(h->w_pair_query.p, pq.data(), nl * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_CHECK(hipMemcpyAsync(h->w_pair_out.p, po.data(), nl * 8, hipMemcpyHostToDevice, h->stream));
+        // rows = (possibly renormalised) centroids as queries, columns = the same table as the vector tile
+        ScanArgs sa{d_cq.as<float>(), d_cq.as<float>(), h->w_items.as<ScanItem>(), h->w_pair_query.as<uint32_t>(),
+                    h->w_pair_out.as<uint64_t>(), d_full.as<float>(), h->dpad, h->metric};
+        launch_scan(sa, items.size(), h->stream);
+        launch_pack_upper(d_full.as<float>(), (uint32_t)nl, h->d_interdis.as<float>(), h->stream);
+        HIP_CHECK(hipStreamSynchronize(h->stream));
+        if (h->metric == METRIC_IP) {
+            // acos on the host libm, as the reference does (IndexIVF.cpp:109-110)
+            std::vector<float> t(sz);
+            HIP_CHECK(hipMemcpy(t.data(), h->d_interdis.p, sz * 4, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < sz; i++) t[i] = std::acos(t[i]);
+            HIP_CHECK(hipMemcpy(h->d_interdis.p, t.data(), sz * 4, hipMemcpyHostToDevice));
+        }
+    }
+    h->have_interdis = true;
+    API_END
+}
+
+int amd_ivf_get_interdis(amd_ivf_t* h, float* table) {
+    API_BEGIN
+    use_device(h);
+    if (!h->have_interdis) throw EngineError("centroid table not set");
+    HIP_CHECK(hipMemcpy(table, h->d_interdis.p, h->nlist * (h->nlist - 1) / 2 * 4, hipMemcpyDeviceToHost));
+    API_END
+}
+
+int amd_ivf_set_tuner(amd_ivf_t* h, size_t max_topk, size_t ntraces, const size_t* trace_len, const float* const* trace_x,
+                      const float* const* trace_y, const float* const* trace_std, const float* arcos_list) {
+    API_BEGIN
+    use_device(h);
+    std::vector<uint32_t> off(ntraces + 1, 0);
+    for (size_t i = 0; i < ntraces; i++) off[i + 1] = off[i] + (uint32_t)trace_len[i];
+    std::vector<float> x(off[ntraces]), y(off[ntraces]), sd(off[ntraces]);
+    for (size_t i = 0; i < ntraces; i++) {
+        if (trace_len[i] == 0) throw EngineError("empty trace");
+        memcpy(&x[off[i]], trace_x[i], trace_len[i] * 4);
+        memcpy(&y[off[i]], trace_y[i], trace_len[i] * 4);
+        memcpy(&sd[off[i]], trace_std[i], trace_len[i] * 4);
+    }
+    h->d_trace_off.ensure(off.size() * 4);
+    h->d_trace_x.ensure(x.size() * 4);
+    h->d_trace_y.ensure(x.size() * 4);
+    h->d_trace_std.ensure(x.size() * 4);
+    h->d_arcos.ensure(500 * 4);
+    HIP_CHECK(hipMemcpy(h->d_trace_off.p, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(h->d_trace_x.p, x.data(), x.size() * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(h->d_trace_y.p, y.data(), x.size() * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(h->d_trace_std.p, sd.data(), x.size() * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(h->d_arcos.p, arcos_list, 500 * 4, hipMemcpyHostToDevice));
+    h->tuner_max_topk = max_topk;
+    h->tuner_ntraces = ntraces;
+    h->have_tuner = true;
+    API_END
+}
+
+int amd_ivf_search_adaptive(amd_ivf_t* h, size_t start, size_t n, size_t query_topk, float multipler, float std_m,
+                            const float* require_acc, const float* gt_D, int profile, int coarse_mode,
+                            uint64_t* my_nprobe, float* t_recalls, float* D, int64_t* I) {
+    API_BEGIN
+    use_device(h);
+    if (!h->have_tuner || !h->have_interdis)
+        throw EngineError("Search tune start can't start without IVF_pro init and training");
+    if (start + n > h->n_resident) throw EngineError("resident query range out of bounds");
+    if (n == 0) return 0;
+    const size_t K = h->tuner_max_topk, nlist = h->nlist;
+    if (nlist <= nlist / 8 + 20) throw EngineError("tune mode needs nprobe(=nlist) > nlist/8 + 20");
+    size_t ntr = 0;
+    while (((size_t)1 << ntr) <= nlist / 8) ntr++;
+    if (h->tuner_ntraces < ntr) throw EngineError("not enough traces for this nlist");
+    if (query_topk == 0 || query_topk > K) throw EngineError("query_topk out of range");
+    WallClock wc(h->stream);
+    h->scan_bytes = 0;
+    upload_lists(h);
+    const size_t nabs = start + n;
+    // per-absolute-query arrays on the device
+    DevBuf &d_req = h->w_misc2, &d_np = h->w_misc3;
+    d_req.ensure(nabs * 4 * 2 + (gt_D ? nabs * K * 4 : 0) + 64);
+    float* dreq = d_req.as<float>();
+    float* dtr = dreq + nabs;
+    float* dgt = gt_D ? dtr + nabs : nullptr;
+    d_np.ensure(nabs * 8);
+    HIP_CHECK(hipMemcpyAsync(dreq, require_acc, nabs * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_CHECK(hipMemcpyAsync(dtr, t_recalls, nabs * 4, hipMemcpyHostToDevice, h->stream));
+    if (gt_D) HIP_CHECK(hipMemcpyAsync(dgt, gt_D, nabs * K * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_CHECK(hipMemcpyAsync(d_np.p, my_nprobe, nabs * 8, hipMemcpyHostToDevice, h->stream));
+    // full coarse ranking (Error_sys::search sets nprobe = nlist, profile.cpp:220)
+    const float* d_x = h->d_resident.as<float>() + start * h->dpad;
+    h->w_cdis.ensure(n * nlist * 4);
+    h->w_ckeys.ensure(n * nlist * 8);
+    coarse_dev(h, d_x, n, nlist, coarse_mode, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>());
+    init_state(h, n, K, true);
+    RoundSpec base;
+    base.k = (int)K;
+    base.id_offset = start;
+    base.d_x = d_x;
+    base.d_cdis = h->w_cdis.as<float>();
+    base.d_ckeys = h->w_ckeys.as<int64_t>();
+    base.coarse_stride = (uint32_t)nlist;
+    base.tuner = make_tuner(h, query_topk, multipler, std_m, dreq, dgt, d_np.as<unsigned long long>(), dtr, profile);
+    run_rounds(h, base, n, 4, nlist, d_np.as<unsigned long long>(), start);
+    HIP_CHECK(hipMemcpyAsync(D, h->w_D.p, n * K * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipMemcpyAsync(I, h->w_I.p, n * K * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipMemcpyAsync(my_nprobe + start, d_np.as<unsigned long long>() + start, n * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipMemcpyAsync(t_recalls + start, dtr + start, n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    fold_stats(h, n);
+    finish_timing(h, wc.stop());
+    API_END
+}
+
+int amd_ivf_train_samples(amd_ivf_t* h, size_t start, size_t n, size_t max_topk, const float* gt_D, size_t train_num,
+                          int coarse_mode, float* const* raw, float* D, int64_t* I) {
+    API_BEGIN
+    use_device(h);
+    if (!h->have_interdis) throw EngineError("Search tune start can't start without IVF_pro init and training");
+    if (start + n > h->n_resident) throw EngineError("resident query range out of bounds");
+    if (n == 0) return 0;
+    const size_t K = max_topk, nlist = h->nlist;
+    if (nlist <= nlist / 8 + 20) throw EngineError("train mode needs nprobe(=nlist) > nlist/8 + 20");
+    size_t ntr = 0;
+    while (((size_t)1 << ntr) <= nlist / 8) ntr++;
+    upload_lists(h);
+    const size_t per = train_num * (K / 4) * 2;  // floats per raw trace
+    DevBuf d_raw;
+    d_raw.ensure(ntr * per * 4 + 64);
+    std::vector<float*> ptrs(ntr);
+    for (size_t i = 0; i < ntr; i++) {
+        ptrs[i] = d_raw.as<float>() + i * per;
+        HIP_CHECK(hipMemcpyAsync(ptrs[i], raw[i], per * 4, hipMemcpyHostToDevice, h->stream));
+    }
+    h->w_rawptrs.ensure(ntr * sizeof(float*));
+    HIP_CHECK(hipMemcpyAsync(h->w_rawptrs.p, ptrs.data(), ntr * sizeof(float*), hipMemcpyHostToDevice, h->stream));
+    const size_t nabs = start + n;
+    h->w_misc2.ensure(nabs * K * 4 + 64);
+    HIP_CHECK(hipMemcpyAsync(h->w_misc2.p, gt_D, nabs * K * 4, hipMemcpyHostToDevice, h->stream));
+    if (!h->d_arcos.p) {
+        // construct_arcos (IVF_pro.cpp:151-160) on the host libm
+        std::vector<float> lut(500);
+        float sc = 500 / 2;
+        for (int i = 0; i < 500; i++) lut[i] = std::acos(float(i - sc) / sc);
+        h->d_arcos.ensure(500 * 4);
+        HIP_CHECK(hipMemcpy(h->d_arcos.p, lut.data(), 500 * 4, hipMemcpyHostToDevice));
+    }
+    const float* d_x = h->d_resident.as<float>() + start * h->dpad;
+    h->w_cdis.ensure(n * nlist * 4);
+    h->w_ckeys.ensure(n * nlist * 8);
+    coarse_dev(h, d_x, n, nlist, coarse_mode, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>());
+    init_state(h, n, K, true);
+    RoundSpec base;
+    base.k = (int)K;
+    base.id_offset = start;
+    base.d_x = d_x;
+    base.d_cdis = h->w_cdis.as<float>();
+    base.d_ckeys = h->w_ckeys.as<int64_t>();
+    base.coarse_stride = (uint32_t)nlist;
+    base.train.enabled = 1;
+    base.train.ntraces = (uint32_t)ntr;
+    base.train.interdis = h->d_interdis.as<float>();
+    base.train.arcos = h->d_arcos.as<float>();
+    base.train.gt_D = h->w_misc2.as<float>();
+    base.train.raw = reinterpret_cast<float* const*>(h->w_rawptrs.p);
+    run_rounds(h, base, n, 32, nlist, nullptr, start);
+    HIP_CHECK(hipMemcpyAsync(D, h->w_D.p, n * K * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipMemcpyAsync(I, h->w_I.p, n * K * 8, hipMemcpyDeviceToHost, h->stream));
+    for (size_t i = 0; i < ntr; i++)
+        HIP_CHECK(hipMemcpyAsync(raw[i], ptrs[i], per * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    double ms[NCAT], ln[NCAT];
+    h->timer.collect(ms, NCAT, ln);
+    API_END
+}
+
+int amd_ivf_merge_tables(int metric, size_t n, size_t k, size_t nshard, const float* all_D, const int64_t* all_I, float* D,
+                         int64_t* I) {
+    API_BEGIN
+    if (k == 0) return 0;
+    // IndexShards.cpp:44-105: per query, a heap over (distance, shard) of the shards' current heads.
+    // L2 pops the smallest first, IP the largest; -1 ids end a shard's row; padding carries the
+    // *heap's* neutral value (so -FLT_MAX for L2), as the reference does.
+    const bool smallest_first = metric == METRIC_L2;
+    auto before = [&](float a, float b) { return smallest_first ? a < b : a > b; };  // C::cmp
+    const size_t stride = n * k;
+    std::vector<int> pointer(nshard), sid(nshard);
+    std::vector<float> hv(nshard);
+    for (size_t i = 0; i < n; i++) {
+        const float* Din = all_D + i * k;
+        const int64_t* Iin = all_I + i * k;
+        size_t hs = 0;
+        auto push = [&](float v, int s) {
+            size_t c = ++hs;
+            while (c > 1) {
+                size_t f = c >> 1;
+                if (!before(v, hv[f - 1])) break;
+                hv[c - 1] = hv[f - 1];
+                sid[c - 1] = sid[f - 1];
+                c = f;
+            }
+            hv[c - 1] = v;
+            sid[c - 1] = s;
+        };
+        auto pop = [&]() {
+            size_t kk = hs--;
+            float v = hv[kk - 1];
+            size_t c = 1;
+            for (;;) {
+                size_t c1 = c << 1, c2 = c1 + 1;
+                if (c1 > kk) break;
+                if (c2 == kk + 1 || before(hv[c1 - 1], hv[c2 - 1])) {
+                    if (before(v, hv[c1 - 1])) break;
+                    hv[c - 1] = hv[c1 - 1];
+                    sid[c - 1] = sid[c1 - 1];
+                    c = c1;
+                } else {
+                    if (before(v, hv[c2 - 1])) break;
+                    hv[c - 1] = hv[c2 - 1];
+                    sid[c - 1] = sid[c2 - 1];
+                    c = c2;
+                }
+            }
+            hv[c - 1] = hv[kk - 1];
+            sid[c - 1] = sid[kk - 1];
+        };
+        for (size_t s = 0; s < nshard; s++) {
+            pointer[s] = 0;
+            if (Iin[stride * s] >= 0) push(Din[stride * s], (int)s);
+        }
+        for (size_t j = 0; j < k; j++) {
+            if (hs == 0) {
+                I[i * k + j] = -1;
+                D[i * k + j] = smallest_first ? -FLT_MAX : FLT_MAX;
+            } else {
+                int s = sid[0];
+                int& p = pointer[s];
+                D[i * k + j] = hv[0];
+                I[i * k + j] = Iin[stride * s + p];
+                pop();
+                p++;
+                if ((size_t)p < k && Iin[stride * s + p] >= 0) push(Din[stride * s + p], s);
+            }
+        }
+    }
+    API_END
+}
+
+int amd_ivf_last_timing(amd_ivf_t* h, double out[6]) {
+    for (int i = 0; i < 6; i++) out[i] = h->timing[i];
+    return 0;
+}
+
+}  // extern "C"

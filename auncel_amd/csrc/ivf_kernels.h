@@ -1,0 +1,130 @@
+// Device-side data structures and kernel launch wrappers of the gfx950 IVF-Flat engine.
+// (internal: the public boundary is include/auncel_amd.h)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace amdivf {
+
+constexpr int METRIC_IP = 0;
+constexpr int METRIC_L2 = 1;
+
+// ---------------------------------------------------------------------------- distance tiles
+// One workgroup (256 threads = 4 waves) computes the distances between up to QG*RQ queries and
+// up to (4/QG)*64*RV consecutive vectors of one inverted list (or of the centroid table).
+constexpr int SCAN_RQ = 8;    // queries per wave (query operands live in SGPRs)
+constexpr int SCAN_RV = 2;    // vectors per lane
+constexpr int SCAN_DC = 32;   // dimensions staged through LDS per step
+constexpr int SCAN_WAVE_VECS = 64 * SCAN_RV;
+
+struct ScanItem {
+    uint64_t vec_base;   // global index (into codes) of the tile's first vector
+    uint32_t nvec;       // vectors in the tile
+    uint32_t vec_off;    // position of the tile's first vector inside its list
+    uint32_t pair_begin; // first entry of this tile in the pair arrays
+    uint32_t npair;      // queries in the tile (<= qg * SCAN_RQ)
+    uint32_t qg;         // query groups per workgroup: 1, 2 or 4
+    uint32_t pad;
+};
+
+struct ScanArgs {
+    const float* codes;       // vectors, row-major, row stride d floats (d % 4 == 0)
+    const float* queries;     // query matrix, row stride d floats
+    const ScanItem* items;
+    const uint32_t* pair_query;  // query row of each pair
+    const uint64_t* pair_out;    // offset of each pair's distance row in `dist`
+    float* dist;
+    int d;
+    int metric;
+};
+
+void launch_scan(const ScanArgs& a, size_t nitems, hipStream_t s);
+
+// ---------------------------------------------------------------------------- ordered selection
+// One wave per query replays the reference's sequential heap (Heap.h) over the distance rows in
+// probe order, evaluates the Auncel stop rule after every probe, and collects training samples.
+struct TunerDev {
+    int enabled;
+    int profile;
+    uint32_t max_topk, query_topk, ntraces;
+    float multipler, std_m;
+    const float* interdis;     // packed upper-triangular centroid table
+    const float* arcos;        // 500-entry LUT
+    const uint32_t* trace_off; // ntraces + 1
+    const float *trace_x, *trace_y, *trace_std;
+    const float* require_acc;  // by absolute query id
+    const float* gt_D;         // by absolute query id, k wide (may be null)
+    unsigned long long* my_nprobe;  // by absolute query id
+    float* t_recalls;               // by absolute query id
+};
+
+struct TrainDev {
+    int enabled;
+    uint32_t ntraces;
+    const float* interdis;
+    const float* arcos;
+    const float* gt_D;    // by absolute query id, k wide
+    float* const* raw;    // ntraces device pointers
+};
+
+struct ReplayArgs {
+    int metric;
+    int k;
+    uint32_t nlist;
+    uint32_t nq;               // queries in this launch
+    const uint32_t* qsel;      // [nq] query slot of each launch position (null: identity)
+    uint32_t total_nprobe;     // length of the reference's probe loop (0: not bounded here)
+    uint32_t round_probes;     // row stride of seg_* arrays
+    uint64_t id_offset;        // absolute query id of query 0 of this launch
+    const float* dist;
+    const uint64_t* seg_off;   // [nq][round_probes] offset of the distance row       (by launch position)
+    const int32_t* seg_list;   // [nq][round_probes] list number, <0 = missing centroid (by launch position)
+    const uint32_t* seg_count; // [nq] probes supplied this round                      (by launch position)
+    const uint64_t* list_off;  // nlist + 1 (vectors)
+    const int64_t* ids;        // per stored vector
+    int store_pairs;
+    int identity_ids;          // ids are the positions themselves (coarse quantiser rows)
+    unsigned long long max_codes;
+    int finalize_all;          // fixed-nprobe mode: every query ends after this round
+    // per-query state carried across rounds
+    float* heap_val;           // [nq][k]
+    int64_t* heap_ref;         // [nq][k]  (list << 32 | position), -1 = empty
+    uint32_t* stage;           // probes consumed so far
+    unsigned long long* nscan; // codes visited so far
+    uint32_t* done;            // 1 once the query has its final result
+    float* pre_val;            // stop-rule state
+    uint32_t* stoped;
+    float* dtb;                // [nq][nlist/8+20] distance-to-boundary vector
+    const float* coarse_dis;   // [nq][coarse_stride] full coarse ranking (tune / train)
+    const int64_t* coarse_keys;
+    uint32_t coarse_stride;
+    // outputs
+    float* D;                  // [nq][k]
+    int64_t* I;
+    unsigned long long* stats; // {nlist, ndis, nheap}
+    uint32_t* error;           // != 0: the reference would have thrown (code)
+    int raw_heap_out;          // scanner API: leave the heap un-reordered in D/I
+    TunerDev tuner;
+    TrainDev train;
+};
+
+void launch_replay(const ReplayArgs& a, hipStream_t s);
+
+constexpr uint32_t ERR_ARCOS_DOMAIN = 1;
+constexpr uint32_t ERR_COSINE_PRECOND = 2;
+constexpr uint32_t ERR_INVALID_KEY = 3;
+
+// ---------------------------------------------------------------------------- coarse helpers
+// full ascending/descending sort of each row of `dis` (nlist entries) keeping the first nprobe
+void launch_sort_rows(const float* dis, uint32_t nq, uint32_t nlist, uint32_t nprobe, int metric, float* out_dis,
+                      int64_t* out_keys, hipStream_t s);
+
+// packed upper triangle (IVF_pro.cpp:21-39 layout) of a full nlist x nlist distance matrix
+void launch_pack_upper(const float* full, uint32_t nlist, float* out, hipStream_t s);
+
+// fill helpers
+void launch_fill_f32(float* p, size_t n, float v, hipStream_t s);
+void launch_fill_i64(int64_t* p, size_t n, int64_t v, hipStream_t s);
+
+}  // namespace amdivf

@@ -1,0 +1,138 @@
+/* auncel_amd.h -- C ABI of the MI355X (gfx950) IVF-Flat search engine.
+ *
+ * This is the drop-in boundary for Auncel's IVF-Flat search hot path: plain pointers and
+ * sizes, no C++/torch types.  Every entry point names the reference interface it replaces
+ * (paths relative to the reference repo's Auncel/ directory).  The host-side C++ mirror of
+ * the reference classes (auncel_amd/csrc/host/, namespace faiss) calls only these functions;
+ * INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions (same as the reference's c_api, c_api/error_c.h:20-33, macros_impl.h:22-58):
+ *   - every function returns 0 on success, -1 unknown error, -2 engine exception (what the
+ *     reference raises as FaissException: invalid key, arcos domain, cosine-theorem
+ *     precondition, tune without tuner...), -4 std::exception / HIP runtime failure;
+ *     amd_ivf_last_error() returns the message of the last failure on the calling thread.
+ *   - matrices are compact row-major; ids are int64 ("long" idx_t, Index.h:67); outputs are
+ *     fully overwritten, sorted best first, padded with id -1 and +/-FLT_MAX (Heap.h:317-320).
+ *   - x / D / I / keys / coarse_dis arguments are HOST pointers unless the function name ends
+ *     in _dev, in which case they are device pointers on the handle's GPU.
+ *   - there is NO CPU fallback: without a usable HIP device every call fails with -4.
+ */
+#ifndef AUNCEL_AMD_H
+#define AUNCEL_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMD_IVF_METRIC_INNER_PRODUCT 0 /* MetricType, Index.h:49-52 */
+#define AMD_IVF_METRIC_L2 1
+
+typedef struct amd_ivf amd_ivf_t;
+
+const char* amd_ivf_last_error(void);
+int amd_ivf_device_count(int* count);
+
+/* ---- index lifetime and contents ------------------------------------------------------ */
+
+/* IndexIVFFlat(quantizer, d, nlist, metric)  [IndexIVFFlat.cpp:28-33, IndexIVF.cpp:146-170] */
+int amd_ivf_create(int d, size_t nlist, int metric, int device, amd_ivf_t** out);
+int amd_ivf_destroy(amd_ivf_t* h);
+
+/* quantizer->add(nlist, centroids): IndexFlat::xb, row-major nlist x d  [IndexFlat.cpp:30-33] */
+int amd_ivf_set_centroids(amd_ivf_t* h, const float* centroids);
+
+/* ArrayInvertedLists contents: per list l, sizes[l] vectors codes[l] (sizes[l] x d fp32) and
+ * ids[l]; copied to HBM CSR-packed  [InvertedLists.h:182-202, InvertedLists.cpp:138-196] */
+int amd_ivf_set_lists(amd_ivf_t* h, const size_t* sizes, const float* const* codes, const int64_t* const* ids);
+
+/* IndexIVFFlat::add_core: assign each vector to its nearest centroid (exact kernel) and append
+ * it to that list in input order; xids == NULL -> ids ntotal..ntotal+n-1; precomputed_idx may
+ * be NULL, entries < 0 are skipped  [IndexIVFFlat.cpp:41-80] */
+int amd_ivf_add(amd_ivf_t* h, size_t n, const float* x, const int64_t* xids, const int64_t* precomputed_idx);
+
+int amd_ivf_ntotal(const amd_ivf_t* h, size_t* ntotal);
+int amd_ivf_list_size(const amd_ivf_t* h, size_t list_no, size_t* size);
+/* InvertedLists::get_codes / get_ids: copy one list back to the host */
+int amd_ivf_get_list(const amd_ivf_t* h, size_t list_no, float* codes, int64_t* ids);
+
+/* ---- search ---------------------------------------------------------------------------- */
+
+/* quantizer->search(n, x, nprobe, coarse_dis, keys)  [IndexFlat.cpp:42-56].
+ * mode 0: exact per-pair kernel, same fp32 summation order as the reference's default (SSE)
+ *         build of fvec_L2sqr / fvec_inner_product, i.e. knn_L2sqr_sse [utils.cpp:454-490];
+ * mode 1: |x|^2+|y|^2-2x.y on the fp32 MFMA path, i.e. knn_L2sqr_blas [utils.cpp:538-608]
+ *         (the reference takes it for n >= 20; its rounding belongs to the vendor BLAS);
+ * mode -1: pick as the reference does (n < 20 && d % 4 == 0 -> 0, else 1)  [utils.cpp:644-655] */
+int amd_ivf_coarse(amd_ivf_t* h, size_t n, const float* x, size_t nprobe, float* coarse_dis, int64_t* keys, int mode);
+
+/* IndexIVF::search_preassigned (plain branch)  [IndexIVF.cpp:382-736; vanilla faiss/IndexIVF.cpp:250-428] */
+int amd_ivf_search_preassigned(amd_ivf_t* h, size_t n, const float* x, size_t k, size_t nprobe, const int64_t* keys,
+                               const float* coarse_dis, float* D, int64_t* I, int store_pairs, size_t max_codes);
+
+/* IndexIVF::search(n, x, k, D, I): coarse + scan without leaving the device  [IndexIVF.cpp:335-353] */
+int amd_ivf_search(amd_ivf_t* h, size_t n, const float* x, size_t k, size_t nprobe, int coarse_mode, float* D,
+                   int64_t* I);
+
+/* InvertedListScanner: set_query + set_list + scan_codes on a caller-owned raw binary heap
+ * (simi/idxi, k entries, heapified by the caller as in tests/test_lowlevel_ivf.cpp:150-175);
+ * returns the number of heap updates in *nup  [IndexIVFFlat.cpp:101-137] */
+int amd_ivf_scan_codes(amd_ivf_t* h, const float* query, size_t list_no, int store_pairs, size_t k, float* simi,
+                       int64_t* idxi, size_t* nup);
+/* InvertedListScanner::distance_to_code for vector `offset` of list `list_no`  [IndexIVFFlat.cpp:110-115] */
+int amd_ivf_distance_to_code(amd_ivf_t* h, const float* query, size_t list_no, size_t offset, float* dis);
+
+/* IndexIVFStats {nq, nlist, ndis, nheap_updates}  [IndexIVF.h:361-374, IndexIVF.cpp:731-734] */
+int amd_ivf_stats(amd_ivf_t* h, size_t stats[4], int reset);
+
+/* ---- resident query sets (Error_sys::set_queries keeps the query matrix and later searches
+ *      slices of it, profile.cpp:173-227): upload once, search slices with data already in HBM */
+int amd_ivf_set_queries(amd_ivf_t* h, size_t n, const float* x);
+int amd_ivf_search_resident(amd_ivf_t* h, size_t start, size_t n, size_t k, size_t nprobe, int coarse_mode, float* D,
+                            int64_t* I);
+
+/* ---- Auncel error-bound machinery (IVF_pro.{h,cpp}, profile.{h,cpp}) -------------------- */
+
+/* Level1Quantizer::train_q1 table: interdis_cem[(2 nlist-1-i) i/2 + j-1-i], i<j  [IndexIVF.cpp:97-117].
+ * With table == NULL it is computed on the device from the current centroids (L2: squared
+ * distances; IP: reference normalisation quirk + acos); otherwise it is uploaded as given. */
+int amd_ivf_set_interdis(amd_ivf_t* h, const float* table);
+int amd_ivf_get_interdis(amd_ivf_t* h, float* table); /* nlist(nlist-1)/2 floats */
+
+/* IndexIVF::init_tune + trained traces: ntraces = log2(nlist/8)+1 maps sum-of-angles -> k-scaling,
+ * trace i has trace_len[i] ascending bins (x, y, std)  [IndexIVF.cpp:203-244, IVF_pro.h:47-66].
+ * arcos_list: 500-entry acos LUT (error_pro::construct_arcos, IVF_pro.cpp:151-160). */
+int amd_ivf_set_tuner(amd_ivf_t* h, size_t max_topk, size_t ntraces, const size_t* trace_len, const float* const* trace_x,
+                      const float* const* trace_y, const float* const* trace_std, const float* arcos_list);
+
+/* search_preassigned, tune branch, driven as Error_sys::search does (nprobe = nlist, k = max_topk)
+ * on resident queries [start, start+n): per-query adaptive stop  [IndexIVF.cpp:507-638, profile.cpp:211-227].
+ * require_acc / gt_D (may be NULL unless profile) / my_nprobe / t_recalls are indexed by absolute query id
+ * like the reference's arrays (id_q = i + offset, IndexIVF.cpp:487); my_nprobe entries must be 0 on entry
+ * for queries that have not been searched (Error_sys::set_queries zeroes them). */
+int amd_ivf_search_adaptive(amd_ivf_t* h, size_t start, size_t n, size_t query_topk, float multipler, float std_m,
+                            const float* require_acc, const float* gt_D, int profile, int coarse_mode,
+                            uint64_t* my_nprobe, float* t_recalls, float* D, int64_t* I);
+
+/* search_preassigned, training branch, driven as Error_sys::sys_train does: raw (sum_angle, kscaling)
+ * samples for stages 1,2,4..nlist/8 of resident queries [start, start+n); raw[i] has
+ * train_num*(max_topk/4) (x,y) pairs and must be pre-filled with (-1,-1)  [IndexIVF.cpp:640-673, profile.cpp:88-156] */
+int amd_ivf_train_samples(amd_ivf_t* h, size_t start, size_t n, size_t max_topk, const float* gt_D, size_t train_num,
+                          int coarse_mode, float* const* raw, float* D, int64_t* I);
+
+/* ---- sharding (IndexShards over list-id shards, IndexShards.cpp:44-105,261-311) ----------- */
+
+/* k-way merge of nshard sorted result tables (all_D/all_I: nshard x n x k) -- host-side, as in the reference */
+int amd_ivf_merge_tables(int metric, size_t n, size_t k, size_t nshard, const float* all_D, const int64_t* all_I,
+                         float* D, int64_t* I);
+
+/* ---- measurement hooks (bench.py): time of the kernels of the last search call, from HIP events
+ *      recorded on the engine's own stream: {coarse_ms, scan_ms, select_ms, total_ms, scan_launches,
+ *      scan_bytes_algorithmic} */
+int amd_ivf_last_timing(amd_ivf_t* h, double out[6]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AUNCEL_AMD_H */
