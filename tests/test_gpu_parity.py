@@ -194,16 +194,14 @@ def test_trace_training_samples(capi, oracle, name):
     ntr = len(traces_from_gold(gold))
     raw = [np.full((ts * (K // 4), 2), -1, dtype=np.float32) for _ in range(ntr)]
     D, I = h.train_samples(0, ts, K, gold["gtD"], ts, raw)
-    if name == "auncel_sift_d32":
-        # integer data: the reference's BLAS coarse path is exact, goldens apply directly
-        exp_raw, eD, eI = [gold[f"raw_trace{i}"] for i in range(ntr)], gold["train_D"], gold["train_I"]
-    else:
-        # float data: the reference trained through vendor-BLAS coarse distances (unpinned); the
-        # pinned oracle fed with the exact coarse ranking is the expectation
-        lists = oracle.Lists(case["metric"], gold["centroids"], case["xb"], gold["assign"])
-        exp_raw = [np.full((ts * (K // 4), 2), -1, dtype=np.float32) for _ in range(ntr)]
-        eD, eI = oracle.train_samples(lists, case["xq"][:ts], K, gold["coarse_keys_sse"][:ts], gold["coarse_dis_sse"][:ts],
-                                      gold["interdis_cem"], gold["arcos_list"], gold["gtD"], 0, ts, exp_raw)
+    # The reference trains in batches of >= 20 queries, i.e. through vendor-BLAS coarse distances
+    # (unpinned rounding; the k-means centroids are not integers even on integer data).  The
+    # expectation is therefore the pinned oracle fed with the exact coarse ranking, which is what
+    # the engine's coarse kernel produces bit for bit (test_coarse_exact).
+    lists = oracle.Lists(case["metric"], gold["centroids"], case["xb"], gold["assign"])
+    exp_raw = [np.full((ts * (K // 4), 2), -1, dtype=np.float32) for _ in range(ntr)]
+    eD, eI = oracle.train_samples(lists, case["xq"][:ts], K, gold["coarse_keys_sse"][:ts], gold["coarse_dis_sse"][:ts],
+                                  gold["interdis_cem"], gold["arcos_list"], gold["gtD"], 0, ts, exp_raw)
     assert np.array_equal(I, eI)
     assert np.array_equal(bits(D), bits(eD))
     for i in range(ntr):
