@@ -21,7 +21,7 @@ SYMBOLS = [
     "amd_ivf_set_lists", "amd_ivf_add", "amd_ivf_ntotal", "amd_ivf_list_size", "amd_ivf_get_list", "amd_ivf_coarse",
     "amd_ivf_search_preassigned", "amd_ivf_search", "amd_ivf_scan_codes", "amd_ivf_distance_to_code", "amd_ivf_stats",
     "amd_ivf_set_queries", "amd_ivf_search_resident", "amd_ivf_set_interdis", "amd_ivf_get_interdis",
-    "amd_ivf_set_tuner", "amd_ivf_search_adaptive", "amd_ivf_train_samples", "amd_ivf_merge_tables",
+    "amd_ivf_set_tuner", "amd_ivf_search_adaptive", "amd_ivf_train_samples", "amd_ivf_trace_sb", "amd_ivf_arcos_table", "amd_ivf_merge_tables",
     "amd_ivf_last_timing",
 ]
 
@@ -80,6 +80,23 @@ def merge_tables(metric, all_D, all_I):
     I = np.empty((n, k), np.int64)
     _chk(lib().amd_ivf_merge_tables(metric, C.c_size_t(n), C.c_size_t(k), C.c_size_t(nshard), _f(all_D), _i(all_I), _f(D), _i(I)))
     return D, I
+
+
+def trace_sb(raw_xy, bs=250):
+    raw = f32(raw_xy)
+    n = raw.shape[0]
+    cap = n // bs + 2
+    ox, oy, os_ = (np.zeros(cap, np.float32) for _ in range(3))
+    nb = C.c_size_t(0)
+    _chk(lib().amd_ivf_trace_sb(_f(raw), C.c_size_t(n), C.c_size_t(bs), _f(ox), _f(oy), _f(os_), C.byref(nb)))
+    return ox[:nb.value].copy(), oy[:nb.value].copy(), os_[:nb.value].copy()
+
+
+def arcos_table():
+    """error_pro::construct_arcos (IVF_pro.cpp:151-160): 500-entry acos LUT, fp32"""
+    out = np.zeros(500, np.float32)
+    _chk(lib().amd_ivf_arcos_table(_f(out)))
+    return out
 
 
 class Handle:

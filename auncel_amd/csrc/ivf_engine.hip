@@ -1226,8 +1226,7 @@ int amd_ivf_train_samples(amd_ivf_t* h, size_t start, size_t n, size_t max_topk,
     if (!h->d_arcos.p) {
         // construct_arcos (IVF_pro.cpp:151-160) on the host libm
         std::vector<float> lut(500);
-        float sc = 500 / 2;
-        for (int i = 0; i < 500; i++) lut[i] = std::acos(float(i - sc) / sc);
+        amd_ivf_arcos_table(lut.data());
         h->d_arcos.ensure(500 * 4);
         HIP_CHECK(hipMemcpy(h->d_arcos.p, lut.data(), 500 * 4, hipMemcpyHostToDevice));
     }
@@ -1257,6 +1256,48 @@ int amd_ivf_train_samples(amd_ivf_t* h, size_t start, size_t n, size_t max_topk,
     HIP_CHECK(hipStreamSynchronize(h->stream));
     double ms[NCAT], ln[NCAT];
     h->timer.collect(ms, NCAT, ln);
+    API_END
+}
+
+int amd_ivf_arcos_table(float out[500]) {
+    const int len = 500;
+    const float sc = len / 2;
+    for (int i = 0; i < len; i++) {
+        const float x = float(i - sc) / sc;
+        out[i] = std::acos(x);
+    }
+    return 0;
+}
+
+int amd_ivf_trace_sb(const float* raw_xy, size_t n, size_t bs, float* out_x, float* out_y, float* out_std,
+                     size_t* nbuckets) {
+    API_BEGIN
+    if (bs == 0) throw EngineError("bucket size must be positive");
+    // std::sort with the reference's comparator and container type: equal keys must land in the
+    // same order for the bucket means to agree bit for bit
+    std::vector<std::pair<float, float>> tr(n);
+    for (size_t i = 0; i < n; i++) tr[i] = std::make_pair(raw_xy[2 * i], raw_xy[2 * i + 1]);
+    std::sort(tr.begin(), tr.end(),
+              [](std::pair<float, float>& l, std::pair<float, float>& r) { return l.first > r.first; });
+    size_t size = 0;
+    for (auto& p : tr) size += (p.first < 0 && p.second < 0) ? 0 : 1;
+    const size_t sz = (size + bs - 1) / bs;
+    for (size_t b = 0; b < sz; b++) {
+        const size_t left = b * bs, right = std::min((b + 1) * bs, size);
+        float mx = 0, my = 0;
+        for (size_t idx = left; idx < right; idx++) {
+            const size_t j = idx - left;
+            mx = (float)j / (float)(j + 1) * mx + tr[idx].first / (j + 1);
+            my = (float)j / (float)(j + 1) * my + tr[idx].second / (j + 1);
+        }
+        double accum = 0.;
+        for (size_t idx = left; idx < right; idx++) accum += (tr[idx].second - my) * (tr[idx].second - my);
+        const float sd = std::sqrt(accum / bs);  // always / bs, also for the last partial bucket
+        out_x[sz - 1 - b] = mx;
+        out_y[sz - 1 - b] = my;
+        out_std[sz - 1 - b] = sd;
+    }
+    *nbuckets = sz;
     API_END
 }
 

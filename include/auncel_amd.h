@@ -121,6 +121,16 @@ int amd_ivf_search_adaptive(amd_ivf_t* h, size_t start, size_t n, size_t query_t
 int amd_ivf_train_samples(amd_ivf_t* h, size_t start, size_t n, size_t max_topk, const float* gt_D, size_t train_num,
                           int coarse_mode, float* const* raw, float* D, int64_t* I);
 
+/* error_pro::construct_arcos: the 500-entry acos LUT, computed with the host libm exactly as the
+ * reference does (LUT[i] = acosf((i-250)/250.f))  [IVF_pro.cpp:151-160] */
+int amd_ivf_arcos_table(float out[500]);
+
+/* Trace::SB: sort the raw samples by x descending, drop unset (-1,-1) ones, bucket by `bs` (250 in the
+ * reference), mean x / mean y / std y per bucket, ascending on return; out_* need n/bs + 1 entries;
+ * *nbuckets receives the count.  Host-side, like the reference  [IVF_pro.cpp:109-149] */
+int amd_ivf_trace_sb(const float* raw_xy, size_t n, size_t bs, float* out_x, float* out_y, float* out_std,
+                     size_t* nbuckets);
+
 /* ---- sharding (IndexShards over list-id shards, IndexShards.cpp:44-105,261-311) ----------- */
 
 /* k-way merge of nshard sorted result tables (all_D/all_I: nshard x n x k) -- host-side, as in the reference */

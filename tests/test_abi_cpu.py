@@ -51,3 +51,19 @@ def test_merge_tables_host(capi, oracle, name):
         D, I = capi.merge_tables(case["metric"], np.stack(allD), np.stack(allI))
         assert np.array_equal(I, gold[f"I_shards_k{k}"])
         assert np.array_equal(D.view(np.uint32), gold[f"D_shards_k{k}"].view(np.uint32))
+
+
+@pytest.mark.parametrize("name", ["auncel_sift_d32", "auncel_gauss_d64"])
+def test_trace_sb_host(capi, name):
+    """Trace::SB bucketing (host side of the product) against the reference's traces"""
+    case, gold = load_case(name)
+    i = 0
+    while f"raw_trace{i}" in gold:
+        x, y, s = capi.trace_sb(gold[f"raw_trace{i}"])
+        assert np.array_equal(x.view(np.uint32), gold[f"sb_trace{i}"][:, 0].view(np.uint32))
+        assert np.array_equal(y.view(np.uint32), gold[f"sb_trace{i}"][:, 1].view(np.uint32))
+        assert np.array_equal(s.view(np.uint32), gold[f"sb_stds{i}"].view(np.uint32))
+        i += 1
+    assert i == 8
+    # numpy arccos vs the reference's LUT (std::acos on float)
+    assert np.array_equal(capi.arcos_table().view(np.uint32), gold["arcos_list"].view(np.uint32))
