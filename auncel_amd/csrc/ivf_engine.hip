@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -145,7 +146,7 @@ struct amd_ivf {
     DevBuf d_interdis;
     bool have_interdis = false;
     DevBuf d_arcos, d_trace_off, d_trace_x, d_trace_y, d_trace_std;
-    size_t tuner_max_topk = 0, tuner_ntraces = 0;
+    size_t tuner_max_topk = 0, tuner_ntraces = 0, tuner_trace_cap = 0;
     bool have_tuner = false;
 
     // workspaces (grow only)
@@ -431,6 +432,7 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
         ra.coarse_dis = r.d_cdis;
         ra.coarse_keys = r.d_ckeys;
         ra.coarse_stride = r.coarse_stride;
+        ra.trace_cap = (uint32_t)h->tuner_trace_cap;
         ra.D = h->w_D.as<float>();
         ra.I = h->w_I.as<int64_t>();
         ra.stats = h->w_stats.as<unsigned long long>();
@@ -705,6 +707,14 @@ void run_rounds(amd_ivf* h, RoundSpec& base, size_t n, size_t first_round, size_
         for (size_t i = 0; i < n; i++) {
             if (done[i]) continue;
             size_t target = stage[i] + round_len;
+            if (base.tuner.enabled) {
+                // an unfired query at stage s cannot stop before floor((s+1) * multipler): that many probes
+                // are waste-free; beyond it allow growth-1 of over-scan to keep the number of rounds small
+                static const double grow_env = getenv("AUNCEL_AMD_ROUND_GROW") ? atof(getenv("AUNCEL_AMD_ROUND_GROW")) : 2.0;
+                const double grow = std::max<double>(base.tuner.multipler, grow_env);
+                const size_t safe = (size_t)((float)(stage[i] + 1) * base.tuner.multipler);
+                target = std::max<size_t>({safe, (size_t)(stage[i] * grow), stage[i] + first_round});
+            }
             if (np[i] != 0) target = std::max<size_t>(np[i], stage[i] + 1);
             target = std::min(target, total_nprobe);
             if (target <= stage[i]) target = std::min<size_t>(stage[i] + 1, total_nprobe);
@@ -1139,6 +1149,8 @@ int amd_ivf_set_tuner(amd_ivf_t* h, size_t max_topk, size_t ntraces, const size_
     HIP_CHECK(hipMemcpy(h->d_arcos.p, arcos_list, 500 * 4, hipMemcpyHostToDevice));
     h->tuner_max_topk = max_topk;
     h->tuner_ntraces = ntraces;
+    h->tuner_trace_cap = 0;
+    for (size_t i = 0; i < ntraces; i++) h->tuner_trace_cap = std::max(h->tuner_trace_cap, trace_len[i]);
     h->have_tuner = true;
     API_END
 }

@@ -99,6 +99,7 @@ struct ReplayArgs {
     const float* coarse_dis;   // [nq][coarse_stride] full coarse ranking (tune / train)
     const int64_t* coarse_keys;
     uint32_t coarse_stride;
+    uint32_t trace_cap;        // longest trace (LDS cache size), tune mode
     // outputs
     float* D;                  // [nq][k]
     int64_t* I;

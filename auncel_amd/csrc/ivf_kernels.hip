@@ -208,17 +208,6 @@ __device__ inline float cosine_theorem_dev(float a, float b, float c, uint32_t* 
     return c / 2 - temp;
 }
 
-// error_pro::sum_angle (IVF_pro.cpp:162-177), n = 15
-__device__ inline float sum_angle_dev(const float* lut, float kdis, const float* dtb, uint32_t start, uint32_t* err) {
-    float sum = 0;
-    for (uint32_t i = start; i < start + 15; i++) {
-        const float b = dtb[i];
-        if (b >= kdis) continue;
-        sum += arcos_lut(lut, b / kdis, err);
-    }
-    return sum;
-}
-
 // Trace::search (IVF_pro.cpp:84-107)
 __device__ inline float trace_search(const float* x, const float* y, const float* sd, uint32_t n, float k, float sc) {
     if (k <= x[0]) return y[0] + sc * sd[0];
@@ -234,28 +223,6 @@ __device__ inline float trace_search(const float* x, const float* y, const float
     }
     if (x[low] > k) low--;
     return y[low] + sc * sd[low];
-}
-
-// error_pro::cur_num (IVF_pro.cpp:258-291)
-__device__ inline uint32_t cur_num_dev(const TunerDev& t, const float* Ds, const float* dtb, uint32_t index,
-                                       uint32_t* err) {
-    const uint32_t o = t.trace_off[index], n = t.trace_off[index + 1] - o;
-    const float *tx = t.trace_x + o, *ty = t.trace_y + o, *ts = t.trace_std + o;
-    const uint32_t start = (1u << index) - 1;
-    const unsigned long long query_k = t.query_topk;
-    unsigned long long high = query_k - 1, low = 0, middle = 0;
-    {
-        const float g = trace_search(tx, ty, ts, n, sum_angle_dev(t.arcos, Ds[high], dtb, start, err), t.std_m);
-        if ((double)((float)query_k * g) <= (double)query_k * 1.005) return (uint32_t)query_k;
-    }
-    while (low <= high) {
-        middle = (low + high) / 2;
-        if (middle <= 0) return 0;
-        const float g = trace_search(tx, ty, ts, n, sum_angle_dev(t.arcos, Ds[middle], dtb, start, err), t.std_m);
-        if ((float)(middle + 1) * g <= (float)query_k) low = middle + 1;
-        else high = middle - 1;
-    }
-    return (uint32_t)(low + 1);
 }
 
 // kscaling (IVF_pro.cpp:72-82)
@@ -289,17 +256,84 @@ __device__ inline void set_online_dev(int metric, uint32_t nlist, const float* c
     }
 }
 
-// ascending sort of src[0..k) into dst by ranking (values only matter)
-__device__ inline void rank_sort(const float* src, float* dst, int k, int lane) {
+// best-first sort of the heap values into srt by ranking (values only matter)
+template <bool IsMax> __device__ inline void rank_sort_best_first(const float* src, float* dst, int k, int lane) {
     for (int i = lane; i < k; i += 64) {
         const float x = src[i];
         int rank = 0;
         for (int j = 0; j < k; j++) {
             const float y = src[j];
-            rank += (y < x) || (y == x && j < i);
+            rank += (IsMax ? (y < x) : (y > x)) || (y == x && j < i);
         }
         dst[rank] = x;
     }
+}
+
+// srt holds the k heap values best first.  A heap update replaces the worst value (the heap top,
+// == srt[k-1]) by `val`: shift the worse ones down by one slot and drop val into the gap.
+template <bool IsMax> __device__ inline void sorted_replace_worst(float* srt, int k, float val, int lane) {
+    int pos = 0;
+    for (int c = (k - 1) / 64; c >= 0; c--) {
+        const int idx = c * 64 + lane;
+        const bool in = idx < k - 1;
+        const float s = in ? srt[idx] : 0.f;
+        const bool worse = in && (IsMax ? s > val : s < val);
+        pos += __builtin_popcountll(__ballot(in && !worse));
+        wave_sync();
+        if (worse) srt[idx + 1] = s;
+        wave_sync();
+    }
+    srt[pos] = val;
+    wave_sync();
+}
+
+// error_pro::sum_angle (IVF_pro.cpp:162-177), n = 15: the 15 terms on 15 lanes, then summed in the
+// reference's order (a skipped term adds +0, which leaves the non-negative running sum unchanged)
+__device__ inline float sum_angle_par(const float* lut, float kdis, const float* dtb, uint32_t start, int lane, uint32_t* err) {
+    float t = 0.f;
+    if (lane < 15) {
+        const float b = dtb[start + lane];
+        if (!(b >= kdis)) t = arcos_lut(lut, b / kdis, err);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 15; i++) sum += __shfl(t, i);
+    return sum;
+}
+
+struct TraceLds {
+    const float *x, *y, *sd;
+    uint32_t n;
+};
+
+// error_pro::cur_num (IVF_pro.cpp:258-291); Ds(m) = m-th best value (IP: its arcos)
+template <bool IsMax>
+__device__ inline uint32_t cur_num_lds(const TraceLds& tr, const float* lut, const float* srt, const float* dtb, uint32_t index,
+                                       uint32_t query_topk, float std_m, int lane, uint32_t* err) {
+    const uint32_t start = (1u << index) - 1;
+    const unsigned long long query_k = query_topk;
+    unsigned long long high = query_k - 1, low = 0, middle = 0;
+    auto Ds = [&](unsigned long long m) { return IsMax ? srt[m] : arcos_lut(lut, srt[m], err); };
+    {
+        const float g = trace_search(tr.x, tr.y, tr.sd, tr.n, sum_angle_par(lut, Ds(high), dtb, start, lane, err), std_m);
+        if ((double)((float)query_k * g) <= (double)query_k * 1.005) return (uint32_t)query_k;
+    }
+    while (low <= high) {
+        middle = (low + high) / 2;
+        if (middle <= 0) return 0;
+        const float g = trace_search(tr.x, tr.y, tr.sd, tr.n, sum_angle_par(lut, Ds(middle), dtb, start, lane, err), std_m);
+        if ((float)(middle + 1) * g <= (float)query_k) low = middle + 1;
+        else high = middle - 1;
+    }
+    return (uint32_t)(low + 1);
+}
+
+__host__ __device__ inline size_t replay_wave_bytes(int k, uint32_t nlist, bool geo, bool tune, bool train, uint32_t trace_cap) {
+    size_t b = (size_t)k * 16;                       // href | hval | srt
+    if (geo) b += (size_t)(nlist / 8 + 20) * 4;      // dtb
+    if (tune) b += (size_t)trace_cap * 12;           // cached trace (x | y | std)
+    if (train) b += (size_t)k * 4;                   // ground-truth row
+    return (b + 15) & ~(size_t)15;
 }
 
 template <bool IsMax>
@@ -307,18 +341,30 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool tune = a.tuner.enabled != 0, training = a.train.enabled != 0, geo = tune || training;
+    const int k = a.k;
+    const uint32_t nlist = a.nlist;
+    const uint32_t max_num = nlist / 8 + 20;
+
+    // shared: the acos LUT; per wave: href | hval | srt | dtb | trace cache | gt row
+    float* lut = reinterpret_cast<float*>(smem);
+    if (geo) {
+        const float* g = tune ? a.tuner.arcos : a.train.arcos;
+        for (int i = threadIdx.x; i < 500; i += 256) lut[i] = g[i];
+        __syncthreads();
+    }
     const uint32_t li = blockIdx.x * 4 + wave;   // position in this launch
     if (li >= a.nq) return;
     const uint32_t qi = a.qsel ? a.qsel[li] : li;  // query slot (state / output row)
     if (a.done[qi]) return;
 
-    const int k = a.k;
-    // per-wave LDS: ref[k] (8B) | val[k] | tmp[k] | srt[k]
-    unsigned char* base = smem + (size_t)wave * ((size_t)k * 20 + 16);
+    unsigned char* base = smem + (geo ? 2000 : 0) + (size_t)wave * replay_wave_bytes(k, nlist, geo, tune, training, a.trace_cap);
     int64_t* href = reinterpret_cast<int64_t*>(base);
     float* hval = reinterpret_cast<float*>(base + (size_t)k * 8);
-    float* tmp = hval + k;
-    float* srt = tmp + k;
+    float* srt = hval + k;
+    float* dtb = srt + k;                                  // geo only
+    float* trc = dtb + (geo ? max_num : 0);                // tune only: x | y | std, trace_cap each
+    float* gtrow = trc + (tune ? 3 * a.trace_cap : 0);     // training only
 
     for (int i = lane; i < k; i += 64) {
         hval[i] = a.heap_val[(size_t)qi * k + i];
@@ -327,12 +373,7 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
     wave_sync();
 
     const unsigned long long id_q = a.id_offset + qi;
-    const uint32_t nlist = a.nlist;
-    const bool tune = a.tuner.enabled != 0, training = a.train.enabled != 0;
-    const uint32_t max_num = nlist / 8 + 20;
-    float* dtb = (tune || training) ? a.dtb + (size_t)qi * max_num : nullptr;
     uint32_t err = 0;
-
     uint32_t ik0 = a.stage[qi];
     const uint32_t cnt = a.seg_count[li];
     unsigned long long nscan = a.nscan[qi];
@@ -340,20 +381,37 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
     uint32_t stoped = a.stoped ? a.stoped[qi] : 0u;
     unsigned long long st_nlist = 0, st_nheap = 0, st_ndis = 0;
 
-    if ((tune || training) && ik0 == 0) {
-        set_online_dev(a.metric, nlist, a.coarse_dis + (size_t)qi * a.coarse_stride,
-                       a.coarse_keys + (size_t)qi * a.coarse_stride, tune ? a.tuner.interdis : a.train.interdis,
-                       tune ? a.tuner.arcos : a.train.arcos, dtb, lane, &err);
-        __threadfence_block();
+    if (geo) {
+        float* gdtb = a.dtb + (size_t)qi * max_num;
+        if (ik0 == 0) {
+            set_online_dev(a.metric, nlist, a.coarse_dis + (size_t)qi * a.coarse_stride,
+                           a.coarse_keys + (size_t)qi * a.coarse_stride, tune ? a.tuner.interdis : a.train.interdis, lut,
+                           dtb, lane, &err);
+            wave_sync();
+            for (uint32_t i = lane; i < max_num; i += 64) gdtb[i] = dtb[i];
+        } else {
+            for (uint32_t i = lane; i < max_num; i += 64) dtb[i] = gdtb[i];
+        }
+        rank_sort_best_first<IsMax>(hval, srt, k, lane);
+        if (training) {
+            const float* gt = a.train.gt_D + id_q * (unsigned long long)k;
+            for (int i = lane; i < k; i += 64) gtrow[i] = gt[i];
+        }
         wave_sync();
     }
 
     uint32_t query_k = 0;
-    float true_KD_K = 0.f;
+    float true_KD_K = 0.f, racc = 0.f;
+    unsigned long long np = 0;
+    int cached_ind = -1;
+    TraceLds tr{trc, trc + a.trace_cap, trc + 2 * a.trace_cap, 0};
     if (tune) {
         query_k = a.tuner.query_topk;
         if (a.tuner.gt_D) true_KD_K = a.tuner.gt_D[id_q * (unsigned long long)k + query_k - 1];
+        racc = a.tuner.require_acc[id_q];
+        np = a.tuner.my_nprobe[id_q];
     }
+    const unsigned long long np_in = np;
 
     bool finished = false;
     uint32_t consumed = 0;
@@ -372,15 +430,15 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
                 st_nlist++;
                 const float* seg = a.dist + a.seg_off[(size_t)li * a.round_probes + p];
                 const int64_t refbase = REF_TAG | ((int64_t)key << 32);
-                for (uint32_t b0 = 0; b0 < n; b0 += 256) {
-                    float v[4];
+                for (uint32_t b0 = 0; b0 < n; b0 += 512) {
+                    float v[8];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
+                    for (int u = 0; u < 8; u++) {
                         const uint32_t j = b0 + u * 64 + lane;
                         v[u] = j < n ? seg[j] : hneutral<IsMax>();
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
+                    for (int u = 0; u < 8; u++) {
                         unsigned long long m = __ballot(hcmp<IsMax>(hval[0], v[u]));
                         while (m) {
                             const int l = __builtin_ctzll(m);
@@ -390,6 +448,7 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
                                 heap_pop<IsMax>(k, hval, href);
                                 heap_push<IsMax>(k, hval, href, val, refbase | (int64_t)(b0 + u * 64 + l));
                                 st_nheap++;
+                                if (geo) sorted_replace_worst<IsMax>(srt, k, val, lane);
                             }
                         }
                     }
@@ -405,67 +464,67 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
         if (a.total_nprobe && ik + 1 >= a.total_nprobe) finished = true;  // end of the probe loop
         wave_sync();
         if (tune) {
-            // IndexIVF.cpp:551-638
+            // IndexIVF.cpp:551-638.  Once my_nprobe is known nothing the rule computes can change the
+            // outcome any more (L2: no throwing path left), so only the stop test remains.
             const uint32_t stage = ik + 1;
-            uint32_t ind = 0;
-            const uint32_t tmp_stage = stage >= nlist / 8 ? nlist / 8 - 1 : stage;
-            while (tmp_stage > (1u << ind)) ind++;
-            if (!IsMax) {
-                for (int i = lane; i < k; i += 64) tmp[i] = arcos_lut(a.tuner.arcos, hval[i], &err);
-                wave_sync();
-                rank_sort(tmp, srt, k, lane);
-            } else {
-                rank_sort(hval, srt, k, lane);
+            const bool fired = IsMax && np != 0;
+            if (!fired) {
+                uint32_t ind = 0;
+                const uint32_t tmp_stage = stage >= nlist / 8 ? nlist / 8 - 1 : stage;
+                while (tmp_stage > (1u << ind)) ind++;
+                if ((int)ind != cached_ind) {
+                    const uint32_t o = a.tuner.trace_off[ind], n = a.tuner.trace_off[ind + 1] - o;
+                    for (uint32_t i = lane; i < n; i += 64) {
+                        trc[i] = a.tuner.trace_x[o + i];
+                        trc[a.trace_cap + i] = a.tuner.trace_y[o + i];
+                        trc[2 * a.trace_cap + i] = a.tuner.trace_std[o + i];
+                    }
+                    tr.n = n;
+                    cached_ind = (int)ind;
+                    wave_sync();
+                }
+                if (!IsMax) {
+                    // the reference converts all k heap values (IndexIVF.cpp:562-564): any out-of-domain one throws
+                    for (int i = lane; i < k; i += 64) (void)arcos_lut(lut, srt[i], &err);
+                    err = wave_max_u32(err);
+                    if (err) {
+                        finished = true;
+                        break;
+                    }
+                }
+                const uint32_t pre_num = cur_num_lds<IsMax>(tr, lut, srt, dtb, ind, query_k, a.tuner.std_m, lane, &err);
+                float recall = (float)pre_num / (float)query_k;
+                const float max_val = IsMax ? fmaxf(-1.f, srt[k - 1]) : fminf(FLT_MAX, srt[k - 1]);
+                const unsigned long long stops = (unsigned long long)(racc * 12);
+                if (stage > 1) {
+                    if (max_val == pre_val) stoped++;
+                    else stoped = 0;
+                    if (stoped >= stops) recall = 1;
+                }
+                pre_val = max_val;
+                if (recall >= racc && np == 0) {
+                    np = (unsigned long long)((float)stage * a.tuner.multipler);
+                    if (np >= nlist && lane == 0) a.tuner.t_recalls[id_q] = 1.f;
+                }
+                if (stage >= nlist / 8 && np == 0) {
+                    np = (unsigned long long)((float)stage * a.tuner.multipler);
+                    if (np >= nlist && lane == 0) a.tuner.t_recalls[id_q] = 1.f;
+                }
+                err = wave_max_u32(err);
+                if (err) finished = true;
             }
-            wave_sync();
-            err = wave_max_u32(err);
-            if (err) {
-                finished = true;
-                break;
-            }
-            const uint32_t pre_num = cur_num_dev(a.tuner, srt, dtb, ind, &err);
-            float recall = (float)pre_num / (float)query_k;
-            // heap extreme + ground-truth hit count
-            float ext = IsMax ? -1.f : FLT_MAX;
-            uint32_t hits = 0;
-            for (int i = lane; i < k; i += 64) {
-                const float s = hval[i];
-                ext = IsMax ? fmaxf(ext, s) : fminf(ext, s);
-                if (IsMax ? ((double)s <= (double)true_KD_K * 1.0005) : ((double)s >= (double)true_KD_K * 0.9995)) hits++;
-            }
-            for (int off = 32; off; off >>= 1) {
-                const float o = __shfl_xor(ext, off);
-                ext = IsMax ? fmaxf(ext, o) : fminf(ext, o);
-                hits += __shfl_xor(hits, off);
-            }
-            const float max_val = ext;
-            const float racc = a.tuner.require_acc[id_q];
-            const unsigned long long stops = (unsigned long long)(racc * 12);
-            if (stage > 1) {
-                if (max_val == pre_val) stoped++;
-                else stoped = 0;
-                if (stoped >= stops) recall = 1;
-            }
-            pre_val = max_val;
-            const float true_recall = (float)hits / (float)query_k;
-            unsigned long long np = a.tuner.my_nprobe[id_q];
-            bool np_changed = false;
-            if (recall >= racc && np == 0) {
-                np = (unsigned long long)((float)stage * a.tuner.multipler);
-                np_changed = true;
-                if (np >= nlist && lane == 0) a.tuner.t_recalls[id_q] = 1.f;
-            }
-            if (stage >= nlist / 8 && np == 0) {
-                np = (unsigned long long)((float)stage * a.tuner.multipler);
-                np_changed = true;
-                if (np >= nlist && lane == 0) a.tuner.t_recalls[id_q] = 1.f;
-            }
-            if (np_changed && lane == 0) a.tuner.my_nprobe[id_q] = np;
             if (np != 0 && np <= stage) {
-                if (a.tuner.profile && lane == 0) a.tuner.t_recalls[id_q] = true_recall;
+                if (a.tuner.profile) {
+                    uint32_t hits = 0;
+                    for (int i = lane; i < k; i += 64) {
+                        const float s = hval[i];
+                        if (IsMax ? ((double)s <= (double)true_KD_K * 1.0005) : ((double)s >= (double)true_KD_K * 0.9995)) hits++;
+                    }
+                    for (int off = 32; off; off >>= 1) hits += __shfl_xor(hits, off);
+                    if (lane == 0) a.tuner.t_recalls[id_q] = (float)hits / (float)query_k;
+                }
                 finished = true;
             }
-            if (err) finished = true;
         }
         if (training && !finished) {
             // IndexIVF.cpp:640-673
@@ -475,18 +534,15 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
             } else if ((stage & (stage - 1)) == 0) {
                 uint32_t ind = 0;
                 while (stage != (1u << ind)) ind++;
-                rank_sort(hval, srt, k, lane);
-                wave_sync();
-                const float* gt = a.train.gt_D + id_q * (unsigned long long)k;
                 float* out = a.train.raw[ind] + 2ull * (id_q * (unsigned long long)(k / 4));
                 uint32_t count = 0;
                 for (int ij = 0; ij < k; ij++) {
-                    const float dv = IsMax ? srt[ij] : srt[k - 1 - ij];
-                    const float ks = kscaling_dev(dv, (uint32_t)ij, gt, (uint32_t)k);
+                    const float dv = srt[ij];  // L2 ascending / IP descending, as the reference walks them
+                    const float ks = kscaling_dev(dv, (uint32_t)ij, gtrow, (uint32_t)k);
                     if (ks < 0) break;
                     float tval = dv;
-                    if (!IsMax) tval = arcos_lut(a.train.arcos, tval, &err);
-                    const float sum_a = sum_angle_dev(a.train.arcos, tval, dtb, stage - 1, &err);
+                    if (!IsMax) tval = arcos_lut(lut, tval, &err);
+                    const float sum_a = sum_angle_par(lut, tval, dtb, stage - 1, lane, &err);
                     if (lane == 0) {
                         out[2 * count] = sum_a;
                         out[2 * count + 1] = ks;
@@ -494,6 +550,7 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
                     count++;
                     if (count >= (uint32_t)(k / 4)) break;
                 }
+                err = wave_max_u32(err);
                 if (err) finished = true;
             }
         }
@@ -505,6 +562,7 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
         a.nscan[qi] = nscan;
         if (a.pre_val) a.pre_val[qi] = pre_val;
         if (a.stoped) a.stoped[qi] = stoped;
+        if (tune && np != np_in) a.tuner.my_nprobe[id_q] = np;
         if (st_nlist) atomicAdd(&a.stats[0], st_nlist);
         if (st_ndis) atomicAdd(&a.stats[1], st_ndis);
         if (st_nheap) atomicAdd(&a.stats[2], st_nheap);
@@ -564,13 +622,14 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
 
 void launch_replay(const ReplayArgs& a, hipStream_t s) {
     if (a.nq == 0) return;
-    const size_t shmem = 4 * ((size_t)a.k * 20 + 16);
+    const bool tune = a.tuner.enabled != 0, train = a.train.enabled != 0, geo = tune || train;
+    const size_t shmem = (geo ? 2000 : 0) + 4 * replay_wave_bytes(a.k, a.nlist, geo, tune, train, a.trace_cap);
     const dim3 grid((a.nq + 3) / 4), block(256);
     if (a.metric == METRIC_L2) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(replay_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(replay_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         hipLaunchKernelGGL(replay_kernel<true>, grid, block, shmem, s, a);
     } else {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(replay_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(replay_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         hipLaunchKernelGGL(replay_kernel<false>, grid, block, shmem, s, a);
     }
 }
@@ -633,10 +692,10 @@ void launch_sort_rows(const float* dis, uint32_t nq, uint32_t nlist, uint32_t np
     while (npow2 < nlist) npow2 <<= 1;
     const size_t shmem = (size_t)npow2 * 8;
     if (metric == METRIC_L2) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(sort_rows_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sort_rows_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         hipLaunchKernelGGL(sort_rows_kernel<true>, dim3(nq), dim3(256), shmem, s, dis, nlist, npow2, nprobe, out_dis, out_keys);
     } else {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(sort_rows_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sort_rows_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         hipLaunchKernelGGL(sort_rows_kernel<false>, dim3(nq), dim3(256), shmem, s, dis, nlist, npow2, nprobe, out_dis, out_keys);
     }
 }
