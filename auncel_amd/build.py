@@ -15,7 +15,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "auncel_amd.h")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if os.path.isfile(os.path.join(CSRC, f))] + [os.path.join(HERE, "..", "include", "auncel_amd.h")]
     return any(os.path.getmtime(p) > t for p in deps)
 
 
@@ -29,5 +29,22 @@ def build(force=False):
     return LIB
 
 
+HOST_LIB = os.path.join(LIBDIR, "libfaiss_amd.so")
+HOST_DIR = os.path.join(CSRC, "host")
+
+
+def build_host(force=False):
+    """C++ mirror of the reference's classes (namespace faiss) on top of the C ABI"""
+    build(force)
+    srcs = [os.path.join(HOST_DIR, f) for f in os.listdir(HOST_DIR)]
+    if not force and os.path.exists(HOST_LIB) and all(os.path.getmtime(p) <= os.path.getmtime(HOST_LIB) for p in srcs + [LIB]):
+        return HOST_LIB
+    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", os.path.join(HOST_DIR, "faiss_amd.cpp"), "-o", HOST_LIB,
+           "-L" + LIBDIR, "-launcel_amd", "-Wl,-rpath,$ORIGIN"]
+    subprocess.run(cmd, check=True)
+    return HOST_LIB
+
+
 if __name__ == "__main__":
     print(build(force=True))
+    print(build_host(force=True))

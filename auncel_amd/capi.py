@@ -21,7 +21,8 @@ SYMBOLS = [
     "amd_ivf_set_lists", "amd_ivf_add", "amd_ivf_ntotal", "amd_ivf_list_size", "amd_ivf_get_list", "amd_ivf_coarse",
     "amd_ivf_search_preassigned", "amd_ivf_search", "amd_ivf_scan_codes", "amd_ivf_distance_to_code", "amd_ivf_stats",
     "amd_ivf_set_queries", "amd_ivf_search_resident", "amd_ivf_set_interdis", "amd_ivf_get_interdis",
-    "amd_ivf_set_tuner", "amd_ivf_search_adaptive", "amd_ivf_train_samples", "amd_ivf_trace_sb", "amd_ivf_arcos_table", "amd_ivf_merge_tables",
+    "amd_ivf_set_tuner", "amd_ivf_search_adaptive", "amd_ivf_search_adaptive_x", "amd_ivf_train_samples",
+    "amd_ivf_train_samples_x", "amd_ivf_trace_sb", "amd_ivf_arcos_table", "amd_ivf_merge_tables",
     "amd_ivf_last_timing",
 ]
 

@@ -1,0 +1,46 @@
+// faiss::Index as the Auncel tree declares it (Auncel/Index.h:42-134): same field and method names,
+// so that code written against the reference (eval/*.cpp) compiles against this mirror.  Every
+// compute method of the concrete classes goes to the MI355X engine through include/auncel_amd.h.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+
+namespace faiss {
+
+enum MetricType { METRIC_INNER_PRODUCT = 0, METRIC_L2 = 1 };
+typedef enum IndexType { IVF, HNSW, OTHER } IndexType;
+
+struct RangeSearchResult;
+
+struct Index {
+    using idx_t = long;
+    using component_t = float;
+    using distance_t = float;
+
+    // Auncel additions (Index.h:71-77)
+    bool tune = false;
+    IndexType type = OTHER;
+    virtual void set_tune_mode() { tune = true; }
+    virtual void set_tune_off() { tune = false; }
+
+    int d;
+    idx_t ntotal;
+    bool verbose;
+    bool is_trained;
+    MetricType metric_type;
+
+    explicit Index(idx_t d = 0, MetricType metric = METRIC_L2)
+        : d((int)d), ntotal(0), verbose(false), is_trained(true), metric_type(metric) {}
+    virtual ~Index() {}
+
+    virtual void train(idx_t /*n*/, const float* /*x*/) {}
+    virtual void add(idx_t n, const float* x) = 0;
+    virtual void add_with_ids(idx_t n, const float* x, const long* xids);
+    virtual void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const = 0;
+    virtual void reset() = 0;
+    /// nearest-neighbour labels only (Index.cpp:42-48)
+    void assign(idx_t n, const float* x, idx_t* labels, idx_t k = 1);
+};
+
+}  // namespace faiss

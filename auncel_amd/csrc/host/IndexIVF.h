@@ -1,0 +1,127 @@
+// faiss::IndexIVF with Auncel's additions (Auncel/IndexIVF.h:37-374), backed by the MI355X engine.
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "IVF_pro.h"
+#include "Index.h"
+#include "InvertedLists.h"
+
+struct amd_ivf;
+
+namespace faiss {
+
+struct ClusteringParameters {
+    int niter = 25;
+    int nredo = 1;
+    bool verbose = false;
+    bool spherical = false;
+    bool update_index = false;
+    bool frozen_centroids = false;
+    int min_points_per_centroid = 39;
+    int max_points_per_centroid = 256;
+    int seed = 1234;
+};
+
+struct Level1Quantizer {
+    Index* quantizer;
+    size_t nlist;
+    std::vector<float> interdis_cem;  ///< packed centroid-to-centroid table (IVF_pro.cpp:21-39 layout)
+    char quantizer_trains_alone;
+    bool own_fields;
+    ClusteringParameters cp;
+    Index* clustering_index;
+
+    void train_q1(size_t n, const float* x, bool verbose, MetricType metric_type);
+    Level1Quantizer(Index* quantizer, size_t nlist, bool t = false);
+    Level1Quantizer();
+    ~Level1Quantizer();
+};
+
+struct IVFSearchParameters {
+    size_t nprobe;
+    size_t max_codes;
+    virtual ~IVFSearchParameters() {}
+};
+
+struct InvertedListScanner;
+
+struct IndexIVF : Index, Level1Quantizer {
+    InvertedLists* invlists;
+    bool own_invlists;
+    bool training = false;
+    error_pro* t;
+    size_t code_size;
+    size_t nprobe;
+    size_t max_codes;
+    int parallel_mode;
+    bool maintain_direct_map;
+    std::vector<idx_t> direct_map;
+
+    IndexIVF(Index* quantizer, size_t d, size_t nlist, size_t code_size, MetricType metric = METRIC_L2);
+    IndexIVF();
+    ~IndexIVF() override;
+
+    void set_tune_mode() override;
+    void set_tune_off() override;
+    void set_train_mode();
+    void set_train_off();
+    void init_tune(size_t train_num, size_t topk, const float* train_q, const float* train_D, const long* train_I,
+                   float* train_cd, long* train_ci);
+
+    void reset() override;
+    void train(idx_t n, const float* x) override;
+    void add(idx_t n, const float* x) override;
+    void add_with_ids(idx_t n, const float* x, const long* xids) override = 0;
+
+    virtual void search_preassigned(idx_t n, const float* x, idx_t k, const idx_t* assign, const float* centroid_dis,
+                                    float* distances, idx_t* labels, bool store_pairs,
+                                    const IVFSearchParameters* params = nullptr) const;
+    void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const override;
+    /// Auncel overload: `offset` = absolute id of query 0 (IndexIVF.cpp:355-378)
+    void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels, size_t offset) const;
+
+    virtual InvertedListScanner* get_InvertedListScanner(bool store_pairs = false) const;
+
+    size_t get_list_size(size_t list_no) const { return invlists->list_size(list_no); }
+    void replace_invlists(InvertedLists* il, bool own = false);
+
+    /// the engine handle (created lazily; contents refreshed when centroids / lists / traces changed)
+    amd_ivf* engine() const;
+    /// register a query matrix as resident in HBM (what Error_sys::set_queries / sys_train pass in)
+    void set_resident_queries(const float* x, size_t n) const;
+
+   private:
+    friend struct EngineScanner;
+    mutable amd_ivf* gpu_ = nullptr;
+    mutable size_t lists_version_ = (size_t)-1;
+    mutable size_t centroid_count_ = (size_t)-1;
+    mutable size_t traces_version_ = (size_t)-1;
+    mutable const float* interdis_uploaded_ = nullptr;
+    mutable size_t interdis_size_ = 0;
+    mutable const float* resident_ptr_ = nullptr;
+    mutable size_t resident_n_ = 0;
+    void sync_engine(bool need_tuner) const;
+    void fold_stats() const;
+};
+
+/// scans one list for one query on a caller-owned raw heap (IndexIVF.h:316-358)
+struct InvertedListScanner {
+    using idx_t = Index::idx_t;
+    virtual void set_query(const float* query_vector) = 0;
+    virtual void set_list(idx_t list_no, float coarse_dis) = 0;
+    virtual float distance_to_code(const uint8_t* code) const = 0;
+    virtual size_t scan_codes(size_t n, const uint8_t* codes, const idx_t* ids, float* distances, idx_t* labels,
+                              size_t k) const = 0;
+    virtual ~InvertedListScanner() {}
+};
+
+struct IndexIVFStats {
+    size_t nq, nlist, ndis, nheap_updates;
+    double quantization_time, search_time;
+    IndexIVFStats() { reset(); }
+    void reset();
+};
+extern IndexIVFStats indexIVF_stats;
+
+}  // namespace faiss

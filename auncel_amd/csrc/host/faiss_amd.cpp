@@ -1,0 +1,747 @@
+// Implementation of the host-side mirror of the reference's classes (namespace faiss) on top of the
+// C ABI of include/auncel_amd.h.  No distance, selection or stop-rule arithmetic happens here: this
+// file is bookkeeping, argument checking and the host-only pieces the reference also keeps on the
+// host (list storage, Trace::SB ordering, the acos table, shard merging, k-means means).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <random>
+#include <sstream>
+#include <stdexcept>
+
+#include "../../../include/auncel_amd.h"
+#include "AutoTune.h"
+#include "FaissAssert.h"
+#include "Heap.h"
+#include "IVF_pro.h"
+#include "IndexFlat.h"
+#include "IndexIVF.h"
+#include "IndexIVFFlat.h"
+#include "IndexShards.h"
+#include "profile.h"
+
+namespace faiss {
+
+namespace {
+
+void chk(int rc, const char* what) {
+    if (rc == 0) return;
+    std::string msg = std::string(what) + ": " + amd_ivf_last_error();
+    if (rc == -2) throw FaissException(msg);
+    throw std::runtime_error(msg);  // HIP failure / no GPU: there is no CPU path to fall back to
+}
+#define AMD(call) chk(call, #call)
+
+int device_id() {
+    const char* e = getenv("AUNCEL_AMD_DEVICE");
+    return e ? atoi(e) : 0;
+}
+
+static_assert(sizeof(long) == sizeof(int64_t), "idx_t must be 64-bit");
+inline int64_t* i64(long* p) { return reinterpret_cast<int64_t*>(p); }
+inline const int64_t* i64(const long* p) { return reinterpret_cast<const int64_t*>(p); }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------- Index
+void Index::add_with_ids(idx_t, const float*, const long*) { FAISS_THROW_MSG("add_with_ids not implemented for this type of index"); }
+
+void Index::assign(idx_t n, const float* x, idx_t* labels, idx_t k) {
+    std::vector<float> dis(n * k);
+    search(n, x, k, dis.data(), labels);
+}
+
+// ------------------------------------------------------------------------------------- IndexFlat
+IndexFlat::IndexFlat(idx_t d, MetricType metric) : Index(d, metric) {}
+
+IndexFlat::~IndexFlat() {
+    if (gpu_) amd_ivf_destroy(gpu_);
+}
+
+void IndexFlat::add(idx_t n, const float* x) {
+    xb.insert(xb.end(), x, x + n * d);
+    ntotal += n;
+}
+
+void IndexFlat::reset() {
+    xb.clear();
+    ntotal = 0;
+}
+
+void IndexFlat::search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const {
+    FAISS_THROW_IF_NOT_MSG(ntotal > 0, "empty flat index");
+    if (!gpu_ || gpu_ntotal_ != ntotal) {
+        if (gpu_) amd_ivf_destroy(gpu_);
+        gpu_ = nullptr;
+        AMD(amd_ivf_create(d, (size_t)ntotal, (int)metric_type, device_id(), &gpu_));
+        AMD(amd_ivf_set_centroids(gpu_, xb.data()));
+        gpu_ntotal_ = ntotal;
+    }
+    AMD(amd_ivf_coarse(gpu_, (size_t)n, x, (size_t)k, distances, i64(labels), coarse_mode));
+}
+
+// ------------------------------------------------------------------------------------- lists
+size_t ArrayInvertedLists::add_entries(size_t list_no, size_t n_entry, const idx_t* ids_in, const uint8_t* code) {
+    if (n_entry == 0) return 0;
+    FAISS_THROW_IF_NOT(list_no < nlist);
+    size_t o = ids[list_no].size();
+    ids[list_no].insert(ids[list_no].end(), ids_in, ids_in + n_entry);
+    codes[list_no].insert(codes[list_no].end(), code, code + n_entry * code_size);
+    version++;
+    return o;
+}
+
+void ArrayInvertedLists::resize(size_t list_no, size_t new_size) {
+    ids[list_no].resize(new_size);
+    codes[list_no].resize(new_size * code_size);
+    version++;
+}
+
+// ------------------------------------------------------------------------------------- error_pro / Trace
+float Trace::search(float k, float std_m) {
+    const size_t n = trace.size();
+    if (k <= trace[0].first) return trace[0].second + std_m * stds[0];
+    if (k >= trace[n - 1].first) return (trace[n - 1].second + std_m * stds[n - 1]) * (k / trace[n - 1].first);
+    size_t lo = 0, hi = n - 1;
+    while (lo <= hi) {
+        size_t mid = (lo + hi) / 2;
+        if (trace[mid].first < k) lo = mid + 1;
+        else hi = mid - 1;
+    }
+    if (trace[lo].first > k) lo--;
+    return trace[lo].second + std_m * stds[lo];
+}
+
+void Trace::SB() {
+    static_assert(sizeof(std::pair<float, float>) == 2 * sizeof(float), "pair layout");
+    const size_t n = trace.size();
+    std::vector<float> x(n / bs + 2), y(n / bs + 2), s(n / bs + 2);
+    size_t nb = 0;
+    AMD(amd_ivf_trace_sb(n ? &trace[0].first : nullptr, n, bs, x.data(), y.data(), s.data(), &nb));
+    trace.resize(nb);
+    stds.resize(nb);
+    for (size_t i = 0; i < nb; i++) {
+        trace[i] = std::make_pair(x[i], y[i]);
+        stds[i] = s[i];
+    }
+}
+
+void error_pro::construct_arcos() {
+    arcos_list.resize(arcos_size);
+    FAISS_THROW_IF_NOT(arcos_size == 500);
+    AMD(amd_ivf_arcos_table(arcos_list.data()));
+}
+
+float error_pro::arcos(float x) {
+    FAISS_THROW_IF_NOT_MSG((x <= 1. && x >= -1.), "arcos's domain definition is [-1, 1]");
+    int index = x * arcos_size / 2 + arcos_size / 2;
+    return arcos_list[index];
+}
+
+void error_pro::train(MetricType) {
+    size_t i = 0;
+    while ((size_t(1) << i) <= nlist / 8) {
+        std::cout << "SB() " << (1 << i) << std::endl;
+        traces[i].SB();
+        i++;
+    }
+    traces_version++;
+}
+
+void error_pro::setparam(int id_) {
+    // same file, same relative path as the reference (IVF_pro.cpp:240-256); silently keeps the
+    // defaults when the file is missing, as the reference does
+    std::ifstream in("../hyperparameter.txt");
+    for (int i = 0; i < 12; i++) {
+        float a, b;
+        if (!(in >> a >> b)) break;
+        if (i == id_ - 1) {
+            multipler = a;
+            std_m = b;
+        }
+    }
+    profile = false;
+}
+
+error_pro::~error_pro() {
+    delete[] train_ci;
+    delete[] train_cd;
+    delete[] my_nprobe;
+    delete[] KD;
+}
+
+// ------------------------------------------------------------------------------------- Level1Quantizer
+Level1Quantizer::Level1Quantizer(Index* quantizer, size_t nlist, bool t)
+    : quantizer(quantizer), nlist(nlist), quantizer_trains_alone(0), own_fields(false), clustering_index(nullptr) {
+    cp.niter = 25;
+    if (t) quantizer->tune = t;
+}
+
+Level1Quantizer::Level1Quantizer() : quantizer(nullptr), nlist(0), quantizer_trains_alone(0), own_fields(false), clustering_index(nullptr) {}
+
+Level1Quantizer::~Level1Quantizer() {
+    if (own_fields) delete quantizer;
+}
+
+namespace {
+
+// Lloyd iterations with GPU assignment (the engine's exact coarse kernel) and host means.  k-means is
+// outside the hot path; this is a plain stand-in for Clustering::train, not a
+// bit-for-bit restatement of it.
+std::vector<float> kmeans(size_t n, const float* x, size_t d, size_t k, const ClusteringParameters& cp, MetricType metric) {
+    FAISS_THROW_IF_NOT_MSG(n >= k, "need at least as many training points as clusters");
+    std::mt19937 rng(cp.seed);
+    std::vector<size_t> perm(n);
+    for (size_t i = 0; i < n; i++) perm[i] = i;
+    std::shuffle(perm.begin(), perm.end(), rng);
+    const size_t ns = std::min(n, (size_t)cp.max_points_per_centroid * k);
+    std::vector<float> xs(ns * d);
+    for (size_t i = 0; i < ns; i++) memcpy(&xs[i * d], x + perm[i] * d, d * sizeof(float));
+    std::vector<float> cen(xs.begin(), xs.begin() + k * d);
+    std::vector<long> assign(ns);
+    std::vector<double> sum(k * d);
+    std::vector<size_t> cnt(k);
+    for (int it = 0; it < cp.niter; it++) {
+        IndexFlat q(d, metric);
+        q.coarse_mode = 0;
+        q.add(k, cen.data());
+        q.assign(ns, xs.data(), assign.data());
+        std::fill(sum.begin(), sum.end(), 0.0);
+        std::fill(cnt.begin(), cnt.end(), 0);
+        for (size_t i = 0; i < ns; i++) {
+            cnt[assign[i]]++;
+            for (size_t c = 0; c < d; c++) sum[assign[i] * d + c] += xs[i * d + c];
+        }
+        for (size_t j = 0; j < k; j++) {
+            if (cnt[j] == 0) {  // re-seed an empty cluster from a random training point
+                size_t r = rng() % ns;
+                memcpy(&cen[j * d], &xs[r * d], d * sizeof(float));
+                continue;
+            }
+            for (size_t c = 0; c < d; c++) cen[j * d + c] = (float)(sum[j * d + c] / cnt[j]);
+            if (cp.spherical) {
+                double nr = 0;
+                for (size_t c = 0; c < d; c++) nr += (double)cen[j * d + c] * cen[j * d + c];
+                nr = std::sqrt(nr);
+                if (nr > 0)
+                    for (size_t c = 0; c < d; c++) cen[j * d + c] = (float)(cen[j * d + c] / nr);
+            }
+        }
+    }
+    return cen;
+}
+
+}  // namespace
+
+void Level1Quantizer::train_q1(size_t n, const float* x, bool verbose, MetricType metric_type) {
+    const size_t d = quantizer->d;
+    if (quantizer->is_trained && ((size_t)quantizer->ntotal == nlist)) {
+        if (verbose) printf("IVF quantizer does not need training.\n");
+        return;
+    }
+    FAISS_THROW_IF_NOT_MSG(quantizer_trains_alone == 0, "only k-means training of a flat quantizer is supported");
+    if (verbose) printf("Training level-1 quantizer on %ld vectors in %ldD\n", (long)n, (long)d);
+    quantizer->reset();
+    std::vector<float> cen = kmeans(n, x, d, nlist, cp, metric_type);
+    quantizer->add(nlist, cen.data());
+    if (quantizer->tune) {
+        // centroid-to-centroid table of the Auncel geometry (IndexIVF.cpp:97-111), computed on the GPU
+        amd_ivf* g = nullptr;
+        AMD(amd_ivf_create((int)d, nlist, (int)metric_type, device_id(), &g));
+        interdis_cem.resize(nlist * (nlist - 1) / 2);
+        int rc = amd_ivf_set_centroids(g, cen.data());
+        if (rc == 0) rc = amd_ivf_set_interdis(g, nullptr);
+        if (rc == 0) rc = amd_ivf_get_interdis(g, interdis_cem.data());
+        amd_ivf_destroy(g);
+        chk(rc, "interdis_cem");
+    }
+    quantizer->is_trained = true;
+}
+
+// ------------------------------------------------------------------------------------- IndexIVF
+IndexIVFStats indexIVF_stats;
+void IndexIVFStats::reset() { memset((void*)this, 0, sizeof(*this)); }
+
+IndexIVF::IndexIVF(Index* quantizer, size_t d, size_t nlist, size_t code_size, MetricType metric)
+    : Index(d, metric),
+      Level1Quantizer(quantizer, nlist),
+      invlists(new ArrayInvertedLists(nlist, code_size)),
+      own_invlists(true),
+      t(nullptr),
+      code_size(code_size),
+      nprobe(1),
+      max_codes(0),
+      parallel_mode(0),
+      maintain_direct_map(false) {
+    FAISS_THROW_IF_NOT(d == (size_t)quantizer->d);
+    is_trained = quantizer->is_trained && ((size_t)quantizer->ntotal == nlist);
+    if (metric_type == METRIC_INNER_PRODUCT) cp.spherical = true;
+    type = IVF;
+    tune = false;
+}
+
+IndexIVF::IndexIVF() : invlists(nullptr), own_invlists(false), t(nullptr), code_size(0), nprobe(1), max_codes(0), parallel_mode(0), maintain_direct_map(false) {
+    type = IVF;
+    tune = false;
+}
+
+IndexIVF::~IndexIVF() {
+    if (own_invlists) delete invlists;
+    if (gpu_) amd_ivf_destroy(gpu_);
+}
+
+void IndexIVF::set_tune_mode() {
+    tune = true;
+    quantizer->tune = true;
+}
+void IndexIVF::set_tune_off() {
+    tune = false;
+    quantizer->tune = false;
+}
+void IndexIVF::set_train_mode() {
+    training = true;
+    quantizer->tune = true;
+}
+void IndexIVF::set_train_off() {
+    training = false;
+    quantizer->tune = false;
+}
+
+void IndexIVF::init_tune(size_t train_num, size_t topk, const float* train_q, const float* train_D, const long* train_I,
+                         float* train_cd, long* train_ci) {
+    t = new error_pro;
+    t->construct_arcos();
+    for (size_t np = 1; np <= nlist / 8; np <<= 1) {
+        Trace tr;
+        tr.nprobe = np;
+        tr.trace.assign((topk / 4) * train_num, std::make_pair(-1.f, -1.f));
+        t->traces.push_back(tr);
+    }
+    t->m_type = metric_type == METRIC_INNER_PRODUCT ? error_pro::IP : error_pro::L2;
+    t->count = 0;
+    t->nlist = nlist;
+    t->max_topk = topk;
+    t->d = d;
+    t->interdis_cem = interdis_cem.data();
+    t->train_num = train_num;
+    t->train_q = train_q;
+    t->train_D = train_D;
+    t->train_I = train_I;
+    t->train_cd = train_cd;
+    t->train_ci = train_ci;
+}
+
+void IndexIVF::reset() {
+    direct_map.clear();
+    invlists->reset();
+    ntotal = 0;
+}
+
+void IndexIVF::train(idx_t n, const float* x) {
+    train_q1(n, x, verbose, metric_type);
+    is_trained = true;
+}
+
+void IndexIVF::add(idx_t n, const float* x) { add_with_ids(n, x, nullptr); }
+
+void IndexIVF::replace_invlists(InvertedLists* il, bool own) {
+    if (own_invlists) delete invlists;
+    invlists = il;
+    own_invlists = own;
+    lists_version_ = (size_t)-1;
+}
+
+amd_ivf* IndexIVF::engine() const {
+    sync_engine(false);
+    return gpu_;
+}
+
+void IndexIVF::sync_engine(bool need_tuner) const {
+    if (!gpu_) AMD(amd_ivf_create(d, nlist, (int)metric_type, device_id(), &gpu_));
+    const IndexFlat* qf = dynamic_cast<const IndexFlat*>(quantizer);
+    FAISS_THROW_IF_NOT_MSG(qf != nullptr, "the MI355X engine needs a flat coarse quantizer");
+    FAISS_THROW_IF_NOT_MSG((size_t)qf->ntotal == nlist, "quantizer is not trained (ntotal != nlist)");
+    if (centroid_count_ != nlist) {
+        AMD(amd_ivf_set_centroids(gpu_, qf->xb.data()));
+        centroid_count_ = nlist;
+    }
+    if (lists_version_ != invlists->version) {
+        FAISS_THROW_IF_NOT_MSG(code_size == sizeof(float) * d, "IVF-Flat codes expected");
+        std::vector<size_t> sizes(nlist);
+        std::vector<const float*> codes(nlist);
+        std::vector<const int64_t*> ids(nlist);
+        for (size_t l = 0; l < nlist; l++) {
+            sizes[l] = invlists->list_size(l);
+            codes[l] = reinterpret_cast<const float*>(invlists->get_codes(l));
+            ids[l] = i64(invlists->get_ids(l));
+        }
+        AMD(amd_ivf_set_lists(gpu_, sizes.data(), codes.data(), ids.data()));
+        lists_version_ = invlists->version;
+        resident_ptr_ = nullptr;  // nothing else to refresh, but keep the invariant explicit
+    }
+    if (!interdis_cem.empty() && (interdis_uploaded_ != interdis_cem.data() || interdis_size_ != interdis_cem.size())) {
+        AMD(amd_ivf_set_interdis(gpu_, interdis_cem.data()));
+        interdis_uploaded_ = interdis_cem.data();
+        interdis_size_ = interdis_cem.size();
+    }
+    if (need_tuner) {
+        FAISS_THROW_IF_NOT_MSG((t != nullptr), "Search tune start can't start without IVF_pro init and training");
+        FAISS_THROW_IF_NOT_MSG(!interdis_cem.empty(), "interdis_cem missing: train() the index in tune mode first");
+        if (traces_version_ != t->traces_version) {
+            const size_t nt = t->traces.size();
+            std::vector<size_t> len(nt);
+            std::vector<std::vector<float>> xs(nt), ys(nt);
+            std::vector<const float*> px(nt), py(nt), ps(nt);
+            for (size_t i = 0; i < nt; i++) {
+                const Trace& tr = t->traces[i];
+                FAISS_THROW_IF_NOT_MSG(tr.stds.size() == tr.trace.size(), "traces are not trained (call error_pro::train)");
+                len[i] = tr.trace.size();
+                xs[i].resize(len[i]);
+                ys[i].resize(len[i]);
+                for (size_t j = 0; j < len[i]; j++) {
+                    xs[i][j] = tr.trace[j].first;
+                    ys[i][j] = tr.trace[j].second;
+                }
+                px[i] = xs[i].data();
+                py[i] = ys[i].data();
+                ps[i] = tr.stds.data();
+            }
+            AMD(amd_ivf_set_tuner(gpu_, t->max_topk, nt, len.data(), px.data(), py.data(), ps.data(), t->arcos_list.data()));
+            traces_version_ = t->traces_version;
+        }
+    }
+}
+
+void IndexIVF::set_resident_queries(const float* x, size_t n) const {
+    sync_engine(false);
+    AMD(amd_ivf_set_queries(gpu_, n, x));
+    resident_ptr_ = x;
+    resident_n_ = n;
+}
+
+void IndexIVF::fold_stats() const {
+    size_t st[4];
+    amd_ivf_stats(gpu_, st, 1);
+    indexIVF_stats.nq += st[0];
+    indexIVF_stats.nlist += st[1];
+    indexIVF_stats.ndis += st[2];
+    indexIVF_stats.nheap_updates += st[3];
+}
+
+void IndexIVF::search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const {
+    if (tune || training) {
+        search(n, x, k, distances, labels, (size_t)0);
+        return;
+    }
+    sync_engine(false);
+    AMD(amd_ivf_search(gpu_, (size_t)n, x, (size_t)k, nprobe, -1, distances, i64(labels)));
+    fold_stats();
+}
+
+void IndexIVF::search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels, size_t offset) const {
+    if (!tune && !training) {
+        sync_engine(false);
+        AMD(amd_ivf_search(gpu_, (size_t)n, x, (size_t)k, nprobe, -1, distances, i64(labels)));
+        fold_stats();
+        return;
+    }
+    FAISS_THROW_IF_NOT_MSG((t != nullptr), "Search tune start can't start without IVF_pro init and training");
+    FAISS_THROW_IF_NOT_MSG(nprobe == nlist, "tune / train mode probes in full coarse order: set nprobe = nlist (profile.cpp:220)");
+    FAISS_THROW_IF_NOT_MSG((size_t)k == t->max_topk, "tune / train mode needs k == max_topk (IndexIVF.cpp:560-561)");
+    // queries that are rows [offset, offset+n) of the registered matrix are already in HBM
+    bool resident = resident_ptr_ && x == resident_ptr_ + offset * (size_t)d && offset + n <= resident_n_;
+    if (training) {
+        sync_engine(false);
+        std::vector<float*> raw(t->traces.size());
+        for (size_t i = 0; i < raw.size(); i++) raw[i] = &t->traces[i].trace[0].first;
+        if (resident)
+            AMD(amd_ivf_train_samples(gpu_, offset, (size_t)n, (size_t)k, t->train_D, t->train_num, -1, raw.data(), distances, i64(labels)));
+        else
+            AMD(amd_ivf_train_samples_x(gpu_, (size_t)n, x, offset, (size_t)k, t->train_D, t->train_num, -1, raw.data(), distances, i64(labels)));
+        return;
+    }
+    sync_engine(true);
+    static_assert(sizeof(size_t) == sizeof(uint64_t), "my_nprobe layout");
+    uint64_t* np = reinterpret_cast<uint64_t*>(t->my_nprobe);
+    if (resident)
+        AMD(amd_ivf_search_adaptive(gpu_, offset, (size_t)n, t->query_topk, t->multipler, t->std_m, t->require_acc, t->train_D,
+                                    t->profile ? 1 : 0, -1, np, t->t_recalls, distances, i64(labels)));
+    else
+        AMD(amd_ivf_search_adaptive_x(gpu_, (size_t)n, x, offset, t->query_topk, t->multipler, t->std_m, t->require_acc, t->train_D,
+                                      t->profile ? 1 : 0, -1, np, t->t_recalls, distances, i64(labels)));
+    fold_stats();
+}
+
+void IndexIVF::search_preassigned(idx_t n, const float* x, idx_t k, const idx_t* keys, const float* coarse_dis,
+                                  float* distances, idx_t* labels, bool store_pairs, const IVFSearchParameters* params) const {
+    const idx_t offset = (k >> 32) & 0xffffffff;  // the reference packs the query offset into k (IndexIVF.cpp:389-392)
+    k = k & 0xffffffff;
+    (void)offset;
+    FAISS_THROW_IF_NOT_MSG(!tune && !training,
+                           "tune / train mode runs through IndexIVF::search(n, x, k, D, I, offset): the engine ranks the "
+                           "centroids itself");
+    const size_t np = params ? params->nprobe : nprobe;
+    const size_t mc = params ? params->max_codes : max_codes;
+    sync_engine(false);
+    AMD(amd_ivf_search_preassigned(gpu_, (size_t)n, x, (size_t)k, np, i64(keys), coarse_dis, distances, i64(labels),
+                                   store_pairs ? 1 : 0, mc));
+    fold_stats();
+}
+
+struct EngineScanner : InvertedListScanner {
+    const IndexIVF* ix;
+    bool store_pairs;
+    std::vector<float> q;
+    idx_t list_no = -1;
+    EngineScanner(const IndexIVF* ix, bool sp) : ix(ix), store_pairs(sp) {}
+    void set_query(const float* query) override { q.assign(query, query + ix->d); }
+    void set_list(idx_t l, float) override { list_no = l; }
+    float distance_to_code(const uint8_t* code) const override {
+        FAISS_THROW_IF_NOT_MSG(list_no >= 0, "set_list first");
+        const uint8_t* base = ix->invlists->get_codes(list_no);
+        const size_t n = ix->invlists->list_size(list_no);
+        FAISS_THROW_IF_NOT_MSG(code >= base && code < base + n * ix->code_size, "code must point into the current list");
+        float dis = 0;
+        ix->sync_engine(false);
+        AMD(amd_ivf_distance_to_code(ix->gpu_, q.data(), (size_t)list_no, (size_t)(code - base) / ix->code_size, &dis));
+        return dis;
+    }
+    size_t scan_codes(size_t n, const uint8_t* codes, const idx_t*, float* simi, idx_t* idxi, size_t k) const override {
+        FAISS_THROW_IF_NOT_MSG(list_no >= 0, "set_list first");
+        FAISS_THROW_IF_NOT_MSG(codes == ix->invlists->get_codes(list_no) && n == ix->invlists->list_size(list_no),
+                               "scan_codes scans the list named by set_list (its codes live in HBM)");
+        size_t nup = 0;
+        ix->sync_engine(false);
+        AMD(amd_ivf_scan_codes(ix->gpu_, q.data(), (size_t)list_no, store_pairs ? 1 : 0, k, simi, i64(idxi), &nup));
+        return nup;
+    }
+};
+
+InvertedListScanner* IndexIVF::get_InvertedListScanner(bool store_pairs) const { return new EngineScanner(this, store_pairs); }
+
+// ------------------------------------------------------------------------------------- IndexIVFFlat
+IndexIVFFlat::IndexIVFFlat(Index* quantizer, size_t d, size_t nlist, MetricType metric)
+    : IndexIVF(quantizer, d, nlist, sizeof(float) * d, metric) {
+    code_size = sizeof(float) * d;
+}
+
+void IndexIVFFlat::add_with_ids(idx_t n, const float* x, const long* xids) { add_core(n, x, xids, nullptr); }
+
+void IndexIVFFlat::add_core(idx_t n, const float* x, const long* xids, const long* precomputed_idx) {
+    FAISS_THROW_IF_NOT(is_trained);
+    FAISS_THROW_IF_NOT_MSG(!(maintain_direct_map && xids), "cannot have direct map and add with ids");
+    std::vector<long> own;
+    const long* idx = precomputed_idx;
+    if (!idx) {
+        own.resize(n);
+        quantizer->assign(n, x, own.data());
+        idx = own.data();
+    }
+    long n_add = 0;
+    for (idx_t i = 0; i < n; i++) {
+        long id = xids ? xids[i] : ntotal + i;
+        long list_no = idx[i];
+        if (list_no < 0) continue;
+        size_t o = invlists->add_entry(list_no, id, reinterpret_cast<const uint8_t*>(x + i * d));
+        if (maintain_direct_map) direct_map.push_back(list_no << 32 | (long)o);
+        n_add++;
+    }
+    if (verbose) printf("IndexIVFFlat::add_core: added %ld / %ld vectors\n", n_add, (long)n);
+    ntotal += n;
+}
+
+// ------------------------------------------------------------------------------------- Error_sys
+Error_sys::Error_sys(Index* in, size_t nq, size_t topk) : train_num(nq), max_topk(topk) {
+    FAISS_THROW_IF_NOT_MSG(nq % 10 == 0, "Train num must be evenly divided by ten");
+    key = "Base";
+    if (IndexIVF* ix = dynamic_cast<IndexIVF*>(in)) {
+        index = ix;
+        key = "IVF";
+        ix->t = nullptr;
+    }
+}
+
+Error_sys::Error_sys() {}
+
+void Error_sys::set_gt(const float* gt_D_in, const Index::idx_t* gt_I_in) {
+    FAISS_THROW_IF_NOT_MSG((gt_D_in != nullptr && gt_I_in != nullptr), "the ground truth must not be null ptr when setting up");
+    train_D.assign(gt_D_in, gt_D_in + train_num * max_topk);
+    train_I.assign(gt_I_in, gt_I_in + train_num * max_topk);
+}
+
+float Error_sys::recall(Index::idx_t* I, Index::idx_t* gtI, size_t topk) {
+    // sorts the caller's id row in place, like the reference (profile.cpp:246-280)
+    std::sort(I, I + topk);
+    size_t m = std::unique(I, I + topk) - I;
+    size_t count = 0;
+    std::vector<char> seen(m, 0);
+    for (size_t i = 0; i < m; i++) {
+        Index::idx_t* p = std::lower_bound(I, I + m, gtI[i]);
+        if (p != I + m && *p == gtI[i] && !seen[p - I]) {
+            seen[p - I] = 1;
+            count++;
+        }
+    }
+    return float(count) / m;
+}
+
+void Error_sys::set_train_point(float* D, Index::idx_t* I, size_t key_v, size_t nq) {
+    FAISS_THROW_IF_NOT_MSG((index && index->t != nullptr), "your must init tune for index first");
+    FAISS_THROW_IF_NOT_MSG((train_I.size() == train_num * max_topk), "ground truth not initialized");
+    TrainPoint tp;
+    tp.key = "nprobe";
+    tp.key_value = key_v;
+    tp.topk_dis.assign(D, D + nq * max_topk);
+    tp.topk_id.assign(I, I + nq * max_topk);
+    tp.acc.resize(nq);
+    for (size_t i = 0; i < nq; i++) tp.acc[i] = recall(I + i * max_topk, train_I.data() + i * max_topk, max_topk);
+    index->t->tps.push_back(tp);
+}
+
+void Error_sys::sys_train(size_t nq, const float* xq) {
+    FAISS_THROW_IF_NOT_MSG(nq <= train_num, "Error sys training does not have the same nb of queries compared with creation");
+    FAISS_THROW_IF_NOT_MSG((train_I.size() == train_num * max_topk), "ground truth not initialized");
+    if (!index) return;
+    IndexIVF* ix = index;
+    ix->init_tune(nq, max_topk, xq, train_D.data(), train_I.data(), nullptr, nullptr);
+    std::cout << "Init IVF done" << std::endl;
+    ix->set_train_mode();
+    ix->nprobe = ix->nlist;
+    ix->set_resident_queries(xq, nq);
+    std::vector<float> D(nq * max_topk);
+    std::vector<Index::idx_t> I(nq * max_topk);
+    const size_t bs = nq / 10;
+    for (size_t q0 = 0; q0 < nq; q0 += bs) {
+        size_t q1 = std::min(nq, q0 + bs);
+        ix->search(q1 - q0, xq + q0 * ix->d, max_topk, D.data() + q0 * max_topk, I.data() + q0 * max_topk, q0);
+    }
+    set_train_point(D.data(), I.data(), ix->nlist, nq);
+    ix->set_train_off();
+    is_trained = true;
+    std::cout << "Start t traing" << std::endl;
+    ix->t->train(METRIC_L2);
+    std::cout << "End t traing" << std::endl;
+    for (size_t ij = 0; ij < std::min<size_t>(8, ix->t->traces.size()); ij++) {  // profile.cpp:158-169
+        std::stringstream ss;
+        ss << "Validation_" << ix->d << "_" << (1 << ij) << ".log";
+        std::ofstream out(ss.str());
+        for (auto& p : ix->t->traces[ij].trace) out << p.first << " " << p.second << std::endl;
+    }
+}
+
+void Error_sys::set_queries(size_t n, const float* q, const float* acc, size_t allo_size) {
+    num = n;
+    queries = q;
+    require_acc = acc;
+    if (!index) return;
+    error_pro* t = index->t;
+    FAISS_THROW_IF_NOT_MSG((t != nullptr), "your must init tune for index first");
+    t->alloc_s = allo_size;
+    delete[] t->my_nprobe;
+    t->my_nprobe = new size_t[allo_size]();
+    size_t ind = 0;
+    for (size_t np = 1; np <= index->nlist / 8; np <<= 1) ind++;
+    delete[] t->KD;
+    t->KD = new float[allo_size * ind]();
+    delete[] t->t_recalls;
+    t->t_recalls = new float[allo_size]();
+    t->require_acc = acc;
+    // every reference harness passes the whole query matrix (allo_size rows, the online ones last):
+    // keep it resident in HBM so that search() only moves results
+    index->set_resident_queries(q, allo_size);
+}
+
+void Error_sys::set_topk(size_t new_topk) {
+    if (index) index->t->query_topk = new_topk;
+}
+
+void Error_sys::search(float* D, int64_t* I, size_t start, size_t search_size) {
+    FAISS_THROW_IF_NOT_MSG(is_trained == true, "Error sys must be trained before searching");
+    FAISS_THROW_IF_NOT_MSG(num <= train_num, "Error sys search num must be lower than all qeuries num");
+    if (!index) return;
+    index->set_tune_mode();
+    index->nprobe = index->nlist;
+    const size_t n = search_size == (size_t)-1 ? num : search_size;
+    index->search(n, queries + start * index->d, max_topk, D, reinterpret_cast<Index::idx_t*>(I), start);
+    index->set_tune_off();
+}
+
+// ------------------------------------------------------------------------------------- IndexShards
+IndexShards::IndexShards(idx_t d, bool threaded, bool successive_ids) : Index(d), threaded(threaded), successive_ids(successive_ids) {}
+
+void IndexShards::add_shard(Index* index) {
+    if (shards.empty()) {
+        d = index->d;
+        metric_type = index->metric_type;
+    }
+    FAISS_THROW_IF_NOT_MSG(index->d == d && index->metric_type == metric_type, "shards must agree on d and metric");
+    shards.push_back(index);
+    ntotal += index->ntotal;
+    is_trained = index->is_trained;
+}
+
+void IndexShards::train(idx_t n, const float* x) {
+    for (Index* s : shards) s->train(n, x);
+    is_trained = true;
+}
+
+void IndexShards::reset() {
+    for (Index* s : shards) s->reset();
+    ntotal = 0;
+}
+
+void IndexShards::add(idx_t n, const float* x) {
+    // contiguous n/nshard slices, as the reference does without ids (tests/test_threaded_index.cpp:205-253)
+    const idx_t ns = count();
+    FAISS_THROW_IF_NOT(ns > 0);
+    for (idx_t i = 0; i < ns; i++) {
+        idx_t i0 = i * n / ns, i1 = (i + 1) * n / ns;
+        if (successive_ids) {
+            shards[i]->add(i1 - i0, x + i0 * d);
+        } else {
+            std::vector<long> ids(i1 - i0);
+            for (idx_t j = i0; j < i1; j++) ids[j - i0] = ntotal + j;
+            shards[i]->add_with_ids(i1 - i0, x + i0 * d, ids.data());
+        }
+    }
+    ntotal += n;
+}
+
+void IndexShards::search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const {
+    const size_t ns = shards.size();
+    std::vector<float> all_D(ns * n * k);
+    std::vector<int64_t> all_I(ns * n * k);
+    // one engine (one GPU) per shard: the calls are independent and overlap on their own streams
+    for (size_t s = 0; s < ns; s++) shards[s]->search(n, x, k, all_D.data() + s * n * k, reinterpret_cast<idx_t*>(all_I.data()) + s * n * k);
+    if (successive_ids) {
+        long base = 0;
+        for (size_t s = 0; s < ns; s++) {
+            if (s)
+                for (size_t i = 0; i < (size_t)(n * k); i++)
+                    if (all_I[s * n * k + i] >= 0) all_I[s * n * k + i] += base;
+            base += shards[s]->ntotal;
+        }
+    }
+    AMD(amd_ivf_merge_tables((int)metric_type, (size_t)n, (size_t)k, ns, all_D.data(), all_I.data(), distances, i64(labels)));
+}
+
+// ------------------------------------------------------------------------------------- factory
+Index* index_factory(int d, const char* description, MetricType metric) {
+    std::string s(description);
+    if (s == "Flat") return new IndexFlat(d, metric);
+    int nlist = 0;
+    char tail[32] = {0};
+    if (sscanf(description, "IVF%d,%31s", &nlist, tail) == 2 && std::string(tail) == "Flat" && nlist > 0) {
+        IndexFlat* q = new IndexFlat(d, metric);
+        IndexIVFFlat* ix = new IndexIVFFlat(q, d, nlist, metric);
+        ix->own_fields = true;
+        return ix;
+    }
+    FAISS_THROW_FMT("index_factory: only \"Flat\" and \"IVF<n>,Flat\" are built on this path, got \"%s\"", description);
+}
+
+}  // namespace faiss

@@ -1155,15 +1155,13 @@ int amd_ivf_set_tuner(amd_ivf_t* h, size_t max_topk, size_t ntraces, const size_
     API_END
 }
 
-int amd_ivf_search_adaptive(amd_ivf_t* h, size_t start, size_t n, size_t query_topk, float multipler, float std_m,
+static void adaptive_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n, size_t query_topk, float multipler, float std_m,
                             const float* require_acc, const float* gt_D, int profile, int coarse_mode,
                             uint64_t* my_nprobe, float* t_recalls, float* D, int64_t* I) {
-    API_BEGIN
     use_device(h);
     if (!h->have_tuner || !h->have_interdis)
         throw EngineError("Search tune start can't start without IVF_pro init and training");
-    if (start + n > h->n_resident) throw EngineError("resident query range out of bounds");
-    if (n == 0) return 0;
+    if (n == 0) return;
     const size_t K = h->tuner_max_topk, nlist = h->nlist;
     if (nlist <= nlist / 8 + 20) throw EngineError("tune mode needs nprobe(=nlist) > nlist/8 + 20");
     size_t ntr = 0;
@@ -1186,7 +1184,6 @@ int amd_ivf_search_adaptive(amd_ivf_t* h, size_t start, size_t n, size_t query_t
     if (gt_D) HIP_CHECK(hipMemcpyAsync(dgt, gt_D, nabs * K * 4, hipMemcpyHostToDevice, h->stream));
     HIP_CHECK(hipMemcpyAsync(d_np.p, my_nprobe, nabs * 8, hipMemcpyHostToDevice, h->stream));
     // full coarse ranking (Error_sys::search sets nprobe = nlist, profile.cpp:220)
-    const float* d_x = h->d_resident.as<float>() + start * h->dpad;
     h->w_cdis.ensure(n * nlist * 4);
     h->w_ckeys.ensure(n * nlist * 8);
     coarse_dev(h, d_x, n, nlist, coarse_mode, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>());
@@ -1207,16 +1204,37 @@ int amd_ivf_search_adaptive(amd_ivf_t* h, size_t start, size_t n, size_t query_t
     HIP_CHECK(hipStreamSynchronize(h->stream));
     fold_stats(h, n);
     finish_timing(h, wc.stop());
+}
+
+int amd_ivf_search_adaptive(amd_ivf_t* h, size_t start, size_t n, size_t query_topk, float multipler, float std_m,
+                            const float* require_acc, const float* gt_D, int profile, int coarse_mode,
+                            uint64_t* my_nprobe, float* t_recalls, float* D, int64_t* I) {
+    API_BEGIN
+    use_device(h);
+    if (start + n > h->n_resident) throw EngineError("resident query range out of bounds");
+    adaptive_core(h, h->d_resident.as<float>() + start * h->dpad, start, n, query_topk, multipler, std_m, require_acc, gt_D,
+                  profile, coarse_mode, my_nprobe, t_recalls, D, I);
     API_END
 }
 
-int amd_ivf_train_samples(amd_ivf_t* h, size_t start, size_t n, size_t max_topk, const float* gt_D, size_t train_num,
-                          int coarse_mode, float* const* raw, float* D, int64_t* I) {
+int amd_ivf_search_adaptive_x(amd_ivf_t* h, size_t n, const float* x, size_t id_offset, size_t query_topk, float multipler,
+                              float std_m, const float* require_acc, const float* gt_D, int profile, int coarse_mode,
+                              uint64_t* my_nprobe, float* t_recalls, float* D, int64_t* I) {
     API_BEGIN
     use_device(h);
-    if (!h->have_interdis) throw EngineError("Search tune start can't start without IVF_pro init and training");
-    if (start + n > h->n_resident) throw EngineError("resident query range out of bounds");
     if (n == 0) return 0;
+    h->w_x.ensure(n * h->dpad * sizeof(float));
+    upload_rows(h, h->w_x.as<float>(), x, n);
+    adaptive_core(h, h->w_x.as<float>(), id_offset, n, query_topk, multipler, std_m, require_acc, gt_D, profile, coarse_mode,
+                  my_nprobe, t_recalls, D, I);
+    API_END
+}
+
+static void train_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n, size_t max_topk, const float* gt_D, size_t train_num,
+                          int coarse_mode, float* const* raw, float* D, int64_t* I) {
+    use_device(h);
+    if (!h->have_interdis) throw EngineError("Search tune start can't start without IVF_pro init and training");
+    if (n == 0) return;
     const size_t K = max_topk, nlist = h->nlist;
     if (nlist <= nlist / 8 + 20) throw EngineError("train mode needs nprobe(=nlist) > nlist/8 + 20");
     size_t ntr = 0;
@@ -1242,7 +1260,6 @@ int amd_ivf_train_samples(amd_ivf_t* h, size_t start, size_t n, size_t max_topk,
         h->d_arcos.ensure(500 * 4);
         HIP_CHECK(hipMemcpy(h->d_arcos.p, lut.data(), 500 * 4, hipMemcpyHostToDevice));
     }
-    const float* d_x = h->d_resident.as<float>() + start * h->dpad;
     h->w_cdis.ensure(n * nlist * 4);
     h->w_ckeys.ensure(n * nlist * 8);
     coarse_dev(h, d_x, n, nlist, coarse_mode, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>());
@@ -1268,6 +1285,25 @@ int amd_ivf_train_samples(amd_ivf_t* h, size_t start, size_t n, size_t max_topk,
     HIP_CHECK(hipStreamSynchronize(h->stream));
     double ms[NCAT], ln[NCAT];
     h->timer.collect(ms, NCAT, ln);
+}
+
+int amd_ivf_train_samples(amd_ivf_t* h, size_t start, size_t n, size_t max_topk, const float* gt_D, size_t train_num,
+                          int coarse_mode, float* const* raw, float* D, int64_t* I) {
+    API_BEGIN
+    use_device(h);
+    if (start + n > h->n_resident) throw EngineError("resident query range out of bounds");
+    train_core(h, h->d_resident.as<float>() + start * h->dpad, start, n, max_topk, gt_D, train_num, coarse_mode, raw, D, I);
+    API_END
+}
+
+int amd_ivf_train_samples_x(amd_ivf_t* h, size_t n, const float* x, size_t id_offset, size_t max_topk, const float* gt_D,
+                            size_t train_num, int coarse_mode, float* const* raw, float* D, int64_t* I) {
+    API_BEGIN
+    use_device(h);
+    if (n == 0) return 0;
+    h->w_x.ensure(n * h->dpad * sizeof(float));
+    upload_rows(h, h->w_x.as<float>(), x, n);
+    train_core(h, h->w_x.as<float>(), id_offset, n, max_topk, gt_D, train_num, coarse_mode, raw, D, I);
     API_END
 }
 

@@ -115,11 +115,20 @@ int amd_ivf_search_adaptive(amd_ivf_t* h, size_t start, size_t n, size_t query_t
                             const float* require_acc, const float* gt_D, int profile, int coarse_mode,
                             uint64_t* my_nprobe, float* t_recalls, float* D, int64_t* I);
 
+/* same, for queries passed by (host) pointer: IndexIVF::search(n, x, k, D, I, offset) with tune on
+ * [IndexIVF.cpp:355-378]; arrays are indexed by id_offset + i */
+int amd_ivf_search_adaptive_x(amd_ivf_t* h, size_t n, const float* x, size_t id_offset, size_t query_topk, float multipler,
+                              float std_m, const float* require_acc, const float* gt_D, int profile, int coarse_mode,
+                              uint64_t* my_nprobe, float* t_recalls, float* D, int64_t* I);
+
 /* search_preassigned, training branch, driven as Error_sys::sys_train does: raw (sum_angle, kscaling)
  * samples for stages 1,2,4..nlist/8 of resident queries [start, start+n); raw[i] has
  * train_num*(max_topk/4) (x,y) pairs and must be pre-filled with (-1,-1)  [IndexIVF.cpp:640-673, profile.cpp:88-156] */
 int amd_ivf_train_samples(amd_ivf_t* h, size_t start, size_t n, size_t max_topk, const float* gt_D, size_t train_num,
                           int coarse_mode, float* const* raw, float* D, int64_t* I);
+
+int amd_ivf_train_samples_x(amd_ivf_t* h, size_t n, const float* x, size_t id_offset, size_t max_topk, const float* gt_D,
+                            size_t train_num, int coarse_mode, float* const* raw, float* D, int64_t* I);
 
 /* error_pro::construct_arcos: the 500-entry acos LUT, computed with the host libm exactly as the
  * reference does (LUT[i] = acosf((i-250)/250.f))  [IVF_pro.cpp:151-160] */

@@ -1,0 +1,204 @@
+// Test driver for the host-side C++ mirror (auncel_amd/csrc/host): runs the flows of the reference's
+// own callers -- tests/test_lowlevel_ivf.cpp (scanner API vs search), IndexShards, and eval/bound.cpp
+// (Error_sys train -> set_queries -> one search() per query) -- on a bundle prepared by
+// tests/test_host_mirror.py and compares with the expected tensors stored in it.
+// usage: host_mirror_driver <fixed|auncel> <bundle.tb>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+
+#include "../../auncel_amd/csrc/host/AutoTune.h"
+#include "../../auncel_amd/csrc/host/FaissException.h"
+#include "../../auncel_amd/csrc/host/Heap.h"
+#include "../../auncel_amd/csrc/host/IndexFlat.h"
+#include "../../auncel_amd/csrc/host/IndexIVFFlat.h"
+#include "../../auncel_amd/csrc/host/IndexShards.h"
+#include "../../auncel_amd/csrc/host/profile.h"
+#include "../../oracle/tbundle.h"
+
+using namespace faiss;
+typedef Index::idx_t idx_t;
+
+static int g_fail = 0;
+static void expect(bool ok, const std::string& what) {
+    if (!ok) {
+        printf("MISMATCH: %s\n", what.c_str());
+        g_fail++;
+    }
+}
+static bool same_f(const float* a, const float* b, size_t n) { return memcmp(a, b, n * 4) == 0; }
+static bool same_i(const idx_t* a, const int64_t* b, size_t n) { return memcmp(a, b, n * 8) == 0; }
+
+static int run_fixed(const tb::Bundle& in) {
+    size_t d = in.scalar<size_t>("d"), nlist = in.scalar<size_t>("nlist"), nprobe = in.scalar<size_t>("nprobe");
+    MetricType mt = in.scalar<int>("metric") == 0 ? METRIC_INNER_PRODUCT : METRIC_L2;
+    const tb::Tensor &cen = in.get("centroids"), &xb = in.get("xb"), &xq = in.get("xq"), &ks = in.get("ks");
+    size_t nb = xb.dims[0], nq = xq.dims[0];
+
+    std::unique_ptr<Index> index(index_factory((int)d, ("IVF" + std::to_string(nlist) + ",Flat").c_str(), mt));
+    IndexIVF* ix = dynamic_cast<IndexIVF*>(index.get());
+    expect(ix != nullptr && index->type == IVF, "index_factory type");
+    ix->quantizer->add(nlist, cen.as<float>());
+    ix->is_trained = true;
+    dynamic_cast<IndexFlat*>(ix->quantizer)->coarse_mode = 0;  // expectations come from the exact coarse path
+    index->add(nb / 3, xb.as<float>());
+    index->add(nb - nb / 3, xb.as<float>() + (nb / 3) * d);
+    expect((size_t)index->ntotal == nb, "ntotal");
+    const int64_t* ls = in.get("list_sizes").as<int64_t>();
+    bool sizes_ok = true;
+    for (size_t l = 0; l < nlist; l++) sizes_ok &= ix->invlists->list_size(l) == (size_t)ls[l];
+    expect(sizes_ok, "list sizes after add");
+    ix->nprobe = nprobe;
+
+    for (size_t ki = 0; ki < ks.numel(); ki++) {
+        size_t k = ks.as<int64_t>()[ki];
+        std::string suf = "_k" + std::to_string(k);
+        std::vector<float> D(nq * k);
+        std::vector<idx_t> I(nq * k);
+        indexIVF_stats.reset();
+        index->search(nq, xq.as<float>(), k, D.data(), I.data());
+        expect(same_i(I.data(), in.get("I" + suf).as<int64_t>(), nq * k), "search ids" + suf);
+        expect(same_f(D.data(), in.get("D" + suf).as<float>(), nq * k), "search distances" + suf);
+        const int64_t* st = in.get("stats" + suf).as<int64_t>();
+        expect(indexIVF_stats.nq == nq && indexIVF_stats.nlist == (size_t)st[0] && indexIVF_stats.ndis == (size_t)st[1] &&
+                   indexIVF_stats.nheap_updates == (size_t)st[2], "indexIVF_stats" + suf);
+        // search_preassigned with the quantizer's own output, store_pairs
+        std::vector<float> cd(nq * nprobe);
+        std::vector<idx_t> ck(nq * nprobe);
+        ix->quantizer->search(nq, xq.as<float>(), nprobe, cd.data(), ck.data());
+        ix->search_preassigned(nq, xq.as<float>(), k, ck.data(), cd.data(), D.data(), I.data(), true);
+        expect(same_i(I.data(), in.get("I" + suf + "_pairs").as<int64_t>(), nq * k), "store_pairs ids" + suf);
+
+        // tests/test_lowlevel_ivf.cpp:82-220: manual quantizer->search + scanner == index->search
+        std::unique_ptr<InvertedListScanner> sc(ix->get_InvertedListScanner());
+        const int64_t* Iref = in.get("I" + suf).as<int64_t>();
+        for (size_t i = 0; i < std::min<size_t>(nq, 4); i++) {
+            std::vector<float> simi(k);
+            std::vector<idx_t> idxi(k);
+            if (mt == METRIC_L2) maxheap_heapify(k, simi.data(), idxi.data()); else minheap_heapify(k, simi.data(), idxi.data());
+            sc->set_query(xq.as<float>() + i * d);
+            for (size_t p = 0; p < nprobe; p++) {
+                idx_t key = ck[i * nprobe + p];
+                if (key < 0 || ix->invlists->list_size(key) == 0) continue;
+                sc->set_list(key, cd[i * nprobe + p]);
+                InvertedLists::ScopedCodes codes(ix->invlists, key);
+                InvertedLists::ScopedIds ids(ix->invlists, key);
+                sc->scan_codes(ix->invlists->list_size(key), codes.get(), ids.get(), simi.data(), idxi.data(), k);
+            }
+            if (mt == METRIC_L2) maxheap_reorder(k, simi.data(), idxi.data()); else minheap_reorder(k, simi.data(), idxi.data());
+            expect(same_i(idxi.data(), Iref + i * k, k), "scanner ids == search ids, query " + std::to_string(i));
+        }
+    }
+
+    size_t nshard = in.scalar_or<size_t>("nshard", 0);
+    if (nshard) {
+        std::vector<idx_t> a(nb), gid(nb);
+        ix->quantizer->assign(nb, xb.as<float>(), a.data());
+        for (size_t i = 0; i < nb; i++) gid[i] = i;
+        std::vector<std::unique_ptr<IndexIVFFlat>> subs;
+        IndexShards shards((idx_t)d, false, false);
+        for (size_t s = 0; s < nshard; s++) {
+            std::unique_ptr<IndexIVFFlat> sub(new IndexIVFFlat(ix->quantizer, d, nlist, mt));
+            std::vector<idx_t> pa(a);
+            for (size_t i = 0; i < nb; i++) if ((size_t)pa[i] % nshard != s) pa[i] = -1;
+            sub->add_core(nb, xb.as<float>(), gid.data(), pa.data());
+            sub->nprobe = nprobe;
+            shards.add_shard(sub.get());
+            subs.push_back(std::move(sub));
+        }
+        for (size_t ki = 0; ki < ks.numel(); ki++) {
+            size_t k = ks.as<int64_t>()[ki];
+            std::vector<float> D(nq * k);
+            std::vector<idx_t> I(nq * k);
+            shards.search(nq, xq.as<float>(), k, D.data(), I.data());
+            expect(same_i(I.data(), in.get("I_shards_k" + std::to_string(k)).as<int64_t>(), nq * k), "shards ids");
+            expect(same_f(D.data(), in.get("D_shards_k" + std::to_string(k)).as<float>(), nq * k), "shards distances");
+        }
+    }
+    return g_fail;
+}
+
+static int run_auncel(const tb::Bundle& in) {
+    size_t d = in.scalar<size_t>("d"), nlist = in.scalar<size_t>("nlist");
+    size_t K = in.scalar<size_t>("max_topk"), ts = in.scalar<size_t>("train_num"), ses = in.scalar<size_t>("test_num");
+    const tb::Tensor &xb = in.get("xb"), &xq = in.get("xq"), &cen = in.get("centroids");
+    size_t nb = xb.dims[0], nq = ts + ses;
+
+    IndexFlatL2 quantizer(d);
+    quantizer.add(nlist, cen.as<float>());
+    quantizer.coarse_mode = 0;
+    IndexIVFFlat index(&quantizer, d, nlist, METRIC_L2);
+    // train_q1's table for these centroids (the k-means itself is out of scope: centroids come from the fixture)
+    index.interdis_cem.assign(in.get("interdis_cem").as<float>(), in.get("interdis_cem").as<float>() + nlist * (nlist - 1) / 2);
+    index.add(nb, xb.as<float>());
+
+    // ---- eval/bound.cpp:356-396
+    Error_sys err_sys(&index, nq, K);
+    err_sys.set_gt(in.get("gtD").as<float>(), reinterpret_cast<const idx_t*>(in.get("gtI").as<int64_t>()));
+    err_sys.sys_train(ts, xq.as<float>());
+    size_t ntr = index.t->traces.size();
+    for (size_t i = 0; i < ntr; i++) {
+        const tb::Tensor& e = in.get("exp_sb_trace" + std::to_string(i));
+        const Trace& tr = index.t->traces[i];
+        bool ok = tr.trace.size() == e.dims[0] && memcmp(&tr.trace[0].first, e.as<float>(), e.dims[0] * 8) == 0 &&
+                  memcmp(tr.stds.data(), in.get("exp_sb_stds" + std::to_string(i)).as<float>(), e.dims[0] * 4) == 0;
+        expect(ok, "sys_train trace " + std::to_string(i));
+    }
+    // continue with the reference's own trained traces so that the online goldens apply
+    for (size_t i = 0; i < ntr; i++) {
+        const tb::Tensor& g = in.get("sb_trace" + std::to_string(i));
+        Trace& tr = index.t->traces[i];
+        tr.trace.resize(g.dims[0]);
+        memcpy(&tr.trace[0].first, g.as<float>(), g.dims[0] * 8);
+        tr.stds.assign(in.get("sb_stds" + std::to_string(i)).as<float>(), in.get("sb_stds" + std::to_string(i)).as<float>() + g.dims[0]);
+    }
+    index.t->traces_version++;
+
+    const tb::Tensor &topks = in.get("topks"), &accs = in.get("require_acc"), &mults = in.get("multipler"), &stdms = in.get("std_m");
+    for (size_t r = 0; r < topks.numel(); r++) {
+        for (int batched = 0; batched < 2; batched++) {
+            std::vector<float> acc(nq, accs.as<float>()[r]);
+            err_sys.set_topk(topks.as<int64_t>()[r]);
+            err_sys.set_queries(ses, xq.as<float>(), acc.data(), ts + ses);
+            index.t->multipler = mults.as<float>()[r];
+            index.t->std_m = stdms.as<float>()[r];
+            index.t->profile = false;
+            std::vector<float> D(ses * K);
+            std::vector<int64_t> I(ses * K);
+            if (!batched)
+                for (size_t i = ts; i < ts + ses; i++) err_sys.search(D.data() + K * (i - ts), I.data() + K * (i - ts), i, 1);
+            else
+                err_sys.search(D.data(), I.data(), ts, ses);
+            std::string suf = "_r" + std::to_string(r);
+            std::string tag = suf + (batched ? " (one batch)" : " (one query per call)");
+            expect(memcmp(I.data(), in.get("I" + suf).as<int64_t>(), ses * K * 8) == 0, "adaptive ids" + tag);
+            expect(same_f(D.data(), in.get("D" + suf).as<float>(), ses * K), "adaptive distances" + tag);
+            expect(memcmp(index.t->my_nprobe + ts, in.get("my_nprobe" + suf).as<uint64_t>(), ses * 8) == 0, "my_nprobe" + tag);
+        }
+    }
+    // tune mode without a tuner is an error, as in the reference (IndexIVF.cpp:514-515)
+    {
+        IndexIVFFlat bare(&quantizer, d, nlist, METRIC_L2);
+        bare.set_tune_mode();
+        bare.nprobe = nlist;
+        bool threw = false;
+        std::vector<float> D(K);
+        std::vector<idx_t> I(K);
+        try { bare.search(1, xq.as<float>(), K, D.data(), I.data(), 0); } catch (const FaissException&) { threw = true; }
+        expect(threw, "tune without init_tune throws FaissException");
+    }
+    return g_fail;
+}
+
+int main(int argc, char** argv) {
+    if (argc != 3) return 2;
+    try {
+        tb::Bundle in = tb::Bundle::load(argv[2]);
+        int f = std::string(argv[1]) == "fixed" ? run_fixed(in) : run_auncel(in);
+        printf(f ? "FAILED %d checks\n" : "ALL OK\n", f);
+        return f ? 1 : 0;
+    } catch (const std::exception& e) {
+        printf("EXCEPTION: %s\n", e.what());
+        return 3;
+    }
+}

@@ -1,0 +1,70 @@
+"""The host-side C++ mirror of the reference's classes (auncel_amd/csrc/host, namespace faiss) run
+through the flows of the reference's own callers by tests/cpp/host_mirror_driver.cpp."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from util import load_case, traces_from_gold
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER_SRC = os.path.join(ROOT, "tests", "cpp", "host_mirror_driver.cpp")
+
+
+@pytest.fixture(scope="module")
+def driver(tmp_path_factory):
+    from auncel_amd import build
+    build.build_host()
+    exe = str(tmp_path_factory.mktemp("drv") / "host_mirror_driver")
+    subprocess.run(["g++", "-std=c++17", "-O1", DRIVER_SRC, "-o", exe, "-L" + build.LIBDIR, "-lfaiss_amd", "-launcel_amd",
+                    "-Wl,-rpath," + build.LIBDIR], check=True)
+    return exe
+
+
+def test_driver_builds_and_links(driver):
+    """CPU-side: the mirror and a caller written against the reference's class names compile and link"""
+    assert os.path.exists(driver)
+
+
+def _run(driver, kind, tensors, tmp_path):
+    from oracle import tbundle
+    f = str(tmp_path / "in.tb")
+    tbundle.save(f, tensors)
+    r = subprocess.run([driver, kind, f], cwd=str(tmp_path), capture_output=True, text=True)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["fixed_sift_l2", "fixed_gauss_l2_d96", "fixed_deep_ip_d96", "fixed_ragged", "fixed_dups"])
+def test_fixed_flows(driver, tmp_path, name):
+    case, gold = load_case(name)
+    t = {k: v for k, v in case.items() if k != "kind"}
+    t.update({k: v for k, v in gold.items() if k != "input_sha"})
+    _run(driver, "fixed", t, tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["auncel_sift_d32", "auncel_gauss_d64"])
+def test_error_sys_flow(driver, oracle, tmp_path, name):
+    case, gold = load_case(name)
+    K, ts = case["max_topk"], case["train_num"]
+    # expectation for sys_train: pinned oracle fed with the exact coarse ranking (see test_gpu_parity)
+    lists = oracle.Lists(case["metric"], gold["centroids"], case["xb"], gold["assign"])
+    ntr = len(traces_from_gold(gold))
+    raw = [np.full((ts * (K // 4), 2), -1, dtype=np.float32) for _ in range(ntr)]
+    oracle.train_samples(lists, case["xq"][:ts], K, gold["coarse_keys_sse"][:ts], gold["coarse_dis_sse"][:ts],
+                         gold["interdis_cem"], gold["arcos_list"], gold["gtD"], 0, ts, raw)
+    t = {k: v for k, v in case.items() if k != "kind"}
+    for k in ("centroids", "interdis_cem", "gtD", "gtI"):
+        t[k] = gold[k]
+    for i in range(ntr):
+        x, y, s = oracle.trace_sb(raw[i])
+        t[f"exp_sb_trace{i}"] = np.stack([x, y], 1)
+        t[f"exp_sb_stds{i}"] = s
+        t[f"sb_trace{i}"] = gold[f"sb_trace{i}"]
+        t[f"sb_stds{i}"] = gold[f"sb_stds{i}"]
+    for r in range(len(case["topks"])):
+        for k in ("I", "D", "my_nprobe"):
+            t[f"{k}_r{r}"] = gold[f"{k}_r{r}"]
+    _run(driver, "auncel", t, tmp_path)
