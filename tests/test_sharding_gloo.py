@@ -1,0 +1,68 @@
+"""N > 1 plumbing on CPU: two gloo ranks each search their list-id shard (the CPU oracle stands in
+for the per-GPU engine here -- the engine itself is covered by test_gpu_parity.test_shards_by_list_id),
+rank 0 gathers and merges with the product's host merge and must reproduce the reference's
+IndexShards output."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, name, q):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")]
+    import torch.distributed as dist
+    from util import load_case
+    from auncel_amd import capi, sharding
+    from oracle import pyoracle
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        case, gold = load_case(name)
+        owner = np.arange(case["nlist"]) % world  # the golden shards are owner(l) = l % nshard
+        ok = True
+        for k in case["ks"]:
+            la = sharding.local_assignment(gold["assign"], owner, rank)
+            sub = pyoracle.Lists(case["metric"], case["centroids"], case["xb"], la)
+            D, I, _ = pyoracle.search_preassigned(sub, case["xq"], int(k), gold["coarse_keys_sse"], gold["coarse_dis_sse"])
+            out = sharding.gather_and_merge(D, I, case["metric"], capi.merge_tables, dist)
+            if rank == 0:
+                ok &= np.array_equal(out[1], gold[f"I_shards_k{k}"]) and np.array_equal(out[0].view(np.uint32), gold[f"D_shards_k{k}"].view(np.uint32))
+            else:
+                ok &= out is None
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["fixed_gauss_l2_d96", "fixed_deep_ip_d96", "fixed_dups"])
+def test_two_rank_shards(name):
+    from auncel_amd import build
+    build.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True), (1, True)]
+
+
+def test_owner_balance():
+    from auncel_amd import sharding
+    rs = np.random.RandomState(0)
+    sizes = rs.randint(0, 5000, size=4096)
+    owner = sharding.assign_owners(sizes, 8)
+    load = np.bincount(owner, weights=sizes, minlength=8)
+    assert load.max() - load.min() <= sizes.max()
+    assert np.array_equal(owner, sharding.assign_owners(sizes, 8))
+    la = sharding.local_assignment(np.array([0, 5, -1, 7]), np.array([1, 0, 0, 0, 0, 1, 0, 1]), 1)
+    assert list(la) == [0, 5, -1, 7]
+    la = sharding.local_assignment(np.array([0, 5, -1, 7]), np.array([1, 0, 0, 0, 0, 1, 0, 1]), 0)
+    assert list(la) == [-1, -1, -1, -1]
