@@ -340,34 +340,48 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
                 }
             }
         }
-        // ---- tiles
-        size_t nitems = 0;
+        // ---- tiles, grouped by workgroup shape (qg 1 | 2 | 4) so that each shape gets its own launch.
+        // The c queries of a list go into blocks of 32 (qg 4: 4 waves x 8 queries x 128 vectors); the
+        // remainder block takes the narrowest shape that holds it (<= 8: qg 1 = 512 vectors per block,
+        // <= 16: qg 2), so that no wave runs without queries.
+        auto rem_qg = [](uint32_t r) -> uint32_t { return r <= SCAN_RQ ? 1 : r <= 2 * SCAN_RQ ? 2 : 4; };
+        size_t n_qg[3] = {0, 0, 0};
         for (size_t l = 0; l < nlist; l++) {
             uint32_t c = lcount[l + 1] - lcount[l];
             if (!c) continue;
-            uint32_t qg = c <= SCAN_RQ ? 1 : c <= 2 * SCAN_RQ ? 2 : 4;
-            size_t tv = (4 / qg) * SCAN_WAVE_VECS, sz = off[l + 1] - off[l];
-            nitems += ((c + qg * SCAN_RQ - 1) / (qg * SCAN_RQ)) * ((sz + tv - 1) / tv);
+            const size_t sz = off[l + 1] - off[l];
+            const uint32_t full = c / (4 * SCAN_RQ), rem = c % (4 * SCAN_RQ);
+            n_qg[2] += (size_t)full * ((sz + SCAN_WAVE_VECS - 1) / SCAN_WAVE_VECS);
+            if (rem) {
+                uint32_t qg = rem_qg(rem);
+                size_t tv = (4 / qg) * SCAN_WAVE_VECS;
+                n_qg[scan_qg_class(qg)] += (sz + tv - 1) / tv;
+            }
         }
+        const size_t nitems = n_qg[0] + n_qg[1] + n_qg[2];
         h->p_items.ensure(std::max<size_t>(nitems, 1) * sizeof(ScanItem));
         ScanItem* items = h->p_items.as<ScanItem>();
-        size_t ni = 0;
+        size_t cur[3] = {0, n_qg[0], n_qg[0] + n_qg[1]};
         for (size_t l = 0; l < nlist; l++) {
             uint32_t c = lcount[l + 1] - lcount[l];
             if (!c) continue;
-            uint32_t qg = c <= SCAN_RQ ? 1 : c <= 2 * SCAN_RQ ? 2 : 4;
-            uint32_t tv = (4 / qg) * SCAN_WAVE_VECS, sz = (uint32_t)(off[l + 1] - off[l]);
-            for (uint32_t vb = 0; vb < sz; vb += tv)
-                for (uint32_t qb = 0; qb < c; qb += qg * SCAN_RQ) {
+            const uint32_t sz = (uint32_t)(off[l + 1] - off[l]);
+            for (uint32_t qb = 0; qb < c; qb += 4 * SCAN_RQ) {
+                const uint32_t nq_blk = std::min<uint32_t>(4 * SCAN_RQ, c - qb);
+                const uint32_t qg = rem_qg(nq_blk);
+                const uint32_t tv = (4 / qg) * SCAN_WAVE_VECS;
+                size_t& ni = cur[scan_qg_class(qg)];
+                for (uint32_t vb = 0; vb < sz; vb += tv) {
                     ScanItem& it = items[ni++];
                     it.vec_base = off[l] + vb;
                     it.nvec = std::min(tv, sz - vb);
                     it.vec_off = vb;
                     it.pair_begin = lcount[l] + qb;
-                    it.npair = std::min<uint32_t>(qg * SCAN_RQ, c - qb);
+                    it.npair = nq_blk;
                     it.qg = qg;
                     it.pad = 0;
                 }
+            }
         }
         // ---- upload + launch
         h->w_dist.ensure(std::max<uint64_t>(cursor, 1) * sizeof(float));
@@ -399,7 +413,7 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
         sa.metric = h->metric;
         if (nitems) {
             size_t t = h->timer.begin(CAT_SCAN, s);
-            launch_scan(sa, nitems, s);
+            launch_scan(sa, n_qg, s);
             h->timer.end(t, s);
         }
         ReplayArgs ra{};
@@ -557,7 +571,9 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
         sa.d = h->dpad;
         sa.metric = h->metric;
         size_t t = h->timer.begin(CAT_COARSE, s);
-        launch_scan(sa, nitems, s);
+        size_t n_qg[3] = {0, 0, 0};
+        n_qg[scan_qg_class(qg)] = nitems;
+        launch_scan(sa, n_qg, s);
         if (use_heap) {
             // the reference's own selection: a heap of nprobe over centroids 0..nlist-1 (utils.cpp:454-490)
             const size_t k = nprobe;
@@ -1037,7 +1053,8 @@ int amd_ivf_distance_to_code(amd_ivf_t* h, const float* query, size_t list_no, s
     HIP_CHECK(hipMemcpyAsync(h->w_pair_out.p, &po, 8, hipMemcpyHostToDevice, h->stream));
     ScanArgs sa{h->d_codes.as<float>(), h->w_x.as<float>(), h->w_items.as<ScanItem>(), h->w_pair_query.as<uint32_t>(),
                 h->w_pair_out.as<uint64_t>(), h->w_dist.as<float>(), h->dpad, h->metric};
-    launch_scan(sa, 1, h->stream);
+    const size_t one_qg1[3] = {1, 0, 0};
+    launch_scan(sa, one_qg1, h->stream);
     HIP_CHECK(hipMemcpyAsync(dis, h->w_dist.p, 4, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
     API_END
@@ -1101,7 +1118,8 @@ int amd_ivf_set_interdis(amd_ivf_t* h, const float* table) {
         // rows = (possibly renormalised) centroids as queries, columns = the same table as the vector tile
         ScanArgs sa{d_cq.as<float>(), d_cq.as<float>(), h->w_items.as<ScanItem>(), h->w_pair_query.as<uint32_t>(),
                     h->w_pair_out.as<uint64_t>(), d_full.as<float>(), h->dpad, h->metric};
-        launch_scan(sa, items.size(), h->stream);
+        const size_t all_qg4[3] = {0, 0, items.size()};
+        launch_scan(sa, all_qg4, h->stream);
         launch_pack_upper(d_full.as<float>(), (uint32_t)nl, h->d_interdis.as<float>(), h->stream);
         HIP_CHECK(hipStreamSynchronize(h->stream));
         if (h->metric == METRIC_IP) {

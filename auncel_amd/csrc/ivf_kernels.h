@@ -39,7 +39,9 @@ struct ScanArgs {
     int metric;
 };
 
-void launch_scan(const ScanArgs& a, size_t nitems, hipStream_t s);
+// items grouped by qg (1, then 2, then 4); n_qg = item count of each group
+void launch_scan(const ScanArgs& a, const size_t n_qg[3], hipStream_t s);
+inline int scan_qg_class(uint32_t qg) { return qg == 1 ? 0 : qg == 2 ? 1 : 2; }
 
 // ---------------------------------------------------------------------------- ordered selection
 // One wave per query replays the reference's sequential heap (Heap.h) over the distance rows in

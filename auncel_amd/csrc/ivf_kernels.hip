@@ -27,21 +27,23 @@ namespace amdivf {
 // a wave are wave-uniform: they are fetched with scalar loads and used as SGPR operands, so a
 // query value costs neither LDS bandwidth nor VGPRs.
 constexpr int LDS_ROW = SCAN_DC + 4;                 // dwords per staged row (pad = one 16-B slot)
-constexpr int TILE_MAX_VECS = 4 * SCAN_WAVE_VECS;    // 512
 
-template <int METRIC>
+// QG = query groups per workgroup (1, 2 or 4): 4 waves = QG groups of 8 queries x (4/QG) blocks of 128
+// vectors.  The staged tile, and with it the LDS footprint and the occupancy, depends on QG:
+// QG 4 -> 128 rows (18 KB), QG 2 -> 256 rows (36 KB), QG 1 -> 512 rows (72 KB).
+template <int METRIC, int QG>
 __global__ __launch_bounds__(256) void scan_tiles_kernel(ScanArgs a) {
-    __shared__ float lds[TILE_MAX_VECS * LDS_ROW];   // 73,728 B
+    constexpr int qg = QG;
+    constexpr int vg = 4 / QG;
+    constexpr int tile_vecs = vg * SCAN_WAVE_VECS;
+    __shared__ float lds[tile_vecs * LDS_ROW];
 
     const ScanItem it = a.items[blockIdx.x];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qg = (int)it.qg;                      // 1, 2 or 4
-    const int vg = 4 / qg;
     const int qgi = wave & (qg - 1);
     const int vgi = wave / qg;
-    const int tile_vecs = vg * SCAN_WAVE_VECS;
     const int d = a.d;
 
     const float* qptr[SCAN_RQ];
@@ -74,6 +76,7 @@ __global__ __launch_bounds__(256) void scan_tiles_kernel(ScanArgs a) {
         }
         __syncthreads();
         const float* myrow = &lds[(vgi * SCAN_WAVE_VECS + lane) * LDS_ROW];
+        if ((uint32_t)(qgi * SCAN_RQ) >= it.npair) continue;  // wave without queries: staging + barriers only
         for (int s = 0; s < nslot; s++) {
             float4 y[SCAN_RV];
 #pragma unroll
@@ -115,12 +118,20 @@ __global__ __launch_bounds__(256) void scan_tiles_kernel(ScanArgs a) {
     }
 }
 
-void launch_scan(const ScanArgs& a, size_t nitems, hipStream_t s) {
-    if (nitems == 0) return;
+template <int QG> static void launch_scan_qg(ScanArgs a, size_t first, size_t n, hipStream_t s) {
+    if (n == 0) return;
+    a.items += first;
     if (a.metric == METRIC_L2)
-        hipLaunchKernelGGL(scan_tiles_kernel<METRIC_L2>, dim3((unsigned)nitems), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((scan_tiles_kernel<METRIC_L2, QG>), dim3((unsigned)n), dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL(scan_tiles_kernel<METRIC_IP>, dim3((unsigned)nitems), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((scan_tiles_kernel<METRIC_IP, QG>), dim3((unsigned)n), dim3(256), 0, s, a);
+}
+
+// items must be grouped by qg: first n_qg[0] items with qg 1, then n_qg[1] with qg 2, then n_qg[2] with qg 4
+void launch_scan(const ScanArgs& a, const size_t n_qg[3], hipStream_t s) {
+    launch_scan_qg<4>(a, n_qg[0] + n_qg[1], n_qg[2], s);
+    launch_scan_qg<2>(a, n_qg[0], n_qg[1], s);
+    launch_scan_qg<1>(a, 0, n_qg[0], s);
 }
 
 // =============================================================================================
