@@ -24,7 +24,8 @@ def build(force=False):
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    extra = os.environ.get("AUNCEL_AMD_CXXFLAGS", "").split()
+    cmd = [hipcc] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     subprocess.run(cmd, check=True)
     return LIB
 

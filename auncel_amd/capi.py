@@ -269,6 +269,7 @@ class Handle:
         return D, I
 
     def last_timing(self):
-        t = (C.c_double * 6)()
+        t = (C.c_double * 8)()
         lib().amd_ivf_last_timing(self._h, t)
-        return dict(coarse_ms=t[0], scan_ms=t[1], select_ms=t[2], total_ms=t[3], scan_launches=t[4], scan_bytes=t[5])
+        return dict(coarse_ms=t[0], scan_ms=t[1], select_ms=t[2], total_ms=t[3], scan_launches=t[4], scan_bytes=t[5],
+                    slot_efficiency=t[6], rounds=t[7])

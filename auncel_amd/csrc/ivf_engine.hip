@@ -12,6 +12,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/auncel_amd.h"
@@ -33,6 +34,35 @@ struct EngineError : std::runtime_error {  // what the reference raises as Faiss
         if (_e != hipSuccess)                                                                        \
             throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " at " #expr); \
     } while (0)
+
+// Range of a set of fp32 values when all of them are integers (else ok = false).  When every operand of a
+// scan is an integer of magnitude <= 4095, x - y and (x - y)^2 (or x * y) are exactly representable, so
+// fma(t, t, acc) and acc + t * t round identically: the scan kernel may then fuse (2 VALU ops per element
+// instead of 3) without changing a single bit of any distance.
+struct IntRange {
+    bool ok = true;
+    float lo = 0.f, hi = 0.f;
+    void add(const float* x, size_t n) {
+        if (!ok) return;
+        float l = lo, h = hi;
+        bool good = true;
+        for (size_t i = 0; i < n; i++) {
+            const float v = x[i];
+            good &= (v == (float)(int)v) & (v >= -4095.f) & (v <= 4095.f);
+            l = v < l ? v : l;
+            h = v > h ? v : h;
+        }
+        ok = good;
+        lo = l;
+        hi = h;
+    }
+    void merge(const IntRange& o) {
+        ok = ok && o.ok;
+        lo = std::min(lo, o.lo);
+        hi = std::max(hi, o.hi);
+    }
+    bool fusable_with(const IntRange& o) const { return ok && o.ok && std::max(hi, o.hi) <= 4095.f && std::min(lo, o.lo) >= -4095.f; }
+};
 
 struct DevBuf {
     void* p = nullptr;
@@ -141,6 +171,8 @@ struct amd_ivf {
     // resident queries
     DevBuf d_resident;
     size_t n_resident = 0;
+    IntRange db_range, centroid_range, resident_range, call_range;  // see IntRange
+    int allow_fused = 1;
 
     // Auncel state
     DevBuf d_interdis;
@@ -150,6 +182,8 @@ struct amd_ivf {
     bool have_tuner = false;
 
     // workspaces (grow only)
+    DevBuf w_qtile, w_group_p0, w_group_cnt;
+    PinnedBuf p_group_p0, p_group_cnt;
     DevBuf w_x, w_dist, w_items, w_pair_query, w_pair_out, w_seg_off, w_seg_list, w_seg_count, w_qsel;
     DevBuf w_heap_val, w_heap_ref, w_stage, w_nscan, w_done, w_pre_val, w_stoped, w_dtb, w_D, w_I;
     DevBuf w_cdis, w_ckeys, w_stats, w_error, w_misc, w_misc2, w_misc3, w_rawptrs;
@@ -158,14 +192,24 @@ struct amd_ivf {
 
     size_t dist_budget_floats = (size_t)768 << 20;  // 3 GiB of distances per scan launch
     size_t stats_host[4] = {0, 0, 0, 0};
-    double timing[6] = {0, 0, 0, 0, 0, 0};
-    double scan_bytes = 0;
+    double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double scan_bytes = 0, scan_slots = 0, scan_useful = 0;
     EventTimer timer;
 
+    // Query lanes: a large adaptive batch is cut into slices that run their rounds concurrently, each on
+    // its own stream with its own workspaces (kids borrow the index data of `parent`), so that one
+    // slice's latency-bound selection and host-side round planning overlap another slice's VALU-bound scan.
+    amd_ivf* parent = nullptr;
+    std::vector<std::unique_ptr<amd_ivf>> kids;
+
     ~amd_ivf() {
+        kids.clear();
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
+
+static inline amd_ivf* ix(amd_ivf* h) { return h->parent ? h->parent : h; }
+static inline const amd_ivf* ix(const amd_ivf* h) { return h->parent ? h->parent : h; }
 
 namespace {
 
@@ -240,6 +284,40 @@ void init_state(amd_ivf* h, size_t n, size_t k, bool tune_or_train) {
     if (tune_or_train) h->w_dtb.ensure(n * (h->nlist / 8 + 20) * sizeof(float));
 }
 
+// ------------------------------------------------------------------------------------ query tiles
+// Groups of 8 consecutive pairs (never crossing a list) get their query rows gathered and interleaved into
+// the layout the scan kernel's scalar loads want.  `ranges`: (first pair, pair count) of every run of pairs
+// that must start a new group (one per list); returns the group index of each run's first group.
+std::vector<uint32_t> pack_query_tiles(amd_ivf* h, const float* d_queries, const std::vector<std::pair<uint32_t, uint32_t>>& ranges) {
+    std::vector<uint32_t> first(ranges.size());
+    size_t ng = 0;
+    for (size_t i = 0; i < ranges.size(); i++) {
+        first[i] = (uint32_t)ng;
+        ng += (ranges[i].second + SCAN_RQ - 1) / SCAN_RQ;
+    }
+    h->p_group_p0.ensure(std::max<size_t>(ng, 1) * 4);
+    h->p_group_cnt.ensure(std::max<size_t>(ng, 1) * 4);
+    uint32_t* gp = h->p_group_p0.as<uint32_t>();
+    uint32_t* gc = h->p_group_cnt.as<uint32_t>();
+    size_t g = 0;
+    for (auto& r : ranges)
+        for (uint32_t o = 0; o < r.second; o += SCAN_RQ) {
+            gp[g] = r.first + o;
+            gc[g] = std::min<uint32_t>(SCAN_RQ, r.second - o);
+            g++;
+        }
+    h->w_group_p0.ensure(std::max<size_t>(ng, 1) * 4);
+    h->w_group_cnt.ensure(std::max<size_t>(ng, 1) * 4);
+    h->w_qtile.ensure(std::max<size_t>(ng, 1) * (size_t)h->dpad * SCAN_RQ * sizeof(float));
+    if (ng) {
+        HIP_CHECK(hipMemcpyAsync(h->w_group_p0.p, gp, ng * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_CHECK(hipMemcpyAsync(h->w_group_cnt.p, gc, ng * 4, hipMemcpyHostToDevice, h->stream));
+        launch_pack_queries(d_queries, h->w_pair_query.as<uint32_t>(), h->w_group_p0.as<uint32_t>(), h->w_group_cnt.as<uint32_t>(), ng,
+                            h->dpad, h->w_qtile.as<float>(), h->stream);
+    }
+    return first;
+}
+
 // ------------------------------------------------------------------------------------ rounds
 struct RoundSpec {
     // participating query slots and, for each, the probes [p0, p0+cnt) to run this round
@@ -260,13 +338,14 @@ struct RoundSpec {
     const int64_t* d_ckeys = nullptr;
     uint32_t coarse_stride = 0;
     int raw_heap_out = 0;
+    int fused = 0;
 };
 
 void exec_round(amd_ivf* h, const RoundSpec& r) {
     const size_t m = r.slot.size();
     if (m == 0) return;
     const size_t nlist = h->nlist;
-    const std::vector<uint64_t>& off = h->h_list_off;
+    const std::vector<uint64_t>& off = ix(h)->h_list_off;
     size_t q0 = 0;
     std::vector<uint32_t> lcount(nlist + 1);
     while (q0 < m) {
@@ -346,6 +425,18 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
         // <= 16: qg 2), so that no wave runs without queries.
         auto rem_qg = [](uint32_t r) -> uint32_t { return r <= SCAN_RQ ? 1 : r <= 2 * SCAN_RQ ? 2 : 4; };
         size_t n_qg[3] = {0, 0, 0};
+        std::vector<uint32_t> gbase(nlist, 0);
+        std::vector<std::pair<uint32_t, uint32_t>> qranges;
+        {
+            uint32_t g = 0;
+            for (size_t l = 0; l < nlist; l++) {
+                uint32_t c = lcount[l + 1] - lcount[l];
+                if (!c) continue;
+                gbase[l] = g;
+                g += (c + SCAN_RQ - 1) / SCAN_RQ;
+                qranges.emplace_back(lcount[l], c);
+            }
+        }
         for (size_t l = 0; l < nlist; l++) {
             uint32_t c = lcount[l + 1] - lcount[l];
             if (!c) continue;
@@ -379,7 +470,10 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
                     it.pair_begin = lcount[l] + qb;
                     it.npair = nq_blk;
                     it.qg = qg;
-                    it.pad = 0;
+                    it.qgroup = gbase[l] + qb / SCAN_RQ;
+                    // bookkeeping: (query, vector) slots the waves that run will compute vs pairs wanted
+                    h->scan_slots += (double)((nq_blk + SCAN_RQ - 1) / SCAN_RQ) * SCAN_RQ * (qg == 4 ? SCAN_WAVE_VECS : qg == 2 ? 2 * SCAN_WAVE_VECS : 4 * SCAN_WAVE_VECS);
+                    h->scan_useful += (double)nq_blk * it.nvec;
                 }
             }
         }
@@ -402,8 +496,10 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
             HIP_CHECK(hipMemcpyAsync(h->w_pair_out.p, pair_out, npairs * 8, hipMemcpyHostToDevice, s));
             HIP_CHECK(hipMemcpyAsync(h->w_items.p, items, nitems * sizeof(ScanItem), hipMemcpyHostToDevice, s));
         }
+        if (npairs) pack_query_tiles(h, r.d_x, qranges);
         ScanArgs sa{};
-        sa.codes = h->d_codes.as<float>();
+        sa.qtile = h->w_qtile.as<float>();
+        sa.codes = ix(h)->d_codes.as<float>();
         sa.queries = r.d_x;
         sa.items = h->w_items.as<ScanItem>();
         sa.pair_query = h->w_pair_query.as<uint32_t>();
@@ -411,6 +507,7 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
         sa.dist = h->w_dist.as<float>();
         sa.d = h->dpad;
         sa.metric = h->metric;
+        sa.fused = r.fused;
         if (nitems) {
             size_t t = h->timer.begin(CAT_SCAN, s);
             launch_scan(sa, n_qg, s);
@@ -429,8 +526,8 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
         ra.seg_off = h->w_seg_off.as<uint64_t>();
         ra.seg_list = h->w_seg_list.as<int32_t>();
         ra.seg_count = h->w_seg_count.as<uint32_t>();
-        ra.list_off = h->d_list_off.as<uint64_t>();
-        ra.ids = h->d_ids.as<int64_t>();
+        ra.list_off = ix(h)->d_list_off.as<uint64_t>();
+        ra.ids = ix(h)->d_ids.as<int64_t>();
         ra.store_pairs = r.store_pairs;
         ra.identity_ids = 0;
         ra.max_codes = r.max_codes;
@@ -446,7 +543,7 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
         ra.coarse_dis = r.d_cdis;
         ra.coarse_keys = r.d_ckeys;
         ra.coarse_stride = r.coarse_stride;
-        ra.trace_cap = (uint32_t)h->tuner_trace_cap;
+        ra.trace_cap = (uint32_t)ix(h)->tuner_trace_cap;
         ra.D = h->w_D.as<float>();
         ra.I = h->w_I.as<int64_t>();
         ra.stats = h->w_stats.as<unsigned long long>();
@@ -494,6 +591,8 @@ void finish_timing(amd_ivf* h, double wall_ms) {
     h->timing[3] = wall_ms;
     h->timing[4] = ln[CAT_SCAN];
     h->timing[5] = h->scan_bytes;
+    h->timing[6] = h->scan_slots > 0 ? h->scan_useful / h->scan_slots : 0;
+    h->timing[7] = ln[CAT_SELECT];
 }
 
 struct WallClock {
@@ -519,8 +618,8 @@ struct WallClock {
 
 // ------------------------------------------------------------------------------------ coarse
 // distances of n device queries (row stride dpad) to every centroid -> sorted top-nprobe on device
-void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode, float* d_out_dis, int64_t* d_out_keys) {
-    if (!h->have_centroids) throw EngineError("quantizer has no centroids");
+void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode, float* d_out_dis, int64_t* d_out_keys, int fused) {
+    if (!ix(h)->have_centroids) throw EngineError("quantizer has no centroids");
     (void)mode;  // TODO(round 2): mode 1 = MFMA |x|^2+|y|^2-2xy path; the exact kernel serves both for now
     const size_t nlist = h->nlist;
     hipStream_t s = h->stream;
@@ -552,7 +651,7 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
                 it.pair_begin = qb;
                 it.npair = std::min<uint32_t>(qg * SCAN_RQ, (uint32_t)m - qb);
                 it.qg = qg;
-                it.pad = 0;
+                it.qgroup = qb / SCAN_RQ;
             }
         h->w_dist.ensure(m * nlist * sizeof(float));
         h->w_pair_query.ensure(m * 4);
@@ -561,8 +660,10 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
         HIP_CHECK(hipMemcpyAsync(h->w_pair_query.p, pq, m * 4, hipMemcpyHostToDevice, s));
         HIP_CHECK(hipMemcpyAsync(h->w_pair_out.p, po, m * 8, hipMemcpyHostToDevice, s));
         HIP_CHECK(hipMemcpyAsync(h->w_items.p, items, nitems * sizeof(ScanItem), hipMemcpyHostToDevice, s));
+        pack_query_tiles(h, d_x, {{0u, (uint32_t)m}});
         ScanArgs sa{};
-        sa.codes = h->d_centroids.as<float>();
+        sa.qtile = h->w_qtile.as<float>();
+        sa.codes = ix(h)->d_centroids.as<float>();
         sa.queries = d_x;
         sa.items = h->w_items.as<ScanItem>();
         sa.pair_query = h->w_pair_query.as<uint32_t>();
@@ -570,6 +671,7 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
         sa.dist = h->w_dist.as<float>();
         sa.d = h->dpad;
         sa.metric = h->metric;
+        sa.fused = fused;
         size_t t = h->timer.begin(CAT_COARSE, s);
         size_t n_qg[3] = {0, 0, 0};
         n_qg[scan_qg_class(qg)] = nitems;
@@ -636,7 +738,7 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
 
 // ------------------------------------------------------------------------------------ searches
 void search_fixed_core(amd_ivf* h, const float* d_x, size_t n, size_t k, size_t nprobe, const int64_t* keys, float* D,
-                       int64_t* I, int store_pairs, size_t max_codes) {
+                       int64_t* I, int store_pairs, size_t max_codes, const IntRange& qr) {
     upload_lists(h);
     init_state(h, n, k, false);
     RoundSpec r;
@@ -665,6 +767,7 @@ void search_fixed_core(amd_ivf* h, const float* d_x, size_t n, size_t k, size_t 
     r.max_codes = max_codes;
     r.finalize_all = 1;
     r.d_x = d_x;
+    r.fused = h->allow_fused && h->db_range.fusable_with(qr);
     exec_round(h, r);
     check_device_error(h);
     HIP_CHECK(hipMemcpyAsync(D, h->w_D.p, n * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -673,14 +776,15 @@ void search_fixed_core(amd_ivf* h, const float* d_x, size_t n, size_t k, size_t 
     fold_stats(h, n);
 }
 
-void search_full(amd_ivf* h, const float* d_x, size_t n, size_t k, size_t nprobe, int coarse_mode, float* D, int64_t* I) {
+void search_full(amd_ivf* h, const float* d_x, size_t n, size_t k, size_t nprobe, int coarse_mode, float* D, int64_t* I, const IntRange& qr) {
     h->w_cdis.ensure(n * nprobe * 4);
     h->w_ckeys.ensure(n * nprobe * 8);
-    coarse_dev(h, d_x, n, nprobe, coarse_mode, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>());
+    coarse_dev(h, d_x, n, nprobe, coarse_mode, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>(),
+               h->allow_fused && h->centroid_range.fusable_with(qr));
     std::vector<int64_t> keys(n * nprobe);
     HIP_CHECK(hipMemcpyAsync(keys.data(), h->w_ckeys.p, n * nprobe * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
-    search_fixed_core(h, d_x, n, k, nprobe, keys.data(), D, I, 0, 0);
+    search_fixed_core(h, d_x, n, k, nprobe, keys.data(), D, I, 0, 0, qr);
 }
 
 TunerDev make_tuner(amd_ivf* h, size_t query_topk, float multipler, float std_m, const float* d_req, const float* d_gt,
@@ -688,17 +792,17 @@ TunerDev make_tuner(amd_ivf* h, size_t query_topk, float multipler, float std_m,
     TunerDev t{};
     t.enabled = 1;
     t.profile = profile;
-    t.max_topk = (uint32_t)h->tuner_max_topk;
+    t.max_topk = (uint32_t)ix(h)->tuner_max_topk;
     t.query_topk = (uint32_t)query_topk;
-    t.ntraces = (uint32_t)h->tuner_ntraces;
+    t.ntraces = (uint32_t)ix(h)->tuner_ntraces;
     t.multipler = multipler;
     t.std_m = std_m;
-    t.interdis = h->d_interdis.as<float>();
-    t.arcos = h->d_arcos.as<float>();
-    t.trace_off = h->d_trace_off.as<uint32_t>();
-    t.trace_x = h->d_trace_x.as<float>();
-    t.trace_y = h->d_trace_y.as<float>();
-    t.trace_std = h->d_trace_std.as<float>();
+    t.interdis = ix(h)->d_interdis.as<float>();
+    t.arcos = ix(h)->d_arcos.as<float>();
+    t.trace_off = ix(h)->d_trace_off.as<uint32_t>();
+    t.trace_x = ix(h)->d_trace_x.as<float>();
+    t.trace_y = ix(h)->d_trace_y.as<float>();
+    t.trace_std = ix(h)->d_trace_std.as<float>();
     t.require_acc = d_req;
     t.gt_D = d_gt;
     t.my_nprobe = d_np;
@@ -818,6 +922,7 @@ int amd_ivf_create(int d, size_t nlist, int metric, int device, amd_ivf_t** out)
     h->h_codes.resize(nlist);
     h->h_ids.resize(nlist);
     h->h_list_off.assign(nlist + 1, 0);
+    if (getenv("AUNCEL_AMD_NO_FUSED")) h->allow_fused = 0;
     *out = h.release();
     API_END
 }
@@ -842,14 +947,18 @@ int amd_ivf_set_centroids(amd_ivf_t* h, const float* centroids) {
     HIP_CHECK(hipStreamSynchronize(h->stream));
     h->have_centroids = true;
     h->have_interdis = false;
+    h->centroid_range = IntRange();
+    h->centroid_range.add(centroids, h->nlist * (size_t)h->d);
     API_END
 }
 
 int amd_ivf_set_lists(amd_ivf_t* h, const size_t* sizes, const float* const* codes, const int64_t* const* ids) {
     API_BEGIN
     size_t nt = 0;
+    h->db_range = IntRange();
     for (size_t l = 0; l < h->nlist; l++) {
         size_t n = sizes[l];
+        h->db_range.add(codes[l], n * (size_t)h->d);
         h->h_codes[l].assign(n * h->dpad, 0.f);
         for (size_t j = 0; j < n; j++) memcpy(&h->h_codes[l][j * h->dpad], codes[l] + j * h->d, h->d * sizeof(float));
         h->h_ids[l].assign(ids[l], ids[l] + n);
@@ -876,7 +985,7 @@ int amd_ivf_add(amd_ivf_t* h, size_t n, const float* x, const int64_t* xids, con
         for (size_t i0 = 0; i0 < n; i0 += bs) {
             size_t m = std::min(bs, n - i0);
             upload_rows(h, h->w_x.as<float>(), x + i0 * h->d, m);
-            coarse_dev(h, h->w_x.as<float>(), m, 1, 0, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>());
+            coarse_dev(h, h->w_x.as<float>(), m, 1, 0, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>(), 0);
             HIP_CHECK(hipMemcpyAsync(assign.data() + i0, h->w_ckeys.p, m * 8, hipMemcpyDeviceToHost, h->stream));
             HIP_CHECK(hipStreamSynchronize(h->stream));
         }
@@ -895,6 +1004,7 @@ int amd_ivf_add(amd_ivf_t* h, size_t n, const float* x, const int64_t* xids, con
         memcpy(&c[o], x + i * h->d, h->d * sizeof(float));
         h->h_ids[l].push_back(id);
     }
+    h->db_range.add(x, n * (size_t)h->d);
     h->ntotal += n;
     h->lists_dirty = true;
     API_END
@@ -934,11 +1044,15 @@ int amd_ivf_coarse(amd_ivf_t* h, size_t n, const float* x, size_t nprobe, float*
     if (n == 0) return 0;
     WallClock wc(h->stream);
     h->scan_bytes = 0;
+    h->scan_slots = h->scan_useful = 0;
     h->w_x.ensure(n * h->dpad * sizeof(float));
     upload_rows(h, h->w_x.as<float>(), x, n);
     h->w_cdis.ensure(n * nprobe * 4);
     h->w_ckeys.ensure(n * nprobe * 8);
-    coarse_dev(h, h->w_x.as<float>(), n, nprobe, mode, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>());
+    IntRange qr;
+    qr.add(x, n * (size_t)h->d);
+    coarse_dev(h, h->w_x.as<float>(), n, nprobe, mode, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>(),
+               h->allow_fused && h->centroid_range.fusable_with(qr));
     HIP_CHECK(hipMemcpyAsync(coarse_dis, h->w_cdis.p, n * nprobe * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipMemcpyAsync(keys, h->w_ckeys.p, n * nprobe * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -954,9 +1068,12 @@ int amd_ivf_search_preassigned(amd_ivf_t* h, size_t n, const float* x, size_t k,
     if (n == 0 || k == 0) return 0;
     WallClock wc(h->stream);
     h->scan_bytes = 0;
+    h->scan_slots = h->scan_useful = 0;
     h->w_x.ensure(n * h->dpad * sizeof(float));
     upload_rows(h, h->w_x.as<float>(), x, n);
-    search_fixed_core(h, h->w_x.as<float>(), n, k, nprobe, keys, D, I, store_pairs, max_codes);
+    IntRange qr;
+    qr.add(x, n * (size_t)h->d);
+    search_fixed_core(h, h->w_x.as<float>(), n, k, nprobe, keys, D, I, store_pairs, max_codes, qr);
     finish_timing(h, wc.stop());
     API_END
 }
@@ -967,9 +1084,12 @@ int amd_ivf_search(amd_ivf_t* h, size_t n, const float* x, size_t k, size_t npro
     if (n == 0 || k == 0) return 0;
     WallClock wc(h->stream);
     h->scan_bytes = 0;
+    h->scan_slots = h->scan_useful = 0;
     h->w_x.ensure(n * h->dpad * sizeof(float));
     upload_rows(h, h->w_x.as<float>(), x, n);
-    search_full(h, h->w_x.as<float>(), n, k, nprobe, coarse_mode, D, I);
+    IntRange qr;
+    qr.add(x, n * (size_t)h->d);
+    search_full(h, h->w_x.as<float>(), n, k, nprobe, coarse_mode, D, I, qr);
     finish_timing(h, wc.stop());
     API_END
 }
@@ -981,6 +1101,8 @@ int amd_ivf_set_queries(amd_ivf_t* h, size_t n, const float* x) {
     upload_rows(h, h->d_resident.as<float>(), x, n);
     HIP_CHECK(hipStreamSynchronize(h->stream));
     h->n_resident = n;
+    h->resident_range = IntRange();
+    h->resident_range.add(x, n * (size_t)h->d);
     API_END
 }
 
@@ -991,7 +1113,8 @@ int amd_ivf_search_resident(amd_ivf_t* h, size_t start, size_t n, size_t k, size
     if (n == 0 || k == 0) return 0;
     WallClock wc(h->stream);
     h->scan_bytes = 0;
-    search_full(h, h->d_resident.as<float>() + start * h->dpad, n, k, nprobe, coarse_mode, D, I);
+    h->scan_slots = h->scan_useful = 0;
+    search_full(h, h->d_resident.as<float>() + start * h->dpad, n, k, nprobe, coarse_mode, D, I, h->resident_range);
     finish_timing(h, wc.stop());
     API_END
 }
@@ -1020,6 +1143,11 @@ int amd_ivf_scan_codes(amd_ivf_t* h, const float* query, size_t list_no, int sto
     r.finalize_all = 1;
     r.raw_heap_out = 1;
     r.d_x = h->w_x.as<float>();
+    {
+        IntRange qr;
+        qr.add(query, (size_t)h->d);
+        r.fused = h->allow_fused && h->db_range.fusable_with(qr);
+    }
     exec_round(h, r);
     check_device_error(h);
     HIP_CHECK(hipMemcpyAsync(simi, h->w_D.p, k * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1045,14 +1173,15 @@ int amd_ivf_distance_to_code(amd_ivf_t* h, const float* query, size_t list_no, s
     h->w_items.ensure(sizeof(ScanItem));
     h->w_pair_query.ensure(4);
     h->w_pair_out.ensure(8);
-    ScanItem it{h->h_list_off[list_no] + offset, 1, 0, 0, 1, 1, 0};
+    ScanItem it{h->h_list_off[list_no] + offset, 1, 0, 0, 1, 1, 0};  // qgroup 0
     uint32_t pq = 0;
     uint64_t po = 0;
     HIP_CHECK(hipMemcpyAsync(h->w_items.p, &it, sizeof(it), hipMemcpyHostToDevice, h->stream));
     HIP_CHECK(hipMemcpyAsync(h->w_pair_query.p, &pq, 4, hipMemcpyHostToDevice, h->stream));
     HIP_CHECK(hipMemcpyAsync(h->w_pair_out.p, &po, 8, hipMemcpyHostToDevice, h->stream));
+    pack_query_tiles(h, h->w_x.as<float>(), {{0u, 1u}});
     ScanArgs sa{h->d_codes.as<float>(), h->w_x.as<float>(), h->w_items.as<ScanItem>(), h->w_pair_query.as<uint32_t>(),
-                h->w_pair_out.as<uint64_t>(), h->w_dist.as<float>(), h->dpad, h->metric};
+                h->w_pair_out.as<uint64_t>(), h->w_dist.as<float>(), h->w_qtile.as<float>(), h->dpad, h->metric, 0};
     const size_t one_qg1[3] = {1, 0, 0};
     launch_scan(sa, one_qg1, h->stream);
     HIP_CHECK(hipMemcpyAsync(dis, h->w_dist.p, 4, hipMemcpyDeviceToHost, h->stream));
@@ -1108,7 +1237,7 @@ int amd_ivf_set_interdis(amd_ivf_t* h, const float* table) {
         for (uint32_t vb = 0; vb < nl; vb += tv)
             for (uint32_t qb = 0; qb < nl; qb += qg * SCAN_RQ)
                 items.push_back(ScanItem{vb, std::min<uint32_t>(tv, (uint32_t)nl - vb), vb, qb,
-                                         std::min<uint32_t>(qg * SCAN_RQ, (uint32_t)nl - qb), qg, 0});
+                                         std::min<uint32_t>(qg * SCAN_RQ, (uint32_t)nl - qb), qg, qb / SCAN_RQ});
         h->w_items.ensure(items.size() * sizeof(ScanItem));
         h->w_pair_query.ensure(nl * 4);
         h->w_pair_out.ensure(nl * 8);
@@ -1116,8 +1245,9 @@ int amd_ivf_set_interdis(amd_ivf_t* h, const float* table) {
         HIP_CHECK(hipMemcpyAsync(h->w_pair_query.p, pq.data(), nl * 4, hipMemcpyHostToDevice, h->stream));
         HIP_CHECK(hipMemcpyAsync(h->w_pair_out.p, po.data(), nl * 8, hipMemcpyHostToDevice, h->stream));
         // rows = (possibly renormalised) centroids as queries, columns = the same table as the vector tile
+        pack_query_tiles(h, d_cq.as<float>(), {{0u, (uint32_t)nl}});
         ScanArgs sa{d_cq.as<float>(), d_cq.as<float>(), h->w_items.as<ScanItem>(), h->w_pair_query.as<uint32_t>(),
-                    h->w_pair_out.as<uint64_t>(), d_full.as<float>(), h->dpad, h->metric};
+                    h->w_pair_out.as<uint64_t>(), d_full.as<float>(), h->w_qtile.as<float>(), h->dpad, h->metric, 0};
         const size_t all_qg4[3] = {0, 0, items.size()};
         launch_scan(sa, all_qg4, h->stream);
         launch_pack_upper(d_full.as<float>(), (uint32_t)nl, h->d_interdis.as<float>(), h->stream);
@@ -1173,9 +1303,45 @@ int amd_ivf_set_tuner(amd_ivf_t* h, size_t max_topk, size_t ntraces, const size_
     API_END
 }
 
+// one slice of an adaptive batch: queries [q0, q0+n) of the call, on lane `L` (L == h or one of h's kids)
+static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n, size_t query_topk, float multipler, float std_m,
+                           const float* dreq, const float* dgt, unsigned long long* dnp, float* dtr, int profile, int coarse_mode,
+                           float* D, int64_t* I, const IntRange& qr) {
+    use_device(L);
+    const size_t K = ix(L)->tuner_max_topk, nlist = L->nlist;
+    L->w_cdis.ensure(n * nlist * 4);
+    L->w_ckeys.ensure(n * nlist * 8);
+    // full coarse ranking (Error_sys::search sets nprobe = nlist, profile.cpp:220)
+    coarse_dev(L, d_x, n, nlist, coarse_mode, L->w_cdis.as<float>(), L->w_ckeys.as<int64_t>(),
+               ix(L)->allow_fused && ix(L)->centroid_range.fusable_with(qr));
+    init_state(L, n, K, true);
+    RoundSpec base;
+    base.fused = ix(L)->allow_fused && ix(L)->db_range.fusable_with(qr);
+    base.k = (int)K;
+    base.id_offset = id0;
+    base.d_x = d_x;
+    base.d_cdis = L->w_cdis.as<float>();
+    base.d_ckeys = L->w_ckeys.as<int64_t>();
+    base.coarse_stride = (uint32_t)nlist;
+    base.tuner = make_tuner(L, query_topk, multipler, std_m, dreq, dgt, dnp, dtr, profile);
+    run_rounds(L, base, n, 4, nlist, dnp, id0);
+    HIP_CHECK(hipMemcpyAsync(D, L->w_D.p, n * K * 4, hipMemcpyDeviceToHost, L->stream));
+    HIP_CHECK(hipMemcpyAsync(I, L->w_I.p, n * K * 8, hipMemcpyDeviceToHost, L->stream));
+    HIP_CHECK(hipStreamSynchronize(L->stream));
+    fold_stats(L, n);
+}
+
+static size_t lane_count(size_t n) {
+    static const int env = getenv("AUNCEL_AMD_LANES") ? atoi(getenv("AUNCEL_AMD_LANES")) : 0;
+    if (env > 0) return (size_t)env;
+    (void)n;
+    return 1;  // measured on MI355X: concurrent slices halve the queries per list and lose more in the
+               // VALU-bound scan than they hide of selection + planning (bench: 1 lane 25 ms/step, 2 lanes 29)
+}
+
 static void adaptive_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n, size_t query_topk, float multipler, float std_m,
                             const float* require_acc, const float* gt_D, int profile, int coarse_mode,
-                            uint64_t* my_nprobe, float* t_recalls, float* D, int64_t* I) {
+                            uint64_t* my_nprobe, float* t_recalls, float* D, int64_t* I, const IntRange& qr) {
     use_device(h);
     if (!h->have_tuner || !h->have_interdis)
         throw EngineError("Search tune start can't start without IVF_pro init and training");
@@ -1187,10 +1353,9 @@ static void adaptive_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n
     if (h->tuner_ntraces < ntr) throw EngineError("not enough traces for this nlist");
     if (query_topk == 0 || query_topk > K) throw EngineError("query_topk out of range");
     WallClock wc(h->stream);
-    h->scan_bytes = 0;
     upload_lists(h);
     const size_t nabs = start + n;
-    // per-absolute-query arrays on the device
+    // per-absolute-query arrays on the device, shared by all lanes
     DevBuf &d_req = h->w_misc2, &d_np = h->w_misc3;
     d_req.ensure(nabs * 4 * 2 + (gt_D ? nabs * K * 4 : 0) + 64);
     float* dreq = d_req.as<float>();
@@ -1201,27 +1366,70 @@ static void adaptive_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n
     HIP_CHECK(hipMemcpyAsync(dtr, t_recalls, nabs * 4, hipMemcpyHostToDevice, h->stream));
     if (gt_D) HIP_CHECK(hipMemcpyAsync(dgt, gt_D, nabs * K * 4, hipMemcpyHostToDevice, h->stream));
     HIP_CHECK(hipMemcpyAsync(d_np.p, my_nprobe, nabs * 8, hipMemcpyHostToDevice, h->stream));
-    // full coarse ranking (Error_sys::search sets nprobe = nlist, profile.cpp:220)
-    h->w_cdis.ensure(n * nlist * 4);
-    h->w_ckeys.ensure(n * nlist * 8);
-    coarse_dev(h, d_x, n, nlist, coarse_mode, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>());
-    init_state(h, n, K, true);
-    RoundSpec base;
-    base.k = (int)K;
-    base.id_offset = start;
-    base.d_x = d_x;
-    base.d_cdis = h->w_cdis.as<float>();
-    base.d_ckeys = h->w_ckeys.as<int64_t>();
-    base.coarse_stride = (uint32_t)nlist;
-    base.tuner = make_tuner(h, query_topk, multipler, std_m, dreq, dgt, d_np.as<unsigned long long>(), dtr, profile);
-    run_rounds(h, base, n, 4, nlist, d_np.as<unsigned long long>(), start);
-    HIP_CHECK(hipMemcpyAsync(D, h->w_D.p, n * K * 4, hipMemcpyDeviceToHost, h->stream));
-    HIP_CHECK(hipMemcpyAsync(I, h->w_I.p, n * K * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+
+    const size_t nl = std::min(lane_count(n), std::max<size_t>(1, n / 64));
+    while (h->kids.size() + 1 < nl) {
+        std::unique_ptr<amd_ivf> kid(new amd_ivf);
+        kid->parent = h;
+        kid->d = h->d;
+        kid->dpad = h->dpad;
+        kid->nlist = h->nlist;
+        kid->metric = h->metric;
+        kid->device = h->device;
+        kid->dist_budget_floats = h->dist_budget_floats;
+        HIP_CHECK(hipStreamCreateWithFlags(&kid->stream, hipStreamNonBlocking));
+        h->kids.push_back(std::move(kid));
+    }
+    std::vector<amd_ivf*> lanes(nl);
+    lanes[0] = h;
+    for (size_t i = 1; i < nl; i++) lanes[i] = h->kids[i - 1].get();
+    for (amd_ivf* L : lanes) {
+        L->scan_bytes = 0;
+        L->scan_slots = L->scan_useful = 0;
+    }
+    std::vector<std::exception_ptr> errs(nl);
+    auto run = [&](size_t i) {
+        const size_t q0 = n * i / nl, q1 = n * (i + 1) / nl;
+        try {
+            adaptive_slice(lanes[i], d_x + q0 * h->dpad, start + q0, q1 - q0, query_topk, multipler, std_m, dreq, dgt,
+                           d_np.as<unsigned long long>(), dtr, profile, coarse_mode, D + q0 * K, I + q0 * K, qr);
+        } catch (...) {
+            errs[i] = std::current_exception();
+        }
+    };
+    std::vector<std::thread> th;
+    for (size_t i = 1; i < nl; i++) th.emplace_back(run, i);
+    run(0);
+    for (auto& t : th) t.join();
+    for (auto& e : errs)
+        if (e) std::rethrow_exception(e);
     HIP_CHECK(hipMemcpyAsync(my_nprobe + start, d_np.as<unsigned long long>() + start, n * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipMemcpyAsync(t_recalls + start, dtr + start, n * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
-    fold_stats(h, n);
-    finish_timing(h, wc.stop());
+    // fold the kids' counters and kernel timings into the handle
+    const double wall = wc.stop();
+    double ms[NCAT] = {0, 0, 0}, ln[NCAT] = {0, 0, 0};
+    double bytes = 0, slots = 0, useful = 0;
+    for (amd_ivf* L : lanes) {
+        double m[NCAT], c[NCAT];
+        L->timer.collect(m, NCAT, c);
+        for (int k = 0; k < NCAT; k++) ms[k] += m[k], ln[k] += c[k];
+        bytes += L->scan_bytes;
+        slots += L->scan_slots;
+        useful += L->scan_useful;
+        if (L != h) {
+            for (int k = 0; k < 4; k++) h->stats_host[k] += L->stats_host[k], L->stats_host[k] = 0;
+        }
+    }
+    h->timing[0] = ms[CAT_COARSE];
+    h->timing[1] = ms[CAT_SCAN];
+    h->timing[2] = ms[CAT_SELECT];
+    h->timing[3] = wall;
+    h->timing[4] = ln[CAT_SCAN];
+    h->timing[5] = bytes;
+    h->timing[6] = slots > 0 ? useful / slots : 0;
+    h->timing[7] = ln[CAT_SELECT];
 }
 
 int amd_ivf_search_adaptive(amd_ivf_t* h, size_t start, size_t n, size_t query_topk, float multipler, float std_m,
@@ -1231,7 +1439,7 @@ int amd_ivf_search_adaptive(amd_ivf_t* h, size_t start, size_t n, size_t query_t
     use_device(h);
     if (start + n > h->n_resident) throw EngineError("resident query range out of bounds");
     adaptive_core(h, h->d_resident.as<float>() + start * h->dpad, start, n, query_topk, multipler, std_m, require_acc, gt_D,
-                  profile, coarse_mode, my_nprobe, t_recalls, D, I);
+                  profile, coarse_mode, my_nprobe, t_recalls, D, I, h->resident_range);
     API_END
 }
 
@@ -1243,13 +1451,15 @@ int amd_ivf_search_adaptive_x(amd_ivf_t* h, size_t n, const float* x, size_t id_
     if (n == 0) return 0;
     h->w_x.ensure(n * h->dpad * sizeof(float));
     upload_rows(h, h->w_x.as<float>(), x, n);
+    IntRange qr;
+    qr.add(x, n * (size_t)h->d);
     adaptive_core(h, h->w_x.as<float>(), id_offset, n, query_topk, multipler, std_m, require_acc, gt_D, profile, coarse_mode,
-                  my_nprobe, t_recalls, D, I);
+                  my_nprobe, t_recalls, D, I, qr);
     API_END
 }
 
 static void train_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n, size_t max_topk, const float* gt_D, size_t train_num,
-                          int coarse_mode, float* const* raw, float* D, int64_t* I) {
+                          int coarse_mode, float* const* raw, float* D, int64_t* I, const IntRange& qr) {
     use_device(h);
     if (!h->have_interdis) throw EngineError("Search tune start can't start without IVF_pro init and training");
     if (n == 0) return;
@@ -1280,9 +1490,11 @@ static void train_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n, s
     }
     h->w_cdis.ensure(n * nlist * 4);
     h->w_ckeys.ensure(n * nlist * 8);
-    coarse_dev(h, d_x, n, nlist, coarse_mode, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>());
+    coarse_dev(h, d_x, n, nlist, coarse_mode, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>(),
+               h->allow_fused && h->centroid_range.fusable_with(qr));
     init_state(h, n, K, true);
     RoundSpec base;
+    base.fused = h->allow_fused && h->db_range.fusable_with(qr);
     base.k = (int)K;
     base.id_offset = start;
     base.d_x = d_x;
@@ -1310,7 +1522,8 @@ int amd_ivf_train_samples(amd_ivf_t* h, size_t start, size_t n, size_t max_topk,
     API_BEGIN
     use_device(h);
     if (start + n > h->n_resident) throw EngineError("resident query range out of bounds");
-    train_core(h, h->d_resident.as<float>() + start * h->dpad, start, n, max_topk, gt_D, train_num, coarse_mode, raw, D, I);
+    train_core(h, h->d_resident.as<float>() + start * h->dpad, start, n, max_topk, gt_D, train_num, coarse_mode, raw, D, I,
+               h->resident_range);
     API_END
 }
 
@@ -1321,7 +1534,9 @@ int amd_ivf_train_samples_x(amd_ivf_t* h, size_t n, const float* x, size_t id_of
     if (n == 0) return 0;
     h->w_x.ensure(n * h->dpad * sizeof(float));
     upload_rows(h, h->w_x.as<float>(), x, n);
-    train_core(h, h->w_x.as<float>(), id_offset, n, max_topk, gt_D, train_num, coarse_mode, raw, D, I);
+    IntRange qr;
+    qr.add(x, n * (size_t)h->d);
+    train_core(h, h->w_x.as<float>(), id_offset, n, max_topk, gt_D, train_num, coarse_mode, raw, D, I, qr);
     API_END
 }
 
@@ -1439,8 +1654,8 @@ int amd_ivf_merge_tables(int metric, size_t n, size_t k, size_t nshard, const fl
     API_END
 }
 
-int amd_ivf_last_timing(amd_ivf_t* h, double out[6]) {
-    for (int i = 0; i < 6; i++) out[i] = h->timing[i];
+int amd_ivf_last_timing(amd_ivf_t* h, double out[8]) {
+    for (int i = 0; i < 8; i++) out[i] = h->timing[i];
     return 0;
 }
 

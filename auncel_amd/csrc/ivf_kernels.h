@@ -15,7 +15,10 @@ constexpr int METRIC_L2 = 1;
 // up to (4/QG)*64*RV consecutive vectors of one inverted list (or of the centroid table).
 constexpr int SCAN_RQ = 8;    // queries per wave (query operands live in SGPRs)
 constexpr int SCAN_RV = 2;    // vectors per lane
-constexpr int SCAN_DC = 32;   // dimensions staged through LDS per step
+#ifndef AUNCEL_SCAN_DC
+#define AUNCEL_SCAN_DC 16
+#endif
+constexpr int SCAN_DC = AUNCEL_SCAN_DC;   // dimensions staged through LDS per step
 constexpr int SCAN_WAVE_VECS = 64 * SCAN_RV;
 
 struct ScanItem {
@@ -25,7 +28,7 @@ struct ScanItem {
     uint32_t pair_begin; // first entry of this tile in the pair arrays
     uint32_t npair;      // queries in the tile (<= qg * SCAN_RQ)
     uint32_t qg;         // query groups per workgroup: 1, 2 or 4
-    uint32_t pad;
+    uint32_t qgroup;     // index of the tile's first 8-query group in the packed query tiles
 };
 
 struct ScanArgs {
@@ -35,12 +38,19 @@ struct ScanArgs {
     const uint32_t* pair_query;  // query row of each pair
     const uint64_t* pair_out;    // offset of each pair's distance row in `dist`
     float* dist;
+    const float* qtile;       // packed query operands: [group][d/4][8 queries][4 floats] (pack_queries)
     int d;
     int metric;
+    int fused;  // 1: fma(t, t, acc) -- only when the operands make it bit-identical to mul + add (see engine)
 };
 
 // items grouped by qg (1, then 2, then 4); n_qg = item count of each group
 void launch_scan(const ScanArgs& a, const size_t n_qg[3], hipStream_t s);
+
+// gather + interleave the query rows of every group of (up to) 8 pairs: group g holds pairs
+// [group_p0[g], group_p0[g] + group_cnt[g]); missing slots are zero
+void launch_pack_queries(const float* queries, const uint32_t* pair_query, const uint32_t* group_p0, const uint32_t* group_cnt,
+                         size_t ngroups, int d, float* qtile, hipStream_t s);
 inline int scan_qg_class(uint32_t qg) { return qg == 1 ? 0 : qg == 2 ? 1 : 2; }
 
 // ---------------------------------------------------------------------------- ordered selection

@@ -26,17 +26,23 @@ namespace amdivf {
 // its rows with conflict-free ds_read_b128 (row stride 36 dwords).  The SCAN_RQ query operands of
 // a wave are wave-uniform: they are fetched with scalar loads and used as SGPR operands, so a
 // query value costs neither LDS bandwidth nor VGPRs.
+typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int LDS_ROW = SCAN_DC + 4;                 // dwords per staged row (pad = one 16-B slot)
 
 // QG = query groups per workgroup (1, 2 or 4): 4 waves = QG groups of 8 queries x (4/QG) blocks of 128
 // vectors.  The staged tile, and with it the LDS footprint and the occupancy, depends on QG:
 // QG 4 -> 128 rows (18 KB), QG 2 -> 256 rows (36 KB), QG 1 -> 512 rows (72 KB).
-template <int METRIC, int QG>
+template <int METRIC, int QG, bool FUSED>
 __global__ __launch_bounds__(256) void scan_tiles_kernel(ScanArgs a) {
     constexpr int qg = QG;
     constexpr int vg = 4 / QG;
     constexpr int tile_vecs = vg * SCAN_WAVE_VECS;
-    __shared__ float lds[tile_vecs * LDS_ROW];
+    // two staging buffers: chunk c+1 is fetched into registers while chunk c is being consumed, and written
+    // to the other buffer, so a workgroup needs one barrier per chunk and hides its own fetch latency
+    __shared__ float lds[2][tile_vecs * LDS_ROW];
+    constexpr int SLOTS = SCAN_DC / 4;                     // 16-B slots per staged row
+    constexpr int NLD = tile_vecs * SLOTS / 256;           // fetches per thread per chunk
+    static_assert(tile_vecs * SLOTS % 256 == 0, "tile must split evenly over the workgroup");
 
     const ScanItem it = a.items[blockIdx.x];
     const int tid = threadIdx.x;
@@ -46,62 +52,106 @@ __global__ __launch_bounds__(256) void scan_tiles_kernel(ScanArgs a) {
     const int vgi = wave / qg;
     const int d = a.d;
 
-    const float* qptr[SCAN_RQ];
-#pragma unroll
-    for (int r = 0; r < SCAN_RQ; r++) {
-        uint32_t local = (uint32_t)(qgi * SCAN_RQ + r);
-        uint32_t pi = it.pair_begin + (local < it.npair ? local : 0u);
-        qptr[r] = a.queries + (size_t)a.pair_query[pi] * (size_t)d;
-    }
+    // the wave's 8 query operands of one 4-dimension step are 128 contiguous bytes (pack_queries): they come
+    // in through the scalar cache with two wide scalar loads and stay in SGPRs
+    const float4* qtile = reinterpret_cast<const float4*>(a.qtile + (size_t)(it.qgroup + qgi) * (size_t)d * SCAN_RQ);
 
-    float acc[SCAN_RQ][SCAN_RV][4];
+    // running sums (s0, s1) and (s2, s3) of the reference's 4-lane accumulator, as two register pairs
+    f2 acc[SCAN_RQ][SCAN_RV][2];
 #pragma unroll
     for (int r = 0; r < SCAN_RQ; r++)
 #pragma unroll
-        for (int v = 0; v < SCAN_RV; v++)
-#pragma unroll
-            for (int l = 0; l < 4; l++) acc[r][v][l] = 0.f;
+        for (int v = 0; v < SCAN_RV; v++) acc[r][v][0] = acc[r][v][1] = f2{0.f, 0.f};
 
     const float* tile_base = a.codes + (size_t)it.vec_base * (size_t)d;
+    const bool has_queries = (uint32_t)(qgi * SCAN_RQ) < it.npair;
 
-    for (int c0 = 0; c0 < d; c0 += SCAN_DC) {
+    // fetches run two chunks ahead of the compute (register staging, PF sets): at 4 steps per chunk one chunk
+    // of lead does not cover an HBM round trip under load
+    constexpr int PF = 2;
+    float4 pre[PF][NLD];
+    auto fetch = [&](int c0, float4 (&dst)[NLD]) {
         const int nslot = (d - c0 >= SCAN_DC ? SCAN_DC : d - c0) >> 2;
-        __syncthreads();
-        for (int idx = tid; idx < tile_vecs * (SCAN_DC / 4); idx += 256) {
-            const int row = idx >> 3, slot = idx & 7;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < (int)it.nvec && slot < nslot)
-                val = *reinterpret_cast<const float4*>(tile_base + (size_t)row * d + c0 + slot * 4);
-            *reinterpret_cast<float4*>(&lds[row * LDS_ROW + slot * 4]) = val;
+#pragma unroll
+        for (int i = 0; i < NLD; i++) {
+            const int idx = tid + i * 256;
+            const int row = idx / SLOTS, slot = idx % SLOTS;
+            dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c0 < d && row < (int)it.nvec && slot < nslot)
+                dst[i] = *reinterpret_cast<const float4*>(tile_base + (size_t)row * d + c0 + slot * 4);
+        }
+    };
+
+    fetch(0, pre[0]);
+    fetch(SCAN_DC, pre[1]);
+    int buf = 0;
+    // the chunk loop is unrolled by PF so that the staging registers are indexed statically
+    for (int c0 = 0; c0 < d; c0 += PF * SCAN_DC) {
+#pragma unroll
+      for (int ph = 0; ph < PF; ph++, buf ^= 1) {
+        const int cc = c0 + ph * SCAN_DC;
+        if (cc >= d) break;
+        const int nslot = (d - cc >= SCAN_DC ? SCAN_DC : d - cc) >> 2;
+        float* stage = lds[buf];
+#pragma unroll
+        for (int i = 0; i < NLD; i++) {
+            const int idx = tid + i * 256;
+            *reinterpret_cast<float4*>(&stage[(idx / SLOTS) * LDS_ROW + (idx % SLOTS) * 4]) = pre[ph][i];
         }
         __syncthreads();
-        const float* myrow = &lds[(vgi * SCAN_WAVE_VECS + lane) * LDS_ROW];
-        if ((uint32_t)(qgi * SCAN_RQ) >= it.npair) continue;  // wave without queries: staging + barriers only
-        for (int s = 0; s < nslot; s++) {
-            float4 y[SCAN_RV];
+        fetch(cc + PF * SCAN_DC, pre[ph]);
+        if (!has_queries) continue;  // wave without queries: staging + barriers only
+        const float* myrow = &stage[(vgi * SCAN_WAVE_VECS + lane) * LDS_ROW];
+        // operands of step s+1 (queries: scalar loads, vectors: LDS rows) are requested before step s is computed
+        const float4* qs = qtile + (size_t)(cc >> 2) * SCAN_RQ;
+        float4 qn[SCAN_RQ], yn[SCAN_RV];
 #pragma unroll
-            for (int v = 0; v < SCAN_RV; v++)
-                y[v] = *reinterpret_cast<const float4*>(myrow + v * 64 * LDS_ROW + s * 4);
+        for (int r = 0; r < SCAN_RQ; r++) qn[r] = qs[r];
+#pragma unroll
+        for (int v = 0; v < SCAN_RV; v++) yn[v] = *reinterpret_cast<const float4*>(myrow + v * 64 * LDS_ROW);
+#pragma unroll
+        for (int s = 0; s < SLOTS; s++) {
+            if (s >= nslot) break;  // partial last chunk (wave-uniform)
+            float4 qc[SCAN_RQ];
+            f2 ya[SCAN_RV], yb[SCAN_RV];  // elements (0,1) and (2,3) of the 4-wide step: sums 0,1 and 2,3
+#pragma unroll
+            for (int r = 0; r < SCAN_RQ; r++) qc[r] = qn[r];
+#pragma unroll
+            for (int v = 0; v < SCAN_RV; v++) {
+                ya[v] = f2{yn[v].x, yn[v].y};
+                yb[v] = f2{yn[v].z, yn[v].w};
+            }
+            if (s + 1 < nslot) {
+#pragma unroll
+                for (int v = 0; v < SCAN_RV; v++) yn[v] = *reinterpret_cast<const float4*>(myrow + v * 64 * LDS_ROW + (s + 1) * 4);
+#pragma unroll
+                for (int r = 0; r < SCAN_RQ; r++) qn[r] = qs[(s + 1) * SCAN_RQ + r];
+            }
 #pragma unroll
             for (int r = 0; r < SCAN_RQ; r++) {
-                const float4 q = *reinterpret_cast<const float4*>(qptr[r] + c0 + s * 4);
+                const f2 qa = f2{qc[r].x, qc[r].y}, qb = f2{qc[r].z, qc[r].w};
 #pragma unroll
                 for (int v = 0; v < SCAN_RV; v++) {
                     if (METRIC == METRIC_L2) {
-                        float t0 = y[v].x - q.x, t1 = y[v].y - q.y, t2 = y[v].z - q.z, t3 = y[v].w - q.w;
-                        acc[r][v][0] += t0 * t0;
-                        acc[r][v][1] += t1 * t1;
-                        acc[r][v][2] += t2 * t2;
-                        acc[r][v][3] += t3 * t3;
+                        const f2 ta = ya[v] - qa, tb = yb[v] - qb;
+                        if (FUSED) {  // products exactly representable: one rounding either way
+                            acc[r][v][0] = __builtin_elementwise_fma(ta, ta, acc[r][v][0]);
+                            acc[r][v][1] = __builtin_elementwise_fma(tb, tb, acc[r][v][1]);
+                        } else {
+                            acc[r][v][0] += ta * ta;
+                            acc[r][v][1] += tb * tb;
+                        }
+                    } else if (FUSED) {
+                        acc[r][v][0] = __builtin_elementwise_fma(ya[v], qa, acc[r][v][0]);
+                        acc[r][v][1] = __builtin_elementwise_fma(yb[v], qb, acc[r][v][1]);
                     } else {
-                        acc[r][v][0] += y[v].x * q.x;
-                        acc[r][v][1] += y[v].y * q.y;
-                        acc[r][v][2] += y[v].z * q.z;
-                        acc[r][v][3] += y[v].w * q.w;
+                        acc[r][v][0] += ya[v] * qa;
+                        acc[r][v][1] += yb[v] * qb;
                     }
                 }
             }
         }
+      }
     }
 
 #pragma unroll
@@ -112,19 +162,41 @@ __global__ __launch_bounds__(256) void scan_tiles_kernel(ScanArgs a) {
 #pragma unroll
             for (int v = 0; v < SCAN_RV; v++) {
                 int lv = vgi * SCAN_WAVE_VECS + v * 64 + lane;
-                if (lv < (int)it.nvec) out[lv] = (acc[r][v][0] + acc[r][v][1]) + (acc[r][v][2] + acc[r][v][3]);
+                if (lv < (int)it.nvec) out[lv] = (acc[r][v][0].x + acc[r][v][0].y) + (acc[r][v][1].x + acc[r][v][1].y);
             }
         }
     }
 }
 
+__global__ __launch_bounds__(256) void pack_queries_kernel(const float* queries, const uint32_t* pair_query, const uint32_t* group_p0,
+                                                           const uint32_t* group_cnt, int d, float* qtile) {
+    const uint32_t g = blockIdx.x;
+    const uint32_t p0 = group_p0[g], cnt = group_cnt[g];
+    float4* out = reinterpret_cast<float4*>(qtile + (size_t)g * d * SCAN_RQ);
+    const int nstep = d >> 2;
+    for (int idx = threadIdx.x; idx < nstep * SCAN_RQ; idx += 256) {
+        const int step = idx / SCAN_RQ, r = idx % SCAN_RQ;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((uint32_t)r < cnt) v = *reinterpret_cast<const float4*>(queries + (size_t)pair_query[p0 + r] * d + step * 4);
+        out[idx] = v;
+    }
+}
+
+void launch_pack_queries(const float* queries, const uint32_t* pair_query, const uint32_t* group_p0, const uint32_t* group_cnt,
+                         size_t ngroups, int d, float* qtile, hipStream_t s) {
+    if (ngroups) hipLaunchKernelGGL(pack_queries_kernel, dim3((unsigned)ngroups), dim3(256), 0, s, queries, pair_query, group_p0, group_cnt, d, qtile);
+}
+
 template <int QG> static void launch_scan_qg(ScanArgs a, size_t first, size_t n, hipStream_t s) {
     if (n == 0) return;
     a.items += first;
-    if (a.metric == METRIC_L2)
-        hipLaunchKernelGGL((scan_tiles_kernel<METRIC_L2, QG>), dim3((unsigned)n), dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL((scan_tiles_kernel<METRIC_IP, QG>), dim3((unsigned)n), dim3(256), 0, s, a);
+    if (a.metric == METRIC_L2) {
+        if (a.fused) hipLaunchKernelGGL((scan_tiles_kernel<METRIC_L2, QG, true>), dim3((unsigned)n), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((scan_tiles_kernel<METRIC_L2, QG, false>), dim3((unsigned)n), dim3(256), 0, s, a);
+    } else {
+        if (a.fused) hipLaunchKernelGGL((scan_tiles_kernel<METRIC_IP, QG, true>), dim3((unsigned)n), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((scan_tiles_kernel<METRIC_IP, QG, false>), dim3((unsigned)n), dim3(256), 0, s, a);
+    }
 }
 
 // items must be grouped by qg: first n_qg[0] items with qg 1, then n_qg[1] with qg 2, then n_qg[2] with qg 4
@@ -441,15 +513,18 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
                 st_nlist++;
                 const float* seg = a.dist + a.seg_off[(size_t)li * a.round_probes + p];
                 const int64_t refbase = REF_TAG | ((int64_t)key << 32);
-                for (uint32_t b0 = 0; b0 < n; b0 += 512) {
-                    float v[8];
+                // 2048 candidates per trip: 32 coalesced 256-B loads in flight per wave (the loop is
+                // latency-bound: one wave per query, a trip costs one HBM round trip)
+                constexpr int NLD = 32;
+                for (uint32_t b0 = 0; b0 < n; b0 += NLD * 64) {
+                    float v[NLD];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
+                    for (int u = 0; u < NLD; u++) {
                         const uint32_t j = b0 + u * 64 + lane;
-                        v[u] = j < n ? seg[j] : hneutral<IsMax>();
+                        v[u] = j < n ? __builtin_nontemporal_load(seg + j) : hneutral<IsMax>();
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
+                    for (int u = 0; u < NLD; u++) {
                         unsigned long long m = __ballot(hcmp<IsMax>(hval[0], v[u]));
                         while (m) {
                             const int l = __builtin_ctzll(m);

@@ -197,7 +197,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    scan_ms = scan_bytes = scan_launches = coarse_ms = select_ms = 0.0
+    scan_ms = scan_bytes = scan_launches = coarse_ms = select_ms = slot_eff = 0.0
     h.stats(reset=True)
     barrier()
     t0 = time.perf_counter()
@@ -209,6 +209,7 @@ def main():
         scan_launches += tm["scan_launches"]
         coarse_ms += tm["coarse_ms"]
         select_ms += tm["select_ms"]
+        slot_eff += tm["slot_efficiency"] / args.steps
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -255,6 +256,7 @@ def main():
             "algorithmic_bytes_per_launch": alg_bytes / max(scan_launches, 1),
             "computed_over_algorithmic": scan_bytes / alg_bytes if alg_bytes else None,
             "launches_per_step": scan_launches / args.steps,
+            "tile_slot_efficiency": slot_eff,
             "other_kernels_ms_per_step": {"coarse": coarse_ms / args.steps, "select": select_ms / args.steps},
         },
     }

@@ -148,8 +148,9 @@ int amd_ivf_merge_tables(int metric, size_t n, size_t k, size_t nshard, const fl
 
 /* ---- measurement hooks (bench.py): time of the kernels of the last search call, from HIP events
  *      recorded on the engine's own stream: {coarse_ms, scan_ms, select_ms, total_ms, scan_launches,
- *      scan_bytes_algorithmic} */
-int amd_ivf_last_timing(amd_ivf_t* h, double out[6]);
+ *      bytes of the distances the scan tiles computed (x d x 4), fraction of the computed (query, vector)
+ *      slots that were wanted pairs, select launches (= rounds x sub-batches)} */
+int amd_ivf_last_timing(amd_ivf_t* h, double out[8]);
 
 #ifdef __cplusplus
 }

@@ -23,4 +23,4 @@ for k in (10, 100):
             if best is None or dt < best[0]: best = (dt, tm)
         dt, tm = best
         print(f"k {k} nprobe {nprobe}: qps {nq/dt:.0f} wall {dt*1e3:.2f}ms scan {tm['scan_ms']:.2f} select {tm['select_ms']:.2f} coarse {tm['coarse_ms']:.2f} "
-              f"scan GB/s {tm['scan_bytes']/1e6/max(tm['scan_ms'],1e-9):.0f} Gdist/s {tm['scan_bytes']/512/1e6/max(tm['scan_ms'],1e-9):.1f}", flush=True)
+              f"slot_eff {tm['slot_efficiency']:.3f} scan GB/s {tm['scan_bytes']/1e6/max(tm['scan_ms'],1e-9):.0f} Gdist/s {tm['scan_bytes']/512/1e6/max(tm['scan_ms'],1e-9):.1f}", flush=True)

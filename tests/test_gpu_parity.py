@@ -206,3 +206,23 @@ def test_trace_training_samples(capi, oracle, name):
     assert np.array_equal(bits(D), bits(eD))
     for i in range(ntr):
         assert np.array_equal(bits(raw[i]), bits(exp_raw[i])), i
+
+
+def test_fused_path_is_bit_identical(capi, monkeypatch):
+    """integer-valued operands (|v| <= 4095): the engine switches the scan to fma(t, t, acc); every
+    product is exactly representable there, so results must not change by a single bit (and they are
+    compared with the reference's goldens by the tests above as well)"""
+    case, gold = load_case("fixed_sift_l2")
+    h1 = make_index(capi, case, gold)
+    monkeypatch.setenv("AUNCEL_AMD_NO_FUSED", "1")
+    h2 = make_index(capi, case, gold)
+    monkeypatch.delenv("AUNCEL_AMD_NO_FUSED")
+    for k in (10, 100):
+        D1, I1 = h1.search(case["xq"], k, case["nprobe"])
+        D2, I2 = h2.search(case["xq"], k, case["nprobe"])
+        assert np.array_equal(I1, I2) and np.array_equal(bits(D1), bits(D2))
+    # values outside the exact range switch it off again: same index, queries scaled by 1000
+    xq = case["xq"] * np.float32(1000.0)
+    D1, I1 = h1.search(xq, 10, case["nprobe"])
+    D2, I2 = h2.search(xq, 10, case["nprobe"])
+    assert np.array_equal(I1, I2) and np.array_equal(bits(D1), bits(D2))
