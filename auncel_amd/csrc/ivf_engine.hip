@@ -830,7 +830,7 @@ void run_rounds(amd_ivf* h, RoundSpec& base, size_t n, size_t first_round, size_
             if (base.tuner.enabled) {
                 // an unfired query at stage s cannot stop before floor((s+1) * multipler): that many probes
                 // are waste-free; beyond it allow growth-1 of over-scan to keep the number of rounds small
-                static const double grow_env = getenv("AUNCEL_AMD_ROUND_GROW") ? atof(getenv("AUNCEL_AMD_ROUND_GROW")) : 2.0;
+                static const double grow_env = getenv("AUNCEL_AMD_ROUND_GROW") ? atof(getenv("AUNCEL_AMD_ROUND_GROW")) : 2.5;
                 const double grow = std::max<double>(base.tuner.multipler, grow_env);
                 const size_t safe = (size_t)((float)(stage[i] + 1) * base.tuner.multipler);
                 target = std::max<size_t>({safe, (size_t)(stage[i] * grow), stage[i] + first_round});
@@ -1315,6 +1315,8 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
     coarse_dev(L, d_x, n, nlist, coarse_mode, L->w_cdis.as<float>(), L->w_ckeys.as<int64_t>(),
                ix(L)->allow_fused && ix(L)->centroid_range.fusable_with(qr));
     init_state(L, n, K, true);
+    launch_set_online(L->metric, (uint32_t)nlist, (uint32_t)n, L->w_cdis.as<float>(), L->w_ckeys.as<int64_t>(), (uint32_t)nlist,
+                      ix(L)->d_interdis.as<float>(), ix(L)->d_arcos.as<float>(), L->w_dtb.as<float>(), L->w_error.as<uint32_t>(), L->stream);
     RoundSpec base;
     base.fused = ix(L)->allow_fused && ix(L)->db_range.fusable_with(qr);
     base.k = (int)K;
@@ -1324,7 +1326,8 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
     base.d_ckeys = L->w_ckeys.as<int64_t>();
     base.coarse_stride = (uint32_t)nlist;
     base.tuner = make_tuner(L, query_topk, multipler, std_m, dreq, dgt, dnp, dtr, profile);
-    run_rounds(L, base, n, 4, nlist, dnp, id0);
+    static const size_t first_env = getenv("AUNCEL_AMD_ROUND_FIRST") ? (size_t)atoi(getenv("AUNCEL_AMD_ROUND_FIRST")) : 12;
+    run_rounds(L, base, n, first_env, nlist, dnp, id0);
     HIP_CHECK(hipMemcpyAsync(D, L->w_D.p, n * K * 4, hipMemcpyDeviceToHost, L->stream));
     HIP_CHECK(hipMemcpyAsync(I, L->w_I.p, n * K * 8, hipMemcpyDeviceToHost, L->stream));
     HIP_CHECK(hipStreamSynchronize(L->stream));
@@ -1493,6 +1496,8 @@ static void train_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n, s
     coarse_dev(h, d_x, n, nlist, coarse_mode, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>(),
                h->allow_fused && h->centroid_range.fusable_with(qr));
     init_state(h, n, K, true);
+    launch_set_online(h->metric, (uint32_t)nlist, (uint32_t)n, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>(), (uint32_t)nlist,
+                      h->d_interdis.as<float>(), h->d_arcos.as<float>(), h->w_dtb.as<float>(), h->w_error.as<uint32_t>(), h->stream);
     RoundSpec base;
     base.fused = h->allow_fused && h->db_range.fusable_with(qr);
     base.k = (int)K;

@@ -124,6 +124,10 @@ struct ReplayArgs {
 
 void launch_replay(const ReplayArgs& a, hipStream_t s);
 
+// error_pro::set_online for nq queries: dtb[q][nlist/8+20] from the full coarse ranking (before round 0)
+void launch_set_online(int metric, uint32_t nlist, uint32_t nq, const float* coarse_dis, const int64_t* coarse_keys,
+                       uint32_t coarse_stride, const float* interdis, const float* arcos, float* dtb, uint32_t* error, hipStream_t s);
+
 constexpr uint32_t ERR_ARCOS_DOMAIN = 1;
 constexpr uint32_t ERR_COSINE_PRECOND = 2;
 constexpr uint32_t ERR_INVALID_KEY = 3;

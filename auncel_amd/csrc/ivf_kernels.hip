@@ -216,7 +216,8 @@ constexpr int64_t REF_TAG = 1ll << 62;
 template <bool IsMax> __device__ __forceinline__ bool hcmp(float a, float b) { return IsMax ? a > b : a < b; }
 template <bool IsMax> __device__ __forceinline__ float hneutral() { return IsMax ? FLT_MAX : -FLT_MAX; }
 
-// Heap.h:88-118 -- executed redundantly by every lane of the wave (uniform control flow)
+// Heap.h:88-118 -- executed redundantly by every lane of the wave (uniform control flow).  Both children's
+// value and id are requested together so that a level costs one LDS round trip.
 template <bool IsMax> __device__ inline void heap_pop(int k, float* val, int64_t* ref) {
     val--;
     ref--;
@@ -225,19 +226,15 @@ template <bool IsMax> __device__ inline void heap_pop(int k, float* val, int64_t
     for (;;) {
         const int i1 = i << 1, i2 = i1 + 1;
         if (i1 > k) break;
-        const float c1 = val[i1];
-        if (i2 == k + 1 || hcmp<IsMax>(c1, val[i2])) {
-            if (hcmp<IsMax>(v, c1)) break;
-            val[i] = c1;
-            ref[i] = ref[i1];
-            i = i1;
-        } else {
-            const float c2 = val[i2];
-            if (hcmp<IsMax>(v, c2)) break;
-            val[i] = c2;
-            ref[i] = ref[i2];
-            i = i2;
-        }
+        const int j2 = i2 <= k ? i2 : i1;  // i2 == k + 1: there is no right child
+        const float c1 = val[i1], c2 = val[j2];
+        const int64_t r1 = ref[i1], r2 = ref[j2];
+        const bool left = (i2 == k + 1) || hcmp<IsMax>(c1, c2);
+        const float c = left ? c1 : c2;
+        if (hcmp<IsMax>(v, c)) break;
+        val[i] = c;
+        ref[i] = left ? r1 : r2;
+        i = left ? i1 : i2;
     }
     val[i] = val[k];
     ref[i] = ref[k];
@@ -291,12 +288,13 @@ __device__ inline float cosine_theorem_dev(float a, float b, float c, uint32_t* 
     return c / 2 - temp;
 }
 
-// Trace::search (IVF_pro.cpp:84-107)
-__device__ inline float trace_search(const float* x, const float* y, const float* sd, uint32_t n, float k, float sc) {
-    if (k <= x[0]) return y[0] + sc * sd[0];
+// Trace::search (IVF_pro.cpp:84-107); z[i] = y[i] + std_m * sd[i] is formed once per cached trace with the
+// reference's own expression, so every return value is the same fp32 number
+__device__ inline float trace_search(const float* x, const float* z, uint32_t n, float k) {
+    if (k <= x[0]) return z[0];
     if (k >= x[n - 1]) {
         const float ampli = k / x[n - 1];
-        return (y[n - 1] + sc * sd[n - 1]) * ampli;
+        return z[n - 1] * ampli;
     }
     unsigned long long high = n - 1, low = 0, middle = 0;
     while (low <= high) {
@@ -305,7 +303,7 @@ __device__ inline float trace_search(const float* x, const float* y, const float
         else high = middle - 1;
     }
     if (x[low] > k) low--;
-    return y[low] + sc * sd[low];
+    return z[low];
 }
 
 // kscaling (IVF_pro.cpp:72-82)
@@ -337,6 +335,29 @@ __device__ inline void set_online_dev(int metric, uint32_t nlist, const float* c
         // the reference converts all max_num coarse values up front (IVF_pro.cpp:208-211)
         for (uint32_t k = lane; k < max_num; k += 64) (void)arcos_lut(lut, cd[k], err);
     }
+}
+
+// one wave per query: disToBoundary rows for a batch of queries (run once, before the first round)
+__global__ __launch_bounds__(256) void set_online_kernel(int metric, uint32_t nlist, uint32_t nq, const float* coarse_dis,
+                                                         const int64_t* coarse_keys, uint32_t coarse_stride, const float* interdis,
+                                                         const float* arcos, float* dtb, uint32_t* error) {
+    __shared__ float lut[500];
+    for (int i = threadIdx.x; i < 500; i += 256) lut[i] = arcos[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint32_t qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= nq) return;
+    uint32_t err = 0;
+    set_online_dev(metric, nlist, coarse_dis + (size_t)qi * coarse_stride, coarse_keys + (size_t)qi * coarse_stride, interdis, lut,
+                   dtb + (size_t)qi * (nlist / 8 + 20), lane, &err);
+    err = wave_max_u32(err);
+    if (err && lane == 0) atomicMax(error, err);
+}
+
+void launch_set_online(int metric, uint32_t nlist, uint32_t nq, const float* coarse_dis, const int64_t* coarse_keys,
+                       uint32_t coarse_stride, const float* interdis, const float* arcos, float* dtb, uint32_t* error, hipStream_t s) {
+    if (nq) hipLaunchKernelGGL(set_online_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, metric, nlist, nq, coarse_dis, coarse_keys,
+                               coarse_stride, interdis, arcos, dtb, error);
 }
 
 // best-first sort of the heap values into srt by ranking (values only matter)
@@ -372,10 +393,10 @@ template <bool IsMax> __device__ inline void sorted_replace_worst(float* srt, in
 
 // error_pro::sum_angle (IVF_pro.cpp:162-177), n = 15: the 15 terms on 15 lanes, then summed in the
 // reference's order (a skipped term adds +0, which leaves the non-negative running sum unchanged)
-__device__ inline float sum_angle_par(const float* lut, float kdis, const float* dtb, uint32_t start, int lane, uint32_t* err) {
+__device__ inline float sum_angle_par(const float* lut, float kdis, const float* dwin, int lane, uint32_t* err) {
     float t = 0.f;
     if (lane < 15) {
-        const float b = dtb[start + lane];
+        const float b = dwin[lane];  // the 15 boundary distances of this stage (window of disToBoundary)
         if (!(b >= kdis)) t = arcos_lut(lut, b / kdis, err);
     }
     float sum = 0.f;
@@ -385,26 +406,25 @@ __device__ inline float sum_angle_par(const float* lut, float kdis, const float*
 }
 
 struct TraceLds {
-    const float *x, *y, *sd;
+    const float *x, *z;
     uint32_t n;
 };
 
 // error_pro::cur_num (IVF_pro.cpp:258-291); Ds(m) = m-th best value (IP: its arcos)
 template <bool IsMax>
-__device__ inline uint32_t cur_num_lds(const TraceLds& tr, const float* lut, const float* srt, const float* dtb, uint32_t index,
-                                       uint32_t query_topk, float std_m, int lane, uint32_t* err) {
-    const uint32_t start = (1u << index) - 1;
+__device__ inline uint32_t cur_num_lds(const TraceLds& tr, const float* lut, const float* srt, const float* dwin,
+                                       uint32_t query_topk, int lane, uint32_t* err) {
     const unsigned long long query_k = query_topk;
     unsigned long long high = query_k - 1, low = 0, middle = 0;
     auto Ds = [&](unsigned long long m) { return IsMax ? srt[m] : arcos_lut(lut, srt[m], err); };
     {
-        const float g = trace_search(tr.x, tr.y, tr.sd, tr.n, sum_angle_par(lut, Ds(high), dtb, start, lane, err), std_m);
+        const float g = trace_search(tr.x, tr.z, tr.n, sum_angle_par(lut, Ds(high), dwin, lane, err));
         if ((double)((float)query_k * g) <= (double)query_k * 1.005) return (uint32_t)query_k;
     }
     while (low <= high) {
         middle = (low + high) / 2;
         if (middle <= 0) return 0;
-        const float g = trace_search(tr.x, tr.y, tr.sd, tr.n, sum_angle_par(lut, Ds(middle), dtb, start, lane, err), std_m);
+        const float g = trace_search(tr.x, tr.z, tr.n, sum_angle_par(lut, Ds(middle), dwin, lane, err));
         if ((float)(middle + 1) * g <= (float)query_k) low = middle + 1;
         else high = middle - 1;
     }
@@ -412,9 +432,10 @@ __device__ inline uint32_t cur_num_lds(const TraceLds& tr, const float* lut, con
 }
 
 __host__ __device__ inline size_t replay_wave_bytes(int k, uint32_t nlist, bool geo, bool tune, bool train, uint32_t trace_cap) {
+    (void)nlist;
     size_t b = (size_t)k * 16;                       // href | hval | srt
-    if (geo) b += (size_t)(nlist / 8 + 20) * 4;      // dtb
-    if (tune) b += (size_t)trace_cap * 12;           // cached trace (x | y | std)
+    if (geo) b += 16 * 4 + 16 * 4;                   // window of disToBoundary | values inserted during the current probe
+    if (tune) b += (size_t)trace_cap * 8;            // cached trace (x | z)
     if (train) b += (size_t)k * 4;                   // ground-truth row
     return (b + 15) & ~(size_t)15;
 }
@@ -445,9 +466,11 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
     int64_t* href = reinterpret_cast<int64_t*>(base);
     float* hval = reinterpret_cast<float*>(base + (size_t)k * 8);
     float* srt = hval + k;
-    float* dtb = srt + k;                                  // geo only
-    float* trc = dtb + (geo ? max_num : 0);                // tune only: x | y | std, trace_cap each
-    float* gtrow = trc + (tune ? 3 * a.trace_cap : 0);     // training only
+    float* dwin = srt + k;                                 // geo only: 16 boundary distances of the current stage
+    float* pend = dwin + (geo ? 16 : 0);                   // geo only: values inserted during the current probe
+    float* trc = pend + (geo ? 16 : 0);                    // tune only: x | z, trace_cap each
+    float* gtrow = trc + (tune ? 2 * a.trace_cap : 0);     // training only
+    const float* gdtb = geo ? a.dtb + (size_t)qi * max_num : nullptr;  // disToBoundary (set_online_kernel)
 
     for (int i = lane; i < k; i += 64) {
         hval[i] = a.heap_val[(size_t)qi * k + i];
@@ -464,17 +487,8 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
     uint32_t stoped = a.stoped ? a.stoped[qi] : 0u;
     unsigned long long st_nlist = 0, st_nheap = 0, st_ndis = 0;
 
+    int win_start = -1;
     if (geo) {
-        float* gdtb = a.dtb + (size_t)qi * max_num;
-        if (ik0 == 0) {
-            set_online_dev(a.metric, nlist, a.coarse_dis + (size_t)qi * a.coarse_stride,
-                           a.coarse_keys + (size_t)qi * a.coarse_stride, tune ? a.tuner.interdis : a.train.interdis, lut,
-                           dtb, lane, &err);
-            wave_sync();
-            for (uint32_t i = lane; i < max_num; i += 64) gdtb[i] = dtb[i];
-        } else {
-            for (uint32_t i = lane; i < max_num; i += 64) dtb[i] = gdtb[i];
-        }
         rank_sort_best_first<IsMax>(hval, srt, k, lane);
         if (training) {
             const float* gt = a.train.gt_D + id_q * (unsigned long long)k;
@@ -487,7 +501,7 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
     float true_KD_K = 0.f, racc = 0.f;
     unsigned long long np = 0;
     int cached_ind = -1;
-    TraceLds tr{trc, trc + a.trace_cap, trc + 2 * a.trace_cap, 0};
+    TraceLds tr{trc, trc + a.trace_cap, 0};
     if (tune) {
         query_k = a.tuner.query_topk;
         if (a.tuner.gt_D) true_KD_K = a.tuner.gt_D[id_q * (unsigned long long)k + query_k - 1];
@@ -513,6 +527,7 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
                 st_nlist++;
                 const float* seg = a.dist + a.seg_off[(size_t)li * a.round_probes + p];
                 const int64_t refbase = REF_TAG | ((int64_t)key << 32);
+                uint32_t npend = 0;
                 // 2048 candidates per trip: 32 coalesced 256-B loads in flight per wave (the loop is
                 // latency-bound: one wave per query, a trip costs one HBM round trip)
                 constexpr int NLD = 32;
@@ -534,9 +549,21 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
                                 heap_pop<IsMax>(k, hval, href);
                                 heap_push<IsMax>(k, hval, href, val, refbase | (int64_t)(b0 + u * 64 + l));
                                 st_nheap++;
-                                if (geo) sorted_replace_worst<IsMax>(srt, k, val, lane);
+                                if (geo) {  // the sorted view is only read at the end of the probe: defer
+                                    if (npend < 16) pend[npend] = val;
+                                    npend++;
+                                }
                             }
                         }
+                    }
+                }
+                if (geo && npend) {
+                    wave_sync();
+                    if (npend <= 16) {
+                        for (uint32_t u = 0; u < npend; u++) sorted_replace_worst<IsMax>(srt, k, pend[u], lane);
+                    } else {
+                        rank_sort_best_first<IsMax>(hval, srt, k, lane);
+                        wave_sync();
                     }
                 }
                 nscan += n;
@@ -560,11 +587,12 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
                 while (tmp_stage > (1u << ind)) ind++;
                 if ((int)ind != cached_ind) {
                     const uint32_t o = a.tuner.trace_off[ind], n = a.tuner.trace_off[ind + 1] - o;
+                    const float sc = a.tuner.std_m;
                     for (uint32_t i = lane; i < n; i += 64) {
                         trc[i] = a.tuner.trace_x[o + i];
-                        trc[a.trace_cap + i] = a.tuner.trace_y[o + i];
-                        trc[2 * a.trace_cap + i] = a.tuner.trace_std[o + i];
+                        trc[a.trace_cap + i] = a.tuner.trace_y[o + i] + sc * a.tuner.trace_std[o + i];
                     }
+                    if (lane < 15) dwin[lane] = gdtb[(1u << ind) - 1 + lane];  // sum_angle start = 2^ind - 1
                     tr.n = n;
                     cached_ind = (int)ind;
                     wave_sync();
@@ -578,7 +606,7 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
                         break;
                     }
                 }
-                const uint32_t pre_num = cur_num_lds<IsMax>(tr, lut, srt, dtb, ind, query_k, a.tuner.std_m, lane, &err);
+                const uint32_t pre_num = cur_num_lds<IsMax>(tr, lut, srt, dwin, query_k, lane, &err);
                 float recall = (float)pre_num / (float)query_k;
                 const float max_val = IsMax ? fmaxf(-1.f, srt[k - 1]) : fminf(FLT_MAX, srt[k - 1]);
                 const unsigned long long stops = (unsigned long long)(racc * 12);
@@ -621,6 +649,12 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
                 uint32_t ind = 0;
                 while (stage != (1u << ind)) ind++;
                 float* out = a.train.raw[ind] + 2ull * (id_q * (unsigned long long)(k / 4));
+                if (win_start != (int)(stage - 1)) {
+                    wave_sync();
+                    if (lane < 15) dwin[lane] = gdtb[stage - 1 + lane];
+                    win_start = (int)(stage - 1);
+                    wave_sync();
+                }
                 uint32_t count = 0;
                 for (int ij = 0; ij < k; ij++) {
                     const float dv = srt[ij];  // L2 ascending / IP descending, as the reference walks them
@@ -628,7 +662,7 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
                     if (ks < 0) break;
                     float tval = dv;
                     if (!IsMax) tval = arcos_lut(lut, tval, &err);
-                    const float sum_a = sum_angle_par(lut, tval, dtb, stage - 1, lane, &err);
+                    const float sum_a = sum_angle_par(lut, tval, dwin, lane, &err);
                     if (lane == 0) {
                         out[2 * count] = sum_a;
                         out[2 * count + 1] = ks;
