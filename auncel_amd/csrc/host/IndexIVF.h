@@ -57,6 +57,9 @@ struct IndexIVF : Index, Level1Quantizer {
     int parallel_mode;
     bool maintain_direct_map;
     std::vector<idx_t> direct_map;
+    /// coarse quantisation inside search(): -1 = the reference's switch (exact kernel below 20 queries, GEMM
+    /// formulation on the matrix cores from 20 on, utils.cpp:644-655), 0 = always exact, 1 = always GEMM
+    int coarse_mode = -1;
 
     IndexIVF(Index* quantizer, size_t d, size_t nlist, size_t code_size, MetricType metric = METRIC_L2);
     IndexIVF();

@@ -438,14 +438,14 @@ void IndexIVF::search(idx_t n, const float* x, idx_t k, float* distances, idx_t*
         return;
     }
     sync_engine(false);
-    AMD(amd_ivf_search(gpu_, (size_t)n, x, (size_t)k, nprobe, -1, distances, i64(labels)));
+    AMD(amd_ivf_search(gpu_, (size_t)n, x, (size_t)k, nprobe, coarse_mode, distances, i64(labels)));
     fold_stats();
 }
 
 void IndexIVF::search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels, size_t offset) const {
     if (!tune && !training) {
         sync_engine(false);
-        AMD(amd_ivf_search(gpu_, (size_t)n, x, (size_t)k, nprobe, -1, distances, i64(labels)));
+        AMD(amd_ivf_search(gpu_, (size_t)n, x, (size_t)k, nprobe, coarse_mode, distances, i64(labels)));
         fold_stats();
         return;
     }
@@ -459,9 +459,9 @@ void IndexIVF::search(idx_t n, const float* x, idx_t k, float* distances, idx_t*
         std::vector<float*> raw(t->traces.size());
         for (size_t i = 0; i < raw.size(); i++) raw[i] = &t->traces[i].trace[0].first;
         if (resident)
-            AMD(amd_ivf_train_samples(gpu_, offset, (size_t)n, (size_t)k, t->train_D, t->train_num, -1, raw.data(), distances, i64(labels)));
+            AMD(amd_ivf_train_samples(gpu_, offset, (size_t)n, (size_t)k, t->train_D, t->train_num, coarse_mode, raw.data(), distances, i64(labels)));
         else
-            AMD(amd_ivf_train_samples_x(gpu_, (size_t)n, x, offset, (size_t)k, t->train_D, t->train_num, -1, raw.data(), distances, i64(labels)));
+            AMD(amd_ivf_train_samples_x(gpu_, (size_t)n, x, offset, (size_t)k, t->train_D, t->train_num, coarse_mode, raw.data(), distances, i64(labels)));
         return;
     }
     sync_engine(true);
@@ -469,10 +469,10 @@ void IndexIVF::search(idx_t n, const float* x, idx_t k, float* distances, idx_t*
     uint64_t* np = reinterpret_cast<uint64_t*>(t->my_nprobe);
     if (resident)
         AMD(amd_ivf_search_adaptive(gpu_, offset, (size_t)n, t->query_topk, t->multipler, t->std_m, t->require_acc, t->train_D,
-                                    t->profile ? 1 : 0, -1, np, t->t_recalls, distances, i64(labels)));
+                                    t->profile ? 1 : 0, coarse_mode, np, t->t_recalls, distances, i64(labels)));
     else
         AMD(amd_ivf_search_adaptive_x(gpu_, (size_t)n, x, offset, t->query_topk, t->multipler, t->std_m, t->require_acc, t->train_D,
-                                      t->profile ? 1 : 0, -1, np, t->t_recalls, distances, i64(labels)));
+                                      t->profile ? 1 : 0, coarse_mode, np, t->t_recalls, distances, i64(labels)));
     fold_stats();
 }
 

@@ -8,6 +8,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -164,7 +165,7 @@ struct amd_ivf {
     std::vector<std::vector<int64_t>> h_ids;
     std::vector<uint64_t> h_list_off;
     bool lists_dirty = true;
-    DevBuf d_codes, d_ids, d_list_off, d_centroids;
+    DevBuf d_codes, d_ids, d_list_off, d_centroids, d_centroid_norms;
     std::vector<float> h_centroids;  // nlist x dpad
     bool have_centroids = false;
 
@@ -182,13 +183,14 @@ struct amd_ivf {
     bool have_tuner = false;
 
     // workspaces (grow only)
-    DevBuf w_qtile, w_group_p0, w_group_cnt;
+    DevBuf w_qtile, w_group_p0, w_group_cnt, w_xnorms;
     PinnedBuf p_group_p0, p_group_cnt;
     DevBuf w_x, w_dist, w_items, w_pair_query, w_pair_out, w_seg_off, w_seg_list, w_seg_count, w_qsel;
     DevBuf w_heap_val, w_heap_ref, w_stage, w_nscan, w_done, w_pre_val, w_stoped, w_dtb, w_D, w_I;
     DevBuf w_cdis, w_ckeys, w_stats, w_error, w_misc, w_misc2, w_misc3, w_rawptrs;
     DevBuf c_heap_val, c_heap_ref, c_stage, c_nscan, c_done, c_seg_off, c_seg_list, c_seg_count;
-    PinnedBuf p_items, p_pair_query, p_pair_out, p_seg_off, p_seg_list, p_seg_count, p_qsel;
+    PinnedBuf p_items, p_pair_query, p_pair_out, p_seg_off, p_seg_list, p_seg_count, p_qsel, p_seg_begin;
+    DevBuf w_seg_begin;
 
     size_t dist_budget_floats = (size_t)768 << 20;  // 3 GiB of distances per scan launch
     size_t stats_host[4] = {0, 0, 0, 0};
@@ -201,9 +203,17 @@ struct amd_ivf {
     // slice's latency-bound selection and host-side round planning overlap another slice's VALU-bound scan.
     amd_ivf* parent = nullptr;
     std::vector<std::unique_ptr<amd_ivf>> kids;
+    // side streams for the sparse tile shapes of a round (fork / join around the dense launch)
+    hipStream_t aux[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
 
     ~amd_ivf() {
         kids.clear();
+        for (int i = 0; i < 2; i++) {
+            if (aux[i]) (void)hipStreamDestroy(aux[i]);
+            if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
+        }
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -341,9 +351,16 @@ struct RoundSpec {
     int fused = 0;
 };
 
+static bool dbg_timing() {
+    static const bool on = getenv("AUNCEL_AMD_DEBUG_TIMING") != nullptr;
+    return on;
+}
+static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 void exec_round(amd_ivf* h, const RoundSpec& r) {
     const size_t m = r.slot.size();
     if (m == 0) return;
+    const double t_enter = now_us();
     const size_t nlist = h->nlist;
     const std::vector<uint64_t>& off = ix(h)->h_list_off;
     size_t q0 = 0;
@@ -366,36 +383,44 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
             q1++;
         }
         const size_t mb = q1 - q0;
-        if (rp == 0) rp = 1;
-        // ---- segments (query-major distance rows) and pairs grouped by list
-        h->p_seg_off.ensure(mb * rp * 8);
-        h->p_seg_list.ensure(mb * rp * 4);
+        (void)rp;
+        // ---- segments (query-major distance rows, CSR over the queries) and pairs grouped by list
+        size_t nseg = 0;
+        for (size_t i = 0; i < mb; i++) nseg += r.cnt[q0 + i];
+        h->p_seg_off.ensure(std::max<size_t>(nseg, 1) * 8);
+        h->p_seg_list.ensure(std::max<size_t>(nseg, 1) * 4);
         h->p_seg_count.ensure(mb * 4);
+        h->p_seg_begin.ensure(mb * 4);
         h->p_qsel.ensure(mb * 4);
         uint64_t* seg_off = h->p_seg_off.as<uint64_t>();
         int32_t* seg_list = h->p_seg_list.as<int32_t>();
         uint32_t* seg_count = h->p_seg_count.as<uint32_t>();
+        uint32_t* seg_begin = h->p_seg_begin.as<uint32_t>();
         uint32_t* qsel = h->p_qsel.as<uint32_t>();
         std::fill(lcount.begin(), lcount.end(), 0u);
         size_t npairs = 0;
         uint64_t cursor = 0;
         double bytes = 0;
-        for (size_t i = 0; i < mb; i++) {
-            const size_t qi = q0 + i;
-            seg_count[i] = r.cnt[qi];
-            qsel[i] = r.slot[qi];
-            for (uint32_t p = 0; p < rp; p++) {
-                int64_t key = -1;
-                if (p < r.cnt[qi]) key = r.keys[(size_t)r.slot[qi] * r.key_stride + r.p0[qi] + p];
-                seg_list[i * rp + p] = (int32_t)key;
-                seg_off[i * rp + p] = cursor;
-                if (key >= 0) {
-                    size_t sz = off[key + 1] - off[key];
-                    if (sz) {
-                        lcount[key + 1]++;
-                        npairs++;
-                        cursor += sz;
-                        bytes += (double)sz * h->d * 4.0;
+        {
+            uint32_t sp = 0;
+            for (size_t i = 0; i < mb; i++) {
+                const size_t qi = q0 + i;
+                seg_count[i] = r.cnt[qi];
+                seg_begin[i] = sp;
+                qsel[i] = r.slot[qi];
+                const int64_t* kq = r.keys + (size_t)r.slot[qi] * r.key_stride + r.p0[qi];
+                for (uint32_t p = 0; p < r.cnt[qi]; p++, sp++) {
+                    const int64_t key = kq[p];
+                    seg_list[sp] = (int32_t)key;
+                    seg_off[sp] = cursor;
+                    if (key >= 0) {
+                        const size_t sz = off[key + 1] - off[key];
+                        if (sz) {
+                            lcount[key + 1]++;
+                            npairs++;
+                            cursor += sz;
+                            bytes += (double)sz * h->d * 4.0;
+                        }
                     }
                 }
             }
@@ -410,12 +435,13 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
             std::vector<uint32_t> fill(lcount.begin(), lcount.end() - 1);
             for (size_t i = 0; i < mb; i++) {
                 const size_t qi = q0 + i;
+                const uint32_t sb = seg_begin[i];
                 for (uint32_t p = 0; p < r.cnt[qi]; p++) {
-                    int32_t key = seg_list[i * rp + p];
+                    int32_t key = seg_list[sb + p];
                     if (key < 0 || off[key + 1] == off[key]) continue;
                     uint32_t pos = fill[key]++;
                     pair_query[pos] = r.slot[qi];
-                    pair_out[pos] = seg_off[i * rp + p];
+                    pair_out[pos] = seg_off[sb + p];
                 }
             }
         }
@@ -479,23 +505,28 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
         }
         // ---- upload + launch
         h->w_dist.ensure(std::max<uint64_t>(cursor, 1) * sizeof(float));
-        h->w_seg_off.ensure(mb * rp * 8);
-        h->w_seg_list.ensure(mb * rp * 4);
+        h->w_seg_off.ensure(std::max<size_t>(nseg, 1) * 8);
+        h->w_seg_list.ensure(std::max<size_t>(nseg, 1) * 4);
         h->w_seg_count.ensure(mb * 4);
+        h->w_seg_begin.ensure(mb * 4);
         h->w_qsel.ensure(mb * 4);
         h->w_pair_query.ensure(std::max<size_t>(npairs, 1) * 4);
         h->w_pair_out.ensure(std::max<size_t>(npairs, 1) * 8);
         h->w_items.ensure(std::max<size_t>(nitems, 1) * sizeof(ScanItem));
         hipStream_t s = h->stream;
-        HIP_CHECK(hipMemcpyAsync(h->w_seg_off.p, seg_off, mb * rp * 8, hipMemcpyHostToDevice, s));
-        HIP_CHECK(hipMemcpyAsync(h->w_seg_list.p, seg_list, mb * rp * 4, hipMemcpyHostToDevice, s));
+        if (nseg) {
+            HIP_CHECK(hipMemcpyAsync(h->w_seg_off.p, seg_off, nseg * 8, hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipMemcpyAsync(h->w_seg_list.p, seg_list, nseg * 4, hipMemcpyHostToDevice, s));
+        }
         HIP_CHECK(hipMemcpyAsync(h->w_seg_count.p, seg_count, mb * 4, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(h->w_seg_begin.p, seg_begin, mb * 4, hipMemcpyHostToDevice, s));
         HIP_CHECK(hipMemcpyAsync(h->w_qsel.p, qsel, mb * 4, hipMemcpyHostToDevice, s));
         if (npairs) {
             HIP_CHECK(hipMemcpyAsync(h->w_pair_query.p, pair_query, npairs * 4, hipMemcpyHostToDevice, s));
             HIP_CHECK(hipMemcpyAsync(h->w_pair_out.p, pair_out, npairs * 8, hipMemcpyHostToDevice, s));
             HIP_CHECK(hipMemcpyAsync(h->w_items.p, items, nitems * sizeof(ScanItem), hipMemcpyHostToDevice, s));
         }
+        const double t_prep = now_us();
         if (npairs) pack_query_tiles(h, r.d_x, qranges);
         ScanArgs sa{};
         sa.qtile = h->w_qtile.as<float>();
@@ -509,8 +540,26 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
         sa.metric = h->metric;
         sa.fused = r.fused;
         if (nitems) {
+            if (!h->aux[0]) {
+                for (int i = 0; i < 2; i++) {
+                    HIP_CHECK(hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
+                    HIP_CHECK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+                }
+                HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            }
             size_t t = h->timer.begin(CAT_SCAN, s);
-            launch_scan(sa, n_qg, s);
+            const bool fork = (n_qg[0] || n_qg[1]) && n_qg[2];
+            if (fork) {
+                HIP_CHECK(hipEventRecord(h->ev_fork, s));
+                for (int i = 0; i < 2; i++) HIP_CHECK(hipStreamWaitEvent(h->aux[i], h->ev_fork, 0));
+                launch_scan(sa, n_qg, s, h->aux[0], h->aux[1]);
+                for (int i = 0; i < 2; i++) {
+                    HIP_CHECK(hipEventRecord(h->ev_join[i], h->aux[i]));
+                    HIP_CHECK(hipStreamWaitEvent(s, h->ev_join[i], 0));
+                }
+            } else {
+                launch_scan(sa, n_qg, s);
+            }
             h->timer.end(t, s);
         }
         ReplayArgs ra{};
@@ -520,7 +569,8 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
         ra.nq = (uint32_t)mb;
         ra.qsel = h->w_qsel.as<uint32_t>();
         ra.total_nprobe = r.total_nprobe;
-        ra.round_probes = rp;
+        ra.round_probes = 0;
+        ra.seg_begin = h->w_seg_begin.as<uint32_t>();
         ra.id_offset = r.id_offset;
         ra.dist = h->w_dist.as<float>();
         ra.seg_off = h->w_seg_off.as<uint64_t>();
@@ -551,13 +601,36 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
         ra.raw_heap_out = r.raw_heap_out;
         ra.tuner = r.tuner;
         ra.train = r.train;
+        static const bool dbg_replay = getenv("AUNCEL_AMD_DEBUG_REPLAY") != nullptr;
+        if (dbg_replay) {
+            h->w_misc.ensure(mb * 32);
+            ra.dbg = h->w_misc.as<unsigned long long>();
+        }
         {
             size_t t = h->timer.begin(CAT_SELECT, s);
             launch_replay(ra, s);
             h->timer.end(t, s);
         }
+        if (dbg_replay) {
+            std::vector<unsigned long long> dbg(mb * 4);
+            HIP_CHECK(hipMemcpyAsync(dbg.data(), h->w_misc.p, mb * 32, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            for (int c = 0; c < 4; c++) {
+                std::vector<unsigned long long> v(mb);
+                for (size_t i = 0; i < mb; i++) v[i] = dbg[i * 4 + c];
+                std::sort(v.begin(), v.end());
+                double sum = 0;
+                for (auto x : v) sum += x;
+                static const char* nm[4] = {"wave cycles", "heap updates", "candidates", "rule evaluations"};
+                fprintf(stderr, "[replay] %-16s mean %.0f p50 %llu p90 %llu p99 %llu max %llu\n", nm[c], sum / mb, v[mb / 2], v[mb * 9 / 10], v[mb * 99 / 100], v[mb - 1]);
+            }
+        }
         // the pinned staging buffers are reused by the next sub-batch
+        const double t_launched = now_us();
         HIP_CHECK(hipStreamSynchronize(s));
+        if (dbg_timing())
+            fprintf(stderr, "[round] queries %zu pairs %zu items %zu: host prep %.0f us, launch %.0f us, gpu wait %.0f us\n", mb, npairs, nitems,
+                    t_prep - t_enter, t_launched - t_prep, now_us() - t_launched);
         q0 = q1;
     }
 }
@@ -620,7 +693,9 @@ struct WallClock {
 // distances of n device queries (row stride dpad) to every centroid -> sorted top-nprobe on device
 void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode, float* d_out_dis, int64_t* d_out_keys, int fused) {
     if (!ix(h)->have_centroids) throw EngineError("quantizer has no centroids");
-    (void)mode;  // TODO(round 2): mode 1 = MFMA |x|^2+|y|^2-2xy path; the exact kernel serves both for now
+    // mode 0: exact per-pair kernel; 1: GEMM formulation on the matrix cores; -1: the reference's own switch
+    // (utils.cpp:624-655: exact for fewer than 20 queries when d % 4 == 0, BLAS otherwise)
+    const bool gemm = mode == 1 || (mode < 0 && !(n < 20 && h->d % 4 == 0));
     const size_t nlist = h->nlist;
     hipStream_t s = h->stream;
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(n, h->dist_budget_floats / std::max<size_t>(nlist, 1)));
@@ -673,9 +748,16 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
         sa.metric = h->metric;
         sa.fused = fused;
         size_t t = h->timer.begin(CAT_COARSE, s);
-        size_t n_qg[3] = {0, 0, 0};
-        n_qg[scan_qg_class(qg)] = nitems;
-        launch_scan(sa, n_qg, s);
+        if (gemm) {
+            h->w_xnorms.ensure(m * sizeof(float));
+            launch_row_norms(d_x + c0 * h->dpad, m, h->dpad, h->w_xnorms.as<float>(), s);
+            launch_coarse_gemm(h->metric, d_x + c0 * h->dpad, ix(h)->d_centroids.as<float>(), h->w_xnorms.as<float>(),
+                               ix(h)->d_centroid_norms.as<float>(), (int)m, (int)nlist, h->dpad, h->w_dist.as<float>(), s);
+        } else {
+            size_t n_qg[3] = {0, 0, 0};
+            n_qg[scan_qg_class(qg)] = nitems;
+            launch_scan(sa, n_qg, s);
+        }
         if (use_heap) {
             // the reference's own selection: a heap of nprobe over centroids 0..nlist-1 (utils.cpp:454-490)
             const size_t k = nprobe;
@@ -821,6 +903,7 @@ void run_rounds(amd_ivf* h, RoundSpec& base, size_t n, size_t first_round, size_
     std::vector<unsigned long long> np(n, 0);
     size_t round_len = first_round;
     for (;;) {
+        const double t_plan0 = now_us();
         // plan: every unfinished query runs either up to its known my_nprobe or one more block of round_len
         std::vector<uint32_t> slot, p0, cnt;
         size_t need_cols = 0;
@@ -854,6 +937,7 @@ void run_rounds(amd_ivf* h, RoundSpec& base, size_t n, size_t first_round, size_
             have = new_have;
             stride = new_have;
         }
+        const double t_plan1 = now_us();
         RoundSpec r = base;
         r.slot = slot;
         r.p0 = p0;
@@ -862,12 +946,14 @@ void run_rounds(amd_ivf* h, RoundSpec& base, size_t n, size_t first_round, size_
         r.key_stride = stride;
         r.total_nprobe = (uint32_t)total_nprobe;
         exec_round(h, r);
+        const double t_rb0 = now_us();
         check_device_error(h);
         HIP_CHECK(hipMemcpyAsync(stage.data(), h->w_stage.p, n * 4, hipMemcpyDeviceToHost, h->stream));
         HIP_CHECK(hipMemcpyAsync(done.data(), h->w_done.p, n * 4, hipMemcpyDeviceToHost, h->stream));
         if (d_np_abs)
             HIP_CHECK(hipMemcpyAsync(np.data(), d_np_abs + start, n * 8, hipMemcpyDeviceToHost, h->stream));
         HIP_CHECK(hipStreamSynchronize(h->stream));
+        if (dbg_timing()) fprintf(stderr, "[rounds] plan+keys %.0f us, readback %.0f us\n", t_plan1 - t_plan0, now_us() - t_rb0);
         round_len = std::min<size_t>(round_len * 2, 64);
     }
 }
@@ -944,6 +1030,8 @@ int amd_ivf_set_centroids(amd_ivf_t* h, const float* centroids) {
     h->d_centroids.ensure(h->nlist * h->dpad * sizeof(float));
     HIP_CHECK(hipMemcpyAsync(h->d_centroids.p, h->h_centroids.data(), h->nlist * h->dpad * sizeof(float),
                              hipMemcpyHostToDevice, h->stream));
+    h->d_centroid_norms.ensure(h->nlist * sizeof(float));
+    launch_row_norms(h->d_centroids.as<float>(), h->nlist, h->dpad, h->d_centroid_norms.as<float>(), h->stream);
     HIP_CHECK(hipStreamSynchronize(h->stream));
     h->have_centroids = true;
     h->have_interdis = false;

@@ -45,7 +45,8 @@ struct ScanArgs {
 };
 
 // items grouped by qg (1, then 2, then 4); n_qg = item count of each group
-void launch_scan(const ScanArgs& a, const size_t n_qg[3], hipStream_t s);
+// the three shapes are independent: s2 / s1 (optional) let the sparse shapes run beside the dense one
+void launch_scan(const ScanArgs& a, const size_t n_qg[3], hipStream_t s, hipStream_t s2 = nullptr, hipStream_t s1 = nullptr);
 
 // gather + interleave the query rows of every group of (up to) 8 pairs: group g holds pairs
 // [group_p0[g], group_p0[g] + group_cnt[g]); missing slots are zero
@@ -93,6 +94,7 @@ struct ReplayArgs {
     const uint64_t* seg_off;   // [nq][round_probes] offset of the distance row       (by launch position)
     const int32_t* seg_list;   // [nq][round_probes] list number, <0 = missing centroid (by launch position)
     const uint32_t* seg_count; // [nq] probes supplied this round                      (by launch position)
+    const uint32_t* seg_begin; // [nq] first entry of the query in seg_off / seg_list; null: li * round_probes
     const uint64_t* list_off;  // nlist + 1 (vectors)
     const int64_t* ids;        // per stored vector
     int store_pairs;
@@ -118,6 +120,7 @@ struct ReplayArgs {
     unsigned long long* stats; // {nlist, ndis, nheap}
     uint32_t* error;           // != 0: the reference would have thrown (code)
     int raw_heap_out;          // scanner API: leave the heap un-reordered in D/I
+    unsigned long long* dbg;   // optional [nq][4]: wave cycles, heap updates, candidates, stages evaluated
     TunerDev tuner;
     TrainDev train;
 };
@@ -136,6 +139,11 @@ constexpr uint32_t ERR_INVALID_KEY = 3;
 // full ascending/descending sort of each row of `dis` (nlist entries) keeping the first nprobe
 void launch_sort_rows(const float* dis, uint32_t nq, uint32_t nlist, uint32_t nprobe, int metric, float* out_dis,
                       int64_t* out_keys, hipStream_t s);
+
+// GEMM-formulated coarse distances on the fp32 matrix cores (row stride d, d % 4 == 0)
+void launch_row_norms(const float* x, size_t n, int d, float* out, hipStream_t s);
+void launch_coarse_gemm(int metric, const float* X, const float* Y, const float* xn, const float* yn, int nq, int ny, int d, float* out,
+                        hipStream_t s);
 
 // packed upper triangle (IVF_pro.cpp:21-39 layout) of a full nlist x nlist distance matrix
 void launch_pack_upper(const float* full, uint32_t nlist, float* out, hipStream_t s);

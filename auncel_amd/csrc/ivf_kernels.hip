@@ -200,10 +200,10 @@ template <int QG> static void launch_scan_qg(ScanArgs a, size_t first, size_t n,
 }
 
 // items must be grouped by qg: first n_qg[0] items with qg 1, then n_qg[1] with qg 2, then n_qg[2] with qg 4
-void launch_scan(const ScanArgs& a, const size_t n_qg[3], hipStream_t s) {
+void launch_scan(const ScanArgs& a, const size_t n_qg[3], hipStream_t s, hipStream_t s2, hipStream_t s1) {
     launch_scan_qg<4>(a, n_qg[0] + n_qg[1], n_qg[2], s);
-    launch_scan_qg<2>(a, n_qg[0], n_qg[1], s);
-    launch_scan_qg<1>(a, 0, n_qg[0], s);
+    launch_scan_qg<2>(a, n_qg[0], n_qg[1], s2 ? s2 : s);
+    launch_scan_qg<1>(a, 0, n_qg[0], s1 ? s1 : s);
 }
 
 // =============================================================================================
@@ -479,9 +479,12 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
     wave_sync();
 
     const unsigned long long id_q = a.id_offset + qi;
+    const unsigned long long dbg_t0 = a.dbg ? __builtin_readcyclecounter() : 0;
+    unsigned long long dbg_evals = 0;
     uint32_t err = 0;
     uint32_t ik0 = a.stage[qi];
     const uint32_t cnt = a.seg_count[li];
+    const size_t seg0 = a.seg_begin ? (size_t)a.seg_begin[li] : (size_t)li * a.round_probes;
     unsigned long long nscan = a.nscan[qi];
     float pre_val = a.pre_val ? a.pre_val[qi] : 0.f;
     uint32_t stoped = a.stoped ? a.stoped[qi] : 0u;
@@ -515,7 +518,7 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
     for (uint32_t p = 0; p < cnt && !finished; p++) {
         const uint32_t ik = ik0 + p;
         consumed = p + 1;
-        const int key = a.seg_list[(size_t)li * a.round_probes + p];
+        const int key = a.seg_list[seg0 + p];
         if (key >= 0) {
             if ((uint32_t)key >= nlist) {
                 err = ERR_INVALID_KEY;
@@ -525,7 +528,7 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
             const uint32_t n = a.identity_ids ? a.nlist : (uint32_t)(a.list_off[key + 1] - a.list_off[key]);
             if (n > 0) {
                 st_nlist++;
-                const float* seg = a.dist + a.seg_off[(size_t)li * a.round_probes + p];
+                const float* seg = a.dist + a.seg_off[seg0 + p];
                 const int64_t refbase = REF_TAG | ((int64_t)key << 32);
                 uint32_t npend = 0;
                 // 2048 candidates per trip: 32 coalesced 256-B loads in flight per wave (the loop is
@@ -606,6 +609,7 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
                         break;
                     }
                 }
+                dbg_evals++;
                 const uint32_t pre_num = cur_num_lds<IsMax>(tr, lut, srt, dwin, query_k, lane, &err);
                 float recall = (float)pre_num / (float)query_k;
                 const float max_val = IsMax ? fmaxf(-1.f, srt[k - 1]) : fminf(FLT_MAX, srt[k - 1]);
@@ -687,6 +691,12 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
         if (st_ndis) atomicAdd(&a.stats[1], st_ndis);
         if (st_nheap) atomicAdd(&a.stats[2], st_nheap);
         if (err) atomicMax(a.error, err);
+        if (a.dbg) {
+            a.dbg[(size_t)li * 4 + 0] = __builtin_readcyclecounter() - dbg_t0;
+            a.dbg[(size_t)li * 4 + 1] = st_nheap;
+            a.dbg[(size_t)li * 4 + 2] = st_ndis;
+            a.dbg[(size_t)li * 4 + 3] = dbg_evals;
+        }
     }
 
     wave_sync();
@@ -752,6 +762,85 @@ void launch_replay(const ReplayArgs& a, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(replay_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         hipLaunchKernelGGL(replay_kernel<false>, grid, block, shmem, s, a);
     }
+}
+
+// =============================================================================================
+// coarse quantiser, GEMM formulation (the reference's knn_L2sqr_blas / knn_inner_product_blas,
+// utils.cpp:494-608): dis = |x|^2 + |y|^2 - 2 x.y clamped at 0, x.y on the fp32 matrix cores
+// =============================================================================================
+// This is the one dense contraction of the hot path.  v_mfma_f32_32x32x2_f32 accumulates a k-ordered fp32 fma
+// chain per output element; the reference's sgemm order belongs to the vendor BLAS, so on float data the two
+// agree to rounding only (exactly on integer-valued data, where every order is exact).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void row_norms_kernel(const float* x, size_t n, int d, float* out) {
+    // fvec_norm_L2sqr, SSE order (utils_simd.cpp): four running sums, (s0+s1)+(s2+s3)
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4* r = reinterpret_cast<const float4*>(x + i * d);
+    float s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (int c = 0; c < d / 4; c++) {
+        const float4 v = r[c];
+        s0 += v.x * v.x;
+        s1 += v.y * v.y;
+        s2 += v.z * v.z;
+        s3 += v.w * v.w;
+    }
+    out[i] = (s0 + s1) + (s2 + s3);
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(256) void coarse_gemm_kernel(const float* X, const float* Y, const float* xn, const float* yn, int nq,
+                                                          int ny, int d, float* out) {
+    __shared__ float As[64][33], Bs[64][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int wq = wave >> 1, wc = wave & 1;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = 0.f;
+    for (int k0 = 0; k0 < d; k0 += 32) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int idx = tid + i * 256, row = idx >> 5, col = idx & 31;
+            As[row][col] = (q0 + row < nq && k0 + col < d) ? X[(size_t)(q0 + row) * d + k0 + col] : 0.f;
+            Bs[row][col] = (c0 + row < ny && k0 + col < d) ? Y[(size_t)(c0 + row) * d + k0 + col] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 32; kk += 2) {
+            const float a = As[wq * 32 + (lane & 31)][kk + (lane >> 5)];
+            const float b = Bs[wc * 32 + (lane & 31)][kk + (lane >> 5)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), col = lane & 31;
+        const int q = q0 + wq * 32 + row, c = c0 + wc * 32 + col;
+        if (q < nq && c < ny) {
+            const float ip = acc[reg];
+            float dis = ip;
+            if (METRIC == METRIC_L2) {
+                dis = xn[q] + yn[c] - 2 * ip;
+                if (dis < 0) dis = 0;  // utils.cpp:593
+            }
+            out[(size_t)q * ny + c] = dis;
+        }
+    }
+}
+
+void launch_row_norms(const float* x, size_t n, int d, float* out, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(row_norms_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, d, out);
+}
+
+void launch_coarse_gemm(int metric, const float* X, const float* Y, const float* xn, const float* yn, int nq, int ny, int d, float* out,
+                        hipStream_t s) {
+    if (nq == 0 || ny == 0) return;
+    const dim3 grid((ny + 63) / 64, (nq + 63) / 64);
+    if (metric == METRIC_L2) hipLaunchKernelGGL(coarse_gemm_kernel<METRIC_L2>, grid, dim3(256), 0, s, X, Y, xn, yn, nq, ny, d, out);
+    else hipLaunchKernelGGL(coarse_gemm_kernel<METRIC_IP>, grid, dim3(256), 0, s, X, Y, xn, yn, nq, ny, d, out);
 }
 
 // =============================================================================================

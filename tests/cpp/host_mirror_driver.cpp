@@ -41,6 +41,7 @@ static int run_fixed(const tb::Bundle& in) {
     ix->quantizer->add(nlist, cen.as<float>());
     ix->is_trained = true;
     dynamic_cast<IndexFlat*>(ix->quantizer)->coarse_mode = 0;  // expectations come from the exact coarse path
+    ix->coarse_mode = 0;
     index->add(nb / 3, xb.as<float>());
     index->add(nb - nb / 3, xb.as<float>() + (nb / 3) * d);
     expect((size_t)index->ntotal == nb, "ntotal");
@@ -99,6 +100,7 @@ static int run_fixed(const tb::Bundle& in) {
         IndexShards shards((idx_t)d, false, false);
         for (size_t s = 0; s < nshard; s++) {
             std::unique_ptr<IndexIVFFlat> sub(new IndexIVFFlat(ix->quantizer, d, nlist, mt));
+            sub->coarse_mode = 0;
             std::vector<idx_t> pa(a);
             for (size_t i = 0; i < nb; i++) if ((size_t)pa[i] % nshard != s) pa[i] = -1;
             sub->add_core(nb, xb.as<float>(), gid.data(), pa.data());
@@ -128,6 +130,7 @@ static int run_auncel(const tb::Bundle& in) {
     quantizer.add(nlist, cen.as<float>());
     quantizer.coarse_mode = 0;
     IndexIVFFlat index(&quantizer, d, nlist, METRIC_L2);
+    index.coarse_mode = 0;  // goldens: exact coarse ranking (the reference's one-query-per-call path)
     // train_q1's table for these centroids (the k-means itself is out of scope: centroids come from the fixture)
     index.interdis_cem.assign(in.get("interdis_cem").as<float>(), in.get("interdis_cem").as<float>() + nlist * (nlist - 1) / 2);
     index.add(nb, xb.as<float>());

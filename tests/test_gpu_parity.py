@@ -226,3 +226,30 @@ def test_fused_path_is_bit_identical(capi, monkeypatch):
     D1, I1 = h1.search(xq, 10, case["nprobe"])
     D2, I2 = h2.search(xq, 10, case["nprobe"])
     assert np.array_equal(I1, I2) and np.array_equal(bits(D1), bits(D2))
+
+
+@pytest.mark.parametrize("name", FIXED)
+def test_coarse_gemm_mode(capi, name):
+    """mode 1 = |x|^2 + |y|^2 - 2 x.y on the fp32 matrix cores (the reference's BLAS branch).  Integer-valued
+    data: every summation order is exact, so the reference's MKL-made goldens apply bit for bit; float data:
+    vendor-BLAS rounding is unpinned, distances must agree with the exact kernel to 1e-4 relative."""
+    case, gold = load_case(name)
+    h = make_index(capi, case, gold)
+    D, I = h.coarse(case["xq"], case["nprobe"], mode=1)
+    if name in ("fixed_sift_l2", "fixed_odd_d30", "fixed_ragged", "fixed_dups"):
+        assert np.array_equal(bits(D), bits(gold["coarse_dis_blas"]))
+        same = I == gold["coarse_keys_blas"]
+        for q, j in zip(*np.nonzero(~same)):  # ids may differ only inside groups of equal distances
+            tie = D[q] == D[q, j]
+            assert set(I[q][tie]) == set(gold["coarse_keys_blas"][q][tie])
+    else:
+        De, Ie = h.coarse(case["xq"], case["nprobe"], mode=0)
+        assert np.allclose(D, De, rtol=1e-4, atol=1e-5)
+        assert (I == Ie).mean() > 0.99
+    # mode -1 follows the reference's switch: >= 20 queries -> GEMM branch
+    Dm, Im = h.coarse(case["xq"], case["nprobe"], mode=-1)
+    assert np.array_equal(bits(Dm), bits(D)) and np.array_equal(Im, I)
+    D1, I1 = h.coarse(case["xq"][:5], case["nprobe"], mode=-1)
+    if case["d"] % 4 == 0:
+        De, Ie = h.coarse(case["xq"][:5], case["nprobe"], mode=0)
+        assert np.array_equal(bits(D1), bits(De)) and np.array_equal(I1, Ie)
