@@ -261,6 +261,21 @@ def main():
         },
     }
 
+    # HBM traffic of the scan per launch: PMC counters cannot be read from inside this process; the figure comes
+    # from the committed rocprofv3 --pmc passes over this same command (profiles/collect.sh -> summarize.py),
+    # FETCH_SIZE doubled for the scan's wide loads as MI355X_MICROARCH.md prescribes, and only when that profile
+    # was taken on this workload
+    try:
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+        if cands:
+            pj = json.load(open(cands[-1]))
+            if pj.get("_workload") == out["config"]["workload"]:
+                out["roofline"]["traffic"] = pj["scan_tiles_kernel [lists]"]["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = os.path.relpath(cands[-1], ROOT)
+    except Exception as e:  # a missing or stale profile leaves traffic null
+        log("no PMC traffic figure:", e)
+
     # ---- CPU baseline: the pinned CPU restatement of the reference path, all host cores, bounded sample
     if rank == 0 and world == 1 and not args.no_cpu:
         from oracle import pyoracle
