@@ -184,7 +184,8 @@ struct amd_ivf {
 
     // workspaces (grow only)
     DevBuf w_qtile, w_group_p0, w_group_cnt, w_xnorms;
-    PinnedBuf p_group_p0, p_group_cnt;
+    PinnedBuf p_group_p0, p_group_cnt, p_counters;
+    DevBuf w_pl_cnt, w_pl_need, w_pl_dist_base, w_pl_lcount, w_pl_lstart, w_pl_gbase, w_pl_ibase, w_pl_fill, w_pl_counters;
     DevBuf w_x, w_dist, w_items, w_pair_query, w_pair_out, w_seg_off, w_seg_list, w_seg_count, w_qsel;
     DevBuf w_heap_val, w_heap_ref, w_stage, w_nscan, w_done, w_pre_val, w_stoped, w_dtb, w_D, w_I;
     DevBuf w_cdis, w_ckeys, w_stats, w_error, w_misc, w_misc2, w_misc3, w_rawptrs;
@@ -892,7 +893,190 @@ TunerDev make_tuner(amd_ivf* h, size_t query_topk, float multipler, float std_m,
     return t;
 }
 
-// multi-round driver shared by the adaptive search and the trace training
+// multi-round driver with the round planning on the device (ivf_plan.hip): per round the host zeroes two small
+// arrays, launches the planning kernels, reads back nine counters and launches pack + scan + replay
+void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first_round, size_t total_nprobe,
+                       const unsigned long long* d_np_abs /* may be null */) {
+    amd_ivf* I = ix(h);
+    const size_t nlist = h->nlist;
+    hipStream_t s = h->stream;
+    static const double grow_env = getenv("AUNCEL_AMD_ROUND_GROW") ? atof(getenv("AUNCEL_AMD_ROUND_GROW")) : 2.5;
+    const size_t seg_cap = (size_t)2 << 20;
+    size_t maxlist = 0;
+    for (size_t l = 0; l < nlist; l++) maxlist = std::max<size_t>(maxlist, I->h_list_off[l + 1] - I->h_list_off[l]);
+    const size_t item_cap = (seg_cap / (4 * SCAN_RQ) + nlist) * ((maxlist + SCAN_WAVE_VECS - 1) / SCAN_WAVE_VECS) + nlist * 4 + 16;
+    const size_t budget = std::max<size_t>(h->dist_budget_floats, I->h_list_off[nlist] + 1);
+    h->w_pl_cnt.ensure(n * 4);
+    h->w_pl_need.ensure(n * 8);
+    h->w_seg_begin.ensure(n * 4);
+    h->w_pl_dist_base.ensure(n * 8);
+    h->w_qsel.ensure(n * 4);
+    h->w_seg_list.ensure(seg_cap * 4);
+    h->w_seg_off.ensure(seg_cap * 8);
+    h->w_pair_query.ensure(seg_cap * 4);
+    h->w_pair_out.ensure(seg_cap * 8);
+    h->w_group_p0.ensure(seg_cap * 4);
+    h->w_group_cnt.ensure(seg_cap * 4);
+    h->w_items.ensure(item_cap * sizeof(ScanItem));
+    h->w_pl_lcount.ensure(nlist * 4);
+    h->w_pl_lstart.ensure(nlist * 4);
+    h->w_pl_gbase.ensure(nlist * 4);
+    h->w_pl_ibase.ensure(3 * nlist * 4);
+    h->w_pl_fill.ensure(nlist * 4);
+    h->w_pl_counters.ensure(96);  // 16 uint32 counters | double bytes | 2 x u64 slot bookkeeping
+    h->p_counters.ensure(96);
+    h->w_dist.ensure(budget * sizeof(float));
+    HIP_CHECK(hipMemsetAsync(h->w_pl_counters.p, 0, 96, s));
+
+    PlanArgs pa{};
+    pa.nq = (uint32_t)n;
+    pa.nlist = (uint32_t)nlist;
+    pa.total_nprobe = (uint32_t)total_nprobe;
+    pa.key_stride = base.coarse_stride;
+    pa.slot_base = 0;
+    pa.first_round = (uint32_t)first_round;
+    pa.tune = base.tuner.enabled;
+    pa.d = h->d;
+    pa.multipler = base.tuner.multipler;
+    pa.grow = std::max<double>(base.tuner.multipler, grow_env);
+    pa.id_offset = base.id_offset;
+    pa.dist_budget = budget;
+    pa.seg_cap = (uint32_t)seg_cap;
+    pa.keys = base.d_ckeys;
+    pa.list_off = I->d_list_off.as<uint64_t>();
+    pa.stage = h->w_stage.as<uint32_t>();
+    pa.done = h->w_done.as<uint32_t>();
+    pa.my_nprobe = d_np_abs;
+    pa.cnt = h->w_pl_cnt.as<uint32_t>();
+    pa.need = h->w_pl_need.as<unsigned long long>();
+    pa.seg_begin = h->w_seg_begin.as<uint32_t>();
+    pa.dist_base = h->w_pl_dist_base.as<unsigned long long>();
+    pa.qsel = h->w_qsel.as<uint32_t>();
+    pa.seg_list = h->w_seg_list.as<int32_t>();
+    pa.seg_off = h->w_seg_off.as<uint64_t>();
+    pa.lcount = h->w_pl_lcount.as<uint32_t>();
+    pa.lstart = h->w_pl_lstart.as<uint32_t>();
+    pa.gbase = h->w_pl_gbase.as<uint32_t>();
+    pa.ibase = h->w_pl_ibase.as<uint32_t>();
+    pa.fill = h->w_pl_fill.as<uint32_t>();
+    pa.pair_query = h->w_pair_query.as<uint32_t>();
+    pa.pair_out = h->w_pair_out.as<uint64_t>();
+    pa.group_p0 = h->w_group_p0.as<uint32_t>();
+    pa.group_cnt = h->w_group_cnt.as<uint32_t>();
+    pa.items = h->w_items.as<ScanItem>();
+    pa.item_cap = (uint32_t)item_cap;
+    pa.counters = h->w_pl_counters.as<uint32_t>();
+    pa.bytes = reinterpret_cast<double*>(h->w_pl_counters.as<uint32_t>() + 16);
+    pa.acc64 = reinterpret_cast<unsigned long long*>(h->w_pl_counters.as<uint32_t>() + 18);
+
+    if (!h->aux[0]) {
+        for (int i = 0; i < 2; i++) {
+            HIP_CHECK(hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
+            HIP_CHECK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+        }
+        HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    }
+    size_t round_len = first_round;
+    uint32_t* hc = h->p_counters.as<uint32_t>();
+    for (;;) {
+        const double t0 = now_us();
+        HIP_CHECK(hipMemsetAsync(h->w_pl_lcount.p, 0, nlist * 4, s));
+        HIP_CHECK(hipMemsetAsync(h->w_pl_counters.as<uint32_t>() + 6, 0, 4, s));
+        pa.round_len = (uint32_t)round_len;
+        launch_plan(pa, s);
+        HIP_CHECK(hipMemcpyAsync(hc, h->w_pl_counters.p, 96, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        const double t1 = now_us();
+        const uint32_t nact = hc[0], npairs = hc[2], ngroups = hc[3];
+        if (nact == 0) break;
+        const size_t n_qg[3] = {hc[4], hc[5], hc[8]};
+        const size_t nitems = n_qg[0] + n_qg[1] + n_qg[2];
+        if (nitems > item_cap) throw std::runtime_error("tile list overflow");
+        if (npairs) {
+            h->w_qtile.ensure((size_t)ngroups * (size_t)h->dpad * SCAN_RQ * sizeof(float));
+            launch_pack_queries(base.d_x, h->w_pair_query.as<uint32_t>(), h->w_group_p0.as<uint32_t>(), h->w_group_cnt.as<uint32_t>(), ngroups,
+                                h->dpad, h->w_qtile.as<float>(), s);
+            ScanArgs sa{};
+            sa.qtile = h->w_qtile.as<float>();
+            sa.codes = I->d_codes.as<float>();
+            sa.queries = base.d_x;
+            sa.items = h->w_items.as<ScanItem>();
+            sa.pair_query = h->w_pair_query.as<uint32_t>();
+            sa.pair_out = h->w_pair_out.as<uint64_t>();
+            sa.dist = h->w_dist.as<float>();
+            sa.d = h->dpad;
+            sa.metric = h->metric;
+            sa.fused = base.fused;
+            size_t t = h->timer.begin(CAT_SCAN, s);
+            const bool fork = (n_qg[0] || n_qg[1]) && n_qg[2];
+            if (fork) {
+                HIP_CHECK(hipEventRecord(h->ev_fork, s));
+                for (int i = 0; i < 2; i++) HIP_CHECK(hipStreamWaitEvent(h->aux[i], h->ev_fork, 0));
+                launch_scan(sa, n_qg, s, h->aux[0], h->aux[1]);
+                for (int i = 0; i < 2; i++) {
+                    HIP_CHECK(hipEventRecord(h->ev_join[i], h->aux[i]));
+                    HIP_CHECK(hipStreamWaitEvent(s, h->ev_join[i], 0));
+                }
+            } else {
+                launch_scan(sa, n_qg, s);
+            }
+            h->timer.end(t, s);
+        }
+        ReplayArgs ra{};
+        ra.metric = h->metric;
+        ra.k = base.k;
+        ra.nlist = (uint32_t)nlist;
+        ra.nq = nact;
+        ra.qsel = h->w_qsel.as<uint32_t>();
+        ra.total_nprobe = (uint32_t)total_nprobe;
+        ra.round_probes = 0;
+        ra.id_offset = base.id_offset;
+        ra.dist = h->w_dist.as<float>();
+        ra.seg_off = h->w_seg_off.as<uint64_t>();
+        ra.seg_list = h->w_seg_list.as<int32_t>();
+        ra.seg_count = h->w_pl_cnt.as<uint32_t>();
+        ra.seg_begin = h->w_seg_begin.as<uint32_t>();
+        ra.seg_by_slot = 1;
+        ra.list_off = I->d_list_off.as<uint64_t>();
+        ra.ids = I->d_ids.as<int64_t>();
+        ra.store_pairs = base.store_pairs;
+        ra.heap_val = h->w_heap_val.as<float>();
+        ra.heap_ref = h->w_heap_ref.as<int64_t>();
+        ra.stage = h->w_stage.as<uint32_t>();
+        ra.nscan = h->w_nscan.as<unsigned long long>();
+        ra.done = h->w_done.as<uint32_t>();
+        ra.pre_val = h->w_pre_val.as<float>();
+        ra.stoped = h->w_stoped.as<uint32_t>();
+        ra.dtb = h->w_dtb.as<float>();
+        ra.coarse_dis = base.d_cdis;
+        ra.coarse_keys = base.d_ckeys;
+        ra.coarse_stride = base.coarse_stride;
+        ra.trace_cap = (uint32_t)I->tuner_trace_cap;
+        ra.D = h->w_D.as<float>();
+        ra.I = h->w_I.as<int64_t>();
+        ra.stats = h->w_stats.as<unsigned long long>();
+        ra.error = h->w_error.as<uint32_t>();
+        ra.tuner = base.tuner;
+        ra.train = base.train;
+        {
+            size_t t = h->timer.begin(CAT_SELECT, s);
+            launch_replay(ra, s);
+            h->timer.end(t, s);
+        }
+        if (dbg_timing())
+            fprintf(stderr, "[round/dev] active %u pairs %u groups %u tiles %zu: plan+readback %.0f us, launches %.0f us\n", nact, npairs, ngroups,
+                    nitems, t1 - t0, now_us() - t1);
+        round_len = std::min<size_t>(round_len * 2, 64);
+    }
+    check_device_error(h);
+    h->scan_bytes += *reinterpret_cast<double*>(hc + 16);
+    const unsigned long long* acc = reinterpret_cast<const unsigned long long*>(hc + 18);
+    h->scan_slots += (double)acc[0];
+    h->scan_useful += (double)acc[1];
+}
+
+// multi-round driver shared by the adaptive search and the trace training (host-side planning: kept for reference /
+// AUNCEL_AMD_HOST_PLAN=1)
 void run_rounds(amd_ivf* h, RoundSpec& base, size_t n, size_t first_round, size_t total_nprobe,
                 const unsigned long long* d_np_abs /* may be null */, size_t start) {
     // keys for probes [0, have) of every slot are kept on the host and extended on demand
@@ -1415,7 +1599,9 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
     base.coarse_stride = (uint32_t)nlist;
     base.tuner = make_tuner(L, query_topk, multipler, std_m, dreq, dgt, dnp, dtr, profile);
     static const size_t first_env = getenv("AUNCEL_AMD_ROUND_FIRST") ? (size_t)atoi(getenv("AUNCEL_AMD_ROUND_FIRST")) : 12;
-    run_rounds(L, base, n, first_env, nlist, dnp, id0);
+    static const bool host_plan = getenv("AUNCEL_AMD_HOST_PLAN") != nullptr;
+    if (host_plan) run_rounds(L, base, n, first_env, nlist, dnp, id0);
+    else run_rounds_device(L, base, n, first_env, nlist, dnp);
     HIP_CHECK(hipMemcpyAsync(D, L->w_D.p, n * K * 4, hipMemcpyDeviceToHost, L->stream));
     HIP_CHECK(hipMemcpyAsync(I, L->w_I.p, n * K * 8, hipMemcpyDeviceToHost, L->stream));
     HIP_CHECK(hipStreamSynchronize(L->stream));
@@ -1600,7 +1786,8 @@ static void train_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n, s
     base.train.arcos = h->d_arcos.as<float>();
     base.train.gt_D = h->w_misc2.as<float>();
     base.train.raw = reinterpret_cast<float* const*>(h->w_rawptrs.p);
-    run_rounds(h, base, n, 32, nlist, nullptr, start);
+    if (getenv("AUNCEL_AMD_HOST_PLAN")) run_rounds(h, base, n, 32, nlist, nullptr, start);
+    else run_rounds_device(h, base, n, 32, nlist, nullptr);
     HIP_CHECK(hipMemcpyAsync(D, h->w_D.p, n * K * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipMemcpyAsync(I, h->w_I.p, n * K * 8, hipMemcpyDeviceToHost, h->stream));
     for (size_t i = 0; i < ntr; i++)

@@ -95,6 +95,7 @@ struct ReplayArgs {
     const int32_t* seg_list;   // [nq][round_probes] list number, <0 = missing centroid (by launch position)
     const uint32_t* seg_count; // [nq] probes supplied this round                      (by launch position)
     const uint32_t* seg_begin; // [nq] first entry of the query in seg_off / seg_list; null: li * round_probes
+    int seg_by_slot;           // seg_count / seg_begin are indexed by query slot instead of launch position
     const uint64_t* list_off;  // nlist + 1 (vectors)
     const int64_t* ids;        // per stored vector
     int store_pairs;
@@ -130,6 +131,53 @@ void launch_replay(const ReplayArgs& a, hipStream_t s);
 // error_pro::set_online for nq queries: dtb[q][nlist/8+20] from the full coarse ranking (before round 0)
 void launch_set_online(int metric, uint32_t nlist, uint32_t nq, const float* coarse_dis, const int64_t* coarse_keys,
                        uint32_t coarse_stride, const float* interdis, const float* arcos, float* dtb, uint32_t* error, hipStream_t s);
+
+// ---------------------------------------------------------------------------- device-side round planning
+struct PlanArgs {
+    uint32_t nq;               // query slots of this search (state arrays are indexed by slot)
+    uint32_t nlist;
+    uint32_t total_nprobe;     // length of the probe loop (= nlist in tune / train mode)
+    uint32_t key_stride;
+    uint32_t slot_base;        // row of slot 0 in the query matrix the scan reads (pair_query = slot_base + slot)
+    uint32_t first_round, round_len;
+    int tune;
+    int d;
+    float multipler;
+    double grow;
+    unsigned long long id_offset;
+    unsigned long long dist_budget;  // floats
+    uint32_t seg_cap;
+    const int64_t* keys;             // [nq][key_stride] coarse ranking
+    const uint64_t* list_off;
+    const uint32_t* stage;
+    const uint32_t* done;
+    const unsigned long long* my_nprobe;  // by absolute id, may be null
+    // outputs
+    uint32_t* cnt;                   // [nq] probes this round (0: finished or deferred)
+    unsigned long long* need;        // [nq]
+    uint32_t* seg_begin;             // [nq]
+    unsigned long long* dist_base;   // [nq]
+    uint32_t* qsel;                  // active slots, compacted
+    int32_t* seg_list;
+    uint64_t* seg_off;
+    uint32_t* lcount;                // [nlist] zeroed by the host before the round
+    uint32_t* lstart;
+    uint32_t* gbase;
+    uint32_t* ibase;                 // [3][nlist]
+    uint32_t* fill;
+    uint32_t* pair_query;
+    uint64_t* pair_out;
+    uint32_t* group_p0;
+    uint32_t* group_cnt;
+    ScanItem* items;
+    uint32_t item_cap;
+    unsigned long long* acc64;       // [0] += (query, vector) slots computed, [1] += pairs wanted (tile bookkeeping)
+    uint32_t* counters;              // [0] active queries [1] segments [2] pairs [3] groups [4] tiles qg1 [5] tiles qg2
+                                     // [6] scratch (compaction cursor, zeroed by host) [7] MiB of distances [8] tiles qg4
+    double* bytes;                   // [0] += algorithmic bytes of the round's distances
+};
+
+void launch_plan(const PlanArgs& a, hipStream_t s);
 
 constexpr uint32_t ERR_ARCOS_DOMAIN = 1;
 constexpr uint32_t ERR_COSINE_PRECOND = 2;

@@ -483,8 +483,9 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
     unsigned long long dbg_evals = 0;
     uint32_t err = 0;
     uint32_t ik0 = a.stage[qi];
-    const uint32_t cnt = a.seg_count[li];
-    const size_t seg0 = a.seg_begin ? (size_t)a.seg_begin[li] : (size_t)li * a.round_probes;
+    const uint32_t si = a.seg_by_slot ? qi : li;
+    const uint32_t cnt = a.seg_count[si];
+    const size_t seg0 = a.seg_begin ? (size_t)a.seg_begin[si] : (size_t)li * a.round_probes;
     unsigned long long nscan = a.nscan[qi];
     float pre_val = a.pre_val ? a.pre_val[qi] : 0.f;
     uint32_t stoped = a.stoped ? a.stoped[qi] : 0u;

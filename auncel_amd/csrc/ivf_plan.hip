@@ -1,0 +1,286 @@
+// Device-side round planning for the adaptive (Auncel) search.
+//
+// A round scans probes [stage, stage + cnt) of every unfinished query.  Everything the scan and replay kernels
+// need for a round -- per-query probe counts, the query-major layout of the distance rows, the (query, probe)
+// pairs grouped by inverted list, the packed query groups and the tile list -- is derived here on the GPU from
+// the per-query state the replay kernel left behind, so that a round costs the host one 32-byte read-back
+// instead of a pass over every pair.
+#include "ivf_kernels.h"
+
+namespace amdivf {
+
+// ---- 1. how many probes does each query run this round, and how many distances is that
+__global__ __launch_bounds__(256) void plan_counts_kernel(PlanArgs a) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.nq) return;
+    uint32_t cnt = 0;
+    unsigned long long need = 0;
+    if (!a.done[i]) {
+        const uint32_t stage = a.stage[i];
+        unsigned long long target = (unsigned long long)stage + a.round_len;
+        const unsigned long long np = a.my_nprobe ? a.my_nprobe[a.id_offset + i] : 0ull;
+        if (a.tune) {
+            // an unfired query at stage s cannot stop before floor((s+1) * multipler): that much is waste-free;
+            // beyond it `grow` trades over-scan against the number of rounds
+            const unsigned long long safe = (unsigned long long)((float)(stage + 1) * a.multipler);
+            const unsigned long long g = (unsigned long long)((double)stage * a.grow);
+            target = safe > g ? safe : g;
+            if (target < (unsigned long long)stage + a.first_round) target = (unsigned long long)stage + a.first_round;
+        }
+        if (np != 0) target = np > (unsigned long long)stage + 1 ? np : (unsigned long long)stage + 1;
+        if (target > a.total_nprobe) target = a.total_nprobe;
+        if (target <= stage) target = stage + 1 < a.total_nprobe ? stage + 1 : a.total_nprobe;
+        cnt = (uint32_t)(target - stage);
+        const int64_t* kq = a.keys + (size_t)i * a.key_stride + stage;
+        for (uint32_t p = 0; p < cnt; p++) {
+            const int64_t key = kq[p];
+            if (key >= 0 && (unsigned long long)key < a.nlist) need += a.list_off[key + 1] - a.list_off[key];
+        }
+    }
+    a.cnt[i] = cnt;
+    a.need[i] = need;
+}
+
+// ---- 2. one block: prefix sums over the queries, budget cut, list of active queries
+__global__ __launch_bounds__(1024) void plan_prefix_kernel(PlanArgs a) {
+    __shared__ unsigned long long s_need[1024];
+    __shared__ uint32_t s_cnt[1024], s_act[1024];
+    __shared__ unsigned long long carry_need;
+    __shared__ uint32_t carry_cnt, carry_act, cut;
+    const int t = threadIdx.x;
+    if (t == 0) {
+        carry_need = 0;
+        carry_cnt = 0;
+        carry_act = 0;
+        cut = 0xffffffffu;
+    }
+    __syncthreads();
+    for (uint32_t base = 0; base < a.nq; base += 1024) {
+        const uint32_t i = base + t;
+        uint32_t c = i < a.nq ? a.cnt[i] : 0;
+        unsigned long long nd = i < a.nq ? a.need[i] : 0;
+        s_cnt[t] = c;
+        s_need[t] = nd;
+        s_act[t] = c ? 1u : 0u;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {  // inclusive Hillis-Steele scan
+            uint32_t vc = 0, va = 0;
+            unsigned long long vn = 0;
+            if (t >= off) {
+                vc = s_cnt[t - off];
+                vn = s_need[t - off];
+                va = s_act[t - off];
+            }
+            __syncthreads();
+            s_cnt[t] += vc;
+            s_need[t] += vn;
+            s_act[t] += va;
+            __syncthreads();
+        }
+        const uint32_t ecnt = carry_cnt + s_cnt[t] - c;                   // exclusive
+        const unsigned long long eneed = carry_need + s_need[t] - nd;
+        const uint32_t eact = carry_act + s_act[t] - (c ? 1u : 0u);
+        if (i < a.nq) {
+            // a query that does not fit the distance / segment budget of this round waits for the next one
+            const bool fits = (eneed + nd <= a.dist_budget && ecnt + c <= a.seg_cap) || eact == 0;
+            if (c && !fits) atomicMin(&cut, i);
+            a.seg_begin[i] = ecnt;
+            a.dist_base[i] = eneed;
+        }
+        __syncthreads();
+        if (t == 1023) {
+            carry_cnt += s_cnt[t];
+            carry_need += s_need[t];
+            carry_act += s_act[t];
+        }
+        __syncthreads();
+    }
+    // queries at or after the cut are deferred; everything before keeps its prefix values
+    uint32_t nact = 0, nseg = 0;
+    unsigned long long ndist = 0;
+    __shared__ uint32_t s_nact, s_nseg;
+    __shared__ unsigned long long s_ndist;
+    if (t == 0) {
+        s_nact = 0;
+        s_nseg = 0;
+        s_ndist = 0;
+    }
+    __syncthreads();
+    for (uint32_t i = t; i < a.nq; i += 1024) {
+        if (i >= cut) a.cnt[i] = 0;
+        if (a.cnt[i]) {
+            nact++;
+            nseg += a.cnt[i];
+            ndist += a.need[i];
+        }
+    }
+    atomicAdd(&s_nact, nact);
+    atomicAdd(&s_nseg, nseg);
+    atomicAdd(&s_ndist, ndist);
+    __syncthreads();
+    if (t == 0) {
+        a.counters[0] = s_nact;
+        a.counters[1] = s_nseg;
+        a.counters[7] = (uint32_t)(s_ndist >> 20);  // MiB of distances, for bookkeeping
+        a.bytes[0] += (double)s_ndist * (double)a.d * 4.0;
+    }
+}
+
+// ---- 3. segments of every active query + histogram of pairs per list
+__global__ __launch_bounds__(256) void plan_segments_kernel(PlanArgs a) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.nq) return;
+    const uint32_t c = a.cnt[i];
+    if (!c) return;
+    const uint32_t slot = atomicAdd(&a.counters[6], 1u);  // compaction order is irrelevant
+    a.qsel[slot] = i;
+    const uint32_t stage = a.stage[i];
+    const int64_t* kq = a.keys + (size_t)i * a.key_stride + stage;
+    unsigned long long cur = a.dist_base[i];
+    const uint32_t sb = a.seg_begin[i];
+    for (uint32_t p = 0; p < c; p++) {
+        const int64_t key = kq[p];
+        a.seg_list[sb + p] = (int32_t)key;
+        a.seg_off[sb + p] = cur;
+        if (key >= 0 && (unsigned long long)key < a.nlist) {
+            const unsigned long long sz = a.list_off[key + 1] - a.list_off[key];
+            if (sz) {
+                atomicAdd(&a.lcount[key], 1u);
+                cur += sz;
+            }
+        }
+    }
+}
+
+// ---- 4. one block: per-list pair offsets, query-group bases, tile counts per workgroup shape
+__device__ inline uint32_t shape_of(uint32_t r) { return r <= SCAN_RQ ? 1u : r <= 2 * SCAN_RQ ? 2u : 4u; }
+
+__global__ __launch_bounds__(1024) void plan_lists_kernel(PlanArgs a) {
+    __shared__ uint32_t s[5][1024];
+    __shared__ uint32_t carry[5];
+    const int t = threadIdx.x;
+    if (t < 5) carry[t] = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < a.nlist; base += 1024) {
+        const uint32_t l = base + t;
+        uint32_t v[5] = {0, 0, 0, 0, 0};  // pairs, groups, tiles of shape 1, 2, 4
+        if (l < a.nlist) {
+            const uint32_t c = a.lcount[l];
+            if (c) {
+                const unsigned long long sz = a.list_off[l + 1] - a.list_off[l];
+                v[0] = c;
+                v[1] = (c + SCAN_RQ - 1) / SCAN_RQ;
+                const uint32_t full = c / (4 * SCAN_RQ), rem = c % (4 * SCAN_RQ);
+                v[4] = full * (uint32_t)((sz + SCAN_WAVE_VECS - 1) / SCAN_WAVE_VECS);
+                if (rem) {
+                    const uint32_t qg = shape_of(rem);
+                    const uint32_t tv = (4 / qg) * SCAN_WAVE_VECS;
+                    v[qg == 1 ? 2 : qg == 2 ? 3 : 4] += (uint32_t)((sz + tv - 1) / tv);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) s[k][t] = v[k];
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            uint32_t w[5] = {0, 0, 0, 0, 0};
+            if (t >= off)
+#pragma unroll
+                for (int k = 0; k < 5; k++) w[k] = s[k][t - off];
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 5; k++) s[k][t] += w[k];
+            __syncthreads();
+        }
+        if (l < a.nlist) {
+            a.lstart[l] = carry[0] + s[0][t] - v[0];
+            a.gbase[l] = carry[1] + s[1][t] - v[1];
+            a.ibase[0 * a.nlist + l] = carry[2] + s[2][t] - v[2];
+            a.ibase[1 * a.nlist + l] = carry[3] + s[3][t] - v[3];
+            a.ibase[2 * a.nlist + l] = carry[4] + s[4][t] - v[4];
+            a.fill[l] = 0;
+        }
+        __syncthreads();
+        if (t == 1023)
+#pragma unroll
+            for (int k = 0; k < 5; k++) carry[k] += s[k][t];
+        __syncthreads();
+    }
+    if (t == 0) {
+        a.counters[2] = carry[0];  // pairs
+        a.counters[3] = carry[1];  // query groups
+        a.counters[4] = carry[2];  // tiles of shape 1
+        a.counters[5] = carry[3];  // tiles of shape 2
+        a.counters[8] = carry[4];  // tiles of shape 4
+    }
+}
+
+// ---- 5. pairs into their list's range
+__global__ __launch_bounds__(256) void plan_scatter_kernel(PlanArgs a) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.nq) return;
+    const uint32_t c = a.cnt[i];
+    if (!c) return;
+    const uint32_t sb = a.seg_begin[i];
+    for (uint32_t p = 0; p < c; p++) {
+        const int32_t key = a.seg_list[sb + p];
+        if (key < 0 || (uint32_t)key >= a.nlist) continue;
+        if (a.list_off[key + 1] == a.list_off[key]) continue;
+        const uint32_t pos = a.lstart[key] + atomicAdd(&a.fill[key], 1u);
+        a.pair_query[pos] = a.slot_base + i;
+        a.pair_out[pos] = a.seg_off[sb + p];
+    }
+}
+
+// ---- 6. tiles and query groups of every list (one thread per list), shapes 1 | 2 | 4 in three item ranges
+__global__ __launch_bounds__(256) void plan_items_kernel(PlanArgs a) {
+    const uint32_t l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= a.nlist) return;
+    const uint32_t c = a.lcount[l];
+    if (!c) return;
+    const uint32_t p0 = a.lstart[l], g0 = a.gbase[l];
+    for (uint32_t o = 0, g = 0; o < c; o += SCAN_RQ, g++) {
+        a.group_p0[g0 + g] = p0 + o;
+        a.group_cnt[g0 + g] = c - o < (uint32_t)SCAN_RQ ? c - o : (uint32_t)SCAN_RQ;
+    }
+    const uint32_t n1 = a.counters[4], n2 = a.counters[5];
+    uint32_t cur[3] = {a.ibase[l], n1 + a.ibase[a.nlist + l], n1 + n2 + a.ibase[2 * a.nlist + l]};
+    const uint32_t sz = (uint32_t)(a.list_off[l + 1] - a.list_off[l]);
+    const uint64_t vb0 = a.list_off[l];
+    unsigned long long slots = 0, useful = 0;
+    for (uint32_t qb = 0; qb < c; qb += 4 * SCAN_RQ) {
+        const uint32_t nq_blk = c - qb < 4u * SCAN_RQ ? c - qb : 4u * SCAN_RQ;
+        const uint32_t qg = shape_of(nq_blk);
+        const uint32_t tv = (4 / qg) * SCAN_WAVE_VECS;
+        uint32_t& ni = cur[qg == 1 ? 0 : qg == 2 ? 1 : 2];
+        for (uint32_t vb = 0; vb < sz; vb += tv) {
+            ScanItem it;
+            it.vec_base = vb0 + vb;
+            it.nvec = sz - vb < tv ? sz - vb : tv;
+            it.vec_off = vb;
+            it.pair_begin = p0 + qb;
+            it.npair = nq_blk;
+            it.qg = qg;
+            it.qgroup = g0 + qb / SCAN_RQ;
+            if (ni < a.item_cap) a.items[ni] = it;
+            ni++;
+            slots += (unsigned long long)((nq_blk + SCAN_RQ - 1) / SCAN_RQ) * SCAN_RQ * tv;
+            useful += (unsigned long long)nq_blk * it.nvec;
+        }
+    }
+    atomicAdd(&a.acc64[0], slots);
+    atomicAdd(&a.acc64[1], useful);
+}
+
+void launch_plan(const PlanArgs& a, hipStream_t s) {
+    if (a.nq == 0) return;
+    const unsigned gq = (a.nq + 255) / 256, gl = (a.nlist + 255) / 256;
+    hipLaunchKernelGGL(plan_counts_kernel, dim3(gq), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(plan_prefix_kernel, dim3(1), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(plan_segments_kernel, dim3(gq), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(plan_lists_kernel, dim3(1), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(plan_scatter_kernel, dim3(gq), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(plan_items_kernel, dim3(gl), dim3(256), 0, s, a);
+}
+
+}  // namespace amdivf
