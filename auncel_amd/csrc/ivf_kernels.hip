@@ -306,6 +306,25 @@ __device__ inline float trace_search(const float* x, const float* z, uint32_t n,
     return z[low];
 }
 
+// The same lookup with the wave's lanes: on a non-decreasing x the reference's binary search ends on
+// low = #{x < k}, then steps back unless x[low] == k; counting needs one LDS pass instead of ~9 dependent reads.
+// (Only used when the trace was verified to be sorted at upload; bucket means can in principle come out of
+// Trace::SB out of order by a rounding error, and then the search path matters.)
+__device__ inline float trace_search_par(const float* x, const float* z, uint32_t n, float k, int lane) {
+    if (k <= x[0]) return z[0];
+    if (k >= x[n - 1]) {
+        const float ampli = k / x[n - 1];
+        return z[n - 1] * ampli;
+    }
+    uint32_t low = 0;
+    for (uint32_t b = 0; b < n; b += 64) {
+        const uint32_t i = b + lane;
+        low += __builtin_popcountll(__ballot(i < n && x[i] < k));
+    }
+    if (x[low] > k) low--;
+    return z[low];
+}
+
 // kscaling (IVF_pro.cpp:72-82)
 __device__ inline float kscaling_dev(float kdis, uint32_t in, const float* gt, uint32_t max_topk) {
     uint32_t index = 0;
@@ -408,6 +427,7 @@ __device__ inline float sum_angle_par(const float* lut, float kdis, const float*
 struct TraceLds {
     const float *x, *z;
     uint32_t n;
+    bool sorted;
 };
 
 // error_pro::cur_num (IVF_pro.cpp:258-291); Ds(m) = m-th best value (IP: its arcos)
@@ -418,13 +438,15 @@ __device__ inline uint32_t cur_num_lds(const TraceLds& tr, const float* lut, con
     unsigned long long high = query_k - 1, low = 0, middle = 0;
     auto Ds = [&](unsigned long long m) { return IsMax ? srt[m] : arcos_lut(lut, srt[m], err); };
     {
-        const float g = trace_search(tr.x, tr.z, tr.n, sum_angle_par(lut, Ds(high), dwin, lane, err));
+        const float sa = sum_angle_par(lut, Ds(high), dwin, lane, err);
+        const float g = tr.sorted ? trace_search_par(tr.x, tr.z, tr.n, sa, lane) : trace_search(tr.x, tr.z, tr.n, sa);
         if ((double)((float)query_k * g) <= (double)query_k * 1.005) return (uint32_t)query_k;
     }
     while (low <= high) {
         middle = (low + high) / 2;
         if (middle <= 0) return 0;
-        const float g = trace_search(tr.x, tr.z, tr.n, sum_angle_par(lut, Ds(middle), dwin, lane, err));
+        const float sa = sum_angle_par(lut, Ds(middle), dwin, lane, err);
+        const float g = tr.sorted ? trace_search_par(tr.x, tr.z, tr.n, sa, lane) : trace_search(tr.x, tr.z, tr.n, sa);
         if ((float)(middle + 1) * g <= (float)query_k) low = middle + 1;
         else high = middle - 1;
     }
@@ -505,7 +527,7 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
     float true_KD_K = 0.f, racc = 0.f;
     unsigned long long np = 0;
     int cached_ind = -1;
-    TraceLds tr{trc, trc + a.trace_cap, 0};
+    TraceLds tr{trc, trc + a.trace_cap, 0, false};
     if (tune) {
         query_k = a.tuner.query_topk;
         if (a.tuner.gt_D) true_KD_K = a.tuner.gt_D[id_q * (unsigned long long)k + query_k - 1];
@@ -542,17 +564,19 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
                         const uint32_t j = b0 + u * 64 + lane;
                         v[u] = j < n ? __builtin_nontemporal_load(seg + j) : hneutral<IsMax>();
                     }
+                    float top = hval[0];  // heap top, kept in a register between admissions
 #pragma unroll
                     for (int u = 0; u < NLD; u++) {
-                        unsigned long long m = __ballot(hcmp<IsMax>(hval[0], v[u]));
+                        unsigned long long m = __ballot(hcmp<IsMax>(top, v[u]));
                         while (m) {
                             const int l = __builtin_ctzll(m);
                             m &= m - 1;
-                            const float val = __shfl(v[u], l);
-                            if (hcmp<IsMax>(hval[0], val)) {
+                            const float val = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[u]), l));
+                            if (hcmp<IsMax>(top, val)) {
                                 heap_pop<IsMax>(k, hval, href);
                                 heap_push<IsMax>(k, hval, href, val, refbase | (int64_t)(b0 + u * 64 + l));
                                 st_nheap++;
+                                top = hval[0];
                                 if (geo) {  // the sorted view is only read at the end of the probe: defer
                                     if (npend < 16) pend[npend] = val;
                                     npend++;
@@ -598,6 +622,7 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
                     }
                     if (lane < 15) dwin[lane] = gdtb[(1u << ind) - 1 + lane];  // sum_angle start = 2^ind - 1
                     tr.n = n;
+                    tr.sorted = (a.tuner.sorted_mask >> ind) & 1u;
                     cached_ind = (int)ind;
                     wave_sync();
                 }
