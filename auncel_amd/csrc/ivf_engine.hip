@@ -180,7 +180,6 @@ struct amd_ivf {
     bool have_interdis = false;
     DevBuf d_arcos, d_trace_off, d_trace_x, d_trace_y, d_trace_std;
     size_t tuner_max_topk = 0, tuner_ntraces = 0, tuner_trace_cap = 0;
-    uint32_t tuner_sorted_mask = 0;
     bool have_tuner = false;
 
     // workspaces (grow only)
@@ -883,7 +882,6 @@ TunerDev make_tuner(amd_ivf* h, size_t query_topk, float multipler, float std_m,
     t.std_m = std_m;
     t.interdis = ix(h)->d_interdis.as<float>();
     t.arcos = ix(h)->d_arcos.as<float>();
-    t.sorted_mask = ix(h)->tuner_sorted_mask;
     t.trace_off = ix(h)->d_trace_off.as<uint32_t>();
     t.trace_x = ix(h)->d_trace_x.as<float>();
     t.trace_y = ix(h)->d_trace_y.as<float>();
@@ -1572,11 +1570,7 @@ int amd_ivf_set_tuner(amd_ivf_t* h, size_t max_topk, size_t ntraces, const size_
     h->tuner_max_topk = max_topk;
     h->tuner_ntraces = ntraces;
     h->tuner_trace_cap = 0;
-    h->tuner_sorted_mask = 0;
-    for (size_t i = 0; i < ntraces; i++) {
-        h->tuner_trace_cap = std::max(h->tuner_trace_cap, trace_len[i]);
-        if (i < 32 && std::is_sorted(trace_x[i], trace_x[i] + trace_len[i])) h->tuner_sorted_mask |= 1u << i;
-    }
+    for (size_t i = 0; i < ntraces; i++) h->tuner_trace_cap = std::max(h->tuner_trace_cap, trace_len[i]);
     h->have_tuner = true;
     API_END
 }

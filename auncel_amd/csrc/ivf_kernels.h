@@ -64,7 +64,6 @@ struct TunerDev {
     float multipler, std_m;
     const float* interdis;     // packed upper-triangular centroid table
     const float* arcos;        // 500-entry LUT
-    uint32_t sorted_mask;      // bit i: trace i's x array is non-decreasing (checked at upload)
     const uint32_t* trace_off; // ntraces + 1
     const float *trace_x, *trace_y, *trace_std;
     const float* require_acc;  // by absolute query id

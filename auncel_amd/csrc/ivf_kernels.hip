@@ -306,25 +306,6 @@ __device__ inline float trace_search(const float* x, const float* z, uint32_t n,
     return z[low];
 }
 
-// The same lookup with the wave's lanes: on a non-decreasing x the reference's binary search ends on
-// low = #{x < k}, then steps back unless x[low] == k; counting needs one LDS pass instead of ~9 dependent reads.
-// (Only used when the trace was verified to be sorted at upload; bucket means can in principle come out of
-// Trace::SB out of order by a rounding error, and then the search path matters.)
-__device__ inline float trace_search_par(const float* x, const float* z, uint32_t n, float k, int lane) {
-    if (k <= x[0]) return z[0];
-    if (k >= x[n - 1]) {
-        const float ampli = k / x[n - 1];
-        return z[n - 1] * ampli;
-    }
-    uint32_t low = 0;
-    for (uint32_t b = 0; b < n; b += 64) {
-        const uint32_t i = b + lane;
-        low += __builtin_popcountll(__ballot(i < n && x[i] < k));
-    }
-    if (x[low] > k) low--;
-    return z[low];
-}
-
 // kscaling (IVF_pro.cpp:72-82)
 __device__ inline float kscaling_dev(float kdis, uint32_t in, const float* gt, uint32_t max_topk) {
     uint32_t index = 0;
@@ -427,7 +408,6 @@ __device__ inline float sum_angle_par(const float* lut, float kdis, const float*
 struct TraceLds {
     const float *x, *z;
     uint32_t n;
-    bool sorted;
 };
 
 // error_pro::cur_num (IVF_pro.cpp:258-291); Ds(m) = m-th best value (IP: its arcos)
@@ -438,15 +418,13 @@ __device__ inline uint32_t cur_num_lds(const TraceLds& tr, const float* lut, con
     unsigned long long high = query_k - 1, low = 0, middle = 0;
     auto Ds = [&](unsigned long long m) { return IsMax ? srt[m] : arcos_lut(lut, srt[m], err); };
     {
-        const float sa = sum_angle_par(lut, Ds(high), dwin, lane, err);
-        const float g = tr.sorted ? trace_search_par(tr.x, tr.z, tr.n, sa, lane) : trace_search(tr.x, tr.z, tr.n, sa);
+        const float g = trace_search(tr.x, tr.z, tr.n, sum_angle_par(lut, Ds(high), dwin, lane, err));
         if ((double)((float)query_k * g) <= (double)query_k * 1.005) return (uint32_t)query_k;
     }
     while (low <= high) {
         middle = (low + high) / 2;
         if (middle <= 0) return 0;
-        const float sa = sum_angle_par(lut, Ds(middle), dwin, lane, err);
-        const float g = tr.sorted ? trace_search_par(tr.x, tr.z, tr.n, sa, lane) : trace_search(tr.x, tr.z, tr.n, sa);
+        const float g = trace_search(tr.x, tr.z, tr.n, sum_angle_par(lut, Ds(middle), dwin, lane, err));
         if ((float)(middle + 1) * g <= (float)query_k) low = middle + 1;
         else high = middle - 1;
     }
@@ -527,7 +505,7 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
     float true_KD_K = 0.f, racc = 0.f;
     unsigned long long np = 0;
     int cached_ind = -1;
-    TraceLds tr{trc, trc + a.trace_cap, 0, false};
+    TraceLds tr{trc, trc + a.trace_cap, 0};
     if (tune) {
         query_k = a.tuner.query_topk;
         if (a.tuner.gt_D) true_KD_K = a.tuner.gt_D[id_q * (unsigned long long)k + query_k - 1];
@@ -622,7 +600,6 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
                     }
                     if (lane < 15) dwin[lane] = gdtb[(1u << ind) - 1 + lane];  // sum_angle start = 2^ind - 1
                     tr.n = n;
-                    tr.sorted = (a.tuner.sorted_mask >> ind) & 1u;
                     cached_ind = (int)ind;
                     wave_sync();
                 }
