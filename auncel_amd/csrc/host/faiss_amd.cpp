@@ -745,3 +745,210 @@ Index* index_factory(int d, const char* description, MetricType metric) {
 }
 
 }  // namespace faiss
+
+// ------------------------------------------------------------------------------------- index_io
+#include "index_io.h"
+
+namespace faiss {
+
+namespace {
+
+uint32_t fourcc(const char* s) {
+    const unsigned char* x = reinterpret_cast<const unsigned char*>(s);
+    return x[0] | x[1] << 8 | x[2] << 16 | (uint32_t)x[3] << 24;
+}
+
+struct Writer {
+    FILE* f;
+    std::string name;
+    template <class T> void put(const T& v) { raw(&v, sizeof(T)); }
+    void raw(const void* p, size_t n) {
+        if (n && fwrite(p, 1, n, f) != n) FAISS_THROW_FMT("write error in %s", name.c_str());
+    }
+    template <class T> void vec(const std::vector<T>& v) {
+        size_t n = v.size();
+        put(n);
+        raw(v.data(), n * sizeof(T));
+    }
+};
+
+struct Reader {
+    FILE* f;
+    std::string name;
+    template <class T> void get(T& v) { raw(&v, sizeof(T)); }
+    void raw(void* p, size_t n) {
+        if (n && fread(p, 1, n, f) != n) FAISS_THROW_FMT("read error in %s", name.c_str());
+    }
+    template <class T> void vec(std::vector<T>& v) {
+        size_t n;
+        get(n);
+        FAISS_THROW_IF_NOT_MSG(n < (size_t(1) << 40), "implausible vector size in index file");
+        v.resize(n);
+        raw(v.data(), n * sizeof(T));
+    }
+};
+
+// d (int), ntotal, two dummies, is_trained (bool), metric_type (int)   [index_io.cpp:205-213, 562-571]
+void write_header(const Index* idx, Writer& w) {
+    w.put(idx->d);
+    w.put(idx->ntotal);
+    Index::idx_t dummy = 1 << 20;
+    w.put(dummy);
+    w.put(dummy);
+    w.put(idx->is_trained);
+    w.put(idx->metric_type);
+}
+
+void read_header(Index* idx, Reader& r) {
+    r.get(idx->d);
+    r.get(idx->ntotal);
+    Index::idx_t dummy;
+    r.get(dummy);
+    r.get(dummy);
+    r.get(idx->is_trained);
+    r.get(idx->metric_type);
+    idx->verbose = false;
+}
+
+void write_any(const Index* idx, Writer& w);
+
+void write_invlists(const InvertedLists* ils, Writer& w) {
+    const ArrayInvertedLists* al = dynamic_cast<const ArrayInvertedLists*>(ils);
+    if (!al) {
+        w.put(fourcc("il00"));
+        return;
+    }
+    w.put(fourcc("ilar"));
+    w.put(al->nlist);
+    w.put(al->code_size);
+    size_t non0 = 0;
+    for (size_t i = 0; i < al->nlist; i++) non0 += al->ids[i].empty() ? 0 : 1;
+    std::vector<size_t> sizes;
+    if (non0 > al->nlist / 2) {  // dense table of sizes, else (list, size) pairs  [index_io.cpp:296-320]
+        w.put(fourcc("full"));
+        for (size_t i = 0; i < al->nlist; i++) sizes.push_back(al->ids[i].size());
+    } else {
+        w.put(fourcc("sprs"));
+        for (size_t i = 0; i < al->nlist; i++)
+            if (!al->ids[i].empty()) {
+                sizes.push_back(i);
+                sizes.push_back(al->ids[i].size());
+            }
+    }
+    w.vec(sizes);
+    for (size_t i = 0; i < al->nlist; i++) {
+        size_t n = al->ids[i].size();
+        if (!n) continue;
+        w.raw(al->codes[i].data(), n * al->code_size);
+        w.raw(al->ids[i].data(), n * sizeof(Index::idx_t));
+    }
+}
+
+void write_any(const Index* idx, Writer& w) {
+    if (const IndexFlat* f = dynamic_cast<const IndexFlat*>(idx)) {
+        w.put(fourcc(f->metric_type == METRIC_INNER_PRODUCT ? "IxFI" : "IxF2"));
+        write_header(idx, w);
+        w.vec(f->xb);
+    } else if (const IndexIVFFlat* ivf = dynamic_cast<const IndexIVFFlat*>(idx)) {
+        w.put(fourcc("IwFl"));
+        write_header(ivf, w);
+        w.put(ivf->nlist);
+        w.put(ivf->nprobe);
+        write_any(ivf->quantizer, w);
+        w.put(ivf->maintain_direct_map);
+        w.vec(ivf->direct_map);
+        write_invlists(ivf->invlists, w);
+    } else {
+        FAISS_THROW_MSG("write_index: only IndexFlat and IndexIVFFlat are on this path");
+    }
+}
+
+Index* read_any(Reader& r) {
+    uint32_t h;
+    r.get(h);
+    if (h == fourcc("IxFI") || h == fourcc("IxF2")) {
+        IndexFlat* f = h == fourcc("IxFI") ? static_cast<IndexFlat*>(new IndexFlatIP()) : new IndexFlatL2();
+        read_header(f, r);
+        r.vec(f->xb);
+        FAISS_THROW_IF_NOT(f->xb.size() == (size_t)f->ntotal * f->d);
+        return f;
+    }
+    if (h == fourcc("IwFl")) {
+        IndexIVFFlat* ivf = new IndexIVFFlat();
+        read_header(ivf, r);
+        r.get(ivf->nlist);
+        r.get(ivf->nprobe);
+        ivf->quantizer = read_any(r);
+        ivf->own_fields = true;
+        r.get(ivf->maintain_direct_map);
+        r.vec(ivf->direct_map);
+        ivf->code_size = ivf->d * sizeof(float);
+        uint32_t hl;
+        r.get(hl);
+        if (hl == fourcc("il00")) {
+            ivf->invlists = new ArrayInvertedLists(ivf->nlist, ivf->code_size);
+        } else {
+            FAISS_THROW_IF_NOT_MSG(hl == fourcc("ilar"), "unsupported inverted list type");
+            size_t nlist, code_size;
+            r.get(nlist);
+            r.get(code_size);
+            FAISS_THROW_IF_NOT(nlist == ivf->nlist && code_size == ivf->code_size);
+            ArrayInvertedLists* al = new ArrayInvertedLists(nlist, code_size);
+            uint32_t lt;
+            r.get(lt);
+            std::vector<size_t> tab, sizes(nlist, 0);
+            r.vec(tab);
+            if (lt == fourcc("full")) {
+                FAISS_THROW_IF_NOT(tab.size() == nlist);
+                sizes = tab;
+            } else if (lt == fourcc("sprs")) {
+                for (size_t j = 0; j + 1 < tab.size(); j += 2) sizes[tab[j]] = tab[j + 1];
+            } else {
+                FAISS_THROW_MSG("invalid list_type");
+            }
+            for (size_t i = 0; i < nlist; i++) {
+                al->ids[i].resize(sizes[i]);
+                al->codes[i].resize(sizes[i] * code_size);
+                if (sizes[i]) {
+                    r.raw(al->codes[i].data(), sizes[i] * code_size);
+                    r.raw(al->ids[i].data(), sizes[i] * sizeof(Index::idx_t));
+                }
+            }
+            al->version = 1;
+            ivf->invlists = al;
+        }
+        ivf->own_invlists = true;
+        return ivf;
+    }
+    FAISS_THROW_MSG("read_index: only IxF2 / IxFI / IwFl files are on this path");
+}
+
+}  // namespace
+
+void write_index(const Index* idx, const char* fname) {
+    Writer w{fopen(fname, "wb"), fname};
+    FAISS_THROW_IF_NOT_FMT(w.f, "could not open %s for writing", fname);
+    try {
+        write_any(idx, w);
+    } catch (...) {
+        fclose(w.f);
+        throw;
+    }
+    fclose(w.f);
+}
+
+Index* read_index(const char* fname, int) {
+    Reader r{fopen(fname, "rb"), fname};
+    FAISS_THROW_IF_NOT_FMT(r.f, "could not open %s for reading", fname);
+    Index* idx = nullptr;
+    try {
+        idx = read_any(r);
+    } catch (...) {
+        fclose(r.f);
+        throw;
+    }
+    fclose(r.f);
+    return idx;
+}
+
+}  // namespace faiss

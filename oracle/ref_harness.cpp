@@ -6,7 +6,7 @@
 // built binary under oracle/_ref/ travels there but is optional (cpu_baseline kind
 // "reference").  Nothing in the product imports or links this.
 //
-// usage: ref_harness <fixed|auncel> <in.tb> <out.tb>
+// usage: ref_harness <fixed|auncel|io> <in.tb> <out.tb>
 //
 // Reference entry points exercised (file:line in /root/reference/Auncel):
 //   IndexFlat::search             IndexFlat.cpp:42-56   (knn_L2sqr_sse / _blas, utils.cpp:454-655)
@@ -32,6 +32,7 @@
 #include "IndexIVFFlat.h"
 #include "IndexShards.h"
 #include "InvertedLists.h"
+#include "index_io.h"
 #include "profile.h"
 #include "tbundle.h"
 
@@ -171,6 +172,41 @@ static int run_fixed(const tb::Bundle& in, tb::Bundle& out) {
             out.put_i64("I_shards_k" + std::to_string(k), {nq, k}, to_i64(I).data());
         }
     }
+    return 0;
+}
+
+static std::vector<uint8_t> slurp(const char* fn) {
+    FILE* f = fopen(fn, "rb");
+    std::vector<uint8_t> b;
+    if (!f) return b;
+    int c;
+    while ((c = fgetc(f)) != EOF) b.push_back((uint8_t)c);
+    fclose(f);
+    return b;
+}
+
+// write_index of the reference on a small IVF-Flat index: before add ("sprs" list table) and after ("full")
+static int run_io(const tb::Bundle& in, tb::Bundle& out) {
+    size_t d = in.scalar<size_t>("d"), nlist = in.scalar<size_t>("nlist");
+    MetricType mt = in.scalar<int>("metric") == 0 ? METRIC_INNER_PRODUCT : METRIC_L2;
+    const tb::Tensor& cen = in.get("centroids");
+    const tb::Tensor& xb = in.get("xb");
+    size_t nb = xb.dims[0];
+    IndexFlat quantizer(d, mt);
+    quantizer.add(nlist, cen.as<float>());
+    IndexIVFFlat index(&quantizer, d, nlist, mt);
+    index.nprobe = in.scalar<size_t>("nprobe");
+    write_index(&index, "empty.index");
+    std::vector<uint8_t> b0 = slurp("empty.index");
+    out.put("index_empty", tb::U8, {b0.size()}, b0.data());
+    index.init_tune(0, 1, nullptr, nullptr, nullptr, nullptr, nullptr);
+    index.add(nb, xb.as<float>());
+    write_index(&index, "full.index");
+    std::vector<uint8_t> b1 = slurp("full.index");
+    out.put("index_full", tb::U8, {b1.size()}, b1.data());
+    std::vector<idx_t> a(nb);
+    quantizer.assign(nb, xb.as<float>(), a.data());
+    out.put_i64("assign", {nb}, to_i64(a).data());
     return 0;
 }
 
@@ -353,7 +389,7 @@ int main(int argc, char** argv) {
         tb::Bundle out;
         std::string cmd = argv[1];
         // note: sys_train writes Validation_*.log into the CWD: run from a scratch dir
-        int rc = cmd == "fixed" ? run_fixed(in, out) : cmd == "auncel" ? run_auncel(in, out) : 2;
+        int rc = cmd == "fixed" ? run_fixed(in, out) : cmd == "auncel" ? run_auncel(in, out) : cmd == "io" ? run_io(in, out) : 2;
         if (rc == 0) out.save(argv[3]);
         return rc;
     } catch (const std::exception& e) {

@@ -77,7 +77,20 @@ def auncel_gauss_d64():
     return _auncel(xb, xq, 200, 100, [(10, 0.9, 1.7, 1.0), (100, 0.9, 1.2, 3.0)])
 
 
-CASES = {f.__name__: f for f in [fixed_sift_l2, fixed_gauss_l2_d96, fixed_deep_ip_d96, fixed_gist_l2_d960,
+def io_ragged():
+    c = fixed_ragged()
+    c["kind"] = "io"
+    return c
+
+
+def io_sift():
+    xb, xq = synth.sift_like(3000, 4, d=32, nblobs=10, sigma=30.0, seed=31)
+    c = _fixed(xb, xq, 16, 4, [10])
+    c["kind"] = "io"
+    return c
+
+
+CASES = {f.__name__: f for f in [io_ragged, io_sift, fixed_sift_l2, fixed_gauss_l2_d96, fixed_deep_ip_d96, fixed_gist_l2_d960,
                                   fixed_odd_d30, fixed_ragged, fixed_dups, auncel_sift_d32, auncel_gauss_d64]}
 
 

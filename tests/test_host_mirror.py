@@ -68,3 +68,42 @@ def test_error_sys_flow(driver, oracle, tmp_path, name):
         for k in ("I", "D", "my_nprobe"):
             t[f"{k}_r{r}"] = gold[f"{k}_r{r}"]
     _run(driver, "auncel", t, tmp_path)
+
+
+@pytest.mark.parametrize("name", ["io_ragged", "io_sift"])
+def test_index_io_bytes(tmp_path, name):
+    """write_index / read_index of the mirror against index files written by the reference (CPU only)"""
+    from auncel_amd import build
+    from oracle import tbundle
+    build.build_host()
+    exe = str(tmp_path / "index_io_driver")
+    subprocess.run(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "cpp", "index_io_driver.cpp"), "-o", exe, "-L" + build.LIBDIR,
+                    "-lfaiss_amd", "-launcel_amd", "-Wl,-rpath," + build.LIBDIR], check=True)
+    case, gold = load_case(name)
+    t = {k: v for k, v in case.items() if k != "kind"}
+    t.update({k: v for k, v in gold.items() if k != "input_sha"})
+    f = str(tmp_path / "in.tb")
+    tbundle.save(f, t)
+    r = subprocess.run([exe, f, str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/Auncel/eval/bound.cpp"), reason="reference tree not present")
+def test_reference_harness_builds_against_mirror(tmp_path):
+    """drop-in check: the reference's own eval/bound.cpp (the north-star caller) compiles unmodified against the
+    mirror headers and links with libfaiss_amd + libauncel_amd; effect_error / overhead compile as well"""
+    from auncel_amd import build
+    build.build_host()
+    root = tmp_path / "Auncel"
+    root.mkdir()
+    os.symlink("/root/reference/Auncel/eval", root / "eval")  # the sources stay where they are
+    for f in os.listdir(build.HOST_DIR):
+        if f.endswith(".h"):
+            os.symlink(os.path.join(build.HOST_DIR, f), root / f)
+    for src in ("bound", "effect_error", "overhead"):
+        subprocess.run(["g++", "-std=c++17", "-O0", "-fopenmp", "-w", "-c", str(root / "eval" / f"{src}.cpp"), "-o", str(tmp_path / f"{src}.o")],
+                       check=True)
+    subprocess.run(["g++", "-fopenmp", str(tmp_path / "bound.o"), "-L" + build.LIBDIR, "-lfaiss_amd", "-launcel_amd",
+                    "-Wl,-rpath," + build.LIBDIR, "-o", str(tmp_path / "bound")], check=True)
+    r = subprocess.run([str(tmp_path / "bound")], capture_output=True, text=True)  # no argv: usage path, no GPU touched
+    assert r.returncode != 127
