@@ -446,12 +446,10 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
                 }
             }
         }
-        // ---- tiles, grouped by workgroup shape (qg 1 | 2 | 4) so that each shape gets its own launch.
-        // The c queries of a list go into blocks of 32 (qg 4: 4 waves x 8 queries x 128 vectors); the
-        // remainder block takes the narrowest shape that holds it (<= 8: qg 1 = 512 vectors per block,
-        // <= 16: qg 2), so that no wave runs without queries.
-        auto rem_qg = [](uint32_t r) -> uint32_t { return r <= SCAN_RQ ? 1 : r <= 2 * SCAN_RQ ? 2 : 4; };
-        size_t n_qg[3] = {0, 0, 0};
+        // ---- tiles, grouped by workgroup shape (qg 1 | 2 | 4 | 8) so that each shape gets its own launch.  The c queries
+        // of a list go into blocks of 64 (qg 8: 8 waves x 8 queries over one 128-vector tile); the remainder block takes
+        // the narrowest shape that holds it, so that no wave runs without queries.
+        size_t n_qg[4] = {0, 0, 0, 0};
         std::vector<uint32_t> gbase(nlist, 0);
         std::vector<std::pair<uint32_t, uint32_t>> qranges;
         {
@@ -468,26 +466,26 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
             uint32_t c = lcount[l + 1] - lcount[l];
             if (!c) continue;
             const size_t sz = off[l + 1] - off[l];
-            const uint32_t full = c / (4 * SCAN_RQ), rem = c % (4 * SCAN_RQ);
-            n_qg[2] += (size_t)full * ((sz + SCAN_WAVE_VECS - 1) / SCAN_WAVE_VECS);
+            const uint32_t full = c / SCAN_QBLOCK, rem = c % SCAN_QBLOCK;
+            n_qg[3] += (size_t)full * ((sz + SCAN_WAVE_VECS - 1) / SCAN_WAVE_VECS);
             if (rem) {
-                uint32_t qg = rem_qg(rem);
-                size_t tv = (4 / qg) * SCAN_WAVE_VECS;
+                uint32_t qg = scan_shape_of(rem);
+                size_t tv = scan_tile_vecs(qg);
                 n_qg[scan_qg_class(qg)] += (sz + tv - 1) / tv;
             }
         }
-        const size_t nitems = n_qg[0] + n_qg[1] + n_qg[2];
+        const size_t nitems = n_qg[0] + n_qg[1] + n_qg[2] + n_qg[3];
         h->p_items.ensure(std::max<size_t>(nitems, 1) * sizeof(ScanItem));
         ScanItem* items = h->p_items.as<ScanItem>();
-        size_t cur[3] = {0, n_qg[0], n_qg[0] + n_qg[1]};
+        size_t cur[4] = {0, n_qg[0], n_qg[0] + n_qg[1], n_qg[0] + n_qg[1] + n_qg[2]};
         for (size_t l = 0; l < nlist; l++) {
             uint32_t c = lcount[l + 1] - lcount[l];
             if (!c) continue;
             const uint32_t sz = (uint32_t)(off[l + 1] - off[l]);
-            for (uint32_t qb = 0; qb < c; qb += 4 * SCAN_RQ) {
-                const uint32_t nq_blk = std::min<uint32_t>(4 * SCAN_RQ, c - qb);
-                const uint32_t qg = rem_qg(nq_blk);
-                const uint32_t tv = (4 / qg) * SCAN_WAVE_VECS;
+            for (uint32_t qb = 0; qb < c; qb += SCAN_QBLOCK) {
+                const uint32_t nq_blk = std::min<uint32_t>(SCAN_QBLOCK, c - qb);
+                const uint32_t qg = scan_shape_of(nq_blk);
+                const uint32_t tv = scan_tile_vecs(qg);
                 size_t& ni = cur[scan_qg_class(qg)];
                 for (uint32_t vb = 0; vb < sz; vb += tv) {
                     ScanItem& it = items[ni++];
@@ -499,7 +497,7 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
                     it.qg = qg;
                     it.qgroup = gbase[l] + qb / SCAN_RQ;
                     // bookkeeping: (query, vector) slots the waves that run will compute vs pairs wanted
-                    h->scan_slots += (double)((nq_blk + SCAN_RQ - 1) / SCAN_RQ) * SCAN_RQ * (qg == 4 ? SCAN_WAVE_VECS : qg == 2 ? 2 * SCAN_WAVE_VECS : 4 * SCAN_WAVE_VECS);
+                    h->scan_slots += (double)((nq_blk + SCAN_RQ - 1) / SCAN_RQ) * SCAN_RQ * tv;
                     h->scan_useful += (double)nq_blk * it.nvec;
                 }
             }
@@ -549,7 +547,7 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
                 HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
             }
             size_t t = h->timer.begin(CAT_SCAN, s);
-            const bool fork = (n_qg[0] || n_qg[1]) && n_qg[2];
+            const bool fork = (n_qg[0] || n_qg[1]) && (n_qg[2] || n_qg[3]);
             if (fork) {
                 HIP_CHECK(hipEventRecord(h->ev_fork, s));
                 for (int i = 0; i < 2; i++) HIP_CHECK(hipStreamWaitEvent(h->aux[i], h->ev_fork, 0));
@@ -704,8 +702,8 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
     for (size_t c0 = 0; c0 < n; c0 += chunk) {
         const size_t m = std::min(chunk, n - c0);
         // pairs: every query of the chunk against the single "list" = centroid table
-        const uint32_t qg = m <= SCAN_RQ ? 1 : m <= 2 * SCAN_RQ ? 2 : 4;
-        const uint32_t tv = (4 / qg) * SCAN_WAVE_VECS;
+        const uint32_t qg = scan_shape_of((uint32_t)std::min<size_t>(m, SCAN_QBLOCK));
+        const uint32_t tv = scan_tile_vecs(qg);
         const size_t nitems = ((m + qg * SCAN_RQ - 1) / (qg * SCAN_RQ)) * ((nlist + tv - 1) / tv);
         h->p_pair_query.ensure(m * 4);
         h->p_pair_out.ensure(m * 8);
@@ -755,7 +753,7 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
             launch_coarse_gemm(h->metric, d_x + c0 * h->dpad, ix(h)->d_centroids.as<float>(), h->w_xnorms.as<float>(),
                                ix(h)->d_centroid_norms.as<float>(), (int)m, (int)nlist, h->dpad, h->w_dist.as<float>(), s);
         } else {
-            size_t n_qg[3] = {0, 0, 0};
+            size_t n_qg[4] = {0, 0, 0, 0};
             n_qg[scan_qg_class(qg)] = nitems;
             launch_scan(sa, n_qg, s);
         }
@@ -904,7 +902,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     const size_t seg_cap = (size_t)2 << 20;
     size_t maxlist = 0;
     for (size_t l = 0; l < nlist; l++) maxlist = std::max<size_t>(maxlist, I->h_list_off[l + 1] - I->h_list_off[l]);
-    const size_t item_cap = (seg_cap / (4 * SCAN_RQ) + nlist) * ((maxlist + SCAN_WAVE_VECS - 1) / SCAN_WAVE_VECS) + nlist * 4 + 16;
+    const size_t item_cap = (seg_cap / SCAN_QBLOCK + nlist) * ((maxlist + SCAN_WAVE_VECS - 1) / SCAN_WAVE_VECS) + nlist * 4 + 16;
     const size_t budget = std::max<size_t>(h->dist_budget_floats, I->h_list_off[nlist] + 1);
     h->w_pl_cnt.ensure(n * 4);
     h->w_pl_need.ensure(n * 8);
@@ -921,7 +919,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     h->w_pl_lcount.ensure(nlist * 4);
     h->w_pl_lstart.ensure(nlist * 4);
     h->w_pl_gbase.ensure(nlist * 4);
-    h->w_pl_ibase.ensure(3 * nlist * 4);
+    h->w_pl_ibase.ensure(4 * nlist * 4);
     h->w_pl_fill.ensure(nlist * 4);
     h->w_pl_counters.ensure(96);  // 16 uint32 counters | double bytes | 2 x u64 slot bookkeeping
     h->p_counters.ensure(96);
@@ -989,8 +987,8 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         const double t1 = now_us();
         const uint32_t nact = hc[0], npairs = hc[2], ngroups = hc[3];
         if (nact == 0) break;
-        const size_t n_qg[3] = {hc[4], hc[5], hc[8]};
-        const size_t nitems = n_qg[0] + n_qg[1] + n_qg[2];
+        const size_t n_qg[4] = {hc[4], hc[5], hc[8], hc[9]};
+        const size_t nitems = n_qg[0] + n_qg[1] + n_qg[2] + n_qg[3];
         if (nitems > item_cap) throw std::runtime_error("tile list overflow");
         if (npairs) {
             h->w_qtile.ensure((size_t)ngroups * (size_t)h->dpad * SCAN_RQ * sizeof(float));
@@ -1008,7 +1006,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             sa.metric = h->metric;
             sa.fused = base.fused;
             size_t t = h->timer.begin(CAT_SCAN, s);
-            const bool fork = (n_qg[0] || n_qg[1]) && n_qg[2];
+            const bool fork = (n_qg[0] || n_qg[1]) && (n_qg[2] || n_qg[3]);
             if (fork) {
                 HIP_CHECK(hipEventRecord(h->ev_fork, s));
                 for (int i = 0; i < 2; i++) HIP_CHECK(hipStreamWaitEvent(h->aux[i], h->ev_fork, 0));
@@ -1454,7 +1452,7 @@ int amd_ivf_distance_to_code(amd_ivf_t* h, const float* query, size_t list_no, s
     pack_query_tiles(h, h->w_x.as<float>(), {{0u, 1u}});
     ScanArgs sa{h->d_codes.as<float>(), h->w_x.as<float>(), h->w_items.as<ScanItem>(), h->w_pair_query.as<uint32_t>(),
                 h->w_pair_out.as<uint64_t>(), h->w_dist.as<float>(), h->w_qtile.as<float>(), h->dpad, h->metric, 0};
-    const size_t one_qg1[3] = {1, 0, 0};
+    const size_t one_qg1[4] = {1, 0, 0, 0};
     launch_scan(sa, one_qg1, h->stream);
     HIP_CHECK(hipMemcpyAsync(dis, h->w_dist.p, 4, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -1520,7 +1518,7 @@ int amd_ivf_set_interdis(amd_ivf_t* h, const float* table) {
         pack_query_tiles(h, d_cq.as<float>(), {{0u, (uint32_t)nl}});
         ScanArgs sa{d_cq.as<float>(), d_cq.as<float>(), h->w_items.as<ScanItem>(), h->w_pair_query.as<uint32_t>(),
                     h->w_pair_out.as<uint64_t>(), d_full.as<float>(), h->w_qtile.as<float>(), h->dpad, h->metric, 0};
-        const size_t all_qg4[3] = {0, 0, items.size()};
+        const size_t all_qg4[4] = {0, 0, items.size(), 0};
         launch_scan(sa, all_qg4, h->stream);
         launch_pack_upper(d_full.as<float>(), (uint32_t)nl, h->d_interdis.as<float>(), h->stream);
         HIP_CHECK(hipStreamSynchronize(h->stream));

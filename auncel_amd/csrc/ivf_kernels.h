@@ -27,7 +27,7 @@ struct ScanItem {
     uint32_t vec_off;    // position of the tile's first vector inside its list
     uint32_t pair_begin; // first entry of this tile in the pair arrays
     uint32_t npair;      // queries in the tile (<= qg * SCAN_RQ)
-    uint32_t qg;         // query groups per workgroup: 1, 2 or 4
+    uint32_t qg;         // query groups per workgroup: 1, 2, 4 or 8
     uint32_t qgroup;     // index of the tile's first 8-query group in the packed query tiles
 };
 
@@ -44,15 +44,19 @@ struct ScanArgs {
     int fused;  // 1: fma(t, t, acc) -- only when the operands make it bit-identical to mul + add (see engine)
 };
 
-// items grouped by qg (1, then 2, then 4); n_qg = item count of each group
+// items grouped by qg (1, then 2, 4, 8); n_qg = item count of each group
 // the three shapes are independent: s2 / s1 (optional) let the sparse shapes run beside the dense one
-void launch_scan(const ScanArgs& a, const size_t n_qg[3], hipStream_t s, hipStream_t s2 = nullptr, hipStream_t s1 = nullptr);
+void launch_scan(const ScanArgs& a, const size_t n_qg[4], hipStream_t s, hipStream_t s2 = nullptr, hipStream_t s1 = nullptr);
 
 // gather + interleave the query rows of every group of (up to) 8 pairs: group g holds pairs
 // [group_p0[g], group_p0[g] + group_cnt[g]); missing slots are zero
 void launch_pack_queries(const float* queries, const uint32_t* pair_query, const uint32_t* group_p0, const uint32_t* group_cnt,
                          size_t ngroups, int d, float* qtile, hipStream_t s);
-inline int scan_qg_class(uint32_t qg) { return qg == 1 ? 0 : qg == 2 ? 1 : 2; }
+inline __host__ __device__ int scan_qg_class(uint32_t qg) { return qg == 1 ? 0 : qg == 2 ? 1 : qg == 4 ? 2 : 3; }
+// workgroup shape for the last `r` queries of a list (full blocks hold SCAN_QBLOCK = 64 queries)
+constexpr uint32_t SCAN_QBLOCK = 8 * SCAN_RQ;
+inline __host__ __device__ uint32_t scan_shape_of(uint32_t r) { return r <= SCAN_RQ ? 1u : r <= 2 * SCAN_RQ ? 2u : r <= 4 * SCAN_RQ ? 4u : 8u; }
+inline __host__ __device__ uint32_t scan_tile_vecs(uint32_t qg) { return (qg >= 4 ? 1u : 4u / qg) * SCAN_WAVE_VECS; }
 
 // ---------------------------------------------------------------------------- ordered selection
 // One wave per query replays the reference's sequential heap (Heap.h) over the distance rows in
@@ -163,7 +167,7 @@ struct PlanArgs {
     uint32_t* lcount;                // [nlist] zeroed by the host before the round
     uint32_t* lstart;
     uint32_t* gbase;
-    uint32_t* ibase;                 // [3][nlist]
+    uint32_t* ibase;                 // [4][nlist]
     uint32_t* fill;
     uint32_t* pair_query;
     uint64_t* pair_out;
@@ -173,7 +177,7 @@ struct PlanArgs {
     uint32_t item_cap;
     unsigned long long* acc64;       // [0] += (query, vector) slots computed, [1] += pairs wanted (tile bookkeeping)
     uint32_t* counters;              // [0] active queries [1] segments [2] pairs [3] groups [4] tiles qg1 [5] tiles qg2
-                                     // [6] scratch (compaction cursor, zeroed by host) [7] MiB of distances [8] tiles qg4
+                                     // [6] scratch (compaction cursor, zeroed by host) [7] MiB of distances [8] tiles qg4 [9] tiles qg8
     double* bytes;                   // [0] += algorithmic bytes of the round's distances
 };
 

@@ -29,20 +29,21 @@ namespace amdivf {
 typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int LDS_ROW = SCAN_DC + 4;                 // dwords per staged row (pad = one 16-B slot)
 
-// QG = query groups per workgroup (1, 2 or 4): 4 waves = QG groups of 8 queries x (4/QG) blocks of 128
-// vectors.  The staged tile, and with it the LDS footprint and the occupancy, depends on QG:
-// QG 4 -> 128 rows (18 KB), QG 2 -> 256 rows (36 KB), QG 1 -> 512 rows (72 KB).
+// QG = query groups per workgroup (1, 2, 4 or 8): QG groups of 8 queries x VG blocks of 128 vectors, one wave
+// each.  QG 8: 8 waves share one 128-vector tile (64 queries per pass over the list); QG 4: 4 waves, 128 vectors;
+// QG 2 / 1: 4 waves over 256 / 512 vectors.  The staged tile (and the LDS footprint) follows.
 template <int METRIC, int QG, bool FUSED>
-__global__ __launch_bounds__(256) void scan_tiles_kernel(ScanArgs a) {
+__global__ __launch_bounds__(QG == 8 ? 512 : 256) void scan_tiles_kernel(ScanArgs a) {
     constexpr int qg = QG;
-    constexpr int vg = 4 / QG;
+    constexpr int NT = QG == 8 ? 512 : 256;
+    constexpr int vg = QG >= 4 ? 1 : 4 / QG;
     constexpr int tile_vecs = vg * SCAN_WAVE_VECS;
     // two staging buffers: chunk c+1 is fetched into registers while chunk c is being consumed, and written
     // to the other buffer, so a workgroup needs one barrier per chunk and hides its own fetch latency
     __shared__ float lds[2][tile_vecs * LDS_ROW];
     constexpr int SLOTS = SCAN_DC / 4;                     // 16-B slots per staged row
-    constexpr int NLD = tile_vecs * SLOTS / 256;           // fetches per thread per chunk
-    static_assert(tile_vecs * SLOTS % 256 == 0, "tile must split evenly over the workgroup");
+    constexpr int NLD = tile_vecs * SLOTS / NT;            // fetches per thread per chunk
+    static_assert(tile_vecs * SLOTS % NT == 0, "tile must split evenly over the workgroup");
 
     const ScanItem it = a.items[blockIdx.x];
     const int tid = threadIdx.x;
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void scan_tiles_kernel(ScanArgs a) {
         const int nslot = (d - c0 >= SCAN_DC ? SCAN_DC : d - c0) >> 2;
 #pragma unroll
         for (int i = 0; i < NLD; i++) {
-            const int idx = tid + i * 256;
+            const int idx = tid + i * NT;
             const int row = idx / SLOTS, slot = idx % SLOTS;
             dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (c0 < d && row < (int)it.nvec && slot < nslot)
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void scan_tiles_kernel(ScanArgs a) {
         float* stage = lds[buf];
 #pragma unroll
         for (int i = 0; i < NLD; i++) {
-            const int idx = tid + i * 256;
+            const int idx = tid + i * NT;
             *reinterpret_cast<float4*>(&stage[(idx / SLOTS) * LDS_ROW + (idx % SLOTS) * 4]) = pre[ph][i];
         }
         __syncthreads();
@@ -191,16 +192,17 @@ template <int QG> static void launch_scan_qg(ScanArgs a, size_t first, size_t n,
     if (n == 0) return;
     a.items += first;
     if (a.metric == METRIC_L2) {
-        if (a.fused) hipLaunchKernelGGL((scan_tiles_kernel<METRIC_L2, QG, true>), dim3((unsigned)n), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((scan_tiles_kernel<METRIC_L2, QG, false>), dim3((unsigned)n), dim3(256), 0, s, a);
+        if (a.fused) hipLaunchKernelGGL((scan_tiles_kernel<METRIC_L2, QG, true>), dim3((unsigned)n), dim3(QG == 8 ? 512 : 256), 0, s, a);
+        else hipLaunchKernelGGL((scan_tiles_kernel<METRIC_L2, QG, false>), dim3((unsigned)n), dim3(QG == 8 ? 512 : 256), 0, s, a);
     } else {
-        if (a.fused) hipLaunchKernelGGL((scan_tiles_kernel<METRIC_IP, QG, true>), dim3((unsigned)n), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((scan_tiles_kernel<METRIC_IP, QG, false>), dim3((unsigned)n), dim3(256), 0, s, a);
+        if (a.fused) hipLaunchKernelGGL((scan_tiles_kernel<METRIC_IP, QG, true>), dim3((unsigned)n), dim3(QG == 8 ? 512 : 256), 0, s, a);
+        else hipLaunchKernelGGL((scan_tiles_kernel<METRIC_IP, QG, false>), dim3((unsigned)n), dim3(QG == 8 ? 512 : 256), 0, s, a);
     }
 }
 
-// items must be grouped by qg: first n_qg[0] items with qg 1, then n_qg[1] with qg 2, then n_qg[2] with qg 4
-void launch_scan(const ScanArgs& a, const size_t n_qg[3], hipStream_t s, hipStream_t s2, hipStream_t s1) {
+// items must be grouped by qg: n_qg[0] items with qg 1, then n_qg[1] with qg 2, n_qg[2] with qg 4, n_qg[3] with qg 8
+void launch_scan(const ScanArgs& a, const size_t n_qg[4], hipStream_t s, hipStream_t s2, hipStream_t s1) {
+    launch_scan_qg<8>(a, n_qg[0] + n_qg[1] + n_qg[2], n_qg[3], s);
     launch_scan_qg<4>(a, n_qg[0] + n_qg[1], n_qg[2], s);
     launch_scan_qg<2>(a, n_qg[0], n_qg[1], s2 ? s2 : s);
     launch_scan_qg<1>(a, 0, n_qg[0], s1 ? s1 : s);

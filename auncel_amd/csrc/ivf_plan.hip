@@ -153,43 +153,42 @@ __global__ __launch_bounds__(256) void plan_segments_kernel(PlanArgs a) {
 }
 
 // ---- 4. one block: per-list pair offsets, query-group bases, tile counts per workgroup shape
-__device__ inline uint32_t shape_of(uint32_t r) { return r <= SCAN_RQ ? 1u : r <= 2 * SCAN_RQ ? 2u : 4u; }
 
 __global__ __launch_bounds__(1024) void plan_lists_kernel(PlanArgs a) {
-    __shared__ uint32_t s[5][1024];
-    __shared__ uint32_t carry[5];
+    __shared__ uint32_t s[6][1024];
+    __shared__ uint32_t carry[6];
     const int t = threadIdx.x;
-    if (t < 5) carry[t] = 0;
+    if (t < 6) carry[t] = 0;
     __syncthreads();
     for (uint32_t base = 0; base < a.nlist; base += 1024) {
         const uint32_t l = base + t;
-        uint32_t v[5] = {0, 0, 0, 0, 0};  // pairs, groups, tiles of shape 1, 2, 4
+        uint32_t v[6] = {0, 0, 0, 0, 0, 0};  // pairs, groups, tiles of shape 1, 2, 4, 8
         if (l < a.nlist) {
             const uint32_t c = a.lcount[l];
             if (c) {
                 const unsigned long long sz = a.list_off[l + 1] - a.list_off[l];
                 v[0] = c;
                 v[1] = (c + SCAN_RQ - 1) / SCAN_RQ;
-                const uint32_t full = c / (4 * SCAN_RQ), rem = c % (4 * SCAN_RQ);
-                v[4] = full * (uint32_t)((sz + SCAN_WAVE_VECS - 1) / SCAN_WAVE_VECS);
+                const uint32_t full = c / SCAN_QBLOCK, rem = c % SCAN_QBLOCK;
+                v[5] = full * (uint32_t)((sz + SCAN_WAVE_VECS - 1) / SCAN_WAVE_VECS);
                 if (rem) {
-                    const uint32_t qg = shape_of(rem);
-                    const uint32_t tv = (4 / qg) * SCAN_WAVE_VECS;
-                    v[qg == 1 ? 2 : qg == 2 ? 3 : 4] += (uint32_t)((sz + tv - 1) / tv);
+                    const uint32_t qg = scan_shape_of(rem);
+                    const uint32_t tv = scan_tile_vecs(qg);
+                    v[2 + scan_qg_class(qg)] += (uint32_t)((sz + tv - 1) / tv);
                 }
             }
         }
 #pragma unroll
-        for (int k = 0; k < 5; k++) s[k][t] = v[k];
+        for (int k = 0; k < 6; k++) s[k][t] = v[k];
         __syncthreads();
         for (int off = 1; off < 1024; off <<= 1) {
-            uint32_t w[5] = {0, 0, 0, 0, 0};
+            uint32_t w[6] = {0, 0, 0, 0, 0, 0};
             if (t >= off)
 #pragma unroll
-                for (int k = 0; k < 5; k++) w[k] = s[k][t - off];
+                for (int k = 0; k < 6; k++) w[k] = s[k][t - off];
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 5; k++) s[k][t] += w[k];
+            for (int k = 0; k < 6; k++) s[k][t] += w[k];
             __syncthreads();
         }
         if (l < a.nlist) {
@@ -198,12 +197,13 @@ __global__ __launch_bounds__(1024) void plan_lists_kernel(PlanArgs a) {
             a.ibase[0 * a.nlist + l] = carry[2] + s[2][t] - v[2];
             a.ibase[1 * a.nlist + l] = carry[3] + s[3][t] - v[3];
             a.ibase[2 * a.nlist + l] = carry[4] + s[4][t] - v[4];
+            a.ibase[3 * a.nlist + l] = carry[5] + s[5][t] - v[5];
             a.fill[l] = 0;
         }
         __syncthreads();
         if (t == 1023)
 #pragma unroll
-            for (int k = 0; k < 5; k++) carry[k] += s[k][t];
+            for (int k = 0; k < 6; k++) carry[k] += s[k][t];
         __syncthreads();
     }
     if (t == 0) {
@@ -212,6 +212,7 @@ __global__ __launch_bounds__(1024) void plan_lists_kernel(PlanArgs a) {
         a.counters[4] = carry[2];  // tiles of shape 1
         a.counters[5] = carry[3];  // tiles of shape 2
         a.counters[8] = carry[4];  // tiles of shape 4
+        a.counters[9] = carry[5];  // tiles of shape 8
     }
 }
 
@@ -243,16 +244,17 @@ __global__ __launch_bounds__(256) void plan_items_kernel(PlanArgs a) {
         a.group_p0[g0 + g] = p0 + o;
         a.group_cnt[g0 + g] = c - o < (uint32_t)SCAN_RQ ? c - o : (uint32_t)SCAN_RQ;
     }
-    const uint32_t n1 = a.counters[4], n2 = a.counters[5];
-    uint32_t cur[3] = {a.ibase[l], n1 + a.ibase[a.nlist + l], n1 + n2 + a.ibase[2 * a.nlist + l]};
+    const uint32_t n1 = a.counters[4], n2 = a.counters[5], n4 = a.counters[8];
+    uint32_t cur[4] = {a.ibase[l], n1 + a.ibase[a.nlist + l], n1 + n2 + a.ibase[2 * a.nlist + l],
+                       n1 + n2 + n4 + a.ibase[3 * a.nlist + l]};
     const uint32_t sz = (uint32_t)(a.list_off[l + 1] - a.list_off[l]);
     const uint64_t vb0 = a.list_off[l];
     unsigned long long slots = 0, useful = 0;
-    for (uint32_t qb = 0; qb < c; qb += 4 * SCAN_RQ) {
-        const uint32_t nq_blk = c - qb < 4u * SCAN_RQ ? c - qb : 4u * SCAN_RQ;
-        const uint32_t qg = shape_of(nq_blk);
-        const uint32_t tv = (4 / qg) * SCAN_WAVE_VECS;
-        uint32_t& ni = cur[qg == 1 ? 0 : qg == 2 ? 1 : 2];
+    for (uint32_t qb = 0; qb < c; qb += SCAN_QBLOCK) {
+        const uint32_t nq_blk = c - qb < SCAN_QBLOCK ? c - qb : SCAN_QBLOCK;
+        const uint32_t qg = scan_shape_of(nq_blk);
+        const uint32_t tv = scan_tile_vecs(qg);
+        uint32_t& ni = cur[scan_qg_class(qg)];
         for (uint32_t vb = 0; vb < sz; vb += tv) {
             ScanItem it;
             it.vec_base = vb0 + vb;
