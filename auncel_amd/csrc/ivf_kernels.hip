@@ -15,6 +15,8 @@
 #include "ivf_kernels.h"
 
 #include <float.h>
+#include <stdlib.h>
+#include <type_traits>
 
 namespace amdivf {
 
@@ -259,6 +261,136 @@ template <bool IsMax> __device__ inline void heap_push(int k, float* val, int64_
     ref[i] = id;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same heap, resident in registers (k <= 127): node i (1-based, Heap.h numbering) lives in lane
+// i & 63 of register i >> 6, so levels 0-5 (nodes 1..63) are in register 0 and level 6 in register 1.
+// A wave replays one query, so every index below is wave-uniform: nodes are read with v_readlane and
+// written with a lane-select, the sift loops run on the scalar unit, and an update costs a few hundred
+// cycles instead of ~14 dependent LDS round trips.  Each node carries the slot (0..k-1) of its 64-bit
+// id in an LDS table, so ids never move.
+struct RegHeap {
+    float v0, v1;
+    int s0, s1;
+};
+
+__device__ __forceinline__ float rl_f(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+__device__ __forceinline__ int rl_i(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+
+__device__ __forceinline__ float rh_val(const RegHeap& h, int node) {
+    const float a = rl_f(h.v0, node & 63), b = rl_f(h.v1, node & 63);
+    return node < 64 ? a : b;
+}
+__device__ __forceinline__ int rh_slot(const RegHeap& h, int node) {
+    const int a = rl_i(h.s0, node & 63), b = rl_i(h.s1, node & 63);
+    return node < 64 ? a : b;
+}
+__device__ __forceinline__ void rh_set(RegHeap& h, int node, float v, int s, int lane) {
+    const bool in0 = lane == node, in1 = lane == node - 64;
+    h.v0 = in0 ? v : h.v0;
+    h.s0 = in0 ? s : h.s0;
+    h.v1 = in1 ? v : h.v1;
+    h.s1 = in1 ? s : h.s1;
+}
+
+// Heap.h:88-118 (the node being removed, k, still takes part in the child comparisons, as there).
+// KC != 0: k is the compile-time constant KC and every bounds test folds away.  The walk down only compares
+// values; the nodes it passes are rewritten afterwards with mutually independent lane-selects.
+template <bool IsMax, int KC> __device__ __forceinline__ void rh_pop(RegHeap& h, int krt, int lane) {
+    const int k = KC ? KC : krt;
+    const float v = rh_val(h, k);
+    const int sv = rh_slot(h, k);
+    int pos[7];    // pos[j]: node visited on level j (pos[0] = root)
+    float cv[6];   // cv[j]: value moved up into pos[j]
+    pos[0] = 1;
+    int depth = 0;
+    bool going = true;
+#pragma unroll
+    for (int lvl = 0; lvl < 6; lvl++) {  // parent on level lvl (node < 64: register 0), children on level lvl + 1
+        const int i = pos[lvl];
+        const int i1 = i << 1, i2 = i1 + 1;
+        pos[lvl + 1] = i;
+        cv[lvl] = 0.f;
+        if (KC && (2 << lvl) > KC) going = false;  // the whole level lies beyond k
+        if (going && i1 <= k) {
+            const bool only_left = i2 == k + 1;
+            const int j2 = only_left ? i1 : i2;
+            float c1, c2;
+            if (lvl < 5) {
+                c1 = rl_f(h.v0, i1);
+                c2 = rl_f(h.v0, j2);
+            } else {
+                c1 = rl_f(h.v1, i1 - 64);
+                c2 = rl_f(h.v1, j2 - 64);
+            }
+            const bool left = only_left || hcmp<IsMax>(c1, c2);
+            const float c = left ? c1 : c2;
+            if (hcmp<IsMax>(v, c)) {
+                going = false;
+            } else {
+                pos[lvl + 1] = left ? i1 : i2;
+                cv[lvl] = c;
+                depth = lvl + 1;
+            }
+        } else {
+            going = false;
+        }
+    }
+#pragma unroll
+    for (int lvl = 0; lvl < 6; lvl++) {
+        if (KC && (2 << lvl) > KC) break;
+        if (lvl < depth) {
+            const int ci = pos[lvl + 1];
+            const int cs = lvl < 5 ? rl_i(h.s0, ci) : rl_i(h.s1, ci - 64);
+            const bool here = lane == pos[lvl];
+            h.v0 = here ? cv[lvl] : h.v0;
+            h.s0 = here ? cs : h.s0;
+        }
+    }
+    rh_set(h, pos[depth], v, sv, lane);
+}
+
+// Heap.h:125-142
+template <bool IsMax, int KC> __device__ __forceinline__ void rh_push(RegHeap& h, int krt, float v, int sv, int lane) {
+    int i = KC ? KC : krt;
+    while (i > 1) {
+        const int f = i >> 1;  // < 64
+        const float fv = rl_f(h.v0, f);
+        if (!hcmp<IsMax>(v, fv)) break;
+        const int fs = rl_i(h.s0, f);
+        rh_set(h, i, fv, fs, lane);
+        i = f;
+    }
+    rh_set(h, i, v, sv, lane);
+}
+
+// LDS heap arrays (node order) -> registers; slot j holds the id of node j + 1
+__device__ __forceinline__ void rh_load(RegHeap& h, const float* hval, int k, int lane) {
+    h.v0 = (lane >= 1 && lane <= k) ? hval[lane - 1] : 0.f;
+    h.s0 = lane - 1;
+    h.v1 = (lane + 64 <= k) ? hval[lane + 63] : 0.f;
+    h.s1 = lane + 63;
+}
+
+// registers -> LDS heap arrays in node order (ids permuted through registers)
+__device__ __forceinline__ void rh_store(const RegHeap& h, float* hval, int64_t* href, int k, int lane, bool with_refs) {
+    const bool n0 = lane >= 1 && lane <= k, n1 = lane + 64 <= k;
+    int64_t r0 = 0, r1 = 0;
+    if (with_refs) {
+        if (n0) r0 = href[h.s0];
+        if (n1) r1 = href[h.s1];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (n0) hval[lane - 1] = h.v0;
+    if (n1) hval[lane + 63] = h.v1;
+    if (with_refs) {
+        if (n0) href[lane - 1] = r0;
+        if (n1) href[lane + 63] = r1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
     for (int off = 32; off; off >>= 1) {
         const uint32_t o = (uint32_t)__shfl_xor((int)x, off);
@@ -442,13 +574,16 @@ __host__ __device__ inline size_t replay_wave_bytes(int k, uint32_t nlist, bool 
     return (b + 15) & ~(size_t)15;
 }
 
-template <bool IsMax>
-__global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
+// RH: the heap lives in registers (k <= 127); otherwise in LDS
+// NLD: 64-candidate chunks per trip of the candidate stream (registers for two trips are live)
+// KC: compile-time k of the register heap (0: run-time k)
+template <bool IsMax, bool RH, int NLD, int KC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ? 5 : 3))) void replay_kernel(ReplayArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool tune = a.tuner.enabled != 0, training = a.train.enabled != 0, geo = tune || training;
-    const int k = a.k;
+    const int k = KC ? KC : a.k;
     const uint32_t nlist = a.nlist;
     const uint32_t max_num = nlist / 8 + 20;
 
@@ -493,6 +628,9 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
     uint32_t stoped = a.stoped ? a.stoped[qi] : 0u;
     unsigned long long st_nlist = 0, st_nheap = 0, st_ndis = 0;
 
+    RegHeap rh{};
+    if (RH) rh_load(rh, hval, k, lane);
+
     int win_start = -1;
     if (geo) {
         rank_sort_best_first<IsMax>(hval, srt, k, lane);
@@ -516,47 +654,115 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
     }
     const unsigned long long np_in = np;
 
+    // The candidate stream (this round's distance rows, in probe order) comes in trips of NLD x 64 values.
+    // The loads of trip t + 1 are issued before trip t is examined, across probe boundaries: a wave owns one
+    // query, so its own loads in flight are all that hides the HBM round trip.
+    constexpr uint32_t TRIP = NLD * 64;
+    // probe table of the current window of 64 probes, one probe per lane: list number, candidates, row offset
+    uint32_t win0 = 0;
+    int m_key = -1;
+    uint32_t m_n = 0;
+    unsigned long long m_off = 0;
+    auto load_window = [&](uint32_t w0) {
+        win0 = w0;
+        m_key = -1;
+        m_n = 0;
+        m_off = 0;
+        const uint32_t pi = w0 + lane;
+        if (pi < cnt) {
+            m_key = a.seg_list[seg0 + pi];
+            m_off = a.seg_off[seg0 + pi];
+            if (m_key >= 0 && (uint32_t)m_key < nlist)
+                m_n = a.identity_ids ? nlist : (uint32_t)(a.list_off[m_key + 1] - a.list_off[m_key]);
+        }
+    };
+    load_window(0);
+    uint32_t fp = 0, fb = 0;  // fetch cursor: next (probe, offset); it never leaves the consumer's window
+    auto fetch = [&](float (&dst)[NLD]) {
+        for (;;) {
+            if (fp >= cnt || fp >= win0 + 64) return;
+            const uint32_t fn = (uint32_t)rl_i((int)m_n, (int)(fp - win0));
+            if (fb < fn) {
+                const unsigned long long fo = ((unsigned long long)(uint32_t)rl_i((int)(m_off >> 32), (int)(fp - win0)) << 32) |
+                                              (uint32_t)rl_i((int)(uint32_t)m_off, (int)(fp - win0));
+                const float* fseg = a.dist + fo;
+#pragma unroll
+                for (int u = 0; u < NLD; u++) {
+                    const uint32_t j = fb + u * 64 + lane;
+                    dst[u] = j < fn ? __builtin_nontemporal_load(fseg + j) : hneutral<IsMax>();
+                }
+                fb += TRIP;
+                if (fb >= fn) {
+                    fp++;
+                    fb = 0;
+                }
+                return;
+            }
+            fp++;
+            fb = 0;
+        }
+    };
+    float v[NLD], nv[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; u++) v[u] = nv[u] = hneutral<IsMax>();
+    fetch(v);
+
     bool finished = false;
     uint32_t consumed = 0;
     for (uint32_t p = 0; p < cnt && !finished; p++) {
         const uint32_t ik = ik0 + p;
         consumed = p + 1;
-        const int key = a.seg_list[seg0 + p];
+        if (p >= win0 + 64) {  // next window of the probe table; the stream restarts behind it
+            load_window(p);
+            fp = p;
+            fb = 0;
+            fetch(v);
+        }
+        const int key = rl_i(m_key, (int)(p - win0));
         if (key >= 0) {
             if ((uint32_t)key >= nlist) {
                 err = ERR_INVALID_KEY;
                 finished = true;
                 break;
             }
-            const uint32_t n = a.identity_ids ? a.nlist : (uint32_t)(a.list_off[key + 1] - a.list_off[key]);
+            const uint32_t n = (uint32_t)rl_i((int)m_n, (int)(p - win0));
             if (n > 0) {
                 st_nlist++;
-                const float* seg = a.dist + a.seg_off[seg0 + p];
                 const int64_t refbase = REF_TAG | ((int64_t)key << 32);
                 uint32_t npend = 0;
-                // 2048 candidates per trip: 32 coalesced 256-B loads in flight per wave (the loop is
-                // latency-bound: one wave per query, a trip costs one HBM round trip)
-                constexpr int NLD = 32;
-                for (uint32_t b0 = 0; b0 < n; b0 += NLD * 64) {
-                    float v[NLD];
+                for (uint32_t b0 = 0; b0 < n; b0 += TRIP) {
+                    fetch(nv);
+                    float top = RH ? rl_f(rh.v0, 1) : hval[0];  // heap top, kept in a register between admissions
+                    // chunks (64 candidates) holding at least one value that beats the top as it is now
+                    uint32_t umask = 0;
 #pragma unroll
-                    for (int u = 0; u < NLD; u++) {
-                        const uint32_t j = b0 + u * 64 + lane;
-                        v[u] = j < n ? __builtin_nontemporal_load(seg + j) : hneutral<IsMax>();
-                    }
-                    float top = hval[0];  // heap top, kept in a register between admissions
+                    for (int u = 0; u < NLD; u++) umask |= __ballot(hcmp<IsMax>(top, v[u])) ? (1u << u) : 0u;
+                    // one copy of the update code for all chunks (32 inlined copies do not fit the instruction cache)
+                    while (umask) {
+                        const int u = __builtin_ctz(umask);
+                        umask &= umask - 1;
+                        float x = v[0];
 #pragma unroll
-                    for (int u = 0; u < NLD; u++) {
-                        unsigned long long m = __ballot(hcmp<IsMax>(top, v[u]));
+                        for (int t = 1; t < NLD; t++) x = t == u ? v[t] : x;
+                        unsigned long long m = __ballot(hcmp<IsMax>(top, x));
                         while (m) {
                             const int l = __builtin_ctzll(m);
                             m &= m - 1;
-                            const float val = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[u]), l));
+                            const float val = rl_f(x, l);
                             if (hcmp<IsMax>(top, val)) {
-                                heap_pop<IsMax>(k, hval, href);
-                                heap_push<IsMax>(k, hval, href, val, refbase | (int64_t)(b0 + u * 64 + l));
+                                const int64_t nref = refbase | (int64_t)(b0 + u * 64 + l);
+                                if (RH) {
+                                    const int sr = rl_i(rh.s0, 1);  // the evicted root's id slot passes to the new entry
+                                    if (lane == 0) href[sr] = nref;
+                                    rh_pop<IsMax, KC>(rh, k, lane);
+                                    rh_push<IsMax, KC>(rh, k, val, sr, lane);
+                                    top = rl_f(rh.v0, 1);
+                                } else {
+                                    heap_pop<IsMax>(k, hval, href);
+                                    heap_push<IsMax>(k, hval, href, val, nref);
+                                    top = hval[0];
+                                }
                                 st_nheap++;
-                                top = hval[0];
                                 if (geo) {  // the sorted view is only read at the end of the probe: defer
                                     if (npend < 16) pend[npend] = val;
                                     npend++;
@@ -564,12 +770,15 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
                             }
                         }
                     }
+#pragma unroll
+                    for (int u = 0; u < NLD; u++) v[u] = nv[u];
                 }
                 if (geo && npend) {
                     wave_sync();
                     if (npend <= 16) {
                         for (uint32_t u = 0; u < npend; u++) sorted_replace_worst<IsMax>(srt, k, pend[u], lane);
                     } else {
+                        if (RH) rh_store(rh, hval, href, k, lane, false);
                         rank_sort_best_first<IsMax>(hval, srt, k, lane);
                         wave_sync();
                     }
@@ -638,6 +847,7 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
             }
             if (np != 0 && np <= stage) {
                 if (a.tuner.profile) {
+                    if (RH) rh_store(rh, hval, href, k, lane, false);
                     uint32_t hits = 0;
                     for (int i = lane; i < k; i += 64) {
                         const float s = hval[i];
@@ -705,6 +915,7 @@ __global__ __launch_bounds__(256) void replay_kernel(ReplayArgs a) {
     }
 
     wave_sync();
+    if (RH) rh_store(rh, hval, href, k, lane, true);  // back to the node-ordered LDS layout
     if (finished || a.finalize_all || err) {
         if (a.raw_heap_out) {
             for (int i = lane; i < k; i += 64) {
@@ -760,13 +971,24 @@ void launch_replay(const ReplayArgs& a, hipStream_t s) {
     const bool tune = a.tuner.enabled != 0, train = a.train.enabled != 0, geo = tune || train;
     const size_t shmem = (geo ? 2000 : 0) + 4 * replay_wave_bytes(a.k, a.nlist, geo, tune, train, a.trace_cap);
     const dim3 grid((a.nq + 3) / 4), block(256);
-    if (a.metric == METRIC_L2) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(replay_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        hipLaunchKernelGGL(replay_kernel<true>, grid, block, shmem, s, a);
-    } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(replay_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        hipLaunchKernelGGL(replay_kernel<false>, grid, block, shmem, s, a);
-    }
+    static const bool no_rh = getenv("AUNCEL_AMD_LDS_HEAP") != nullptr;
+    const bool rh = a.k <= 127 && !no_rh;
+    auto go = [&](auto kern) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        hipLaunchKernelGGL(kern, grid, block, shmem, s, a);
+    };
+    // few queries: longer trips (more loads in flight per wave) at the price of fewer resident waves
+    static const int nld_env = getenv("AUNCEL_AMD_REPLAY_NLD") ? atoi(getenv("AUNCEL_AMD_REPLAY_NLD")) : 0;
+    const bool wide = nld_env ? nld_env >= 32 : a.nq <= 3072;
+    auto pick = [&](auto is_max) {
+        constexpr bool M = decltype(is_max)::value;
+        if (!rh) return wide ? go(replay_kernel<M, false, 32, 0>) : go(replay_kernel<M, false, 16, 0>);
+        if (a.k == 100) return wide ? go(replay_kernel<M, true, 32, 100>) : go(replay_kernel<M, true, 16, 100>);
+        if (a.k == 10) return wide ? go(replay_kernel<M, true, 32, 10>) : go(replay_kernel<M, true, 16, 10>);
+        return wide ? go(replay_kernel<M, true, 32, 0>) : go(replay_kernel<M, true, 16, 0>);
+    };
+    if (a.metric == METRIC_L2) pick(std::true_type{});
+    else pick(std::false_type{});
 }
 
 // =============================================================================================
