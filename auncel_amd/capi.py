@@ -24,6 +24,7 @@ SYMBOLS = [
     "amd_ivf_set_tuner", "amd_ivf_search_adaptive", "amd_ivf_search_adaptive_x", "amd_ivf_train_samples",
     "amd_ivf_train_samples_x", "amd_ivf_trace_sb", "amd_ivf_arcos_table", "amd_ivf_merge_tables",
     "amd_ivf_last_timing",
+    "amd_ivf_scan_arith",
 ]
 
 
@@ -267,6 +268,10 @@ class Handle:
         _chk(lib().amd_ivf_train_samples(self._h, C.c_size_t(start), C.c_size_t(n), C.c_size_t(max_topk), _f(gt),
                                          C.c_size_t(train_num), coarse_mode, ptrs, _f(D), _i(I)))
         return D, I
+
+    def scan_arith(self):
+        """0 fp32 reference order, 1 fp32 fused, 2 byte codes (include/auncel_amd.h)"""
+        return int(lib().amd_ivf_scan_arith(self._h))
 
     def last_timing(self):
         t = (C.c_double * 8)()

@@ -63,6 +63,14 @@ struct IntRange {
         hi = std::max(hi, o.hi);
     }
     bool fusable_with(const IntRange& o) const { return ok && o.ok && std::max(hi, o.hi) <= 4095.f && std::min(lo, o.lo) >= -4095.f; }
+    // Byte-code scan (scan_tiles_kernel, ARITH 2): both sides hold integers 0..255 and no sum of d products can pass
+    // 2^24, so the reference's fp32 partial sums are exact integers in any order and integer arithmetic gives the
+    // same fp32 distance bit for bit.
+    bool bytes() const { return ok && lo >= 0.f && hi <= 255.f; }
+    bool bytes_with(const IntRange& o, size_t d) const {
+        const double m = std::max(hi, o.hi);
+        return bytes() && o.bytes() && (double)d * m * m <= 16777216.0;
+    }
 };
 
 struct DevBuf {
@@ -174,6 +182,10 @@ struct amd_ivf {
     size_t n_resident = 0;
     IntRange db_range, centroid_range, resident_range, call_range;  // see IntRange
     int allow_fused = 1;
+    int allow_bytes = 1;
+    int last_arith = 0;  // scan arithmetic of the last search: 0 reference order, 1 fused, 2 byte codes
+    DevBuf d_codes8, d_code_norms;  // byte copy of the lists + squared norms, kept while the data qualifies (IntRange::bytes)
+    bool have_codes8 = false;
 
     // Auncel state
     DevBuf d_interdis;
@@ -186,6 +198,7 @@ struct amd_ivf {
     DevBuf w_qtile, w_group_p0, w_group_cnt, w_xnorms;
     PinnedBuf p_group_p0, p_group_cnt, p_counters;
     DevBuf w_pl_cnt, w_pl_need, w_pl_dist_base, w_pl_lcount, w_pl_lstart, w_pl_gbase, w_pl_ibase, w_pl_fill, w_pl_counters;
+    DevBuf w_x8, w_xnorm8;  // byte copy of the current queries + squared norms
     DevBuf w_x, w_dist, w_items, w_pair_query, w_pair_out, w_seg_off, w_seg_list, w_seg_count, w_qsel;
     DevBuf w_heap_val, w_heap_ref, w_stage, w_nscan, w_done, w_pre_val, w_stoped, w_dtb, w_D, w_I;
     DevBuf w_cdis, w_ckeys, w_stats, w_error, w_misc, w_misc2, w_misc3, w_rawptrs;
@@ -246,8 +259,25 @@ void upload_lists(amd_ivf* h) {
     }
     HIP_CHECK(hipMemcpyAsync(h->d_list_off.p, h->h_list_off.data(), (h->nlist + 1) * sizeof(uint64_t),
                              hipMemcpyHostToDevice, h->stream));
+    h->have_codes8 = h->allow_bytes && nt > 0 && h->db_range.bytes() && h->d == h->dpad && h->d % 16 == 0;
+    if (h->have_codes8) {
+        h->d_codes8.ensure(nt * (size_t)h->d);
+        h->d_code_norms.ensure(nt * sizeof(uint32_t));
+        launch_bytes_from_f32(h->d_codes.as<float>(), nt, h->d, h->d_codes8.as<uint8_t>(), h->d_code_norms.as<uint32_t>(), h->stream);
+    }
     HIP_CHECK(hipStreamSynchronize(h->stream));
     h->lists_dirty = false;
+}
+
+// Byte view of n query rows (row stride dpad floats) when the lists have one and the queries qualify; fills
+// ws->w_x8 / w_xnorm8 with the same row numbering.  Returns false when the search has to run in fp32.
+bool byte_queries(amd_ivf* ws, const amd_ivf* index, const float* d_x, size_t n, const IntRange& qr) {
+    if (!index->have_codes8 || !ws->allow_bytes || n == 0) return false;
+    if (!index->db_range.bytes_with(qr, (size_t)index->d)) return false;
+    ws->w_x8.ensure(n * (size_t)index->d);
+    ws->w_xnorm8.ensure(n * sizeof(uint32_t));
+    launch_bytes_from_f32(d_x, n, index->d, ws->w_x8.as<uint8_t>(), ws->w_xnorm8.as<uint32_t>(), ws->stream);
+    return true;
 }
 
 // copy n x d host rows into a device matrix with row stride dpad (zero padded)
@@ -299,7 +329,9 @@ void init_state(amd_ivf* h, size_t n, size_t k, bool tune_or_train) {
 // Groups of 8 consecutive pairs (never crossing a list) get their query rows gathered and interleaved into
 // the layout the scan kernel's scalar loads want.  `ranges`: (first pair, pair count) of every run of pairs
 // that must start a new group (one per list); returns the group index of each run's first group.
-std::vector<uint32_t> pack_query_tiles(amd_ivf* h, const float* d_queries, const std::vector<std::pair<uint32_t, uint32_t>>& ranges) {
+std::vector<uint32_t> pack_query_tiles(amd_ivf* h, const float* d_queries, const std::vector<std::pair<uint32_t, uint32_t>>& ranges,
+                                       int row_words = 0) {
+    if (!row_words) row_words = h->dpad;  // 4-byte words per query row (byte rows: d / 4)
     std::vector<uint32_t> first(ranges.size());
     size_t ng = 0;
     for (size_t i = 0; i < ranges.size(); i++) {
@@ -319,12 +351,12 @@ std::vector<uint32_t> pack_query_tiles(amd_ivf* h, const float* d_queries, const
         }
     h->w_group_p0.ensure(std::max<size_t>(ng, 1) * 4);
     h->w_group_cnt.ensure(std::max<size_t>(ng, 1) * 4);
-    h->w_qtile.ensure(std::max<size_t>(ng, 1) * (size_t)h->dpad * SCAN_RQ * sizeof(float));
+    h->w_qtile.ensure(std::max<size_t>(ng, 1) * (size_t)row_words * SCAN_RQ * sizeof(float));
     if (ng) {
         HIP_CHECK(hipMemcpyAsync(h->w_group_p0.p, gp, ng * 4, hipMemcpyHostToDevice, h->stream));
         HIP_CHECK(hipMemcpyAsync(h->w_group_cnt.p, gc, ng * 4, hipMemcpyHostToDevice, h->stream));
         launch_pack_queries(d_queries, h->w_pair_query.as<uint32_t>(), h->w_group_p0.as<uint32_t>(), h->w_group_cnt.as<uint32_t>(), ng,
-                            h->dpad, h->w_qtile.as<float>(), h->stream);
+                            row_words, h->w_qtile.as<float>(), h->stream);
     }
     return first;
 }
@@ -343,6 +375,7 @@ struct RoundSpec {
     uint32_t total_nprobe = 0;
     uint64_t id_offset = 0;
     const float* d_x = nullptr;  // device queries, row = slot
+    bool bytes = false;          // scan the byte copies (ws->w_x8 / w_xnorm8 hold these queries)
     TunerDev tuner{};
     TrainDev train{};
     const float* d_cdis = nullptr;     // device coarse arrays for set_online (row = slot)
@@ -526,7 +559,10 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
             HIP_CHECK(hipMemcpyAsync(h->w_items.p, items, nitems * sizeof(ScanItem), hipMemcpyHostToDevice, s));
         }
         const double t_prep = now_us();
-        if (npairs) pack_query_tiles(h, r.d_x, qranges);
+        if (npairs) {
+            if (r.bytes) pack_query_tiles(h, h->w_x8.as<float>(), qranges, h->d / 4);
+            else pack_query_tiles(h, r.d_x, qranges);
+        }
         ScanArgs sa{};
         sa.qtile = h->w_qtile.as<float>();
         sa.codes = ix(h)->d_codes.as<float>();
@@ -538,6 +574,12 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
         sa.d = h->dpad;
         sa.metric = h->metric;
         sa.fused = r.fused;
+        if (r.bytes) {
+            sa.codes = ix(h)->d_codes8.as<float>();
+            sa.d = h->d / 4;
+            sa.code_norms = ix(h)->d_code_norms.as<uint32_t>();
+            sa.query_norms = h->w_xnorm8.as<uint32_t>();
+        }
         if (nitems) {
             if (!h->aux[0]) {
                 for (int i = 0; i < 2; i++) {
@@ -849,6 +891,8 @@ void search_fixed_core(amd_ivf* h, const float* d_x, size_t n, size_t k, size_t 
     r.finalize_all = 1;
     r.d_x = d_x;
     r.fused = h->allow_fused && h->db_range.fusable_with(qr);
+    r.bytes = byte_queries(h, ix(h), d_x, n, qr);
+    ix(h)->last_arith = r.bytes ? 2 : r.fused ? 1 : 0;
     exec_round(h, r);
     check_device_error(h);
     HIP_CHECK(hipMemcpyAsync(D, h->w_D.p, n * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -991,9 +1035,10 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         const size_t nitems = n_qg[0] + n_qg[1] + n_qg[2] + n_qg[3];
         if (nitems > item_cap) throw std::runtime_error("tile list overflow");
         if (npairs) {
-            h->w_qtile.ensure((size_t)ngroups * (size_t)h->dpad * SCAN_RQ * sizeof(float));
-            launch_pack_queries(base.d_x, h->w_pair_query.as<uint32_t>(), h->w_group_p0.as<uint32_t>(), h->w_group_cnt.as<uint32_t>(), ngroups,
-                                h->dpad, h->w_qtile.as<float>(), s);
+            const int row_words = base.bytes ? h->d / 4 : h->dpad;
+            h->w_qtile.ensure((size_t)ngroups * (size_t)row_words * SCAN_RQ * sizeof(float));
+            launch_pack_queries(base.bytes ? h->w_x8.as<float>() : base.d_x, h->w_pair_query.as<uint32_t>(), h->w_group_p0.as<uint32_t>(),
+                                h->w_group_cnt.as<uint32_t>(), ngroups, row_words, h->w_qtile.as<float>(), s);
             ScanArgs sa{};
             sa.qtile = h->w_qtile.as<float>();
             sa.codes = I->d_codes.as<float>();
@@ -1005,6 +1050,12 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             sa.d = h->dpad;
             sa.metric = h->metric;
             sa.fused = base.fused;
+            if (base.bytes) {
+                sa.codes = I->d_codes8.as<float>();
+                sa.d = h->d / 4;
+                sa.code_norms = I->d_code_norms.as<uint32_t>();
+                sa.query_norms = h->w_xnorm8.as<uint32_t>();
+            }
             size_t t = h->timer.begin(CAT_SCAN, s);
             const bool fork = (n_qg[0] || n_qg[1]) && (n_qg[2] || n_qg[3]);
             if (fork) {
@@ -1191,6 +1242,7 @@ int amd_ivf_create(int d, size_t nlist, int metric, int device, amd_ivf_t** out)
     h->h_ids.resize(nlist);
     h->h_list_off.assign(nlist + 1, 0);
     if (getenv("AUNCEL_AMD_NO_FUSED")) h->allow_fused = 0;
+    if (getenv("AUNCEL_AMD_NO_BYTES")) h->allow_bytes = 0;
     *out = h.release();
     API_END
 }
@@ -1589,6 +1641,8 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
                       ix(L)->d_interdis.as<float>(), ix(L)->d_arcos.as<float>(), L->w_dtb.as<float>(), L->w_error.as<uint32_t>(), L->stream);
     RoundSpec base;
     base.fused = ix(L)->allow_fused && ix(L)->db_range.fusable_with(qr);
+    base.bytes = byte_queries(L, ix(L), d_x, n, qr);
+    ix(L)->last_arith = base.bytes ? 2 : base.fused ? 1 : 0;
     base.k = (int)K;
     base.id_offset = id0;
     base.d_x = d_x;
@@ -1772,6 +1826,8 @@ static void train_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n, s
                       h->d_interdis.as<float>(), h->d_arcos.as<float>(), h->w_dtb.as<float>(), h->w_error.as<uint32_t>(), h->stream);
     RoundSpec base;
     base.fused = h->allow_fused && h->db_range.fusable_with(qr);
+    base.bytes = byte_queries(h, ix(h), d_x, n, qr);
+    ix(h)->last_arith = base.bytes ? 2 : base.fused ? 1 : 0;
     base.k = (int)K;
     base.id_offset = start;
     base.d_x = d_x;
@@ -1931,6 +1987,8 @@ int amd_ivf_merge_tables(int metric, size_t n, size_t k, size_t nshard, const fl
     }
     API_END
 }
+
+int amd_ivf_scan_arith(amd_ivf_t* h) { return h->last_arith; }
 
 int amd_ivf_last_timing(amd_ivf_t* h, double out[8]) {
     for (int i = 0; i < 8; i++) out[i] = h->timing[i];

@@ -42,6 +42,9 @@ struct ScanArgs {
     int d;
     int metric;
     int fused;  // 1: fma(t, t, acc) -- only when the operands make it bit-identical to mul + add (see engine)
+    // byte-code mode (non-null code_norms): codes / qtile hold bytes, d counts 4-byte words per row
+    const uint32_t* code_norms;   // |y|^2 of every stored vector
+    const uint32_t* query_norms;  // |x|^2 by query row (the rows pair_query names)
 };
 
 // items grouped by qg (1, then 2, 4, 8); n_qg = item count of each group
@@ -52,6 +55,8 @@ void launch_scan(const ScanArgs& a, const size_t n_qg[4], hipStream_t s, hipStre
 // [group_p0[g], group_p0[g] + group_cnt[g]); missing slots are zero
 void launch_pack_queries(const float* queries, const uint32_t* pair_query, const uint32_t* group_p0, const uint32_t* group_cnt,
                          size_t ngroups, int d, float* qtile, hipStream_t s);
+// fp32 rows of integers 0..255 -> byte rows and their squared norms (norms may be null); d % 4 == 0
+void launch_bytes_from_f32(const float* x, size_t n, int d, uint8_t* out, uint32_t* norms, hipStream_t s);
 inline __host__ __device__ int scan_qg_class(uint32_t qg) { return qg == 1 ? 0 : qg == 2 ? 1 : qg == 4 ? 2 : 3; }
 // workgroup shape for the last `r` queries of a list (full blocks hold SCAN_QBLOCK = 64 queries)
 constexpr uint32_t SCAN_QBLOCK = 8 * SCAN_RQ;

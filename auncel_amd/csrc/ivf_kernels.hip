@@ -34,8 +34,18 @@ constexpr int LDS_ROW = SCAN_DC + 4;                 // dwords per staged row (p
 // QG = query groups per workgroup (1, 2, 4 or 8): QG groups of 8 queries x VG blocks of 128 vectors, one wave
 // each.  QG 8: 8 waves share one 128-vector tile (64 queries per pass over the list); QG 4: 4 waves, 128 vectors;
 // QG 2 / 1: 4 waves over 256 / 512 vectors.  The staged tile (and the LDS footprint) follows.
-template <int METRIC, int QG, bool FUSED>
+//
+// ARITH selects the arithmetic (the result is the same fp32 number in all three):
+//   0  the reference's SSE order: four running sums over elements 4i+l, separate multiply and add
+//   1  the same order with fma, legal when operands are small integers (see IntRange in the engine)
+//   2  byte codes: the lists and the queries hold integers 0..255 and d * 255^2 <= 2^24, so every partial sum
+//      of the reference is an exact integer whatever the order; rows are stored as bytes (a quarter of the
+//      HBM traffic), a 16-B slot carries 16 dimensions, and the inner product runs on v_dot4_u32_u8.
+//      L2 = |x|^2 + |y|^2 - 2 x.y in integers.  Here `d` counts 4-byte words per row (dimensions / 4).
+template <int METRIC, int QG, int ARITH>
 __global__ __launch_bounds__(QG == 8 ? 512 : 256) void scan_tiles_kernel(ScanArgs a) {
+    constexpr bool FUSED = ARITH == 1;
+    constexpr bool BYTES = ARITH == 2;
     constexpr int qg = QG;
     constexpr int NT = QG == 8 ? 512 : 256;
     constexpr int vg = QG >= 4 ? 1 : 4 / QG;
@@ -61,10 +71,14 @@ __global__ __launch_bounds__(QG == 8 ? 512 : 256) void scan_tiles_kernel(ScanArg
 
     // running sums (s0, s1) and (s2, s3) of the reference's 4-lane accumulator, as two register pairs
     f2 acc[SCAN_RQ][SCAN_RV][2];
+    uint32_t dot[SCAN_RQ][SCAN_RV];  // ARITH 2
 #pragma unroll
     for (int r = 0; r < SCAN_RQ; r++)
 #pragma unroll
-        for (int v = 0; v < SCAN_RV; v++) acc[r][v][0] = acc[r][v][1] = f2{0.f, 0.f};
+        for (int v = 0; v < SCAN_RV; v++) {
+            acc[r][v][0] = acc[r][v][1] = f2{0.f, 0.f};
+            dot[r][v] = 0u;
+        }
 
     const float* tile_base = a.codes + (size_t)it.vec_base * (size_t)d;
     const bool has_queries = (uint32_t)(qgi * SCAN_RQ) < it.npair;
@@ -135,7 +149,14 @@ __global__ __launch_bounds__(QG == 8 ? 512 : 256) void scan_tiles_kernel(ScanArg
                 const f2 qa = f2{qc[r].x, qc[r].y}, qb = f2{qc[r].z, qc[r].w};
 #pragma unroll
                 for (int v = 0; v < SCAN_RV; v++) {
-                    if (METRIC == METRIC_L2) {
+                    if (BYTES) {
+                        uint32_t t = dot[r][v];
+                        t = __builtin_amdgcn_udot4(__float_as_uint(ya[v].x), __float_as_uint(qa.x), t, false);
+                        t = __builtin_amdgcn_udot4(__float_as_uint(ya[v].y), __float_as_uint(qa.y), t, false);
+                        t = __builtin_amdgcn_udot4(__float_as_uint(yb[v].x), __float_as_uint(qb.x), t, false);
+                        t = __builtin_amdgcn_udot4(__float_as_uint(yb[v].y), __float_as_uint(qb.y), t, false);
+                        dot[r][v] = t;
+                    } else if (METRIC == METRIC_L2) {
                         const f2 ta = ya[v] - qa, tb = yb[v] - qb;
                         if (FUSED) {  // products exactly representable: one rounding either way
                             acc[r][v][0] = __builtin_elementwise_fma(ta, ta, acc[r][v][0]);
@@ -157,18 +178,53 @@ __global__ __launch_bounds__(QG == 8 ? 512 : 256) void scan_tiles_kernel(ScanArg
       }
     }
 
+    uint32_t ynorm[SCAN_RV];
+    if (BYTES && METRIC == METRIC_L2) {
+#pragma unroll
+        for (int v = 0; v < SCAN_RV; v++) {
+            const int lv = vgi * SCAN_WAVE_VECS + v * 64 + lane;
+            ynorm[v] = lv < (int)it.nvec ? a.code_norms[it.vec_base + lv] : 0u;
+        }
+    }
 #pragma unroll
     for (int r = 0; r < SCAN_RQ; r++) {
         uint32_t local = (uint32_t)(qgi * SCAN_RQ + r);
         if (local < it.npair) {
             float* out = a.dist + a.pair_out[it.pair_begin + local] + it.vec_off;
+            uint32_t xnorm = 0;
+            if (BYTES && METRIC == METRIC_L2) xnorm = a.query_norms[a.pair_query[it.pair_begin + local]];
 #pragma unroll
             for (int v = 0; v < SCAN_RV; v++) {
                 int lv = vgi * SCAN_WAVE_VECS + v * 64 + lane;
-                if (lv < (int)it.nvec) out[lv] = (acc[r][v][0].x + acc[r][v][0].y) + (acc[r][v][1].x + acc[r][v][1].y);
+                float res;
+                if (BYTES) res = METRIC == METRIC_L2 ? (float)(xnorm + ynorm[v] - 2u * dot[r][v]) : (float)dot[r][v];
+                else res = (acc[r][v][0].x + acc[r][v][0].y) + (acc[r][v][1].x + acc[r][v][1].y);
+                if (lv < (int)it.nvec) out[lv] = res;
             }
         }
     }
+}
+
+// fp32 rows holding integers 0..255 -> byte rows (+ squared norms); a lane converts 4 dimensions at a time
+__global__ __launch_bounds__(256) void bytes_from_f32_kernel(const float* x, size_t n, int d, uint8_t* out, uint32_t* norms) {
+    const int per_row = d >> 2;  // d % 4 == 0
+    // one wave per row keeps the norm reduction inside the wave
+    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    uint32_t nrm = 0;
+    for (int c = lane; c < per_row; c += 64) {
+        const float4 v = *reinterpret_cast<const float4*>(x + row * (size_t)d + c * 4);
+        const uint32_t b0 = (uint32_t)v.x, b1 = (uint32_t)v.y, b2 = (uint32_t)v.z, b3 = (uint32_t)v.w;
+        *reinterpret_cast<uint32_t*>(out + row * (size_t)d + c * 4) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+        nrm += b0 * b0 + b1 * b1 + b2 * b2 + b3 * b3;
+    }
+    for (int off = 32; off; off >>= 1) nrm += __shfl_xor(nrm, off);
+    if (lane == 0 && norms) norms[row] = nrm;
+}
+
+void launch_bytes_from_f32(const float* x, size_t n, int d, uint8_t* out, uint32_t* norms, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(bytes_from_f32_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, x, n, d, out, norms);
 }
 
 __global__ __launch_bounds__(256) void pack_queries_kernel(const float* queries, const uint32_t* pair_query, const uint32_t* group_p0,
@@ -193,12 +249,16 @@ void launch_pack_queries(const float* queries, const uint32_t* pair_query, const
 template <int QG> static void launch_scan_qg(ScanArgs a, size_t first, size_t n, hipStream_t s) {
     if (n == 0) return;
     a.items += first;
+    const dim3 grid((unsigned)n), block(QG == 8 ? 512 : 256);
+    const int arith = a.code_norms ? 2 : a.fused ? 1 : 0;
     if (a.metric == METRIC_L2) {
-        if (a.fused) hipLaunchKernelGGL((scan_tiles_kernel<METRIC_L2, QG, true>), dim3((unsigned)n), dim3(QG == 8 ? 512 : 256), 0, s, a);
-        else hipLaunchKernelGGL((scan_tiles_kernel<METRIC_L2, QG, false>), dim3((unsigned)n), dim3(QG == 8 ? 512 : 256), 0, s, a);
+        if (arith == 2) hipLaunchKernelGGL((scan_tiles_kernel<METRIC_L2, QG, 2>), grid, block, 0, s, a);
+        else if (arith == 1) hipLaunchKernelGGL((scan_tiles_kernel<METRIC_L2, QG, 1>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((scan_tiles_kernel<METRIC_L2, QG, 0>), grid, block, 0, s, a);
     } else {
-        if (a.fused) hipLaunchKernelGGL((scan_tiles_kernel<METRIC_IP, QG, true>), dim3((unsigned)n), dim3(QG == 8 ? 512 : 256), 0, s, a);
-        else hipLaunchKernelGGL((scan_tiles_kernel<METRIC_IP, QG, false>), dim3((unsigned)n), dim3(QG == 8 ? 512 : 256), 0, s, a);
+        if (arith == 2) hipLaunchKernelGGL((scan_tiles_kernel<METRIC_IP, QG, 2>), grid, block, 0, s, a);
+        else if (arith == 1) hipLaunchKernelGGL((scan_tiles_kernel<METRIC_IP, QG, 1>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((scan_tiles_kernel<METRIC_IP, QG, 0>), grid, block, 0, s, a);
     }
 }
 

@@ -152,6 +152,14 @@ int amd_ivf_merge_tables(int metric, size_t n, size_t k, size_t nshard, const fl
  *      slots that were wanted pairs, select launches (= rounds x sub-batches)} */
 int amd_ivf_last_timing(amd_ivf_t* h, double out[8]);
 
+/* Arithmetic the list scan of the last search ran in.  All three produce the reference's fp32 distance bit for
+ * bit (utils_simd.cpp:391-443 order); the engine picks the cheapest one the data allows:
+ *   0  fp32, the reference's four running sums, separate multiply and add
+ *   1  fp32 with fma: lists and queries hold integers of magnitude <= 4095
+ *   2  byte codes + integer dot products: lists and queries hold integers 0..255 and d * max^2 <= 2^24
+ *      (SIFT / BIGANN descriptors), lists are kept as bytes on the device (1/4 of the HBM traffic) */
+int amd_ivf_scan_arith(amd_ivf_t* h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -228,6 +228,43 @@ def test_fused_path_is_bit_identical(capi, monkeypatch):
     assert np.array_equal(I1, I2) and np.array_equal(bits(D1), bits(D2))
 
 
+@pytest.mark.parametrize("metric", ["l2", "ip"])
+def test_byte_code_path_is_bit_identical(capi, monkeypatch, metric):
+    """integers 0..255 on both sides and d * 255^2 <= 2^24: the lists are kept as bytes and the scan runs on
+    integer dot products.  Every partial sum of the reference is then an exact integer, so nothing may change
+    by a single bit against the fp32 kernels (which the tests above pin to the reference's goldens)."""
+    case, gold = load_case("fixed_sift_l2")
+    m = capi.METRIC_L2 if metric == "l2" else capi.METRIC_IP
+
+    def build():
+        h = capi.Handle(case["d"], case["nlist"], m, 0)
+        h.set_centroids(case["centroids"])
+        h.add(case["xb"])
+        return h
+
+    h1 = build()
+    monkeypatch.setenv("AUNCEL_AMD_NO_BYTES", "1")
+    h2 = build()
+    monkeypatch.delenv("AUNCEL_AMD_NO_BYTES")
+    for k in (10, 100):
+        D1, I1 = h1.search(case["xq"], k, case["nprobe"])
+        D2, I2 = h2.search(case["xq"], k, case["nprobe"])
+        assert h1.scan_arith() == 2 and h2.scan_arith() == 1
+        assert np.array_equal(I1, I2) and np.array_equal(bits(D1), bits(D2))
+    # a query outside 0..255 sends the call back to fp32: same index, one value of 256
+    xq = case["xq"].copy()
+    xq[0, 0] = 256.0
+    D1, I1 = h1.search(xq, 10, case["nprobe"])
+    D2, I2 = h2.search(xq, 10, case["nprobe"])
+    assert h1.scan_arith() == 1
+    assert np.array_equal(I1, I2) and np.array_equal(bits(D1), bits(D2))
+    # non-integer queries: reference order
+    D1, I1 = h1.search(case["xq"] + np.float32(0.5), 10, case["nprobe"])
+    D2, I2 = h2.search(case["xq"] + np.float32(0.5), 10, case["nprobe"])
+    assert h1.scan_arith() == 0
+    assert np.array_equal(I1, I2) and np.array_equal(bits(D1), bits(D2))
+
+
 @pytest.mark.parametrize("name", FIXED)
 def test_coarse_gemm_mode(capi, name):
     """mode 1 = |x|^2 + |y|^2 - 2 x.y on the fp32 matrix cores (the reference's BLAS branch).  Integer-valued
