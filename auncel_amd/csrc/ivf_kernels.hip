@@ -324,43 +324,59 @@ template <bool IsMax> __device__ inline void heap_push(int k, float* val, int64_
 // ---------------------------------------------------------------------------------------------
 // The same heap, resident in registers (k <= 127): node i (1-based, Heap.h numbering) lives in lane
 // i & 63 of register i >> 6, so levels 0-5 (nodes 1..63) are in register 0 and level 6 in register 1.
-// A wave replays one query, so every index below is wave-uniform: nodes are read with v_readlane and
-// written with a lane-select, the sift loops run on the scalar unit, and an update costs a few hundred
-// cycles instead of ~14 dependent LDS round trips.  Each node carries the slot (0..k-1) of its 64-bit
-// id in an LDS table, so ids never move.
+// A wave replays one query, so every index below is wave-uniform: nodes are read with v_readlane and written
+// with v_writelane, and the sift loops run on the scalar unit.  For that the registers hold order keys, not
+// floats: key(x) is an unsigned integer with key(a) < key(b) <=> a < b (gfx950 has no scalar float compare),
+// and the float comes back bit for bit from the key.  Each node carries the slot (0..k-1) of its 64-bit id in
+// an LDS table, so ids never move.  (Keys order -0.0 below +0.0 where floats call them equal; distances from
+// the scan kernels are never -0.0.  NaN never enters: admission is tested on the floats.)
 struct RegHeap {
-    float v0, v1;
-    int s0, s1;
+    uint32_t v0, v1;  // keys
+    uint32_t s0, s1;  // id slots
 };
+
+__device__ __forceinline__ uint32_t fkey(float x) {
+    const uint32_t u = __float_as_uint(x);
+    return u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(uint32_t key) { return __uint_as_float((key & 0x80000000u) ? key ^ 0x80000000u : ~key); }
+template <bool IsMax> __device__ __forceinline__ bool kcmp(uint32_t a, uint32_t b) { return IsMax ? a > b : a < b; }
 
 __device__ __forceinline__ float rl_f(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
 __device__ __forceinline__ int rl_i(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+__device__ __forceinline__ uint32_t rl_u(uint32_t x, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)x, l); }
+// reg[lane l] = val (val and l wave-uniform).  The lane select goes through M0: v_writelane_b32 may name one SGPR.
+__device__ __forceinline__ void wl_u(uint32_t& reg, uint32_t val, int l) {
+    asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(reg) : "s"(val), "s"(l) : "m0");
+}
 
-__device__ __forceinline__ float rh_val(const RegHeap& h, int node) {
-    const float a = rl_f(h.v0, node & 63), b = rl_f(h.v1, node & 63);
+__device__ __forceinline__ uint32_t rh_key(const RegHeap& h, int node) {
+    const uint32_t a = rl_u(h.v0, node & 63), b = rl_u(h.v1, node & 63);
     return node < 64 ? a : b;
 }
-__device__ __forceinline__ int rh_slot(const RegHeap& h, int node) {
-    const int a = rl_i(h.s0, node & 63), b = rl_i(h.s1, node & 63);
+__device__ __forceinline__ uint32_t rh_slot(const RegHeap& h, int node) {
+    const uint32_t a = rl_u(h.s0, node & 63), b = rl_u(h.s1, node & 63);
     return node < 64 ? a : b;
 }
-__device__ __forceinline__ void rh_set(RegHeap& h, int node, float v, int s, int lane) {
-    const bool in0 = lane == node, in1 = lane == node - 64;
-    h.v0 = in0 ? v : h.v0;
-    h.s0 = in0 ? s : h.s0;
-    h.v1 = in1 ? v : h.v1;
-    h.s1 = in1 ? s : h.s1;
+__device__ __forceinline__ void rh_set(RegHeap& h, int node, uint32_t key, uint32_t slot) {
+    if (node < 64) {
+        wl_u(h.v0, key, node);
+        wl_u(h.s0, slot, node);
+    } else {
+        wl_u(h.v1, key, node - 64);
+        wl_u(h.s1, slot, node - 64);
+    }
 }
 
 // Heap.h:88-118 (the node being removed, k, still takes part in the child comparisons, as there).
-// KC != 0: k is the compile-time constant KC and every bounds test folds away.  The walk down only compares
-// values; the nodes it passes are rewritten afterwards with mutually independent lane-selects.
-template <bool IsMax, int KC> __device__ __forceinline__ void rh_pop(RegHeap& h, int krt, int lane) {
+// KC != 0: k is the compile-time constant KC and the bounds tests of complete levels fold away.  The walk down
+// only compares keys; the nodes it passed are rewritten afterwards (independent writes).
+template <bool IsMax, int KC> __device__ __forceinline__ void rh_pop(RegHeap& h, int krt) {
     const int k = KC ? KC : krt;
-    const float v = rh_val(h, k);
-    const int sv = rh_slot(h, k);
-    int pos[7];    // pos[j]: node visited on level j (pos[0] = root)
-    float cv[6];   // cv[j]: value moved up into pos[j]
+    const uint32_t v = rh_key(h, k);
+    const uint32_t sv = rh_slot(h, k);
+    int pos[7];       // pos[j]: node visited on level j (pos[0] = root)
+    uint32_t cv[6];   // cv[j]: key moved up into pos[j]
     pos[0] = 1;
     int depth = 0;
     bool going = true;
@@ -369,22 +385,18 @@ template <bool IsMax, int KC> __device__ __forceinline__ void rh_pop(RegHeap& h,
         const int i = pos[lvl];
         const int i1 = i << 1, i2 = i1 + 1;
         pos[lvl + 1] = i;
-        cv[lvl] = 0.f;
-        if (KC && (2 << lvl) > KC) going = false;  // the whole level lies beyond k
-        if (going && i1 <= k) {
-            const bool only_left = i2 == k + 1;
+        cv[lvl] = 0u;
+        const bool absent = KC && (2 << lvl) > KC;      // the whole child level lies beyond k
+        const bool full = KC && (4 << lvl) - 1 <= KC;   // every node of the child level exists
+        if (absent) going = false;
+        if (going && (full || i1 <= k)) {
+            const bool only_left = !full && i2 == k + 1;
             const int j2 = only_left ? i1 : i2;
-            float c1, c2;
-            if (lvl < 5) {
-                c1 = rl_f(h.v0, i1);
-                c2 = rl_f(h.v0, j2);
-            } else {
-                c1 = rl_f(h.v1, i1 - 64);
-                c2 = rl_f(h.v1, j2 - 64);
-            }
-            const bool left = only_left || hcmp<IsMax>(c1, c2);
-            const float c = left ? c1 : c2;
-            if (hcmp<IsMax>(v, c)) {
+            const uint32_t c1 = lvl < 5 ? rl_u(h.v0, i1) : rl_u(h.v1, i1 - 64);
+            const uint32_t c2 = lvl < 5 ? rl_u(h.v0, j2) : rl_u(h.v1, j2 - 64);
+            const bool left = only_left || kcmp<IsMax>(c1, c2);
+            const uint32_t c = left ? c1 : c2;
+            if (kcmp<IsMax>(v, c)) {
                 going = false;
             } else {
                 pos[lvl + 1] = left ? i1 : i2;
@@ -400,35 +412,34 @@ template <bool IsMax, int KC> __device__ __forceinline__ void rh_pop(RegHeap& h,
         if (KC && (2 << lvl) > KC) break;
         if (lvl < depth) {
             const int ci = pos[lvl + 1];
-            const int cs = lvl < 5 ? rl_i(h.s0, ci) : rl_i(h.s1, ci - 64);
-            const bool here = lane == pos[lvl];
-            h.v0 = here ? cv[lvl] : h.v0;
-            h.s0 = here ? cs : h.s0;
+            const uint32_t cs = lvl < 5 ? rl_u(h.s0, ci) : rl_u(h.s1, ci - 64);
+            wl_u(h.v0, cv[lvl], pos[lvl]);
+            wl_u(h.s0, cs, pos[lvl]);
         }
     }
-    rh_set(h, pos[depth], v, sv, lane);
+    rh_set(h, pos[depth], v, sv);
 }
 
 // Heap.h:125-142
-template <bool IsMax, int KC> __device__ __forceinline__ void rh_push(RegHeap& h, int krt, float v, int sv, int lane) {
+template <bool IsMax, int KC> __device__ __forceinline__ void rh_push(RegHeap& h, int krt, uint32_t v, uint32_t sv) {
     int i = KC ? KC : krt;
     while (i > 1) {
         const int f = i >> 1;  // < 64
-        const float fv = rl_f(h.v0, f);
-        if (!hcmp<IsMax>(v, fv)) break;
-        const int fs = rl_i(h.s0, f);
-        rh_set(h, i, fv, fs, lane);
+        const uint32_t fv = rl_u(h.v0, f);
+        if (!kcmp<IsMax>(v, fv)) break;
+        const uint32_t fs = rl_u(h.s0, f);
+        rh_set(h, i, fv, fs);
         i = f;
     }
-    rh_set(h, i, v, sv, lane);
+    rh_set(h, i, v, sv);
 }
 
 // LDS heap arrays (node order) -> registers; slot j holds the id of node j + 1
 __device__ __forceinline__ void rh_load(RegHeap& h, const float* hval, int k, int lane) {
-    h.v0 = (lane >= 1 && lane <= k) ? hval[lane - 1] : 0.f;
-    h.s0 = lane - 1;
-    h.v1 = (lane + 64 <= k) ? hval[lane + 63] : 0.f;
-    h.s1 = lane + 63;
+    h.v0 = (lane >= 1 && lane <= k) ? fkey(hval[lane - 1]) : 0u;
+    h.s0 = (uint32_t)(lane - 1);
+    h.v1 = (lane + 64 <= k) ? fkey(hval[lane + 63]) : 0u;
+    h.s1 = (uint32_t)(lane + 63);
 }
 
 // registers -> LDS heap arrays in node order (ids permuted through registers)
@@ -441,8 +452,8 @@ __device__ __forceinline__ void rh_store(const RegHeap& h, float* hval, int64_t*
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (n0) hval[lane - 1] = h.v0;
-    if (n1) hval[lane + 63] = h.v1;
+    if (n0) hval[lane - 1] = fkey_inv(h.v0);
+    if (n1) hval[lane + 63] = fkey_inv(h.v1);
     if (with_refs) {
         if (n0) href[lane - 1] = r0;
         if (n1) href[lane + 63] = r1;
@@ -792,7 +803,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
                 uint32_t npend = 0;
                 for (uint32_t b0 = 0; b0 < n; b0 += TRIP) {
                     fetch(nv);
-                    float top = RH ? rl_f(rh.v0, 1) : hval[0];  // heap top, kept in a register between admissions
+                    float top = RH ? fkey_inv(rl_u(rh.v0, 1)) : hval[0];  // heap top, kept in a register between admissions
                     // chunks (64 candidates) holding at least one value that beats the top as it is now
                     uint32_t umask = 0;
 #pragma unroll
@@ -812,11 +823,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
                             if (hcmp<IsMax>(top, val)) {
                                 const int64_t nref = refbase | (int64_t)(b0 + u * 64 + l);
                                 if (RH) {
-                                    const int sr = rl_i(rh.s0, 1);  // the evicted root's id slot passes to the new entry
+                                    const uint32_t sr = rl_u(rh.s0, 1);  // the evicted root's id slot passes to the new entry
                                     if (lane == 0) href[sr] = nref;
-                                    rh_pop<IsMax, KC>(rh, k, lane);
-                                    rh_push<IsMax, KC>(rh, k, val, sr, lane);
-                                    top = rl_f(rh.v0, 1);
+                                    rh_pop<IsMax, KC>(rh, k);
+                                    rh_push<IsMax, KC>(rh, k, fkey(val), sr);
+                                    top = fkey_inv(rl_u(rh.v0, 1));
                                 } else {
                                     heap_pop<IsMax>(k, hval, href);
                                     heap_push<IsMax>(k, hval, href, val, nref);
