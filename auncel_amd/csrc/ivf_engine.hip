@@ -199,6 +199,7 @@ struct amd_ivf {
     PinnedBuf p_group_p0, p_group_cnt, p_counters;
     DevBuf w_pl_cnt, w_pl_need, w_pl_dist_base, w_pl_lcount, w_pl_lstart, w_pl_gbase, w_pl_ibase, w_pl_fill, w_pl_counters;
     DevBuf w_x8, w_xnorm8;  // byte copy of the current queries + squared norms
+    DevBuf w_thr, w_mask, w_pl_pad;  // threshold mode of the device-planned rounds: heap tops, candidate bit masks
     DevBuf w_x, w_dist, w_items, w_pair_query, w_pair_out, w_seg_off, w_seg_list, w_seg_count, w_qsel;
     DevBuf w_heap_val, w_heap_ref, w_stage, w_nscan, w_done, w_pre_val, w_stoped, w_dtb, w_D, w_I;
     DevBuf w_cdis, w_ckeys, w_stats, w_error, w_misc, w_misc2, w_misc3, w_rawptrs;
@@ -313,6 +314,8 @@ void init_state(amd_ivf* h, size_t n, size_t k, bool tune_or_train) {
     h->w_I.ensure(n * k * sizeof(int64_t));
     h->w_stats.ensure(3 * 8);
     h->w_error.ensure(4);
+    h->w_thr.ensure(n * sizeof(float));
+    launch_fill_f32(h->w_thr.as<float>(), n, h->metric == METRIC_L2 ? FLT_MAX : -FLT_MAX, h->stream);
     launch_fill_f32(h->w_heap_val.as<float>(), n * k, h->metric == METRIC_L2 ? FLT_MAX : -FLT_MAX, h->stream);
     launch_fill_i64(h->w_heap_ref.as<int64_t>(), n * k, -1, h->stream);
     HIP_CHECK(hipMemsetAsync(h->w_stage.p, 0, n * 4, h->stream));
@@ -390,6 +393,21 @@ static bool dbg_timing() {
     return on;
 }
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+static void print_replay_dbg(amd_ivf* h, size_t mb, hipStream_t s) {
+    std::vector<unsigned long long> dbg(mb * 8);
+    HIP_CHECK(hipMemcpyAsync(dbg.data(), h->w_misc.p, mb * 64, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    static const char* nm[8] = {"wave cycles", "heap updates", "candidates", "rule evaluations", "stream cycles", "rule cycles", "masked chunks", "probes"};
+    for (int c = 0; c < 8; c++) {
+        std::vector<unsigned long long> v(mb);
+        for (size_t i = 0; i < mb; i++) v[i] = dbg[i * 8 + c];
+        std::sort(v.begin(), v.end());
+        double sum = 0;
+        for (auto x : v) sum += x;
+        fprintf(stderr, "[replay] %-16s mean %.0f p50 %llu p90 %llu p99 %llu max %llu\n", nm[c], sum / mb, v[mb / 2], v[mb * 9 / 10], v[mb * 99 / 100], v[mb - 1]);
+    }
+}
 
 void exec_round(amd_ivf* h, const RoundSpec& r) {
     const size_t m = r.slot.size();
@@ -644,7 +662,8 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
         ra.train = r.train;
         static const bool dbg_replay = getenv("AUNCEL_AMD_DEBUG_REPLAY") != nullptr;
         if (dbg_replay) {
-            h->w_misc.ensure(mb * 32);
+            h->w_misc.ensure(mb * 64);
+            HIP_CHECK(hipMemsetAsync(h->w_misc.p, 0, mb * 64, s));
             ra.dbg = h->w_misc.as<unsigned long long>();
         }
         {
@@ -652,20 +671,7 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
             launch_replay(ra, s);
             h->timer.end(t, s);
         }
-        if (dbg_replay) {
-            std::vector<unsigned long long> dbg(mb * 4);
-            HIP_CHECK(hipMemcpyAsync(dbg.data(), h->w_misc.p, mb * 32, hipMemcpyDeviceToHost, s));
-            HIP_CHECK(hipStreamSynchronize(s));
-            for (int c = 0; c < 4; c++) {
-                std::vector<unsigned long long> v(mb);
-                for (size_t i = 0; i < mb; i++) v[i] = dbg[i * 4 + c];
-                std::sort(v.begin(), v.end());
-                double sum = 0;
-                for (auto x : v) sum += x;
-                static const char* nm[4] = {"wave cycles", "heap updates", "candidates", "rule evaluations"};
-                fprintf(stderr, "[replay] %-16s mean %.0f p50 %llu p90 %llu p99 %llu max %llu\n", nm[c], sum / mb, v[mb / 2], v[mb * 9 / 10], v[mb * 99 / 100], v[mb - 1]);
-            }
-        }
+        if (dbg_replay) print_replay_dbg(h, mb, s);
         // the pinned staging buffers are reused by the next sub-batch
         const double t_launched = now_us();
         HIP_CHECK(hipStreamSynchronize(s));
@@ -947,7 +953,11 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     size_t maxlist = 0;
     for (size_t l = 0; l < nlist; l++) maxlist = std::max<size_t>(maxlist, I->h_list_off[l + 1] - I->h_list_off[l]);
     const size_t item_cap = (seg_cap / SCAN_QBLOCK + nlist) * ((maxlist + SCAN_WAVE_VECS - 1) / SCAN_WAVE_VECS) + nlist * 4 + 16;
-    const size_t budget = std::max<size_t>(h->dist_budget_floats, I->h_list_off[nlist] + 1);
+    // rows are padded to multiples of 64 floats (one mask word covers 64 candidates of one row)
+    const size_t budget = std::max<size_t>(h->dist_budget_floats, I->h_list_off[nlist] + 64 * nlist + 64);
+    static const bool no_thr = getenv("AUNCEL_AMD_NO_THRESHOLD") != nullptr;
+    h->w_pl_pad.ensure(n * 4);
+    h->w_mask.ensure((budget / 64 + 2) * 8);
     h->w_pl_cnt.ensure(n * 4);
     h->w_pl_need.ensure(n * 8);
     h->w_seg_begin.ensure(n * 4);
@@ -991,6 +1001,8 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     pa.my_nprobe = d_np_abs;
     pa.cnt = h->w_pl_cnt.as<uint32_t>();
     pa.need = h->w_pl_need.as<unsigned long long>();
+    pa.pad = h->w_pl_pad.as<uint32_t>();
+    pa.row_align = 64;
     pa.seg_begin = h->w_seg_begin.as<uint32_t>();
     pa.dist_base = h->w_pl_dist_base.as<unsigned long long>();
     pa.qsel = h->w_qsel.as<uint32_t>();
@@ -1020,7 +1032,9 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     }
     size_t round_len = first_round;
     uint32_t* hc = h->p_counters.as<uint32_t>();
-    for (;;) {
+    // Round 0 starts from empty heaps (every distance is wanted: dense rows); later rounds run in threshold mode.
+    for (size_t round = 0;; round++) {
+        const bool thr_mode = round > 0 && !no_thr;
         const double t0 = now_us();
         HIP_CHECK(hipMemsetAsync(h->w_pl_lcount.p, 0, nlist * 4, s));
         HIP_CHECK(hipMemsetAsync(h->w_pl_counters.as<uint32_t>() + 6, 0, 4, s));
@@ -1056,6 +1070,10 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
                 sa.code_norms = I->d_code_norms.as<uint32_t>();
                 sa.query_norms = h->w_xnorm8.as<uint32_t>();
             }
+            if (thr_mode) {
+                sa.thr = h->w_thr.as<float>();
+                sa.mask = h->w_mask.as<unsigned long long>();
+            }
             size_t t = h->timer.begin(CAT_SCAN, s);
             const bool fork = (n_qg[0] || n_qg[1]) && (n_qg[2] || n_qg[3]);
             if (fork) {
@@ -1081,6 +1099,8 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         ra.round_probes = 0;
         ra.id_offset = base.id_offset;
         ra.dist = h->w_dist.as<float>();
+        ra.mask = thr_mode ? h->w_mask.as<unsigned long long>() : nullptr;
+        ra.thr = no_thr ? nullptr : h->w_thr.as<float>();
         ra.seg_off = h->w_seg_off.as<uint64_t>();
         ra.seg_list = h->w_seg_list.as<int32_t>();
         ra.seg_count = h->w_pl_cnt.as<uint32_t>();
@@ -1107,10 +1127,20 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         ra.error = h->w_error.as<uint32_t>();
         ra.tuner = base.tuner;
         ra.train = base.train;
+        static const bool dbg_replay_dev = getenv("AUNCEL_AMD_DEBUG_REPLAY") != nullptr;
+        if (dbg_replay_dev) {
+            h->w_misc.ensure((size_t)nact * 64);
+            HIP_CHECK(hipMemsetAsync(h->w_misc.p, 0, (size_t)nact * 64, s));
+            ra.dbg = h->w_misc.as<unsigned long long>();
+        }
         {
             size_t t = h->timer.begin(CAT_SELECT, s);
             launch_replay(ra, s);
             h->timer.end(t, s);
+        }
+        if (dbg_replay_dev) {
+            fprintf(stderr, "[replay] round %zu: %u queries\n", round, nact);
+            print_replay_dbg(h, nact, s);
         }
         if (dbg_timing())
             fprintf(stderr, "[round/dev] active %u pairs %u groups %u tiles %zu: plan+readback %.0f us, launches %.0f us\n", nact, npairs, ngroups,

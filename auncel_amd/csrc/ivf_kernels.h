@@ -45,6 +45,10 @@ struct ScanArgs {
     // byte-code mode (non-null code_norms): codes / qtile hold bytes, d counts 4-byte words per row
     const uint32_t* code_norms;   // |y|^2 of every stored vector
     const uint32_t* query_norms;  // |x|^2 by query row (the rows pair_query names)
+    // threshold mode (non-null thr): store only distances that beat thr[query row] and write one mask bit per
+    // candidate (mask[i / 64] covers dist[i .. i + 63]); rows of `dist` start on multiples of 64
+    const float* thr;
+    unsigned long long* mask;
 };
 
 // items grouped by qg (1, then 2, 4, 8); n_qg = item count of each group
@@ -100,6 +104,8 @@ struct ReplayArgs {
     uint32_t round_probes;     // row stride of seg_* arrays
     uint64_t id_offset;        // absolute query id of query 0 of this launch
     const float* dist;
+    const unsigned long long* mask;  // threshold mode: bit i of mask[j] set <=> dist[64 j + i] was stored (rows 64-aligned)
+    float* thr;                // [nq] by query slot: heap top when the launch ends (may be null)
     const uint64_t* seg_off;   // [nq][round_probes] offset of the distance row       (by launch position)
     const int32_t* seg_list;   // [nq][round_probes] list number, <0 = missing centroid (by launch position)
     const uint32_t* seg_count; // [nq] probes supplied this round                      (by launch position)
@@ -130,7 +136,8 @@ struct ReplayArgs {
     unsigned long long* stats; // {nlist, ndis, nheap}
     uint32_t* error;           // != 0: the reference would have thrown (code)
     int raw_heap_out;          // scanner API: leave the heap un-reordered in D/I
-    unsigned long long* dbg;   // optional [nq][4]: wave cycles, heap updates, candidates, stages evaluated
+    unsigned long long* dbg;   // optional [nq][8]: wave cycles, heap updates, candidates, stages evaluated, cycles in the
+                               // candidate stream, cycles in the stop rule, masked chunks fetched, probes consumed
     TunerDev tuner;
     TrainDev train;
 };
@@ -163,7 +170,9 @@ struct PlanArgs {
     const unsigned long long* my_nprobe;  // by absolute id, may be null
     // outputs
     uint32_t* cnt;                   // [nq] probes this round (0: finished or deferred)
-    unsigned long long* need;        // [nq]
+    unsigned long long* need;        // [nq] floats of distance rows (rows padded to multiples of `row_align`)
+    uint32_t* pad;                   // [nq] padding inside need
+    uint32_t row_align;              // 1 or 64
     uint32_t* seg_begin;             // [nq]
     unsigned long long* dist_base;   // [nq]
     uint32_t* qsel;                  // active slots, compacted

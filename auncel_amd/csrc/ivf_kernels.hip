@@ -186,20 +186,36 @@ __global__ __launch_bounds__(QG == 8 ? 512 : 256) void scan_tiles_kernel(ScanArg
             ynorm[v] = lv < (int)it.nvec ? a.code_norms[it.vec_base + lv] : 0u;
         }
     }
+    // With thresholds (a.thr: the heap top each query had when the round was planned) only the distances that can
+    // still enter the heap are stored, and every 64-candidate chunk of a row gets a bit mask of those positions:
+    // the replay kernel then reads 1 bit per candidate instead of 4 bytes, and the rest of the row never
+    // leaves the chip.  Rows start on multiples of 64 floats in that mode.
+    const bool masked = a.thr != nullptr;
 #pragma unroll
     for (int r = 0; r < SCAN_RQ; r++) {
         uint32_t local = (uint32_t)(qgi * SCAN_RQ + r);
         if (local < it.npair) {
-            float* out = a.dist + a.pair_out[it.pair_begin + local] + it.vec_off;
+            const unsigned long long row = a.pair_out[it.pair_begin + local] + it.vec_off;
+            float* out = a.dist + row;
+            uint32_t qrow = 0;
+            if (masked || (BYTES && METRIC == METRIC_L2)) qrow = a.pair_query[it.pair_begin + local];
             uint32_t xnorm = 0;
-            if (BYTES && METRIC == METRIC_L2) xnorm = a.query_norms[a.pair_query[it.pair_begin + local]];
+            if (BYTES && METRIC == METRIC_L2) xnorm = a.query_norms[qrow];
+            const float thr = masked ? a.thr[qrow] : 0.f;
 #pragma unroll
             for (int v = 0; v < SCAN_RV; v++) {
-                int lv = vgi * SCAN_WAVE_VECS + v * 64 + lane;
+                const int lv0 = vgi * SCAN_WAVE_VECS + v * 64;
+                const int lv = lv0 + lane;
                 float res;
                 if (BYTES) res = METRIC == METRIC_L2 ? (float)(xnorm + ynorm[v] - 2u * dot[r][v]) : (float)dot[r][v];
                 else res = (acc[r][v][0].x + acc[r][v][0].y) + (acc[r][v][1].x + acc[r][v][1].y);
-                if (lv < (int)it.nvec) out[lv] = res;
+                bool keep = lv < (int)it.nvec;
+                if (masked) {
+                    keep = keep && (METRIC == METRIC_L2 ? thr > res : thr < res);
+                    const unsigned long long m = __ballot(keep);
+                    if (lane == 0 && lv0 < (int)it.nvec) a.mask[(row + lv0) >> 6] = m;
+                }
+                if (keep) out[lv] = res;
             }
         }
     }
@@ -636,11 +652,75 @@ __device__ inline uint32_t cur_num_lds(const TraceLds& tr, const float* lut, con
     return (uint32_t)(low + 1);
 }
 
+// The same function with every probe value of the binary search evaluated at once: term (m, i) of
+// sum_angle(Ds(m)) on lane m * 15 + i (three passes for query_topk = 10), then lane m adds its 15 terms in the
+// reference's order and runs its own Trace::search; the search itself is replayed on the scalar unit over the
+// resulting predicate bits.  Each S(Ds(m)) is formed by the same fp32 operations in the same order as above, and
+// an acos-domain error only counts if the reference's search would have visited that m.
+constexpr uint32_t CURNUM_PAR_MAXK = 10;  // terms[] holds CURNUM_PAR_MAXK * 15 floats per wave
+template <bool IsMax>
+__device__ inline uint32_t cur_num_par(const TraceLds& tr, const float* lut, const float* srt, const float* dwin, float* terms,
+                                       uint32_t query_topk, int lane, uint32_t* err) {
+    const int nterm = (int)query_topk * 15;
+    unsigned long long errm = 0;  // bit m: evaluating S(Ds(m)) left the acos domain
+    for (int base = 0; base < nterm; base += 64) {
+        const int idx = base + lane;
+        uint32_t e = 0;
+        if (idx < nterm) {
+            const int m = idx / 15, i = idx - m * 15;
+            uint32_t e0 = 0;
+            const float kd = IsMax ? srt[m] : arcos_lut(lut, srt[m], &e0);  // IP: the caller has range-checked every srt[]
+            const float b = dwin[i];
+            float t = 0.f;
+            if (!(b >= kd)) t = arcos_lut(lut, b / kd, &e);
+            terms[idx] = t;
+        }
+        unsigned long long eb = __ballot(e != 0);
+        while (eb) {
+            const int l = __builtin_ctzll(eb);
+            eb &= eb - 1;
+            errm |= 1ull << ((base + l) / 15);
+        }
+    }
+    wave_sync();
+    float g = 0.f;
+    if ((uint32_t)lane < query_topk) {
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 15; i++) sum += terms[lane * 15 + i];
+        g = trace_search(tr.x, tr.z, tr.n, sum);
+    }
+    const unsigned long long query_k = query_topk;
+    const bool first_ok = (double)((float)query_k * g) <= (double)query_k * 1.005;
+    const bool step_ok = (float)(lane + 1) * g <= (float)query_k;
+    const unsigned long long mfirst = __ballot((uint32_t)lane == query_topk - 1 && first_ok);
+    const unsigned long long mstep = __ballot((uint32_t)lane < query_topk && step_ok);
+    wave_sync();
+    unsigned long long high = query_k - 1, low = 0, middle = 0;
+    if ((errm >> high) & 1) {
+        *err = ERR_ARCOS_DOMAIN;
+        return 0;
+    }
+    if (mfirst) return (uint32_t)query_k;
+    while (low <= high) {
+        middle = (low + high) / 2;
+        if (middle <= 0) return 0;
+        if ((errm >> middle) & 1) {
+            *err = ERR_ARCOS_DOMAIN;
+            return 0;
+        }
+        if ((mstep >> middle) & 1) low = middle + 1;
+        else high = middle - 1;
+    }
+    return (uint32_t)(low + 1);
+}
+
 __host__ __device__ inline size_t replay_wave_bytes(int k, uint32_t nlist, bool geo, bool tune, bool train, uint32_t trace_cap) {
     (void)nlist;
     size_t b = (size_t)k * 16;                       // href | hval | srt
     if (geo) b += 16 * 4 + 16 * 4;                   // window of disToBoundary | values inserted during the current probe
     if (tune) b += (size_t)trace_cap * 8;            // cached trace (x | z)
+    if (tune) b += CURNUM_PAR_MAXK * 15 * 4 + 8;     // sum_angle terms of cur_num_par
     if (train) b += (size_t)k * 4;                   // ground-truth row
     return (b + 15) & ~(size_t)15;
 }
@@ -677,7 +757,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
     float* dwin = srt + k;                                 // geo only: 16 boundary distances of the current stage
     float* pend = dwin + (geo ? 16 : 0);                   // geo only: values inserted during the current probe
     float* trc = pend + (geo ? 16 : 0);                    // tune only: x | z, trace_cap each
-    float* gtrow = trc + (tune ? 2 * a.trace_cap : 0);     // training only
+    float* terms = trc + (tune ? 2 * a.trace_cap : 0);     // tune only: cur_num_par scratch
+    float* gtrow = terms + (tune ? CURNUM_PAR_MAXK * 15 + 2 : 0);  // training only
     const float* gdtb = geo ? a.dtb + (size_t)qi * max_num : nullptr;  // disToBoundary (set_online_kernel)
 
     for (int i = lane; i < k; i += 64) {
@@ -688,7 +769,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
 
     const unsigned long long id_q = a.id_offset + qi;
     const unsigned long long dbg_t0 = a.dbg ? __builtin_readcyclecounter() : 0;
-    unsigned long long dbg_evals = 0;
+    unsigned long long dbg_evals = 0, dbg_stream = 0, dbg_rule = 0, dbg_chunks = 0, dbg_probes = 0;
     uint32_t err = 0;
     uint32_t ik0 = a.stage[qi];
     const uint32_t si = a.seg_by_slot ? qi : li;
@@ -773,10 +854,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
             fb = 0;
         }
     };
+    // Masked rounds (a.mask: one bit per candidate, written by the scan kernel for the values that beat the heap
+    // top the query had when the round was planned): a row costs one 8-byte load per 64 candidates, and only the
+    // chunks with a bit set are fetched.  Rows start on multiples of 64 floats there.
+    const bool masked = a.mask != nullptr;
     float v[NLD], nv[NLD];
 #pragma unroll
     for (int u = 0; u < NLD; u++) v[u] = nv[u] = hneutral<IsMax>();
-    fetch(v);
+    if (!masked) fetch(v);
+    auto row_offset = [&](uint32_t p) {
+        return ((unsigned long long)rl_u((uint32_t)(m_off >> 32), (int)(p - win0)) << 32) | rl_u((uint32_t)m_off, (int)(p - win0));
+    };
+    unsigned long long mw_pre = 0;   // mask words of chunks 0..63 of probe pre_p, requested one probe ahead
+    uint32_t pre_p = 0xffffffffu;
+    auto prefetch_masks = [&](uint32_t p) {
+        pre_p = 0xffffffffu;
+        if (p >= cnt || p >= win0 + 64) return;
+        const uint32_t pn = rl_u(m_n, (int)(p - win0));
+        if (pn == 0) return;
+        const unsigned long long* mr = a.mask + (row_offset(p) >> 6);
+        mw_pre = (uint32_t)lane < ((pn + 63) >> 6) ? mr[lane] : 0ull;
+        pre_p = p;
+    };
 
     bool finished = false;
     uint32_t consumed = 0;
@@ -787,7 +886,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
             load_window(p);
             fp = p;
             fb = 0;
-            fetch(v);
+            if (!masked) fetch(v);
         }
         const int key = rl_i(m_key, (int)(p - win0));
         if (key >= 0) {
@@ -796,13 +895,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
                 finished = true;
                 break;
             }
-            const uint32_t n = (uint32_t)rl_i((int)m_n, (int)(p - win0));
+            const uint32_t n = rl_u(m_n, (int)(p - win0));
             if (n > 0) {
                 st_nlist++;
+                const unsigned long long dbg_s0 = a.dbg ? __builtin_readcyclecounter() : 0;
                 const int64_t refbase = REF_TAG | ((int64_t)key << 32);
                 uint32_t npend = 0;
-                for (uint32_t b0 = 0; b0 < n; b0 += TRIP) {
-                    fetch(nv);
+                const uint32_t nchunk = (n + 63) >> 6;
+                const unsigned long long roff = row_offset(p);
+                const float* seg = a.dist + roff;
+                const unsigned long long* mrow = masked ? a.mask + (roff >> 6) : nullptr;
+                unsigned long long mw = 0, nz = 0;
+                uint32_t b0 = 0, w0 = 0;
+                if (masked) {
+                    if (pre_p == p) {  // first window of this row was requested while the previous row ran
+                        mw = mw_pre;
+                        nz = __ballot(mw != 0);
+                        w0 = 64;
+                    }
+                    prefetch_masks(p + 1);
+                }
+                for (;;) {
+                    unsigned long long bm = 0;  // masked: lanes of `mw` (chunks w0 - 64 + lane) now held in v[0..)
+                    if (masked) {
+                        while (nz == 0 && w0 < nchunk) {
+                            mw = w0 + lane < nchunk ? mrow[w0 + lane] : 0ull;
+                            nz = __ballot(mw != 0);
+                            w0 += 64;
+                        }
+                        if (nz == 0) break;
+                        if (a.dbg) dbg_chunks += __builtin_popcountll(nz);
+#pragma unroll
+                        for (int t = 0; t < NLD; t++) {
+                            v[t] = hneutral<IsMax>();
+                            if (nz) {
+                                const int c = __builtin_ctzll(nz);
+                                nz &= nz - 1;
+                                bm |= 1ull << c;
+                                const unsigned long long bits =
+                                    ((unsigned long long)rl_u((uint32_t)(mw >> 32), c) << 32) | rl_u((uint32_t)mw, c);
+                                if ((bits >> lane) & 1) v[t] = __builtin_nontemporal_load(seg + (size_t)(w0 - 64 + c) * 64 + lane);
+                            }
+                        }
+                    } else {
+                        if (b0 >= n) break;
+                        fetch(nv);
+                    }
                     float top = RH ? fkey_inv(rl_u(rh.v0, 1)) : hval[0];  // heap top, kept in a register between admissions
                     // chunks (64 candidates) holding at least one value that beats the top as it is now
                     uint32_t umask = 0;
@@ -815,13 +953,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
                         float x = v[0];
 #pragma unroll
                         for (int t = 1; t < NLD; t++) x = t == u ? v[t] : x;
+                        uint32_t cbase = b0 + u * 64;  // position of the chunk's first candidate in its list
+                        if (masked) {
+                            unsigned long long mm = bm;
+                            for (int i = 0; i < u; i++) mm &= mm - 1;
+                            cbase = (w0 - 64 + (uint32_t)__builtin_ctzll(mm)) * 64;
+                        }
                         unsigned long long m = __ballot(hcmp<IsMax>(top, x));
                         while (m) {
                             const int l = __builtin_ctzll(m);
                             m &= m - 1;
                             const float val = rl_f(x, l);
                             if (hcmp<IsMax>(top, val)) {
-                                const int64_t nref = refbase | (int64_t)(b0 + u * 64 + l);
+                                const int64_t nref = refbase | (int64_t)(cbase + l);
                                 if (RH) {
                                     const uint32_t sr = rl_u(rh.s0, 1);  // the evicted root's id slot passes to the new entry
                                     if (lane == 0) href[sr] = nref;
@@ -841,9 +985,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
                             }
                         }
                     }
+                    if (!masked) {
 #pragma unroll
-                    for (int u = 0; u < NLD; u++) v[u] = nv[u];
+                        for (int u = 0; u < NLD; u++) v[u] = nv[u];
+                        b0 += TRIP;
+                    }
                 }
+                if (a.dbg) dbg_stream += __builtin_readcyclecounter() - dbg_s0;
                 if (geo && npend) {
                     wave_sync();
                     if (npend <= 16) {
@@ -864,6 +1012,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
         }
         if (a.total_nprobe && ik + 1 >= a.total_nprobe) finished = true;  // end of the probe loop
         wave_sync();
+        const unsigned long long dbg_r0 = a.dbg ? __builtin_readcyclecounter() : 0;
         if (tune) {
             // IndexIVF.cpp:551-638.  Once my_nprobe is known nothing the rule computes can change the
             // outcome any more (L2: no throwing path left), so only the stop test remains.
@@ -895,7 +1044,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
                     }
                 }
                 dbg_evals++;
-                const uint32_t pre_num = cur_num_lds<IsMax>(tr, lut, srt, dwin, query_k, lane, &err);
+                const uint32_t pre_num = query_k <= CURNUM_PAR_MAXK ? cur_num_par<IsMax>(tr, lut, srt, dwin, terms, query_k, lane, &err)
+                                                                    : cur_num_lds<IsMax>(tr, lut, srt, dwin, query_k, lane, &err);
                 float recall = (float)pre_num / (float)query_k;
                 const float max_val = IsMax ? fmaxf(-1.f, srt[k - 1]) : fminf(FLT_MAX, srt[k - 1]);
                 const unsigned long long stops = (unsigned long long)(racc * 12);
@@ -930,6 +1080,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
                 finished = true;
             }
         }
+        if (a.dbg) dbg_rule += __builtin_readcyclecounter() - dbg_r0;
         if (training && !finished) {
             // IndexIVF.cpp:640-673
             const uint32_t stage = ik + 1;
@@ -978,14 +1129,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
         if (st_nheap) atomicAdd(&a.stats[2], st_nheap);
         if (err) atomicMax(a.error, err);
         if (a.dbg) {
-            a.dbg[(size_t)li * 4 + 0] = __builtin_readcyclecounter() - dbg_t0;
-            a.dbg[(size_t)li * 4 + 1] = st_nheap;
-            a.dbg[(size_t)li * 4 + 2] = st_ndis;
-            a.dbg[(size_t)li * 4 + 3] = dbg_evals;
+            a.dbg[(size_t)li * 8 + 0] = __builtin_readcyclecounter() - dbg_t0;
+            a.dbg[(size_t)li * 8 + 1] = st_nheap;
+            a.dbg[(size_t)li * 8 + 2] = st_ndis;
+            a.dbg[(size_t)li * 8 + 3] = dbg_evals;
+            a.dbg[(size_t)li * 8 + 4] = dbg_stream;
+            a.dbg[(size_t)li * 8 + 5] = dbg_rule;
+            a.dbg[(size_t)li * 8 + 6] = dbg_chunks;
+            a.dbg[(size_t)li * 8 + 7] = consumed;
         }
     }
 
     wave_sync();
+    if (a.thr && lane == 0) a.thr[qi] = RH ? fkey_inv(rl_u(rh.v0, 1)) : hval[0];  // next round's scan stores only what beats this
     if (RH) rh_store(rh, hval, href, k, lane, true);  // back to the node-ordered LDS layout
     if (finished || a.finalize_all || err) {
         if (a.raw_heap_out) {

@@ -13,8 +13,9 @@ namespace amdivf {
 __global__ __launch_bounds__(256) void plan_counts_kernel(PlanArgs a) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.nq) return;
-    uint32_t cnt = 0;
+    uint32_t cnt = 0, pad = 0;
     unsigned long long need = 0;
+    const unsigned long long ra = a.row_align - 1;
     if (!a.done[i]) {
         const uint32_t stage = a.stage[i];
         unsigned long long target = (unsigned long long)stage + a.round_len;
@@ -34,11 +35,16 @@ __global__ __launch_bounds__(256) void plan_counts_kernel(PlanArgs a) {
         const int64_t* kq = a.keys + (size_t)i * a.key_stride + stage;
         for (uint32_t p = 0; p < cnt; p++) {
             const int64_t key = kq[p];
-            if (key >= 0 && (unsigned long long)key < a.nlist) need += a.list_off[key + 1] - a.list_off[key];
+            if (key >= 0 && (unsigned long long)key < a.nlist) {
+                const unsigned long long sz = a.list_off[key + 1] - a.list_off[key], psz = (sz + ra) & ~ra;
+                need += psz;
+                pad += (uint32_t)(psz - sz);
+            }
         }
     }
     a.cnt[i] = cnt;
     a.need[i] = need;
+    a.pad[i] = pad;
 }
 
 // ---- 2. one block: prefix sums over the queries, budget cut, list of active queries
@@ -111,7 +117,7 @@ __global__ __launch_bounds__(1024) void plan_prefix_kernel(PlanArgs a) {
         if (a.cnt[i]) {
             nact++;
             nseg += a.cnt[i];
-            ndist += a.need[i];
+            ndist += a.need[i] - a.pad[i];
         }
     }
     atomicAdd(&s_nact, nact);
@@ -137,6 +143,7 @@ __global__ __launch_bounds__(256) void plan_segments_kernel(PlanArgs a) {
     const uint32_t stage = a.stage[i];
     const int64_t* kq = a.keys + (size_t)i * a.key_stride + stage;
     unsigned long long cur = a.dist_base[i];
+    const unsigned long long ra = a.row_align - 1;
     const uint32_t sb = a.seg_begin[i];
     for (uint32_t p = 0; p < c; p++) {
         const int64_t key = kq[p];
@@ -146,7 +153,7 @@ __global__ __launch_bounds__(256) void plan_segments_kernel(PlanArgs a) {
             const unsigned long long sz = a.list_off[key + 1] - a.list_off[key];
             if (sz) {
                 atomicAdd(&a.lcount[key], 1u);
-                cur += sz;
+                cur += (sz + ra) & ~ra;
             }
         }
     }
