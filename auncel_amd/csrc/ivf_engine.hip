@@ -738,7 +738,9 @@ struct WallClock {
 
 // ------------------------------------------------------------------------------------ coarse
 // distances of n device queries (row stride dpad) to every centroid -> sorted top-nprobe on device
-void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode, float* d_out_dis, int64_t* d_out_keys, int fused) {
+// prefix != 0: the caller reads only the first `prefix` entries of every ranking (launch_sort_rows)
+void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode, float* d_out_dis, int64_t* d_out_keys, int fused,
+                size_t prefix = 0) {
     if (!ix(h)->have_centroids) throw EngineError("quantizer has no centroids");
     // mode 0: exact per-pair kernel; 1: GEMM formulation on the matrix cores; -1: the reference's own switch
     // (utils.cpp:624-655: exact for fewer than 20 queries when d % 4 == 0, BLAS otherwise)
@@ -858,7 +860,7 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
             launch_replay(ra, s);
         } else {
             launch_sort_rows(h->w_dist.as<float>(), (uint32_t)m, (uint32_t)nlist, (uint32_t)nprobe, h->metric,
-                             d_out_dis + c0 * nprobe, d_out_keys + c0 * nprobe, s);
+                             d_out_dis + c0 * nprobe, d_out_keys + c0 * nprobe, s, (uint32_t)prefix);
         }
         h->timer.end(t, s);
         HIP_CHECK(hipStreamSynchronize(s));
@@ -1658,14 +1660,14 @@ int amd_ivf_set_tuner(amd_ivf_t* h, size_t max_topk, size_t ntraces, const size_
 // one slice of an adaptive batch: queries [q0, q0+n) of the call, on lane `L` (L == h or one of h's kids)
 static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n, size_t query_topk, float multipler, float std_m,
                            const float* dreq, const float* dgt, unsigned long long* dnp, float* dtr, int profile, int coarse_mode,
-                           float* D, int64_t* I, const IntRange& qr) {
+                           float* D, int64_t* I, const IntRange& qr, size_t coarse_prefix) {
     use_device(L);
     const size_t K = ix(L)->tuner_max_topk, nlist = L->nlist;
     L->w_cdis.ensure(n * nlist * 4);
     L->w_ckeys.ensure(n * nlist * 8);
     // full coarse ranking (Error_sys::search sets nprobe = nlist, profile.cpp:220)
     coarse_dev(L, d_x, n, nlist, coarse_mode, L->w_cdis.as<float>(), L->w_ckeys.as<int64_t>(),
-               ix(L)->allow_fused && ix(L)->centroid_range.fusable_with(qr));
+               ix(L)->allow_fused && ix(L)->centroid_range.fusable_with(qr), coarse_prefix);
     init_state(L, n, K, true);
     launch_set_online(L->metric, (uint32_t)nlist, (uint32_t)n, L->w_cdis.as<float>(), L->w_ckeys.as<int64_t>(), (uint32_t)nlist,
                       ix(L)->d_interdis.as<float>(), ix(L)->d_arcos.as<float>(), L->w_dtb.as<float>(), L->w_error.as<uint32_t>(), L->stream);
@@ -1727,6 +1729,14 @@ static void adaptive_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n
     HIP_CHECK(hipMemcpyAsync(d_np.p, my_nprobe, nabs * 8, hipMemcpyHostToDevice, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
 
+    // How much of the coarse ranking can be consumed: set_online reads entries 0 .. nlist/8+20, and the probe loop ends at
+    // my_nprobe <= floor((nlist/8) * multipler) (IndexIVF.cpp:615-632) or at a value the caller passed in.  When that is
+    // well short of nlist only this prefix is ranked (launch_sort_rows).
+    size_t coarse_prefix = std::max<size_t>(nlist / 8 + 21, (size_t)((double)(nlist / 8) * (double)multipler) + 2);
+    for (size_t i = start; i < nabs; i++) coarse_prefix = std::max<size_t>(coarse_prefix, (size_t)my_nprobe[i] + 1);
+    coarse_prefix += 16;
+    if (coarse_prefix >= nlist || getenv("AUNCEL_AMD_FULL_COARSE_SORT")) coarse_prefix = 0;
+
     const size_t nl = std::min(lane_count(n), std::max<size_t>(1, n / 64));
     while (h->kids.size() + 1 < nl) {
         std::unique_ptr<amd_ivf> kid(new amd_ivf);
@@ -1752,7 +1762,7 @@ static void adaptive_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n
         const size_t q0 = n * i / nl, q1 = n * (i + 1) / nl;
         try {
             adaptive_slice(lanes[i], d_x + q0 * h->dpad, start + q0, q1 - q0, query_topk, multipler, std_m, dreq, dgt,
-                           d_np.as<unsigned long long>(), dtr, profile, coarse_mode, D + q0 * K, I + q0 * K, qr);
+                           d_np.as<unsigned long long>(), dtr, profile, coarse_mode, D + q0 * K, I + q0 * K, qr, coarse_prefix);
         } catch (...) {
             errs[i] = std::current_exception();
         }
@@ -1849,8 +1859,11 @@ static void train_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n, s
     }
     h->w_cdis.ensure(n * nlist * 4);
     h->w_ckeys.ensure(n * nlist * 8);
+    // training stops after stage nlist/8 + 1 (IndexIVF.cpp:640-673); set_online reads entries 0 .. nlist/8+20
+    size_t coarse_prefix = nlist / 8 + 21 + 16;
+    if (coarse_prefix >= nlist || getenv("AUNCEL_AMD_FULL_COARSE_SORT")) coarse_prefix = 0;
     coarse_dev(h, d_x, n, nlist, coarse_mode, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>(),
-               h->allow_fused && h->centroid_range.fusable_with(qr));
+               h->allow_fused && h->centroid_range.fusable_with(qr), coarse_prefix);
     init_state(h, n, K, true);
     launch_set_online(h->metric, (uint32_t)nlist, (uint32_t)n, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>(), (uint32_t)nlist,
                       h->d_interdis.as<float>(), h->d_arcos.as<float>(), h->w_dtb.as<float>(), h->w_error.as<uint32_t>(), h->stream);

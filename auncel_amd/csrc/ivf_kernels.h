@@ -203,8 +203,9 @@ constexpr uint32_t ERR_INVALID_KEY = 3;
 
 // ---------------------------------------------------------------------------- coarse helpers
 // full ascending/descending sort of each row of `dis` (nlist entries) keeping the first nprobe
+// prefix != 0: only the first `prefix` entries are needed in order; the rest may come out as (neutral, -1)
 void launch_sort_rows(const float* dis, uint32_t nq, uint32_t nlist, uint32_t nprobe, int metric, float* out_dis,
-                      int64_t* out_keys, hipStream_t s);
+                      int64_t* out_keys, hipStream_t s, uint32_t prefix = 0);
 
 // GEMM-formulated coarse distances on the fp32 matrix cores (row stride d, d % 4 == 0)
 void launch_row_norms(const float* x, size_t n, int d, float* out, hipStream_t s);

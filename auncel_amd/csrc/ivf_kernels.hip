@@ -138,11 +138,12 @@ __global__ __launch_bounds__(QG == 8 ? 512 : 256) void scan_tiles_kernel(ScanArg
                 ya[v] = f2{yn[v].x, yn[v].y};
                 yb[v] = f2{yn[v].z, yn[v].w};
             }
-            if (s + 1 < nslot) {
+            {   // unconditional (the last step re-reads its own operands): a branch here costs a register copy per operand
+                const int sn = s + 1 < nslot ? s + 1 : s;
 #pragma unroll
-                for (int v = 0; v < SCAN_RV; v++) yn[v] = *reinterpret_cast<const float4*>(myrow + v * 64 * LDS_ROW + (s + 1) * 4);
+                for (int v = 0; v < SCAN_RV; v++) yn[v] = *reinterpret_cast<const float4*>(myrow + v * 64 * LDS_ROW + sn * 4);
 #pragma unroll
-                for (int r = 0; r < SCAN_RQ; r++) qn[r] = qs[(s + 1) * SCAN_RQ + r];
+                for (int r = 0; r < SCAN_RQ; r++) qn[r] = qs[sn * SCAN_RQ + r];
             }
 #pragma unroll
             for (int r = 0; r < SCAN_RQ; r++) {
@@ -1348,9 +1349,118 @@ __global__ __launch_bounds__(256) void sort_rows_kernel(const float* dis, uint32
     }
 }
 
+// Only the first `prefix` entries of the ranking (the adaptive search never probes past (nlist / 8) * multipler):
+// a workgroup keeps its row in registers (nlist <= 4096), finds by bisection on the order keys the threshold below
+// which at least `prefix` values lie, and sorts just those (S = 1024 or 2048 slots in LDS).  Same total order as
+// sort_rows_kernel; entries [prefix, nprobe) come out as (neutral distance, -1).
+template <bool Ascending>
+__global__ __launch_bounds__(256) void sort_prefix_kernel(const float* dis, uint32_t nlist, uint32_t nprobe, uint32_t prefix, uint32_t S,
+                                                           float* out_dis, int64_t* out_keys) {
+    __shared__ unsigned long long buf[2048];
+    __shared__ uint32_t red[2][4];
+    __shared__ uint32_t s_cnt;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* row = dis + (size_t)q * nlist;
+    constexpr int E = 16;
+    uint32_t key[E];
+#pragma unroll
+    for (int j = 0; j < E; j++) {
+        const uint32_t i = tid + 256 * j;
+        key[j] = 0xffffffffu;
+        if (i < nlist) key[j] = Ascending ? fkey(row[i]) : ~fkey(row[i]);
+    }
+    if (tid == 0) s_cnt = 0;
+    int par = 0;
+    // number of row entries for which pred holds (wave-uniform partial counts from ballots, then 4 waves through LDS)
+    auto block_count = [&](auto pred) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int j = 0; j < E; j++) c += __builtin_popcountll(__ballot(pred(key[j], tid + 256 * j)));
+        if (lane == 0) red[par][wave] = c;
+        __syncthreads();
+        const uint32_t tot = red[par][0] + red[par][1] + red[par][2] + red[par][3];
+        par ^= 1;
+        return tot;
+    };
+    // smallest T with #(key <= T) >= prefix
+    uint32_t lo = 0, hi = 0xffffffffu, cT = nlist;
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        const uint32_t c = block_count([&](uint32_t k, uint32_t) { return k <= mid; });
+        if (c >= prefix) {
+            hi = mid;
+            cT = c;
+            if (c <= S) break;  // any threshold that keeps between prefix and S values will do
+        } else {
+            lo = mid + 1;
+        }
+    }
+    const uint32_t T = hi;
+    uint32_t I = 0xffffffffu;  // among the values equal to T keep the centroids numbered <= I
+    if (cT > S) {              // a run of exactly equal distances straddles the cut: bisect on the centroid number
+        const uint32_t below = block_count([&](uint32_t k, uint32_t) { return k < T; });
+        uint32_t a = 0, b = nlist - 1;
+        while (a < b) {
+            const uint32_t mid = a + (b - a) / 2;
+            const uint32_t c = below + block_count([&](uint32_t k, uint32_t i) { return k == T && i <= mid; });
+            if (c >= prefix) b = mid;
+            else a = mid + 1;
+        }
+        I = b;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < E; j++) {
+        const uint32_t i = tid + 256 * j;
+        const bool take = key[j] < T || (key[j] == T && i <= I);
+        const unsigned long long m = __ballot(take);
+        uint32_t base = 0;
+        if (lane == 0 && m) base = atomicAdd(&s_cnt, (uint32_t)__builtin_popcountll(m));
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (take) buf[base + __builtin_popcountll(m & ((1ull << lane) - 1))] = ((unsigned long long)key[j] << 32) | i;
+    }
+    __syncthreads();
+    const uint32_t C = s_cnt;  // prefix <= C <= S
+    for (uint32_t i = C + tid; i < S; i += 256) buf[i] = ~0ull;
+    __syncthreads();
+    for (uint32_t size = 2; size <= S; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = tid; t < S / 2; t += 256) {
+                const uint32_t l = 2 * t - (t & (stride - 1)), h = l + stride;
+                const bool up = (l & size) == 0;
+                const unsigned long long x = buf[l], y = buf[h];
+                if ((x < y) != up) {
+                    buf[l] = y;
+                    buf[h] = x;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = tid; i < nprobe; i += 256) {
+        float dv = Ascending ? FLT_MAX : -FLT_MAX;
+        int64_t id = -1;
+        if (i < prefix && i < C) {
+            const unsigned long long e = buf[i];
+            const uint32_t k = (uint32_t)(e >> 32);
+            dv = fkey_inv(Ascending ? k : ~k);
+            id = (int64_t)(uint32_t)e;
+        }
+        out_dis[(size_t)q * nprobe + i] = dv;
+        out_keys[(size_t)q * nprobe + i] = id;
+    }
+}
+
+// prefix: 0 = rank all nprobe entries; else only the first `prefix` are needed (see sort_prefix_kernel)
 void launch_sort_rows(const float* dis, uint32_t nq, uint32_t nlist, uint32_t nprobe, int metric, float* out_dis,
-                      int64_t* out_keys, hipStream_t s) {
+                      int64_t* out_keys, hipStream_t s, uint32_t prefix) {
     if (nq == 0) return;
+    if (prefix && prefix < nprobe && prefix <= 2048 && prefix <= nlist && nlist <= 4096) {
+        const uint32_t S = prefix <= 1024 ? 1024u : 2048u;
+        if (metric == METRIC_L2) hipLaunchKernelGGL(sort_prefix_kernel<true>, dim3(nq), dim3(256), 0, s, dis, nlist, nprobe, prefix, S, out_dis, out_keys);
+        else hipLaunchKernelGGL(sort_prefix_kernel<false>, dim3(nq), dim3(256), 0, s, dis, nlist, nprobe, prefix, S, out_dis, out_keys);
+        return;
+    }
     uint32_t npow2 = 2;
     while (npow2 < nlist) npow2 <<= 1;
     const size_t shmem = (size_t)npow2 * 8;

@@ -1,0 +1,20 @@
+"""fixed-nprobe searches of the 10M byte-code workload (for rocprofv3 counter passes): NPROBE, K, REPS from the env"""
+import sys, time, os, numpy as np, torch
+sys.path.insert(0, '/root/repo')
+import bench
+from auncel_amd import capi
+dev = torch.device('cuda', 0)
+nb, d, nlist, nq = int(os.environ.get('NB', 10_000_000)), 128, 4096, 5000
+xb_t, _, draw = bench.gen_data(torch, dev, nb, 0, d, 20000, 35.0, 1235)
+g = torch.Generator(device=dev); g.manual_seed(5)
+xq_t = draw(nq, g)
+cen_t = bench.kmeans_centroids(torch, xb_t, nlist, 4, 99)
+xb, xq, cen = xb_t.cpu().numpy(), xq_t.cpu().numpy(), cen_t.cpu().numpy()
+del xb_t, xq_t, cen_t; torch.cuda.empty_cache()
+h = capi.Handle(d, nlist, capi.METRIC_L2, 0); h.set_centroids(cen); h.add(xb); del xb
+h.set_queries(xq)
+k, nprobe = int(os.environ.get('K', 10)), int(os.environ.get('NPROBE', 32))
+for _ in range(int(os.environ.get('REPS', 3))):
+    t0 = time.perf_counter(); D, I = h.search_resident(0, nq, k, nprobe); dt = time.perf_counter() - t0
+    tm = h.last_timing()
+    print(f"k {k} nprobe {nprobe}: wall {dt*1e3:.2f}ms scan {tm['scan_ms']:.2f} select {tm['select_ms']:.2f} arith {h.scan_arith()}", flush=True)
