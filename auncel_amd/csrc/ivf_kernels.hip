@@ -386,55 +386,33 @@ __device__ __forceinline__ void rh_set(RegHeap& h, int node, uint32_t key, uint3
 }
 
 // Heap.h:88-118 (the node being removed, k, still takes part in the child comparisons, as there).
-// KC != 0: k is the compile-time constant KC and the bounds tests of complete levels fold away.  The walk down
-// only compares keys; the nodes it passed are rewritten afterwards (independent writes).
+// KC != 0: k is the compile-time constant KC and the bounds tests of complete levels fold away.
 template <bool IsMax, int KC> __device__ __forceinline__ void rh_pop(RegHeap& h, int krt) {
     const int k = KC ? KC : krt;
     const uint32_t v = rh_key(h, k);
     const uint32_t sv = rh_slot(h, k);
-    int pos[7];       // pos[j]: node visited on level j (pos[0] = root)
-    uint32_t cv[6];   // cv[j]: key moved up into pos[j]
-    pos[0] = 1;
-    int depth = 0;
-    bool going = true;
+    int i = 1;
 #pragma unroll
     for (int lvl = 0; lvl < 6; lvl++) {  // parent on level lvl (node < 64: register 0), children on level lvl + 1
-        const int i = pos[lvl];
-        const int i1 = i << 1, i2 = i1 + 1;
-        pos[lvl + 1] = i;
-        cv[lvl] = 0u;
         const bool absent = KC && (2 << lvl) > KC;      // the whole child level lies beyond k
         const bool full = KC && (4 << lvl) - 1 <= KC;   // every node of the child level exists
-        if (absent) going = false;
-        if (going && (full || i1 <= k)) {
-            const bool only_left = !full && i2 == k + 1;
-            const int j2 = only_left ? i1 : i2;
-            const uint32_t c1 = lvl < 5 ? rl_u(h.v0, i1) : rl_u(h.v1, i1 - 64);
-            const uint32_t c2 = lvl < 5 ? rl_u(h.v0, j2) : rl_u(h.v1, j2 - 64);
-            const bool left = only_left || kcmp<IsMax>(c1, c2);
-            const uint32_t c = left ? c1 : c2;
-            if (kcmp<IsMax>(v, c)) {
-                going = false;
-            } else {
-                pos[lvl + 1] = left ? i1 : i2;
-                cv[lvl] = c;
-                depth = lvl + 1;
-            }
-        } else {
-            going = false;
-        }
+        if (absent) break;
+        const int i1 = i << 1, i2 = i1 + 1;
+        if (!full && i1 > k) break;
+        const bool only_left = !full && i2 == k + 1;
+        const int j2 = only_left ? i1 : i2;
+        const uint32_t c1 = lvl < 5 ? rl_u(h.v0, i1) : rl_u(h.v1, i1 - 64);
+        const uint32_t c2 = lvl < 5 ? rl_u(h.v0, j2) : rl_u(h.v1, j2 - 64);
+        const bool left = only_left || kcmp<IsMax>(c1, c2);
+        const uint32_t c = left ? c1 : c2;
+        if (kcmp<IsMax>(v, c)) break;
+        const int ci = left ? i1 : i2;
+        const uint32_t cs = lvl < 5 ? rl_u(h.s0, ci) : rl_u(h.s1, ci - 64);
+        wl_u(h.v0, c, i);
+        wl_u(h.s0, cs, i);
+        i = ci;
     }
-#pragma unroll
-    for (int lvl = 0; lvl < 6; lvl++) {
-        if (KC && (2 << lvl) > KC) break;
-        if (lvl < depth) {
-            const int ci = pos[lvl + 1];
-            const uint32_t cs = lvl < 5 ? rl_u(h.s0, ci) : rl_u(h.s1, ci - 64);
-            wl_u(h.v0, cv[lvl], pos[lvl]);
-            wl_u(h.s0, cs, pos[lvl]);
-        }
-    }
-    rh_set(h, pos[depth], v, sv);
+    rh_set(h, i, v, sv);
 }
 
 // Heap.h:125-142
