@@ -219,12 +219,12 @@ struct amd_ivf {
     amd_ivf* parent = nullptr;
     std::vector<std::unique_ptr<amd_ivf>> kids;
     // side streams for the sparse tile shapes of a round (fork / join around the dense launch)
-    hipStream_t aux[2] = {nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    hipStream_t aux[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
 
     ~amd_ivf() {
         kids.clear();
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < 3; i++) {
             if (aux[i]) (void)hipStreamDestroy(aux[i]);
             if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
         }
@@ -600,19 +600,19 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
         }
         if (nitems) {
             if (!h->aux[0]) {
-                for (int i = 0; i < 2; i++) {
+                for (int i = 0; i < 3; i++) {
                     HIP_CHECK(hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
                     HIP_CHECK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
                 }
                 HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
             }
             size_t t = h->timer.begin(CAT_SCAN, s);
-            const bool fork = (n_qg[0] || n_qg[1]) && (n_qg[2] || n_qg[3]);
+            const bool fork = ((n_qg[0] != 0) + (n_qg[1] != 0) + (n_qg[2] != 0) + (n_qg[3] != 0)) > 1;
             if (fork) {
                 HIP_CHECK(hipEventRecord(h->ev_fork, s));
-                for (int i = 0; i < 2; i++) HIP_CHECK(hipStreamWaitEvent(h->aux[i], h->ev_fork, 0));
-                launch_scan(sa, n_qg, s, h->aux[0], h->aux[1]);
-                for (int i = 0; i < 2; i++) {
+                for (int i = 0; i < 3; i++) HIP_CHECK(hipStreamWaitEvent(h->aux[i], h->ev_fork, 0));
+                launch_scan(sa, n_qg, s, h->aux[0], h->aux[1], h->aux[2]);
+                for (int i = 0; i < 3; i++) {
                     HIP_CHECK(hipEventRecord(h->ev_join[i], h->aux[i]));
                     HIP_CHECK(hipStreamWaitEvent(s, h->ev_join[i], 0));
                 }
@@ -1026,7 +1026,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     pa.acc64 = reinterpret_cast<unsigned long long*>(h->w_pl_counters.as<uint32_t>() + 18);
 
     if (!h->aux[0]) {
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < 3; i++) {
             HIP_CHECK(hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
             HIP_CHECK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
         }
@@ -1077,12 +1077,12 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
                 sa.mask = h->w_mask.as<unsigned long long>();
             }
             size_t t = h->timer.begin(CAT_SCAN, s);
-            const bool fork = (n_qg[0] || n_qg[1]) && (n_qg[2] || n_qg[3]);
+            const bool fork = ((n_qg[0] != 0) + (n_qg[1] != 0) + (n_qg[2] != 0) + (n_qg[3] != 0)) > 1;
             if (fork) {
                 HIP_CHECK(hipEventRecord(h->ev_fork, s));
-                for (int i = 0; i < 2; i++) HIP_CHECK(hipStreamWaitEvent(h->aux[i], h->ev_fork, 0));
-                launch_scan(sa, n_qg, s, h->aux[0], h->aux[1]);
-                for (int i = 0; i < 2; i++) {
+                for (int i = 0; i < 3; i++) HIP_CHECK(hipStreamWaitEvent(h->aux[i], h->ev_fork, 0));
+                launch_scan(sa, n_qg, s, h->aux[0], h->aux[1], h->aux[2]);
+                for (int i = 0; i < 3; i++) {
                     HIP_CHECK(hipEventRecord(h->ev_join[i], h->aux[i]));
                     HIP_CHECK(hipStreamWaitEvent(s, h->ev_join[i], 0));
                 }

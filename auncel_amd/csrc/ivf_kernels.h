@@ -52,8 +52,9 @@ struct ScanArgs {
 };
 
 // items grouped by qg (1, then 2, 4, 8); n_qg = item count of each group
-// the three shapes are independent: s2 / s1 (optional) let the sparse shapes run beside the dense one
-void launch_scan(const ScanArgs& a, const size_t n_qg[4], hipStream_t s, hipStream_t s2 = nullptr, hipStream_t s1 = nullptr);
+// the shapes are independent: s2 / s1 / s4 (optional) let the qg 2 / 1 / 4 launches run beside the qg 8 one
+void launch_scan(const ScanArgs& a, const size_t n_qg[4], hipStream_t s, hipStream_t s2 = nullptr, hipStream_t s1 = nullptr,
+                 hipStream_t s4 = nullptr);
 
 // gather + interleave the query rows of every group of (up to) 8 pairs: group g holds pairs
 // [group_p0[g], group_p0[g] + group_cnt[g]); missing slots are zero

@@ -280,9 +280,9 @@ template <int QG> static void launch_scan_qg(ScanArgs a, size_t first, size_t n,
 }
 
 // items must be grouped by qg: n_qg[0] items with qg 1, then n_qg[1] with qg 2, n_qg[2] with qg 4, n_qg[3] with qg 8
-void launch_scan(const ScanArgs& a, const size_t n_qg[4], hipStream_t s, hipStream_t s2, hipStream_t s1) {
+void launch_scan(const ScanArgs& a, const size_t n_qg[4], hipStream_t s, hipStream_t s2, hipStream_t s1, hipStream_t s4) {
     launch_scan_qg<8>(a, n_qg[0] + n_qg[1] + n_qg[2], n_qg[3], s);
-    launch_scan_qg<4>(a, n_qg[0] + n_qg[1], n_qg[2], s);
+    launch_scan_qg<4>(a, n_qg[0] + n_qg[1], n_qg[2], s4 ? s4 : s);
     launch_scan_qg<2>(a, n_qg[0], n_qg[1], s2 ? s2 : s);
     launch_scan_qg<1>(a, 0, n_qg[0], s1 ? s1 : s);
 }
@@ -367,6 +367,14 @@ __device__ __forceinline__ void wl_u(uint32_t& reg, uint32_t val, int l) {
     asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(reg) : "s"(val), "s"(l) : "m0");
 }
 
+// two registers, same lane: one M0 set-up
+__device__ __forceinline__ void wl2_u(uint32_t& r0, uint32_t v0, uint32_t& r1, uint32_t v1, int l) {
+    asm("s_mov_b32 m0, %4\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+        : "+v"(r0), "+v"(r1)
+        : "s"(v0), "s"(v1), "s"(l)
+        : "m0");
+}
+
 __device__ __forceinline__ uint32_t rh_key(const RegHeap& h, int node) {
     const uint32_t a = rl_u(h.v0, node & 63), b = rl_u(h.v1, node & 63);
     return node < 64 ? a : b;
@@ -376,13 +384,8 @@ __device__ __forceinline__ uint32_t rh_slot(const RegHeap& h, int node) {
     return node < 64 ? a : b;
 }
 __device__ __forceinline__ void rh_set(RegHeap& h, int node, uint32_t key, uint32_t slot) {
-    if (node < 64) {
-        wl_u(h.v0, key, node);
-        wl_u(h.s0, slot, node);
-    } else {
-        wl_u(h.v1, key, node - 64);
-        wl_u(h.s1, slot, node - 64);
-    }
+    if (node < 64) wl2_u(h.v0, key, h.s0, slot, node);
+    else wl2_u(h.v1, key, h.s1, slot, node - 64);
 }
 
 // Heap.h:88-118 (the node being removed, k, still takes part in the child comparisons, as there).
@@ -408,8 +411,7 @@ template <bool IsMax, int KC> __device__ __forceinline__ void rh_pop(RegHeap& h,
         if (kcmp<IsMax>(v, c)) break;
         const int ci = left ? i1 : i2;
         const uint32_t cs = lvl < 5 ? rl_u(h.s0, ci) : rl_u(h.s1, ci - 64);
-        wl_u(h.v0, c, i);
-        wl_u(h.s0, cs, i);
+        wl2_u(h.v0, c, h.s0, cs, i);
         i = ci;
     }
     rh_set(h, i, v, sv);

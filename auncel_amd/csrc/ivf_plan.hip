@@ -9,9 +9,11 @@
 
 namespace amdivf {
 
-// ---- 1. how many probes does each query run this round, and how many distances is that
+// ---- 1. how many probes does each query run this round, and how many distances is that (one wave per query:
+//         the probes of a query are spread over the lanes)
 __global__ __launch_bounds__(256) void plan_counts_kernel(PlanArgs a) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
     if (i >= a.nq) return;
     uint32_t cnt = 0, pad = 0;
     unsigned long long need = 0;
@@ -33,7 +35,7 @@ __global__ __launch_bounds__(256) void plan_counts_kernel(PlanArgs a) {
         if (target <= stage) target = stage + 1 < a.total_nprobe ? stage + 1 : a.total_nprobe;
         cnt = (uint32_t)(target - stage);
         const int64_t* kq = a.keys + (size_t)i * a.key_stride + stage;
-        for (uint32_t p = 0; p < cnt; p++) {
+        for (uint32_t p = lane; p < cnt; p += 64) {
             const int64_t key = kq[p];
             if (key >= 0 && (unsigned long long)key < a.nlist) {
                 const unsigned long long sz = a.list_off[key + 1] - a.list_off[key], psz = (sz + ra) & ~ra;
@@ -41,10 +43,16 @@ __global__ __launch_bounds__(256) void plan_counts_kernel(PlanArgs a) {
                 pad += (uint32_t)(psz - sz);
             }
         }
+        for (int off = 32; off; off >>= 1) {
+            need += __shfl_xor(need, off);
+            pad += __shfl_xor(pad, off);
+        }
     }
-    a.cnt[i] = cnt;
-    a.need[i] = need;
-    a.pad[i] = pad;
+    if (lane == 0) {
+        a.cnt[i] = cnt;
+        a.need[i] = need;
+        a.pad[i] = pad;
+    }
 }
 
 // ---- 2. one block: prefix sums over the queries, budget cut, list of active queries
@@ -132,30 +140,46 @@ __global__ __launch_bounds__(1024) void plan_prefix_kernel(PlanArgs a) {
     }
 }
 
-// ---- 3. segments of every active query + histogram of pairs per list
+// ---- 3. segments of every active query + histogram of pairs per list (one wave per query)
 __global__ __launch_bounds__(256) void plan_segments_kernel(PlanArgs a) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
     if (i >= a.nq) return;
     const uint32_t c = a.cnt[i];
     if (!c) return;
-    const uint32_t slot = atomicAdd(&a.counters[6], 1u);  // compaction order is irrelevant
-    a.qsel[slot] = i;
+    if (lane == 0) {
+        const uint32_t slot = atomicAdd(&a.counters[6], 1u);  // compaction order is irrelevant
+        a.qsel[slot] = i;
+    }
     const uint32_t stage = a.stage[i];
     const int64_t* kq = a.keys + (size_t)i * a.key_stride + stage;
-    unsigned long long cur = a.dist_base[i];
+    unsigned long long cur = a.dist_base[i];  // wave-uniform running offset
     const unsigned long long ra = a.row_align - 1;
     const uint32_t sb = a.seg_begin[i];
-    for (uint32_t p = 0; p < c; p++) {
-        const int64_t key = kq[p];
-        a.seg_list[sb + p] = (int32_t)key;
-        a.seg_off[sb + p] = cur;
-        if (key >= 0 && (unsigned long long)key < a.nlist) {
-            const unsigned long long sz = a.list_off[key + 1] - a.list_off[key];
-            if (sz) {
-                atomicAdd(&a.lcount[key], 1u);
-                cur += (sz + ra) & ~ra;
+    for (uint32_t p0 = 0; p0 < c; p0 += 64) {
+        const uint32_t p = p0 + lane;
+        int64_t key = -1;
+        unsigned long long psz = 0;
+        if (p < c) {
+            key = kq[p];
+            if (key >= 0 && (unsigned long long)key < a.nlist) {
+                const unsigned long long sz = a.list_off[key + 1] - a.list_off[key];
+                if (sz) {
+                    atomicAdd(&a.lcount[key], 1u);
+                    psz = (sz + ra) & ~ra;
+                }
             }
         }
+        unsigned long long incl = psz;  // inclusive prefix sum over the lanes
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long o = __shfl_up(incl, off);
+            if ((int)lane >= off) incl += o;
+        }
+        if (p < c) {
+            a.seg_list[sb + p] = (int32_t)key;
+            a.seg_off[sb + p] = cur + incl - psz;
+        }
+        cur += __shfl(incl, 63);
     }
 }
 
@@ -223,14 +247,15 @@ __global__ __launch_bounds__(1024) void plan_lists_kernel(PlanArgs a) {
     }
 }
 
-// ---- 5. pairs into their list's range
+// ---- 5. pairs into their list's range (one wave per query)
 __global__ __launch_bounds__(256) void plan_scatter_kernel(PlanArgs a) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
     if (i >= a.nq) return;
     const uint32_t c = a.cnt[i];
     if (!c) return;
     const uint32_t sb = a.seg_begin[i];
-    for (uint32_t p = 0; p < c; p++) {
+    for (uint32_t p = lane; p < c; p += 64) {
         const int32_t key = a.seg_list[sb + p];
         if (key < 0 || (uint32_t)key >= a.nlist) continue;
         if (a.list_off[key + 1] == a.list_off[key]) continue;
@@ -283,7 +308,7 @@ __global__ __launch_bounds__(256) void plan_items_kernel(PlanArgs a) {
 
 void launch_plan(const PlanArgs& a, hipStream_t s) {
     if (a.nq == 0) return;
-    const unsigned gq = (a.nq + 255) / 256, gl = (a.nlist + 255) / 256;
+    const unsigned gq = (a.nq + 3) / 4 /* one wave per query */, gl = (a.nlist + 255) / 256;
     hipLaunchKernelGGL(plan_counts_kernel, dim3(gq), dim3(256), 0, s, a);
     hipLaunchKernelGGL(plan_prefix_kernel, dim3(1), dim3(1024), 0, s, a);
     hipLaunchKernelGGL(plan_segments_kernel, dim3(gq), dim3(256), 0, s, a);
