@@ -17,7 +17,7 @@ _szp = C.POINTER(C.c_size_t)
 _LIB = None
 
 SYMBOLS = [
-    "amd_ivf_last_error", "amd_ivf_device_count", "amd_ivf_create", "amd_ivf_destroy", "amd_ivf_set_centroids",
+    "amd_ivf_last_error", "amd_ivf_device_count", "amd_ivf_create", "amd_ivf_clone", "amd_ivf_destroy", "amd_ivf_set_centroids",
     "amd_ivf_set_lists", "amd_ivf_add", "amd_ivf_ntotal", "amd_ivf_list_size", "amd_ivf_get_list", "amd_ivf_coarse",
     "amd_ivf_search_preassigned", "amd_ivf_search", "amd_ivf_scan_codes", "amd_ivf_distance_to_code", "amd_ivf_stats",
     "amd_ivf_set_queries", "amd_ivf_search_resident", "amd_ivf_set_interdis", "amd_ivf_get_interdis",
@@ -108,6 +108,19 @@ class Handle:
         self.d, self.nlist, self.metric, self.device = int(d), int(nlist), int(metric), int(device)
         self._h = C.c_void_p()
         _chk(lib().amd_ivf_create(self.d, C.c_size_t(self.nlist), self.metric, self.device, C.byref(self._h)))
+
+    def clone(self):
+        """a second search context over the same device-resident index (include/auncel_amd.h: amd_ivf_clone); the
+        owner is kept alive by the clone"""
+        c = Handle.__new__(Handle)
+        c.d, c.nlist, c.metric, c.device = self.d, self.nlist, self.metric, self.device
+        c._h = C.c_void_p()
+        c._owner = self
+        for attr in ("max_topk",):  # tuner geometry set on the owner by set_tuner
+            if hasattr(self, attr):
+                setattr(c, attr, getattr(self, attr))
+        _chk(lib().amd_ivf_clone(self._h, C.byref(c._h)))
+        return c
 
     def close(self):
         if self._h:

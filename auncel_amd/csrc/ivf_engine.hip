@@ -13,6 +13,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -217,6 +218,8 @@ struct amd_ivf {
     // its own stream with its own workspaces (kids borrow the index data of `parent`), so that one
     // slice's latency-bound selection and host-side round planning overlap another slice's VALU-bound scan.
     amd_ivf* parent = nullptr;
+    bool is_clone = false;  // made by amd_ivf_clone: a search context of its own over the parent's index data
+    std::mutex upload_mu;   // owner only: serialises the first upload of the lists
     std::vector<std::unique_ptr<amd_ivf>> kids;
     // side streams for the sparse tile shapes of a round (fork / join around the dense launch)
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};
@@ -242,6 +245,8 @@ void use_device(const amd_ivf* h) { HIP_CHECK(hipSetDevice(h->device)); }
 
 // ------------------------------------------------------------------------------------ lists
 void upload_lists(amd_ivf* h) {
+    h = ix(h);
+    std::lock_guard<std::mutex> lock(h->upload_mu);
     if (!h->lists_dirty) return;
     use_device(h);
     h->h_list_off.assign(h->nlist + 1, 0);
@@ -883,7 +888,7 @@ void search_fixed_core(amd_ivf* h, const float* d_x, size_t n, size_t k, size_t 
             size_t nscan = 0;
             for (size_t p = 0; p < nprobe; p++) {
                 int64_t key = keys[i * nprobe + p];
-                if (key >= 0 && (size_t)key < h->nlist) nscan += h->h_list_off[key + 1] - h->h_list_off[key];
+                if (key >= 0 && (size_t)key < h->nlist) nscan += ix(h)->h_list_off[key + 1] - ix(h)->h_list_off[key];
                 if (nscan >= max_codes) {
                     r.cnt[i] = (uint32_t)(p + 1);
                     break;
@@ -898,7 +903,7 @@ void search_fixed_core(amd_ivf* h, const float* d_x, size_t n, size_t k, size_t 
     r.max_codes = max_codes;
     r.finalize_all = 1;
     r.d_x = d_x;
-    r.fused = h->allow_fused && h->db_range.fusable_with(qr);
+    r.fused = h->allow_fused && ix(h)->db_range.fusable_with(qr);
     r.bytes = byte_queries(h, ix(h), d_x, n, qr);
     ix(h)->last_arith = r.bytes ? 2 : r.fused ? 1 : 0;
     exec_round(h, r);
@@ -913,7 +918,7 @@ void search_full(amd_ivf* h, const float* d_x, size_t n, size_t k, size_t nprobe
     h->w_cdis.ensure(n * nprobe * 4);
     h->w_ckeys.ensure(n * nprobe * 8);
     coarse_dev(h, d_x, n, nprobe, coarse_mode, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>(),
-               h->allow_fused && h->centroid_range.fusable_with(qr));
+               h->allow_fused && ix(h)->centroid_range.fusable_with(qr));
     std::vector<int64_t> keys(n * nprobe);
     HIP_CHECK(hipMemcpyAsync(keys.data(), h->w_ckeys.p, n * nprobe * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -1279,6 +1284,31 @@ int amd_ivf_create(int d, size_t nlist, int metric, int device, amd_ivf_t** out)
     API_END
 }
 
+// Entry points that change or read back index data are for the owning handle only.
+#define OWNER_ONLY(h) \
+    if ((h)->is_clone) throw EngineError("not available on a search context made by amd_ivf_clone: use the owning handle")
+
+int amd_ivf_clone(amd_ivf_t* h, amd_ivf_t** out) {
+    API_BEGIN
+    amd_ivf* owner = ix(h);
+    use_device(owner);
+    upload_lists(owner);
+    std::unique_ptr<amd_ivf> c(new amd_ivf);
+    c->parent = owner;
+    c->is_clone = true;
+    c->d = owner->d;
+    c->dpad = owner->dpad;
+    c->nlist = owner->nlist;
+    c->metric = owner->metric;
+    c->device = owner->device;
+    c->dist_budget_floats = owner->dist_budget_floats;
+    c->allow_fused = owner->allow_fused;
+    c->allow_bytes = owner->allow_bytes;
+    HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    *out = c.release();
+    API_END
+}
+
 int amd_ivf_destroy(amd_ivf_t* h) {
     API_BEGIN
     if (h) {
@@ -1290,6 +1320,7 @@ int amd_ivf_destroy(amd_ivf_t* h) {
 
 int amd_ivf_set_centroids(amd_ivf_t* h, const float* centroids) {
     API_BEGIN
+    OWNER_ONLY(h);
     use_device(h);
     h->h_centroids.assign(h->nlist * h->dpad, 0.f);
     for (size_t i = 0; i < h->nlist; i++) memcpy(&h->h_centroids[i * h->dpad], centroids + i * h->d, h->d * sizeof(float));
@@ -1308,6 +1339,7 @@ int amd_ivf_set_centroids(amd_ivf_t* h, const float* centroids) {
 
 int amd_ivf_set_lists(amd_ivf_t* h, const size_t* sizes, const float* const* codes, const int64_t* const* ids) {
     API_BEGIN
+    OWNER_ONLY(h);
     size_t nt = 0;
     h->db_range = IntRange();
     for (size_t l = 0; l < h->nlist; l++) {
@@ -1326,6 +1358,7 @@ int amd_ivf_set_lists(amd_ivf_t* h, const size_t* sizes, const float* const* cod
 
 int amd_ivf_add(amd_ivf_t* h, size_t n, const float* x, const int64_t* xids, const int64_t* precomputed_idx) {
     API_BEGIN
+    OWNER_ONLY(h);
     use_device(h);
     std::vector<int64_t> assign;
     const int64_t* idx = precomputed_idx;
@@ -1365,19 +1398,20 @@ int amd_ivf_add(amd_ivf_t* h, size_t n, const float* x, const int64_t* xids, con
 }
 
 int amd_ivf_ntotal(const amd_ivf_t* h, size_t* ntotal) {
-    *ntotal = h->ntotal;
+    *ntotal = ix(h)->ntotal;
     return 0;
 }
 
 int amd_ivf_list_size(const amd_ivf_t* h, size_t list_no, size_t* size) {
     API_BEGIN
     if (list_no >= h->nlist) throw EngineError("Invalid list number");
-    *size = h->h_ids[list_no].size();
+    *size = ix(h)->h_ids[list_no].size();
     API_END
 }
 
 int amd_ivf_get_list(const amd_ivf_t* hc, size_t list_no, float* codes, int64_t* ids) {
     API_BEGIN
+    OWNER_ONLY(hc);
     amd_ivf* h = const_cast<amd_ivf*>(hc);
     if (list_no >= h->nlist) throw EngineError("Invalid list number");
     upload_lists(h);
@@ -1394,6 +1428,7 @@ int amd_ivf_get_list(const amd_ivf_t* hc, size_t list_no, float* codes, int64_t*
 
 int amd_ivf_coarse(amd_ivf_t* h, size_t n, const float* x, size_t nprobe, float* coarse_dis, int64_t* keys, int mode) {
     API_BEGIN
+    OWNER_ONLY(h);
     use_device(h);
     if (n == 0) return 0;
     WallClock wc(h->stream);
@@ -1476,6 +1511,7 @@ int amd_ivf_search_resident(amd_ivf_t* h, size_t start, size_t n, size_t k, size
 int amd_ivf_scan_codes(amd_ivf_t* h, const float* query, size_t list_no, int store_pairs, size_t k, float* simi,
                        int64_t* idxi, size_t* nup) {
     API_BEGIN
+    OWNER_ONLY(h);
     use_device(h);
     if (list_no >= h->nlist) throw EngineError("Invalid key");
     upload_lists(h);
@@ -1517,6 +1553,7 @@ int amd_ivf_scan_codes(amd_ivf_t* h, const float* query, size_t list_no, int sto
 
 int amd_ivf_distance_to_code(amd_ivf_t* h, const float* query, size_t list_no, size_t offset, float* dis) {
     API_BEGIN
+    OWNER_ONLY(h);
     use_device(h);
     if (list_no >= h->nlist) throw EngineError("Invalid key");
     upload_lists(h);
@@ -1552,6 +1589,7 @@ int amd_ivf_stats(amd_ivf_t* h, size_t stats[4], int reset) {
 
 int amd_ivf_set_interdis(amd_ivf_t* h, const float* table) {
     API_BEGIN
+    OWNER_ONLY(h);
     use_device(h);
     const size_t nl = h->nlist, sz = nl * (nl - 1) / 2;
     h->d_interdis.ensure(std::max<size_t>(sz, 1) * 4);
@@ -1620,6 +1658,7 @@ int amd_ivf_set_interdis(amd_ivf_t* h, const float* table) {
 
 int amd_ivf_get_interdis(amd_ivf_t* h, float* table) {
     API_BEGIN
+    OWNER_ONLY(h);
     use_device(h);
     if (!h->have_interdis) throw EngineError("centroid table not set");
     HIP_CHECK(hipMemcpy(table, h->d_interdis.p, h->nlist * (h->nlist - 1) / 2 * 4, hipMemcpyDeviceToHost));
@@ -1629,6 +1668,7 @@ int amd_ivf_get_interdis(amd_ivf_t* h, float* table) {
 int amd_ivf_set_tuner(amd_ivf_t* h, size_t max_topk, size_t ntraces, const size_t* trace_len, const float* const* trace_x,
                       const float* const* trace_y, const float* const* trace_std, const float* arcos_list) {
     API_BEGIN
+    OWNER_ONLY(h);
     use_device(h);
     std::vector<uint32_t> off(ntraces + 1, 0);
     for (size_t i = 0; i < ntraces; i++) off[i + 1] = off[i] + (uint32_t)trace_len[i];
@@ -1704,14 +1744,15 @@ static void adaptive_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n
                             const float* require_acc, const float* gt_D, int profile, int coarse_mode,
                             uint64_t* my_nprobe, float* t_recalls, float* D, int64_t* I, const IntRange& qr) {
     use_device(h);
-    if (!h->have_tuner || !h->have_interdis)
+    const amd_ivf* owner = ix(h);
+    if (!owner->have_tuner || !owner->have_interdis)
         throw EngineError("Search tune start can't start without IVF_pro init and training");
     if (n == 0) return;
-    const size_t K = h->tuner_max_topk, nlist = h->nlist;
+    const size_t K = owner->tuner_max_topk, nlist = h->nlist;
     if (nlist <= nlist / 8 + 20) throw EngineError("tune mode needs nprobe(=nlist) > nlist/8 + 20");
     size_t ntr = 0;
     while (((size_t)1 << ntr) <= nlist / 8) ntr++;
-    if (h->tuner_ntraces < ntr) throw EngineError("not enough traces for this nlist");
+    if (owner->tuner_ntraces < ntr) throw EngineError("not enough traces for this nlist");
     if (query_topk == 0 || query_topk > K) throw EngineError("query_topk out of range");
     WallClock wc(h->stream);
     upload_lists(h);
@@ -1740,7 +1781,7 @@ static void adaptive_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n
     const size_t nl = std::min(lane_count(n), std::max<size_t>(1, n / 64));
     while (h->kids.size() + 1 < nl) {
         std::unique_ptr<amd_ivf> kid(new amd_ivf);
-        kid->parent = h;
+        kid->parent = ix(h);
         kid->d = h->d;
         kid->dpad = h->dpad;
         kid->nlist = h->nlist;
@@ -1897,6 +1938,7 @@ static void train_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n, s
 int amd_ivf_train_samples(amd_ivf_t* h, size_t start, size_t n, size_t max_topk, const float* gt_D, size_t train_num,
                           int coarse_mode, float* const* raw, float* D, int64_t* I) {
     API_BEGIN
+    OWNER_ONLY(h);
     use_device(h);
     if (start + n > h->n_resident) throw EngineError("resident query range out of bounds");
     train_core(h, h->d_resident.as<float>() + start * h->dpad, start, n, max_topk, gt_D, train_num, coarse_mode, raw, D, I,
@@ -1907,6 +1949,7 @@ int amd_ivf_train_samples(amd_ivf_t* h, size_t start, size_t n, size_t max_topk,
 int amd_ivf_train_samples_x(amd_ivf_t* h, size_t n, const float* x, size_t id_offset, size_t max_topk, const float* gt_D,
                             size_t train_num, int coarse_mode, float* const* raw, float* D, int64_t* I) {
     API_BEGIN
+    OWNER_ONLY(h);
     use_device(h);
     if (n == 0) return 0;
     h->w_x.ensure(n * h->dpad * sizeof(float));
@@ -2031,7 +2074,7 @@ int amd_ivf_merge_tables(int metric, size_t n, size_t k, size_t nshard, const fl
     API_END
 }
 
-int amd_ivf_scan_arith(amd_ivf_t* h) { return h->last_arith; }
+int amd_ivf_scan_arith(amd_ivf_t* h) { return ix(h)->last_arith; }
 
 int amd_ivf_last_timing(amd_ivf_t* h, double out[8]) {
     for (int i = 0; i < 8; i++) out[i] = h->timing[i];

@@ -113,6 +113,9 @@ def main():
     ap.add_argument("--std-m", type=float, default=1.0)
     ap.add_argument("--cpu-sample", type=int, default=256)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="batches kept in flight per GPU, each from its own host thread on its own search context "
+                         "(amd_ivf_clone); 1 = one batch at a time")
     args = ap.parse_args()
 
     import torch
@@ -183,11 +186,22 @@ def main():
             chosen = mult
             break
 
-    # ---- timed region: K steps over the resident test batch
-    def step():
+    # ---- timed region: K steps over the resident test batch.  A step is one search_adaptive call over the whole batch;
+    # with --in-flight N the K calls are issued from N host threads, each on its own search context over the same
+    # device-resident index, so that one batch's latency-bound phases (ordered selection, round planning) overlap
+    # another batch's scans.  Every step is a complete, independent search either way.
+    import threading
+    nfl = max(1, min(args.in_flight, args.steps))
+    ctxs = [h] + [h.clone() for _ in range(nfl - 1)]
+    for c in ctxs[1:]:
+        c.set_queries(xq)
+
+    stagger_s = float(os.environ.get("BENCH_STAGGER_MS", "0")) / 1e3
+
+    def step(ctx):
         np_ = np.zeros(ts + ses, dtype=np.uint64)
         tr_ = np.zeros(ts + ses, dtype=np.float32)
-        D, I = h.search_adaptive(ts, ses, topk, chosen, args.std_m, req, np_, tr_)
+        D, I = ctx.search_adaptive(ts, ses, topk, chosen, args.std_m, req, np_, tr_)
         return D, I, np_
 
     def barrier():
@@ -195,30 +209,59 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    scan_ms = scan_bytes = scan_launches = coarse_ms = select_ms = slot_eff = 0.0
-    h.stats(reset=True)
+    def run_steps(nsteps, acc):
+        """steps j, j + nfl, ... on context j; acc collects per-step kernel timings and the last result"""
+        errs = []
+
+        def worker(j):
+            try:
+                if j and stagger_s:
+                    time.sleep(j * stagger_s)  # start the contexts out of phase (scan of one under selection of the other)
+                for _ in range(j, nsteps, nfl):
+                    res = step(ctxs[j])
+                    tm = ctxs[j].last_timing()
+                    with lock:
+                        for key in ("scan_ms", "scan_bytes", "scan_launches", "coarse_ms", "select_ms"):
+                            acc[key] = acc.get(key, 0.0) + tm[key]
+                        acc["slot_eff"] = acc.get("slot_eff", 0.0) + tm["slot_efficiency"]
+                        acc["last"] = res
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        lock = threading.Lock()
+        if nfl == 1:
+            worker(0)
+        else:
+            th = [threading.Thread(target=worker, args=(j,)) for j in range(nfl)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        if errs:
+            raise errs[0]
+
+    run_steps(max(args.warmup, nfl if args.warmup else 0), {})
+    for c in ctxs:
+        c.stats(reset=True)
+    acc = {}
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        D, I, my_np = step()
-        tm = h.last_timing()
-        scan_ms += tm["scan_ms"]
-        scan_bytes += tm["scan_bytes"]
-        scan_launches += tm["scan_launches"]
-        coarse_ms += tm["coarse_ms"]
-        select_ms += tm["select_ms"]
-        slot_eff += tm["slot_efficiency"] / args.steps
+    run_steps(args.steps, acc)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    D, I, my_np = acc["last"]
+    scan_ms, scan_bytes, scan_launches = acc["scan_ms"], acc["scan_bytes"], acc["scan_launches"]
+    coarse_ms, select_ms, slot_eff = acc["coarse_ms"], acc["select_ms"], acc["slot_eff"] / args.steps
 
     rec = recall_dist(D, gtD[ts:], topk)
-    st = h.stats()
+    st = {}
+    for c in ctxs:
+        for key, val in c.stats().items():
+            st[key] = st.get(key, 0) + val
     # algorithmic bytes: the reference's own ndis counter (codes actually visited by the probe loops,
     # IndexIVF.cpp:676,733) x d x 4; `scan_bytes` (distances the tiles computed, incl. the probes a round
     # ran past a query's stop point) is reported beside it as computed_over_algorithmic
@@ -239,6 +282,7 @@ def main():
         "config": {
             "workload": f"SIFT-{args.nb // 1000000}M-like d={d} IVF{nlist},Flat max_topk={K} topk={topk} Auncel error-bound nprobe "
                         f"(bound {args.bound}), batch {ses} resident queries per GPU, index replicated per GPU",
+            "in_flight": nfl,
             "nb": args.nb, "sigma": args.sigma, "multipler": chosen, "std_m": args.std_m,
             "recall_at_10_mean": float(rec.mean()), "recall_at_10_min": float(rec.min()),
             "nprobe_mean": float(my_np[ts:].mean()), "nprobe_max": int(my_np[ts:].max()),

@@ -40,6 +40,17 @@ int amd_ivf_device_count(int* count);
 int amd_ivf_create(int d, size_t nlist, int metric, int device, amd_ivf_t** out);
 int amd_ivf_destroy(amd_ivf_t* h);
 
+/* A second search context over the same device-resident index: its own HIP stream, workspaces and resident
+ * queries; lists, centroids, centroid table and traces stay with (and are owned by) `h`.  The reference's
+ * search() / search_preassigned() are const and re-entrant over the index data (IndexIVF.h:189-207, and
+ * IndexShards(threaded=true) calls them from one thread per shard, IndexShards.cpp:261-311); a context is what a
+ * thread of the caller uses to keep its own batch in flight on the GPU while another thread's batch is in a
+ * latency-bound phase.  Valid on a clone: set_queries, search, search_preassigned, search_resident,
+ * search_adaptive(_x), stats, scan_arith, last_timing, ntotal, list_size, destroy; everything else must go through
+ * `h` and returns -2 here.  Build the index first: clones do not see later add() / set_*() calls until `h` has
+ * searched once, and `h` must outlive its clones. */
+int amd_ivf_clone(amd_ivf_t* h, amd_ivf_t** out);
+
 /* quantizer->add(nlist, centroids): IndexFlat::xb, row-major nlist x d  [IndexFlat.cpp:30-33] */
 int amd_ivf_set_centroids(amd_ivf_t* h, const float* centroids);
 

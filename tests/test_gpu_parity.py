@@ -290,3 +290,46 @@ def test_coarse_gemm_mode(capi, name):
     if case["d"] % 4 == 0:
         De, Ie = h.coarse(case["xq"][:5], case["nprobe"], mode=0)
         assert np.array_equal(bits(D1), bits(De)) and np.array_equal(I1, Ie)
+
+
+def test_clone_searches_concurrently(capi):
+    """amd_ivf_clone: two contexts over one index, a batch in flight on each from two threads; both must reproduce the
+    reference's adaptive-search goldens and the owner's fixed-nprobe result; mutators are refused on the clone"""
+    import threading
+    case, gold = load_case("auncel_sift_d32")
+    K, ts, ses = case["max_topk"], case["train_num"], case["test_num"]
+    h = make_index(capi, case, gold, gold["centroids"])
+    h.set_interdis(None)
+    h.set_tuner(K, traces_from_gold(gold), gold["arcos_list"])
+    c = h.clone()
+    D0, I0 = h.search(case["xq"], 10, 8)
+    out, errs = {}, []
+
+    def work(name, hh):
+        try:
+            hh.set_queries(case["xq"])
+            for _ in range(3):
+                req = np.full(ts + ses, case["require_acc"][0], dtype=np.float32)
+                my_np = np.zeros(ts + ses, dtype=np.uint64)
+                t_rec = np.zeros(ts + ses, dtype=np.float32)
+                D, I = hh.search_adaptive(ts, ses, int(case["topks"][0]), float(case["multipler"][0]), float(case["std_m"][0]),
+                                          req, my_np, t_rec, gt_D=gold["gtD"], profile=False)
+                out[name] = (D, I, my_np[ts:].copy(), hh.search(case["xq"], 10, 8))
+        except Exception as e:  # noqa: BLE001
+            errs.append((name, e))
+
+    th = [threading.Thread(target=work, args=(n, hh)) for n, hh in (("owner", h), ("clone", c))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for name in ("owner", "clone"):
+        D, I, my_np, (Df, If) = out[name]
+        assert np.array_equal(my_np, gold["my_nprobe_r0"]), name
+        assert np.array_equal(I, gold["I_r0"]) and np.array_equal(bits(D), bits(gold["D_r0"])), name
+        assert np.array_equal(If, I0) and np.array_equal(bits(Df), bits(D0)), name
+    with pytest.raises(capi.EngineError):
+        c.add(case["xb"][:4])
+    assert c.ntotal == h.ntotal
+    c.close()
