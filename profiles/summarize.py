@@ -33,15 +33,29 @@ def short(name):
     return name.split("amdivf::")[1].split("(")[0] if "amdivf::" in name else None
 
 
-def timed_rows(rows, steps, key_name):
-    """rows: dicts in dispatch order -> (rows of the timed steps, index of each step start)"""
+def is_sort(n):
+    return n.startswith("sort_rows_kernel") or n.startswith("sort_prefix_kernel")
+
+
+def timed_sequences(rows, j, key_name):
+    """rows: dicts in dispatch order -> dispatch sequences of the timed steps, one per host thread.
+    --in-flight 1: the main thread; the timed steps start at the steps-th-from-last coarse ranking.
+    --in-flight N: the timed steps are issued by N worker threads created for the timed region (the warm-up has its
+    own), i.e. the N thread ids that appear last; everything they dispatch belongs to timed steps."""
+    steps, nfl = j["steps"], j["config"].get("in_flight", 1)
     eng = [r for r in rows if short(r[key_name])]
-    marks = [i for i, r in enumerate(eng) if short(r[key_name]).startswith("sort_rows_kernel")]
-    # a step's coarse scan precedes its sort_rows dispatch by one engine dispatch (pack + scan): back up to the pack
+    if nfl > 1:
+        first = {}
+        for i, r in enumerate(eng):
+            first.setdefault(r["Thread_Id"], i)
+        workers = sorted(first, key=first.get)[-nfl:]
+        return [[r for r in eng if r["Thread_Id"] == t] for t in workers]
+    marks = [i for i, r in enumerate(eng) if is_sort(short(r[key_name]))]
+    # a step's coarse scan precedes its ranking dispatch by one engine dispatch (pack + scan): back up to the pack
     start = marks[-steps]
     while start > 0 and not short(eng[start][key_name]).startswith("pack_queries_kernel"):
         start -= 1
-    return eng[start:]
+    return [eng[start:]]
 
 
 def is_list_scan(seq, i, key_name):
@@ -53,7 +67,7 @@ def is_list_scan(seq, i, key_name):
         m = short(seq[j][key_name])
         if m.startswith("scan_tiles_kernel"):
             continue
-        return not m.startswith("sort_rows_kernel")
+        return not is_sort(m)
     return True
 
 
@@ -61,14 +75,14 @@ lines = []
 tj = bench_json(os.path.join(root, "trace.log"))
 steps = tj["steps"]
 tr = sorted(csv.DictReader(open(glob.glob(os.path.join(root, "trace", "*", "*_kernel_trace.csv"))[0])),
-            key=lambda r: int(r["Start_Timestamp"]))
-seq = timed_rows(tr, steps, "Kernel_Name")
+            key=lambda r: int(r["Dispatch_Id"]))
 agg = defaultdict(list)
-for i, r in enumerate(seq):
-    n = short(r["Kernel_Name"])
-    if n.startswith("scan_tiles_kernel"):
-        n += " [lists]" if is_list_scan(seq, i, "Kernel_Name") else " [coarse]"
-    agg[n].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+for seq in timed_sequences(tr, tj, "Kernel_Name"):
+    for i, r in enumerate(seq):
+        n = short(r["Kernel_Name"])
+        if n.startswith("scan_tiles_kernel"):
+            n += " [lists]" if is_list_scan(seq, i, "Kernel_Name") else " [coarse]"
+        agg[n].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
 lines.append(f"# {tag}: bench.py under rocprofv3 (MI355X), timed region = last {steps} steps\n")
 lines.append("## kernel trace (`rocprofv3 --kernel-trace --stats`)\n")
 lines.append("| kernel | calls | calls/step | total ms | ms/step | avg ms | max ms |")
@@ -79,7 +93,7 @@ scan_ms = sum(sum(v) for k, v in agg.items() if k.endswith("[lists]"))
 rf = tj["roofline"]
 nl = rf["launches_per_step"] * steps
 lines.append("")
-lines.append(f"list-scan launches (one per round, up to three tile shapes each, side by side on three streams): "
+lines.append(f"list-scan launches (one per round, up to four tile shapes each, side by side on four streams): "
              f"{nl:.0f}; summed kernel durations {scan_ms:.2f} ms = {scan_ms/nl:.4f} ms per launch if run back to back; "
              f"bench.py's HIP events around each launch: avg_launch_ms = {rf['avg_launch_ms']:.4f} "
              f"(shapes overlap, so the event span is <= the sum)")
@@ -97,23 +111,24 @@ for grp in ("fetch", "write", "sq", "misc"):
     # one row per (dispatch, counter): rebuild dispatch order
     disp = {}
     for r in rows:
-        d = disp.setdefault(int(r["Dispatch_Id"]), {"Kernel_Name": r["Kernel_Name"], "c": {}, "t": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})
+        d = disp.setdefault(int(r["Dispatch_Id"]), {"Kernel_Name": r["Kernel_Name"], "Thread_Id": r["Thread_Id"], "c": {},
+                                                    "t": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})
         d["c"][r["Counter_Name"]] = d["c"].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     order = [disp[k] for k in sorted(disp)]
-    seq = timed_rows(order, j["steps"], "Kernel_Name")
-    for i, r in enumerate(seq):
-        n = short(r["Kernel_Name"])
-        if n.startswith("scan_tiles_kernel"):
-            n = "scan_tiles_kernel [lists]" if is_list_scan(seq, i, "Kernel_Name") else "scan_tiles_kernel [coarse]"
-        e = pmc.setdefault(n, defaultdict(float))
-        for c, v in r["c"].items():
-            e[c] += v
-        e["_dispatches_" + grp] += 1
-        e["_ns_" + grp] += r["t"]
-        e["_steps_" + grp] = j["steps"]
-        if n.endswith("[lists]"):
-            e["_launches_" + grp] = j["roofline"]["launches_per_step"] * j["steps"]
-            e["_alg_bytes_per_launch"] = j["roofline"]["algorithmic_bytes_per_launch"]
+    for seq in timed_sequences(order, j, "Kernel_Name"):
+        for i, r in enumerate(seq):
+            n = short(r["Kernel_Name"])
+            if n.startswith("scan_tiles_kernel"):
+                n = "scan_tiles_kernel [lists]" if is_list_scan(seq, i, "Kernel_Name") else "scan_tiles_kernel [coarse]"
+            e = pmc.setdefault(n, defaultdict(float))
+            for c, v in r["c"].items():
+                e[c] += v
+            e["_dispatches_" + grp] += 1
+            e["_ns_" + grp] += r["t"]
+            e["_steps_" + grp] = j["steps"]
+            if n.endswith("[lists]"):
+                e["_launches_" + grp] = j["roofline"]["launches_per_step"] * j["steps"]
+                e["_alg_bytes_per_launch"] = j["roofline"]["algorithmic_bytes_per_launch"]
 lines.append("\n## PMC (separate passes: FETCH_SIZE | WRITE_SIZE | SQ_* | GRBM/LDS)\n")
 lines.append("| kernel | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM GB/step (reads x2 for the scan) | VALU insts | wave cycles: active / wait_inst / wait_any | LDS bank conflicts | clock GHz |")
 lines.append("|---|---|---|---|---|---|---|---|")
