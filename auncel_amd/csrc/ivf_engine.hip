@@ -399,6 +399,13 @@ static bool dbg_timing() {
 }
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// queries per full block of a list (ivf_kernels.h): 64 for the byte-code scan, 32 for the fp32 scans
+static uint32_t scan_qblock(bool bytes) {
+    static const int env = getenv("AUNCEL_AMD_QBLOCK") ? atoi(getenv("AUNCEL_AMD_QBLOCK")) : 0;
+    if (env == 32 || env == 64) return (uint32_t)env;
+    return bytes ? 64u : 32u;
+}
+
 static void print_replay_dbg(amd_ivf* h, size_t mb, hipStream_t s) {
     std::vector<unsigned long long> dbg(mb * 8);
     HIP_CHECK(hipMemcpyAsync(dbg.data(), h->w_misc.p, mb * 64, hipMemcpyDeviceToHost, s));
@@ -417,6 +424,7 @@ static void print_replay_dbg(amd_ivf* h, size_t mb, hipStream_t s) {
 void exec_round(amd_ivf* h, const RoundSpec& r) {
     const size_t m = r.slot.size();
     if (m == 0) return;
+    const uint32_t qblock = scan_qblock(r.bytes);
     const double t_enter = now_us();
     const size_t nlist = h->nlist;
     const std::vector<uint64_t>& off = ix(h)->h_list_off;
@@ -522,8 +530,12 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
             uint32_t c = lcount[l + 1] - lcount[l];
             if (!c) continue;
             const size_t sz = off[l + 1] - off[l];
-            const uint32_t full = c / SCAN_QBLOCK, rem = c % SCAN_QBLOCK;
-            n_qg[3] += (size_t)full * ((sz + SCAN_WAVE_VECS - 1) / SCAN_WAVE_VECS);
+            const uint32_t full = c / qblock, rem = c % qblock;
+            if (full) {
+                const uint32_t qg = scan_shape_of(qblock);
+                const size_t tv = scan_tile_vecs(qg);
+                n_qg[scan_qg_class(qg)] += (size_t)full * ((sz + tv - 1) / tv);
+            }
             if (rem) {
                 uint32_t qg = scan_shape_of(rem);
                 size_t tv = scan_tile_vecs(qg);
@@ -538,8 +550,8 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
             uint32_t c = lcount[l + 1] - lcount[l];
             if (!c) continue;
             const uint32_t sz = (uint32_t)(off[l + 1] - off[l]);
-            for (uint32_t qb = 0; qb < c; qb += SCAN_QBLOCK) {
-                const uint32_t nq_blk = std::min<uint32_t>(SCAN_QBLOCK, c - qb);
+            for (uint32_t qb = 0; qb < c; qb += qblock) {
+                const uint32_t nq_blk = std::min<uint32_t>(qblock, c - qb);
                 const uint32_t qg = scan_shape_of(nq_blk);
                 const uint32_t tv = scan_tile_vecs(qg);
                 size_t& ni = cur[scan_qg_class(qg)];
@@ -757,7 +769,7 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
     for (size_t c0 = 0; c0 < n; c0 += chunk) {
         const size_t m = std::min(chunk, n - c0);
         // pairs: every query of the chunk against the single "list" = centroid table
-        const uint32_t qg = scan_shape_of((uint32_t)std::min<size_t>(m, SCAN_QBLOCK));
+        const uint32_t qg = scan_shape_of((uint32_t)std::min<size_t>(m, scan_qblock(false)));
         const uint32_t tv = scan_tile_vecs(qg);
         const size_t nitems = ((m + qg * SCAN_RQ - 1) / (qg * SCAN_RQ)) * ((nlist + tv - 1) / tv);
         h->p_pair_query.ensure(m * 4);
@@ -959,7 +971,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     const size_t seg_cap = (size_t)2 << 20;
     size_t maxlist = 0;
     for (size_t l = 0; l < nlist; l++) maxlist = std::max<size_t>(maxlist, I->h_list_off[l + 1] - I->h_list_off[l]);
-    const size_t item_cap = (seg_cap / SCAN_QBLOCK + nlist) * ((maxlist + SCAN_WAVE_VECS - 1) / SCAN_WAVE_VECS) + nlist * 4 + 16;
+    const size_t item_cap = (seg_cap / 32 + nlist) * ((maxlist + SCAN_WAVE_VECS - 1) / SCAN_WAVE_VECS) + nlist * 4 + 16;
     // rows are padded to multiples of 64 floats (one mask word covers 64 candidates of one row)
     const size_t budget = std::max<size_t>(h->dist_budget_floats, I->h_list_off[nlist] + 64 * nlist + 64);
     static const bool no_thr = getenv("AUNCEL_AMD_NO_THRESHOLD") != nullptr;
@@ -1010,6 +1022,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     pa.need = h->w_pl_need.as<unsigned long long>();
     pa.pad = h->w_pl_pad.as<uint32_t>();
     pa.row_align = 64;
+    pa.qblock = scan_qblock(base.bytes);
     pa.seg_begin = h->w_seg_begin.as<uint32_t>();
     pa.dist_base = h->w_pl_dist_base.as<unsigned long long>();
     pa.qsel = h->w_qsel.as<uint32_t>();

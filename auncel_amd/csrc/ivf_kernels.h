@@ -63,8 +63,9 @@ void launch_pack_queries(const float* queries, const uint32_t* pair_query, const
 // fp32 rows of integers 0..255 -> byte rows and their squared norms (norms may be null); d % 4 == 0
 void launch_bytes_from_f32(const float* x, size_t n, int d, uint8_t* out, uint32_t* norms, hipStream_t s);
 inline __host__ __device__ int scan_qg_class(uint32_t qg) { return qg == 1 ? 0 : qg == 2 ? 1 : qg == 4 ? 2 : 3; }
-// workgroup shape for the last `r` queries of a list (full blocks hold SCAN_QBLOCK = 64 queries)
-constexpr uint32_t SCAN_QBLOCK = 8 * SCAN_RQ;
+// The queries of a list go into blocks of `qblock` (64: 8-wave tiles, the byte-code scan, which is short of HBM and
+// issue slots rather than of VALU; 32: 4-wave tiles, the fp32 scans); the last block takes the narrowest shape that holds it.
+constexpr uint32_t SCAN_QBLOCK = 8 * SCAN_RQ;  // the largest block
 inline __host__ __device__ uint32_t scan_shape_of(uint32_t r) { return r <= SCAN_RQ ? 1u : r <= 2 * SCAN_RQ ? 2u : r <= 4 * SCAN_RQ ? 4u : 8u; }
 inline __host__ __device__ uint32_t scan_tile_vecs(uint32_t qg) { return (qg >= 4 ? 1u : 4u / qg) * SCAN_WAVE_VECS; }
 
@@ -174,6 +175,7 @@ struct PlanArgs {
     unsigned long long* need;        // [nq] floats of distance rows (rows padded to multiples of `row_align`)
     uint32_t* pad;                   // [nq] padding inside need
     uint32_t row_align;              // 1 or 64
+    uint32_t qblock;                 // queries per full block of a list: 64 (8-wave tiles) or 32 (4-wave tiles)
     uint32_t* seg_begin;             // [nq]
     unsigned long long* dist_base;   // [nq]
     uint32_t* qsel;                  // active slots, compacted

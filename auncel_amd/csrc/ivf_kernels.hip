@@ -138,12 +138,19 @@ __global__ __launch_bounds__(QG == 8 ? 512 : 256) void scan_tiles_kernel(ScanArg
                 ya[v] = f2{yn[v].x, yn[v].y};
                 yb[v] = f2{yn[v].z, yn[v].w};
             }
-            {   // unconditional (the last step re-reads its own operands): a branch here costs a register copy per operand
+            if (BYTES) {
+                // unconditional (the last step re-reads its own operands): a branch here costs a register copy per
+                // operand, which the short byte-code steps feel and the fp32 steps do not
                 const int sn = s + 1 < nslot ? s + 1 : s;
 #pragma unroll
                 for (int v = 0; v < SCAN_RV; v++) yn[v] = *reinterpret_cast<const float4*>(myrow + v * 64 * LDS_ROW + sn * 4);
 #pragma unroll
                 for (int r = 0; r < SCAN_RQ; r++) qn[r] = qs[sn * SCAN_RQ + r];
+            } else if (s + 1 < nslot) {
+#pragma unroll
+                for (int v = 0; v < SCAN_RV; v++) yn[v] = *reinterpret_cast<const float4*>(myrow + v * 64 * LDS_ROW + (s + 1) * 4);
+#pragma unroll
+                for (int r = 0; r < SCAN_RQ; r++) qn[r] = qs[(s + 1) * SCAN_RQ + r];
             }
 #pragma unroll
             for (int r = 0; r < SCAN_RQ; r++) {

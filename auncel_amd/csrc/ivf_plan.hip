@@ -200,8 +200,12 @@ __global__ __launch_bounds__(1024) void plan_lists_kernel(PlanArgs a) {
                 const unsigned long long sz = a.list_off[l + 1] - a.list_off[l];
                 v[0] = c;
                 v[1] = (c + SCAN_RQ - 1) / SCAN_RQ;
-                const uint32_t full = c / SCAN_QBLOCK, rem = c % SCAN_QBLOCK;
-                v[5] = full * (uint32_t)((sz + SCAN_WAVE_VECS - 1) / SCAN_WAVE_VECS);
+                const uint32_t full = c / a.qblock, rem = c % a.qblock;
+                if (full) {
+                    const uint32_t qg = scan_shape_of(a.qblock);
+                    const uint32_t tv = scan_tile_vecs(qg);
+                    v[2 + scan_qg_class(qg)] = full * (uint32_t)((sz + tv - 1) / tv);
+                }
                 if (rem) {
                     const uint32_t qg = scan_shape_of(rem);
                     const uint32_t tv = scan_tile_vecs(qg);
@@ -282,8 +286,8 @@ __global__ __launch_bounds__(256) void plan_items_kernel(PlanArgs a) {
     const uint32_t sz = (uint32_t)(a.list_off[l + 1] - a.list_off[l]);
     const uint64_t vb0 = a.list_off[l];
     unsigned long long slots = 0, useful = 0;
-    for (uint32_t qb = 0; qb < c; qb += SCAN_QBLOCK) {
-        const uint32_t nq_blk = c - qb < SCAN_QBLOCK ? c - qb : SCAN_QBLOCK;
+    for (uint32_t qb = 0; qb < c; qb += a.qblock) {
+        const uint32_t nq_blk = c - qb < a.qblock ? c - qb : a.qblock;
         const uint32_t qg = scan_shape_of(nq_blk);
         const uint32_t tv = scan_tile_vecs(qg);
         uint32_t& ni = cur[scan_qg_class(qg)];
