@@ -77,6 +77,14 @@ def auncel_gauss_d64():
     return _auncel(xb, xq, 200, 100, [(10, 0.9, 1.7, 1.0), (100, 0.9, 1.2, 3.0)])
 
 
+def auncel_deep_ip_d64():
+    # inner-product metric through IVF_pro: acos of the similarities, fvec_inter_vecs_IP centroid table.  max_topk stays
+    # below the list sizes: a heap that still holds -FLT_MAX after the first probe makes the reference throw
+    # ("arcos's domain definition is [-1, 1]", IndexIVF.cpp:562-564)
+    xb, xq = synth.deep_like(100000, 300, d=64, nblobs=300, sigma=0.5, seed=23)
+    return _auncel(xb, xq, 200, 100, [(10, 0.9, 1.5, 1.0), (20, 0.9, 1.2, 2.0)], metric=METRIC_IP, K=20)
+
+
 def io_ragged():
     c = fixed_ragged()
     c["kind"] = "io"
@@ -91,7 +99,7 @@ def io_sift():
 
 
 CASES = {f.__name__: f for f in [io_ragged, io_sift, fixed_sift_l2, fixed_gauss_l2_d96, fixed_deep_ip_d96, fixed_gist_l2_d960,
-                                  fixed_odd_d30, fixed_ragged, fixed_dups, auncel_sift_d32, auncel_gauss_d64]}
+                                  fixed_odd_d30, fixed_ragged, fixed_dups, auncel_sift_d32, auncel_gauss_d64, auncel_deep_ip_d64]}
 
 
 def input_sha(case):
