@@ -24,6 +24,7 @@ SYMBOLS = [
     "amd_ivf_set_tuner", "amd_ivf_search_adaptive", "amd_ivf_search_adaptive_x", "amd_ivf_train_samples",
     "amd_ivf_train_samples_x", "amd_ivf_trace_sb", "amd_ivf_arcos_table", "amd_ivf_merge_tables",
     "amd_ivf_last_timing",
+    "amd_ivf_range_search_preassigned", "amd_ivf_range_search", "amd_ivf_range_results",
     "amd_ivf_scan_arith",
 ]
 
@@ -209,6 +210,24 @@ class Handle:
         I = np.empty((n, k), np.int64)
         _chk(lib().amd_ivf_search(self._h, C.c_size_t(n), _f(x), C.c_size_t(k), C.c_size_t(nprobe), coarse_mode, _f(D), _i(I)))
         return D, I
+
+    def range_search(self, x, radius, nprobe, keys=None, coarse_mode=0):
+        """IndexIVF::range_search(_preassigned) -> lims (n + 1), labels, distances"""
+        x = f32(x)
+        n = x.shape[0]
+        lims = np.zeros(n + 1, dtype=np.uintp)
+        lp = lims.ctypes.data_as(_szp)
+        if keys is None:
+            _chk(lib().amd_ivf_range_search(self._h, C.c_size_t(n), _f(x), C.c_float(radius), C.c_size_t(nprobe), coarse_mode, lp))
+        else:
+            keys = i64(keys)
+            assert keys.shape == (n, nprobe)
+            _chk(lib().amd_ivf_range_search_preassigned(self._h, C.c_size_t(n), _f(x), C.c_float(radius), C.c_size_t(nprobe), _i(keys), lp))
+        tot = int(lims[n])
+        labels = np.empty(max(tot, 1), np.int64)
+        dist = np.empty(max(tot, 1), np.float32)
+        _chk(lib().amd_ivf_range_results(self._h, _i(labels), _f(dist)))
+        return lims.astype(np.int64), labels[:tot], dist[:tot]
 
     def scan_codes(self, query, list_no, simi, idxi, store_pairs=False):
         query = f32(query)

@@ -38,6 +38,8 @@ struct Index {
     virtual void add(idx_t n, const float* x) = 0;
     virtual void add_with_ids(idx_t n, const float* x, const long* xids);
     virtual void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const = 0;
+    /// all vectors within `radius` of each query (Index.h:106-117); only the IVF classes implement it here
+    virtual void range_search(idx_t n, const float* x, float radius, RangeSearchResult* result) const;
     virtual void reset() = 0;
     /// nearest-neighbour labels only (Index.cpp:42-48)
     void assign(idx_t n, const float* x, idx_t* labels, idx_t k = 1);

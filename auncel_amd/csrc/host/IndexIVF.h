@@ -84,6 +84,11 @@ struct IndexIVF : Index, Level1Quantizer {
     /// Auncel overload: `offset` = absolute id of query 0 (IndexIVF.cpp:355-378)
     void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels, size_t offset) const;
 
+    /// IndexIVF.cpp:740-857
+    void range_search(idx_t n, const float* x, float radius, RangeSearchResult* result) const override;
+    void range_search_preassigned(idx_t nx, const float* x, float radius, const idx_t* keys, const float* coarse_dis,
+                                  RangeSearchResult* result) const;
+
     virtual InvertedListScanner* get_InvertedListScanner(bool store_pairs = false) const;
 
     size_t get_list_size(size_t list_no) const { return invlists->list_size(list_no); }

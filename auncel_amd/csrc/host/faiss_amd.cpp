@@ -15,6 +15,7 @@
 
 #include "../../../include/auncel_amd.h"
 #include "AutoTune.h"
+#include "AuxIndexStructures.h"
 #include "FaissAssert.h"
 #include "Heap.h"
 #include "IVF_pro.h"
@@ -489,6 +490,45 @@ void IndexIVF::search_preassigned(idx_t n, const float* x, idx_t k, const idx_t*
     sync_engine(false);
     AMD(amd_ivf_search_preassigned(gpu_, (size_t)n, x, (size_t)k, np, i64(keys), coarse_dis, distances, i64(labels),
                                    store_pairs ? 1 : 0, mc));
+    fold_stats();
+}
+
+// ---- range search (IndexIVF.cpp:740-857, AuxIndexStructures.cpp:26-60)
+RangeSearchResult::RangeSearchResult(idx_t nq, bool alloc_lims) : nq((size_t)nq), lims(nullptr), labels(nullptr), distances(nullptr), buffer_size(1024 * 256) {
+    if (alloc_lims) {
+        lims = new size_t[nq + 1];
+        memset(lims, 0, sizeof(*lims) * (nq + 1));
+    }
+}
+void RangeSearchResult::do_allocation() {
+    const size_t ofs = lims[nq];
+    labels = new idx_t[ofs];
+    distances = new float[ofs];
+}
+RangeSearchResult::~RangeSearchResult() {
+    delete[] labels;
+    delete[] distances;
+    delete[] lims;
+}
+
+void Index::range_search(idx_t, const float*, float, RangeSearchResult*) const {
+    FAISS_THROW_MSG("range search not implemented");
+}
+
+void IndexIVF::range_search_preassigned(idx_t nx, const float* x, float radius, const idx_t* keys, const float*,
+                                        RangeSearchResult* result) const {
+    sync_engine(false);
+    AMD(amd_ivf_range_search_preassigned(gpu_, (size_t)nx, x, radius, nprobe, i64(keys), result->lims));
+    result->do_allocation();
+    AMD(amd_ivf_range_results(gpu_, i64(result->labels), result->distances));
+    fold_stats();
+}
+
+void IndexIVF::range_search(idx_t nx, const float* x, float radius, RangeSearchResult* result) const {
+    sync_engine(false);
+    AMD(amd_ivf_range_search(gpu_, (size_t)nx, x, radius, nprobe, coarse_mode, result->lims));
+    result->do_allocation();
+    AMD(amd_ivf_range_results(gpu_, i64(result->labels), result->distances));
     fold_stats();
 }
 

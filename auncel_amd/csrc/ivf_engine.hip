@@ -200,6 +200,10 @@ struct amd_ivf {
     PinnedBuf p_group_p0, p_group_cnt, p_counters;
     DevBuf w_pl_cnt, w_pl_need, w_pl_dist_base, w_pl_lcount, w_pl_lstart, w_pl_gbase, w_pl_ibase, w_pl_fill, w_pl_counters;
     DevBuf w_x8, w_xnorm8;  // byte copy of the current queries + squared norms
+    DevBuf w_rcount, w_roff, w_rlab, w_rdis;  // range search: per-query counts / output offsets / results of a round
+    std::vector<size_t> r_lims;              // results of the last range search (amd_ivf_range_results)
+    std::vector<int64_t> r_labels;
+    std::vector<float> r_dist;
     DevBuf w_thr, w_mask, w_pl_pad;  // threshold mode of the device-planned rounds: heap tops, candidate bit masks
     DevBuf w_x, w_dist, w_items, w_pair_query, w_pair_out, w_seg_off, w_seg_list, w_seg_count, w_qsel;
     DevBuf w_heap_val, w_heap_ref, w_stage, w_nscan, w_done, w_pre_val, w_stoped, w_dtb, w_D, w_I;
@@ -384,6 +388,7 @@ struct RoundSpec {
     uint64_t id_offset = 0;
     const float* d_x = nullptr;  // device queries, row = slot
     bool bytes = false;          // scan the byte copies (ws->w_x8 / w_xnorm8 hold these queries)
+    bool range = false;          // range search: every round in threshold mode (thr = radius), entries collected instead of a replay
     TunerDev tuner{};
     TrainDev train{};
     const float* d_cdis = nullptr;     // device coarse arrays for set_online (row = slot)
@@ -1054,7 +1059,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     uint32_t* hc = h->p_counters.as<uint32_t>();
     // Round 0 starts from empty heaps (every distance is wanted: dense rows); later rounds run in threshold mode.
     for (size_t round = 0;; round++) {
-        const bool thr_mode = round > 0 && !no_thr;
+        const bool thr_mode = base.range || (round > 0 && !no_thr);
         const double t0 = now_us();
         HIP_CHECK(hipMemsetAsync(h->w_pl_lcount.p, 0, nlist * 4, s));
         HIP_CHECK(hipMemsetAsync(h->w_pl_counters.as<uint32_t>() + 6, 0, 4, s));
@@ -1108,6 +1113,62 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
                 launch_scan(sa, n_qg, s);
             }
             h->timer.end(t, s);
+        }
+        if (base.range) {
+            // ---- range search: count, lay out, fill (the scan left masks of the entries inside the radius)
+            RangeArgs ga{};
+            ga.nq = nact;
+            ga.nlist = (uint32_t)nlist;
+            ga.qsel = h->w_qsel.as<uint32_t>();
+            ga.seg_count = h->w_pl_cnt.as<uint32_t>();
+            ga.seg_begin = h->w_seg_begin.as<uint32_t>();
+            ga.seg_list = h->w_seg_list.as<int32_t>();
+            ga.seg_off = h->w_seg_off.as<uint64_t>();
+            ga.list_off = I->d_list_off.as<uint64_t>();
+            ga.ids = I->d_ids.as<int64_t>();
+            ga.dist = h->w_dist.as<float>();
+            ga.mask = h->w_mask.as<unsigned long long>();
+            h->w_rcount.ensure(n * 4);
+            h->w_roff.ensure(n * 8);
+            ga.counts = h->w_rcount.as<uint32_t>();
+            ga.out_off = h->w_roff.as<unsigned long long>();
+            ga.stage = h->w_stage.as<uint32_t>();
+            ga.done = h->w_done.as<uint32_t>();
+            ga.stats = h->w_stats.as<unsigned long long>();
+            ga.error = h->w_error.as<uint32_t>();
+            size_t t = h->timer.begin(CAT_SELECT, s);
+            launch_range_count(ga, s);
+            std::vector<uint32_t> cnts(n), probes(n);
+            HIP_CHECK(hipMemcpyAsync(cnts.data(), h->w_rcount.p, n * 4, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipMemcpyAsync(probes.data(), h->w_pl_cnt.p, n * 4, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            check_device_error(h);
+            // the queries of a round are a run of consecutive slots (everything unfinished before the budget cut), so
+            // appending the rounds keeps the results in query order
+            std::vector<unsigned long long> off(n, 0);
+            size_t tot = 0;
+            for (size_t i = 0; i < n; i++)
+                if (probes[i]) {
+                    off[i] = tot;
+                    tot += cnts[i];
+                    h->r_lims[i + 1] = cnts[i];
+                }
+            if (tot) {
+                h->w_rlab.ensure(tot * 8);
+                h->w_rdis.ensure(tot * 4);
+                ga.out_labels = h->w_rlab.as<int64_t>();
+                ga.out_dist = h->w_rdis.as<float>();
+                HIP_CHECK(hipMemcpyAsync(h->w_roff.p, off.data(), n * 8, hipMemcpyHostToDevice, s));
+                launch_range_fill(ga, s);
+                const size_t at = h->r_labels.size();
+                h->r_labels.resize(at + tot);
+                h->r_dist.resize(at + tot);
+                HIP_CHECK(hipMemcpyAsync(h->r_labels.data() + at, h->w_rlab.p, tot * 8, hipMemcpyDeviceToHost, s));
+                HIP_CHECK(hipMemcpyAsync(h->r_dist.data() + at, h->w_rdis.p, tot * 4, hipMemcpyDeviceToHost, s));
+            }
+            h->timer.end(t, s);
+            HIP_CHECK(hipStreamSynchronize(s));
+            continue;
         }
         ReplayArgs ra{};
         ra.metric = h->metric;
@@ -1505,6 +1566,93 @@ int amd_ivf_set_queries(amd_ivf_t* h, size_t n, const float* x) {
     h->n_resident = n;
     h->resident_range = IntRange();
     h->resident_range.add(x, n * (size_t)h->d);
+    API_END
+}
+
+// IndexIVF::range_search_preassigned (IndexIVF.cpp:759-857): device-planned rounds in threshold mode, radius as threshold
+static void range_core(amd_ivf* h, const float* d_x, size_t n, float radius, size_t nprobe, const int64_t* d_keys, const IntRange& qr,
+                       size_t* lims) {
+    upload_lists(h);
+    init_state(h, n, 1, false);
+    launch_fill_f32(h->w_thr.as<float>(), n, radius, h->stream);
+    h->r_lims.assign(n + 1, 0);
+    h->r_labels.clear();
+    h->r_dist.clear();
+    RoundSpec base;
+    base.range = true;
+    base.k = 1;
+    base.d_x = d_x;
+    base.d_ckeys = d_keys;
+    base.coarse_stride = (uint32_t)nprobe;
+    base.fused = h->allow_fused && ix(h)->db_range.fusable_with(qr);
+    base.bytes = byte_queries(h, ix(h), d_x, n, qr);
+    ix(h)->last_arith = base.bytes ? 2 : base.fused ? 1 : 0;
+    run_rounds_device(h, base, n, nprobe, nprobe, nullptr);
+    for (size_t i = 0; i < n; i++) h->r_lims[i + 1] += h->r_lims[i];
+    memcpy(lims, h->r_lims.data(), (n + 1) * sizeof(size_t));
+    fold_stats(h, n);
+}
+
+int amd_ivf_range_search_preassigned(amd_ivf_t* h, size_t n, const float* x, float radius, size_t nprobe, const int64_t* keys,
+                                     size_t* lims) {
+    API_BEGIN
+    use_device(h);
+    if (nprobe == 0) throw EngineError("nprobe must be positive");
+    WallClock wc(h->stream);
+    h->w_x.ensure(std::max<size_t>(n, 1) * h->dpad * sizeof(float));
+    upload_rows(h, h->w_x.as<float>(), x, n);
+    IntRange qr;
+    qr.add(x, n * (size_t)h->d);
+    h->w_ckeys.ensure(std::max<size_t>(n, 1) * nprobe * 8);
+    if (n) HIP_CHECK(hipMemcpyAsync(h->w_ckeys.p, keys, n * nprobe * 8, hipMemcpyHostToDevice, h->stream));
+    if (n == 0) {
+        h->r_lims.assign(1, 0);
+        h->r_labels.clear();
+        h->r_dist.clear();
+        lims[0] = 0;
+        return 0;
+    }
+    h->scan_bytes = 0;
+    h->scan_slots = h->scan_useful = 0;
+    range_core(h, h->w_x.as<float>(), n, radius, nprobe, h->w_ckeys.as<int64_t>(), qr, lims);
+    finish_timing(h, wc.stop());
+    API_END
+}
+
+int amd_ivf_range_search(amd_ivf_t* h, size_t n, const float* x, float radius, size_t nprobe, int coarse_mode, size_t* lims) {
+    API_BEGIN
+    use_device(h);
+    if (nprobe == 0) throw EngineError("nprobe must be positive");
+    WallClock wc(h->stream);
+    if (n == 0) {
+        h->r_lims.assign(1, 0);
+        h->r_labels.clear();
+        h->r_dist.clear();
+        lims[0] = 0;
+        return 0;
+    }
+    h->w_x.ensure(n * h->dpad * sizeof(float));
+    upload_rows(h, h->w_x.as<float>(), x, n);
+    IntRange qr;
+    qr.add(x, n * (size_t)h->d);
+    upload_lists(h);
+    h->w_cdis.ensure(n * nprobe * 4);
+    h->w_ckeys.ensure(n * nprobe * 8);
+    coarse_dev(h, h->w_x.as<float>(), n, nprobe, coarse_mode, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>(),
+               h->allow_fused && ix(h)->centroid_range.fusable_with(qr));
+    h->scan_bytes = 0;
+    h->scan_slots = h->scan_useful = 0;
+    range_core(h, h->w_x.as<float>(), n, radius, nprobe, h->w_ckeys.as<int64_t>(), qr, lims);
+    finish_timing(h, wc.stop());
+    API_END
+}
+
+int amd_ivf_range_results(amd_ivf_t* h, int64_t* labels, float* distances) {
+    API_BEGIN
+    if (!h->r_labels.empty()) {
+        memcpy(labels, h->r_labels.data(), h->r_labels.size() * sizeof(int64_t));
+        memcpy(distances, h->r_dist.data(), h->r_dist.size() * sizeof(float));
+    }
     API_END
 }
 

@@ -146,6 +146,34 @@ struct ReplayArgs {
 
 void launch_replay(const ReplayArgs& a, hipStream_t s);
 
+// ---------------------------------------------------------------------------- range search
+// IndexIVF::range_search_preassigned: the scan runs in threshold mode with the radius as every query's threshold,
+// so the masks mark exactly the entries scan_codes_range would add.  One wave per query counts its entries, then
+// (offsets known) writes (distance, label) in the reference's order: probes in order, list entries in order.
+struct RangeArgs {
+    uint32_t nq;                 // active queries of this round
+    uint32_t nlist;
+    const uint32_t* qsel;        // [nq] query slot of each launch position
+    const uint32_t* seg_count;   // by slot: probes this round
+    const uint32_t* seg_begin;   // by slot: first entry in seg_list / seg_off
+    const int32_t* seg_list;
+    const uint64_t* seg_off;
+    const uint64_t* list_off;
+    const int64_t* ids;
+    const float* dist;
+    const unsigned long long* mask;
+    uint32_t* counts;                     // by slot: entries found (count pass)
+    const unsigned long long* out_off;    // by slot: first output position (fill pass)
+    int64_t* out_labels;
+    float* out_dist;
+    uint32_t* stage;
+    uint32_t* done;
+    unsigned long long* stats;   // {nlist, ndis, -}
+    uint32_t* error;
+};
+void launch_range_count(const RangeArgs& a, hipStream_t s);
+void launch_range_fill(const RangeArgs& a, hipStream_t s);
+
 // error_pro::set_online for nq queries: dtb[q][nlist/8+20] from the full coarse ranking (before round 0)
 void launch_set_online(int metric, uint32_t nlist, uint32_t nq, const float* coarse_dis, const int64_t* coarse_keys,
                        uint32_t coarse_stride, const float* interdis, const float* arcos, float* dtb, uint32_t* error, hipStream_t s);

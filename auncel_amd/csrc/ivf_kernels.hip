@@ -1207,6 +1207,80 @@ void launch_replay(const ReplayArgs& a, hipStream_t s) {
 }
 
 // =============================================================================================
+// range search: count / fill over the threshold masks (RangeArgs in ivf_kernels.h)
+// =============================================================================================
+template <bool FILL>
+__global__ __launch_bounds__(256) void range_collect_kernel(RangeArgs a) {
+    const uint32_t li = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (li >= a.nq) return;
+    const uint32_t qi = a.qsel[li];
+    const uint32_t cnt = a.seg_count[qi];
+    const size_t seg0 = a.seg_begin[qi];
+    unsigned long long pos = FILL ? a.out_off[qi] : 0ull;  // wave-uniform
+    unsigned long long nlistv = 0, ndis = 0;
+    uint32_t total = 0, err = 0;
+    for (uint32_t p = 0; p < cnt; p++) {
+        const int key = a.seg_list[seg0 + p];
+        if (key < 0) continue;
+        if ((uint32_t)key >= a.nlist) {
+            err = ERR_INVALID_KEY;
+            break;
+        }
+        const unsigned long long lb = a.list_off[key];
+        const uint32_t n = (uint32_t)(a.list_off[key + 1] - lb);
+        if (n == 0) continue;
+        nlistv++;
+        ndis += n;
+        const unsigned long long roff = a.seg_off[seg0 + p];
+        const unsigned long long* mrow = a.mask + (roff >> 6);
+        const uint32_t nchunk = (n + 63) >> 6;
+        for (uint32_t w0 = 0; w0 < nchunk; w0 += 64) {
+            const unsigned long long word = w0 + lane < nchunk ? mrow[w0 + lane] : 0ull;
+            const uint32_t pc = (uint32_t)__builtin_popcountll(word);
+            if (!FILL) {
+                total += pc;
+                continue;
+            }
+            uint32_t incl = pc;  // inclusive prefix over the lanes: where this lane's chunk starts in the output
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
+                if (lane >= off) incl += o;
+            }
+            unsigned long long o = pos + incl - pc;
+            unsigned long long bits = word;
+            while (bits) {
+                const int b = __builtin_ctzll(bits);
+                bits &= bits - 1;
+                const uint32_t cand = (w0 + lane) * 64 + b;
+                a.out_dist[o] = a.dist[roff + cand];
+                a.out_labels[o] = a.ids[lb + cand];
+                o++;
+            }
+            pos += (uint32_t)__shfl((int)incl, 63);
+        }
+    }
+    if (!FILL) {
+        for (int off = 32; off; off >>= 1) total += __shfl_xor(total, off);
+        if (lane == 0) {
+            a.counts[qi] = total;
+            a.stage[qi] += cnt;
+            a.done[qi] = 1;
+            if (nlistv) atomicAdd(&a.stats[0], nlistv);
+            if (ndis) atomicAdd(&a.stats[1], ndis);
+            if (err) atomicMax(a.error, err);
+        }
+    }
+}
+
+void launch_range_count(const RangeArgs& a, hipStream_t s) {
+    if (a.nq) hipLaunchKernelGGL(range_collect_kernel<false>, dim3((a.nq + 3) / 4), dim3(256), 0, s, a);
+}
+void launch_range_fill(const RangeArgs& a, hipStream_t s) {
+    if (a.nq) hipLaunchKernelGGL(range_collect_kernel<true>, dim3((a.nq + 3) / 4), dim3(256), 0, s, a);
+}
+
+// =============================================================================================
 // coarse quantiser, GEMM formulation (the reference's knn_L2sqr_blas / knn_inner_product_blas,
 // utils.cpp:494-608): dis = |x|^2 + |y|^2 - 2 x.y clamped at 0, x.y on the fp32 matrix cores
 // =============================================================================================

@@ -157,6 +157,17 @@ int amd_ivf_trace_sb(const float* raw_xy, size_t n, size_t bs, float* out_x, flo
 int amd_ivf_merge_tables(int metric, size_t n, size_t k, size_t nshard, const float* all_D, const int64_t* all_I,
                          float* D, int64_t* I);
 
+/* ---- range search ------------------------------------------------------------------------------
+ * IndexIVF::range_search / range_search_preassigned (IndexIVF.cpp:740-857) with IVFFlatScanner::scan_codes_range
+ * (IndexIVFFlat.cpp:139-155): all stored vectors of the probed lists with dis < radius (L2) / dis > radius (IP), per
+ * query in the reference's order (probes in order, list entries in order), unsorted.  RangeSearchResult is filled in
+ * two steps as in the reference (lims first, then do_allocation): the search call writes lims (n + 1 entries), the
+ * caller allocates lims[n] labels / distances and fetches them with amd_ivf_range_results from the same handle. */
+int amd_ivf_range_search_preassigned(amd_ivf_t* h, size_t n, const float* x, float radius, size_t nprobe, const int64_t* keys,
+                                     size_t* lims);
+int amd_ivf_range_search(amd_ivf_t* h, size_t n, const float* x, float radius, size_t nprobe, int coarse_mode, size_t* lims);
+int amd_ivf_range_results(amd_ivf_t* h, int64_t* labels, float* distances);
+
 /* ---- measurement hooks (bench.py): time of the kernels of the last search call, from HIP events
  *      recorded on the engine's own stream: {coarse_ms, scan_ms, select_ms, total_ms, scan_launches,
  *      bytes of the distances the scan tiles computed (x d x 4), fraction of the computed (query, vector)

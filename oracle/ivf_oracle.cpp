@@ -599,6 +599,47 @@ size_t orc_scan_codes(int metric, size_t d, const float* query, size_t list_size
     return nheap;
 }
 
+// IndexIVF.cpp:759-857 (parallel_mode 0: a query's results are its probes' in order; the per-thread partial results
+// are laid out query by query by RangeSearchPartialResult::finalize) + IndexIVFFlat.cpp:139-155
+int orc_range_search_preassigned(const orc_index_t* ix, size_t n, const float* x, float radius, size_t nprobe,
+                                 const int64_t* keys, size_t* lims, int64_t* labels, float* distances, size_t* stats) {
+    const size_t d = ix->d;
+    size_t pos = 0, nlistv = 0, ndis = 0;
+    for (size_t i = 0; i < n; i++) {
+        lims[i] = pos;
+        const float* xi = x + i * d;
+        for (size_t ik = 0; ik < nprobe; ik++) {
+            const int64_t key = keys[i * nprobe + ik];
+            if (key < 0) continue;
+            if ((size_t)key >= ix->nlist) {
+                g_err = "Invalid key=" + std::to_string(key) + " nlist=" + std::to_string(ix->nlist);
+                return -1;
+            }
+            const size_t b = ix->list_off[key], e = ix->list_off[key + 1];
+            if (e == b) continue;
+            nlistv++;
+            ndis += e - b;
+            for (size_t j = b; j < e; j++) {
+                const float dis = ix->metric == ORC_METRIC_IP ? inner(xi, ix->codes + j * d, d) : l2sqr(xi, ix->codes + j * d, d);
+                const bool in = ix->metric == ORC_METRIC_IP ? radius < dis : radius > dis;  // C::cmp(radius, dis)
+                if (in) {
+                    if (labels) {
+                        labels[pos] = ix->ids[j];
+                        distances[pos] = dis;
+                    }
+                    pos++;
+                }
+            }
+        }
+    }
+    lims[n] = pos;
+    if (stats && labels) {
+        stats[0] += nlistv;
+        stats[1] += ndis;
+    }
+    return 0;
+}
+
 int orc_search_preassigned(const orc_index_t* ix, size_t n, const float* x, size_t k, size_t nprobe,
                            const int64_t* keys, const float* coarse_dis, float* D, int64_t* I, int store_pairs,
                            size_t max_codes, orc_tuner_t* tuner, size_t offset, size_t* stats, int nthreads) {

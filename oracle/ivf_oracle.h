@@ -71,6 +71,13 @@ int orc_search_preassigned(const orc_index_t* ix, size_t n, const float* x, size
                            const int64_t* keys, const float* coarse_dis, float* D, int64_t* I, int store_pairs,
                            size_t max_codes, orc_tuner_t* tuner, size_t offset, size_t* stats, int nthreads);
 
+/* IndexIVF::range_search_preassigned (IndexIVF.cpp:759-857) with IVFFlatScanner::scan_codes_range
+ * (IndexIVFFlat.cpp:139-155): per query, probes in order, list entries in order, every entry with
+ * radius > dis (L2) / radius < dis (IP).  Two calls: with labels == NULL only lims (n + 1) is filled;
+ * then with buffers of lims[n] entries.  stats: {nlist, ndis} accumulated.  Returns 0 or -1 (invalid key). */
+int orc_range_search_preassigned(const orc_index_t* ix, size_t n, const float* x, float radius, size_t nprobe,
+                                 const int64_t* keys, size_t* lims, int64_t* labels, float* distances, size_t* stats);
+
 /* training branch of search_preassigned: raw (sum_angle, kscaling) samples.
  * raw_traces: ntraces arrays of train_num*(max_topk/4) (x,y) pairs, pre-filled with (-1,-1) */
 int orc_train_samples(const orc_index_t* ix, size_t n, const float* x, size_t max_topk, size_t nprobe,

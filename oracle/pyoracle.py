@@ -173,6 +173,25 @@ def search_preassigned(lists, x, k, keys, coarse_dis, store_pairs=False, max_cod
     return D, I, stats.astype(np.int64)
 
 
+def range_search_preassigned(lists, x, radius, keys):
+    """-> lims (n + 1), labels, distances, stats {nlist, ndis}"""
+    x, keys = f32(x), i64(keys)
+    n, nprobe = keys.shape
+    lims = np.zeros(n + 1, dtype=np.uintp)
+    stats = np.zeros(2, dtype=np.uintp)
+    L = lib()
+    L.orc_range_search_preassigned.restype = C.c_int
+    args = (C.byref(lists.struct), C.c_size_t(n), _f(x), C.c_float(radius), C.c_size_t(nprobe), _i(keys), _s(lims))
+    if L.orc_range_search_preassigned(*args, None, None, _s(stats)):
+        raise RuntimeError(L.orc_last_error().decode())
+    tot = int(lims[n])
+    labels = np.empty(max(tot, 1), dtype=np.int64)
+    dist = np.empty(max(tot, 1), dtype=np.float32)
+    if L.orc_range_search_preassigned(*args, _i(labels), _f(dist), _s(stats)):
+        raise RuntimeError(L.orc_last_error().decode())
+    return lims.astype(np.int64), labels[:tot], dist[:tot], stats.astype(np.int64)
+
+
 def train_samples(lists, x, max_topk, keys, coarse_dis, interdis_cem, arcos, gt_D, offset, train_num, raw):
     """raw: list of (train_num*(max_topk//4), 2) float32 arrays pre-filled with -1, updated in place"""
     x, keys, coarse_dis = f32(x), i64(keys), f32(coarse_dis)

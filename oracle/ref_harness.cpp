@@ -26,6 +26,7 @@
 #include <memory>
 
 #include "Heap.h"
+#include "AuxIndexStructures.h"
 #include "IVF_pro.h"
 #include "IndexFlat.h"
 #include "IndexIVF.h"
@@ -142,6 +143,25 @@ static int run_fixed(const tb::Bundle& in, tb::Bundle& out) {
         out.put_i64("scan_heap_I", {ns, k}, to_i64(HI).data());
         out.put_f32("scan_dist_to_code", {ns, nprobe}, dtc.data());
         out.put_i64("scan_nup", {ns, nprobe}, nup.data());
+    }
+
+    if (in.has("radius")) {  // IndexIVF::range_search_preassigned (IndexIVF.cpp:759-857) on the same coarse ranking
+        const float radius = in.get("radius").as<float>()[0];
+        RangeSearchResult res(nq);
+        indexIVF_stats.reset();
+        index.range_search_preassigned(nq, xq.as<float>(), radius, ck_sse.data(), cd_sse.data(), &res);
+        std::vector<int64_t> lims(nq + 1);
+        for (size_t i = 0; i <= nq; i++) lims[i] = (int64_t)res.lims[i];
+        const size_t tot = res.lims[nq];
+        out.put_i64("range_lims", {nq + 1}, lims.data());
+        std::vector<idx_t> lab(res.labels, res.labels + tot);
+        std::vector<int64_t> lab64 = to_i64(lab);
+        int64_t dummy_l = 0;
+        float dummy_d = 0.f;
+        out.put_i64("range_labels", {tot}, tot ? lab64.data() : &dummy_l);
+        out.put_f32("range_distances", {tot}, tot ? res.distances : &dummy_d);
+        int64_t st[2] = {(int64_t)indexIVF_stats.nlist, (int64_t)indexIVF_stats.ndis};
+        out.put_i64("range_stats", {2}, st);
     }
 
     size_t nshard = in.scalar_or<size_t>("nshard", 0);

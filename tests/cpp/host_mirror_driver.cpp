@@ -8,6 +8,7 @@
 #include <memory>
 
 #include "../../auncel_amd/csrc/host/AutoTune.h"
+#include "../../auncel_amd/csrc/host/AuxIndexStructures.h"
 #include "../../auncel_amd/csrc/host/FaissException.h"
 #include "../../auncel_amd/csrc/host/Heap.h"
 #include "../../auncel_amd/csrc/host/IndexFlat.h"
@@ -89,6 +90,23 @@ static int run_fixed(const tb::Bundle& in) {
             if (mt == METRIC_L2) maxheap_reorder(k, simi.data(), idxi.data()); else minheap_reorder(k, simi.data(), idxi.data());
             expect(same_i(idxi.data(), Iref + i * k, k), "scanner ids == search ids, query " + std::to_string(i));
         }
+    }
+
+    if (in.has("range_lims") && d % 4 == 0) {  // IndexIVF::range_search through the class mirror (RangeSearchResult as in the reference)
+        const float radius = in.get("radius").as<float>()[0];
+        RangeSearchResult res(nq);
+        indexIVF_stats.reset();
+        index->range_search(nq, xq.as<float>(), radius, &res);
+        const int64_t* gl = in.get("range_lims").as<int64_t>();
+        bool lims_ok = true;
+        for (size_t i = 0; i <= nq; i++) lims_ok &= (int64_t)res.lims[i] == gl[i];
+        expect(lims_ok, "range_search lims");
+        if (lims_ok) {
+            expect(same_i(res.labels, in.get("range_labels").as<int64_t>(), res.lims[nq]), "range_search labels");
+            expect(same_f(res.distances, in.get("range_distances").as<float>(), res.lims[nq]), "range_search distances");
+        }
+        const int64_t* st = in.get("range_stats").as<int64_t>();
+        expect(indexIVF_stats.nlist == (size_t)st[0] && indexIVF_stats.ndis == (size_t)st[1], "range_search stats");
     }
 
     size_t nshard = in.scalar_or<size_t>("nshard", 0);

@@ -8,11 +8,20 @@ from auncel_amd import synth
 METRIC_IP, METRIC_L2 = 0, 1  # reference MetricType values (Auncel/Index.h:49-52)
 
 
+def _radius(xb, xq, metric, frac=0.01):
+    """a range-search radius that keeps about `frac` of the (query, vector) pairs: fp32 value taken from a sample"""
+    a, b = xq[:16].astype(np.float64), xb[:4000].astype(np.float64)
+    if metric == METRIC_L2:
+        dd = (a * a).sum(1)[:, None] + (b * b).sum(1)[None, :] - 2.0 * a @ b.T
+        return np.array([np.quantile(dd, frac)], dtype=np.float32)
+    return np.array([np.quantile(a @ b.T, 1.0 - frac)], dtype=np.float32)
+
+
 def _fixed(xb, xq, nlist, nprobe, ks, metric=METRIC_L2, nshard=0, max_codes=0, cseed=99):
     cen = synth.sample_centroids(xb, nlist, seed=cseed)
     return dict(kind="fixed", d=xb.shape[1], nlist=nlist, nprobe=nprobe, metric=metric,
                 centroids=cen, xb=xb, xq=xq, ks=np.array(ks, dtype=np.int64), nshard=nshard,
-                max_codes=max_codes)
+                max_codes=max_codes, radius=_radius(xb, xq, metric))
 
 
 def fixed_sift_l2():

@@ -137,6 +137,33 @@ def test_shards_by_list_id(capi, name):
         assert np.array_equal(bits(D), bits(gold[f"D_shards_k{k}"]))
 
 
+@pytest.mark.parametrize("name", FIXED)
+def test_range_search(capi, name):
+    """IndexIVF::range_search_preassigned: lims, labels and distances in the reference's order, bit for bit"""
+    case, gold = load_case(name)
+    h = make_index(capi, case, gold)
+    radius = float(case["radius"][0])
+    h.stats(reset=True)
+    lims, labels, dist = h.range_search(case["xq"], radius, case["nprobe"], keys=gold["coarse_keys_sse"])
+    assert np.array_equal(lims, gold["range_lims"])
+    assert np.array_equal(labels, gold["range_labels"][:lims[-1]])
+    assert np.array_equal(bits(dist), bits(gold["range_distances"][:lims[-1]]))
+    st = h.stats()
+    assert [st["nlist"], st["ndis"]] == list(gold["range_stats"]) and st["nq"] == case["xq"].shape[0]
+    if case["d"] % 4 == 0:  # own coarse ranking (exact mode) gives the same keys
+        lims2, labels2, dist2 = h.range_search(case["xq"], radius, case["nprobe"])
+        assert np.array_equal(lims2, lims) and np.array_equal(labels2, labels) and np.array_equal(bits(dist2), bits(dist))
+    # nothing inside the radius / everything inside it
+    none = -1.0 if case["metric"] == 1 else 3.0e38
+    lims0, labels0, _ = h.range_search(case["xq"], none, case["nprobe"], keys=gold["coarse_keys_sse"])
+    assert lims0[-1] == 0 and labels0.size == 0
+    every = 3.0e38 if case["metric"] == 1 else -3.0e38
+    limsa, _, _ = h.range_search(case["xq"][:4], every, case["nprobe"], keys=gold["coarse_keys_sse"][:4])
+    sizes = np.array([h.list_size(l) for l in range(case["nlist"])])
+    k4 = gold["coarse_keys_sse"][:4]
+    assert np.array_equal(np.diff(limsa), np.where(k4 >= 0, sizes[np.clip(k4, 0, None)], 0).sum(1))
+
+
 def test_invalid_key_is_an_engine_error(capi):
     case, gold = load_case("fixed_ragged")
     h = make_index(capi, case, gold)

@@ -49,6 +49,18 @@ def _ties_only(D, I, Iref):
 
 
 @pytest.mark.parametrize("name", FIXED)
+def test_range_search_preassigned(oracle, name):
+    """IndexIVF::range_search_preassigned: lims, labels and distances in the reference's order"""
+    case, gold = load_case(name)
+    lists = _lists(oracle, case, gold)
+    lims, labels, dist, stats = oracle.range_search_preassigned(lists, case["xq"], float(case["radius"][0]), gold["coarse_keys_sse"])
+    assert np.array_equal(lims, gold["range_lims"])
+    assert np.array_equal(labels, gold["range_labels"][:lims[-1]])
+    assert np.array_equal(dist.view(np.uint32), gold["range_distances"][:lims[-1]].view(np.uint32))
+    assert list(stats) == list(gold["range_stats"])
+
+
+@pytest.mark.parametrize("name", FIXED)
 def test_search_preassigned(oracle, name):
     case, gold = load_case(name)
     lists = _lists(oracle, case, gold)
