@@ -388,6 +388,7 @@ struct RoundSpec {
     uint64_t id_offset = 0;
     const float* d_x = nullptr;  // device queries, row = slot
     bool bytes = false;          // scan the byte copies (ws->w_x8 / w_xnorm8 hold these queries)
+    bool fixed_two = false;      // fixed nprobe: after round 0 one more round takes all remaining probes (threshold mode)
     bool range = false;          // range search: every round in threshold mode (thr = radius), entries collected instead of a replay
     TunerDev tuner{};
     TrainDev train{};
@@ -890,6 +891,39 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
 }
 
 // ------------------------------------------------------------------------------------ searches
+void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first_round, size_t total_nprobe,
+                       const unsigned long long* d_np_abs);
+
+// Fixed nprobe, planned on the device from keys that are already there (n x nprobe).  With a large heap the probes
+// are split in two rounds: the first few fill the heap, the rest run in threshold mode (the scan stores and the
+// selection reads only what can still enter it).  A small heap settles within a list or two and one dense round is
+// cheaper than a second pass over the lists.
+void search_fixed_device(amd_ivf* h, const float* d_x, size_t n, size_t k, size_t nprobe, const int64_t* d_keys, float* D,
+                         int64_t* I, int store_pairs, size_t max_codes, const IntRange& qr) {
+    upload_lists(h);
+    init_state(h, n, k, false);
+    RoundSpec base;
+    base.k = (int)k;
+    base.store_pairs = store_pairs;
+    base.max_codes = max_codes;
+    base.d_x = d_x;
+    base.d_ckeys = d_keys;
+    base.coarse_stride = (uint32_t)nprobe;
+    base.fused = h->allow_fused && ix(h)->db_range.fusable_with(qr);
+    base.bytes = byte_queries(h, ix(h), d_x, n, qr);
+    ix(h)->last_arith = base.bytes ? 2 : base.fused ? 1 : 0;
+    static const int two_env = getenv("AUNCEL_AMD_FIXED_ROUNDS") ? atoi(getenv("AUNCEL_AMD_FIXED_ROUNDS")) : 0;
+    const bool two = two_env ? two_env == 2 : (k >= 32 && nprobe >= 8);
+    base.fixed_two = two;
+    const size_t first = two ? std::max<size_t>(1, nprobe / 8) : nprobe;
+    run_rounds_device(h, base, n, first, nprobe, nullptr);
+    check_device_error(h);
+    HIP_CHECK(hipMemcpyAsync(D, h->w_D.p, n * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipMemcpyAsync(I, h->w_I.p, n * k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    fold_stats(h, n);
+}
+
 void search_fixed_core(amd_ivf* h, const float* d_x, size_t n, size_t k, size_t nprobe, const int64_t* keys, float* D,
                        int64_t* I, int store_pairs, size_t max_codes, const IntRange& qr) {
     upload_lists(h);
@@ -936,6 +970,11 @@ void search_full(amd_ivf* h, const float* d_x, size_t n, size_t k, size_t nprobe
     h->w_ckeys.ensure(n * nprobe * 8);
     coarse_dev(h, d_x, n, nprobe, coarse_mode, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>(),
                h->allow_fused && ix(h)->centroid_range.fusable_with(qr));
+    static const bool host_plan = getenv("AUNCEL_AMD_HOST_PLAN") != nullptr;
+    if (!host_plan) {
+        search_fixed_device(h, d_x, n, k, nprobe, h->w_ckeys.as<int64_t>(), D, I, 0, 0, qr);
+        return;
+    }
     std::vector<int64_t> keys(n * nprobe);
     HIP_CHECK(hipMemcpyAsync(keys.data(), h->w_ckeys.p, n * nprobe * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -1190,6 +1229,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         ra.list_off = I->d_list_off.as<uint64_t>();
         ra.ids = I->d_ids.as<int64_t>();
         ra.store_pairs = base.store_pairs;
+        ra.max_codes = base.max_codes;
         ra.heap_val = h->w_heap_val.as<float>();
         ra.heap_ref = h->w_heap_ref.as<int64_t>();
         ra.stage = h->w_stage.as<uint32_t>();
@@ -1226,7 +1266,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         if (dbg_timing())
             fprintf(stderr, "[round/dev] active %u pairs %u groups %u tiles %zu: plan+readback %.0f us, launches %.0f us\n", nact, npairs, ngroups,
                     nitems, t1 - t0, now_us() - t1);
-        round_len = std::min<size_t>(round_len * 2, 64);
+        round_len = base.fixed_two ? total_nprobe : std::min<size_t>(round_len * 2, 64);
     }
     check_device_error(h);
     h->scan_bytes += *reinterpret_cast<double*>(hc + 16);
@@ -1536,7 +1576,14 @@ int amd_ivf_search_preassigned(amd_ivf_t* h, size_t n, const float* x, size_t k,
     upload_rows(h, h->w_x.as<float>(), x, n);
     IntRange qr;
     qr.add(x, n * (size_t)h->d);
-    search_fixed_core(h, h->w_x.as<float>(), n, k, nprobe, keys, D, I, store_pairs, max_codes, qr);
+    static const bool host_plan = getenv("AUNCEL_AMD_HOST_PLAN") != nullptr;
+    if (host_plan) {
+        search_fixed_core(h, h->w_x.as<float>(), n, k, nprobe, keys, D, I, store_pairs, max_codes, qr);
+    } else {
+        h->w_ckeys.ensure(n * nprobe * 8);
+        HIP_CHECK(hipMemcpyAsync(h->w_ckeys.p, keys, n * nprobe * 8, hipMemcpyHostToDevice, h->stream));
+        search_fixed_device(h, h->w_x.as<float>(), n, k, nprobe, h->w_ckeys.as<int64_t>(), D, I, store_pairs, max_codes, qr);
+    }
     finish_timing(h, wc.stop());
     API_END
 }
