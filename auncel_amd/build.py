@@ -20,13 +20,18 @@ def needs_build():
 
 
 def build(force=False):
-    if not force and not needs_build():
+    extra = os.environ.get("AUNCEL_AMD_CXXFLAGS", "").split()
+    stamp = os.path.join(LIBDIR, "flags.txt")  # a library built with other flags (experiments) is rebuilt
+    want = " ".join(FLAGS + extra)
+    same_flags = os.path.exists(stamp) and open(stamp).read() == want
+    if not force and same_flags and not needs_build():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    extra = os.environ.get("AUNCEL_AMD_CXXFLAGS", "").split()
     cmd = [hipcc] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     subprocess.run(cmd, check=True)
+    with open(stamp, "w") as f:
+        f.write(want)
     return LIB
 
 

@@ -894,10 +894,11 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
 void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first_round, size_t total_nprobe,
                        const unsigned long long* d_np_abs);
 
-// Fixed nprobe, planned on the device from keys that are already there (n x nprobe).  With a large heap the probes
-// are split in two rounds: the first few fill the heap, the rest run in threshold mode (the scan stores and the
-// selection reads only what can still enter it).  A small heap settles within a list or two and one dense round is
-// cheaper than a second pass over the lists.
+// Fixed nprobe, planned on the device from keys that are already there (n x nprobe).  From 16 probes on they are split
+// in two rounds: the first nprobe / 8 fill the heap, the rest run in threshold mode (the scan stores and the selection
+// reads only what can still enter it; a dense round is bound by those 8 bytes per distance).  Below that one dense
+// round is cheaper than a second pass over the lists (5000 queries, 10M x 128, nprobe 8: 2.7 vs 2.1 M queries/s;
+// nprobe 32: 1.1 vs 1.3).
 void search_fixed_device(amd_ivf* h, const float* d_x, size_t n, size_t k, size_t nprobe, const int64_t* d_keys, float* D,
                          int64_t* I, int store_pairs, size_t max_codes, const IntRange& qr) {
     upload_lists(h);
@@ -913,7 +914,7 @@ void search_fixed_device(amd_ivf* h, const float* d_x, size_t n, size_t k, size_
     base.bytes = byte_queries(h, ix(h), d_x, n, qr);
     ix(h)->last_arith = base.bytes ? 2 : base.fused ? 1 : 0;
     static const int two_env = getenv("AUNCEL_AMD_FIXED_ROUNDS") ? atoi(getenv("AUNCEL_AMD_FIXED_ROUNDS")) : 0;
-    const bool two = two_env ? two_env == 2 : (k >= 32 && nprobe >= 8);
+    const bool two = two_env ? two_env == 2 : nprobe >= 16;
     base.fixed_two = two;
     const size_t first = two ? std::max<size_t>(1, nprobe / 8) : nprobe;
     run_rounds_device(h, base, n, first, nprobe, nullptr);

@@ -302,8 +302,21 @@ def main():
             "launches_per_step": scan_launches / args.steps,
             "tile_slot_efficiency": slot_eff,
             "other_kernels_ms_per_step": {"coarse": coarse_ms / args.steps, "select": select_ms / args.steps},
+            # The lists are shared by the queries of a round, so the kernel is not HBM-bound (traffic << algorithmic bytes):
+            # its own ceiling is the VALU issue rate.  Byte codes: d/4 v_dot4_u32_u8 per distance; scratch/ubench/dot4_rate.hip
+            # measures 550 G wave-instructions/s for it on this chip (1024 SIMDs x 2.15 GHz / 4), i.e. 550e9 * 64 / (d/4)
+            # distances/s.  `achieved` counts every distance the tiles computed (scan_bytes / (4 d)).
+            "compute": {
+                "bound": "valu", "op": "v_dot4_u32_u8" if h.scan_arith() == 2 else "v_pk_fma_f32 / v_pk_mul+add",
+                "unit": "G distances/s",
+                "achieved": (scan_bytes / (4.0 * d)) / (scan_ms / 1e3) / 1e9 if scan_ms > 0 else None,
+                "peak": 550.0 * 64 / ((d / 4.0) if h.scan_arith() == 2 else (d if h.scan_arith() == 1 else 1.5 * d)),
+            },
         },
     }
+
+    cp = out["roofline"]["compute"]
+    cp["frac"] = cp["achieved"] / cp["peak"] if cp["achieved"] else None
 
     # HBM traffic of the scan per launch: PMC counters cannot be read from inside this process; the figure comes
     # from the committed rocprofv3 --pmc passes over this same command (profiles/collect.sh -> summarize.py),
