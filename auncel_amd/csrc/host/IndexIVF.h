@@ -5,23 +5,12 @@
 
 #include "IVF_pro.h"
 #include "Index.h"
+#include "Clustering.h"
 #include "InvertedLists.h"
 
 struct amd_ivf;
 
 namespace faiss {
-
-struct ClusteringParameters {
-    int niter = 25;
-    int nredo = 1;
-    bool verbose = false;
-    bool spherical = false;
-    bool update_index = false;
-    bool frozen_centroids = false;
-    int min_points_per_centroid = 39;
-    int max_points_per_centroid = 256;
-    int seed = 1234;
-};
 
 struct Level1Quantizer {
     Index* quantizer;

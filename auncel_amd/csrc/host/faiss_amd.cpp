@@ -66,11 +66,13 @@ IndexFlat::~IndexFlat() {
 void IndexFlat::add(idx_t n, const float* x) {
     xb.insert(xb.end(), x, x + n * d);
     ntotal += n;
+    gpu_ntotal_ = -1;  // the device copy is stale
 }
 
 void IndexFlat::reset() {
     xb.clear();
     ntotal = 0;
+    gpu_ntotal_ = -1;
 }
 
 void IndexFlat::search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const {
@@ -188,55 +190,174 @@ Level1Quantizer::~Level1Quantizer() {
     if (own_fields) delete quantizer;
 }
 
+// ---- Clustering (Clustering.cpp:36-256, utils.cpp:111-137,229-239,1078-1159)
 namespace {
-
-// Lloyd iterations with GPU assignment (the engine's exact coarse kernel) and host means.  k-means is
-// outside the hot path; this is a plain stand-in for Clustering::train, not a
-// bit-for-bit restatement of it.
-std::vector<float> kmeans(size_t n, const float* x, size_t d, size_t k, const ClusteringParameters& cp, MetricType metric) {
-    FAISS_THROW_IF_NOT_MSG(n >= k, "need at least as many training points as clusters");
-    std::mt19937 rng(cp.seed);
-    std::vector<size_t> perm(n);
-    for (size_t i = 0; i < n; i++) perm[i] = i;
-    std::shuffle(perm.begin(), perm.end(), rng);
-    const size_t ns = std::min(n, (size_t)cp.max_points_per_centroid * k);
-    std::vector<float> xs(ns * d);
-    for (size_t i = 0; i < ns; i++) memcpy(&xs[i * d], x + perm[i] * d, d * sizeof(float));
-    std::vector<float> cen(xs.begin(), xs.begin() + k * d);
-    std::vector<long> assign(ns);
-    std::vector<double> sum(k * d);
-    std::vector<size_t> cnt(k);
-    for (int it = 0; it < cp.niter; it++) {
-        IndexFlat q(d, metric);
-        q.coarse_mode = 0;
-        q.add(k, cen.data());
-        q.assign(ns, xs.data(), assign.data());
-        std::fill(sum.begin(), sum.end(), 0.0);
-        std::fill(cnt.begin(), cnt.end(), 0);
-        for (size_t i = 0; i < ns; i++) {
-            cnt[assign[i]]++;
-            for (size_t c = 0; c < d; c++) sum[assign[i] * d + c] += xs[i * d + c];
-        }
-        for (size_t j = 0; j < k; j++) {
-            if (cnt[j] == 0) {  // re-seed an empty cluster from a random training point
-                size_t r = rng() % ns;
-                memcpy(&cen[j * d], &xs[r * d], d * sizeof(float));
-                continue;
+struct RefRng {  // RandomGenerator
+    std::mt19937 mt;
+    explicit RefRng(long seed) : mt((unsigned int)seed) {}
+    int rand_int(int max) { return mt() % max; }
+    float rand_float() { return mt() / float(mt.max()); }
+};
+void ref_rand_perm(int* perm, size_t n, long seed) {
+    for (size_t i = 0; i < n; i++) perm[i] = (int)i;
+    RefRng rng(seed);
+    for (size_t i = 0; i + 1 < n; i++) {
+        int i2 = (int)i + rng.rand_int((int)(n - i));
+        std::swap(perm[i], perm[i2]);
+    }
+}
+// centroid = fp32 sum of its points in point order / count; void clusters are split off bigger ones
+int km_update_centroids(const float* x, float* centroids, const long* assign, size_t d, size_t k, size_t n, size_t k_frozen) {
+    k -= k_frozen;
+    centroids += k_frozen * d;
+    std::vector<size_t> hassign(k);
+    memset(centroids, 0, sizeof(*centroids) * d * k);
+    for (size_t i = 0; i < n; i++) {
+        long ci = assign[i] - (long)k_frozen;
+        if (ci < 0) continue;
+        float* c = centroids + ci * d;
+        hassign[ci]++;
+        const float* xi = x + i * d;
+        for (size_t j = 0; j < d; j++) c[j] += xi[j];
+    }
+    for (size_t ci = 0; ci < k; ci++) {
+        float* c = centroids + ci * d;
+        float ni = (float)hassign[ci];
+        if (ni != 0)
+            for (size_t j = 0; j < d; j++) c[j] /= ni;
+    }
+    size_t nsplit = 0;
+    RefRng rng(1234);
+    const double EPS = 1 / 1024.;
+    for (size_t ci = 0; ci < k; ci++) {
+        if (hassign[ci] == 0) {
+            size_t cj;
+            for (cj = 0; 1; cj = (cj + 1) % k) {
+                float p = (hassign[cj] - 1.0) / (float)(n - k);
+                float r = rng.rand_float();
+                if (r < p) break;
             }
-            for (size_t c = 0; c < d; c++) cen[j * d + c] = (float)(sum[j * d + c] / cnt[j]);
-            if (cp.spherical) {
-                double nr = 0;
-                for (size_t c = 0; c < d; c++) nr += (double)cen[j * d + c] * cen[j * d + c];
-                nr = std::sqrt(nr);
-                if (nr > 0)
-                    for (size_t c = 0; c < d; c++) cen[j * d + c] = (float)(cen[j * d + c] / nr);
+            memcpy(centroids + ci * d, centroids + cj * d, sizeof(*centroids) * d);
+            for (size_t j = 0; j < d; j++) {
+                if (j % 2 == 0) {
+                    centroids[ci * d + j] *= 1 + EPS;
+                    centroids[cj * d + j] *= 1 - EPS;
+                } else {
+                    centroids[ci * d + j] *= 1 - EPS;
+                    centroids[cj * d + j] *= 1 + EPS;
+                }
+            }
+            hassign[ci] = hassign[cj] / 2;
+            hassign[cj] -= hassign[ci];
+            nsplit++;
+        }
+    }
+    return (int)nsplit;
+}
+// fvec_norm_L2sqr in the reference's SSE order (utils_simd.cpp:137-155)
+float norm_L2sqr_sse(const float* x, size_t d) {
+    float s[4] = {0, 0, 0, 0};
+    size_t i = 0;
+    for (; i + 4 <= d; i += 4)
+        for (int l = 0; l < 4; l++) s[l] += x[i + l] * x[i + l];
+    for (int l = 0; i + l < d; l++) s[l] += x[i + l] * x[i + l];
+    return (s[0] + s[1]) + (s[2] + s[3]);
+}
+}  // namespace
+
+Clustering::Clustering(int d, int k) : d(d), k(k) {}
+Clustering::Clustering(int d, int k, const ClusteringParameters& cp) : ClusteringParameters(cp), d(d), k(k) {}
+
+void Clustering::post_process_centroids() {
+    if (spherical) {  // fvec_renorm_L2 (utils.cpp:377-392)
+        for (size_t i = 0; i < k; i++) {
+            float* xi = centroids.data() + i * d;
+            float nr = norm_L2sqr_sse(xi, d);
+            if (nr > 0) {
+                const float inv_nr = 1.0 / sqrtf(nr);
+                for (size_t j = 0; j < d; j++) xi[j] *= inv_nr;
             }
         }
     }
-    return cen;
+    if (int_centroids)
+        for (size_t i = 0; i < centroids.size(); i++) centroids[i] = roundf(centroids[i]);
 }
 
-}  // namespace
+void Clustering::train(idx_t nx, const float* x_in, Index& index) {
+    FAISS_THROW_IF_NOT_MSG(nx >= (idx_t)k, "Number of training points should be at least as large as number of clusters");
+    for (size_t i = 0; i < (size_t)nx * d; i++) FAISS_THROW_IF_NOT_MSG(std::isfinite(x_in[i]), "input contains NaN's or Inf's");
+    const float* x = x_in;
+    std::vector<float> sub;
+    if ((size_t)nx > k * max_points_per_centroid) {
+        if (verbose) printf("Sampling a subset of %ld / %ld for training\n", (long)(k * max_points_per_centroid), (long)nx);
+        std::vector<int> perm(nx);
+        ref_rand_perm(perm.data(), nx, seed);
+        nx = k * max_points_per_centroid;
+        sub.resize((size_t)nx * d);
+        for (idx_t i = 0; i < nx; i++) memcpy(&sub[i * d], x_in + (size_t)perm[i] * d, sizeof(float) * d);
+        x = sub.data();
+    } else if ((size_t)nx < k * min_points_per_centroid) {
+        fprintf(stderr, "WARNING clustering %ld points to %ld centroids: please provide at least %ld training points\n", (long)nx,
+                (long)k, (long)(k * min_points_per_centroid));
+    }
+    if ((size_t)nx == k) {  // corner case: the training set becomes the centroids
+        centroids.assign(x_in, x_in + d * k);
+        index.reset();
+        index.add(k, x_in);
+        return;
+    }
+    std::vector<idx_t> assign(nx);
+    std::vector<float> dis(nx);
+    float best_err = HUGE_VALF;
+    std::vector<float> best_obj, best_centroids;
+    FAISS_THROW_IF_NOT_MSG(centroids.size() % d == 0, "size of provided input centroids not a multiple of dimension");
+    const size_t n_input_centroids = centroids.size() / d;
+    for (int redo = 0; redo < nredo; redo++) {
+        centroids.resize(d * k);
+        std::vector<int> perm(nx);
+        ref_rand_perm(perm.data(), nx, seed + 1 + redo * 15486557L);
+        for (size_t i = n_input_centroids; i < k; i++) memcpy(&centroids[i * d], x + (size_t)perm[i] * d, d * sizeof(float));
+        post_process_centroids();
+        if (index.ntotal != 0) index.reset();
+        if (!index.is_trained) index.train(k, centroids.data());
+        index.add(k, centroids.data());
+        float err = 0;
+        for (int it = 0; it < niter; it++) {
+            index.search(nx, x, 1, dis.data(), assign.data());  // the GPU part
+            err = 0;
+            for (idx_t j = 0; j < nx; j++) err += dis[j];
+            obj.push_back(err);
+            int nsplit = km_update_centroids(x, centroids.data(), assign.data(), d, k, nx, frozen_centroids ? n_input_centroids : 0);
+            if (verbose) printf("  Iteration %d: objective=%g nsplit=%d\n", it, err, nsplit);
+            post_process_centroids();
+            index.reset();
+            if (update_index) index.train(k, centroids.data());
+            index.add(k, centroids.data());
+        }
+        if (nredo > 1) {
+            if (err < best_err) {
+                best_centroids = centroids;
+                best_obj = obj;
+                best_err = err;
+            }
+            index.reset();
+        }
+    }
+    if (nredo > 1) {
+        centroids = best_centroids;
+        obj = best_obj;
+        index.reset();
+        index.add(k, best_centroids.data());
+    }
+}
+
+float kmeans_clustering(size_t d, size_t n, size_t k, const float* x, float* centroids) {
+    Clustering clus((int)d, (int)k);
+    IndexFlatL2 index(d);
+    clus.train(n, x, index);
+    memcpy(centroids, clus.centroids.data(), sizeof(*centroids) * d * k);
+    return clus.obj.back();
+}
 
 void Level1Quantizer::train_q1(size_t n, const float* x, bool verbose, MetricType metric_type) {
     const size_t d = quantizer->d;
@@ -246,9 +367,15 @@ void Level1Quantizer::train_q1(size_t n, const float* x, bool verbose, MetricTyp
     }
     FAISS_THROW_IF_NOT_MSG(quantizer_trains_alone == 0, "only k-means training of a flat quantizer is supported");
     if (verbose) printf("Training level-1 quantizer on %ld vectors in %ldD\n", (long)n, (long)d);
+    Clustering clus((int)d, (int)nlist, cp);
     quantizer->reset();
-    std::vector<float> cen = kmeans(n, x, d, nlist, cp, metric_type);
-    quantizer->add(nlist, cen.data());
+    if (clustering_index) {
+        clus.train(n, x, *clustering_index);
+        quantizer->add(nlist, clus.centroids.data());
+    } else {
+        clus.train(n, x, *quantizer);
+    }
+    const std::vector<float>& cen = clus.centroids;
     if (quantizer->tune) {
         // centroid-to-centroid table of the Auncel geometry (IndexIVF.cpp:97-111), computed on the GPU
         amd_ivf* g = nullptr;

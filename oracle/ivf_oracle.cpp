@@ -30,6 +30,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <random>
 #include <string>
 #include <utility>
 #include <vector>
@@ -530,6 +531,116 @@ void orc_knn(int metric, const float* x, const float* y, size_t d, size_t nx, si
     } else {
         if (gemm) knn_gemm<false>(x, y, d, nx, ny, k, D, I, nthreads);
         else knn_exact<false>(x, y, d, nx, ny, k, D, I, nthreads);
+    }
+}
+
+// ---- Clustering::train (Clustering.cpp:75-226), rand_perm (utils.cpp:229-239), RandomGenerator (utils.cpp:111-137),
+//      km_update_centroids (utils.cpp:1078-1159)
+namespace {
+struct RefRng {
+    std::mt19937 mt;
+    explicit RefRng(long seed) : mt((unsigned int)seed) {}
+    int rand_int(int max) { return mt() % max; }
+    float rand_float() { return mt() / float(mt.max()); }
+};
+void ref_rand_perm(std::vector<int>& perm, size_t n, long seed) {
+    perm.resize(n);
+    for (size_t i = 0; i < n; i++) perm[i] = (int)i;
+    RefRng rng(seed);
+    for (size_t i = 0; i + 1 < n; i++) {
+        int i2 = (int)i + rng.rand_int((int)(n - i));
+        std::swap(perm[i], perm[i2]);
+    }
+}
+int ref_km_update_centroids(const float* x, float* centroids, const int64_t* assign, size_t d, size_t k, size_t n) {
+    std::vector<size_t> hassign(k);
+    memset(centroids, 0, sizeof(*centroids) * d * k);
+    for (size_t i = 0; i < n; i++) {  // per centroid: fp32 sums in point order (the reference splits the centroids over threads)
+        const size_t ci = (size_t)assign[i];
+        float* c = centroids + ci * d;
+        hassign[ci]++;
+        for (size_t j = 0; j < d; j++) c[j] += x[i * d + j];
+    }
+    for (size_t ci = 0; ci < k; ci++) {
+        float* c = centroids + ci * d;
+        float ni = (float)hassign[ci];
+        if (ni != 0)
+            for (size_t j = 0; j < d; j++) c[j] /= ni;
+    }
+    size_t nsplit = 0;
+    RefRng rng(1234);
+    const double EPS = 1 / 1024.;
+    for (size_t ci = 0; ci < k; ci++) {
+        if (hassign[ci] == 0) {
+            size_t cj;
+            for (cj = 0; 1; cj = (cj + 1) % k) {
+                float p = (hassign[cj] - 1.0) / (float)(n - k);
+                float r = rng.rand_float();
+                if (r < p) break;
+            }
+            memcpy(centroids + ci * d, centroids + cj * d, sizeof(*centroids) * d);
+            for (size_t j = 0; j < d; j++) {
+                if (j % 2 == 0) {
+                    centroids[ci * d + j] *= 1 + EPS;
+                    centroids[cj * d + j] *= 1 - EPS;
+                } else {
+                    centroids[ci * d + j] *= 1 - EPS;
+                    centroids[cj * d + j] *= 1 + EPS;
+                }
+            }
+            hassign[ci] = hassign[cj] / 2;
+            hassign[cj] -= hassign[ci];
+            nsplit++;
+        }
+    }
+    return (int)nsplit;
+}
+void ref_post_process(float* c, size_t d, size_t k, int spherical, int int_centroids) {
+    if (spherical) {  // fvec_renorm_L2 (utils.cpp): x /= sqrt(|x|^2) when the norm is positive
+        for (size_t i = 0; i < k; i++) {
+            float* xi = c + i * d;
+            float nr = inner(xi, xi, d);  // fvec_norm_L2sqr (utils_simd.cpp:137-155): the same 4-lane sums
+            if (nr > 0) {
+                const float inv_nr = 1.0 / sqrtf(nr);
+                for (size_t j = 0; j < d; j++) xi[j] *= inv_nr;
+            }
+        }
+    }
+    if (int_centroids)
+        for (size_t i = 0; i < k * d; i++) c[i] = roundf(c[i]);
+}
+}  // namespace
+
+void orc_kmeans(int metric, size_t d, size_t n, const float* x_in, size_t k, int niter, long seed, size_t max_pts, int spherical,
+                int int_centroids, int gemm, float* centroids, float* obj, int nthreads) {
+    const float* x = x_in;
+    std::vector<float> sub;
+    size_t nx = n;
+    if (nx > k * max_pts) {
+        std::vector<int> perm;
+        ref_rand_perm(perm, nx, seed);
+        nx = k * max_pts;
+        sub.resize(nx * d);
+        for (size_t i = 0; i < nx; i++) memcpy(&sub[i * d], x_in + (size_t)perm[i] * d, sizeof(float) * d);
+        x = sub.data();
+    }
+    if (nx == k) {  // corner case of the reference: copy the training set
+        memcpy(centroids, x_in, sizeof(float) * d * k);
+        return;
+    }
+    std::vector<int> perm;
+    ref_rand_perm(perm, nx, seed + 1);
+    for (size_t i = 0; i < k; i++) memcpy(centroids + i * d, x + (size_t)perm[i] * d, d * sizeof(float));
+    ref_post_process(centroids, d, k, spherical, int_centroids);
+    std::vector<float> dis(nx);
+    std::vector<int64_t> assign(nx);
+    for (int it = 0; it < niter; it++) {
+        orc_knn(metric, x, centroids, d, nx, k, 1, dis.data(), assign.data(), gemm, nthreads);
+        float err = 0;
+        for (size_t j = 0; j < nx; j++) err += dis[j];
+        obj[it] = err;
+        ref_km_update_centroids(x, centroids, assign.data(), d, k, nx);
+        ref_post_process(centroids, d, k, spherical, int_centroids);
     }
 }
 

@@ -71,6 +71,16 @@ int orc_search_preassigned(const orc_index_t* ix, size_t n, const float* x, size
                            const int64_t* keys, const float* coarse_dis, float* D, int64_t* I, int store_pairs,
                            size_t max_codes, orc_tuner_t* tuner, size_t offset, size_t* stats, int nthreads);
 
+/* Clustering::train (Clustering.cpp:75-226) with an IndexFlat of `metric`, nredo 1, no input centroids: sub-sampling by
+ * rand_perm(seed) beyond k * max_points_per_centroid, centroids seeded from rand_perm(seed + 1), niter x { assignment to the
+ * nearest / most similar centroid; objective = float sum of the assignment distances in point order; km_update_centroids
+ * (utils.cpp:1078-1159): fp32 sums in point order, division by the count, void clusters split off bigger ones with
+ * RandomGenerator(1234) and the 1/1024 perturbation }; spherical / int_centroids post-processing.  gemm: assignment
+ * through the |x|^2+|y|^2-2xy restatement of the BLAS branch (the reference takes it from 20 points on; vendor rounding
+ * unpinned) instead of the exact kernel.  obj receives niter values. */
+void orc_kmeans(int metric, size_t d, size_t n, const float* x, size_t k, int niter, long seed, size_t max_points_per_centroid,
+                int spherical, int int_centroids, int gemm, float* centroids, float* obj, int nthreads);
+
 /* IndexIVF::range_search_preassigned (IndexIVF.cpp:759-857) with IVFFlatScanner::scan_codes_range
  * (IndexIVFFlat.cpp:139-155): per query, probes in order, list entries in order, every entry with
  * radius > dis (L2) / radius < dis (IP).  Two calls: with labels == NULL only lims (n + 1) is filled;

@@ -173,6 +173,20 @@ def search_preassigned(lists, x, k, keys, coarse_dis, store_pairs=False, max_cod
     return D, I, stats.astype(np.int64)
 
 
+def kmeans(metric, x, k, niter=25, seed=1234, max_points_per_centroid=256, spherical=False, int_centroids=False, gemm=False,
+           nthreads=8):
+    """Clustering::train restated -> centroids (k, d), objective per iteration"""
+    x = f32(x)
+    n, d = x.shape
+    cen = np.zeros((k, d), dtype=np.float32)
+    obj = np.zeros(niter, dtype=np.float32)
+    L = lib()
+    L.orc_kmeans.restype = None
+    L.orc_kmeans(int(metric), C.c_size_t(d), C.c_size_t(n), _f(x), C.c_size_t(k), int(niter), C.c_long(seed),
+                 C.c_size_t(max_points_per_centroid), int(spherical), int(int_centroids), int(gemm), _f(cen), _f(obj), int(nthreads))
+    return cen, obj
+
+
 def range_search_preassigned(lists, x, radius, keys):
     """-> lims (n + 1), labels, distances, stats {nlist, ndis}"""
     x, keys = f32(x), i64(keys)

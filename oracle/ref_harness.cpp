@@ -27,6 +27,7 @@
 
 #include "Heap.h"
 #include "AuxIndexStructures.h"
+#include "Clustering.h"
 #include "IVF_pro.h"
 #include "IndexFlat.h"
 #include "IndexIVF.h"
@@ -192,6 +193,25 @@ static int run_fixed(const tb::Bundle& in, tb::Bundle& out) {
             out.put_i64("I_shards_k" + std::to_string(k), {nq, k}, to_i64(I).data());
         }
     }
+    return 0;
+}
+
+// Clustering::train over an IndexFlat, as Level1Quantizer::train_q1 runs it (IndexIVF.cpp:84-92)
+static int run_kmeans(const tb::Bundle& in, tb::Bundle& out) {
+    size_t d = in.scalar<size_t>("d"), k = in.scalar<size_t>("k");
+    const tb::Tensor& x = in.get("x");
+    size_t n = x.dims[0];
+    MetricType mt = in.scalar<int>("metric") == 0 ? METRIC_INNER_PRODUCT : METRIC_L2;
+    ClusteringParameters cp;
+    cp.niter = in.scalar<int>("niter");
+    cp.seed = in.scalar_or<int>("seed", 1234);
+    cp.spherical = in.scalar_or<int>("spherical", 0) != 0;
+    cp.max_points_per_centroid = in.scalar_or<int>("max_points_per_centroid", 256);
+    Clustering clus(d, k, cp);
+    IndexFlat index(d, mt);
+    clus.train(n, x.as<float>(), index);
+    out.put_f32("centroids", {k, d}, clus.centroids.data());
+    out.put_f32("obj", {clus.obj.size()}, clus.obj.data());
     return 0;
 }
 
@@ -409,7 +429,7 @@ int main(int argc, char** argv) {
         tb::Bundle out;
         std::string cmd = argv[1];
         // note: sys_train writes Validation_*.log into the CWD: run from a scratch dir
-        int rc = cmd == "fixed" ? run_fixed(in, out) : cmd == "auncel" ? run_auncel(in, out) : cmd == "io" ? run_io(in, out) : 2;
+        int rc = cmd == "fixed" ? run_fixed(in, out) : cmd == "auncel" ? run_auncel(in, out) : cmd == "io" ? run_io(in, out) : cmd == "kmeans" ? run_kmeans(in, out) : 2;
         if (rc == 0) out.save(argv[3]);
         return rc;
     } catch (const std::exception& e) {

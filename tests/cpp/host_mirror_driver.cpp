@@ -3,12 +3,14 @@
 // (Error_sys train -> set_queries -> one search() per query) -- on a bundle prepared by
 // tests/test_host_mirror.py and compares with the expected tensors stored in it.
 // usage: host_mirror_driver <fixed|auncel> <bundle.tb>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <memory>
 
 #include "../../auncel_amd/csrc/host/AutoTune.h"
 #include "../../auncel_amd/csrc/host/AuxIndexStructures.h"
+#include "../../auncel_amd/csrc/host/Clustering.h"
 #include "../../auncel_amd/csrc/host/FaissException.h"
 #include "../../auncel_amd/csrc/host/Heap.h"
 #include "../../auncel_amd/csrc/host/IndexFlat.h"
@@ -211,11 +213,53 @@ static int run_auncel(const tb::Bundle& in) {
     return g_fail;
 }
 
+// faiss::Clustering of the mirror (GPU assignment, reference update procedure) against the compiled reference's
+// centroids / objective, and IndexIVF::train through index_factory
+static int run_kmeans(const tb::Bundle& in) {
+    size_t d = in.scalar<size_t>("d"), k = in.scalar<size_t>("k");
+    const tb::Tensor& x = in.get("x");
+    const size_t n = x.dims[0];
+    MetricType mt = in.scalar<int>("metric") == 0 ? METRIC_INNER_PRODUCT : METRIC_L2;
+    ClusteringParameters cp;
+    cp.niter = in.scalar<int>("niter");
+    cp.seed = in.scalar<int>("seed");
+    cp.spherical = in.scalar<int>("spherical") != 0;
+    cp.max_points_per_centroid = in.scalar<int>("max_points_per_centroid");
+    Clustering clus((int)d, (int)k, cp);
+    IndexFlat index(d, mt);
+    index.coarse_mode = 0;  // exact assignment kernel (the reference's BLAS rounding is unpinned)
+    clus.train(n, x.as<float>(), index);
+    const float* gc = in.get("centroids").as<float>();
+    expect(clus.centroids.size() == k * d && same_f(clus.centroids.data(), gc, k * d), "Clustering::train centroids");
+    const tb::Tensor& go = in.get("obj");
+    bool obj_ok = clus.obj.size() == go.numel();
+    for (size_t i = 0; obj_ok && i < clus.obj.size(); i++) {
+        const float a = clus.obj[i], b = go.as<float>()[i];
+        obj_ok = n < 20 ? memcmp(&a, &b, 4) == 0 : std::fabs(a - b) <= 1e-5f * std::fabs(b);
+    }
+    expect(obj_ok, "Clustering::train objective");
+    expect((size_t)index.ntotal == k, "index holds the final centroids");
+
+    if (mt == METRIC_L2 && !cp.spherical) {  // the same through IndexIVF::train (Level1Quantizer::train_q1)
+        std::unique_ptr<Index> ivf(index_factory((int)d, ("IVF" + std::to_string(k) + ",Flat").c_str(), mt));
+        IndexIVF* ix = dynamic_cast<IndexIVF*>(ivf.get());
+        ix->cp = cp;
+        dynamic_cast<IndexFlat*>(ix->quantizer)->coarse_mode = 0;
+        ivf->train(n, x.as<float>());
+        expect(ivf->is_trained && (size_t)ix->quantizer->ntotal == k, "IndexIVF::train trains the quantizer");
+        std::vector<float> rec(k * d);
+        IndexFlat* q = dynamic_cast<IndexFlat*>(ix->quantizer);
+        expect(q->xb.size() == k * d && same_f(q->xb.data(), gc, k * d), "IndexIVF::train centroids");
+    }
+    return g_fail;
+}
+
 int main(int argc, char** argv) {
     if (argc != 3) return 2;
     try {
         tb::Bundle in = tb::Bundle::load(argv[2]);
-        int f = std::string(argv[1]) == "fixed" ? run_fixed(in) : run_auncel(in);
+        const std::string cmd = argv[1];
+        int f = cmd == "fixed" ? run_fixed(in) : cmd == "kmeans" ? run_kmeans(in) : run_auncel(in);
         printf(f ? "FAILED %d checks\n" : "ALL OK\n", f);
         return f ? 1 : 0;
     } catch (const std::exception& e) {

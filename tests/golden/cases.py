@@ -94,6 +94,36 @@ def auncel_deep_ip_d64():
     return _auncel(xb, xq, 200, 100, [(10, 0.9, 1.5, 1.0), (20, 0.9, 1.2, 2.0)], metric=METRIC_IP, K=20)
 
 
+def _kmeans(x, k, niter, metric=METRIC_L2, spherical=0, max_pts=256, seed=1234):
+    return dict(kind="kmeans", d=x.shape[1], k=k, niter=niter, metric=metric, spherical=spherical,
+                max_points_per_centroid=max_pts, seed=seed, x=x)
+
+
+def kmeans_toy():
+    # fewer than 20 points: the reference assigns through its exact (non-BLAS) path, so every bit is pinned
+    xb, _ = synth.gauss_like(19, 1, d=8, nblobs=4, sigma=0.5, seed=41)
+    return _kmeans(xb, 4, 6)
+
+
+def kmeans_void():
+    # duplicates: clusters run empty and are split off bigger ones (km_update_centroids, utils.cpp:1126-1159)
+    rs = np.random.RandomState(42)
+    base = rs.randint(0, 6, size=(3, 8)).astype(np.float32)
+    x = base[rs.randint(0, 3, size=18)]
+    return _kmeans(x, 6, 5)
+
+
+def kmeans_toy_ip():
+    xb, _ = synth.deep_like(18, 1, d=16, nblobs=3, sigma=0.5, seed=43)
+    return _kmeans(xb, 3, 5, metric=METRIC_IP, spherical=1)
+
+
+def kmeans_sub_int():
+    # sub-sampling (n > k * max_points_per_centroid) and the BLAS assignment path: integer data, objective pinned loosely
+    xb, _ = synth.sift_like(4000, 1, d=16, nblobs=24, sigma=20.0, seed=44)
+    return _kmeans(xb, 24, 8, max_pts=100)
+
+
 def io_ragged():
     c = fixed_ragged()
     c["kind"] = "io"
@@ -108,11 +138,11 @@ def io_sift():
 
 
 CASES = {f.__name__: f for f in [io_ragged, io_sift, fixed_sift_l2, fixed_gauss_l2_d96, fixed_deep_ip_d96, fixed_gist_l2_d960,
-                                  fixed_odd_d30, fixed_ragged, fixed_dups, auncel_sift_d32, auncel_gauss_d64, auncel_deep_ip_d64]}
+                                  fixed_odd_d30, fixed_ragged, fixed_dups, auncel_sift_d32, auncel_gauss_d64, auncel_deep_ip_d64, kmeans_toy, kmeans_void, kmeans_toy_ip, kmeans_sub_int]}
 
 
 def input_sha(case):
-    arrs = [case[k] for k in ("xb", "xq") if k in case]
+    arrs = [case[k] for k in ("xb", "xq", "x") if k in case]
     if "centroids" in case:
         arrs.append(case["centroids"])
     return synth.sha(*arrs)

@@ -45,6 +45,17 @@ def test_fixed_flows(driver, tmp_path, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["kmeans_toy", "kmeans_void", "kmeans_toy_ip", "kmeans_sub_int"])
+def test_clustering(driver, tmp_path, name):
+    """faiss::Clustering / IndexIVF::train of the mirror: assignment on the GPU, the reference's update procedure; centroids
+    bit for bit against the compiled reference (goldens)"""
+    case, gold = load_case(name)
+    t = {k: v for k, v in case.items() if k != "kind"}
+    t.update({k: v for k, v in gold.items() if k != "input_sha"})
+    _run(driver, "kmeans", t, tmp_path)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["auncel_sift_d32", "auncel_gauss_d64"])
 def test_error_sys_flow(driver, oracle, tmp_path, name):
     case, gold = load_case(name)

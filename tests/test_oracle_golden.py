@@ -4,7 +4,7 @@ Bit-exact on ids AND distances for every pinned path."""
 import numpy as np
 import pytest
 
-from util import AUNCEL, FIXED, load_case, traces_from_gold
+from util import AUNCEL, FIXED, KMEANS, load_case, traces_from_gold
 
 
 def _lists(oracle, case, gold, cen=None):
@@ -177,3 +177,19 @@ def test_auncel_online(oracle, name):
             assert np.array_equal(D.view(np.uint32), gold["D" + suf].view(np.uint32)), suf
             assert np.array_equal(tun.t_recalls[ts:].view(np.uint32), gold["t_recalls" + suf].view(np.uint32)), suf
             assert np.array_equal(stats, gold["stats" + suf]), suf
+
+
+@pytest.mark.parametrize("name", KMEANS)
+def test_kmeans(oracle, name):
+    """Clustering::train over an IndexFlat (what Level1Quantizer::train_q1 runs): sub-sampling and seeding permutations,
+    fp32 centroid sums in point order, void-cluster splitting, spherical post-processing.  Centroids bit for bit on every
+    case (on the integer-valued case the reference's BLAS assignment picks the same centroids as the exact kernel); the
+    objective bit for bit where the reference assigns through its exact path (fewer than 20 points)."""
+    case, gold = load_case(name)
+    cen, obj = oracle.kmeans(case["metric"], case["x"], case["k"], case["niter"], case["seed"], case["max_points_per_centroid"],
+                             bool(case["spherical"]))
+    assert np.array_equal(cen.view(np.uint32), gold["centroids"].view(np.uint32))
+    if case["x"].shape[0] < 20:
+        assert np.array_equal(obj.view(np.uint32), gold["obj"].view(np.uint32))
+    else:
+        assert np.allclose(obj, gold["obj"], rtol=1e-5)

@@ -22,6 +22,7 @@ def load_case(name):
 
 FIXED = [n for n in cases.CASES if n.startswith("fixed_")]
 AUNCEL = [n for n in cases.CASES if n.startswith("auncel_")]
+KMEANS = [n for n in cases.CASES if n.startswith("kmeans_")]
 
 
 def traces_from_gold(gold, prefix="sb_"):
