@@ -226,12 +226,12 @@ struct amd_ivf {
     std::mutex upload_mu;   // owner only: serialises the first upload of the lists
     std::vector<std::unique_ptr<amd_ivf>> kids;
     // side streams for the sparse tile shapes of a round (fork / join around the dense launch)
-    hipStream_t aux[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
 
     ~amd_ivf() {
         kids.clear();
-        for (int i = 0; i < 3; i++) {
+        for (int i = 0; i < 4; i++) {
             if (aux[i]) (void)hipStreamDestroy(aux[i]);
             if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
         }
@@ -246,6 +246,21 @@ static inline const amd_ivf* ix(const amd_ivf* h) { return h->parent ? h->parent
 namespace {
 
 void use_device(const amd_ivf* h) { HIP_CHECK(hipSetDevice(h->device)); }
+
+// The main stream of a context carries its latency-bound work (round planning, ordered selection, transfers); with
+// several contexts on one GPU it gets the high priority so that those kernels are not queued behind another context's
+// scan workgroups (the scans themselves run on the normal-priority side streams).
+hipStream_t make_main_stream() {
+    static const bool flat = getenv("AUNCEL_AMD_FLAT_PRIORITY") != nullptr;
+    hipStream_t s = nullptr;
+    int lo = 0, hi = 0;
+    if (!flat && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo) {
+        HIP_CHECK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi));
+    } else {
+        HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    }
+    return s;
+}
 
 // ------------------------------------------------------------------------------------ lists
 void upload_lists(amd_ivf* h) {
@@ -623,19 +638,19 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
         }
         if (nitems) {
             if (!h->aux[0]) {
-                for (int i = 0; i < 3; i++) {
+                for (int i = 0; i < 4; i++) {
                     HIP_CHECK(hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
                     HIP_CHECK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
                 }
                 HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
             }
             size_t t = h->timer.begin(CAT_SCAN, s);
-            const bool fork = ((n_qg[0] != 0) + (n_qg[1] != 0) + (n_qg[2] != 0) + (n_qg[3] != 0)) > 1;
+            const bool fork = true;  // every shape on a side stream (see make_main_stream)
             if (fork) {
                 HIP_CHECK(hipEventRecord(h->ev_fork, s));
-                for (int i = 0; i < 3; i++) HIP_CHECK(hipStreamWaitEvent(h->aux[i], h->ev_fork, 0));
-                launch_scan(sa, n_qg, s, h->aux[0], h->aux[1], h->aux[2]);
-                for (int i = 0; i < 3; i++) {
+                for (int i = 0; i < 4; i++) HIP_CHECK(hipStreamWaitEvent(h->aux[i], h->ev_fork, 0));
+                launch_scan(sa, n_qg, h->aux[3], h->aux[0], h->aux[1], h->aux[2]);
+                for (int i = 0; i < 4; i++) {
                     HIP_CHECK(hipEventRecord(h->ev_join[i], h->aux[i]));
                     HIP_CHECK(hipStreamWaitEvent(s, h->ev_join[i], 0));
                 }
@@ -1089,7 +1104,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     pa.acc64 = reinterpret_cast<unsigned long long*>(h->w_pl_counters.as<uint32_t>() + 18);
 
     if (!h->aux[0]) {
-        for (int i = 0; i < 3; i++) {
+        for (int i = 0; i < 4; i++) {
             HIP_CHECK(hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
             HIP_CHECK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
         }
@@ -1140,12 +1155,12 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
                 sa.mask = h->w_mask.as<unsigned long long>();
             }
             size_t t = h->timer.begin(CAT_SCAN, s);
-            const bool fork = ((n_qg[0] != 0) + (n_qg[1] != 0) + (n_qg[2] != 0) + (n_qg[3] != 0)) > 1;
+            const bool fork = true;  // every shape on a side stream (see make_main_stream)
             if (fork) {
                 HIP_CHECK(hipEventRecord(h->ev_fork, s));
-                for (int i = 0; i < 3; i++) HIP_CHECK(hipStreamWaitEvent(h->aux[i], h->ev_fork, 0));
-                launch_scan(sa, n_qg, s, h->aux[0], h->aux[1], h->aux[2]);
-                for (int i = 0; i < 3; i++) {
+                for (int i = 0; i < 4; i++) HIP_CHECK(hipStreamWaitEvent(h->aux[i], h->ev_fork, 0));
+                launch_scan(sa, n_qg, h->aux[3], h->aux[0], h->aux[1], h->aux[2]);
+                for (int i = 0; i < 4; i++) {
                     HIP_CHECK(hipEventRecord(h->ev_join[i], h->aux[i]));
                     HIP_CHECK(hipStreamWaitEvent(s, h->ev_join[i], 0));
                 }
@@ -1389,7 +1404,7 @@ int amd_ivf_create(int d, size_t nlist, int metric, int device, amd_ivf_t** out)
     h->metric = metric;
     h->device = device;
     HIP_CHECK(hipSetDevice(device));
-    HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->stream = make_main_stream();
     h->h_codes.resize(nlist);
     h->h_ids.resize(nlist);
     h->h_list_off.assign(nlist + 1, 0);
@@ -1419,7 +1434,7 @@ int amd_ivf_clone(amd_ivf_t* h, amd_ivf_t** out) {
     c->dist_budget_floats = owner->dist_budget_floats;
     c->allow_fused = owner->allow_fused;
     c->allow_bytes = owner->allow_bytes;
-    HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->stream = make_main_stream();
     *out = c.release();
     API_END
 }
@@ -1997,7 +2012,7 @@ static void adaptive_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n
         kid->metric = h->metric;
         kid->device = h->device;
         kid->dist_budget_floats = h->dist_budget_floats;
-        HIP_CHECK(hipStreamCreateWithFlags(&kid->stream, hipStreamNonBlocking));
+        kid->stream = make_main_stream();
         h->kids.push_back(std::move(kid));
     }
     std::vector<amd_ivf*> lanes(nl);

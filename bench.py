@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--std-m", type=float, default=1.0)
     ap.add_argument("--cpu-sample", type=int, default=256)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=2,
+    ap.add_argument("--in-flight", type=int, default=3,
                     help="batches kept in flight per GPU, each from its own host thread on its own search context "
                          "(amd_ivf_clone); 1 = one batch at a time")
     args = ap.parse_args()
