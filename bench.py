@@ -253,15 +253,26 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    st = {}
+    for c in ctxs:
+        for key, val in c.stats().items():
+            st[key] = st.get(key, 0) + val
+    # the same steps one batch at a time (after the timed region, not part of `value`): per-launch kernel figures without
+    # another batch sharing the chip
+    solo = {}
+    if nfl > 1:
+        nfl_keep, nfl = nfl, 1
+        barrier()
+        ts0 = time.perf_counter()
+        run_steps(args.steps, solo)
+        barrier()
+        solo["elapsed"] = time.perf_counter() - ts0
+        nfl = nfl_keep
     D, I, my_np = acc["last"]
     scan_ms, scan_bytes, scan_launches = acc["scan_ms"], acc["scan_bytes"], acc["scan_launches"]
     coarse_ms, select_ms, slot_eff = acc["coarse_ms"], acc["select_ms"], acc["slot_eff"] / args.steps
 
     rec = recall_dist(D, gtD[ts:], topk)
-    st = {}
-    for c in ctxs:
-        for key, val in c.stats().items():
-            st[key] = st.get(key, 0) + val
     # algorithmic bytes: the reference's own ndis counter (codes actually visited by the probe loops,
     # IndexIVF.cpp:676,733) x d x 4; `scan_bytes` (distances the tiles computed, incl. the probes a round
     # ran past a query's stop point) is reported beside it as computed_over_algorithmic
@@ -317,6 +328,16 @@ def main():
 
     cp = out["roofline"]["compute"]
     cp["frac"] = cp["achieved"] / cp["peak"] if cp["achieved"] else None
+    if solo:
+        s_ms = solo["scan_ms"]
+        out["one_batch_at_a_time"] = {
+            "value": ses * args.steps / solo["elapsed"], "unit": "queries/s", "ms_per_step": 1000.0 * solo["elapsed"] / args.steps,
+            "scan_avg_launch_ms": s_ms / max(solo["scan_launches"], 1),
+            "scan_algorithmic_GBps": (alg_bytes / 1e9) / (s_ms / 1e3),
+            "scan_G_distances_per_s": (solo["scan_bytes"] / (4.0 * d)) / (s_ms / 1e3) / 1e9,
+            "scan_frac_of_valu_peak": (solo["scan_bytes"] / (4.0 * d)) / (s_ms / 1e3) / 1e9 / cp["peak"],
+            "other_kernels_ms_per_step": {"coarse": solo["coarse_ms"] / args.steps, "select": solo["select_ms"] / args.steps},
+        }
 
     # HBM traffic of the scan per launch: PMC counters cannot be read from inside this process; the figure comes
     # from the committed rocprofv3 --pmc passes over this same command (profiles/collect.sh -> summarize.py),
