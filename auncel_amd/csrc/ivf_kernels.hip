@@ -223,11 +223,7 @@ __global__ __launch_bounds__(QG == 8 ? 512 : 256) void scan_tiles_kernel(ScanArg
                     const unsigned long long m = __ballot(keep);
                     if (lane == 0 && lv0 < (int)it.nvec) a.mask[(row + lv0) >> 6] = m;
                 }
-#if defined(AUNCEL_EXP_NOSTORE)
-                if (keep && (!BYTES || res == 12345.678f)) out[lv] = res;
-#else
                 if (keep) out[lv] = res;
-#endif
             }
         }
     }
