@@ -83,6 +83,33 @@ __global__ __launch_bounds__(QG == 8 ? 512 : 256) void scan_tiles_kernel(ScanArg
     const float* tile_base = a.codes + (size_t)it.vec_base * (size_t)d;
     const bool has_queries = (uint32_t)(qgi * SCAN_RQ) < it.npair;
 
+    // What the epilogue needs per query -- row offset of its distances, |x|^2, threshold -- is fetched now by lane r
+    // for query r (and |y|^2 per vector by every lane), so that the loads ride under the tile's arithmetic instead of
+    // forming two dependent scalar round trips per query at the end.
+    const bool masked = a.thr != nullptr;
+    unsigned long long e_row = 0;
+    uint32_t e_xn = 0;
+    float e_thr = 0.f;
+    uint32_t ynorm[SCAN_RV];
+    if (has_queries) {
+        const uint32_t local = (uint32_t)(qgi * SCAN_RQ + lane);
+        if (lane < SCAN_RQ && local < it.npair) {
+            e_row = a.pair_out[it.pair_begin + local] + it.vec_off;
+            if (masked || (BYTES && METRIC == METRIC_L2)) {
+                const uint32_t qrow = a.pair_query[it.pair_begin + local];
+                if (BYTES && METRIC == METRIC_L2) e_xn = a.query_norms[qrow];
+                if (masked) e_thr = a.thr[qrow];
+            }
+        }
+        if (BYTES && METRIC == METRIC_L2) {
+#pragma unroll
+            for (int v = 0; v < SCAN_RV; v++) {
+                const int lv = vgi * SCAN_WAVE_VECS + v * 64 + lane;
+                ynorm[v] = lv < (int)it.nvec ? a.code_norms[it.vec_base + lv] : 0u;
+            }
+        }
+    }
+
     // fetches run two chunks ahead of the compute (register staging, PF sets): at 4 steps per chunk one chunk
     // of lead does not cover an HBM round trip under load
     constexpr int PF = 2;
@@ -186,30 +213,20 @@ __global__ __launch_bounds__(QG == 8 ? 512 : 256) void scan_tiles_kernel(ScanArg
       }
     }
 
-    uint32_t ynorm[SCAN_RV];
-    if (BYTES && METRIC == METRIC_L2) {
-#pragma unroll
-        for (int v = 0; v < SCAN_RV; v++) {
-            const int lv = vgi * SCAN_WAVE_VECS + v * 64 + lane;
-            ynorm[v] = lv < (int)it.nvec ? a.code_norms[it.vec_base + lv] : 0u;
-        }
-    }
     // With thresholds (a.thr: the heap top each query had when the round was planned) only the distances that can
     // still enter the heap are stored, and every 64-candidate chunk of a row gets a bit mask of those positions:
     // the replay kernel then reads 1 bit per candidate instead of 4 bytes, and the rest of the row never
     // leaves the chip.  Rows start on multiples of 64 floats in that mode.
-    const bool masked = a.thr != nullptr;
+    if (!has_queries) return;
 #pragma unroll
     for (int r = 0; r < SCAN_RQ; r++) {
         uint32_t local = (uint32_t)(qgi * SCAN_RQ + r);
         if (local < it.npair) {
-            const unsigned long long row = a.pair_out[it.pair_begin + local] + it.vec_off;
+            const unsigned long long row = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(e_row >> 32), r) << 32) |
+                                           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e_row, r);
             float* out = a.dist + row;
-            uint32_t qrow = 0;
-            if (masked || (BYTES && METRIC == METRIC_L2)) qrow = a.pair_query[it.pair_begin + local];
-            uint32_t xnorm = 0;
-            if (BYTES && METRIC == METRIC_L2) xnorm = a.query_norms[qrow];
-            const float thr = masked ? a.thr[qrow] : 0.f;
+            const uint32_t xnorm = (uint32_t)__builtin_amdgcn_readlane((int)e_xn, r);
+            const float thr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e_thr), r));
 #pragma unroll
             for (int v = 0; v < SCAN_RV; v++) {
                 const int lv0 = vgi * SCAN_WAVE_VECS + v * 64;
