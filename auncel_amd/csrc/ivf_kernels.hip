@@ -218,6 +218,9 @@ __global__ __launch_bounds__(QG == 8 ? 512 : 256) void scan_tiles_kernel(ScanArg
     // the replay kernel then reads 1 bit per candidate instead of 4 bytes, and the rest of the row never
     // leaves the chip.  Rows start on multiples of 64 floats in that mode.
     if (!has_queries) return;
+    // threshold mode: the 64-bit masks of the wave's SCAN_RQ x SCAN_RV chunks are parked in lanes r * SCAN_RV + v and
+    // stored by one instruction at the end (a predicated store per chunk costs more scalar work than the chunk's test)
+    uint32_t mk_lo = 0, mk_hi = 0;
 #pragma unroll
     for (int r = 0; r < SCAN_RQ; r++) {
         uint32_t local = (uint32_t)(qgi * SCAN_RQ + r);
@@ -238,11 +241,20 @@ __global__ __launch_bounds__(QG == 8 ? 512 : 256) void scan_tiles_kernel(ScanArg
                 if (masked) {
                     keep = keep && (METRIC == METRIC_L2 ? thr > res : thr < res);
                     const unsigned long long m = __ballot(keep);
-                    if (lane == 0 && lv0 < (int)it.nvec) a.mask[(row + lv0) >> 6] = m;
+                    const bool mine = lane == r * SCAN_RV + v;
+                    mk_lo = mine ? (uint32_t)m : mk_lo;
+                    mk_hi = mine ? (uint32_t)(m >> 32) : mk_hi;
                 }
                 if (keep) out[lv] = res;
             }
         }
+    }
+    if (masked && lane < SCAN_RQ * SCAN_RV) {
+        const int r = lane / SCAN_RV, v = lane % SCAN_RV;
+        const int lv0 = vgi * SCAN_WAVE_VECS + v * 64;
+        const unsigned long long row = __shfl(e_row, r);  // lane r holds the row offset of query r
+        if ((uint32_t)(qgi * SCAN_RQ + r) < it.npair && lv0 < (int)it.nvec)
+            a.mask[(row + lv0) >> 6] = ((unsigned long long)mk_hi << 32) | mk_lo;
     }
 }
 
