@@ -126,12 +126,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # BENCH_DIST_BACKEND=gloo BENCH_DEVICE=0: rehearsal of the multi-rank flow on a box with one GPU (all ranks on it)
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if "BENCH_DEVICE" in os.environ:
+        local = int(os.environ["BENCH_DEVICE"])
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the max-over-ranks reduction lives
 
     d, nlist, K, topk, ts, ses = args.d, args.nlist, args.maxtopk, args.topk, args.train, args.test
     t0 = time.time()
@@ -250,7 +258,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = {}
@@ -288,12 +296,14 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        # arithmetic of the dominant kernel: byte codes and integer dot products when the data is uint8-valued (bit-identical
+        # to the reference's fp32 results there), fp32 in the reference's summation order otherwise
+        "dtype": "u8" if h.scan_arith() == 2 else "f32",
         "data": "synthetic",
         "config": {
             "workload": f"SIFT-{args.nb // 1000000}M-like d={d} IVF{nlist},Flat max_topk={K} topk={topk} Auncel error-bound nprobe "
                         f"(bound {args.bound}), batch {ses} resident queries per GPU, index replicated per GPU",
-            "in_flight": nfl,
+            "in_flight": nfl, "scan_arith": {0: "fp32 reference order", 1: "fp32 fused", 2: "byte codes, v_dot4_u32_u8"}[h.scan_arith()],
             "nb": args.nb, "sigma": args.sigma, "multipler": chosen, "std_m": args.std_m,
             "recall_at_10_mean": float(rec.mean()), "recall_at_10_min": float(rec.min()),
             "nprobe_mean": float(my_np[ts:].mean()), "nprobe_max": int(my_np[ts:].max()),
