@@ -503,6 +503,9 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
     return x;
 }
 
+// largest error code raised by any lane (0 in the common case: one ballot, no shuffles)
+__device__ __forceinline__ uint32_t wave_err(uint32_t err) { return __ballot(err != 0) ? wave_max_u32(err) : 0u; }
+
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -613,7 +616,7 @@ template <bool IsMax> __device__ inline void rank_sort_best_first(const float* s
 
 // srt holds the k heap values best first.  A heap update replaces the worst value (the heap top,
 // == srt[k-1]) by `val`: shift the worse ones down by one slot and drop val into the gap.
-template <bool IsMax> __device__ inline void sorted_replace_worst(float* srt, int k, float val, int lane) {
+template <bool IsMax> __device__ inline int sorted_replace_worst(float* srt, int k, float val, int lane) {
     int pos = 0;
     for (int c = (k - 1) / 64; c >= 0; c--) {
         const int idx = c * 64 + lane;
@@ -627,6 +630,7 @@ template <bool IsMax> __device__ inline void sorted_replace_worst(float* srt, in
     }
     srt[pos] = val;
     wave_sync();
+    return pos;  // where val landed in the best-first order
 }
 
 // error_pro::sum_angle (IVF_pro.cpp:162-177), n = 15: the 15 terms on 15 lanes, then summed in the
@@ -814,6 +818,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
     float true_KD_K = 0.f, racc = 0.f;
     unsigned long long np = 0;
     int cached_ind = -1;
+    // cur_num is a pure function of the trace / window of `ind` and of the query_k best heap values: its value is kept
+    // until one of them changes (in the later rounds most probes leave the best values alone)
+    bool have_pre = false, top_changed = true, srt_changed = true;
+    uint32_t kept_pre = 0;
     TraceLds tr{trc, trc + a.trace_cap, 0};
     if (tune) {
         query_k = a.tuner.query_topk;
@@ -1011,12 +1019,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
                 if (a.dbg) dbg_stream += __builtin_readcyclecounter() - dbg_s0;
                 if (geo && npend) {
                     wave_sync();
+                    srt_changed = true;
                     if (npend <= 16) {
-                        for (uint32_t u = 0; u < npend; u++) sorted_replace_worst<IsMax>(srt, k, pend[u], lane);
+                        for (uint32_t u = 0; u < npend; u++)
+                            if (sorted_replace_worst<IsMax>(srt, k, pend[u], lane) < (int)query_k) top_changed = true;
                     } else {
                         if (RH) rh_store(rh, hval, href, k, lane, false);
                         rank_sort_best_first<IsMax>(hval, srt, k, lane);
                         wave_sync();
+                        top_changed = true;
                     }
                 }
                 nscan += n;
@@ -1049,20 +1060,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
                     if (lane < 15) dwin[lane] = gdtb[(1u << ind) - 1 + lane];  // sum_angle start = 2^ind - 1
                     tr.n = n;
                     cached_ind = (int)ind;
+                    have_pre = false;
                     wave_sync();
                 }
-                if (!IsMax) {
+                if (!IsMax && srt_changed) {
                     // the reference converts all k heap values (IndexIVF.cpp:562-564): any out-of-domain one throws
                     for (int i = lane; i < k; i += 64) (void)arcos_lut(lut, srt[i], &err);
-                    err = wave_max_u32(err);
+                    err = wave_err(err);
                     if (err) {
                         finished = true;
                         break;
                     }
                 }
-                dbg_evals++;
-                const uint32_t pre_num = query_k <= CURNUM_PAR_MAXK ? cur_num_par<IsMax>(tr, lut, srt, dwin, terms, query_k, lane, &err)
-                                                                    : cur_num_lds<IsMax>(tr, lut, srt, dwin, query_k, lane, &err);
+                srt_changed = false;
+                if (!have_pre || top_changed) {
+                    dbg_evals++;
+                    kept_pre = query_k <= CURNUM_PAR_MAXK ? cur_num_par<IsMax>(tr, lut, srt, dwin, terms, query_k, lane, &err)
+                                                          : cur_num_lds<IsMax>(tr, lut, srt, dwin, query_k, lane, &err);
+                    have_pre = true;
+                    top_changed = false;
+                }
+                const uint32_t pre_num = kept_pre;
                 float recall = (float)pre_num / (float)query_k;
                 const float max_val = IsMax ? fmaxf(-1.f, srt[k - 1]) : fminf(FLT_MAX, srt[k - 1]);
                 const unsigned long long stops = (unsigned long long)(racc * 12);
@@ -1080,7 +1098,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
                     np = (unsigned long long)((float)stage * a.tuner.multipler);
                     if (np >= nlist && lane == 0) a.tuner.t_recalls[id_q] = 1.f;
                 }
-                err = wave_max_u32(err);
+                err = wave_err(err);
                 if (err) finished = true;
             }
             if (np != 0 && np <= stage) {
@@ -1128,12 +1146,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
                     count++;
                     if (count >= (uint32_t)(k / 4)) break;
                 }
-                err = wave_max_u32(err);
+                err = wave_err(err);
                 if (err) finished = true;
             }
         }
     }
-    err = wave_max_u32(err);
+    err = wave_err(err);
 
     if (lane == 0) {
         a.stage[qi] = ik0 + consumed;
