@@ -453,6 +453,47 @@ template <bool IsMax, int KC> __device__ __forceinline__ void rh_pop(RegHeap& h,
     rh_set(h, i, v, sv);
 }
 
+// The same walk for k = 100, written out in assembly: the compiler's structured control flow spends five scalar
+// instructions per level on exit flags; here a level is 9 scalar + 5 vector instructions and one branch.  Levels 0-4
+// (children in register 0, all present), then level 5 (children 64..100 in register 1; node 50 has the left child only,
+// which the equal-keys case of the selection handles: both reads name the same lane and the "right" pick is that lane).
+#define RH_ASM_LEVEL(MAXOP, CMPOP)                                                                                      \
+    "s_lshl_b32 %[a], %[i], 1\n\ts_or_b32 %[b], %[a], 1\n\tv_readlane_b32 %[k1], %[v0], %[a]\n\tv_readlane_b32 %[k2], %[v0], %[b]\n\t" \
+    MAXOP " %[c], %[k1], %[k2]\n\t" CMPOP " %[v], %[c]\n\ts_cbranch_scc1 9f\n\t" CMPOP " %[k1], %[k2]\n\ts_cselect_b32 %[a], %[a], %[b]\n\t" \
+    "v_readlane_b32 %[cs], %[s0], %[a]\n\ts_mov_b32 m0, %[i]\n\ts_nop 0\n\tv_writelane_b32 %[v0], %[c], m0\n\t"                       \
+    "v_writelane_b32 %[s0], %[cs], m0\n\ts_mov_b32 %[i], %[a]\n\t"
+#define RH_ASM_LAST(MAXOP, CMPOP)                                                                                       \
+    "s_cmp_gt_u32 %[i], 50\n\ts_cbranch_scc1 9f\n\ts_lshl_b32 %[a], %[i], 1\n\ts_sub_u32 %[a], %[a], 64\n\ts_or_b32 %[b], %[a], 1\n\t"     \
+    "s_cmp_eq_u32 %[i], 50\n\ts_cselect_b32 %[b], %[a], %[b]\n\tv_readlane_b32 %[k1], %[v1], %[a]\n\tv_readlane_b32 %[k2], %[v1], %[b]\n\t" \
+    MAXOP " %[c], %[k1], %[k2]\n\t" CMPOP " %[v], %[c]\n\ts_cbranch_scc1 9f\n\t" CMPOP " %[k1], %[k2]\n\ts_cselect_b32 %[a], %[a], %[b]\n\t" \
+    "v_readlane_b32 %[cs], %[s1], %[a]\n\ts_mov_b32 m0, %[i]\n\ts_nop 0\n\tv_writelane_b32 %[v0], %[c], m0\n\t"                       \
+    "v_writelane_b32 %[s0], %[cs], m0\n\ts_add_u32 %[i], %[a], 64\n\t"                                                 \
+    "9:\n\t"
+template <bool IsMax> __device__ __forceinline__ void rh_pop_k100(RegHeap& h) {
+    const uint32_t v = rl_u(h.v1, 100 - 64);
+    const uint32_t sv = rl_u(h.s1, 100 - 64);
+    int i = 1;
+    uint32_t a, b, k1, k2, c, cs;
+    if (IsMax) {
+        asm volatile(RH_ASM_LEVEL("s_max_u32", "s_cmp_gt_u32") RH_ASM_LEVEL("s_max_u32", "s_cmp_gt_u32") RH_ASM_LEVEL("s_max_u32", "s_cmp_gt_u32")
+                         RH_ASM_LEVEL("s_max_u32", "s_cmp_gt_u32") RH_ASM_LEVEL("s_max_u32", "s_cmp_gt_u32") RH_ASM_LAST("s_max_u32", "s_cmp_gt_u32")
+                     : [i] "+s"(i), [v0] "+v"(h.v0), [s0] "+v"(h.s0), [a] "=&s"(a), [b] "=&s"(b), [k1] "=&s"(k1), [k2] "=&s"(k2),
+                       [c] "=&s"(c), [cs] "=&s"(cs)
+                     : [v] "s"(v), [v1] "v"(h.v1), [s1] "v"(h.s1)
+                     : "m0", "scc");
+    } else {
+        asm volatile(RH_ASM_LEVEL("s_min_u32", "s_cmp_lt_u32") RH_ASM_LEVEL("s_min_u32", "s_cmp_lt_u32") RH_ASM_LEVEL("s_min_u32", "s_cmp_lt_u32")
+                         RH_ASM_LEVEL("s_min_u32", "s_cmp_lt_u32") RH_ASM_LEVEL("s_min_u32", "s_cmp_lt_u32") RH_ASM_LAST("s_min_u32", "s_cmp_lt_u32")
+                     : [i] "+s"(i), [v0] "+v"(h.v0), [s0] "+v"(h.s0), [a] "=&s"(a), [b] "=&s"(b), [k1] "=&s"(k1), [k2] "=&s"(k2),
+                       [c] "=&s"(c), [cs] "=&s"(cs)
+                     : [v] "s"(v), [v1] "v"(h.v1), [s1] "v"(h.s1)
+                     : "m0", "scc");
+    }
+    rh_set(h, i, v, sv);
+}
+#undef RH_ASM_LEVEL
+#undef RH_ASM_LAST
+
 // Heap.h:125-142
 template <bool IsMax, int KC> __device__ __forceinline__ void rh_push(RegHeap& h, int krt, uint32_t v, uint32_t sv) {
     int i = KC ? KC : krt;
@@ -801,6 +842,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
     uint32_t stoped = a.stoped ? a.stoped[qi] : 0u;
     unsigned long long st_nlist = 0, st_nheap = 0, st_ndis = 0;
 
+    constexpr bool asm_off = false;  // true: the C++ walk for k = 100 too
     RegHeap rh{};
     if (RH) rh_load(rh, hval, k, lane);
 
@@ -994,7 +1036,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
                                 if (RH) {
                                     const uint32_t sr = rl_u(rh.s0, 1);  // the evicted root's id slot passes to the new entry
                                     if (lane == 0) href[sr] = nref;
-                                    rh_pop<IsMax, KC>(rh, k);
+                                    if (KC == 100 && !asm_off) rh_pop_k100<IsMax>(rh);
+                                    else rh_pop<IsMax, KC>(rh, k);
                                     rh_push<IsMax, KC>(rh, k, fkey(val), sr);
                                     top = fkey_inv(rl_u(rh.v0, 1));
                                 } else {
