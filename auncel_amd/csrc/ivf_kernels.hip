@@ -419,9 +419,16 @@ __device__ __forceinline__ uint32_t rh_slot(const RegHeap& h, int node) {
     const uint32_t a = rl_u(h.s0, node & 63), b = rl_u(h.s1, node & 63);
     return node < 64 ? a : b;
 }
+// node <- (key, slot); the register is picked by one branch (in C++ the compiler copies both registers around it)
 __device__ __forceinline__ void rh_set(RegHeap& h, int node, uint32_t key, uint32_t slot) {
-    if (node < 64) wl2_u(h.v0, key, h.s0, slot, node);
-    else wl2_u(h.v1, key, h.s1, slot, node - 64);
+    asm volatile(
+        "s_cmp_gt_u32 %[n], 63\n\ts_cbranch_scc1 1f\n\t"
+        "s_mov_b32 m0, %[n]\n\ts_nop 0\n\tv_writelane_b32 %[v0], %[k], m0\n\tv_writelane_b32 %[s0], %[s], m0\n\ts_branch 2f\n"
+        "1:\n\ts_sub_u32 m0, %[n], 64\n\ts_nop 0\n\tv_writelane_b32 %[v1], %[k], m0\n\tv_writelane_b32 %[s1], %[s], m0\n"
+        "2:\n\t"
+        : [v0] "+v"(h.v0), [s0] "+v"(h.s0), [v1] "+v"(h.v1), [s1] "+v"(h.s1)
+        : [n] "s"(node), [k] "s"(key), [s] "s"(slot)
+        : "m0", "scc");
 }
 
 // Heap.h:88-118 (the node being removed, k, still takes part in the child comparisons, as there).
