@@ -515,6 +515,29 @@ template <bool IsMax, int KC> __device__ __forceinline__ void rh_push(RegHeap& h
     rh_set(h, i, v, sv);
 }
 
+// Heap.h:125-142 for k = 100: the ancestors of node 100 are fixed (50, 25, 12, 6, 3, 1), a new value rarely climbs
+// past the first
+template <bool IsMax> __device__ __forceinline__ void rh_push_k100(RegHeap& h, uint32_t v, uint32_t sv) {
+    int i = 100;
+#define RH_PUSH_STEP(F)                         \
+    {                                           \
+        const uint32_t fv = rl_u(h.v0, F);      \
+        if (!kcmp<IsMax>(v, fv)) goto done;     \
+        const uint32_t fs = rl_u(h.s0, F);      \
+        rh_set(h, i, fv, fs);                   \
+        i = F;                                  \
+    }
+    RH_PUSH_STEP(50)
+    RH_PUSH_STEP(25)
+    RH_PUSH_STEP(12)
+    RH_PUSH_STEP(6)
+    RH_PUSH_STEP(3)
+    RH_PUSH_STEP(1)
+#undef RH_PUSH_STEP
+done:
+    rh_set(h, i, v, sv);
+}
+
 // LDS heap arrays (node order) -> registers; slot j holds the id of node j + 1
 __device__ __forceinline__ void rh_load(RegHeap& h, const float* hval, int k, int lane) {
     h.v0 = (lane >= 1 && lane <= k) ? fkey(hval[lane - 1]) : 0u;
@@ -1045,7 +1068,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
                                     if (lane == 0) href[sr] = nref;
                                     if (KC == 100 && !asm_off) rh_pop_k100<IsMax>(rh);
                                     else rh_pop<IsMax, KC>(rh, k);
-                                    rh_push<IsMax, KC>(rh, k, fkey(val), sr);
+                                    if (KC == 100 && !asm_off) rh_push_k100<IsMax>(rh, fkey(val), sr);
+                                    else rh_push<IsMax, KC>(rh, k, fkey(val), sr);
                                     top = fkey_inv(rl_u(rh.v0, 1));
                                 } else {
                                     heap_pop<IsMax>(k, hval, href);
