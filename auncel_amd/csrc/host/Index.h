@@ -41,6 +41,11 @@ struct Index {
     /// all vectors within `radius` of each query (Index.h:106-117); only the IVF classes implement it here
     virtual void range_search(idx_t n, const float* x, float radius, RangeSearchResult* result) const;
     virtual void reset() = 0;
+    /// stored vector of one id / a range of ids, search + stored vectors of the results (Index.h:119-157); only the IVF
+    /// classes implement them here
+    virtual void reconstruct(idx_t key, float* recons) const;
+    virtual void reconstruct_n(idx_t i0, idx_t ni, float* recons) const;
+    virtual void search_and_reconstruct(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels, float* recons) const;
     /// nearest-neighbour labels only (Index.cpp:42-48)
     void assign(idx_t n, const float* x, idx_t* labels, idx_t k = 1);
 };

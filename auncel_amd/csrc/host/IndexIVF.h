@@ -73,6 +73,13 @@ struct IndexIVF : Index, Level1Quantizer {
     /// Auncel overload: `offset` = absolute id of query 0 (IndexIVF.cpp:355-378)
     void search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels, size_t offset) const;
 
+    /// IndexIVF.cpp:305-328,869-945
+    void make_direct_map(bool new_maintain_direct_map = true);
+    void reconstruct(idx_t key, float* recons) const override;
+    void reconstruct_n(idx_t i0, idx_t ni, float* recons) const override;
+    void search_and_reconstruct(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels, float* recons) const override;
+    virtual void reconstruct_from_offset(idx_t list_no, idx_t offset, float* recons) const;
+
     /// IndexIVF.cpp:740-857
     void range_search(idx_t n, const float* x, float radius, RangeSearchResult* result) const override;
     void range_search_preassigned(idx_t nx, const float* x, float radius, const idx_t* keys, const float* coarse_dis,

@@ -11,6 +11,7 @@ struct IndexIVFFlat : IndexIVF {
     /// precomputed_idx: list numbers from a previous assignment, entries < 0 skipped (IndexIVFFlat.cpp:41-80)
     virtual void add_core(idx_t n, const float* x, const long* xids, const long* precomputed_idx);
     void add_with_ids(idx_t n, const float* x, const long* xids) override;
+    void reconstruct_from_offset(idx_t list_no, idx_t offset, float* recons) const override;  ///< IndexIVFFlat.cpp:226-230
 };
 
 }  // namespace faiss

@@ -620,6 +620,85 @@ void IndexIVF::search_preassigned(idx_t n, const float* x, idx_t k, const idx_t*
     fold_stats();
 }
 
+// ---- stored vectors back (IndexIVF.cpp:305-328,869-945, IndexIVFFlat.cpp:226-230)
+void Index::reconstruct(idx_t, float*) const { FAISS_THROW_MSG("reconstruct not implemented for this type of index"); }
+void Index::reconstruct_n(idx_t i0, idx_t ni, float* recons) const {
+    for (idx_t i = 0; i < ni; i++) reconstruct(i0 + i, recons + i * d);
+}
+void Index::search_and_reconstruct(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels, float* recons) const {
+    search(n, x, k, distances, labels);
+    for (idx_t i = 0; i < n; ++i)
+        for (idx_t j = 0; j < k; ++j) {
+            const idx_t ij = i * k + j, key = labels[ij];
+            float* reconstructed = recons + ij * d;
+            if (key < 0) memset(reconstructed, -1, sizeof(*reconstructed) * d);  // NaNs, as the reference fills them
+            else reconstruct(key, reconstructed);
+        }
+}
+
+void IndexIVF::make_direct_map(bool new_maintain_direct_map) {
+    if (new_maintain_direct_map == maintain_direct_map) return;
+    if (new_maintain_direct_map) {
+        direct_map.resize(ntotal, -1);
+        for (size_t key = 0; key < nlist; key++) {
+            const size_t list_size = invlists->list_size(key);
+            const idx_t* idlist = invlists->get_ids(key);
+            for (long ofs = 0; ofs < (long)list_size; ofs++) {
+                FAISS_THROW_IF_NOT_MSG(0 <= idlist[ofs] && idlist[ofs] < ntotal, "direct map supported only for seuquential ids");
+                direct_map[idlist[ofs]] = (long)key << 32 | ofs;
+            }
+        }
+    } else {
+        direct_map.clear();
+    }
+    maintain_direct_map = new_maintain_direct_map;
+}
+
+void IndexIVF::reconstruct(idx_t key, float* recons) const {
+    FAISS_THROW_IF_NOT_MSG((idx_t)direct_map.size() == ntotal, "direct map is not initialized");
+    FAISS_THROW_IF_NOT_MSG(key >= 0 && key < (idx_t)direct_map.size(), "invalid key");
+    reconstruct_from_offset(direct_map[key] >> 32, direct_map[key] & 0xffffffff, recons);
+}
+
+void IndexIVF::reconstruct_n(idx_t i0, idx_t ni, float* recons) const {
+    FAISS_THROW_IF_NOT(ni == 0 || (i0 >= 0 && i0 + ni <= ntotal));
+    for (size_t list_no = 0; list_no < nlist; list_no++) {
+        const size_t list_size = invlists->list_size(list_no);
+        const idx_t* idlist = invlists->get_ids(list_no);
+        for (size_t offset = 0; offset < list_size; offset++) {
+            const idx_t id = idlist[offset];
+            if (!(id >= i0 && id < i0 + ni)) continue;
+            reconstruct_from_offset((idx_t)list_no, (idx_t)offset, recons + (id - i0) * d);
+        }
+    }
+}
+
+void IndexIVF::search_and_reconstruct(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels, float* recons) const {
+    std::vector<idx_t> idx(n * nprobe);
+    std::vector<float> coarse_dis(n * nprobe);
+    quantizer->search(n, x, nprobe, coarse_dis.data(), idx.data());
+    // store_pairs: (list_no << 32 | offset) instead of ids, to find the codes
+    search_preassigned(n, x, k, idx.data(), coarse_dis.data(), distances, labels, true);
+    for (idx_t i = 0; i < n; ++i)
+        for (idx_t j = 0; j < k; ++j) {
+            const idx_t ij = i * k + j, key = labels[ij];
+            float* reconstructed = recons + ij * d;
+            if (key < 0) {
+                memset(reconstructed, -1, sizeof(*reconstructed) * d);
+            } else {
+                const long list_no = key >> 32, offset = key & 0xffffffff;
+                labels[ij] = invlists->get_ids(list_no)[offset];
+                reconstruct_from_offset(list_no, offset, reconstructed);
+            }
+        }
+}
+
+void IndexIVF::reconstruct_from_offset(idx_t, idx_t, float*) const { FAISS_THROW_MSG("reconstruct_from_offset not implemented"); }
+
+void IndexIVFFlat::reconstruct_from_offset(idx_t list_no, idx_t offset, float* recons) const {
+    memcpy(recons, invlists->get_codes(list_no) + (size_t)offset * code_size, code_size);
+}
+
 // ---- range search (IndexIVF.cpp:740-857, AuxIndexStructures.cpp:26-60)
 RangeSearchResult::RangeSearchResult(idx_t nq, bool alloc_lims) : nq((size_t)nq), lims(nullptr), labels(nullptr), distances(nullptr), buffer_size(1024 * 256) {
     if (alloc_lims) {

@@ -94,6 +94,32 @@ static int run_fixed(const tb::Bundle& in) {
         }
     }
 
+    {   // search_and_reconstruct / reconstruct_n / make_direct_map + reconstruct (IndexIVF.cpp:305-328,869-938)
+        const size_t k = ks.as<int64_t>()[0];
+        std::vector<float> D(nq * k), R(nq * k * d);
+        std::vector<idx_t> I(nq * k);
+        index->search_and_reconstruct(nq, xq.as<float>(), k, D.data(), I.data(), R.data());
+        expect(same_i(I.data(), in.get("I_k" + std::to_string(k)).as<int64_t>(), nq * k), "search_and_reconstruct ids");
+        bool rec_ok = true;
+        for (size_t i = 0; i < nq * k; i++) {
+            if (I[i] < 0) {
+                for (size_t j = 0; j < d; j++) rec_ok &= std::isnan(R[i * d + j]);
+            } else {
+                rec_ok &= memcmp(&R[i * d], xb.as<float>() + (size_t)I[i] * d, d * sizeof(float)) == 0;
+            }
+        }
+        expect(rec_ok, "search_and_reconstruct vectors");
+        const size_t n0 = nb / 3, nn = std::min<size_t>(50, nb - n0);
+        std::vector<float> rn(nn * d);
+        index->reconstruct_n(n0, nn, rn.data());
+        expect(memcmp(rn.data(), xb.as<float>() + n0 * d, nn * d * sizeof(float)) == 0, "reconstruct_n");
+        ix->make_direct_map(true);
+        std::vector<float> r1(d);
+        index->reconstruct((idx_t)(nb - 1), r1.data());
+        expect(memcmp(r1.data(), xb.as<float>() + (nb - 1) * d, d * sizeof(float)) == 0, "reconstruct via direct map");
+        ix->make_direct_map(false);
+    }
+
     if (in.has("range_lims") && d % 4 == 0) {  // IndexIVF::range_search through the class mirror (RangeSearchResult as in the reference)
         const float radius = in.get("radius").as<float>()[0];
         RangeSearchResult res(nq);
