@@ -1314,7 +1314,8 @@ void launch_replay(const ReplayArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(kern, grid, block, shmem, s, a);
     };
     // few queries: longer trips (more loads in flight per wave) at the price of fewer resident waves
-    static const int nld_env = getenv("AUNCEL_AMD_REPLAY_NLD") ? atoi(getenv("AUNCEL_AMD_REPLAY_NLD")) : 0;
+    const char* nld_s = getenv("AUNCEL_AMD_REPLAY_NLD");  // read per launch: the tests run both variants in one process
+    const int nld_env = nld_s ? atoi(nld_s) : 0;
     const bool wide = nld_env ? nld_env >= 32 : a.nq <= 3072;
     auto pick = [&](auto is_max) {
         constexpr bool M = decltype(is_max)::value;
