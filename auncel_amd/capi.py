@@ -24,6 +24,7 @@ SYMBOLS = [
     "amd_ivf_set_tuner", "amd_ivf_search_adaptive", "amd_ivf_search_adaptive_x", "amd_ivf_train_samples",
     "amd_ivf_train_samples_x", "amd_ivf_trace_sb", "amd_ivf_arcos_table", "amd_ivf_merge_tables",
     "amd_ivf_last_timing",
+    "amd_ivf_kmeans",
     "amd_ivf_range_search_preassigned", "amd_ivf_range_search", "amd_ivf_range_results",
     "amd_ivf_scan_arith",
 ]
@@ -74,6 +75,19 @@ def device_count():
     n = C.c_int(0)
     _chk(lib().amd_ivf_device_count(C.byref(n)))
     return n.value
+
+
+def kmeans(metric, x, k, niter=25, seed=1234, max_points_per_centroid=256, spherical=False, int_centroids=False, coarse_mode=0,
+           device=0):
+    """Clustering::train on the GPU (include/auncel_amd.h: amd_ivf_kmeans) -> centroids (k, d), objective per iteration"""
+    x = f32(x)
+    n, d = x.shape
+    cen = np.zeros((k, d), np.float32)
+    obj = np.zeros(niter, np.float32)
+    _chk(lib().amd_ivf_kmeans(int(d), C.c_size_t(n), _f(x), C.c_size_t(k), int(metric), int(niter), C.c_long(seed),
+                              C.c_size_t(max_points_per_centroid), int(spherical), int(int_centroids), int(coarse_mode), int(device),
+                              _f(cen), _f(obj)))
+    return cen, obj
 
 
 def merge_tables(metric, all_D, all_I):

@@ -14,6 +14,7 @@
 #include <stdexcept>
 
 #include "../../../include/auncel_amd.h"
+#include "../kmeans_host.h"
 #include "AutoTune.h"
 #include "AuxIndexStructures.h"
 #include "FaissAssert.h"
@@ -192,21 +193,9 @@ Level1Quantizer::~Level1Quantizer() {
 
 // ---- Clustering (Clustering.cpp:36-256, utils.cpp:111-137,229-239,1078-1159)
 namespace {
-struct RefRng {  // RandomGenerator
-    std::mt19937 mt;
-    explicit RefRng(long seed) : mt((unsigned int)seed) {}
-    int rand_int(int max) { return mt() % max; }
-    float rand_float() { return mt() / float(mt.max()); }
-};
-void ref_rand_perm(int* perm, size_t n, long seed) {
-    for (size_t i = 0; i < n; i++) perm[i] = (int)i;
-    RefRng rng(seed);
-    for (size_t i = 0; i + 1 < n; i++) {
-        int i2 = (int)i + rng.rand_int((int)(n - i));
-        std::swap(perm[i], perm[i2]);
-    }
-}
-// centroid = fp32 sum of its points in point order / count; void clusters are split off bigger ones
+namespace km = amdivf_kmeans;
+// centroid = fp32 sum of its points in point order / count; void clusters are split off bigger ones (host version, for
+// an assignment index that is not an IndexFlat; the IndexFlat case runs in the engine, amd_ivf_kmeans)
 int km_update_centroids(const float* x, float* centroids, const long* assign, size_t d, size_t k, size_t n, size_t k_frozen) {
     k -= k_frozen;
     centroids += k_frozen * d;
@@ -226,72 +215,38 @@ int km_update_centroids(const float* x, float* centroids, const long* assign, si
         if (ni != 0)
             for (size_t j = 0; j < d; j++) c[j] /= ni;
     }
-    size_t nsplit = 0;
-    RefRng rng(1234);
-    const double EPS = 1 / 1024.;
-    for (size_t ci = 0; ci < k; ci++) {
-        if (hassign[ci] == 0) {
-            size_t cj;
-            for (cj = 0; 1; cj = (cj + 1) % k) {
-                float p = (hassign[cj] - 1.0) / (float)(n - k);
-                float r = rng.rand_float();
-                if (r < p) break;
-            }
-            memcpy(centroids + ci * d, centroids + cj * d, sizeof(*centroids) * d);
-            for (size_t j = 0; j < d; j++) {
-                if (j % 2 == 0) {
-                    centroids[ci * d + j] *= 1 + EPS;
-                    centroids[cj * d + j] *= 1 - EPS;
-                } else {
-                    centroids[ci * d + j] *= 1 - EPS;
-                    centroids[cj * d + j] *= 1 + EPS;
-                }
-            }
-            hassign[ci] = hassign[cj] / 2;
-            hassign[cj] -= hassign[ci];
-            nsplit++;
-        }
-    }
-    return (int)nsplit;
-}
-// fvec_norm_L2sqr in the reference's SSE order (utils_simd.cpp:137-155)
-float norm_L2sqr_sse(const float* x, size_t d) {
-    float s[4] = {0, 0, 0, 0};
-    size_t i = 0;
-    for (; i + 4 <= d; i += 4)
-        for (int l = 0; l < 4; l++) s[l] += x[i + l] * x[i + l];
-    for (int l = 0; i + l < d; l++) s[l] += x[i + l] * x[i + l];
-    return (s[0] + s[1]) + (s[2] + s[3]);
+    return km::split_void_clusters(centroids, hassign, d, k, n);
 }
 }  // namespace
 
 Clustering::Clustering(int d, int k) : d(d), k(k) {}
 Clustering::Clustering(int d, int k, const ClusteringParameters& cp) : ClusteringParameters(cp), d(d), k(k) {}
 
-void Clustering::post_process_centroids() {
-    if (spherical) {  // fvec_renorm_L2 (utils.cpp:377-392)
-        for (size_t i = 0; i < k; i++) {
-            float* xi = centroids.data() + i * d;
-            float nr = norm_L2sqr_sse(xi, d);
-            if (nr > 0) {
-                const float inv_nr = 1.0 / sqrtf(nr);
-                for (size_t j = 0; j < d; j++) xi[j] *= inv_nr;
-            }
-        }
-    }
-    if (int_centroids)
-        for (size_t i = 0; i < centroids.size(); i++) centroids[i] = roundf(centroids[i]);
-}
+void Clustering::post_process_centroids() { km::post_process(centroids.data(), d, k, spherical, int_centroids); }
 
 void Clustering::train(idx_t nx, const float* x_in, Index& index) {
     FAISS_THROW_IF_NOT_MSG(nx >= (idx_t)k, "Number of training points should be at least as large as number of clusters");
     for (size_t i = 0; i < (size_t)nx * d; i++) FAISS_THROW_IF_NOT_MSG(std::isfinite(x_in[i]), "input contains NaN's or Inf's");
+    if (IndexFlat* fl = dynamic_cast<IndexFlat*>(&index)) {
+        // the whole procedure on the device (training set resident, assignment + centroid update on the GPU)
+        if (nredo == 1 && centroids.empty() && !update_index && fl->d == (int)d) {
+            centroids.resize(d * k);
+            const size_t o = obj.size();
+            obj.resize(o + niter);
+            AMD(amd_ivf_kmeans((int)d, (size_t)nx, x_in, k, (int)fl->metric_type, niter, seed, (size_t)max_points_per_centroid,
+                               spherical ? 1 : 0, int_centroids ? 1 : 0, fl->coarse_mode, device_id(), centroids.data(), obj.data() + o));
+            if ((size_t)nx == k) obj.resize(o);  // the corner case copies the training set and records no objective
+            index.reset();
+            index.add(k, centroids.data());
+            return;
+        }
+    }
     const float* x = x_in;
     std::vector<float> sub;
     if ((size_t)nx > k * max_points_per_centroid) {
         if (verbose) printf("Sampling a subset of %ld / %ld for training\n", (long)(k * max_points_per_centroid), (long)nx);
         std::vector<int> perm(nx);
-        ref_rand_perm(perm.data(), nx, seed);
+        km::rand_perm(perm.data(), nx, seed);
         nx = k * max_points_per_centroid;
         sub.resize((size_t)nx * d);
         for (idx_t i = 0; i < nx; i++) memcpy(&sub[i * d], x_in + (size_t)perm[i] * d, sizeof(float) * d);
@@ -315,7 +270,7 @@ void Clustering::train(idx_t nx, const float* x_in, Index& index) {
     for (int redo = 0; redo < nredo; redo++) {
         centroids.resize(d * k);
         std::vector<int> perm(nx);
-        ref_rand_perm(perm.data(), nx, seed + 1 + redo * 15486557L);
+        km::rand_perm(perm.data(), nx, seed + 1 + redo * 15486557L);
         for (size_t i = n_input_centroids; i < k; i++) memcpy(&centroids[i * d], x + (size_t)perm[i] * d, d * sizeof(float));
         post_process_centroids();
         if (index.ntotal != 0) index.reset();

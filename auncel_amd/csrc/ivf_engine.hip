@@ -19,6 +19,7 @@
 
 #include "../../include/auncel_amd.h"
 #include "ivf_kernels.h"
+#include "kmeans_host.h"
 
 using namespace amdivf;
 
@@ -2295,6 +2296,90 @@ int amd_ivf_merge_tables(int metric, size_t n, size_t k, size_t nshard, const fl
                 if ((size_t)p < k && Iin[stride * s + p] >= 0) push(Din[stride * s + p], s);
             }
         }
+    }
+    API_END
+}
+
+// Clustering::train over an IndexFlat (Clustering.cpp:75-226) with the training set resident on the device: every
+// iteration's assignment runs through the coarse kernels, the centroid update through ivf_kmeans.hip (fp32 sums in point
+// order); what is sequential in the reference -- permutations, the objective's running sum, void-cluster splitting -- stays
+// on the host (kmeans_host.h).
+int amd_ivf_kmeans(int d, size_t n, const float* x_in, size_t k, int metric, int niter, long seed, size_t max_points_per_centroid,
+                   int spherical, int int_centroids, int coarse_mode, int device, float* centroids, float* obj) {
+    API_BEGIN
+    namespace km = amdivf_kmeans;
+    if (d <= 0 || k == 0) throw EngineError("bad dimension / k");
+    if (n < k) throw EngineError("Number of training points should be at least as large as number of clusters");
+    const float* x = x_in;
+    std::vector<float> sub;
+    size_t nx = n;
+    if (nx > k * max_points_per_centroid) {
+        std::vector<int> perm(nx);
+        km::rand_perm(perm.data(), nx, seed);
+        nx = k * max_points_per_centroid;
+        sub.resize(nx * (size_t)d);
+        for (size_t i = 0; i < nx; i++) memcpy(&sub[i * d], x_in + (size_t)perm[i] * d, sizeof(float) * d);
+        x = sub.data();
+    }
+    if (nx == k) {  // the reference's corner case: the training set becomes the centroids
+        memcpy(centroids, x_in, sizeof(float) * (size_t)d * k);
+        return 0;
+    }
+    {
+        std::vector<int> perm(nx);
+        km::rand_perm(perm.data(), nx, seed + 1);
+        for (size_t i = 0; i < k; i++) memcpy(centroids + i * d, x + (size_t)perm[i] * d, d * sizeof(float));
+    }
+    km::post_process(centroids, d, k, spherical != 0, int_centroids != 0);
+
+    amd_ivf_t* raw = nullptr;
+    if (amd_ivf_create(d, k, metric, device, &raw)) throw EngineError(g_last_error);
+    std::unique_ptr<amd_ivf> h(raw);
+    use_device(h.get());
+    hipStream_t s = h->stream;
+    const size_t dpad = h->dpad;
+    h->d_resident.ensure(nx * dpad * sizeof(float));
+    upload_rows(h.get(), h->d_resident.as<float>(), x, nx);
+    IntRange qr;
+    qr.add(x, nx * (size_t)d);
+    DevBuf d_dis, d_keys, keys_in, keys_out, idx_in, idx_out, counts, seg, temp, d_cen;
+    d_dis.ensure(nx * 4);
+    d_keys.ensure(nx * 8);
+    keys_in.ensure(nx * 4);
+    keys_out.ensure(nx * 4);
+    idx_in.ensure(nx * 4);
+    idx_out.ensure(nx * 4);
+    counts.ensure(k * 4);
+    seg.ensure((k + 1) * 4);
+    const size_t temp_bytes = kmeans_sort_temp_bytes(nx);
+    temp.ensure(std::max<size_t>(temp_bytes, 16));
+    d_cen.ensure(k * (size_t)d * 4);
+    std::vector<float> dis(nx);
+    std::vector<uint32_t> cnt(k), off(k + 1);
+    std::vector<size_t> hassign(k);
+    for (int it = 0; it < niter; it++) {
+        if (amd_ivf_set_centroids(h.get(), centroids)) throw EngineError(g_last_error);
+        coarse_dev(h.get(), h->d_resident.as<float>(), nx, 1, coarse_mode, d_dis.as<float>(), d_keys.as<int64_t>(),
+                   h->allow_fused && h->centroid_range.fusable_with(qr));
+        HIP_CHECK(hipMemcpyAsync(dis.data(), d_dis.p, nx * 4, hipMemcpyDeviceToHost, s));
+        launch_kmeans_group(d_keys.as<int64_t>(), nx, (uint32_t)k, keys_in.as<uint32_t>(), keys_out.as<uint32_t>(), idx_in.as<uint32_t>(),
+                            idx_out.as<uint32_t>(), counts.as<uint32_t>(), temp.p, temp_bytes, s);
+        HIP_CHECK(hipMemcpyAsync(cnt.data(), counts.p, k * 4, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        float err = 0;  // the reference's running fp32 sum, in point order
+        for (size_t j = 0; j < nx; j++) err += dis[j];
+        if (obj) obj[it] = err;
+        off[0] = 0;
+        for (size_t c = 0; c < k; c++) {
+            off[c + 1] = off[c] + cnt[c];
+            hassign[c] = cnt[c];
+        }
+        HIP_CHECK(hipMemcpyAsync(seg.p, off.data(), (k + 1) * 4, hipMemcpyHostToDevice, s));
+        launch_kmeans_sums(h->d_resident.as<float>(), dpad, d, idx_out.as<uint32_t>(), seg.as<uint32_t>(), (uint32_t)k, d_cen.as<float>(), s);
+        HIP_CHECK(hipMemcpyAsync(centroids, d_cen.p, k * (size_t)d * 4, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        km::split_void_clusters(centroids, hassign, d, k, nx);
+        km::post_process(centroids, d, k, spherical != 0, int_centroids != 0);
     }
     API_END
 }

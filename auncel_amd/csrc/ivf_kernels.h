@@ -246,6 +246,13 @@ void launch_coarse_gemm(int metric, const float* X, const float* Y, const float*
 // packed upper triangle (IVF_pro.cpp:21-39 layout) of a full nlist x nlist distance matrix
 void launch_pack_upper(const float* full, uint32_t nlist, float* out, hipStream_t s);
 
+// k-means centroid update (ivf_kmeans.hip): points grouped by centroid with a stable sort, then fp32 sums in point order
+size_t kmeans_sort_temp_bytes(size_t n);
+void launch_kmeans_group(const int64_t* assign, size_t n, uint32_t k, uint32_t* keys_in, uint32_t* keys_out, uint32_t* idx_in,
+                         uint32_t* idx_out, uint32_t* counts, void* temp, size_t temp_bytes, hipStream_t s);
+void launch_kmeans_sums(const float* x, size_t stride, int d, const uint32_t* idx_sorted, const uint32_t* seg_off, uint32_t k, float* centroids,
+                        hipStream_t s);
+
 // fill helpers
 void launch_fill_f32(float* p, size_t n, float v, hipStream_t s);
 void launch_fill_i64(int64_t* p, size_t n, int64_t v, hipStream_t s);

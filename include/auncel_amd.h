@@ -157,6 +157,17 @@ int amd_ivf_trace_sb(const float* raw_xy, size_t n, size_t bs, float* out_x, flo
 int amd_ivf_merge_tables(int metric, size_t n, size_t k, size_t nshard, const float* all_D, const int64_t* all_I,
                          float* D, int64_t* I);
 
+/* ---- k-means -------------------------------------------------------------------------------------
+ * Clustering::train (Clustering.cpp:75-226) over an IndexFlat of `metric`, as Level1Quantizer::train_q1 runs it
+ * (IndexIVF.cpp:84-92): sub-sampling beyond k * max_points_per_centroid and seeding with the reference's rand_perm /
+ * RandomGenerator (utils.cpp:111-137,229-239), niter x { assignment (coarse_mode as in amd_ivf_coarse: 0 exact kernel,
+ * 1 |x|^2+|y|^2-2xy on the matrix cores, -1 the reference's switch), objective, km_update_centroids (utils.cpp:1078-1159)
+ * in its fp32 summation order, void-cluster splitting }, spherical / int_centroids post-processing.  nredo 1, no input
+ * centroids.  centroids: k x d out; obj: niter objective values out (may be NULL).  With coarse_mode 0 the centroids
+ * equal the reference's bit for bit wherever its BLAS assignment picks the same centroids (tests/golden/kmeans_*). */
+int amd_ivf_kmeans(int d, size_t n, const float* x, size_t k, int metric, int niter, long seed, size_t max_points_per_centroid,
+                   int spherical, int int_centroids, int coarse_mode, int device, float* centroids, float* obj);
+
 /* ---- range search ------------------------------------------------------------------------------
  * IndexIVF::range_search / range_search_preassigned (IndexIVF.cpp:740-857) with IVFFlatScanner::scan_codes_range
  * (IndexIVFFlat.cpp:139-155): all stored vectors of the probed lists with dis < radius (L2) / dis > radius (IP), per

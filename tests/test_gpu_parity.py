@@ -4,7 +4,7 @@ distances bit-exact (stronger than the 1e-4 relative the north star asks for).""
 import numpy as np
 import pytest
 
-from util import AUNCEL, FIXED, load_case, traces_from_gold
+from util import KMEANS, AUNCEL, FIXED, load_case, traces_from_gold
 
 pytestmark = pytest.mark.gpu
 
@@ -360,3 +360,17 @@ def test_clone_searches_concurrently(capi):
         c.add(case["xb"][:4])
     assert c.ntotal == h.ntotal
     c.close()
+
+
+@pytest.mark.parametrize("name", KMEANS)
+def test_kmeans_on_the_device(capi, name):
+    """amd_ivf_kmeans: training set resident, assignment and centroid update on the GPU, the reference's sequential choices
+    on the host; centroids bit for bit against the compiled reference's Clustering::train"""
+    case, gold = load_case(name)
+    cen, obj = capi.kmeans(case["metric"], case["x"], case["k"], case["niter"], case["seed"], case["max_points_per_centroid"],
+                           bool(case["spherical"]))
+    assert np.array_equal(bits(cen), bits(gold["centroids"]))
+    if case["x"].shape[0] < 20:
+        assert np.array_equal(bits(obj), bits(gold["obj"]))
+    else:
+        assert np.allclose(obj, gold["obj"], rtol=1e-5)
