@@ -1029,7 +1029,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     amd_ivf* I = ix(h);
     const size_t nlist = h->nlist;
     hipStream_t s = h->stream;
-    static const double grow_env = getenv("AUNCEL_AMD_ROUND_GROW") ? atof(getenv("AUNCEL_AMD_ROUND_GROW")) : 2.5;
+    static const double grow_env = getenv("AUNCEL_AMD_ROUND_GROW") ? atof(getenv("AUNCEL_AMD_ROUND_GROW")) : 3.5;
     const size_t seg_cap = (size_t)2 << 20;
     size_t maxlist = 0;
     for (size_t l = 0; l < nlist; l++) maxlist = std::max<size_t>(maxlist, I->h_list_off[l + 1] - I->h_list_off[l]);
@@ -1315,7 +1315,7 @@ void run_rounds(amd_ivf* h, RoundSpec& base, size_t n, size_t first_round, size_
             if (base.tuner.enabled) {
                 // an unfired query at stage s cannot stop before floor((s+1) * multipler): that many probes
                 // are waste-free; beyond it allow growth-1 of over-scan to keep the number of rounds small
-                static const double grow_env = getenv("AUNCEL_AMD_ROUND_GROW") ? atof(getenv("AUNCEL_AMD_ROUND_GROW")) : 2.5;
+                static const double grow_env = getenv("AUNCEL_AMD_ROUND_GROW") ? atof(getenv("AUNCEL_AMD_ROUND_GROW")) : 3.5;
                 const double grow = std::max<double>(base.tuner.multipler, grow_env);
                 const size_t safe = (size_t)((float)(stage[i] + 1) * base.tuner.multipler);
                 target = std::max<size_t>({safe, (size_t)(stage[i] * grow), stage[i] + first_round});

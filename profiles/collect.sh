@@ -14,4 +14,8 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python bench.py 
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python bench.py --no-cpu --steps 5 > $out/write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $out/sq -- python bench.py --no-cpu --steps 5 > $out/sq.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_SMEM --output-format csv -d $out/misc -- python bench.py --no-cpu --steps 5 > $out/misc.log 2>&1
-find $out -name "*.csv" | head -30
+# gpurun brings back at most 64 MiB: summarise here, keep the summaries, the kernel trace and its stats, drop the raw counter dumps
+python profiles/summarize.py $out $tag gpurun_out/summary_$tag > $out/summarize.log 2>&1
+cp $out/trace/*/*_kernel_stats.csv gpurun_out/summary_$tag/${tag}_kernel_stats.csv
+rm -rf $out/fetch $out/write $out/sq $out/misc
+find $out gpurun_out/summary_$tag -type f | head -30

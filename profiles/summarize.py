@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise the rocprofv3 output of profiles/collect.sh for bench.py.
 
-usage: summarize.py <gpurun_out/prof_TAG> <TAG>   -> writes profiles/<TAG>_summary.md and profiles/<TAG>_pmc.json
+usage: summarize.py <gpurun_out/prof_TAG> <TAG> [outdir]   -> writes <outdir or profiles>/<TAG>_summary.md and <TAG>_pmc.json
 
 The timed region of bench.py is its last `steps` steps.  Every step starts with the coarse quantisation, whose
 row sort (sort_rows_kernel) is dispatched exactly once per step, so the dispatches from the steps-th-from-last
@@ -17,7 +17,8 @@ import sys
 from collections import defaultdict
 
 root, tag = sys.argv[1], sys.argv[2]
-here = os.path.dirname(os.path.abspath(__file__))
+here = sys.argv[3] if len(sys.argv) > 3 else os.path.dirname(os.path.abspath(__file__))  # where the summaries go
+os.makedirs(here, exist_ok=True)
 
 
 def bench_json(log):

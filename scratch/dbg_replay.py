@@ -8,9 +8,9 @@ nb, d, nlist, nq = int(os.environ.get('NB', 10_000_000)), 128, 4096, 5000
 xb_t, _, draw = bench.gen_data(torch, dev, nb, 0, d, 20000, 35.0, 1235)
 g = torch.Generator(device=dev); g.manual_seed(5)
 xq_t = draw(nq, g)
-cen_t = bench.kmeans_centroids(torch, xb_t, nlist, 4, 99)
-xb, xq, cen = xb_t.cpu().numpy(), xq_t.cpu().numpy(), cen_t.cpu().numpy()
-del xb_t, xq_t, cen_t; torch.cuda.empty_cache()
+xb, xq = xb_t.cpu().numpy(), xq_t.cpu().numpy()
+del xb_t, xq_t; torch.cuda.empty_cache()
+cen, _ = capi.kmeans(capi.METRIC_L2, xb, nlist, niter=25)  # the reference's IVF training
 h = capi.Handle(d, nlist, capi.METRIC_L2, 0); h.set_centroids(cen); h.add(xb); del xb
 h.set_queries(xq)
 for k, nprobe in ((100, 12), (100, 32), (10, 32)):

@@ -4,14 +4,14 @@ import bench
 from auncel_amd import capi
 dev = torch.device('cuda', 0)
 nb, d, nlist, nq = 10_000_000, 128, 4096, 2000
-for sigma, blobs in [(20, 20000), (30, 20000), (40, 20000), (30, 100000)]:
+for sigma, blobs in [(35, 20000), (45, 20000), (55, 20000), (70, 20000)]:
     xb_t, _, draw = bench.gen_data(torch, dev, nb, 0, d, blobs, sigma, 1235)
     g = torch.Generator(device=dev); g.manual_seed(5)
     xq_t = draw(nq, g)
-    cen_t = bench.kmeans_centroids(torch, xb_t, nlist, 4, 99)
     gtD, gtI = bench.ground_truth(torch, xb_t, xq_t, 100)
-    xb, xq, cen = xb_t.cpu().numpy(), xq_t.cpu().numpy(), cen_t.cpu().numpy()
-    del xb_t, xq_t, cen_t; torch.cuda.empty_cache()
+    xb, xq = xb_t.cpu().numpy(), xq_t.cpu().numpy()
+    del xb_t, xq_t; torch.cuda.empty_cache()
+    cen, _ = capi.kmeans(capi.METRIC_L2, xb, nlist, niter=25)  # the reference's IVF training
     h = capi.Handle(d, nlist, capi.METRIC_L2, 0); h.set_centroids(cen); h.add(xb); del xb
     h.set_queries(xq)
     for nprobe in (4, 8, 16, 32, 64, 128):

@@ -98,13 +98,12 @@ def main():
         kind, nb, nq, nlist, k, nprobes, metric = cfgs[c]
         xb_t, xq_t = gen(torch, dev, kind, nb, nq)
         d = xb_t.shape[1]
-        cen_t = bench.kmeans_centroids(torch, xb_t, nlist, 4, 99)
-        if metric == capi.METRIC_IP:
-            cen_t = normalize(cen_t)
         gtI = gt_ids(torch, xb_t, xq_t, k, metric == capi.METRIC_IP)
-        xb, xq, cen = xb_t.cpu().numpy(), xq_t.cpu().numpy(), cen_t.cpu().numpy()
-        del xb_t, xq_t, cen_t
+        xb, xq = xb_t.cpu().numpy(), xq_t.cpu().numpy()
+        del xb_t, xq_t
         torch.cuda.empty_cache()
+        # coarse centroids by the reference's IVF training (Clustering::train, 25 iterations) on the GPU
+        cen, _ = capi.kmeans(metric, xb, nlist, niter=25)
         h = capi.Handle(d, nlist, metric, 0)
         h.set_centroids(cen)
         if metric == capi.METRIC_IP:

@@ -49,7 +49,8 @@ def main():
     g = torch.Generator(device=dev)
     g.manual_seed(7)
     xq_t = draw(args.nq, g)
-    cen_t = bench.kmeans_centroids(torch, xb_t, nlist, 4, 99)
+    cen_np, _ = capi.kmeans(capi.METRIC_L2, xb_t.cpu().numpy(), nlist, niter=25, device=local)  # the reference's IVF training
+    cen_t = torch.from_numpy(cen_np).to(dev)
     gtD, _ = bench.ground_truth(torch, xb_t, xq_t[:1000], args.k)
     # every rank derives the same list assignment (exact on this integer data), then keeps the lists it owns
     cn = (cen_t * cen_t).sum(1)
