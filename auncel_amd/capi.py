@@ -21,7 +21,8 @@ SYMBOLS = [
     "amd_ivf_set_lists", "amd_ivf_add", "amd_ivf_ntotal", "amd_ivf_list_size", "amd_ivf_get_list", "amd_ivf_coarse",
     "amd_ivf_search_preassigned", "amd_ivf_search", "amd_ivf_scan_codes", "amd_ivf_distance_to_code", "amd_ivf_stats",
     "amd_ivf_set_queries", "amd_ivf_search_resident", "amd_ivf_set_interdis", "amd_ivf_get_interdis",
-    "amd_ivf_set_tuner", "amd_ivf_search_adaptive", "amd_ivf_search_adaptive_x", "amd_ivf_train_samples",
+    "amd_ivf_set_tuner", "amd_ivf_search_adaptive", "amd_ivf_search_adaptive_x", "amd_ivf_search_timed", "amd_ivf_search_timed_x",
+    "amd_ivf_train_samples",
     "amd_ivf_train_samples_x", "amd_ivf_trace_sb", "amd_ivf_arcos_table", "amd_ivf_merge_tables",
     "amd_ivf_last_timing",
     "amd_ivf_kmeans",
@@ -305,6 +306,30 @@ class Handle:
                                            C.c_float(multipler), C.c_float(std_m), _f(req), _f(gt), int(profile), coarse_mode,
                                            my_nprobe.ctypes.data_as(_u64p), _f(t_recalls), _f(D), _i(I)))
         return D, I
+
+    def search_timed(self, start, n, k, nprobe, budget_ms, coarse_mode=0):
+        """Error_sys::time_search over resident queries [start, start+n); budget_ms is indexed by absolute query id.
+        Returns (D, I, nprobe_used)."""
+        b = f32(budget_ms)
+        assert b.size >= start + n
+        D = np.empty((n, k), np.float32)
+        I = np.empty((n, k), np.int64)
+        used = np.zeros(n, np.uint64)
+        _chk(lib().amd_ivf_search_timed(self._h, C.c_size_t(start), C.c_size_t(n), C.c_size_t(k), C.c_size_t(nprobe), _f(b), coarse_mode,
+                                        used.ctypes.data_as(_u64p), _f(D), _i(I)))
+        return D, I, used
+
+    def search_timed_x(self, x, id_offset, k, nprobe, budget_ms, coarse_mode=0):
+        x = f32(x)
+        n = x.shape[0]
+        b = f32(budget_ms)
+        assert b.size >= id_offset + n
+        D = np.empty((n, k), np.float32)
+        I = np.empty((n, k), np.int64)
+        used = np.zeros(n, np.uint64)
+        _chk(lib().amd_ivf_search_timed_x(self._h, C.c_size_t(n), _f(x), C.c_size_t(id_offset), C.c_size_t(k), C.c_size_t(nprobe), _f(b),
+                                          coarse_mode, used.ctypes.data_as(_u64p), _f(D), _i(I)))
+        return D, I, used
 
     def train_samples(self, start, n, max_topk, gt_D, train_num, raw, coarse_mode=0):
         gt = f32(gt_D)

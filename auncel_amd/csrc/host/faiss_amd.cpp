@@ -516,7 +516,7 @@ void IndexIVF::fold_stats() const {
 }
 
 void IndexIVF::search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const {
-    if (tune || training) {
+    if (tune || training || (t && t->time_tune)) {
         search(n, x, k, distances, labels, (size_t)0);
         return;
     }
@@ -528,7 +528,16 @@ void IndexIVF::search(idx_t n, const float* x, idx_t k, float* distances, idx_t*
 void IndexIVF::search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels, size_t offset) const {
     if (!tune && !training) {
         sync_engine(false);
-        AMD(amd_ivf_search(gpu_, (size_t)n, x, (size_t)k, nprobe, coarse_mode, distances, i64(labels)));
+        if (t && t->time_tune) {
+            // IndexIVF.cpp:504-506,545-549: the plain probe loop, left when the budget t->require_acc[id_q] (ms) is used up
+            const bool res = resident_ptr_ && x == resident_ptr_ + offset * (size_t)d && offset + n <= resident_n_;
+            if (res)
+                AMD(amd_ivf_search_timed(gpu_, offset, (size_t)n, (size_t)k, nprobe, t->require_acc, coarse_mode, nullptr, distances, i64(labels)));
+            else
+                AMD(amd_ivf_search_timed_x(gpu_, (size_t)n, x, offset, (size_t)k, nprobe, t->require_acc, coarse_mode, nullptr, distances, i64(labels)));
+        } else {
+            AMD(amd_ivf_search(gpu_, (size_t)n, x, (size_t)k, nprobe, coarse_mode, distances, i64(labels)));
+        }
         fold_stats();
         return;
     }
@@ -869,6 +878,18 @@ void Error_sys::search(float* D, int64_t* I, size_t start, size_t search_size) {
     const size_t n = search_size == (size_t)-1 ? num : search_size;
     index->search(n, queries + start * index->d, max_topk, D, reinterpret_cast<Index::idx_t*>(I), start);
     index->set_tune_off();
+}
+
+void Error_sys::time_search(float* D, int64_t* I, size_t start, size_t search_size) {  // profile.cpp:229-244
+    FAISS_THROW_IF_NOT_MSG(is_trained == true, "Error sys must be trained before searching");
+    FAISS_THROW_IF_NOT_MSG(num <= train_num, "Error sys search num must be lower than all qeuries num");
+    if (!index) return;
+    FAISS_THROW_IF_NOT_MSG(index->t != nullptr, "time_search needs init_tune (it reads t->time_tune and the budgets in t->require_acc)");
+    index->t->time_tune = true;
+    index->nprobe = index->nlist;
+    const size_t n = search_size == (size_t)-1 ? num : search_size;
+    index->search(n, queries + start * index->d, max_topk, D, reinterpret_cast<Index::idx_t*>(I), start);
+    index->t->time_tune = true;  // sic: the reference leaves it on
 }
 
 // ------------------------------------------------------------------------------------- IndexShards

@@ -28,6 +28,7 @@ class Error_sys {
     void sys_train(size_t nq, const float* xq);
     void set_queries(size_t n, const float* q, const float* acc, size_t allo_size);
     void search(float* D, int64_t* I, size_t start, size_t search_size = -1);
+    void time_search(float* D, int64_t* I, size_t start, size_t search_size = -1);
     void set_topk(size_t new_topk);
     float recall(Index::idx_t* I, Index::idx_t* gtI, size_t topk);
 };

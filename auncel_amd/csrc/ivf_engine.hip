@@ -212,6 +212,7 @@ struct amd_ivf {
     DevBuf c_heap_val, c_heap_ref, c_stage, c_nscan, c_done, c_seg_off, c_seg_list, c_seg_count;
     PinnedBuf p_items, p_pair_query, p_pair_out, p_seg_off, p_seg_list, p_seg_count, p_qsel, p_seg_begin;
     DevBuf w_seg_begin;
+    DevBuf w_limit;  // time-bounded search: per-slot end of the probe loop (plan_counts_kernel -> replay_kernel)
 
     size_t dist_budget_floats = (size_t)768 << 20;  // 3 GiB of distances per scan launch
     size_t stats_host[4] = {0, 0, 0, 0};
@@ -413,6 +414,9 @@ struct RoundSpec {
     uint32_t coarse_stride = 0;
     int raw_heap_out = 0;
     int fused = 0;
+    // time-bounded search: budgets in ms (device, by absolute id) and the host clock (us) the budgets count from
+    const float* d_budget_ms = nullptr;
+    double t_start_us = 0;
 };
 
 static bool dbg_timing() {
@@ -1104,6 +1108,11 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     pa.counters = h->w_pl_counters.as<uint32_t>();
     pa.bytes = reinterpret_cast<double*>(h->w_pl_counters.as<uint32_t>() + 16);
     pa.acc64 = reinterpret_cast<unsigned long long*>(h->w_pl_counters.as<uint32_t>() + 18);
+    if (base.d_budget_ms) {
+        h->w_limit.ensure(n * 4);
+        pa.budget_ms = base.d_budget_ms;
+        pa.limit = h->w_limit.as<uint32_t>();
+    }
 
     if (!h->aux[0]) {
         for (int i = 0; i < 4; i++) {
@@ -1121,6 +1130,10 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         HIP_CHECK(hipMemsetAsync(h->w_pl_lcount.p, 0, nlist * 4, s));
         HIP_CHECK(hipMemsetAsync(h->w_pl_counters.as<uint32_t>() + 6, 0, 4, s));
         pa.round_len = (uint32_t)round_len;
+        if (base.d_budget_ms) {  // the clock is read once the previous round has finished
+            HIP_CHECK(hipStreamSynchronize(s));
+            pa.elapsed_ms = (float)((now_us() - base.t_start_us) * 1e-3);
+        }
         launch_plan(pa, s);
         HIP_CHECK(hipMemcpyAsync(hc, h->w_pl_counters.p, 96, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
@@ -1266,6 +1279,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         ra.error = h->w_error.as<uint32_t>();
         ra.tuner = base.tuner;
         ra.train = base.train;
+        ra.limit = base.d_budget_ms ? h->w_limit.as<uint32_t>() : nullptr;
         static const bool dbg_replay_dev = getenv("AUNCEL_AMD_DEBUG_REPLAY") != nullptr;
         if (dbg_replay_dev) {
             h->w_misc.ensure((size_t)nact * 64);
@@ -1730,6 +1744,76 @@ int amd_ivf_search_resident(amd_ivf_t* h, size_t start, size_t n, size_t k, size
     h->scan_bytes = 0;
     h->scan_slots = h->scan_useful = 0;
     search_full(h, h->d_resident.as<float>() + start * h->dpad, n, k, nprobe, coarse_mode, D, I, h->resident_range);
+    finish_timing(h, wc.stop());
+    API_END
+}
+
+// Error_sys::time_search (profile.cpp:229-244): IndexIVF::search with tune off and t->time_tune on -- the plain probe loop
+// over nprobe = nlist probes, left when the time budget of the query is used up (IndexIVF.cpp:504-506,545-549).
+static void timed_core(amd_ivf* h, const float* d_x, size_t start, size_t n, size_t k, size_t nprobe, const float* budget_ms, int coarse_mode,
+                       uint64_t* nprobe_used, float* D, int64_t* I, const IntRange& qr) {
+    const double t_start = now_us();
+    nprobe = std::min<size_t>(nprobe, h->nlist);
+    upload_lists(h);
+    DevBuf& d_b = h->w_misc2;
+    d_b.ensure((start + n) * 4);
+    HIP_CHECK(hipMemcpyAsync(d_b.p, budget_ms, (start + n) * 4, hipMemcpyHostToDevice, h->stream));
+    h->w_cdis.ensure(n * nprobe * 4);
+    h->w_ckeys.ensure(n * nprobe * 8);
+    coarse_dev(h, d_x, n, nprobe, coarse_mode, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>(),
+               h->allow_fused && ix(h)->centroid_range.fusable_with(qr));
+    init_state(h, n, k, false);
+    RoundSpec base;
+    base.k = (int)k;
+    base.id_offset = start;
+    base.d_x = d_x;
+    base.d_ckeys = h->w_ckeys.as<int64_t>();
+    base.coarse_stride = (uint32_t)nprobe;
+    base.fused = h->allow_fused && ix(h)->db_range.fusable_with(qr);
+    base.bytes = byte_queries(h, ix(h), d_x, n, qr);
+    ix(h)->last_arith = base.bytes ? 2 : base.fused ? 1 : 0;
+    base.d_budget_ms = d_b.as<float>();
+    base.t_start_us = t_start;
+    static const size_t first_env = getenv("AUNCEL_AMD_TIMED_FIRST") ? (size_t)atoi(getenv("AUNCEL_AMD_TIMED_FIRST")) : 4;
+    run_rounds_device(h, base, n, std::max<size_t>(1, first_env), nprobe, nullptr);
+    check_device_error(h);
+    std::vector<uint32_t> stage(nprobe_used ? n : 0);
+    if (nprobe_used) HIP_CHECK(hipMemcpyAsync(stage.data(), h->w_stage.p, n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipMemcpyAsync(D, h->w_D.p, n * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipMemcpyAsync(I, h->w_I.p, n * k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < stage.size(); i++) nprobe_used[i] = stage[i];
+    fold_stats(h, n);
+}
+
+int amd_ivf_search_timed(amd_ivf_t* h, size_t start, size_t n, size_t k, size_t nprobe, const float* budget_ms, int coarse_mode,
+                         uint64_t* nprobe_used, float* D, int64_t* I) {
+    API_BEGIN
+    use_device(h);
+    if (start + n > h->n_resident) throw EngineError("resident query range out of bounds");
+    if (n == 0 || k == 0 || nprobe == 0) return 0;
+    WallClock wc(h->stream);
+    h->scan_bytes = 0;
+    h->scan_slots = h->scan_useful = 0;
+    timed_core(h, h->d_resident.as<float>() + start * h->dpad, start, n, k, nprobe, budget_ms, coarse_mode, nprobe_used, D, I,
+               h->resident_range);
+    finish_timing(h, wc.stop());
+    API_END
+}
+
+int amd_ivf_search_timed_x(amd_ivf_t* h, size_t n, const float* x, size_t id_offset, size_t k, size_t nprobe, const float* budget_ms,
+                           int coarse_mode, uint64_t* nprobe_used, float* D, int64_t* I) {
+    API_BEGIN
+    use_device(h);
+    if (n == 0 || k == 0) return 0;
+    WallClock wc(h->stream);
+    h->scan_bytes = 0;
+    h->scan_slots = h->scan_useful = 0;
+    h->w_x.ensure(n * h->dpad * sizeof(float));
+    upload_rows(h, h->w_x.as<float>(), x, n);
+    IntRange qr;
+    qr.add(x, n * (size_t)h->d);
+    timed_core(h, h->w_x.as<float>(), id_offset, n, k, nprobe, budget_ms, coarse_mode, nprobe_used, D, I, qr);
     finish_timing(h, wc.stop());
     API_END
 }

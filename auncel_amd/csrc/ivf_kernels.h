@@ -119,6 +119,7 @@ struct ReplayArgs {
     int identity_ids;          // ids are the positions themselves (coarse quantiser rows)
     unsigned long long max_codes;
     int finalize_all;          // fixed-nprobe mode: every query ends after this round
+    const uint32_t* limit;     // [slot] time-bounded search: this query's probe loop ends at limit[slot] (null: total_nprobe)
     // per-query state carried across rounds
     float* heap_val;           // [nq][k]
     int64_t* heap_ref;         // [nq][k]  (list << 32 | position), -1 = empty
@@ -198,6 +199,11 @@ struct PlanArgs {
     const uint32_t* stage;
     const uint32_t* done;
     const unsigned long long* my_nprobe;  // by absolute id, may be null
+    // time-bounded search (IndexIVF.cpp:504-506,545-549): budgets in ms by absolute id, ms elapsed when this round is
+    // planned, and the per-slot end of the probe loop the plan derives from them (read by the replay)
+    const float* budget_ms;
+    float elapsed_ms;
+    uint32_t* limit;
     // outputs
     uint32_t* cnt;                   // [nq] probes this round (0: finished or deferred)
     unsigned long long* need;        // [nq] floats of distance rows (rows padded to multiples of `row_align`)

@@ -864,6 +864,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
     unsigned long long dbg_evals = 0, dbg_stream = 0, dbg_rule = 0, dbg_chunks = 0, dbg_probes = 0;
     uint32_t err = 0;
     uint32_t ik0 = a.stage[qi];
+    const uint32_t loop_end = a.limit ? a.limit[qi] : a.total_nprobe;
     const uint32_t si = a.seg_by_slot ? qi : li;
     const uint32_t cnt = a.seg_count[si];
     const size_t seg0 = a.seg_begin ? (size_t)a.seg_begin[si] : (size_t)li * a.round_probes;
@@ -1112,7 +1113,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
             finished = true;
             break;
         }
-        if (a.total_nprobe && ik + 1 >= a.total_nprobe) finished = true;  // end of the probe loop
+        if (loop_end && ik + 1 >= loop_end) finished = true;  // end of the probe loop
         wave_sync();
         const unsigned long long dbg_r0 = a.dbg ? __builtin_readcyclecounter() : 0;
         if (tune) {

@@ -31,7 +31,25 @@ __global__ __launch_bounds__(256) void plan_counts_kernel(PlanArgs a) {
             if (target < (unsigned long long)stage + a.first_round) target = (unsigned long long)stage + a.first_round;
         }
         if (np != 0) target = np > (unsigned long long)stage + 1 ? np : (unsigned long long)stage + 1;
+        bool last = false;
+        if (a.budget_ms) {
+            // The reference leaves the probe loop after probe ik when another one is not expected to fit:
+            // el >= 0.95 * budget - el / (ik + 1)  (IndexIVF.cpp:545-549).  A round covers several probes, so the same
+            // estimate (el / stage per probe) gives the number that still fit; a query takes them all in this round
+            // and ends with it, unless that would more than double its stage -- then it is re-examined after the round.
+            target = (unsigned long long)stage + a.first_round;
+            if (stage > 0) {
+                const float per = a.elapsed_ms / (float)stage, room = 0.95f * a.budget_ms[a.id_offset + i] - a.elapsed_ms;
+                const float fit = room > 0.f ? floorf(room / fmaxf(per, 1e-9f)) : 0.f;
+                const unsigned long long cap = stage > a.first_round ? stage : a.first_round;
+                unsigned long long len = fit >= (float)a.total_nprobe ? a.total_nprobe : (unsigned long long)fit;
+                if (len < 1) len = 1;  // a query never ends between rounds: its final state is written by the replay
+                last = len <= cap;
+                target = (unsigned long long)stage + (last ? len : cap);
+            }
+        }
         if (target > a.total_nprobe) target = a.total_nprobe;
+        if (a.limit && lane == 0) a.limit[i] = last ? (uint32_t)target : a.total_nprobe;
         if (target <= stage) target = stage + 1 < a.total_nprobe ? stage + 1 : a.total_nprobe;
         cnt = (uint32_t)(target - stage);
         const int64_t* kq = a.keys + (size_t)i * a.key_stride + stage;

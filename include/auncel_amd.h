@@ -132,6 +132,20 @@ int amd_ivf_search_adaptive_x(amd_ivf_t* h, size_t n, const float* x, size_t id_
                               float std_m, const float* require_acc, const float* gt_D, int profile, int coarse_mode,
                               uint64_t* my_nprobe, float* t_recalls, float* D, int64_t* I);
 
+/* Time-bounded search: Error_sys::time_search (profile.cpp:229-244) = IndexIVF::search with tune off, nprobe = nlist and
+ * error_pro::time_tune on: the plain probe loop (nprobe probes; time_search sets nprobe = nlist) over resident queries [start, start+n), heap of k, left when the
+ * query's budget is used up.  budget_ms is indexed by absolute query id (the reference keeps the budgets in
+ * t->require_acc[id_q], effect_time.cpp:274-281).  The reference tests after every probe ik whether one more is expected to
+ * fit, `el >= 0.95 budget - el / (ik + 1)` (IndexIVF.cpp:545-549); the engine reads the clock between rounds and lets a
+ * query take as many further probes as the same estimate says still fit (at most doubling per round).  The clock starts
+ * when the call is entered (coarse quantisation included, which the reference's t0 leaves out).  Whatever the timing, the
+ * result of query i is exactly search_preassigned's over its first nprobe_used[i] probes (nprobe_used may be NULL). */
+int amd_ivf_search_timed(amd_ivf_t* h, size_t start, size_t n, size_t k, size_t nprobe, const float* budget_ms, int coarse_mode,
+                         uint64_t* nprobe_used, float* D, int64_t* I);
+/* same for queries passed by (host) pointer; budget_ms[id_offset + i] belongs to query i */
+int amd_ivf_search_timed_x(amd_ivf_t* h, size_t n, const float* x, size_t id_offset, size_t k, size_t nprobe,
+                           const float* budget_ms, int coarse_mode, uint64_t* nprobe_used, float* D, int64_t* I);
+
 /* search_preassigned, training branch, driven as Error_sys::sys_train does: raw (sum_angle, kscaling)
  * samples for stages 1,2,4..nlist/8 of resident queries [start, start+n); raw[i] has
  * train_num*(max_topk/4) (x,y) pairs and must be pre-filled with (-1,-1)  [IndexIVF.cpp:640-673, profile.cpp:88-156] */

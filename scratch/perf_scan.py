@@ -5,7 +5,7 @@ import bench
 from auncel_amd import capi
 dev = torch.device('cuda', 0)
 nb, d, nlist, nq = int(os.environ.get('NB', 10_000_000)), 128, 4096, 5000
-xb_t, _, draw = bench.gen_data(torch, dev, nb, 0, d, 20000, 35.0, 1235)
+xb_t, _, draw = bench.gen_data(torch, dev, nb, 0, d, 20000, bench.SIGMA, 1235)
 g = torch.Generator(device=dev); g.manual_seed(5)
 xq_t = draw(nq, g)
 xb, xq = xb_t.cpu().numpy(), xq_t.cpu().numpy()

@@ -1,10 +1,10 @@
-import sys, time, numpy as np, torch
+import os, sys, time, numpy as np, torch
 sys.path.insert(0, '/root/repo')
 import bench
 from auncel_amd import capi
 dev = torch.device('cuda', 0)
 nb, d, nlist, nq = 10_000_000, 128, 4096, 2000
-for sigma, blobs in [(35, 20000), (45, 20000), (55, 20000), (70, 20000)]:
+for sigma, blobs in [(float(s), 20000) for s in os.environ.get("SIGMAS", "38,40,42").split(",")]:
     xb_t, _, draw = bench.gen_data(torch, dev, nb, 0, d, blobs, sigma, 1235)
     g = torch.Generator(device=dev); g.manual_seed(5)
     xq_t = draw(nq, g)

@@ -4,7 +4,7 @@ import bench
 from auncel_amd import capi
 dev = torch.device('cuda', 0)
 nb, d, nlist, K, topk, ts, ses = 10_000_000, 128, 4096, 100, 10, 5000, 5000
-xb_t, _, draw = bench.gen_data(torch, dev, nb, 0, d, 20000, 35.0, 1235)
+xb_t, _, draw = bench.gen_data(torch, dev, nb, 0, d, 20000, bench.SIGMA, 1235)
 g = torch.Generator(device=dev); g.manual_seed(777)
 xq_t = draw(ts + ses, g)
 cen_t = bench.kmeans_centroids(torch, xb_t, nlist, 4, 99)

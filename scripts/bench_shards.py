@@ -45,7 +45,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
     d, nlist = 128, args.nlist
-    xb_t, _, draw = bench.gen_data(torch, dev, args.nb, 0, d, 20000, 35.0, 1235)
+    xb_t, _, draw = bench.gen_data(torch, dev, args.nb, 0, d, 20000, bench.SIGMA, 1235)
     g = torch.Generator(device=dev)
     g.manual_seed(7)
     xq_t = draw(args.nq, g)

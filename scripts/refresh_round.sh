@@ -1,0 +1,11 @@
+#!/bin/bash
+# Everything the round's committed numbers come from, in one gpurun call:
+#   gpurun --timeout 2700 -- 'bash scripts/refresh_round.sh r01'
+tag=${1:-r01}
+bash profiles/collect.sh $tag > gpurun_out/collect_$tag.log 2>&1
+python bench.py > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.log
+python scratch/perf_scan.py > gpurun_out/perf_scan_$tag.txt 2> gpurun_out/perf_scan_$tag.log
+python scripts/bench_configs.py > gpurun_out/configs_$tag.jsonl 2> gpurun_out/configs_$tag.log
+python scripts/bench_shards.py > gpurun_out/shards_$tag.json 2> gpurun_out/shards_$tag.log
+python scripts/effect_time.py > gpurun_out/effect_time_$tag.jsonl 2> gpurun_out/effect_time_$tag.log
+tail -3 gpurun_out/bench_$tag.log; cat gpurun_out/effect_time_$tag.jsonl; du -sh gpurun_out

@@ -374,3 +374,49 @@ def test_kmeans_on_the_device(capi, name):
         assert np.array_equal(bits(obj), bits(gold["obj"]))
     else:
         assert np.allclose(obj, gold["obj"], rtol=1e-5)
+
+
+def _check_timed(oracle, lists, xq, k, cd, ck, D, I, used, nprobe):
+    """whatever the clock did, query i must hold search_preassigned's result over its first used[i] probes"""
+    assert used.min() >= 1 and used.max() <= nprobe
+    for u in np.unique(used):
+        sel = np.nonzero(used == u)[0]
+        u = int(u)
+        eD, eI, _ = oracle.search_preassigned(lists, xq[sel], k, ck[sel, :u], cd[sel, :u])
+        assert np.array_equal(I[sel], eI), u
+        assert np.array_equal(bits(D[sel]), bits(eD)), u
+
+
+@pytest.mark.parametrize("name", ["fixed_sift_l2", "fixed_deep_ip_d96", "fixed_ragged", "fixed_gist_l2_d960"])
+def test_time_bounded_search(capi, oracle, name):
+    """Error_sys::time_search (SURVEY 8 a15): the probe loop left on a per-query time budget.  The stopping points depend
+    on the clock, the results may not: they are pinned per query against the oracle at the probe count the engine reports."""
+    case, gold = load_case(name)
+    h = make_index(capi, case, gold)
+    lists = oracle.Lists(case["metric"], case["centroids"], case["xb"], gold["assign"])
+    xq, nlist = case["xq"], case["nlist"]
+    n = xq.shape[0]
+    k = int(case["ks"][-1])
+    cd, ck = h.coarse(xq, nlist, mode=0)
+    h.set_queries(xq)
+    rs = np.random.RandomState(7)
+    # no time at all: round 0 (4 probes) and the one probe every query is owed afterwards
+    D, I, used = h.search_timed(0, n, k, nlist, np.zeros(n, np.float32))
+    assert used.max() <= min(5, nlist)
+    _check_timed(oracle, lists, xq, k, cd, ck, D, I, used, nlist)
+    # all the time in the world: the full probe loop = plain search with nprobe = nlist
+    D, I, used = h.search_timed(0, n, k, nlist, np.full(n, 1e9, np.float32))
+    assert np.all(used == nlist)
+    fD, fI = h.search(xq, k, nlist, coarse_mode=0)
+    assert np.array_equal(I, fI) and np.array_equal(bits(D), bits(fD))
+    _check_timed(oracle, lists, xq[:8], k, cd[:8], ck[:8], D[:8], I[:8], used[:8], nlist)
+    # budgets around the cost of a round, a slice of the resident queries (budgets are indexed by absolute id),
+    # a shorter probe loop, and the same through the host-pointer entry
+    for rep in range(3):
+        b = rs.choice([0.0, 0.05, 0.1, 0.2, 0.4, 0.8, 3.0], size=n).astype(np.float32)
+        nprobe = [nlist, max(1, nlist // 2), nlist][rep]
+        if rep < 2:
+            D, I, used = h.search_timed(3, n - 3, k, nprobe, b)
+        else:
+            D, I, used = h.search_timed_x(xq[3:], 3, k, nprobe, b)
+        _check_timed(oracle, lists, xq[3:], k, cd[3:], ck[3:], D, I, used, nprobe)

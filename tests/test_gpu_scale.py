@@ -92,3 +92,29 @@ def test_adaptive_sample_vs_oracle(setup):
     assert np.array_equal(tun.my_nprobe[ts:ts + S].astype(np.uint64), my_np[ts:ts + S])
     assert np.array_equal(I[:S], oI) and np.array_equal(D[:S].view(np.uint32), oD.view(np.uint32))
     assert my_np[ts:].min() >= 1 and len(np.unique(my_np[ts:])) > 3  # the bound really adapts per query
+
+
+def test_time_bounded_search_follows_the_budget(setup):
+    """effect_time.cpp's loop: one query per call, budgets of a few ms.  More budget -> deeper probe loop; the call returns
+    within the budget (plus slack for a shared box); results pinned against the oracle at the reported depth."""
+    import time
+    h, orc, xq, nlist = setup["h"], setup["orc"], setup["xq"], setup["nlist"]
+    h.set_queries(xq)
+    K = 100
+    S = 24
+    budgets = np.zeros(len(xq), np.float32)
+    budgets[:S] = np.tile([1.0, 2.0, 4.0, 8.0], S // 4)
+    h.search_timed(0, 1, K, nlist, budgets)  # warm-up (allocations)
+    used, wall = np.zeros(S, np.int64), np.zeros(S)
+    cd, ck = orc.knn(1, xq[:S], setup["cen"], nlist, nthreads=8)
+    for i in range(S):
+        t0 = time.perf_counter()
+        D, I, u = h.search_timed(i, 1, K, nlist, budgets)
+        wall[i] = (time.perf_counter() - t0) * 1e3
+        used[i] = int(u[0])
+        oD, oI, _ = orc.search_preassigned(setup["lists"], xq[i:i + 1], K, ck[i:i + 1, :used[i]], cd[i:i + 1, :used[i]])
+        assert np.array_equal(I, oI) and np.array_equal(D.view(np.uint32), oD.view(np.uint32))
+    b = budgets[:S]
+    means = [used[b == v].mean() for v in (1.0, 2.0, 4.0, 8.0)]
+    assert means[0] <= means[1] <= means[2] <= means[3] and means[3] > means[0], means
+    assert np.median(wall / b) < 1.5, (wall, b)

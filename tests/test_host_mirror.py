@@ -102,7 +102,7 @@ def test_index_io_bytes(tmp_path, name):
 @pytest.mark.skipif(not os.path.exists("/root/reference/Auncel/eval/bound.cpp"), reason="reference tree not present")
 def test_reference_harness_builds_against_mirror(tmp_path):
     """drop-in check: the reference's own eval/bound.cpp (the north-star caller) compiles unmodified against the
-    mirror headers and links with libfaiss_amd + libauncel_amd; effect_error / overhead compile as well"""
+    mirror headers and links with libfaiss_amd + libauncel_amd, and so does effect_time.cpp; effect_error / overhead compile as well"""
     from auncel_amd import build
     build.build_host()
     root = tmp_path / "Auncel"
@@ -111,10 +111,13 @@ def test_reference_harness_builds_against_mirror(tmp_path):
     for f in os.listdir(build.HOST_DIR):
         if f.endswith(".h"):
             os.symlink(os.path.join(build.HOST_DIR, f), root / f)
-    for src in ("bound", "effect_error", "overhead"):
+    for src in ("bound", "effect_error", "overhead", "effect_time"):
         subprocess.run(["g++", "-std=c++17", "-O0", "-fopenmp", "-w", "-c", str(root / "eval" / f"{src}.cpp"), "-o", str(tmp_path / f"{src}.o")],
                        check=True)
     subprocess.run(["g++", "-fopenmp", str(tmp_path / "bound.o"), "-L" + build.LIBDIR, "-lfaiss_amd", "-launcel_amd",
                     "-Wl,-rpath," + build.LIBDIR, "-o", str(tmp_path / "bound")], check=True)
     r = subprocess.run([str(tmp_path / "bound")], capture_output=True, text=True)  # no argv: usage path, no GPU touched
     assert r.returncode != 127
+    # effect_time.cpp is the caller of Error_sys::time_search
+    subprocess.run(["g++", "-fopenmp", str(tmp_path / "effect_time.o"), "-L" + build.LIBDIR, "-lfaiss_amd", "-launcel_amd",
+                    "-Wl,-rpath," + build.LIBDIR, "-o", str(tmp_path / "effect_time")], check=True)
