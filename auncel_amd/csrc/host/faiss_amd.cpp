@@ -764,6 +764,110 @@ void IndexIVFFlat::add_core(idx_t n, const float* x, const long* xids, const lon
     ntotal += n;
 }
 
+// ------------------------------------------------------------------------------------- IndexIVFFlatDedup
+// Auncel/IndexIVFFlat.cpp:233-380
+IndexIVFFlatDedup::IndexIVFFlatDedup(Index* quantizer, size_t d, size_t nlist_, MetricType metric) : IndexIVFFlat(quantizer, d, nlist_, metric) {}
+
+namespace {
+// utils.cpp:1584-1593 (the classic string hash): keys the training-set dedup
+uint64_t bytes_hash(const uint8_t* p, long n) {
+    uint64_t h = (uint64_t)p[0] << 7;
+    for (long i = 0; i < n; i++) h = (1000003 * h) ^ p[i];
+    return h ^ (uint64_t)n;
+}
+}  // namespace
+
+void IndexIVFFlatDedup::train(idx_t n, const float* x) {
+    // keep the first copy of every vector; as in the reference a hash remembers only the last vector that produced it
+    std::unordered_map<uint64_t, idx_t> last_with_hash;
+    std::vector<float> uniq((size_t)n * d);
+    long nu = 0;
+    for (idx_t i = 0; i < n; i++) {
+        const float* xi = x + i * d;
+        const uint64_t hv = bytes_hash(reinterpret_cast<const uint8_t*>(xi), (long)code_size);
+        auto it = last_with_hash.find(hv);
+        if (it != last_with_hash.end() && !memcmp(uniq.data() + it->second * d, xi, code_size)) continue;
+        last_with_hash[hv] = nu;
+        memcpy(uniq.data() + nu * d, xi, code_size);
+        nu++;
+    }
+    if (verbose) printf("IndexIVFFlatDedup::train: train on %ld points after dedup (was %ld points)\n", nu, (long)n);
+    IndexIVFFlat::train(nu, uniq.data());
+}
+
+void IndexIVFFlatDedup::add_with_ids(idx_t na, const float* x, const long* xids) {
+    FAISS_THROW_IF_NOT(is_trained);
+    FAISS_THROW_IF_NOT_MSG(!maintain_direct_map, "IVFFlatDedup not implemented with direct_map");
+    std::vector<long> list_of(na);
+    quantizer->assign(na, x, list_of.data());
+    long n_add = 0, n_dup = 0;
+    for (idx_t i = 0; i < na; i++) {
+        const idx_t id = xids ? xids[i] : ntotal + i;
+        const long list_no = list_of[i];
+        if (list_no < 0) continue;
+        const uint8_t* xi = reinterpret_cast<const uint8_t*>(x + i * d);
+        // first stored entry of the list holding the same bytes
+        const uint8_t* codes = invlists->get_codes(list_no);
+        const long ls = (long)invlists->list_size(list_no);
+        long found = -1;
+        for (long o = 0; o < ls && found < 0; o++)
+            if (!memcmp(codes + (size_t)o * code_size, xi, code_size)) found = o;
+        if (found < 0) {
+            invlists->add_entry(list_no, id, xi);
+        } else {
+            instances.insert(std::make_pair(invlists->get_ids(list_no)[found], id));
+            n_dup++;
+        }
+        n_add++;
+    }
+    if (verbose) printf("IndexIVFFlat::add_with_ids: added %ld / %ld vectors (out of which %ld are duplicates)\n", n_add, (long)na, n_dup);
+    ntotal += n_add;
+}
+
+// From the first result that has copies on, every entry is followed by its copies at the same distance until the row
+// is full (IndexIVFFlat.cpp:340-376).
+void IndexIVFFlatDedup::expand_instances(idx_t n, idx_t k, float* distances, idx_t* labels) const {
+    std::vector<idx_t> lab(k);
+    std::vector<float> dis(k);
+    for (idx_t i = 0; i < n; i++) {
+        idx_t* li = labels + i * k;
+        float* di = distances + i * k;
+        idx_t first = 0;
+        while (first < k && instances.find(li[first]) == instances.end()) first++;
+        if (first == k) continue;
+        idx_t w = first, r = first;  // write position in the expanded row, read position in the search result
+        while (w < k) {
+            auto range = instances.equal_range(li[r]);
+            lab[w] = li[r];
+            dis[w] = di[r];
+            w++;
+            for (auto it = range.first; w < k && it != range.second; ++it) {
+                lab[w] = it->second;
+                dis[w] = di[r];
+                w++;
+            }
+            r++;
+        }
+        std::copy(lab.begin() + first, lab.end(), li + first);
+        std::copy(dis.begin() + first, dis.end(), di + first);
+    }
+}
+
+void IndexIVFFlatDedup::search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const {
+    IndexIVFFlat::search(n, x, k, distances, labels);  // the mirror's search ranks the centroids on the device itself
+    expand_instances(n, k, distances, labels);
+}
+
+void IndexIVFFlatDedup::search_preassigned(idx_t n, const float* x, idx_t k, const idx_t* assign, const float* centroid_dis,
+                                           float* distances, idx_t* labels, bool store_pairs, const IVFSearchParameters* params) const {
+    FAISS_THROW_IF_NOT_MSG(!store_pairs, "store_pairs not supported in IVFDedup");
+    IndexIVFFlat::search_preassigned(n, x, k, assign, centroid_dis, distances, labels, false, params);
+    expand_instances(n, k & 0xffffffff, distances, labels);
+}
+
+void IndexIVFFlatDedup::range_search(idx_t, const float*, float, RangeSearchResult*) const { FAISS_THROW_MSG("not implemented"); }
+void IndexIVFFlatDedup::reconstruct_from_offset(idx_t, idx_t, float*) const { FAISS_THROW_MSG("not implemented"); }
+
 // ------------------------------------------------------------------------------------- Error_sys
 Error_sys::Error_sys(Index* in, size_t nq, size_t topk) : train_num(nq), max_topk(topk) {
     FAISS_THROW_IF_NOT_MSG(nq % 10 == 0, "Train num must be evenly divided by ten");

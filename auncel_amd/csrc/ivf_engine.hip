@@ -935,7 +935,8 @@ void search_fixed_device(amd_ivf* h, const float* d_x, size_t n, size_t k, size_
     ix(h)->last_arith = base.bytes ? 2 : base.fused ? 1 : 0;
     const char* two_s = getenv("AUNCEL_AMD_FIXED_ROUNDS");  // read per call: the tests run both ways in one process
     const int two_env = two_s ? atoi(two_s) : 0;
-    const bool two = two_env ? two_env == 2 : nprobe >= 16;
+    // a handful of queries: the second round's planning + synchronisation costs more than threshold mode saves
+    const bool two = two_env ? two_env == 2 : nprobe >= 16 && n * nprobe >= 4096;
     base.fixed_two = two;
     const size_t first = two ? std::max<size_t>(1, nprobe / 8) : nprobe;
     run_rounds_device(h, base, n, first, nprobe, nullptr);

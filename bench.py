@@ -116,7 +116,7 @@ def main():
     ap.add_argument("--maxtopk", type=int, default=100)
     ap.add_argument("--bound", type=float, default=0.95)
     ap.add_argument("--std-m", type=float, default=1.0)
-    ap.add_argument("--cpu-sample", type=int, default=256)
+    ap.add_argument("--cpu-sample", type=int, default=2048)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--kmeans", choices=["engine", "torch"], default="engine",
                     help="coarse centroids: the engine's Clustering::train restatement (amd_ivf_kmeans, the reference's IVF "

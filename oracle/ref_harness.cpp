@@ -165,6 +165,28 @@ static int run_fixed(const tb::Bundle& in, tb::Bundle& out) {
         out.put_i64("range_stats", {2}, st);
     }
 
+    if (in.scalar_or<int>("dedup", 0) > 0) {  // IndexIVFFlatDedup (IndexIVFFlat.cpp:233-380) over the same quantizer and data
+        IndexIVFFlatDedup dd(&quantizer, d, nlist, mt);
+        dd.init_tune(0, 1, nullptr, nullptr, nullptr, nullptr, nullptr);
+        const size_t half = nb / 2;  // two calls: the second finds duplicates of the first in the lists
+        dd.add(half, xb.as<float>());
+        dd.add(nb - half, xb.as<float>() + half * d);
+        dd.nprobe = nprobe;
+        std::vector<int64_t> sizes(nlist);
+        for (size_t l = 0; l < nlist; l++) sizes[l] = dd.invlists->list_size(l);
+        out.put_i64("dedup_list_sizes", {nlist}, sizes.data());
+        int64_t tot[2] = {(int64_t)dd.ntotal, (int64_t)dd.instances.size()};
+        out.put_i64("dedup_ntotal_ninst", {2}, tot);
+        for (size_t ki = 0; ki < ks.numel(); ki++) {
+            size_t k = ks.as<int64_t>()[ki];
+            std::vector<float> D(nq * k);
+            std::vector<idx_t> I(nq * k);
+            dd.search_preassigned(nq, xq.as<float>(), k, ck_sse.data(), cd_sse.data(), D.data(), I.data(), false);
+            out.put_f32("D_dedup_k" + std::to_string(k), {nq, k}, D.data());
+            out.put_i64("I_dedup_k" + std::to_string(k), {nq, k}, to_i64(I).data());
+        }
+    }
+
     size_t nshard = in.scalar_or<size_t>("nshard", 0);
     if (nshard > 0) {  // lists sharded by list id: owner(l) = l % nshard, global ids
         std::vector<idx_t> a(nb), gid(nb);

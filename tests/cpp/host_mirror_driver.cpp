@@ -137,6 +137,38 @@ static int run_fixed(const tb::Bundle& in) {
         expect(indexIVF_stats.nlist == (size_t)st[0] && indexIVF_stats.ndis == (size_t)st[1], "range_search stats");
     }
 
+    if (in.scalar_or<int>("dedup", 0) > 0) {  // IndexIVFFlatDedup against the compiled reference's (same two add() calls)
+        IndexIVFFlatDedup dd(ix->quantizer, d, nlist, mt);
+        dd.coarse_mode = 0;
+        const size_t half = nb / 2;
+        dd.add(half, xb.as<float>());
+        dd.add(nb - half, xb.as<float>() + half * d);
+        dd.nprobe = nprobe;
+        const int64_t* dls = in.get("dedup_list_sizes").as<int64_t>();
+        bool ok = true;
+        for (size_t l = 0; l < nlist; l++) ok &= dd.invlists->list_size(l) == (size_t)dls[l];
+        expect(ok, "dedup list sizes");
+        const int64_t* tot = in.get("dedup_ntotal_ninst").as<int64_t>();
+        expect(dd.ntotal == tot[0] && (int64_t)dd.instances.size() == tot[1], "dedup ntotal / instances");
+        const tb::Tensor &ck = in.get("coarse_keys_sse"), &cd = in.get("coarse_dis_sse");
+        std::vector<idx_t> keys(ck.as<int64_t>(), ck.as<int64_t>() + nq * nprobe);
+        for (size_t ki = 0; ki < ks.numel(); ki++) {
+            size_t k = ks.as<int64_t>()[ki];
+            std::string suf = "_dedup_k" + std::to_string(k);
+            std::vector<float> D(nq * k);
+            std::vector<idx_t> I(nq * k);
+            dd.search_preassigned(nq, xq.as<float>(), k, keys.data(), cd.as<float>(), D.data(), I.data(), false);
+            expect(same_i(I.data(), in.get("I" + suf).as<int64_t>(), nq * k), "dedup search_preassigned ids" + suf);
+            expect(same_f(D.data(), in.get("D" + suf).as<float>(), nq * k), "dedup search_preassigned distances" + suf);
+            dd.search(nq, xq.as<float>(), k, D.data(), I.data());  // coarse ranking on the device (exact kernel)
+            expect(same_i(I.data(), in.get("I" + suf).as<int64_t>(), nq * k), "dedup search ids" + suf);
+            expect(same_f(D.data(), in.get("D" + suf).as<float>(), nq * k), "dedup search distances" + suf);
+        }
+        bool threw = false;
+        try { dd.search_preassigned(1, xq.as<float>(), 1, keys.data(), cd.as<float>(), nullptr, nullptr, true); } catch (const FaissException&) { threw = true; }
+        expect(threw, "dedup store_pairs throws");
+    }
+
     size_t nshard = in.scalar_or<size_t>("nshard", 0);
     if (nshard) {
         std::vector<idx_t> a(nb), gid(nb);

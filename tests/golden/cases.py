@@ -17,11 +17,11 @@ def _radius(xb, xq, metric, frac=0.01):
     return np.array([np.quantile(a @ b.T, 1.0 - frac)], dtype=np.float32)
 
 
-def _fixed(xb, xq, nlist, nprobe, ks, metric=METRIC_L2, nshard=0, max_codes=0, cseed=99):
+def _fixed(xb, xq, nlist, nprobe, ks, metric=METRIC_L2, nshard=0, max_codes=0, cseed=99, dedup=0):
     cen = synth.sample_centroids(xb, nlist, seed=cseed)
     return dict(kind="fixed", d=xb.shape[1], nlist=nlist, nprobe=nprobe, metric=metric,
                 centroids=cen, xb=xb, xq=xq, ks=np.array(ks, dtype=np.int64), nshard=nshard,
-                max_codes=max_codes, radius=_radius(xb, xq, metric))
+                max_codes=max_codes, radius=_radius(xb, xq, metric), dedup=dedup)
 
 
 def fixed_sift_l2():
@@ -64,7 +64,7 @@ def fixed_dups():
     base = rs.randint(0, 4, size=(500, 16)).astype(np.float32)
     xb = base[rs.randint(0, 500, size=8000)]
     xq = base[rs.randint(0, 500, size=48)] + (rs.randint(0, 2, size=(48, 16))).astype(np.float32)
-    return _fixed(xb, xq, 16, 6, [10, 100], nshard=2)
+    return _fixed(xb, xq, 16, 6, [10, 100], nshard=2, dedup=1)
 
 
 def _auncel(xb, xq, ts, ses, runs, metric=METRIC_L2, nlist=1024, K=100, niter=10):
