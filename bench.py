@@ -297,6 +297,8 @@ def main():
     coarse_ms, select_ms, slot_eff = acc["coarse_ms"], acc["select_ms"], acc["slot_eff"] / args.steps
 
     rec = recall_dist(D, gtD[ts:], topk)
+    log("my_nprobe of the timed queries: percentiles 10/25/50/75/90/95/99 =", np.percentile(my_np[ts:], [10, 25, 50, 75, 90, 95, 99]).tolist(),
+        "; share <= 12:", float((my_np[ts:] <= 12).mean()), "<= 42:", float((my_np[ts:] <= 42).mean()))
     # algorithmic bytes: the reference's own ndis counter (codes actually visited by the probe loops,
     # IndexIVF.cpp:676,733) x d x 4; `scan_bytes` (distances the tiles computed, incl. the probes a round
     # ran past a query's stop point) is reported beside it as computed_over_algorithmic
@@ -405,10 +407,21 @@ def main():
         oD, oI, _ = pyoracle.search_preassigned(lists, xs, K, ck, cd, tuner=stt, offset=ts, nthreads=cores)
         cpu_s = time.perf_counter() - tc
         same = bool(np.array_equal(oI, I[:S]) and np.array_equal(oD, D[:S]) and np.array_equal(tun.my_nprobe[ts:ts + S], my_np[ts:ts + S]))
+        # one thread: what the shipped reference does -- its IndexIVF.cpp cannot be built with OpenMP (Auncel/IndexIVF.cpp:484-486)
+        # and eval/bound.cpp issues one search() per query
+        S1 = min(64, S)
+        tun1 = pyoracle.Tuner(h.get_interdis(), traces, K, ts + ses, arcos=capi.arcos_table())
+        st1 = tun1.struct(topk, req, chosen, args.std_m)
+        t1 = time.perf_counter()
+        cd1, ck1 = pyoracle.knn(pyoracle.METRIC_L2, xs[:S1], cen, nlist, nthreads=1)
+        pyoracle.search_preassigned(lists, xs[:S1], K, ck1, cd1, tuner=st1, offset=ts, nthreads=1)
+        cpu1_s = time.perf_counter() - t1
         out["cpu_baseline"] = {"value": S / cpu_s, "unit": "queries/s", "cores": cores, "kind": "port",
                                "sample": f"first {S} of the {ses} timed queries, same index, coarse + adaptive scan, OpenMP over queries",
-                               "gpu_matches_cpu_on_sample": same}
-        log(f"cpu baseline: {S / cpu_s:.1f} q/s on {cores} threads (setup {time.time() - t0:.1f}s); parity on sample: {same}")
+                               "gpu_matches_cpu_on_sample": same,
+                               "one_thread": {"value": S1 / cpu1_s, "unit": "queries/s", "cores": 1, "sample": f"first {S1} of the timed queries"}}
+        log(f"cpu baseline: {S / cpu_s:.1f} q/s on {cores} threads, {S1 / cpu1_s:.1f} q/s on one (setup {time.time() - t0:.1f}s); "
+            f"parity on sample: {same}")
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
