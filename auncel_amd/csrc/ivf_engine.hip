@@ -1073,6 +1073,8 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     pa.key_stride = base.coarse_stride;
     pa.slot_base = 0;
     pa.first_round = (uint32_t)first_round;
+    static const size_t inc_env = getenv("AUNCEL_AMD_ROUND_INC") ? (size_t)atoi(getenv("AUNCEL_AMD_ROUND_INC")) : 0;
+    pa.min_inc = (uint32_t)(inc_env ? inc_env : first_round);
     pa.tune = base.tuner.enabled;
     pa.d = h->d;
     pa.multipler = base.tuner.multipler;

@@ -187,6 +187,7 @@ struct PlanArgs {
     uint32_t key_stride;
     uint32_t slot_base;        // row of slot 0 in the query matrix the scan reads (pair_query = slot_base + slot)
     uint32_t first_round, round_len;
+    uint32_t min_inc;          // tune mode: probes a later round adds at least (round 0 runs first_round)
     int tune;
     int d;
     float multipler;

@@ -28,7 +28,8 @@ __global__ __launch_bounds__(256) void plan_counts_kernel(PlanArgs a) {
             const unsigned long long safe = (unsigned long long)((float)(stage + 1) * a.multipler);
             const unsigned long long g = (unsigned long long)((double)stage * a.grow);
             target = safe > g ? safe : g;
-            if (target < (unsigned long long)stage + a.first_round) target = (unsigned long long)stage + a.first_round;
+            const unsigned long long inc = stage == 0 ? a.first_round : a.min_inc;
+            if (target < (unsigned long long)stage + inc) target = (unsigned long long)stage + inc;
         }
         if (np != 0) target = np > (unsigned long long)stage + 1 ? np : (unsigned long long)stage + 1;
         bool last = false;
