@@ -295,13 +295,19 @@ class Handle:
         self.max_topk = max_topk
 
     def search_adaptive(self, start, n, query_topk, multipler, std_m, require_acc, my_nprobe, t_recalls, gt_D=None,
-                        profile=False, coarse_mode=0):
+                        profile=False, coarse_mode=0, out=None):
+        """out: optional (D, I) arrays to fill -- a caller that hands over page-locked memory gets its results by direct DMA"""
         req = f32(require_acc)
         gt = f32(gt_D) if gt_D is not None else None
         assert my_nprobe.dtype == np.uint64 and t_recalls.dtype == np.float32
         K = self.max_topk
-        D = np.empty((n, K), np.float32)
-        I = np.empty((n, K), np.int64)
+        if out is not None:
+            D, I = out
+            assert D.shape == (n, K) and D.dtype == np.float32 and D.flags.c_contiguous
+            assert I.shape == (n, K) and I.dtype == np.int64 and I.flags.c_contiguous
+        else:
+            D = np.empty((n, K), np.float32)
+            I = np.empty((n, K), np.int64)
         _chk(lib().amd_ivf_search_adaptive(self._h, C.c_size_t(start), C.c_size_t(n), C.c_size_t(query_topk),
                                            C.c_float(multipler), C.c_float(std_m), _f(req), _f(gt), int(profile), coarse_mode,
                                            my_nprobe.ctypes.data_as(_u64p), _f(t_recalls), _f(D), _i(I)))

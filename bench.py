@@ -103,8 +103,8 @@ def recall_dist(D, gtD, topk):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--nb", type=int, default=10_000_000)
     ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--nlist", type=int, default=4096)
@@ -121,6 +121,7 @@ def main():
     ap.add_argument("--kmeans", choices=["engine", "torch"], default="engine",
                     help="coarse centroids: the engine's Clustering::train restatement (amd_ivf_kmeans, the reference's IVF "
                          "training: 25 iterations, 256 points per centroid) or a 4-step torch Lloyd")
+    ap.add_argument("--pinned-out", type=int, default=1, help="1: result buffers in page-locked host memory, 0: pageable")
     ap.add_argument("--in-flight", type=int, default=3,
                     help="batches kept in flight per GPU, each from its own host thread on its own search context "
                          "(amd_ivf_clone); 1 = one batch at a time")
@@ -222,10 +223,20 @@ def main():
 
     stagger_s = float(os.environ.get("BENCH_STAGGER_MS", "0")) / 1e3
 
+    # result buffers of every context: page-locked host memory (the caller's choice in the reference's API too), so that
+    # the 6 MB of (D, I) of a step come back by direct DMA instead of through the runtime's staging copies
+    outs = {}
+    for c in ctxs:
+        if args.pinned_out:
+            outs[id(c)] = (torch.empty((ses, K), dtype=torch.float32).pin_memory().numpy(),
+                           torch.empty((ses, K), dtype=torch.int64).pin_memory().numpy())
+        else:
+            outs[id(c)] = None
+
     def step(ctx):
         np_ = np.zeros(ts + ses, dtype=np.uint64)
         tr_ = np.zeros(ts + ses, dtype=np.float32)
-        D, I = ctx.search_adaptive(ts, ses, topk, chosen, args.std_m, req, np_, tr_)
+        D, I = ctx.search_adaptive(ts, ses, topk, chosen, args.std_m, req, np_, tr_, out=outs[id(ctx)])
         return D, I, np_
 
     def barrier():
