@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--std-m", type=float, default=1.0)
     ap.add_argument("--cpu-sample", type=int, default=2048)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-ref", action="store_true", help="cpu_baseline from the CPU restatement only (skip oracle/_ref/ref_harness)")
     ap.add_argument("--kmeans", choices=["engine", "torch"], default="engine",
                     help="coarse centroids: the engine's Clustering::train restatement (amd_ivf_kmeans, the reference's IVF "
                          "training: 25 iterations, 256 points per centroid) or a 4-step torch Lloyd")
@@ -397,6 +398,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         from oracle import pyoracle
         S = min(args.cpu_sample, ses)
+        try:
+            log(f"host: os.cpu_count {os.cpu_count()}, affinity {len(os.sched_getaffinity(0))}, cgroup cpu.max {open('/sys/fs/cgroup/cpu.max').read().strip()}")
+        except Exception:  # noqa: BLE001
+            pass
         t0 = time.time()
         codes, ids, off = [], [], np.zeros(nlist + 1, dtype=np.uintp)
         for l in range(nlist):
@@ -433,6 +438,33 @@ def main():
                                "one_thread": {"value": S1 / cpu1_s, "unit": "queries/s", "cores": 1, "sample": f"first {S1} of the timed queries"}}
         log(f"cpu baseline: {S / cpu_s:.1f} q/s on {cores} threads, {S1 / cpu1_s:.1f} q/s on one (setup {time.time() - t0:.1f}s); "
             f"parity on sample: {same}")
+        # The compiled reference itself (oracle/_ref/ref_harness, built from /root/reference where that exists; the binary
+        # travels, the sources do not): same lists, centroids and traces, eval/bound.cpp's one-search-per-query loop on one
+        # thread -- as the reference runs -- and the same calls spread over the host cores.
+        from oracle import refbench
+        if refbench.available() and not args.no_ref:
+            try:
+                t0 = time.time()
+                ro = refbench.run(cen, lists.off, lists.codes, lists.ids, traces, xs, ts, K, topk, args.bound, chosen, args.std_m,
+                                  single_thread_queries=S1, threads=cores)
+                same_ref = bool(np.array_equal(ro["I"], I[:S]) and np.array_equal(ro["D"], D[:S])
+                                and np.array_equal(ro["my_nprobe"].astype(np.uint64), my_np[ts:ts + S]))
+                port = out["cpu_baseline"]
+                out["cpu_baseline"] = {
+                    "value": S / ro["seconds_all_threads"], "unit": "queries/s", "cores": ro["threads"], "kind": "reference",
+                    "sample": f"first {S} of the {ses} timed queries; the compiled reference (Auncel/*.cpp, -O3 -msse4) on the engine's "
+                              "lists / centroids / traces, one IndexIVF::search(1, ...) per query in tune mode, OpenMP over queries",
+                    "gpu_matches_cpu_on_sample": same_ref,
+                    "one_thread": {"value": ro["queries_one_thread"] / ro["seconds_one_thread"], "unit": "queries/s", "cores": 1,
+                                   "sample": f"first {ro['queries_one_thread']} of the timed queries, Error_sys::search(D, I, i, 1) per query "
+                                             "(eval/bound.cpp:380-386) -- what the shipped reference does"},
+                    "port": {k: port[k] for k in ("value", "cores", "gpu_matches_cpu_on_sample", "one_thread")},
+                }
+                log(f"reference on the host: {S / ro['seconds_all_threads']:.1f} q/s on {ro['threads']} threads, "
+                    f"{ro['queries_one_thread'] / ro['seconds_one_thread']:.1f} q/s on one ({time.time() - t0:.1f}s incl. hand-over); "
+                    f"GPU == reference on the sample: {same_ref}")
+            except Exception as e:  # noqa: BLE001 -- the port's figures stay
+                log("reference harness not usable here:", repr(e))
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -20,7 +20,9 @@
 //   Error_sys                     profile.cpp:28-280
 #include <unistd.h>
 
+#include <chrono>
 #include <cmath>
+#include <omp.h>
 #include <cstdio>
 #include <iostream>
 #include <memory>
@@ -441,6 +443,93 @@ static int run_auncel(const tb::Bundle& in, tb::Bundle& out) {
     return 0;
 }
 
+// bench.py's cpu_baseline, kind "reference": the compiled reference itself, timed on the host.  The index is assembled from
+// the centroids and the inverted lists the engine built (same list order: ArrayInvertedLists::add_entries per list), the
+// traces are the trained ones, and the search is bound.cpp's loop -- one Error_sys::search(D, I, i, 1) per query
+// (eval/bound.cpp:380-386) -- first on one thread, as the reference runs (its IndexIVF.cpp has no OpenMP), then the same
+// per-query calls spread over the host cores (every query writes only its own slots of my_nprobe / t_recalls).
+static int run_bench(const tb::Bundle& in, tb::Bundle& out) {
+    const size_t d = in.scalar<size_t>("d"), nlist = in.scalar<size_t>("nlist"), K = in.scalar<size_t>("max_topk");
+    const size_t topk = in.scalar<size_t>("topk"), id0 = in.scalar<size_t>("id0");
+    const size_t S1 = in.scalar<size_t>("single_thread_queries");
+    const tb::Tensor &cen = in.get("centroids"), &off = in.get("list_off"), &codes = in.get("codes"), &ids = in.get("ids");
+    const tb::Tensor& xq = in.get("xq");  // S x d: queries id0 .. id0 + S
+    const size_t S = xq.dims[0], nall = ((id0 + S + 9) / 10) * 10;
+    const float acc = in.get("require_acc").as<float>()[0];
+
+    IndexFlat quantizer(d, METRIC_L2);
+    quantizer.add(nlist, cen.as<float>());
+    IndexIVFFlat index(&quantizer, d, nlist, METRIC_L2);
+    index.is_trained = true;
+    index.interdis_cem.resize(nlist * (nlist - 1) / 2);
+    fvec_inter_vecs(index.interdis_cem.data(), cen.as<float>(), nlist, d);  // train_q1, IndexIVF.cpp:97-100
+    const int64_t* lo = off.as<int64_t>();
+    for (size_t l = 0; l < nlist; l++) {
+        const size_t n = (size_t)(lo[l + 1] - lo[l]);
+        if (n) index.invlists->add_entries(l, n, (const idx_t*)(ids.as<int64_t>() + lo[l]), (const uint8_t*)(codes.as<float>() + (size_t)lo[l] * d));
+    }
+    index.ntotal = lo[nlist];
+
+    Error_sys es(&index, nall, K);  // resets index.t
+    std::vector<float> zeroD(nall * K, 0.f);  // train_D is read for logging only (IndexIVF.cpp:509)
+    index.init_tune(nall, K, nullptr, zeroD.data(), nullptr, nullptr, nullptr);
+    const size_t ntr = index.t->traces.size();
+    for (size_t i = 0; i < ntr; i++) {
+        const tb::Tensor &tx = in.get("trace_x" + std::to_string(i)), &ty = in.get("trace_y" + std::to_string(i)), &tsd = in.get("trace_std" + std::to_string(i));
+        Trace& tr = index.t->traces[i];
+        tr.trace.resize(tx.numel());
+        for (size_t j = 0; j < tx.numel(); j++) tr.trace[j] = std::make_pair(tx.as<float>()[j], ty.as<float>()[j]);
+        tr.stds.assign(tsd.as<float>(), tsd.as<float>() + tsd.numel());
+    }
+    es.is_trained = true;
+    std::vector<float> xall(nall * d, 0.f), req(nall, acc);
+    memcpy(xall.data() + id0 * d, xq.as<float>(), S * d * sizeof(float));
+    std::vector<float> D(S * K);
+    std::vector<int64_t> I(S * K);
+    auto arm = [&]() {
+        es.set_topk(topk);
+        es.set_queries(S, xall.data(), req.data(), nall);
+        index.t->multipler = (float)in.scalar<double>("multipler");
+        index.t->std_m = (float)in.scalar<double>("std_m");
+        index.t->profile = false;
+    };
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+
+    arm();
+    const int max_threads = omp_get_max_threads();
+    omp_set_num_threads(1);  // the quantizer's own `omp parallel for` (utils.cpp:454-490) would otherwise raise a full team per query
+    double t0 = now();
+    for (size_t i = 0; i < std::min(S1, S); i++) es.search(D.data() + i * K, I.data() + i * K, id0 + i, 1);
+    const double t_single = now() - t0;
+    omp_set_num_threads(max_threads);
+
+    arm();
+    index.set_tune_mode();
+    index.nprobe = nlist;
+    int nthreads = 1;
+    t0 = now();
+#pragma omp parallel
+    {
+#pragma omp single
+        nthreads = omp_get_num_threads();
+#pragma omp for schedule(dynamic, 1)
+        for (long i = 0; i < (long)S; i++)
+            index.search(1, xall.data() + (id0 + i) * d, K, D.data() + i * K, (idx_t*)(I.data() + i * K), id0 + i);
+    }
+    const double t_all = now() - t0;
+    index.set_tune_off();
+
+    out.put_f32("D", {S, K}, D.data());
+    out.put_i64("I", {S, K}, I.data());
+    std::vector<uint64_t> np(index.t->my_nprobe + id0, index.t->my_nprobe + id0 + S);
+    out.put_u64("my_nprobe", {S}, np.data());
+    out.put_scalar_f64("seconds_one_thread", t_single);
+    out.put_scalar_i64("queries_one_thread", (int64_t)std::min(S1, S));
+    out.put_scalar_f64("seconds_all_threads", t_all);
+    out.put_scalar_i64("threads", nthreads);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc != 4) {
         fprintf(stderr, "usage: %s <fixed|auncel> <in.tb> <out.tb>\n", argv[0]);
@@ -451,7 +540,7 @@ int main(int argc, char** argv) {
         tb::Bundle out;
         std::string cmd = argv[1];
         // note: sys_train writes Validation_*.log into the CWD: run from a scratch dir
-        int rc = cmd == "fixed" ? run_fixed(in, out) : cmd == "auncel" ? run_auncel(in, out) : cmd == "io" ? run_io(in, out) : cmd == "kmeans" ? run_kmeans(in, out) : 2;
+        int rc = cmd == "fixed" ? run_fixed(in, out) : cmd == "auncel" ? run_auncel(in, out) : cmd == "io" ? run_io(in, out) : cmd == "kmeans" ? run_kmeans(in, out) : cmd == "bench" ? run_bench(in, out) : 2;
         if (rc == 0) out.save(argv[3]);
         return rc;
     } catch (const std::exception& e) {

@@ -193,3 +193,23 @@ def test_kmeans(oracle, name):
         assert np.array_equal(obj.view(np.uint32), gold["obj"].view(np.uint32))
     else:
         assert np.allclose(obj, gold["obj"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["auncel_sift_d32"])
+def test_reference_bench_mode(oracle, name):
+    """bench.py's cpu_baseline (kind "reference") runs the compiled reference through ref_harness's `bench` mode on an index
+    assembled from lists and traces handed over by the caller: same (D, I, my_nprobe) as the reference's own end-to-end run"""
+    from oracle import refbench
+    if not refbench.available():
+        pytest.skip("oracle/_ref/ref_harness not built (reference sources absent)")
+    case, gold = load_case(name)
+    ts, ses, K = case["train_num"], case["test_num"], case["max_topk"]
+    lists = oracle.Lists(case["metric"], gold["centroids"], case["xb"], gold["assign"])
+    r = 0
+    out = refbench.run(gold["centroids"], lists.off, lists.codes, lists.ids, traces_from_gold(gold), case["xq"][ts:ts + ses], ts, K,
+                       int(case["topks"][r]), float(case["require_acc"][r]), float(case["multipler"][r]), float(case["std_m"][r]),
+                       single_thread_queries=8, threads=4)
+    assert np.array_equal(out["I"], gold[f"I_r{r}"])
+    assert np.array_equal(out["D"].view(np.uint32), gold[f"D_r{r}"].view(np.uint32))
+    assert np.array_equal(out["my_nprobe"], gold[f"my_nprobe_r{r}"])
+    assert out["seconds_one_thread"] > 0 and out["seconds_all_threads"] > 0 and out["threads"] == 4
