@@ -29,6 +29,18 @@ sys.path.insert(0, ROOT)
 SIGMA = 38.0
 
 
+def host_cores():
+    """hardware threads this process may actually use: the affinity mask, cut by a cgroup CPU quota if there is one"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except Exception:  # noqa: BLE001 -- no cgroup v2 file: the mask is all there is
+        pass
+    return n
+
+
 def log(*a):
     if int(os.environ.get("RANK", "0")) == 0:
         print("[bench]", *a, file=sys.stderr, flush=True)
@@ -414,7 +426,7 @@ def main():
         lists.off, lists.codes, lists.ids = off, np.concatenate(codes), np.concatenate(ids)
         del codes, ids
         lists.struct = pyoracle.OrcIndex(lists.metric, d, nlist, pyoracle._s(lists.off), pyoracle._f(lists.codes), pyoracle._i(lists.ids))
-        cores = os.cpu_count() or 1
+        cores = host_cores()  # threads beyond a CPU quota only get throttled
         xs = xq[ts:ts + S]
         tun = pyoracle.Tuner(h.get_interdis(), traces, K, ts + ses, arcos=capi.arcos_table())
         stt = tun.struct(topk, req, chosen, args.std_m)
