@@ -2,11 +2,11 @@
 // (/root/reference/Auncel/*.cpp built into oracle/_ref/ by oracle/Makefile) and dumps what
 // the reference computes for a given input bundle.  It is how tests/golden/*.npz are made
 // (tests/golden/make_golden.py) and how the CPU restatement in oracle/ivf_oracle.cpp is
-// pinned.  It only exists in this container: /root/reference is not on the GPU box, the
-// built binary under oracle/_ref/ travels there but is optional (cpu_baseline kind
-// "reference").  Nothing in the product imports or links this.
+// pinned.  It is built only in the container that has /root/reference; the binary under
+// oracle/_ref/ travels to the GPU box, where bench.py's cpu_baseline leg runs its `bench` mode
+// (kind "reference", oracle/refbench.py).  Nothing in the product imports or links this.
 //
-// usage: ref_harness <fixed|auncel|io> <in.tb> <out.tb>
+// usage: ref_harness <fixed|auncel|io|kmeans|bench> <in.tb> <out.tb>
 //
 // Reference entry points exercised (file:line in /root/reference/Auncel):
 //   IndexFlat::search             IndexFlat.cpp:42-56   (knn_L2sqr_sse / _blas, utils.cpp:454-655)
@@ -532,7 +532,7 @@ static int run_bench(const tb::Bundle& in, tb::Bundle& out) {
 
 int main(int argc, char** argv) {
     if (argc != 4) {
-        fprintf(stderr, "usage: %s <fixed|auncel> <in.tb> <out.tb>\n", argv[0]);
+        fprintf(stderr, "usage: %s <fixed|auncel|io|kmeans|bench> <in.tb> <out.tb>\n", argv[0]);
         return 2;
     }
     try {
