@@ -1175,11 +1175,14 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
                 sa.mask = h->w_mask.as<unsigned long long>();
             }
             size_t t = h->timer.begin(CAT_SCAN, s);
+            static const int nstreams = getenv("AUNCEL_AMD_SCAN_STREAMS") ? atoi(getenv("AUNCEL_AMD_SCAN_STREAMS")) : 4;
             const bool fork = true;  // every shape on a side stream (see make_main_stream)
             if (fork) {
                 HIP_CHECK(hipEventRecord(h->ev_fork, s));
                 for (int i = 0; i < 4; i++) HIP_CHECK(hipStreamWaitEvent(h->aux[i], h->ev_fork, 0));
-                launch_scan(sa, n_qg, h->aux[3], h->aux[0], h->aux[1], h->aux[2]);
+                if (nstreams == 1) launch_scan(sa, n_qg, h->aux[3], h->aux[3], h->aux[3], h->aux[3]);
+                else if (nstreams == 2) launch_scan(sa, n_qg, h->aux[3], h->aux[0], h->aux[0], h->aux[3]);  // 8,4 | 2,1
+                else launch_scan(sa, n_qg, h->aux[3], h->aux[0], h->aux[1], h->aux[2]);
                 for (int i = 0; i < 4; i++) {
                     HIP_CHECK(hipEventRecord(h->ev_join[i], h->aux[i]));
                     HIP_CHECK(hipStreamWaitEvent(s, h->ev_join[i], 0));
