@@ -249,6 +249,30 @@ namespace {
 
 void use_device(const amd_ivf* h) { HIP_CHECK(hipSetDevice(h->device)); }
 
+// Host waits.  hipStreamSynchronize spins on the completion signal: lowest wake-up latency, one busy core per waiting thread.
+// AUNCEL_AMD_BLOCKING_SYNC=1 waits on a blocking event instead (the thread sleeps until the interrupt), for hosts where the
+// calling threads outnumber the cores they may use.
+hipError_t stream_sync(hipStream_t s) {
+    static const bool blocking = [] {
+        const char* e = getenv("AUNCEL_AMD_BLOCKING_SYNC");
+        return e && *e && *e != '0';
+    }();
+    if (!blocking) return hipStreamSynchronize(s);
+    thread_local hipEvent_t ev = nullptr;
+    thread_local int ev_dev = -1;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (!ev || ev_dev != dev) {
+        e = hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+        ev_dev = dev;
+    }
+    e = hipEventRecord(ev, s);
+    if (e != hipSuccess) return e;
+    return hipEventSynchronize(ev);
+}
+
 // The main stream of a context carries its latency-bound work (round planning, ordered selection, transfers); with
 // several contexts on one GPU it gets the high priority so that those kernels are not queued behind another context's
 // scan workgroups (the scans themselves run on the normal-priority side streams).
@@ -292,7 +316,7 @@ void upload_lists(amd_ivf* h) {
         h->d_code_norms.ensure(nt * sizeof(uint32_t));
         launch_bytes_from_f32(h->d_codes.as<float>(), nt, h->d, h->d_codes8.as<uint8_t>(), h->d_code_norms.as<uint32_t>(), h->stream);
     }
-    HIP_CHECK(hipStreamSynchronize(h->stream));
+    HIP_CHECK(stream_sync(h->stream));
     h->lists_dirty = false;
 }
 
@@ -435,7 +459,7 @@ static uint32_t scan_qblock(bool bytes) {
 static void print_replay_dbg(amd_ivf* h, size_t mb, hipStream_t s) {
     std::vector<unsigned long long> dbg(mb * 8);
     HIP_CHECK(hipMemcpyAsync(dbg.data(), h->w_misc.p, mb * 64, hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipStreamSynchronize(s));
+    HIP_CHECK(stream_sync(s));
     static const char* nm[8] = {"wave cycles", "heap updates", "candidates", "rule evaluations", "stream cycles", "rule cycles", "masked chunks", "probes"};
     for (int c = 0; c < 8; c++) {
         std::vector<unsigned long long> v(mb);
@@ -717,7 +741,7 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
         if (dbg_replay) print_replay_dbg(h, mb, s);
         // the pinned staging buffers are reused by the next sub-batch
         const double t_launched = now_us();
-        HIP_CHECK(hipStreamSynchronize(s));
+        HIP_CHECK(stream_sync(s));
         if (dbg_timing())
             fprintf(stderr, "[round] queries %zu pairs %zu items %zu: host prep %.0f us, launch %.0f us, gpu wait %.0f us\n", mb, npairs, nitems,
                     t_prep - t_enter, t_launched - t_prep, now_us() - t_launched);
@@ -728,7 +752,7 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
 void check_device_error(amd_ivf* h) {
     uint32_t err = 0;
     HIP_CHECK(hipMemcpyAsync(&err, h->w_error.p, 4, hipMemcpyDeviceToHost, h->stream));
-    HIP_CHECK(hipStreamSynchronize(h->stream));
+    HIP_CHECK(stream_sync(h->stream));
     if (err == ERR_ARCOS_DOMAIN) throw EngineError("arcos's domain definition is [-1, 1]");
     if (err == ERR_COSINE_PRECOND) throw EngineError("cosine theorem's prerequisites");
     if (err == ERR_INVALID_KEY) throw EngineError("Invalid key");
@@ -738,7 +762,7 @@ void check_device_error(amd_ivf* h) {
 void fold_stats(amd_ivf* h, size_t nq) {
     unsigned long long st[3];
     HIP_CHECK(hipMemcpyAsync(st, h->w_stats.p, 24, hipMemcpyDeviceToHost, h->stream));
-    HIP_CHECK(hipStreamSynchronize(h->stream));
+    HIP_CHECK(stream_sync(h->stream));
     h->stats_host[0] += nq;
     h->stats_host[1] += st[0];
     h->stats_host[2] += st[1];
@@ -906,7 +930,7 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
                              d_out_dis + c0 * nprobe, d_out_keys + c0 * nprobe, s, (uint32_t)prefix);
         }
         h->timer.end(t, s);
-        HIP_CHECK(hipStreamSynchronize(s));
+        HIP_CHECK(stream_sync(s));
     }
 }
 
@@ -943,7 +967,7 @@ void search_fixed_device(amd_ivf* h, const float* d_x, size_t n, size_t k, size_
     check_device_error(h);
     HIP_CHECK(hipMemcpyAsync(D, h->w_D.p, n * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipMemcpyAsync(I, h->w_I.p, n * k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-    HIP_CHECK(hipStreamSynchronize(h->stream));
+    HIP_CHECK(stream_sync(h->stream));
     fold_stats(h, n);
 }
 
@@ -984,7 +1008,7 @@ void search_fixed_core(amd_ivf* h, const float* d_x, size_t n, size_t k, size_t 
     check_device_error(h);
     HIP_CHECK(hipMemcpyAsync(D, h->w_D.p, n * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipMemcpyAsync(I, h->w_I.p, n * k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-    HIP_CHECK(hipStreamSynchronize(h->stream));
+    HIP_CHECK(stream_sync(h->stream));
     fold_stats(h, n);
 }
 
@@ -1000,7 +1024,7 @@ void search_full(amd_ivf* h, const float* d_x, size_t n, size_t k, size_t nprobe
     }
     std::vector<int64_t> keys(n * nprobe);
     HIP_CHECK(hipMemcpyAsync(keys.data(), h->w_ckeys.p, n * nprobe * 8, hipMemcpyDeviceToHost, h->stream));
-    HIP_CHECK(hipStreamSynchronize(h->stream));
+    HIP_CHECK(stream_sync(h->stream));
     search_fixed_core(h, d_x, n, k, nprobe, keys.data(), D, I, 0, 0, qr);
 }
 
@@ -1134,12 +1158,12 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         HIP_CHECK(hipMemsetAsync(h->w_pl_counters.as<uint32_t>() + 6, 0, 4, s));
         pa.round_len = (uint32_t)round_len;
         if (base.d_budget_ms) {  // the clock is read once the previous round has finished
-            HIP_CHECK(hipStreamSynchronize(s));
+            HIP_CHECK(stream_sync(s));
             pa.elapsed_ms = (float)((now_us() - base.t_start_us) * 1e-3);
         }
         launch_plan(pa, s);
         HIP_CHECK(hipMemcpyAsync(hc, h->w_pl_counters.p, 96, hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipStreamSynchronize(s));
+        HIP_CHECK(stream_sync(s));
         const double t1 = now_us();
         const uint32_t nact = hc[0], npairs = hc[2], ngroups = hc[3];
         if (nact == 0) break;
@@ -1219,7 +1243,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             std::vector<uint32_t> cnts(n), probes(n);
             HIP_CHECK(hipMemcpyAsync(cnts.data(), h->w_rcount.p, n * 4, hipMemcpyDeviceToHost, s));
             HIP_CHECK(hipMemcpyAsync(probes.data(), h->w_pl_cnt.p, n * 4, hipMemcpyDeviceToHost, s));
-            HIP_CHECK(hipStreamSynchronize(s));
+            HIP_CHECK(stream_sync(s));
             check_device_error(h);
             // the queries of a round are a run of consecutive slots (everything unfinished before the budget cut), so
             // appending the rounds keeps the results in query order
@@ -1245,7 +1269,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
                 HIP_CHECK(hipMemcpyAsync(h->r_dist.data() + at, h->w_rdis.p, tot * 4, hipMemcpyDeviceToHost, s));
             }
             h->timer.end(t, s);
-            HIP_CHECK(hipStreamSynchronize(s));
+            HIP_CHECK(stream_sync(s));
             continue;
         }
         ReplayArgs ra{};
@@ -1356,7 +1380,7 @@ void run_rounds(amd_ivf* h, RoundSpec& base, size_t n, size_t first_round, size_
             std::vector<int64_t> nk(n * new_have);
             HIP_CHECK(hipMemcpy2DAsync(nk.data(), new_have * 8, base.d_ckeys, (size_t)base.coarse_stride * 8, new_have * 8, n,
                                        hipMemcpyDeviceToHost, h->stream));
-            HIP_CHECK(hipStreamSynchronize(h->stream));
+            HIP_CHECK(stream_sync(h->stream));
             hkeys.swap(nk);
             have = new_have;
             stride = new_have;
@@ -1376,7 +1400,7 @@ void run_rounds(amd_ivf* h, RoundSpec& base, size_t n, size_t first_round, size_
         HIP_CHECK(hipMemcpyAsync(done.data(), h->w_done.p, n * 4, hipMemcpyDeviceToHost, h->stream));
         if (d_np_abs)
             HIP_CHECK(hipMemcpyAsync(np.data(), d_np_abs + start, n * 8, hipMemcpyDeviceToHost, h->stream));
-        HIP_CHECK(hipStreamSynchronize(h->stream));
+        HIP_CHECK(stream_sync(h->stream));
         if (dbg_timing()) fprintf(stderr, "[rounds] plan+keys %.0f us, readback %.0f us\n", t_plan1 - t_plan0, now_us() - t_rb0);
         round_len = std::min<size_t>(round_len * 2, 64);
     }
@@ -1483,7 +1507,7 @@ int amd_ivf_set_centroids(amd_ivf_t* h, const float* centroids) {
                              hipMemcpyHostToDevice, h->stream));
     h->d_centroid_norms.ensure(h->nlist * sizeof(float));
     launch_row_norms(h->d_centroids.as<float>(), h->nlist, h->dpad, h->d_centroid_norms.as<float>(), h->stream);
-    HIP_CHECK(hipStreamSynchronize(h->stream));
+    HIP_CHECK(stream_sync(h->stream));
     h->have_centroids = true;
     h->have_interdis = false;
     h->centroid_range = IntRange();
@@ -1528,7 +1552,7 @@ int amd_ivf_add(amd_ivf_t* h, size_t n, const float* x, const int64_t* xids, con
             upload_rows(h, h->w_x.as<float>(), x + i0 * h->d, m);
             coarse_dev(h, h->w_x.as<float>(), m, 1, 0, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>(), 0);
             HIP_CHECK(hipMemcpyAsync(assign.data() + i0, h->w_ckeys.p, m * 8, hipMemcpyDeviceToHost, h->stream));
-            HIP_CHECK(hipStreamSynchronize(h->stream));
+            HIP_CHECK(stream_sync(h->stream));
         }
         idx = assign.data();
         double ms[NCAT], ln[NCAT];
@@ -1575,7 +1599,7 @@ int amd_ivf_get_list(const amd_ivf_t* hc, size_t list_no, float* codes, int64_t*
         HIP_CHECK(hipMemcpy2DAsync(codes, h->d * sizeof(float), h->d_codes.as<float>() + h->h_list_off[list_no] * h->dpad,
                                    h->dpad * sizeof(float), h->d * sizeof(float), n, hipMemcpyDeviceToHost, h->stream));
         HIP_CHECK(hipMemcpyAsync(ids, h->d_ids.as<int64_t>() + h->h_list_off[list_no], n * 8, hipMemcpyDeviceToHost, h->stream));
-        HIP_CHECK(hipStreamSynchronize(h->stream));
+        HIP_CHECK(stream_sync(h->stream));
     }
     API_END
 }
@@ -1598,7 +1622,7 @@ int amd_ivf_coarse(amd_ivf_t* h, size_t n, const float* x, size_t nprobe, float*
                h->allow_fused && h->centroid_range.fusable_with(qr));
     HIP_CHECK(hipMemcpyAsync(coarse_dis, h->w_cdis.p, n * nprobe * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipMemcpyAsync(keys, h->w_ckeys.p, n * nprobe * 8, hipMemcpyDeviceToHost, h->stream));
-    HIP_CHECK(hipStreamSynchronize(h->stream));
+    HIP_CHECK(stream_sync(h->stream));
     finish_timing(h, wc.stop());
     API_END
 }
@@ -1649,7 +1673,7 @@ int amd_ivf_set_queries(amd_ivf_t* h, size_t n, const float* x) {
     use_device(h);
     h->d_resident.ensure(std::max<size_t>(n, 1) * h->dpad * sizeof(float));
     upload_rows(h, h->d_resident.as<float>(), x, n);
-    HIP_CHECK(hipStreamSynchronize(h->stream));
+    HIP_CHECK(stream_sync(h->stream));
     h->n_resident = n;
     h->resident_range = IntRange();
     h->resident_range.add(x, n * (size_t)h->d);
@@ -1789,7 +1813,7 @@ static void timed_core(amd_ivf* h, const float* d_x, size_t start, size_t n, siz
     if (nprobe_used) HIP_CHECK(hipMemcpyAsync(stage.data(), h->w_stage.p, n * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipMemcpyAsync(D, h->w_D.p, n * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipMemcpyAsync(I, h->w_I.p, n * k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-    HIP_CHECK(hipStreamSynchronize(h->stream));
+    HIP_CHECK(stream_sync(h->stream));
     for (size_t i = 0; i < stage.size(); i++) nprobe_used[i] = stage[i];
     fold_stats(h, n);
 }
@@ -1862,7 +1886,7 @@ int amd_ivf_scan_codes(amd_ivf_t* h, const float* query, size_t list_no, int sto
     HIP_CHECK(hipMemcpyAsync(idxi, h->w_I.p, k * 8, hipMemcpyDeviceToHost, h->stream));
     unsigned long long st[3];
     HIP_CHECK(hipMemcpyAsync(st, h->w_stats.p, 24, hipMemcpyDeviceToHost, h->stream));
-    HIP_CHECK(hipStreamSynchronize(h->stream));
+    HIP_CHECK(stream_sync(h->stream));
     if (nup) *nup = st[2];
     double ms[NCAT], ln[NCAT];
     h->timer.collect(ms, NCAT, ln);
@@ -1894,7 +1918,7 @@ int amd_ivf_distance_to_code(amd_ivf_t* h, const float* query, size_t list_no, s
     const size_t one_qg1[4] = {1, 0, 0, 0};
     launch_scan(sa, one_qg1, h->stream);
     HIP_CHECK(hipMemcpyAsync(dis, h->w_dist.p, 4, hipMemcpyDeviceToHost, h->stream));
-    HIP_CHECK(hipStreamSynchronize(h->stream));
+    HIP_CHECK(stream_sync(h->stream));
     API_END
 }
 
@@ -1913,7 +1937,7 @@ int amd_ivf_set_interdis(amd_ivf_t* h, const float* table) {
     h->d_interdis.ensure(std::max<size_t>(sz, 1) * 4);
     if (table) {
         HIP_CHECK(hipMemcpyAsync(h->d_interdis.p, table, sz * 4, hipMemcpyHostToDevice, h->stream));
-        HIP_CHECK(hipStreamSynchronize(h->stream));
+        HIP_CHECK(stream_sync(h->stream));
     } else {
         if (!h->have_centroids) throw EngineError("quantizer has no centroids");
         // all-pairs centroid distances with the scan kernel, then pack the upper triangle
@@ -1961,7 +1985,7 @@ int amd_ivf_set_interdis(amd_ivf_t* h, const float* table) {
         const size_t all_qg4[4] = {0, 0, items.size(), 0};
         launch_scan(sa, all_qg4, h->stream);
         launch_pack_upper(d_full.as<float>(), (uint32_t)nl, h->d_interdis.as<float>(), h->stream);
-        HIP_CHECK(hipStreamSynchronize(h->stream));
+        HIP_CHECK(stream_sync(h->stream));
         if (h->metric == METRIC_IP) {
             // acos on the host libm, as the reference does (IndexIVF.cpp:109-110)
             std::vector<float> t(sz);
@@ -2046,7 +2070,7 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
     else run_rounds_device(L, base, n, first_env, nlist, dnp);
     HIP_CHECK(hipMemcpyAsync(D, L->w_D.p, n * K * 4, hipMemcpyDeviceToHost, L->stream));
     HIP_CHECK(hipMemcpyAsync(I, L->w_I.p, n * K * 8, hipMemcpyDeviceToHost, L->stream));
-    HIP_CHECK(hipStreamSynchronize(L->stream));
+    HIP_CHECK(stream_sync(L->stream));
     fold_stats(L, n);
 }
 
@@ -2086,7 +2110,7 @@ static void adaptive_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n
     HIP_CHECK(hipMemcpyAsync(dtr, t_recalls, nabs * 4, hipMemcpyHostToDevice, h->stream));
     if (gt_D) HIP_CHECK(hipMemcpyAsync(dgt, gt_D, nabs * K * 4, hipMemcpyHostToDevice, h->stream));
     HIP_CHECK(hipMemcpyAsync(d_np.p, my_nprobe, nabs * 8, hipMemcpyHostToDevice, h->stream));
-    HIP_CHECK(hipStreamSynchronize(h->stream));
+    HIP_CHECK(stream_sync(h->stream));
 
     // How much of the coarse ranking can be consumed: set_online reads entries 0 .. nlist/8+20, and the probe loop ends at
     // my_nprobe <= floor((nlist/8) * multipler) (IndexIVF.cpp:615-632) or at a value the caller passed in.  When that is
@@ -2134,7 +2158,7 @@ static void adaptive_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n
         if (e) std::rethrow_exception(e);
     HIP_CHECK(hipMemcpyAsync(my_nprobe + start, d_np.as<unsigned long long>() + start, n * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipMemcpyAsync(t_recalls + start, dtr + start, n * 4, hipMemcpyDeviceToHost, h->stream));
-    HIP_CHECK(hipStreamSynchronize(h->stream));
+    HIP_CHECK(stream_sync(h->stream));
     // fold the kids' counters and kernel timings into the handle
     const double wall = wc.stop();
     double ms[NCAT] = {0, 0, 0}, ln[NCAT] = {0, 0, 0};
@@ -2248,7 +2272,7 @@ static void train_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n, s
     HIP_CHECK(hipMemcpyAsync(I, h->w_I.p, n * K * 8, hipMemcpyDeviceToHost, h->stream));
     for (size_t i = 0; i < ntr; i++)
         HIP_CHECK(hipMemcpyAsync(raw[i], ptrs[i], per * 4, hipMemcpyDeviceToHost, h->stream));
-    HIP_CHECK(hipStreamSynchronize(h->stream));
+    HIP_CHECK(stream_sync(h->stream));
     double ms[NCAT], ln[NCAT];
     h->timer.collect(ms, NCAT, ln);
 }
@@ -2457,7 +2481,7 @@ int amd_ivf_kmeans(int d, size_t n, const float* x_in, size_t k, int metric, int
         launch_kmeans_group(d_keys.as<int64_t>(), nx, (uint32_t)k, keys_in.as<uint32_t>(), keys_out.as<uint32_t>(), idx_in.as<uint32_t>(),
                             idx_out.as<uint32_t>(), counts.as<uint32_t>(), temp.p, temp_bytes, s);
         HIP_CHECK(hipMemcpyAsync(cnt.data(), counts.p, k * 4, hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipStreamSynchronize(s));
+        HIP_CHECK(stream_sync(s));
         float err = 0;  // the reference's running fp32 sum, in point order
         for (size_t j = 0; j < nx; j++) err += dis[j];
         if (obj) obj[it] = err;
@@ -2469,7 +2493,7 @@ int amd_ivf_kmeans(int d, size_t n, const float* x_in, size_t k, int metric, int
         HIP_CHECK(hipMemcpyAsync(seg.p, off.data(), (k + 1) * 4, hipMemcpyHostToDevice, s));
         launch_kmeans_sums(h->d_resident.as<float>(), dpad, d, idx_out.as<uint32_t>(), seg.as<uint32_t>(), (uint32_t)k, d_cen.as<float>(), s);
         HIP_CHECK(hipMemcpyAsync(centroids, d_cen.p, k * (size_t)d * 4, hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipStreamSynchronize(s));
+        HIP_CHECK(stream_sync(s));
         km::split_void_clusters(centroids, hassign, d, k, nx);
         km::post_process(centroids, d, k, spherical != 0, int_centroids != 0);
     }

@@ -159,6 +159,11 @@ def main():
         else:
             dist.init_process_group(backend)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
+    # Host waits: every batch in flight has a host thread waiting on its stream between rounds.  Spinning waits (the HIP default)
+    # are ~2 % faster but need a core each; when the ranks' threads outnumber the cores this process tree may use (cgroup quota),
+    # the engine sleeps on blocking events instead (include/auncel_amd.h: AUNCEL_AMD_BLOCKING_SYNC).
+    if host_cores() < world * (args.in_flight + 1):
+        os.environ.setdefault("AUNCEL_AMD_BLOCKING_SYNC", "1")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the max-over-ranks reduction lives
@@ -345,7 +350,7 @@ def main():
         "config": {
             "workload": f"SIFT-{args.nb // 1000000}M-like d={d} IVF{nlist},Flat max_topk={K} topk={topk} Auncel error-bound nprobe "
                         f"(bound {args.bound}), batch {ses} resident queries per GPU, index replicated per GPU",
-            "in_flight": nfl, "scan_arith": {0: "fp32 reference order", 1: "fp32 fused", 2: "byte codes, v_dot4_u32_u8"}[h.scan_arith()],
+            "in_flight": nfl, "host_wait": "blocking events" if os.environ.get("AUNCEL_AMD_BLOCKING_SYNC", "0") not in ("", "0") else "spin", "host_cores": host_cores(), "scan_arith": {0: "fp32 reference order", 1: "fp32 fused", 2: "byte codes, v_dot4_u32_u8"}[h.scan_arith()],
             "nb": args.nb, "sigma": args.sigma, "multipler": chosen, "std_m": args.std_m,
             "recall_at_10_mean": float(rec.mean()), "recall_at_10_min": float(rec.min()),
             "nprobe_mean": float(my_np[ts:].mean()), "nprobe_max": int(my_np[ts:].max()),

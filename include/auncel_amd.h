@@ -193,6 +193,11 @@ int amd_ivf_range_search_preassigned(amd_ivf_t* h, size_t n, const float* x, flo
 int amd_ivf_range_search(amd_ivf_t* h, size_t n, const float* x, float radius, size_t nprobe, int coarse_mode, size_t* lims);
 int amd_ivf_range_results(amd_ivf_t* h, int64_t* labels, float* distances);
 
+/* ---- environment ----------------------------------------------------------------------------------
+ * AUNCEL_AMD_BLOCKING_SYNC=1   host threads wait for the device on blocking events (sleep until the interrupt) instead of
+ *                              hipStreamSynchronize's spinning: for hosts where the calling threads outnumber their cores
+ * The other AUNCEL_AMD_* variables the sources read are measurement switches (DESIGN.md names the ones it quotes). */
+
 /* ---- measurement hooks (bench.py): time of the kernels of the last search call, from HIP events
  *      recorded on the engine's own stream: {coarse_ms, scan_ms, select_ms, total_ms, scan_launches,
  *      bytes of the distances the scan tiles computed (x d x 4), fraction of the computed (query, vector)
