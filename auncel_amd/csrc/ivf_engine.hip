@@ -1156,6 +1156,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         const double t0 = now_us();
         HIP_CHECK(hipMemsetAsync(h->w_pl_lcount.p, 0, nlist * 4, s));
         HIP_CHECK(hipMemsetAsync(h->w_pl_counters.as<uint32_t>() + 6, 0, 4, s));
+        HIP_CHECK(hipMemsetAsync(h->w_pl_counters.as<uint32_t>() + 10, 0, 4, s));
         pa.round_len = (uint32_t)round_len;
         if (base.d_budget_ms) {  // the clock is read once the previous round has finished
             HIP_CHECK(stream_sync(s));
@@ -1330,6 +1331,9 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         if (dbg_timing())
             fprintf(stderr, "[round/dev] active %u pairs %u groups %u tiles %zu: plan+readback %.0f us, launches %.0f us\n", nact, npairs, ngroups,
                     nitems, t1 - t0, now_us() - t1);
+        // every query of this round ends with it and none was deferred: no further planning pass (and no read-back) is needed
+        static const bool no_skip = getenv("AUNCEL_AMD_NO_LAST_PLAN_SKIP") != nullptr;
+        if (!no_skip && !base.train.enabled && hc[10] == 0) break;
         round_len = base.fixed_two ? total_nprobe : std::min<size_t>(round_len * 2, 64);
     }
     check_device_error(h);

@@ -232,6 +232,7 @@ struct PlanArgs {
     unsigned long long* acc64;       // [0] += (query, vector) slots computed, [1] += pairs wanted (tile bookkeeping)
     uint32_t* counters;              // [0] active queries [1] segments [2] pairs [3] groups [4] tiles qg1 [5] tiles qg2
                                      // [6] scratch (compaction cursor, zeroed by host) [7] MiB of distances [8] tiles qg4 [9] tiles qg8
+                                     // [10] queries that may still be unfinished after this round (zeroed by host)
     double* bytes;                   // [0] += algorithmic bytes of the round's distances
 };
 

@@ -53,6 +53,9 @@ __global__ __launch_bounds__(256) void plan_counts_kernel(PlanArgs a) {
         if (a.limit && lane == 0) a.limit[i] = last ? (uint32_t)target : a.total_nprobe;
         if (target <= stage) target = stage + 1 < a.total_nprobe ? stage + 1 : a.total_nprobe;
         cnt = (uint32_t)(target - stage);
+        // queries this round cannot be the last one for: the host skips the next planning pass when there are none
+        const bool ends = target >= a.total_nprobe || last || (a.tune && np != 0);
+        if (!ends && lane == 0) atomicAdd(&a.counters[10], 1u);
         const int64_t* kq = a.keys + (size_t)i * a.key_stride + stage;
         for (uint32_t p = lane; p < cnt; p += 64) {
             const int64_t key = kq[p];
@@ -140,7 +143,10 @@ __global__ __launch_bounds__(1024) void plan_prefix_kernel(PlanArgs a) {
     }
     __syncthreads();
     for (uint32_t i = t; i < a.nq; i += 1024) {
-        if (i >= cut) a.cnt[i] = 0;
+        if (i >= cut && a.cnt[i]) {
+            a.cnt[i] = 0;
+            atomicAdd(&a.counters[10], 1u);  // deferred to the next round
+        }
         if (a.cnt[i]) {
             nact++;
             nseg += a.cnt[i];
