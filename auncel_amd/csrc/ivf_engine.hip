@@ -441,6 +441,7 @@ struct RoundSpec {
     // time-bounded search: budgets in ms (device, by absolute id) and the host clock (us) the budgets count from
     const float* d_budget_ms = nullptr;
     double t_start_us = 0;
+    bool caller_checks_error = false;  // the caller reads the error word back together with its results (finish_results)
 };
 
 static bool dbg_timing() {
@@ -769,6 +770,27 @@ void fold_stats(amd_ivf* h, size_t nq) {
     h->stats_host[3] += st[2];
 }
 
+// Final read-back of a search: results, error word and counters behind one synchronisation.  An error is raised after the
+// copies (the reference throws in the middle of its loop and leaves partial output behind as well).
+void finish_results(amd_ivf* h, size_t n, size_t k, float* D, int64_t* I, uint32_t* stage_out = nullptr) {
+    uint32_t err = 0;
+    unsigned long long st[3];
+    HIP_CHECK(hipMemcpyAsync(&err, h->w_error.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipMemcpyAsync(st, h->w_stats.p, 24, hipMemcpyDeviceToHost, h->stream));
+    if (stage_out) HIP_CHECK(hipMemcpyAsync(stage_out, h->w_stage.p, n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipMemcpyAsync(D, h->w_D.p, n * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipMemcpyAsync(I, h->w_I.p, n * k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(stream_sync(h->stream));
+    if (err == ERR_ARCOS_DOMAIN) throw EngineError("arcos's domain definition is [-1, 1]");
+    if (err == ERR_COSINE_PRECOND) throw EngineError("cosine theorem's prerequisites");
+    if (err == ERR_INVALID_KEY) throw EngineError("Invalid key");
+    if (err) throw EngineError("device-side error " + std::to_string(err));
+    h->stats_host[0] += n;
+    h->stats_host[1] += st[0];
+    h->stats_host[2] += st[1];
+    h->stats_host[3] += st[2];
+}
+
 void finish_timing(amd_ivf* h, double wall_ms) {
     double ms[NCAT], ln[NCAT];
     h->timer.collect(ms, NCAT, ln);
@@ -963,12 +985,9 @@ void search_fixed_device(amd_ivf* h, const float* d_x, size_t n, size_t k, size_
     const bool two = two_env ? two_env == 2 : nprobe >= 16 && n * nprobe >= 4096;
     base.fixed_two = two;
     const size_t first = two ? std::max<size_t>(1, nprobe / 8) : nprobe;
+    base.caller_checks_error = true;
     run_rounds_device(h, base, n, first, nprobe, nullptr);
-    check_device_error(h);
-    HIP_CHECK(hipMemcpyAsync(D, h->w_D.p, n * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    HIP_CHECK(hipMemcpyAsync(I, h->w_I.p, n * k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-    HIP_CHECK(stream_sync(h->stream));
-    fold_stats(h, n);
+    finish_results(h, n, k, D, I);
 }
 
 void search_fixed_core(amd_ivf* h, const float* d_x, size_t n, size_t k, size_t nprobe, const int64_t* keys, float* D,
@@ -1336,7 +1355,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         if (!no_skip && !base.train.enabled && hc[10] == 0) break;
         round_len = base.fixed_two ? total_nprobe : std::min<size_t>(round_len * 2, 64);
     }
-    check_device_error(h);
+    if (!base.caller_checks_error) check_device_error(h);
     h->scan_bytes += *reinterpret_cast<double*>(hc + 16);
     const unsigned long long* acc = reinterpret_cast<const unsigned long long*>(hc + 18);
     h->scan_slots += (double)acc[0];
@@ -1811,15 +1830,11 @@ static void timed_core(amd_ivf* h, const float* d_x, size_t start, size_t n, siz
     base.d_budget_ms = d_b.as<float>();
     base.t_start_us = t_start;
     static const size_t first_env = getenv("AUNCEL_AMD_TIMED_FIRST") ? (size_t)atoi(getenv("AUNCEL_AMD_TIMED_FIRST")) : 4;
+    base.caller_checks_error = true;
     run_rounds_device(h, base, n, std::max<size_t>(1, first_env), nprobe, nullptr);
-    check_device_error(h);
     std::vector<uint32_t> stage(nprobe_used ? n : 0);
-    if (nprobe_used) HIP_CHECK(hipMemcpyAsync(stage.data(), h->w_stage.p, n * 4, hipMemcpyDeviceToHost, h->stream));
-    HIP_CHECK(hipMemcpyAsync(D, h->w_D.p, n * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    HIP_CHECK(hipMemcpyAsync(I, h->w_I.p, n * k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-    HIP_CHECK(stream_sync(h->stream));
+    finish_results(h, n, k, D, I, nprobe_used ? stage.data() : nullptr);
     for (size_t i = 0; i < stage.size(); i++) nprobe_used[i] = stage[i];
-    fold_stats(h, n);
 }
 
 int amd_ivf_search_timed(amd_ivf_t* h, size_t start, size_t n, size_t k, size_t nprobe, const float* budget_ms, int coarse_mode,
@@ -2070,12 +2085,17 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
     base.tuner = make_tuner(L, query_topk, multipler, std_m, dreq, dgt, dnp, dtr, profile);
     static const size_t first_env = getenv("AUNCEL_AMD_ROUND_FIRST") ? (size_t)atoi(getenv("AUNCEL_AMD_ROUND_FIRST")) : 12;
     static const bool host_plan = getenv("AUNCEL_AMD_HOST_PLAN") != nullptr;
-    if (host_plan) run_rounds(L, base, n, first_env, nlist, dnp, id0);
-    else run_rounds_device(L, base, n, first_env, nlist, dnp);
-    HIP_CHECK(hipMemcpyAsync(D, L->w_D.p, n * K * 4, hipMemcpyDeviceToHost, L->stream));
-    HIP_CHECK(hipMemcpyAsync(I, L->w_I.p, n * K * 8, hipMemcpyDeviceToHost, L->stream));
-    HIP_CHECK(stream_sync(L->stream));
-    fold_stats(L, n);
+    if (host_plan) {
+        run_rounds(L, base, n, first_env, nlist, dnp, id0);
+        HIP_CHECK(hipMemcpyAsync(D, L->w_D.p, n * K * 4, hipMemcpyDeviceToHost, L->stream));
+        HIP_CHECK(hipMemcpyAsync(I, L->w_I.p, n * K * 8, hipMemcpyDeviceToHost, L->stream));
+        HIP_CHECK(stream_sync(L->stream));
+        fold_stats(L, n);
+        return;
+    }
+    base.caller_checks_error = true;
+    run_rounds_device(L, base, n, first_env, nlist, dnp);
+    finish_results(L, n, K, D, I);
 }
 
 static size_t lane_count(size_t n) {
