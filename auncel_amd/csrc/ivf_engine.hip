@@ -2130,11 +2130,11 @@ static void adaptive_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n
     float* dtr = dreq + nabs;
     float* dgt = gt_D ? dtr + nabs : nullptr;
     d_np.ensure(nabs * 8);
-    HIP_CHECK(hipMemcpyAsync(dreq, require_acc, nabs * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_CHECK(hipMemcpyAsync(dtr, t_recalls, nabs * 4, hipMemcpyHostToDevice, h->stream));
-    if (gt_D) HIP_CHECK(hipMemcpyAsync(dgt, gt_D, nabs * K * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_CHECK(hipMemcpyAsync(d_np.p, my_nprobe, nabs * 8, hipMemcpyHostToDevice, h->stream));
-    HIP_CHECK(stream_sync(h->stream));
+    // only the entries of this call's queries are read or written on the device (everything is indexed by absolute id)
+    HIP_CHECK(hipMemcpyAsync(dreq + start, require_acc + start, n * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_CHECK(hipMemcpyAsync(dtr + start, t_recalls + start, n * 4, hipMemcpyHostToDevice, h->stream));
+    if (gt_D) HIP_CHECK(hipMemcpyAsync(dgt + start * K, gt_D + start * K, n * K * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_CHECK(hipMemcpyAsync(d_np.as<unsigned long long>() + start, my_nprobe + start, n * 8, hipMemcpyHostToDevice, h->stream));
 
     // How much of the coarse ranking can be consumed: set_online reads entries 0 .. nlist/8+20, and the probe loop ends at
     // my_nprobe <= floor((nlist/8) * multipler) (IndexIVF.cpp:615-632) or at a value the caller passed in.  When that is
