@@ -77,60 +77,69 @@ __global__ __launch_bounds__(256) void plan_counts_kernel(PlanArgs a) {
     }
 }
 
-// ---- 2. one block: prefix sums over the queries, budget cut, list of active queries
-__global__ __launch_bounds__(1024) void plan_prefix_kernel(PlanArgs a) {
-    __shared__ unsigned long long s_need[1024];
-    __shared__ uint32_t s_cnt[1024], s_act[1024];
-    __shared__ unsigned long long carry_need;
-    __shared__ uint32_t carry_cnt, carry_act, cut;
-    const int t = threadIdx.x;
-    if (t == 0) {
-        carry_need = 0;
-        carry_cnt = 0;
-        carry_act = 0;
-        cut = 0xffffffffu;
+// exclusive prefix sum of one value per thread over a block of 1024 threads (16 waves): shuffles inside the waves, one LDS
+// hop for the wave totals; `total` receives the block's sum.  s_wave: 17 entries of shared memory, reusable on return.
+template <typename T> __device__ __forceinline__ T block_scan_1024(T v, T* s_wave, T& total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    T incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const T o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) s_wave[w] = incl;
+    __syncthreads();
+    if (w == 0) {
+        const T x = lane < 16 ? s_wave[lane] : (T)0;
+        T inc = x;
+        for (int off = 1; off < 16; off <<= 1) {
+            const T o = __shfl_up(inc, off);
+            if (lane >= off) inc += o;
+        }
+        if (lane < 16) s_wave[lane] = inc - x;
+        if (lane == 15) s_wave[16] = inc;
     }
     __syncthreads();
-    for (uint32_t base = 0; base < a.nq; base += 1024) {
-        const uint32_t i = base + t;
-        uint32_t c = i < a.nq ? a.cnt[i] : 0;
-        unsigned long long nd = i < a.nq ? a.need[i] : 0;
-        s_cnt[t] = c;
-        s_need[t] = nd;
-        s_act[t] = c ? 1u : 0u;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {  // inclusive Hillis-Steele scan
-            uint32_t vc = 0, va = 0;
-            unsigned long long vn = 0;
-            if (t >= off) {
-                vc = s_cnt[t - off];
-                vn = s_need[t - off];
-                va = s_act[t - off];
-            }
-            __syncthreads();
-            s_cnt[t] += vc;
-            s_need[t] += vn;
-            s_act[t] += va;
-            __syncthreads();
-        }
-        const uint32_t ecnt = carry_cnt + s_cnt[t] - c;                   // exclusive
-        const unsigned long long eneed = carry_need + s_need[t] - nd;
-        const uint32_t eact = carry_act + s_act[t] - (c ? 1u : 0u);
-        if (i < a.nq) {
-            // a query that does not fit the distance / segment budget of this round waits for the next one
-            const bool fits = (eneed + nd <= a.dist_budget && ecnt + c <= a.seg_cap) || eact == 0;
-            if (c && !fits) atomicMin(&cut, i);
-            a.seg_begin[i] = ecnt;
-            a.dist_base[i] = eneed;
-        }
-        __syncthreads();
-        if (t == 1023) {
-            carry_cnt += s_cnt[t];
-            carry_need += s_need[t];
-            carry_act += s_act[t];
-        }
-        __syncthreads();
+    const T res = s_wave[w] + incl - v;
+    total = s_wave[16];
+    __syncthreads();
+    return res;
+}
+
+// ---- 2. one block: prefix sums over the queries, budget cut, list of active queries.  Thread t owns the queries
+//         [t * per, (t + 1) * per): sums of its own, one block scan of the 1024 sums, then its queries again.
+__global__ __launch_bounds__(1024) void plan_prefix_kernel(PlanArgs a) {
+    __shared__ unsigned long long s_w64[17];
+    __shared__ uint32_t s_w32[17];
+    __shared__ uint32_t cut;
+    const uint32_t t = threadIdx.x;
+    if (t == 0) cut = 0xffffffffu;
+    const uint32_t per = (a.nq + 1023) / 1024, q0 = t * per, q1 = q0 + per < a.nq ? q0 + per : a.nq;
+    unsigned long long my_need = 0;
+    uint32_t my_cnt = 0, my_act = 0;
+    for (uint32_t i = q0; i < q1; i++) {
+        const uint32_t c = a.cnt[i];
+        my_cnt += c;
+        my_act += c ? 1u : 0u;
+        my_need += a.need[i];
     }
+    unsigned long long tot_need;
+    uint32_t tot32;
+    unsigned long long eneed = block_scan_1024(my_need, s_w64, tot_need);
+    uint32_t ecnt = block_scan_1024(my_cnt, s_w32, tot32);
+    uint32_t eact = block_scan_1024(my_act, s_w32, tot32);
+    for (uint32_t i = q0; i < q1; i++) {
+        const uint32_t c = a.cnt[i];
+        const unsigned long long nd = a.need[i];
+        // a query that does not fit the distance / segment budget of this round waits for the next one
+        const bool fits = (eneed + nd <= a.dist_budget && ecnt + c <= a.seg_cap) || eact == 0;
+        if (c && !fits) atomicMin(&cut, i);
+        a.seg_begin[i] = ecnt;
+        a.dist_base[i] = eneed;
+        eneed += nd;
+        ecnt += c;
+        eact += c ? 1u : 0u;
+    }
+    __syncthreads();
     // queries at or after the cut are deferred; everything before keeps its prefix values
     uint32_t nact = 0, nseg = 0;
     unsigned long long ndist = 0;
@@ -208,71 +217,63 @@ __global__ __launch_bounds__(256) void plan_segments_kernel(PlanArgs a) {
     }
 }
 
-// ---- 4. one block: per-list pair offsets, query-group bases, tile counts per workgroup shape
+// ---- 4. one block: per-list pair offsets, query-group bases, tile counts per workgroup shape (thread t owns a run of lists)
 
 __global__ __launch_bounds__(1024) void plan_lists_kernel(PlanArgs a) {
-    __shared__ uint32_t s[6][1024];
-    __shared__ uint32_t carry[6];
-    const int t = threadIdx.x;
-    if (t < 6) carry[t] = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < a.nlist; base += 1024) {
-        const uint32_t l = base + t;
-        uint32_t v[6] = {0, 0, 0, 0, 0, 0};  // pairs, groups, tiles of shape 1, 2, 4, 8
-        if (l < a.nlist) {
-            const uint32_t c = a.lcount[l];
-            if (c) {
-                const unsigned long long sz = a.list_off[l + 1] - a.list_off[l];
-                v[0] = c;
-                v[1] = (c + SCAN_RQ - 1) / SCAN_RQ;
-                const uint32_t full = c / a.qblock, rem = c % a.qblock;
-                if (full) {
-                    const uint32_t qg = scan_shape_of(a.qblock);
-                    const uint32_t tv = scan_tile_vecs(qg);
-                    v[2 + scan_qg_class(qg)] = full * (uint32_t)((sz + tv - 1) / tv);
-                }
-                if (rem) {
-                    const uint32_t qg = scan_shape_of(rem);
-                    const uint32_t tv = scan_tile_vecs(qg);
-                    v[2 + scan_qg_class(qg)] += (uint32_t)((sz + tv - 1) / tv);
-                }
-            }
+    __shared__ uint32_t s_w[17];
+    const uint32_t t = threadIdx.x;
+    // pairs, groups, tiles of shape 1, 2, 4, 8 of list l
+    auto values = [&](uint32_t l, uint32_t (&v)[6]) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) v[k] = 0;
+        const uint32_t c = a.lcount[l];
+        if (!c) return;
+        const unsigned long long sz = a.list_off[l + 1] - a.list_off[l];
+        v[0] = c;
+        v[1] = (c + SCAN_RQ - 1) / SCAN_RQ;
+        const uint32_t full = c / a.qblock, rem = c % a.qblock;
+        if (full) {
+            const uint32_t qg = scan_shape_of(a.qblock);
+            const uint32_t tv = scan_tile_vecs(qg);
+            v[2 + scan_qg_class(qg)] = full * (uint32_t)((sz + tv - 1) / tv);
         }
-#pragma unroll
-        for (int k = 0; k < 6; k++) s[k][t] = v[k];
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            uint32_t w[6] = {0, 0, 0, 0, 0, 0};
-            if (t >= off)
-#pragma unroll
-                for (int k = 0; k < 6; k++) w[k] = s[k][t - off];
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < 6; k++) s[k][t] += w[k];
-            __syncthreads();
+        if (rem) {
+            const uint32_t qg = scan_shape_of(rem);
+            const uint32_t tv = scan_tile_vecs(qg);
+            v[2 + scan_qg_class(qg)] += (uint32_t)((sz + tv - 1) / tv);
         }
-        if (l < a.nlist) {
-            a.lstart[l] = carry[0] + s[0][t] - v[0];
-            a.gbase[l] = carry[1] + s[1][t] - v[1];
-            a.ibase[0 * a.nlist + l] = carry[2] + s[2][t] - v[2];
-            a.ibase[1 * a.nlist + l] = carry[3] + s[3][t] - v[3];
-            a.ibase[2 * a.nlist + l] = carry[4] + s[4][t] - v[4];
-            a.ibase[3 * a.nlist + l] = carry[5] + s[5][t] - v[5];
-            a.fill[l] = 0;
-        }
-        __syncthreads();
-        if (t == 1023)
+    };
+    const uint32_t per = (a.nlist + 1023) / 1024, l0 = t * per, l1 = l0 + per < a.nlist ? l0 + per : a.nlist;
+    uint32_t mine[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t l = l0; l < l1; l++) {
+        uint32_t v[6];
+        values(l, v);
 #pragma unroll
-            for (int k = 0; k < 6; k++) carry[k] += s[k][t];
-        __syncthreads();
+        for (int k = 0; k < 6; k++) mine[k] += v[k];
+    }
+    uint32_t ex[6], tot[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) ex[k] = block_scan_1024(mine[k], s_w, tot[k]);
+    for (uint32_t l = l0; l < l1; l++) {
+        uint32_t v[6];
+        values(l, v);
+        a.lstart[l] = ex[0];
+        a.gbase[l] = ex[1];
+        a.ibase[0 * a.nlist + l] = ex[2];
+        a.ibase[1 * a.nlist + l] = ex[3];
+        a.ibase[2 * a.nlist + l] = ex[4];
+        a.ibase[3 * a.nlist + l] = ex[5];
+        a.fill[l] = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) ex[k] += v[k];
     }
     if (t == 0) {
-        a.counters[2] = carry[0];  // pairs
-        a.counters[3] = carry[1];  // query groups
-        a.counters[4] = carry[2];  // tiles of shape 1
-        a.counters[5] = carry[3];  // tiles of shape 2
-        a.counters[8] = carry[4];  // tiles of shape 4
-        a.counters[9] = carry[5];  // tiles of shape 8
+        a.counters[2] = tot[0];  // pairs
+        a.counters[3] = tot[1];  // query groups
+        a.counters[4] = tot[2];  // tiles of shape 1
+        a.counters[5] = tot[3];  // tiles of shape 2
+        a.counters[8] = tot[4];  // tiles of shape 4
+        a.counters[9] = tot[5];  // tiles of shape 8
     }
 }
 
