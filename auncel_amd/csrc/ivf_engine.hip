@@ -365,16 +365,21 @@ void init_state(amd_ivf* h, size_t n, size_t k, bool tune_or_train) {
     h->w_stats.ensure(3 * 8);
     h->w_error.ensure(4);
     h->w_thr.ensure(n * sizeof(float));
-    launch_fill_f32(h->w_thr.as<float>(), n, h->metric == METRIC_L2 ? FLT_MAX : -FLT_MAX, h->stream);
-    launch_fill_f32(h->w_heap_val.as<float>(), n * k, h->metric == METRIC_L2 ? FLT_MAX : -FLT_MAX, h->stream);
-    launch_fill_i64(h->w_heap_ref.as<int64_t>(), n * k, -1, h->stream);
-    HIP_CHECK(hipMemsetAsync(h->w_stage.p, 0, n * 4, h->stream));
-    HIP_CHECK(hipMemsetAsync(h->w_nscan.p, 0, n * 8, h->stream));
-    HIP_CHECK(hipMemsetAsync(h->w_done.p, 0, n * 4, h->stream));
-    HIP_CHECK(hipMemsetAsync(h->w_pre_val.p, 0, n * 4, h->stream));
-    HIP_CHECK(hipMemsetAsync(h->w_stoped.p, 0, n * 4, h->stream));
-    HIP_CHECK(hipMemsetAsync(h->w_stats.p, 0, 24, h->stream));
-    HIP_CHECK(hipMemsetAsync(h->w_error.p, 0, 4, h->stream));
+    InitStateArgs ia{};
+    ia.n = n;
+    ia.k = k;
+    ia.neutral = h->metric == METRIC_L2 ? FLT_MAX : -FLT_MAX;
+    ia.heap_val = h->w_heap_val.as<float>();
+    ia.heap_ref = h->w_heap_ref.as<int64_t>();
+    ia.thr = h->w_thr.as<float>();
+    ia.stage = h->w_stage.as<uint32_t>();
+    ia.nscan = h->w_nscan.as<unsigned long long>();
+    ia.done = h->w_done.as<uint32_t>();
+    ia.pre_val = h->w_pre_val.as<float>();
+    ia.stoped = h->w_stoped.as<uint32_t>();
+    ia.stats = h->w_stats.as<unsigned long long>();
+    ia.error = h->w_error.as<uint32_t>();
+    launch_init_state(ia, h->stream);
     if (tune_or_train) h->w_dtb.ensure(n * (h->nlist / 8 + 20) * sizeof(float));
 }
 

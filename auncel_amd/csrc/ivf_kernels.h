@@ -264,6 +264,21 @@ void launch_kmeans_sums(const float* x, size_t stride, int d, const uint32_t* id
                         hipStream_t s);
 
 // fill helpers
+struct InitStateArgs {
+    size_t n, k;
+    float neutral;  // FLT_MAX (L2) / -FLT_MAX (IP)
+    float* heap_val;
+    int64_t* heap_ref;
+    float* thr;
+    uint32_t* stage;
+    unsigned long long* nscan;
+    uint32_t* done;
+    float* pre_val;
+    uint32_t* stoped;
+    unsigned long long* stats;  // 3 counters
+    uint32_t* error;
+};
+void launch_init_state(const InitStateArgs& a, hipStream_t s);
 void launch_fill_f32(float* p, size_t n, float v, hipStream_t s);
 void launch_fill_i64(int64_t* p, size_t n, int64_t v, hipStream_t s);
 

@@ -15,6 +15,7 @@
 #include "ivf_kernels.h"
 
 #include <float.h>
+#include <algorithm>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -1690,6 +1691,33 @@ __global__ void fill_i64_kernel(int64_t* p, size_t n, int64_t v) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
+// per-query state of a search in one launch: empty heaps (neutral value, id -1), thresholds, zeroed stage / nscan / done /
+// stop-rule state, counters and error word
+__global__ __launch_bounds__(256) void init_state_kernel(InitStateArgs a) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    const size_t nk = a.n * a.k;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nk; i += stride) {
+        a.heap_val[i] = a.neutral;
+        a.heap_ref[i] = -1;
+    }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += stride) {
+        a.thr[i] = a.neutral;
+        a.stage[i] = 0;
+        a.nscan[i] = 0;
+        a.done[i] = 0;
+        a.pre_val[i] = 0.f;
+        a.stoped[i] = 0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 3) a.stats[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 3) *a.error = 0;
+}
+
+void launch_init_state(const InitStateArgs& a, hipStream_t s) {
+    const size_t work = std::max<size_t>(a.n * a.k, 1);
+    const unsigned grid = (unsigned)std::min<size_t>((work + 255) / 256, 4096);
+    hipLaunchKernelGGL(init_state_kernel, dim3(grid), dim3(256), 0, s, a);
+}
+
 void launch_fill_f32(float* p, size_t n, float v, hipStream_t s) {
     if (n) hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, v);
 }
