@@ -128,7 +128,7 @@ def main():
     ap.add_argument("--maxtopk", type=int, default=100)
     ap.add_argument("--bound", type=float, default=0.95)
     ap.add_argument("--std-m", type=float, default=1.0)
-    ap.add_argument("--cpu-sample", type=int, default=2048)
+    ap.add_argument("--cpu-sample", type=int, default=5000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ref", action="store_true", help="cpu_baseline from the CPU restatement only (skip oracle/_ref/ref_harness)")
     ap.add_argument("--kmeans", choices=["engine", "torch"], default="engine",
