@@ -6,7 +6,7 @@
 // oracle/_ref/ travels to the GPU box, where bench.py's cpu_baseline leg runs its `bench` mode
 // (kind "reference", oracle/refbench.py).  Nothing in the product imports or links this.
 //
-// usage: ref_harness <fixed|auncel|io|kmeans|bench> <in.tb> <out.tb>
+// usage: ref_harness <fixed|auncel|io|kmeans|bench|fixedbench> <in.tb> <out.tb>
 //
 // Reference entry points exercised (file:line in /root/reference/Auncel):
 //   IndexFlat::search             IndexFlat.cpp:42-56   (knn_L2sqr_sse / _blas, utils.cpp:454-655)
@@ -530,9 +530,48 @@ static int run_bench(const tb::Bundle& in, tb::Bundle& out) {
     return 0;
 }
 
+// scripts/bench_configs.py: the compiled reference's plain IndexIVF::search on an index assembled from the engine's lists,
+// one query per call (the exact coarse path, utils.cpp:417-490) spread over the host threads; either metric.
+static int run_fixedbench(const tb::Bundle& in, tb::Bundle& out) {
+    const size_t d = in.scalar<size_t>("d"), nlist = in.scalar<size_t>("nlist"), k = in.scalar<size_t>("k"), nprobe = in.scalar<size_t>("nprobe");
+    const MetricType mt = in.scalar<int>("metric") == 0 ? METRIC_INNER_PRODUCT : METRIC_L2;
+    const tb::Tensor &cen = in.get("centroids"), &off = in.get("list_off"), &codes = in.get("codes"), &ids = in.get("ids"), &xq = in.get("xq");
+    const size_t S = xq.dims[0];
+    IndexFlat quantizer(d, mt);
+    quantizer.add(nlist, cen.as<float>());
+    IndexIVFFlat index(&quantizer, d, nlist, mt);
+    index.is_trained = true;
+    index.init_tune(0, 1, nullptr, nullptr, nullptr, nullptr, nullptr);  // `t` is dereferenced by plain searches too (IndexIVF.cpp:529)
+    const int64_t* lo = off.as<int64_t>();
+    for (size_t l = 0; l < nlist; l++) {
+        const size_t n = (size_t)(lo[l + 1] - lo[l]);
+        if (n) index.invlists->add_entries(l, n, (const idx_t*)(ids.as<int64_t>() + lo[l]), (const uint8_t*)(codes.as<float>() + (size_t)lo[l] * d));
+    }
+    index.ntotal = lo[nlist];
+    index.nprobe = nprobe;
+    std::vector<float> D(S * k);
+    std::vector<int64_t> I(S * k);
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    int nthreads = 1;
+    const double t0 = now();
+#pragma omp parallel
+    {
+#pragma omp single
+        nthreads = omp_get_num_threads();
+#pragma omp for schedule(dynamic, 1)
+        for (long i = 0; i < (long)S; i++) index.search(1, xq.as<float>() + i * d, k, D.data() + i * k, (idx_t*)(I.data() + i * k));
+    }
+    const double t_all = now() - t0;
+    out.put_f32("D", {S, k}, D.data());
+    out.put_i64("I", {S, k}, I.data());
+    out.put_scalar_f64("seconds_all_threads", t_all);
+    out.put_scalar_i64("threads", nthreads);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc != 4) {
-        fprintf(stderr, "usage: %s <fixed|auncel|io|kmeans|bench> <in.tb> <out.tb>\n", argv[0]);
+        fprintf(stderr, "usage: %s <fixed|auncel|io|kmeans|bench|fixedbench> <in.tb> <out.tb>\n", argv[0]);
         return 2;
     }
     try {
@@ -540,7 +579,7 @@ int main(int argc, char** argv) {
         tb::Bundle out;
         std::string cmd = argv[1];
         // note: sys_train writes Validation_*.log into the CWD: run from a scratch dir
-        int rc = cmd == "fixed" ? run_fixed(in, out) : cmd == "auncel" ? run_auncel(in, out) : cmd == "io" ? run_io(in, out) : cmd == "kmeans" ? run_kmeans(in, out) : cmd == "bench" ? run_bench(in, out) : 2;
+        int rc = cmd == "fixed" ? run_fixed(in, out) : cmd == "auncel" ? run_auncel(in, out) : cmd == "io" ? run_io(in, out) : cmd == "kmeans" ? run_kmeans(in, out) : cmd == "bench" ? run_bench(in, out) : cmd == "fixedbench" ? run_fixedbench(in, out) : 2;
         if (rc == 0) out.save(argv[3]);
         return rc;
     } catch (const std::exception& e) {

@@ -42,3 +42,18 @@ def run(centroids, list_off, codes, ids, traces, xq, id0, max_topk, topk, requir
     return {"D": out["D"], "I": out["I"], "my_nprobe": out["my_nprobe"], "seconds_one_thread": float(out["seconds_one_thread"][0]),
             "queries_one_thread": int(out["queries_one_thread"][0]), "seconds_all_threads": float(out["seconds_all_threads"][0]),
             "threads": int(out["threads"][0])}
+
+
+def run_fixed(metric, centroids, list_off, codes, ids, xq, k, nprobe, threads=None, timeout=900, tmpdir=None):
+    """IndexIVF::search(1, x, k, ...) of the compiled reference for every row of xq (nprobe fixed), OpenMP over queries"""
+    with tempfile.TemporaryDirectory(dir=tmpdir) as tmp:
+        fin, fout = os.path.join(tmp, "in.tb"), os.path.join(tmp, "out.tb")
+        tbundle.save(fin, {"d": int(centroids.shape[1]), "nlist": int(centroids.shape[0]), "k": int(k), "nprobe": int(nprobe),
+                           "metric": int(metric), "centroids": np.ascontiguousarray(centroids, dtype=np.float32),
+                           "list_off": np.ascontiguousarray(list_off).astype(np.int64), "codes": codes,
+                           "ids": np.ascontiguousarray(ids, dtype=np.int64), "xq": np.ascontiguousarray(xq, dtype=np.float32)})
+        env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL", OMP_NUM_THREADS=str(threads or os.cpu_count() or 1))
+        subprocess.run([HARNESS, "fixedbench", fin, fout], check=True, cwd=tmp, env=env, timeout=timeout, stdout=subprocess.DEVNULL)
+        os.remove(fin)
+        out = tbundle.load(fout)
+    return {"D": out["D"], "I": out["I"], "seconds_all_threads": float(out["seconds_all_threads"][0]), "threads": int(out["threads"][0])}

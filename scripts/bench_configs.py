@@ -86,10 +86,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cfg", default="1,3,5")
     ap.add_argument("--sample", type=int, default=64)
+    ap.add_argument("--ref-sample", type=int, default=2000, help="queries the compiled reference runs (oracle/_ref/ref_harness fixedbench)")
     args = ap.parse_args()
     import torch
     from auncel_amd import capi
-    from oracle import pyoracle
+    from oracle import pyoracle, refbench
     dev = torch.device("cuda", 0)
     cfgs = {"1": ("sift", 1_000_000, 10000, 1024, 10, (8,), capi.METRIC_L2),
             "3": ("deep", 10_000_000, 10000, 4096, 100, (16, 32, 64), capi.METRIC_IP),
@@ -138,18 +139,28 @@ def main():
             dt, tm, st = best
             recall = np.mean([len(set(I[i]) & set(gtI[i])) / k for i in range(0, nq, 10)])
             S = args.sample
-            cores = os.cpu_count() or 1
+            cores = bench.host_cores()
             tc = time.perf_counter()
             cd, ck = pyoracle.knn(metric, xq[:S], cen, nprobe, nthreads=cores)
             oD, oI, _ = pyoracle.search_preassigned(lists, xq[:S], k, ck, cd, nthreads=cores)
             cpu = S / (time.perf_counter() - tc)
             same = bool(np.array_equal(oI, I[:S]) and np.array_equal(oD.view(np.uint32), D[:S].view(np.uint32)))
+            # the compiled reference itself, where its harness is present (oracle/_ref): IndexIVF::search, one query per call
+            ref = None
+            if refbench.available():
+                try:
+                    SR = min(nq, args.ref_sample)
+                    ro = refbench.run_fixed(metric, cen, lists.off, lists.codes, lists.ids, xq[:SR], k, nprobe, threads=cores)
+                    ref = {"qps": SR / ro["seconds_all_threads"], "threads": ro["threads"], "queries": SR,
+                           "gpu_equals_reference": bool(np.array_equal(ro["I"], I[:SR]) and np.array_equal(ro["D"].view(np.uint32), D[:SR].view(np.uint32)))}
+                except Exception as e:  # noqa: BLE001
+                    ref = {"error": repr(e)}
             alg = st["ndis"] * d * 4.0
             print(json.dumps({"config": c, "data": kind + "-like synthetic", "nb": nb, "d": d, "nlist": nlist, "k": k, "nprobe": nprobe,
                               "metric": "IP" if metric == 0 else "L2", "batch": nq, "qps": nq / dt, "recall_at_k": float(recall),
                               "scan_ms": tm["scan_ms"], "select_ms": tm["select_ms"], "coarse_ms": tm["coarse_ms"],
                               "scan_algorithmic_GBps": alg / 1e6 / max(tm["scan_ms"], 1e-9), "tile_slot_efficiency": tm["slot_efficiency"],
-                              "cpu_oracle_qps": cpu, "cpu_threads": cores, "gpu_equals_cpu_on_sample": same}), flush=True)
+                              "cpu_oracle_qps": cpu, "cpu_threads": cores, "gpu_equals_cpu_on_sample": same, "reference": ref}), flush=True)
         h.close()
         del lists
 
