@@ -257,6 +257,30 @@ static int run_auncel(const tb::Bundle& in) {
             expect(memcmp(index.t->my_nprobe + ts, in.get("my_nprobe" + suf).as<uint64_t>(), ses * 8) == 0, "my_nprobe" + tag);
         }
     }
+    // ---- eval/effect_time.cpp:270-297: time-bounded search, budgets (ms) in the accuracy array.  With budgets nobody can
+    //      use up the probe loop runs to its end: the plain search with nprobe = nlist; with no budget at all a query still
+    //      gets its first probes and returns something sorted
+    {
+        const size_t n_t = std::min<size_t>(ses, 16);
+        std::vector<float> budget(nq, 1e9f);
+        err_sys.set_queries(ses, xq.as<float>(), budget.data(), ts + ses);
+        std::vector<float> D(n_t * K), Df(n_t * K);
+        std::vector<int64_t> I(n_t * K);
+        std::vector<idx_t> If(n_t * K);
+        for (size_t i = 0; i < n_t; i++) err_sys.time_search(D.data() + K * i, I.data() + K * i, ts + i, 1);
+        expect(index.t->time_tune, "time_search leaves time_tune on (profile.cpp:242)");
+        index.t->time_tune = false;
+        index.nprobe = nlist;
+        index.search(n_t, xq.as<float>() + ts * d, K, Df.data(), If.data());
+        expect(memcmp(I.data(), If.data(), n_t * K * 8) == 0 && same_f(D.data(), Df.data(), n_t * K), "time_search with unlimited budgets = full probe loop");
+        std::fill(budget.begin(), budget.end(), 0.f);
+        err_sys.time_search(D.data(), I.data(), ts, (long)n_t);
+        index.t->time_tune = false;
+        bool sorted = true;
+        for (size_t i = 0; i < n_t; i++)
+            for (size_t j = 1; j < K; j++) sorted &= D[i * K + j - 1] <= D[i * K + j];
+        expect(sorted && I[0] >= 0, "time_search without budget returns the first probes' results");
+    }
     // tune mode without a tuner is an error, as in the reference (IndexIVF.cpp:514-515)
     {
         IndexIVFFlat bare(&quantizer, d, nlist, METRIC_L2);
