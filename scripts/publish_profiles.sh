@@ -7,3 +7,4 @@ cp gpurun_out/perf_scan_$tag.txt profiles/${tag}_fixed_nprobe.txt
 cp gpurun_out/configs_$tag.jsonl profiles/${tag}_other_configs.jsonl
 cp gpurun_out/shards_$tag.json profiles/${tag}_shards_one_gpu.json
 cp gpurun_out/effect_time_$tag.jsonl profiles/${tag}_effect_time.jsonl
+cp gpurun_out/latency1_$tag.txt profiles/${tag}_latency_batch1.txt
