@@ -134,6 +134,9 @@ def main():
     ap.add_argument("--kmeans", choices=["engine", "torch"], default="engine",
                     help="coarse centroids: the engine's Clustering::train restatement (amd_ivf_kmeans, the reference's IVF "
                          "training: 25 iterations, 256 points per centroid) or a 4-step torch Lloyd")
+    ap.add_argument("--stagger-ms", type=float, default=0.8,
+                    help="context j issues its first step j x this many ms after context 0 (inside the timed region): out of phase, the "
+                         "scan of one batch runs under the selection of another; started together they tend to stay in step")
     ap.add_argument("--pinned-out", type=int, default=1, help="1: result buffers in page-locked host memory, 0: pageable")
     ap.add_argument("--in-flight", type=int, default=4,
                     help="batches kept in flight per GPU, each from its own host thread on its own search context "
@@ -239,7 +242,7 @@ def main():
     for c in ctxs[1:]:
         c.set_queries(xq)
 
-    stagger_s = float(os.environ.get("BENCH_STAGGER_MS", "0")) / 1e3
+    stagger_s = float(os.environ.get("BENCH_STAGGER_MS", args.stagger_ms)) / 1e3
 
     # result buffers of every context: page-locked host memory (the caller's choice in the reference's API too), so that
     # the 6 MB of (D, I) of a step come back by direct DMA instead of through the runtime's staging copies
