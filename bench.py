@@ -142,6 +142,9 @@ def main():
                     help="batches kept in flight per GPU, each from its own host thread on its own search context "
                          "(amd_ivf_clone); 1 = one batch at a time")
     args = ap.parse_args()
+    # hardware queues the HIP runtime maps its streams onto (ROCm's default, pinned here because the figure is sensitive to it:
+    # with 8 queues four batches in flight lose 8 % and six collapse, profiles/r01_in_flight_sweep.txt); must precede HIP start-up
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
 
     import torch
     import torch.distributed as dist
@@ -353,7 +356,7 @@ def main():
         "config": {
             "workload": f"SIFT-{args.nb // 1000000}M-like d={d} IVF{nlist},Flat max_topk={K} topk={topk} Auncel error-bound nprobe "
                         f"(bound {args.bound}), batch {ses} resident queries per GPU, index replicated per GPU",
-            "in_flight": nfl, "host_wait": "blocking events" if os.environ.get("AUNCEL_AMD_BLOCKING_SYNC", "0") not in ("", "0") else "spin", "host_cores": host_cores(), "scan_arith": {0: "fp32 reference order", 1: "fp32 fused", 2: "byte codes, v_dot4_u32_u8"}[h.scan_arith()],
+            "in_flight": nfl, "host_wait": "blocking events" if os.environ.get("AUNCEL_AMD_BLOCKING_SYNC", "0") not in ("", "0") else "spin", "host_cores": host_cores(), "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "stagger_ms": stagger_s * 1e3, "scan_arith": {0: "fp32 reference order", 1: "fp32 fused", 2: "byte codes, v_dot4_u32_u8"}[h.scan_arith()],
             "nb": args.nb, "sigma": args.sigma, "multipler": chosen, "std_m": args.std_m,
             "recall_at_10_mean": float(rec.mean()), "recall_at_10_min": float(rec.min()),
             "nprobe_mean": float(my_np[ts:].mean()), "nprobe_max": int(my_np[ts:].max()),
