@@ -201,6 +201,9 @@ struct amd_ivf {
     PinnedBuf p_group_p0, p_group_cnt, p_counters;
     DevBuf w_pl_cnt, w_pl_need, w_pl_dist_base, w_pl_lcount, w_pl_lstart, w_pl_gbase, w_pl_ibase, w_pl_fill, w_pl_counters;
     DevBuf w_x8, w_xnorm8;  // byte copy of the current queries + squared norms
+    const float* x8_src = nullptr;  // what w_x8 holds when it is a slice of the resident queries (byte_queries)
+    size_t x8_n = 0;
+    uint64_t x8_gen = 0, resident_gen = 1;
     DevBuf w_rcount, w_roff, w_rlab, w_rdis;  // range search: per-query counts / output offsets / results of a round
     std::vector<size_t> r_lims;              // results of the last range search (amd_ivf_range_results)
     std::vector<int64_t> r_labels;
@@ -325,9 +328,16 @@ void upload_lists(amd_ivf* h) {
 bool byte_queries(amd_ivf* ws, const amd_ivf* index, const float* d_x, size_t n, const IntRange& qr) {
     if (!index->have_codes8 || !ws->allow_bytes || n == 0) return false;
     if (!index->db_range.bytes_with(qr, (size_t)index->d)) return false;
+    // a slice of the resident query matrix that was converted by the previous call is still there
+    const float* r0 = ws->d_resident.as<float>();
+    const bool resident = ws->n_resident && d_x >= r0 && d_x + n * (size_t)ws->dpad <= r0 + ws->n_resident * (size_t)ws->dpad;
+    if (resident && ws->x8_src == d_x && ws->x8_n == n && ws->x8_gen == ws->resident_gen) return true;
     ws->w_x8.ensure(n * (size_t)index->d);
     ws->w_xnorm8.ensure(n * sizeof(uint32_t));
     launch_bytes_from_f32(d_x, n, index->d, ws->w_x8.as<uint8_t>(), ws->w_xnorm8.as<uint32_t>(), ws->stream);
+    ws->x8_src = resident ? d_x : nullptr;
+    ws->x8_n = n;
+    ws->x8_gen = ws->resident_gen;
     return true;
 }
 
@@ -1703,6 +1713,7 @@ int amd_ivf_set_queries(amd_ivf_t* h, size_t n, const float* x) {
     upload_rows(h, h->d_resident.as<float>(), x, n);
     HIP_CHECK(stream_sync(h->stream));
     h->n_resident = n;
+    h->resident_gen++;
     h->resident_range = IntRange();
     h->resident_range.add(x, n * (size_t)h->d);
     API_END
