@@ -186,7 +186,10 @@ struct amd_ivf {
     int allow_fused = 1;
     int allow_bytes = 1;
     int last_arith = 0;  // scan arithmetic of the last search: 0 reference order, 1 fused, 2 byte codes
-    DevBuf d_codes8, d_code_norms;  // byte copy of the lists + squared norms, kept while the data qualifies (IntRange::bytes)
+    // byte copy of the lists in MFMA fragment order (ivf_kernels.h) + per-slot constants, kept while the data qualifies
+    // (IntRange::bytes); block_off[l] = first 32-vector block of list l
+    DevBuf d_frag, d_cy, d_block_off;
+    std::vector<uint64_t> h_block_off;
     bool have_codes8 = false;
 
     // Auncel state
@@ -200,7 +203,7 @@ struct amd_ivf {
     DevBuf w_qtile, w_group_p0, w_group_cnt, w_xnorms;
     PinnedBuf p_group_p0, p_group_cnt, p_counters;
     DevBuf w_pl_cnt, w_pl_need, w_pl_dist_base, w_pl_lcount, w_pl_lstart, w_pl_gbase, w_pl_ibase, w_pl_fill, w_pl_counters;
-    DevBuf w_x8, w_xnorm8;  // byte copy of the current queries + squared norms
+    DevBuf w_x8, w_xnorm8;  // signed byte copy of the current queries + per-query constants (launch_sbytes_from_f32)
     const float* x8_src = nullptr;  // what w_x8 holds when it is a slice of the resident queries (byte_queries)
     size_t x8_n = 0;
     uint64_t x8_gen = 0, resident_gen = 1;
@@ -313,11 +316,17 @@ void upload_lists(amd_ivf* h) {
     }
     HIP_CHECK(hipMemcpyAsync(h->d_list_off.p, h->h_list_off.data(), (h->nlist + 1) * sizeof(uint64_t),
                              hipMemcpyHostToDevice, h->stream));
-    h->have_codes8 = h->allow_bytes && nt > 0 && h->db_range.bytes() && h->d == h->dpad && h->d % 16 == 0;
+    h->have_codes8 = h->allow_bytes && nt > 0 && h->db_range.bytes() && (double)h->d * 255.0 * 255.0 < 2147483648.0;
     if (h->have_codes8) {
-        h->d_codes8.ensure(nt * (size_t)h->d);
-        h->d_code_norms.ensure(nt * sizeof(uint32_t));
-        launch_bytes_from_f32(h->d_codes.as<float>(), nt, h->d, h->d_codes8.as<uint8_t>(), h->d_code_norms.as<uint32_t>(), h->stream);
+        h->h_block_off.assign(h->nlist + 1, 0);
+        for (size_t l = 0; l < h->nlist; l++) h->h_block_off[l + 1] = h->h_block_off[l] + mfma_list_blocks(h->h_ids[l].size());
+        const uint64_t nblk = h->h_block_off[h->nlist];
+        h->d_block_off.ensure((h->nlist + 1) * sizeof(uint64_t));
+        HIP_CHECK(hipMemcpyAsync(h->d_block_off.p, h->h_block_off.data(), (h->nlist + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+        h->d_frag.ensure(nblk * mfma_ksteps(h->d) * 1024);
+        h->d_cy.ensure(nblk * 32 * sizeof(int32_t));
+        launch_frag_from_f32(h->d_codes.as<float>(), h->d_list_off.as<uint64_t>(), h->d_block_off.as<uint64_t>(), (uint32_t)h->nlist, nblk, h->d,
+                             h->dpad, h->metric, h->d_frag.as<uint8_t>(), h->d_cy.as<int32_t>(), h->stream);
     }
     HIP_CHECK(stream_sync(h->stream));
     h->lists_dirty = false;
@@ -332,9 +341,9 @@ bool byte_queries(amd_ivf* ws, const amd_ivf* index, const float* d_x, size_t n,
     const float* r0 = ws->d_resident.as<float>();
     const bool resident = ws->n_resident && d_x >= r0 && d_x + n * (size_t)ws->dpad <= r0 + ws->n_resident * (size_t)ws->dpad;
     if (resident && ws->x8_src == d_x && ws->x8_n == n && ws->x8_gen == ws->resident_gen) return true;
-    ws->w_x8.ensure(n * (size_t)index->d);
-    ws->w_xnorm8.ensure(n * sizeof(uint32_t));
-    launch_bytes_from_f32(d_x, n, index->d, ws->w_x8.as<uint8_t>(), ws->w_xnorm8.as<uint32_t>(), ws->stream);
+    ws->w_x8.ensure(n * (size_t)mfma_ksteps(index->d) * 32);
+    ws->w_xnorm8.ensure(n * sizeof(int32_t));
+    launch_sbytes_from_f32(d_x, n, index->d, index->dpad, index->metric, ws->w_x8.as<int8_t>(), ws->w_xnorm8.as<int32_t>(), ws->stream);
     ws->x8_src = resident ? d_x : nullptr;
     ws->x8_n = n;
     ws->x8_gen = ws->resident_gen;
@@ -596,6 +605,10 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
             uint32_t c = lcount[l + 1] - lcount[l];
             if (!c) continue;
             const size_t sz = off[l + 1] - off[l];
+            if (r.bytes) {  // scan_mfma_kernel items: (chunk of the list) x (block of 32 queries)
+                n_qg[3] += (size_t)((c + MFMA_QBLOCK - 1) / MFMA_QBLOCK) * ((sz + MFMA_CHUNK - 1) / MFMA_CHUNK);
+                continue;
+            }
             const uint32_t full = c / qblock, rem = c % qblock;
             if (full) {
                 const uint32_t qg = scan_shape_of(qblock);
@@ -616,6 +629,23 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
             uint32_t c = lcount[l + 1] - lcount[l];
             if (!c) continue;
             const uint32_t sz = (uint32_t)(off[l + 1] - off[l]);
+            if (r.bytes) {
+                size_t& ni = cur[3];
+                for (uint32_t vb = 0; vb < sz; vb += MFMA_CHUNK)
+                    for (uint32_t qb = 0; qb < c; qb += MFMA_QBLOCK) {
+                        ScanItem& it = items[ni++];
+                        it.vec_base = ix(h)->h_block_off[l] + vb / MFMA_BLOCK;
+                        it.nvec = std::min<uint32_t>(MFMA_CHUNK, sz - vb);
+                        it.vec_off = vb;
+                        it.pair_begin = lcount[l] + qb;
+                        it.npair = std::min<uint32_t>(MFMA_QBLOCK, c - qb);
+                        it.qg = 0;
+                        it.qgroup = 0;
+                        h->scan_slots += (double)MFMA_QBLOCK * (((it.nvec + 63) / 64) * 64);
+                        h->scan_useful += (double)it.npair * it.nvec;
+                    }
+                continue;
+            }
             for (uint32_t qb = 0; qb < c; qb += qblock) {
                 const uint32_t nq_blk = std::min<uint32_t>(qblock, c - qb);
                 const uint32_t qg = scan_shape_of(nq_blk);
@@ -660,10 +690,7 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
             HIP_CHECK(hipMemcpyAsync(h->w_items.p, items, nitems * sizeof(ScanItem), hipMemcpyHostToDevice, s));
         }
         const double t_prep = now_us();
-        if (npairs) {
-            if (r.bytes) pack_query_tiles(h, h->w_x8.as<float>(), qranges, h->d / 4);
-            else pack_query_tiles(h, r.d_x, qranges);
-        }
+        if (npairs && !r.bytes) pack_query_tiles(h, r.d_x, qranges);
         ScanArgs sa{};
         sa.qtile = h->w_qtile.as<float>();
         sa.codes = ix(h)->d_codes.as<float>();
@@ -675,13 +702,23 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
         sa.d = h->dpad;
         sa.metric = h->metric;
         sa.fused = r.fused;
-        if (r.bytes) {
-            sa.codes = ix(h)->d_codes8.as<float>();
-            sa.d = h->d / 4;
-            sa.code_norms = ix(h)->d_code_norms.as<uint32_t>();
-            sa.query_norms = h->w_xnorm8.as<uint32_t>();
-        }
-        if (nitems) {
+        MfmaScanArgs ma{};
+        ma.codes_frag = ix(h)->d_frag.as<uint8_t>();
+        ma.code_cy = ix(h)->d_cy.as<int32_t>();
+        ma.queries8 = h->w_x8.as<int8_t>();
+        ma.query_cx = h->w_xnorm8.as<int32_t>();
+        ma.items = h->w_items.as<ScanItem>();
+        ma.pair_query = h->w_pair_query.as<uint32_t>();
+        ma.pair_out = h->w_pair_out.as<uint64_t>();
+        ma.dist = h->w_dist.as<float>();
+        ma.d = h->d;
+        ma.metric = h->metric;
+        ma.nitems = (uint32_t)nitems;
+        if (nitems && r.bytes) {
+            size_t t = h->timer.begin(CAT_SCAN, s);
+            launch_scan_mfma(ma, s);
+            h->timer.end(t, s);
+        } else if (nitems) {
             if (!h->aux[0]) {
                 for (int i = 0; i < 4; i++) {
                     HIP_CHECK(hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
@@ -1150,6 +1187,10 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     pa.pad = h->w_pl_pad.as<uint32_t>();
     pa.row_align = 64;
     pa.qblock = scan_qblock(base.bytes);
+    if (base.bytes) {
+        pa.mfma_chunk = MFMA_CHUNK;
+        pa.block_off = I->d_block_off.as<uint64_t>();
+    }
     pa.seg_begin = h->w_seg_begin.as<uint32_t>();
     pa.dist_base = h->w_pl_dist_base.as<unsigned long long>();
     pa.qsel = h->w_qsel.as<uint32_t>();
@@ -1205,10 +1246,37 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         const size_t n_qg[4] = {hc[4], hc[5], hc[8], hc[9]};
         const size_t nitems = n_qg[0] + n_qg[1] + n_qg[2] + n_qg[3];
         if (nitems > item_cap) throw std::runtime_error("tile list overflow");
-        if (npairs) {
-            const int row_words = base.bytes ? h->d / 4 : h->dpad;
+        static const bool xcd_off = getenv("AUNCEL_AMD_NO_XCD_CHUNKS") != nullptr;
+        if (npairs && base.bytes) {
+            // byte codes: one launch of scan_mfma_kernel (no query packing: the A operand is gathered from the query matrix)
+            MfmaScanArgs ma{};
+            ma.codes_frag = I->d_frag.as<uint8_t>();
+            ma.code_cy = I->d_cy.as<int32_t>();
+            ma.queries8 = h->w_x8.as<int8_t>();
+            ma.query_cx = h->w_xnorm8.as<int32_t>();
+            ma.items = h->w_items.as<ScanItem>();
+            ma.pair_query = h->w_pair_query.as<uint32_t>();
+            ma.pair_out = h->w_pair_out.as<uint64_t>();
+            ma.dist = h->w_dist.as<float>();
+            ma.d = h->d;
+            ma.metric = h->metric;
+            ma.xcd_chunks = xcd_off ? 0 : 1;
+            ma.nitems = (uint32_t)nitems;
+            if (thr_mode) {
+                ma.thr = h->w_thr.as<float>();
+                ma.mask = h->w_mask.as<unsigned long long>();
+            }
+            size_t t = h->timer.begin(CAT_SCAN, s);
+            HIP_CHECK(hipEventRecord(h->ev_fork, s));
+            HIP_CHECK(hipStreamWaitEvent(h->aux[3], h->ev_fork, 0));
+            launch_scan_mfma(ma, h->aux[3]);
+            HIP_CHECK(hipEventRecord(h->ev_join[3], h->aux[3]));
+            HIP_CHECK(hipStreamWaitEvent(s, h->ev_join[3], 0));
+            h->timer.end(t, s);
+        } else if (npairs) {
+            const int row_words = h->dpad;
             h->w_qtile.ensure((size_t)ngroups * (size_t)row_words * SCAN_RQ * sizeof(float));
-            launch_pack_queries(base.bytes ? h->w_x8.as<float>() : base.d_x, h->w_pair_query.as<uint32_t>(), h->w_group_p0.as<uint32_t>(),
+            launch_pack_queries(base.d_x, h->w_pair_query.as<uint32_t>(), h->w_group_p0.as<uint32_t>(),
                                 h->w_group_cnt.as<uint32_t>(), ngroups, row_words, h->w_qtile.as<float>(), s);
             ScanArgs sa{};
             sa.qtile = h->w_qtile.as<float>();
@@ -1221,14 +1289,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             sa.d = h->dpad;
             sa.metric = h->metric;
             sa.fused = base.fused;
-            static const bool xcd_off = getenv("AUNCEL_AMD_NO_XCD_CHUNKS") != nullptr;
             sa.xcd_chunks = xcd_off ? 0 : 1;  // measured: 3 % off the scan launches of the bench workload
-            if (base.bytes) {
-                sa.codes = I->d_codes8.as<float>();
-                sa.d = h->d / 4;
-                sa.code_norms = I->d_code_norms.as<uint32_t>();
-                sa.query_norms = h->w_xnorm8.as<uint32_t>();
-            }
             if (thr_mode) {
                 sa.thr = h->w_thr.as<float>();
                 sa.mask = h->w_mask.as<unsigned long long>();

@@ -42,9 +42,6 @@ struct ScanArgs {
     int d;
     int metric;
     int fused;  // 1: fma(t, t, acc) -- only when the operands make it bit-identical to mul + add (see engine)
-    // byte-code mode (non-null code_norms): codes / qtile hold bytes, d counts 4-byte words per row
-    const uint32_t* code_norms;   // |y|^2 of every stored vector
-    const uint32_t* query_norms;  // |x|^2 by query row (the rows pair_query names)
     // threshold mode (non-null thr): store only distances that beat thr[query row] and write one mask bit per
     // candidate (mask[i / 64] covers dist[i .. i + 63]); rows of `dist` start on multiples of 64
     const float* thr;
@@ -62,8 +59,49 @@ void launch_scan(const ScanArgs& a, const size_t n_qg[4], hipStream_t s, hipStre
 // [group_p0[g], group_p0[g] + group_cnt[g]); missing slots are zero
 void launch_pack_queries(const float* queries, const uint32_t* pair_query, const uint32_t* group_p0, const uint32_t* group_cnt,
                          size_t ngroups, int d, float* qtile, hipStream_t s);
-// fp32 rows of integers 0..255 -> byte rows and their squared norms (norms may be null); d % 4 == 0
-void launch_bytes_from_f32(const float* x, size_t n, int d, uint8_t* out, uint32_t* norms, hipStream_t s);
+
+// ---------------------------------------------------------------------------- byte-code scan on the i8 matrix cores
+// When lists and queries hold integers 0..255 (and d * max^2 <= 2^24, so that every fp32 partial sum of the reference is an
+// exact integer whatever the order) the distance tiles are integer contractions: v_mfma_i32_32x32x32_i8 on bytes re-centred
+// to signed (u - 128), L2 = |xs|^2 + |ys|^2 - 2 xs.ys (translation invariant), IP = xs.ys + 128 sum(x) + 128 sum(y) - 16384 d.
+//
+// Storage of the lists for that kernel ("fragment order"): every list is cut into blocks of 32 vectors (lists padded to an
+// even number of blocks); a block is ks x 64 x 16 bytes, ks = ceil(d / 32): 16-byte piece (s, lane) holds bytes
+// [h * 16 ks + 16 s, + 16) of vector (lane & 31), h = lane >> 5 -- exactly the B operand of K-step s, so a wave fetches an
+// operand with one fully coalesced 1-KiB load and no LDS staging.  Padding vectors / dimensions are signed zeros.
+// code_cy: one int32 per stored slot (block * 32 + vector): |ys|^2 (L2) or 128 sum(y) (IP).
+constexpr uint32_t MFMA_BLOCK = 32;        // vectors per block = N of the MFMA
+constexpr uint32_t MFMA_QBLOCK = 32;       // queries per item = M of the MFMA
+#ifndef AUNCEL_MFMA_CHUNK
+#define AUNCEL_MFMA_CHUNK 256
+#endif
+constexpr uint32_t MFMA_CHUNK = AUNCEL_MFMA_CHUNK;  // vectors per work item (a multiple of 64)
+inline __host__ __device__ uint32_t mfma_ksteps(int d) { return (uint32_t)(d + 31) / 32; }
+inline __host__ __device__ uint64_t mfma_list_blocks(uint64_t size) { return ((size + 63) / 64) * 2; }
+
+struct MfmaScanArgs {
+    const uint8_t* codes_frag;    // lists in fragment order
+    const int32_t* code_cy;       // per stored slot
+    const int8_t* queries8;       // signed query bytes, row stride ks * 32
+    const int32_t* query_cx;      // per query row: |xs|^2 (L2) or 128 sum(x) - 16384 d (IP)
+    const ScanItem* items;        // vec_base = first 32-block of the chunk (global block number), nvec = vectors of the chunk,
+                                  // vec_off = position of the chunk in its list, pair_begin / npair (<= 32) = its queries
+    const uint32_t* pair_query;
+    const uint64_t* pair_out;
+    float* dist;
+    const float* thr;             // threshold mode (see ScanArgs)
+    unsigned long long* mask;
+    int d;
+    int metric;
+    int xcd_chunks;
+    uint32_t nitems;
+};
+void launch_scan_mfma(const MfmaScanArgs& a, hipStream_t s);
+// fp32 lists (CSR rows, row stride dpad floats, integers 0..255) -> fragment order + code_cy; block_off[l] = first block of list l
+void launch_frag_from_f32(const float* codes, const uint64_t* list_off, const uint64_t* block_off, uint32_t nlist, uint64_t nblocks, int d,
+                          int dpad, int metric, uint8_t* out, int32_t* cy, hipStream_t s);
+// fp32 query rows (integers 0..255) -> signed byte rows (row stride ks * 32, zero padded) + query_cx
+void launch_sbytes_from_f32(const float* x, size_t n, int d, int dpad, int metric, int8_t* out, int32_t* cx, hipStream_t s);
 inline __host__ __device__ int scan_qg_class(uint32_t qg) { return qg == 1 ? 0 : qg == 2 ? 1 : qg == 4 ? 2 : 3; }
 // The queries of a list go into blocks of `qblock` (64: 8-wave tiles, the byte-code scan, which is short of HBM and
 // issue slots rather than of VALU; 32: 4-wave tiles, the fp32 scans); the last block takes the narrowest shape that holds it.
@@ -213,6 +251,8 @@ struct PlanArgs {
     uint32_t* pad;                   // [nq] padding inside need
     uint32_t row_align;              // 1 or 64
     uint32_t qblock;                 // queries per full block of a list: 64 (8-wave tiles) or 32 (4-wave tiles)
+    uint32_t mfma_chunk;             // != 0: items for scan_mfma_kernel (vectors per item); counted as tiles of shape 8
+    const uint64_t* block_off;       // mfma: first 32-vector block of every list in the fragment-order storage
     uint32_t* seg_begin;             // [nq]
     unsigned long long* dist_base;   // [nq]
     uint32_t* qsel;                  // active slots, compacted

@@ -16,10 +16,20 @@
 
 #include <float.h>
 #include <algorithm>
+#include <stdexcept>
 #include <stdlib.h>
+#include <string>
 #include <type_traits>
+#include <utility>
 
 namespace amdivf {
+
+// A launch the runtime rejects (grid, LDS or register limits) leaves nothing on the stream, and the later synchronisation
+// succeeds: without this check a search would return untouched output buffers as if they were results.
+static void check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) throw std::runtime_error(std::string("kernel launch failed (") + what + "): " + hipGetErrorString(e));
+}
 
 // =============================================================================================
 // K-scan: distance tiles
@@ -36,17 +46,13 @@ constexpr int LDS_ROW = SCAN_DC + 4;                 // dwords per staged row (p
 // each.  QG 8: 8 waves share one 128-vector tile (64 queries per pass over the list); QG 4: 4 waves, 128 vectors;
 // QG 2 / 1: 4 waves over 256 / 512 vectors.  The staged tile (and the LDS footprint) follows.
 //
-// ARITH selects the arithmetic (the result is the same fp32 number in all three):
+// ARITH selects the arithmetic (the result is the same fp32 number either way):
 //   0  the reference's SSE order: four running sums over elements 4i+l, separate multiply and add
 //   1  the same order with fma, legal when operands are small integers (see IntRange in the engine)
-//   2  byte codes: the lists and the queries hold integers 0..255 and d * 255^2 <= 2^24, so every partial sum
-//      of the reference is an exact integer whatever the order; rows are stored as bytes (a quarter of the
-//      HBM traffic), a 16-B slot carries 16 dimensions, and the inner product runs on v_dot4_u32_u8.
-//      L2 = |x|^2 + |y|^2 - 2 x.y in integers.  Here `d` counts 4-byte words per row (dimensions / 4).
+// (uint8-valued data takes scan_mfma_kernel below instead: exact integer contraction on the i8 matrix cores)
 template <int METRIC, int QG, int ARITH>
 __global__ __launch_bounds__(QG == 8 ? 512 : 256) void scan_tiles_kernel(ScanArgs a) {
     constexpr bool FUSED = ARITH == 1;
-    constexpr bool BYTES = ARITH == 2;
     constexpr int qg = QG;
     constexpr int NT = QG == 8 ? 512 : 256;
     constexpr int vg = QG >= 4 ? 1 : 4 / QG;
@@ -80,14 +86,10 @@ __global__ __launch_bounds__(QG == 8 ? 512 : 256) void scan_tiles_kernel(ScanArg
 
     // running sums (s0, s1) and (s2, s3) of the reference's 4-lane accumulator, as two register pairs
     f2 acc[SCAN_RQ][SCAN_RV][2];
-    uint32_t dot[SCAN_RQ][SCAN_RV];  // ARITH 2
 #pragma unroll
     for (int r = 0; r < SCAN_RQ; r++)
 #pragma unroll
-        for (int v = 0; v < SCAN_RV; v++) {
-            acc[r][v][0] = acc[r][v][1] = f2{0.f, 0.f};
-            dot[r][v] = 0u;
-        }
+        for (int v = 0; v < SCAN_RV; v++) acc[r][v][0] = acc[r][v][1] = f2{0.f, 0.f};
 
     const float* tile_base = a.codes + (size_t)it.vec_base * (size_t)d;
     const bool has_queries = (uint32_t)(qgi * SCAN_RQ) < it.npair;
@@ -97,25 +99,12 @@ __global__ __launch_bounds__(QG == 8 ? 512 : 256) void scan_tiles_kernel(ScanArg
     // forming two dependent scalar round trips per query at the end.
     const bool masked = a.thr != nullptr;
     unsigned long long e_row = 0;
-    uint32_t e_xn = 0;
     float e_thr = 0.f;
-    uint32_t ynorm[SCAN_RV];
     if (has_queries) {
         const uint32_t local = (uint32_t)(qgi * SCAN_RQ + lane);
         if (lane < SCAN_RQ && local < it.npair) {
             e_row = a.pair_out[it.pair_begin + local] + it.vec_off;
-            if (masked || (BYTES && METRIC == METRIC_L2)) {
-                const uint32_t qrow = a.pair_query[it.pair_begin + local];
-                if (BYTES && METRIC == METRIC_L2) e_xn = a.query_norms[qrow];
-                if (masked) e_thr = a.thr[qrow];
-            }
-        }
-        if (BYTES && METRIC == METRIC_L2) {
-#pragma unroll
-            for (int v = 0; v < SCAN_RV; v++) {
-                const int lv = vgi * SCAN_WAVE_VECS + v * 64 + lane;
-                ynorm[v] = lv < (int)it.nvec ? a.code_norms[it.vec_base + lv] : 0u;
-            }
+            if (masked) e_thr = a.thr[a.pair_query[it.pair_begin + local]];
         }
     }
 
@@ -174,15 +163,7 @@ __global__ __launch_bounds__(QG == 8 ? 512 : 256) void scan_tiles_kernel(ScanArg
                 ya[v] = f2{yn[v].x, yn[v].y};
                 yb[v] = f2{yn[v].z, yn[v].w};
             }
-            if (BYTES) {
-                // unconditional (the last step re-reads its own operands): a branch here costs a register copy per
-                // operand, which the short byte-code steps feel and the fp32 steps do not
-                const int sn = s + 1 < nslot ? s + 1 : s;
-#pragma unroll
-                for (int v = 0; v < SCAN_RV; v++) yn[v] = *reinterpret_cast<const float4*>(myrow + v * 64 * LDS_ROW + sn * 4);
-#pragma unroll
-                for (int r = 0; r < SCAN_RQ; r++) qn[r] = qs[sn * SCAN_RQ + r];
-            } else if (s + 1 < nslot) {
+            if (s + 1 < nslot) {
 #pragma unroll
                 for (int v = 0; v < SCAN_RV; v++) yn[v] = *reinterpret_cast<const float4*>(myrow + v * 64 * LDS_ROW + (s + 1) * 4);
 #pragma unroll
@@ -193,14 +174,7 @@ __global__ __launch_bounds__(QG == 8 ? 512 : 256) void scan_tiles_kernel(ScanArg
                 const f2 qa = f2{qc[r].x, qc[r].y}, qb = f2{qc[r].z, qc[r].w};
 #pragma unroll
                 for (int v = 0; v < SCAN_RV; v++) {
-                    if (BYTES) {
-                        uint32_t t = dot[r][v];
-                        t = __builtin_amdgcn_udot4(__float_as_uint(ya[v].x), __float_as_uint(qa.x), t, false);
-                        t = __builtin_amdgcn_udot4(__float_as_uint(ya[v].y), __float_as_uint(qa.y), t, false);
-                        t = __builtin_amdgcn_udot4(__float_as_uint(yb[v].x), __float_as_uint(qb.x), t, false);
-                        t = __builtin_amdgcn_udot4(__float_as_uint(yb[v].y), __float_as_uint(qb.y), t, false);
-                        dot[r][v] = t;
-                    } else if (METRIC == METRIC_L2) {
+                    if (METRIC == METRIC_L2) {
                         const f2 ta = ya[v] - qa, tb = yb[v] - qb;
                         if (FUSED) {  // products exactly representable: one rounding either way
                             acc[r][v][0] = __builtin_elementwise_fma(ta, ta, acc[r][v][0]);
@@ -237,15 +211,12 @@ __global__ __launch_bounds__(QG == 8 ? 512 : 256) void scan_tiles_kernel(ScanArg
             const unsigned long long row = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(e_row >> 32), r) << 32) |
                                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e_row, r);
             float* out = a.dist + row;
-            const uint32_t xnorm = (uint32_t)__builtin_amdgcn_readlane((int)e_xn, r);
             const float thr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e_thr), r));
 #pragma unroll
             for (int v = 0; v < SCAN_RV; v++) {
                 const int lv0 = vgi * SCAN_WAVE_VECS + v * 64;
                 const int lv = lv0 + lane;
-                float res;
-                if (BYTES) res = METRIC == METRIC_L2 ? (float)(xnorm + ynorm[v] - 2u * dot[r][v]) : (float)dot[r][v];
-                else res = (acc[r][v][0].x + acc[r][v][0].y) + (acc[r][v][1].x + acc[r][v][1].y);
+                const float res = (acc[r][v][0].x + acc[r][v][0].y) + (acc[r][v][1].x + acc[r][v][1].y);
                 bool keep = lv < (int)it.nvec;
                 if (masked) {
                     keep = keep && (METRIC == METRIC_L2 ? thr > res : thr < res);
@@ -265,28 +236,6 @@ __global__ __launch_bounds__(QG == 8 ? 512 : 256) void scan_tiles_kernel(ScanArg
         if ((uint32_t)(qgi * SCAN_RQ + r) < it.npair && lv0 < (int)it.nvec)
             a.mask[(row + lv0) >> 6] = ((unsigned long long)mk_hi << 32) | mk_lo;
     }
-}
-
-// fp32 rows holding integers 0..255 -> byte rows (+ squared norms); a lane converts 4 dimensions at a time
-__global__ __launch_bounds__(256) void bytes_from_f32_kernel(const float* x, size_t n, int d, uint8_t* out, uint32_t* norms) {
-    const int per_row = d >> 2;  // d % 4 == 0
-    // one wave per row keeps the norm reduction inside the wave
-    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (row >= n) return;
-    uint32_t nrm = 0;
-    for (int c = lane; c < per_row; c += 64) {
-        const float4 v = *reinterpret_cast<const float4*>(x + row * (size_t)d + c * 4);
-        const uint32_t b0 = (uint32_t)v.x, b1 = (uint32_t)v.y, b2 = (uint32_t)v.z, b3 = (uint32_t)v.w;
-        *reinterpret_cast<uint32_t*>(out + row * (size_t)d + c * 4) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
-        nrm += b0 * b0 + b1 * b1 + b2 * b2 + b3 * b3;
-    }
-    for (int off = 32; off; off >>= 1) nrm += __shfl_xor(nrm, off);
-    if (lane == 0 && norms) norms[row] = nrm;
-}
-
-void launch_bytes_from_f32(const float* x, size_t n, int d, uint8_t* out, uint32_t* norms, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(bytes_from_f32_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, x, n, d, out, norms);
 }
 
 __global__ __launch_bounds__(256) void pack_queries_kernel(const float* queries, const uint32_t* pair_query, const uint32_t* group_p0,
@@ -313,16 +262,14 @@ template <int QG> static void launch_scan_qg(ScanArgs a, size_t first, size_t n,
     a.items += first;
     a.nitems = (uint32_t)n;
     const dim3 grid((unsigned)(a.xcd_chunks ? ((n + 7) / 8) * 8 : n)), block(QG == 8 ? 512 : 256);
-    const int arith = a.code_norms ? 2 : a.fused ? 1 : 0;
     if (a.metric == METRIC_L2) {
-        if (arith == 2) hipLaunchKernelGGL((scan_tiles_kernel<METRIC_L2, QG, 2>), grid, block, 0, s, a);
-        else if (arith == 1) hipLaunchKernelGGL((scan_tiles_kernel<METRIC_L2, QG, 1>), grid, block, 0, s, a);
+        if (a.fused) hipLaunchKernelGGL((scan_tiles_kernel<METRIC_L2, QG, 1>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((scan_tiles_kernel<METRIC_L2, QG, 0>), grid, block, 0, s, a);
     } else {
-        if (arith == 2) hipLaunchKernelGGL((scan_tiles_kernel<METRIC_IP, QG, 2>), grid, block, 0, s, a);
-        else if (arith == 1) hipLaunchKernelGGL((scan_tiles_kernel<METRIC_IP, QG, 1>), grid, block, 0, s, a);
+        if (a.fused) hipLaunchKernelGGL((scan_tiles_kernel<METRIC_IP, QG, 1>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((scan_tiles_kernel<METRIC_IP, QG, 0>), grid, block, 0, s, a);
     }
+    check_launch("scan_tiles_kernel");
 }
 
 // items must be grouped by qg: n_qg[0] items with qg 1, then n_qg[1] with qg 2, n_qg[2] with qg 4, n_qg[3] with qg 8
@@ -331,6 +278,296 @@ void launch_scan(const ScanArgs& a, const size_t n_qg[4], hipStream_t s, hipStre
     launch_scan_qg<4>(a, n_qg[0] + n_qg[1], n_qg[2], s4 ? s4 : s);
     launch_scan_qg<2>(a, n_qg[0], n_qg[1], s2 ? s2 : s);
     launch_scan_qg<1>(a, 0, n_qg[0], s1 ? s1 : s);
+}
+
+
+// =============================================================================================
+// K-scan, byte codes: distance tiles on the i8 matrix cores
+// =============================================================================================
+// One wave = one work item: up to 32 queries probing a list x a chunk of MFMA_CHUNK consecutive vectors of it.  The query
+// bytes are the A operand (rows = queries), gathered once per item straight from the (L2-resident) signed query matrix; the
+// list streams through as the B operand in pairs of 32-vector blocks, fetched in fragment order (ivf_kernels.h) with
+// coalesced 16-byte-per-lane loads -- every byte of a list is read once per item from HBM, no LDS staging, no barriers;
+// the waves of a CU in their load phase are what keeps the memory pipe full.  v_mfma_i32_32x32x32_i8 leaves query
+// (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) x vector (lane & 31) in accumulator register `reg`, so a register of a block is two
+// 128-byte runs of two distance rows.  Exact integers throughout: t = 2 x.y - |y|^2 (L2) or x.y + cy (IP) is compared with
+// the query's threshold in the integer domain (a v_cmp per register is the 64-candidate ballot), res = cx -/+ t is converted
+// once.  K order inside the contraction is irrelevant (integers), so both operands use "lane half h owns bytes
+// [16 ks h, 16 ks (h + 1))", which makes a lane's ks pieces of a query row contiguous.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// reg[lane LANE] = val (val wave-uniform, LANE a compile-time constant: an inline operand, so the one SGPR slot is val's)
+template <int LANE> __device__ __forceinline__ void writelane_c(int& reg, uint32_t val) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(reg) : "s"(val), "n"(LANE));
+}
+template <int... I, class F> __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+
+// NKS = K-steps (d <= 32 NKS) with the query operand resident in registers; 0 = any d, query pieces re-read per block pair
+template <int METRIC, bool MASKED, int NKS>
+__global__ __launch_bounds__(256) void scan_mfma_kernel(MfmaScanArgs a) {
+    __shared__ int s_cx[4][32];
+    __shared__ int s_u[4][32];
+    __shared__ unsigned long long s_row[4][32];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = lane & 31, h = lane >> 5;
+    uint32_t wg = blockIdx.x;
+    if (a.xcd_chunks) wg = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // XCD x takes the x-th eighth of the items
+    const uint32_t item_no = wg * 4 + wave;
+    if (item_no >= a.nitems) return;  // (no workgroup barrier below)
+    const ScanItem it = a.items[item_no];
+    const int ks = NKS ? NKS : (int)mfma_ksteps(a.d);
+    const size_t qstride = (size_t)ks * 32;
+
+    // ---- per-query operands, lane m (both halves) for query m of the item
+    const bool qok = (uint32_t)m < it.npair;
+    uint32_t qrow = 0;
+    unsigned long long row = 0;
+    int cx = 0, u = 0x7fffffff;
+    if (qok) {
+        qrow = a.pair_query[it.pair_begin + m];
+        row = a.pair_out[it.pair_begin + m] + it.vec_off;
+        cx = a.query_cx[qrow];
+        if (MASKED) {
+            // the reference keeps a candidate iff C::cmp(top, dis): L2 top > dis, IP top < dis.  dis is an integer in
+            // [0, 2^24]; the threshold (a heap top, or a range-search radius) need not be: L2 dis < ceil(thr), IP dis > floor(thr).
+            const float thr = a.thr[qrow];
+            if (METRIC == METRIC_L2) {
+                const float c = ceilf(thr);
+                const int T = !(c > 0.f) ? 0 : (c >= 1073741824.f ? 1073741824 : (int)c);  // NaN -> nothing passes
+                u = cx - T;          // keep <=> 2 x.y - |y|^2 > |x|^2 - T
+            } else {
+                const float f = floorf(thr);
+                const int T = !(f < 1073741824.f) ? 0x7fffffff : (f <= -1073741824.f ? -1073741824 : (int)f);
+                u = T == 0x7fffffff ? T : T - cx;  // keep <=> x.y + cy > T - cx
+            }
+        }
+    }
+    if (h == 0) {
+        s_cx[wave][m] = cx;
+        s_u[wave][m] = u;
+        s_row[wave][m] = row;
+    }
+    const int8_t* qp = a.queries8 + (size_t)qrow * qstride + (size_t)h * (size_t)(16 * ks);
+    v4i af[NKS ? NKS : 1];
+    if (NKS) {
+#pragma unroll
+        for (int s = 0; s < NKS; s++) af[s] = qok ? *reinterpret_cast<const v4i*>(qp + 16 * s) : v4i{0, 0, 0, 0};
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // thresholds / cx in accumulator layout: register 4 g + i of lane half h belongs to query 8 g + 4 h + i
+    int ur[16], cxr[16];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const v4i tu = *reinterpret_cast<const v4i*>(&s_u[wave][8 * g + 4 * h]);
+        const v4i tc = *reinterpret_cast<const v4i*>(&s_cx[wave][8 * g + 4 * h]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            ur[4 * g + i] = tu[i];
+            cxr[4 * g + i] = tc[i];
+        }
+    }
+
+    const size_t block_bytes = (size_t)ks * 1024;
+    const uint32_t npairs = (it.nvec + 63) >> 6;
+    uint32_t* mask32 = reinterpret_cast<uint32_t*>(a.mask);
+    // Software pipeline (resident-operand form): the B pieces of pair p + 1 are requested right after the MFMAs of pair p
+    // have consumed their registers, and land while the epilogue of pair p runs; the scheduling barriers keep the compiler
+    // from sinking the loads back to their uses (it otherwise recycles three registers and keeps three loads in flight).
+    v4i b[2][NKS ? NKS : 1];
+    int cyn[2] = {0, 0};
+    auto fetch_pair = [&](uint32_t p) {
+        const uint64_t blk = it.vec_base + 2 * p;
+        const uint8_t* bp = a.codes_frag + blk * block_bytes + (size_t)lane * 16;
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int s = 0; s < (NKS ? NKS : 1); s++)
+                b[j][s] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(bp + j * block_bytes + (size_t)s * 1024));
+        cyn[0] = a.code_cy[blk * 32 + m];
+        cyn[1] = a.code_cy[blk * 32 + 32 + m];
+    };
+    if (NKS) fetch_pair(0);
+    for (uint32_t p = 0; p < npairs; p++) {
+        v16i acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[j][i] = 0;
+        int cy[2];
+        if (NKS) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < NKS; s++) {
+                acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[s], b[0][s], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[s], b[1][s], acc[1], 0, 0, 0);
+            }
+            cy[0] = cyn[0];
+            cy[1] = cyn[1];
+            __builtin_amdgcn_sched_barrier(0);
+            if (p + 1 < npairs) fetch_pair(p + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            const uint64_t blk = it.vec_base + 2 * p;
+            const uint8_t* bp = a.codes_frag + blk * block_bytes + (size_t)lane * 16;
+            cy[0] = a.code_cy[blk * 32 + m];
+            cy[1] = a.code_cy[blk * 32 + 32 + m];
+            for (int s = 0; s < ks; s++) {
+                const v4i aq = qok ? *reinterpret_cast<const v4i*>(qp + 16 * s) : v4i{0, 0, 0, 0};
+                const v4i b0 = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(bp + (size_t)s * 1024));
+                const v4i b1 = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(bp + block_bytes + (size_t)s * 1024));
+                acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq, b0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq, b1, acc[1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const uint32_t lv = (2 * p + j) * 32 + m;           // position of this lane's vector in the chunk
+            const bool vok = lv < it.nvec;
+            const unsigned long long vmask = __ballot(vok);
+            int word = 0;  // threshold mode: lane q (< 32) collects the 32-candidate mask word of query q
+            static_for(std::make_integer_sequence<int, 16>{}, [&](auto R) {
+                constexpr int reg = decltype(R)::value;
+                constexpr int q0 = (reg & 3) + 8 * (reg >> 2);  // query of lane half 0; half 1: q0 + 4
+                const int t = METRIC == METRIC_L2 ? 2 * acc[j][reg] - cy[j] : acc[j][reg] + cy[j];
+                if (MASKED) {
+                    const bool keep = t > ur[reg];
+                    const unsigned long long bal = __ballot(keep) & vmask;
+                    writelane_c<q0>(word, (uint32_t)bal);
+                    writelane_c<q0 + 4>(word, (uint32_t)(bal >> 32));
+                    if (bal) {  // rare after round 0: the query's cx and row come from LDS only then
+                        const unsigned long long rr = s_row[wave][q0 + 4 * h];
+                        const int cq = s_cx[wave][q0 + 4 * h];
+                        if (keep && vok) a.dist[rr + lv] = (float)(METRIC == METRIC_L2 ? cq - t : cq + t);
+                    }
+                } else {
+                    const unsigned long long rr = s_row[wave][q0 + 4 * h];
+                    const int res = METRIC == METRIC_L2 ? cxr[reg] - t : cxr[reg] + t;
+                    if (vok && (uint32_t)(q0 + 4 * h) < it.npair) a.dist[rr + lv] = (float)res;
+                }
+            });
+            // rows start on multiples of 64 floats, chunks on multiples of 64 vectors: word index = (row + position) / 32.
+            // The odd block of a 64-candidate chunk past the list's end gets its (zero) word too.
+            if (MASKED && lane < 32 && qok) mask32[(row + (2 * p + j) * 32) >> 5] = (uint32_t)word;
+        }
+    }
+}
+
+void launch_scan_mfma(const MfmaScanArgs& a, hipStream_t s) {
+    if (a.nitems == 0) return;
+    const unsigned nwg = (a.nitems + 3) / 4;
+    const dim3 grid(a.xcd_chunks ? ((nwg + 7) / 8) * 8 : nwg), block(256);
+    const bool masked = a.thr != nullptr;
+    const int ks = (int)mfma_ksteps(a.d);
+    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, 0, s, a); };
+    auto pick_ks = [&](auto metric, auto msk) {
+        constexpr int M = decltype(metric)::value;
+        constexpr bool K = decltype(msk)::value;
+        switch (ks) {
+            case 1: return go(scan_mfma_kernel<M, K, 1>);
+            case 2: return go(scan_mfma_kernel<M, K, 2>);
+            case 3: return go(scan_mfma_kernel<M, K, 3>);
+            case 4: return go(scan_mfma_kernel<M, K, 4>);
+            default: return go(scan_mfma_kernel<M, K, 0>);
+        }
+    };
+    if (a.metric == METRIC_L2) {
+        if (masked) pick_ks(std::integral_constant<int, METRIC_L2>{}, std::true_type{});
+        else pick_ks(std::integral_constant<int, METRIC_L2>{}, std::false_type{});
+    } else {
+        if (masked) pick_ks(std::integral_constant<int, METRIC_IP>{}, std::true_type{});
+        else pick_ks(std::integral_constant<int, METRIC_IP>{}, std::false_type{});
+    }
+    check_launch("scan_mfma_kernel");
+}
+
+// fp32 lists -> fragment order (one wave per 32-vector block; the block's list by bisection over block_off)
+__global__ __launch_bounds__(64) void frag_from_f32_kernel(const float* codes, const uint64_t* list_off, const uint64_t* block_off, uint32_t nlist,
+                                                           int d, int dpad, int metric, uint8_t* out, int32_t* cy) {
+    const uint64_t blk = blockIdx.x;
+    const int lane = threadIdx.x, v = lane & 31, h = lane >> 5;
+    uint32_t lo = 0, hi = nlist;  // largest l with block_off[l] <= blk
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (block_off[mid] <= blk) lo = mid;
+        else hi = mid;
+    }
+    const uint64_t pos = (blk - block_off[lo]) * 32 + v, size = list_off[lo + 1] - list_off[lo];
+    const bool ok = pos < size;
+    const float* src = codes + (list_off[lo] + (ok ? pos : 0)) * (uint64_t)dpad;
+    const int ks = (int)mfma_ksteps(d);
+    int sq = 0, sum = 0;
+    for (int s = 0; s < ks; s++) {
+        const int c0 = h * 16 * ks + 16 * s;
+        v4i piece;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            uint32_t word = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int c = c0 + 4 * w + b;
+                int sv = 0;  // padding: signed zero
+                if (ok && c < d) {
+                    const int uv = (int)src[c];
+                    sv = uv - 128;
+                    sq += sv * sv;
+                    sum += uv;
+                }
+                word |= (uint32_t)(sv & 0xff) << (8 * b);
+            }
+            piece[w] = (int)word;
+        }
+        *reinterpret_cast<v4i*>(out + blk * (uint64_t)ks * 1024 + (uint64_t)s * 1024 + (uint64_t)lane * 16) = piece;
+    }
+    sq += __shfl_xor(sq, 32);
+    sum += __shfl_xor(sum, 32);
+    if (h == 0) cy[blk * 32 + v] = !ok ? 0 : metric == METRIC_L2 ? sq : 128 * sum;
+}
+
+void launch_frag_from_f32(const float* codes, const uint64_t* list_off, const uint64_t* block_off, uint32_t nlist, uint64_t nblocks, int d,
+                          int dpad, int metric, uint8_t* out, int32_t* cy, hipStream_t s) {
+    if (nblocks == 0) return;
+    hipLaunchKernelGGL(frag_from_f32_kernel, dim3((unsigned)nblocks), dim3(64), 0, s, codes, list_off, block_off, nlist, d, dpad, metric, out, cy);
+    check_launch("frag_from_f32_kernel");
+}
+
+// fp32 query rows -> signed byte rows (stride 32 ks, zero padded) + cx; one wave per row
+__global__ __launch_bounds__(256) void sbytes_from_f32_kernel(const float* x, size_t n, int d, int dpad, int metric, int8_t* out, int32_t* cx) {
+    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const int stride = (int)mfma_ksteps(d) * 32;
+    int sq = 0, sum = 0;
+    for (int c = lane * 4; c < stride; c += 256) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            int sv = 0;
+            if (c + b < d) {
+                const int uv = (int)x[row * (size_t)dpad + c + b];
+                sv = uv - 128;
+                sq += sv * sv;
+                sum += uv;
+            }
+            word |= (uint32_t)(sv & 0xff) << (8 * b);
+        }
+        *reinterpret_cast<uint32_t*>(out + row * (size_t)stride + c) = word;
+    }
+    for (int off = 32; off; off >>= 1) {
+        sq += __shfl_xor(sq, off);
+        sum += __shfl_xor(sum, off);
+    }
+    if (lane == 0) cx[row] = metric == METRIC_L2 ? sq : 128 * sum - 16384 * d;
+}
+
+void launch_sbytes_from_f32(const float* x, size_t n, int d, int dpad, int metric, int8_t* out, int32_t* cx, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(sbytes_from_f32_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, x, n, d, dpad, metric, out, cx);
+    check_launch("sbytes_from_f32_kernel");
 }
 
 // =============================================================================================

@@ -231,6 +231,10 @@ __global__ __launch_bounds__(1024) void plan_lists_kernel(PlanArgs a) {
         const unsigned long long sz = a.list_off[l + 1] - a.list_off[l];
         v[0] = c;
         v[1] = (c + SCAN_RQ - 1) / SCAN_RQ;
+        if (a.mfma_chunk) {  // byte codes: one item per (chunk of the list, block of 32 queries), all in the last class
+            v[5] = ((c + MFMA_QBLOCK - 1) / MFMA_QBLOCK) * (uint32_t)((sz + a.mfma_chunk - 1) / a.mfma_chunk);
+            return;
+        }
         const uint32_t full = c / a.qblock, rem = c % a.qblock;
         if (full) {
             const uint32_t qg = scan_shape_of(a.qblock);
@@ -312,6 +316,30 @@ __global__ __launch_bounds__(256) void plan_items_kernel(PlanArgs a) {
     const uint32_t sz = (uint32_t)(a.list_off[l + 1] - a.list_off[l]);
     const uint64_t vb0 = a.list_off[l];
     unsigned long long slots = 0, useful = 0;
+    if (a.mfma_chunk) {
+        // items of one chunk are consecutive (its query blocks): they run close together on one XCD (scan_mfma_kernel's
+        // item order), so a chunk fetched for one query block is still in that L2 for the next
+        uint32_t ni = cur[3];
+        const uint64_t b0 = a.block_off[l];
+        for (uint32_t vb = 0; vb < sz; vb += a.mfma_chunk)
+            for (uint32_t qb = 0; qb < c; qb += MFMA_QBLOCK) {
+                ScanItem it;
+                it.vec_base = b0 + vb / MFMA_BLOCK;
+                it.nvec = sz - vb < a.mfma_chunk ? sz - vb : a.mfma_chunk;
+                it.vec_off = vb;
+                it.pair_begin = p0 + qb;
+                it.npair = c - qb < MFMA_QBLOCK ? c - qb : MFMA_QBLOCK;
+                it.qg = 0;
+                it.qgroup = 0;
+                if (ni < a.item_cap) a.items[ni] = it;
+                ni++;
+                slots += (unsigned long long)MFMA_QBLOCK * (((it.nvec + 63) / 64) * 64);
+                useful += (unsigned long long)it.npair * it.nvec;
+            }
+        atomicAdd(&a.acc64[0], slots);
+        atomicAdd(&a.acc64[1], useful);
+        return;
+    }
     for (uint32_t qb = 0; qb < c; qb += a.qblock) {
         const uint32_t nq_blk = c - qb < a.qblock ? c - qb : a.qblock;
         const uint32_t qg = scan_shape_of(nq_blk);
