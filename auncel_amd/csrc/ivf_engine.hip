@@ -64,7 +64,15 @@ struct IntRange {
         lo = std::min(lo, o.lo);
         hi = std::max(hi, o.hi);
     }
-    bool fusable_with(const IntRange& o) const { return ok && o.ok && std::max(hi, o.hi) <= 4095.f && std::min(lo, o.lo) >= -4095.f; }
+    // Inner product: |x|, |y| <= 4095 keeps every product below 2^24.  L2 squares the difference, so it is the spread of the
+    // two ranges together that must stay within 4096 (|x - y| <= 4096, (x - y)^2 <= 2^24): operands of opposite signs
+    // up to 4095 each would give differences up to 8190, whose squares fp32 no longer holds exactly.
+    bool fusable_with(const IntRange& o, int metric) const {
+        if (!(ok && o.ok)) return false;
+        const float l = std::min(lo, o.lo), h = std::max(hi, o.hi);
+        if (metric == METRIC_L2) return h - l <= 4096.f;
+        return h <= 4095.f && l >= -4095.f;
+    }
     // Byte-code scan (scan_tiles_kernel, ARITH 2): both sides hold integers 0..255 and no sum of d products can pass
     // 2^24, so the reference's fp32 partial sums are exact integers in any order and integer arithmetic gives the
     // same fp32 distance bit for bit.
@@ -218,6 +226,11 @@ struct amd_ivf {
     DevBuf c_heap_val, c_heap_ref, c_stage, c_nscan, c_done, c_seg_off, c_seg_list, c_seg_count;
     PinnedBuf p_items, p_pair_query, p_pair_out, p_seg_off, p_seg_list, p_seg_count, p_qsel, p_seg_begin;
     DevBuf w_seg_begin;
+    // chained rounds: the planning counters of every round of the last search (grid hints for the next one of the same shape)
+    DevBuf w_pl_hist;
+    PinnedBuf p_hist;
+    std::vector<uint32_t> round_hint;  // [round][16]
+    uint64_t hint_sig = 0;
     DevBuf w_limit;  // time-bounded search: per-slot end of the probe loop (plan_counts_kernel -> replay_kernel)
 
     size_t dist_budget_floats = (size_t)768 << 20;  // 3 GiB of distances per scan launch
@@ -606,7 +619,7 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
             if (!c) continue;
             const size_t sz = off[l + 1] - off[l];
             if (r.bytes) {  // scan_mfma_kernel items: (chunk of the list) x (block of 32 queries)
-                n_qg[3] += (size_t)((c + MFMA_QBLOCK - 1) / MFMA_QBLOCK) * ((sz + MFMA_CHUNK - 1) / MFMA_CHUNK);
+                n_qg[3] += (size_t)((c + MFMA_QBLOCK - 1) / MFMA_QBLOCK) * ((sz + mfma_chunk() - 1) / mfma_chunk());
                 continue;
             }
             const uint32_t full = c / qblock, rem = c % qblock;
@@ -631,11 +644,11 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
             const uint32_t sz = (uint32_t)(off[l + 1] - off[l]);
             if (r.bytes) {
                 size_t& ni = cur[3];
-                for (uint32_t vb = 0; vb < sz; vb += MFMA_CHUNK)
+                for (uint32_t vb = 0; vb < sz; vb += mfma_chunk())
                     for (uint32_t qb = 0; qb < c; qb += MFMA_QBLOCK) {
                         ScanItem& it = items[ni++];
                         it.vec_base = ix(h)->h_block_off[l] + vb / MFMA_BLOCK;
-                        it.nvec = std::min<uint32_t>(MFMA_CHUNK, sz - vb);
+                        it.nvec = std::min<uint32_t>(mfma_chunk(), sz - vb);
                         it.vec_off = vb;
                         it.pair_begin = lcount[l] + qb;
                         it.npair = std::min<uint32_t>(MFMA_QBLOCK, c - qb);
@@ -809,6 +822,7 @@ void check_device_error(amd_ivf* h) {
     if (err == ERR_ARCOS_DOMAIN) throw EngineError("arcos's domain definition is [-1, 1]");
     if (err == ERR_COSINE_PRECOND) throw EngineError("cosine theorem's prerequisites");
     if (err == ERR_INVALID_KEY) throw EngineError("Invalid key");
+    if (err == ERR_ITEM_OVERFLOW) throw std::runtime_error("tile list overflow");
     if (err) throw EngineError("device-side error " + std::to_string(err));
 }
 
@@ -836,6 +850,7 @@ void finish_results(amd_ivf* h, size_t n, size_t k, float* D, int64_t* I, uint32
     if (err == ERR_ARCOS_DOMAIN) throw EngineError("arcos's domain definition is [-1, 1]");
     if (err == ERR_COSINE_PRECOND) throw EngineError("cosine theorem's prerequisites");
     if (err == ERR_INVALID_KEY) throw EngineError("Invalid key");
+    if (err == ERR_ITEM_OVERFLOW) throw std::runtime_error("tile list overflow");
     if (err) throw EngineError("device-side error " + std::to_string(err));
     h->stats_host[0] += n;
     h->stats_host[1] += st[0];
@@ -1028,7 +1043,7 @@ void search_fixed_device(amd_ivf* h, const float* d_x, size_t n, size_t k, size_
     base.d_x = d_x;
     base.d_ckeys = d_keys;
     base.coarse_stride = (uint32_t)nprobe;
-    base.fused = h->allow_fused && ix(h)->db_range.fusable_with(qr);
+    base.fused = h->allow_fused && ix(h)->db_range.fusable_with(qr, h->metric);
     base.bytes = byte_queries(h, ix(h), d_x, n, qr);
     ix(h)->last_arith = base.bytes ? 2 : base.fused ? 1 : 0;
     const char* two_s = getenv("AUNCEL_AMD_FIXED_ROUNDS");  // read per call: the tests run both ways in one process
@@ -1072,7 +1087,7 @@ void search_fixed_core(amd_ivf* h, const float* d_x, size_t n, size_t k, size_t 
     r.max_codes = max_codes;
     r.finalize_all = 1;
     r.d_x = d_x;
-    r.fused = h->allow_fused && ix(h)->db_range.fusable_with(qr);
+    r.fused = h->allow_fused && ix(h)->db_range.fusable_with(qr, h->metric);
     r.bytes = byte_queries(h, ix(h), d_x, n, qr);
     ix(h)->last_arith = r.bytes ? 2 : r.fused ? 1 : 0;
     exec_round(h, r);
@@ -1087,7 +1102,7 @@ void search_full(amd_ivf* h, const float* d_x, size_t n, size_t k, size_t nprobe
     h->w_cdis.ensure(n * nprobe * 4);
     h->w_ckeys.ensure(n * nprobe * 8);
     coarse_dev(h, d_x, n, nprobe, coarse_mode, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>(),
-               h->allow_fused && ix(h)->centroid_range.fusable_with(qr));
+               h->allow_fused && ix(h)->centroid_range.fusable_with(qr, h->metric));
     static const bool host_plan = getenv("AUNCEL_AMD_HOST_PLAN") != nullptr;
     if (!host_plan) {
         search_fixed_device(h, d_x, n, k, nprobe, h->w_ckeys.as<int64_t>(), D, I, 0, 0, qr);
@@ -1122,20 +1137,48 @@ TunerDev make_tuner(amd_ivf* h, size_t query_topk, float multipler, float std_m,
     return t;
 }
 
-// multi-round driver with the round planning on the device (ivf_plan.hip): per round the host zeroes two small
-// arrays, launches the planning kernels, reads back nine counters and launches pack + scan + replay
+// Multi-round driver with the round planning on the device (ivf_plan.hip).
+//
+// Chained (the default): the host enqueues plan -> scan -> selection for several rounds back to back without reading
+// anything back.  Every launch of a round takes its size from the counters the planning kernels leave on the device: the
+// scans are resident grids walking a device-side item count, the selection is sized by the number of queries and its
+// surplus waves leave at once.  After a batch of rounds the next round is planned and only then does the host look (one
+// 96-byte read-back): no active query left -> done.  A fixed-nprobe search whose rounds provably fit the buffers needs no
+// look at all.
+// Synchronous (range search, time-bounded search, AUNCEL_AMD_SYNC_ROUNDS=1): one read-back per round; the range search lays
+// out its results and the time-bounded search reads the clock between rounds.
 void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first_round, size_t total_nprobe,
                        const unsigned long long* d_np_abs /* may be null */) {
     amd_ivf* I = ix(h);
     const size_t nlist = h->nlist;
     hipStream_t s = h->stream;
-    static const double grow_env = getenv("AUNCEL_AMD_ROUND_GROW") ? atof(getenv("AUNCEL_AMD_ROUND_GROW")) : 3.5;
-    const size_t seg_cap = (size_t)2 << 20;
+    static const bool sync_env = getenv("AUNCEL_AMD_SYNC_ROUNDS") != nullptr || getenv("AUNCEL_AMD_DEBUG_REPLAY") != nullptr;
+    const bool chained = !(base.range || base.d_budget_ms || sync_env);
+    // over-scan against rounds: the byte-code scan is bound by its one pass over the lists, not by the pairs it computes, so
+    // its rounds grow fast (12 -> 144 -> all); the fp32 scans pay for every distance (12 -> 42 -> 147)
+    static const double grow_env = getenv("AUNCEL_AMD_ROUND_GROW") ? atof(getenv("AUNCEL_AMD_ROUND_GROW")) : 0.0;
+    const double grow = grow_env > 0 ? grow_env : base.bytes ? 12.0 : 3.5;
+    // pairs of a round: the packed query tiles of the fp32 scans (8 queries x dpad floats per group) must fit 4 GiB
+    size_t seg_cap = (size_t)2 << 20;
+    if (!base.bytes) {
+        const size_t groups = ((size_t)4 << 30) / ((size_t)h->dpad * SCAN_RQ * sizeof(float));
+        seg_cap = std::min(seg_cap, std::max<size_t>((size_t)64 << 10, (groups > nlist ? groups - nlist : 0) * SCAN_RQ));
+    }
     size_t maxlist = 0;
     for (size_t l = 0; l < nlist; l++) maxlist = std::max<size_t>(maxlist, I->h_list_off[l + 1] - I->h_list_off[l]);
     const size_t item_cap = (seg_cap / 32 + nlist) * ((maxlist + SCAN_WAVE_VECS - 1) / SCAN_WAVE_VECS) + nlist * 4 + 16;
     // rows are padded to multiples of 64 floats (one mask word covers 64 candidates of one row)
-    const size_t budget = std::max<size_t>(h->dist_budget_floats, I->h_list_off[nlist] + 64 * nlist + 64);
+    // A query's rows of a round are consecutive, one (padded) list length per probe, whether the scan stores every distance
+    // (round 0) or the < 1 % that beat the threshold: after round 0 the buffer is address space more than traffic, and a
+    // round that does not fit is cut (plan_prefix_kernel defers the remaining queries: another pass over the lists).  8 GiB
+    // hold 2500 unfinished queries x 144 probes of the bench workload; small searches take what they can ever need.
+    static const size_t budget_env = getenv("AUNCEL_AMD_DIST_BUDGET_MB") ? (size_t)atol(getenv("AUNCEL_AMD_DIST_BUDGET_MB")) << 18 : 0;
+    const size_t padded_max = (maxlist + 63) & ~(size_t)63;
+    const double all_rows = (double)n * (double)std::min<size_t>(total_nprobe, nlist) * (double)padded_max;
+    size_t budget = budget_env ? budget_env : std::max<size_t>(h->dist_budget_floats, (size_t)2 << 30);
+    if (all_rows < (double)budget) budget = (size_t)all_rows + 64;
+    budget = std::max<size_t>(budget, I->h_list_off[nlist] + 64 * nlist + 64);
+    if (base.bytes && budget > ((size_t)1 << 31)) throw std::runtime_error("distance rows beyond 2^31 floats (byte-code scan offsets are 32-bit)");
     static const bool no_thr = getenv("AUNCEL_AMD_NO_THRESHOLD") != nullptr;
     h->w_pl_pad.ensure(n * 4);
     h->w_mask.ensure((budget / 64 + 2) * 8);
@@ -1160,6 +1203,9 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     h->p_counters.ensure(96);
     h->w_dist.ensure(budget * sizeof(float));
     HIP_CHECK(hipMemsetAsync(h->w_pl_counters.p, 0, 96, s));
+    // groups of 8 pairs never cross a list: at most pairs / 8 + one partial group per list
+    const size_t group_cap = seg_cap / SCAN_RQ + nlist;
+    if (chained && !base.bytes) h->w_qtile.ensure(group_cap * (size_t)h->dpad * SCAN_RQ * sizeof(float));
 
     PlanArgs pa{};
     pa.nq = (uint32_t)n;
@@ -1173,7 +1219,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     pa.tune = base.tuner.enabled;
     pa.d = h->d;
     pa.multipler = base.tuner.multipler;
-    pa.grow = std::max<double>(base.tuner.multipler, grow_env);
+    pa.grow = std::max<double>(base.tuner.multipler, grow);
     pa.id_offset = base.id_offset;
     pa.dist_budget = budget;
     pa.seg_cap = (uint32_t)seg_cap;
@@ -1188,7 +1234,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     pa.row_align = 64;
     pa.qblock = scan_qblock(base.bytes);
     if (base.bytes) {
-        pa.mfma_chunk = MFMA_CHUNK;
+        pa.mfma_chunk = mfma_chunk();
         pa.block_off = I->d_block_off.as<uint64_t>();
     }
     pa.seg_begin = h->w_seg_begin.as<uint32_t>();
@@ -1210,6 +1256,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     pa.counters = h->w_pl_counters.as<uint32_t>();
     pa.bytes = reinterpret_cast<double*>(h->w_pl_counters.as<uint32_t>() + 16);
     pa.acc64 = reinterpret_cast<unsigned long long*>(h->w_pl_counters.as<uint32_t>() + 18);
+    pa.error = h->w_error.as<uint32_t>();
     if (base.d_budget_ms) {
         h->w_limit.ensure(n * 4);
         pa.budget_ms = base.d_budget_ms;
@@ -1223,31 +1270,36 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         }
         HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     }
-    size_t round_len = first_round;
     uint32_t* hc = h->p_counters.as<uint32_t>();
-    // Round 0 starts from empty heaps (every distance is wanted: dense rows); later rounds run in threshold mode.
-    for (size_t round = 0;; round++) {
-        const bool thr_mode = base.range || (round > 0 && !no_thr);
-        const double t0 = now_us();
-        HIP_CHECK(hipMemsetAsync(h->w_pl_lcount.p, 0, nlist * 4, s));
-        HIP_CHECK(hipMemsetAsync(h->w_pl_counters.as<uint32_t>() + 6, 0, 4, s));
-        HIP_CHECK(hipMemsetAsync(h->w_pl_counters.as<uint32_t>() + 10, 0, 4, s));
+    const uint32_t* dcnt = h->w_pl_counters.as<uint32_t>();
+    // grid hints: what each round of the previous search of this shape needed
+    constexpr size_t MAX_HIST = 32;
+    const uint64_t sig = (uint64_t)n * 1000003u ^ (uint64_t)first_round * 10007u ^ (uint64_t)total_nprobe * 101u ^ (base.bytes ? 1u : 0u) ^
+                         (base.tuner.enabled ? 2u : 0u) ^ (base.train.enabled ? 4u : 0u) ^ ((uint64_t)base.k << 40);
+    if (chained) {
+        h->w_pl_hist.ensure(MAX_HIST * 64);
+        h->p_hist.ensure(MAX_HIST * 64);
+        if (h->hint_sig != sig) h->round_hint.clear();
+        h->hint_sig = sig;
+    }
+    auto hint_of = [&](size_t round, int counter) -> uint32_t {
+        return chained && (round + 1) * 16 <= h->round_hint.size() ? h->round_hint[round * 16 + counter] : 0u;
+    };
+    size_t planned_rounds = 0;  // plans launched so far (round r's counters reach history[r] when round r + 1 is planned)
+    auto plan_round = [&](size_t round_len) {
         pa.round_len = (uint32_t)round_len;
-        if (base.d_budget_ms) {  // the clock is read once the previous round has finished
-            HIP_CHECK(stream_sync(s));
-            pa.elapsed_ms = (float)((now_us() - base.t_start_us) * 1e-3);
-        }
+        pa.history = chained && planned_rounds >= 1 && planned_rounds <= MAX_HIST ? h->w_pl_hist.as<uint32_t>() + (planned_rounds - 1) * 16 : nullptr;
         launch_plan(pa, s);
-        HIP_CHECK(hipMemcpyAsync(hc, h->w_pl_counters.p, 96, hipMemcpyDeviceToHost, s));
-        HIP_CHECK(stream_sync(s));
-        const double t1 = now_us();
-        const uint32_t nact = hc[0], npairs = hc[2], ngroups = hc[3];
-        if (nact == 0) break;
-        const size_t n_qg[4] = {hc[4], hc[5], hc[8], hc[9]};
-        const size_t nitems = n_qg[0] + n_qg[1] + n_qg[2] + n_qg[3];
-        if (nitems > item_cap) throw std::runtime_error("tile list overflow");
-        static const bool xcd_off = getenv("AUNCEL_AMD_NO_XCD_CHUNKS") != nullptr;
-        if (npairs && base.bytes) {
+        planned_rounds++;
+    };
+    static const bool xcd_off = getenv("AUNCEL_AMD_NO_XCD_CHUNKS") != nullptr;
+    static const int nstreams = getenv("AUNCEL_AMD_SCAN_STREAMS") ? atoi(getenv("AUNCEL_AMD_SCAN_STREAMS")) : 4;
+
+    // ---- the scan of a planned round.  counts == nullptr: sizes on the device (chained); else the counters read back.
+    auto enqueue_scan = [&](bool thr_mode, const uint32_t* counts, size_t round) {
+        if (counts && counts[CNT_PAIRS] == 0) return;
+        size_t t = h->timer.begin(CAT_SCAN, s);
+        if (base.bytes) {
             // byte codes: one launch of scan_mfma_kernel (no query packing: the A operand is gathered from the query matrix)
             MfmaScanArgs ma{};
             ma.codes_frag = I->d_frag.as<uint8_t>();
@@ -1261,23 +1313,24 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             ma.d = h->d;
             ma.metric = h->metric;
             ma.xcd_chunks = xcd_off ? 0 : 1;
-            ma.nitems = (uint32_t)nitems;
+            ma.nitems = counts ? counts[CNT_QG8] : 0;
+            ma.dev_nitems = counts ? nullptr : dcnt + CNT_QG8;
+            ma.hint_nitems = hint_of(round, CNT_QG8);
             if (thr_mode) {
                 ma.thr = h->w_thr.as<float>();
                 ma.mask = h->w_mask.as<unsigned long long>();
             }
-            size_t t = h->timer.begin(CAT_SCAN, s);
+            // the scan runs on a normal-priority side stream (see make_main_stream)
             HIP_CHECK(hipEventRecord(h->ev_fork, s));
             HIP_CHECK(hipStreamWaitEvent(h->aux[3], h->ev_fork, 0));
             launch_scan_mfma(ma, h->aux[3]);
             HIP_CHECK(hipEventRecord(h->ev_join[3], h->aux[3]));
             HIP_CHECK(hipStreamWaitEvent(s, h->ev_join[3], 0));
-            h->timer.end(t, s);
-        } else if (npairs) {
-            const int row_words = h->dpad;
-            h->w_qtile.ensure((size_t)ngroups * (size_t)row_words * SCAN_RQ * sizeof(float));
-            launch_pack_queries(base.d_x, h->w_pair_query.as<uint32_t>(), h->w_group_p0.as<uint32_t>(),
-                                h->w_group_cnt.as<uint32_t>(), ngroups, row_words, h->w_qtile.as<float>(), s);
+        } else {
+            const size_t ngroups = counts ? counts[CNT_GROUPS] : group_cap;
+            if (counts) h->w_qtile.ensure(ngroups * (size_t)h->dpad * SCAN_RQ * sizeof(float));
+            launch_pack_queries(base.d_x, h->w_pair_query.as<uint32_t>(), h->w_group_p0.as<uint32_t>(), h->w_group_cnt.as<uint32_t>(), ngroups,
+                                h->dpad, h->w_qtile.as<float>(), s, counts ? nullptr : dcnt + CNT_GROUPS, hint_of(round, CNT_GROUPS));
             ScanArgs sa{};
             sa.qtile = h->w_qtile.as<float>();
             sa.codes = I->d_codes.as<float>();
@@ -1290,89 +1343,45 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             sa.metric = h->metric;
             sa.fused = base.fused;
             sa.xcd_chunks = xcd_off ? 0 : 1;  // measured: 3 % off the scan launches of the bench workload
+            sa.dev_counts = counts ? nullptr : dcnt;
+            sa.hint_qg[0] = hint_of(round, CNT_QG1);
+            sa.hint_qg[1] = hint_of(round, CNT_QG2);
+            sa.hint_qg[2] = hint_of(round, CNT_QG4);
+            sa.hint_qg[3] = hint_of(round, CNT_QG8);
             if (thr_mode) {
                 sa.thr = h->w_thr.as<float>();
                 sa.mask = h->w_mask.as<unsigned long long>();
             }
-            size_t t = h->timer.begin(CAT_SCAN, s);
-            static const int nstreams = getenv("AUNCEL_AMD_SCAN_STREAMS") ? atoi(getenv("AUNCEL_AMD_SCAN_STREAMS")) : 4;
-            const bool fork = true;  // every shape on a side stream (see make_main_stream)
-            if (fork) {
-                HIP_CHECK(hipEventRecord(h->ev_fork, s));
-                for (int i = 0; i < 4; i++) HIP_CHECK(hipStreamWaitEvent(h->aux[i], h->ev_fork, 0));
-                if (nstreams == 1) launch_scan(sa, n_qg, h->aux[3], h->aux[3], h->aux[3], h->aux[3]);
-                else if (nstreams == 2) launch_scan(sa, n_qg, h->aux[3], h->aux[0], h->aux[0], h->aux[3]);  // 8,4 | 2,1
-                else launch_scan(sa, n_qg, h->aux[3], h->aux[0], h->aux[1], h->aux[2]);
-                for (int i = 0; i < 4; i++) {
-                    HIP_CHECK(hipEventRecord(h->ev_join[i], h->aux[i]));
-                    HIP_CHECK(hipStreamWaitEvent(s, h->ev_join[i], 0));
-                }
-            } else {
-                launch_scan(sa, n_qg, s);
+            size_t n_qg[4] = {0, 0, 0, 0};
+            if (counts) {
+                n_qg[0] = counts[CNT_QG1];
+                n_qg[1] = counts[CNT_QG2];
+                n_qg[2] = counts[CNT_QG4];
+                n_qg[3] = counts[CNT_QG8];
             }
-            h->timer.end(t, s);
-        }
-        if (base.range) {
-            // ---- range search: count, lay out, fill (the scan left masks of the entries inside the radius)
-            RangeArgs ga{};
-            ga.nq = nact;
-            ga.nlist = (uint32_t)nlist;
-            ga.qsel = h->w_qsel.as<uint32_t>();
-            ga.seg_count = h->w_pl_cnt.as<uint32_t>();
-            ga.seg_begin = h->w_seg_begin.as<uint32_t>();
-            ga.seg_list = h->w_seg_list.as<int32_t>();
-            ga.seg_off = h->w_seg_off.as<uint64_t>();
-            ga.list_off = I->d_list_off.as<uint64_t>();
-            ga.ids = I->d_ids.as<int64_t>();
-            ga.dist = h->w_dist.as<float>();
-            ga.mask = h->w_mask.as<unsigned long long>();
-            h->w_rcount.ensure(n * 4);
-            h->w_roff.ensure(n * 8);
-            ga.counts = h->w_rcount.as<uint32_t>();
-            ga.out_off = h->w_roff.as<unsigned long long>();
-            ga.stage = h->w_stage.as<uint32_t>();
-            ga.done = h->w_done.as<uint32_t>();
-            ga.stats = h->w_stats.as<unsigned long long>();
-            ga.error = h->w_error.as<uint32_t>();
-            size_t t = h->timer.begin(CAT_SELECT, s);
-            launch_range_count(ga, s);
-            std::vector<uint32_t> cnts(n), probes(n);
-            HIP_CHECK(hipMemcpyAsync(cnts.data(), h->w_rcount.p, n * 4, hipMemcpyDeviceToHost, s));
-            HIP_CHECK(hipMemcpyAsync(probes.data(), h->w_pl_cnt.p, n * 4, hipMemcpyDeviceToHost, s));
-            HIP_CHECK(stream_sync(s));
-            check_device_error(h);
-            // the queries of a round are a run of consecutive slots (everything unfinished before the budget cut), so
-            // appending the rounds keeps the results in query order
-            std::vector<unsigned long long> off(n, 0);
-            size_t tot = 0;
-            for (size_t i = 0; i < n; i++)
-                if (probes[i]) {
-                    off[i] = tot;
-                    tot += cnts[i];
-                    h->r_lims[i + 1] = cnts[i];
-                }
-            if (tot) {
-                h->w_rlab.ensure(tot * 8);
-                h->w_rdis.ensure(tot * 4);
-                ga.out_labels = h->w_rlab.as<int64_t>();
-                ga.out_dist = h->w_rdis.as<float>();
-                HIP_CHECK(hipMemcpyAsync(h->w_roff.p, off.data(), n * 8, hipMemcpyHostToDevice, s));
-                launch_range_fill(ga, s);
-                const size_t at = h->r_labels.size();
-                h->r_labels.resize(at + tot);
-                h->r_dist.resize(at + tot);
-                HIP_CHECK(hipMemcpyAsync(h->r_labels.data() + at, h->w_rlab.p, tot * 8, hipMemcpyDeviceToHost, s));
-                HIP_CHECK(hipMemcpyAsync(h->r_dist.data() + at, h->w_rdis.p, tot * 4, hipMemcpyDeviceToHost, s));
+            // every shape on a side stream (see make_main_stream)
+            HIP_CHECK(hipEventRecord(h->ev_fork, s));
+            for (int i = 0; i < 4; i++) HIP_CHECK(hipStreamWaitEvent(h->aux[i], h->ev_fork, 0));
+            if (nstreams == 1) launch_scan(sa, n_qg, h->aux[3], h->aux[3], h->aux[3], h->aux[3]);
+            else if (nstreams == 2) launch_scan(sa, n_qg, h->aux[3], h->aux[0], h->aux[0], h->aux[3]);  // 8,4 | 2,1
+            else launch_scan(sa, n_qg, h->aux[3], h->aux[0], h->aux[1], h->aux[2]);
+            for (int i = 0; i < 4; i++) {
+                HIP_CHECK(hipEventRecord(h->ev_join[i], h->aux[i]));
+                HIP_CHECK(hipStreamWaitEvent(s, h->ev_join[i], 0));
             }
-            h->timer.end(t, s);
-            HIP_CHECK(stream_sync(s));
-            continue;
         }
+        h->timer.end(t, s);
+    };
+
+    // ---- ordered selection of a scanned round.  nact: active queries (sync) or the bound n with the count on the device.
+    auto enqueue_replay = [&](bool thr_mode, uint32_t nact, bool on_device, size_t round) {
         ReplayArgs ra{};
         ra.metric = h->metric;
         ra.k = base.k;
         ra.nlist = (uint32_t)nlist;
         ra.nq = nact;
+        ra.nq_dev = on_device ? dcnt + CNT_ACTIVE : nullptr;
+        ra.nq_hint = on_device && round > 0 ? std::max<uint32_t>(1, nact / 3) : nact;
         ra.qsel = h->w_qsel.as<uint32_t>();
         ra.total_nprobe = (uint32_t)total_nprobe;
         ra.round_probes = 0;
@@ -1423,15 +1432,131 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             fprintf(stderr, "[replay] round %zu: %u queries\n", round, nact);
             print_replay_dbg(h, nact, s);
         }
-        if (dbg_timing())
-            fprintf(stderr, "[round/dev] active %u pairs %u groups %u tiles %zu: plan+readback %.0f us, launches %.0f us\n", nact, npairs, ngroups,
-                    nitems, t1 - t0, now_us() - t1);
-        // every query of this round ends with it and none was deferred: no further planning pass (and no read-back) is needed
-        static const bool no_skip = getenv("AUNCEL_AMD_NO_LAST_PLAN_SKIP") != nullptr;
-        if (!no_skip && !base.train.enabled && hc[10] == 0) break;
-        round_len = base.fixed_two ? total_nprobe : std::min<size_t>(round_len * 2, 64);
+    };
+    auto next_round_len = [&](size_t round_len) { return base.fixed_two ? total_nprobe : std::min<size_t>(round_len * 2, 64); };
+    auto plan_and_look = [&](size_t round_len) {
+        plan_round(round_len);
+        HIP_CHECK(hipMemcpyAsync(hc, h->w_pl_counters.p, 96, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(stream_sync(s));
+    };
+    static const bool no_skip = getenv("AUNCEL_AMD_NO_LAST_PLAN_SKIP") != nullptr;
+    size_t round_len = first_round;
+
+    if (chained) {
+        // a fixed-nprobe search ends with its last planned round when no query can be deferred (rows and pairs fit the buffers)
+        const size_t padded = (maxlist + 63) & ~(size_t)63;
+        const bool fits = (double)n * (double)total_nprobe * (double)padded <= (double)budget && n * total_nprobe <= seg_cap;
+        const bool fixed_complete = !base.tuner.enabled && !base.train.enabled && fits && (base.fixed_two || first_round >= total_nprobe);
+        static const size_t ahead_env = getenv("AUNCEL_AMD_ROUNDS_AHEAD") ? (size_t)atoi(getenv("AUNCEL_AMD_ROUNDS_AHEAD")) : 0;
+        size_t batch = ahead_env ? ahead_env : base.train.enabled ? 4 : base.tuner.enabled ? 2 : (base.fixed_two ? 2 : 1);
+        if (fixed_complete) batch = base.fixed_two && first_round < total_nprobe ? 2 : 1;
+        bool planned = false;  // the round at hand has been planned (and looked at) already
+        for (size_t round = 0;;) {
+            for (size_t b = 0; b < batch; b++, round++) {
+                const bool thr_mode = round > 0 && !no_thr;
+                if (!planned) plan_round(round_len);
+                planned = false;
+                enqueue_scan(thr_mode, nullptr, round);
+                enqueue_replay(thr_mode, (uint32_t)n, true, round);
+                round_len = next_round_len(round_len);
+            }
+            if (fixed_complete) break;
+            plan_and_look(round_len);
+            if (dbg_timing())
+                fprintf(stderr, "[rounds/chained] after round %zu: active %u pairs %u items %u may-continue %u MiB %u\n", round, hc[CNT_ACTIVE],
+                        hc[CNT_PAIRS], hc[CNT_QG1] + hc[CNT_QG2] + hc[CNT_QG4] + hc[CNT_QG8], hc[10], hc[7]);
+            if (hc[CNT_ACTIVE] == 0) break;
+            planned = true;
+            batch = ahead_env ? ahead_env : 2;
+        }
+    } else {
+        // Round 0 starts from empty heaps (every distance is wanted: dense rows); later rounds run in threshold mode.
+        for (size_t round = 0;; round++) {
+            const bool thr_mode = base.range || (round > 0 && !no_thr);
+            const double t0 = now_us();
+            if (base.d_budget_ms) {  // the clock is read once the previous round has finished
+                HIP_CHECK(stream_sync(s));
+                pa.elapsed_ms = (float)((now_us() - base.t_start_us) * 1e-3);
+            }
+            plan_and_look(round_len);
+            const double t1 = now_us();
+            const uint32_t nact = hc[CNT_ACTIVE];
+            if (nact == 0) break;
+            enqueue_scan(thr_mode, hc, round);
+            if (base.range) {
+                // ---- range search: count, lay out, fill (the scan left masks of the entries inside the radius)
+                RangeArgs ga{};
+                ga.nq = nact;
+                ga.nlist = (uint32_t)nlist;
+                ga.qsel = h->w_qsel.as<uint32_t>();
+                ga.seg_count = h->w_pl_cnt.as<uint32_t>();
+                ga.seg_begin = h->w_seg_begin.as<uint32_t>();
+                ga.seg_list = h->w_seg_list.as<int32_t>();
+                ga.seg_off = h->w_seg_off.as<uint64_t>();
+                ga.list_off = I->d_list_off.as<uint64_t>();
+                ga.ids = I->d_ids.as<int64_t>();
+                ga.dist = h->w_dist.as<float>();
+                ga.mask = h->w_mask.as<unsigned long long>();
+                h->w_rcount.ensure(n * 4);
+                h->w_roff.ensure(n * 8);
+                ga.counts = h->w_rcount.as<uint32_t>();
+                ga.out_off = h->w_roff.as<unsigned long long>();
+                ga.stage = h->w_stage.as<uint32_t>();
+                ga.done = h->w_done.as<uint32_t>();
+                ga.stats = h->w_stats.as<unsigned long long>();
+                ga.error = h->w_error.as<uint32_t>();
+                size_t t = h->timer.begin(CAT_SELECT, s);
+                launch_range_count(ga, s);
+                std::vector<uint32_t> cnts(n), probes(n);
+                HIP_CHECK(hipMemcpyAsync(cnts.data(), h->w_rcount.p, n * 4, hipMemcpyDeviceToHost, s));
+                HIP_CHECK(hipMemcpyAsync(probes.data(), h->w_pl_cnt.p, n * 4, hipMemcpyDeviceToHost, s));
+                HIP_CHECK(stream_sync(s));
+                check_device_error(h);
+                // the queries of a round are a run of consecutive slots (everything unfinished before the budget cut), so
+                // appending the rounds keeps the results in query order
+                std::vector<unsigned long long> off(n, 0);
+                size_t tot = 0;
+                for (size_t i = 0; i < n; i++)
+                    if (probes[i]) {
+                        off[i] = tot;
+                        tot += cnts[i];
+                        h->r_lims[i + 1] = cnts[i];
+                    }
+                if (tot) {
+                    h->w_rlab.ensure(tot * 8);
+                    h->w_rdis.ensure(tot * 4);
+                    ga.out_labels = h->w_rlab.as<int64_t>();
+                    ga.out_dist = h->w_rdis.as<float>();
+                    HIP_CHECK(hipMemcpyAsync(h->w_roff.p, off.data(), n * 8, hipMemcpyHostToDevice, s));
+                    launch_range_fill(ga, s);
+                    const size_t at = h->r_labels.size();
+                    h->r_labels.resize(at + tot);
+                    h->r_dist.resize(at + tot);
+                    HIP_CHECK(hipMemcpyAsync(h->r_labels.data() + at, h->w_rlab.p, tot * 8, hipMemcpyDeviceToHost, s));
+                    HIP_CHECK(hipMemcpyAsync(h->r_dist.data() + at, h->w_rdis.p, tot * 4, hipMemcpyDeviceToHost, s));
+                }
+                h->timer.end(t, s);
+                HIP_CHECK(stream_sync(s));
+                continue;
+            }
+            enqueue_replay(thr_mode, nact, false, round);
+            if (dbg_timing())
+                fprintf(stderr, "[round/dev] active %u pairs %u groups %u: plan+readback %.0f us, launches %.0f us\n", nact, hc[CNT_PAIRS],
+                        hc[CNT_GROUPS], t1 - t0, now_us() - t1);
+            // every query of this round ends with it and none was deferred: no further planning pass (and no read-back) is needed
+            if (!no_skip && !base.train.enabled && hc[10] == 0) break;
+            round_len = next_round_len(round_len);
+        }
     }
     if (!base.caller_checks_error) check_device_error(h);
+    if (chained) {  // the bookkeeping counters of the last round (bytes, slots) have not been read yet; nor has the history
+        const size_t nh = std::min(planned_rounds ? planned_rounds - 1 : 0, MAX_HIST);
+        HIP_CHECK(hipMemcpyAsync(hc, h->w_pl_counters.p, 96, hipMemcpyDeviceToHost, s));
+        if (nh) HIP_CHECK(hipMemcpyAsync(h->p_hist.p, h->w_pl_hist.p, nh * 64, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(stream_sync(s));
+        h->round_hint.assign(h->p_hist.as<uint32_t>(), h->p_hist.as<uint32_t>() + nh * 16);
+        h->round_hint.insert(h->round_hint.end(), hc, hc + 16);  // the last planned round
+    }
     h->scan_bytes += *reinterpret_cast<double*>(hc + 16);
     const unsigned long long* acc = reinterpret_cast<const unsigned long long*>(hc + 18);
     h->scan_slots += (double)acc[0];
@@ -1718,7 +1843,7 @@ int amd_ivf_coarse(amd_ivf_t* h, size_t n, const float* x, size_t nprobe, float*
     IntRange qr;
     qr.add(x, n * (size_t)h->d);
     coarse_dev(h, h->w_x.as<float>(), n, nprobe, mode, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>(),
-               h->allow_fused && h->centroid_range.fusable_with(qr));
+               h->allow_fused && h->centroid_range.fusable_with(qr, h->metric));
     HIP_CHECK(hipMemcpyAsync(coarse_dis, h->w_cdis.p, n * nprobe * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipMemcpyAsync(keys, h->w_ckeys.p, n * nprobe * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(stream_sync(h->stream));
@@ -1795,7 +1920,7 @@ static void range_core(amd_ivf* h, const float* d_x, size_t n, float radius, siz
     base.d_x = d_x;
     base.d_ckeys = d_keys;
     base.coarse_stride = (uint32_t)nprobe;
-    base.fused = h->allow_fused && ix(h)->db_range.fusable_with(qr);
+    base.fused = h->allow_fused && ix(h)->db_range.fusable_with(qr, h->metric);
     base.bytes = byte_queries(h, ix(h), d_x, n, qr);
     ix(h)->last_arith = base.bytes ? 2 : base.fused ? 1 : 0;
     run_rounds_device(h, base, n, nprobe, nprobe, nullptr);
@@ -1850,7 +1975,7 @@ int amd_ivf_range_search(amd_ivf_t* h, size_t n, const float* x, float radius, s
     h->w_cdis.ensure(n * nprobe * 4);
     h->w_ckeys.ensure(n * nprobe * 8);
     coarse_dev(h, h->w_x.as<float>(), n, nprobe, coarse_mode, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>(),
-               h->allow_fused && ix(h)->centroid_range.fusable_with(qr));
+               h->allow_fused && ix(h)->centroid_range.fusable_with(qr, h->metric));
     h->scan_bytes = 0;
     h->scan_slots = h->scan_useful = 0;
     range_core(h, h->w_x.as<float>(), n, radius, nprobe, h->w_ckeys.as<int64_t>(), qr, lims);
@@ -1893,7 +2018,7 @@ static void timed_core(amd_ivf* h, const float* d_x, size_t start, size_t n, siz
     h->w_cdis.ensure(n * nprobe * 4);
     h->w_ckeys.ensure(n * nprobe * 8);
     coarse_dev(h, d_x, n, nprobe, coarse_mode, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>(),
-               h->allow_fused && ix(h)->centroid_range.fusable_with(qr));
+               h->allow_fused && ix(h)->centroid_range.fusable_with(qr, h->metric));
     init_state(h, n, k, false);
     RoundSpec base;
     base.k = (int)k;
@@ -1901,7 +2026,7 @@ static void timed_core(amd_ivf* h, const float* d_x, size_t start, size_t n, siz
     base.d_x = d_x;
     base.d_ckeys = h->w_ckeys.as<int64_t>();
     base.coarse_stride = (uint32_t)nprobe;
-    base.fused = h->allow_fused && ix(h)->db_range.fusable_with(qr);
+    base.fused = h->allow_fused && ix(h)->db_range.fusable_with(qr, h->metric);
     base.bytes = byte_queries(h, ix(h), d_x, n, qr);
     ix(h)->last_arith = base.bytes ? 2 : base.fused ? 1 : 0;
     base.d_budget_ms = d_b.as<float>();
@@ -1974,7 +2099,7 @@ int amd_ivf_scan_codes(amd_ivf_t* h, const float* query, size_t list_no, int sto
     {
         IntRange qr;
         qr.add(query, (size_t)h->d);
-        r.fused = h->allow_fused && h->db_range.fusable_with(qr);
+        r.fused = h->allow_fused && h->db_range.fusable_with(qr, h->metric);
     }
     exec_round(h, r);
     check_device_error(h);
@@ -2145,12 +2270,12 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
     L->w_ckeys.ensure(n * nlist * 8);
     // full coarse ranking (Error_sys::search sets nprobe = nlist, profile.cpp:220)
     coarse_dev(L, d_x, n, nlist, coarse_mode, L->w_cdis.as<float>(), L->w_ckeys.as<int64_t>(),
-               ix(L)->allow_fused && ix(L)->centroid_range.fusable_with(qr), coarse_prefix);
+               ix(L)->allow_fused && ix(L)->centroid_range.fusable_with(qr, L->metric), coarse_prefix);
     init_state(L, n, K, true);
     launch_set_online(L->metric, (uint32_t)nlist, (uint32_t)n, L->w_cdis.as<float>(), L->w_ckeys.as<int64_t>(), (uint32_t)nlist,
                       ix(L)->d_interdis.as<float>(), ix(L)->d_arcos.as<float>(), L->w_dtb.as<float>(), L->w_error.as<uint32_t>(), L->stream);
     RoundSpec base;
-    base.fused = ix(L)->allow_fused && ix(L)->db_range.fusable_with(qr);
+    base.fused = ix(L)->allow_fused && ix(L)->db_range.fusable_with(qr, L->metric);
     base.bytes = byte_queries(L, ix(L), d_x, n, qr);
     ix(L)->last_arith = base.bytes ? 2 : base.fused ? 1 : 0;
     base.k = (int)K;
@@ -2347,12 +2472,12 @@ static void train_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n, s
     size_t coarse_prefix = nlist / 8 + 21 + 16;
     if (coarse_prefix >= nlist || getenv("AUNCEL_AMD_FULL_COARSE_SORT")) coarse_prefix = 0;
     coarse_dev(h, d_x, n, nlist, coarse_mode, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>(),
-               h->allow_fused && h->centroid_range.fusable_with(qr), coarse_prefix);
+               h->allow_fused && h->centroid_range.fusable_with(qr, h->metric), coarse_prefix);
     init_state(h, n, K, true);
     launch_set_online(h->metric, (uint32_t)nlist, (uint32_t)n, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>(), (uint32_t)nlist,
                       h->d_interdis.as<float>(), h->d_arcos.as<float>(), h->w_dtb.as<float>(), h->w_error.as<uint32_t>(), h->stream);
     RoundSpec base;
-    base.fused = h->allow_fused && h->db_range.fusable_with(qr);
+    base.fused = h->allow_fused && h->db_range.fusable_with(qr, h->metric);
     base.bytes = byte_queries(h, ix(h), d_x, n, qr);
     ix(h)->last_arith = base.bytes ? 2 : base.fused ? 1 : 0;
     base.k = (int)K;
@@ -2577,7 +2702,7 @@ int amd_ivf_kmeans(int d, size_t n, const float* x_in, size_t k, int metric, int
     for (int it = 0; it < niter; it++) {
         if (amd_ivf_set_centroids(h.get(), centroids)) throw EngineError(g_last_error);
         coarse_dev(h.get(), h->d_resident.as<float>(), nx, 1, coarse_mode, d_dis.as<float>(), d_keys.as<int64_t>(),
-                   h->allow_fused && h->centroid_range.fusable_with(qr));
+                   h->allow_fused && h->centroid_range.fusable_with(qr, h->metric));
         HIP_CHECK(hipMemcpyAsync(dis.data(), d_dis.p, nx * 4, hipMemcpyDeviceToHost, s));
         launch_kmeans_group(d_keys.as<int64_t>(), nx, (uint32_t)k, keys_in.as<uint32_t>(), keys_out.as<uint32_t>(), idx_in.as<uint32_t>(),
                             idx_out.as<uint32_t>(), counts.as<uint32_t>(), temp.p, temp_bytes, s);

@@ -5,7 +5,25 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <stdexcept>
+#include <string>
+
 namespace amdivf {
+
+// A launch the runtime rejects (grid, LDS or register limits) leaves nothing on the stream, and the later synchronisation
+// succeeds: without this check a search would return untouched output buffers as if they were results.
+inline void check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) throw std::runtime_error(std::string("kernel launch failed: ") + what + ": " + hipGetErrorString(e));
+}
+// (the error state is per thread and sticky: an unrelated earlier call, e.g. the elapsed time of an event pair that was
+// never recorded, must not be taken for this launch's)
+#define LAUNCH(...)                     \
+    do {                                \
+        (void)hipGetLastError();        \
+        hipLaunchKernelGGL(__VA_ARGS__); \
+        ::amdivf::check_launch(#__VA_ARGS__); \
+    } while (0)
 
 constexpr int METRIC_IP = 0;
 constexpr int METRIC_L2 = 1;
@@ -48,17 +66,27 @@ struct ScanArgs {
     unsigned long long* mask;
     int xcd_chunks;     // 1: XCD x (workgroup id % 8) takes the x-th eighth of the item list (consecutive items share an L2)
     uint32_t nitems;    // items of the shape being launched (set by launch_scan)
+    // Device-chained rounds: the item counts of the four shapes are only known on the device (PlanArgs::counters); the launch
+    // is then a fixed grid of resident workgroups that walk the items of their shape.  dev_counts = that counter array.
+    const uint32_t* dev_counts;
+    // ... sized by what the same round needed last time (0: no idea, one resident grid): the grid is a hint, never an input to
+    // correctness -- workgroups stride over the true count -- and a right-sized grid lets the dispatcher interleave the
+    // workgroups of several search contexts where resident grids would run one context's launch to its end first.
+    uint32_t hint_qg[4];
 };
 
 // items grouped by qg (1, then 2, 4, 8); n_qg = item count of each group
 // the shapes are independent: s2 / s1 / s4 (optional) let the qg 2 / 1 / 4 launches run beside the qg 8 one
 void launch_scan(const ScanArgs& a, const size_t n_qg[4], hipStream_t s, hipStream_t s2 = nullptr, hipStream_t s1 = nullptr,
                  hipStream_t s4 = nullptr);
+// counters of PlanArgs that the chained launches read
+constexpr int CNT_ACTIVE = 0, CNT_PAIRS = 2, CNT_GROUPS = 3, CNT_QG1 = 4, CNT_QG2 = 5, CNT_QG4 = 8, CNT_QG8 = 9;
+unsigned resident_grid(unsigned workgroups_per_cu);  // CUs of the current device x workgroups_per_cu
 
 // gather + interleave the query rows of every group of (up to) 8 pairs: group g holds pairs
 // [group_p0[g], group_p0[g] + group_cnt[g]); missing slots are zero
 void launch_pack_queries(const float* queries, const uint32_t* pair_query, const uint32_t* group_p0, const uint32_t* group_cnt,
-                         size_t ngroups, int d, float* qtile, hipStream_t s);
+                         size_t ngroups, int d, float* qtile, hipStream_t s, const uint32_t* dev_ngroups = nullptr, uint32_t hint = 0);
 
 // ---------------------------------------------------------------------------- byte-code scan on the i8 matrix cores
 // When lists and queries hold integers 0..255 (and d * max^2 <= 2^24, so that every fp32 partial sum of the reference is an
@@ -72,10 +100,7 @@ void launch_pack_queries(const float* queries, const uint32_t* pair_query, const
 // code_cy: one int32 per stored slot (block * 32 + vector): |ys|^2 (L2) or 128 sum(y) (IP).
 constexpr uint32_t MFMA_BLOCK = 32;        // vectors per block = N of the MFMA
 constexpr uint32_t MFMA_QBLOCK = 32;       // queries per item = M of the MFMA
-#ifndef AUNCEL_MFMA_CHUNK
-#define AUNCEL_MFMA_CHUNK 256
-#endif
-constexpr uint32_t MFMA_CHUNK = AUNCEL_MFMA_CHUNK;  // vectors per work item (a multiple of 64)
+uint32_t mfma_chunk();                     // vectors per work item (a multiple of 64; AUNCEL_AMD_MFMA_CHUNK, default 256)
 inline __host__ __device__ uint32_t mfma_ksteps(int d) { return (uint32_t)(d + 31) / 32; }
 inline __host__ __device__ uint64_t mfma_list_blocks(uint64_t size) { return ((size + 63) / 64) * 2; }
 
@@ -95,6 +120,8 @@ struct MfmaScanArgs {
     int metric;
     int xcd_chunks;
     uint32_t nitems;
+    const uint32_t* dev_nitems;   // chained rounds: the item count lives on the device; the grid is a hint (see ScanArgs)
+    uint32_t hint_nitems;         // items the same round had last time (0: unknown -> a resident grid)
 };
 void launch_scan_mfma(const MfmaScanArgs& a, hipStream_t s);
 // fp32 lists (CSR rows, row stride dpad floats, integers 0..255) -> fragment order + code_cy; block_off[l] = first block of list l
@@ -140,7 +167,9 @@ struct ReplayArgs {
     int metric;
     int k;
     uint32_t nlist;
-    uint32_t nq;               // queries in this launch
+    uint32_t nq;               // queries in this launch (chained rounds: an upper bound, the count is *nq_dev)
+    const uint32_t* nq_dev;
+    uint32_t nq_hint;          // expected number of queries (picks the kernel variant); 0: nq
     const uint32_t* qsel;      // [nq] query slot of each launch position (null: identity)
     uint32_t total_nprobe;     // length of the reference's probe loop (0: not bounded here)
     uint32_t round_probes;     // row stride of seg_* arrays
@@ -269,7 +298,9 @@ struct PlanArgs {
     uint32_t* group_cnt;
     ScanItem* items;
     uint32_t item_cap;
+    uint32_t* error;                 // device error word (ERR_ITEM_OVERFLOW: the round needs more tiles than item_cap)
     unsigned long long* acc64;       // [0] += (query, vector) slots computed, [1] += pairs wanted (tile bookkeeping)
+    uint32_t* history;               // null or 16 uint32: receives the counters as the previous round's planning left them
     uint32_t* counters;              // [0] active queries [1] segments [2] pairs [3] groups [4] tiles qg1 [5] tiles qg2
                                      // [6] scratch (compaction cursor, zeroed by host) [7] MiB of distances [8] tiles qg4 [9] tiles qg8
                                      // [10] queries that may still be unfinished after this round (zeroed by host)
@@ -281,6 +312,7 @@ void launch_plan(const PlanArgs& a, hipStream_t s);
 constexpr uint32_t ERR_ARCOS_DOMAIN = 1;
 constexpr uint32_t ERR_COSINE_PRECOND = 2;
 constexpr uint32_t ERR_INVALID_KEY = 3;
+constexpr uint32_t ERR_ITEM_OVERFLOW = 4;
 
 // ---------------------------------------------------------------------------- coarse helpers
 // full ascending/descending sort of each row of `dis` (nlist entries) keeping the first nprobe

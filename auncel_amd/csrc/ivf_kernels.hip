@@ -24,13 +24,6 @@
 
 namespace amdivf {
 
-// A launch the runtime rejects (grid, LDS or register limits) leaves nothing on the stream, and the later synchronisation
-// succeeds: without this check a search would return untouched output buffers as if they were results.
-static void check_launch(const char* what) {
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) throw std::runtime_error(std::string("kernel launch failed (") + what + "): " + hipGetErrorString(e));
-}
-
 // =============================================================================================
 // K-scan: distance tiles
 // =============================================================================================
@@ -50,29 +43,24 @@ constexpr int LDS_ROW = SCAN_DC + 4;                 // dwords per staged row (p
 //   0  the reference's SSE order: four running sums over elements 4i+l, separate multiply and add
 //   1  the same order with fma, legal when operands are small integers (see IntRange in the engine)
 // (uint8-valued data takes scan_mfma_kernel below instead: exact integer contraction on the i8 matrix cores)
+template <int QG> struct ScanShape {
+    static constexpr int NT = QG == 8 ? 512 : 256;
+    static constexpr int vg = QG >= 4 ? 1 : 4 / QG;
+    static constexpr int tile_vecs = vg * SCAN_WAVE_VECS;
+    static constexpr int lds_floats = tile_vecs * LDS_ROW;
+};
+
+// one tile; every wave of the workgroup takes part in all of its barriers
 template <int METRIC, int QG, int ARITH>
-__global__ __launch_bounds__(QG == 8 ? 512 : 256) void scan_tiles_kernel(ScanArgs a) {
+__device__ __forceinline__ void scan_tile_one(const ScanArgs& a, const ScanItem it, float (*lds)[ScanShape<QG>::lds_floats]) {
     constexpr bool FUSED = ARITH == 1;
     constexpr int qg = QG;
-    constexpr int NT = QG == 8 ? 512 : 256;
-    constexpr int vg = QG >= 4 ? 1 : 4 / QG;
-    constexpr int tile_vecs = vg * SCAN_WAVE_VECS;
-    // two staging buffers: chunk c+1 is fetched into registers while chunk c is being consumed, and written
-    // to the other buffer, so a workgroup needs one barrier per chunk and hides its own fetch latency
-    __shared__ float lds[2][tile_vecs * LDS_ROW];
+    constexpr int NT = ScanShape<QG>::NT;
+    constexpr int vg = ScanShape<QG>::vg;
+    constexpr int tile_vecs = ScanShape<QG>::tile_vecs;
     constexpr int SLOTS = SCAN_DC / 4;                     // 16-B slots per staged row
     constexpr int NLD = tile_vecs * SLOTS / NT;            // fetches per thread per chunk
     static_assert(tile_vecs * SLOTS % NT == 0, "tile must split evenly over the workgroup");
-
-    // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Consecutive items are the tiles of one list for
-    // one block of queries: with the plain order they would be spread over all XCDs and each L2 would fetch the block's packed
-    // query operands for itself.  XCD x takes the x-th eighth of the item list instead, so a block's tiles share one L2.
-    uint32_t item_no = blockIdx.x;
-    if (a.xcd_chunks) {  // grid = 8 * per workgroups, per = ceil(items / 8)
-        item_no = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-        if (item_no >= a.nitems) return;
-    }
-    const ScanItem it = a.items[item_no];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -238,38 +226,107 @@ __global__ __launch_bounds__(QG == 8 ? 512 : 256) void scan_tiles_kernel(ScanArg
     }
 }
 
-__global__ __launch_bounds__(256) void pack_queries_kernel(const float* queries, const uint32_t* pair_query, const uint32_t* group_p0,
-                                                           const uint32_t* group_cnt, int d, float* qtile) {
-    const uint32_t g = blockIdx.x;
-    const uint32_t p0 = group_p0[g], cnt = group_cnt[g];
-    float4* out = reinterpret_cast<float4*>(qtile + (size_t)g * d * SCAN_RQ);
-    const int nstep = d >> 2;
-    for (int idx = threadIdx.x; idx < nstep * SCAN_RQ; idx += 256) {
-        const int step = idx / SCAN_RQ, r = idx % SCAN_RQ;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((uint32_t)r < cnt) v = *reinterpret_cast<const float4*>(queries + (size_t)pair_query[p0 + r] * d + step * 4);
-        out[idx] = v;
+// Which items a workgroup walks.  Host-sized launches: one item per workgroup (the grid is the item count).  Chained rounds
+// (a.dev_counts): a resident grid, every workgroup strides over the items of its shape, whose count the planning kernels
+// left on the device.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2); consecutive items are the
+// tiles of one list for one block of queries, so with xcd_chunks XCD x takes the x-th eighth of the item list and a block's
+// tiles (and its packed query operands) stay in one L2.
+struct ItemWalk {
+    uint32_t cur, end, step;
+    __device__ ItemWalk(uint32_t n, int xcd_chunks) {
+        if (xcd_chunks) {
+            const uint32_t per = (n + 7) >> 3, x = blockIdx.x & 7;
+            cur = x * per + (blockIdx.x >> 3);
+            end = (x + 1) * per < n ? (x + 1) * per : n;
+            step = gridDim.x >> 3;
+        } else {
+            cur = blockIdx.x;
+            end = n;
+            step = gridDim.x;
+        }
+    }
+};
+
+template <int METRIC, int QG, int ARITH>
+__global__ __launch_bounds__(QG == 8 ? 512 : 256) void scan_tiles_kernel(ScanArgs a) {
+    // two staging buffers: chunk c+1 is fetched into registers while chunk c is being consumed, and written
+    // to the other buffer, so a workgroup needs one barrier per chunk and hides its own fetch latency
+    __shared__ float lds[2][ScanShape<QG>::lds_floats];
+    uint32_t n = a.nitems;
+    const ScanItem* items = a.items;
+    if (a.dev_counts) {  // shapes are laid out qg 1 | 2 | 4 | 8 in the item array
+        const uint32_t n1 = a.dev_counts[CNT_QG1], n2 = a.dev_counts[CNT_QG2], n4 = a.dev_counts[CNT_QG4], n8 = a.dev_counts[CNT_QG8];
+        n = QG == 1 ? n1 : QG == 2 ? n2 : QG == 4 ? n4 : n8;
+        items += QG == 1 ? 0 : QG == 2 ? n1 : QG == 4 ? n1 + n2 : n1 + n2 + n4;
+    }
+    ItemWalk w(n, a.xcd_chunks);
+    for (uint32_t i = w.cur; i < w.end; i += w.step) {
+        scan_tile_one<METRIC, QG, ARITH>(a, items[i], lds);
+        __syncthreads();  // the staging buffers are reused by the next tile
     }
 }
 
+__global__ __launch_bounds__(256) void pack_queries_kernel(const float* queries, const uint32_t* pair_query, const uint32_t* group_p0,
+                                                           const uint32_t* group_cnt, int d, float* qtile, uint32_t ngroups,
+                                                           const uint32_t* dev_ngroups) {
+    if (dev_ngroups) ngroups = *dev_ngroups;
+    for (uint32_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const uint32_t p0 = group_p0[g], cnt = group_cnt[g];
+        float4* out = reinterpret_cast<float4*>(qtile + (size_t)g * d * SCAN_RQ);
+        const int nstep = d >> 2;
+        for (int idx = threadIdx.x; idx < nstep * SCAN_RQ; idx += 256) {
+            const int step = idx / SCAN_RQ, r = idx % SCAN_RQ;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((uint32_t)r < cnt) v = *reinterpret_cast<const float4*>(queries + (size_t)pair_query[p0 + r] * d + step * 4);
+            out[idx] = v;
+        }
+    }
+}
+
+// dev_ngroups: the group count is on the device (chained rounds); ngroups is then only the capacity of the buffers
 void launch_pack_queries(const float* queries, const uint32_t* pair_query, const uint32_t* group_p0, const uint32_t* group_cnt,
-                         size_t ngroups, int d, float* qtile, hipStream_t s) {
-    if (ngroups) hipLaunchKernelGGL(pack_queries_kernel, dim3((unsigned)ngroups), dim3(256), 0, s, queries, pair_query, group_p0, group_cnt, d, qtile);
+                         size_t ngroups, int d, float* qtile, hipStream_t s, const uint32_t* dev_ngroups, uint32_t hint) {
+    if (!ngroups && !dev_ngroups) return;
+    const unsigned grid = dev_ngroups ? (hint ? hint + hint / 8 + 8 : resident_grid(16)) : (unsigned)ngroups;
+    LAUNCH(pack_queries_kernel, dim3(grid), dim3(256), 0, s, queries, pair_query, group_p0, group_cnt, d, qtile, (uint32_t)ngroups, dev_ngroups);
+}
+
+unsigned resident_grid(unsigned per_cu) {
+    static const unsigned cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return (unsigned)n;
+    }();
+    return ((cus * per_cu + 7) / 8) * 8;  // a multiple of the 8 XCDs
+}
+
+// workgroups of `kern` that fit a CU at once (resident grids: more would queue behind the others and start their share late)
+template <class K> static unsigned blocks_per_cu(K kern, int threads, size_t dyn_lds = 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, dyn_lds) != hipSuccess || nb <= 0) nb = 1;
+    return (unsigned)nb;
 }
 
 template <int QG> static void launch_scan_qg(ScanArgs a, size_t first, size_t n, hipStream_t s) {
-    if (n == 0) return;
-    a.items += first;
+    if (n == 0 && !a.dev_counts) return;
+    if (!a.dev_counts) a.items += first;
     a.nitems = (uint32_t)n;
-    const dim3 grid((unsigned)(a.xcd_chunks ? ((n + 7) / 8) * 8 : n)), block(QG == 8 ? 512 : 256);
+    // chained rounds: n is only a bound; a resident grid walks the device-side count
+    const int threads = QG == 8 ? 512 : 256;
+    const uint32_t hint = a.hint_qg[scan_qg_class(QG)];
+    auto go = [&](auto kern) {
+        static const unsigned per_cu = blocks_per_cu(kern, threads);
+        const unsigned hinted = ((unsigned)((size_t)hint + hint / 8 + 7) / 8) * 8 + 8;  // last time's count + 12 %
+        const dim3 grid((unsigned)(a.dev_counts ? (hint ? hinted : resident_grid(per_cu)) : a.xcd_chunks ? ((n + 7) / 8) * 8 : n)), block(threads);
+        LAUNCH(kern, grid, block, 0, s, a);
+    };
     if (a.metric == METRIC_L2) {
-        if (a.fused) hipLaunchKernelGGL((scan_tiles_kernel<METRIC_L2, QG, 1>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((scan_tiles_kernel<METRIC_L2, QG, 0>), grid, block, 0, s, a);
+        if (a.fused) go(scan_tiles_kernel<METRIC_L2, QG, 1>);
+        else go(scan_tiles_kernel<METRIC_L2, QG, 0>);
     } else {
-        if (a.fused) hipLaunchKernelGGL((scan_tiles_kernel<METRIC_IP, QG, 1>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((scan_tiles_kernel<METRIC_IP, QG, 0>), grid, block, 0, s, a);
+        if (a.fused) go(scan_tiles_kernel<METRIC_IP, QG, 1>);
+        else go(scan_tiles_kernel<METRIC_IP, QG, 0>);
     }
-    check_launch("scan_tiles_kernel");
 }
 
 // items must be grouped by qg: n_qg[0] items with qg 1, then n_qg[1] with qg 2, n_qg[2] with qg 4, n_qg[3] with qg 8
@@ -296,6 +353,14 @@ void launch_scan(const ScanArgs& a, const size_t n_qg[4], hipStream_t s, hipStre
 // [16 ks h, 16 ks (h + 1))", which makes a lane's ks pieces of a query row contiguous.
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+// B operand loads.  A chunk is read by one item per block of 32 queries probing its list; those items are neighbouring waves
+// of one workgroup, so with the default cache policy the second reader finds the chunk in L2 (a streaming hint sends every
+// reader to HBM: 3.3 GB instead of 1.3 GB per round on the bench workload).  AUNCEL_MFMA_NT=1 restores the hint.
+#if defined(AUNCEL_MFMA_NT) && AUNCEL_MFMA_NT
+#define MFMA_BLOAD(p) __builtin_nontemporal_load(p)
+#else
+#define MFMA_BLOAD(p) (*(p))
+#endif
 
 // reg[lane LANE] = val (val wave-uniform, LANE a compile-time constant: an inline operand, so the one SGPR slot is val's)
 template <int LANE> __device__ __forceinline__ void writelane_c(int& reg, uint32_t val) {
@@ -307,20 +372,27 @@ template <int... I, class F> __device__ __forceinline__ void static_for(std::int
 
 // NKS = K-steps (d <= 32 NKS) with the query operand resident in registers; 0 = any d, query pieces re-read per block pair
 template <int METRIC, bool MASKED, int NKS>
-__global__ __launch_bounds__(256) void scan_mfma_kernel(MfmaScanArgs a) {
+// (four waves per SIMD: with the register budget stated the compiler accumulates in VGPRs and needs no AGPR copies)
+#ifndef AUNCEL_MFMA_WAVES
+#define AUNCEL_MFMA_WAVES 4
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AUNCEL_MFMA_WAVES, 8))) void scan_mfma_kernel(MfmaScanArgs a) {
     __shared__ int s_cx[4][32];
     __shared__ int s_u[4][32];
-    __shared__ unsigned long long s_row[4][32];
+    __shared__ uint32_t s_row[4][32];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = lane & 31, h = lane >> 5;
-    uint32_t wg = blockIdx.x;
-    if (a.xcd_chunks) wg = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // XCD x takes the x-th eighth of the items
-    const uint32_t item_no = wg * 4 + wave;
-    if (item_no >= a.nitems) return;  // (no workgroup barrier below)
-    const ScanItem it = a.items[item_no];
     const int ks = NKS ? NKS : (int)mfma_ksteps(a.d);
     const size_t qstride = (size_t)ks * 32;
+    // items of this wave: workgroup w of the walk takes items 4 w .. 4 w + 3 (host-sized launch: one such group per workgroup;
+    // chained rounds: resident workgroups stride over the device-side count).  No workgroup barrier anywhere below.
+    const uint32_t nitems = a.dev_nitems ? *a.dev_nitems : a.nitems;
+    ItemWalk w((nitems + 3) >> 2, a.xcd_chunks);
+    for (uint32_t wi = w.cur; wi < w.end; wi += w.step) {
+    const uint32_t item_no = wi * 4 + wave;
+    if (item_no >= nitems) break;
+    const ScanItem it = a.items[item_no];
 
     // ---- per-query operands, lane m (both halves) for query m of the item
     const bool qok = (uint32_t)m < it.npair;
@@ -346,10 +418,12 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(MfmaScanArgs a) {
             }
         }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the previous item's reads of this wave's LDS rows are done
+    __builtin_amdgcn_wave_barrier();
     if (h == 0) {
         s_cx[wave][m] = cx;
         s_u[wave][m] = u;
-        s_row[wave][m] = row;
+        s_row[wave][m] = (uint32_t)row;
     }
     const int8_t* qp = a.queries8 + (size_t)qrow * qstride + (size_t)h * (size_t)(16 * ks);
     v4i af[NKS ? NKS : 1];
@@ -359,111 +433,120 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(MfmaScanArgs a) {
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // thresholds / cx in accumulator layout: register 4 g + i of lane half h belongs to query 8 g + 4 h + i
+    // thresholds / cx / row offsets in accumulator layout: register 4 g + i of lane half h belongs to query 8 g + 4 h + i.
+    // Threshold mode keeps thresholds and rows (cx is read from LDS for the few values it stores); the dense mode cx and rows.
     int ur[16], cxr[16];
+    uint32_t rowr[16];  // in floats: the distance buffer is at most 2^31 floats
 #pragma unroll
     for (int g = 0; g < 4; g++) {
         const v4i tu = *reinterpret_cast<const v4i*>(&s_u[wave][8 * g + 4 * h]);
         const v4i tc = *reinterpret_cast<const v4i*>(&s_cx[wave][8 * g + 4 * h]);
+        const v4i tr = *reinterpret_cast<const v4i*>(&s_row[wave][8 * g + 4 * h]);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             ur[4 * g + i] = tu[i];
             cxr[4 * g + i] = tc[i];
+            rowr[4 * g + i] = (uint32_t)tr[i];
         }
     }
 
     const size_t block_bytes = (size_t)ks * 1024;
-    const uint32_t npairs = (it.nvec + 63) >> 6;
+    const uint32_t nblk = ((it.nvec + 63) >> 6) * 2;  // lists are stored in pairs of blocks: a 64-candidate mask word is two of ours
     uint32_t* mask32 = reinterpret_cast<uint32_t*>(a.mask);
-    // Software pipeline (resident-operand form): the B pieces of pair p + 1 are requested right after the MFMAs of pair p
-    // have consumed their registers, and land while the epilogue of pair p runs; the scheduling barriers keep the compiler
+    // Software pipeline (resident-operand form): the B pieces of block i + 1 are requested right after the MFMAs of block i
+    // have consumed their registers, and land while the epilogue of block i runs; the scheduling barriers keep the compiler
     // from sinking the loads back to their uses (it otherwise recycles three registers and keeps three loads in flight).
-    v4i b[2][NKS ? NKS : 1];
-    int cyn[2] = {0, 0};
-    auto fetch_pair = [&](uint32_t p) {
-        const uint64_t blk = it.vec_base + 2 * p;
+    v4i b[NKS ? NKS : 1];
+    int cyn = 0;
+    auto fetch_block = [&](uint32_t i) {
+        const uint64_t blk = it.vec_base + i;
         const uint8_t* bp = a.codes_frag + blk * block_bytes + (size_t)lane * 16;
 #pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int s = 0; s < (NKS ? NKS : 1); s++)
-                b[j][s] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(bp + j * block_bytes + (size_t)s * 1024));
-        cyn[0] = a.code_cy[blk * 32 + m];
-        cyn[1] = a.code_cy[blk * 32 + 32 + m];
+        for (int s = 0; s < (NKS ? NKS : 1); s++) b[s] = MFMA_BLOAD(reinterpret_cast<const v4i*>(bp + (size_t)s * 1024));
+        cyn = a.code_cy[blk * 32 + m];
     };
-    if (NKS) fetch_pair(0);
-    for (uint32_t p = 0; p < npairs; p++) {
-        v16i acc[2];
+    if (NKS) fetch_block(0);
+    for (uint32_t i = 0; i < nblk; i++) {
+        v16i acc;
 #pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int i = 0; i < 16; i++) acc[j][i] = 0;
-        int cy[2];
+        for (int r = 0; r < 16; r++) acc[r] = 0;
+        int cy;
         if (NKS) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = 0; s < NKS; s++) {
-                acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[s], b[0][s], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[s], b[1][s], acc[1], 0, 0, 0);
-            }
-            cy[0] = cyn[0];
-            cy[1] = cyn[1];
+            for (int s = 0; s < NKS; s++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[s], b[s], acc, 0, 0, 0);
+            cy = cyn;
             __builtin_amdgcn_sched_barrier(0);
-            if (p + 1 < npairs) fetch_pair(p + 1);
+            if (i + 1 < nblk) fetch_block(i + 1);
             __builtin_amdgcn_sched_barrier(0);
         } else {
-            const uint64_t blk = it.vec_base + 2 * p;
+            const uint64_t blk = it.vec_base + i;
             const uint8_t* bp = a.codes_frag + blk * block_bytes + (size_t)lane * 16;
-            cy[0] = a.code_cy[blk * 32 + m];
-            cy[1] = a.code_cy[blk * 32 + 32 + m];
+            cy = a.code_cy[blk * 32 + m];
             for (int s = 0; s < ks; s++) {
                 const v4i aq = qok ? *reinterpret_cast<const v4i*>(qp + 16 * s) : v4i{0, 0, 0, 0};
-                const v4i b0 = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(bp + (size_t)s * 1024));
-                const v4i b1 = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(bp + block_bytes + (size_t)s * 1024));
-                acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq, b0, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq, b1, acc[1], 0, 0, 0);
+                const v4i b0 = MFMA_BLOAD(reinterpret_cast<const v4i*>(bp + (size_t)s * 1024));
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(aq, b0, acc, 0, 0, 0);
             }
         }
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const uint32_t lv = (2 * p + j) * 32 + m;           // position of this lane's vector in the chunk
-            const bool vok = lv < it.nvec;
-            const unsigned long long vmask = __ballot(vok);
-            int word = 0;  // threshold mode: lane q (< 32) collects the 32-candidate mask word of query q
-            static_for(std::make_integer_sequence<int, 16>{}, [&](auto R) {
-                constexpr int reg = decltype(R)::value;
-                constexpr int q0 = (reg & 3) + 8 * (reg >> 2);  // query of lane half 0; half 1: q0 + 4
-                const int t = METRIC == METRIC_L2 ? 2 * acc[j][reg] - cy[j] : acc[j][reg] + cy[j];
-                if (MASKED) {
-                    const bool keep = t > ur[reg];
-                    const unsigned long long bal = __ballot(keep) & vmask;
-                    writelane_c<q0>(word, (uint32_t)bal);
-                    writelane_c<q0 + 4>(word, (uint32_t)(bal >> 32));
-                    if (bal) {  // rare after round 0: the query's cx and row come from LDS only then
-                        const unsigned long long rr = s_row[wave][q0 + 4 * h];
-                        const int cq = s_cx[wave][q0 + 4 * h];
-                        if (keep && vok) a.dist[rr + lv] = (float)(METRIC == METRIC_L2 ? cq - t : cq + t);
-                    }
-                } else {
-                    const unsigned long long rr = s_row[wave][q0 + 4 * h];
-                    const int res = METRIC == METRIC_L2 ? cxr[reg] - t : cxr[reg] + t;
-                    if (vok && (uint32_t)(q0 + 4 * h) < it.npair) a.dist[rr + lv] = (float)res;
+        const uint32_t lv = i * 32 + m;           // position of this lane's vector in the chunk
+        const bool vok = lv < it.nvec;
+        const unsigned long long vmask = __ballot(vok);
+        int word = 0;  // threshold mode: lane q (< 32) collects the 32-candidate mask word of query q
+        static_for(std::make_integer_sequence<int, 16>{}, [&](auto R) {
+            constexpr int reg = decltype(R)::value;
+            constexpr int q0 = (reg & 3) + 8 * (reg >> 2);  // query of lane half 0; half 1: q0 + 4
+            const int t = METRIC == METRIC_L2 ? 2 * acc[reg] - cy : acc[reg] + cy;
+            if (MASKED) {
+                const bool keep = t > ur[reg];
+                const unsigned long long bal = __ballot(keep) & vmask;
+                writelane_c<q0>(word, (uint32_t)bal);
+                writelane_c<q0 + 4>(word, (uint32_t)(bal >> 32));
+                if (bal && keep && vok) {  // rare after round 0: the query's cx comes from LDS only then
+                    const int cq = s_cx[wave][q0 + 4 * h];
+                    uint32_t off = rowr[reg] + lv;
+                    asm volatile("" : "+v"(off));  // 64-bit addresses are formed here, not hoisted as 16 register pairs
+                    a.dist[off] = (float)(METRIC == METRIC_L2 ? cq - t : cq + t);
                 }
-            });
-            // rows start on multiples of 64 floats, chunks on multiples of 64 vectors: word index = (row + position) / 32.
-            // The odd block of a 64-candidate chunk past the list's end gets its (zero) word too.
-            if (MASKED && lane < 32 && qok) mask32[(row + (2 * p + j) * 32) >> 5] = (uint32_t)word;
-        }
+            } else {
+                const int res = METRIC == METRIC_L2 ? cxr[reg] - t : cxr[reg] + t;
+                uint32_t off = rowr[reg] + lv;
+                asm volatile("" : "+v"(off));
+                if (vok && (uint32_t)(q0 + 4 * h) < it.npair) a.dist[off] = (float)res;
+            }
+        });
+        // rows start on multiples of 64 floats, chunks on multiples of 64 vectors: word index = (row + position) / 32.
+        // The odd block of a 64-candidate chunk past the list's end gets its (zero) word too.
+        if (MASKED && lane < 32 && qok) mask32[(row + i * 32) >> 5] = (uint32_t)word;
     }
+    }  // items
+}
+
+uint32_t mfma_chunk() {
+    static const uint32_t v = [] {
+        const char* e = getenv("AUNCEL_AMD_MFMA_CHUNK");
+        const long x = e ? atol(e) : 0;
+        return x >= 64 ? (uint32_t)((x + 63) / 64 * 64) : 256u;
+    }();
+    return v;
 }
 
 void launch_scan_mfma(const MfmaScanArgs& a, hipStream_t s) {
-    if (a.nitems == 0) return;
+    if (a.nitems == 0 && !a.dev_nitems) return;
     const unsigned nwg = (a.nitems + 3) / 4;
-    const dim3 grid(a.xcd_chunks ? ((nwg + 7) / 8) * 8 : nwg), block(256);
+    static const unsigned per_cu_env = getenv("AUNCEL_AMD_MFMA_WG_PER_CU") ? (unsigned)atoi(getenv("AUNCEL_AMD_MFMA_WG_PER_CU")) : 0;
     const bool masked = a.thr != nullptr;
     const int ks = (int)mfma_ksteps(a.d);
-    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, 0, s, a); };
+    static const bool no_hint = getenv("AUNCEL_AMD_RESIDENT_GRIDS") != nullptr;
+    auto go = [&](auto kern) {
+        static const unsigned per_cu = blocks_per_cu(kern, 256);
+        const size_t hwg = ((size_t)a.hint_nitems + a.hint_nitems / 8 + 3) / 4;  // last time's count + 12 %, four items per workgroup
+        const unsigned hinted = (unsigned)((hwg + 7) / 8) * 8 + 8;
+        const dim3 grid(a.dev_nitems ? (a.hint_nitems && !no_hint ? hinted : resident_grid(per_cu_env ? per_cu_env : per_cu))
+                                     : a.xcd_chunks ? ((nwg + 7) / 8) * 8 : nwg),
+                        block(256);
+        LAUNCH(kern, grid, block, 0, s, a);
+    };
     auto pick_ks = [&](auto metric, auto msk) {
         constexpr int M = decltype(metric)::value;
         constexpr bool K = decltype(msk)::value;
@@ -482,7 +565,6 @@ void launch_scan_mfma(const MfmaScanArgs& a, hipStream_t s) {
         if (masked) pick_ks(std::integral_constant<int, METRIC_IP>{}, std::true_type{});
         else pick_ks(std::integral_constant<int, METRIC_IP>{}, std::false_type{});
     }
-    check_launch("scan_mfma_kernel");
 }
 
 // fp32 lists -> fragment order (one wave per 32-vector block; the block's list by bisection over block_off)
@@ -531,8 +613,7 @@ __global__ __launch_bounds__(64) void frag_from_f32_kernel(const float* codes, c
 void launch_frag_from_f32(const float* codes, const uint64_t* list_off, const uint64_t* block_off, uint32_t nlist, uint64_t nblocks, int d,
                           int dpad, int metric, uint8_t* out, int32_t* cy, hipStream_t s) {
     if (nblocks == 0) return;
-    hipLaunchKernelGGL(frag_from_f32_kernel, dim3((unsigned)nblocks), dim3(64), 0, s, codes, list_off, block_off, nlist, d, dpad, metric, out, cy);
-    check_launch("frag_from_f32_kernel");
+    LAUNCH(frag_from_f32_kernel, dim3((unsigned)nblocks), dim3(64), 0, s, codes, list_off, block_off, nlist, d, dpad, metric, out, cy);
 }
 
 // fp32 query rows -> signed byte rows (stride 32 ks, zero padded) + cx; one wave per row
@@ -566,8 +647,7 @@ __global__ __launch_bounds__(256) void sbytes_from_f32_kernel(const float* x, si
 
 void launch_sbytes_from_f32(const float* x, size_t n, int d, int dpad, int metric, int8_t* out, int32_t* cx, hipStream_t s) {
     if (n == 0) return;
-    hipLaunchKernelGGL(sbytes_from_f32_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, x, n, d, dpad, metric, out, cx);
-    check_launch("sbytes_from_f32_kernel");
+    LAUNCH(sbytes_from_f32_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, x, n, d, dpad, metric, out, cx);
 }
 
 // =============================================================================================
@@ -915,7 +995,7 @@ __global__ __launch_bounds__(256) void set_online_kernel(int metric, uint32_t nl
 
 void launch_set_online(int metric, uint32_t nlist, uint32_t nq, const float* coarse_dis, const int64_t* coarse_keys,
                        uint32_t coarse_stride, const float* interdis, const float* arcos, float* dtb, uint32_t* error, hipStream_t s) {
-    if (nq) hipLaunchKernelGGL(set_online_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, metric, nlist, nq, coarse_dis, coarse_keys,
+    if (nq) LAUNCH(set_online_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, metric, nlist, nq, coarse_dis, coarse_keys,
                                coarse_stride, interdis, arcos, dtb, error);
 }
 
@@ -1085,7 +1165,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
         __syncthreads();
     }
     const uint32_t li = blockIdx.x * 4 + wave;   // position in this launch
-    if (li >= a.nq) return;
+    if (li >= (a.nq_dev ? *a.nq_dev : a.nq)) return;
     const uint32_t qi = a.qsel ? a.qsel[li] : li;  // query slot (state / output row)
     if (a.done[qi]) return;
 
@@ -1551,20 +1631,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
 }
 
 void launch_replay(const ReplayArgs& a, hipStream_t s) {
-    if (a.nq == 0) return;
+    if (a.nq == 0) return;  // (chained rounds: nq is the bound the grid is sized by)
     const bool tune = a.tuner.enabled != 0, train = a.train.enabled != 0, geo = tune || train;
     const size_t shmem = (geo ? 2000 : 0) + 4 * replay_wave_bytes(a.k, a.nlist, geo, tune, train, a.trace_cap);
     const dim3 grid((a.nq + 3) / 4), block(256);
     static const bool no_rh = getenv("AUNCEL_AMD_LDS_HEAP") != nullptr;
     const bool rh = a.k <= 127 && !no_rh;
+    // the heap (LDS form) and its sorted view take 16 k bytes per query, four queries per workgroup, of the CU's 160 KiB
+    if (shmem > 160 * 1024)
+        throw std::runtime_error("k = " + std::to_string(a.k) + " is beyond the selection kernel's LDS heap (" + std::to_string(shmem) +
+                                 " bytes of 163840 per workgroup)");
     auto go = [&](auto kern) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        hipLaunchKernelGGL(kern, grid, block, shmem, s, a);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) throw std::runtime_error(std::string("selection kernel: cannot reserve LDS: ") + hipGetErrorString(e));
+        LAUNCH(kern, grid, block, shmem, s, a);
     };
     // few queries: longer trips (more loads in flight per wave) at the price of fewer resident waves
     const char* nld_s = getenv("AUNCEL_AMD_REPLAY_NLD");  // read per launch: the tests run both variants in one process
     const int nld_env = nld_s ? atoi(nld_s) : 0;
-    const bool wide = nld_env ? nld_env >= 32 : a.nq <= 3072;
+    const bool wide = nld_env ? nld_env >= 32 : (a.nq_hint ? a.nq_hint : a.nq) <= 3072;
     auto pick = [&](auto is_max) {
         constexpr bool M = decltype(is_max)::value;
         if (!rh) return wide ? go(replay_kernel<M, false, 32, 0>) : go(replay_kernel<M, false, 16, 0>);
@@ -1644,10 +1729,10 @@ __global__ __launch_bounds__(256) void range_collect_kernel(RangeArgs a) {
 }
 
 void launch_range_count(const RangeArgs& a, hipStream_t s) {
-    if (a.nq) hipLaunchKernelGGL(range_collect_kernel<false>, dim3((a.nq + 3) / 4), dim3(256), 0, s, a);
+    if (a.nq) LAUNCH(range_collect_kernel<false>, dim3((a.nq + 3) / 4), dim3(256), 0, s, a);
 }
 void launch_range_fill(const RangeArgs& a, hipStream_t s) {
-    if (a.nq) hipLaunchKernelGGL(range_collect_kernel<true>, dim3((a.nq + 3) / 4), dim3(256), 0, s, a);
+    if (a.nq) LAUNCH(range_collect_kernel<true>, dim3((a.nq + 3) / 4), dim3(256), 0, s, a);
 }
 
 // =============================================================================================
@@ -1718,15 +1803,15 @@ __global__ __launch_bounds__(256) void coarse_gemm_kernel(const float* X, const 
 }
 
 void launch_row_norms(const float* x, size_t n, int d, float* out, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(row_norms_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, d, out);
+    if (n) LAUNCH(row_norms_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, d, out);
 }
 
 void launch_coarse_gemm(int metric, const float* X, const float* Y, const float* xn, const float* yn, int nq, int ny, int d, float* out,
                         hipStream_t s) {
     if (nq == 0 || ny == 0) return;
     const dim3 grid((ny + 63) / 64, (nq + 63) / 64);
-    if (metric == METRIC_L2) hipLaunchKernelGGL(coarse_gemm_kernel<METRIC_L2>, grid, dim3(256), 0, s, X, Y, xn, yn, nq, ny, d, out);
-    else hipLaunchKernelGGL(coarse_gemm_kernel<METRIC_IP>, grid, dim3(256), 0, s, X, Y, xn, yn, nq, ny, d, out);
+    if (metric == METRIC_L2) LAUNCH(coarse_gemm_kernel<METRIC_L2>, grid, dim3(256), 0, s, X, Y, xn, yn, nq, ny, d, out);
+    else LAUNCH(coarse_gemm_kernel<METRIC_IP>, grid, dim3(256), 0, s, X, Y, xn, yn, nq, ny, d, out);
 }
 
 // =============================================================================================
@@ -1888,8 +1973,8 @@ void launch_sort_rows(const float* dis, uint32_t nq, uint32_t nlist, uint32_t np
     if (nq == 0) return;
     if (prefix && prefix < nprobe && prefix <= 2048 && prefix <= nlist && nlist <= 4096) {
         const uint32_t S = prefix <= 1024 ? 1024u : 2048u;
-        if (metric == METRIC_L2) hipLaunchKernelGGL(sort_prefix_kernel<true>, dim3(nq), dim3(256), 0, s, dis, nlist, nprobe, prefix, S, out_dis, out_keys);
-        else hipLaunchKernelGGL(sort_prefix_kernel<false>, dim3(nq), dim3(256), 0, s, dis, nlist, nprobe, prefix, S, out_dis, out_keys);
+        if (metric == METRIC_L2) LAUNCH(sort_prefix_kernel<true>, dim3(nq), dim3(256), 0, s, dis, nlist, nprobe, prefix, S, out_dis, out_keys);
+        else LAUNCH(sort_prefix_kernel<false>, dim3(nq), dim3(256), 0, s, dis, nlist, nprobe, prefix, S, out_dis, out_keys);
         return;
     }
     uint32_t npow2 = 2;
@@ -1897,10 +1982,10 @@ void launch_sort_rows(const float* dis, uint32_t nq, uint32_t nlist, uint32_t np
     const size_t shmem = (size_t)npow2 * 8;
     if (metric == METRIC_L2) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sort_rows_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        hipLaunchKernelGGL(sort_rows_kernel<true>, dim3(nq), dim3(256), shmem, s, dis, nlist, npow2, nprobe, out_dis, out_keys);
+        LAUNCH(sort_rows_kernel<true>, dim3(nq), dim3(256), shmem, s, dis, nlist, npow2, nprobe, out_dis, out_keys);
     } else {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sort_rows_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        hipLaunchKernelGGL(sort_rows_kernel<false>, dim3(nq), dim3(256), shmem, s, dis, nlist, npow2, nprobe, out_dis, out_keys);
+        LAUNCH(sort_rows_kernel<false>, dim3(nq), dim3(256), shmem, s, dis, nlist, npow2, nprobe, out_dis, out_keys);
     }
 }
 
@@ -1914,7 +1999,7 @@ __global__ void pack_upper_kernel(const float* full, uint32_t nlist, float* out)
 }
 
 void launch_pack_upper(const float* full, uint32_t nlist, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(pack_upper_kernel, dim3((nlist + 255) / 256, nlist), dim3(256), 0, s, full, nlist, out);
+    LAUNCH(pack_upper_kernel, dim3((nlist + 255) / 256, nlist), dim3(256), 0, s, full, nlist, out);
 }
 
 }  // namespace amdivf
@@ -1952,13 +2037,13 @@ __global__ __launch_bounds__(256) void init_state_kernel(InitStateArgs a) {
 void launch_init_state(const InitStateArgs& a, hipStream_t s) {
     const size_t work = std::max<size_t>(a.n * a.k, 1);
     const unsigned grid = (unsigned)std::min<size_t>((work + 255) / 256, 4096);
-    hipLaunchKernelGGL(init_state_kernel, dim3(grid), dim3(256), 0, s, a);
+    LAUNCH(init_state_kernel, dim3(grid), dim3(256), 0, s, a);
 }
 
 void launch_fill_f32(float* p, size_t n, float v, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, v);
+    if (n) LAUNCH(fill_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, v);
 }
 void launch_fill_i64(int64_t* p, size_t n, int64_t v, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(fill_i64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, v);
+    if (n) LAUNCH(fill_i64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, v);
 }
 }  // namespace amdivf

@@ -40,7 +40,7 @@ size_t kmeans_sort_temp_bytes(size_t n) {
 void launch_kmeans_group(const int64_t* assign, size_t n, uint32_t k, uint32_t* keys_in, uint32_t* keys_out, uint32_t* idx_in,
                          uint32_t* idx_out, uint32_t* counts, void* temp, size_t temp_bytes, hipStream_t s) {
     (void)hipMemsetAsync(counts, 0, (size_t)k * 4, s);
-    hipLaunchKernelGGL(kmeans_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, assign, n, keys_in, idx_in, counts);
+    LAUNCH(kmeans_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, assign, n, keys_in, idx_in, counts);
     int bits = 1;
     while ((1ull << bits) < k) bits++;
     (void)hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, idx_in, idx_out, (int)n, 0, bits, s);
@@ -48,7 +48,7 @@ void launch_kmeans_group(const int64_t* assign, size_t n, uint32_t k, uint32_t* 
 
 void launch_kmeans_sums(const float* x, size_t stride, int d, const uint32_t* idx_sorted, const uint32_t* seg_off, uint32_t k, float* centroids,
                         hipStream_t s) {
-    hipLaunchKernelGGL(kmeans_sums_kernel, dim3(k, (unsigned)((d + 63) / 64)), dim3(64), 0, s, x, stride, d, idx_sorted, seg_off, centroids);
+    LAUNCH(kmeans_sums_kernel, dim3(k, (unsigned)((d + 63) / 64)), dim3(64), 0, s, x, stride, d, idx_sorted, seg_off, centroids);
 }
 
 }  // namespace amdivf

@@ -12,6 +12,8 @@ namespace amdivf {
 // ---- 1. how many probes does each query run this round, and how many distances is that (one wave per query:
 //         the probes of a query are spread over the lanes)
 __global__ __launch_bounds__(256) void plan_counts_kernel(PlanArgs a) {
+    // the per-list pair histogram of the round starts from zero (plan_segments_kernel, next on the stream, fills it)
+    for (uint32_t l = blockIdx.x * 256 + threadIdx.x; l < a.nlist; l += gridDim.x * 256) a.lcount[l] = 0;
     const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
     if (i >= a.nq) return;
@@ -272,6 +274,7 @@ __global__ __launch_bounds__(1024) void plan_lists_kernel(PlanArgs a) {
         for (int k = 0; k < 6; k++) ex[k] += v[k];
     }
     if (t == 0) {
+        if (tot[2] + tot[3] + tot[4] + tot[5] > a.item_cap) atomicMax(a.error, ERR_ITEM_OVERFLOW);
         a.counters[2] = tot[0];  // pairs
         a.counters[3] = tot[1];  // query groups
         a.counters[4] = tot[2];  // tiles of shape 1
@@ -364,15 +367,24 @@ __global__ __launch_bounds__(256) void plan_items_kernel(PlanArgs a) {
     atomicAdd(&a.acc64[1], useful);
 }
 
+// counters a round accumulates into with atomics
+__global__ void plan_reset_kernel(uint32_t* counters, uint32_t* history) {
+    if (history)
+        for (int i = 0; i < 16; i++) history[i] = counters[i];
+    counters[6] = 0;
+    counters[10] = 0;
+}
+
 void launch_plan(const PlanArgs& a, hipStream_t s) {
     if (a.nq == 0) return;
+    LAUNCH(plan_reset_kernel, dim3(1), dim3(1), 0, s, a.counters, a.history);
     const unsigned gq = (a.nq + 3) / 4 /* one wave per query */, gl = (a.nlist + 255) / 256;
-    hipLaunchKernelGGL(plan_counts_kernel, dim3(gq), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(plan_prefix_kernel, dim3(1), dim3(1024), 0, s, a);
-    hipLaunchKernelGGL(plan_segments_kernel, dim3(gq), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(plan_lists_kernel, dim3(1), dim3(1024), 0, s, a);
-    hipLaunchKernelGGL(plan_scatter_kernel, dim3(gq), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(plan_items_kernel, dim3(gl), dim3(256), 0, s, a);
+    LAUNCH(plan_counts_kernel, dim3(gq), dim3(256), 0, s, a);
+    LAUNCH(plan_prefix_kernel, dim3(1), dim3(1024), 0, s, a);
+    LAUNCH(plan_segments_kernel, dim3(gq), dim3(256), 0, s, a);
+    LAUNCH(plan_lists_kernel, dim3(1), dim3(1024), 0, s, a);
+    LAUNCH(plan_scatter_kernel, dim3(gq), dim3(256), 0, s, a);
+    LAUNCH(plan_items_kernel, dim3(gl), dim3(256), 0, s, a);
 }
 
 }  // namespace amdivf

@@ -31,13 +31,18 @@ def make_case(seed):
     nb = int(rs.choice([50, 300, 2000, 9000]))
     nq = int(rs.choice([1, 3, 19, 64, 130]))
     metric = int(rs.choice([0, 1]))
-    kind = rs.choice(["bytes", "smallint", "float", "dups"])
+    kind = rs.choice(["bytes", "smallint", "float", "dups", "wideint"])
     if kind == "bytes":
         xb = rs.randint(0, 256, size=(nb, d)).astype(np.float32)
         xq = rs.randint(0, 256, size=(nq, d)).astype(np.float32)
     elif kind == "smallint":
         xb = rs.randint(-20, 21, size=(nb, d)).astype(np.float32)
         xq = rs.randint(-20, 21, size=(nq, d)).astype(np.float32)
+    elif kind == "wideint":
+        # signed integers whose differences pass 4096: (x - y)^2 is no longer exact in fp32, so the fused scan
+        # (fma(t, t, acc)) would round differently from the reference's mul + add -- it must not be chosen here
+        xb = rs.randint(-4000, 4001, size=(nb, d)).astype(np.float32)
+        xq = rs.randint(-4000, 4001, size=(nq, d)).astype(np.float32)
     elif kind == "dups":
         base = rs.randint(0, 5, size=(max(nb // 20, 2), d)).astype(np.float32)
         xb = base[rs.randint(0, len(base), size=nb)]
@@ -92,3 +97,17 @@ def test_search_and_range_against_oracle(capi, oracle, monkeypatch, seed):
     assert np.array_equal(lims, elims) and np.array_equal(lab, elab) and np.array_equal(bits(dis), bits(edis))
     st = h.stats()
     assert [st["nlist"], st["ndis"]] == list(est)
+
+
+def test_oversized_k_fails_loudly(capi):
+    """k beyond the selection kernel's LDS heap must come back as an error, not as untouched output buffers"""
+    rs = np.random.RandomState(3)
+    xb = rs.randn(4000, 16).astype(np.float32)
+    h = capi.Handle(16, 4, 1, 0)
+    h.set_centroids(xb[:4].copy())
+    h.set_lists_from_assign(xb, rs.randint(0, 4, size=4000))
+    keys = np.tile(np.arange(4, dtype=np.int64), (2, 1))
+    with pytest.raises(RuntimeError, match="LDS heap"):
+        h.search_preassigned(xb[:2], 3000, keys)
+    D, I = h.search_preassigned(xb[:2], 2000, keys)  # the largest sizes still run
+    assert (I[:, 0] == np.arange(2)).all()
