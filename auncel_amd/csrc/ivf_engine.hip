@@ -227,6 +227,7 @@ struct amd_ivf {
     PinnedBuf p_items, p_pair_query, p_pair_out, p_seg_off, p_seg_list, p_seg_count, p_qsel, p_seg_begin;
     DevBuf w_seg_begin;
     // chained rounds: the planning counters of every round of the last search (grid hints for the next one of the same shape)
+    DevBuf w_cval, w_cpos, w_ccnt, w_cprobes, w_href_tmp;  // two-kernel selection (launch_select_lanes)
     DevBuf w_pl_hist;
     PinnedBuf p_hist;
     std::vector<uint32_t> round_hint;  // [round][16]
@@ -394,7 +395,7 @@ void init_state(amd_ivf* h, size_t n, size_t k, bool tune_or_train) {
     h->w_stoped.ensure(n * 4);
     h->w_D.ensure(n * k * sizeof(float));
     h->w_I.ensure(n * k * sizeof(int64_t));
-    h->w_stats.ensure(3 * 8);
+    h->w_stats.ensure(4 * 8);
     h->w_error.ensure(4);
     h->w_thr.ensure(n * sizeof(float));
     InitStateArgs ia{};
@@ -1203,6 +1204,16 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     h->p_counters.ensure(96);
     h->w_dist.ensure(budget * sizeof(float));
     HIP_CHECK(hipMemsetAsync(h->w_pl_counters.p, 0, 96, s));
+    // two-kernel selection: per query a candidate list of capq entries (a round's first probe always fits: capq >= any list)
+    const size_t capq = std::max<size_t>(4096, ((maxlist + 63) & ~(size_t)63) + 64);
+    const bool lanes_ok = capq * n <= ((size_t)1 << 29) && !base.range;
+    if (lanes_ok) {
+        h->w_cval.ensure(n * capq * 4);
+        h->w_cpos.ensure(n * capq * 4);
+        h->w_ccnt.ensure(seg_cap * 4);
+        h->w_cprobes.ensure(n * 4);
+        h->w_href_tmp.ensure(n * (size_t)base.k * 8);
+    }
     // groups of 8 pairs never cross a list: at most pairs / 8 + one partial group per list
     const size_t group_cap = seg_cap / SCAN_RQ + nlist;
     if (chained && !base.bytes) h->w_qtile.ensure(group_cap * (size_t)h->dpad * SCAN_RQ * sizeof(float));
@@ -1373,6 +1384,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         h->timer.end(t, s);
     };
 
+    bool lanes_used = false;
     // ---- ordered selection of a scanned round.  nact: active queries (sync) or the bound n with the count on the device.
     auto enqueue_replay = [&](bool thr_mode, uint32_t nact, bool on_device, size_t round) {
         ReplayArgs ra{};
@@ -1417,6 +1429,14 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         ra.tuner = base.tuner;
         ra.train = base.train;
         ra.limit = base.d_budget_ms ? h->w_limit.as<uint32_t>() : nullptr;
+        if (lanes_ok) {
+            ra.cval = h->w_cval.as<float>();
+            ra.cpos = h->w_cpos.as<uint32_t>();
+            ra.ccnt = h->w_ccnt.as<uint32_t>();
+            ra.cprobes = h->w_cprobes.as<uint32_t>();
+            ra.capq = (uint32_t)capq;
+            ra.href_tmp = h->w_href_tmp.as<int64_t>();
+        }
         static const bool dbg_replay_dev = getenv("AUNCEL_AMD_DEBUG_REPLAY") != nullptr;
         if (dbg_replay_dev) {
             h->w_misc.ensure((size_t)nact * 64);
@@ -1425,7 +1445,12 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         }
         {
             size_t t = h->timer.begin(CAT_SELECT, s);
-            launch_replay(ra, s);
+            if (select_lanes_supported(ra)) {
+                launch_select_lanes(ra, s);
+                lanes_used = true;
+            } else {
+                launch_replay(ra, s);
+            }
             h->timer.end(t, s);
         }
         if (dbg_replay_dev) {
@@ -1446,7 +1471,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         // a fixed-nprobe search ends with its last planned round when no query can be deferred (rows and pairs fit the buffers)
         const size_t padded = (maxlist + 63) & ~(size_t)63;
         const bool fits = (double)n * (double)total_nprobe * (double)padded <= (double)budget && n * total_nprobe <= seg_cap;
-        const bool fixed_complete = !base.tuner.enabled && !base.train.enabled && fits && (base.fixed_two || first_round >= total_nprobe);
+        bool fixed_complete = !base.tuner.enabled && !base.train.enabled && fits && (base.fixed_two || first_round >= total_nprobe);
         static const size_t ahead_env = getenv("AUNCEL_AMD_ROUNDS_AHEAD") ? (size_t)atoi(getenv("AUNCEL_AMD_ROUNDS_AHEAD")) : 0;
         size_t batch = ahead_env ? ahead_env : base.train.enabled ? 4 : base.tuner.enabled ? 2 : (base.fixed_two ? 2 : 1);
         if (fixed_complete) batch = base.fixed_two && first_round < total_nprobe ? 2 : 1;
@@ -1460,7 +1485,15 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
                 enqueue_replay(thr_mode, (uint32_t)n, true, round);
                 round_len = next_round_len(round_len);
             }
-            if (fixed_complete) break;
+            if (fixed_complete && !lanes_used) break;
+            if (fixed_complete) {
+                // ... unless the selection had to cut a query's round short (compact list full): those queries need more rounds
+                unsigned long long cut = 0;
+                HIP_CHECK(hipMemcpyAsync(&cut, h->w_stats.as<unsigned long long>() + 3, 8, hipMemcpyDeviceToHost, s));
+                HIP_CHECK(stream_sync(s));
+                if (cut == 0) break;
+                fixed_complete = false;
+            }
             plan_and_look(round_len);
             if (dbg_timing())
                 fprintf(stderr, "[rounds/chained] after round %zu: active %u pairs %u items %u may-continue %u MiB %u\n", round, hc[CNT_ACTIVE],

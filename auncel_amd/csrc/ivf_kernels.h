@@ -205,16 +205,27 @@ struct ReplayArgs {
     // outputs
     float* D;                  // [nq][k]
     int64_t* I;
-    unsigned long long* stats; // {nlist, ndis, nheap}
+    unsigned long long* stats; // {nlist, ndis, nheap, queries whose round was cut short by the compact list's capacity}
     uint32_t* error;           // != 0: the reference would have thrown (code)
     int raw_heap_out;          // scanner API: leave the heap un-reordered in D/I
     unsigned long long* dbg;   // optional [nq][8]: wave cycles, heap updates, candidates, stages evaluated, cycles in the
                                // candidate stream, cycles in the stop rule, masked chunks fetched, probes consumed
     TunerDev tuner;
     TrainDev train;
+    // Two-kernel selection (launch_select_lanes): compact_kernel turns a round's distance rows into one short, ordered
+    // candidate list per query; replay_lanes_kernel replays the reference's heap over those lists, one query per lane.
+    float* cval;               // [slot][capq] candidate values, stream order
+    uint32_t* cpos;            // [slot][capq] position of each candidate in its list
+    uint32_t* ccnt;            // candidates per (query, probe), indexed like seg_list
+    uint32_t* cprobes;         // [slot] probes of this round whose candidates are in the list (the rest are re-planned)
+    uint32_t capq;             // entries per query (>= the longest list, so a round's first probe always fits)
+    int64_t* href_tmp;         // [slot][k] ids by heap slot while a round runs
 };
 
 void launch_replay(const ReplayArgs& a, hipStream_t s);
+// the same selection as launch_replay (same state arrays in, same out) by compact_kernel + replay_lanes_kernel
+bool select_lanes_supported(const ReplayArgs& a);
+void launch_select_lanes(const ReplayArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------------------- range search
 // IndexIVF::range_search_preassigned: the scan runs in threshold mode with the radius as every query's threshold,
@@ -347,7 +358,7 @@ struct InitStateArgs {
     uint32_t* done;
     float* pre_val;
     uint32_t* stoped;
-    unsigned long long* stats;  // 3 counters
+    unsigned long long* stats;  // 4 counters
     uint32_t* error;
 };
 void launch_init_state(const InitStateArgs& a, hipStream_t s);

@@ -1662,6 +1662,634 @@ void launch_replay(const ReplayArgs& a, hipStream_t s) {
 }
 
 // =============================================================================================
+// Selection in two kernels: compact_kernel (K1) + replay_lanes_kernel (K2)
+// =============================================================================================
+// replay_kernel spends one wave per query and ~140 scalar + vector instructions per heap update on a serial walk; a round 0
+// of the bench workload is ~520 updates per query and the CU's issue ports are the bound.  Here the two halves of that
+// work are separated:
+//   K1, one wave per query, reads the round's distance rows once and keeps, in stream order, only the candidates that can
+//      still enter the heap: those better than a threshold T that is always >= the heap top the reference has at that
+//      point.  T starts as the heap top the round begins with and is refreshed every so often (after 128, 256, 512 ...
+//      candidates) to the k-th best of a pool of values seen so far -- any k values seen bound the top from above, the
+//      best k seen give it exactly.  A dense round 0 of 29 000 candidates leaves ~900, a threshold-mode round ~100.
+//   K2, one query per LANE, replays the reference's heap_pop / heap_push (Heap.h:88-142) over those short lists with
+//      the heap in LDS ([node][lane]: conflict-free), re-testing each candidate against the current top, and evaluates
+//      the stop rule after every probe.  64 queries advance per instruction; a launch is ~80 waves that occupy a
+//      fraction of the chip and overlap with other contexts' scans.
+// Same state arrays in, same state and results out as replay_kernel: the two can take turns between rounds.
+constexpr int POOL_CAP = 1024;             // K1: values per query between two threshold refreshes
+constexpr int LANES_MAXK = 255;            // K2: heap slots are bytes
+constexpr int LANES_BEST = 10;             // K2: best values kept sorted per query (query_topk <= this in tune mode)
+constexpr bool LANES_DEFAULT = false;      // AUNCEL_AMD_LANES=1 / 0 overrides
+
+template <bool IsMax> __device__ __forceinline__ uint32_t okey(float x) {  // smaller key <=> better candidate
+    const uint32_t kx = fkey(x);
+    return IsMax ? kx : ~kx;
+}
+template <bool IsMax> __device__ __forceinline__ float okey_inv(uint32_t key) { return fkey_inv(IsMax ? key : ~key); }
+
+template <bool IsMax>
+__global__ __launch_bounds__(256) void compact_kernel(ReplayArgs a) {
+    __shared__ float s_pool[4][POOL_CAP];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t li = blockIdx.x * 4 + wave;
+    if (li >= (a.nq_dev ? *a.nq_dev : a.nq)) return;
+    const uint32_t qi = a.qsel ? a.qsel[li] : li;
+    if (a.done[qi]) return;
+    const int k = a.k;
+    const uint32_t nlist = a.nlist;
+    const uint32_t cnt = a.seg_count[qi];
+    const size_t seg0 = a.seg_begin[qi];
+    float* pool = s_pool[wave];
+    const size_t base = (size_t)qi * a.capq;
+    const bool masked = a.mask != nullptr;
+    float T = a.heap_val[(size_t)qi * k];  // the root: worst value kept
+    uint32_t npool = 0;
+    if (!masked) {
+        for (int i = lane; i < k; i += 64) pool[i] = a.heap_val[(size_t)qi * k + i];
+        npool = (uint32_t)k;
+    }
+    wave_sync();
+    const unsigned long long lt_mask = (1ull << lane) - 1;
+
+    // T <- (about) the k-th best of the pool; the pool keeps what is at least that good.  Bisection on the order keys for the
+    // smallest key X with #(key <= X) >= k, left early once the count is within k / 8 of k: any X with at least k pool values
+    // at or below it is a valid bound.  Always leaves npool <= POOL_CAP - 64.
+    auto refresh = [&]() {
+        constexpr int R = POOL_CAP / 64;
+        uint32_t key[R];
+        wave_sync();  // the pool as the other lanes left it
+#pragma unroll
+        for (int r = 0; r < R; r++) key[r] = (uint32_t)(r * 64 + lane) < npool ? okey<IsMax>(pool[r * 64 + lane]) : 0xffffffffu;
+        auto count_le = [&](uint32_t x) {
+            uint32_t c = 0;
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                if ((uint32_t)(r * 64) < npool) c += __builtin_popcountll(__ballot(key[r] <= x && (uint32_t)(r * 64 + lane) < npool));
+            return c;
+        };
+        uint32_t lo = 0, hi = okey<IsMax>(T);
+        const uint32_t want = (uint32_t)k, slack = (uint32_t)k / 8;
+        uint32_t chi = count_le(hi);
+        if (chi >= want) {  // (always: T is a bound already; kept as a guard)
+            while (lo < hi) {
+                const uint32_t mid = lo + (hi - lo) / 2;
+                const uint32_t c = count_le(mid);
+                if (c >= want) {
+                    hi = mid;
+                    chi = c;
+                    if (c <= want + slack) break;
+                } else {
+                    lo = mid + 1;
+                }
+            }
+            T = okey_inv<IsMax>(hi);
+        }
+        // keep the values at or below the bound (at least k of them); if equal values still overfill the pool, any k of them do
+        wave_sync();
+        uint32_t out = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if ((uint32_t)(r * 64) >= npool) break;
+            const bool keep = key[r] <= hi && (uint32_t)(r * 64 + lane) < npool;
+            const unsigned long long m = __ballot(keep);
+            const uint32_t room = (uint32_t)(POOL_CAP - 128) > out ? (uint32_t)(POOL_CAP - 128) - out : 0u;
+            const uint32_t rank = __builtin_popcountll(m & lt_mask);
+            if (keep && rank < room) pool[out + rank] = okey_inv<IsMax>(key[r]);
+            const uint32_t c = __builtin_popcountll(m);
+            out += c < room ? c : room;
+        }
+        npool = out;
+        wave_sync();
+    };
+
+    uint32_t cursor = 0, since = 0, next_refresh = 128, probes_done = cnt;
+    for (uint32_t p = 0; p < cnt; p++) {
+        const int key = a.seg_list[seg0 + p];
+        uint32_t n = 0;
+        if (key >= 0 && (uint32_t)key < nlist) n = (uint32_t)(a.list_off[key + 1] - a.list_off[key]);
+        const unsigned long long roff = a.seg_off[seg0 + p];
+        const uint32_t c0 = cursor;
+        bool overflow = false;
+        if (n && masked) {
+            const unsigned long long* mrow = a.mask + (roff >> 6);
+            const uint32_t nchunk = (n + 63) >> 6;
+            for (uint32_t w0 = 0; w0 < nchunk && !overflow; w0 += 64) {
+                unsigned long long word = w0 + lane < nchunk ? mrow[w0 + lane] : 0ull;
+                const uint32_t pc = (uint32_t)__builtin_popcountll(word);
+                if (!__ballot(pc != 0)) continue;
+                uint32_t incl = pc;
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
+                    if (lane >= off) incl += o;
+                }
+                const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+                if (cursor + total > a.capq) {
+                    overflow = true;
+                    break;
+                }
+                size_t idx = base + cursor + incl - pc;
+                while (word) {
+                    const int b = __builtin_ctzll(word);
+                    word &= word - 1;
+                    const uint32_t pos = (w0 + lane) * 64 + b;
+                    a.cval[idx] = a.dist[roff + pos];
+                    a.cpos[idx] = pos;
+                    idx++;
+                }
+                cursor += total;
+            }
+        } else if (n) {
+            const float* row = a.dist + roff;
+            for (uint32_t j0 = 0; j0 < n && !overflow; j0 += 256) {
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t j = j0 + u * 64 + lane;
+                    v[u] = j < n ? __builtin_nontemporal_load(row + j) : hneutral<IsMax>();
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (j0 + u * 64 >= n) break;
+                    if (npool + 64 > (uint32_t)POOL_CAP) {
+                        refresh();
+                        since = 0;
+                    }
+                    const bool pass = hcmp<IsMax>(T, v[u]);
+                    const unsigned long long bal = __ballot(pass);
+                    if (bal) {
+                        const uint32_t c = (uint32_t)__builtin_popcountll(bal);
+                        if (cursor + c > a.capq) {
+                            overflow = true;
+                            break;
+                        }
+                        const uint32_t r = (uint32_t)__builtin_popcountll(bal & lt_mask);
+                        if (pass) {
+                            a.cval[base + cursor + r] = v[u];
+                            a.cpos[base + cursor + r] = j0 + u * 64 + lane;
+                            pool[npool + r] = v[u];
+                        }
+                        cursor += c;
+                        npool += c;
+                    }
+                    since += 64;
+                    if (since >= next_refresh) {
+                        wave_sync();
+                        refresh();
+                        since = 0;
+                        next_refresh = next_refresh < 4096 ? next_refresh * 2 : 4096;
+                    }
+                }
+            }
+        }
+        if (overflow) {  // never at p == 0 (capq >= list length): the rest of the round is left to the next one
+            cursor = c0;
+            probes_done = p;
+            break;
+        }
+        if (lane == 0) a.ccnt[seg0 + p] = cursor - c0;
+    }
+    if (lane == 0) a.cprobes[qi] = probes_done;
+}
+
+// Trace::search on a trace held as x | y | std (z = y + std_m * std formed with the reference's expression)
+__device__ inline float trace_search_xyz(const float* x, const float* y, const float* sd, float sc, uint32_t n, float kv) {
+    if (kv <= x[0]) return y[0] + sc * sd[0];
+    if (kv >= x[n - 1]) {
+        const float ampli = kv / x[n - 1];
+        return (y[n - 1] + sc * sd[n - 1]) * ampli;
+    }
+    unsigned long long high = n - 1, low = 0, middle = 0;
+    while (low <= high) {
+        middle = (low + high) / 2;
+        if (x[middle] < kv) low = middle + 1;
+        else high = middle - 1;
+    }
+    if (x[low] > kv) low--;
+    return y[low] + sc * sd[low];
+}
+
+__host__ __device__ inline size_t lanes_lds_bytes(int k, bool tune, uint32_t trace_cap) {
+    size_t b = (size_t)k * 64 * 4 + (size_t)k * 64;       // heap values | heap slots (bytes)
+    b = (b + 15) & ~(size_t)15;
+    b += (size_t)LANES_BEST * 64 * 4;                     // best values, sorted, per lane
+    if (tune) b += 512 * 4 + 16 * 64 * 4 + (size_t)trace_cap * 8;  // acos LUT | disToBoundary windows | cached trace (x | z)
+    return b;
+}
+
+template <bool IsMax>
+__global__ __launch_bounds__(64) void replay_lanes_kernel(ReplayArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int k = a.k;
+    const uint32_t nlist = a.nlist;
+    const bool tune = a.tuner.enabled != 0;
+    float* hv = reinterpret_cast<float*>(smem);
+    uint8_t* hs = reinterpret_cast<uint8_t*>(hv + (size_t)k * 64);
+    float* bst = reinterpret_cast<float*>(smem + ((((size_t)k * 64 * 5) + 15) & ~(size_t)15));
+    float* lut = bst + LANES_BEST * 64;
+    float* dwin = lut + 512;
+    float* trc = dwin + 16 * 64;
+#define HV(i) hv[(size_t)(i) * 64 + lane]
+#define HS(i) hs[(size_t)(i) * 64 + lane]
+#define BST(i) bst[(i) * 64 + lane]
+#define DWIN(i) dwin[(i) * 64 + lane]
+    if (tune) {
+        for (int i = lane; i < 500; i += 64) lut[i] = a.tuner.arcos[i];
+    }
+    const uint32_t nact = a.nq_dev ? *a.nq_dev : a.nq;
+    const uint32_t li = blockIdx.x * 64 + lane;
+    if (blockIdx.x * 64 >= nact) return;  // whole wave idle
+    const uint32_t qi = li < nact ? (a.qsel ? a.qsel[li] : li) : 0u;
+    bool live = li < nact && !a.done[qi];
+    const size_t hb = (size_t)qi * k;
+    const uint32_t max_num = nlist / 8 + 20;
+
+    // ---- heap of the query into this lane's column; ids stay in a table indexed by slot
+    for (int i = 0; i < k; i++) {
+        HV(i) = live ? a.heap_val[hb + i] : hneutral<IsMax>();
+        HS(i) = (uint8_t)i;
+        if (live) a.href_tmp[hb + i] = a.heap_ref[hb + i];
+    }
+    // the LANES_BEST best values, best first
+    for (int i = 0; i < LANES_BEST; i++) BST(i) = hneutral<IsMax>();
+    for (int i = 0; i < k; i++) {
+        const float x = HV(i);
+        if (hcmp<IsMax>(BST(LANES_BEST - 1), x)) {
+            int j = LANES_BEST - 1;
+            while (j > 0 && hcmp<IsMax>(BST(j - 1), x)) {
+                BST(j) = BST(j - 1);
+                j--;
+            }
+            BST(j) = x;
+        }
+    }
+    wave_sync();
+
+    const unsigned long long id_q = a.id_offset + qi;
+    uint32_t err = 0;
+    const uint32_t ik0 = live ? a.stage[qi] : 0u;
+    const uint32_t loop_end = a.total_nprobe;
+    const uint32_t cnt = live ? min(a.seg_count[qi], a.cprobes[qi]) : 0u;
+    const bool truncated = live && a.cprobes[qi] < a.seg_count[qi];
+    const size_t seg0 = live ? (size_t)a.seg_begin[qi] : 0;
+    const size_t cbase = (size_t)qi * a.capq;
+    unsigned long long nscan = live ? a.nscan[qi] : 0ull;
+    float pre_val = live && a.pre_val ? a.pre_val[qi] : 0.f;
+    uint32_t stoped = live && a.stoped ? a.stoped[qi] : 0u;
+    unsigned long long st_nlist = 0, st_nheap = 0, st_ndis = 0;
+    float top = HV(0);
+
+    uint32_t query_k = 0;
+    float true_KD_K = 0.f, racc = 0.f;
+    unsigned long long np = 0;
+    int cached_ind = -1;       // this lane's window / cur_num cache
+    int trace_ind = -1;        // trace held in LDS (wave-uniform)
+    uint32_t trace_n = 0;
+    bool have_pre = false, top_changed = true;
+    uint32_t kept_pre = 0;
+    if (tune && live) {
+        query_k = a.tuner.query_topk;
+        if (a.tuner.gt_D) true_KD_K = a.tuner.gt_D[id_q * (unsigned long long)k + query_k - 1];
+        racc = a.tuner.require_acc[id_q];
+        np = a.tuner.my_nprobe[id_q];
+    }
+    if (tune) query_k = a.tuner.query_topk;
+    const unsigned long long np_in = np;
+    const float* gdtb = tune ? a.dtb + (size_t)qi * max_num : nullptr;
+
+    bool finished = false;
+    uint32_t consumed = 0, cur = 0;
+    uint32_t maxcnt = cnt;
+    for (int off = 32; off; off >>= 1) maxcnt = max(maxcnt, (uint32_t)__shfl_xor((int)maxcnt, off));
+
+    for (uint32_t p = 0; p < maxcnt; p++) {
+        const bool on = live && !finished && p < cnt;
+        if (!__ballot(on)) break;
+        const uint32_t ik = ik0 + p;
+        uint32_t ncand = 0, n = 0;
+        int key = -1;
+        if (on) {
+            consumed = p + 1;
+            key = a.seg_list[seg0 + p];
+            if (key >= 0) {
+                if ((uint32_t)key >= nlist) {
+                    err = ERR_INVALID_KEY;
+                    finished = true;
+                } else {
+                    n = (uint32_t)(a.list_off[key + 1] - a.list_off[key]);
+                    if (n) ncand = a.ccnt[seg0 + p];
+                }
+            }
+        }
+        const bool scan = on && !finished && n > 0;
+        // ---- the probe's candidates: Heap.h:88-142 per lane (IndexIVFFlat.cpp:125-135: strictly better than the top only)
+        uint32_t maxc = scan ? ncand : 0u;
+        for (int off = 32; off; off >>= 1) maxc = max(maxc, (uint32_t)__shfl_xor((int)maxc, off));
+        const int64_t refbase = REF_TAG | ((int64_t)key << 32);
+        for (uint32_t j = 0; j < maxc; j++) {
+            if (scan && j < ncand) {
+                const float val = a.cval[cbase + cur + j];
+                if (hcmp<IsMax>(top, val)) {
+                    const uint32_t pos = a.cpos[cbase + cur + j];
+                    // heap_pop: the last node's value walks down from the root
+                    const uint8_t sr = HS(0);  // the evicted root's id slot passes to the new entry
+                    {
+                        const float v = HV(k - 1);
+                        const uint8_t sv = HS(k - 1);
+                        int i = 1;
+                        for (;;) {
+                            const int i1 = i << 1, i2 = i1 + 1;
+                            if (i1 > k) break;
+                            const int j2 = i2 <= k ? i2 : i1;
+                            const float c1 = HV(i1 - 1), c2 = HV(j2 - 1);
+                            const bool left = (i2 == k + 1) || hcmp<IsMax>(c1, c2);
+                            const float c = left ? c1 : c2;
+                            if (hcmp<IsMax>(v, c)) break;
+                            const int ci = left ? i1 : i2;
+                            HV(i - 1) = c;
+                            HS(i - 1) = HS(ci - 1);
+                            i = ci;
+                        }
+                        HV(i - 1) = v;
+                        HS(i - 1) = sv;
+                    }
+                    // heap_push: the new value walks up from the last node
+                    {
+                        int i = k;
+                        while (i > 1) {
+                            const int f = i >> 1;
+                            const float fv = HV(f - 1);
+                            if (!hcmp<IsMax>(val, fv)) break;
+                            HV(i - 1) = fv;
+                            HS(i - 1) = HS(f - 1);
+                            i = f;
+                        }
+                        HV(i - 1) = val;
+                        HS(i - 1) = sr;
+                    }
+                    a.href_tmp[hb + sr] = refbase | (int64_t)pos;
+                    top = HV(0);
+                    st_nheap++;
+                    if (hcmp<IsMax>(BST(LANES_BEST - 1), val)) {
+                        int jb = LANES_BEST - 1;
+                        while (jb > 0 && hcmp<IsMax>(BST(jb - 1), val)) {
+                            BST(jb) = BST(jb - 1);
+                            jb--;
+                        }
+                        BST(jb) = val;
+                        if ((uint32_t)jb < query_k) top_changed = true;
+                    }
+                }
+            }
+        }
+        if (scan) {
+            cur += ncand;
+            st_nlist++;
+            nscan += n;
+            st_ndis += n;
+        }
+        bool rule = on && !finished;
+        if (rule && a.max_codes && nscan >= a.max_codes) {
+            finished = true;
+            rule = false;
+        }
+        if (rule && loop_end && ik + 1 >= loop_end) finished = true;  // end of the probe loop (the rule is still evaluated)
+        if (tune) {
+            // IndexIVF.cpp:551-638, one query per lane.  Once my_nprobe is known nothing the rule computes can change the
+            // outcome any more (L2: no throwing path left), so only the stop test remains.
+            const uint32_t stage = ik + 1;
+            const bool fired = IsMax && np != 0;
+            const bool eval = rule && !fired;
+            uint32_t ind = 0;
+            {
+                const uint32_t tmp_stage = stage >= nlist / 8 ? nlist / 8 - 1 : stage;
+                while (tmp_stage > (1u << ind)) ind++;
+            }
+            // the trace of the first evaluating lane's stage goes to LDS (the lanes of a wave are nearly always at the same
+            // stage); a lane at another stage reads its trace from memory
+            const unsigned long long em = __ballot(eval);
+            if (em) {
+                const int ind_u = __shfl((int)ind, __builtin_ctzll(em));
+                if (trace_ind != ind_u) {
+                    wave_sync();
+                    const uint32_t o = a.tuner.trace_off[ind_u], tn = a.tuner.trace_off[ind_u + 1] - o;
+                    const float sc = a.tuner.std_m;
+                    for (uint32_t i = lane; i < tn; i += 64) {
+                        trc[i] = a.tuner.trace_x[o + i];
+                        trc[a.trace_cap + i] = a.tuner.trace_y[o + i] + sc * a.tuner.trace_std[o + i];
+                    }
+                    trace_ind = ind_u;
+                    trace_n = tn;
+                    wave_sync();
+                }
+            }
+            if (eval) {
+                if ((int)ind != cached_ind) {
+                    for (int i = 0; i < 15; i++) DWIN(i) = gdtb[(1u << ind) - 1 + i];  // sum_angle start = 2^ind - 1
+                    cached_ind = (int)ind;
+                    have_pre = false;
+                }
+                if (!IsMax) {
+                    // the reference converts all k heap values (IndexIVF.cpp:562-564): any out-of-domain one throws.  The
+                    // smallest is the root, the largest the best value.
+                    (void)arcos_lut(lut, top, &err);
+                    (void)arcos_lut(lut, BST(0), &err);
+                }
+                if (!err && (!have_pre || top_changed)) {
+                    const TraceLds tr{trc, trc + a.trace_cap, trace_n};
+                    const bool in_lds = (int)ind == trace_ind;
+                    const uint32_t go = a.tuner.trace_off[ind], gn = a.tuner.trace_off[ind + 1] - go;
+                    auto S = [&](unsigned long long m) {
+                        const float kd = IsMax ? BST((int)m) : arcos_lut(lut, BST((int)m), &err);
+                        float sum = 0.f;
+                        for (int i = 0; i < 15; i++) {
+                            const float b = DWIN(i);
+                            float t = 0.f;
+                            if (!(b >= kd)) t = arcos_lut(lut, b / kd, &err);
+                            sum += t;
+                        }
+                        if (in_lds) return trace_search(tr.x, tr.z, tr.n, sum);
+                        return trace_search_xyz(a.tuner.trace_x + go, a.tuner.trace_y + go, a.tuner.trace_std + go, a.tuner.std_m, gn, sum);
+                    };
+                    const unsigned long long qk = query_k;
+                    unsigned long long high = qk - 1, low = 0, middle = 0;
+                    uint32_t res = 0;
+                    bool found = false;
+                    {
+                        const float g = S(high);
+                        if ((double)((float)qk * g) <= (double)qk * 1.005) {
+                            res = (uint32_t)qk;
+                            found = true;
+                        }
+                    }
+                    while (!found && !err && low <= high) {
+                        middle = (low + high) / 2;
+                        if (middle <= 0) {
+                            res = 0;
+                            found = true;
+                            break;
+                        }
+                        const float g = S(middle);
+                        if ((float)(middle + 1) * g <= (float)qk) low = middle + 1;
+                        else high = middle - 1;
+                    }
+                    if (!found) res = (uint32_t)(low + 1);
+                    kept_pre = res;
+                    have_pre = true;
+                    top_changed = false;
+                }
+                if (err) {
+                    finished = true;
+                } else {
+                    float recall = (float)kept_pre / (float)query_k;
+                    const float max_val = IsMax ? fmaxf(-1.f, top) : fminf(FLT_MAX, top);
+                    const unsigned long long stops = (unsigned long long)(racc * 12);
+                    if (stage > 1) {
+                        if (max_val == pre_val) stoped++;
+                        else stoped = 0;
+                        if (stoped >= stops) recall = 1;
+                    }
+                    pre_val = max_val;
+                    if (recall >= racc && np == 0) {
+                        np = (unsigned long long)((float)stage * a.tuner.multipler);
+                        if (np >= nlist) a.tuner.t_recalls[id_q] = 1.f;
+                    }
+                    if (stage >= nlist / 8 && np == 0) {
+                        np = (unsigned long long)((float)stage * a.tuner.multipler);
+                        if (np >= nlist) a.tuner.t_recalls[id_q] = 1.f;
+                    }
+                }
+            }
+            if (rule && !err && np != 0 && np <= stage) {
+                if (a.tuner.profile) {
+                    uint32_t hits = 0;
+                    for (int i = 0; i < k; i++) {
+                        const float s = HV(i);
+                        if (IsMax ? ((double)s <= (double)true_KD_K * 1.0005) : ((double)s >= (double)true_KD_K * 0.9995)) hits++;
+                    }
+                    a.tuner.t_recalls[id_q] = (float)hits / (float)query_k;
+                }
+                finished = true;
+            }
+        }
+    }
+
+    // ---- state out
+    unsigned long long tot_nlist = st_nlist, tot_ndis = st_ndis, tot_nheap = st_nheap;
+    uint32_t werr = err;
+    for (int off = 32; off; off >>= 1) {
+        tot_nlist += __shfl_xor(tot_nlist, off);
+        tot_ndis += __shfl_xor(tot_ndis, off);
+        tot_nheap += __shfl_xor(tot_nheap, off);
+        const uint32_t o = (uint32_t)__shfl_xor((int)werr, off);
+        werr = werr > o ? werr : o;
+    }
+    if (lane == 0) {
+        if (tot_nlist) atomicAdd(&a.stats[0], tot_nlist);
+        if (tot_ndis) atomicAdd(&a.stats[1], tot_ndis);
+        if (tot_nheap) atomicAdd(&a.stats[2], tot_nheap);
+        if (werr) atomicMax(a.error, werr);
+    }
+    if (!live) return;
+    a.stage[qi] = ik0 + consumed;
+    a.nscan[qi] = nscan;
+    if (a.pre_val) a.pre_val[qi] = pre_val;
+    if (a.stoped) a.stoped[qi] = stoped;
+    if (tune && np != np_in) a.tuner.my_nprobe[id_q] = np;
+    if (a.thr) a.thr[qi] = top;  // next round's scan stores only what beats this
+    if (truncated && !finished && !err) atomicAdd(&a.stats[3], 1ull);  // the host plans another round for what is left
+    const bool finalize = finished || err || (a.finalize_all && !truncated);
+    if (finalize) {
+        // heap_reorder (Heap.h:295-322): k pops, valid entries collected from the back
+        int ii = 0;
+        for (int i = 0; i < k; i++) {
+            const float v0 = HV(0);
+            const uint8_t s0 = HS(0);
+            const int64_t id0 = a.href_tmp[hb + s0];
+            const int kk = k - i;
+            {
+                const float v = HV(kk - 1);
+                const uint8_t sv = HS(kk - 1);
+                int n1 = 1;
+                for (;;) {
+                    const int i1 = n1 << 1, i2 = i1 + 1;
+                    if (i1 > kk) break;
+                    const int j2 = i2 <= kk ? i2 : i1;
+                    const float c1 = HV(i1 - 1), c2 = HV(j2 - 1);
+                    const bool left = (i2 == kk + 1) || hcmp<IsMax>(c1, c2);
+                    const float c = left ? c1 : c2;
+                    if (hcmp<IsMax>(v, c)) break;
+                    const int ci = left ? i1 : i2;
+                    HV(n1 - 1) = c;
+                    HS(n1 - 1) = HS(ci - 1);
+                    n1 = ci;
+                }
+                HV(n1 - 1) = v;
+                HS(n1 - 1) = sv;
+            }
+            HV(k - ii - 1) = v0;
+            HS(k - ii - 1) = s0;
+            if (id0 != -1) ii++;
+        }
+        // valid entries now sit in [k - ii, k): move to the front, pad the rest
+        for (int i = 0; i < k; i++) {
+            float v = hneutral<IsMax>();
+            int64_t id = -1;
+            if (i < ii) {
+                v = HV(k - ii + i);
+                int64_t ref = a.href_tmp[hb + HS(k - ii + i)];
+                if (ref & REF_TAG) {
+                    ref &= ~REF_TAG;
+                    if (!a.store_pairs) ref = a.ids[a.list_off[ref >> 32] + (uint64_t)(ref & 0xffffffffll)];
+                }
+                id = ref;
+            }
+            a.D[hb + i] = v;
+            a.I[hb + i] = id;
+        }
+        a.done[qi] = 1;
+    } else {
+        for (int i = 0; i < k; i++) {
+            a.heap_val[hb + i] = HV(i);
+            a.heap_ref[hb + i] = a.href_tmp[hb + HS(i)];
+        }
+    }
+#undef HV
+#undef HS
+#undef BST
+#undef DWIN
+}
+
+bool select_lanes_supported(const ReplayArgs& a) {
+    // read per call: the tests run both selections in one process
+    const char* e = getenv("AUNCEL_AMD_LANES");
+    if (e ? atoi(e) == 0 : !LANES_DEFAULT) return false;
+    if (a.k < 1 || a.k > LANES_MAXK || a.k > POOL_CAP - 192) return false;
+    if (a.train.enabled || a.raw_heap_out || a.identity_ids || a.limit || a.dbg) return false;
+    if (!a.seg_by_slot || !a.seg_begin || !a.qsel || !a.cval) return false;
+    if (a.tuner.enabled && (a.tuner.query_topk > (uint32_t)LANES_BEST || a.tuner.query_topk > (uint32_t)a.k)) return false;
+    if (a.tuner.enabled && a.trace_cap > 4096) return false;
+    return true;
+}
+
+void launch_select_lanes(const ReplayArgs& a, hipStream_t s) {
+    if (a.nq == 0) return;
+    const bool tune = a.tuner.enabled != 0;
+    const size_t shmem = lanes_lds_bytes(a.k, tune, a.trace_cap);
+    const dim3 g1((a.nq + 3) / 4), g2((a.nq + 63) / 64);
+    auto go = [&](auto k1, auto k2) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) throw std::runtime_error(std::string("selection kernel: cannot reserve LDS: ") + hipGetErrorString(e));
+        LAUNCH(k1, g1, dim3(256), 0, s, a);
+        LAUNCH(k2, g2, dim3(64), shmem, s, a);
+    };
+    if (a.metric == METRIC_L2) go(compact_kernel<true>, replay_lanes_kernel<true>);
+    else go(compact_kernel<false>, replay_lanes_kernel<false>);
+}
+
+// =============================================================================================
 // range search: count / fill over the threshold masks (RangeArgs in ivf_kernels.h)
 // =============================================================================================
 template <bool FILL>
@@ -2030,8 +2658,8 @@ __global__ __launch_bounds__(256) void init_state_kernel(InitStateArgs a) {
         a.pre_val[i] = 0.f;
         a.stoped[i] = 0;
     }
-    if (blockIdx.x == 0 && threadIdx.x < 3) a.stats[threadIdx.x] = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 3) *a.error = 0;
+    if (blockIdx.x == 0 && threadIdx.x < 4) a.stats[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 4) *a.error = 0;
 }
 
 void launch_init_state(const InitStateArgs& a, hipStream_t s) {
