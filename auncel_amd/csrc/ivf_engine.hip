@@ -227,7 +227,7 @@ struct amd_ivf {
     PinnedBuf p_items, p_pair_query, p_pair_out, p_seg_off, p_seg_list, p_seg_count, p_qsel, p_seg_begin;
     DevBuf w_seg_begin;
     // chained rounds: the planning counters of every round of the last search (grid hints for the next one of the same shape)
-    DevBuf w_cval, w_cpos, w_ccnt, w_cprobes, w_href_tmp;  // two-kernel selection (launch_select_lanes)
+    DevBuf w_cand, w_ccnt, w_cprobes, w_href_tmp;  // two-kernel selection (launch_select_lanes)
     DevBuf w_pl_hist;
     PinnedBuf p_hist;
     std::vector<uint32_t> round_hint;  // [round][16]
@@ -499,7 +499,10 @@ static void print_replay_dbg(amd_ivf* h, size_t mb, hipStream_t s) {
     std::vector<unsigned long long> dbg(mb * 8);
     HIP_CHECK(hipMemcpyAsync(dbg.data(), h->w_misc.p, mb * 64, hipMemcpyDeviceToHost, s));
     HIP_CHECK(stream_sync(s));
-    static const char* nm[8] = {"wave cycles", "heap updates", "candidates", "rule evaluations", "stream cycles", "rule cycles", "masked chunks", "probes"};
+    static const bool lanes = getenv("AUNCEL_AMD_LANES") && atoi(getenv("AUNCEL_AMD_LANES"));
+    static const char* nm_replay[8] = {"wave cycles", "heap updates", "candidates", "rule evaluations", "stream cycles", "rule cycles", "masked chunks", "probes"};
+    static const char* nm_lanes[8] = {"wave cycles", "wave heap updates", "run-ahead rounds", "prologue cycles", "candidate loop cycles", "rule cycles", "staging cycles", "epilogue cycles"};
+    const char* const* nm = lanes ? nm_lanes : nm_replay;
     for (int c = 0; c < 8; c++) {
         std::vector<unsigned long long> v(mb);
         for (size_t i = 0; i < mb; i++) v[i] = dbg[i * 8 + c];
@@ -1208,9 +1211,8 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     const size_t capq = std::max<size_t>(4096, ((maxlist + 63) & ~(size_t)63) + 64);
     const bool lanes_ok = capq * n <= ((size_t)1 << 29) && !base.range;
     if (lanes_ok) {
-        h->w_cval.ensure(n * capq * 4);
-        h->w_cpos.ensure(n * capq * 4);
-        h->w_ccnt.ensure(seg_cap * 4);
+        h->w_cand.ensure(n * capq * 8);
+        h->w_ccnt.ensure(seg_cap * 16);
         h->w_cprobes.ensure(n * 4);
         h->w_href_tmp.ensure(n * (size_t)base.k * 8);
     }
@@ -1430,9 +1432,8 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         ra.train = base.train;
         ra.limit = base.d_budget_ms ? h->w_limit.as<uint32_t>() : nullptr;
         if (lanes_ok) {
-            ra.cval = h->w_cval.as<float>();
-            ra.cpos = h->w_cpos.as<uint32_t>();
-            ra.ccnt = h->w_ccnt.as<uint32_t>();
+            ra.cand = h->w_cand.as<uint2>();
+            ra.cmeta = h->w_ccnt.as<uint4>();
             ra.cprobes = h->w_cprobes.as<uint32_t>();
             ra.capq = (uint32_t)capq;
             ra.href_tmp = h->w_href_tmp.as<int64_t>();

@@ -214,9 +214,9 @@ struct ReplayArgs {
     TrainDev train;
     // Two-kernel selection (launch_select_lanes): compact_kernel turns a round's distance rows into one short, ordered
     // candidate list per query; replay_lanes_kernel replays the reference's heap over those lists, one query per lane.
-    float* cval;               // [slot][capq] candidate values, stream order
-    uint32_t* cpos;            // [slot][capq] position of each candidate in its list
-    uint32_t* ccnt;            // candidates per (query, probe), indexed like seg_list
+    uint2* cand;               // [slot][capq] candidates in stream order: (value bits, position in the list)
+    uint32_t lanes;            // queries per wave of replay_lanes_kernel (set by launch_select_lanes)
+    uint4* cmeta;              // per (query, probe), indexed like seg_list: (candidates, list length, list number, -)
     uint32_t* cprobes;         // [slot] probes of this round whose candidates are in the list (the rest are re-planned)
     uint32_t capq;             // entries per query (>= the longest list, so a round's first probe always fits)
     int64_t* href_tmp;         // [slot][k] ids by heap slot while a round runs

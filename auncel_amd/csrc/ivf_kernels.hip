@@ -1678,7 +1678,7 @@ void launch_replay(const ReplayArgs& a, hipStream_t s) {
 //      fraction of the chip and overlap with other contexts' scans.
 // Same state arrays in, same state and results out as replay_kernel: the two can take turns between rounds.
 constexpr int POOL_CAP = 1024;             // K1: values per query between two threshold refreshes
-constexpr int LANES_MAXK = 255;            // K2: heap slots are bytes
+constexpr int LANES_MAXK = 200;            // K2: the heap of 64 queries (8 bytes per node and query) + staging must fit 160 KiB
 constexpr int LANES_BEST = 10;             // K2: best values kept sorted per query (query_topk <= this in tune mode)
 constexpr bool LANES_DEFAULT = false;      // AUNCEL_AMD_LANES=1 / 0 overrides
 
@@ -1794,8 +1794,7 @@ __global__ __launch_bounds__(256) void compact_kernel(ReplayArgs a) {
                     const int b = __builtin_ctzll(word);
                     word &= word - 1;
                     const uint32_t pos = (w0 + lane) * 64 + b;
-                    a.cval[idx] = a.dist[roff + pos];
-                    a.cpos[idx] = pos;
+                    a.cand[idx] = make_uint2(__float_as_uint(a.dist[roff + pos]), pos);
                     idx++;
                 }
                 cursor += total;
@@ -1826,8 +1825,7 @@ __global__ __launch_bounds__(256) void compact_kernel(ReplayArgs a) {
                         }
                         const uint32_t r = (uint32_t)__builtin_popcountll(bal & lt_mask);
                         if (pass) {
-                            a.cval[base + cursor + r] = v[u];
-                            a.cpos[base + cursor + r] = j0 + u * 64 + lane;
+                            a.cand[base + cursor + r] = make_uint2(__float_as_uint(v[u]), j0 + u * 64 + lane);
                             pool[npool + r] = v[u];
                         }
                         cursor += c;
@@ -1848,7 +1846,7 @@ __global__ __launch_bounds__(256) void compact_kernel(ReplayArgs a) {
             probes_done = p;
             break;
         }
-        if (lane == 0) a.ccnt[seg0 + p] = cursor - c0;
+        if (lane == 0) a.cmeta[seg0 + p] = make_uint4(cursor - c0, n, (uint32_t)key, 0u);
     }
     if (lane == 0) a.cprobes[qi] = probes_done;
 }
@@ -1870,14 +1868,25 @@ __device__ inline float trace_search_xyz(const float* x, const float* y, const f
     return y[low] + sc * sd[low];
 }
 
+constexpr int LANES_CHUNK = 64;            // K2: candidates per query staged in LDS at a time
+constexpr int LANES_CQ_ROW = 65;           // entries per staged row (+1: the transposing writes spread over the banks)
 __host__ __device__ inline size_t lanes_lds_bytes(int k, bool tune, uint32_t trace_cap) {
-    size_t b = (size_t)k * 64 * 4 + (size_t)k * 64;       // heap values | heap slots (bytes)
-    b = (b + 15) & ~(size_t)15;
-    b += (size_t)LANES_BEST * 64 * 4;                     // best values, sorted, per lane
+    size_t b = (size_t)k * LANES_CQ_ROW * 8;               // heap: (value, id slot) per node and lane, rows of 65
+    b += (size_t)LANES_CHUNK * LANES_CQ_ROW * 8;           // staged candidates: (value, position)
     if (tune) b += 512 * 4 + 16 * 64 * 4 + (size_t)trace_cap * 8;  // acos LUT | disToBoundary windows | cached trace (x | z)
     return b;
 }
 
+// One query per lane, `a.lanes` lanes per wave (a launch wants about one wave per CU: the kernel is a chain of dependent LDS
+// round trips per query, and work that only some lanes have -- a heap update, a rule evaluation -- costs the wave its full
+// latency whatever the number of lanes that take part).
+//   * a probe's candidates are staged through LDS 64 per query at a time (coalesced row loads, transposing writes); every
+//     lane then runs ahead on its own to its next candidate that beats its heap top, and the lanes that found one update
+//     their heaps together: the wave pays for max-over-lanes admissions per chunk, not for every candidate position;
+//   * heap nodes are (value, id slot) pairs, one 8-byte LDS access each; heap_pop reads children and grandchildren together
+//     and decides two levels per round trip; heap_push reads the fixed ancestor chain of node k in one;
+//   * the LANES_BEST best values live in registers (insertion network), the window of disToBoundary and the stage's trace
+//     in LDS.
 template <bool IsMax>
 __global__ __launch_bounds__(64) void replay_lanes_kernel(ReplayArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1885,63 +1894,86 @@ __global__ __launch_bounds__(64) void replay_lanes_kernel(ReplayArgs a) {
     const int k = a.k;
     const uint32_t nlist = a.nlist;
     const bool tune = a.tuner.enabled != 0;
-    float* hv = reinterpret_cast<float*>(smem);
-    uint8_t* hs = reinterpret_cast<uint8_t*>(hv + (size_t)k * 64);
-    float* bst = reinterpret_cast<float*>(smem + ((((size_t)k * 64 * 5) + 15) & ~(size_t)15));
-    float* lut = bst + LANES_BEST * 64;
+    uint2* h64 = reinterpret_cast<uint2*>(smem);
+    uint2* cq = h64 + (size_t)k * LANES_CQ_ROW;
+    float* lut = reinterpret_cast<float*>(cq + LANES_CHUNK * LANES_CQ_ROW);
     float* dwin = lut + 512;
     float* trc = dwin + 16 * 64;
-#define HV(i) hv[(size_t)(i) * 64 + lane]
-#define HS(i) hs[(size_t)(i) * 64 + lane]
-#define BST(i) bst[(i) * 64 + lane]
+#define H(i) h64[(size_t)(i) * LANES_CQ_ROW + lane]
+#define HC(i, col) h64[(size_t)(i) * LANES_CQ_ROW + (col)]
+#define HVAL(i) __uint_as_float(H(i).x)
 #define DWIN(i) dwin[(i) * 64 + lane]
     if (tune) {
         for (int i = lane; i < 500; i += 64) lut[i] = a.tuner.arcos[i];
     }
     const uint32_t nact = a.nq_dev ? *a.nq_dev : a.nq;
-    const uint32_t li = blockIdx.x * 64 + lane;
-    if (blockIdx.x * 64 >= nact) return;  // whole wave idle
-    const uint32_t qi = li < nact ? (a.qsel ? a.qsel[li] : li) : 0u;
-    bool live = li < nact && !a.done[qi];
+    const uint32_t L = a.lanes;
+    if (blockIdx.x * L >= nact) return;  // whole wave idle
+    const bool dbg = a.dbg != nullptr;
+    const unsigned long long t_start = dbg ? __builtin_readcyclecounter() : 0;
+    unsigned long long t_stage = 0, t_loop = 0, t_rule = 0, n_upd = 0, n_skip = 0;
+    const uint32_t li = blockIdx.x * L + lane;
+    const bool mine = (uint32_t)lane < L && li < nact;
+    const uint32_t qi = mine ? (a.qsel ? a.qsel[li] : li) : 0u;
+    const bool live = mine && !a.done[qi];
     const size_t hb = (size_t)qi * k;
     const uint32_t max_num = nlist / 8 + 20;
 
     // ---- heap of the query into this lane's column; ids stay in a table indexed by slot
-    for (int i = 0; i < k; i++) {
-        HV(i) = live ? a.heap_val[hb + i] : hneutral<IsMax>();
-        HS(i) = (uint8_t)i;
-        if (live) a.href_tmp[hb + i] = a.heap_ref[hb + i];
-    }
-    // the LANES_BEST best values, best first
-    for (int i = 0; i < LANES_BEST; i++) BST(i) = hneutral<IsMax>();
-    for (int i = 0; i < k; i++) {
-        const float x = HV(i);
-        if (hcmp<IsMax>(BST(LANES_BEST - 1), x)) {
-            int j = LANES_BEST - 1;
-            while (j > 0 && hcmp<IsMax>(BST(j - 1), x)) {
-                BST(j) = BST(j - 1);
-                j--;
-            }
-            BST(j) = x;
+    float b[LANES_BEST];  // best values, best first
+#pragma unroll
+    for (int i = 0; i < LANES_BEST; i++) b[i] = hneutral<IsMax>();
+    auto best_insert = [&](float x) {  // x is known to beat b[LANES_BEST - 1]; equal values keep their order
+#pragma unroll
+        for (int i = 0; i < LANES_BEST; i++) {
+            const bool better = hcmp<IsMax>(b[i], x);
+            const float t = better ? x : b[i];
+            x = better ? b[i] : x;
+            b[i] = t;
+        }
+    };
+    auto best_get = [&](uint32_t m) {
+        float r = b[0];
+#pragma unroll
+        for (int i = 1; i < LANES_BEST; i++) r = m == (uint32_t)i ? b[i] : r;
+        return r;
+    };
+    // (row by row with the whole wave: a lane walking its own k entries would pay a memory round trip per entry)
+    for (uint32_t r = 0; r < L; r++) {
+        const bool lr = __builtin_amdgcn_readlane((int)live, (int)r) != 0;
+        const size_t rb = (size_t)(uint32_t)__builtin_amdgcn_readlane((int)qi, (int)r) * k;
+        for (int i = lane; i < k; i += 64) {
+            HC(i, r) = make_uint2(__float_as_uint(lr ? a.heap_val[rb + i] : hneutral<IsMax>()), (uint32_t)i);
+            if (lr) a.href_tmp[rb + i] = a.heap_ref[rb + i];
         }
     }
     wave_sync();
+    for (int i = 0; i < k; i++) {
+        const float x = HVAL(i);
+        if (hcmp<IsMax>(b[LANES_BEST - 1], x)) best_insert(x);
+    }
+    // ancestors of node k (heap_push always starts there): k, k/2, ..., 1
+    int depth = 0;
+    for (int t = k; t >= 1; t >>= 1) depth++;
+    wave_sync();
+    const unsigned long long t_pro = dbg ? __builtin_readcyclecounter() : 0;
 
     const unsigned long long id_q = a.id_offset + qi;
     uint32_t err = 0;
     const uint32_t ik0 = live ? a.stage[qi] : 0u;
     const uint32_t loop_end = a.total_nprobe;
-    const uint32_t cnt = live ? min(a.seg_count[qi], a.cprobes[qi]) : 0u;
-    const bool truncated = live && a.cprobes[qi] < a.seg_count[qi];
+    const uint32_t planned = live ? a.seg_count[qi] : 0u, ready = live ? a.cprobes[qi] : 0u;
+    const uint32_t cnt = planned < ready ? planned : ready;
+    const bool truncated = live && ready < planned;
     const size_t seg0 = live ? (size_t)a.seg_begin[qi] : 0;
-    const size_t cbase = (size_t)qi * a.capq;
+    const uint2* cand = a.cand + (size_t)qi * a.capq;
     unsigned long long nscan = live ? a.nscan[qi] : 0ull;
     float pre_val = live && a.pre_val ? a.pre_val[qi] : 0.f;
     uint32_t stoped = live && a.stoped ? a.stoped[qi] : 0u;
     unsigned long long st_nlist = 0, st_nheap = 0, st_ndis = 0;
-    float top = HV(0);
+    float top = HVAL(0);
 
-    uint32_t query_k = 0;
+    const uint32_t query_k = tune ? a.tuner.query_topk : 0u;
     float true_KD_K = 0.f, racc = 0.f;
     unsigned long long np = 0;
     int cached_ind = -1;       // this lane's window / cur_num cache
@@ -1950,17 +1982,80 @@ __global__ __launch_bounds__(64) void replay_lanes_kernel(ReplayArgs a) {
     bool have_pre = false, top_changed = true;
     uint32_t kept_pre = 0;
     if (tune && live) {
-        query_k = a.tuner.query_topk;
         if (a.tuner.gt_D) true_KD_K = a.tuner.gt_D[id_q * (unsigned long long)k + query_k - 1];
         racc = a.tuner.require_acc[id_q];
         np = a.tuner.my_nprobe[id_q];
     }
-    if (tune) query_k = a.tuner.query_topk;
     const unsigned long long np_in = np;
     const float* gdtb = tune ? a.dtb + (size_t)qi * max_num : nullptr;
 
+    // one heap update: heap_pop (Heap.h:88-118) then heap_push (Heap.h:125-142) of (val, slot of the evicted root)
+    auto heap_update = [&](float val, int64_t ref) {
+        const uint32_t sr = H(0).y;
+        float rootv;  // the root after the pop
+        {
+            const uint2 ve = H(k - 1);
+            const float v = __uint_as_float(ve.x);
+            int i = 1;
+            bool first = true;
+            rootv = v;
+            for (;;) {
+                const int i1 = i << 1;
+                if (i1 > k) break;
+                const int i2 = i1 + 1, g = i << 2;
+                // children and grandchildren in one round trip (indices past k are clamped and ignored)
+                const int n2 = i2 <= k ? i2 : k, g0 = g <= k ? g : k, g1 = g + 1 <= k ? g + 1 : k, g2 = g + 2 <= k ? g + 2 : k,
+                          g3 = g + 3 <= k ? g + 3 : k;
+                const uint2 c1 = H(i1 - 1), c2 = H(n2 - 1), d0 = H(g0 - 1), d1 = H(g1 - 1), d2 = H(g2 - 1), d3 = H(g3 - 1);
+                const bool leftA = (i2 == k + 1) || hcmp<IsMax>(__uint_as_float(c1.x), __uint_as_float(c2.x));
+                const uint2 c = leftA ? c1 : c2;
+                if (hcmp<IsMax>(v, __uint_as_float(c.x))) break;
+                H(i - 1) = c;
+                if (first) rootv = __uint_as_float(c.x);
+                first = false;
+                i = leftA ? i1 : i2;
+                const int j1 = i << 1;
+                if (j1 > k) break;
+                const int j2 = j1 + 1;
+                const uint2 e1 = leftA ? d0 : d2, e2 = leftA ? d1 : d3;
+                const bool leftB = (j2 == k + 1) || hcmp<IsMax>(__uint_as_float(e1.x), __uint_as_float(e2.x));
+                const uint2 e = leftB ? e1 : e2;
+                if (hcmp<IsMax>(v, __uint_as_float(e.x))) break;
+                H(i - 1) = e;
+                i = leftB ? j1 : j2;
+            }
+            H(i - 1) = ve;
+        }
+        {
+            // the ancestors of node k, read together, then shifted down as far as val climbs
+            uint2 fe[8];
+#pragma unroll
+            for (int t = 1; t < 8; t++) fe[t] = H((t < depth ? k >> t : 1) - 1);
+            int i = k;
+            bool reached_root = depth == 1;
+#pragma unroll
+            for (int t = 1; t < 8; t++) {
+                if (t >= depth) break;
+                if (!hcmp<IsMax>(val, __uint_as_float(fe[t].x))) break;
+                H(i - 1) = fe[t];
+                i = k >> t;
+                if (t == depth - 1) reached_root = true;
+            }
+            H(i - 1) = make_uint2(__float_as_uint(val), sr);
+            top = reached_root ? val : rootv;
+        }
+        a.href_tmp[hb + sr] = ref;
+        st_nheap++;
+        if (hcmp<IsMax>(b[LANES_BEST - 1], val)) {
+            if (query_k && hcmp<IsMax>(b[query_k - 1], val)) top_changed = true;
+            best_insert(val);
+        }
+    };
+
     bool finished = false;
     uint32_t consumed = 0, cur = 0;
+    uint4 meta_next = make_uint4(0u, 0u, 0xffffffffu, 0u);
+    if (cnt) meta_next = a.cmeta[seg0];
     uint32_t maxcnt = cnt;
     for (int off = 32; off; off >>= 1) maxcnt = max(maxcnt, (uint32_t)__shfl_xor((int)maxcnt, off));
 
@@ -1970,80 +2065,65 @@ __global__ __launch_bounds__(64) void replay_lanes_kernel(ReplayArgs a) {
         const uint32_t ik = ik0 + p;
         uint32_t ncand = 0, n = 0;
         int key = -1;
+        const uint4 meta = meta_next;  // (candidates, list length, key) of this probe, requested one probe ahead
+        if (live && p + 1 < cnt) meta_next = a.cmeta[seg0 + p + 1];
         if (on) {
             consumed = p + 1;
-            key = a.seg_list[seg0 + p];
+            key = (int)meta.z;
             if (key >= 0) {
                 if ((uint32_t)key >= nlist) {
                     err = ERR_INVALID_KEY;
                     finished = true;
                 } else {
-                    n = (uint32_t)(a.list_off[key + 1] - a.list_off[key]);
-                    if (n) ncand = a.ccnt[seg0 + p];
+                    n = meta.y;
+                    ncand = meta.x;
                 }
             }
         }
         const bool scan = on && !finished && n > 0;
-        // ---- the probe's candidates: Heap.h:88-142 per lane (IndexIVFFlat.cpp:125-135: strictly better than the top only)
+        // ---- the probe's candidates (IndexIVFFlat.cpp:125-135: only what is strictly better than the top enters)
         uint32_t maxc = scan ? ncand : 0u;
         for (int off = 32; off; off >>= 1) maxc = max(maxc, (uint32_t)__shfl_xor((int)maxc, off));
         const int64_t refbase = REF_TAG | ((int64_t)key << 32);
-        for (uint32_t j = 0; j < maxc; j++) {
-            if (scan && j < ncand) {
-                const float val = a.cval[cbase + cur + j];
-                if (hcmp<IsMax>(top, val)) {
-                    const uint32_t pos = a.cpos[cbase + cur + j];
-                    // heap_pop: the last node's value walks down from the root
-                    const uint8_t sr = HS(0);  // the evicted root's id slot passes to the new entry
-                    {
-                        const float v = HV(k - 1);
-                        const uint8_t sv = HS(k - 1);
-                        int i = 1;
-                        for (;;) {
-                            const int i1 = i << 1, i2 = i1 + 1;
-                            if (i1 > k) break;
-                            const int j2 = i2 <= k ? i2 : i1;
-                            const float c1 = HV(i1 - 1), c2 = HV(j2 - 1);
-                            const bool left = (i2 == k + 1) || hcmp<IsMax>(c1, c2);
-                            const float c = left ? c1 : c2;
-                            if (hcmp<IsMax>(v, c)) break;
-                            const int ci = left ? i1 : i2;
-                            HV(i - 1) = c;
-                            HS(i - 1) = HS(ci - 1);
-                            i = ci;
-                        }
-                        HV(i - 1) = v;
-                        HS(i - 1) = sv;
-                    }
-                    // heap_push: the new value walks up from the last node
-                    {
-                        int i = k;
-                        while (i > 1) {
-                            const int f = i >> 1;
-                            const float fv = HV(f - 1);
-                            if (!hcmp<IsMax>(val, fv)) break;
-                            HV(i - 1) = fv;
-                            HS(i - 1) = HS(f - 1);
-                            i = f;
-                        }
-                        HV(i - 1) = val;
-                        HS(i - 1) = sr;
-                    }
-                    a.href_tmp[hb + sr] = refbase | (int64_t)pos;
-                    top = HV(0);
-                    st_nheap++;
-                    if (hcmp<IsMax>(BST(LANES_BEST - 1), val)) {
-                        int jb = LANES_BEST - 1;
-                        while (jb > 0 && hcmp<IsMax>(BST(jb - 1), val)) {
-                            BST(jb) = BST(jb - 1);
-                            jb--;
-                        }
-                        BST(jb) = val;
-                        if ((uint32_t)jb < query_k) top_changed = true;
+        for (uint32_t c0 = 0; c0 < maxc; c0 += LANES_CHUNK) {
+            // stage entries [c0, c0 + 64) of every scanning lane's list: row r (lane r's list) is read by the whole wave, entry e
+            // by lane e, and lands in column r of the staged chunk
+            const uint32_t left = scan && ncand > c0 ? ncand - c0 : 0u;
+            const uint2* rowp = cand + cur + c0;
+            const unsigned long long t_s0 = dbg ? __builtin_readcyclecounter() : 0;
+            wave_sync();
+            for (uint32_t r = 0; r < L; r++) {
+                const uint32_t rn = (uint32_t)__builtin_amdgcn_readlane((int)left, (int)r);
+                if (!rn) continue;
+                const unsigned long long rp = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)((unsigned long long)rowp >> 32), (int)r) << 32) |
+                                              (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(unsigned long long)rowp, (int)r);
+                if ((uint32_t)lane < rn) cq[(size_t)lane * LANES_CQ_ROW + r] = reinterpret_cast<const uint2*>(rp)[lane];
+            }
+            wave_sync();
+            const unsigned long long t_s1 = dbg ? __builtin_readcyclecounter() : 0;
+            t_stage += t_s1 - t_s0;
+            const uint32_t ne = left < (uint32_t)LANES_CHUNK ? left : (uint32_t)LANES_CHUNK;
+            uint32_t e = 0;
+            for (;;) {
+                // every lane runs ahead to its next candidate that beats its top
+                bool has = false;
+                uint2 ent = make_uint2(0u, 0u);
+                while (e < ne) {
+                    ent = cq[(size_t)e * LANES_CQ_ROW + lane];
+                    e++;
+                    if (hcmp<IsMax>(top, __uint_as_float(ent.x))) {
+                        has = true;
+                        break;
                     }
                 }
+                n_skip++;
+                if (!__ballot(has)) break;
+                n_upd++;
+                if (has) heap_update(__uint_as_float(ent.x), refbase | (int64_t)ent.y);
             }
+            if (dbg) t_loop += __builtin_readcyclecounter() - t_s1;
         }
+        const unsigned long long t_r0 = dbg ? __builtin_readcyclecounter() : 0;
         if (scan) {
             cur += ncand;
             st_nlist++;
@@ -2095,19 +2175,27 @@ __global__ __launch_bounds__(64) void replay_lanes_kernel(ReplayArgs a) {
                     // the reference converts all k heap values (IndexIVF.cpp:562-564): any out-of-domain one throws.  The
                     // smallest is the root, the largest the best value.
                     (void)arcos_lut(lut, top, &err);
-                    (void)arcos_lut(lut, BST(0), &err);
+                    (void)arcos_lut(lut, b[0], &err);
                 }
                 if (!err && (!have_pre || top_changed)) {
                     const TraceLds tr{trc, trc + a.trace_cap, trace_n};
                     const bool in_lds = (int)ind == trace_ind;
-                    const uint32_t go = a.tuner.trace_off[ind], gn = a.tuner.trace_off[ind + 1] - go;
+                    uint32_t go = 0, gn = 0;
+                    if (!in_lds) {
+                        go = a.tuner.trace_off[ind];
+                        gn = a.tuner.trace_off[ind + 1] - go;
+                    }
+                    float dw[15];
+#pragma unroll
+                    for (int i = 0; i < 15; i++) dw[i] = DWIN(i);
                     auto S = [&](unsigned long long m) {
-                        const float kd = IsMax ? BST((int)m) : arcos_lut(lut, BST((int)m), &err);
+                        const float bm = best_get((uint32_t)m);
+                        const float kd = IsMax ? bm : arcos_lut(lut, bm, &err);
                         float sum = 0.f;
+#pragma unroll
                         for (int i = 0; i < 15; i++) {
-                            const float b = DWIN(i);
                             float t = 0.f;
-                            if (!(b >= kd)) t = arcos_lut(lut, b / kd, &err);
+                            if (!(dw[i] >= kd)) t = arcos_lut(lut, dw[i] / kd, &err);
                             sum += t;
                         }
                         if (in_lds) return trace_search(tr.x, tr.z, tr.n, sum);
@@ -2166,7 +2254,7 @@ __global__ __launch_bounds__(64) void replay_lanes_kernel(ReplayArgs a) {
                 if (a.tuner.profile) {
                     uint32_t hits = 0;
                     for (int i = 0; i < k; i++) {
-                        const float s = HV(i);
+                        const float s = HVAL(i);
                         if (IsMax ? ((double)s <= (double)true_KD_K * 1.0005) : ((double)s >= (double)true_KD_K * 0.9995)) hits++;
                     }
                     a.tuner.t_recalls[id_q] = (float)hits / (float)query_k;
@@ -2174,9 +2262,11 @@ __global__ __launch_bounds__(64) void replay_lanes_kernel(ReplayArgs a) {
                 finished = true;
             }
         }
+        if (dbg) t_rule += __builtin_readcyclecounter() - t_r0;
     }
 
     // ---- state out
+    const unsigned long long t_epi = dbg ? __builtin_readcyclecounter() : 0;
     unsigned long long tot_nlist = st_nlist, tot_ndis = st_ndis, tot_nheap = st_nheap;
     uint32_t werr = err;
     for (int off = 32; off; off >>= 1) {
@@ -2192,73 +2282,91 @@ __global__ __launch_bounds__(64) void replay_lanes_kernel(ReplayArgs a) {
         if (tot_nheap) atomicAdd(&a.stats[2], tot_nheap);
         if (werr) atomicMax(a.error, werr);
     }
-    if (!live) return;
-    a.stage[qi] = ik0 + consumed;
-    a.nscan[qi] = nscan;
-    if (a.pre_val) a.pre_val[qi] = pre_val;
-    if (a.stoped) a.stoped[qi] = stoped;
-    if (tune && np != np_in) a.tuner.my_nprobe[id_q] = np;
-    if (a.thr) a.thr[qi] = top;  // next round's scan stores only what beats this
+    if (live) {
+        a.stage[qi] = ik0 + consumed;
+        a.nscan[qi] = nscan;
+        if (a.pre_val) a.pre_val[qi] = pre_val;
+        if (a.stoped) a.stoped[qi] = stoped;
+        if (tune && np != np_in) a.tuner.my_nprobe[id_q] = np;
+        if (a.thr) a.thr[qi] = top;  // next round's scan stores only what beats this
+    }
     if (truncated && !finished && !err) atomicAdd(&a.stats[3], 1ull);  // the host plans another round for what is left
-    const bool finalize = finished || err || (a.finalize_all && !truncated);
+    const bool finalize = live && (finished || err || (a.finalize_all && !truncated));
+    int ii = 0;
     if (finalize) {
-        // heap_reorder (Heap.h:295-322): k pops, valid entries collected from the back
-        int ii = 0;
+        // heap_reorder (Heap.h:295-322): k pops, valid entries collected from the back.  An entry without an id (-1) is one
+        // of the initial ones, and those are the only entries holding the neutral value (anything admitted beat a top).
         for (int i = 0; i < k; i++) {
-            const float v0 = HV(0);
-            const uint8_t s0 = HS(0);
-            const int64_t id0 = a.href_tmp[hb + s0];
+            const uint2 r0 = H(0);
             const int kk = k - i;
             {
-                const float v = HV(kk - 1);
-                const uint8_t sv = HS(kk - 1);
+                const uint2 ve = H(kk - 1);
+                const float v = __uint_as_float(ve.x);
                 int n1 = 1;
                 for (;;) {
                     const int i1 = n1 << 1, i2 = i1 + 1;
                     if (i1 > kk) break;
                     const int j2 = i2 <= kk ? i2 : i1;
-                    const float c1 = HV(i1 - 1), c2 = HV(j2 - 1);
-                    const bool left = (i2 == kk + 1) || hcmp<IsMax>(c1, c2);
-                    const float c = left ? c1 : c2;
-                    if (hcmp<IsMax>(v, c)) break;
-                    const int ci = left ? i1 : i2;
-                    HV(n1 - 1) = c;
-                    HS(n1 - 1) = HS(ci - 1);
-                    n1 = ci;
+                    const uint2 c1 = H(i1 - 1), c2 = H(j2 - 1);
+                    const bool left = (i2 == kk + 1) || hcmp<IsMax>(__uint_as_float(c1.x), __uint_as_float(c2.x));
+                    const uint2 c = left ? c1 : c2;
+                    if (hcmp<IsMax>(v, __uint_as_float(c.x))) break;
+                    H(n1 - 1) = c;
+                    n1 = left ? i1 : i2;
                 }
-                HV(n1 - 1) = v;
-                HS(n1 - 1) = sv;
+                H(n1 - 1) = ve;
             }
-            HV(k - ii - 1) = v0;
-            HS(k - ii - 1) = s0;
-            if (id0 != -1) ii++;
-        }
-        // valid entries now sit in [k - ii, k): move to the front, pad the rest
-        for (int i = 0; i < k; i++) {
-            float v = hneutral<IsMax>();
-            int64_t id = -1;
-            if (i < ii) {
-                v = HV(k - ii + i);
-                int64_t ref = a.href_tmp[hb + HS(k - ii + i)];
-                if (ref & REF_TAG) {
-                    ref &= ~REF_TAG;
-                    if (!a.store_pairs) ref = a.ids[a.list_off[ref >> 32] + (uint64_t)(ref & 0xffffffffll)];
-                }
-                id = ref;
-            }
-            a.D[hb + i] = v;
-            a.I[hb + i] = id;
+            H(k - ii - 1) = r0;
+            if (__uint_as_float(r0.x) != hneutral<IsMax>()) ii++;
         }
         a.done[qi] = 1;
-    } else {
-        for (int i = 0; i < k; i++) {
-            a.heap_val[hb + i] = HV(i);
-            a.heap_ref[hb + i] = a.href_tmp[hb + HS(i)];
+    }
+    wave_sync();
+    // results / carried state leave row by row with the whole wave (ids through the slot table)
+    for (uint32_t r = 0; r < L; r++) {
+        if (!__builtin_amdgcn_readlane((int)live, (int)r)) continue;
+        const size_t rb = (size_t)(uint32_t)__builtin_amdgcn_readlane((int)qi, (int)r) * k;
+        if (__builtin_amdgcn_readlane((int)finalize, (int)r)) {
+            const int iir = __builtin_amdgcn_readlane(ii, (int)r);  // valid entries sit in [k - ii, k): to the front, pad the rest
+            for (int i = lane; i < k; i += 64) {
+                float v = hneutral<IsMax>();
+                int64_t id = -1;
+                if (i < iir) {
+                    const uint2 en = HC(k - iir + i, r);
+                    v = __uint_as_float(en.x);
+                    int64_t ref = a.href_tmp[rb + en.y];
+                    if (ref >= 0 && (ref & REF_TAG)) {
+                        ref &= ~REF_TAG;
+                        if (!a.store_pairs) ref = a.ids[a.list_off[ref >> 32] + (uint64_t)(ref & 0xffffffffll)];
+                    }
+                    id = ref;
+                }
+                a.D[rb + i] = v;
+                a.I[rb + i] = id;
+            }
+        } else {
+            for (int i = lane; i < k; i += 64) {
+                const uint2 en = HC(i, r);
+                a.heap_val[rb + i] = __uint_as_float(en.x);
+                a.heap_ref[rb + i] = a.href_tmp[rb + en.y];
+            }
         }
     }
-#undef HV
-#undef HS
-#undef BST
+    if (dbg && lane == 0) {
+        unsigned long long* o = a.dbg + (size_t)blockIdx.x * 8;
+        const unsigned long long t_end = __builtin_readcyclecounter();
+        o[0] = t_end - t_start;  // wave cycles
+        o[1] = n_upd;            // wave-level heap updates
+        o[2] = n_skip;           // run-ahead rounds
+        o[3] = t_pro - t_start;  // prologue cycles
+        o[4] = t_loop;           // candidate loop cycles
+        o[5] = t_rule;           // rule cycles
+        o[6] = t_stage;          // staging cycles
+        o[7] = t_end - t_epi;    // epilogue cycles
+    }
+#undef H
+#undef HC
+#undef HVAL
 #undef DWIN
 }
 
@@ -2267,8 +2375,8 @@ bool select_lanes_supported(const ReplayArgs& a) {
     const char* e = getenv("AUNCEL_AMD_LANES");
     if (e ? atoi(e) == 0 : !LANES_DEFAULT) return false;
     if (a.k < 1 || a.k > LANES_MAXK || a.k > POOL_CAP - 192) return false;
-    if (a.train.enabled || a.raw_heap_out || a.identity_ids || a.limit || a.dbg) return false;
-    if (!a.seg_by_slot || !a.seg_begin || !a.qsel || !a.cval) return false;
+    if (a.train.enabled || a.raw_heap_out || a.identity_ids || a.limit) return false;
+    if (!a.seg_by_slot || !a.seg_begin || !a.qsel || !a.cand) return false;
     if (a.tuner.enabled && (a.tuner.query_topk > (uint32_t)LANES_BEST || a.tuner.query_topk > (uint32_t)a.k)) return false;
     if (a.tuner.enabled && a.trace_cap > 4096) return false;
     return true;
@@ -2278,12 +2386,22 @@ void launch_select_lanes(const ReplayArgs& a, hipStream_t s) {
     if (a.nq == 0) return;
     const bool tune = a.tuner.enabled != 0;
     const size_t shmem = lanes_lds_bytes(a.k, tune, a.trace_cap);
-    const dim3 g1((a.nq + 3) / 4), g2((a.nq + 63) / 64);
+    ReplayArgs b = a;
+    // lanes per wave: about one wave per CU (see replay_lanes_kernel); nq_hint = queries expected in this launch
+    const uint32_t expect = a.nq_hint ? a.nq_hint : a.nq;
+    const char* le = getenv("AUNCEL_AMD_LANES_PER_WAVE");
+    uint32_t L = le ? (uint32_t)atoi(le) : 0;
+    if (!L) {
+        L = 4;
+        while (L < 64 && expect / L > resident_grid(1)) L *= 2;
+    }
+    b.lanes = L < 1 ? 1 : L > 64 ? 64 : L;
+    const dim3 g1((a.nq + 3) / 4), g2((a.nq + b.lanes - 1) / b.lanes);
     auto go = [&](auto k1, auto k2) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) throw std::runtime_error(std::string("selection kernel: cannot reserve LDS: ") + hipGetErrorString(e));
-        LAUNCH(k1, g1, dim3(256), 0, s, a);
-        LAUNCH(k2, g2, dim3(64), shmem, s, a);
+        LAUNCH(k1, g1, dim3(256), 0, s, b);
+        LAUNCH(k2, g2, dim3(64), shmem, s, b);
     };
     if (a.metric == METRIC_L2) go(compact_kernel<true>, replay_lanes_kernel<true>);
     else go(compact_kernel<false>, replay_lanes_kernel<false>);
