@@ -24,7 +24,7 @@ SYMBOLS = [
     "amd_ivf_set_tuner", "amd_ivf_search_adaptive", "amd_ivf_search_adaptive_x", "amd_ivf_search_timed", "amd_ivf_search_timed_x",
     "amd_ivf_train_samples",
     "amd_ivf_train_samples_x", "amd_ivf_trace_sb", "amd_ivf_arcos_table", "amd_ivf_merge_tables",
-    "amd_ivf_last_timing",
+    "amd_ivf_last_timing", "amd_ivf_last_scan_min_bytes", "amd_ivf_set_byte_codes",
     "amd_ivf_kmeans",
     "amd_ivf_range_search_preassigned", "amd_ivf_range_search", "amd_ivf_range_results",
     "amd_ivf_scan_arith",
@@ -353,5 +353,11 @@ class Handle:
     def last_timing(self):
         t = (C.c_double * 8)()
         lib().amd_ivf_last_timing(self._h, t)
+        mb = C.c_double(0)
+        lib().amd_ivf_last_scan_min_bytes(self._h, C.byref(mb))
         return dict(coarse_ms=t[0], scan_ms=t[1], select_ms=t[2], total_ms=t[3], scan_launches=t[4], scan_bytes=t[5],
-                    slot_efficiency=t[6], rounds=t[7])
+                    slot_efficiency=t[6], rounds=t[7], scan_min_bytes=mb.value)
+
+    def set_byte_codes(self, enable):
+        """False: scan the fp32 lists even where the byte codes qualify (same results)"""
+        lib().amd_ivf_set_byte_codes(self._h, int(bool(enable)))

@@ -237,7 +237,8 @@ struct amd_ivf {
     size_t dist_budget_floats = (size_t)768 << 20;  // 3 GiB of distances per scan launch
     size_t stats_host[4] = {0, 0, 0, 0};
     double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    double scan_bytes = 0, scan_slots = 0, scan_useful = 0;
+    double last_min_bytes = 0;
+    double scan_bytes = 0, scan_slots = 0, scan_useful = 0, scan_min_bytes = 0;
     EventTimer timer;
 
     // Query lanes: a large adaptive batch is cut into slices that run their rounds concurrently, each on
@@ -871,6 +872,7 @@ void finish_timing(amd_ivf* h, double wall_ms) {
     h->timing[3] = wall_ms;
     h->timing[4] = ln[CAT_SCAN];
     h->timing[5] = h->scan_bytes;
+    h->last_min_bytes = h->scan_min_bytes;
     h->timing[6] = h->scan_slots > 0 ? h->scan_useful / h->scan_slots : 0;
     h->timing[7] = ln[CAT_SELECT];
 }
@@ -1269,6 +1271,8 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     pa.counters = h->w_pl_counters.as<uint32_t>();
     pa.bytes = reinterpret_cast<double*>(h->w_pl_counters.as<uint32_t>() + 16);
     pa.acc64 = reinterpret_cast<unsigned long long*>(h->w_pl_counters.as<uint32_t>() + 18);
+    pa.min_bytes = reinterpret_cast<double*>(h->w_pl_counters.as<uint32_t>() + 22);
+    pa.row_bytes = base.bytes ? mfma_ksteps(h->d) * 32 : (uint32_t)h->dpad * 4;
     pa.error = h->w_error.as<uint32_t>();
     if (base.d_budget_ms) {
         h->w_limit.ensure(n * 4);
@@ -1301,6 +1305,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     size_t planned_rounds = 0;  // plans launched so far (round r's counters reach history[r] when round r + 1 is planned)
     auto plan_round = [&](size_t round_len) {
         pa.round_len = (uint32_t)round_len;
+        pa.dense_round = !(base.range || (planned_rounds > 0 && !no_thr));
         pa.history = chained && planned_rounds >= 1 && planned_rounds <= MAX_HIST ? h->w_pl_hist.as<uint32_t>() + (planned_rounds - 1) * 16 : nullptr;
         launch_plan(pa, s);
         planned_rounds++;
@@ -1592,6 +1597,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         h->round_hint.insert(h->round_hint.end(), hc, hc + 16);  // the last planned round
     }
     h->scan_bytes += *reinterpret_cast<double*>(hc + 16);
+    h->scan_min_bytes += *reinterpret_cast<double*>(hc + 22);
     const unsigned long long* acc = reinterpret_cast<const unsigned long long*>(hc + 18);
     h->scan_slots += (double)acc[0];
     h->scan_useful += (double)acc[1];
@@ -1868,7 +1874,7 @@ int amd_ivf_coarse(amd_ivf_t* h, size_t n, const float* x, size_t nprobe, float*
     use_device(h);
     if (n == 0) return 0;
     WallClock wc(h->stream);
-    h->scan_bytes = 0;
+    h->scan_bytes = h->scan_min_bytes = 0;
     h->scan_slots = h->scan_useful = 0;
     h->w_x.ensure(n * h->dpad * sizeof(float));
     upload_rows(h, h->w_x.as<float>(), x, n);
@@ -1892,7 +1898,7 @@ int amd_ivf_search_preassigned(amd_ivf_t* h, size_t n, const float* x, size_t k,
     use_device(h);
     if (n == 0 || k == 0) return 0;
     WallClock wc(h->stream);
-    h->scan_bytes = 0;
+    h->scan_bytes = h->scan_min_bytes = 0;
     h->scan_slots = h->scan_useful = 0;
     h->w_x.ensure(n * h->dpad * sizeof(float));
     upload_rows(h, h->w_x.as<float>(), x, n);
@@ -1915,7 +1921,7 @@ int amd_ivf_search(amd_ivf_t* h, size_t n, const float* x, size_t k, size_t npro
     use_device(h);
     if (n == 0 || k == 0) return 0;
     WallClock wc(h->stream);
-    h->scan_bytes = 0;
+    h->scan_bytes = h->scan_min_bytes = 0;
     h->scan_slots = h->scan_useful = 0;
     h->w_x.ensure(n * h->dpad * sizeof(float));
     upload_rows(h, h->w_x.as<float>(), x, n);
@@ -1982,7 +1988,7 @@ int amd_ivf_range_search_preassigned(amd_ivf_t* h, size_t n, const float* x, flo
         lims[0] = 0;
         return 0;
     }
-    h->scan_bytes = 0;
+    h->scan_bytes = h->scan_min_bytes = 0;
     h->scan_slots = h->scan_useful = 0;
     range_core(h, h->w_x.as<float>(), n, radius, nprobe, h->w_ckeys.as<int64_t>(), qr, lims);
     finish_timing(h, wc.stop());
@@ -2010,7 +2016,7 @@ int amd_ivf_range_search(amd_ivf_t* h, size_t n, const float* x, float radius, s
     h->w_ckeys.ensure(n * nprobe * 8);
     coarse_dev(h, h->w_x.as<float>(), n, nprobe, coarse_mode, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>(),
                h->allow_fused && ix(h)->centroid_range.fusable_with(qr, h->metric));
-    h->scan_bytes = 0;
+    h->scan_bytes = h->scan_min_bytes = 0;
     h->scan_slots = h->scan_useful = 0;
     range_core(h, h->w_x.as<float>(), n, radius, nprobe, h->w_ckeys.as<int64_t>(), qr, lims);
     finish_timing(h, wc.stop());
@@ -2032,7 +2038,7 @@ int amd_ivf_search_resident(amd_ivf_t* h, size_t start, size_t n, size_t k, size
     if (start + n > h->n_resident) throw EngineError("resident query range out of bounds");
     if (n == 0 || k == 0) return 0;
     WallClock wc(h->stream);
-    h->scan_bytes = 0;
+    h->scan_bytes = h->scan_min_bytes = 0;
     h->scan_slots = h->scan_useful = 0;
     search_full(h, h->d_resident.as<float>() + start * h->dpad, n, k, nprobe, coarse_mode, D, I, h->resident_range);
     finish_timing(h, wc.stop());
@@ -2080,7 +2086,7 @@ int amd_ivf_search_timed(amd_ivf_t* h, size_t start, size_t n, size_t k, size_t 
     if (start + n > h->n_resident) throw EngineError("resident query range out of bounds");
     if (n == 0 || k == 0 || nprobe == 0) return 0;
     WallClock wc(h->stream);
-    h->scan_bytes = 0;
+    h->scan_bytes = h->scan_min_bytes = 0;
     h->scan_slots = h->scan_useful = 0;
     timed_core(h, h->d_resident.as<float>() + start * h->dpad, start, n, k, nprobe, budget_ms, coarse_mode, nprobe_used, D, I,
                h->resident_range);
@@ -2094,7 +2100,7 @@ int amd_ivf_search_timed_x(amd_ivf_t* h, size_t n, const float* x, size_t id_off
     use_device(h);
     if (n == 0 || k == 0) return 0;
     WallClock wc(h->stream);
-    h->scan_bytes = 0;
+    h->scan_bytes = h->scan_min_bytes = 0;
     h->scan_slots = h->scan_useful = 0;
     h->w_x.ensure(n * h->dpad * sizeof(float));
     upload_rows(h, h->w_x.as<float>(), x, n);
@@ -2397,7 +2403,7 @@ static void adaptive_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n
     lanes[0] = h;
     for (size_t i = 1; i < nl; i++) lanes[i] = h->kids[i - 1].get();
     for (amd_ivf* L : lanes) {
-        L->scan_bytes = 0;
+        L->scan_bytes = L->scan_min_bytes = 0;
         L->scan_slots = L->scan_useful = 0;
     }
     std::vector<std::exception_ptr> errs(nl);
@@ -2422,12 +2428,13 @@ static void adaptive_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n
     // fold the kids' counters and kernel timings into the handle
     const double wall = wc.stop();
     double ms[NCAT] = {0, 0, 0}, ln[NCAT] = {0, 0, 0};
-    double bytes = 0, slots = 0, useful = 0;
+    double bytes = 0, slots = 0, useful = 0, min_bytes = 0;
     for (amd_ivf* L : lanes) {
         double m[NCAT], c[NCAT];
         L->timer.collect(m, NCAT, c);
         for (int k = 0; k < NCAT; k++) ms[k] += m[k], ln[k] += c[k];
         bytes += L->scan_bytes;
+        min_bytes += L->scan_min_bytes;
         slots += L->scan_slots;
         useful += L->scan_useful;
         if (L != h) {
@@ -2440,6 +2447,7 @@ static void adaptive_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n
     h->timing[3] = wall;
     h->timing[4] = ln[CAT_SCAN];
     h->timing[5] = bytes;
+    h->last_min_bytes = min_bytes;
     h->timing[6] = slots > 0 ? useful / slots : 0;
     h->timing[7] = ln[CAT_SELECT];
 }
@@ -2761,6 +2769,16 @@ int amd_ivf_kmeans(int d, size_t n, const float* x_in, size_t k, int metric, int
 }
 
 int amd_ivf_scan_arith(amd_ivf_t* h) { return ix(h)->last_arith; }
+
+int amd_ivf_set_byte_codes(amd_ivf_t* h, int enable) {
+    h->allow_bytes = enable ? 1 : 0;
+    return 0;
+}
+
+int amd_ivf_last_scan_min_bytes(amd_ivf_t* h, double* bytes) {
+    *bytes = h->last_min_bytes;
+    return 0;
+}
 
 int amd_ivf_last_timing(amd_ivf_t* h, double out[8]) {
     for (int i = 0; i < 8; i++) out[i] = h->timing[i];

@@ -316,6 +316,11 @@ struct PlanArgs {
                                      // [6] scratch (compaction cursor, zeroed by host) [7] MiB of distances [8] tiles qg4 [9] tiles qg8
                                      // [10] queries that may still be unfinished after this round (zeroed by host)
     double* bytes;                   // [0] += algorithmic bytes of the round's distances
+    // [0] += bytes the round cannot avoid moving through HBM: every probed list once (row_bytes per stored vector) and the
+    // rows it writes (4 bytes per distance of a dense round, one mask bit per distance in threshold mode)
+    double* min_bytes;
+    uint32_t row_bytes;
+    int dense_round;
 };
 
 void launch_plan(const PlanArgs& a, hipStream_t s);

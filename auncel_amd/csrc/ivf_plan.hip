@@ -173,6 +173,7 @@ __global__ __launch_bounds__(1024) void plan_prefix_kernel(PlanArgs a) {
         a.counters[1] = s_nseg;
         a.counters[7] = (uint32_t)(s_ndist >> 20);  // MiB of distances, for bookkeeping
         a.bytes[0] += (double)s_ndist * (double)a.d * 4.0;
+        if (a.min_bytes) a.min_bytes[0] += a.dense_round ? (double)s_ndist * 4.0 : (double)s_ndist / 8.0;
     }
 }
 
@@ -251,12 +252,15 @@ __global__ __launch_bounds__(1024) void plan_lists_kernel(PlanArgs a) {
     };
     const uint32_t per = (a.nlist + 1023) / 1024, l0 = t * per, l1 = l0 + per < a.nlist ? l0 + per : a.nlist;
     uint32_t mine[6] = {0, 0, 0, 0, 0, 0};
+    double list_bytes = 0;
     for (uint32_t l = l0; l < l1; l++) {
         uint32_t v[6];
         values(l, v);
 #pragma unroll
         for (int k = 0; k < 6; k++) mine[k] += v[k];
+        if (v[0]) list_bytes += (double)(a.list_off[l + 1] - a.list_off[l]) * (double)a.row_bytes;
     }
+    if (a.min_bytes && list_bytes > 0) atomicAdd(a.min_bytes, list_bytes);
     uint32_t ex[6], tot[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) ex[k] = block_scan_1024(mine[k], s_w, tot[k]);

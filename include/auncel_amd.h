@@ -203,6 +203,10 @@ int amd_ivf_range_results(amd_ivf_t* h, int64_t* labels, float* distances);
  *      bytes of the distances the scan tiles computed (x d x 4), fraction of the computed (query, vector)
  *      slots that were wanted pairs, select launches (= rounds x sub-batches)} */
 int amd_ivf_last_timing(amd_ivf_t* h, double out[8]);
+/* bytes the scans of the last search could not avoid moving through HBM: every probed list once per round (as stored:
+ * d bytes per vector in byte-code mode, 4 d in fp32) plus the rows written (4 bytes per distance of a dense round, one
+ * mask bit per distance in threshold mode).  A lower bound of the traffic, counted on the device by the planning kernels. */
+int amd_ivf_last_scan_min_bytes(amd_ivf_t* h, double* bytes);
 
 /* Arithmetic the list scan of the last search ran in.  All three produce the reference's fp32 distance bit for
  * bit (utils_simd.cpp:391-443 order); the engine picks the cheapest one the data allows:
@@ -211,6 +215,9 @@ int amd_ivf_last_timing(amd_ivf_t* h, double out[8]);
  *   2  byte codes + integer dot products: lists and queries hold integers 0..255 and d * max^2 <= 2^24
  *      (SIFT / BIGANN descriptors), lists are kept as bytes on the device (1/4 of the HBM traffic) */
 int amd_ivf_scan_arith(amd_ivf_t* h);
+/* enable = 0: this handle (the index owner or a search context of amd_ivf_clone) scans the fp32 lists even where the byte
+ * codes qualify (same results; bench.py's fp32_path leg).  enable = 1 restores the default. */
+int amd_ivf_set_byte_codes(amd_ivf_t* h, int enable);
 
 #ifdef __cplusplus
 }

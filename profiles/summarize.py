@@ -83,6 +83,8 @@ for seq in timed_sequences(tr, tj, "Kernel_Name"):
         n = short(r["Kernel_Name"])
         if n.startswith("scan_tiles_kernel"):
             n += " [lists]" if is_list_scan(seq, i, "Kernel_Name") else " [coarse]"
+        elif n.startswith("scan_mfma_kernel"):
+            n += " [lists]"
         agg[n].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
 lines.append(f"# {tag}: bench.py under rocprofv3 (MI355X), timed region = last {steps} steps\n")
 lines.append("## kernel trace (`rocprofv3 --kernel-trace --stats`)\n")
@@ -91,6 +93,7 @@ lines.append("|---|---|---|---|---|---|---|")
 for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
     lines.append(f"| {k} | {len(v)} | {len(v)/steps:.1f} | {sum(v):.3f} | {sum(v)/steps:.3f} | {sum(v)/len(v):.4f} | {max(v):.4f} |")
 scan_ms = sum(sum(v) for k, v in agg.items() if k.endswith("[lists]"))
+lines_scan = {k: v for k, v in agg.items() if k.endswith("[lists]")}
 rf = tj["roofline"]
 nl = rf["launches_per_step"] * steps
 lines.append("")
@@ -121,6 +124,8 @@ for grp in ("fetch", "write", "sq", "misc"):
             n = short(r["Kernel_Name"])
             if n.startswith("scan_tiles_kernel"):
                 n = "scan_tiles_kernel [lists]" if is_list_scan(seq, i, "Kernel_Name") else "scan_tiles_kernel [coarse]"
+            elif n.startswith("scan_mfma_kernel"):
+                n = "scan_mfma_kernel [lists]"  # dense (round 0) and threshold-mode launches together
             e = pmc.setdefault(n, defaultdict(float))
             for c, v in r["c"].items():
                 e[c] += v
@@ -136,7 +141,7 @@ lines.append("|---|---|---|---|---|---|---|---|")
 out = {}
 for k, e in sorted(pmc.items(), key=lambda kv: -kv[1].get("FETCH_SIZE", 0)):
     st = e.get("_steps_fetch", steps)
-    corr = 2.0 if k.startswith("scan_tiles_kernel") else 1.0
+    corr = 2.0 if k.startswith("scan_tiles_kernel") or k.startswith("scan_mfma_kernel") else 1.0
     hbm = (e.get("FETCH_SIZE", 0) * corr + e.get("WRITE_SIZE", 0)) * 1024
     wc = e.get("SQ_WAVE_CYCLES", 0)
     frac = (f"{e.get('SQ_ACTIVE_INST_ANY', 0)/wc:.2f} / {e.get('SQ_WAIT_INST_ANY', 0)/wc:.2f} / {e.get('SQ_WAIT_ANY', 0)/wc:.2f}" if wc else "-")
@@ -149,9 +154,14 @@ for k, e in sorted(pmc.items(), key=lambda kv: -kv[1].get("FETCH_SIZE", 0)):
         out[k]["launches"] = e.get("_launches_fetch", 0)
         out[k]["hbm_bytes_per_launch"] = hbm / max(e.get("_launches_fetch", 1), 1)
         out[k]["algorithmic_bytes_per_launch"] = e.get("_alg_bytes_per_launch", 0)
-ls = out.get("scan_tiles_kernel [lists]")
+ls = out.get("scan_mfma_kernel [lists]") or out.get("scan_tiles_kernel [lists]")
 if ls:
     lines.append("")
+    ns_ = pmc[[k for k in pmc if k.endswith("[lists]")][0]]
+    if ns_.get("_ns_fetch") and ns_.get("_launches_fetch"):
+        per_launch_ms = ns_["_ns_fetch"] / ns_["_launches_fetch"] / 1e6
+        lines.append(f"scan [lists]: {ls['hbm_bytes_per_launch']/1e9:.3f} GB per launch in {per_launch_ms:.3f} ms (the FETCH_SIZE pass) = "
+                     f"{ls['hbm_bytes_per_launch']/1e9/per_launch_ms*1e3:.0f} GB/s = {ls['hbm_bytes_per_launch']/1e9/per_launch_ms*1e3/8000:.2f} of the 8 TB/s HBM peak")
     lines.append(f"scan [lists]: {ls['hbm_bytes_per_launch']/1e9:.3f} GB of HBM traffic per launch against "
                  f"{ls['algorithmic_bytes_per_launch']/1e9:.2f} GB algorithmic (ndis x d x 4 B) = "
                  f"{ls['hbm_bytes_per_launch']/ls['algorithmic_bytes_per_launch']:.3f}x: every list byte fetched once is used by "

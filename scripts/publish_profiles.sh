@@ -1,6 +1,6 @@
 #!/bin/bash
 # copy what scripts/refresh_round.sh brought back under gpurun_out/ into the tracked profiles/ directory
-tag=${1:-r01}
+tag=${1:-r02}
 cp gpurun_out/summary_$tag/${tag}_summary.md gpurun_out/summary_$tag/${tag}_pmc.json gpurun_out/summary_$tag/${tag}_kernel_stats.csv profiles/
 cp gpurun_out/bench_$tag.json profiles/${tag}_bench_line.json
 cp gpurun_out/perf_scan_$tag.txt profiles/${tag}_fixed_nprobe.txt

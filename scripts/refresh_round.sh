@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything the round's committed numbers come from, in one gpurun call:
-#   gpurun --timeout 2700 -- 'bash scripts/refresh_round.sh r01'
-tag=${1:-r01}
+#   gpurun --timeout 2700 -- 'bash scripts/refresh_round.sh r02'
+tag=${1:-r02}
 bash profiles/collect.sh $tag > gpurun_out/collect_$tag.log 2>&1
 python bench.py > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.log
 python scratch/perf_scan.py > gpurun_out/perf_scan_$tag.txt 2> gpurun_out/perf_scan_$tag.log

@@ -94,6 +94,34 @@ def auncel_deep_ip_d64():
     return _auncel(xb, xq, 200, 100, [(10, 0.9, 1.5, 1.0), (20, 0.9, 1.2, 2.0)], metric=METRIC_IP, K=20)
 
 
+def auncel_sift_nl4096():
+    # BASELINE config 2's shape: nlist = 4096 changes max_num (532), the trace count (10), the coarse prefix ranking and the
+    # round planner's scale.  make_golden.py trims what would not fit the repository (trim_big below).
+    xb, xq = synth.sift_like(400000, 400, d=32, nblobs=1200, sigma=45.0, seed=24)
+    c = _auncel(xb, xq, 200, 200, [(10, 0.95, 1.0, 0.5), (10, 0.9, 1.2, 1.0)], nlist=4096, niter=8)
+    c["big"] = 1
+    return c
+
+
+BIG_KEEP_COLS = 704  # coarse ranking columns kept for big cases: the probe loop ends by floor(nlist / 8 * multipler) <= 614
+
+
+def trim_big(out, case):
+    """golden tensors of a `big` case that are O(nlist^2) or O(nq * nlist): replaced by digests / the part the tests read"""
+    import hashlib
+    ts = case["train_num"]
+    t = out.pop("interdis_cem")
+    out["interdis_cem_sha"] = np.array(hashlib.sha256(np.ascontiguousarray(t).tobytes()).hexdigest())
+    out["interdis_cem_sample"] = t[::4099].copy()
+    for k in ("coarse_dis_sse", "coarse_keys_sse"):
+        out[k + "_test"] = out.pop(k)[ts:, :BIG_KEEP_COLS].copy()
+    for k in ("coarse_dis_blas_train", "coarse_keys_blas_train", "train_D", "train_I", "cenTocen"):
+        out.pop(k, None)
+    for k in [k for k in out if k.startswith("raw_trace") or k.endswith("_batched")]:
+        out.pop(k)
+    return out
+
+
 def _kmeans(x, k, niter, metric=METRIC_L2, spherical=0, max_pts=256, seed=1234):
     return dict(kind="kmeans", d=x.shape[1], k=k, niter=niter, metric=metric, spherical=spherical,
                 max_points_per_centroid=max_pts, seed=seed, x=x)
@@ -138,7 +166,7 @@ def io_sift():
 
 
 CASES = {f.__name__: f for f in [io_ragged, io_sift, fixed_sift_l2, fixed_gauss_l2_d96, fixed_deep_ip_d96, fixed_gist_l2_d960,
-                                  fixed_odd_d30, fixed_ragged, fixed_dups, auncel_sift_d32, auncel_gauss_d64, auncel_deep_ip_d64, kmeans_toy, kmeans_void, kmeans_toy_ip, kmeans_sub_int]}
+                                  fixed_odd_d30, fixed_ragged, fixed_dups, auncel_sift_d32, auncel_gauss_d64, auncel_deep_ip_d64, auncel_sift_nl4096, kmeans_toy, kmeans_void, kmeans_toy_ip, kmeans_sub_int]}
 
 
 def input_sha(case):

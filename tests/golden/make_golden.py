@@ -31,6 +31,7 @@ def main():
     for name in names:
         case = cases.CASES[name]()
         kind = case.pop("kind")
+        big = case.pop("big", 0)
         with tempfile.TemporaryDirectory() as tmp:
             fin, fout = os.path.join(tmp, "in.tb"), os.path.join(tmp, "out.tb")
             tbundle.save(fin, case)
@@ -38,6 +39,8 @@ def main():
             subprocess.run([HARNESS, kind, fin, fout], check=True, cwd=tmp, env=env,
                            stdout=subprocess.DEVNULL)
             out = tbundle.load(fout)
+        if big:
+            out = cases.trim_big(out, case)
         out["input_sha"] = np.array(cases.input_sha(case))
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
         sz = os.path.getsize(os.path.join(HERE, name + ".npz"))

@@ -4,7 +4,7 @@ distances bit-exact (stronger than the 1e-4 relative the north star asks for).""
 import numpy as np
 import pytest
 
-from util import KMEANS, AUNCEL, FIXED, load_case, traces_from_gold
+from util import KMEANS, AUNCEL, AUNCEL_BIG, FIXED, load_case, traces_from_gold
 
 pytestmark = pytest.mark.gpu
 
@@ -184,13 +184,48 @@ def test_interdis_table(capi, name):
     assert np.array_equal(bits(h.get_interdis()), bits(gold["interdis_cem"]))
 
 
+@pytest.mark.parametrize("lanes", ["0", "1"])
 @pytest.mark.parametrize("name", AUNCEL)
-def test_adaptive_search(capi, name):
-    """Error_sys::search: per-query error-bounded nprobe (my_nprobe), results, recall log"""
+def test_adaptive_search(capi, monkeypatch, name, lanes):
+    """Error_sys::search: per-query error-bounded nprobe (my_nprobe), results, recall log -- with the one-kernel selection
+    (replay_kernel) and the two-kernel one (compact_kernel + replay_lanes_kernel)"""
+    monkeypatch.setenv("AUNCEL_AMD_LANES", lanes)
     case, gold = load_case(name)
     K, ts, ses = case["max_topk"], case["train_num"], case["test_num"]
     h = make_index(capi, case, gold, gold["centroids"])
     h.set_interdis(None)
+    h.set_tuner(K, traces_from_gold(gold), gold["arcos_list"])
+    h.set_queries(case["xq"])
+    for r in range(len(case["topks"])):
+        for prof in (False, True):
+            req = np.full(ts + ses, case["require_acc"][r], dtype=np.float32)
+            my_np = np.zeros(ts + ses, dtype=np.uint64)
+            t_rec = np.zeros(ts + ses, dtype=np.float32)
+            h.stats(reset=True)
+            D, I = h.search_adaptive(ts, ses, int(case["topks"][r]), float(case["multipler"][r]), float(case["std_m"][r]),
+                                     req, my_np, t_rec, gt_D=gold["gtD"], profile=prof)
+            suf = f"_r{r}" + ("_prof" if prof else "")
+            assert np.array_equal(my_np[ts:], gold["my_nprobe" + suf]), suf
+            assert np.array_equal(I, gold["I" + suf]), suf
+            assert np.array_equal(bits(D), bits(gold["D" + suf])), suf
+            assert np.array_equal(bits(t_rec[ts:]), bits(gold["t_recalls" + suf])), suf
+            st = h.stats()
+            assert [st["nlist"], st["ndis"], st["nheap_updates"]] == list(gold["stats" + suf]), suf
+
+
+@pytest.mark.parametrize("lanes", ["0", "1"])
+@pytest.mark.parametrize("name", AUNCEL_BIG)
+def test_adaptive_search_nlist4096(capi, monkeypatch, name, lanes):
+    """BASELINE config 2's shape against the compiled reference: IVF4096 (max_num 532, ten traces, the prefix coarse
+    ranking, the round planner at 4096 lists), both selection paths"""
+    import hashlib
+    monkeypatch.setenv("AUNCEL_AMD_LANES", lanes)
+    case, gold = load_case(name)
+    K, ts, ses = case["max_topk"], case["train_num"], case["test_num"]
+    h = make_index(capi, case, gold, gold["centroids"])
+    h.set_interdis(None)
+    inter = h.get_interdis()
+    assert hashlib.sha256(np.ascontiguousarray(inter).tobytes()).hexdigest() == str(gold["interdis_cem_sha"])
     h.set_tuner(K, traces_from_gold(gold), gold["arcos_list"])
     h.set_queries(case["xq"])
     for r in range(len(case["topks"])):

@@ -118,3 +118,78 @@ def test_time_bounded_search_follows_the_budget(setup):
     means = [used[b == v].mean() for v in (1.0, 2.0, 4.0, 8.0)]
     assert means[0] <= means[1] <= means[2] <= means[3] and means[3] > means[0], means
     assert np.median(wall / b) < 1.5, (wall, b)
+
+
+def _oracle_lists(pyoracle, h, metric, cen, nlist, d):
+    codes, ids, off = [], [], np.zeros(nlist + 1, dtype=np.uintp)
+    for l in range(nlist):
+        c, i = h.get_list(l)
+        codes.append(c)
+        ids.append(i)
+        off[l + 1] = off[l] + len(i)
+    lists = pyoracle.Lists.__new__(pyoracle.Lists)
+    lists.metric, lists.centroids, lists.nlist, lists.d = metric, cen, nlist, d
+    lists.off, lists.codes, lists.ids = off, np.concatenate(codes), np.concatenate(ids)
+    lists.struct = pyoracle.OrcIndex(metric, d, nlist, pyoracle._s(lists.off), pyoracle._f(lists.codes), pyoracle._i(lists.ids))
+    return lists
+
+
+def test_many_queries_per_list(setup):
+    """every list probed by hundreds of queries (2000 queries x nprobe 64 over 64 lists): the scans' widest shapes (full
+    blocks of 32 / 64 queries per list, several query blocks per chunk) against the pinned oracle, bytes and fp32"""
+    capi, orc = setup["capi"], setup["orc"]
+    from auncel_amd import synth
+    nb, nq, d, nlist = 200_000, 2000, 128, 64
+    xb, xq = synth.sift_like(nb, nq, d=d, nblobs=300, sigma=35.0, seed=77)
+    cen = synth.sample_centroids(xb, nlist, seed=5)
+    h = capi.Handle(d, nlist, capi.METRIC_L2, 0)
+    h.set_centroids(cen)
+    h.add(xb)
+    lists = _oracle_lists(orc, h, 1, cen, nlist, d)
+    S = 64
+    cd, ck = orc.knn(1, xq[:S], cen, nlist, nthreads=8)
+    oD, oI, _ = orc.search_preassigned(lists, xq[:S], 10, ck, cd, nthreads=8)
+    for use_bytes in (True, False):
+        h.set_byte_codes(use_bytes)
+        D, I = h.search(xq, 10, nlist)
+        assert h.scan_arith() == (2 if use_bytes else 1)
+        assert np.array_equal(I[:S], oI) and np.array_equal(D[:S].view(np.uint32), oD.view(np.uint32))
+        assert np.all(np.diff(D, axis=1) >= 0)
+
+
+def test_deep_like_ip_k100_2000_queries(setup):
+    """BASELINE config 3's shape at 2000 queries: inner product, float data, k = 100 (register heap), nprobe 32"""
+    capi, orc = setup["capi"], setup["orc"]
+    from auncel_amd import synth
+    nb, nq, d, nlist, k, nprobe = 300_000, 2000, 96, 256, 100, 32
+    xb, xq = synth.deep_like(nb, nq, d=d, nblobs=500, sigma=0.4, seed=78)
+    cen = synth.sample_centroids(xb, nlist, seed=6)
+    h = capi.Handle(d, nlist, capi.METRIC_IP, 0)
+    h.set_centroids(cen)
+    h.add(xb)
+    D, I = h.search(xq, k, nprobe)
+    lists = _oracle_lists(orc, h, 0, cen, nlist, d)
+    S = 96
+    cd, ck = orc.knn(0, xq[:S], cen, nprobe, nthreads=8)
+    oD, oI, _ = orc.search_preassigned(lists, xq[:S], k, ck, cd, nthreads=8)
+    assert np.array_equal(I[:S], oI) and np.array_equal(D[:S].view(np.uint32), oD.view(np.uint32))
+    assert np.all(np.diff(D, axis=1) <= 0)
+
+
+def test_gist_like_d960_2000_queries(setup):
+    """BASELINE config 5's shape at 2000 queries: d = 960 float data, IVF with short lists, nprobe 32"""
+    capi, orc = setup["capi"], setup["orc"]
+    from auncel_amd import synth
+    nb, nq, d, nlist, k, nprobe = 60_000, 2000, 960, 256, 10, 32
+    xb, xq = synth.gist_like(nb, nq, d=d, nblobs=200, sigma=0.06, seed=79)
+    cen = synth.sample_centroids(xb, nlist, seed=7)
+    h = capi.Handle(d, nlist, capi.METRIC_L2, 0)
+    h.set_centroids(cen)
+    h.add(xb)
+    D, I = h.search(xq, k, nprobe)
+    lists = _oracle_lists(orc, h, 1, cen, nlist, d)
+    S = 64
+    cd, ck = orc.knn(1, xq[:S], cen, nprobe, nthreads=8)
+    oD, oI, _ = orc.search_preassigned(lists, xq[:S], k, ck, cd, nthreads=8)
+    assert np.array_equal(I[:S], oI) and np.array_equal(D[:S].view(np.uint32), oD.view(np.uint32))
+    assert np.all(np.diff(D, axis=1) >= 0)

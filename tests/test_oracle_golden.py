@@ -4,7 +4,7 @@ Bit-exact on ids AND distances for every pinned path."""
 import numpy as np
 import pytest
 
-from util import AUNCEL, FIXED, KMEANS, load_case, traces_from_gold
+from util import AUNCEL, AUNCEL_BIG, FIXED, KMEANS, load_case, traces_from_gold
 
 
 def _lists(oracle, case, gold, cen=None):
@@ -171,6 +171,38 @@ def test_auncel_online(oracle, name):
                             gt_D=gold["gtD"], profile=prof)
             D, I, stats = oracle.search_preassigned(lists, case["xq"][ts:], K, gold["coarse_keys_sse"][ts:],
                                                     gold["coarse_dis_sse"][ts:], tuner=st, offset=ts)
+            suf = f"_r{r}" + ("_prof" if prof else "")
+            assert np.array_equal(tun.my_nprobe[ts:].astype(np.uint64), gold["my_nprobe" + suf]), suf
+            assert np.array_equal(I, gold["I" + suf]), suf
+            assert np.array_equal(D.view(np.uint32), gold["D" + suf].view(np.uint32)), suf
+            assert np.array_equal(tun.t_recalls[ts:].view(np.uint32), gold["t_recalls" + suf].view(np.uint32)), suf
+            assert np.array_equal(stats, gold["stats" + suf]), suf
+
+
+@pytest.mark.parametrize("name", AUNCEL_BIG)
+def test_auncel_online_nlist4096(oracle, name):
+    """BASELINE config 2's shape (IVF4096: max_num 532, ten traces): the restatement against the compiled reference's run.
+    The O(nlist^2) table is pinned through its digest, the coarse ranking through the columns the probe loop can reach."""
+    import hashlib
+    case, gold = load_case(name)
+    K, ts, ses, nlist = case["max_topk"], case["train_num"], case["test_num"], case["nlist"]
+    cen = gold["centroids"]
+    inter = oracle.interdis(case["metric"], cen)
+    assert hashlib.sha256(np.ascontiguousarray(inter).tobytes()).hexdigest() == str(gold["interdis_cem_sha"])
+    assert np.array_equal(inter[::4099].view(np.uint32), gold["interdis_cem_sample"].view(np.uint32))
+    lists = _lists(oracle, case, gold, cen)
+    traces = traces_from_gold(gold)
+    assert len(traces) == 10
+    ck, cd = gold["coarse_keys_sse_test"], gold["coarse_dis_sse_test"]
+    for i in range(0, ses, 13):
+        dtb, _ = oracle.set_online(case["metric"], nlist, cd[i], ck[i], inter, gold["arcos_list"])
+        assert np.array_equal(dtb.view(np.uint32), gold["disToBoundary"][i].view(np.uint32))
+    for r in range(len(case["topks"])):
+        for prof in (False, True):
+            tun = oracle.Tuner(inter, traces, K, ts + ses, arcos=gold["arcos_list"])
+            req = np.full(ts + ses, case["require_acc"][r], dtype=np.float32)
+            st = tun.struct(int(case["topks"][r]), req, float(case["multipler"][r]), float(case["std_m"][r]), gt_D=gold["gtD"], profile=prof)
+            D, I, stats = oracle.search_preassigned(lists, case["xq"][ts:], K, ck, cd, tuner=st, offset=ts)
             suf = f"_r{r}" + ("_prof" if prof else "")
             assert np.array_equal(tun.my_nprobe[ts:].astype(np.uint64), gold["my_nprobe" + suf]), suf
             assert np.array_equal(I, gold["I" + suf]), suf

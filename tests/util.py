@@ -21,7 +21,8 @@ def load_case(name):
 
 
 FIXED = [n for n in cases.CASES if n.startswith("fixed_")]
-AUNCEL = [n for n in cases.CASES if n.startswith("auncel_")]
+AUNCEL_BIG = ["auncel_sift_nl4096"]  # nlist = 4096 (BASELINE config 2's shape); golden trimmed by cases.trim_big
+AUNCEL = [n for n in cases.CASES if n.startswith("auncel_") and n not in AUNCEL_BIG]
 KMEANS = [n for n in cases.CASES if n.startswith("kmeans_")]
 
 
