@@ -46,7 +46,7 @@ def build_host(force=False):
     if not force and os.path.exists(HOST_LIB) and all(os.path.getmtime(p) <= os.path.getmtime(HOST_LIB) for p in srcs + [LIB]):
         return HOST_LIB
     cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", os.path.join(HOST_DIR, "faiss_amd.cpp"), "-o", HOST_LIB,
-           "-L" + LIBDIR, "-launcel_amd", "-Wl,-rpath,$ORIGIN"]
+           "-L" + LIBDIR, "-launcel_amd", "-Wl,-rpath,$ORIGIN", "-pthread"]
     subprocess.run(cmd, check=True)
     return HOST_LIB
 

@@ -24,6 +24,11 @@ struct Index {
     virtual void set_tune_mode() { tune = true; }
     virtual void set_tune_off() { tune = false; }
 
+    /// MI355X this index's engine lives on: -1 = AUNCEL_AMD_DEVICE or device 0.  Not in the reference (its indexes are host
+    /// objects); IndexShards::add_shard deals unassigned shards round-robin over the node's GPUs, one host thread each.
+    int amd_device = -1;
+    virtual void set_device(int device) { amd_device = device; }
+
     int d;
     idx_t ntotal;
     bool verbose;

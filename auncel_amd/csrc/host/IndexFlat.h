@@ -24,6 +24,9 @@ struct IndexFlat : Index {
 
     /// which coarse mode search() asks the engine for: -1 reference switch (default), 0 exact, 1 GEMM
     int coarse_mode = -1;
+    /// bumped by add() / reset(): device copies of the vectors (here and in an IndexIVF using this as its quantizer)
+    /// are refreshed when it moves
+    size_t version = 0;
 
    private:
     mutable amd_ivf* gpu_ = nullptr;

@@ -55,6 +55,8 @@ struct IndexIVF : Index, Level1Quantizer {
     ~IndexIVF() override;
 
     void set_tune_mode() override;
+    /// the engine of this index and of its flat quantizer move together (before their first use)
+    void set_device(int device) override;
     void set_tune_off() override;
     void set_train_mode();
     void set_train_off();
@@ -100,6 +102,8 @@ struct IndexIVF : Index, Level1Quantizer {
     mutable amd_ivf* gpu_ = nullptr;
     mutable size_t lists_version_ = (size_t)-1;
     mutable size_t centroid_count_ = (size_t)-1;
+    mutable size_t centroid_version_ = (size_t)-1;
+    mutable float interdis_print_[3] = {0, 0, 0};
     mutable size_t traces_version_ = (size_t)-1;
     mutable const float* interdis_uploaded_ = nullptr;
     mutable size_t interdis_size_ = 0;

@@ -12,6 +12,9 @@
 #include <random>
 #include <sstream>
 #include <stdexcept>
+#include <thread>
+#include <exception>
+#include <vector>
 
 #include "../../../include/auncel_amd.h"
 #include "../kmeans_host.h"
@@ -38,7 +41,8 @@ void chk(int rc, const char* what) {
 }
 #define AMD(call) chk(call, #call)
 
-int device_id() {
+int device_id(int assigned = -1) {
+    if (assigned >= 0) return assigned;
     const char* e = getenv("AUNCEL_AMD_DEVICE");
     return e ? atoi(e) : 0;
 }
@@ -68,12 +72,14 @@ void IndexFlat::add(idx_t n, const float* x) {
     xb.insert(xb.end(), x, x + n * d);
     ntotal += n;
     gpu_ntotal_ = -1;  // the device copy is stale
+    version++;
 }
 
 void IndexFlat::reset() {
     xb.clear();
     ntotal = 0;
     gpu_ntotal_ = -1;
+    version++;
 }
 
 void IndexFlat::search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const {
@@ -81,7 +87,7 @@ void IndexFlat::search(idx_t n, const float* x, idx_t k, float* distances, idx_t
     if (!gpu_ || gpu_ntotal_ != ntotal) {
         if (gpu_) amd_ivf_destroy(gpu_);
         gpu_ = nullptr;
-        AMD(amd_ivf_create(d, (size_t)ntotal, (int)metric_type, device_id(), &gpu_));
+        AMD(amd_ivf_create(d, (size_t)ntotal, (int)metric_type, device_id(amd_device), &gpu_));
         AMD(amd_ivf_set_centroids(gpu_, xb.data()));
         gpu_ntotal_ = ntotal;
     }
@@ -234,7 +240,7 @@ void Clustering::train(idx_t nx, const float* x_in, Index& index) {
             const size_t o = obj.size();
             obj.resize(o + niter);
             AMD(amd_ivf_kmeans((int)d, (size_t)nx, x_in, k, (int)fl->metric_type, niter, seed, (size_t)max_points_per_centroid,
-                               spherical ? 1 : 0, int_centroids ? 1 : 0, fl->coarse_mode, device_id(), centroids.data(), obj.data() + o));
+                               spherical ? 1 : 0, int_centroids ? 1 : 0, fl->coarse_mode, device_id(fl->amd_device), centroids.data(), obj.data() + o));
             if ((size_t)nx == k) obj.resize(o);  // the corner case copies the training set and records no objective
             index.reset();
             index.add(k, centroids.data());
@@ -334,7 +340,7 @@ void Level1Quantizer::train_q1(size_t n, const float* x, bool verbose, MetricTyp
     if (quantizer->tune) {
         // centroid-to-centroid table of the Auncel geometry (IndexIVF.cpp:97-111), computed on the GPU
         amd_ivf* g = nullptr;
-        AMD(amd_ivf_create((int)d, nlist, (int)metric_type, device_id(), &g));
+        AMD(amd_ivf_create((int)d, nlist, (int)metric_type, device_id(quantizer->amd_device), &g));
         interdis_cem.resize(nlist * (nlist - 1) / 2);
         int rc = amd_ivf_set_centroids(g, cen.data());
         if (rc == 0) rc = amd_ivf_set_interdis(g, nullptr);
@@ -431,6 +437,12 @@ void IndexIVF::train(idx_t n, const float* x) {
 
 void IndexIVF::add(idx_t n, const float* x) { add_with_ids(n, x, nullptr); }
 
+void IndexIVF::set_device(int device) {
+    FAISS_THROW_IF_NOT_MSG(gpu_ == nullptr || device == amd_device, "the index already lives on another device");
+    amd_device = device;
+    if (quantizer) quantizer->set_device(device);
+}
+
 void IndexIVF::replace_invlists(InvertedLists* il, bool own) {
     if (own_invlists) delete invlists;
     invlists = il;
@@ -444,13 +456,16 @@ amd_ivf* IndexIVF::engine() const {
 }
 
 void IndexIVF::sync_engine(bool need_tuner) const {
-    if (!gpu_) AMD(amd_ivf_create(d, nlist, (int)metric_type, device_id(), &gpu_));
+    if (!gpu_) AMD(amd_ivf_create(d, nlist, (int)metric_type, device_id(amd_device), &gpu_));
     const IndexFlat* qf = dynamic_cast<const IndexFlat*>(quantizer);
     FAISS_THROW_IF_NOT_MSG(qf != nullptr, "the MI355X engine needs a flat coarse quantizer");
     FAISS_THROW_IF_NOT_MSG((size_t)qf->ntotal == nlist, "quantizer is not trained (ntotal != nlist)");
-    if (centroid_count_ != nlist) {
+    // (the quantizer's version, not just its size: retraining with the same nlist must reach the device too)
+    if (centroid_count_ != nlist || centroid_version_ != qf->version) {
         AMD(amd_ivf_set_centroids(gpu_, qf->xb.data()));
         centroid_count_ = nlist;
+        centroid_version_ = qf->version;
+        interdis_uploaded_ = nullptr;  // the centroid table belongs to the old centroids
     }
     if (lists_version_ != invlists->version) {
         FAISS_THROW_IF_NOT_MSG(code_size == sizeof(float) * d, "IVF-Flat codes expected");
@@ -466,10 +481,15 @@ void IndexIVF::sync_engine(bool need_tuner) const {
         lists_version_ = invlists->version;
         resident_ptr_ = nullptr;  // nothing else to refresh, but keep the invariant explicit
     }
-    if (!interdis_cem.empty() && (interdis_uploaded_ != interdis_cem.data() || interdis_size_ != interdis_cem.size())) {
+    // interdis_cem is a public vector the caller may refill in place (train_q1 does): pointer and size alone would miss
+    // that, so three of its values are remembered as well
+    const size_t isz = interdis_cem.size();
+    const float print[3] = {isz ? interdis_cem[0] : 0.f, isz ? interdis_cem[isz / 2] : 0.f, isz ? interdis_cem[isz - 1] : 0.f};
+    if (isz && (interdis_uploaded_ != interdis_cem.data() || interdis_size_ != isz || memcmp(print, interdis_print_, sizeof(print)) != 0)) {
         AMD(amd_ivf_set_interdis(gpu_, interdis_cem.data()));
         interdis_uploaded_ = interdis_cem.data();
-        interdis_size_ = interdis_cem.size();
+        interdis_size_ = isz;
+        memcpy(interdis_print_, print, sizeof(print));
     }
     if (need_tuner) {
         FAISS_THROW_IF_NOT_MSG((t != nullptr), "Search tune start can't start without IVF_pro init and training");
@@ -1005,13 +1025,42 @@ void IndexShards::add_shard(Index* index) {
         metric_type = index->metric_type;
     }
     FAISS_THROW_IF_NOT_MSG(index->d == d && index->metric_type == metric_type, "shards must agree on d and metric");
+    // one MI355X per shard: a shard without a device of its own takes the next one of the node, round robin
+    if (index->amd_device < 0 && !getenv("AUNCEL_AMD_DEVICE")) {
+        int ndev = 0;
+        if (amd_ivf_device_count(&ndev) == 0 && ndev > 1) index->set_device((int)(shards.size() % (size_t)ndev));
+    }
     shards.push_back(index);
     ntotal += index->ntotal;
     is_trained = index->is_trained;
 }
 
+// f(shard number, shard) on every shard: from one host thread per shard when `threaded` (the reference keeps a WorkerThread
+// per shard, ThreadedIndex-inl.h:121-150; each thread then drives its own GPU through its shard's engine handle), one
+// after the other otherwise.  The first exception is rethrown once every shard has returned.
+template <class F> static void run_on_shards(const std::vector<Index*>& shards, bool threaded, F f) {
+    const size_t ns = shards.size();
+    if (!threaded || ns < 2) {
+        for (size_t i = 0; i < ns; i++) f(i, shards[i]);
+        return;
+    }
+    std::vector<std::exception_ptr> errs(ns);
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < ns; i++)
+        th.emplace_back([&, i] {
+            try {
+                f(i, shards[i]);
+            } catch (...) {
+                errs[i] = std::current_exception();
+            }
+        });
+    for (auto& t : th) t.join();
+    for (auto& e : errs)
+        if (e) std::rethrow_exception(e);
+}
+
 void IndexShards::train(idx_t n, const float* x) {
-    for (Index* s : shards) s->train(n, x);
+    run_on_shards(shards, threaded, [&](size_t, Index* s) { s->train(n, x); });
     is_trained = true;
 }
 
@@ -1024,16 +1073,17 @@ void IndexShards::add(idx_t n, const float* x) {
     // contiguous n/nshard slices, as the reference does without ids (tests/test_threaded_index.cpp:205-253)
     const idx_t ns = count();
     FAISS_THROW_IF_NOT(ns > 0);
-    for (idx_t i = 0; i < ns; i++) {
-        idx_t i0 = i * n / ns, i1 = (i + 1) * n / ns;
+    const idx_t base = ntotal;
+    run_on_shards(shards, threaded, [&](size_t si, Index* sh) {
+        const idx_t i = (idx_t)si, i0 = i * n / ns, i1 = (i + 1) * n / ns;
         if (successive_ids) {
-            shards[i]->add(i1 - i0, x + i0 * d);
+            sh->add(i1 - i0, x + i0 * d);
         } else {
             std::vector<long> ids(i1 - i0);
-            for (idx_t j = i0; j < i1; j++) ids[j - i0] = ntotal + j;
-            shards[i]->add_with_ids(i1 - i0, x + i0 * d, ids.data());
+            for (idx_t j = i0; j < i1; j++) ids[j - i0] = base + j;
+            sh->add_with_ids(i1 - i0, x + i0 * d, ids.data());
         }
-    }
+    });
     ntotal += n;
 }
 
@@ -1041,8 +1091,10 @@ void IndexShards::search(idx_t n, const float* x, idx_t k, float* distances, idx
     const size_t ns = shards.size();
     std::vector<float> all_D(ns * n * k);
     std::vector<int64_t> all_I(ns * n * k);
-    // one engine (one GPU) per shard: the calls are independent and overlap on their own streams
-    for (size_t s = 0; s < ns; s++) shards[s]->search(n, x, k, all_D.data() + s * n * k, reinterpret_cast<idx_t*>(all_I.data()) + s * n * k);
+    // IndexShards.cpp:261-311: every shard searches the whole batch (its own lists, its own GPU), rows merged on the host
+    run_on_shards(shards, threaded, [&](size_t s, Index* sh) {
+        sh->search(n, x, k, all_D.data() + s * n * k, reinterpret_cast<idx_t*>(all_I.data()) + s * n * k);
+    });
     if (successive_ids) {
         long base = 0;
         for (size_t s = 0; s < ns; s++) {

@@ -112,6 +112,125 @@ def recall_dist(D, gtD, topk):
     return (D[:, :topk] <= thr).sum(1) / float(topk)
 
 
+def run_shards(args, torch, dist, capi, rank, world, local, dev, red_dev):
+    """BASELINE configs[3]: SIFT-10M-like, IVF4096,Flat, k = topk, fixed nprobe; the inverted lists are sharded by list id over
+    the ranks (the reference's IndexShards over sub-indexes that share one coarse quantizer, Auncel/IndexShards.cpp:261-311;
+    owner balanced by list bytes), every rank scans the probed lists it owns for the whole batch, the per-rank (D, I) tables
+    (n x k x 12 bytes) are gathered on rank 0 and merged there with merge_tables semantics (IndexShards.cpp:44-105).  No
+    data-path collective.  Strong scaling: database and batch are fixed as N grows.  N = 1 runs the same code with one shard.
+    A step = one such search + merge over the whole batch of `--test` resident queries."""
+    from auncel_amd import sharding
+    d, nlist, k, nq = args.d, args.nlist, args.topk, args.test
+    t0 = time.time()
+    xb_t, _, draw = gen_data(torch, dev, args.nb, 0, d, args.blobs, args.sigma, 1235)
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)  # the same queries on every rank
+    xq_t = draw(nq, g)
+    nvalid = min(1000, nq)
+    gtD, _ = ground_truth(torch, xb_t, xq_t[:nvalid], k)
+    xb = xb_t.cpu().numpy()
+    xq = xq_t.cpu().numpy()
+    del xb_t, xq_t
+    torch.cuda.empty_cache()
+    cen, _ = capi.kmeans(capi.METRIC_L2, xb, nlist, niter=25, coarse_mode=0, device=local)  # the reference's IVF training
+    # every rank derives the same list assignment with the engine's exact assignment kernel, then keeps the lists it owns
+    q = capi.Handle(d, nlist, capi.METRIC_L2, local)
+    q.set_centroids(cen)
+    assign = np.empty(args.nb, dtype=np.int64)
+    for i0 in range(0, args.nb, 1 << 20):
+        assign[i0:i0 + (1 << 20)] = q.coarse(xb[i0:i0 + (1 << 20)], 1, mode=0)[1][:, 0]
+    del q
+    sizes = np.bincount(assign, minlength=nlist)
+    owner = sharding.assign_owners(sizes, world)
+    mine = sharding.local_assignment(assign, owner, rank)
+    h = capi.Handle(d, nlist, capi.METRIC_L2, local)
+    h.set_centroids(cen)
+    keep = mine >= 0
+    h.add(xb[keep], xids=np.nonzero(keep)[0].astype(np.int64), precomputed_idx=mine[keep])
+    del xb
+    h.set_queries(xq)
+    log(f"shards: data, k-means, assignment, {int(keep.sum())} of {args.nb} vectors on rank 0: {time.time() - t0:.1f}s")
+
+    acc = {}
+
+    def step():
+        D, I = h.search_resident(0, nq, k, args.nprobe)
+        tm = h.last_timing()
+        for key in ("scan_ms", "scan_launches", "scan_min_bytes", "coarse_ms", "select_ms"):
+            acc[key] = acc.get(key, 0.0) + tm[key]
+        return sharding.gather_and_merge(D, I, capi.METRIC_L2, capi.merge_tables, dist if world > 1 else None)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    acc.clear()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        D, I = out
+        rec = recall_dist(D[:nvalid], gtD, k)
+        load = np.bincount(owner, weights=sizes, minlength=world)
+        launches = max(acc["scan_launches"], 1)
+        per_launch = acc["scan_min_bytes"] / launches
+        achieved = (per_launch / 1e9) / (acc["scan_ms"] / launches / 1e3) if acc["scan_ms"] > 0 else None
+        line = {
+            "metric": "queries/sec, SIFT-10M d=128 IVF4096 k=10 fixed nprobe, IndexShards (lists sharded by list id, host top-k merge)",
+            "value": nq * args.steps / elapsed, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u8" if h.scan_arith() == 2 else "f32", "data": "synthetic",
+            "config": {"workload": f"SIFT-{args.nb // 1000000}M-like d={d} IVF{nlist},Flat k={k} nprobe={args.nprobe}, IndexShards over {world} GPU(s): "
+                                   f"lists sharded by list id, batch {nq} resident queries searched by every shard, host merge_tables on rank 0",
+                       "nb": args.nb, "sigma": args.sigma, "nprobe": args.nprobe, "recall_at_k_mean": float(rec.mean()),
+                       # distances of the merged result (sorted rows: identical for any number of shards, whatever the order
+                       # the merge gives equal distances)
+                       "distances_sha256": __import__("hashlib").sha256(np.ascontiguousarray(D).tobytes()).hexdigest(),
+                       "shard_bytes_max_over_min": float(load.max() / max(load.min(), 1))},
+            "roofline": {"bound": "hbm", "kernel": "scan_mfma_kernel" if h.scan_arith() == 2 else "scan_tiles_kernel", "achieved": achieved,
+                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0 if achieved else None, "traffic": None,
+                         "traffic_source": "engine's lower bound (every probed list once per round + rows written), rank 0's shard",
+                         "min_bytes_per_launch": per_launch, "avg_launch_ms": acc["scan_ms"] / launches, "launches_per_step": launches / args.steps,
+                         "other_kernels_ms_per_step": {"coarse": acc["coarse_ms"] / args.steps, "select": acc["select_ms"] / args.steps}},
+        }
+        if world == 1 and not args.no_cpu:
+            # CPU side: the pinned restatement of IndexIVF::search (coarse + search_preassigned) on a bounded sample, all host cores
+            from oracle import pyoracle
+            S = min(args.cpu_sample, 2000, nq)
+            codes, ids, off = [], [], np.zeros(nlist + 1, dtype=np.uintp)
+            for l in range(nlist):
+                c, i_ = h.get_list(l)
+                codes.append(c)
+                ids.append(i_)
+                off[l + 1] = off[l] + len(i_)
+            lists = pyoracle.Lists.__new__(pyoracle.Lists)
+            lists.metric, lists.centroids, lists.nlist, lists.d = pyoracle.METRIC_L2, cen, nlist, d
+            lists.off, lists.codes, lists.ids = off, np.concatenate(codes), np.concatenate(ids)
+            del codes, ids
+            lists.struct = pyoracle.OrcIndex(lists.metric, d, nlist, pyoracle._s(lists.off), pyoracle._f(lists.codes), pyoracle._i(lists.ids))
+            cores = host_cores()
+            tc = time.perf_counter()
+            cd, ck = pyoracle.knn(pyoracle.METRIC_L2, xq[:S], cen, args.nprobe, nthreads=cores)
+            oD, oI, _ = pyoracle.search_preassigned(lists, xq[:S], k, ck, cd, nthreads=cores)
+            cpu_s = time.perf_counter() - tc
+            line["cpu_baseline"] = {"value": S / cpu_s, "unit": "queries/s", "cores": cores, "kind": "port",
+                                    "sample": f"first {S} of the {nq} queries, same lists, coarse + search_preassigned, OpenMP over queries",
+                                    "gpu_matches_cpu_on_sample": bool(np.array_equal(oI, I[:S]) and np.array_equal(oD, D[:S]))}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,6 +248,10 @@ def main():
     ap.add_argument("--bound", type=float, default=0.95)
     ap.add_argument("--std-m", type=float, default=1.0)
     ap.add_argument("--cpu-sample", type=int, default=5000)
+    ap.add_argument("--mode", choices=["adaptive", "shards"], default="adaptive",
+                    help="adaptive: BASELINE config 2, the headline (replicas at N > 1).  shards: config 4 -- fixed nprobe, the inverted "
+                         "lists sharded by list id over the N GPUs (IndexShards), per-GPU partial top-k merged on the host; strong scaling")
+    ap.add_argument("--nprobe", type=int, default=32, help="--mode shards: probes per query")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-legs", action="store_true",
                     help="skip the untimed extra legs (one batch at a time, fp32 path, guaranteed-bound point): profiling runs")
@@ -175,6 +298,9 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the max-over-ranks reduction lives
+
+    if args.mode == "shards":
+        return run_shards(args, torch, dist, capi, rank, world, local, dev, red_dev)
 
     d, nlist, K, topk, ts, ses = args.d, args.nlist, args.maxtopk, args.topk, args.train, args.test
     t0 = time.time()

@@ -186,13 +186,19 @@ static int run_fixed(const tb::Bundle& in) {
             shards.add_shard(sub.get());
             subs.push_back(std::move(sub));
         }
-        for (size_t ki = 0; ki < ks.numel(); ki++) {
-            size_t k = ks.as<int64_t>()[ki];
-            std::vector<float> D(nq * k);
-            std::vector<idx_t> I(nq * k);
-            shards.search(nq, xq.as<float>(), k, D.data(), I.data());
-            expect(same_i(I.data(), in.get("I_shards_k" + std::to_string(k)).as<int64_t>(), nq * k), "shards ids");
-            expect(same_f(D.data(), in.get("D_shards_k" + std::to_string(k)).as<float>(), nq * k), "shards distances");
+        // serial, then one host thread per shard (IndexShards(threaded = true): each thread drives its shard's engine,
+        // on its own GPU where the node has several)
+        for (int threaded = 0; threaded < 2; threaded++) {
+            shards.threaded = threaded != 0;
+            for (size_t ki = 0; ki < ks.numel(); ki++) {
+                size_t k = ks.as<int64_t>()[ki];
+                std::vector<float> D(nq * k);
+                std::vector<idx_t> I(nq * k);
+                shards.search(nq, xq.as<float>(), k, D.data(), I.data());
+                const std::string tag = threaded ? " (threaded)" : "";
+                expect(same_i(I.data(), in.get("I_shards_k" + std::to_string(k)).as<int64_t>(), nq * k), "shards ids" + tag);
+                expect(same_f(D.data(), in.get("D_shards_k" + std::to_string(k)).as<float>(), nq * k), "shards distances" + tag);
+            }
         }
     }
     return g_fail;
