@@ -3,6 +3,7 @@
 // file is bookkeeping, argument checking and the host-only pieces the reference also keeps on the
 // host (list storage, Trace::SB ordering, the acos table, shard merging, k-means means).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -579,13 +580,30 @@ void IndexIVF::search(idx_t n, const float* x, idx_t k, float* distances, idx_t*
     sync_engine(true);
     static_assert(sizeof(size_t) == sizeof(uint64_t), "my_nprobe layout");
     uint64_t* np = reinterpret_cast<uint64_t*>(t->my_nprobe);
+    // error_pro::overhead_profile (IVF_pro.h:95; IndexIVF.cpp:529-539,614,634-637): rule on every probe, no stop before nlist / 8
+    const int flags = (t->profile ? 1 : 0) | (t->overhead_profile ? 2 : 0);
     if (resident)
         AMD(amd_ivf_search_adaptive(gpu_, offset, (size_t)n, t->query_topk, t->multipler, t->std_m, t->require_acc, t->train_D,
-                                    t->profile ? 1 : 0, coarse_mode, np, t->t_recalls, distances, i64(labels)));
+                                    flags, coarse_mode, np, t->t_recalls, distances, i64(labels)));
     else
         AMD(amd_ivf_search_adaptive_x(gpu_, (size_t)n, x, offset, t->query_topk, t->multipler, t->std_m, t->require_acc, t->train_D,
-                                      t->profile ? 1 : 0, coarse_mode, np, t->t_recalls, distances, i64(labels)));
+                                      flags, coarse_mode, np, t->t_recalls, distances, i64(labels)));
     fold_stats();
+    if (t->overhead_profile) {
+        // The reference sums the time of its scan_one_list calls inside the loop and prints it (IndexIVF.cpp:679-680) for
+        // eval/overhead.cpp to set against the whole search ("With ELP").  Kernels of a batch cannot be split that way: the
+        // figure here is the same search without the rule -- the plain probe loop over nlist / 8 probes, k = max_topk --
+        // timed on the host.  Its results equal the ones just returned (same probes, same heap); they are discarded.
+        std::vector<float> D2((size_t)n * k);
+        std::vector<idx_t> I2((size_t)n * k);
+        const auto t0 = std::chrono::steady_clock::now();
+        if (resident) AMD(amd_ivf_search_resident(gpu_, offset, (size_t)n, (size_t)k, nlist / 8, coarse_mode, D2.data(), i64(I2.data())));
+        else AMD(amd_ivf_search(gpu_, (size_t)n, x, (size_t)k, nlist / 8, coarse_mode, D2.data(), i64(I2.data())));
+        const double overh = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        size_t st[4];
+        amd_ivf_stats(gpu_, st, 1);  // (not part of the search the caller asked for)
+        printf("Without ELP search Time: %.3f s\n", overh);
+    }
 }
 
 void IndexIVF::search_preassigned(idx_t n, const float* x, idx_t k, const idx_t* keys, const float* coarse_dis,

@@ -1124,7 +1124,8 @@ TunerDev make_tuner(amd_ivf* h, size_t query_topk, float multipler, float std_m,
                     unsigned long long* d_np, float* d_tr, int profile) {
     TunerDev t{};
     t.enabled = 1;
-    t.profile = profile;
+    t.profile = profile & 1;
+    t.overhead = (profile & 2) ? 1 : 0;
     t.max_topk = (uint32_t)ix(h)->tuner_max_topk;
     t.query_topk = (uint32_t)query_topk;
     t.ntraces = (uint32_t)ix(h)->tuner_ntraces;

@@ -142,6 +142,7 @@ inline __host__ __device__ uint32_t scan_tile_vecs(uint32_t qg) { return (qg >= 
 struct TunerDev {
     int enabled;
     int profile;
+    int overhead;   // error_pro::overhead_profile: the rule runs on every probe, its verdict is ignored, the loop ends at nlist / 8
     uint32_t max_topk, query_topk, ntraces;
     float multipler, std_m;
     const float* interdis;     // packed upper-triangular centroid table

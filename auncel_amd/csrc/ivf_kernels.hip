@@ -1447,7 +1447,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
             // IndexIVF.cpp:551-638.  Once my_nprobe is known nothing the rule computes can change the
             // outcome any more (L2: no throwing path left), so only the stop test remains.
             const uint32_t stage = ik + 1;
-            const bool fired = IsMax && np != 0;
+            const bool overhead = a.tuner.overhead != 0;  // IndexIVF.cpp:614,634-637
+            const bool fired = IsMax && np != 0 && !overhead;
             if (!fired) {
                 uint32_t ind = 0;
                 const uint32_t tmp_stage = stage >= nlist / 8 ? nlist / 8 - 1 : stage;
@@ -1492,18 +1493,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
                     if (stoped >= stops) recall = 1;
                 }
                 pre_val = max_val;
-                if (recall >= racc && np == 0) {
-                    np = (unsigned long long)((float)stage * a.tuner.multipler);
-                    if (np >= nlist && lane == 0) a.tuner.t_recalls[id_q] = 1.f;
-                }
-                if (stage >= nlist / 8 && np == 0) {
-                    np = (unsigned long long)((float)stage * a.tuner.multipler);
-                    if (np >= nlist && lane == 0) a.tuner.t_recalls[id_q] = 1.f;
+                if (!overhead) {
+                    if (recall >= racc && np == 0) {
+                        np = (unsigned long long)((float)stage * a.tuner.multipler);
+                        if (np >= nlist && lane == 0) a.tuner.t_recalls[id_q] = 1.f;
+                    }
+                    if (stage >= nlist / 8 && np == 0) {
+                        np = (unsigned long long)((float)stage * a.tuner.multipler);
+                        if (np >= nlist && lane == 0) a.tuner.t_recalls[id_q] = 1.f;
+                    }
                 }
                 err = wave_err(err);
                 if (err) finished = true;
             }
-            if (np != 0 && np <= stage) {
+            if (overhead) {
+                if (stage >= nlist / 8) finished = true;
+            } else if (np != 0 && np <= stage) {
                 if (a.tuner.profile) {
                     if (RH) rh_store(rh, hval, href, k, lane, false);
                     uint32_t hits = 0;
@@ -2379,6 +2384,7 @@ bool select_lanes_supported(const ReplayArgs& a) {
     if (!a.seg_by_slot || !a.seg_begin || !a.qsel || !a.cand) return false;
     if (a.tuner.enabled && (a.tuner.query_topk > (uint32_t)LANES_BEST || a.tuner.query_topk > (uint32_t)a.k)) return false;
     if (a.tuner.enabled && a.trace_cap > 4096) return false;
+    if (a.tuner.enabled && a.tuner.overhead) return false;
     return true;
 }
 

@@ -121,7 +121,12 @@ int amd_ivf_set_tuner(amd_ivf_t* h, size_t max_topk, size_t ntraces, const size_
  * on resident queries [start, start+n): per-query adaptive stop  [IndexIVF.cpp:507-638, profile.cpp:211-227].
  * require_acc / gt_D (may be NULL unless profile) / my_nprobe / t_recalls are indexed by absolute query id
  * like the reference's arrays (id_q = i + offset, IndexIVF.cpp:487); my_nprobe entries must be 0 on entry
- * for queries that have not been searched (Error_sys::set_queries zeroes them). */
+ * for queries that have not been searched (Error_sys::set_queries zeroes them).
+ * profile: bit 0 = error_pro::profile (t_recalls gets the true recall at the stop, IndexIVF.cpp:628-631);
+ *          bit 1 = error_pro::overhead_profile (IndexIVF.cpp:529-539,614,634-637; eval/overhead.cpp:284-290): the rule is
+ *          evaluated on every probe, its verdict ignored, every query runs to stage nlist / 8 and my_nprobe stays as
+ *          passed.  The reference prints the time of the list scans alone next to it; here that is the same search without
+ *          the rule, amd_ivf_search_resident(start, n, max_topk, nlist / 8) (the class mirror times both). */
 int amd_ivf_search_adaptive(amd_ivf_t* h, size_t start, size_t n, size_t query_topk, float multipler, float std_m,
                             const float* require_acc, const float* gt_D, int profile, int coarse_mode,
                             uint64_t* my_nprobe, float* t_recalls, float* D, int64_t* I);

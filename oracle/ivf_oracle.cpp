@@ -352,6 +352,10 @@ void search_one(const orc_index_t* ix, size_t i, const float* x, size_t k, size_
             pre_val = max_val;
             float true_recall = cnt / float(query_k);
             float require_recall = t->require_acc[id_q];
+            if (t->overhead_profile) {  // IndexIVF.cpp:614,634-637: the rule has run, its verdict is ignored
+                if (stage >= nlist / 8) break;
+                continue;  // (tune and training are never on together: Error_sys sets one or the other)
+            }
             size_t& np = t->my_nprobe[id_q];
             if (recall >= require_recall && np == 0) {
                 np = stage * t->multipler;

@@ -41,6 +41,7 @@ typedef struct {
     size_t* my_nprobe;        /* in/out, indexed by query id */
     float* t_recalls;         /* out, indexed by query id */
     int profile;
+    int overhead_profile;     /* IVF_pro.h:95: rule evaluated on every probe, no stop before stage nlist / 8 (eval/overhead.cpp) */
 } orc_tuner_t;
 
 float orc_fvec_L2sqr(const float* x, const float* y, size_t d);

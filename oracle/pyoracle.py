@@ -27,7 +27,7 @@ class OrcTuner(C.Structure):
                 ("multipler", C.c_float), ("std_m", C.c_float), ("interdis_cem", c_f32p), ("arcos_list", c_f32p),
                 ("trace_off", c_szp), ("trace_x", c_f32p), ("trace_y", c_f32p), ("trace_std", c_f32p),
                 ("require_acc", c_f32p), ("gt_D", c_f32p), ("my_nprobe", c_szp), ("t_recalls", c_f32p),
-                ("profile", C.c_int)]
+                ("profile", C.c_int), ("overhead_profile", C.c_int)]
 
 
 def build():
@@ -106,13 +106,13 @@ class Tuner:
         self.my_nprobe = np.zeros(nq_alloc, dtype=np.uintp)
         self.t_recalls = np.zeros(nq_alloc, dtype=np.float32)
 
-    def struct(self, query_topk, require_acc, multipler, std_m, gt_D=None, profile=False):
+    def struct(self, query_topk, require_acc, multipler, std_m, gt_D=None, profile=False, overhead_profile=False):
         self.req = f32(require_acc)
         self.gt = f32(gt_D) if gt_D is not None else None
         return OrcTuner(self.max_topk, query_topk, self.ntraces, multipler, std_m, _f(self.interdis),
                         _f(self.arcos), _s(self.off), _f(self.tx), _f(self.ty), _f(self.ts), _f(self.req),
                         _f(self.gt) if self.gt is not None else None, _s(self.my_nprobe), _f(self.t_recalls),
-                        int(profile))
+                        int(profile), int(overhead_profile))
 
 
 def arcos_table():

@@ -440,6 +440,29 @@ static int run_auncel(const tb::Bundle& in, tb::Bundle& out) {
             }
         }
     }
+    // ---- eval/overhead.cpp:284-290: the same search with ix->t->overhead_profile on (rule on every probe, no stop before
+    // stage nlist / 8).  Results and counters are deterministic; the two times it prints are not recorded.
+    {
+        std::vector<float> req(nq, accs.as<float>()[0]);
+        es.set_topk(topks.as<int64_t>()[0]);
+        es.set_queries(ses, xq.as<float>(), req.data(), ts + ses);
+        index.t->multipler = mults.as<float>()[0];
+        index.t->std_m = stdms.as<float>()[0];
+        index.t->profile = false;
+        index.t->overhead_profile = true;
+        std::vector<float> D(ses * K);
+        std::vector<int64_t> I(ses * K);
+        indexIVF_stats.reset();
+        // one query per call: the exact coarse path (n < 20), the ranking the restatement and the engine are fed
+        for (size_t i = ts; i < ts + ses; i++) es.search(D.data() + (i - ts) * K, I.data() + (i - ts) * K, i, 1);
+        index.t->overhead_profile = false;
+        out.put_f32("D_overhead", {ses, K}, D.data());
+        out.put_i64("I_overhead", {ses, K}, I.data());
+        std::vector<uint64_t> np(index.t->my_nprobe + ts, index.t->my_nprobe + ts + ses);
+        out.put_u64("my_nprobe_overhead", {ses}, np.data());
+        int64_t st[3] = {(int64_t)indexIVF_stats.nlist, (int64_t)indexIVF_stats.ndis, (int64_t)indexIVF_stats.nheap_updates};
+        out.put_i64("stats_overhead", {3}, st);
+    }
     return 0;
 }
 

@@ -263,6 +263,25 @@ static int run_auncel(const tb::Bundle& in) {
             expect(memcmp(index.t->my_nprobe + ts, in.get("my_nprobe" + suf).as<uint64_t>(), ses * 8) == 0, "my_nprobe" + tag);
         }
     }
+    // ---- eval/overhead.cpp:284-290: ix->t->overhead_profile = true, then Error_sys::search over the batch
+    if (in.has("I_overhead")) {
+        std::vector<float> acc(nq, accs.as<float>()[0]);
+        err_sys.set_topk(topks.as<int64_t>()[0]);
+        err_sys.set_queries(ses, xq.as<float>(), acc.data(), ts + ses);
+        index.t->multipler = mults.as<float>()[0];
+        index.t->std_m = stdms.as<float>()[0];
+        index.t->profile = false;
+        index.t->overhead_profile = true;
+        std::vector<float> D(ses * K);
+        std::vector<int64_t> I(ses * K);
+        for (size_t i = ts; i < ts + ses; i++) err_sys.search(D.data() + K * (i - ts), I.data() + K * (i - ts), i, 1);
+        index.t->overhead_profile = false;
+        expect(memcmp(I.data(), in.get("I_overhead").as<int64_t>(), ses * K * 8) == 0, "overhead_profile ids");
+        expect(same_f(D.data(), in.get("D_overhead").as<float>(), ses * K), "overhead_profile distances");
+        bool zero = true;
+        for (size_t i = ts; i < ts + ses; i++) zero = zero && index.t->my_nprobe[i] == 0;
+        expect(zero, "overhead_profile leaves my_nprobe alone");
+    }
     // ---- eval/effect_time.cpp:270-297: time-bounded search, budgets (ms) in the accuracy array.  With budgets nobody can
     //      use up the probe loop runs to its end: the plain search with nprobe = nlist; with no budget at all a query still
     //      gets its first probes and returns something sorted

@@ -245,6 +245,31 @@ def test_adaptive_search_nlist4096(capi, monkeypatch, name, lanes):
             assert [st["nlist"], st["ndis"], st["nheap_updates"]] == list(gold["stats" + suf]), suf
 
 
+@pytest.mark.parametrize("name", AUNCEL + AUNCEL_BIG)
+def test_overhead_profile(capi, name):
+    """error_pro::overhead_profile (eval/overhead.cpp): rule on every probe, verdict ignored, every query to stage nlist / 8;
+    the plain nlist / 8 search gives the same results (what the class mirror times as "without ELP")"""
+    case, gold = load_case(name)
+    K, ts, ses = case["max_topk"], case["train_num"], case["test_num"]
+    h = make_index(capi, case, gold, gold["centroids"])
+    h.set_interdis(None)
+    h.set_tuner(K, traces_from_gold(gold), gold["arcos_list"])
+    h.set_queries(case["xq"])
+    req = np.full(ts + ses, case["require_acc"][0], dtype=np.float32)
+    my_np = np.zeros(ts + ses, dtype=np.uint64)
+    t_rec = np.zeros(ts + ses, dtype=np.float32)
+    h.stats(reset=True)
+    D, I = h.search_adaptive(ts, ses, int(case["topks"][0]), float(case["multipler"][0]), float(case["std_m"][0]), req, my_np, t_rec,
+                             gt_D=gold["gtD"], profile=2)
+    assert not my_np.any() and not gold["my_nprobe_overhead"].any()
+    assert np.array_equal(I, gold["I_overhead"])
+    assert np.array_equal(bits(D), bits(gold["D_overhead"]))
+    st = h.stats()
+    assert [st["nlist"], st["ndis"], st["nheap_updates"]] == list(gold["stats_overhead"])
+    D2, I2 = h.search_resident(ts, ses, K, case["nlist"] // 8)
+    assert np.array_equal(I2, I) and np.array_equal(bits(D2), bits(D))
+
+
 @pytest.mark.parametrize("name", AUNCEL)
 def test_trace_training_samples(capi, oracle, name):
     """Error_sys::sys_train's search pass: raw (sum_angle, kscaling) samples per power-of-two stage"""

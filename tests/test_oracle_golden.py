@@ -179,6 +179,27 @@ def test_auncel_online(oracle, name):
             assert np.array_equal(stats, gold["stats" + suf]), suf
 
 
+@pytest.mark.parametrize("name", AUNCEL + AUNCEL_BIG)
+def test_auncel_overhead_profile(oracle, name):
+    """error_pro::overhead_profile (eval/overhead.cpp:284-290): the rule runs on every probe, its verdict is ignored, the
+    probe loop ends at stage nlist / 8"""
+    case, gold = load_case(name)
+    K, ts, ses = case["max_topk"], case["train_num"], case["test_num"]
+    cen = gold["centroids"]
+    inter = gold["interdis_cem"] if "interdis_cem" in gold else oracle.interdis(case["metric"], cen)
+    ck = gold["coarse_keys_sse"][ts:] if "coarse_keys_sse" in gold else gold["coarse_keys_sse_test"]
+    cd = gold["coarse_dis_sse"][ts:] if "coarse_dis_sse" in gold else gold["coarse_dis_sse_test"]
+    lists = _lists(oracle, case, gold, cen)
+    tun = oracle.Tuner(inter, traces_from_gold(gold), K, ts + ses, arcos=gold["arcos_list"])
+    req = np.full(ts + ses, case["require_acc"][0], dtype=np.float32)
+    st = tun.struct(int(case["topks"][0]), req, float(case["multipler"][0]), float(case["std_m"][0]), gt_D=gold["gtD"], overhead_profile=True)
+    D, I, stats = oracle.search_preassigned(lists, case["xq"][ts:], K, ck, cd, tuner=st, offset=ts)
+    assert np.array_equal(tun.my_nprobe[ts:].astype(np.uint64), gold["my_nprobe_overhead"]) and not gold["my_nprobe_overhead"].any()
+    assert np.array_equal(I, gold["I_overhead"])
+    assert np.array_equal(D.view(np.uint32), gold["D_overhead"].view(np.uint32))
+    assert np.array_equal(stats, gold["stats_overhead"])
+
+
 @pytest.mark.parametrize("name", AUNCEL_BIG)
 def test_auncel_online_nlist4096(oracle, name):
     """BASELINE config 2's shape (IVF4096: max_num 532, ten traces): the restatement against the compiled reference's run.
