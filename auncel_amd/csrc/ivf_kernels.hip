@@ -1290,7 +1290,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
     auto row_offset = [&](uint32_t p) {
         return ((unsigned long long)rl_u((uint32_t)(m_off >> 32), (int)(p - win0)) << 32) | rl_u((uint32_t)m_off, (int)(p - win0));
     };
-    unsigned long long mw_pre = 0;   // mask words of chunks 0..63 of probe pre_p, requested one probe ahead
+    // mask words of chunks 0..63 and 64..127 of probe pre_p (8192 candidates: all but the very longest lists), requested one
+    // probe ahead: the row of a probe then costs no memory round trip of its own
+    unsigned long long mw_pre = 0, mw_pre2 = 0;
     uint32_t pre_p = 0xffffffffu;
     auto prefetch_masks = [&](uint32_t p) {
         pre_p = 0xffffffffu;
@@ -1298,7 +1300,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
         const uint32_t pn = rl_u(m_n, (int)(p - win0));
         if (pn == 0) return;
         const unsigned long long* mr = a.mask + (row_offset(p) >> 6);
-        mw_pre = (uint32_t)lane < ((pn + 63) >> 6) ? mr[lane] : 0ull;
+        const uint32_t pch = (pn + 63) >> 6;
+        mw_pre = (uint32_t)lane < pch ? mr[lane] : 0ull;
+        mw_pre2 = (uint32_t)lane + 64 < pch ? mr[lane + 64] : 0ull;
         pre_p = p;
     };
 
@@ -1330,11 +1334,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
                 const unsigned long long roff = row_offset(p);
                 const float* seg = a.dist + roff;
                 const unsigned long long* mrow = masked ? a.mask + (roff >> 6) : nullptr;
-                unsigned long long mw = 0, nz = 0;
+                unsigned long long mw = 0, nz = 0, mw2 = 0;
+                bool have2 = false;
                 uint32_t b0 = 0, w0 = 0;
                 if (masked) {
-                    if (pre_p == p) {  // first window of this row was requested while the previous row ran
+                    if (pre_p == p) {  // the first two windows of this row were requested while the previous row ran
                         mw = mw_pre;
+                        mw2 = mw_pre2;
+                        have2 = true;
                         nz = __ballot(mw != 0);
                         w0 = 64;
                     }
@@ -1344,7 +1351,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
                     unsigned long long bm = 0;  // masked: lanes of `mw` (chunks w0 - 64 + lane) now held in v[0..)
                     if (masked) {
                         while (nz == 0 && w0 < nchunk) {
-                            mw = w0 + lane < nchunk ? mrow[w0 + lane] : 0ull;
+                            if (w0 == 64 && have2) mw = mw2;
+                            else mw = w0 + lane < nchunk ? mrow[w0 + lane] : 0ull;
                             nz = __ballot(mw != 0);
                             w0 += 64;
                         }
