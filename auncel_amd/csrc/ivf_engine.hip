@@ -233,6 +233,7 @@ struct amd_ivf {
     std::vector<uint32_t> round_hint;  // [round][16]
     uint64_t hint_sig = 0;
     DevBuf w_limit;  // time-bounded search: per-slot end of the probe loop (plan_counts_kernel -> replay_kernel)
+    DevBuf w_tie_rows;  // rankings re-run through the reference's heap because of equal distances (launch_heap_tie_order)
 
     size_t dist_budget_floats = (size_t)768 << 20;  // 3 GiB of distances per scan launch
     size_t stats_host[4] = {0, 0, 0, 0};
@@ -911,6 +912,13 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
     hipStream_t s = h->stream;
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(n, h->dist_budget_floats / std::max<size_t>(nlist, 1)));
     const bool use_heap = nprobe <= 128;
+    // Longer rankings are sorted; between exactly equal distances the reference's order is an artefact of its heap's
+    // history, reproduced by re-running that heap for the rows concerned (launch_heap_tie_order).  AUNCEL_AMD_COARSE_TIES:
+    // "heap" always, "id" never (such runs stay in centroid-number order), default: calls of fewer than 20 queries, the
+    // regime in which the reference ranks exact distances at all (utils.cpp:624-655; from 20 queries on it ranks sgemm
+    // output, whose low bits -- and with them which distances coincide -- belong to the BLAS library).
+    const char* ties_env = getenv("AUNCEL_AMD_COARSE_TIES");
+    const bool heap_ties = !use_heap && (ties_env ? !strcmp(ties_env, "heap") || (strcmp(ties_env, "id") && n < 20) : n < 20);
     for (size_t c0 = 0; c0 < n; c0 += chunk) {
         const size_t m = std::min(chunk, n - c0);
         // pairs: every query of the chunk against the single "list" = centroid table
@@ -1023,6 +1031,15 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
         } else {
             launch_sort_rows(h->w_dist.as<float>(), (uint32_t)m, (uint32_t)nlist, (uint32_t)nprobe, h->metric,
                              d_out_dis + c0 * nprobe, d_out_keys + c0 * nprobe, s, (uint32_t)prefix);
+            if (heap_ties) {
+                if (!h->w_tie_rows.p) {
+                    h->w_tie_rows.ensure(8);
+                    HIP_CHECK(hipMemsetAsync(h->w_tie_rows.p, 0, 8, s));
+                }
+                const size_t nout = prefix && prefix < nprobe ? prefix : nprobe;
+                (void)launch_heap_tie_order(h->w_dist.as<float>(), (uint32_t)m, (uint32_t)nlist, (uint32_t)nprobe, (uint32_t)nout, h->metric,
+                                            d_out_dis + c0 * nprobe, d_out_keys + c0 * nprobe, h->w_tie_rows.as<unsigned long long>(), s);
+            }
         }
         h->timer.end(t, s);
         HIP_CHECK(stream_sync(s));
@@ -2779,6 +2796,22 @@ int amd_ivf_set_byte_codes(amd_ivf_t* h, int enable) {
 int amd_ivf_last_scan_min_bytes(amd_ivf_t* h, double* bytes) {
     *bytes = h->last_min_bytes;
     return 0;
+}
+
+int amd_ivf_coarse_tie_rows(amd_ivf_t* h, uint64_t* rows) {
+    API_BEGIN
+    use_device(h);
+    *rows = 0;
+    auto add = [&](amd_ivf* c) {
+        if (!c->w_tie_rows.p) return;
+        uint64_t v = 0;
+        HIP_CHECK(stream_sync(c->stream));
+        HIP_CHECK(hipMemcpy(&v, c->w_tie_rows.p, 8, hipMemcpyDeviceToHost));
+        *rows += v;
+    };
+    add(h);
+    for (auto& kid : h->kids) add(kid.get());  // the slices of an adaptive batch run on these
+    API_END
 }
 
 int amd_ivf_last_timing(amd_ivf_t* h, double out[8]) {

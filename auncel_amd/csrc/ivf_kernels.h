@@ -337,6 +337,12 @@ constexpr uint32_t ERR_ITEM_OVERFLOW = 4;
 void launch_sort_rows(const float* dis, uint32_t nq, uint32_t nlist, uint32_t nprobe, int metric, float* out_dis,
                       int64_t* out_keys, hipStream_t s, uint32_t prefix = 0);
 
+// Rows whose first `nout` entries hold (or end inside) a run of exactly equal distances are re-ranked by the reference's
+// own heap (utils.cpp:417-490, Heap.h:88-142,295-322), whose order inside such a run depends on its history; *nrows
+// counts them.  false = heap + row exceed one workgroup's LDS, nothing launched.
+bool launch_heap_tie_order(const float* dis, uint32_t nq, uint32_t nlist, uint32_t nprobe, uint32_t nout, int metric, float* out_dis,
+                           int64_t* out_keys, unsigned long long* nrows, hipStream_t s);
+
 // GEMM-formulated coarse distances on the fp32 matrix cores (row stride d, d % 4 == 0)
 void launch_row_norms(const float* x, size_t n, int d, float* out, hipStream_t s);
 void launch_coarse_gemm(int metric, const float* X, const float* Y, const float* xn, const float* yn, int nq, int ny, int d, float* out,

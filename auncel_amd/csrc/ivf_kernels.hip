@@ -901,6 +901,11 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
     return x;
 }
 
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) {
+    for (int off = 32; off; off >>= 1) x += (uint32_t)__shfl_xor((int)x, off);
+    return x;
+}
+
 // largest error code raised by any lane (0 in the common case: one ballot, no shuffles)
 __device__ __forceinline__ uint32_t wave_err(uint32_t err) { return __ballot(err != 0) ? wave_max_u32(err) : 0u; }
 
@@ -2747,6 +2752,232 @@ void launch_sort_rows(const float* dis, uint32_t nq, uint32_t nlist, uint32_t np
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sort_rows_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         LAUNCH(sort_rows_kernel<false>, dim3(nq), dim3(256), shmem, s, dis, nlist, npow2, nprobe, out_dis, out_keys);
     }
+}
+
+// =============================================================================================
+// reference order inside runs of exactly equal coarse distances (rankings longer than 128)
+// =============================================================================================
+// knn_L2sqr_sse / knn_inner_product_sse (utils.cpp:417-490) keep a binary heap of nprobe entries over centroids
+// 0..nlist-1 and heap-sort it at the end (Heap.h:88-142, 295-322): between exactly equal distances the output order is
+// what the heap's history leaves, not a function of (distance, centroid number).  The sort kernels above order such runs
+// by centroid number; this kernel re-runs the reference's heap for the rows in which that can show -- a run of equal
+// distances inside the first `nout` entries (the part of the ranking the caller reads) or across their end -- and
+// overwrites those entries.  One wave per row, heap and distance row in LDS; the heap walk is a chain of dependent
+// compares, so lane 0 does it (rows with such runs are rare: two centroids at bit-equal fp32 distance from one query).
+struct HeapEnt {
+    float v;
+    uint32_t id;
+};
+
+// heap_pop's walk (Heap.h:88-118) on the 1-based array h[1..k], started at slot `start`: the hole moves to the better child
+// (the right one between equals) until `last` beats it, `last` lands in the hole
+template <bool IsMax> __device__ inline void lds_sift_down(HeapEnt* h, uint32_t k, uint32_t start, HeapEnt last) {
+    uint32_t i = start;
+    while (true) {
+        const uint32_t i1 = i << 1, i2 = i1 + 1;
+        if (i1 > k) break;
+        const HeapEnt c1 = h[i1], c2 = h[i2];  // h has k + 2 slots: reading past k is harmless
+        if (i2 == k + 1 || hcmp<IsMax>(c1.v, c2.v)) {
+            if (hcmp<IsMax>(last.v, c1.v)) break;
+            h[i] = c1;
+            i = i1;
+        } else {
+            if (hcmp<IsMax>(last.v, c2.v)) break;
+            h[i] = c2;
+            i = i2;
+        }
+    }
+    h[i] = last;
+}
+
+template <bool IsMax> __device__ inline void lds_heap_pop(HeapEnt* h, uint32_t k) { lds_sift_down<IsMax>(h, k, 1, h[k]); }
+
+// heap_push (Heap.h:125-142)
+template <bool IsMax> __device__ inline void lds_heap_push(HeapEnt* h, uint32_t k, float val, uint32_t id) {
+    uint32_t i = k;
+    while (i > 1) {
+        const uint32_t f = i >> 1;
+        const HeapEnt fe = h[f];
+        if (!hcmp<IsMax>(val, fe.v)) break;
+        h[i] = fe;
+        i = f;
+    }
+    h[i] = HeapEnt{val, id};
+}
+
+// ---- nprobe == nlist == n = 2^m (what Error_sys::search asks for, profile.cpp:220): the same heap without walking it
+// one entry at a time.
+//
+// Filling.  With k = n every centroid enters: step j pops one of the n initial (FLT_MAX, -1) entries and pushes x_j into
+// slot n, and the entry it re-inserts from the root is the one pushed the step before.  All initial entries are equal, so
+// the pop's walk from the root runs through them (to the right between two of them, else towards the one that is left) to
+// the last one on its way, and from there on it is an ordinary sift-down of x_{j-1} into the finished heaps below.  The
+// initial entries therefore disappear in right-to-left post-order of slots 1..n-1, slot p receives x_{j(p)-1} with j(p) its
+// place in that order, and every step is a sift-down inside subtree(p) only: steps of disjoint subtrees commute, so whole
+// levels go at once, bottom-up (this is Floyd's heap construction with the reference's value-to-slot assignment and its
+// tie rules).  Slot n hangs under the leftmost leaf n/2, the last slots in post-order are n/2 and its ancestors; from
+// step n - m on the pushes can move up that path, and those m steps are replayed one by one.
+//
+// Heap sort (heap_reorder).  Pop t takes the entry of slot n - t and walks it down from the root; a walk only ever
+// touches the level it is on and reads the one below, so the next pop can start two levels behind it.  Lanes hold the
+// walks in flight, one level per tick each; a pop may not start while a walk in flight is above slot n - t (it could
+// still change the entry the pop is about to take).  2.4 ticks per pop instead of one walk of m levels (measured, nlist
+// 4096: 2.8 ms a row against 12.4 ms for the plain walk below; the filling takes 0.06 ms of that).
+// (scratch/heap_proto.py is the model both halves were checked with, entry for entry, against the literal heap.)
+template <bool IsMax> __device__ inline void floyd_fill_pow2(HeapEnt* a, const float* row, uint32_t n, int lane) {
+    const int m = 31 - __builtin_clz(n);
+    const uint32_t F = n >> 1;
+    for (int dp = m - 1; dp >= 1; dp--) {
+        const uint32_t base = 1u << dp;
+        for (uint32_t o = lane; o < base; o += 64) {
+            const uint32_t p = base + o;
+            if ((F >> (m - 1 - dp)) == p) continue;  // n/2 and its ancestors: the last m steps, below
+            uint32_t j = (1u << (m - dp)) - 1;       // right-to-left post-order place of p: its own subtree ...
+            for (int t = 1; t <= dp; t++)            // ... and the right siblings of the left turns on the way to it
+                if (!((p >> (dp - t)) & 1)) j += (1u << (m - t)) - 1;
+            lds_sift_down<IsMax>(a, n - 1, p, HeapEnt{row[j - 1], j - 1});
+        }
+        wave_sync();
+    }
+    if (lane == 0) {
+        a[n] = HeapEnt{row[n - m - 1], n - m - 1};
+        uint32_t A = F;
+        for (uint32_t j = n - m; j < n; j++, A >>= 1) {
+            lds_sift_down<IsMax>(a, n, A, a[n]);
+            lds_heap_push<IsMax>(a, n, row[j], j);
+        }
+    }
+    wave_sync();
+}
+
+template <bool IsMax> __device__ inline void heapsort_pipelined(HeapEnt* a, uint32_t n, uint32_t* out_id, int lane) {
+    // one walk per lane: hole = slot the walk stands on (0: lane free), s = heap size of its pop, lvl = depth of hole,
+    // (Lv, Lid) = the entry it carries.  Every lane runs the same straight-line tick: free lanes read slot 0 and store nothing.
+    uint32_t hole = 0, s = 0, lvl = 0, Lid = 0;
+    float Lv = 0.f;
+    uint32_t t = 0, since = 2;  // pops started; ticks since the last start
+    const uint4* a4 = reinterpret_cast<const uint4*>(a);
+    const uint2* a2 = reinterpret_cast<const uint2*>(a);
+    while (true) {
+        const unsigned long long act = __ballot(hole != 0);
+        if (t == n && !act) break;
+        const uint32_t sc = n - t, dsc = 31 - __builtin_clz(sc | 1);
+        const bool above = hole != 0 && lvl <= dsc && (sc >> ((dsc - lvl) & 31)) == hole;
+        const bool create = t < n && since >= 2 && !__ballot(above);
+        const bool mine = create && lane == __builtin_ctzll(~act);
+        hole = mine ? 1u : hole;
+        s = mine ? sc : s;
+        lvl = mine ? 0u : lvl;
+        const uint32_t i1 = hole << 1;
+        const uint4 ch = a4[(i1 < n ? i1 : n) >> 1];  // both children (a has n + 2 slots)
+        const uint2 ls = a2[mine ? sc : 0u];
+        const uint32_t top_id = a2[1].y;
+        if (mine) out_id[sc - 1] = top_id;  // heap_reorder: the top goes behind the shrinking heap
+        Lv = mine ? __uint_as_float(ls.x) : Lv;
+        Lid = mine ? ls.y : Lid;
+        const float c1v = __uint_as_float(ch.x), c2v = __uint_as_float(ch.z);
+        const bool left = i1 == s || hcmp<IsMax>(c1v, c2v);  // a single child, or the better one (the right one between equals)
+        const float cv = left ? c1v : c2v;
+        const uint32_t cid = left ? ch.y : ch.w;
+        const bool done = i1 > s || hcmp<IsMax>(Lv, cv);
+        if (hole != 0) a[hole] = HeapEnt{done ? Lv : cv, done ? Lid : cid};
+        hole = hole != 0 && !done ? (left ? i1 : i1 + 1) : 0u;
+        lvl++;
+        t += create ? 1u : 0u;
+        since = create ? 1u : since + 1;
+        wave_sync();
+    }
+}
+
+template <bool IsMax>
+__global__ __launch_bounds__(64) void heap_tie_order_kernel(const float* dis, uint32_t nlist, uint32_t nprobe, uint32_t nout,
+                                                            float* out_dis, int64_t* out_keys, unsigned long long* nrows) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    HeapEnt* h = reinterpret_cast<HeapEnt*>(smem);                           // nprobe + 2 entries, [0] unused
+    float* row = reinterpret_cast<float*>(smem + (size_t)(nprobe + 2) * 8);  // nlist
+    const uint32_t q = blockIdx.x, lane = threadIdx.x;
+    const float* grow = dis + (size_t)q * nlist;
+    float* od = out_dis + (size_t)q * nprobe;
+    int64_t* ok = out_keys + (size_t)q * nprobe;
+    const float neutral = IsMax ? FLT_MAX : -FLT_MAX;
+    const uint32_t nreal = nout < nlist ? nout : nlist;  // leading entries that are centroids (the rest is padding)
+    bool tie = false;
+    for (uint32_t i = lane; i + 1 < nreal; i += 64) tie |= od[i] == od[i + 1];
+    if (nreal && nreal < nlist) {
+        // a run across the end of what was ranked: more centroids at the last distance than entries that carry it
+        const float T = od[nreal - 1];
+        uint32_t in_row = 0, in_out = 0;
+        for (uint32_t j = lane; j < nlist; j += 64) in_row += grow[j] == T;
+        for (uint32_t i = lane; i < nreal; i += 64) in_out += od[i] == T;
+        in_row = wave_sum_u32(in_row);
+        in_out = wave_sum_u32(in_out);
+        tie |= in_row > in_out;
+    }
+    if (!__ballot(tie)) return;
+    bool enters = true;  // every centroid beats the initial entries (utils.cpp:478: "if (disij < simi[0])")
+    for (uint32_t j = lane; j < nlist; j += 64) {
+        const float v = grow[j];
+        row[j] = v;
+        enters &= hcmp<IsMax>(neutral, v);
+    }
+    for (uint32_t i = lane; i < nprobe + 2; i += 64) h[i] = HeapEnt{neutral, 0xffffffffu};  // heap_heapify, no input
+    wave_sync();
+    if (lane == 0) atomicAdd(nrows, 1ull);
+    if (nprobe == nlist && (nlist & (nlist - 1)) == 0 && nlist >= 64 && !__ballot(!enters)) {
+        floyd_fill_pow2<IsMax>(h, row, nlist, (int)lane);
+        uint32_t* out_id = reinterpret_cast<uint32_t*>(row);  // the distances are not needed any more
+        heapsort_pipelined<IsMax>(h, nlist, out_id, (int)lane);
+        // same distances in the same places, only centroid numbers inside runs of equal distances move
+        for (uint32_t i = lane; i < nout && i < nprobe; i += 64) ok[i] = (int64_t)out_id[i];
+        return;
+    }
+    uint32_t nvalid = 0;
+    if (lane == 0) {
+        const uint32_t k = nprobe;
+        for (uint32_t j = 0; j < nlist; j++) {
+            const float dj = row[j];
+            if (hcmp<IsMax>(h[1].v, dj)) {
+                lds_heap_pop<IsMax>(h, k);
+                lds_heap_push<IsMax>(h, k, dj, j);
+            }
+        }
+        // heap_reorder: k pops, each popped entry stored behind the shrinking heap; entries without an id are dropped
+        uint32_t ii = 0;
+        for (uint32_t i = 0; i < k; i++) {
+            const HeapEnt top = h[1];
+            lds_heap_pop<IsMax>(h, k - i);
+            h[k - ii] = top;
+            if (top.id != 0xffffffffu) ii++;
+        }
+        nvalid = ii;
+    }
+    wave_sync();
+    nvalid = (uint32_t)__builtin_amdgcn_readfirstlane((int)nvalid);
+    for (uint32_t i = lane; i < nout && i < nprobe; i += 64) {
+        const bool real = i < nvalid;
+        const HeapEnt e = real ? h[nprobe - nvalid + 1 + i] : HeapEnt{neutral, 0xffffffffu};
+        od[i] = e.v;
+        ok[i] = real ? (int64_t)e.id : -1;
+    }
+}
+
+size_t heap_tie_order_lds(uint32_t nlist, uint32_t nprobe) { return (size_t)(nprobe + 2) * 8 + (size_t)nlist * 4; }
+
+// nout: leading entries of each ranking the caller reads (<= nprobe); rows without a run of equal distances there are left
+// as they are.  Returns false (nothing launched) when heap and row do not fit one workgroup's LDS.
+bool launch_heap_tie_order(const float* dis, uint32_t nq, uint32_t nlist, uint32_t nprobe, uint32_t nout, int metric, float* out_dis,
+                           int64_t* out_keys, unsigned long long* nrows, hipStream_t s) {
+    if (nq == 0) return true;
+    const size_t shmem = heap_tie_order_lds(nlist, nprobe);
+    if (shmem > 160 * 1024) return false;
+    if (metric == METRIC_L2) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(heap_tie_order_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        LAUNCH(heap_tie_order_kernel<true>, dim3(nq), dim3(64), shmem, s, dis, nlist, nprobe, nout, out_dis, out_keys, nrows);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(heap_tie_order_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        LAUNCH(heap_tie_order_kernel<false>, dim3(nq), dim3(64), shmem, s, dis, nlist, nprobe, nout, out_dis, out_keys, nrows);
+    }
+    return true;
 }
 
 // =============================================================================================

@@ -212,6 +212,13 @@ int amd_ivf_last_timing(amd_ivf_t* h, double out[8]);
  * d bytes per vector in byte-code mode, 4 d in fp32) plus the rows written (4 bytes per distance of a dense round, one
  * mask bit per distance in threshold mode).  A lower bound of the traffic, counted on the device by the planning kernels. */
 int amd_ivf_last_scan_min_bytes(amd_ivf_t* h, double* bytes);
+/* Coarse rankings longer than 128 are sorted on the device; inside a run of exactly equal distances the reference's order
+ * (knn_L2sqr_sse / knn_inner_product_sse, Auncel/utils.cpp:417-490: a binary heap over centroids 0..nlist-1, heap-sorted
+ * at the end, Heap.h:295-322) depends on the heap's history.  Rows that hold such a run in the part of the ranking that
+ * is read are re-run through that heap on the device: in calls of fewer than 20 queries by default (the reference's exact
+ * regime), in every call with AUNCEL_AMD_COARSE_TIES=heap, never with =id (runs stay in centroid-number order).
+ * *rows = rankings re-run so far on this handle. */
+int amd_ivf_coarse_tie_rows(amd_ivf_t* h, uint64_t* rows);
 
 /* Arithmetic the list scan of the last search ran in.  All three produce the reference's fp32 distance bit for
  * bit (utils_simd.cpp:391-443 order); the engine picks the cheapest one the data allows:

@@ -6,7 +6,7 @@ bash profiles/collect.sh $tag > gpurun_out/collect_$tag.log 2>&1
 python bench.py > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.log
 python scratch/perf_scan.py > gpurun_out/perf_scan_$tag.txt 2> gpurun_out/perf_scan_$tag.log
 python scripts/bench_configs.py > gpurun_out/configs_$tag.jsonl 2> gpurun_out/configs_$tag.log
-python scripts/bench_shards.py > gpurun_out/shards_$tag.json 2> gpurun_out/shards_$tag.log
+python bench.py --mode shards --test 10000 > gpurun_out/shards_$tag.json 2> gpurun_out/shards_$tag.log
 python scripts/effect_time.py > gpurun_out/effect_time_$tag.jsonl 2> gpurun_out/effect_time_$tag.log
 python scratch/latency1.py > gpurun_out/latency1_$tag.txt 2> gpurun_out/latency1_$tag.log
 tail -3 gpurun_out/bench_$tag.log; cat gpurun_out/effect_time_$tag.jsonl; du -sh gpurun_out
