@@ -43,7 +43,7 @@ def lib():
         if not os.path.exists(_build.LIB):
             raise ImportError(f"{_build.LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950).  auncel_amd has no CPU fallback.")
-        L = C.CDLL(_build.LIB)
+        L = C.CDLL(os.environ.get("AUNCEL_AMD_LIB", _build.LIB))  # AUNCEL_AMD_LIB: a differently built engine (kernel experiments)
         L.amd_ivf_last_error.restype = C.c_char_p
         for s in SYMBOLS[1:]:
             getattr(L, s).restype = C.c_int

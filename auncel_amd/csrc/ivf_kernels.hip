@@ -70,7 +70,19 @@ __device__ __forceinline__ void scan_tile_one(const ScanArgs& a, const ScanItem 
 
     // the wave's 8 query operands of one 4-dimension step are 128 contiguous bytes (pack_queries): they come
     // in through the scalar cache with two wide scalar loads and stay in SGPRs
-    const float4* qtile = reinterpret_cast<const float4*>(a.qtile + (size_t)(it.qgroup + qgi) * (size_t)d * SCAN_RQ);
+    // (constant address space: inside the item loop of the chained rounds the compiler sees the previous item's stores
+    // between these loads and the kernel entry, may not assume plain global memory unchanged, and would fetch the
+    // operands with per-lane vector loads -- eight 1-KB broadcasts per step through the CU's one texture path, which
+    // bounded every shape of this kernel at 11 T element pairs/s; measured with scalar loads: 15-17 T.  Requesting them
+    // half a step at a time, or across the chunk boundary, was measured too: 13 and 15 T -- the SGPR file is full
+    // either way and the spill traffic decides)
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef const v4f __attribute__((address_space(4)))* const_f4p;
+    const const_f4p qtile = (const_f4p)(uintptr_t)(a.qtile + (size_t)(it.qgroup + qgi) * (size_t)d * SCAN_RQ);
+    auto qload = [](const_f4p p) {
+        const v4f t = *p;
+        return make_float4(t.x, t.y, t.z, t.w);
+    };
 
     // running sums (s0, s1) and (s2, s3) of the reference's 4-lane accumulator, as two register pairs
     f2 acc[SCAN_RQ][SCAN_RV][2];
@@ -133,10 +145,10 @@ __device__ __forceinline__ void scan_tile_one(const ScanArgs& a, const ScanItem 
         if (!has_queries) continue;  // wave without queries: staging + barriers only
         const float* myrow = &stage[(vgi * SCAN_WAVE_VECS + lane) * LDS_ROW];
         // operands of step s+1 (queries: scalar loads, vectors: LDS rows) are requested before step s is computed
-        const float4* qs = qtile + (size_t)(cc >> 2) * SCAN_RQ;
+        const const_f4p qs = qtile + (size_t)(cc >> 2) * SCAN_RQ;
         float4 qn[SCAN_RQ], yn[SCAN_RV];
 #pragma unroll
-        for (int r = 0; r < SCAN_RQ; r++) qn[r] = qs[r];
+        for (int r = 0; r < SCAN_RQ; r++) qn[r] = qload(qs + r);
 #pragma unroll
         for (int v = 0; v < SCAN_RV; v++) yn[v] = *reinterpret_cast<const float4*>(myrow + v * 64 * LDS_ROW);
 #pragma unroll
@@ -155,7 +167,7 @@ __device__ __forceinline__ void scan_tile_one(const ScanArgs& a, const ScanItem 
 #pragma unroll
                 for (int v = 0; v < SCAN_RV; v++) yn[v] = *reinterpret_cast<const float4*>(myrow + v * 64 * LDS_ROW + (s + 1) * 4);
 #pragma unroll
-                for (int r = 0; r < SCAN_RQ; r++) qn[r] = qs[(s + 1) * SCAN_RQ + r];
+                for (int r = 0; r < SCAN_RQ; r++) qn[r] = qload(qs + (s + 1) * SCAN_RQ + r);
             }
 #pragma unroll
             for (int r = 0; r < SCAN_RQ; r++) {
@@ -453,6 +465,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AUNCEL_MFMA
     const size_t block_bytes = (size_t)ks * 1024;
     const uint32_t nblk = ((it.nvec + 63) >> 6) * 2;  // lists are stored in pairs of blocks: a 64-candidate mask word is two of ours
     uint32_t* mask32 = reinterpret_cast<uint32_t*>(a.mask);
+    // What was measured on this loop in round 2 and did not move a launch (0.52 ms by HIP events): two and three blocks
+    // requested ahead at three waves per SIMD (0.54 / 0.86), four at two (0.65), five waves per SIMD with the per-register
+    // operands re-read from LDS (0.54), the next item's header and first block requested under the current item (0.52),
+    // lane writes only for registers with a candidate (0.52), unconditional stores into per-wave trash lines so that the
+    // wait at the top is a count instead of vmcnt(0) (0.41 vs 0.42 on a dense round).  Without any epilogue a dense
+    // launch takes 0.25 ms (4.6 TB/s; torch's copy reaches 5.5 on this box): the distance stores and the second query
+    // block of a list are what the rest pays for.
     // Software pipeline (resident-operand form): the B pieces of block i + 1 are requested right after the MFMAs of block i
     // have consumed their registers, and land while the epilogue of block i runs; the scheduling barriers keep the compiler
     // from sinking the loads back to their uses (it otherwise recycles three registers and keeps three loads in flight).
