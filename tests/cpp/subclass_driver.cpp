@@ -1,0 +1,144 @@
+// TEST INFRASTRUCTURE.  INTEGRATION.md route B, executed: the reference's own classes (compiled from /root/reference into
+// oracle/_ref/libfaiss_ref.a) drive integration/AmdIndexIVFFlat.h, the subclass a maintainer adds to the reference tree, and
+// every result is compared bit for bit with the same calls on the reference's CPU IndexIVFFlat:
+//   * IndexIVF::search with fixed nprobe (batched and one query per call, k = 10 / 100, nprobe 1 / 8 / 200, store_pairs),
+//   * Error_sys::sys_train (the training branch, traces after Trace::SB),
+//   * Error_sys::search, one query per call as eval/bound.cpp:380-386 does (tune branch: D, I, my_nprobe, t_recalls).
+// Built by oracle/Makefile (target subclass) in the container that has the reference; the binary travels to the GPU box.
+#include "Auncel/gpu_amd/AmdIndexIVFFlat.h"
+
+#include <cstdio>
+#include <cstring>
+#include <random>
+
+#include "Auncel/IVF_pro.h"
+#include "Auncel/profile.h"
+
+using namespace faiss;
+typedef Index::idx_t idx_t;
+
+static int bad = 0;
+static void expect(bool ok, const char* what) {
+    std::printf("%-72s %s\n", what, ok ? "equal" : "DIFFERENT");
+    if (!ok) bad++;
+}
+template <class T> static bool same(const std::vector<T>& a, const std::vector<T>& b) {
+    return a.size() == b.size() && std::memcmp(a.data(), b.data(), a.size() * sizeof(T)) == 0;
+}
+
+int main(int argc, char** argv) {
+    const bool bytes = argc > 1 && !std::strcmp(argv[1], "bytes");  // uint8-valued data (byte-code scan) or float data
+    const size_t d = 32, nb = 60000, nlist = 1024, ts = 100, ses = 60, nq = ts + ses, K = 100;
+    std::mt19937 rng(7);
+    std::normal_distribution<float> g(0.f, 1.f);
+    std::vector<float> centres(256 * d), xb(nb * d), xq(nq * d);
+    for (float& v : centres) v = bytes ? 40.f + 30.f * g(rng) + 80.f : g(rng);
+    auto draw = [&](std::vector<float>& out, size_t n) {
+        for (size_t i = 0; i < n; i++) {
+            const size_t c = rng() % 256;
+            for (size_t j = 0; j < d; j++) {
+                float v = centres[c * d + j] + (bytes ? 25.f : 0.6f) * g(rng);
+                if (bytes) v = std::floor(std::min(255.f, std::max(0.f, v)));
+                out[i * d + j] = v;
+            }
+        }
+    };
+    draw(xb, nb);
+    draw(xq, nq);
+
+    // ---- the reference on the CPU
+    IndexFlat q1(d, METRIC_L2);
+    IndexIVFFlat ref(&q1, d, nlist, METRIC_L2);
+    ref.cp.niter = 6;
+    ref.set_tune_mode();  // bound.cpp:261-263: train also fills interdis_cem
+    ref.train(nb, xb.data());
+    ref.set_tune_off();
+    ref.add(nb, xb.data());
+    // ---- the same index behind the subclass
+    IndexFlat q2(d, METRIC_L2);
+    q2.add(nlist, q1.xb.data());
+    AmdIndexIVFFlat amd(&q2, d, nlist, METRIC_L2, 0);
+    amd.is_trained = true;
+    amd.interdis_cem = ref.interdis_cem;
+    amd.add(nb, xb.data());
+
+    // ---- fixed nprobe through IndexIVF::search (the quantizer runs on the host in both; search_preassigned is the override)
+    ref.init_tune(0, 1, nullptr, nullptr, nullptr, nullptr, nullptr);  // plain searches dereference `t` (IndexIVF.cpp:529)
+    amd.init_tune(0, 1, nullptr, nullptr, nullptr, nullptr, nullptr);
+    for (size_t k : {(size_t)10, (size_t)100})
+        for (size_t nprobe : {(size_t)1, (size_t)8, (size_t)200}) {
+            ref.nprobe = amd.nprobe = nprobe;
+            std::vector<float> D1(nq * k), D2(nq * k);
+            std::vector<idx_t> I1(nq * k), I2(nq * k);
+            ref.search(nq, xq.data(), k, D1.data(), I1.data());
+            amd.search(nq, xq.data(), k, D2.data(), I2.data());
+            char what[128];
+            std::snprintf(what, sizeof what, "search, %zu queries in one call, k %zu nprobe %zu", nq, k, nprobe);
+            expect(same(D1, D2) && same(I1, I2), what);
+            for (size_t i = 0; i < 20; i++) {
+                ref.search(1, xq.data() + i * d, k, D1.data() + i * k, I1.data() + i * k);
+                amd.search(1, xq.data() + i * d, k, D2.data() + i * k, I2.data() + i * k);
+            }
+            std::snprintf(what, sizeof what, "search, one query per call, k %zu nprobe %zu", k, nprobe);
+            expect(same(D1, D2) && same(I1, I2), what);
+        }
+    {
+        ref.nprobe = amd.nprobe = 8;
+        std::vector<float> cd(nq * 8), D1(nq * 10), D2(nq * 10);
+        std::vector<idx_t> ck(nq * 8), I1(nq * 10), I2(nq * 10);
+        q1.search(nq, xq.data(), 8, cd.data(), ck.data());
+        ref.search_preassigned(nq, xq.data(), 10, ck.data(), cd.data(), D1.data(), I1.data(), true);
+        amd.search_preassigned(nq, xq.data(), 10, ck.data(), cd.data(), D2.data(), I2.data(), true);
+        expect(same(D1, D2) && same(I1, I2), "search_preassigned, store_pairs");
+    }
+
+    // ---- Auncel: exact ground truth, training, adaptive search
+    std::vector<float> gtD(nq * K);
+    std::vector<idx_t> gtI(nq * K);
+    {
+        IndexFlat flat(d, METRIC_L2);
+        flat.add(nb, xb.data());
+        for (size_t i = 0; i < nq; i++) flat.search(1, xq.data() + i * d, K, gtD.data() + i * K, gtI.data() + i * K);
+    }
+    Error_sys es1(&ref, nq, K), es2(&amd, nq, K);  // bound.cpp:356 (each makes its index a fresh error_pro)
+    es1.set_gt(gtD.data(), gtI.data());
+    es2.set_gt(gtD.data(), gtI.data());
+    es1.sys_train(ts, xq.data());
+    es2.sys_train(ts, xq.data());
+    bool traces_same = ref.t->traces.size() == amd.t->traces.size();
+    for (size_t i = 0; traces_same && i < ref.t->traces.size(); i++)
+        traces_same = ref.t->traces[i].trace == amd.t->traces[i].trace && ref.t->traces[i].stds == amd.t->traces[i].stds;
+    expect(traces_same, "Error_sys::sys_train: traces after Trace::SB");
+
+    for (int prof = 0; prof < 2; prof++)
+        for (size_t topk : {(size_t)10, (size_t)100}) {
+            std::vector<float> req(nq, topk == 10 ? 0.9f : 0.95f);
+            std::vector<float> D1(ses * K), D2(ses * K);
+            std::vector<idx_t> I1(ses * K), I2(ses * K);
+            Error_sys* es[2] = {&es1, &es2};
+            IndexIVF* ix[2] = {&ref, &amd};
+            for (int w = 0; w < 2; w++) {
+                es[w]->set_topk(topk);
+                es[w]->set_queries(ses, xq.data(), req.data(), ts + ses);
+                ix[w]->t->multipler = 1.5f;
+                ix[w]->t->std_m = 1.0f;
+                ix[w]->t->profile = prof == 1;
+                float* D = w ? D2.data() : D1.data();
+                idx_t* I = w ? I2.data() : I1.data();
+                for (size_t i = ts; i < ts + ses; i++) es[w]->search(D + (i - ts) * K, I + (i - ts) * K, i, 1);
+            }
+            char what[128];
+            std::snprintf(what, sizeof what, "Error_sys::search per query, query_topk %zu%s: D, I", topk, prof ? ", profile" : "");
+            expect(same(D1, D2) && same(I1, I2), what);
+            bool np = true, tr = true;
+            for (size_t i = ts; i < ts + ses; i++) {
+                np = np && ref.t->my_nprobe[i] == amd.t->my_nprobe[i];
+                tr = tr && std::memcmp(&ref.t->t_recalls[i], &amd.t->t_recalls[i], 4) == 0;
+            }
+            std::snprintf(what, sizeof what, "Error_sys::search per query, query_topk %zu%s: my_nprobe", topk, prof ? ", profile" : "");
+            expect(np, what);
+            if (prof) expect(tr, "                                               t_recalls");
+        }
+    std::printf(bad ? "SUBCLASS PARITY FAILED (%d)\n" : "SUBCLASS PARITY OK\n", bad);
+    return bad ? 1 : 0;
+}
