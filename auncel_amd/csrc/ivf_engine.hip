@@ -193,6 +193,7 @@ struct amd_ivf {
     IntRange db_range, centroid_range, resident_range, call_range;  // see IntRange
     int allow_fused = 1;
     int allow_bytes = 1;
+    int ties_override = -1;  // coarse_dev: -1 as AUNCEL_AMD_COARSE_TIES / the call size say, 0 centroid-number order, 1 the reference's heap
     int last_arith = 0;  // scan arithmetic of the last search: 0 reference order, 1 fused, 2 byte codes
     // byte copy of the lists in MFMA fragment order (ivf_kernels.h) + per-slot constants, kept while the data qualifies
     // (IntRange::bytes); block_off[l] = first 32-vector block of list l
@@ -918,7 +919,8 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
     // regime in which the reference ranks exact distances at all (utils.cpp:624-655; from 20 queries on it ranks sgemm
     // output, whose low bits -- and with them which distances coincide -- belong to the BLAS library).
     const char* ties_env = getenv("AUNCEL_AMD_COARSE_TIES");
-    const bool heap_ties = !use_heap && (ties_env ? !strcmp(ties_env, "heap") || (strcmp(ties_env, "id") && n < 20) : n < 20);
+    const bool heap_ties = !use_heap && (h->ties_override >= 0 ? h->ties_override == 1
+                                         : ties_env ? !strcmp(ties_env, "heap") || (strcmp(ties_env, "id") && n < 20) : n < 20);
     for (size_t c0 = 0; c0 < n; c0 += chunk) {
         const size_t m = std::min(chunk, n - c0);
         // pairs: every query of the chunk against the single "list" = centroid table
@@ -2075,8 +2077,16 @@ static void timed_core(amd_ivf* h, const float* d_x, size_t start, size_t n, siz
     HIP_CHECK(hipMemcpyAsync(d_b.p, budget_ms, (start + n) * 4, hipMemcpyHostToDevice, h->stream));
     h->w_cdis.ensure(n * nprobe * 4);
     h->w_ckeys.ensure(n * nprobe * 8);
+    // Runs of equal coarse distances stay in centroid-number order here unless AUNCEL_AMD_COARSE_TIES=heap: where the
+    // clock decides how deep a query goes, which of two equidistant lists comes first is immaterial, and re-running the
+    // reference's heap over all nlist entries (2.8 ms at 4096) would cost more than most budgets.
+    {
+        const char* te = getenv("AUNCEL_AMD_COARSE_TIES");
+        h->ties_override = te && !strcmp(te, "heap") ? 1 : 0;
+    }
     coarse_dev(h, d_x, n, nprobe, coarse_mode, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>(),
                h->allow_fused && ix(h)->centroid_range.fusable_with(qr, h->metric));
+    h->ties_override = -1;
     init_state(h, n, k, false);
     RoundSpec base;
     base.k = (int)k;
@@ -2366,7 +2376,7 @@ static size_t lane_count(size_t n) {
                // VALU-bound scan than they hide of selection + planning (bench: 1 lane 25 ms/step, 2 lanes 29)
 }
 
-static void adaptive_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n, size_t query_topk, float multipler, float std_m,
+static void adaptive_core_once(amd_ivf_t* h, const float* d_x, size_t start, size_t n, size_t query_topk, float multipler, float std_m,
                             const float* require_acc, const float* gt_D, int profile, int coarse_mode,
                             uint64_t* my_nprobe, float* t_recalls, float* D, int64_t* I, const IntRange& qr) {
     use_device(h);
@@ -2468,6 +2478,62 @@ static void adaptive_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n
     h->last_min_bytes = min_bytes;
     h->timing[6] = slots > 0 ? useful / slots : 0;
     h->timing[7] = ln[CAT_SELECT];
+}
+
+// Fewer than 20 queries per call is the regime in which the reference ranks exact coarse distances (utils.cpp:624-655), so
+// there the order inside runs of bit-equal distances has to be its heap's.  Re-running that heap costs up to 2.8 ms a
+// ranking (nlist 4096) and one ranking in eight holds such a run somewhere in the prefix that may be read -- but a query
+// only ever reads entries below max(my_nprobe, 2 my_nprobe + 14) (the probes it scans; the set_online windows of the stages
+// it evaluates: stage s reads entries up to 2^ceil(log2 s) + 14).  So: search with the runs in centroid-number order,
+// which differs from the heap's only inside them; if no query's first run starts below its bound the result is the
+// reference's, otherwise (about one call in a hundred) the call is repeated with the heap's order.
+static void adaptive_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n, size_t query_topk, float multipler, float std_m,
+                          const float* require_acc, const float* gt_D, int profile, int coarse_mode,
+                          uint64_t* my_nprobe, float* t_recalls, float* D, int64_t* I, const IntRange& qr) {
+    const bool speculate = n > 0 && n < 20 && !getenv("AUNCEL_AMD_COARSE_TIES") && h->nlist > 128 && multipler >= 1.f && !(profile & 2);
+    if (!speculate) {
+        adaptive_core_once(h, d_x, start, n, query_topk, multipler, std_m, require_acc, gt_D, profile, coarse_mode, my_nprobe, t_recalls, D, I, qr);
+        return;
+    }
+    size_t stats0[4];
+    for (int i = 0; i < 4; i++) stats0[i] = h->stats_host[i];
+    const std::vector<uint64_t> np0(my_nprobe + start, my_nprobe + start + n);
+    const std::vector<float> tr0(t_recalls + start, t_recalls + start + n);
+    h->ties_override = 0;
+    try {
+        adaptive_core_once(h, d_x, start, n, query_topk, multipler, std_m, require_acc, gt_D, profile, coarse_mode, my_nprobe, t_recalls, D, I, qr);
+    } catch (...) {
+        h->ties_override = -1;
+        throw;
+    }
+    h->ties_override = -1;
+    // first run of equal distances in every ranking of the call (they are still in the slice's workspace)
+    const size_t nlist = h->nlist;
+    size_t nreal = std::max<size_t>(nlist / 8 + 21, (size_t)((double)(nlist / 8) * (double)multipler) + 2);
+    for (size_t i = 0; i < n; i++) nreal = std::max<size_t>(nreal, (size_t)np0[i] + 1);
+    nreal = std::min(nreal + 16, nlist);  // what adaptive_core_once had ranked (its coarse_prefix)
+    h->w_misc.ensure(n * 4);
+    launch_first_tie(h->w_cdis.as<float>(), (uint32_t)n, (uint32_t)nlist, (uint32_t)nreal, h->w_misc.as<uint32_t>(), h->stream);
+    std::vector<uint32_t> first(n);
+    HIP_CHECK(hipMemcpyAsync(first.data(), h->w_misc.p, n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(stream_sync(h->stream));
+    bool redo = false;
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t bound = 2 * my_nprobe[start + i] + 14;
+        redo = redo || first[i] < bound || bound + 1 >= nreal;  // (a run across the end of what was ranked: only deep queries get there)
+    }
+    if (!redo) return;
+    for (int i = 0; i < 4; i++) h->stats_host[i] = stats0[i];
+    std::copy(np0.begin(), np0.end(), my_nprobe + start);
+    std::copy(tr0.begin(), tr0.end(), t_recalls + start);
+    h->ties_override = 1;
+    try {
+        adaptive_core_once(h, d_x, start, n, query_topk, multipler, std_m, require_acc, gt_D, profile, coarse_mode, my_nprobe, t_recalls, D, I, qr);
+    } catch (...) {
+        h->ties_override = -1;
+        throw;
+    }
+    h->ties_override = -1;
 }
 
 int amd_ivf_search_adaptive(amd_ivf_t* h, size_t start, size_t n, size_t query_topk, float multipler, float std_m,

@@ -343,6 +343,10 @@ void launch_sort_rows(const float* dis, uint32_t nq, uint32_t nlist, uint32_t np
 bool launch_heap_tie_order(const float* dis, uint32_t nq, uint32_t nlist, uint32_t nprobe, uint32_t nout, int metric, float* out_dis,
                            int64_t* out_keys, unsigned long long* nrows, hipStream_t s);
 
+// position of the first pair of equal neighbours among the first nreal entries of every sorted ranking (row stride `stride`
+// floats), 0xffffffff if there is none
+void launch_first_tie(const float* sorted_dis, uint32_t nq, uint32_t stride, uint32_t nreal, uint32_t* out, hipStream_t s);
+
 // GEMM-formulated coarse distances on the fp32 matrix cores (row stride d, d % 4 == 0)
 void launch_row_norms(const float* x, size_t n, int d, float* out, hipStream_t s);
 void launch_coarse_gemm(int metric, const float* X, const float* Y, const float* xn, const float* yn, int nq, int ny, int d, float* out,

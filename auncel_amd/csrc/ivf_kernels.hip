@@ -2980,6 +2980,22 @@ __global__ __launch_bounds__(64) void heap_tie_order_kernel(const float* dis, ui
     }
 }
 
+__global__ __launch_bounds__(64) void first_tie_kernel(const float* sorted_dis, uint32_t stride, uint32_t nreal, uint32_t* out) {
+    const float* od = sorted_dis + (size_t)blockIdx.x * stride;
+    uint32_t first = 0xffffffffu;
+    for (uint32_t i = threadIdx.x; i + 1 < nreal; i += 64)
+        if (od[i] == od[i + 1] && i < first) first = i;
+    for (int off = 32; off; off >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)first, off);
+        first = o < first ? o : first;
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = first;
+}
+
+void launch_first_tie(const float* sorted_dis, uint32_t nq, uint32_t stride, uint32_t nreal, uint32_t* out, hipStream_t s) {
+    if (nq) LAUNCH(first_tie_kernel, dim3(nq), dim3(64), 0, s, sorted_dis, stride, nreal, out);
+}
+
 size_t heap_tie_order_lds(uint32_t nlist, uint32_t nprobe) { return (size_t)(nprobe + 2) * 8 + (size_t)nlist * 4; }
 
 // nout: leading entries of each ranking the caller reads (<= nprobe); rows without a run of equal distances there are left

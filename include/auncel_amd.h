@@ -214,9 +214,15 @@ int amd_ivf_last_timing(amd_ivf_t* h, double out[8]);
 int amd_ivf_last_scan_min_bytes(amd_ivf_t* h, double* bytes);
 /* Coarse rankings longer than 128 are sorted on the device; inside a run of exactly equal distances the reference's order
  * (knn_L2sqr_sse / knn_inner_product_sse, Auncel/utils.cpp:417-490: a binary heap over centroids 0..nlist-1, heap-sorted
- * at the end, Heap.h:295-322) depends on the heap's history.  Rows that hold such a run in the part of the ranking that
- * is read are re-run through that heap on the device: in calls of fewer than 20 queries by default (the reference's exact
- * regime), in every call with AUNCEL_AMD_COARSE_TIES=heap, never with =id (runs stay in centroid-number order).
+ * at the end, Heap.h:295-322) depends on the heap's history.  Rankings that hold such a run in the part that is read can
+ * be re-run through that heap on the device (up to 2.8 ms each at nlist 4096).  Policy:
+ *   calls of fewer than 20 queries (the reference's exact regime; what eval/*.cpp issue) -- fixed-nprobe search, coarse,
+ *     training: re-run.  Adaptive search: searched with such runs in centroid-number order first; a query reads only
+ *     entries below 2 my_nprobe + 14, so if no run starts below that the result is the reference's, else the call is
+ *     repeated with the heap's order -- same results as always re-running, at a hundredth of the cost.  Time-bounded
+ *     search: centroid-number order (the clock decides the depth);
+ *   larger calls: centroid-number order (the reference ranks sgemm output there);
+ *   AUNCEL_AMD_COARSE_TIES=heap: always re-run; =id: never.
  * *rows = rankings re-run so far on this handle. */
 int amd_ivf_coarse_tie_rows(amd_ivf_t* h, uint64_t* rows);
 
