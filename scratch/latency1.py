@@ -40,8 +40,11 @@ for name, fn in (("search_resident k=10 nprobe=16", lambda i: h.search_resident(
                  ("search_resident k=100 nprobe=16", lambda i: h.search_resident(i, 1, 100, 16)),
                  ("search_adaptive (bound 0.95)", adaptive),
                  ("search_timed budget 2 ms", lambda i: h.search_timed(i, 1, K, nlist, bud))):
+    rows0 = h.coarse_tie_rows()
     t = lat(fn)
     tm = h.last_timing()
+    if "adaptive" in name:
+        print(f"  ({h.coarse_tie_rows() - rows0} of the {len(t)} adaptive calls were repeated with the reference's heap order: a run of equal coarse distances below 2 my_nprobe + 14)")
     print(f"{name}: median {np.median(t):.3f} ms p90 {np.percentile(t, 90):.3f} min {t.min():.3f} | last call kernels: coarse {tm['coarse_ms']:.3f} scan {tm['scan_ms']:.3f} select {tm['select_ms']:.3f} total {tm['total_ms']:.3f} rounds {tm['rounds']:.0f}", flush=True)
 if os.environ.get('AUNCEL_AMD_DEBUG_TIMING'):
     adaptive(ts + 300)
