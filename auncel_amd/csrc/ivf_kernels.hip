@@ -2544,46 +2544,94 @@ __global__ __launch_bounds__(256) void row_norms_kernel(const float* x, size_t n
     out[i] = (s0 + s1) + (s2 + s3);
 }
 
+// 128 x 128 output tile per workgroup, a 64 x 64 quarter (2 x 2 MFMA tiles, 64 accumulator registers) per wave; K in
+// chunks of 16 dimensions, double-buffered through LDS with one barrier per chunk, fetched with 16-byte loads one chunk
+// ahead.  An LDS row holds the even dimensions of the chunk, then the odd ones ([row][k & 1][k >> 1], stride 20 floats): lane
+// (m, h) of v_mfma_f32_32x32x2_f32 takes A[m][2 s + h], so one ds_read_b128 feeds four consecutive k-steps, and eight
+// lanes' rows fall on disjoint banks.  The k-steps run in ascending order as before (same rounding as the first version).
+constexpr int GEMM_TK = 16, GEMM_LD = 20;
+
 template <int METRIC>
 __global__ __launch_bounds__(256) void coarse_gemm_kernel(const float* X, const float* Y, const float* xn, const float* yn, int nq,
                                                           int ny, int d, float* out) {
-    __shared__ float As[64][33], Bs[64][33];
+    __shared__ __align__(16) float As[2][128 * GEMM_LD], Bs[2][128 * GEMM_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int q0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int q0 = blockIdx.y * 128, c0 = blockIdx.x * 128;
     const int wq = wave >> 1, wc = wave & 1;
-    f32x16 acc;
+    const int m = lane & 31, h = lane >> 5;
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 16; i++) acc[i] = 0.f;
-    for (int k0 = 0; k0 < d; k0 += 32) {
-        __syncthreads();
+    for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int idx = tid + i * 256, row = idx >> 5, col = idx & 31;
-            As[row][col] = (q0 + row < nq && k0 + col < d) ? X[(size_t)(q0 + row) * d + k0 + col] : 0.f;
-            Bs[row][col] = (c0 + row < ny && k0 + col < d) ? Y[(size_t)(c0 + row) * d + k0 + col] : 0.f;
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    float4 pa[2], pb[2];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int idx = tid + i * 256, row = idx >> 2, c = idx & 3;
+            const bool kok = k0 + 4 * c < d;
+            pa[i] = q0 + row < nq && kok ? *reinterpret_cast<const float4*>(X + (size_t)(q0 + row) * d + k0 + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pb[i] = c0 + row < ny && kok ? *reinterpret_cast<const float4*>(Y + (size_t)(c0 + row) * d + k0 + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        __syncthreads();
+    };
+    auto stage = [&](int buf) {
 #pragma unroll
-        for (int kk = 0; kk < 32; kk += 2) {
-            const float a = As[wq * 32 + (lane & 31)][kk + (lane >> 5)];
-            const float b = Bs[wc * 32 + (lane & 31)][kk + (lane >> 5)];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        for (int i = 0; i < 2; i++) {
+            const int idx = tid + i * 256, row = idx >> 2, c = idx & 3;
+            float* ar = &As[buf][row * GEMM_LD + 2 * c];
+            float* br = &Bs[buf][row * GEMM_LD + 2 * c];
+            *reinterpret_cast<float2*>(ar) = make_float2(pa[i].x, pa[i].z);      // dimensions 4c, 4c+2 -> even half
+            *reinterpret_cast<float2*>(ar + 8) = make_float2(pa[i].y, pa[i].w);  // 4c+1, 4c+3 -> odd half
+            *reinterpret_cast<float2*>(br) = make_float2(pb[i].x, pb[i].z);
+            *reinterpret_cast<float2*>(br + 8) = make_float2(pb[i].y, pb[i].w);
         }
-    }
+    };
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < d; k0 += GEMM_TK, buf ^= 1) {
+        const bool more = k0 + GEMM_TK < d;
+        if (more) fetch(k0 + GEMM_TK);
+        const float* a_base = &As[buf][(wq * 64 + m) * GEMM_LD + h * 8];
+        const float* b_base = &Bs[buf][(wc * 64 + m) * GEMM_LD + h * 8];
 #pragma unroll
-    for (int reg = 0; reg < 16; reg++) {
-        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), col = lane & 31;
-        const int q = q0 + wq * 32 + row, c = c0 + wc * 32 + col;
-        if (q < nq && c < ny) {
-            const float ip = acc[reg];
-            float dis = ip;
-            if (METRIC == METRIC_L2) {
-                dis = xn[q] + yn[c] - 2 * ip;
-                if (dis < 0) dis = 0;  // utils.cpp:593
+        for (int j0 = 0; j0 < 8; j0 += 4) {
+            const float4 a0 = *reinterpret_cast<const float4*>(a_base + j0), a1 = *reinterpret_cast<const float4*>(a_base + 32 * GEMM_LD + j0);
+            const float4 b0 = *reinterpret_cast<const float4*>(b_base + j0), b1 = *reinterpret_cast<const float4*>(b_base + 32 * GEMM_LD + j0);
+            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv0[s], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv1[s], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv0[s], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv1[s], acc[1][1], 0, 0, 0);
             }
-            out[(size_t)q * ny + c] = dis;
         }
+        if (more) stage(buf ^ 1);
+        __syncthreads();
     }
+#pragma unroll
+    for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+        for (int tj = 0; tj < 2; tj++)
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h, col = m;
+                const int q = q0 + wq * 64 + ti * 32 + row, c = c0 + wc * 64 + tj * 32 + col;
+                if (q < nq && c < ny) {
+                    const float ip = acc[ti][tj][reg];
+                    float dis = ip;
+                    if (METRIC == METRIC_L2) {
+                        dis = xn[q] + yn[c] - 2 * ip;
+                        if (dis < 0) dis = 0;  // utils.cpp:593
+                    }
+                    out[(size_t)q * ny + c] = dis;
+                }
+            }
 }
 
 void launch_row_norms(const float* x, size_t n, int d, float* out, hipStream_t s) {
@@ -2593,7 +2641,7 @@ void launch_row_norms(const float* x, size_t n, int d, float* out, hipStream_t s
 void launch_coarse_gemm(int metric, const float* X, const float* Y, const float* xn, const float* yn, int nq, int ny, int d, float* out,
                         hipStream_t s) {
     if (nq == 0 || ny == 0) return;
-    const dim3 grid((ny + 63) / 64, (nq + 63) / 64);
+    const dim3 grid((ny + 127) / 128, (nq + 127) / 128);
     if (metric == METRIC_L2) LAUNCH(coarse_gemm_kernel<METRIC_L2>, grid, dim3(256), 0, s, X, Y, xn, yn, nq, ny, d, out);
     else LAUNCH(coarse_gemm_kernel<METRIC_IP>, grid, dim3(256), 0, s, X, Y, xn, yn, nq, ny, d, out);
 }
