@@ -3,13 +3,17 @@ import sys, time, os, numpy as np
 sys.path.insert(0, '/root/repo')
 from auncel_amd import capi
 rs = np.random.RandomState(1)
-shapes = [("cfg3-like", 2_000_000, 96, 1024, 0, 100, 64), ("cfg5-like", 250_000, 960, 1024, 1, 10, 64), ("d128 L2", 2_000_000, 128, 1024, 1, 10, 64)]
+shapes = [("cfg3-like", 2_000_000, 96, 1024, 0, 100, 64), ("cfg5-like", 250_000, 960, 1024, 1, 10, 64), ("d128 L2", 2_000_000, 128, 1024, 1, 10, 64),
+          ("cfg5-true np32", 1_000_000, 960, 4096, 1, 10, 32), ("cfg5-true np64", 1_000_000, 960, 4096, 1, 10, 64), ("cfg5-true np8 (one dense round)", 1_000_000, 960, 4096, 1, 10, 8)]
 only = os.environ.get("SHAPE")
 for name, nb, d, nlist, metric, k, nprobe in shapes:
     if only and only not in name: continue
     nq = 10000
     cen0 = rs.randn(nlist, d).astype(np.float32)
-    xb = (cen0[rs.randint(0, nlist, nb)] + 0.5 * rs.randn(nb, d).astype(np.float32)).astype(np.float32)
+    xb = np.empty((nb, d), np.float32)
+    for i0 in range(0, nb, 100000):
+        m = min(100000, nb - i0)
+        xb[i0:i0 + m] = cen0[rs.randint(0, nlist, m)] + 0.5 * rs.randn(m, d).astype(np.float32)
     xq = (cen0[rs.randint(0, nlist, nq)] + 0.5 * rs.randn(nq, d).astype(np.float32)).astype(np.float32)
     if metric == 0:
         xb /= np.linalg.norm(xb, axis=1, keepdims=True); xq /= np.linalg.norm(xq, axis=1, keepdims=True)
