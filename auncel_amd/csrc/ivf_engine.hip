@@ -193,6 +193,15 @@ struct amd_ivf {
     IntRange db_range, centroid_range, resident_range, call_range;  // see IntRange
     int allow_fused = 1;
     int allow_bytes = 1;
+    // small device-to-host copies go through page-locked staging and are handed out after the call's synchronisation: a copy
+    // into pageable memory blocks the host for ~20 us each, and a search ends with up to nine of them (d2h_small / flush_small)
+    PinnedBuf p_small;
+    size_t small_used = 0;
+    struct SmallCopy {
+        void* dst;
+        size_t off, bytes;
+    };
+    std::vector<SmallCopy> small;
     int ties_override = -1;  // coarse_dev: -1 as AUNCEL_AMD_COARSE_TIES / the call size say, 0 centroid-number order, 1 the reference's heap
     int last_arith = 0;  // scan arithmetic of the last search: 0 reference order, 1 fused, 2 byte codes
     // byte copy of the lists in MFMA fragment order (ivf_kernels.h) + per-slot constants, kept while the data qualifies
@@ -822,10 +831,31 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
     }
 }
 
+static void d2h_small(amd_ivf* h, void* dst, const void* src, size_t bytes, hipStream_t s) {
+    constexpr size_t LIMIT = (size_t)64 << 10, CAP = (size_t)1 << 20;
+    const size_t off = (h->small_used + 63) & ~(size_t)63;
+    if (bytes == 0) return;
+    if (bytes > LIMIT || off + bytes > CAP) {
+        HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
+        return;
+    }
+    h->p_small.ensure(CAP);
+    HIP_CHECK(hipMemcpyAsync(h->p_small.as<unsigned char>() + off, src, bytes, hipMemcpyDeviceToHost, s));
+    h->small.push_back({dst, off, bytes});
+    h->small_used = off + bytes;
+}
+// after the stream the copies were queued on has been synchronised
+static void flush_small(amd_ivf* h) {
+    for (const auto& c : h->small) memcpy(c.dst, h->p_small.as<unsigned char>() + c.off, c.bytes);
+    h->small.clear();
+    h->small_used = 0;
+}
+
 void check_device_error(amd_ivf* h) {
     uint32_t err = 0;
-    HIP_CHECK(hipMemcpyAsync(&err, h->w_error.p, 4, hipMemcpyDeviceToHost, h->stream));
+    d2h_small(h, &err, h->w_error.p, 4, h->stream);
     HIP_CHECK(stream_sync(h->stream));
+    flush_small(h);
     if (err == ERR_ARCOS_DOMAIN) throw EngineError("arcos's domain definition is [-1, 1]");
     if (err == ERR_COSINE_PRECOND) throw EngineError("cosine theorem's prerequisites");
     if (err == ERR_INVALID_KEY) throw EngineError("Invalid key");
@@ -835,8 +865,9 @@ void check_device_error(amd_ivf* h) {
 
 void fold_stats(amd_ivf* h, size_t nq) {
     unsigned long long st[3];
-    HIP_CHECK(hipMemcpyAsync(st, h->w_stats.p, 24, hipMemcpyDeviceToHost, h->stream));
+    d2h_small(h, st, h->w_stats.p, 24, h->stream);
     HIP_CHECK(stream_sync(h->stream));
+    flush_small(h);
     h->stats_host[0] += nq;
     h->stats_host[1] += st[0];
     h->stats_host[2] += st[1];
@@ -848,12 +879,13 @@ void fold_stats(amd_ivf* h, size_t nq) {
 void finish_results(amd_ivf* h, size_t n, size_t k, float* D, int64_t* I, uint32_t* stage_out = nullptr) {
     uint32_t err = 0;
     unsigned long long st[3];
-    HIP_CHECK(hipMemcpyAsync(&err, h->w_error.p, 4, hipMemcpyDeviceToHost, h->stream));
-    HIP_CHECK(hipMemcpyAsync(st, h->w_stats.p, 24, hipMemcpyDeviceToHost, h->stream));
-    if (stage_out) HIP_CHECK(hipMemcpyAsync(stage_out, h->w_stage.p, n * 4, hipMemcpyDeviceToHost, h->stream));
-    HIP_CHECK(hipMemcpyAsync(D, h->w_D.p, n * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    HIP_CHECK(hipMemcpyAsync(I, h->w_I.p, n * k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    d2h_small(h, &err, h->w_error.p, 4, h->stream);
+    d2h_small(h, st, h->w_stats.p, 24, h->stream);
+    if (stage_out) d2h_small(h, stage_out, h->w_stage.p, n * 4, h->stream);
+    d2h_small(h, D, h->w_D.p, n * k * sizeof(float), h->stream);
+    d2h_small(h, I, h->w_I.p, n * k * sizeof(int64_t), h->stream);
     HIP_CHECK(stream_sync(h->stream));
+    flush_small(h);
     if (err == ERR_ARCOS_DOMAIN) throw EngineError("arcos's domain definition is [-1, 1]");
     if (err == ERR_COSINE_PRECOND) throw EngineError("cosine theorem's prerequisites");
     if (err == ERR_INVALID_KEY) throw EngineError("Invalid key");
@@ -2450,9 +2482,10 @@ static void adaptive_core_once(amd_ivf_t* h, const float* d_x, size_t start, siz
     for (auto& t : th) t.join();
     for (auto& e : errs)
         if (e) std::rethrow_exception(e);
-    HIP_CHECK(hipMemcpyAsync(my_nprobe + start, d_np.as<unsigned long long>() + start, n * 8, hipMemcpyDeviceToHost, h->stream));
-    HIP_CHECK(hipMemcpyAsync(t_recalls + start, dtr + start, n * 4, hipMemcpyDeviceToHost, h->stream));
+    d2h_small(h, my_nprobe + start, d_np.as<unsigned long long>() + start, n * 8, h->stream);
+    d2h_small(h, t_recalls + start, dtr + start, n * 4, h->stream);
     HIP_CHECK(stream_sync(h->stream));
+    flush_small(h);
     // fold the kids' counters and kernel timings into the handle
     const double wall = wc.stop();
     double ms[NCAT] = {0, 0, 0}, ln[NCAT] = {0, 0, 0};
@@ -2515,8 +2548,9 @@ static void adaptive_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n
     h->w_misc.ensure(n * 4);
     launch_first_tie(h->w_cdis.as<float>(), (uint32_t)n, (uint32_t)nlist, (uint32_t)nreal, h->w_misc.as<uint32_t>(), h->stream);
     std::vector<uint32_t> first(n);
-    HIP_CHECK(hipMemcpyAsync(first.data(), h->w_misc.p, n * 4, hipMemcpyDeviceToHost, h->stream));
+    d2h_small(h, first.data(), h->w_misc.p, n * 4, h->stream);
     HIP_CHECK(stream_sync(h->stream));
+    flush_small(h);
     bool redo = false;
     for (size_t i = 0; i < n; i++) {
         const uint64_t bound = 2 * my_nprobe[start + i] + 14;
