@@ -202,6 +202,10 @@ struct amd_ivf {
         size_t off, bytes;
     };
     std::vector<SmallCopy> small;
+    bool want_first_tie = false;        // adaptive_slice: also leave the start of each ranking's first run of equal distances
+    size_t first_tie_nreal = 0;
+    DevBuf w_first_tie;
+    std::vector<uint32_t> first_tie_host;
     int ties_override = -1;  // coarse_dev: -1 as AUNCEL_AMD_COARSE_TIES / the call size say, 0 centroid-number order, 1 the reference's heap
     int last_arith = 0;  // scan arithmetic of the last search: 0 reference order, 1 fused, 2 byte codes
     // byte copy of the lists in MFMA fragment order (ivf_kernels.h) + per-slot constants, kept while the data qualifies
@@ -1531,7 +1535,8 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         const bool fits = (double)n * (double)total_nprobe * (double)padded <= (double)budget && n * total_nprobe <= seg_cap;
         bool fixed_complete = !base.tuner.enabled && !base.train.enabled && fits && (base.fixed_two || first_round >= total_nprobe);
         static const size_t ahead_env = getenv("AUNCEL_AMD_ROUNDS_AHEAD") ? (size_t)atoi(getenv("AUNCEL_AMD_ROUNDS_AHEAD")) : 0;
-        size_t batch = ahead_env ? ahead_env : base.train.enabled ? 4 : base.tuner.enabled ? 2 : (base.fixed_two ? 2 : 1);
+        // (a handful of queries: three in four are done after the first round, and looking costs less than a round of empty launches)
+        size_t batch = ahead_env ? ahead_env : base.train.enabled ? 4 : base.tuner.enabled ? (n < 20 ? 1 : 2) : (base.fixed_two ? 2 : 1);
         if (fixed_complete) batch = base.fixed_two && first_round < total_nprobe ? 2 : 1;
         bool planned = false;  // the round at hand has been planned (and looked at) already
         for (size_t round = 0;;) {
@@ -2371,6 +2376,10 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
     // full coarse ranking (Error_sys::search sets nprobe = nlist, profile.cpp:220)
     coarse_dev(L, d_x, n, nlist, coarse_mode, L->w_cdis.as<float>(), L->w_ckeys.as<int64_t>(),
                ix(L)->allow_fused && ix(L)->centroid_range.fusable_with(qr, L->metric), coarse_prefix);
+    if (L->want_first_tie) {
+        L->w_first_tie.ensure(n * 4);
+        launch_first_tie(L->w_cdis.as<float>(), (uint32_t)n, (uint32_t)nlist, (uint32_t)L->first_tie_nreal, L->w_first_tie.as<uint32_t>(), L->stream);
+    }
     init_state(L, n, K, true);
     launch_set_online(L->metric, (uint32_t)nlist, (uint32_t)n, L->w_cdis.as<float>(), L->w_ckeys.as<int64_t>(), (uint32_t)nlist,
                       ix(L)->d_interdis.as<float>(), ix(L)->d_arcos.as<float>(), L->w_dtb.as<float>(), L->w_error.as<uint32_t>(), L->stream);
@@ -2484,6 +2493,10 @@ static void adaptive_core_once(amd_ivf_t* h, const float* d_x, size_t start, siz
         if (e) std::rethrow_exception(e);
     d2h_small(h, my_nprobe + start, d_np.as<unsigned long long>() + start, n * 8, h->stream);
     d2h_small(h, t_recalls + start, dtr + start, n * 4, h->stream);
+    if (h->want_first_tie) {
+        h->first_tie_host.assign(n, 0);
+        d2h_small(h, h->first_tie_host.data(), h->w_first_tie.p, n * 4, h->stream);
+    }
     HIP_CHECK(stream_sync(h->stream));
     flush_small(h);
     // fold the kids' counters and kernel timings into the handle
@@ -2532,25 +2545,25 @@ static void adaptive_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n
     for (int i = 0; i < 4; i++) stats0[i] = h->stats_host[i];
     const std::vector<uint64_t> np0(my_nprobe + start, my_nprobe + start + n);
     const std::vector<float> tr0(t_recalls + start, t_recalls + start + n);
+    // the start of the first run of equal distances in every ranking of the call comes back with the results
+    // (first_tie_kernel right behind the coarse ranking, over what adaptive_core_once ranks: its coarse_prefix)
+    const size_t nlist = h->nlist;
+    size_t nreal = std::max<size_t>(nlist / 8 + 21, (size_t)((double)(nlist / 8) * (double)multipler) + 2);
+    for (size_t i = 0; i < n; i++) nreal = std::max<size_t>(nreal, (size_t)np0[i] + 1);
+    nreal = std::min(nreal + 16, nlist);
     h->ties_override = 0;
+    h->want_first_tie = true;
+    h->first_tie_nreal = nreal;
     try {
         adaptive_core_once(h, d_x, start, n, query_topk, multipler, std_m, require_acc, gt_D, profile, coarse_mode, my_nprobe, t_recalls, D, I, qr);
     } catch (...) {
         h->ties_override = -1;
+        h->want_first_tie = false;
         throw;
     }
     h->ties_override = -1;
-    // first run of equal distances in every ranking of the call (they are still in the slice's workspace)
-    const size_t nlist = h->nlist;
-    size_t nreal = std::max<size_t>(nlist / 8 + 21, (size_t)((double)(nlist / 8) * (double)multipler) + 2);
-    for (size_t i = 0; i < n; i++) nreal = std::max<size_t>(nreal, (size_t)np0[i] + 1);
-    nreal = std::min(nreal + 16, nlist);  // what adaptive_core_once had ranked (its coarse_prefix)
-    h->w_misc.ensure(n * 4);
-    launch_first_tie(h->w_cdis.as<float>(), (uint32_t)n, (uint32_t)nlist, (uint32_t)nreal, h->w_misc.as<uint32_t>(), h->stream);
-    std::vector<uint32_t> first(n);
-    d2h_small(h, first.data(), h->w_misc.p, n * 4, h->stream);
-    HIP_CHECK(stream_sync(h->stream));
-    flush_small(h);
+    h->want_first_tie = false;
+    const std::vector<uint32_t>& first = h->first_tie_host;
     bool redo = false;
     for (size_t i = 0; i < n; i++) {
         const uint64_t bound = 2 * my_nprobe[start + i] + 14;
