@@ -2890,7 +2890,7 @@ template <bool IsMax> __device__ inline void lds_heap_push(HeapEnt* h, uint32_t 
 // walks in flight, one level per tick each; a pop may not start while a walk in flight is above slot n - t (it could
 // still change the entry the pop is about to take).  2.4 ticks per pop instead of one walk of m levels (measured, nlist
 // 4096: 2.8 ms a row against 12.4 ms for the plain walk below; the filling takes 0.06 ms of that).
-// (scratch/heap_proto.py is the model both halves were checked with, entry for entry, against the literal heap.)
+// (tests/heap_tie_model.py is the model both halves were checked with, entry for entry, against the literal heap.)
 template <bool IsMax> __device__ inline void floyd_fill_pow2(HeapEnt* a, const float* row, uint32_t n, int lane) {
     const int m = 31 - __builtin_clz(n);
     const uint32_t F = n >> 1;

@@ -1,4 +1,8 @@
-"""prototype: reference heap ranking (k = n = 2^m) == Floyd-style parallel build + tail + pipelined heapsort"""
+"""Model of heap_tie_order_kernel's fast path (auncel_amd/csrc/ivf_kernels.hip): the reference's coarse ranking with
+nprobe == nlist == 2^m -- a binary heap filled one centroid at a time, then heap-sorted (Auncel/utils.cpp:454-490,
+Heap.h:88-142,295-322) -- restated as (1) a level-parallel Floyd-style build with the reference's slot assignment plus the
+last m steps one by one, and (2) a heap sort whose pops are pipelined two levels apart.  ref_rank is the literal heap;
+tests/test_heap_tie_model.py holds the three to each other and to the oracle's knn on tie-heavy rows."""
 import numpy as np, sys
 
 M = float('inf')
