@@ -844,6 +844,7 @@ static void d2h_small(amd_ivf* h, void* dst, const void* src, size_t bytes, hipS
         return;
     }
     h->p_small.ensure(CAP);
+    if (h->small.empty()) h->small_used = 0;
     HIP_CHECK(hipMemcpyAsync(h->p_small.as<unsigned char>() + off, src, bytes, hipMemcpyDeviceToHost, s));
     h->small.push_back({dst, off, bytes});
     h->small_used = off + bytes;
@@ -855,11 +856,21 @@ static void flush_small(amd_ivf* h) {
     h->small_used = 0;
 }
 
+// a failed synchronisation must not leave copies pending: their destinations may be the caller's stack
+static void sync_and_flush(amd_ivf* h, hipStream_t s) {
+    const hipError_t e = stream_sync(s);
+    if (e != hipSuccess) {
+        h->small.clear();
+        h->small_used = 0;
+        HIP_CHECK(e);
+    }
+    flush_small(h);
+}
+
 void check_device_error(amd_ivf* h) {
     uint32_t err = 0;
     d2h_small(h, &err, h->w_error.p, 4, h->stream);
-    HIP_CHECK(stream_sync(h->stream));
-    flush_small(h);
+    sync_and_flush(h, h->stream);
     if (err == ERR_ARCOS_DOMAIN) throw EngineError("arcos's domain definition is [-1, 1]");
     if (err == ERR_COSINE_PRECOND) throw EngineError("cosine theorem's prerequisites");
     if (err == ERR_INVALID_KEY) throw EngineError("Invalid key");
@@ -870,8 +881,7 @@ void check_device_error(amd_ivf* h) {
 void fold_stats(amd_ivf* h, size_t nq) {
     unsigned long long st[3];
     d2h_small(h, st, h->w_stats.p, 24, h->stream);
-    HIP_CHECK(stream_sync(h->stream));
-    flush_small(h);
+    sync_and_flush(h, h->stream);
     h->stats_host[0] += nq;
     h->stats_host[1] += st[0];
     h->stats_host[2] += st[1];
@@ -888,8 +898,7 @@ void finish_results(amd_ivf* h, size_t n, size_t k, float* D, int64_t* I, uint32
     if (stage_out) d2h_small(h, stage_out, h->w_stage.p, n * 4, h->stream);
     d2h_small(h, D, h->w_D.p, n * k * sizeof(float), h->stream);
     d2h_small(h, I, h->w_I.p, n * k * sizeof(int64_t), h->stream);
-    HIP_CHECK(stream_sync(h->stream));
-    flush_small(h);
+    sync_and_flush(h, h->stream);
     if (err == ERR_ARCOS_DOMAIN) throw EngineError("arcos's domain definition is [-1, 1]");
     if (err == ERR_COSINE_PRECOND) throw EngineError("cosine theorem's prerequisites");
     if (err == ERR_INVALID_KEY) throw EngineError("Invalid key");
@@ -2497,8 +2506,7 @@ static void adaptive_core_once(amd_ivf_t* h, const float* d_x, size_t start, siz
         h->first_tie_host.assign(n, 0);
         d2h_small(h, h->first_tie_host.data(), h->w_first_tie.p, n * 4, h->stream);
     }
-    HIP_CHECK(stream_sync(h->stream));
-    flush_small(h);
+    sync_and_flush(h, h->stream);
     // fold the kids' counters and kernel timings into the handle
     const double wall = wc.stop();
     double ms[NCAT] = {0, 0, 0}, ln[NCAT] = {0, 0, 0};

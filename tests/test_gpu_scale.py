@@ -94,9 +94,11 @@ def test_adaptive_sample_vs_oracle(setup):
     assert my_np[ts:].min() >= 1 and len(np.unique(my_np[ts:])) > 3  # the bound really adapts per query
 
 
-def test_time_bounded_search_follows_the_budget(setup):
+def test_time_bounded_search_follows_the_budget(setup, monkeypatch):
     """effect_time.cpp's loop: one query per call, budgets of a few ms.  More budget -> deeper probe loop; the call returns
-    within the budget (plus slack for a shared box); results pinned against the oracle at the reported depth."""
+    within the budget (plus slack for a shared box); results pinned against the oracle at the reported depth.  The
+    time-bounded path keeps runs of bit-equal coarse distances in centroid-number order (include/auncel_amd.h), so the
+    oracle is fed that ranking: same distances as its own, same centroids, runs ordered by number."""
     import time
     h, orc, xq, nlist = setup["h"], setup["orc"], setup["xq"], setup["nlist"]
     h.set_queries(xq)
@@ -106,7 +108,13 @@ def test_time_bounded_search_follows_the_budget(setup):
     budgets[:S] = np.tile([1.0, 2.0, 4.0, 8.0], S // 4)
     h.search_timed(0, 1, K, nlist, budgets)  # warm-up (allocations)
     used, wall = np.zeros(S, np.int64), np.zeros(S)
-    cd, ck = orc.knn(1, xq[:S], setup["cen"], nlist, nthreads=8)
+    ocd, ock = orc.knn(1, xq[:S], setup["cen"], nlist, nthreads=8)
+    monkeypatch.setenv("AUNCEL_AMD_COARSE_TIES", "id")
+    cd, ck = h.coarse(xq[:S], nlist, mode=0)
+    monkeypatch.delenv("AUNCEL_AMD_COARSE_TIES")
+    assert np.array_equal(cd.view(np.uint32), ocd.view(np.uint32))
+    for i in range(S):
+        assert np.array_equal(ck[i], ock[i][np.lexsort((ock[i], ocd[i]))])  # the oracle's ranking with runs sorted by centroid number
     for i in range(S):
         t0 = time.perf_counter()
         D, I, u = h.search_timed(i, 1, K, nlist, budgets)
