@@ -2,6 +2,7 @@
 // oracle/_ref/libfaiss_ref.a) drive integration/AmdIndexIVFFlat.h, the subclass a maintainer adds to the reference tree, and
 // every result is compared bit for bit with the same calls on the reference's CPU IndexIVFFlat:
 //   * IndexIVF::search with fixed nprobe (batched and one query per call, k = 10 / 100, nprobe 1 / 8 / 200, store_pairs),
+//   * the reference's IndexShards(threaded) over two AmdIndexIVFFlat shards (two engine handles driven from its WorkerThreads),
 //   * Error_sys::sys_train (the training branch, traces after Trace::SB),
 //   * Error_sys::search, one query per call as eval/bound.cpp:380-386 does (tune branch: D, I, my_nprobe, t_recalls).
 // Built by oracle/Makefile (target subclass) in the container that has the reference; the binary travels to the GPU box.
@@ -12,6 +13,7 @@
 #include <random>
 
 #include "Auncel/IVF_pro.h"
+#include "Auncel/IndexShards.h"
 #include "Auncel/profile.h"
 
 using namespace faiss;
@@ -90,6 +92,36 @@ int main(int argc, char** argv) {
         ref.search_preassigned(nq, xq.data(), 10, ck.data(), cd.data(), D1.data(), I1.data(), true);
         amd.search_preassigned(nq, xq.data(), 10, ck.data(), cd.data(), D2.data(), I2.data(), true);
         expect(same(D1, D2) && same(I1, I2), "search_preassigned, store_pairs");
+    }
+
+    // ---- the reference's IndexShards (threaded: one WorkerThread per shard, IndexShards.cpp:261-311) over two shards that split the
+    // data by id range, once with the reference's CPU shards, once with two AmdIndexIVFFlat (two engine handles driven concurrently)
+    {
+        const size_t half = nb / 2;
+        IndexFlat qa(d, METRIC_L2), qb(d, METRIC_L2), qc(d, METRIC_L2), qd(d, METRIC_L2);
+        for (IndexFlat* q : {&qa, &qb, &qc, &qd}) q->add(nlist, q1.xb.data());
+        IndexIVFFlat ca(&qa, d, nlist, METRIC_L2), cb(&qb, d, nlist, METRIC_L2);
+        AmdIndexIVFFlat ga(&qc, d, nlist, METRIC_L2, 0), gb(&qd, d, nlist, METRIC_L2, 0);
+        for (IndexIVF* ix : std::initializer_list<IndexIVF*>{&ca, &cb, &ga, &gb}) {
+            ix->is_trained = true;
+            ix->init_tune(0, 1, nullptr, nullptr, nullptr, nullptr, nullptr);
+            ix->nprobe = 16;
+        }
+        ca.add(half, xb.data());
+        cb.add(nb - half, xb.data() + half * d);
+        ga.add(half, xb.data());
+        gb.add(nb - half, xb.data() + half * d);
+        IndexShards cpu_shards((int)d, true, true), amd_shards((int)d, true, true);
+        cpu_shards.add_shard(&ca);
+        cpu_shards.add_shard(&cb);
+        amd_shards.add_shard(&ga);
+        amd_shards.add_shard(&gb);
+        const size_t k = 10;
+        std::vector<float> D1(nq * k), D2(nq * k);
+        std::vector<idx_t> I1(nq * k), I2(nq * k);
+        cpu_shards.search(nq, xq.data(), k, D1.data(), I1.data());
+        amd_shards.search(nq, xq.data(), k, D2.data(), I2.data());
+        expect(same(D1, D2) && same(I1, I2), "IndexShards(threaded) over two shards, successive ids, k 10 nprobe 16");
     }
 
     // ---- Auncel: exact ground truth, training, adaptive search
