@@ -16,11 +16,16 @@ __global__ __launch_bounds__(256) void plan_counts_kernel(PlanArgs a) {
     for (uint32_t l = blockIdx.x * 256 + threadIdx.x; l < a.nlist; l += gridDim.x * 256) a.lcount[l] = 0;
     const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
-    if (i >= a.nq) return;
+    // queries that may need another round are counted per workgroup first: one atomic per query on the one counter
+    // serialises thousands of waves in the L2
+    __shared__ uint32_t s_more;
+    if (threadIdx.x == 0) s_more = 0;
+    __syncthreads();
+    const bool have = i < a.nq;
     uint32_t cnt = 0, pad = 0;
     unsigned long long need = 0;
     const unsigned long long ra = a.row_align - 1;
-    if (!a.done[i]) {
+    if (have && !a.done[i]) {
         const uint32_t stage = a.stage[i];
         unsigned long long target = (unsigned long long)stage + a.round_len;
         const unsigned long long np = a.my_nprobe ? a.my_nprobe[a.id_offset + i] : 0ull;
@@ -57,7 +62,7 @@ __global__ __launch_bounds__(256) void plan_counts_kernel(PlanArgs a) {
         cnt = (uint32_t)(target - stage);
         // queries this round cannot be the last one for: the host skips the next planning pass when there are none
         const bool ends = target >= a.total_nprobe || last || (a.tune && np != 0);
-        if (!ends && lane == 0) atomicAdd(&a.counters[10], 1u);
+        if (!ends && lane == 0) atomicAdd(&s_more, 1u);
         const int64_t* kq = a.keys + (size_t)i * a.key_stride + stage;
         for (uint32_t p = lane; p < cnt; p += 64) {
             const int64_t key = kq[p];
@@ -72,11 +77,13 @@ __global__ __launch_bounds__(256) void plan_counts_kernel(PlanArgs a) {
             pad += __shfl_xor(pad, off);
         }
     }
-    if (lane == 0) {
+    if (have && lane == 0) {
         a.cnt[i] = cnt;
         a.need[i] = need;
         a.pad[i] = pad;
     }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_more) atomicAdd(&a.counters[10], s_more);
 }
 
 // exclusive prefix sum of one value per thread over a block of 1024 threads (16 waves): shuffles inside the waves, one LDS
@@ -181,13 +188,19 @@ __global__ __launch_bounds__(1024) void plan_prefix_kernel(PlanArgs a) {
 __global__ __launch_bounds__(256) void plan_segments_kernel(PlanArgs a) {
     const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
-    if (i >= a.nq) return;
-    const uint32_t c = a.cnt[i];
+    // launch positions of the active queries (compaction order is irrelevant): one atomic per workgroup on the shared counter,
+    // not one per query -- thousands of waves on one address queue up in the L2
+    __shared__ uint32_t s_n, s_base;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const uint32_t c = i < a.nq ? a.cnt[i] : 0u;
+    uint32_t local = 0;
+    if (c && lane == 0) local = atomicAdd(&s_n, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n) s_base = atomicAdd(&a.counters[6], s_n);
+    __syncthreads();
     if (!c) return;
-    if (lane == 0) {
-        const uint32_t slot = atomicAdd(&a.counters[6], 1u);  // compaction order is irrelevant
-        a.qsel[slot] = i;
-    }
+    if (lane == 0) a.qsel[s_base + local] = i;
     const uint32_t stage = a.stage[i];
     const int64_t* kq = a.keys + (size_t)i * a.key_stride + stage;
     unsigned long long cur = a.dist_base[i];  // wave-uniform running offset
