@@ -320,11 +320,7 @@ __global__ __launch_bounds__(256) void plan_scatter_kernel(PlanArgs a) {
 }
 
 // ---- 6. tiles and query groups of every list (one thread per list), shapes 1 | 2 | 4 in three item ranges
-__global__ __launch_bounds__(256) void plan_items_kernel(PlanArgs a) {
-    const uint32_t l = blockIdx.x * 256 + threadIdx.x;
-    if (l >= a.nlist) return;
-    const uint32_t c = a.lcount[l];
-    if (!c) return;
+__device__ inline void items_of_list(const PlanArgs& a, uint32_t l, uint32_t c, unsigned long long& slots, unsigned long long& useful) {
     const uint32_t p0 = a.lstart[l], g0 = a.gbase[l];
     for (uint32_t o = 0, g = 0; o < c; o += SCAN_RQ, g++) {
         a.group_p0[g0 + g] = p0 + o;
@@ -335,7 +331,6 @@ __global__ __launch_bounds__(256) void plan_items_kernel(PlanArgs a) {
                        n1 + n2 + n4 + a.ibase[3 * a.nlist + l]};
     const uint32_t sz = (uint32_t)(a.list_off[l + 1] - a.list_off[l]);
     const uint64_t vb0 = a.list_off[l];
-    unsigned long long slots = 0, useful = 0;
     if (a.mfma_chunk) {
         // items of one chunk are consecutive (its query blocks): they run close together on one XCD (scan_mfma_kernel's
         // item order), so a chunk fetched for one query block is still in that L2 for the next
@@ -356,8 +351,6 @@ __global__ __launch_bounds__(256) void plan_items_kernel(PlanArgs a) {
                 slots += (unsigned long long)MFMA_QBLOCK * (((it.nvec + 63) / 64) * 64);
                 useful += (unsigned long long)it.npair * it.nvec;
             }
-        atomicAdd(&a.acc64[0], slots);
-        atomicAdd(&a.acc64[1], useful);
         return;
     }
     for (uint32_t qb = 0; qb < c; qb += a.qblock) {
@@ -380,8 +373,23 @@ __global__ __launch_bounds__(256) void plan_items_kernel(PlanArgs a) {
             useful += (unsigned long long)nq_blk * it.nvec;
         }
     }
-    atomicAdd(&a.acc64[0], slots);
-    atomicAdd(&a.acc64[1], useful);
+}
+
+
+__global__ __launch_bounds__(256) void plan_items_kernel(PlanArgs a) {
+    const uint32_t l = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t c = l < a.nlist ? a.lcount[l] : 0u;
+    unsigned long long slots = 0, useful = 0;
+    if (c) items_of_list(a, l, c, slots, useful);
+    // one pair of atomics per wave, not per list
+    for (int off = 32; off; off >>= 1) {
+        slots += __shfl_xor(slots, off);
+        useful += __shfl_xor(useful, off);
+    }
+    if ((threadIdx.x & 63) == 0 && slots) {
+        atomicAdd(&a.acc64[0], slots);
+        atomicAdd(&a.acc64[1], useful);
+    }
 }
 
 // counters a round accumulates into with atomics
