@@ -6,30 +6,43 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libauncel_amd.so")
-SOURCES = ["ivf_kernels.hip", "ivf_plan.hip", "ivf_kmeans.hip", "ivf_engine.hip"]
+SOURCES = ["ivf_kernels.hip", "ivf_select.hip", "ivf_plan.hip", "ivf_kmeans.hip", "ivf_engine.hip"]
 # -ffp-contract=off: products and sums are rounded separately, as in the reference's SSE build
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result"]
 
 
-def needs_build():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if os.path.isfile(os.path.join(CSRC, f))] + [os.path.join(HERE, "..", "include", "auncel_amd.h")]
-    return any(os.path.getmtime(p) > t for p in deps)
+def _deps(src):
+    """a source and the headers next to it (plus the public header)"""
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    return [os.path.join(CSRC, src)] + hdrs + [os.path.join(HERE, "..", "include", "auncel_amd.h")]
 
 
 def build(force=False):
+    """one object per source, compiled in parallel and only when stale, then linked"""
+    from concurrent.futures import ThreadPoolExecutor
     extra = os.environ.get("AUNCEL_AMD_CXXFLAGS", "").split()
-    stamp = os.path.join(LIBDIR, "flags.txt")  # a library built with other flags (experiments) is rebuilt
+    stamp = os.path.join(LIBDIR, "flags.txt")  # objects built with other flags (experiments) are rebuilt
     want = " ".join(FLAGS + extra)
     same_flags = os.path.exists(stamp) and open(stamp).read() == want
-    if not force and same_flags and not needs_build():
-        return LIB
     os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
-    subprocess.run(cmd, check=True)
+    cflags = [f for f in FLAGS if f != "-shared"]
+    todo = []
+    for s in SOURCES:
+        o = os.path.join(objdir, s + ".o")
+        stale = force or not same_flags or not os.path.exists(o) or any(os.path.getmtime(p) > os.path.getmtime(o) for p in _deps(s))
+        if stale:
+            todo.append([hipcc] + cflags + extra + ["-c", os.path.join(CSRC, s), "-o", o])
+    if not todo and os.path.exists(LIB) and same_flags:
+        return LIB
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        for r in ex.map(lambda c: subprocess.run(c), todo):
+            if r.returncode != 0:
+                raise RuntimeError("hipcc failed")
+    objs = [os.path.join(objdir, s + ".o") for s in SOURCES]
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB], check=True)
     with open(stamp, "w") as f:
         f.write(want)
     return LIB

@@ -24,7 +24,7 @@ SYMBOLS = [
     "amd_ivf_set_tuner", "amd_ivf_search_adaptive", "amd_ivf_search_adaptive_x", "amd_ivf_search_timed", "amd_ivf_search_timed_x",
     "amd_ivf_train_samples",
     "amd_ivf_train_samples_x", "amd_ivf_trace_sb", "amd_ivf_arcos_table", "amd_ivf_merge_tables",
-    "amd_ivf_last_timing", "amd_ivf_last_scan_min_bytes", "amd_ivf_coarse_tie_rows", "amd_ivf_set_byte_codes",
+    "amd_ivf_last_timing", "amd_ivf_last_scan_min_bytes", "amd_ivf_coarse_tie_rows", "amd_ivf_last_tie_fixed", "amd_ivf_set_byte_codes",
     "amd_ivf_kmeans",
     "amd_ivf_range_search_preassigned", "amd_ivf_range_search", "amd_ivf_range_results",
     "amd_ivf_scan_arith",
@@ -362,6 +362,12 @@ class Handle:
         """coarse rankings re-run through the reference's heap so far (runs of equal distances, include/auncel_amd.h)"""
         v = C.c_uint64(0)
         _chk(lib().amd_ivf_coarse_tie_rows(self._h, C.byref(v)))
+        return int(v.value)
+
+    def last_tie_fixed(self):
+        """queries of the last search whose result came from the heap replayed over their admission log (include/auncel_amd.h)"""
+        v = C.c_uint64(0)
+        _chk(lib().amd_ivf_last_tie_fixed(self._h, C.byref(v)))
         return int(v.value)
 
     def set_byte_codes(self, enable):

@@ -1,0 +1,96 @@
+// Device-side helpers shared by the scan, selection and coarse-ranking kernels (gfx950).
+#pragma once
+#include "ivf_kernels.h"
+
+#include <float.h>
+
+namespace amdivf {
+
+// heap entries made by this kernel carry (REF_TAG | list << 32 | position); anything else in the
+// id slot is a caller-supplied id (scanner API) or -1 (empty)
+constexpr int64_t REF_TAG = 1ll << 62;
+
+template <bool IsMax> __device__ __forceinline__ bool hcmp(float a, float b) { return IsMax ? a > b : a < b; }
+template <bool IsMax> __device__ __forceinline__ float hneutral() { return IsMax ? FLT_MAX : -FLT_MAX; }
+
+// Heap.h:88-118 -- executed redundantly by every lane of the wave (uniform control flow).  Both children's
+// value and id are requested together so that a level costs one LDS round trip.
+template <bool IsMax> __device__ inline void heap_pop(int k, float* val, int64_t* ref) {
+    val--;
+    ref--;
+    const float v = val[k];
+    int i = 1;
+    for (;;) {
+        const int i1 = i << 1, i2 = i1 + 1;
+        if (i1 > k) break;
+        const int j2 = i2 <= k ? i2 : i1;  // i2 == k + 1: there is no right child
+        const float c1 = val[i1], c2 = val[j2];
+        const int64_t r1 = ref[i1], r2 = ref[j2];
+        const bool left = (i2 == k + 1) || hcmp<IsMax>(c1, c2);
+        const float c = left ? c1 : c2;
+        if (hcmp<IsMax>(v, c)) break;
+        val[i] = c;
+        ref[i] = left ? r1 : r2;
+        i = left ? i1 : i2;
+    }
+    val[i] = val[k];
+    ref[i] = ref[k];
+}
+
+// Heap.h:125-142
+template <bool IsMax> __device__ inline void heap_push(int k, float* val, int64_t* ref, float v, int64_t id) {
+    val--;
+    ref--;
+    int i = k;
+    while (i > 1) {
+        const int f = i >> 1;
+        const float fv = val[f];
+        if (!hcmp<IsMax>(v, fv)) break;
+        val[i] = fv;
+        ref[i] = ref[f];
+        i = f;
+    }
+    val[i] = v;
+    ref[i] = id;
+}
+
+__device__ __forceinline__ uint32_t fkey(float x) {
+    const uint32_t u = __float_as_uint(x);
+    return u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(uint32_t key) { return __uint_as_float((key & 0x80000000u) ? key ^ 0x80000000u : ~key); }
+template <bool IsMax> __device__ __forceinline__ bool kcmp(uint32_t a, uint32_t b) { return IsMax ? a > b : a < b; }
+
+__device__ __forceinline__ float rl_f(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+__device__ __forceinline__ int rl_i(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+__device__ __forceinline__ uint32_t rl_u(uint32_t x, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)x, l); }
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
+    for (int off = 32; off; off >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)x, off);
+        x = x > o ? x : o;
+    }
+    return x;
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) {
+    for (int off = 32; off; off >>= 1) x += (uint32_t)__shfl_xor((int)x, off);
+    return x;
+}
+
+// largest error code raised by any lane (0 in the common case: one ballot, no shuffles)
+__device__ __forceinline__ uint32_t wave_err(uint32_t err) { return __ballot(err != 0) ? wave_max_u32(err) : 0u; }
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// order keys: smaller key <=> better candidate, whatever the metric
+template <bool IsMax> __device__ __forceinline__ uint32_t okey(float x) {
+    const uint32_t kx = fkey(x);
+    return IsMax ? kx : ~kx;
+}
+template <bool IsMax> __device__ __forceinline__ float okey_inv(uint32_t key) { return fkey_inv(IsMax ? key : ~key); }
+
+}  // namespace amdivf

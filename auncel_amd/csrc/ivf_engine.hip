@@ -240,12 +240,14 @@ struct amd_ivf {
     DevBuf c_heap_val, c_heap_ref, c_stage, c_nscan, c_done, c_seg_off, c_seg_list, c_seg_count;
     PinnedBuf p_items, p_pair_query, p_pair_out, p_seg_off, p_seg_list, p_seg_count, p_qsel, p_seg_begin;
     DevBuf w_seg_begin;
+    DevBuf w_log, w_log_cnt, w_amb, w_tie_flag;  // sorted-array selection: admission logs, ambiguity marks, tie_fix flags
+    size_t last_state_n = 0;                     // queries of the last search (amd_ivf_last_tie_fixed reads their flags)
     // chained rounds: the planning counters of every round of the last search (grid hints for the next one of the same shape)
-    DevBuf w_cand, w_ccnt, w_cprobes, w_href_tmp;  // two-kernel selection (launch_select_lanes)
     DevBuf w_pl_hist;
     PinnedBuf p_hist;
     std::vector<uint32_t> round_hint;  // [round][16]
     uint64_t hint_sig = 0;
+    bool force_heap_select = false;  // (set while a search is repeated after ERR_LOG_OVERFLOW)
     DevBuf w_limit;  // time-bounded search: per-slot end of the probe loop (plan_counts_kernel -> replay_kernel)
     DevBuf w_tie_rows;  // rankings re-run through the reference's heap because of equal distances (launch_heap_tie_order)
 
@@ -414,6 +416,10 @@ void init_state(amd_ivf* h, size_t n, size_t k, bool tune_or_train) {
     h->w_stats.ensure(4 * 8);
     h->w_error.ensure(4);
     h->w_thr.ensure(n * sizeof(float));
+    h->w_log_cnt.ensure(n * 4);
+    h->w_amb.ensure(n * 4);
+    h->w_tie_flag.ensure(n * 4);
+    h->last_state_n = n;
     InitStateArgs ia{};
     ia.n = n;
     ia.k = k;
@@ -428,6 +434,9 @@ void init_state(amd_ivf* h, size_t n, size_t k, bool tune_or_train) {
     ia.stoped = h->w_stoped.as<uint32_t>();
     ia.stats = h->w_stats.as<unsigned long long>();
     ia.error = h->w_error.as<uint32_t>();
+    ia.log_cnt = h->w_log_cnt.as<uint32_t>();
+    ia.amb = h->w_amb.as<uint32_t>();
+    ia.tie_flag = h->w_tie_flag.as<uint32_t>();
     launch_init_state(ia, h->stream);
     if (tune_or_train) h->w_dtb.ensure(n * (h->nlist / 8 + 20) * sizeof(float));
 }
@@ -515,10 +524,8 @@ static void print_replay_dbg(amd_ivf* h, size_t mb, hipStream_t s) {
     std::vector<unsigned long long> dbg(mb * 8);
     HIP_CHECK(hipMemcpyAsync(dbg.data(), h->w_misc.p, mb * 64, hipMemcpyDeviceToHost, s));
     HIP_CHECK(stream_sync(s));
-    static const bool lanes = getenv("AUNCEL_AMD_LANES") && atoi(getenv("AUNCEL_AMD_LANES"));
     static const char* nm_replay[8] = {"wave cycles", "heap updates", "candidates", "rule evaluations", "stream cycles", "rule cycles", "masked chunks", "probes"};
-    static const char* nm_lanes[8] = {"wave cycles", "wave heap updates", "run-ahead rounds", "prologue cycles", "candidate loop cycles", "rule cycles", "staging cycles", "epilogue cycles"};
-    const char* const* nm = lanes ? nm_lanes : nm_replay;
+    const char* const* nm = nm_replay;
     for (int c = 0; c < 8; c++) {
         std::vector<unsigned long long> v(mb);
         for (size_t i = 0; i < mb; i++) v[i] = dbg[i * 8 + c];
@@ -867,19 +874,59 @@ static void sync_and_flush(amd_ivf* h, hipStream_t s) {
     flush_small(h);
 }
 
-void check_device_error(amd_ivf* h) {
-    uint32_t err = 0;
-    d2h_small(h, &err, h->w_error.p, 4, h->stream);
-    sync_and_flush(h, h->stream);
+// a query admitted more candidates than its admission log holds: the search is repeated with the heap kernels
+struct SelectLogOverflow : std::runtime_error {
+    SelectLogOverflow() : std::runtime_error("selection log overflow") {}
+};
+
+static void throw_device_error(uint32_t err) {
     if (err == ERR_ARCOS_DOMAIN) throw EngineError("arcos's domain definition is [-1, 1]");
     if (err == ERR_COSINE_PRECOND) throw EngineError("cosine theorem's prerequisites");
     if (err == ERR_INVALID_KEY) throw EngineError("Invalid key");
     if (err == ERR_ITEM_OVERFLOW) throw std::runtime_error("tile list overflow");
+    if (err == ERR_LOG_OVERFLOW) throw SelectLogOverflow();
     if (err) throw EngineError("device-side error " + std::to_string(err));
+}
+
+// copies queued with d2h_small name caller memory (often stack variables): if the sequence is left by an exception before
+// its sync_and_flush, they must not stay pending for the next call's flush
+struct SmallCopies {
+    amd_ivf* h;
+    explicit SmallCopies(amd_ivf* hh) : h(hh) {}
+    ~SmallCopies() {
+        h->small.clear();
+        h->small_used = 0;
+    }
+};
+
+void check_device_error(amd_ivf* h) {
+    uint32_t err = 0;
+    SmallCopies guard(h);
+    d2h_small(h, &err, h->w_error.p, 4, h->stream);
+    sync_and_flush(h, h->stream);
+    throw_device_error(err);
+}
+
+// body(): a whole search on h (state initialised inside, outputs written only on success).  ERR_LOG_OVERFLOW from the
+// sorted-array selection -> once more with the reference's heap as the selection.
+template <class F> static void with_select_fallback(amd_ivf* h, F&& body) {
+    try {
+        body();
+    } catch (const SelectLogOverflow&) {
+        h->force_heap_select = true;
+        try {
+            body();
+        } catch (...) {
+            h->force_heap_select = false;
+            throw;
+        }
+        h->force_heap_select = false;
+    }
 }
 
 void fold_stats(amd_ivf* h, size_t nq) {
     unsigned long long st[3];
+    SmallCopies guard(h);
     d2h_small(h, st, h->w_stats.p, 24, h->stream);
     sync_and_flush(h, h->stream);
     h->stats_host[0] += nq;
@@ -893,17 +940,14 @@ void fold_stats(amd_ivf* h, size_t nq) {
 void finish_results(amd_ivf* h, size_t n, size_t k, float* D, int64_t* I, uint32_t* stage_out = nullptr) {
     uint32_t err = 0;
     unsigned long long st[3];
+    SmallCopies guard(h);
     d2h_small(h, &err, h->w_error.p, 4, h->stream);
     d2h_small(h, st, h->w_stats.p, 24, h->stream);
     if (stage_out) d2h_small(h, stage_out, h->w_stage.p, n * 4, h->stream);
     d2h_small(h, D, h->w_D.p, n * k * sizeof(float), h->stream);
     d2h_small(h, I, h->w_I.p, n * k * sizeof(int64_t), h->stream);
     sync_and_flush(h, h->stream);
-    if (err == ERR_ARCOS_DOMAIN) throw EngineError("arcos's domain definition is [-1, 1]");
-    if (err == ERR_COSINE_PRECOND) throw EngineError("cosine theorem's prerequisites");
-    if (err == ERR_INVALID_KEY) throw EngineError("Invalid key");
-    if (err == ERR_ITEM_OVERFLOW) throw std::runtime_error("tile list overflow");
-    if (err) throw EngineError("device-side error " + std::to_string(err));
+    throw_device_error(err);
     h->stats_host[0] += n;
     h->stats_host[1] += st[0];
     h->stats_host[2] += st[1];
@@ -1123,8 +1167,11 @@ void search_fixed_device(amd_ivf* h, const float* d_x, size_t n, size_t k, size_
     base.fixed_two = two;
     const size_t first = two ? std::max<size_t>(1, nprobe / 8) : nprobe;
     base.caller_checks_error = true;
-    run_rounds_device(h, base, n, first, nprobe, nullptr);
-    finish_results(h, n, k, D, I);
+    with_select_fallback(h, [&] {
+        if (h->force_heap_select) init_state(h, n, k, false);
+        run_rounds_device(h, base, n, first, nprobe, nullptr);
+        finish_results(h, n, k, D, I);
+    });
 }
 
 void search_fixed_core(amd_ivf* h, const float* d_x, size_t n, size_t k, size_t nprobe, const int64_t* keys, float* D,
@@ -1274,15 +1321,12 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     h->p_counters.ensure(96);
     h->w_dist.ensure(budget * sizeof(float));
     HIP_CHECK(hipMemsetAsync(h->w_pl_counters.p, 0, 96, s));
-    // two-kernel selection: per query a candidate list of capq entries (a round's first probe always fits: capq >= any list)
-    const size_t capq = std::max<size_t>(4096, ((maxlist + 63) & ~(size_t)63) + 64);
-    const bool lanes_ok = capq * n <= ((size_t)1 << 29) && !base.range;
-    if (lanes_ok) {
-        h->w_cand.ensure(n * capq * 8);
-        h->w_ccnt.ensure(seg_cap * 16);
-        h->w_cprobes.ensure(n * 4);
-        h->w_href_tmp.ensure(n * (size_t)base.k * 8);
-    }
+    // sorted-array selection: global positions must fit 32 bits; a query's admission log holds 32 k entries (k (1 + ln(N / k))
+    // are expected: ~5 k for a million candidates), beyond which the call is repeated with the heap kernels
+    const size_t log_cap = std::min<size_t>(4096, (std::max<size_t>(256, 32 * (size_t)base.k) + 63) & ~(size_t)63);
+    const bool sorted_ok = !base.range && !base.train.enabled && !base.raw_heap_out && base.k <= 128 && I->h_list_off[nlist] < 0xffffffffull &&
+                           !h->force_heap_select;
+    if (sorted_ok) h->w_log.ensure(n * log_cap * 8);
     // groups of 8 pairs never cross a list: at most pairs / 8 + one partial group per list
     const size_t group_cap = seg_cap / SCAN_RQ + nlist;
     if (chained && !base.bytes) h->w_qtile.ensure(group_cap * (size_t)h->dpad * SCAN_RQ * sizeof(float));
@@ -1456,7 +1500,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         h->timer.end(t, s);
     };
 
-    bool lanes_used = false;
+    bool sorted_used = false;
     // ---- ordered selection of a scanned round.  nact: active queries (sync) or the bound n with the count on the device.
     auto enqueue_replay = [&](bool thr_mode, uint32_t nact, bool on_device, size_t round) {
         ReplayArgs ra{};
@@ -1501,13 +1545,14 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         ra.tuner = base.tuner;
         ra.train = base.train;
         ra.limit = base.d_budget_ms ? h->w_limit.as<uint32_t>() : nullptr;
-        if (lanes_ok) {
-            ra.cand = h->w_cand.as<uint2>();
-            ra.cmeta = h->w_ccnt.as<uint4>();
-            ra.cprobes = h->w_cprobes.as<uint32_t>();
-            ra.capq = (uint32_t)capq;
-            ra.href_tmp = h->w_href_tmp.as<int64_t>();
+        if (sorted_ok) {
+            ra.log = h->w_log.as<uint2>();
+            ra.log_cap = (uint32_t)log_cap;
+            ra.log_cnt = h->w_log_cnt.as<uint32_t>();
+            ra.amb = h->w_amb.as<uint32_t>();
+            ra.tie_flag = h->w_tie_flag.as<uint32_t>();
         }
+        sorted_used = sorted_used || replay_sorted_applies(ra);
         static const bool dbg_replay_dev = getenv("AUNCEL_AMD_DEBUG_REPLAY") != nullptr;
         if (dbg_replay_dev) {
             h->w_misc.ensure((size_t)nact * 64);
@@ -1516,12 +1561,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         }
         {
             size_t t = h->timer.begin(CAT_SELECT, s);
-            if (select_lanes_supported(ra)) {
-                launch_select_lanes(ra, s);
-                lanes_used = true;
-            } else {
-                launch_replay(ra, s);
-            }
+            launch_replay(ra, s);
             h->timer.end(t, s);
         }
         if (dbg_replay_dev) {
@@ -1557,15 +1597,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
                 enqueue_replay(thr_mode, (uint32_t)n, true, round);
                 round_len = next_round_len(round_len);
             }
-            if (fixed_complete && !lanes_used) break;
-            if (fixed_complete) {
-                // ... unless the selection had to cut a query's round short (compact list full): those queries need more rounds
-                unsigned long long cut = 0;
-                HIP_CHECK(hipMemcpyAsync(&cut, h->w_stats.as<unsigned long long>() + 3, 8, hipMemcpyDeviceToHost, s));
-                HIP_CHECK(stream_sync(s));
-                if (cut == 0) break;
-                fixed_complete = false;
-            }
+            if (fixed_complete) break;
             plan_and_look(round_len);
             if (dbg_timing())
                 fprintf(stderr, "[rounds/chained] after round %zu: active %u pairs %u items %u may-continue %u MiB %u\n", round, hc[CNT_ACTIVE],
@@ -1652,6 +1684,23 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             if (!no_skip && !base.train.enabled && hc[10] == 0) break;
             round_len = next_round_len(round_len);
         }
+    }
+    if (sorted_used) {  // the flagged queries' results come from the reference's heap replayed over their admission logs
+        TieFixArgs ta{};
+        ta.metric = h->metric;
+        ta.k = base.k;
+        ta.nq = (uint32_t)n;
+        ta.nlist = (uint32_t)nlist;
+        ta.log = h->w_log.as<uint2>();
+        ta.log_cap = (uint32_t)log_cap;
+        ta.log_cnt = h->w_log_cnt.as<uint32_t>();
+        ta.tie_flag = h->w_tie_flag.as<uint32_t>();
+        ta.list_off = I->d_list_off.as<uint64_t>();
+        ta.ids = I->d_ids.as<int64_t>();
+        ta.store_pairs = base.store_pairs;
+        size_t t = h->timer.begin(CAT_SELECT, s);
+        launch_tie_fix(ta, s);
+        h->timer.end(t, s);
     }
     if (!base.caller_checks_error) check_device_error(h);
     if (chained) {  // the bookkeeping counters of the last round (bytes, slots) have not been read yet; nor has the history
@@ -2147,9 +2196,12 @@ static void timed_core(amd_ivf* h, const float* d_x, size_t start, size_t n, siz
     base.t_start_us = t_start;
     static const size_t first_env = getenv("AUNCEL_AMD_TIMED_FIRST") ? (size_t)atoi(getenv("AUNCEL_AMD_TIMED_FIRST")) : 4;
     base.caller_checks_error = true;
-    run_rounds_device(h, base, n, std::max<size_t>(1, first_env), nprobe, nullptr);
     std::vector<uint32_t> stage(nprobe_used ? n : 0);
-    finish_results(h, n, k, D, I, nprobe_used ? stage.data() : nullptr);
+    with_select_fallback(h, [&] {
+        if (h->force_heap_select) init_state(h, n, k, false);
+        run_rounds_device(h, base, n, std::max<size_t>(1, first_env), nprobe, nullptr);
+        finish_results(h, n, k, D, I, nprobe_used ? stage.data() : nullptr);
+    });
     for (size_t i = 0; i < stage.size(); i++) nprobe_used[i] = stage[i];
 }
 
@@ -2419,7 +2471,7 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
 }
 
 static size_t lane_count(size_t n) {
-    static const int env = getenv("AUNCEL_AMD_LANES") ? atoi(getenv("AUNCEL_AMD_LANES")) : 0;
+    static const int env = getenv("AUNCEL_AMD_SLICES") ? atoi(getenv("AUNCEL_AMD_SLICES")) : 0;
     if (env > 0) return (size_t)env;
     (void)n;
     return 1;  // measured on MI355X: concurrent slices halve the queries per list and lose more in the
@@ -2481,6 +2533,7 @@ static void adaptive_core_once(amd_ivf_t* h, const float* d_x, size_t start, siz
     lanes[0] = h;
     for (size_t i = 1; i < nl; i++) lanes[i] = h->kids[i - 1].get();
     for (amd_ivf* L : lanes) {
+        L->force_heap_select = h->force_heap_select;
         L->scan_bytes = L->scan_min_bytes = 0;
         L->scan_slots = L->scan_useful = 0;
     }
@@ -2546,7 +2599,7 @@ static void adaptive_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n
                           uint64_t* my_nprobe, float* t_recalls, float* D, int64_t* I, const IntRange& qr) {
     const bool speculate = n > 0 && n < 20 && !getenv("AUNCEL_AMD_COARSE_TIES") && h->nlist > 128 && multipler >= 1.f && !(profile & 2);
     if (!speculate) {
-        adaptive_core_once(h, d_x, start, n, query_topk, multipler, std_m, require_acc, gt_D, profile, coarse_mode, my_nprobe, t_recalls, D, I, qr);
+        with_select_fallback(h, [&] { adaptive_core_once(h, d_x, start, n, query_topk, multipler, std_m, require_acc, gt_D, profile, coarse_mode, my_nprobe, t_recalls, D, I, qr); });
         return;
     }
     size_t stats0[4];
@@ -2563,7 +2616,7 @@ static void adaptive_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n
     h->want_first_tie = true;
     h->first_tie_nreal = nreal;
     try {
-        adaptive_core_once(h, d_x, start, n, query_topk, multipler, std_m, require_acc, gt_D, profile, coarse_mode, my_nprobe, t_recalls, D, I, qr);
+        with_select_fallback(h, [&] { adaptive_core_once(h, d_x, start, n, query_topk, multipler, std_m, require_acc, gt_D, profile, coarse_mode, my_nprobe, t_recalls, D, I, qr); });
     } catch (...) {
         h->ties_override = -1;
         h->want_first_tie = false;
@@ -2583,7 +2636,7 @@ static void adaptive_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n
     std::copy(tr0.begin(), tr0.end(), t_recalls + start);
     h->ties_override = 1;
     try {
-        adaptive_core_once(h, d_x, start, n, query_topk, multipler, std_m, require_acc, gt_D, profile, coarse_mode, my_nprobe, t_recalls, D, I, qr);
+        with_select_fallback(h, [&] { adaptive_core_once(h, d_x, start, n, query_topk, multipler, std_m, require_acc, gt_D, profile, coarse_mode, my_nprobe, t_recalls, D, I, qr); });
     } catch (...) {
         h->ties_override = -1;
         throw;
@@ -2919,6 +2972,21 @@ int amd_ivf_last_scan_min_bytes(amd_ivf_t* h, double* bytes) {
     return 0;
 }
 
+int amd_ivf_last_tie_fixed(amd_ivf_t* h, uint64_t* queries) {
+    API_BEGIN
+    use_device(h);
+    *queries = 0;
+    auto add = [&](amd_ivf* c) {
+        if (!c->w_tie_flag.p || !c->last_state_n) return;
+        std::vector<uint32_t> f(c->last_state_n);
+        HIP_CHECK(stream_sync(c->stream));
+        HIP_CHECK(hipMemcpy(f.data(), c->w_tie_flag.p, f.size() * 4, hipMemcpyDeviceToHost));
+        for (uint32_t v : f) *queries += v == 2;
+    };
+    add(h);
+    for (auto& kid : h->kids) add(kid.get());
+    API_END
+}
 int amd_ivf_coarse_tie_rows(amd_ivf_t* h, uint64_t* rows) {
     API_BEGIN
     use_device(h);

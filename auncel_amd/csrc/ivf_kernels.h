@@ -206,27 +206,41 @@ struct ReplayArgs {
     // outputs
     float* D;                  // [nq][k]
     int64_t* I;
-    unsigned long long* stats; // {nlist, ndis, nheap, queries whose round was cut short by the compact list's capacity}
+    unsigned long long* stats; // {nlist, ndis, nheap, -}
     uint32_t* error;           // != 0: the reference would have thrown (code)
     int raw_heap_out;          // scanner API: leave the heap un-reordered in D/I
     unsigned long long* dbg;   // optional [nq][8]: wave cycles, heap updates, candidates, stages evaluated, cycles in the
                                // candidate stream, cycles in the stop rule, masked chunks fetched, probes consumed
     TunerDev tuner;
     TrainDev train;
-    // Two-kernel selection (launch_select_lanes): compact_kernel turns a round's distance rows into one short, ordered
-    // candidate list per query; replay_lanes_kernel replays the reference's heap over those lists, one query per lane.
-    uint2* cand;               // [slot][capq] candidates in stream order: (value bits, position in the list)
-    uint32_t lanes;            // queries per wave of replay_lanes_kernel (set by launch_select_lanes)
-    uint4* cmeta;              // per (query, probe), indexed like seg_list: (candidates, list length, list number, -)
-    uint32_t* cprobes;         // [slot] probes of this round whose candidates are in the list (the rest are re-planned)
-    uint32_t capq;             // entries per query (>= the longest list, so a round's first probe always fits)
-    int64_t* href_tmp;         // [slot][k] ids by heap slot while a round runs
+    // Sorted-array selection (replay_kernel MODE 2; null log: the heap kernels).  heap_val / heap_ref then hold the k best in
+    // best-first order (values, global positions) between rounds.
+    uint2* log;                // [slot][log_cap] admissions in order: (value bits, global position = list_off[list] + position)
+    uint32_t log_cap;
+    uint32_t* log_cnt;         // [slot]
+    uint32_t* amb;             // [slot] order key of a value whose id became ambiguous (0xffffffff: none)
+    uint32_t* tie_flag;        // [slot] set when the query's result has to come from tie_fix_kernel
 };
 
+bool replay_sorted_applies(const ReplayArgs& a);
 void launch_replay(const ReplayArgs& a, hipStream_t s);
-// the same selection as launch_replay (same state arrays in, same out) by compact_kernel + replay_lanes_kernel
-bool select_lanes_supported(const ReplayArgs& a);
-void launch_select_lanes(const ReplayArgs& a, hipStream_t s);
+
+// see tie_fix_kernel (ivf_select.hip)
+struct TieFixArgs {
+    int metric;
+    int k;
+    uint32_t nq, nlist;
+    const uint2* log;
+    uint32_t log_cap;
+    const uint32_t* log_cnt;
+    uint32_t* tie_flag;
+    const uint64_t* list_off;
+    const int64_t* ids;
+    int store_pairs, identity_ids;
+    float* D;
+    int64_t* I;
+};
+void launch_tie_fix(const TieFixArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------------------- range search
 // IndexIVF::range_search_preassigned: the scan runs in threshold mode with the radius as every query's threshold,
@@ -330,6 +344,7 @@ constexpr uint32_t ERR_ARCOS_DOMAIN = 1;
 constexpr uint32_t ERR_COSINE_PRECOND = 2;
 constexpr uint32_t ERR_INVALID_KEY = 3;
 constexpr uint32_t ERR_ITEM_OVERFLOW = 4;
+constexpr uint32_t ERR_LOG_OVERFLOW = 5;  // a query admitted more candidates than its admission log holds
 
 // ---------------------------------------------------------------------------- coarse helpers
 // full ascending/descending sort of each row of `dis` (nlist entries) keeping the first nprobe
@@ -376,6 +391,7 @@ struct InitStateArgs {
     uint32_t* stoped;
     unsigned long long* stats;  // 4 counters
     uint32_t* error;
+    uint32_t *log_cnt, *amb, *tie_flag;  // sorted-array selection (may be null)
 };
 void launch_init_state(const InitStateArgs& a, hipStream_t s);
 void launch_fill_f32(float* p, size_t n, float v, hipStream_t s);

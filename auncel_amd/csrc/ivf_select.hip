@@ -1,0 +1,1227 @@
+// gfx950 (MI355X, CDNA4) selection kernels of the IVF-Flat search engine.
+//
+// Selection contract: the reference keeps its k best in a binary heap that only admits strictly
+// better candidates (Heap.h:88-142, IndexIVFFlat.cpp:125-135); which of several equal distances
+// survives, and the order of equal distances in the output, depend on the heap's history.
+#include "ivf_dev.h"
+
+#include <algorithm>
+#include <stdexcept>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <type_traits>
+#include <utility>
+
+namespace amdivf {
+
+// =============================================================================================
+// K-replay: ordered selection + Auncel stop rule + training samples
+// =============================================================================================
+// ---------------------------------------------------------------------------------------------
+// The same heap, resident in registers (k <= 127): node i (1-based, Heap.h numbering) lives in lane
+// i & 63 of register i >> 6, so levels 0-5 (nodes 1..63) are in register 0 and level 6 in register 1.
+// A wave replays one query, so every index below is wave-uniform: nodes are read with v_readlane and written
+// with v_writelane, and the sift loops run on the scalar unit.  For that the registers hold order keys, not
+// floats: key(x) is an unsigned integer with key(a) < key(b) <=> a < b (gfx950 has no scalar float compare),
+// and the float comes back bit for bit from the key.  Each node carries the slot (0..k-1) of its 64-bit id in
+// an LDS table, so ids never move.  (Keys order -0.0 below +0.0 where floats call them equal; distances from
+// the scan kernels are never -0.0.  NaN never enters: admission is tested on the floats.)
+struct RegHeap {
+    uint32_t v0, v1;  // keys
+    uint32_t s0, s1;  // id slots
+};
+
+// reg[lane l] = val (val and l wave-uniform).  The lane select goes through M0: v_writelane_b32 may name one SGPR.
+__device__ __forceinline__ void wl_u(uint32_t& reg, uint32_t val, int l) {
+    asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(reg) : "s"(val), "s"(l) : "m0");
+}
+
+// two registers, same lane: one M0 set-up
+__device__ __forceinline__ void wl2_u(uint32_t& r0, uint32_t v0, uint32_t& r1, uint32_t v1, int l) {
+    asm("s_mov_b32 m0, %4\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+        : "+v"(r0), "+v"(r1)
+        : "s"(v0), "s"(v1), "s"(l)
+        : "m0");
+}
+
+__device__ __forceinline__ uint32_t rh_key(const RegHeap& h, int node) {
+    const uint32_t a = rl_u(h.v0, node & 63), b = rl_u(h.v1, node & 63);
+    return node < 64 ? a : b;
+}
+__device__ __forceinline__ uint32_t rh_slot(const RegHeap& h, int node) {
+    const uint32_t a = rl_u(h.s0, node & 63), b = rl_u(h.s1, node & 63);
+    return node < 64 ? a : b;
+}
+// node <- (key, slot); the register is picked by one branch (in C++ the compiler copies both registers around it)
+__device__ __forceinline__ void rh_set(RegHeap& h, int node, uint32_t key, uint32_t slot) {
+    asm volatile(
+        "s_cmp_gt_u32 %[n], 63\n\ts_cbranch_scc1 1f\n\t"
+        "s_mov_b32 m0, %[n]\n\ts_nop 0\n\tv_writelane_b32 %[v0], %[k], m0\n\tv_writelane_b32 %[s0], %[s], m0\n\ts_branch 2f\n"
+        "1:\n\ts_sub_u32 m0, %[n], 64\n\ts_nop 0\n\tv_writelane_b32 %[v1], %[k], m0\n\tv_writelane_b32 %[s1], %[s], m0\n"
+        "2:\n\t"
+        : [v0] "+v"(h.v0), [s0] "+v"(h.s0), [v1] "+v"(h.v1), [s1] "+v"(h.s1)
+        : [n] "s"(node), [k] "s"(key), [s] "s"(slot)
+        : "m0", "scc");
+}
+
+// Heap.h:88-118 (the node being removed, k, still takes part in the child comparisons, as there).
+// KC != 0: k is the compile-time constant KC and the bounds tests of complete levels fold away.
+template <bool IsMax, int KC> __device__ __forceinline__ void rh_pop(RegHeap& h, int krt) {
+    const int k = KC ? KC : krt;
+    const uint32_t v = rh_key(h, k);
+    const uint32_t sv = rh_slot(h, k);
+    int i = 1;
+#pragma unroll
+    for (int lvl = 0; lvl < 6; lvl++) {  // parent on level lvl (node < 64: register 0), children on level lvl + 1
+        const bool absent = KC && (2 << lvl) > KC;      // the whole child level lies beyond k
+        const bool full = KC && (4 << lvl) - 1 <= KC;   // every node of the child level exists
+        if (absent) break;
+        const int i1 = i << 1, i2 = i1 + 1;
+        if (!full && i1 > k) break;
+        const bool only_left = !full && i2 == k + 1;
+        const int j2 = only_left ? i1 : i2;
+        const uint32_t c1 = lvl < 5 ? rl_u(h.v0, i1) : rl_u(h.v1, i1 - 64);
+        const uint32_t c2 = lvl < 5 ? rl_u(h.v0, j2) : rl_u(h.v1, j2 - 64);
+        const bool left = only_left || kcmp<IsMax>(c1, c2);
+        const uint32_t c = left ? c1 : c2;
+        if (kcmp<IsMax>(v, c)) break;
+        const int ci = left ? i1 : i2;
+        const uint32_t cs = lvl < 5 ? rl_u(h.s0, ci) : rl_u(h.s1, ci - 64);
+        wl2_u(h.v0, c, h.s0, cs, i);
+        i = ci;
+    }
+    rh_set(h, i, v, sv);
+}
+
+// The same walk for k = 100, written out in assembly: the compiler's structured control flow spends five scalar
+// instructions per level on exit flags; here a level is 9 scalar + 5 vector instructions and one branch.  Levels 0-4
+// (children in register 0, all present), then level 5 (children 64..100 in register 1; node 50 has the left child only,
+// which the equal-keys case of the selection handles: both reads name the same lane and the "right" pick is that lane).
+#define RH_ASM_LEVEL(MAXOP, CMPOP)                                                                                      \
+    "s_lshl_b32 %[a], %[i], 1\n\ts_or_b32 %[b], %[a], 1\n\tv_readlane_b32 %[k1], %[v0], %[a]\n\tv_readlane_b32 %[k2], %[v0], %[b]\n\t" \
+    MAXOP " %[c], %[k1], %[k2]\n\t" CMPOP " %[v], %[c]\n\ts_cbranch_scc1 9f\n\t" CMPOP " %[k1], %[k2]\n\ts_cselect_b32 %[a], %[a], %[b]\n\t" \
+    "v_readlane_b32 %[cs], %[s0], %[a]\n\ts_mov_b32 m0, %[i]\n\ts_nop 0\n\tv_writelane_b32 %[v0], %[c], m0\n\t"                       \
+    "v_writelane_b32 %[s0], %[cs], m0\n\ts_mov_b32 %[i], %[a]\n\t"
+#define RH_ASM_LAST(MAXOP, CMPOP)                                                                                       \
+    "s_cmp_gt_u32 %[i], 50\n\ts_cbranch_scc1 9f\n\ts_lshl_b32 %[a], %[i], 1\n\ts_sub_u32 %[a], %[a], 64\n\ts_or_b32 %[b], %[a], 1\n\t"     \
+    "s_cmp_eq_u32 %[i], 50\n\ts_cselect_b32 %[b], %[a], %[b]\n\tv_readlane_b32 %[k1], %[v1], %[a]\n\tv_readlane_b32 %[k2], %[v1], %[b]\n\t" \
+    MAXOP " %[c], %[k1], %[k2]\n\t" CMPOP " %[v], %[c]\n\ts_cbranch_scc1 9f\n\t" CMPOP " %[k1], %[k2]\n\ts_cselect_b32 %[a], %[a], %[b]\n\t" \
+    "v_readlane_b32 %[cs], %[s1], %[a]\n\ts_mov_b32 m0, %[i]\n\ts_nop 0\n\tv_writelane_b32 %[v0], %[c], m0\n\t"                       \
+    "v_writelane_b32 %[s0], %[cs], m0\n\ts_add_u32 %[i], %[a], 64\n\t"                                                 \
+    "9:\n\t"
+template <bool IsMax> __device__ __forceinline__ void rh_pop_k100(RegHeap& h) {
+    const uint32_t v = rl_u(h.v1, 100 - 64);
+    const uint32_t sv = rl_u(h.s1, 100 - 64);
+    int i = 1;
+    uint32_t a, b, k1, k2, c, cs;
+    if (IsMax) {
+        asm volatile(RH_ASM_LEVEL("s_max_u32", "s_cmp_gt_u32") RH_ASM_LEVEL("s_max_u32", "s_cmp_gt_u32") RH_ASM_LEVEL("s_max_u32", "s_cmp_gt_u32")
+                         RH_ASM_LEVEL("s_max_u32", "s_cmp_gt_u32") RH_ASM_LEVEL("s_max_u32", "s_cmp_gt_u32") RH_ASM_LAST("s_max_u32", "s_cmp_gt_u32")
+                     : [i] "+s"(i), [v0] "+v"(h.v0), [s0] "+v"(h.s0), [a] "=&s"(a), [b] "=&s"(b), [k1] "=&s"(k1), [k2] "=&s"(k2),
+                       [c] "=&s"(c), [cs] "=&s"(cs)
+                     : [v] "s"(v), [v1] "v"(h.v1), [s1] "v"(h.s1)
+                     : "m0", "scc");
+    } else {
+        asm volatile(RH_ASM_LEVEL("s_min_u32", "s_cmp_lt_u32") RH_ASM_LEVEL("s_min_u32", "s_cmp_lt_u32") RH_ASM_LEVEL("s_min_u32", "s_cmp_lt_u32")
+                         RH_ASM_LEVEL("s_min_u32", "s_cmp_lt_u32") RH_ASM_LEVEL("s_min_u32", "s_cmp_lt_u32") RH_ASM_LAST("s_min_u32", "s_cmp_lt_u32")
+                     : [i] "+s"(i), [v0] "+v"(h.v0), [s0] "+v"(h.s0), [a] "=&s"(a), [b] "=&s"(b), [k1] "=&s"(k1), [k2] "=&s"(k2),
+                       [c] "=&s"(c), [cs] "=&s"(cs)
+                     : [v] "s"(v), [v1] "v"(h.v1), [s1] "v"(h.s1)
+                     : "m0", "scc");
+    }
+    rh_set(h, i, v, sv);
+}
+#undef RH_ASM_LEVEL
+#undef RH_ASM_LAST
+
+// Heap.h:125-142
+template <bool IsMax, int KC> __device__ __forceinline__ void rh_push(RegHeap& h, int krt, uint32_t v, uint32_t sv) {
+    int i = KC ? KC : krt;
+    while (i > 1) {
+        const int f = i >> 1;  // < 64
+        const uint32_t fv = rl_u(h.v0, f);
+        if (!kcmp<IsMax>(v, fv)) break;
+        const uint32_t fs = rl_u(h.s0, f);
+        rh_set(h, i, fv, fs);
+        i = f;
+    }
+    rh_set(h, i, v, sv);
+}
+
+// Heap.h:125-142 for k = 100: the ancestors of node 100 are fixed (50, 25, 12, 6, 3, 1), a new value rarely climbs
+// past the first
+template <bool IsMax> __device__ __forceinline__ void rh_push_k100(RegHeap& h, uint32_t v, uint32_t sv) {
+    int i = 100;
+#define RH_PUSH_STEP(F)                         \
+    {                                           \
+        const uint32_t fv = rl_u(h.v0, F);      \
+        if (!kcmp<IsMax>(v, fv)) goto done;     \
+        const uint32_t fs = rl_u(h.s0, F);      \
+        rh_set(h, i, fv, fs);                   \
+        i = F;                                  \
+    }
+    RH_PUSH_STEP(50)
+    RH_PUSH_STEP(25)
+    RH_PUSH_STEP(12)
+    RH_PUSH_STEP(6)
+    RH_PUSH_STEP(3)
+    RH_PUSH_STEP(1)
+#undef RH_PUSH_STEP
+done:
+    rh_set(h, i, v, sv);
+}
+
+// LDS heap arrays (node order) -> registers; slot j holds the id of node j + 1
+__device__ __forceinline__ void rh_load(RegHeap& h, const float* hval, int k, int lane) {
+    h.v0 = (lane >= 1 && lane <= k) ? fkey(hval[lane - 1]) : 0u;
+    h.s0 = (uint32_t)(lane - 1);
+    h.v1 = (lane + 64 <= k) ? fkey(hval[lane + 63]) : 0u;
+    h.s1 = (uint32_t)(lane + 63);
+}
+
+// registers -> LDS heap arrays in node order (ids permuted through registers)
+__device__ __forceinline__ void rh_store(const RegHeap& h, float* hval, int64_t* href, int k, int lane, bool with_refs) {
+    const bool n0 = lane >= 1 && lane <= k, n1 = lane + 64 <= k;
+    int64_t r0 = 0, r1 = 0;
+    if (with_refs) {
+        if (n0) r0 = href[h.s0];
+        if (n1) r1 = href[h.s1];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (n0) hval[lane - 1] = fkey_inv(h.v0);
+    if (n1) hval[lane + 63] = fkey_inv(h.v1);
+    if (with_refs) {
+        if (n0) href[lane - 1] = r0;
+        if (n1) href[lane + 63] = r1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// error_pro::arcos (IVF_pro.cpp:179-184)
+__device__ inline float arcos_lut(const float* lut, float x, uint32_t* err) {
+    if (!(x <= 1.0 && x >= -1.0)) {
+        *err = ERR_ARCOS_DOMAIN;
+        return 0.f;
+    }
+    int index = (int)(x * 500.f / 2.f + 250.f);
+    return lut[index];
+}
+
+// cosine_theorem (IVF_pro.cpp:41-51): pow(float,int) promotes to double
+__device__ inline float cosine_theorem_dev(float a, float b, float c, uint32_t* err) {
+    if (!(a <= b)) *err = ERR_COSINE_PRECOND;
+    float temp = (float)((double)a * (double)a + (double)c * (double)c - (double)b * (double)b);
+    temp = temp / (2 * c);
+    return c / 2 - temp;
+}
+
+// Trace::search (IVF_pro.cpp:84-107); z[i] = y[i] + std_m * sd[i] is formed once per cached trace with the
+// reference's own expression, so every return value is the same fp32 number
+__device__ inline float trace_search(const float* x, const float* z, uint32_t n, float k) {
+    if (k <= x[0]) return z[0];
+    if (k >= x[n - 1]) {
+        const float ampli = k / x[n - 1];
+        return z[n - 1] * ampli;
+    }
+    unsigned long long high = n - 1, low = 0, middle = 0;
+    while (low <= high) {
+        middle = (low + high) / 2;
+        if (x[middle] < k) low = middle + 1;
+        else high = middle - 1;
+    }
+    if (x[low] > k) low--;
+    return z[low];
+}
+
+// kscaling (IVF_pro.cpp:72-82)
+__device__ inline float kscaling_dev(float kdis, uint32_t in, const float* gt, uint32_t max_topk) {
+    uint32_t index = 0;
+    for (; index < max_topk; index++) {
+        const float df = fabsf(gt[index] - kdis);
+        if ((double)(df / kdis) < 1e-5 || (double)df < 1e-5) break;
+    }
+    if (index >= max_topk) return -1.f;
+    return (float)(index + 1) / (float)(in + 1);
+}
+
+// error_pro::set_online (IVF_pro.cpp:196-238): lanes split the entries
+__device__ inline void set_online_dev(int metric, uint32_t nlist, const float* cd, const int64_t* ci,
+                                      const float* interdis, const float* lut, float* dtb, int lane, uint32_t* err) {
+    const uint32_t max_num = nlist / 8 + 20;
+    const unsigned long long cur = (unsigned long long)ci[0];
+    const float a0 = metric == METRIC_IP ? arcos_lut(lut, cd[0], err) : cd[0];
+    for (uint32_t k = lane; k < max_num - 1; k += 64) {
+        const unsigned long long dst = (unsigned long long)ci[k + 1];
+        const unsigned long long i = cur < dst ? cur : dst, j = cur < dst ? dst : cur;
+        const float c = interdis[(2ull * nlist - 1 - i) * i / 2 + j - 1 - i];
+        const float b = metric == METRIC_IP ? arcos_lut(lut, cd[k + 1], err) : cd[k + 1];
+        dtb[k] = cosine_theorem_dev(a0, b, c, err);
+    }
+    if (lane == 0) dtb[max_num - 1] = 0.f;
+    if (metric == METRIC_IP) {
+        // the reference converts all max_num coarse values up front (IVF_pro.cpp:208-211)
+        for (uint32_t k = lane; k < max_num; k += 64) (void)arcos_lut(lut, cd[k], err);
+    }
+}
+
+// one wave per query: disToBoundary rows for a batch of queries (run once, before the first round)
+__global__ __launch_bounds__(256) void set_online_kernel(int metric, uint32_t nlist, uint32_t nq, const float* coarse_dis,
+                                                         const int64_t* coarse_keys, uint32_t coarse_stride, const float* interdis,
+                                                         const float* arcos, float* dtb, uint32_t* error) {
+    __shared__ float lut[500];
+    for (int i = threadIdx.x; i < 500; i += 256) lut[i] = arcos[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint32_t qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= nq) return;
+    uint32_t err = 0;
+    set_online_dev(metric, nlist, coarse_dis + (size_t)qi * coarse_stride, coarse_keys + (size_t)qi * coarse_stride, interdis, lut,
+                   dtb + (size_t)qi * (nlist / 8 + 20), lane, &err);
+    err = wave_max_u32(err);
+    if (err && lane == 0) atomicMax(error, err);
+}
+
+void launch_set_online(int metric, uint32_t nlist, uint32_t nq, const float* coarse_dis, const int64_t* coarse_keys,
+                       uint32_t coarse_stride, const float* interdis, const float* arcos, float* dtb, uint32_t* error, hipStream_t s) {
+    if (nq) LAUNCH(set_online_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, metric, nlist, nq, coarse_dis, coarse_keys,
+                               coarse_stride, interdis, arcos, dtb, error);
+}
+
+// best-first sort of the heap values into srt by ranking (values only matter)
+template <bool IsMax> __device__ inline void rank_sort_best_first(const float* src, float* dst, int k, int lane) {
+    for (int i = lane; i < k; i += 64) {
+        const float x = src[i];
+        int rank = 0;
+        for (int j = 0; j < k; j++) {
+            const float y = src[j];
+            rank += (IsMax ? (y < x) : (y > x)) || (y == x && j < i);
+        }
+        dst[rank] = x;
+    }
+}
+
+// srt holds the k heap values best first.  A heap update replaces the worst value (the heap top,
+// == srt[k-1]) by `val`: shift the worse ones down by one slot and drop val into the gap.
+template <bool IsMax> __device__ inline int sorted_replace_worst(float* srt, int k, float val, int lane) {
+    int pos = 0;
+    for (int c = (k - 1) / 64; c >= 0; c--) {
+        const int idx = c * 64 + lane;
+        const bool in = idx < k - 1;
+        const float s = in ? srt[idx] : 0.f;
+        const bool worse = in && (IsMax ? s > val : s < val);
+        pos += __builtin_popcountll(__ballot(in && !worse));
+        wave_sync();
+        if (worse) srt[idx + 1] = s;
+        wave_sync();
+    }
+    srt[pos] = val;
+    wave_sync();
+    return pos;  // where val landed in the best-first order
+}
+
+// error_pro::sum_angle (IVF_pro.cpp:162-177), n = 15: the 15 terms on 15 lanes, then summed in the
+// reference's order (a skipped term adds +0, which leaves the non-negative running sum unchanged)
+__device__ inline float sum_angle_par(const float* lut, float kdis, const float* dwin, int lane, uint32_t* err) {
+    float t = 0.f;
+    if (lane < 15) {
+        const float b = dwin[lane];  // the 15 boundary distances of this stage (window of disToBoundary)
+        if (!(b >= kdis)) t = arcos_lut(lut, b / kdis, err);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 15; i++) sum += __shfl(t, i);
+    return sum;
+}
+
+struct TraceLds {
+    const float *x, *z;
+    uint32_t n;
+};
+
+// error_pro::cur_num (IVF_pro.cpp:258-291); Ds(m) = m-th best value (IP: its arcos)
+template <bool IsMax>
+__device__ inline uint32_t cur_num_lds(const TraceLds& tr, const float* lut, const float* srt, const float* dwin,
+                                       uint32_t query_topk, int lane, uint32_t* err) {
+    const unsigned long long query_k = query_topk;
+    unsigned long long high = query_k - 1, low = 0, middle = 0;
+    auto Ds = [&](unsigned long long m) { return IsMax ? srt[m] : arcos_lut(lut, srt[m], err); };
+    {
+        const float g = trace_search(tr.x, tr.z, tr.n, sum_angle_par(lut, Ds(high), dwin, lane, err));
+        if ((double)((float)query_k * g) <= (double)query_k * 1.005) return (uint32_t)query_k;
+    }
+    while (low <= high) {
+        middle = (low + high) / 2;
+        if (middle <= 0) return 0;
+        const float g = trace_search(tr.x, tr.z, tr.n, sum_angle_par(lut, Ds(middle), dwin, lane, err));
+        if ((float)(middle + 1) * g <= (float)query_k) low = middle + 1;
+        else high = middle - 1;
+    }
+    return (uint32_t)(low + 1);
+}
+
+// The same function with every probe value of the binary search evaluated at once: term (m, i) of
+// sum_angle(Ds(m)) on lane m * 15 + i (three passes for query_topk = 10), then lane m adds its 15 terms in the
+// reference's order and runs its own Trace::search; the search itself is replayed on the scalar unit over the
+// resulting predicate bits.  Each S(Ds(m)) is formed by the same fp32 operations in the same order as above, and
+// an acos-domain error only counts if the reference's search would have visited that m.
+constexpr uint32_t CURNUM_PAR_MAXK = 10;  // terms[] holds CURNUM_PAR_MAXK * 15 floats per wave
+template <bool IsMax>
+__device__ inline uint32_t cur_num_par(const TraceLds& tr, const float* lut, const float* srt, const float* dwin, float* terms,
+                                       uint32_t query_topk, int lane, uint32_t* err) {
+    const int nterm = (int)query_topk * 15;
+    unsigned long long errm = 0;  // bit m: evaluating S(Ds(m)) left the acos domain
+    for (int base = 0; base < nterm; base += 64) {
+        const int idx = base + lane;
+        uint32_t e = 0;
+        if (idx < nterm) {
+            const int m = idx / 15, i = idx - m * 15;
+            uint32_t e0 = 0;
+            const float kd = IsMax ? srt[m] : arcos_lut(lut, srt[m], &e0);  // IP: the caller has range-checked every srt[]
+            const float b = dwin[i];
+            float t = 0.f;
+            if (!(b >= kd)) t = arcos_lut(lut, b / kd, &e);
+            terms[idx] = t;
+        }
+        unsigned long long eb = __ballot(e != 0);
+        while (eb) {
+            const int l = __builtin_ctzll(eb);
+            eb &= eb - 1;
+            errm |= 1ull << ((base + l) / 15);
+        }
+    }
+    wave_sync();
+    float g = 0.f;
+    if ((uint32_t)lane < query_topk) {
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 15; i++) sum += terms[lane * 15 + i];
+        g = trace_search(tr.x, tr.z, tr.n, sum);
+    }
+    const unsigned long long query_k = query_topk;
+    const bool first_ok = (double)((float)query_k * g) <= (double)query_k * 1.005;
+    const bool step_ok = (float)(lane + 1) * g <= (float)query_k;
+    const unsigned long long mfirst = __ballot((uint32_t)lane == query_topk - 1 && first_ok);
+    const unsigned long long mstep = __ballot((uint32_t)lane < query_topk && step_ok);
+    wave_sync();
+    unsigned long long high = query_k - 1, low = 0, middle = 0;
+    if ((errm >> high) & 1) {
+        *err = ERR_ARCOS_DOMAIN;
+        return 0;
+    }
+    if (mfirst) return (uint32_t)query_k;
+    while (low <= high) {
+        middle = (low + high) / 2;
+        if (middle <= 0) return 0;
+        if ((errm >> middle) & 1) {
+            *err = ERR_ARCOS_DOMAIN;
+            return 0;
+        }
+        if ((mstep >> middle) & 1) low = middle + 1;
+        else high = middle - 1;
+    }
+    return (uint32_t)(low + 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The k best as a SORTED array in registers (k <= 128): entry i lives in lane i & 63 of register i >> 6, as an order key
+// (okey: smaller = better) next to the global position of its vector (list_off[list] + position: what ids[] is indexed
+// by).  The reference's heap and this array hold the same multiset of values at every moment -- both admit a candidate iff
+// it is strictly better than the worst of the k, both evict a worst one -- so the admissions (hence nheap_updates, the
+// thresholds, every input of the stop rule) are the reference's.  Which *id* goes with a value is history-free too unless
+// equal values meet: (a) a worst value is evicted while an equal one stays (`amb` remembers the value until nothing that
+// bad is left), (b) two equal values are both in the final k (their output order is the heap's).  Such a query is flagged
+// and tie_fix_kernel replays the reference's heap over the query's admission log; everybody else's result is the array.
+constexpr uint32_t SKEY_SENT = 0xff7fffffu;   // okey of the empty entry (FLT_MAX for L2, -FLT_MAX for IP)
+constexpr uint32_t SPOS_NONE = 0xffffffffu;
+
+struct SortedRegs {
+    uint32_t k0, k1;  // order keys, ascending
+    uint32_t g0, g1;  // global positions
+};
+
+// lane i <- lane i - 1 across the whole wave; lane 0 <- carry (wave-uniform)
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t x, uint32_t carry) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ uint32_t sr_key(const SortedRegs& r, int i) { return i < 64 ? rl_u(r.k0, i) : rl_u(r.k1, i - 64); }
+
+// insert (key, gpos) behind the entries that are <= key; everything worse moves down one place (the old entry k - 1 is
+// thereby evicted: it slides into the unused tail).  Returns the position taken.
+template <bool TWO> __device__ __forceinline__ int sr_insert(SortedRegs& r, uint32_t key, uint32_t gpos, int lane) {
+    const unsigned long long m0 = __ballot(r.k0 > key);
+    const uint32_t kv = key, gv = gpos;
+    if (TWO) {
+        const unsigned long long m1 = __ballot(r.k1 > key);
+        const uint32_t ck = rl_u(r.k0, 63), cg = rl_u(r.g0, 63);
+        const uint32_t t1 = wave_shr1(r.k1, ck), u1 = wave_shr1(r.g1, cg);
+        const bool mv1 = (m1 >> lane) & 1;
+        const unsigned long long ins1 = m1 & ~((m1 << 1) | (m0 >> 63));
+        const bool in1 = (ins1 >> lane) & 1;
+        r.k1 = in1 ? kv : mv1 ? t1 : r.k1;
+        r.g1 = in1 ? gv : mv1 ? u1 : r.g1;
+        if (m0 == 0) return 64 + (m1 ? __builtin_ctzll(m1) : 64);
+    } else if (m0 == 0) {
+        return 64;
+    }
+    const uint32_t t0 = wave_shr1(r.k0, 0u), u0 = wave_shr1(r.g0, 0u);
+    const bool mv0 = (m0 >> lane) & 1;
+    const unsigned long long ins0 = m0 & ~(m0 << 1);
+    const bool in0 = (ins0 >> lane) & 1;
+    r.k0 = in0 ? kv : mv0 ? t0 : r.k0;
+    r.g0 = in0 ? gv : mv0 ? u0 : r.g0;
+    return __builtin_ctzll(m0);
+}
+
+// (list << 32 | position) of a global position: the list whose range holds it (empty lists skipped by the search)
+__device__ inline int64_t pair_of_gpos(const uint64_t* list_off, uint32_t nlist, uint32_t gpos) {
+    uint32_t lo = 0, hi = nlist;  // invariant: list_off[lo] <= gpos < list_off[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (list_off[mid] <= gpos) lo = mid;
+        else hi = mid;
+    }
+    return ((int64_t)lo << 32) | (int64_t)(gpos - list_off[lo]);
+}
+
+__host__ __device__ inline size_t replay_wave_bytes(int k, uint32_t nlist, bool geo, bool tune, bool train, uint32_t trace_cap) {
+    (void)nlist;
+    size_t b = (size_t)k * 16;                       // href | hval | srt
+    if (geo) b += 16 * 4 + 16 * 4;                   // window of disToBoundary | values inserted during the current probe
+    if (tune) b += (size_t)trace_cap * 8;            // cached trace (x | z)
+    if (tune) b += CURNUM_PAR_MAXK * 15 * 4 + 8;     // sum_angle terms of cur_num_par
+    if (train) b += (size_t)k * 4;                   // ground-truth row
+    return (b + 15) & ~(size_t)15;
+}
+
+// MODE 0: the reference's heap in LDS; 1: the same heap in registers (k <= 127); 2: the k best as a sorted register
+//         array + admission log (k <= 128; see SortedRegs) -- the default wherever it applies
+// NLD: 64-candidate chunks per trip of the candidate stream (registers for two trips are live)
+// KC: compile-time k of the register heap / sorted array (0: run-time k)
+template <bool IsMax, int MODE, int NLD, int KC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ? 5 : 3))) void replay_kernel(ReplayArgs a) {
+    constexpr bool RH = MODE == 1, SORTED = MODE == 2;
+    constexpr bool TWO = KC == 0 || KC > 64;  // sorted array: entries 64.. exist
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool tune = a.tuner.enabled != 0, training = a.train.enabled != 0, geo = tune || training;
+    const int k = KC ? KC : a.k;
+    const uint32_t nlist = a.nlist;
+    const uint32_t max_num = nlist / 8 + 20;
+
+    // shared: the acos LUT; per wave: href | hval | srt | dtb | trace cache | gt row
+    float* lut = reinterpret_cast<float*>(smem);
+    if (geo) {
+        const float* g = tune ? a.tuner.arcos : a.train.arcos;
+        for (int i = threadIdx.x; i < 500; i += 256) lut[i] = g[i];
+        __syncthreads();
+    }
+    const uint32_t li = blockIdx.x * 4 + wave;   // position in this launch
+    if (li >= (a.nq_dev ? *a.nq_dev : a.nq)) return;
+    const uint32_t qi = a.qsel ? a.qsel[li] : li;  // query slot (state / output row)
+    if (a.done[qi]) return;
+
+    unsigned char* base = smem + (geo ? 2000 : 0) + (size_t)wave * replay_wave_bytes(k, nlist, geo, tune, training, a.trace_cap);
+    int64_t* href = reinterpret_cast<int64_t*>(base);
+    float* hval = reinterpret_cast<float*>(base + (size_t)k * 8);
+    float* srt = hval + k;
+    float* dwin = srt + k;                                 // geo only: 16 boundary distances of the current stage
+    float* pend = dwin + (geo ? 16 : 0);                   // geo only: values inserted during the current probe
+    float* trc = pend + (geo ? 16 : 0);                    // tune only: x | z, trace_cap each
+    float* terms = trc + (tune ? 2 * a.trace_cap : 0);     // tune only: cur_num_par scratch
+    float* gtrow = terms + (tune ? CURNUM_PAR_MAXK * 15 + 2 : 0);  // training only
+    const float* gdtb = geo ? a.dtb + (size_t)qi * max_num : nullptr;  // disToBoundary (set_online_kernel)
+
+    SortedRegs sreg{0xffffffffu, 0xffffffffu, SPOS_NONE, SPOS_NONE};
+    uint32_t amb = 0xffffffffu, logn = 0, log_v = 0, log_g = 0;
+    uint2* const qlog = SORTED ? a.log + (size_t)qi * a.log_cap : nullptr;
+    if (SORTED) {
+        // state between rounds: values best first in heap_val, global positions in heap_ref (-1: empty)
+        if (lane < k) {
+            sreg.k0 = okey<IsMax>(a.heap_val[(size_t)qi * k + lane]);
+            sreg.g0 = (uint32_t)a.heap_ref[(size_t)qi * k + lane];
+        }
+        if (TWO && lane + 64 < k) {
+            sreg.k1 = okey<IsMax>(a.heap_val[(size_t)qi * k + lane + 64]);
+            sreg.g1 = (uint32_t)a.heap_ref[(size_t)qi * k + lane + 64];
+        }
+        amb = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.amb[qi]);
+        logn = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.log_cnt[qi]);
+        if ((uint32_t)lane < (logn & 63u)) {  // the open block of the log comes back into the staging registers
+            const uint2 e = qlog[(logn & ~63u) + lane];
+            log_v = e.x;
+            log_g = e.y;
+        }
+    } else {
+        for (int i = lane; i < k; i += 64) {
+            hval[i] = a.heap_val[(size_t)qi * k + i];
+            href[i] = a.heap_ref[(size_t)qi * k + i];
+        }
+        wave_sync();
+    }
+
+    const unsigned long long id_q = a.id_offset + qi;
+    const unsigned long long dbg_t0 = a.dbg ? __builtin_readcyclecounter() : 0;
+    unsigned long long dbg_evals = 0, dbg_stream = 0, dbg_rule = 0, dbg_chunks = 0, dbg_probes = 0;
+    uint32_t err = 0;
+    uint32_t ik0 = a.stage[qi];
+    const uint32_t loop_end = a.limit ? a.limit[qi] : a.total_nprobe;
+    const uint32_t si = a.seg_by_slot ? qi : li;
+    const uint32_t cnt = a.seg_count[si];
+    const size_t seg0 = a.seg_begin ? (size_t)a.seg_begin[si] : (size_t)li * a.round_probes;
+    unsigned long long nscan = a.nscan[qi];
+    float pre_val = a.pre_val ? a.pre_val[qi] : 0.f;
+    uint32_t stoped = a.stoped ? a.stoped[qi] : 0u;
+    unsigned long long st_nlist = 0, st_nheap = 0, st_ndis = 0;
+
+    constexpr bool asm_off = false;  // true: the C++ walk for k = 100 too
+    RegHeap rh{};
+    if (RH) rh_load(rh, hval, k, lane);
+
+    int win_start = -1;
+    auto srt_from_regs = [&]() {  // the sorted view the stop rule reads
+        if (lane < k) srt[lane] = okey_inv<IsMax>(sreg.k0);
+        if (TWO && lane + 64 < k) srt[lane + 64] = okey_inv<IsMax>(sreg.k1);
+    };
+    if (geo) {
+        if (SORTED) srt_from_regs();
+        else rank_sort_best_first<IsMax>(hval, srt, k, lane);
+        if (training) {
+            const float* gt = a.train.gt_D + id_q * (unsigned long long)k;
+            for (int i = lane; i < k; i += 64) gtrow[i] = gt[i];
+        }
+        wave_sync();
+    }
+
+    uint32_t query_k = 0;
+    float true_KD_K = 0.f, racc = 0.f;
+    unsigned long long np = 0;
+    int cached_ind = -1;
+    // cur_num is a pure function of the trace / window of `ind` and of the query_k best heap values: its value is kept
+    // until one of them changes (in the later rounds most probes leave the best values alone)
+    bool have_pre = false, top_changed = true, srt_changed = true;
+    uint32_t kept_pre = 0;
+    TraceLds tr{trc, trc + a.trace_cap, 0};
+    if (tune) {
+        query_k = a.tuner.query_topk;
+        if (a.tuner.gt_D) true_KD_K = a.tuner.gt_D[id_q * (unsigned long long)k + query_k - 1];
+        racc = a.tuner.require_acc[id_q];
+        np = a.tuner.my_nprobe[id_q];
+    }
+    const unsigned long long np_in = np;
+
+    // The candidate stream (this round's distance rows, in probe order) comes in trips of NLD x 64 values.
+    // The loads of trip t + 1 are issued before trip t is examined, across probe boundaries: a wave owns one
+    // query, so its own loads in flight are all that hides the HBM round trip.
+    constexpr uint32_t TRIP = NLD * 64;
+    // probe table of the current window of 64 probes, one probe per lane: list number, candidates, row offset
+    uint32_t win0 = 0;
+    int m_key = -1;
+    uint32_t m_n = 0;
+    unsigned long long m_off = 0;
+    auto load_window = [&](uint32_t w0) {
+        win0 = w0;
+        m_key = -1;
+        m_n = 0;
+        m_off = 0;
+        const uint32_t pi = w0 + lane;
+        if (pi < cnt) {
+            m_key = a.seg_list[seg0 + pi];
+            m_off = a.seg_off[seg0 + pi];
+            if (m_key >= 0 && (uint32_t)m_key < nlist)
+                m_n = a.identity_ids ? nlist : (uint32_t)(a.list_off[m_key + 1] - a.list_off[m_key]);
+        }
+    };
+    load_window(0);
+    uint32_t fp = 0, fb = 0;  // fetch cursor: next (probe, offset); it never leaves the consumer's window
+    auto fetch = [&](float (&dst)[NLD]) {
+        for (;;) {
+            if (fp >= cnt || fp >= win0 + 64) return;
+            const uint32_t fn = (uint32_t)rl_i((int)m_n, (int)(fp - win0));
+            if (fb < fn) {
+                const unsigned long long fo = ((unsigned long long)(uint32_t)rl_i((int)(m_off >> 32), (int)(fp - win0)) << 32) |
+                                              (uint32_t)rl_i((int)(uint32_t)m_off, (int)(fp - win0));
+                const float* fseg = a.dist + fo;
+#pragma unroll
+                for (int u = 0; u < NLD; u++) {
+                    const uint32_t j = fb + u * 64 + lane;
+                    dst[u] = j < fn ? __builtin_nontemporal_load(fseg + j) : hneutral<IsMax>();
+                }
+                fb += TRIP;
+                if (fb >= fn) {
+                    fp++;
+                    fb = 0;
+                }
+                return;
+            }
+            fp++;
+            fb = 0;
+        }
+    };
+    // Masked rounds (a.mask: one bit per candidate, written by the scan kernel for the values that beat the heap
+    // top the query had when the round was planned): a row costs one 8-byte load per 64 candidates, and only the
+    // chunks with a bit set are fetched.  Rows start on multiples of 64 floats there.
+    const bool masked = a.mask != nullptr;
+    float v[NLD], nv[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; u++) v[u] = nv[u] = hneutral<IsMax>();
+    if (!masked) fetch(v);
+    auto row_offset = [&](uint32_t p) {
+        return ((unsigned long long)rl_u((uint32_t)(m_off >> 32), (int)(p - win0)) << 32) | rl_u((uint32_t)m_off, (int)(p - win0));
+    };
+    // mask words of chunks 0..63 and 64..127 of probe pre_p (8192 candidates: all but the very longest lists), requested one
+    // probe ahead: the row of a probe then costs no memory round trip of its own
+    unsigned long long mw_pre = 0, mw_pre2 = 0;
+    uint32_t pre_p = 0xffffffffu;
+    auto prefetch_masks = [&](uint32_t p) {
+        pre_p = 0xffffffffu;
+        if (p >= cnt || p >= win0 + 64) return;
+        const uint32_t pn = rl_u(m_n, (int)(p - win0));
+        if (pn == 0) return;
+        const unsigned long long* mr = a.mask + (row_offset(p) >> 6);
+        const uint32_t pch = (pn + 63) >> 6;
+        mw_pre = (uint32_t)lane < pch ? mr[lane] : 0ull;
+        mw_pre2 = (uint32_t)lane + 64 < pch ? mr[lane + 64] : 0ull;
+        pre_p = p;
+    };
+
+    bool finished = false;
+    uint32_t consumed = 0;
+    for (uint32_t p = 0; p < cnt && !finished; p++) {
+        const uint32_t ik = ik0 + p;
+        consumed = p + 1;
+        if (p >= win0 + 64) {  // next window of the probe table; the stream restarts behind it
+            load_window(p);
+            fp = p;
+            fb = 0;
+            if (!masked) fetch(v);
+        }
+        const int key = rl_i(m_key, (int)(p - win0));
+        if (key >= 0) {
+            if ((uint32_t)key >= nlist) {
+                err = ERR_INVALID_KEY;
+                finished = true;
+                break;
+            }
+            const uint32_t n = rl_u(m_n, (int)(p - win0));
+            if (n > 0) {
+                st_nlist++;
+                const unsigned long long dbg_s0 = a.dbg ? __builtin_readcyclecounter() : 0;
+                const int64_t refbase = REF_TAG | ((int64_t)key << 32);
+                const uint32_t lbase = SORTED && !a.identity_ids ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a.list_off[key]) : 0u;
+                int ins_min = 128;
+                const unsigned long long nheap0 = st_nheap;
+                uint32_t npend = 0;
+                const uint32_t nchunk = (n + 63) >> 6;
+                const unsigned long long roff = row_offset(p);
+                const float* seg = a.dist + roff;
+                const unsigned long long* mrow = masked ? a.mask + (roff >> 6) : nullptr;
+                unsigned long long mw = 0, nz = 0, mw2 = 0;
+                bool have2 = false;
+                uint32_t b0 = 0, w0 = 0;
+                if (masked) {
+                    if (pre_p == p) {  // the first two windows of this row were requested while the previous row ran
+                        mw = mw_pre;
+                        mw2 = mw_pre2;
+                        have2 = true;
+                        nz = __ballot(mw != 0);
+                        w0 = 64;
+                    }
+                    prefetch_masks(p + 1);
+                }
+                for (;;) {
+                    unsigned long long bm = 0;  // masked: lanes of `mw` (chunks w0 - 64 + lane) now held in v[0..)
+                    if (masked) {
+                        while (nz == 0 && w0 < nchunk) {
+                            if (w0 == 64 && have2) mw = mw2;
+                            else mw = w0 + lane < nchunk ? mrow[w0 + lane] : 0ull;
+                            nz = __ballot(mw != 0);
+                            w0 += 64;
+                        }
+                        if (nz == 0) break;
+                        if (a.dbg) dbg_chunks += __builtin_popcountll(nz);
+#pragma unroll
+                        for (int t = 0; t < NLD; t++) {
+                            v[t] = hneutral<IsMax>();
+                            if (nz) {
+                                const int c = __builtin_ctzll(nz);
+                                nz &= nz - 1;
+                                bm |= 1ull << c;
+                                const unsigned long long bits =
+                                    ((unsigned long long)rl_u((uint32_t)(mw >> 32), c) << 32) | rl_u((uint32_t)mw, c);
+                                if ((bits >> lane) & 1) v[t] = __builtin_nontemporal_load(seg + (size_t)(w0 - 64 + c) * 64 + lane);
+                            }
+                        }
+                    } else {
+                        if (b0 >= n) break;
+                        fetch(nv);
+                    }
+                    // heap top (the worst of the k), kept in a register between admissions
+                    float top = SORTED ? okey_inv<IsMax>(sr_key(sreg, k - 1)) : RH ? fkey_inv(rl_u(rh.v0, 1)) : hval[0];
+                    // chunks (64 candidates) holding at least one value that beats the top as it is now
+                    uint32_t umask = 0;
+#pragma unroll
+                    for (int u = 0; u < NLD; u++) umask |= __ballot(hcmp<IsMax>(top, v[u])) ? (1u << u) : 0u;
+                    // one copy of the update code for all chunks (32 inlined copies do not fit the instruction cache)
+                    while (umask) {
+                        const int u = __builtin_ctz(umask);
+                        umask &= umask - 1;
+                        float x = v[0];
+#pragma unroll
+                        for (int t = 1; t < NLD; t++) x = t == u ? v[t] : x;
+                        uint32_t cbase = b0 + u * 64;  // position of the chunk's first candidate in its list
+                        if (masked) {
+                            unsigned long long mm = bm;
+                            for (int i = 0; i < u; i++) mm &= mm - 1;
+                            cbase = (w0 - 64 + (uint32_t)__builtin_ctzll(mm)) * 64;
+                        }
+                        unsigned long long m = __ballot(hcmp<IsMax>(top, x));
+                        while (m) {
+                            const int l = __builtin_ctzll(m);
+                            m &= m - 1;
+                            const float val = rl_f(x, l);
+                            if (hcmp<IsMax>(top, val)) {
+                                const int64_t nref = refbase | (int64_t)(cbase + l);
+                                if (SORTED) {
+                                    const uint32_t wk = sr_key(sreg, k - 1);
+                                    if (k > 1 && wk != SKEY_SENT && sr_key(sreg, k - 2) == wk) amb = wk;  // one of several equal worst goes
+                                    const uint32_t vb = __float_as_uint(val), gp = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lbase + cbase + (uint32_t)l));
+                                    const int at = sr_insert<TWO>(sreg, okey<IsMax>(val), gp, lane);
+                                    ins_min = at < ins_min ? at : ins_min;
+                                    if (logn >= a.log_cap) {
+                                        err = ERR_LOG_OVERFLOW;
+                                    } else {
+                                        wl2_u(log_v, vb, log_g, gp, __builtin_amdgcn_readfirstlane((int)(logn & 63u)));
+                                        if ((logn & 63u) == 63u) qlog[(logn & ~63u) + lane] = make_uint2(log_v, log_g);
+                                        logn++;
+                                    }
+                                    top = okey_inv<IsMax>(sr_key(sreg, k - 1));
+                                } else if (RH) {
+                                    const uint32_t sr = rl_u(rh.s0, 1);  // the evicted root's id slot passes to the new entry
+                                    if (lane == 0) href[sr] = nref;
+                                    if (KC == 100 && !asm_off) rh_pop_k100<IsMax>(rh);
+                                    else rh_pop<IsMax, KC>(rh, k);
+                                    if (KC == 100 && !asm_off) rh_push_k100<IsMax>(rh, fkey(val), sr);
+                                    else rh_push<IsMax, KC>(rh, k, fkey(val), sr);
+                                    top = fkey_inv(rl_u(rh.v0, 1));
+                                } else {
+                                    heap_pop<IsMax>(k, hval, href);
+                                    heap_push<IsMax>(k, hval, href, val, nref);
+                                    top = hval[0];
+                                }
+                                st_nheap++;
+                                if (geo && !SORTED) {  // the sorted view is only read at the end of the probe: defer
+                                    if (npend < 16) pend[npend] = val;
+                                    npend++;
+                                }
+                            }
+                        }
+                    }
+                    if (!masked) {
+#pragma unroll
+                        for (int u = 0; u < NLD; u++) v[u] = nv[u];
+                        b0 += TRIP;
+                    }
+                }
+                if (a.dbg) dbg_stream += __builtin_readcyclecounter() - dbg_s0;
+                if (SORTED && geo && st_nheap != nheap0) {
+                    wave_sync();
+                    srt_from_regs();
+                    wave_sync();
+                    srt_changed = true;
+                    if (ins_min < (int)query_k) top_changed = true;
+                }
+                if (!SORTED && geo && npend) {
+                    wave_sync();
+                    srt_changed = true;
+                    if (npend <= 16) {
+                        for (uint32_t u = 0; u < npend; u++)
+                            if (sorted_replace_worst<IsMax>(srt, k, pend[u], lane) < (int)query_k) top_changed = true;
+                    } else {
+                        if (RH) rh_store(rh, hval, href, k, lane, false);
+                        rank_sort_best_first<IsMax>(hval, srt, k, lane);
+                        wave_sync();
+                        top_changed = true;
+                    }
+                }
+                nscan += n;
+                st_ndis += n;
+            }
+        }
+        if (a.max_codes && nscan >= a.max_codes) {
+            finished = true;
+            break;
+        }
+        if (loop_end && ik + 1 >= loop_end) finished = true;  // end of the probe loop
+        wave_sync();
+        const unsigned long long dbg_r0 = a.dbg ? __builtin_readcyclecounter() : 0;
+        if (tune) {
+            // IndexIVF.cpp:551-638.  Once my_nprobe is known nothing the rule computes can change the
+            // outcome any more (L2: no throwing path left), so only the stop test remains.
+            const uint32_t stage = ik + 1;
+            const bool overhead = a.tuner.overhead != 0;  // IndexIVF.cpp:614,634-637
+            const bool fired = IsMax && np != 0 && !overhead;
+            if (!fired) {
+                uint32_t ind = 0;
+                const uint32_t tmp_stage = stage >= nlist / 8 ? nlist / 8 - 1 : stage;
+                while (tmp_stage > (1u << ind)) ind++;
+                if ((int)ind != cached_ind) {
+                    const uint32_t o = a.tuner.trace_off[ind], n = a.tuner.trace_off[ind + 1] - o;
+                    const float sc = a.tuner.std_m;
+                    for (uint32_t i = lane; i < n; i += 64) {
+                        trc[i] = a.tuner.trace_x[o + i];
+                        trc[a.trace_cap + i] = a.tuner.trace_y[o + i] + sc * a.tuner.trace_std[o + i];
+                    }
+                    if (lane < 15) dwin[lane] = gdtb[(1u << ind) - 1 + lane];  // sum_angle start = 2^ind - 1
+                    tr.n = n;
+                    cached_ind = (int)ind;
+                    have_pre = false;
+                    wave_sync();
+                }
+                if (!IsMax && srt_changed) {
+                    // the reference converts all k heap values (IndexIVF.cpp:562-564): any out-of-domain one throws
+                    for (int i = lane; i < k; i += 64) (void)arcos_lut(lut, srt[i], &err);
+                    err = wave_err(err);
+                    if (err) {
+                        finished = true;
+                        break;
+                    }
+                }
+                srt_changed = false;
+                if (!have_pre || top_changed) {
+                    dbg_evals++;
+                    kept_pre = query_k <= CURNUM_PAR_MAXK ? cur_num_par<IsMax>(tr, lut, srt, dwin, terms, query_k, lane, &err)
+                                                          : cur_num_lds<IsMax>(tr, lut, srt, dwin, query_k, lane, &err);
+                    have_pre = true;
+                    top_changed = false;
+                }
+                const uint32_t pre_num = kept_pre;
+                float recall = (float)pre_num / (float)query_k;
+                const float max_val = IsMax ? fmaxf(-1.f, srt[k - 1]) : fminf(FLT_MAX, srt[k - 1]);
+                const unsigned long long stops = (unsigned long long)(racc * 12);
+                if (stage > 1) {
+                    if (max_val == pre_val) stoped++;
+                    else stoped = 0;
+                    if (stoped >= stops) recall = 1;
+                }
+                pre_val = max_val;
+                if (!overhead) {
+                    if (recall >= racc && np == 0) {
+                        np = (unsigned long long)((float)stage * a.tuner.multipler);
+                        if (np >= nlist && lane == 0) a.tuner.t_recalls[id_q] = 1.f;
+                    }
+                    if (stage >= nlist / 8 && np == 0) {
+                        np = (unsigned long long)((float)stage * a.tuner.multipler);
+                        if (np >= nlist && lane == 0) a.tuner.t_recalls[id_q] = 1.f;
+                    }
+                }
+                err = wave_err(err);
+                if (err) finished = true;
+            }
+            if (overhead) {
+                if (stage >= nlist / 8) finished = true;
+            } else if (np != 0 && np <= stage) {
+                if (a.tuner.profile) {
+                    if (RH) rh_store(rh, hval, href, k, lane, false);
+                    uint32_t hits = 0;
+                    for (int i = lane; i < k; i += 64) {
+                        const float s = SORTED ? srt[i] : hval[i];
+                        if (IsMax ? ((double)s <= (double)true_KD_K * 1.0005) : ((double)s >= (double)true_KD_K * 0.9995)) hits++;
+                    }
+                    for (int off = 32; off; off >>= 1) hits += __shfl_xor(hits, off);
+                    if (lane == 0) a.tuner.t_recalls[id_q] = (float)hits / (float)query_k;
+                }
+                finished = true;
+            }
+        }
+        if (a.dbg) dbg_rule += __builtin_readcyclecounter() - dbg_r0;
+        if (training && !finished) {
+            // IndexIVF.cpp:640-673
+            const uint32_t stage = ik + 1;
+            if (stage > nlist / 8) {
+                finished = true;
+            } else if ((stage & (stage - 1)) == 0) {
+                uint32_t ind = 0;
+                while (stage != (1u << ind)) ind++;
+                float* out = a.train.raw[ind] + 2ull * (id_q * (unsigned long long)(k / 4));
+                if (win_start != (int)(stage - 1)) {
+                    wave_sync();
+                    if (lane < 15) dwin[lane] = gdtb[stage - 1 + lane];
+                    win_start = (int)(stage - 1);
+                    wave_sync();
+                }
+                uint32_t count = 0;
+                for (int ij = 0; ij < k; ij++) {
+                    const float dv = srt[ij];  // L2 ascending / IP descending, as the reference walks them
+                    const float ks = kscaling_dev(dv, (uint32_t)ij, gtrow, (uint32_t)k);
+                    if (ks < 0) break;
+                    float tval = dv;
+                    if (!IsMax) tval = arcos_lut(lut, tval, &err);
+                    const float sum_a = sum_angle_par(lut, tval, dwin, lane, &err);
+                    if (lane == 0) {
+                        out[2 * count] = sum_a;
+                        out[2 * count + 1] = ks;
+                    }
+                    count++;
+                    if (count >= (uint32_t)(k / 4)) break;
+                }
+                err = wave_err(err);
+                if (err) finished = true;
+            }
+        }
+    }
+    err = wave_err(err);
+
+    if (lane == 0) {
+        a.stage[qi] = ik0 + consumed;
+        a.nscan[qi] = nscan;
+        if (a.pre_val) a.pre_val[qi] = pre_val;
+        if (a.stoped) a.stoped[qi] = stoped;
+        if (tune && np != np_in) a.tuner.my_nprobe[id_q] = np;
+        if (st_nlist) atomicAdd(&a.stats[0], st_nlist);
+        if (st_ndis) atomicAdd(&a.stats[1], st_ndis);
+        if (st_nheap) atomicAdd(&a.stats[2], st_nheap);
+        if (err) atomicMax(a.error, err);
+        if (a.dbg) {
+            a.dbg[(size_t)li * 8 + 0] = __builtin_readcyclecounter() - dbg_t0;
+            a.dbg[(size_t)li * 8 + 1] = st_nheap;
+            a.dbg[(size_t)li * 8 + 2] = st_ndis;
+            a.dbg[(size_t)li * 8 + 3] = dbg_evals;
+            a.dbg[(size_t)li * 8 + 4] = dbg_stream;
+            a.dbg[(size_t)li * 8 + 5] = dbg_rule;
+            a.dbg[(size_t)li * 8 + 6] = dbg_chunks;
+            a.dbg[(size_t)li * 8 + 7] = consumed;
+        }
+    }
+
+    wave_sync();
+    if (SORTED) {
+        if (a.thr && lane == 0) a.thr[qi] = okey_inv<IsMax>(sr_key(sreg, k - 1));  // next round's scan stores only what beats this
+        // the open block of the admission log, and where it stands
+        if ((uint32_t)lane < (logn & 63u)) qlog[(logn & ~63u) + lane] = make_uint2(log_v, log_g);
+        if (lane == 0) a.log_cnt[qi] = logn;
+        const bool in0 = lane < k, in1 = TWO && lane + 64 < k;
+        if (finished || a.finalize_all || err) {
+            // equal values among the k (their order is the heap's), or a value of which a copy was evicted while this one stayed
+            const uint32_t p0 = wave_shr1(sreg.k0, 0xfffffffeu), p1 = TWO ? wave_shr1(sreg.k1, rl_u(sreg.k0, 63)) : 0u;
+            const bool dup = (in0 && lane >= 1 && sreg.k0 == p0 && sreg.k0 != SKEY_SENT) || (in1 && sreg.k1 == p1 && sreg.k1 != SKEY_SENT);
+            const bool tainted = __ballot(dup) != 0 || sr_key(sreg, k - 1) == amb;
+            if (tainted && !err) {
+                if (lane == 0) a.tie_flag[qi] = 1;  // tie_fix_kernel writes this query's (D, I)
+            } else {
+                auto put = [&](int i, uint32_t key, uint32_t g) {
+                    const bool empty = key == SKEY_SENT && g == SPOS_NONE;
+                    int64_t id = -1;
+                    if (!empty) id = a.identity_ids ? (int64_t)g : a.store_pairs ? pair_of_gpos(a.list_off, nlist, g) : a.ids[g];
+                    a.D[(size_t)qi * k + i] = empty ? hneutral<IsMax>() : okey_inv<IsMax>(key);
+                    a.I[(size_t)qi * k + i] = id;
+                };
+                if (in0) put(lane, sreg.k0, sreg.g0);
+                if (in1) put(lane + 64, sreg.k1, sreg.g1);
+            }
+            if (lane == 0) a.done[qi] = 1;
+        } else {
+            if (in0) {
+                a.heap_val[(size_t)qi * k + lane] = okey_inv<IsMax>(sreg.k0);
+                a.heap_ref[(size_t)qi * k + lane] = sreg.g0 == SPOS_NONE ? -1 : (int64_t)sreg.g0;
+            }
+            if (in1) {
+                a.heap_val[(size_t)qi * k + lane + 64] = okey_inv<IsMax>(sreg.k1);
+                a.heap_ref[(size_t)qi * k + lane + 64] = sreg.g1 == SPOS_NONE ? -1 : (int64_t)sreg.g1;
+            }
+            if (lane == 0) a.amb[qi] = amb;
+        }
+        return;
+    }
+    if (a.thr && lane == 0) a.thr[qi] = RH ? fkey_inv(rl_u(rh.v0, 1)) : hval[0];  // next round's scan stores only what beats this
+    if (RH) rh_store(rh, hval, href, k, lane, true);  // back to the node-ordered LDS layout
+    if (finished || a.finalize_all || err) {
+        if (a.raw_heap_out) {
+            for (int i = lane; i < k; i += 64) {
+                int64_t ref = href[i];
+                if (ref >= 0 && (ref & REF_TAG)) {
+                    ref &= ~REF_TAG;
+                    if (!a.store_pairs) ref = a.ids[a.list_off[ref >> 32] + (uint64_t)(ref & 0xffffffffll)];
+                }
+                a.D[(size_t)qi * k + i] = hval[i];
+                a.I[(size_t)qi * k + i] = ref;
+            }
+        } else {
+            // heap_reorder (Heap.h:295-322)
+            int ii = 0;
+            for (int i = 0; i < k; i++) {
+                const float v = hval[0];
+                const int64_t id = href[0];
+                heap_pop<IsMax>(k - i, hval, href);
+                hval[k - ii - 1] = v;
+                href[k - ii - 1] = id;
+                if (id != -1) ii++;
+            }
+            wave_sync();
+            // valid entries now sit in [k-ii, k): move to the front, pad the rest
+            for (int i = lane; i < k; i += 64) {
+                float v = hneutral<IsMax>();
+                int64_t id = -1;
+                if (i < ii) {
+                    v = hval[k - ii + i];
+                    int64_t ref = href[k - ii + i];
+                    if (ref & REF_TAG) {
+                        ref &= ~REF_TAG;
+                        if (a.identity_ids) ref &= 0xffffffffll;
+                        else if (!a.store_pairs) ref = a.ids[a.list_off[ref >> 32] + (uint64_t)(ref & 0xffffffffll)];
+                    }
+                    id = ref;
+                }
+                a.D[(size_t)qi * k + i] = v;
+                a.I[(size_t)qi * k + i] = id;
+            }
+        }
+        if (lane == 0) a.done[qi] = 1;
+    } else {
+        for (int i = lane; i < k; i += 64) {
+            a.heap_val[(size_t)qi * k + i] = hval[i];
+            a.heap_ref[(size_t)qi * k + i] = href[i];
+        }
+    }
+}
+
+// the sorted-array selection applies when positions fit 32 bits (the caller checks ntotal) and the result is the
+// reordered one; the heap kernels remain for the scanner API (raw heap out), trace training, k > 128 and on request
+bool replay_sorted_applies(const ReplayArgs& a) {
+    const char* e = getenv("AUNCEL_AMD_SELECT");  // read per launch: the tests run both selections in one process
+    if (e && !strcmp(e, "heap")) return false;
+    return a.log != nullptr && a.k >= 1 && a.k <= 128 && !a.train.enabled && !a.raw_heap_out;
+}
+
+void launch_replay(const ReplayArgs& a, hipStream_t s) {
+    if (a.nq == 0) return;  // (chained rounds: nq is the bound the grid is sized by)
+    const bool tune = a.tuner.enabled != 0, train = a.train.enabled != 0, geo = tune || train;
+    const size_t shmem = (geo ? 2000 : 0) + 4 * replay_wave_bytes(a.k, a.nlist, geo, tune, train, a.trace_cap);
+    const dim3 grid((a.nq + 3) / 4), block(256);
+    static const bool no_rh = getenv("AUNCEL_AMD_LDS_HEAP") != nullptr;
+    const bool sorted = replay_sorted_applies(a);
+    const bool rh = a.k <= 127 && !no_rh;
+    // the heap (LDS form) and its sorted view take 16 k bytes per query, four queries per workgroup, of the CU's 160 KiB
+    if (shmem > 160 * 1024)
+        throw std::runtime_error("k = " + std::to_string(a.k) + " is beyond the selection kernel's LDS heap (" + std::to_string(shmem) +
+                                 " bytes of 163840 per workgroup)");
+    auto go = [&](auto kern) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) throw std::runtime_error(std::string("selection kernel: cannot reserve LDS: ") + hipGetErrorString(e));
+        LAUNCH(kern, grid, block, shmem, s, a);
+    };
+    // few queries: longer trips (more loads in flight per wave) at the price of fewer resident waves
+    const char* nld_s = getenv("AUNCEL_AMD_REPLAY_NLD");  // read per launch: the tests run both variants in one process
+    const int nld_env = nld_s ? atoi(nld_s) : 0;
+    const bool wide = nld_env ? nld_env >= 32 : (a.nq_hint ? a.nq_hint : a.nq) <= 3072;
+    auto pick = [&](auto is_max) {
+        constexpr bool M = decltype(is_max)::value;
+        if (sorted) {
+            if (a.k == 100) return wide ? go(replay_kernel<M, 2, 32, 100>) : go(replay_kernel<M, 2, 16, 100>);
+            if (a.k == 10) return wide ? go(replay_kernel<M, 2, 32, 10>) : go(replay_kernel<M, 2, 16, 10>);
+            return wide ? go(replay_kernel<M, 2, 32, 0>) : go(replay_kernel<M, 2, 16, 0>);
+        }
+        if (!rh) return wide ? go(replay_kernel<M, 0, 32, 0>) : go(replay_kernel<M, 0, 16, 0>);
+        if (a.k == 100) return wide ? go(replay_kernel<M, 1, 32, 100>) : go(replay_kernel<M, 1, 16, 100>);
+        if (a.k == 10) return wide ? go(replay_kernel<M, 1, 32, 10>) : go(replay_kernel<M, 1, 16, 10>);
+        return wide ? go(replay_kernel<M, 1, 32, 0>) : go(replay_kernel<M, 1, 16, 0>);
+    };
+    if (a.metric == METRIC_L2) pick(std::true_type{});
+    else pick(std::false_type{});
+}
+
+// ---------------------------------------------------------------------------------------------
+// Queries the sorted-array selection flagged (equal values met): the reference's heap (Heap.h:88-142), replayed over the
+// query's admission log -- every entry was admitted, in this order, so each is one heap_pop + heap_push -- then
+// heap_reorder (Heap.h:295-322).  One wave per flagged query; the others leave at once.
+template <bool IsMax, bool RH, int KC>
+__global__ __launch_bounds__(256) void tie_fix_kernel(TieFixArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t qi = blockIdx.x * 4 + wave;
+    if (qi >= a.nq || !a.tie_flag[qi]) return;
+    const int k = KC ? KC : a.k;
+    unsigned char* base = smem + (size_t)wave * (size_t)k * 12;
+    int64_t* href = reinterpret_cast<int64_t*>(base);
+    float* hval = reinterpret_cast<float*>(base + (size_t)k * 8);
+    for (int i = lane; i < k; i += 64) {
+        hval[i] = hneutral<IsMax>();
+        href[i] = -1;
+    }
+    wave_sync();
+    RegHeap rh{};
+    if (RH) rh_load(rh, hval, k, lane);
+    const uint2* qlog = a.log + (size_t)qi * a.log_cap;
+    const uint32_t n = a.log_cnt[qi];
+    uint2 e = (uint32_t)lane < n ? qlog[lane] : make_uint2(0u, 0u);
+    for (uint32_t b = 0; b < n; b += 64) {
+        const uint2 cur = e;
+        if (b + 64 + lane < n) e = qlog[b + 64 + lane];
+        const uint32_t cnt = n - b < 64u ? n - b : 64u;
+        for (uint32_t l = 0; l < cnt; l++) {
+            const float val = __uint_as_float(rl_u(cur.x, (int)l));
+            const int64_t g = (int64_t)rl_u(cur.y, (int)l);
+            if (RH) {
+                const uint32_t sr = rl_u(rh.s0, 1);
+                if (lane == 0) href[sr] = g;
+                if (KC == 100) rh_pop_k100<IsMax>(rh);
+                else rh_pop<IsMax, KC>(rh, k);
+                if (KC == 100) rh_push_k100<IsMax>(rh, fkey(val), sr);
+                else rh_push<IsMax, KC>(rh, k, fkey(val), sr);
+            } else {
+                heap_pop<IsMax>(k, hval, href);
+                heap_push<IsMax>(k, hval, href, val, g);
+            }
+        }
+    }
+    wave_sync();
+    if (RH) rh_store(rh, hval, href, k, lane, true);
+    int ii = 0;
+    for (int i = 0; i < k; i++) {
+        const float v = hval[0];
+        const int64_t id = href[0];
+        heap_pop<IsMax>(k - i, hval, href);
+        hval[k - ii - 1] = v;
+        href[k - ii - 1] = id;
+        if (id != -1) ii++;
+    }
+    wave_sync();
+    for (int i = lane; i < k; i += 64) {
+        float v = hneutral<IsMax>();
+        int64_t id = -1;
+        if (i < ii) {
+            v = hval[k - ii + i];
+            const uint32_t g = (uint32_t)href[k - ii + i];
+            id = a.identity_ids ? (int64_t)g : a.store_pairs ? pair_of_gpos(a.list_off, a.nlist, g) : a.ids[g];
+        }
+        a.D[(size_t)qi * k + i] = v;
+        a.I[(size_t)qi * k + i] = id;
+    }
+    if (lane == 0) a.tie_flag[qi] = 2;  // (counted by the engine's statistics)
+}
+
+void launch_tie_fix(const TieFixArgs& a, hipStream_t s) {
+    if (a.nq == 0) return;
+    const size_t shmem = 4 * (size_t)a.k * 12;
+    const dim3 grid((a.nq + 3) / 4), block(256);
+    auto go = [&](auto kern) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) throw std::runtime_error(std::string("tie_fix kernel: cannot reserve LDS: ") + hipGetErrorString(e));
+        LAUNCH(kern, grid, block, shmem, s, a);
+    };
+    auto pick = [&](auto is_max) {
+        constexpr bool M = decltype(is_max)::value;
+        if (a.k > 127) return go(tie_fix_kernel<M, false, 0>);
+        if (a.k == 100) return go(tie_fix_kernel<M, true, 100>);
+        if (a.k == 10) return go(tie_fix_kernel<M, true, 10>);
+        return go(tie_fix_kernel<M, true, 0>);
+    };
+    if (a.metric == METRIC_L2) pick(std::true_type{});
+    else pick(std::false_type{});
+}
+}  // namespace amdivf

@@ -225,6 +225,11 @@ int amd_ivf_last_scan_min_bytes(amd_ivf_t* h, double* bytes);
  *   AUNCEL_AMD_COARSE_TIES=heap: always re-run; =id: never.
  * *rows = rankings re-run so far on this handle. */
 int amd_ivf_coarse_tie_rows(amd_ivf_t* h, uint64_t* rows);
+/* Selection diagnostics of the last search on this handle.  The k best of a query are kept as a sorted array (same
+ * admissions as the reference's heap, Auncel/Heap.h:88-142); a query in which equal distances met -- the only case in which
+ * the heap's history decides an id or an output order -- gets its result from the reference's heap replayed over the query's
+ * admission log.  *queries = how many queries of the last search took that second path. */
+int amd_ivf_last_tie_fixed(amd_ivf_t* h, uint64_t* queries);
 
 /* Arithmetic the list scan of the last search ran in.  All three produce the reference's fp32 distance bit for
  * bit (utils_simd.cpp:391-443 order); the engine picks the cheapest one the data allows:

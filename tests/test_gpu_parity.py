@@ -184,12 +184,12 @@ def test_interdis_table(capi, name):
     assert np.array_equal(bits(h.get_interdis()), bits(gold["interdis_cem"]))
 
 
-@pytest.mark.parametrize("lanes", ["0", "1"])
+@pytest.mark.parametrize("select", ["sorted", "heap"])
 @pytest.mark.parametrize("name", AUNCEL)
-def test_adaptive_search(capi, monkeypatch, name, lanes):
-    """Error_sys::search: per-query error-bounded nprobe (my_nprobe), results, recall log -- with the one-kernel selection
-    (replay_kernel) and the two-kernel one (compact_kernel + replay_lanes_kernel)"""
-    monkeypatch.setenv("AUNCEL_AMD_LANES", lanes)
+def test_adaptive_search(capi, monkeypatch, name, select):
+    """Error_sys::search: per-query error-bounded nprobe (my_nprobe), results, recall log -- with the sorted-array selection
+    (+ tie_fix_kernel for the queries in which equal distances meet) and with the reference's heap replayed for every query"""
+    monkeypatch.setenv("AUNCEL_AMD_SELECT", select)
     case, gold = load_case(name)
     K, ts, ses = case["max_topk"], case["train_num"], case["test_num"]
     h = make_index(capi, case, gold, gold["centroids"])
@@ -213,13 +213,13 @@ def test_adaptive_search(capi, monkeypatch, name, lanes):
             assert [st["nlist"], st["ndis"], st["nheap_updates"]] == list(gold["stats" + suf]), suf
 
 
-@pytest.mark.parametrize("lanes", ["0", "1"])
+@pytest.mark.parametrize("select", ["sorted", "heap"])
 @pytest.mark.parametrize("name", AUNCEL_BIG)
-def test_adaptive_search_nlist4096(capi, monkeypatch, name, lanes):
+def test_adaptive_search_nlist4096(capi, monkeypatch, name, select):
     """BASELINE config 2's shape against the compiled reference: IVF4096 (max_num 532, ten traces, the prefix coarse
     ranking, the round planner at 4096 lists), both selection paths"""
     import hashlib
-    monkeypatch.setenv("AUNCEL_AMD_LANES", lanes)
+    monkeypatch.setenv("AUNCEL_AMD_SELECT", select)
     case, gold = load_case(name)
     K, ts, ses = case["max_topk"], case["train_num"], case["test_num"]
     h = make_index(capi, case, gold, gold["centroids"])
@@ -480,3 +480,31 @@ def test_time_bounded_search(capi, oracle, name):
         else:
             D, I, used = h.search_timed_x(xq[3:], 3, k, nprobe, b)
         _check_timed(oracle, lists, xq[3:], k, cd[3:], ck[3:], D, I, used, nprobe)
+
+
+def test_selection_log_overflow_falls_back_to_the_heap(capi, oracle):
+    """Every candidate of a list is better than the one before it (vectors ordered by decreasing distance to the query):
+    every one of them is admitted, the sorted-array selection's admission log (32 k entries) runs over, and the search is
+    repeated with the reference's heap -- same result as the oracle, nheap_updates included."""
+    n, d, k = 3000, 4, 10
+    xb = np.zeros((n, d), dtype=np.float32)
+    xb[:, 0] = np.arange(n, 0, -1, dtype=np.float32)          # the query sits at the origin: distances n^2 .. 1
+    xb[:, 1] = (np.arange(n) % 2).astype(np.float32)          # two lists, alternating
+    cen = np.array([[n / 2, 0, 0, 0], [n / 2, 1, 0, 0]], dtype=np.float32)
+    assign = (np.arange(n) % 2).astype(np.int64)
+    xq = np.zeros((3, d), dtype=np.float32)
+    xq[1, 1] = 1.0
+    xq[2, 0] = 7.5
+    keys = np.tile(np.array([0, 1], dtype=np.int64), (3, 1))
+    lists = oracle.Lists(1, cen, xb, assign)
+    eD, eI, est = oracle.search_preassigned(lists, xq, k, keys, np.zeros(keys.shape, np.float32))
+    assert est[2] > 2 * 32 * k  # more admissions than a query's log holds
+    h = capi.Handle(d, 2, capi.METRIC_L2, 0)
+    h.set_centroids(cen)
+    h.set_lists_from_assign(xb, assign)
+    h.stats(reset=True)
+    D, I = h.search_preassigned(xq, k, keys)
+    assert np.array_equal(I, eI)
+    assert np.array_equal(bits(D), bits(eD))
+    st = h.stats()
+    assert [st["nlist"], st["ndis"], st["nheap_updates"]] == list(est)

@@ -79,7 +79,7 @@ def test_search_and_range_against_oracle(capi, oracle, monkeypatch, seed):
                                                 max_codes=max_codes)
         for rounds in ("1", "2"):
             monkeypatch.setenv("AUNCEL_AMD_FIXED_ROUNDS", rounds)
-            monkeypatch.setenv("AUNCEL_AMD_LANES", "1" if (seed + int(rounds)) % 3 == 0 else "0")  # both selection paths
+            monkeypatch.setenv("AUNCEL_AMD_SELECT", "heap" if (seed + int(rounds)) % 3 == 0 else "sorted")  # both selection paths
             h.stats(reset=True)
             D, I = h.search_preassigned(c["xq"], c["k"], keys, store_pairs=pairs, max_codes=max_codes)
             tag = f"{c['kind']} d={c['d']} nlist={c['nlist']} k={c['k']} nprobe={c['nprobe']} pairs={pairs} mc={max_codes} rounds={rounds}"
@@ -88,7 +88,7 @@ def test_search_and_range_against_oracle(capi, oracle, monkeypatch, seed):
             st = h.stats()
             assert [st["nlist"], st["ndis"], st["nheap_updates"]] == list(est), tag
     monkeypatch.delenv("AUNCEL_AMD_FIXED_ROUNDS")
-    monkeypatch.delenv("AUNCEL_AMD_LANES")
+    monkeypatch.delenv("AUNCEL_AMD_SELECT")
     # range search around the median of the exact k-th distances
     eD, _, _ = oracle.search_preassigned(lists, c["xq"], 1, keys, np.zeros(keys.shape, np.float32))
     fin = eD[np.isfinite(eD) & (np.abs(eD) < 1e37)]

@@ -69,8 +69,8 @@ def test_adaptive_against_oracle(capi, oracle, monkeypatch, seed):
     c = make_case(seed)
     # both stream widths of the selection kernel (the narrow one is what 5000-query batches get)
     monkeypatch.setenv("AUNCEL_AMD_REPLAY_NLD", "16" if seed % 2 else "32")
-    # every third shape through the two-kernel selection (compact_kernel + replay_lanes_kernel) where it applies
-    monkeypatch.setenv("AUNCEL_AMD_LANES", "1" if seed % 3 == 0 else "0")
+    # every third shape with the reference's heap as the selection for every query (the default: sorted array + tie_fix)
+    monkeypatch.setenv("AUNCEL_AMD_SELECT", "heap" if seed % 3 == 0 else "sorted")
     nq, K = c["xq"].shape[0], c["K"]
     _, a = oracle.knn(c["metric"], c["xb"], c["cen"], 1, nthreads=8)
     assign = a[:, 0]
