@@ -28,6 +28,7 @@ SYMBOLS = [
     "amd_ivf_kmeans",
     "amd_ivf_range_search_preassigned", "amd_ivf_range_search", "amd_ivf_range_results",
     "amd_ivf_scan_arith",
+    "amd_ivf_read_fvecs", "amd_ivf_read_ivecs", "amd_ivf_read_fbin", "amd_ivf_read_ibin", "amd_ivf_free",
 ]
 
 
@@ -47,6 +48,7 @@ def lib():
         L.amd_ivf_last_error.restype = C.c_char_p
         for s in SYMBOLS[1:]:
             getattr(L, s).restype = C.c_int
+        L.amd_ivf_free.restype = None
         _LIB = L
     return _LIB
 
@@ -108,6 +110,44 @@ def trace_sb(raw_xy, bs=250):
     nb = C.c_size_t(0)
     _chk(lib().amd_ivf_trace_sb(_f(raw), C.c_size_t(n), C.c_size_t(bs), _f(ox), _f(oy), _f(os_), C.byref(nb)))
     return ox[:nb.value].copy(), oy[:nb.value].copy(), os_[:nb.value].copy()
+
+
+def _take(ptr, n, d, ctype, dtype):
+    """copy a malloc'ed n x d matrix out of the library and release it"""
+    try:
+        out = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(n * d,)).astype(dtype, copy=True).reshape(n, d) if n * d else np.zeros((n, d), dtype)
+    finally:
+        lib().amd_ivf_free(ptr)
+    return out
+
+
+def read_fvecs(path):
+    """fvecs_read (Auncel/eval/bound.cpp:29-58) -> float32 (n, d)"""
+    d, n, p = C.c_size_t(0), C.c_size_t(0), _f32p()
+    _chk(lib().amd_ivf_read_fvecs(os.fsencode(path), C.byref(d), C.byref(n), C.byref(p)))
+    return _take(p, n.value, d.value, C.c_float, np.float32)
+
+
+def read_ivecs(path):
+    """ivecs_read (Auncel/eval/bound.cpp:61-63) -> int32 (n, d)"""
+    d, n, p = C.c_size_t(0), C.c_size_t(0), C.POINTER(C.c_int32)()
+    _chk(lib().amd_ivf_read_ivecs(os.fsencode(path), C.byref(d), C.byref(n), C.byref(p)))
+    return _take(p, n.value, d.value, C.c_int32, np.int32)
+
+
+def read_fbin(path, num=0, nbytes=4):
+    """fbin_read (Auncel/eval/bound.cpp:65-109): `num` rows (0: the header's count); nbytes 1 = signed chars widened, as the
+    harness reads its u8 SIFT files -> float32 (rows, d), header row count"""
+    d, n, p = C.c_size_t(0), C.c_size_t(0), _f32p()
+    _chk(lib().amd_ivf_read_fbin(os.fsencode(path), C.c_size_t(num), int(nbytes), C.byref(d), C.byref(n), C.byref(p)))
+    return _take(p, num if num else n.value, d.value, C.c_float, np.float32), n.value
+
+
+def read_ibin(path, num=0):
+    """ibin_read (Auncel/eval/bound.cpp:111-113) -> int32 (rows, d), header row count"""
+    d, n, p = C.c_size_t(0), C.c_size_t(0), C.POINTER(C.c_int32)()
+    _chk(lib().amd_ivf_read_ibin(os.fsencode(path), C.c_size_t(num), C.byref(d), C.byref(n), C.byref(p)))
+    return _take(p, num if num else n.value, d.value, C.c_int32, np.int32), n.value
 
 
 def arcos_table():

@@ -1698,6 +1698,8 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         ta.list_off = I->d_list_off.as<uint64_t>();
         ta.ids = I->d_ids.as<int64_t>();
         ta.store_pairs = base.store_pairs;
+        ta.D = h->w_D.as<float>();
+        ta.I = h->w_I.as<int64_t>();
         size_t t = h->timer.begin(CAT_SELECT, s);
         launch_tie_fix(ta, s);
         h->timer.end(t, s);
@@ -1806,6 +1808,10 @@ void run_rounds(amd_ivf* h, RoundSpec& base, size_t n, size_t first_round, size_
         g_last_error = "unknown error";          \
         return -1;                               \
     }
+
+namespace amdivf {
+void set_last_error(const std::string& msg) { g_last_error = msg; }  // (dataset_io.cpp)
+}
 
 extern "C" {
 

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include <stdexcept>
 #include <string>
@@ -15,6 +17,13 @@ namespace amdivf {
 inline void check_launch(const char* what) {
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) throw std::runtime_error(std::string("kernel launch failed: ") + what + ": " + hipGetErrorString(e));
+    // AUNCEL_AMD_SYNC_LAUNCH=1 (debugging): name every launch and wait for it, so that a device fault points at its kernel
+    static const bool sync_each = getenv("AUNCEL_AMD_SYNC_LAUNCH") != nullptr;
+    if (sync_each) {
+        fprintf(stderr, "[launch] %.100s\n", what);
+        const hipError_t s = hipDeviceSynchronize();
+        if (s != hipSuccess) throw std::runtime_error(std::string("kernel failed: ") + what + ": " + hipGetErrorString(s));
+    }
 }
 // (the error state is per thread and sticky: an unrelated earlier call, e.g. the elapsed time of an event pair that was
 // never recorded, must not be taken for this launch's)

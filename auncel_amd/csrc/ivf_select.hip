@@ -1146,7 +1146,7 @@ __global__ __launch_bounds__(256) void tie_fix_kernel(TieFixArgs a) {
     const uint32_t qi = blockIdx.x * 4 + wave;
     if (qi >= a.nq || !a.tie_flag[qi]) return;
     const int k = KC ? KC : a.k;
-    unsigned char* base = smem + (size_t)wave * (size_t)k * 12;
+    unsigned char* base = smem + (size_t)wave * (((size_t)k * 12 + 15) & ~(size_t)15);
     int64_t* href = reinterpret_cast<int64_t*>(base);
     float* hval = reinterpret_cast<float*>(base + (size_t)k * 8);
     for (int i = lane; i < k; i += 64) {
@@ -1207,7 +1207,7 @@ __global__ __launch_bounds__(256) void tie_fix_kernel(TieFixArgs a) {
 
 void launch_tie_fix(const TieFixArgs& a, hipStream_t s) {
     if (a.nq == 0) return;
-    const size_t shmem = 4 * (size_t)a.k * 12;
+    const size_t shmem = 4 * (((size_t)a.k * 12 + 15) & ~(size_t)15);
     const dim3 grid((a.nq + 3) / 4), block(256);
     auto go = [&](auto kern) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);

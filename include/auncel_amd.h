@@ -242,6 +242,21 @@ int amd_ivf_scan_arith(amd_ivf_t* h);
  * codes qualify (same results; bench.py's fp32_path leg).  enable = 1 restores the default. */
 int amd_ivf_set_byte_codes(amd_ivf_t* h, int enable);
 
+/* ------------------------------------------------------------------------------------------------
+ * Dataset files of the reference's harness (Auncel/eval/bound.cpp:29-113; host only).  Buffers are malloc'ed
+ * here and released with amd_ivf_free.  Where the harness aborts (missing file, size that is not a whole number of rows,
+ * short read) these return -2 and amd_ivf_last_error() says why.
+ *   read_fvecs / read_ivecs   fvecs_read / ivecs_read (:29-63): every row = int32 d followed by d 4-byte values; *x is n x d.
+ *   read_fbin                 fbin_read (:65-109): int32 n, int32 d, then `num` rows (0: n rows) of d values of `bytes`
+ *                             bytes each: 4 = fp32; 1 = one byte per value read as a SIGNED char and widened to float,
+ *                             exactly as the harness does for its u8 SIFT files.  *n is the header's count, as there.
+ *   read_ibin                 ibin_read (:111-113): the same container holding int32 (ground-truth ids). */
+int amd_ivf_read_fvecs(const char* path, size_t* d, size_t* n, float** x);
+int amd_ivf_read_ivecs(const char* path, size_t* d, size_t* n, int32_t** x);
+int amd_ivf_read_fbin(const char* path, size_t num, int bytes, size_t* d, size_t* n, float** x);
+int amd_ivf_read_ibin(const char* path, size_t num, size_t* d, size_t* n, int32_t** x);
+void amd_ivf_free(void* p);
+
 #ifdef __cplusplus
 }
 #endif
