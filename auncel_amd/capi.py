@@ -21,9 +21,9 @@ SYMBOLS = [
     "amd_ivf_set_lists", "amd_ivf_add", "amd_ivf_ntotal", "amd_ivf_list_size", "amd_ivf_get_list", "amd_ivf_coarse",
     "amd_ivf_search_preassigned", "amd_ivf_search", "amd_ivf_scan_codes", "amd_ivf_distance_to_code", "amd_ivf_stats",
     "amd_ivf_set_queries", "amd_ivf_search_resident", "amd_ivf_set_interdis", "amd_ivf_get_interdis",
-    "amd_ivf_set_tuner", "amd_ivf_search_adaptive", "amd_ivf_search_adaptive_x", "amd_ivf_search_timed", "amd_ivf_search_timed_x",
+    "amd_ivf_set_tuner", "amd_ivf_search_adaptive", "amd_ivf_search_adaptive_x", "amd_ivf_search_adaptive_pre", "amd_ivf_search_timed", "amd_ivf_search_timed_x",
     "amd_ivf_train_samples",
-    "amd_ivf_train_samples_x", "amd_ivf_trace_sb", "amd_ivf_arcos_table", "amd_ivf_merge_tables",
+    "amd_ivf_train_samples_x", "amd_ivf_train_samples_pre", "amd_ivf_trace_sb", "amd_ivf_arcos_table", "amd_ivf_merge_tables",
     "amd_ivf_last_timing", "amd_ivf_last_scan_min_bytes", "amd_ivf_coarse_tie_rows", "amd_ivf_last_tie_fixed", "amd_ivf_set_byte_codes",
     "amd_ivf_kmeans",
     "amd_ivf_range_search_preassigned", "amd_ivf_range_search", "amd_ivf_range_results",
@@ -351,6 +351,33 @@ class Handle:
         _chk(lib().amd_ivf_search_adaptive(self._h, C.c_size_t(start), C.c_size_t(n), C.c_size_t(query_topk),
                                            C.c_float(multipler), C.c_float(std_m), _f(req), _f(gt), int(profile), coarse_mode,
                                            my_nprobe.ctypes.data_as(_u64p), _f(t_recalls), _f(D), _i(I)))
+        return D, I
+
+    def search_adaptive_pre(self, x, id_offset, keys, coarse_dis, query_topk, multipler, std_m, require_acc, my_nprobe, t_recalls,
+                            gt_D=None, profile=False):
+        """search_preassigned with tune on over the caller's coarse ranking (keys / coarse_dis rows, nprobe entries each)"""
+        x, keys, cd = f32(x), i64(keys), f32(coarse_dis)
+        n, nprobe = keys.shape
+        req = f32(require_acc)
+        gt = f32(gt_D) if gt_D is not None else None
+        assert my_nprobe.dtype == np.uint64 and t_recalls.dtype == np.float32
+        K = self.max_topk
+        D = np.empty((n, K), np.float32)
+        I = np.empty((n, K), np.int64)
+        _chk(lib().amd_ivf_search_adaptive_pre(self._h, C.c_size_t(n), _f(x), C.c_size_t(id_offset), C.c_size_t(nprobe), _i(keys), _f(cd),
+                                               C.c_size_t(query_topk), C.c_float(multipler), C.c_float(std_m), _f(req), _f(gt),
+                                               int(profile), my_nprobe.ctypes.data_as(_u64p), _f(t_recalls), _f(D), _i(I)))
+        return D, I
+
+    def train_samples_pre(self, x, id_offset, keys, coarse_dis, max_topk, gt_D, train_num, raw):
+        """the training branch over the caller's coarse ranking"""
+        x, keys, cd, gt = f32(x), i64(keys), f32(coarse_dis), f32(gt_D)
+        n, nprobe = keys.shape
+        D = np.empty((n, max_topk), np.float32)
+        I = np.empty((n, max_topk), np.int64)
+        ptrs = (_f32p * len(raw))(*[_f(r) for r in raw])
+        _chk(lib().amd_ivf_train_samples_pre(self._h, C.c_size_t(n), _f(x), C.c_size_t(id_offset), C.c_size_t(nprobe), _i(keys), _f(cd),
+                                             C.c_size_t(max_topk), _f(gt), C.c_size_t(train_num), ptrs, _f(D), _i(I)))
         return D, I
 
     def search_timed(self, start, n, k, nprobe, budget_ms, coarse_mode=0):

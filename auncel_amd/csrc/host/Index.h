@@ -28,6 +28,8 @@ struct Index {
     /// objects); IndexShards::add_shard deals unassigned shards round-robin over the node's GPUs, one host thread each.
     int amd_device = -1;
     virtual void set_device(int device) { amd_device = device; }
+    /// true once the index holds device state on `amd_device` (it can no longer be given another device)
+    virtual bool device_bound() const { return false; }
 
     int d;
     idx_t ntotal;

@@ -1,6 +1,7 @@
 // faiss::IndexFlat (Auncel/IndexFlat.h:21-87) -- the coarse quantiser.  `xb` is the host copy of the
 // vectors (public in the reference, harnesses read it); search() runs on the GPU.
 #pragma once
+#include <mutex>
 #include <vector>
 
 #include "Index.h"
@@ -29,6 +30,9 @@ struct IndexFlat : Index {
     size_t version = 0;
 
    private:
+    // search() is const and, as in the reference, may be called from several threads (shards sharing one quantizer): the device
+    // copy is created lazily and the engine handle has one stream and one set of work buffers, so calls are serialised here
+    mutable std::mutex gpu_mu_;
     mutable amd_ivf* gpu_ = nullptr;
     mutable idx_t gpu_ntotal_ = -1;
 };

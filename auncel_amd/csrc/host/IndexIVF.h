@@ -57,6 +57,7 @@ struct IndexIVF : Index, Level1Quantizer {
     void set_tune_mode() override;
     /// the engine of this index and of its flat quantizer move together (before their first use)
     void set_device(int device) override;
+    bool device_bound() const override;
     void set_tune_off() override;
     void set_train_mode();
     void set_train_off();

@@ -85,6 +85,7 @@ void IndexFlat::reset() {
 
 void IndexFlat::search(idx_t n, const float* x, idx_t k, float* distances, idx_t* labels) const {
     FAISS_THROW_IF_NOT_MSG(ntotal > 0, "empty flat index");
+    std::lock_guard<std::mutex> lock(gpu_mu_);
     if (!gpu_ || gpu_ntotal_ != ntotal) {
         if (gpu_) amd_ivf_destroy(gpu_);
         gpu_ = nullptr;
@@ -441,8 +442,11 @@ void IndexIVF::add(idx_t n, const float* x) { add_with_ids(n, x, nullptr); }
 void IndexIVF::set_device(int device) {
     FAISS_THROW_IF_NOT_MSG(gpu_ == nullptr || device == amd_device, "the index already lives on another device");
     amd_device = device;
-    if (quantizer) quantizer->set_device(device);
+    // a quantizer that already has a device keeps it (shards share one: its rankings come back to the host either way)
+    if (quantizer && quantizer->amd_device < 0) quantizer->set_device(device);
 }
+
+bool IndexIVF::device_bound() const { return gpu_ != nullptr; }
 
 void IndexIVF::replace_invlists(InvertedLists* il, bool own) {
     if (own_invlists) delete invlists;
@@ -1044,7 +1048,8 @@ void IndexShards::add_shard(Index* index) {
     }
     FAISS_THROW_IF_NOT_MSG(index->d == d && index->metric_type == metric_type, "shards must agree on d and metric");
     // one MI355X per shard: a shard without a device of its own takes the next one of the node, round robin
-    if (index->amd_device < 0 && !getenv("AUNCEL_AMD_DEVICE")) {
+    // (an index that already holds device state stays where it is)
+    if (index->amd_device < 0 && !index->device_bound() && !getenv("AUNCEL_AMD_DEVICE")) {
         int ndev = 0;
         if (amd_ivf_device_count(&ndev) == 0 && ndev > 1) index->set_device((int)(shards.size() % (size_t)ndev));
     }

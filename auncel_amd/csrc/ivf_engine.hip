@@ -241,6 +241,9 @@ struct amd_ivf {
     PinnedBuf p_items, p_pair_query, p_pair_out, p_seg_off, p_seg_list, p_seg_count, p_qsel, p_seg_begin;
     DevBuf w_seg_begin;
     DevBuf w_log, w_log_cnt, w_amb, w_tie_flag;  // sorted-array selection: admission logs, ambiguity marks, tie_fix flags
+    DevBuf w_log_snap, w_fin_round, w_fix_pos, w_fix_val, w_fix_ref;  // tie_fix_kernel: per-round log counts, heaps replayed so far
+    hipStream_t fix_stream = nullptr;            // tie_fix_kernel runs here, under the next round
+    hipEvent_t ev_sel = nullptr, ev_fix[2] = {nullptr, nullptr};
     size_t last_state_n = 0;                     // queries of the last search (amd_ivf_last_tie_fixed reads their flags)
     // chained rounds: the planning counters of every round of the last search (grid hints for the next one of the same shape)
     DevBuf w_pl_hist;
@@ -248,6 +251,11 @@ struct amd_ivf {
     std::vector<uint32_t> round_hint;  // [round][16]
     uint64_t hint_sig = 0;
     bool force_heap_select = false;  // (set while a search is repeated after ERR_LOG_OVERFLOW)
+    // tune / train search over a coarse ranking the caller supplies (amd_ivf_search_adaptive_pre, amd_ivf_train_samples_pre):
+    // host rows of this call's (or slice's) queries, given_nprobe entries each; null: the engine ranks the centroids itself
+    const int64_t* given_keys = nullptr;
+    const float* given_dis = nullptr;
+    size_t given_nprobe = 0;
     DevBuf w_limit;  // time-bounded search: per-slot end of the probe loop (plan_counts_kernel -> replay_kernel)
     DevBuf w_tie_rows;  // rankings re-run through the reference's heap because of equal distances (launch_heap_tie_order)
 
@@ -276,6 +284,10 @@ struct amd_ivf {
             if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
         }
         if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (fix_stream) (void)hipStreamDestroy(fix_stream);
+        if (ev_sel) (void)hipEventDestroy(ev_sel);
+        for (int i = 0; i < 2; i++)
+            if (ev_fix[i]) (void)hipEventDestroy(ev_fix[i]);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -419,6 +431,14 @@ void init_state(amd_ivf* h, size_t n, size_t k, bool tune_or_train) {
     h->w_log_cnt.ensure(n * 4);
     h->w_amb.ensure(n * 4);
     h->w_tie_flag.ensure(n * 4);
+    h->w_log_snap.ensure(2 * n * 4);
+    h->w_fin_round.ensure(n * 4);
+    h->w_fix_pos.ensure(n * 4);
+    const bool fix_state = k <= 128 && !h->force_heap_select;  // (the heaps tie_fix_kernel replays: sorted-array selection only)
+    if (fix_state) {
+        h->w_fix_val.ensure(n * k * sizeof(float));
+        h->w_fix_ref.ensure(n * k * sizeof(int64_t));
+    }
     h->last_state_n = n;
     InitStateArgs ia{};
     ia.n = n;
@@ -437,6 +457,13 @@ void init_state(amd_ivf* h, size_t n, size_t k, bool tune_or_train) {
     ia.log_cnt = h->w_log_cnt.as<uint32_t>();
     ia.amb = h->w_amb.as<uint32_t>();
     ia.tie_flag = h->w_tie_flag.as<uint32_t>();
+    ia.log_snap = h->w_log_snap.as<uint32_t>();
+    ia.fin_round = h->w_fin_round.as<uint32_t>();
+    ia.fix_pos = h->w_fix_pos.as<uint32_t>();
+    if (fix_state) {
+        ia.fix_val = h->w_fix_val.as<float>();
+        ia.fix_ref = h->w_fix_ref.as<int64_t>();
+    }
     launch_init_state(ia, h->stream);
     if (tune_or_train) h->w_dtb.ensure(n * (h->nlist / 8 + 20) * sizeof(float));
 }
@@ -1291,15 +1318,15 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     // round that does not fit is cut (plan_prefix_kernel defers the remaining queries: another pass over the lists).  8 GiB
     // hold 2500 unfinished queries x 144 probes of the bench workload; small searches take what they can ever need.
     static const size_t budget_env = getenv("AUNCEL_AMD_DIST_BUDGET_MB") ? (size_t)atol(getenv("AUNCEL_AMD_DIST_BUDGET_MB")) << 18 : 0;
-    const size_t padded_max = (maxlist + 63) & ~(size_t)63;
+    const size_t padded_max = (maxlist + 1023) & ~(size_t)1023;
     const double all_rows = (double)n * (double)std::min<size_t>(total_nprobe, nlist) * (double)padded_max;
     size_t budget = budget_env ? budget_env : std::max<size_t>(h->dist_budget_floats, (size_t)2 << 30);
     if (all_rows < (double)budget) budget = (size_t)all_rows + 64;
-    budget = std::max<size_t>(budget, I->h_list_off[nlist] + 64 * nlist + 64);
+    budget = std::max<size_t>(budget, I->h_list_off[nlist] + 1024 * nlist + 1024);
     if (base.bytes && budget > ((size_t)1 << 31)) throw std::runtime_error("distance rows beyond 2^31 floats (byte-code scan offsets are 32-bit)");
     static const bool no_thr = getenv("AUNCEL_AMD_NO_THRESHOLD") != nullptr;
     h->w_pl_pad.ensure(n * 4);
-    h->w_mask.ensure((budget / 64 + 2) * 8);
+    h->w_mask.ensure((budget / 64 + 2 + 256) * 8);  // (+ the words the selection's stream requests past a region's end)
     h->w_pl_cnt.ensure(n * 4);
     h->w_pl_need.ensure(n * 8);
     h->w_seg_begin.ensure(n * 4);
@@ -1319,7 +1346,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     h->w_pl_fill.ensure(nlist * 4);
     h->w_pl_counters.ensure(96);  // 16 uint32 counters | double bytes | 2 x u64 slot bookkeeping
     h->p_counters.ensure(96);
-    h->w_dist.ensure(budget * sizeof(float));
+    h->w_dist.ensure((budget + 4096) * sizeof(float));  // (+ the blocks the selection's stream requests past a region's end)
     HIP_CHECK(hipMemsetAsync(h->w_pl_counters.p, 0, 96, s));
     // sorted-array selection: global positions must fit 32 bits; a query's admission log holds 32 k entries (k (1 + ln(N / k))
     // are expected: ~5 k for a million candidates), beyond which the call is repeated with the heap kernels
@@ -1355,7 +1382,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     pa.cnt = h->w_pl_cnt.as<uint32_t>();
     pa.need = h->w_pl_need.as<unsigned long long>();
     pa.pad = h->w_pl_pad.as<uint32_t>();
-    pa.row_align = 64;
+    pa.row_align = sorted_ok ? 1024 : 64;  // (select_sorted_kernel reads dense rows in groups of four blocks of 256 candidates)
     pa.qblock = scan_qblock(base.bytes);
     if (base.bytes) {
         pa.mfma_chunk = mfma_chunk();
@@ -1500,7 +1527,8 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         h->timer.end(t, s);
     };
 
-    bool sorted_used = false;
+    bool fix_pending = false;
+    size_t last_fix_round = 0;
     // ---- ordered selection of a scanned round.  nact: active queries (sync) or the bound n with the count on the device.
     auto enqueue_replay = [&](bool thr_mode, uint32_t nact, bool on_device, size_t round) {
         ReplayArgs ra{};
@@ -1551,8 +1579,14 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             ra.log_cnt = h->w_log_cnt.as<uint32_t>();
             ra.amb = h->w_amb.as<uint32_t>();
             ra.tie_flag = h->w_tie_flag.as<uint32_t>();
+            ra.round = (uint32_t)round;
+            ra.log_snap = h->w_log_snap.as<uint32_t>();
+            ra.nq_total = (uint32_t)n;
+            ra.fin_round = h->w_fin_round.as<uint32_t>();
         }
-        sorted_used = sorted_used || replay_sorted_applies(ra);
+        const bool sorted_now = replay_sorted_applies(ra);
+        // (tie_fix_kernel of round - 2 read the log counts this round's selection is about to overwrite)
+        if (sorted_now && round >= 2) HIP_CHECK(hipStreamWaitEvent(s, h->ev_fix[round & 1], 0));
         static const bool dbg_replay_dev = getenv("AUNCEL_AMD_DEBUG_REPLAY") != nullptr;
         if (dbg_replay_dev) {
             h->w_misc.ensure((size_t)nact * 64);
@@ -1563,6 +1597,42 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             size_t t = h->timer.begin(CAT_SELECT, s);
             launch_replay(ra, s);
             h->timer.end(t, s);
+        }
+        if (sorted_now) {
+            // the reference's heap over what this round admitted (and the results of the flagged queries that finished in it), on
+            // a side stream: it runs under the next round's scan and selection
+            if (!h->fix_stream) {
+                HIP_CHECK(hipStreamCreateWithFlags(&h->fix_stream, hipStreamNonBlocking));
+                HIP_CHECK(hipEventCreateWithFlags(&h->ev_sel, hipEventDisableTiming));
+                for (int i = 0; i < 2; i++) HIP_CHECK(hipEventCreateWithFlags(&h->ev_fix[i], hipEventDisableTiming));
+            }
+            TieFixArgs ta{};
+            ta.metric = h->metric;
+            ta.k = base.k;
+            ta.nq = (uint32_t)n;
+            ta.nlist = (uint32_t)nlist;
+            ta.log = h->w_log.as<uint2>();
+            ta.log_cap = (uint32_t)log_cap;
+            ta.round = (uint32_t)round;
+            ta.log_snap = h->w_log_snap.as<uint32_t>();
+            ta.fin_round = h->w_fin_round.as<uint32_t>();
+            ta.fix_val = h->w_fix_val.as<float>();
+            ta.fix_ref = h->w_fix_ref.as<int64_t>();
+            ta.fix_pos = h->w_fix_pos.as<uint32_t>();
+            ta.tie_flag = h->w_tie_flag.as<uint32_t>();
+            ta.list_off = I->d_list_off.as<uint64_t>();
+            ta.ids = I->d_ids.as<int64_t>();
+            ta.store_pairs = base.store_pairs;
+            ta.D = h->w_D.as<float>();
+            ta.I = h->w_I.as<int64_t>();
+            HIP_CHECK(hipEventRecord(h->ev_sel, s));
+            HIP_CHECK(hipStreamWaitEvent(h->fix_stream, h->ev_sel, 0));
+            size_t t = h->timer.begin(CAT_SELECT, h->fix_stream);
+            launch_tie_fix(ta, h->fix_stream);
+            h->timer.end(t, h->fix_stream);
+            HIP_CHECK(hipEventRecord(h->ev_fix[round & 1], h->fix_stream));
+            fix_pending = true;
+            last_fix_round = round;
         }
         if (dbg_replay_dev) {
             fprintf(stderr, "[replay] round %zu: %u queries\n", round, nact);
@@ -1580,7 +1650,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
 
     if (chained) {
         // a fixed-nprobe search ends with its last planned round when no query can be deferred (rows and pairs fit the buffers)
-        const size_t padded = (maxlist + 63) & ~(size_t)63;
+        const size_t padded = (maxlist + 1023) & ~(size_t)1023;
         const bool fits = (double)n * (double)total_nprobe * (double)padded <= (double)budget && n * total_nprobe <= seg_cap;
         bool fixed_complete = !base.tuner.enabled && !base.train.enabled && fits && (base.fixed_two || first_round >= total_nprobe);
         static const size_t ahead_env = getenv("AUNCEL_AMD_ROUNDS_AHEAD") ? (size_t)atoi(getenv("AUNCEL_AMD_ROUNDS_AHEAD")) : 0;
@@ -1685,25 +1755,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             round_len = next_round_len(round_len);
         }
     }
-    if (sorted_used) {  // the flagged queries' results come from the reference's heap replayed over their admission logs
-        TieFixArgs ta{};
-        ta.metric = h->metric;
-        ta.k = base.k;
-        ta.nq = (uint32_t)n;
-        ta.nlist = (uint32_t)nlist;
-        ta.log = h->w_log.as<uint2>();
-        ta.log_cap = (uint32_t)log_cap;
-        ta.log_cnt = h->w_log_cnt.as<uint32_t>();
-        ta.tie_flag = h->w_tie_flag.as<uint32_t>();
-        ta.list_off = I->d_list_off.as<uint64_t>();
-        ta.ids = I->d_ids.as<int64_t>();
-        ta.store_pairs = base.store_pairs;
-        ta.D = h->w_D.as<float>();
-        ta.I = h->w_I.as<int64_t>();
-        size_t t = h->timer.begin(CAT_SELECT, s);
-        launch_tie_fix(ta, s);
-        h->timer.end(t, s);
-    }
+    if (fix_pending) HIP_CHECK(hipStreamWaitEvent(s, h->ev_fix[last_fix_round & 1], 0));  // the last round's tie_fix_kernel
     if (!base.caller_checks_error) check_device_error(h);
     if (chained) {  // the bookkeeping counters of the last round (bytes, slots) have not been read yet; nor has the history
         const size_t nh = std::min(planned_rounds ? planned_rounds - 1 : 0, MAX_HIST);
@@ -2433,22 +2485,39 @@ int amd_ivf_set_tuner(amd_ivf_t* h, size_t max_topk, size_t ntraces, const size_
 }
 
 // one slice of an adaptive batch: queries [q0, q0+n) of the call, on lane `L` (L == h or one of h's kids)
+// The coarse ranking of a tune / train search into w_cdis / w_ckeys: the engine's own over all nlist centroids (what
+// Error_sys::search asks its quantizer for, profile.cpp:220), or the rows the caller handed to search_preassigned
+// (Auncel/IndexIVF.cpp:382-386).  Returns the row length = the length of the probe loop.
+static size_t coarse_or_given(amd_ivf_t* L, const float* d_x, size_t n, int coarse_mode, bool fused_ok, size_t coarse_prefix) {
+    const size_t nlist = L->nlist;
+    if (!L->given_keys) {
+        L->w_cdis.ensure(n * nlist * 4);
+        L->w_ckeys.ensure(n * nlist * 8);
+        coarse_dev(L, d_x, n, nlist, coarse_mode, L->w_cdis.as<float>(), L->w_ckeys.as<int64_t>(), fused_ok, coarse_prefix);
+        return nlist;
+    }
+    const size_t np = L->given_nprobe;
+    if (np <= nlist / 8 + 20) throw EngineError("tune / train mode reads coarse entries 0 .. nlist/8 + 20: nprobe too small");
+    L->w_cdis.ensure(n * np * 4);
+    L->w_ckeys.ensure(n * np * 8);
+    HIP_CHECK(hipMemcpyAsync(L->w_cdis.p, L->given_dis, n * np * 4, hipMemcpyHostToDevice, L->stream));
+    HIP_CHECK(hipMemcpyAsync(L->w_ckeys.p, L->given_keys, n * np * 8, hipMemcpyHostToDevice, L->stream));
+    return np;
+}
+
 static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n, size_t query_topk, float multipler, float std_m,
                            const float* dreq, const float* dgt, unsigned long long* dnp, float* dtr, int profile, int coarse_mode,
                            float* D, int64_t* I, const IntRange& qr, size_t coarse_prefix) {
     use_device(L);
     const size_t K = ix(L)->tuner_max_topk, nlist = L->nlist;
-    L->w_cdis.ensure(n * nlist * 4);
-    L->w_ckeys.ensure(n * nlist * 8);
-    // full coarse ranking (Error_sys::search sets nprobe = nlist, profile.cpp:220)
-    coarse_dev(L, d_x, n, nlist, coarse_mode, L->w_cdis.as<float>(), L->w_ckeys.as<int64_t>(),
-               ix(L)->allow_fused && ix(L)->centroid_range.fusable_with(qr, L->metric), coarse_prefix);
+    // full coarse ranking (Error_sys::search sets nprobe = nlist, profile.cpp:220), or the caller's
+    const size_t np_row = coarse_or_given(L, d_x, n, coarse_mode, ix(L)->allow_fused && ix(L)->centroid_range.fusable_with(qr, L->metric), coarse_prefix);
     if (L->want_first_tie) {
         L->w_first_tie.ensure(n * 4);
         launch_first_tie(L->w_cdis.as<float>(), (uint32_t)n, (uint32_t)nlist, (uint32_t)L->first_tie_nreal, L->w_first_tie.as<uint32_t>(), L->stream);
     }
     init_state(L, n, K, true);
-    launch_set_online(L->metric, (uint32_t)nlist, (uint32_t)n, L->w_cdis.as<float>(), L->w_ckeys.as<int64_t>(), (uint32_t)nlist,
+    launch_set_online(L->metric, (uint32_t)nlist, (uint32_t)n, L->w_cdis.as<float>(), L->w_ckeys.as<int64_t>(), (uint32_t)np_row,
                       ix(L)->d_interdis.as<float>(), ix(L)->d_arcos.as<float>(), L->w_dtb.as<float>(), L->w_error.as<uint32_t>(), L->stream);
     RoundSpec base;
     base.fused = ix(L)->allow_fused && ix(L)->db_range.fusable_with(qr, L->metric);
@@ -2459,12 +2528,12 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
     base.d_x = d_x;
     base.d_cdis = L->w_cdis.as<float>();
     base.d_ckeys = L->w_ckeys.as<int64_t>();
-    base.coarse_stride = (uint32_t)nlist;
+    base.coarse_stride = (uint32_t)np_row;
     base.tuner = make_tuner(L, query_topk, multipler, std_m, dreq, dgt, dnp, dtr, profile);
     static const size_t first_env = getenv("AUNCEL_AMD_ROUND_FIRST") ? (size_t)atoi(getenv("AUNCEL_AMD_ROUND_FIRST")) : 12;
     static const bool host_plan = getenv("AUNCEL_AMD_HOST_PLAN") != nullptr;
     if (host_plan) {
-        run_rounds(L, base, n, first_env, nlist, dnp, id0);
+        run_rounds(L, base, n, first_env, np_row, dnp, id0);
         HIP_CHECK(hipMemcpyAsync(D, L->w_D.p, n * K * 4, hipMemcpyDeviceToHost, L->stream));
         HIP_CHECK(hipMemcpyAsync(I, L->w_I.p, n * K * 8, hipMemcpyDeviceToHost, L->stream));
         HIP_CHECK(stream_sync(L->stream));
@@ -2472,7 +2541,7 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
         return;
     }
     base.caller_checks_error = true;
-    run_rounds_device(L, base, n, first_env, nlist, dnp);
+    run_rounds_device(L, base, n, first_env, np_row, dnp);
     finish_results(L, n, K, D, I);
 }
 
@@ -2538,6 +2607,12 @@ static void adaptive_core_once(amd_ivf_t* h, const float* d_x, size_t start, siz
     std::vector<amd_ivf*> lanes(nl);
     lanes[0] = h;
     for (size_t i = 1; i < nl; i++) lanes[i] = h->kids[i - 1].get();
+    for (size_t i = 1; i < nl; i++) {  // the slices' rows of a caller-supplied coarse ranking
+        const size_t q0 = n * i / nl;
+        lanes[i]->given_keys = h->given_keys ? h->given_keys + q0 * h->given_nprobe : nullptr;
+        lanes[i]->given_dis = h->given_keys ? h->given_dis + q0 * h->given_nprobe : nullptr;
+        lanes[i]->given_nprobe = h->given_nprobe;
+    }
     for (amd_ivf* L : lanes) {
         L->force_heap_select = h->force_heap_select;
         L->scan_bytes = L->scan_min_bytes = 0;
@@ -2603,7 +2678,7 @@ static void adaptive_core_once(amd_ivf_t* h, const float* d_x, size_t start, siz
 static void adaptive_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n, size_t query_topk, float multipler, float std_m,
                           const float* require_acc, const float* gt_D, int profile, int coarse_mode,
                           uint64_t* my_nprobe, float* t_recalls, float* D, int64_t* I, const IntRange& qr) {
-    const bool speculate = n > 0 && n < 20 && !getenv("AUNCEL_AMD_COARSE_TIES") && h->nlist > 128 && multipler >= 1.f && !(profile & 2);
+    const bool speculate = !h->given_keys && n > 0 && n < 20 && !getenv("AUNCEL_AMD_COARSE_TIES") && h->nlist > 128 && multipler >= 1.f && !(profile & 2);
     if (!speculate) {
         with_select_fallback(h, [&] { adaptive_core_once(h, d_x, start, n, query_topk, multipler, std_m, require_acc, gt_D, profile, coarse_mode, my_nprobe, t_recalls, D, I, qr); });
         return;
@@ -2676,6 +2751,38 @@ int amd_ivf_search_adaptive_x(amd_ivf_t* h, size_t n, const float* x, size_t id_
     API_END
 }
 
+// scope of a caller-supplied coarse ranking on a handle
+struct GivenCoarse {
+    amd_ivf* h;
+    GivenCoarse(amd_ivf* hh, size_t nprobe, const int64_t* keys, const float* dis) : h(hh) {
+        if (!keys || !dis) throw EngineError("keys and coarse_dis are required");
+        h->given_keys = keys;
+        h->given_dis = dis;
+        h->given_nprobe = nprobe;
+    }
+    ~GivenCoarse() {
+        h->given_keys = nullptr;
+        h->given_dis = nullptr;
+        h->given_nprobe = 0;
+    }
+};
+
+int amd_ivf_search_adaptive_pre(amd_ivf_t* h, size_t n, const float* x, size_t id_offset, size_t nprobe, const int64_t* keys,
+                                const float* coarse_dis, size_t query_topk, float multipler, float std_m, const float* require_acc,
+                                const float* gt_D, int profile, uint64_t* my_nprobe, float* t_recalls, float* D, int64_t* I) {
+    API_BEGIN
+    use_device(h);
+    if (n == 0) return 0;
+    h->w_x.ensure(n * h->dpad * sizeof(float));
+    upload_rows(h, h->w_x.as<float>(), x, n);
+    IntRange qr;
+    qr.add(x, n * (size_t)h->d);
+    GivenCoarse given(h, nprobe, keys, coarse_dis);
+    adaptive_core(h, h->w_x.as<float>(), id_offset, n, query_topk, multipler, std_m, require_acc, gt_D, profile, 0, my_nprobe, t_recalls,
+                  D, I, qr);
+    API_END
+}
+
 static void train_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n, size_t max_topk, const float* gt_D, size_t train_num,
                           int coarse_mode, float* const* raw, float* D, int64_t* I, const IntRange& qr) {
     use_device(h);
@@ -2706,15 +2813,12 @@ static void train_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n, s
         h->d_arcos.ensure(500 * 4);
         HIP_CHECK(hipMemcpy(h->d_arcos.p, lut.data(), 500 * 4, hipMemcpyHostToDevice));
     }
-    h->w_cdis.ensure(n * nlist * 4);
-    h->w_ckeys.ensure(n * nlist * 8);
     // training stops after stage nlist/8 + 1 (IndexIVF.cpp:640-673); set_online reads entries 0 .. nlist/8+20
     size_t coarse_prefix = nlist / 8 + 21 + 16;
     if (coarse_prefix >= nlist || getenv("AUNCEL_AMD_FULL_COARSE_SORT")) coarse_prefix = 0;
-    coarse_dev(h, d_x, n, nlist, coarse_mode, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>(),
-               h->allow_fused && h->centroid_range.fusable_with(qr, h->metric), coarse_prefix);
+    const size_t np_row = coarse_or_given(h, d_x, n, coarse_mode, h->allow_fused && h->centroid_range.fusable_with(qr, h->metric), coarse_prefix);
     init_state(h, n, K, true);
-    launch_set_online(h->metric, (uint32_t)nlist, (uint32_t)n, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>(), (uint32_t)nlist,
+    launch_set_online(h->metric, (uint32_t)nlist, (uint32_t)n, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>(), (uint32_t)np_row,
                       h->d_interdis.as<float>(), h->d_arcos.as<float>(), h->w_dtb.as<float>(), h->w_error.as<uint32_t>(), h->stream);
     RoundSpec base;
     base.fused = h->allow_fused && h->db_range.fusable_with(qr, h->metric);
@@ -2725,15 +2829,15 @@ static void train_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n, s
     base.d_x = d_x;
     base.d_cdis = h->w_cdis.as<float>();
     base.d_ckeys = h->w_ckeys.as<int64_t>();
-    base.coarse_stride = (uint32_t)nlist;
+    base.coarse_stride = (uint32_t)np_row;
     base.train.enabled = 1;
     base.train.ntraces = (uint32_t)ntr;
     base.train.interdis = h->d_interdis.as<float>();
     base.train.arcos = h->d_arcos.as<float>();
     base.train.gt_D = h->w_misc2.as<float>();
     base.train.raw = reinterpret_cast<float* const*>(h->w_rawptrs.p);
-    if (getenv("AUNCEL_AMD_HOST_PLAN")) run_rounds(h, base, n, 32, nlist, nullptr, start);
-    else run_rounds_device(h, base, n, 32, nlist, nullptr);
+    if (getenv("AUNCEL_AMD_HOST_PLAN")) run_rounds(h, base, n, 32, np_row, nullptr, start);
+    else run_rounds_device(h, base, n, 32, np_row, nullptr);
     HIP_CHECK(hipMemcpyAsync(D, h->w_D.p, n * K * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipMemcpyAsync(I, h->w_I.p, n * K * 8, hipMemcpyDeviceToHost, h->stream));
     for (size_t i = 0; i < ntr; i++)
@@ -2765,6 +2869,22 @@ int amd_ivf_train_samples_x(amd_ivf_t* h, size_t n, const float* x, size_t id_of
     IntRange qr;
     qr.add(x, n * (size_t)h->d);
     train_core(h, h->w_x.as<float>(), id_offset, n, max_topk, gt_D, train_num, coarse_mode, raw, D, I, qr);
+    API_END
+}
+
+int amd_ivf_train_samples_pre(amd_ivf_t* h, size_t n, const float* x, size_t id_offset, size_t nprobe, const int64_t* keys,
+                              const float* coarse_dis, size_t max_topk, const float* gt_D, size_t train_num, float* const* raw, float* D,
+                              int64_t* I) {
+    API_BEGIN
+    OWNER_ONLY(h);
+    use_device(h);
+    if (n == 0) return 0;
+    h->w_x.ensure(n * h->dpad * sizeof(float));
+    upload_rows(h, h->w_x.as<float>(), x, n);
+    IntRange qr;
+    qr.add(x, n * (size_t)h->d);
+    GivenCoarse given(h, nprobe, keys, coarse_dis);
+    train_core(h, h->w_x.as<float>(), id_offset, n, max_topk, gt_D, train_num, 0, raw, D, I, qr);
     API_END
 }
 

@@ -229,6 +229,11 @@ struct ReplayArgs {
     uint32_t* log_cnt;         // [slot]
     uint32_t* amb;             // [slot] order key of a value whose id became ambiguous (0xffffffff: none)
     uint32_t* tie_flag;        // [slot] set when the query's result has to come from tie_fix_kernel
+    uint32_t round;            // number of this round within the search
+    uint32_t* log_snap;        // [2][nq_total] log_cnt as this round left it, by round parity (tie_fix_kernel of this round reads it
+                               //               while the next round's selection already appends)
+    uint32_t nq_total;
+    uint32_t* fin_round;       // [slot] the round in which the query got its final state (0xffffffff: not yet)
 };
 
 bool replay_sorted_applies(const ReplayArgs& a);
@@ -241,7 +246,12 @@ struct TieFixArgs {
     uint32_t nq, nlist;
     const uint2* log;
     uint32_t log_cap;
-    const uint32_t* log_cnt;
+    uint32_t round;              // the selection round this launch follows
+    const uint32_t* log_snap;    // [2][nq]
+    const uint32_t* fin_round;   // [nq]
+    float* fix_val;              // [nq][k] the reference's heap (node order) as far as the log has been replayed
+    int64_t* fix_ref;            // [nq][k] global positions, -1 = empty
+    uint32_t* fix_pos;           // [nq] log entries replayed so far
     uint32_t* tie_flag;
     const uint64_t* list_off;
     const int64_t* ids;
@@ -401,6 +411,9 @@ struct InitStateArgs {
     unsigned long long* stats;  // 4 counters
     uint32_t* error;
     uint32_t *log_cnt, *amb, *tie_flag;  // sorted-array selection (may be null)
+    uint32_t *log_snap, *fin_round, *fix_pos;
+    float* fix_val;
+    int64_t* fix_ref;
 };
 void launch_init_state(const InitStateArgs& a, hipStream_t s);
 void launch_fill_f32(float* p, size_t n, float v, hipStream_t s);

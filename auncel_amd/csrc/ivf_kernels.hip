@@ -1319,6 +1319,10 @@ __global__ __launch_bounds__(256) void init_state_kernel(InitStateArgs a) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nk; i += stride) {
         a.heap_val[i] = a.neutral;
         a.heap_ref[i] = -1;
+        if (a.fix_val) {
+            a.fix_val[i] = a.neutral;
+            a.fix_ref[i] = -1;
+        }
     }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += stride) {
         a.thr[i] = a.neutral;
@@ -1331,6 +1335,10 @@ __global__ __launch_bounds__(256) void init_state_kernel(InitStateArgs a) {
             a.log_cnt[i] = 0;
             a.amb[i] = 0xffffffffu;
             a.tie_flag[i] = 0;
+            a.log_snap[i] = 0;
+            a.log_snap[a.n + i] = 0;
+            a.fin_round[i] = 0xffffffffu;
+            a.fix_pos[i] = 0;
         }
     }
     if (blockIdx.x == 0 && threadIdx.x < 4) a.stats[threadIdx.x] = 0;

@@ -497,14 +497,13 @@ __host__ __device__ inline size_t replay_wave_bytes(int k, uint32_t nlist, bool 
     return (b + 15) & ~(size_t)15;
 }
 
-// MODE 0: the reference's heap in LDS; 1: the same heap in registers (k <= 127); 2: the k best as a sorted register
-//         array + admission log (k <= 128; see SortedRegs) -- the default wherever it applies
+// The reference's heap itself, replayed for every query: what the scanner API (raw heap in / out), trace training, the coarse
+// quantiser's short rankings, k > 128 and AUNCEL_AMD_SELECT=heap use (everything else: select_sorted_kernel below).
+// RH: the heap lives in registers (k <= 127); otherwise in LDS
 // NLD: 64-candidate chunks per trip of the candidate stream (registers for two trips are live)
-// KC: compile-time k of the register heap / sorted array (0: run-time k)
-template <bool IsMax, int MODE, int NLD, int KC>
+// KC: compile-time k of the register heap (0: run-time k)
+template <bool IsMax, bool RH, int NLD, int KC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ? 5 : 3))) void replay_kernel(ReplayArgs a) {
-    constexpr bool RH = MODE == 1, SORTED = MODE == 2;
-    constexpr bool TWO = KC == 0 || KC > 64;  // sorted array: entries 64.. exist
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -536,33 +535,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
     float* gtrow = terms + (tune ? CURNUM_PAR_MAXK * 15 + 2 : 0);  // training only
     const float* gdtb = geo ? a.dtb + (size_t)qi * max_num : nullptr;  // disToBoundary (set_online_kernel)
 
-    SortedRegs sreg{0xffffffffu, 0xffffffffu, SPOS_NONE, SPOS_NONE};
-    uint32_t amb = 0xffffffffu, logn = 0, log_v = 0, log_g = 0;
-    uint2* const qlog = SORTED ? a.log + (size_t)qi * a.log_cap : nullptr;
-    if (SORTED) {
-        // state between rounds: values best first in heap_val, global positions in heap_ref (-1: empty)
-        if (lane < k) {
-            sreg.k0 = okey<IsMax>(a.heap_val[(size_t)qi * k + lane]);
-            sreg.g0 = (uint32_t)a.heap_ref[(size_t)qi * k + lane];
-        }
-        if (TWO && lane + 64 < k) {
-            sreg.k1 = okey<IsMax>(a.heap_val[(size_t)qi * k + lane + 64]);
-            sreg.g1 = (uint32_t)a.heap_ref[(size_t)qi * k + lane + 64];
-        }
-        amb = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.amb[qi]);
-        logn = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.log_cnt[qi]);
-        if ((uint32_t)lane < (logn & 63u)) {  // the open block of the log comes back into the staging registers
-            const uint2 e = qlog[(logn & ~63u) + lane];
-            log_v = e.x;
-            log_g = e.y;
-        }
-    } else {
-        for (int i = lane; i < k; i += 64) {
-            hval[i] = a.heap_val[(size_t)qi * k + i];
-            href[i] = a.heap_ref[(size_t)qi * k + i];
-        }
-        wave_sync();
+    for (int i = lane; i < k; i += 64) {
+        hval[i] = a.heap_val[(size_t)qi * k + i];
+        href[i] = a.heap_ref[(size_t)qi * k + i];
     }
+    wave_sync();
 
     const unsigned long long id_q = a.id_offset + qi;
     const unsigned long long dbg_t0 = a.dbg ? __builtin_readcyclecounter() : 0;
@@ -583,13 +560,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
     if (RH) rh_load(rh, hval, k, lane);
 
     int win_start = -1;
-    auto srt_from_regs = [&]() {  // the sorted view the stop rule reads
-        if (lane < k) srt[lane] = okey_inv<IsMax>(sreg.k0);
-        if (TWO && lane + 64 < k) srt[lane + 64] = okey_inv<IsMax>(sreg.k1);
-    };
     if (geo) {
-        if (SORTED) srt_from_regs();
-        else rank_sort_best_first<IsMax>(hval, srt, k, lane);
+        rank_sort_best_first<IsMax>(hval, srt, k, lane);
         if (training) {
             const float* gt = a.train.gt_D + id_q * (unsigned long long)k;
             for (int i = lane; i < k; i += 64) gtrow[i] = gt[i];
@@ -712,9 +684,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
                 st_nlist++;
                 const unsigned long long dbg_s0 = a.dbg ? __builtin_readcyclecounter() : 0;
                 const int64_t refbase = REF_TAG | ((int64_t)key << 32);
-                const uint32_t lbase = SORTED && !a.identity_ids ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a.list_off[key]) : 0u;
-                int ins_min = 128;
-                const unsigned long long nheap0 = st_nheap;
                 uint32_t npend = 0;
                 const uint32_t nchunk = (n + 63) >> 6;
                 const unsigned long long roff = row_offset(p);
@@ -760,8 +729,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
                         if (b0 >= n) break;
                         fetch(nv);
                     }
-                    // heap top (the worst of the k), kept in a register between admissions
-                    float top = SORTED ? okey_inv<IsMax>(sr_key(sreg, k - 1)) : RH ? fkey_inv(rl_u(rh.v0, 1)) : hval[0];
+                    float top = RH ? fkey_inv(rl_u(rh.v0, 1)) : hval[0];  // heap top, kept in a register between admissions
                     // chunks (64 candidates) holding at least one value that beats the top as it is now
                     uint32_t umask = 0;
 #pragma unroll
@@ -786,21 +754,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
                             const float val = rl_f(x, l);
                             if (hcmp<IsMax>(top, val)) {
                                 const int64_t nref = refbase | (int64_t)(cbase + l);
-                                if (SORTED) {
-                                    const uint32_t wk = sr_key(sreg, k - 1);
-                                    if (k > 1 && wk != SKEY_SENT && sr_key(sreg, k - 2) == wk) amb = wk;  // one of several equal worst goes
-                                    const uint32_t vb = __float_as_uint(val), gp = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lbase + cbase + (uint32_t)l));
-                                    const int at = sr_insert<TWO>(sreg, okey<IsMax>(val), gp, lane);
-                                    ins_min = at < ins_min ? at : ins_min;
-                                    if (logn >= a.log_cap) {
-                                        err = ERR_LOG_OVERFLOW;
-                                    } else {
-                                        wl2_u(log_v, vb, log_g, gp, __builtin_amdgcn_readfirstlane((int)(logn & 63u)));
-                                        if ((logn & 63u) == 63u) qlog[(logn & ~63u) + lane] = make_uint2(log_v, log_g);
-                                        logn++;
-                                    }
-                                    top = okey_inv<IsMax>(sr_key(sreg, k - 1));
-                                } else if (RH) {
+                                if (RH) {
                                     const uint32_t sr = rl_u(rh.s0, 1);  // the evicted root's id slot passes to the new entry
                                     if (lane == 0) href[sr] = nref;
                                     if (KC == 100 && !asm_off) rh_pop_k100<IsMax>(rh);
@@ -814,7 +768,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
                                     top = hval[0];
                                 }
                                 st_nheap++;
-                                if (geo && !SORTED) {  // the sorted view is only read at the end of the probe: defer
+                                if (geo) {  // the sorted view is only read at the end of the probe: defer
                                     if (npend < 16) pend[npend] = val;
                                     npend++;
                                 }
@@ -828,14 +782,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
                     }
                 }
                 if (a.dbg) dbg_stream += __builtin_readcyclecounter() - dbg_s0;
-                if (SORTED && geo && st_nheap != nheap0) {
-                    wave_sync();
-                    srt_from_regs();
-                    wave_sync();
-                    srt_changed = true;
-                    if (ins_min < (int)query_k) top_changed = true;
-                }
-                if (!SORTED && geo && npend) {
+                if (geo && npend) {
                     wave_sync();
                     srt_changed = true;
                     if (npend <= 16) {
@@ -929,7 +876,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
                     if (RH) rh_store(rh, hval, href, k, lane, false);
                     uint32_t hits = 0;
                     for (int i = lane; i < k; i += 64) {
-                        const float s = SORTED ? srt[i] : hval[i];
+                        const float s = hval[i];
                         if (IsMax ? ((double)s <= (double)true_KD_K * 1.0005) : ((double)s >= (double)true_KD_K * 0.9995)) hits++;
                     }
                     for (int off = 32; off; off >>= 1) hits += __shfl_xor(hits, off);
@@ -999,44 +946,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
     }
 
     wave_sync();
-    if (SORTED) {
-        if (a.thr && lane == 0) a.thr[qi] = okey_inv<IsMax>(sr_key(sreg, k - 1));  // next round's scan stores only what beats this
-        // the open block of the admission log, and where it stands
-        if ((uint32_t)lane < (logn & 63u)) qlog[(logn & ~63u) + lane] = make_uint2(log_v, log_g);
-        if (lane == 0) a.log_cnt[qi] = logn;
-        const bool in0 = lane < k, in1 = TWO && lane + 64 < k;
-        if (finished || a.finalize_all || err) {
-            // equal values among the k (their order is the heap's), or a value of which a copy was evicted while this one stayed
-            const uint32_t p0 = wave_shr1(sreg.k0, 0xfffffffeu), p1 = TWO ? wave_shr1(sreg.k1, rl_u(sreg.k0, 63)) : 0u;
-            const bool dup = (in0 && lane >= 1 && sreg.k0 == p0 && sreg.k0 != SKEY_SENT) || (in1 && sreg.k1 == p1 && sreg.k1 != SKEY_SENT);
-            const bool tainted = __ballot(dup) != 0 || sr_key(sreg, k - 1) == amb;
-            if (tainted && !err) {
-                if (lane == 0) a.tie_flag[qi] = 1;  // tie_fix_kernel writes this query's (D, I)
-            } else {
-                auto put = [&](int i, uint32_t key, uint32_t g) {
-                    const bool empty = key == SKEY_SENT && g == SPOS_NONE;
-                    int64_t id = -1;
-                    if (!empty) id = a.identity_ids ? (int64_t)g : a.store_pairs ? pair_of_gpos(a.list_off, nlist, g) : a.ids[g];
-                    a.D[(size_t)qi * k + i] = empty ? hneutral<IsMax>() : okey_inv<IsMax>(key);
-                    a.I[(size_t)qi * k + i] = id;
-                };
-                if (in0) put(lane, sreg.k0, sreg.g0);
-                if (in1) put(lane + 64, sreg.k1, sreg.g1);
-            }
-            if (lane == 0) a.done[qi] = 1;
-        } else {
-            if (in0) {
-                a.heap_val[(size_t)qi * k + lane] = okey_inv<IsMax>(sreg.k0);
-                a.heap_ref[(size_t)qi * k + lane] = sreg.g0 == SPOS_NONE ? -1 : (int64_t)sreg.g0;
-            }
-            if (in1) {
-                a.heap_val[(size_t)qi * k + lane + 64] = okey_inv<IsMax>(sreg.k1);
-                a.heap_ref[(size_t)qi * k + lane + 64] = sreg.g1 == SPOS_NONE ? -1 : (int64_t)sreg.g1;
-            }
-            if (lane == 0) a.amb[qi] = amb;
-        }
-        return;
-    }
     if (a.thr && lane == 0) a.thr[qi] = RH ? fkey_inv(rl_u(rh.v0, 1)) : hval[0];  // next round's scan stores only what beats this
     if (RH) rh_store(rh, hval, href, k, lane, true);  // back to the node-ordered LDS layout
     if (finished || a.finalize_all || err) {
@@ -1089,6 +998,500 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
     }
 }
 
+// =============================================================================================
+// select_sorted_kernel: the selection of the device-planned rounds (sorted register array + admission log, see SortedRegs)
+// =============================================================================================
+// One wave per query.  A query's rows of a round are one contiguous region (row starts on multiples of 1024 floats, rows in
+// probe order), so the candidates are read as one linear stream that runs ahead of the consumer across probe boundaries:
+//   dense round   blocks of 256 candidates, one 16-byte load per lane (lane l holds candidates 4l .. 4l+3 of the block), in
+//                 groups of four (rows start on multiples of 1024 floats) with the next group in flight; a block costs a min3,
+//                 a min and a compare unless something in it beats the worst of the k;
+//   masked round  the round's mask words (one per 64 candidates, written by the scan for what beats the round's threshold), 64
+//                 words per step with the next step's words in flight; the few marked chunks of a step are fetched together.
+// After every probe the stop rule is evaluated exactly as IndexIVF.cpp:551-638 does (tune mode); a probe that admitted
+// nothing costs a handful of scalar instructions.
+__host__ __device__ inline size_t select_wave_bytes(int k, bool tune, uint32_t trace_cap) {
+    size_t b = 0;
+    if (tune) b += (size_t)k * 4 + 16 * 4 + (size_t)trace_cap * 8 + CURNUM_PAR_MAXK * 15 * 4 + 8;  // srt | dwin | trace x,z | cur_num_par terms
+    return (b + 15) & ~(size_t)15;
+}
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <bool IsMax, bool MASKED, bool TUNE, int KC>
+__global__ __launch_bounds__(256) void select_sorted_kernel(ReplayArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr bool TWO = KC == 0 || KC > 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int k = KC ? KC : a.k;
+    const uint32_t nlist = a.nlist;
+    const uint32_t max_num = nlist / 8 + 20;
+    float* lut = reinterpret_cast<float*>(smem);
+    if (TUNE) {
+        for (int i = threadIdx.x; i < 500; i += 256) lut[i] = a.tuner.arcos[i];
+        __syncthreads();
+    }
+    const uint32_t li = blockIdx.x * 4 + wave;
+    if (li >= (a.nq_dev ? *a.nq_dev : a.nq)) return;
+    const uint32_t qi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.qsel ? a.qsel[li] : li));
+    if (a.done[qi]) return;
+
+    unsigned char* wbase = smem + (TUNE ? 2000 : 0) + (size_t)wave * select_wave_bytes(k, TUNE, a.trace_cap);
+    float* srt = reinterpret_cast<float*>(wbase);       // tune: the k values best first, as the rule reads them
+    float* dwin = srt + k;                              // 16 boundary distances of the current stage
+    float* trc = dwin + 16;                             // x | z of the cached trace, trace_cap each
+    float* terms = trc + 2 * a.trace_cap;               // cur_num_par scratch
+    const float* gdtb = TUNE ? a.dtb + (size_t)qi * max_num : nullptr;
+
+    // ---- state
+    SortedRegs sr{0xffffffffu, 0xffffffffu, SPOS_NONE, SPOS_NONE};
+    if (lane < k) {
+        sr.k0 = okey<IsMax>(a.heap_val[(size_t)qi * k + lane]);
+        sr.g0 = (uint32_t)a.heap_ref[(size_t)qi * k + lane];
+    }
+    if (TWO && lane + 64 < k) {
+        sr.k1 = okey<IsMax>(a.heap_val[(size_t)qi * k + lane + 64]);
+        sr.g1 = (uint32_t)a.heap_ref[(size_t)qi * k + lane + 64];
+    }
+    uint32_t amb = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.amb[qi]);
+    uint32_t logn = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.log_cnt[qi]);
+    uint2* const qlog = a.log + (size_t)qi * a.log_cap;
+    uint32_t log_v = 0, log_g = 0;
+    if ((uint32_t)lane < (logn & 63u)) {  // the open block of the log comes back into the staging registers
+        const uint2 e = qlog[(logn & ~63u) + lane];
+        log_v = e.x;
+        log_g = e.y;
+    }
+    auto worst_key = [&]() { return sr_key(sr, k - 1); };
+    float top = okey_inv<IsMax>(worst_key());  // the worst of the k: what a candidate has to beat
+    auto srt_from_regs = [&]() {
+        if (lane < k) srt[lane] = okey_inv<IsMax>(sr.k0);
+        if (TWO && lane + 64 < k) srt[lane + 64] = okey_inv<IsMax>(sr.k1);
+    };
+    if (TUNE) {
+        srt_from_regs();
+        wave_sync();
+    }
+
+    const unsigned long long id_q = a.id_offset + qi;
+    uint32_t err = 0;
+    const uint32_t ik0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.stage[qi]);
+    const uint32_t loop_end = a.limit ? a.limit[qi] : a.total_nprobe;
+    const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.seg_count[qi]);
+    const size_t seg0 = (size_t)a.seg_begin[qi];
+    unsigned long long nscan = a.nscan[qi];
+    float pre_val = a.pre_val[qi];
+    uint32_t stoped = a.stoped[qi];
+    unsigned long long st_nlist = 0, st_ndis = 0;
+    uint32_t st_nheap = 0;
+    const unsigned long long dbg_t0 = a.dbg ? __builtin_readcyclecounter() : 0;
+    unsigned long long dbg_rule = 0;
+    uint32_t dbg_evals = 0, dbg_chunks = 0;
+
+    // ---- stop-rule state (IndexIVF.cpp:551-638)
+    uint32_t query_k = 0;
+    float true_KD_K = 0.f, racc = 0.f;
+    unsigned long long np = 0;
+    int cached_ind = -1;
+    bool have_pre = false, top_changed = true, srt_changed = true;
+    uint32_t kept_pre = 0;
+    TraceLds tr{trc, trc + a.trace_cap, 0};
+    if (TUNE) {
+        query_k = a.tuner.query_topk;
+        if (a.tuner.gt_D) true_KD_K = a.tuner.gt_D[id_q * (unsigned long long)k + query_k - 1];
+        racc = a.tuner.require_acc[id_q];
+        np = a.tuner.my_nprobe[id_q];
+    }
+    const unsigned long long np_in = np;
+    const uint32_t nl8 = nlist / 8;
+    const bool overhead = TUNE && a.tuner.overhead != 0;  // IndexIVF.cpp:614,634-637
+    const float mult = TUNE ? a.tuner.multipler : 1.f;
+    const unsigned long long stops = (unsigned long long)(racc * 12);
+    float kept_recall = 0.f;
+
+    // ---- one admission (the candidate beats the worst of the k): IndexIVFFlat.cpp:125-135 on the sorted array
+    int ins_min = 128;       // best position taken during the current probe
+    auto admit = [&](float val, uint32_t gp) {
+        const uint32_t evicted = okey<IsMax>(top);  // (== the key of entry k - 1)
+        gp = (uint32_t)__builtin_amdgcn_readfirstlane((int)gp);
+        const int at = sr_insert<TWO>(sr, okey<IsMax>(val), gp, lane);
+        ins_min = at < ins_min ? at : ins_min;
+        if (logn >= a.log_cap) {
+            err = ERR_LOG_OVERFLOW;
+        } else {
+            wl2_u(log_v, (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(val)), log_g, gp,
+                  __builtin_amdgcn_readfirstlane((int)(logn & 63u)));
+            if ((logn & 63u) == 63u) qlog[(logn & ~63u) + lane] = make_uint2(log_v, log_g);
+            logn++;
+        }
+        st_nheap++;
+        // the entry that left was one of several equal worst values iff the new worst equals it (the new value is strictly better)
+        const uint32_t wk = worst_key();
+        if (wk == evicted && wk != SKEY_SENT) amb = wk;
+        top = okey_inv<IsMax>(wk);
+    };
+
+    // ---- probe table: a window of 64 probes, one per lane (list number, list length)
+    uint32_t win0 = 0;
+    int m_key = -1;
+    uint32_t m_n = 0, m_base = 0;  // list length, global position of the list's first vector
+    auto load_window = [&](uint32_t w0) {
+        win0 = w0;
+        m_key = -1;
+        m_n = 0;
+        m_base = 0;
+        const uint32_t pi = w0 + lane;
+        if (pi < cnt) {
+            m_key = a.seg_list[seg0 + pi];
+            if (m_key >= 0 && (uint32_t)m_key < nlist) {
+                const uint64_t o0 = a.list_off[m_key], o1 = a.list_off[m_key + 1];
+                m_n = (uint32_t)(o1 - o0);
+                m_base = a.identity_ids ? 0u : (uint32_t)o0;
+            }
+        }
+    };
+    load_window(0);
+    // the region of this query's rows: contiguous, every row padded to a multiple of 1024 floats
+    unsigned long long region_off = cnt ? a.seg_off[seg0] : 0ull;
+    region_off = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(region_off >> 32)) << 32) |
+                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)region_off);
+
+    // ---- the candidate stream
+    // dense: R0..R3 hold blocks bpos .. bpos + 3 (in ring order starting at `slot`)
+    const f4* region4 = reinterpret_cast<const f4*>(a.dist + region_off) + lane;  // block b: region4[b * 64]
+    f4 R0, R1, R2, R3;
+    uint32_t gpos = 0;  // group of four blocks held in R0..R3
+    // masked: W = the mask words of step `step` (word step * 64 + lane of the region), Wn = the next step's
+    const unsigned long long* rmask = MASKED ? a.mask + (region_off >> 6) + lane : nullptr;
+    const float* region1 = a.dist + region_off + lane;  // chunk c (64 candidates): region1[c * 64]
+    unsigned long long W = 0, Wn = 0;
+    uint32_t wstep = 0;           // words [wstep * 64, wstep * 64 + 64) are in W
+    if (!MASKED) {
+        R0 = __builtin_nontemporal_load(region4);
+        R1 = __builtin_nontemporal_load(region4 + 64);
+        R2 = __builtin_nontemporal_load(region4 + 128);
+        R3 = __builtin_nontemporal_load(region4 + 192);
+    } else {
+        W = __builtin_nontemporal_load(rmask);
+        Wn = __builtin_nontemporal_load(rmask + 64);
+    }
+    uint32_t wpos = 0;  // masked: first word of the current row (region word index)
+
+    // a block of 256 candidates (lane l: candidates 4l .. 4l + 3, the block's first is number c0 of its list) in which
+    // something may beat the worst of the k, or that holds the padding behind the row's end
+    auto dense_block = [&](const f4 x, uint32_t c0, uint32_t n, uint32_t lbase) {
+        const uint32_t valid = n > c0 ? n - c0 : 0u;  // candidates of the row in this block (>= 256: all)
+        const uint32_t p4 = 4u * lane;
+        const unsigned long long h0 = __ballot(hcmp<IsMax>(top, x.x) && p4 < valid);
+        const unsigned long long h1 = __ballot(hcmp<IsMax>(top, x.y) && p4 + 1 < valid);
+        const unsigned long long h2 = __ballot(hcmp<IsMax>(top, x.z) && p4 + 2 < valid);
+        const unsigned long long h3 = __ballot(hcmp<IsMax>(top, x.w) && p4 + 3 < valid);
+        unsigned long long any = h0 | h1 | h2 | h3;
+        while (any) {
+            const int l = __builtin_ctzll(any);
+            any &= any - 1;
+            const uint32_t g0 = lbase + c0 + 4u * (uint32_t)l;
+            // the lane's candidates in position order; one admission site
+            uint32_t nib = (uint32_t)((h0 >> l) & 1) | ((uint32_t)((h1 >> l) & 1) << 1) | ((uint32_t)((h2 >> l) & 1) << 2) |
+                           ((uint32_t)((h3 >> l) & 1) << 3);
+            const float v0 = rl_f(x.x, l), v1 = rl_f(x.y, l), v2 = rl_f(x.z, l), v3 = rl_f(x.w, l);
+            while (nib) {
+                const int sidx = __builtin_ctz(nib);
+                nib &= nib - 1;
+                const float val = sidx == 0 ? v0 : sidx == 1 ? v1 : sidx == 2 ? v2 : v3;
+                if (hcmp<IsMax>(top, val)) admit(val, g0 + (uint32_t)sidx);
+            }
+        }
+    };
+
+    bool finished = false;
+    uint32_t consumed = 0;
+    for (uint32_t p = 0; p < cnt && !finished; p++) {
+        const uint32_t ik = ik0 + p;
+        consumed = p + 1;
+        if (p >= win0 + 64) load_window(p);
+        const int key = rl_i(m_key, (int)(p - win0));
+        ins_min = 128;
+        const uint32_t nheap0 = st_nheap;
+        if (key >= 0) {
+            if ((uint32_t)key >= nlist) {
+                err = ERR_INVALID_KEY;
+                finished = true;
+                break;
+            }
+            const uint32_t n = rl_u(m_n, (int)(p - win0));
+            if (n > 0) {
+                st_nlist++;
+                const uint32_t lbase = rl_u(m_base, (int)(p - win0));
+                if (!MASKED) {
+                    // The row is a whole number of groups of four blocks (rows start on multiples of 1024 floats): R0..R3 hold the
+                    // current group, each register is refilled with its block of the next group (of the region: whatever row that is
+                    // in) as soon as it has been looked at.
+                    const uint32_t ngrp = (n + 1023u) >> 10;
+                    for (uint32_t g = 0; g < ngrp; g++) {
+                        const f4* nxt = region4 + (size_t)(gpos + 1) * 256;
+#define SEL_BLOCK(R, U)                                                                                                       \
+    {                                                                                                                         \
+        const f4 x = R;                                                                                                       \
+        R = __builtin_nontemporal_load(nxt + (U) * 64);                                                                       \
+        const float best = IsMax ? fminf(fminf(fminf(x.x, x.y), x.z), x.w) : fmaxf(fmaxf(fmaxf(x.x, x.y), x.z), x.w);         \
+        if (__ballot(hcmp<IsMax>(top, best)) != 0) dense_block(x, g * 1024u + (U) * 256u, n, lbase);                          \
+    }
+                        SEL_BLOCK(R0, 0)
+                        SEL_BLOCK(R1, 1)
+                        SEL_BLOCK(R2, 2)
+                        SEL_BLOCK(R3, 3)
+#undef SEL_BLOCK
+                        gpos++;
+                    }
+                } else {
+                    // words [wpos, wend) of the region are this row's chunks (the scan leaves no bit behind the row's end); the
+                    // words of the padding up to the next multiple of 256 candidates are never written and never read
+                    const uint32_t row_w0 = wpos, wend = wpos + ((n + 63u) >> 6);
+                    while (wpos < wend) {
+                        const uint32_t s0 = wstep * 64u;              // first word of the step in W
+                        if (wpos >= s0 + 64u) {                       // next step
+                            W = Wn;
+                            wstep++;
+                            Wn = __builtin_nontemporal_load(rmask + (size_t)(wstep + 1) * 64);
+                            continue;
+                        }
+                        // this row's words inside the step: lanes [wpos - s0, min(wend - s0, 64))
+                        const uint32_t lo = wpos - s0, hi = wend - s0 < 64u ? wend - s0 : 64u;
+                        unsigned long long nz = __ballot(W != 0ull);
+                        nz &= ~0ull << lo;
+                        if (hi < 64u) nz &= (1ull << hi) - 1ull;
+                        wpos = s0 + hi;
+                        // the marked chunks, four at a time: their values are requested together
+                        while (nz) {
+                            int c0 = -1, c1 = -1, c2 = -1, c3 = -1;
+                            float x0 = 0.f, x1 = 0.f, x2 = 0.f, x3 = 0.f;
+                            c0 = __builtin_ctzll(nz);
+                            nz &= nz - 1;
+                            x0 = __builtin_nontemporal_load(region1 + (size_t)(s0 + c0) * 64);
+                            if (nz) {
+                                c1 = __builtin_ctzll(nz);
+                                nz &= nz - 1;
+                                x1 = __builtin_nontemporal_load(region1 + (size_t)(s0 + c1) * 64);
+                            }
+                            if (nz) {
+                                c2 = __builtin_ctzll(nz);
+                                nz &= nz - 1;
+                                x2 = __builtin_nontemporal_load(region1 + (size_t)(s0 + c2) * 64);
+                            }
+                            if (nz) {
+                                c3 = __builtin_ctzll(nz);
+                                nz &= nz - 1;
+                                x3 = __builtin_nontemporal_load(region1 + (size_t)(s0 + c3) * 64);
+                            }
+                            auto chunk = [&](int c, float x) {
+                                if (c < 0) return;
+                                if (a.dbg) dbg_chunks++;
+                                const unsigned long long bits = ((unsigned long long)rl_u((uint32_t)(W >> 32), c) << 32) | rl_u((uint32_t)W, c);
+                                const uint32_t cb = (s0 + (uint32_t)c - row_w0) * 64u;  // position of the chunk's first candidate in its list
+                                unsigned long long m = __ballot(((bits >> lane) & 1) && hcmp<IsMax>(top, x));
+                                while (m) {
+                                    const int l = __builtin_ctzll(m);
+                                    m &= m - 1;
+                                    const float val = rl_f(x, l);
+                                    if (hcmp<IsMax>(top, val)) admit(val, lbase + cb + (uint32_t)l);
+                                }
+                            };
+                            chunk(c0, x0);
+                            chunk(c1, x1);
+                            chunk(c2, x2);
+                            chunk(c3, x3);
+                        }
+                    }
+                    wpos = row_w0 + (((n + 1023u) >> 10) << 4);
+                }
+                nscan += n;
+                st_ndis += n;
+            }
+        }
+        if (TUNE && st_nheap != nheap0) {
+            wave_sync();
+            srt_from_regs();
+            wave_sync();
+            srt_changed = true;
+            if (ins_min < (int)query_k) top_changed = true;
+        }
+        if (a.max_codes && nscan >= a.max_codes) {
+            finished = true;
+            break;
+        }
+        if (loop_end && ik + 1 >= loop_end) finished = true;  // end of the probe loop
+        if (TUNE) {
+            const unsigned long long dbg_r0 = a.dbg ? __builtin_readcyclecounter() : 0;
+            // IndexIVF.cpp:551-638.  Once my_nprobe is known nothing the rule computes can change the outcome any more (L2: no
+            // throwing path left), so only the stop test remains.
+            const uint32_t stage = ik + 1;
+            const bool fired = IsMax && np != 0 && !overhead;
+            if (!fired) {
+                const uint32_t tmp_stage = stage >= nl8 ? nl8 - 1 : stage;
+                const uint32_t ind = tmp_stage <= 1u ? 0u : 32u - (uint32_t)__builtin_clz(tmp_stage - 1u);  // smallest ind with tmp_stage <= 2^ind
+                if ((int)ind != cached_ind) {
+                    const uint32_t o = a.tuner.trace_off[ind], tn = a.tuner.trace_off[ind + 1] - o;
+                    const float sc = a.tuner.std_m;
+                    wave_sync();
+                    for (uint32_t i = lane; i < tn; i += 64) {
+                        trc[i] = a.tuner.trace_x[o + i];
+                        trc[a.trace_cap + i] = a.tuner.trace_y[o + i] + sc * a.tuner.trace_std[o + i];
+                    }
+                    if (lane < 15) dwin[lane] = gdtb[(1u << ind) - 1 + lane];  // sum_angle start = 2^ind - 1
+                    tr.n = tn;
+                    cached_ind = (int)ind;
+                    have_pre = false;
+                    wave_sync();
+                }
+                if (!IsMax && srt_changed) {
+                    // the reference converts all k heap values (IndexIVF.cpp:562-564): any out-of-domain one throws
+                    for (int i = lane; i < k; i += 64) (void)arcos_lut(lut, srt[i], &err);
+                    err = wave_err(err);
+                    if (err) {
+                        finished = true;
+                        break;
+                    }
+                }
+                srt_changed = false;
+                if (!have_pre || top_changed) {
+                    dbg_evals++;
+                    kept_pre = query_k <= CURNUM_PAR_MAXK ? cur_num_par<IsMax>(tr, lut, srt, dwin, terms, query_k, lane, &err)
+                                                          : cur_num_lds<IsMax>(tr, lut, srt, dwin, query_k, lane, &err);
+                    have_pre = true;
+                    top_changed = false;
+                    err = wave_err(err);
+                    if (err) finished = true;
+                    kept_recall = (float)kept_pre / (float)query_k;
+                }
+                float recall = kept_recall;
+                const float max_val = IsMax ? fmaxf(-1.f, top) : fminf(FLT_MAX, top);  // (top == srt[k - 1])
+                if (stage > 1) {
+                    if (max_val == pre_val) stoped++;
+                    else stoped = 0;
+                    if (stoped >= stops) recall = 1;
+                }
+                pre_val = max_val;
+                if (!overhead) {
+                    if (recall >= racc && np == 0) {
+                        np = (unsigned long long)((float)stage * mult);
+                        if (np >= nlist && lane == 0) a.tuner.t_recalls[id_q] = 1.f;
+                    }
+                    if (stage >= nl8 && np == 0) {
+                        np = (unsigned long long)((float)stage * mult);
+                        if (np >= nlist && lane == 0) a.tuner.t_recalls[id_q] = 1.f;
+                    }
+                }
+            }
+            if (overhead) {
+                if (stage >= nl8) finished = true;
+            } else if (np != 0 && np <= stage) {
+                if (a.tuner.profile) {
+                    uint32_t hits = 0;
+                    for (int i = lane; i < k; i += 64) {
+                        const float s = srt[i];
+                        if (IsMax ? ((double)s <= (double)true_KD_K * 1.0005) : ((double)s >= (double)true_KD_K * 0.9995)) hits++;
+                    }
+                    for (int off = 32; off; off >>= 1) hits += __shfl_xor(hits, off);
+                    if (lane == 0) a.tuner.t_recalls[id_q] = (float)hits / (float)query_k;
+                }
+                finished = true;
+            }
+            if (a.dbg) dbg_rule += __builtin_readcyclecounter() - dbg_r0;
+        }
+    }
+    err = wave_err(err);
+
+    if (lane == 0) {
+        a.stage[qi] = ik0 + consumed;
+        a.nscan[qi] = nscan;
+        a.pre_val[qi] = pre_val;
+        a.stoped[qi] = stoped;
+        if (TUNE && np != np_in) a.tuner.my_nprobe[id_q] = np;
+        if (st_nlist) atomicAdd(&a.stats[0], st_nlist);
+        if (st_ndis) atomicAdd(&a.stats[1], st_ndis);
+        if (st_nheap) atomicAdd(&a.stats[2], (unsigned long long)st_nheap);
+        if (err) atomicMax(a.error, err);
+        if (a.dbg) {
+            a.dbg[(size_t)li * 8 + 0] = __builtin_readcyclecounter() - dbg_t0;
+            a.dbg[(size_t)li * 8 + 1] = st_nheap;
+            a.dbg[(size_t)li * 8 + 2] = st_ndis;
+            a.dbg[(size_t)li * 8 + 3] = dbg_evals;
+            a.dbg[(size_t)li * 8 + 4] = 0;
+            a.dbg[(size_t)li * 8 + 5] = dbg_rule;
+            a.dbg[(size_t)li * 8 + 6] = dbg_chunks;
+            a.dbg[(size_t)li * 8 + 7] = consumed;
+        }
+        if (a.thr) a.thr[qi] = top;  // next round's scan stores only what beats this
+        a.log_cnt[qi] = logn;
+        a.log_snap[(size_t)(a.round & 1u) * a.nq_total + qi] = logn;
+        if (finished || a.finalize_all || err) a.fin_round[qi] = a.round;
+    }
+    // the open block of the admission log
+    if ((uint32_t)lane < (logn & 63u)) qlog[(logn & ~63u) + lane] = make_uint2(log_v, log_g);
+    const bool in0 = lane < k, in1 = TWO && lane + 64 < k;
+    if (finished || a.finalize_all || err) {
+        // equal values among the k (their order is the heap's), or a value of which a copy was evicted while this one stayed
+        const uint32_t p0 = wave_shr1(sr.k0, 0xfffffffeu), p1 = TWO ? wave_shr1(sr.k1, rl_u(sr.k0, 63)) : 0u;
+        const bool dup = (in0 && lane >= 1 && sr.k0 == p0 && sr.k0 != SKEY_SENT) || (in1 && sr.k1 == p1 && sr.k1 != SKEY_SENT);
+        const bool tainted = __ballot(dup) != 0 || worst_key() == amb;
+        if (tainted && !err) {
+            if (lane == 0) a.tie_flag[qi] = 1;  // tie_fix_kernel writes this query's (D, I)
+        } else {
+            auto put = [&](int i, uint32_t key, uint32_t g) {
+                const bool empty = key == SKEY_SENT && g == SPOS_NONE;
+                int64_t id = -1;
+                if (!empty) id = a.identity_ids ? (int64_t)g : a.store_pairs ? pair_of_gpos(a.list_off, nlist, g) : a.ids[g];
+                a.D[(size_t)qi * k + i] = empty ? hneutral<IsMax>() : okey_inv<IsMax>(key);
+                a.I[(size_t)qi * k + i] = id;
+            };
+            if (in0) put(lane, sr.k0, sr.g0);
+            if (in1) put(lane + 64, sr.k1, sr.g1);
+        }
+        if (lane == 0) a.done[qi] = 1;
+    } else {
+        if (in0) {
+            a.heap_val[(size_t)qi * k + lane] = okey_inv<IsMax>(sr.k0);
+            a.heap_ref[(size_t)qi * k + lane] = sr.g0 == SPOS_NONE ? -1 : (int64_t)sr.g0;
+        }
+        if (in1) {
+            a.heap_val[(size_t)qi * k + lane + 64] = okey_inv<IsMax>(sr.k1);
+            a.heap_ref[(size_t)qi * k + lane + 64] = sr.g1 == SPOS_NONE ? -1 : (int64_t)sr.g1;
+        }
+        if (lane == 0) a.amb[qi] = amb;
+    }
+}
+
+void launch_select_sorted(const ReplayArgs& a, hipStream_t s) {
+    if (a.nq == 0) return;
+    const bool tune = a.tuner.enabled != 0;
+    const size_t shmem = (tune ? 2000 : 0) + 4 * select_wave_bytes(a.k, tune, a.trace_cap);
+    if (shmem > 160 * 1024) throw std::runtime_error("selection kernel: trace cache beyond LDS");
+    const dim3 grid((a.nq + 3) / 4), block(256);
+    auto go = [&](auto kern) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) throw std::runtime_error(std::string("selection kernel: cannot reserve LDS: ") + hipGetErrorString(e));
+        LAUNCH(kern, grid, block, shmem, s, a);
+    };
+    auto pick_k = [&](auto is_max, auto masked, auto tn) {
+        constexpr bool M = decltype(is_max)::value, MK = decltype(masked)::value, T = decltype(tn)::value;
+        if (a.k == 100) return go(select_sorted_kernel<M, MK, T, 100>);
+        if (a.k == 10) return go(select_sorted_kernel<M, MK, T, 10>);
+        return go(select_sorted_kernel<M, MK, T, 0>);
+    };
+    auto pick_t = [&](auto is_max, auto masked) {
+        if (tune) pick_k(is_max, masked, std::true_type{});
+        else pick_k(is_max, masked, std::false_type{});
+    };
+    auto pick_m = [&](auto is_max) {
+        if (a.mask) pick_t(is_max, std::true_type{});
+        else pick_t(is_max, std::false_type{});
+    };
+    if (a.metric == METRIC_L2) pick_m(std::true_type{});
+    else pick_m(std::false_type{});
+}
+
 // the sorted-array selection applies when positions fit 32 bits (the caller checks ntotal) and the result is the
 // reordered one; the heap kernels remain for the scanner API (raw heap out), trace training, k > 128 and on request
 bool replay_sorted_applies(const ReplayArgs& a) {
@@ -1103,7 +1506,10 @@ void launch_replay(const ReplayArgs& a, hipStream_t s) {
     const size_t shmem = (geo ? 2000 : 0) + 4 * replay_wave_bytes(a.k, a.nlist, geo, tune, train, a.trace_cap);
     const dim3 grid((a.nq + 3) / 4), block(256);
     static const bool no_rh = getenv("AUNCEL_AMD_LDS_HEAP") != nullptr;
-    const bool sorted = replay_sorted_applies(a);
+    if (replay_sorted_applies(a)) {
+        launch_select_sorted(a, s);
+        return;
+    }
     const bool rh = a.k <= 127 && !no_rh;
     // the heap (LDS form) and its sorted view take 16 k bytes per query, four queries per workgroup, of the CU's 160 KiB
     if (shmem > 160 * 1024)
@@ -1120,46 +1526,52 @@ void launch_replay(const ReplayArgs& a, hipStream_t s) {
     const bool wide = nld_env ? nld_env >= 32 : (a.nq_hint ? a.nq_hint : a.nq) <= 3072;
     auto pick = [&](auto is_max) {
         constexpr bool M = decltype(is_max)::value;
-        if (sorted) {
-            if (a.k == 100) return wide ? go(replay_kernel<M, 2, 32, 100>) : go(replay_kernel<M, 2, 16, 100>);
-            if (a.k == 10) return wide ? go(replay_kernel<M, 2, 32, 10>) : go(replay_kernel<M, 2, 16, 10>);
-            return wide ? go(replay_kernel<M, 2, 32, 0>) : go(replay_kernel<M, 2, 16, 0>);
-        }
-        if (!rh) return wide ? go(replay_kernel<M, 0, 32, 0>) : go(replay_kernel<M, 0, 16, 0>);
-        if (a.k == 100) return wide ? go(replay_kernel<M, 1, 32, 100>) : go(replay_kernel<M, 1, 16, 100>);
-        if (a.k == 10) return wide ? go(replay_kernel<M, 1, 32, 10>) : go(replay_kernel<M, 1, 16, 10>);
-        return wide ? go(replay_kernel<M, 1, 32, 0>) : go(replay_kernel<M, 1, 16, 0>);
+        if (!rh) return wide ? go(replay_kernel<M, false, 32, 0>) : go(replay_kernel<M, false, 16, 0>);
+        if (a.k == 100) return wide ? go(replay_kernel<M, true, 32, 100>) : go(replay_kernel<M, true, 16, 100>);
+        if (a.k == 10) return wide ? go(replay_kernel<M, true, 32, 10>) : go(replay_kernel<M, true, 16, 10>);
+        return wide ? go(replay_kernel<M, true, 32, 0>) : go(replay_kernel<M, true, 16, 0>);
     };
     if (a.metric == METRIC_L2) pick(std::true_type{});
     else pick(std::false_type{});
 }
 
 // ---------------------------------------------------------------------------------------------
-// Queries the sorted-array selection flagged (equal values met): the reference's heap (Heap.h:88-142), replayed over the
-// query's admission log -- every entry was admitted, in this order, so each is one heap_pop + heap_push -- then
-// heap_reorder (Heap.h:295-322).  One wave per flagged query; the others leave at once.
+// The reference's heap (Heap.h:88-142), replayed over the admission logs: every log entry was admitted, in this order, so
+// each is one heap_pop + heap_push.  Launched behind every selection round, on a side stream, so that it runs under the next
+// round's scan and selection:
+//   a query still searching          the entries the round added are replayed and the heap (node order) is saved;
+//   a query that finished this round if the selection flagged it (equal values met: the only case in which the heap's history
+//                                    decides an id or an output order), the rest of its log is replayed, then heap_reorder
+//                                    (Heap.h:295-322) gives its (D, I); the others' results are the sorted arrays already.
+// One wave per query; what is left for the end of the search is the last round's handful of entries.
 template <bool IsMax, bool RH, int KC>
 __global__ __launch_bounds__(256) void tie_fix_kernel(TieFixArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t qi = blockIdx.x * 4 + wave;
-    if (qi >= a.nq || !a.tie_flag[qi]) return;
+    if (qi >= a.nq) return;
+    const uint32_t fin_r = a.fin_round[qi];
+    if (fin_r < a.round) return;                        // finished in an earlier round: dealt with then
+    const bool fin = fin_r == a.round;
+    if (fin && a.tie_flag[qi] != 1) return;             // finished now, and its sorted array is the result
+    const uint32_t pos = a.fix_pos[qi];
+    const uint32_t n = a.log_snap[(size_t)(a.round & 1u) * a.nq + qi];
+    if (!fin && n <= pos) return;                       // nothing new to replay
     const int k = KC ? KC : a.k;
     unsigned char* base = smem + (size_t)wave * (((size_t)k * 12 + 15) & ~(size_t)15);
     int64_t* href = reinterpret_cast<int64_t*>(base);
     float* hval = reinterpret_cast<float*>(base + (size_t)k * 8);
     for (int i = lane; i < k; i += 64) {
-        hval[i] = hneutral<IsMax>();
-        href[i] = -1;
+        hval[i] = a.fix_val[(size_t)qi * k + i];
+        href[i] = a.fix_ref[(size_t)qi * k + i];
     }
     wave_sync();
     RegHeap rh{};
     if (RH) rh_load(rh, hval, k, lane);
     const uint2* qlog = a.log + (size_t)qi * a.log_cap;
-    const uint32_t n = a.log_cnt[qi];
-    uint2 e = (uint32_t)lane < n ? qlog[lane] : make_uint2(0u, 0u);
-    for (uint32_t b = 0; b < n; b += 64) {
+    uint2 e = pos + lane < n ? qlog[pos + lane] : make_uint2(0u, 0u);
+    for (uint32_t b = pos; b < n; b += 64) {
         const uint2 cur = e;
         if (b + 64 + lane < n) e = qlog[b + 64 + lane];
         const uint32_t cnt = n - b < 64u ? n - b : 64u;
@@ -1181,6 +1593,14 @@ __global__ __launch_bounds__(256) void tie_fix_kernel(TieFixArgs a) {
     }
     wave_sync();
     if (RH) rh_store(rh, hval, href, k, lane, true);
+    if (!fin) {
+        for (int i = lane; i < k; i += 64) {
+            a.fix_val[(size_t)qi * k + i] = hval[i];
+            a.fix_ref[(size_t)qi * k + i] = href[i];
+        }
+        if (lane == 0) a.fix_pos[qi] = n;
+        return;
+    }
     int ii = 0;
     for (int i = 0; i < k; i++) {
         const float v = hval[0];

@@ -137,6 +137,15 @@ int amd_ivf_search_adaptive_x(amd_ivf_t* h, size_t n, const float* x, size_t id_
                               float std_m, const float* require_acc, const float* gt_D, int profile, int coarse_mode,
                               uint64_t* my_nprobe, float* t_recalls, float* D, int64_t* I);
 
+/* IndexIVF::search_preassigned with tune on, over the coarse ranking the CALLER passes (Auncel/IndexIVF.cpp:382-386: keys and
+ * coarse_dis are arguments there; Error_sys::search gets them from its quantizer with nprobe = nlist, profile.cpp:220): rows of
+ * nprobe entries per query, best first.  The probe loop has nprobe steps and set_online reads entries 0 .. nlist/8 + 20, so
+ * nprobe must exceed nlist/8 + 20 (else -2).  Everything else as amd_ivf_search_adaptive_x.  This is what a subclass overriding
+ * search_preassigned uses when the order of the reference's own quantizer (its BLAS, its tie order) has to be kept. */
+int amd_ivf_search_adaptive_pre(amd_ivf_t* h, size_t n, const float* x, size_t id_offset, size_t nprobe, const int64_t* keys,
+                                const float* coarse_dis, size_t query_topk, float multipler, float std_m, const float* require_acc,
+                                const float* gt_D, int profile, uint64_t* my_nprobe, float* t_recalls, float* D, int64_t* I);
+
 /* Time-bounded search: Error_sys::time_search (profile.cpp:229-244) = IndexIVF::search with tune off, nprobe = nlist and
  * error_pro::time_tune on: the plain probe loop (nprobe probes; time_search sets nprobe = nlist) over resident queries [start, start+n), heap of k, left when the
  * query's budget is used up.  budget_ms is indexed by absolute query id (the reference keeps the budgets in
@@ -159,6 +168,12 @@ int amd_ivf_train_samples(amd_ivf_t* h, size_t start, size_t n, size_t max_topk,
 
 int amd_ivf_train_samples_x(amd_ivf_t* h, size_t n, const float* x, size_t id_offset, size_t max_topk, const float* gt_D,
                             size_t train_num, int coarse_mode, float* const* raw, float* D, int64_t* I);
+
+/* the training branch over the caller's coarse ranking (search_preassigned with training on and its keys / coarse_dis
+ * arguments, IndexIVF.cpp:382-386,640-673); nprobe > nlist/8 + 20 */
+int amd_ivf_train_samples_pre(amd_ivf_t* h, size_t n, const float* x, size_t id_offset, size_t nprobe, const int64_t* keys,
+                              const float* coarse_dis, size_t max_topk, const float* gt_D, size_t train_num, float* const* raw,
+                              float* D, int64_t* I);
 
 /* error_pro::construct_arcos: the 500-entry acos LUT, computed with the host libm exactly as the
  * reference does (LUT[i] = acosf((i-250)/250.f))  [IVF_pro.cpp:151-160] */

@@ -200,6 +200,30 @@ static int run_fixed(const tb::Bundle& in) {
                 expect(same_f(D.data(), in.get("D_shards_k" + std::to_string(k)).as<float>(), nq * k), "shards distances" + tag);
             }
         }
+        // IndexShards::add from one host thread per shard while the shards share one quantizer (IndexFlat::search is
+        // re-entrant in the reference): the same lists as the serial add, shard by shard
+        {
+            std::vector<std::unique_ptr<IndexIVFFlat>> ser, par;
+            IndexShards s_ser((idx_t)d, false, false), s_par((idx_t)d, true, false);
+            for (size_t s = 0; s < nshard; s++) {
+                ser.emplace_back(new IndexIVFFlat(ix->quantizer, d, nlist, mt));
+                par.emplace_back(new IndexIVFFlat(ix->quantizer, d, nlist, mt));
+                ser.back()->coarse_mode = par.back()->coarse_mode = 0;
+                s_ser.add_shard(ser.back().get());
+                s_par.add_shard(par.back().get());
+            }
+            s_ser.add((idx_t)nb, xb.as<float>());
+            s_par.add((idx_t)nb, xb.as<float>());
+            bool same = s_ser.ntotal == s_par.ntotal;
+            for (size_t s = 0; s < nshard && same; s++)
+                for (size_t l = 0; l < nlist && same; l++) {
+                    const size_t n0 = ser[s]->invlists->list_size(l);
+                    same = n0 == par[s]->invlists->list_size(l) &&
+                           (n0 == 0 || (memcmp(ser[s]->invlists->get_ids(l), par[s]->invlists->get_ids(l), n0 * sizeof(idx_t)) == 0 &&
+                                        memcmp(ser[s]->invlists->get_codes(l), par[s]->invlists->get_codes(l), n0 * d * sizeof(float)) == 0));
+                }
+            expect(same, "threaded IndexShards::add with a shared quantizer == serial add");
+        }
     }
     return g_fail;
 }

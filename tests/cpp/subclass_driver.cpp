@@ -10,6 +10,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <new>
 #include <random>
 
 #include "Auncel/IVF_pro.h"
@@ -171,6 +172,89 @@ int main(int argc, char** argv) {
             expect(np, what);
             if (prof) expect(tr, "                                               t_recalls");
         }
+    // ---- the whole batch in one call (the reference ranks it through sgemm): with device_coarse off the subclass searches over
+    // the keys / coarse_dis its caller passes, i.e. the reference's own ranking, and must return the reference's result
+    {
+        amd.device_coarse = false;
+        std::vector<float> req(nq, 0.9f);
+        std::vector<float> D1(ses * K), D2(ses * K);
+        std::vector<idx_t> I1(ses * K), I2(ses * K);
+        Error_sys* es[2] = {&es1, &es2};
+        IndexIVF* ix[2] = {&ref, &amd};
+        for (int w = 0; w < 2; w++) {
+            es[w]->set_topk(10);
+            es[w]->set_queries(ses, xq.data(), req.data(), ts + ses);
+            ix[w]->t->multipler = 1.5f;
+            ix[w]->t->std_m = 1.0f;
+            ix[w]->t->profile = false;
+            es[w]->search(w ? D2.data() : D1.data(), w ? I2.data() : I1.data(), ts, ses);
+        }
+        bool np = true;
+        for (size_t i = ts; i < ts + ses; i++) np = np && ref.t->my_nprobe[i] == amd.t->my_nprobe[i];
+        expect(same(D1, D2) && same(I1, I2) && np, "Error_sys::search, the batch in one call, caller's coarse ranking: D, I, my_nprobe");
+        amd.device_coarse = true;
+    }
+
+    // ---- traces retrained in place (same storage, same bin counts): the device copy has to follow
+    {
+        for (IndexIVF* ix : std::initializer_list<IndexIVF*>{&ref, &amd})
+            for (Trace& tr : ix->t->traces)
+                for (auto& pt : tr.trace) pt.second *= 1.25f;
+        std::vector<float> req(nq, 0.9f);
+        std::vector<float> D1(ses * K), D2(ses * K);
+        std::vector<idx_t> I1(ses * K), I2(ses * K);
+        Error_sys* es[2] = {&es1, &es2};
+        for (int w = 0; w < 2; w++) {
+            es[w]->set_topk(10);
+            es[w]->set_queries(ses, xq.data(), req.data(), ts + ses);
+            for (size_t i = ts; i < ts + ses; i++) es[w]->search((w ? D2.data() : D1.data()) + (i - ts) * K, (w ? I2.data() : I1.data()) + (i - ts) * K, i, 1);
+        }
+        bool np = true;
+        for (size_t i = ts; i < ts + ses; i++) np = np && ref.t->my_nprobe[i] == amd.t->my_nprobe[i];
+        expect(same(D1, D2) && same(I1, I2) && np, "Error_sys::search after the traces changed in place");
+    }
+
+    // ---- add after a search: the device lists follow
+    {
+        ref.set_tune_off();
+        amd.set_tune_off();
+        std::vector<float> extra(2000 * d);
+        draw(extra, 2000);
+        ref.add(2000, extra.data());
+        amd.add(2000, extra.data());
+        ref.nprobe = amd.nprobe = 8;
+        std::vector<float> D1(nq * 10), D2(nq * 10);
+        std::vector<idx_t> I1(nq * 10), I2(nq * 10);
+        ref.search(nq, xq.data(), 10, D1.data(), I1.data());
+        amd.search(nq, xq.data(), 10, D2.data(), I2.data());
+        expect(same(D1, D2) && same(I1, I2), "search after an add that followed a search");
+    }
+
+    // ---- an index destroyed and another one constructed at the same address (and searched from the same thread): the second
+    // must not see anything of the first (search contexts are owned by the index, not keyed by its address)
+    {
+        alignas(AmdIndexIVFFlat) static unsigned char spot[sizeof(AmdIndexIVFFlat)];
+        const size_t part[2] = {nb / 3, nb / 2};
+        for (int round = 0; round < 2; round++) {
+            IndexFlat qr(d, METRIC_L2), qg(d, METRIC_L2);
+            qr.add(nlist, q1.xb.data());
+            qg.add(nlist, q1.xb.data());
+            IndexIVFFlat cpu(&qr, d, nlist, METRIC_L2);
+            AmdIndexIVFFlat* gpu = new (spot) AmdIndexIVFFlat(&qg, d, nlist, METRIC_L2, 0);
+            for (IndexIVF* ix : std::initializer_list<IndexIVF*>{&cpu, gpu}) {
+                ix->is_trained = true;
+                ix->init_tune(0, 1, nullptr, nullptr, nullptr, nullptr, nullptr);
+                ix->nprobe = 8;
+                ix->add(part[round], xb.data() + (round ? 1000 * d : 0));
+            }
+            std::vector<float> D1(nq * 10), D2(nq * 10);
+            std::vector<idx_t> I1(nq * 10), I2(nq * 10);
+            cpu.search(nq, xq.data(), 10, D1.data(), I1.data());
+            gpu->search(nq, xq.data(), 10, D2.data(), I2.data());
+            expect(same(D1, D2) && same(I1, I2), round ? "a second index constructed where a destroyed one was" : "an index in static storage");
+            gpu->~AmdIndexIVFFlat();
+        }
+    }
     std::printf(bad ? "SUBCLASS PARITY FAILED (%d)\n" : "SUBCLASS PARITY OK\n", bad);
     return bad ? 1 : 0;
 }

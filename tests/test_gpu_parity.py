@@ -508,3 +508,50 @@ def test_selection_log_overflow_falls_back_to_the_heap(capi, oracle):
     assert np.array_equal(bits(D), bits(eD))
     st = h.stats()
     assert [st["nlist"], st["ndis"], st["nheap_updates"]] == list(est)
+
+
+@pytest.mark.parametrize("name", AUNCEL)
+def test_adaptive_search_over_the_callers_coarse_ranking(capi, name):
+    """IndexIVF::search_preassigned in tune mode with the keys / coarse_dis the caller passes (Auncel/IndexIVF.cpp:382-386): the
+    reference's own per-query rankings go in, its (D, I, my_nprobe, t_recalls) must come out"""
+    case, gold = load_case(name)
+    K, ts, ses = case["max_topk"], case["train_num"], case["test_num"]
+    h = make_index(capi, case, gold, gold["centroids"])
+    h.set_interdis(None)
+    h.set_tuner(K, traces_from_gold(gold), gold["arcos_list"])
+    keys, cd = gold["coarse_keys_sse"][ts:], gold["coarse_dis_sse"][ts:]
+    for r in range(len(case["topks"])):
+        for prof in (False, True):
+            req = np.full(ts + ses, case["require_acc"][r], dtype=np.float32)
+            my_np = np.zeros(ts + ses, dtype=np.uint64)
+            t_rec = np.zeros(ts + ses, dtype=np.float32)
+            D, I = h.search_adaptive_pre(case["xq"][ts:], ts, keys, cd, int(case["topks"][r]), float(case["multipler"][r]),
+                                         float(case["std_m"][r]), req, my_np, t_rec, gt_D=gold["gtD"], profile=prof)
+            suf = f"_r{r}" + ("_prof" if prof else "")
+            assert np.array_equal(my_np[ts:], gold["my_nprobe" + suf]), suf
+            assert np.array_equal(I, gold["I" + suf]), suf
+            assert np.array_equal(bits(D), bits(gold["D" + suf])), suf
+            assert np.array_equal(bits(t_rec[ts:]), bits(gold["t_recalls" + suf])), suf
+    # a ranking too short for set_online (entries 0 .. nlist/8 + 20) is refused like the reference's precondition
+    short = case["nlist"] // 8 + 20
+    with pytest.raises(capi.EngineError) as e:
+        h.search_adaptive_pre(case["xq"][ts:], ts, keys[:, :short], cd[:, :short], int(case["topks"][0]), 1.0, 1.0,
+                              np.full(ts + ses, 0.9, np.float32), np.zeros(ts + ses, np.uint64), np.zeros(ts + ses, np.float32))
+    assert e.value.code == -2
+
+
+@pytest.mark.parametrize("name", AUNCEL)
+def test_training_over_the_references_blas_ranking(capi, name):
+    """Error_sys::sys_train ranks its training batch through vendor BLAS (unpinned rounding); handed that very ranking
+    (search_preassigned's keys / coarse_dis arguments), the training branch must write the reference's raw traces bit for bit"""
+    case, gold = load_case(name)
+    if "coarse_keys_blas_train" not in gold:
+        pytest.skip("golden without the training batch's ranking")
+    K, ts = case["max_topk"], case["train_num"]
+    h = make_index(capi, case, gold, gold["centroids"])
+    h.set_interdis(None)
+    ntr = len(traces_from_gold(gold))
+    raw = [np.full((ts * (K // 4), 2), -1, dtype=np.float32) for _ in range(ntr)]
+    h.train_samples_pre(case["xq"][:ts], 0, gold["coarse_keys_blas_train"], gold["coarse_dis_blas_train"], K, gold["gtD"], ts, raw)
+    for i in range(ntr):
+        assert np.array_equal(bits(raw[i]), bits(gold[f"raw_trace{i}"])), i

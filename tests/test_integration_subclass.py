@@ -18,7 +18,7 @@ int main() {
     faiss::IndexFlatL2 quantizer(8);
     faiss::AmdIndexIVFFlat index(&quantizer, 8, 4, faiss::METRIC_L2, 0);
     faiss::IndexIVF* base = &index;  // the reference's callers hold IndexIVF*: the override is reached through the vtable
-    std::printf("%zu %d\n", base->nlist, (int)index.lists_stale);
+    std::printf("%zu %d\n", base->nlist, (int)index.device_coarse);
     return 0;
 }
 """
