@@ -20,11 +20,11 @@ SYMBOLS = [
     "amd_ivf_last_error", "amd_ivf_device_count", "amd_ivf_create", "amd_ivf_clone", "amd_ivf_destroy", "amd_ivf_set_centroids",
     "amd_ivf_set_lists", "amd_ivf_add", "amd_ivf_ntotal", "amd_ivf_list_size", "amd_ivf_get_list", "amd_ivf_coarse",
     "amd_ivf_search_preassigned", "amd_ivf_search", "amd_ivf_scan_codes", "amd_ivf_distance_to_code", "amd_ivf_stats",
-    "amd_ivf_set_queries", "amd_ivf_search_resident", "amd_ivf_set_interdis", "amd_ivf_get_interdis",
+    "amd_ivf_set_queries", "amd_ivf_search_resident", "amd_ivf_search_resident_preassigned", "amd_ivf_coarse_resident", "amd_ivf_set_interdis", "amd_ivf_get_interdis",
     "amd_ivf_set_tuner", "amd_ivf_search_adaptive", "amd_ivf_search_adaptive_x", "amd_ivf_search_adaptive_pre", "amd_ivf_search_timed", "amd_ivf_search_timed_x",
     "amd_ivf_train_samples",
     "amd_ivf_train_samples_x", "amd_ivf_train_samples_pre", "amd_ivf_trace_sb", "amd_ivf_arcos_table", "amd_ivf_merge_tables",
-    "amd_ivf_last_timing", "amd_ivf_last_scan_min_bytes", "amd_ivf_coarse_tie_rows", "amd_ivf_last_tie_fixed", "amd_ivf_set_byte_codes",
+    "amd_ivf_last_timing", "amd_ivf_last_scan_min_bytes", "amd_ivf_coarse_tie_rows", "amd_ivf_last_tie_fixed", "amd_ivf_last_round_hints", "amd_ivf_set_byte_codes",
     "amd_ivf_kmeans",
     "amd_ivf_range_search_preassigned", "amd_ivf_range_search", "amd_ivf_range_results",
     "amd_ivf_scan_arith",
@@ -430,6 +430,32 @@ class Handle:
         v = C.c_uint64(0)
         _chk(lib().amd_ivf_coarse_tie_rows(self._h, C.byref(v)))
         return int(v.value)
+
+    def coarse_resident(self, start, n, nprobe, mode=0, want_dis=True):
+        """the coarse ranking of resident queries [start, start + n) -> (coarse_dis or None, keys)"""
+        keys = np.empty((n, nprobe), np.int64)
+        dis = np.empty((n, nprobe), np.float32) if want_dis else None
+        _chk(lib().amd_ivf_coarse_resident(self._h, C.c_size_t(start), C.c_size_t(n), C.c_size_t(nprobe), _f(dis), _i(keys), mode))
+        return dis, keys
+
+    def search_resident_preassigned(self, start, n, k, keys, out=None):
+        """search_preassigned over resident queries [start, start + n) with the caller's keys (n x nprobe)"""
+        keys = i64(keys)
+        assert keys.shape[0] == n
+        if out is not None:
+            D, I = out
+        else:
+            D = np.empty((n, k), np.float32)
+            I = np.empty((n, k), np.int64)
+        _chk(lib().amd_ivf_search_resident_preassigned(self._h, C.c_size_t(start), C.c_size_t(n), C.c_size_t(k), C.c_size_t(keys.shape[1]),
+                                                       _i(keys), _f(D), _i(I)))
+        return D, I
+
+    def last_round_hints(self):
+        """(scan launches of the last search sized from the previous search's counts, those whose hint was too small)"""
+        v = (C.c_uint64 * 2)()
+        _chk(lib().amd_ivf_last_round_hints(self._h, v))
+        return int(v[0]), int(v[1])
 
     def last_tie_fixed(self):
         """queries of the last search whose result came from the heap replayed over their admission log (include/auncel_amd.h)"""

@@ -250,6 +250,7 @@ struct amd_ivf {
     PinnedBuf p_hist;
     std::vector<uint32_t> round_hint;  // [round][16]
     uint64_t hint_sig = 0;
+    uint64_t hinted_rounds = 0, short_rounds = 0;  // last search: scan launches sized by a hint / of those, grids smaller than the work
     bool force_heap_select = false;  // (set while a search is repeated after ERR_LOG_OVERFLOW)
     // tune / train search over a coarse ranking the caller supplies (amd_ivf_search_adaptive_pre, amd_ivf_train_samples_pre):
     // host rows of this call's (or slice's) queries, given_nprobe entries each; null: the engine ranks the centroids itself
@@ -1438,6 +1439,8 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     auto hint_of = [&](size_t round, int counter) -> uint32_t {
         return chained && (round + 1) * 16 <= h->round_hint.size() ? h->round_hint[round * 16 + counter] : 0u;
     };
+    const std::vector<uint32_t> hints_used = chained ? h->round_hint : std::vector<uint32_t>();  // (compared with what the rounds needed)
+    h->hinted_rounds = h->short_rounds = 0;
     size_t planned_rounds = 0;  // plans launched so far (round r's counters reach history[r] when round r + 1 is planned)
     auto plan_round = [&](size_t round_len) {
         pa.round_len = (uint32_t)round_len;
@@ -1764,6 +1767,15 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         HIP_CHECK(stream_sync(s));
         h->round_hint.assign(h->p_hist.as<uint32_t>(), h->p_hist.as<uint32_t>() + nh * 16);
         h->round_hint.insert(h->round_hint.end(), hc, hc + 16);  // the last planned round
+        // a scan grid is its hint + 12 %; a round that needed more still covers its items (the workgroups stride over the
+        // device-side count), only with fewer workgroups than it would have been given
+        for (size_t r = 0; (r + 1) * 16 <= hints_used.size() && (r + 1) * 16 <= h->round_hint.size(); r++)
+            for (int c : {CNT_QG1, CNT_QG2, CNT_QG4, CNT_QG8}) {
+                const uint32_t used = hints_used[r * 16 + c], need = h->round_hint[r * 16 + c];
+                if (!used) continue;
+                h->hinted_rounds++;
+                if (need > used + used / 8 + 8) h->short_rounds++;
+            }
     }
     h->scan_bytes += *reinterpret_cast<double*>(hc + 16);
     h->scan_min_bytes += *reinterpret_cast<double*>(hc + 22);
@@ -2064,6 +2076,25 @@ int amd_ivf_coarse(amd_ivf_t* h, size_t n, const float* x, size_t nprobe, float*
     API_END
 }
 
+int amd_ivf_coarse_resident(amd_ivf_t* h, size_t start, size_t n, size_t nprobe, float* coarse_dis, int64_t* keys, int mode) {
+    API_BEGIN
+    use_device(h);
+    if (start + n > h->n_resident) throw EngineError("resident query range out of bounds");
+    if (n == 0) return 0;
+    WallClock wc(h->stream);
+    h->scan_bytes = h->scan_min_bytes = 0;
+    h->scan_slots = h->scan_useful = 0;
+    h->w_cdis.ensure(n * nprobe * 4);
+    h->w_ckeys.ensure(n * nprobe * 8);
+    coarse_dev(h, h->d_resident.as<float>() + start * h->dpad, n, nprobe, mode, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>(),
+               h->allow_fused && ix(h)->centroid_range.fusable_with(h->resident_range, h->metric));
+    if (coarse_dis) HIP_CHECK(hipMemcpyAsync(coarse_dis, h->w_cdis.p, n * nprobe * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipMemcpyAsync(keys, h->w_ckeys.p, n * nprobe * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(stream_sync(h->stream));
+    finish_timing(h, wc.stop());
+    API_END
+}
+
 int amd_ivf_search_preassigned(amd_ivf_t* h, size_t n, const float* x, size_t k, size_t nprobe, const int64_t* keys,
                                const float* coarse_dis, float* D, int64_t* I, int store_pairs, size_t max_codes) {
     API_BEGIN
@@ -2202,6 +2233,23 @@ int amd_ivf_range_results(amd_ivf_t* h, int64_t* labels, float* distances) {
         memcpy(labels, h->r_labels.data(), h->r_labels.size() * sizeof(int64_t));
         memcpy(distances, h->r_dist.data(), h->r_dist.size() * sizeof(float));
     }
+    API_END
+}
+
+int amd_ivf_search_resident_preassigned(amd_ivf_t* h, size_t start, size_t n, size_t k, size_t nprobe, const int64_t* keys, float* D,
+                                        int64_t* I) {
+    API_BEGIN
+    use_device(h);
+    if (start + n > h->n_resident) throw EngineError("resident query range out of bounds");
+    if (n == 0 || k == 0) return 0;
+    if (!keys) throw EngineError("keys are required");
+    WallClock wc(h->stream);
+    h->scan_bytes = h->scan_min_bytes = 0;
+    h->scan_slots = h->scan_useful = 0;
+    h->w_ckeys.ensure(n * nprobe * 8);
+    HIP_CHECK(hipMemcpyAsync(h->w_ckeys.p, keys, n * nprobe * 8, hipMemcpyHostToDevice, h->stream));
+    search_fixed_device(h, h->d_resident.as<float>() + start * h->dpad, n, k, nprobe, h->w_ckeys.as<int64_t>(), D, I, 0, 0, h->resident_range);
+    finish_timing(h, wc.stop());
     API_END
 }
 
@@ -3095,6 +3143,16 @@ int amd_ivf_set_byte_codes(amd_ivf_t* h, int enable) {
 
 int amd_ivf_last_scan_min_bytes(amd_ivf_t* h, double* bytes) {
     *bytes = h->last_min_bytes;
+    return 0;
+}
+
+int amd_ivf_last_round_hints(amd_ivf_t* h, uint64_t out[2]) {
+    out[0] = h->hinted_rounds;
+    out[1] = h->short_rounds;
+    for (auto& kid : h->kids) {
+        out[0] += kid->hinted_rounds;
+        out[1] += kid->short_rounds;
+    }
     return 0;
 }
 

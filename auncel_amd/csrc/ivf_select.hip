@@ -450,30 +450,29 @@ __device__ __forceinline__ uint32_t wave_shr1(uint32_t x, uint32_t carry) {
 __device__ __forceinline__ uint32_t sr_key(const SortedRegs& r, int i) { return i < 64 ? rl_u(r.k0, i) : rl_u(r.k1, i - 64); }
 
 // insert (key, gpos) behind the entries that are <= key; everything worse moves down one place (the old entry k - 1 is
-// thereby evicted: it slides into the unused tail).  Returns the position taken.
+// thereby evicted: it slides into the unused tail).  Returns the position taken.  Lane i takes the new entry iff its own key
+// is worse and its left neighbour's is not; the lanes to its right take their left neighbour's entry.
 template <bool TWO> __device__ __forceinline__ int sr_insert(SortedRegs& r, uint32_t key, uint32_t gpos, int lane) {
-    const unsigned long long m0 = __ballot(r.k0 > key);
-    const uint32_t kv = key, gv = gpos;
+    (void)lane;
+    const bool w0 = r.k0 > key;
+    const unsigned long long m0 = __ballot(w0);
+    int at = 128 - __builtin_popcountll(m0);
     if (TWO) {
-        const unsigned long long m1 = __ballot(r.k1 > key);
-        const uint32_t ck = rl_u(r.k0, 63), cg = rl_u(r.g0, 63);
-        const uint32_t t1 = wave_shr1(r.k1, ck), u1 = wave_shr1(r.g1, cg);
-        const bool mv1 = (m1 >> lane) & 1;
-        const unsigned long long ins1 = m1 & ~((m1 << 1) | (m0 >> 63));
-        const bool in1 = (ins1 >> lane) & 1;
-        r.k1 = in1 ? kv : mv1 ? t1 : r.k1;
-        r.g1 = in1 ? gv : mv1 ? u1 : r.g1;
-        if (m0 == 0) return 64 + (m1 ? __builtin_ctzll(m1) : 64);
-    } else if (m0 == 0) {
-        return 64;
+        const bool w1 = r.k1 > key;
+        at -= __builtin_popcountll(__ballot(w1));
+        const uint32_t t1 = wave_shr1(r.k1, rl_u(r.k0, 63)), u1 = wave_shr1(r.g1, rl_u(r.g0, 63));
+        const bool p1 = t1 > key;  // the left neighbour moves too: take its entry, else this is the gap
+        r.k1 = w1 ? (p1 ? t1 : key) : r.k1;
+        r.g1 = w1 ? (p1 ? u1 : gpos) : r.g1;
+        if (m0 == 0) return at;
+    } else {
+        at -= 64;
     }
-    const uint32_t t0 = wave_shr1(r.k0, 0u), u0 = wave_shr1(r.g0, 0u);
-    const bool mv0 = (m0 >> lane) & 1;
-    const unsigned long long ins0 = m0 & ~(m0 << 1);
-    const bool in0 = (ins0 >> lane) & 1;
-    r.k0 = in0 ? kv : mv0 ? t0 : r.k0;
-    r.g0 = in0 ? gv : mv0 ? u0 : r.g0;
-    return __builtin_ctzll(m0);
+    const uint32_t t0 = wave_shr1(r.k0, 0u), u0 = wave_shr1(r.g0, 0u);  // (lane 0's left neighbour: nothing is better than key 0)
+    const bool p0 = t0 > key;
+    r.k0 = w0 ? (p0 ? t0 : key) : r.k0;
+    r.g0 = w0 ? (p0 ? u0 : gpos) : r.g0;
+    return at;
 }
 
 // (list << 32 | position) of a global position: the list whose range holds it (empty lists skipped by the search)
@@ -1010,16 +1009,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
 //                 words per step with the next step's words in flight; the few marked chunks of a step are fetched together.
 // After every probe the stop rule is evaluated exactly as IndexIVF.cpp:551-638 does (tune mode); a probe that admitted
 // nothing costs a handful of scalar instructions.
-__host__ __device__ inline size_t select_wave_bytes(int k, bool tune, uint32_t trace_cap) {
+__host__ __device__ inline size_t select_wave_bytes(int k, bool tune, bool dense, uint32_t trace_cap) {
     size_t b = 0;
     if (tune) b += (size_t)k * 4 + 16 * 4 + (size_t)trace_cap * 8 + CURNUM_PAR_MAXK * 15 * 4 + 8;  // srt | dwin | trace x,z | cur_num_par terms
+    if (dense) b += 5 * 128 * 4;  // the first k candidates of a search, ranked at once: keys, value bits, positions | sorted keys, positions
     return (b + 15) & ~(size_t)15;
 }
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+#ifndef AUNCEL_SEL_WAVES
+#define AUNCEL_SEL_WAVES 5  // waves per SIMD the dense-round kernel is compiled for: 5 keeps a 5000-query batch resident at once
+#endif
+
 template <bool IsMax, bool MASKED, bool TUNE, int KC>
-__global__ __launch_bounds__(256) void select_sorted_kernel(ReplayArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 : AUNCEL_SEL_WAVES))) void select_sorted_kernel(ReplayArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr bool TWO = KC == 0 || KC > 64;
     const int lane = threadIdx.x & 63;
@@ -1037,11 +1041,12 @@ __global__ __launch_bounds__(256) void select_sorted_kernel(ReplayArgs a) {
     const uint32_t qi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.qsel ? a.qsel[li] : li));
     if (a.done[qi]) return;
 
-    unsigned char* wbase = smem + (TUNE ? 2000 : 0) + (size_t)wave * select_wave_bytes(k, TUNE, a.trace_cap);
+    unsigned char* wbase = smem + (TUNE ? 2000 : 0) + (size_t)wave * select_wave_bytes(k, TUNE, !MASKED, a.trace_cap);
     float* srt = reinterpret_cast<float*>(wbase);       // tune: the k values best first, as the rule reads them
     float* dwin = srt + k;                              // 16 boundary distances of the current stage
     float* trc = dwin + 16;                             // x | z of the cached trace, trace_cap each
     float* terms = trc + 2 * a.trace_cap;               // cur_num_par scratch
+    uint32_t* fill = reinterpret_cast<uint32_t*>(wbase + select_wave_bytes(k, TUNE, false, a.trace_cap));  // dense rounds: 5 x 128 words
     const float* gdtb = TUNE ? a.dtb + (size_t)qi * max_num : nullptr;
 
     // ---- state
@@ -1064,7 +1069,8 @@ __global__ __launch_bounds__(256) void select_sorted_kernel(ReplayArgs a) {
         log_g = e.y;
     }
     auto worst_key = [&]() { return sr_key(sr, k - 1); };
-    float top = okey_inv<IsMax>(worst_key());  // the worst of the k: what a candidate has to beat
+    uint32_t topk = worst_key();          // the worst of the k: what a candidate has to beat (as an order key, for the scalar unit,
+    float top = okey_inv<IsMax>(topk);    // and as the float the vector compares take)
     auto srt_from_regs = [&]() {
         if (lane < k) srt[lane] = okey_inv<IsMax>(sr.k0);
         if (TWO && lane + 64 < k) srt[lane + 64] = okey_inv<IsMax>(sr.k1);
@@ -1112,10 +1118,10 @@ __global__ __launch_bounds__(256) void select_sorted_kernel(ReplayArgs a) {
 
     // ---- one admission (the candidate beats the worst of the k): IndexIVFFlat.cpp:125-135 on the sorted array
     int ins_min = 128;       // best position taken during the current probe
-    auto admit = [&](float val, uint32_t gp) {
-        const uint32_t evicted = okey<IsMax>(top);  // (== the key of entry k - 1)
+    auto admit = [&](float val, uint32_t ckey, uint32_t gp) {
+        const uint32_t evicted = topk;
         gp = (uint32_t)__builtin_amdgcn_readfirstlane((int)gp);
-        const int at = sr_insert<TWO>(sr, okey<IsMax>(val), gp, lane);
+        const int at = sr_insert<TWO>(sr, ckey, gp, lane);
         ins_min = at < ins_min ? at : ins_min;
         if (logn >= a.log_cap) {
             err = ERR_LOG_OVERFLOW;
@@ -1129,6 +1135,7 @@ __global__ __launch_bounds__(256) void select_sorted_kernel(ReplayArgs a) {
         // the entry that left was one of several equal worst values iff the new worst equals it (the new value is strictly better)
         const uint32_t wk = worst_key();
         if (wk == evicted && wk != SKEY_SENT) amb = wk;
+        topk = wk;
         top = okey_inv<IsMax>(wk);
     };
 
@@ -1180,13 +1187,14 @@ __global__ __launch_bounds__(256) void select_sorted_kernel(ReplayArgs a) {
 
     // a block of 256 candidates (lane l: candidates 4l .. 4l + 3, the block's first is number c0 of its list) in which
     // something may beat the worst of the k, or that holds the padding behind the row's end
-    auto dense_block = [&](const f4 x, uint32_t c0, uint32_t n, uint32_t lbase) {
+    auto dense_block = [&](const f4 x, uint32_t c0, uint32_t n, uint32_t lbase, uint32_t taken) {
         const uint32_t valid = n > c0 ? n - c0 : 0u;  // candidates of the row in this block (>= 256: all)
+        const uint32_t skip = taken > c0 ? taken - c0 : 0u;  // ... of which the first `skip` are in the array already (fill_first_k)
         const uint32_t p4 = 4u * lane;
-        const unsigned long long h0 = __ballot(hcmp<IsMax>(top, x.x) && p4 < valid);
-        const unsigned long long h1 = __ballot(hcmp<IsMax>(top, x.y) && p4 + 1 < valid);
-        const unsigned long long h2 = __ballot(hcmp<IsMax>(top, x.z) && p4 + 2 < valid);
-        const unsigned long long h3 = __ballot(hcmp<IsMax>(top, x.w) && p4 + 3 < valid);
+        const unsigned long long h0 = __ballot(hcmp<IsMax>(top, x.x) && p4 < valid && p4 >= skip);
+        const unsigned long long h1 = __ballot(hcmp<IsMax>(top, x.y) && p4 + 1 < valid && p4 + 1 >= skip);
+        const unsigned long long h2 = __ballot(hcmp<IsMax>(top, x.z) && p4 + 2 < valid && p4 + 2 >= skip);
+        const unsigned long long h3 = __ballot(hcmp<IsMax>(top, x.w) && p4 + 3 < valid && p4 + 3 >= skip);
         unsigned long long any = h0 | h1 | h2 | h3;
         while (any) {
             const int l = __builtin_ctzll(any);
@@ -1200,10 +1208,69 @@ __global__ __launch_bounds__(256) void select_sorted_kernel(ReplayArgs a) {
                 const int sidx = __builtin_ctz(nib);
                 nib &= nib - 1;
                 const float val = sidx == 0 ? v0 : sidx == 1 ? v1 : sidx == 2 ? v2 : v3;
-                if (hcmp<IsMax>(top, val)) admit(val, g0 + (uint32_t)sidx);
+                const uint32_t ck = okey<IsMax>(val);  // (it beat an earlier worst in the vector compare: not a NaN)
+                if (ck < topk) admit(val, ck, g0 + (uint32_t)sidx);
             }
         }
     };
+
+    // The first min(k, n) candidates of a search all enter (the array is empty): ranked against each other at once instead of
+    // inserted one by one.  x: the row's first block; returns how many were taken.  (Equal values keep arrival order, as
+    // sr_insert would leave them; the entries that go are empty ones: nothing for `amb` to note.)
+    auto fill_first_k = [&](const f4 x, uint32_t n, uint32_t lbase) -> uint32_t {
+        const uint32_t m = n < (uint32_t)k ? n : (uint32_t)k;
+        uint32_t *fk = fill, *fv = fill + 128, *fg = fill + 256, *sk = fill + 384, *sg = fill + 512;
+        const float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const uint32_t j = 4u * lane + c;
+            if (j < m) {
+                fk[j] = okey<IsMax>(xs[c]);
+                fv[j] = __float_as_uint(xs[c]);
+                fg[j] = lbase + j;
+                qlog[j] = make_uint2(__float_as_uint(xs[c]), lbase + j);
+            }
+        }
+        wave_sync();
+        const uint32_t j0 = lane, j1 = lane + 64;
+        const uint32_t k0v = j0 < m ? fk[j0] : 0u, k1v = j1 < m ? fk[j1] : 0u;
+        uint32_t r0 = 0, r1 = 0;
+        for (uint32_t i = 0; i < m; i++) {
+            const uint32_t ki = fk[i];
+            r0 += (ki < k0v || (ki == k0v && i < j0)) ? 1u : 0u;
+            r1 += (ki < k1v || (ki == k1v && i < j1)) ? 1u : 0u;
+        }
+        if (j0 < m) {
+            sk[r0] = k0v;
+            sg[r0] = fg[j0];
+        }
+        if (j1 < m) {
+            sk[r1] = k1v;
+            sg[r1] = fg[j1];
+        }
+        wave_sync();
+        if (j0 < m) {
+            sr.k0 = sk[j0];
+            sr.g0 = sg[j0];
+        }
+        if (TWO && j1 < m) {
+            sr.k1 = sk[j1];
+            sr.g1 = sg[j1];
+        }
+        // the admission log holds them in arrival order; its open block goes to the staging registers
+        logn = m;
+        if ((uint32_t)lane < (m & 63u)) {
+            log_v = fv[(m & ~63u) + lane];
+            log_g = fg[(m & ~63u) + lane];
+        }
+        st_nheap += m;
+        ins_min = 0;
+        topk = worst_key();
+        top = okey_inv<IsMax>(topk);
+        wave_sync();
+        return m;
+    };
+    bool fresh = !MASKED && logn == 0 && sr_key(sr, 0) == SKEY_SENT;  // nothing admitted yet in this search
 
     bool finished = false;
     uint32_t consumed = 0;
@@ -1229,6 +1296,11 @@ __global__ __launch_bounds__(256) void select_sorted_kernel(ReplayArgs a) {
                     // current group, each register is refilled with its block of the next group (of the region: whatever row that is
                     // in) as soon as it has been looked at.
                     const uint32_t ngrp = (n + 1023u) >> 10;
+                    uint32_t taken = 0;
+                    if (fresh) {
+                        taken = fill_first_k(R0, n, lbase);
+                        fresh = false;
+                    }
                     for (uint32_t g = 0; g < ngrp; g++) {
                         const f4* nxt = region4 + (size_t)(gpos + 1) * 256;
 #define SEL_BLOCK(R, U)                                                                                                       \
@@ -1236,7 +1308,7 @@ __global__ __launch_bounds__(256) void select_sorted_kernel(ReplayArgs a) {
         const f4 x = R;                                                                                                       \
         R = __builtin_nontemporal_load(nxt + (U) * 64);                                                                       \
         const float best = IsMax ? fminf(fminf(fminf(x.x, x.y), x.z), x.w) : fmaxf(fmaxf(fmaxf(x.x, x.y), x.z), x.w);         \
-        if (__ballot(hcmp<IsMax>(top, best)) != 0) dense_block(x, g * 1024u + (U) * 256u, n, lbase);                          \
+        if (__ballot(hcmp<IsMax>(top, best)) != 0) dense_block(x, g * 1024u + (U) * 256u, n, lbase, taken);                   \
     }
                         SEL_BLOCK(R0, 0)
                         SEL_BLOCK(R1, 1)
@@ -1295,7 +1367,8 @@ __global__ __launch_bounds__(256) void select_sorted_kernel(ReplayArgs a) {
                                     const int l = __builtin_ctzll(m);
                                     m &= m - 1;
                                     const float val = rl_f(x, l);
-                                    if (hcmp<IsMax>(top, val)) admit(val, lbase + cb + (uint32_t)l);
+                                    const uint32_t ck = okey<IsMax>(val);
+                                    if (ck < topk) admit(val, ck, lbase + cb + (uint32_t)l);
                                 }
                             };
                             chunk(c0, x0);
@@ -1466,7 +1539,7 @@ __global__ __launch_bounds__(256) void select_sorted_kernel(ReplayArgs a) {
 void launch_select_sorted(const ReplayArgs& a, hipStream_t s) {
     if (a.nq == 0) return;
     const bool tune = a.tuner.enabled != 0;
-    const size_t shmem = (tune ? 2000 : 0) + 4 * select_wave_bytes(a.k, tune, a.trace_cap);
+    const size_t shmem = (tune ? 2000 : 0) + 4 * select_wave_bytes(a.k, tune, a.mask == nullptr, a.trace_cap);
     if (shmem > 160 * 1024) throw std::runtime_error("selection kernel: trace cache beyond LDS");
     const dim3 grid((a.nq + 3) / 4), block(256);
     auto go = [&](auto kern) {
@@ -1592,8 +1665,8 @@ __global__ __launch_bounds__(256) void tie_fix_kernel(TieFixArgs a) {
         }
     }
     wave_sync();
-    if (RH) rh_store(rh, hval, href, k, lane, true);
     if (!fin) {
+        if (RH) rh_store(rh, hval, href, k, lane, true);
         for (int i = lane; i < k; i += 64) {
             a.fix_val[(size_t)qi * k + i] = hval[i];
             a.fix_ref[(size_t)qi * k + i] = href[i];
@@ -1601,14 +1674,47 @@ __global__ __launch_bounds__(256) void tie_fix_kernel(TieFixArgs a) {
         if (lane == 0) a.fix_pos[qi] = n;
         return;
     }
+    // heap_reorder (Heap.h:295-322): pop everything, worst first, filling the row from its end; empty entries are dropped
     int ii = 0;
-    for (int i = 0; i < k; i++) {
-        const float v = hval[0];
-        const int64_t id = href[0];
-        heap_pop<IsMax>(k - i, hval, href);
-        hval[k - ii - 1] = v;
-        href[k - ii - 1] = id;
-        if (id != -1) ii++;
+    if (RH) {
+        // (in registers: the popped root's value and id slot go to a staging pair, one lane per output position)
+        uint32_t out_key = 0, out_slot = 0;  // lane j <-> output position k - 1 - j (and k - 65 - j in the second pair)
+        uint32_t out_key2 = 0, out_slot2 = 0;
+        for (int i = 0; i < k; i++) {
+            const uint32_t rk = rl_u(rh.v0, 1), rs = rl_u(rh.s0, 1);
+            const int64_t id = href[rs];  // (uniform LDS read)
+            rh_pop<IsMax, 0>(rh, k - i);
+            if (id != -1) {
+                if (ii < 64) wl2_u(out_key, rk, out_slot, rs, ii);
+                else wl2_u(out_key2, rk, out_slot2, rs, ii - 64);
+                ii++;
+            }
+        }
+        // the j-th valid entry popped belongs at position k - 1 - j (the valid ones end up in [k - ii, k), best first)
+        wave_sync();
+        float* pv = hval;            // reuse: the register heap no longer needs its LDS image
+        int64_t* pr = href;
+        int64_t r_a = -1, r_b = -1;
+        if (lane < ii && lane < 64) r_a = href[out_slot];
+        if (lane + 64 < ii) r_b = href[out_slot2];
+        wave_sync();
+        if (lane < ii && lane < 64) {
+            pv[k - 1 - lane] = fkey_inv(out_key);
+            pr[k - 1 - lane] = r_a;
+        }
+        if (lane + 64 < ii) {
+            pv[k - 65 - lane] = fkey_inv(out_key2);
+            pr[k - 65 - lane] = r_b;
+        }
+    } else {
+        for (int i = 0; i < k; i++) {
+            const float v = hval[0];
+            const int64_t id = href[0];
+            heap_pop<IsMax>(k - i, hval, href);
+            hval[k - ii - 1] = v;
+            href[k - ii - 1] = id;
+            if (id != -1) ii++;
+        }
     }
     wave_sync();
     for (int i = lane; i < k; i += 64) {

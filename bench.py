@@ -64,6 +64,40 @@ def gen_data(torch, dev, nb, nq, d, nblobs, sigma, seed):
     return xb, centres, draw
 
 
+def find_data_files(root):
+    """--data DIR: base / query / ground-truth files of the reference's harness layouts (Auncel/eval/bound.cpp:29-113,225-340):
+    *base*.fvecs|.fbin|.u8bin, *query*.fvecs|.fbin|.u8bin, *groundtruth*|*gt*.ivecs|.ibin"""
+    names = sorted(os.listdir(root))
+
+    def pick(words, exts):
+        for n in names:
+            low = n.lower()
+            if any(w in low for w in words) and low.endswith(exts):
+                return os.path.join(root, n)
+        return None
+
+    vec = (".fvecs", ".fbin", ".u8bin", ".bvecs.fbin")
+    return pick(("base", "learn_as_base"), vec), pick(("query",), vec), pick(("groundtruth", "gt"), (".ivecs", ".ibin"))
+
+
+def read_vectors(capi, path, limit=0):
+    """one of the harness's vector files -> float32 (n, d); .u8bin keeps the unsigned byte values (the harness's own fbin_read
+    widens them as signed chars, eval/bound.cpp:83-92 -- capi.read_fbin(nbytes=1) -- which would fold 128..255 below zero)"""
+    low = path.lower()
+    if low.endswith(".fvecs"):
+        x = capi.read_fvecs(path)
+        return x[:limit] if limit else x
+    if low.endswith(".u8bin"):
+        x, _ = capi.read_fbin(path, num=limit, nbytes=1)
+        return np.where(x < 0, x + 256.0, x).astype(np.float32)
+    x, _ = capi.read_fbin(path, num=limit, nbytes=4)
+    return x
+
+
+def read_ids(capi, path):
+    return capi.read_ivecs(path) if path.lower().endswith(".ivecs") else capi.read_ibin(path)[0]
+
+
 def kmeans_centroids(torch, xb, nlist, iters, seed):
     """bench infrastructure only (k-means is outside the hot path): a few Lloyd steps on a sample"""
     g = torch.Generator(device=xb.device)
@@ -115,10 +149,12 @@ def recall_dist(D, gtD, topk):
 def run_shards(args, torch, dist, capi, rank, world, local, dev, red_dev):
     """BASELINE configs[3]: SIFT-10M-like, IVF4096,Flat, k = topk, fixed nprobe; the inverted lists are sharded by list id over
     the ranks (the reference's IndexShards over sub-indexes that share one coarse quantizer, Auncel/IndexShards.cpp:261-311;
-    owner balanced by list bytes), every rank scans the probed lists it owns for the whole batch, the per-rank (D, I) tables
-    (n x k x 12 bytes) are gathered on rank 0 and merged there with merge_tables semantics (IndexShards.cpp:44-105).  No
-    data-path collective.  Strong scaling: database and batch are fixed as N grows.  N = 1 runs the same code with one shard.
-    A step = one such search + merge over the whole batch of `--test` resident queries."""
+    owner balanced by list bytes).  The coarse quantization is computed once: rank r ranks the queries
+    [r n / N, (r + 1) n / N) and the key rows (n x nprobe x 8 bytes) are all-gathered -- the path's one exchange step, RCCL over
+    xGMI; every rank then scans the probed lists it owns for the whole batch, the per-rank (D, I) tables (n x k x 12 bytes) are
+    gathered on rank 0 and merged there with merge_tables semantics (IndexShards.cpp:44-105).  Strong scaling: database and
+    batch are fixed as N grows.  N = 1 runs the same code with one shard.  A step = coarse + all-gather + search + merge over
+    the whole batch of `--test` resident queries.  Returns the result line (rank 0) or None."""
     from auncel_amd import sharding
     d, nlist, k, nq = args.d, args.nlist, args.topk, args.test
     t0 = time.time()
@@ -152,11 +188,18 @@ def run_shards(args, torch, dist, capi, rank, world, local, dev, red_dev):
     log(f"shards: data, k-means, assignment, {int(keep.sum())} of {args.nb} vectors on rank 0: {time.time() - t0:.1f}s")
 
     acc = {}
+    counts = [(r + 1) * nq // world - r * nq // world for r in range(world)]
+    q0 = rank * nq // world
 
     def step():
-        D, I = h.search_resident(0, nq, k, args.nprobe)
+        _, ck = h.coarse_resident(q0, counts[rank], args.nprobe, mode=0, want_dis=False)
+        acc["coarse_ms"] = acc.get("coarse_ms", 0.0) + h.last_timing()["coarse_ms"]
+        tx = time.perf_counter()
+        keys = sharding.allgather_rows(ck, counts, dist if world > 1 else None)
+        acc["exchange_ms"] = acc.get("exchange_ms", 0.0) + (time.perf_counter() - tx) * 1e3
+        D, I = h.search_resident_preassigned(0, nq, k, keys)
         tm = h.last_timing()
-        for key in ("scan_ms", "scan_launches", "scan_min_bytes", "coarse_ms", "select_ms"):
+        for key in ("scan_ms", "scan_launches", "scan_min_bytes", "select_ms"):
             acc[key] = acc.get(key, 0.0) + tm[key]
         return sharding.gather_and_merge(D, I, capi.METRIC_L2, capi.merge_tables, dist if world > 1 else None)
 
@@ -178,6 +221,16 @@ def run_shards(args, torch, dist, capi, rank, world, local, dev, red_dev):
         t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # per-rank kernel times of the timed region (ms per step): what divides by N and what does not
+    mine = [acc.get(key, 0.0) / args.steps for key in ("coarse_ms", "exchange_ms", "scan_ms", "select_ms")]
+    if world > 1:
+        tt = torch.tensor(mine, device=red_dev, dtype=torch.float64)
+        allt = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        per_rank = [[float(v) for v in t_.tolist()] for t_ in allt]
+    else:
+        per_rank = [mine]
+    line = None
     if rank == 0:
         D, I = out
         rec = recall_dist(D[:nvalid], gtD, k)
@@ -193,6 +246,8 @@ def run_shards(args, torch, dist, capi, rank, world, local, dev, red_dev):
             "config": {"workload": f"SIFT-{args.nb // 1000000}M-like d={d} IVF{nlist},Flat k={k} nprobe={args.nprobe}, IndexShards over {world} GPU(s): "
                                    f"lists sharded by list id, batch {nq} resident queries searched by every shard, host merge_tables on rank 0",
                        "nb": args.nb, "sigma": args.sigma, "nprobe": args.nprobe, "recall_at_k_mean": float(rec.mean()),
+                       "per_rank_ms_per_step": {"columns": ["coarse (own share of the batch)", "all-gather of the key rows (host wall)", "scan", "select"],
+                                                "rows": per_rank},
                        # distances of the merged result (sorted rows: identical for any number of shards, whatever the order
                        # the merge gives equal distances)
                        "distances_sha256": __import__("hashlib").sha256(np.ascontiguousarray(D).tobytes()).hexdigest(),
@@ -226,9 +281,9 @@ def run_shards(args, torch, dist, capi, rank, world, local, dev, red_dev):
             line["cpu_baseline"] = {"value": S / cpu_s, "unit": "queries/s", "cores": cores, "kind": "port",
                                     "sample": f"first {S} of the {nq} queries, same lists, coarse + search_preassigned, OpenMP over queries",
                                     "gpu_matches_cpu_on_sample": bool(np.array_equal(oI, I[:S]) and np.array_equal(oD, D[:S]))}
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    del h
+    torch.cuda.empty_cache()
+    return line
 
 
 def main():
@@ -263,6 +318,13 @@ def main():
                     help="context j issues its first step j x this many ms after context 0 (inside the timed region): out of phase, the "
                          "scan of one batch runs under the selection of another; started together they tend to stay in step")
     ap.add_argument("--pinned-out", type=int, default=1, help="1: result buffers in page-locked host memory, 0: pageable")
+    ap.add_argument("--slices", type=int, default=4,
+                    help="distinct resident query slices of --test queries each; step s searches slice s mod this (no step repeats the "
+                         "previous step's batch)")
+    ap.add_argument("--data", default=None,
+                    help="directory with base / query / ground-truth files in the reference harness's layouts (.fvecs/.ivecs, .fbin/.ibin, "
+                         ".u8bin): the same pipeline on real data instead of the synthetic blobs")
+    ap.add_argument("--data-rows", type=int, default=0, help="--data: base vectors to read (0: the whole file)")
     ap.add_argument("--in-flight", type=int, default=4,
                     help="batches kept in flight per GPU, each from its own host thread on its own search context "
                          "(amd_ivf_clone); 1 = one batch at a time")
@@ -300,16 +362,48 @@ def main():
     red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the max-over-ranks reduction lives
 
     if args.mode == "shards":
-        return run_shards(args, torch, dist, capi, rank, world, local, dev, red_dev)
+        line = run_shards(args, torch, dist, capi, rank, world, local, dev, red_dev)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     d, nlist, K, topk, ts, ses = args.d, args.nlist, args.maxtopk, args.topk, args.train, args.test
+    nsl = max(1, args.slices)
     t0 = time.time()
-    xb_t, _, draw = gen_data(torch, dev, args.nb, 0, d, args.blobs, args.sigma, 1235)
-    gq = torch.Generator(device=dev)
-    gq.manual_seed(777 + rank)  # every replica searches its own query set
-    xq_t = draw(ts + ses, gq)
+    data_desc, gt_check = "synthetic", None
+    if args.data:
+        fb, fq, fg = find_data_files(args.data)
+        assert fb and fq, f"--data {args.data}: need *base* and *query* files (.fvecs / .fbin / .u8bin)"
+        xb_h = read_vectors(capi, fb, args.data_rows)
+        xq_h = read_vectors(capi, fq)
+        args.nb, d = xb_h.shape
+        assert xq_h.shape[1] == d
+        # the query file is cut like the reference's run (eval/bound.cpp:337-340): a training half, then the timed slices
+        nsl = max(1, min(nsl, (xq_h.shape[0] - ts) // ses))
+        assert xq_h.shape[0] >= ts + ses, f"{fq}: {xq_h.shape[0]} queries, need {ts} training + {ses} timed"
+        xq_h = xq_h[:ts + nsl * ses]
+        xb_t = torch.from_numpy(xb_h).to(dev)
+        xq_t = torch.from_numpy(xq_h).to(dev)
+        del xb_h, xq_h
+        data_desc = f"real: {os.path.basename(fb)}, {os.path.basename(fq)}"
+    else:
+        xb_t, _, draw = gen_data(torch, dev, args.nb, 0, d, args.blobs, args.sigma, 1235)
+        gq = torch.Generator(device=dev)
+        gq.manual_seed(777 + rank)  # every replica searches its own query set
+        xq_t = draw(ts + nsl * ses, gq)
     cen_t = kmeans_centroids(torch, xb_t, nlist, 4, 99)
     gtD, gtI = ground_truth(torch, xb_t, xq_t, K)
+    if args.data and fg:
+        # the file's ids against the brute-force kernel on 200 queries: a true neighbour is within the computed k-th distance
+        gi = read_ids(capi, fg)
+        m = min(200, gi.shape[0], xq_t.shape[0])
+        kk = min(topk, gi.shape[1])
+        dd = ((xb_t[torch.from_numpy(gi[:m, :kk].astype(np.int64)).to(dev)] - xq_t[:m, None, :]) ** 2).sum(2).cpu().numpy()
+        gt_check = {"file": os.path.basename(fg), "queries": int(m), "k": int(kk),
+                    "agrees_with_brute_force": bool((dd <= gtD[:m, kk - 1:kk] * (1 + 1e-6) + 1e-3).all())}
+        log("ground-truth file check:", gt_check)
     xb, xq, cen = xb_t.cpu().numpy(), xq_t.cpu().numpy(), cen_t.cpu().numpy()
     del xb_t, xq_t, cen_t
     torch.cuda.empty_cache()
@@ -354,14 +448,15 @@ def main():
     #               "Error bound is guaranteed" (eval/bound.cpp:404-414)
     # std_m scales the spread term of the k-scaling estimate (Trace::search: mean + std_m * std), multipler the probe count
     # at which a fired query stops.
-    req = np.full(ts + ses, args.bound, dtype=np.float32)
+    nall = ts + nsl * ses
+    req = np.full(nall, args.bound, dtype=np.float32)
     grid = [(1.0, sm) for sm in (0.0, 0.25, 0.5, 0.75) if sm < args.std_m]
     grid += [(m, args.std_m) for m in (1.0, 1.25, 1.5, 1.75, 2.0, 2.5, 3.0, 4.0, 5.0, 6.0, 8.0, 12.0, 16.0, 24.0)]
     nval = ts - tfit
     headline, guaranteed, best_min = None, None, (0.0, None)
     for mult, sm in grid:
-        np_ = np.zeros(ts + ses, dtype=np.uint64)
-        tr_ = np.zeros(ts + ses, dtype=np.float32)
+        np_ = np.zeros(nall, dtype=np.uint64)
+        tr_ = np.zeros(nall, dtype=np.float32)
         D, I = h.search_adaptive(tfit, nval, topk, mult, sm, req, np_, tr_)
         rec = recall_dist(D, gtD[tfit:ts], topk)
         se = float(rec.std() / np.sqrt(nval))
@@ -404,11 +499,13 @@ def main():
 
     hyper = {"mult": chosen, "std_m": chosen_std}
 
-    def step(ctx):
-        np_ = np.zeros(ts + ses, dtype=np.uint64)
-        tr_ = np.zeros(ts + ses, dtype=np.float32)
-        D, I = ctx.search_adaptive(ts, ses, topk, hyper["mult"], hyper["std_m"], req, np_, tr_, out=outs[id(ctx)])
-        return D, I, np_
+    def step(ctx, stepno):
+        """step s searches slice s mod nsl of the resident queries: consecutive steps never see the same batch"""
+        start = ts + (stepno % nsl) * ses
+        np_ = np.zeros(nall, dtype=np.uint64)
+        tr_ = np.zeros(nall, dtype=np.float32)
+        D, I = ctx.search_adaptive(start, ses, topk, hyper["mult"], hyper["std_m"], req, np_, tr_, out=outs[id(ctx)])
+        return D, I, np_, start
 
     def barrier():
         if world > 1:
@@ -423,10 +520,13 @@ def main():
             try:
                 if j and stagger_s:
                     time.sleep(j * stagger_s)  # start the contexts out of phase (scan of one under selection of the other)
-                for _ in range(j, nsteps, nfl):
-                    res = step(ctxs[j])
+                for sn in range(j, nsteps, nfl):
+                    res = step(ctxs[j], sn)
                     tm = ctxs[j].last_timing()
+                    hints = ctxs[j].last_round_hints()
                     with lock:
+                        acc["hinted_launches"] = acc.get("hinted_launches", 0) + hints[0]
+                        acc["short_hints"] = acc.get("short_hints", 0) + hints[1]
                         for key in ("scan_ms", "scan_bytes", "scan_launches", "coarse_ms", "select_ms", "scan_min_bytes"):
                             acc[key] = acc.get(key, 0.0) + tm[key]
                         acc["slot_eff"] = acc.get("slot_eff", 0.0) + tm["slot_efficiency"]
@@ -476,8 +576,10 @@ def main():
         nfl = nfl_keep
     workload = (f"SIFT-{args.nb // 1000000}M-like d={d} IVF{nlist},Flat max_topk={K} topk={topk} Auncel error-bound nprobe "
                 f"(bound {args.bound}), batch {ses} resident queries per GPU, index replicated per GPU")
-    D, I, my_np = acc["last"]
+    D, I, my_np, q_start = acc["last"]
     D, I, my_np = D.copy(), I.copy(), my_np.copy()  # (the result buffers are reused by the legs below)
+    my_sl = my_np[q_start:q_start + ses]  # my_nprobe of the slice the last timed step searched
+    gt_sl = gtD[q_start:q_start + ses]
 
     def timed_leg(nsteps):
         """nsteps more steps with the current settings, after the timed region (never part of `value`)"""
@@ -498,12 +600,16 @@ def main():
         for c in ctxs:
             c.set_byte_codes(False)
         leg = timed_leg(max(4, args.steps // 3))
-        fD, fI, f_np = leg["last"]
+        fD, fI, f_np, f_start = leg["last"]
         nst = max(4, args.steps // 3)
+        if f_start != q_start:  # the same slice as the timed region's last step, for the comparison
+            fD, fI, f_np, f_start = step(ctxs[0], (q_start - ts) // ses)
+            fD, fI = fD.copy(), fI.copy()
         fp32 = {"value": ses * nst / leg["elapsed"], "unit": "queries/s", "ms_per_step": 1000.0 * leg["elapsed"] / nst,
                 "scan_arith": {0: "fp32 reference order", 1: "fp32 fused"}.get(ctxs[0].scan_arith(), "?"),
                 "scan_avg_launch_ms": leg["scan_ms"] / max(leg["scan_launches"], 1),
-                "same_results_as_byte_codes": bool(np.array_equal(fD, D) and np.array_equal(fI, I) and np.array_equal(f_np, my_np))}
+                "same_results_as_byte_codes": bool(np.array_equal(fD, D) and np.array_equal(fI, I) and
+                                                   np.array_equal(f_np[q_start:q_start + ses], my_sl))}
         for c in ctxs:
             c.set_byte_codes(True)
     # the reference's acceptance check at the operating point chosen for it on the training half
@@ -512,20 +618,20 @@ def main():
         hyper["mult"], hyper["std_m"] = guaranteed
         nst = max(4, args.steps // 3)
         leg = timed_leg(nst)
-        gD, gI, g_np = leg["last"]
-        grec = recall_dist(gD, gtD[ts:], topk)
+        gD, gI, g_np, g_start = leg["last"]
+        grec = recall_dist(gD, gtD[g_start:g_start + ses], topk)
         guar.update({"multipler": guaranteed[0], "std_m": guaranteed[1], "value": ses * nst / leg["elapsed"], "unit": "queries/s",
                      "recall_min_test": float(grec.min()), "recall_mean_test": float(grec.mean()),
-                     "bound_guaranteed_on_test": bool(grec.min() >= args.bound), "nprobe_mean": float(g_np[ts:].mean())})
+                     "bound_guaranteed_on_test": bool(grec.min() >= args.bound), "nprobe_mean": float(g_np[g_start:g_start + ses].mean())})
         hyper["mult"], hyper["std_m"] = chosen, chosen_std
     elif guaranteed is None:
         guar["note"] = "no grid point up to multipler 24 holds the bound for every validation query"
     scan_ms, scan_bytes, scan_launches = acc["scan_ms"], acc["scan_bytes"], acc["scan_launches"]
     coarse_ms, select_ms, slot_eff = acc["coarse_ms"], acc["select_ms"], acc["slot_eff"] / args.steps
 
-    rec = recall_dist(D, gtD[ts:], topk)
-    log("my_nprobe of the timed queries: percentiles 10/25/50/75/90/95/99 =", np.percentile(my_np[ts:], [10, 25, 50, 75, 90, 95, 99]).tolist(),
-        "; share <= 12:", float((my_np[ts:] <= 12).mean()), "<= 42:", float((my_np[ts:] <= 42).mean()))
+    rec = recall_dist(D, gt_sl, topk)
+    log("my_nprobe of the timed queries: percentiles 10/25/50/75/90/95/99 =", np.percentile(my_sl, [10, 25, 50, 75, 90, 95, 99]).tolist(),
+        "; share <= 12:", float((my_sl <= 12).mean()), "<= 42:", float((my_sl <= 42).mean()))
     # algorithmic bytes: the reference's own ndis counter (codes actually visited by the probe loops,
     # IndexIVF.cpp:676,733) x d x 4; `scan_bytes` (distances the tiles computed, incl. the probes a round
     # ran past a query's stop point) is reported beside it as computed_over_algorithmic
@@ -572,9 +678,13 @@ def main():
         # uint8-valued (bit-identical to the reference's fp32 results there), fp32 in the reference's
         # summation order otherwise
         "dtype": "u8" if arith == 2 else "f32",
-        "data": "synthetic",
+        "data": data_desc,
         "config": {
             "workload": workload,
+            "query_slices": nsl, "queries_per_slice": ses,
+            # scan grids of the device-chained rounds are sized from the previous search's counts (+ 12 %); a round that needs
+            # more runs on fewer workgroups than it would have been given (it is still complete: the workgroups stride)
+            "round_hint": {"launches_sized_by_a_hint": int(acc.get("hinted_launches", 0)), "hint_too_small": int(acc.get("short_hints", 0))},
             "in_flight": nfl, "host_wait": "blocking events" if os.environ.get("AUNCEL_AMD_BLOCKING_SYNC", "0") not in ("", "0") else "spin", "host_cores": host_cores(), "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "stagger_ms": stagger_s * 1e3,
             "scan_arith": {0: "fp32 reference order", 1: "fp32 fused", 2: "byte codes, v_mfma_i32_32x32x32_i8"}[arith],
             "nb": args.nb, "sigma": args.sigma, "multipler": chosen, "std_m": args.std_m,
@@ -582,7 +692,7 @@ def main():
             "recall_at_10_mean": float(rec.mean()), "recall_at_10_min": float(rec.min()),
             "recall_target_met_on_timed_half": bool(rec.mean() >= args.bound),
             "bound_guaranteed": bool(rec.min() >= args.bound),  # eval/bound.cpp:404-414 at the headline point
-            "nprobe_mean": float(my_np[ts:].mean()), "nprobe_max": int(my_np[ts:].max()),
+            "nprobe_mean": float(my_sl.mean()), "nprobe_max": int(my_sl.max()),
             "ndis_per_query": st["ndis"] / float(ses * args.steps),
         },
         # The list scan is bound by HBM: it streams every probed list once per round (shared by all the queries probing it)
@@ -659,12 +769,12 @@ def main():
         del codes, ids
         lists.struct = pyoracle.OrcIndex(lists.metric, d, nlist, pyoracle._s(lists.off), pyoracle._f(lists.codes), pyoracle._i(lists.ids))
         cores = host_cores()  # threads beyond a CPU quota only get throttled
-        xs = xq[ts:ts + S]
-        tun = pyoracle.Tuner(h.get_interdis(), traces, K, ts + ses, arcos=capi.arcos_table())
+        xs = xq[q_start:q_start + S]  # the slice the last timed step searched
+        tun = pyoracle.Tuner(h.get_interdis(), traces, K, nall, arcos=capi.arcos_table())
         stt = tun.struct(topk, req, chosen, args.std_m)
         tc = time.perf_counter()
         cd, ck = pyoracle.knn(pyoracle.METRIC_L2, xs, cen, nlist, nthreads=cores)
-        oD, oI, _ = pyoracle.search_preassigned(lists, xs, K, ck, cd, tuner=stt, offset=ts, nthreads=cores)
+        oD, oI, _ = pyoracle.search_preassigned(lists, xs, K, ck, cd, tuner=stt, offset=q_start, nthreads=cores)
         cpu_s = time.perf_counter() - tc
         # Two comparisons.  (1) the engine in the reference's exact regime: runs of bit-equal coarse distances ordered by
         # re-running the reference's heap (AUNCEL_AMD_COARSE_TIES=heap; the default for calls of fewer than 20 queries, where
@@ -675,20 +785,20 @@ def main():
         def same_as(oD_, oI_, onp_, D_, I_, np_):
             return bool(np.array_equal(oI_, I_) and np.array_equal(oD_, D_) and np.array_equal(onp_, np_))
 
-        timed_same = same_as(oD, oI, tun.my_nprobe[ts:ts + S], D[:S], I[:S], my_np[ts:ts + S])
-        timed_diff = int(((oI != I[:S]).any(1) | (oD != D[:S]).any(1) | (tun.my_nprobe[ts:ts + S] != my_np[ts:ts + S])).sum())
+        timed_same = same_as(oD, oI, tun.my_nprobe[q_start:q_start + S], D[:S], I[:S], my_np[q_start:q_start + S])
+        timed_diff = int(((oI != I[:S]).any(1) | (oD != D[:S]).any(1) | (tun.my_nprobe[q_start:q_start + S] != my_np[q_start:q_start + S])).sum())
         prev_ties = os.environ.get("AUNCEL_AMD_COARSE_TIES")
         os.environ["AUNCEL_AMD_COARSE_TIES"] = "heap"
         rows0 = h.coarse_tie_rows()
-        xnp, xtr = np.zeros(ts + ses, dtype=np.uint64), np.zeros(ts + ses, dtype=np.float32)
-        xD, xI = h.search_adaptive(ts, S, topk, chosen, args.std_m, req, xnp, xtr)
+        xnp, xtr = np.zeros(nall, dtype=np.uint64), np.zeros(nall, dtype=np.float32)
+        xD, xI = h.search_adaptive(q_start, S, topk, chosen, args.std_m, req, xnp, xtr)
         tie_rows = h.coarse_tie_rows() - rows0
         if prev_ties is None:
             del os.environ["AUNCEL_AMD_COARSE_TIES"]
         else:
             os.environ["AUNCEL_AMD_COARSE_TIES"] = prev_ties
-        xD, xI, xnp = xD.copy(), xI.copy(), xnp[ts:ts + S].copy()
-        same = same_as(oD, oI, tun.my_nprobe[ts:ts + S], xD, xI, xnp)
+        xD, xI, xnp = xD.copy(), xI.copy(), xnp[q_start:q_start + S].copy()
+        same = same_as(oD, oI, tun.my_nprobe[q_start:q_start + S], xD, xI, xnp)
         parity = {"exact_regime": "AUNCEL_AMD_COARSE_TIES=heap: runs of bit-equal coarse distances ordered by the reference's heap "
                                   "(the default below 20 queries per call)",
                   "coarse_rankings_with_such_runs": int(tie_rows), "queries": S,
@@ -697,20 +807,20 @@ def main():
                   "timed_configuration_queries_differing": timed_diff}
         if not same:
             log("PARITY MISMATCH vs the CPU restatement: rows differing in I / D / my_nprobe:", int((oI != xI).any(1).sum()),
-                int((oD != xD).any(1).sum()), int((tun.my_nprobe[ts:ts + S] != xnp).sum()), "of", S)
+                int((oD != xD).any(1).sum()), int((tun.my_nprobe[q_start:q_start + S] != xnp).sum()), "of", S)
         log(f"parity vs the CPU restatement on {S} queries: exact regime {same} ({tie_rows} rankings re-run through the heap); "
             f"timed configuration differs on {timed_diff} queries")
         # one thread: what the shipped reference does -- its IndexIVF.cpp cannot be built with OpenMP (Auncel/IndexIVF.cpp:484-486)
         # and eval/bound.cpp issues one search() per query
         S1 = min(64, S)
-        tun1 = pyoracle.Tuner(h.get_interdis(), traces, K, ts + ses, arcos=capi.arcos_table())
+        tun1 = pyoracle.Tuner(h.get_interdis(), traces, K, nall, arcos=capi.arcos_table())
         st1 = tun1.struct(topk, req, chosen, args.std_m)
         t1 = time.perf_counter()
         cd1, ck1 = pyoracle.knn(pyoracle.METRIC_L2, xs[:S1], cen, nlist, nthreads=1)
-        pyoracle.search_preassigned(lists, xs[:S1], K, ck1, cd1, tuner=st1, offset=ts, nthreads=1)
+        pyoracle.search_preassigned(lists, xs[:S1], K, ck1, cd1, tuner=st1, offset=q_start, nthreads=1)
         cpu1_s = time.perf_counter() - t1
         out["cpu_baseline"] = {"value": S / cpu_s, "unit": "queries/s", "cores": cores, "kind": "port",
-                               "sample": f"first {S} of the {ses} timed queries, same index, coarse + adaptive scan, OpenMP over queries",
+                               "sample": f"first {S} of the {ses} queries of the last timed step's slice, same index, coarse + adaptive scan, OpenMP over queries",
                                "gpu_matches_cpu_on_sample": same, "parity": parity,
                                "one_thread": {"value": S1 / cpu1_s, "unit": "queries/s", "cores": 1, "sample": f"first {S1} of the timed queries"}}
         log(f"cpu baseline: {S / cpu_s:.1f} q/s on {cores} threads, {S1 / cpu1_s:.1f} q/s on one (setup {time.time() - t0:.1f}s); "
@@ -722,16 +832,16 @@ def main():
         if refbench.available() and not args.no_ref:
             try:
                 t0 = time.time()
-                ro = refbench.run(cen, lists.off, lists.codes, lists.ids, traces, xs, ts, K, topk, args.bound, chosen, args.std_m,
+                ro = refbench.run(cen, lists.off, lists.codes, lists.ids, traces, xs, q_start, K, topk, args.bound, chosen, args.std_m,
                                   single_thread_queries=S1, threads=cores)
                 rnp = ro["my_nprobe"].astype(np.uint64)
                 same_ref = same_as(ro["D"], ro["I"], rnp, xD, xI, xnp)
                 parity_ref = dict(parity, timed_configuration_queries_differing=int(
-                    ((ro["I"] != I[:S]).any(1) | (ro["D"] != D[:S]).any(1) | (rnp != my_np[ts:ts + S])).sum()))
+                    ((ro["I"] != I[:S]).any(1) | (ro["D"] != D[:S]).any(1) | (rnp != my_np[q_start:q_start + S])).sum()))
                 port = out["cpu_baseline"]
                 out["cpu_baseline"] = {
                     "value": S / ro["seconds_all_threads"], "unit": "queries/s", "cores": ro["threads"], "kind": "reference",
-                    "sample": f"first {S} of the {ses} timed queries; the compiled reference (Auncel/*.cpp, -O3 -msse4) on the engine's "
+                    "sample": f"first {S} of the {ses} queries of the last timed step's slice; the compiled reference (Auncel/*.cpp, -O3 -msse4) on the engine's "
                               "lists / centroids / traces, one IndexIVF::search(1, ...) per query in tune mode, OpenMP over queries",
                     "gpu_matches_cpu_on_sample": same_ref, "parity": parity_ref,
                     "one_thread": {"value": ro["queries_one_thread"] / ro["seconds_one_thread"], "unit": "queries/s", "cores": 1,
@@ -745,6 +855,24 @@ def main():
                     f"{parity_ref['timed_configuration_queries_differing']})")
             except Exception as e:  # noqa: BLE001 -- the port's figures stay
                 log("reference harness not usable here:", repr(e))
+    if gt_check is not None:
+        out["config"]["ground_truth_file"] = gt_check
+    if world > 1:
+        # north_star's split next to the replicas: the inverted lists sharded by list id over the same N GPUs (BASELINE config 4,
+        # Auncel/IndexShards.cpp:261-311), fixed nprobe, run after the replica timing; one driver command records both
+        while len(ctxs) > 1:  # (the search contexts go before the index they were cloned from)
+            ctxs.pop()
+        del ctxs, h
+        torch.cuda.empty_cache()
+        sargs = argparse.Namespace(**vars(args))
+        sargs.test = 2 * ses  # the reference's 10 000-query batch
+        sl = run_shards(sargs, torch, dist, capi, rank, world, local, dev, red_dev)
+        if rank == 0 and sl is not None:
+            out["shards"] = {"metric": sl["metric"], "value": sl["value"], "unit": sl["unit"], "ms_per_step": sl["ms_per_step"],
+                             "scaling": sl["scaling"], "n_gpus": sl["n_gpus"], "nprobe": sargs.nprobe, "batch": sargs.test,
+                             "distances_sha256": sl["config"]["distances_sha256"], "recall_at_k_mean": sl["config"]["recall_at_k_mean"],
+                             "per_rank_ms_per_step": sl["config"]["per_rank_ms_per_step"],
+                             "shard_bytes_max_over_min": sl["config"]["shard_bytes_max_over_min"], "roofline": sl["roofline"]}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -97,6 +97,12 @@ int amd_ivf_distance_to_code(amd_ivf_t* h, const float* query, size_t list_no, s
 /* IndexIVFStats {nq, nlist, ndis, nheap_updates}  [IndexIVF.h:361-374, IndexIVF.cpp:731-734] */
 int amd_ivf_stats(amd_ivf_t* h, size_t stats[4], int reset);
 
+/* amd_ivf_coarse over resident queries [start, start + n) (coarse_dis may be NULL: keys only) */
+int amd_ivf_coarse_resident(amd_ivf_t* h, size_t start, size_t n, size_t nprobe, float* coarse_dis, int64_t* keys, int mode);
+/* search_preassigned over resident queries [start, start + n): the caller's keys (n x nprobe, host), the engine's lists.
+ * What a shard of an IndexShards runs when the coarse ranking was computed once, elsewhere. */
+int amd_ivf_search_resident_preassigned(amd_ivf_t* h, size_t start, size_t n, size_t k, size_t nprobe, const int64_t* keys, float* D,
+                                        int64_t* I);
 /* ---- resident query sets (Error_sys::set_queries keeps the query matrix and later searches
  *      slices of it, profile.cpp:173-227): upload once, search slices with data already in HBM */
 int amd_ivf_set_queries(amd_ivf_t* h, size_t n, const float* x);
@@ -240,6 +246,12 @@ int amd_ivf_last_scan_min_bytes(amd_ivf_t* h, double* bytes);
  *   AUNCEL_AMD_COARSE_TIES=heap: always re-run; =id: never.
  * *rows = rankings re-run so far on this handle. */
 int amd_ivf_coarse_tie_rows(amd_ivf_t* h, uint64_t* rows);
+/* Launch sizing of the last search.  The device-planned rounds are enqueued without reading anything back, so a scan's grid is
+ * sized from what the same round of the previous search of this shape needed (+ 12 %); its workgroups stride over the item
+ * count the planner left on the device, so a round that needs more is still complete -- it just runs on fewer workgroups than it
+ * would have been given.  out[0] = scan launches of the last search that were sized by such a hint, out[1] = those whose hint
+ * was too small. */
+int amd_ivf_last_round_hints(amd_ivf_t* h, uint64_t out[2]);
 /* Selection diagnostics of the last search on this handle.  The k best of a query are kept as a sorted array (same
  * admissions as the reference's heap, Auncel/Heap.h:88-142); a query in which equal distances met -- the only case in which
  * the heap's history decides an id or an output order -- gets its result from the reference's heap replayed over the query's

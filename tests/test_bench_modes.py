@@ -34,3 +34,50 @@ def test_shards_mode_two_ranks_equals_one():
     assert two["config"]["shard_bytes_max_over_min"] < 1.2
     for j in (one, two):
         assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] <= 1.0
+        rows = j["config"]["per_rank_ms_per_step"]["rows"]
+        assert len(rows) == j["n_gpus"] and all(len(r) == 4 for r in rows)
+    # the coarse ranking is computed once: each of the two ranks ranks its half of the batch
+    assert sum(r[0] for r in two["config"]["per_rank_ms_per_step"]["rows"]) / 2 < 0.9 * one["config"]["per_rank_ms_per_step"]["rows"][0][0] + 0.05
+
+
+@pytest.mark.gpu
+def test_default_mode_two_ranks_records_both_splits(tmp_path):
+    """the command the driver issues for N > 1 (no --mode): replicas of the adaptive search, and behind them the list-id shards of
+    north_star / BASELINE config 4 as a `shards` block of the same line; query slices rotate; real-data files are taken when given"""
+    small = ["--nb", "200000", "--nlist", "1024", "--train", "500", "--test", "500", "--blobs", "500", "--steps", "4", "--warmup", "1",
+             "--no-cpu", "--no-legs", "--kmeans", "torch", "--in-flight", "2"]
+    port = 29900 + os.getpid() % 90
+    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(port), "bench.py", "--gpus", "2"] + small, {"BENCH_DIST_BACKEND": "gloo", "BENCH_DEVICE": "0"})
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["data"] == "synthetic"
+    assert two["config"]["query_slices"] == 4 and "round_hint" in two["config"]
+    sh = two["shards"]
+    assert sh["n_gpus"] == 2 and sh["scaling"] == "strong" and sh["value"] > 0 and len(sh["distances_sha256"]) == 64
+    assert len(sh["per_rank_ms_per_step"]["rows"]) == 2 and sh["roofline"]["bound"] == "hbm"
+
+
+@pytest.mark.gpu
+def test_bench_takes_real_data_files(tmp_path):
+    """--data DIR: base / query / ground-truth files in the harness's layouts go through the same pipeline"""
+    import numpy as np
+    rs = np.random.RandomState(11)
+    cen = rs.randint(0, 160, size=(200, 32))
+    xb = np.clip(cen[rs.randint(0, 200, 60000)] + rs.randn(60000, 32) * 20, 0, 255).astype(np.uint8)
+    xq = np.clip(cen[rs.randint(0, 200, 1200)] + rs.randn(1200, 32) * 20, 0, 255).astype(np.uint8)
+    for name, x in (("sift_base.u8bin", xb), ("sift_query.u8bin", xq)):
+        with open(tmp_path / name, "wb") as f:
+            np.array(x.shape, dtype=np.int32).tofile(f)
+            x.tofile(f)
+    # exact ground truth ids (.ivecs) for the first 300 queries
+    xbf, xqf = xb.astype(np.float32), xq[:300].astype(np.float32)
+    dist = (xqf ** 2).sum(1)[:, None] + (xbf ** 2).sum(1)[None, :] - 2 * xqf @ xbf.T
+    gt = np.argsort(dist, axis=1, kind="stable")[:, :100].astype(np.int32)
+    rows = np.empty((300, 101), dtype=np.int32)
+    rows[:, 0] = 100
+    rows[:, 1:] = gt
+    rows.tofile(tmp_path / "sift_groundtruth.ivecs")
+    j = _run([sys.executable, "bench.py", "--data", str(tmp_path), "--nlist", "1024", "--train", "500", "--test", "300", "--steps", "3",
+              "--warmup", "1", "--no-cpu", "--no-legs", "--kmeans", "torch", "--in-flight", "1"], {})
+    assert j["data"].startswith("real: sift_base.u8bin") and j["dtype"] == "u8"
+    assert j["config"]["nb"] == 60000 and j["config"]["query_slices"] == 2
+    assert j["config"]["ground_truth_file"]["agrees_with_brute_force"] is True
