@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
@@ -251,6 +252,7 @@ struct amd_ivf {
     std::vector<uint32_t> round_hint;  // [round][16]
     uint64_t hint_sig = 0;
     uint64_t hinted_rounds = 0, short_rounds = 0;  // last search: scan launches sized by a hint / of those, grids smaller than the work
+    std::atomic<int> live_contexts{1};  // on the index owner: itself + its clones (amd_ivf_clone / amd_ivf_destroy)
     bool force_heap_select = false;  // (set while a search is repeated after ERR_LOG_OVERFLOW)
     // tune / train search over a coarse ranking the caller supplies (amd_ivf_search_adaptive_pre, amd_ivf_train_samples_pre):
     // host rows of this call's (or slice's) queries, given_nprobe entries each; null: the engine ranks the centroids itself
@@ -1530,8 +1532,37 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         h->timer.end(t, s);
     };
 
-    bool fix_pending = false;
+    bool fix_pending = false, sorted_any = false;
     size_t last_fix_round = 0;
+    // tie_fix_kernel: behind every round on a side stream when this context has the GPU to itself (latency), one pass at the end
+    // when the index has several search contexts (their kernels fill the GPU while it runs; more streams would only crowd the
+    // hardware queues)
+    static const char* fix_env = getenv("AUNCEL_AMD_TIE_FIX");
+    const bool eager_fix = fix_env ? !strcmp(fix_env, "eager") : I->live_contexts.load() <= 1;
+    auto tie_fix_args = [&](uint32_t round, int final_pass) {
+        TieFixArgs ta{};
+        ta.metric = h->metric;
+        ta.k = base.k;
+        ta.nq = (uint32_t)n;
+        ta.nlist = (uint32_t)nlist;
+        ta.log = h->w_log.as<uint2>();
+        ta.log_cap = (uint32_t)log_cap;
+        ta.round = round;
+        ta.final_pass = final_pass;
+        ta.log_cnt = h->w_log_cnt.as<uint32_t>();
+        ta.log_snap = h->w_log_snap.as<uint32_t>();
+        ta.fin_round = h->w_fin_round.as<uint32_t>();
+        ta.fix_val = h->w_fix_val.as<float>();
+        ta.fix_ref = h->w_fix_ref.as<int64_t>();
+        ta.fix_pos = h->w_fix_pos.as<uint32_t>();
+        ta.tie_flag = h->w_tie_flag.as<uint32_t>();
+        ta.list_off = I->d_list_off.as<uint64_t>();
+        ta.ids = I->d_ids.as<int64_t>();
+        ta.store_pairs = base.store_pairs;
+        ta.D = h->w_D.as<float>();
+        ta.I = h->w_I.as<int64_t>();
+        return ta;
+    };
     // ---- ordered selection of a scanned round.  nact: active queries (sync) or the bound n with the count on the device.
     auto enqueue_replay = [&](bool thr_mode, uint32_t nact, bool on_device, size_t round) {
         ReplayArgs ra{};
@@ -1589,7 +1620,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         }
         const bool sorted_now = replay_sorted_applies(ra);
         // (tie_fix_kernel of round - 2 read the log counts this round's selection is about to overwrite)
-        if (sorted_now && round >= 2) HIP_CHECK(hipStreamWaitEvent(s, h->ev_fix[round & 1], 0));
+        if (sorted_now && eager_fix && round >= 2) HIP_CHECK(hipStreamWaitEvent(s, h->ev_fix[round & 1], 0));
         static const bool dbg_replay_dev = getenv("AUNCEL_AMD_DEBUG_REPLAY") != nullptr;
         if (dbg_replay_dev) {
             h->w_misc.ensure((size_t)nact * 64);
@@ -1601,7 +1632,8 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             launch_replay(ra, s);
             h->timer.end(t, s);
         }
-        if (sorted_now) {
+        sorted_any = sorted_any || sorted_now;
+        if (sorted_now && eager_fix) {
             // the reference's heap over what this round admitted (and the results of the flagged queries that finished in it), on
             // a side stream: it runs under the next round's scan and selection
             if (!h->fix_stream) {
@@ -1609,25 +1641,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
                 HIP_CHECK(hipEventCreateWithFlags(&h->ev_sel, hipEventDisableTiming));
                 for (int i = 0; i < 2; i++) HIP_CHECK(hipEventCreateWithFlags(&h->ev_fix[i], hipEventDisableTiming));
             }
-            TieFixArgs ta{};
-            ta.metric = h->metric;
-            ta.k = base.k;
-            ta.nq = (uint32_t)n;
-            ta.nlist = (uint32_t)nlist;
-            ta.log = h->w_log.as<uint2>();
-            ta.log_cap = (uint32_t)log_cap;
-            ta.round = (uint32_t)round;
-            ta.log_snap = h->w_log_snap.as<uint32_t>();
-            ta.fin_round = h->w_fin_round.as<uint32_t>();
-            ta.fix_val = h->w_fix_val.as<float>();
-            ta.fix_ref = h->w_fix_ref.as<int64_t>();
-            ta.fix_pos = h->w_fix_pos.as<uint32_t>();
-            ta.tie_flag = h->w_tie_flag.as<uint32_t>();
-            ta.list_off = I->d_list_off.as<uint64_t>();
-            ta.ids = I->d_ids.as<int64_t>();
-            ta.store_pairs = base.store_pairs;
-            ta.D = h->w_D.as<float>();
-            ta.I = h->w_I.as<int64_t>();
+            TieFixArgs ta = tie_fix_args((uint32_t)round, 0);
             HIP_CHECK(hipEventRecord(h->ev_sel, s));
             HIP_CHECK(hipStreamWaitEvent(h->fix_stream, h->ev_sel, 0));
             size_t t = h->timer.begin(CAT_SELECT, h->fix_stream);
@@ -1759,6 +1773,11 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         }
     }
     if (fix_pending) HIP_CHECK(hipStreamWaitEvent(s, h->ev_fix[last_fix_round & 1], 0));  // the last round's tie_fix_kernel
+    if (sorted_any && !eager_fix) {
+        size_t t = h->timer.begin(CAT_SELECT, s);
+        launch_tie_fix(tie_fix_args(0, 1), s);
+        h->timer.end(t, s);
+    }
     if (!base.caller_checks_error) check_device_error(h);
     if (chained) {  // the bookkeeping counters of the last round (bytes, slots) have not been read yet; nor has the history
         const size_t nh = std::min(planned_rounds ? planned_rounds - 1 : 0, MAX_HIST);
@@ -1932,6 +1951,7 @@ int amd_ivf_clone(amd_ivf_t* h, amd_ivf_t** out) {
     c->allow_fused = owner->allow_fused;
     c->allow_bytes = owner->allow_bytes;
     c->stream = make_main_stream();
+    owner->live_contexts.fetch_add(1);
     *out = c.release();
     API_END
 }
@@ -1940,6 +1960,7 @@ int amd_ivf_destroy(amd_ivf_t* h) {
     API_BEGIN
     if (h) {
         use_device(h);
+        if (h->is_clone && h->parent) h->parent->live_contexts.fetch_sub(1);
         delete h;
     }
     API_END

@@ -247,6 +247,8 @@ struct TieFixArgs {
     const uint2* log;
     uint32_t log_cap;
     uint32_t round;              // the selection round this launch follows
+    int final_pass;              // 1: one launch at the end of the search instead of one per round: every flagged query, whole log
+    const uint32_t* log_cnt;     // [nq] (final pass)
     const uint32_t* log_snap;    // [2][nq]
     const uint32_t* fin_round;   // [nq]
     float* fix_val;              // [nq][k] the reference's heap (node order) as far as the log has been replayed

@@ -1610,8 +1610,10 @@ void launch_replay(const ReplayArgs& a, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------------
 // The reference's heap (Heap.h:88-142), replayed over the admission logs: every log entry was admitted, in this order, so
-// each is one heap_pop + heap_push.  Launched behind every selection round, on a side stream, so that it runs under the next
-// round's scan and selection:
+// each is one heap_pop + heap_push.  Either one launch at the end of the search over the flagged queries (final_pass: several
+// search contexts share the GPU, whose other work hides it), or one behind every selection round, on a side stream, so that it
+// runs under the next round's scan and selection (a lone context: what is left for the end of the search is the last round's
+// handful of entries):
 //   a query still searching          the entries the round added are replayed and the heap (node order) is saved;
 //   a query that finished this round if the selection flagged it (equal values met: the only case in which the heap's history
 //                                    decides an id or an output order), the rest of its log is replayed, then heap_reorder
@@ -1624,13 +1626,21 @@ __global__ __launch_bounds__(256) void tie_fix_kernel(TieFixArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t qi = blockIdx.x * 4 + wave;
     if (qi >= a.nq) return;
-    const uint32_t fin_r = a.fin_round[qi];
-    if (fin_r < a.round) return;                        // finished in an earlier round: dealt with then
-    const bool fin = fin_r == a.round;
-    if (fin && a.tie_flag[qi] != 1) return;             // finished now, and its sorted array is the result
+    bool fin;
+    uint32_t n;
     const uint32_t pos = a.fix_pos[qi];
-    const uint32_t n = a.log_snap[(size_t)(a.round & 1u) * a.nq + qi];
-    if (!fin && n <= pos) return;                       // nothing new to replay
+    if (a.final_pass) {
+        if (a.tie_flag[qi] != 1) return;                // (its sorted array is the result, or it was dealt with in its round)
+        fin = true;
+        n = a.log_cnt[qi];
+    } else {
+        const uint32_t fin_r = a.fin_round[qi];
+        if (fin_r < a.round) return;                    // finished in an earlier round: dealt with then
+        fin = fin_r == a.round;
+        if (fin && a.tie_flag[qi] != 1) return;         // finished now, and its sorted array is the result
+        n = a.log_snap[(size_t)(a.round & 1u) * a.nq + qi];
+        if (!fin && n <= pos) return;                   // nothing new to replay
+    }
     const int k = KC ? KC : a.k;
     unsigned char* base = smem + (size_t)wave * (((size_t)k * 12 + 15) & ~(size_t)15);
     int64_t* href = reinterpret_cast<int64_t*>(base);
