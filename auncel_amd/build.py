@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libauncel_amd.so")
-SOURCES = ["ivf_kernels.hip", "ivf_select.hip", "dataset_io.cpp", "ivf_plan.hip", "ivf_kmeans.hip", "ivf_engine.hip"]
+SOURCES = ["ivf_kernels.hip", "ivf_select.hip", "ivf_filter.hip", "dataset_io.cpp", "ivf_plan.hip", "ivf_kmeans.hip", "ivf_engine.hip"]
 # -ffp-contract=off: products and sums are rounded separately, as in the reference's SSE build
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result"]
 

@@ -214,6 +214,12 @@ struct amd_ivf {
     DevBuf d_frag, d_cy, d_block_off;
     std::vector<uint64_t> h_block_off;
     bool have_codes8 = false;
+    // fp32 copy of the lists in fragment order + |y|^2 / |y| per slot (ivf_filter.hip), kept when the data does not qualify for
+    // byte codes: threshold rounds run as a matrix-core filter over it, the exact distance only for what the filter keeps
+    DevBuf d_frag32, d_yn;
+    bool have_frag32 = false;
+    int allow_filter = 1;
+    DevBuf w_xf, w_xn, w_surv, w_surv_cnt;  // packed queries + norms of the current search, the filter's survivors
 
     // Auncel state
     DevBuf d_interdis;
@@ -364,12 +370,25 @@ void upload_lists(amd_ivf* h) {
     HIP_CHECK(hipMemcpyAsync(h->d_list_off.p, h->h_list_off.data(), (h->nlist + 1) * sizeof(uint64_t),
                              hipMemcpyHostToDevice, h->stream));
     h->have_codes8 = h->allow_bytes && nt > 0 && h->db_range.bytes() && (double)h->d * 255.0 * 255.0 < 2147483648.0;
-    if (h->have_codes8) {
+    h->have_frag32 = !h->have_codes8 && h->allow_filter && nt > 0 && nt < 0xffffffffull;
+    if (h->have_codes8 || h->have_frag32) {
         h->h_block_off.assign(h->nlist + 1, 0);
         for (size_t l = 0; l < h->nlist; l++) h->h_block_off[l + 1] = h->h_block_off[l] + mfma_list_blocks(h->h_ids[l].size());
-        const uint64_t nblk = h->h_block_off[h->nlist];
         h->d_block_off.ensure((h->nlist + 1) * sizeof(uint64_t));
         HIP_CHECK(hipMemcpyAsync(h->d_block_off.p, h->h_block_off.data(), (h->nlist + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+    }
+    if (h->have_frag32) {
+        const uint64_t nblk = h->h_block_off[h->nlist];
+        h->d_frag32.ensure(nblk * filter_steps(h->d) * 1024);
+        h->d_yn.ensure(nblk * 32 * sizeof(float));
+        launch_frag32_from_f32(h->d_codes.as<float>(), h->d_list_off.as<uint64_t>(), h->d_block_off.as<uint64_t>(), (uint32_t)h->nlist, nblk, h->d,
+                               h->dpad, h->metric, h->d_frag32.as<float>(), h->d_yn.as<float>(), h->stream);
+    } else {
+        h->d_frag32.release();
+        h->d_yn.release();
+    }
+    if (h->have_codes8) {
+        const uint64_t nblk = h->h_block_off[h->nlist];
         h->d_frag.ensure(nblk * mfma_ksteps(h->d) * 1024);
         h->d_cy.ensure(nblk * 32 * sizeof(int32_t));
         launch_frag_from_f32(h->d_codes.as<float>(), h->d_list_off.as<uint64_t>(), h->d_block_off.as<uint64_t>(), (uint32_t)h->nlist, nblk, h->d,
@@ -395,6 +414,14 @@ bool byte_queries(amd_ivf* ws, const amd_ivf* index, const float* d_x, size_t n,
     ws->x8_n = n;
     ws->x8_gen = ws->resident_gen;
     return true;
+}
+
+// fp32 searches: threshold rounds as matrix-core filter + exact rescoring (ivf_filter.hip) when the index keeps the
+// fragment-ordered fp32 copy.  AUNCEL_AMD_FILTER=0 (read per search: the tests run both ways) keeps scan_tiles_kernel throughout.
+bool filter_available(const amd_ivf* ws, const amd_ivf* index, bool bytes) {
+    const char* e = getenv("AUNCEL_AMD_FILTER");
+    if (e && atoi(e) == 0) return false;
+    return !bytes && index->have_frag32 && ws->allow_filter;
 }
 
 // copy n x d host rows into a device matrix with row stride dpad (zero padded)
@@ -1193,9 +1220,12 @@ void search_fixed_device(amd_ivf* h, const float* d_x, size_t n, size_t k, size_
     const char* two_s = getenv("AUNCEL_AMD_FIXED_ROUNDS");  // read per call: the tests run both ways in one process
     const int two_env = two_s ? atoi(two_s) : 0;
     // a handful of queries: the second round's planning + synchronisation costs more than threshold mode saves
-    const bool two = two_env ? two_env == 2 : nprobe >= 16 && n * nprobe >= 4096;
+    // (fp32 lists with the matrix-core filter: a threshold round costs its list bytes, not its distances -- one dense probe gives
+    // the thresholds, everything else goes through the filter)
+    const bool filt = filter_available(h, ix(h), base.bytes);
+    const bool two = two_env ? two_env == 2 : filt ? (nprobe >= 4 && n * nprobe >= 1024) : (nprobe >= 16 && n * nprobe >= 4096);
     base.fixed_two = two;
-    const size_t first = two ? std::max<size_t>(1, nprobe / 8) : nprobe;
+    const size_t first = two ? (filt ? 1 : std::max<size_t>(1, nprobe / 8)) : nprobe;
     base.caller_checks_error = true;
     with_select_fallback(h, [&] {
         if (h->force_heap_select) init_state(h, n, k, false);
@@ -1295,9 +1325,10 @@ TunerDev make_tuner(amd_ivf* h, size_t query_topk, float multipler, float std_m,
 // look at all.
 // Synchronous (range search, time-bounded search, AUNCEL_AMD_SYNC_ROUNDS=1): one read-back per round; the range search lays
 // out its results and the time-bounded search reads the clock between rounds.
-void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first_round, size_t total_nprobe,
+void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first_round_in, size_t total_nprobe,
                        const unsigned long long* d_np_abs /* may be null */) {
     amd_ivf* I = ix(h);
+    size_t first_round = first_round_in;
     const size_t nlist = h->nlist;
     hipStream_t s = h->stream;
     static const bool sync_env = getenv("AUNCEL_AMD_SYNC_ROUNDS") != nullptr || getenv("AUNCEL_AMD_DEBUG_REPLAY") != nullptr;
@@ -1305,7 +1336,11 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     // over-scan against rounds: the byte-code scan is bound by its one pass over the lists, not by the pairs it computes, so
     // its rounds grow fast (12 -> 144 -> all); the fp32 scans pay for every distance (12 -> 42 -> 147)
     static const double grow_env = getenv("AUNCEL_AMD_ROUND_GROW") ? atof(getenv("AUNCEL_AMD_ROUND_GROW")) : 0.0;
-    const double grow = grow_env > 0 ? grow_env : base.bytes ? 12.0 : 3.5;
+    // fp32 lists with the matrix-core filter (ivf_filter.hip): threshold rounds cost their list bytes too, and the first round --
+    // the only one computed on the vector ALU in the reference's rounding sequence -- shrinks to one probe per query
+    const bool filter_ok = filter_available(h, I, base.bytes) && !base.range;
+    if (filter_ok && base.tuner.enabled) first_round = 1;
+    const double grow = grow_env > 0 ? grow_env : (base.bytes || filter_ok) ? 12.0 : 3.5;
     // pairs of a round: the packed query tiles of the fp32 scans (8 queries x dpad floats per group) must fit 4 GiB
     size_t seg_cap = (size_t)2 << 20;
     if (!base.bytes) {
@@ -1326,6 +1361,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     size_t budget = budget_env ? budget_env : std::max<size_t>(h->dist_budget_floats, (size_t)2 << 30);
     if (all_rows < (double)budget) budget = (size_t)all_rows + 64;
     budget = std::max<size_t>(budget, I->h_list_off[nlist] + 1024 * nlist + 1024);
+    if (filter_ok && budget > ((size_t)1 << 31)) budget = (size_t)1 << 31;  // (the filter's survivor entries hold 32-bit row positions)
     if (base.bytes && budget > ((size_t)1 << 31)) throw std::runtime_error("distance rows beyond 2^31 floats (byte-code scan offsets are 32-bit)");
     static const bool no_thr = getenv("AUNCEL_AMD_NO_THRESHOLD") != nullptr;
     h->w_pl_pad.ensure(n * 4);
@@ -1369,7 +1405,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     pa.slot_base = 0;
     pa.first_round = (uint32_t)first_round;
     static const size_t inc_env = getenv("AUNCEL_AMD_ROUND_INC") ? (size_t)atoi(getenv("AUNCEL_AMD_ROUND_INC")) : 0;
-    pa.min_inc = (uint32_t)(inc_env ? inc_env : first_round);
+    pa.min_inc = (uint32_t)(inc_env ? inc_env : filter_ok && base.tuner.enabled ? 12 : first_round);
     pa.tune = base.tuner.enabled;
     pa.d = h->d;
     pa.multipler = base.tuner.multipler;
@@ -1390,6 +1426,14 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     if (base.bytes) {
         pa.mfma_chunk = mfma_chunk();
         pa.block_off = I->d_block_off.as<uint64_t>();
+    }
+    constexpr size_t SURV_CAP = (size_t)8 << 20;
+    if (filter_ok) {
+        h->w_xf.ensure(n * (size_t)filter_steps(h->d) * 8 * sizeof(float));
+        h->w_xn.ensure(n * sizeof(float));
+        h->w_surv.ensure(SURV_CAP * sizeof(uint4));
+        h->w_surv_cnt.ensure(4);
+        launch_filter_queries(base.d_x, n, h->d, h->dpad, h->metric, h->w_xf.as<float>(), h->w_xn.as<float>(), s);
     }
     pa.seg_begin = h->w_seg_begin.as<uint32_t>();
     pa.dist_base = h->w_pl_dist_base.as<unsigned long long>();
@@ -1447,6 +1491,13 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     auto plan_round = [&](size_t round_len) {
         pa.round_len = (uint32_t)round_len;
         pa.dense_round = !(base.range || (planned_rounds > 0 && !no_thr));
+        if (filter_ok) {  // threshold rounds of an fp32 search: items in the matrix-core form (a chunk x a block of 32 queries)
+            const bool mf = !pa.dense_round;
+            pa.mfma_chunk = mf ? mfma_chunk() : 0;
+            pa.block_off = mf ? I->d_block_off.as<uint64_t>() : nullptr;
+            pa.qblock = scan_qblock(mf);
+            pa.row_bytes = (uint32_t)h->dpad * 4;
+        }
         pa.history = chained && planned_rounds >= 1 && planned_rounds <= MAX_HIST ? h->w_pl_hist.as<uint32_t>() + (planned_rounds - 1) * 16 : nullptr;
         launch_plan(pa, s);
         planned_rounds++;
@@ -1483,6 +1534,36 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             HIP_CHECK(hipEventRecord(h->ev_fork, s));
             HIP_CHECK(hipStreamWaitEvent(h->aux[3], h->ev_fork, 0));
             launch_scan_mfma(ma, h->aux[3]);
+            HIP_CHECK(hipEventRecord(h->ev_join[3], h->aux[3]));
+            HIP_CHECK(hipStreamWaitEvent(s, h->ev_join[3], 0));
+        } else if (filter_ok && thr_mode) {
+            FilterScanArgs fa{};
+            fa.codes_frag = I->d_frag32.as<float>();
+            fa.yn = I->d_yn.as<float>();
+            fa.xf = h->w_xf.as<float>();
+            fa.xn = h->w_xn.as<float>();
+            fa.codes = I->d_codes.as<float>();
+            fa.queries = base.d_x;
+            fa.items = h->w_items.as<ScanItem>();
+            fa.pair_query = h->w_pair_query.as<uint32_t>();
+            fa.pair_out = h->w_pair_out.as<uint64_t>();
+            fa.dist = h->w_dist.as<float>();
+            fa.thr = h->w_thr.as<float>();
+            fa.mask = h->w_mask.as<unsigned long long>();
+            fa.surv = h->w_surv.as<uint4>();
+            fa.surv_count = h->w_surv_cnt.as<uint32_t>();
+            fa.surv_cap = (uint32_t)SURV_CAP;
+            fa.d = h->d;
+            fa.dpad = h->dpad;
+            fa.metric = h->metric;
+            fa.xcd_chunks = xcd_off ? 0 : 1;
+            fa.nitems = counts ? counts[CNT_QG8] : 0;
+            fa.dev_nitems = counts ? nullptr : dcnt + CNT_QG8;
+            fa.hint_nitems = hint_of(round, CNT_QG8);
+            HIP_CHECK(hipMemsetAsync(h->w_surv_cnt.p, 0, 4, s));
+            HIP_CHECK(hipEventRecord(h->ev_fork, s));
+            HIP_CHECK(hipStreamWaitEvent(h->aux[3], h->ev_fork, 0));
+            launch_scan_filter(fa, h->aux[3]);
             HIP_CHECK(hipEventRecord(h->ev_join[3], h->aux[3]));
             HIP_CHECK(hipStreamWaitEvent(s, h->ev_join[3], 0));
         } else {

@@ -1,0 +1,317 @@
+// gfx950 (MI355X, CDNA4): the fp32 list scan of threshold rounds as a filter on the matrix cores + exact rescoring.
+//
+// The reference's distance (Auncel/utils_simd.cpp:391-443: four running fp32 sums, products and sums rounded separately) is
+// a rounding *sequence* the matrix cores cannot produce, and computing it for every (query, vector) pair binds the fp32 scan
+// to the vector ALU (scan_tiles_kernel: 3 packed instructions per 2 elements).  In a threshold round only the candidates
+// that beat the query's threshold matter -- typically a per cent of the pairs.  So:
+//   1. scan_filter_kernel   x.y of 32 queries x 32 vectors per v_mfma_f32_32x32x2_f32 chain, lists streamed once from a
+//                           fragment-ordered fp32 copy (coalesced 16-byte loads, no LDS); with the exact |x|^2, |y|^2 this
+//                           gives the distance up to a rigorous error bound eps(x, y) (below); a candidate is kept iff even
+//                           its most favourable value, approx -/+ eps, beats the threshold.  Kept candidates get their mask
+//                           bit and an entry in the survivor list.
+//   2. rescore_kernel       one lane per survivor: the reference's own rounding sequence on the two fp32 rows; the exact
+//                           distance goes into the distance row.  A survivor whose exact distance does not beat the threshold
+//                           keeps its mask bit: the selection re-tests every candidate against the query's current worst
+//                           value anyway, so it costs a comparison, never a wrong result.
+// Nothing the selection sees differs from what scan_tiles_kernel would have written for the candidates that can enter.
+//
+// Error bound (u = 2^-24; S = |x|^2 + |y|^2; all norms accumulated in double and rounded once):
+//   reference value r vs the real distance D:  |r - D| <= (d/4 + 4) u * 2 S        (L2: d/4 + 3 roundings per running sum, all
+//                                                                                  terms >= 0 and <= 2 S in total)
+//   MFMA dot product p vs x.y:                  |p - x.y| <= d u |x||y| <= d u S / 2   (any order of fp32 fused steps)
+//   approx = xn + yn - 2 p in fp32:             three more roundings, each <= u * 2 S
+//   =>  |approx - r| <= (1.5 d + 20) u S.  The kernel uses C = (2 d + 32) u (a quarter more, and the rounding of the test
+//   itself) and keeps iff (1 - C)(xn + yn) - 2 p < thr.  Inner product: |p - r| <= 2 d u |x||y|; kept iff p + C |x||y| > thr.
+#include "ivf_dev.h"
+
+#include <algorithm>
+#include <stdexcept>
+#include <stdlib.h>
+#include <string>
+#include <type_traits>
+#include <utility>
+
+namespace amdivf {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------
+// fp32 lists (CSR rows, row stride dpad) -> fragment order: a list is a run of 32-vector blocks (block_off[l] = its first, an
+// even number of them as for the byte codes); a block is filter_steps(d) pieces of 64 lanes x 16 bytes, lane (v = l & 31,
+// h = l >> 5) of piece j holding elements 8 j + 4 h .. + 3 of vector v (zero beyond d).  yn[slot] = |y|^2 (L2) or |y| (IP).
+__global__ __launch_bounds__(64) void frag32_from_f32_kernel(const float* codes, const uint64_t* list_off, const uint64_t* block_off, uint32_t nlist,
+                                                             int d, int dpad, int metric, float* out, float* yn) {
+    const uint64_t blk = blockIdx.x;
+    const int lane = threadIdx.x, v = lane & 31, h = lane >> 5;
+    uint32_t lo = 0, hi = nlist;  // largest l with block_off[l] <= blk
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (block_off[mid] <= blk) lo = mid;
+        else hi = mid;
+    }
+    const uint64_t pos = (blk - block_off[lo]) * 32 + v, size = list_off[lo + 1] - list_off[lo];
+    const bool ok = pos < size;
+    const float* src = codes + (list_off[lo] + (ok ? pos : 0)) * (uint64_t)dpad;
+    const int J = (int)filter_steps(d);
+    double sq = 0.0;
+    for (int j = 0; j < J; j++) {
+        v4f piece;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const int c = 8 * j + 4 * h + w;
+            const float val = ok && c < d ? src[c] : 0.f;
+            piece[w] = val;
+            sq += (double)val * (double)val;
+        }
+        *reinterpret_cast<v4f*>(out + (blk * (uint64_t)J + (uint64_t)j) * 256 + (uint64_t)lane * 4) = piece;
+    }
+    sq += __shfl_xor(sq, 32);
+    if (h == 0) yn[blk * 32 + v] = !ok ? 0.f : metric == METRIC_L2 ? (float)sq : (float)sqrt(sq);
+}
+
+void launch_frag32_from_f32(const float* codes, const uint64_t* list_off, const uint64_t* block_off, uint32_t nlist, uint64_t nblocks, int d,
+                            int dpad, int metric, float* out, float* yn, hipStream_t s) {
+    if (nblocks == 0) return;
+    LAUNCH(frag32_from_f32_kernel, dim3((unsigned)nblocks), dim3(64), 0, s, codes, list_off, block_off, nlist, d, dpad, metric, out, yn);
+}
+
+// query rows (stride dpad) -> rows of 8 J floats (zero beyond d) + |x|^2 (L2) or |x| (IP); one wave per row
+__global__ __launch_bounds__(256) void filter_queries_kernel(const float* x, size_t n, int d, int dpad, int metric, float* xf, float* xn) {
+    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const int stride = (int)filter_steps(d) * 8;
+    double sq = 0.0;
+    for (int c = lane; c < stride; c += 64) {
+        const float val = c < d ? x[row * (size_t)dpad + c] : 0.f;
+        xf[row * (size_t)stride + c] = val;
+        sq += (double)val * (double)val;
+    }
+    for (int off = 32; off; off >>= 1) sq += __shfl_xor(sq, off);
+    if (lane == 0) xn[row] = metric == METRIC_L2 ? (float)sq : (float)sqrt(sq);
+}
+
+void launch_filter_queries(const float* x, size_t n, int d, int dpad, int metric, float* xf, float* xn, hipStream_t s) {
+    if (n == 0) return;
+    LAUNCH(filter_queries_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, x, n, d, dpad, metric, xf, xn);
+}
+
+// ---------------------------------------------------------------------------------------------
+// the reference's distance between two fp32 rows (utils_simd.cpp:391-443): sums 0..3 over elements 4 i + l, products and sums
+// rounded separately (this file is built with -ffp-contract=off), (s0 + s1) + (s2 + s3); rows are zero-padded to dpad (% 4)
+template <int METRIC> __device__ __forceinline__ float exact_distance(const float* x, const float* y, int dpad) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int c = 0; c < dpad; c += 4) {
+        const v4f a = *reinterpret_cast<const v4f*>(x + c), b = *reinterpret_cast<const v4f*>(y + c);
+        if (METRIC == METRIC_L2) {
+            const float t0 = b.x - a.x, t1 = b.y - a.y, t2 = b.z - a.z, t3 = b.w - a.w;
+            s0 += t0 * t0;
+            s1 += t1 * t1;
+            s2 += t2 * t2;
+            s3 += t3 * t3;
+        } else {
+            s0 += b.x * a.x;
+            s1 += b.y * a.y;
+            s2 += b.z * a.z;
+            s3 += b.w * a.w;
+        }
+    }
+    return (s0 + s1) + (s2 + s3);
+}
+
+// one lane per survivor of the filter: exact distance into the distance row
+template <int METRIC> __global__ __launch_bounds__(256) void rescore_kernel(FilterScanArgs a) {
+    const uint32_t n = *a.surv_count < a.surv_cap ? *a.surv_count : a.surv_cap;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint4 e = a.surv[i];  // (distance row position, query row, vector, -)
+        a.dist[e.x] = exact_distance<METRIC>(a.queries + (size_t)e.y * a.dpad, a.codes + (size_t)e.z * a.dpad, a.dpad);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One wave = one work item as in scan_mfma_kernel: up to 32 queries probing a list x a chunk of consecutive vectors of it.
+// A operand: the queries' rows (lane (m, h): elements 8 j + 4 h .. + 3 of query m, piece j), resident in registers when
+// NJ != 0 (d <= 128), re-read from the (L2-resident) packed query matrix otherwise; B operand: the list in fragment order,
+// P pieces in flight.  Piece j feeds four v_mfma_f32_32x32x2_f32 (element i of both 4-vectors: k = lane half).
+template <int METRIC, int NJ> __global__ __launch_bounds__(256) void scan_filter_kernel(FilterScanArgs a) {
+    __shared__ float s_u[4][32];
+    __shared__ float s_c[4][32];
+    __shared__ uint32_t s_row[4][32];
+    __shared__ uint32_t s_q[4][32];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = lane & 31, h = lane >> 5;
+    const int J = NJ ? NJ : (int)filter_steps(a.d);
+    const size_t qstride = (size_t)J * 8;
+    const float C = (float)(2 * a.d + 32) * 5.9604644775390625e-08f;  // (2 d + 32) 2^-24
+    const uint32_t nitems = a.dev_nitems ? *a.dev_nitems : a.nitems;
+    ItemWalk w((nitems + 3) >> 2, a.xcd_chunks);
+    for (uint32_t wi = w.cur; wi < w.end; wi += w.step) {
+        const uint32_t item_no = wi * 4 + wave;
+        if (item_no >= nitems) break;
+        const ScanItem it = a.items[item_no];
+        // ---- per-query operands, lane m (both halves) for query m of the item
+        const bool qok = (uint32_t)m < it.npair;
+        uint32_t qrow = 0;
+        unsigned long long row = 0;
+        float u = __builtin_inff(), cq = 0.f;  // kept iff t > u: nothing passes for an absent query
+        if (qok) {
+            qrow = a.pair_query[it.pair_begin + m];
+            row = a.pair_out[it.pair_begin + m] + it.vec_off;
+            const float thr = a.thr[qrow], xn = a.xn[qrow];
+            if (METRIC == METRIC_L2) {
+                u = (1.f - C) * xn - thr;  // kept iff 2 p - (1 - C) yn > (1 - C) xn - thr   (NaN thr: nothing passes)
+                if (!(thr == thr)) u = __builtin_inff();
+            } else {
+                u = thr;                   // kept iff p + C |x||y| > thr
+                if (!(thr == thr)) u = __builtin_inff();
+                cq = C * xn;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the previous item's reads of this wave's LDS rows are done
+        __builtin_amdgcn_wave_barrier();
+        if (h == 0) {
+            s_u[wave][m] = u;
+            s_c[wave][m] = cq;
+            s_row[wave][m] = (uint32_t)row;
+            s_q[wave][m] = qrow;
+        }
+        const float* qp = a.xf + (size_t)qrow * qstride + (size_t)h * 4;
+        v4f af[NJ ? NJ : 1];
+        if (NJ) {
+#pragma unroll
+            for (int j = 0; j < NJ; j++) af[j] = qok ? *reinterpret_cast<const v4f*>(qp + 8 * j) : v4f{0.f, 0.f, 0.f, 0.f};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // thresholds in accumulator layout: register 4 g + i of lane half h belongs to query 8 g + 4 h + i
+        float ur[16], cr[16];
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const v4f tu = *reinterpret_cast<const v4f*>(&s_u[wave][8 * g + 4 * h]);
+            const v4f tc = *reinterpret_cast<const v4f*>(&s_c[wave][8 * g + 4 * h]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                ur[4 * g + i] = tu[i];
+                cr[4 * g + i] = tc[i];
+            }
+        }
+        const uint32_t nblk = ((it.nvec + 63) >> 6) * 2;  // lists are stored in pairs of blocks: a 64-candidate mask word is two of ours
+        uint32_t* mask32 = reinterpret_cast<uint32_t*>(a.mask);
+        const float* bbase = a.codes_frag + (size_t)it.vec_base * (size_t)J * 256 + (size_t)lane * 4;
+
+        for (uint32_t i = 0; i < nblk; i++) {
+            v16f acc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = 0.f;
+            const float* bp = bbase + (size_t)i * (size_t)J * 256;
+            const float yn = a.yn[(it.vec_base + i) * 32 + m];
+            if constexpr (NJ != 0) {
+                // P pieces in flight: registers bq[j % P] (static indices: the loop is fully unrolled)
+                constexpr int P = NJ >= 8 ? 8 : NJ;
+                v4f bq[P];
+#pragma unroll
+                for (int j = 0; j < P; j++) bq[j] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(bp + (size_t)j * 256));
+#pragma unroll
+                for (int j = 0; j < NJ; j++) {
+                    const v4f b4 = bq[j % P];
+                    if (j + P < NJ) bq[j % P] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(bp + (size_t)(j + P) * 256));
+#pragma unroll
+                    for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][e], b4[e], acc, 0, 0, 0);
+                }
+            } else {
+                constexpr int P = 4;
+                v4f bq[P], aq[P];
+#pragma unroll
+                for (int j = 0; j < P; j++) {
+                    bq[j] = j < J ? __builtin_nontemporal_load(reinterpret_cast<const v4f*>(bp + (size_t)j * 256)) : v4f{0.f, 0.f, 0.f, 0.f};
+                    aq[j] = j < J && qok ? *reinterpret_cast<const v4f*>(qp + 8 * j) : v4f{0.f, 0.f, 0.f, 0.f};
+                }
+                for (int j0 = 0; j0 < J; j0 += P) {
+#pragma unroll
+                    for (int jj = 0; jj < P; jj++) {
+                        const int j = j0 + jj;
+                        const v4f b4 = bq[jj], a4 = aq[jj];
+                        if (j + P < J) {
+                            bq[jj] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(bp + (size_t)(j + P) * 256));
+                            aq[jj] = qok ? *reinterpret_cast<const v4f*>(qp + 8 * (j + P)) : v4f{0.f, 0.f, 0.f, 0.f};
+                        }
+                        if (j < J) {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc, 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            const uint32_t lv = i * 32 + m;           // position of this lane's vector in the chunk
+            const bool vok = lv < it.nvec;
+            const unsigned long long vmask = __ballot(vok);
+            const float c1yn = (1.f - C) * yn;
+            int word = 0;  // lane q (< 32) collects the 32-candidate mask word of query q
+            unsigned long long kept[16];
+            uint32_t total = 0;
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                const float t = METRIC == METRIC_L2 ? fmaf(2.f, acc[reg], -c1yn) : fmaf(cr[reg], yn, acc[reg]);
+                const bool keep = t > ur[reg];
+                kept[reg] = __ballot(keep) & vmask;
+                total += (uint32_t)__builtin_popcountll(kept[reg]);
+            }
+            static_for(std::make_integer_sequence<int, 16>{}, [&](auto R) {
+                constexpr int reg = decltype(R)::value;
+                constexpr int q0 = (reg & 3) + 8 * (reg >> 2);  // query of lane half 0; half 1: q0 + 4
+                writelane_c<q0>(word, (uint32_t)kept[reg]);
+                writelane_c<q0 + 4>(word, (uint32_t)(kept[reg] >> 32));
+            });
+            if (lane < 32 && qok) mask32[(row + i * 32) >> 5] = (uint32_t)word;
+            if (total) {
+                // survivors: (distance row position, query row, vector) for rescore_kernel; beyond the list's capacity the exact
+                // distance is computed here (slow, never wrong)
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(a.surv_count, total);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+                for (int reg = 0; reg < 16; reg++) {
+                    const unsigned long long kb = kept[reg];
+                    if (kb == 0) continue;
+                    if ((kb >> lane) & 1) {
+                        const int q = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                        const uint32_t slot = base + (uint32_t)__builtin_popcountll(kb & lt);
+                        const uint32_t off = s_row[wave][q] + lv, qr = s_q[wave][q], vec = it.qgroup + lv;
+                        if (slot < a.surv_cap) a.surv[slot] = make_uint4(off, qr, vec, 0u);
+                        else a.dist[off] = exact_distance<METRIC>(a.queries + (size_t)qr * a.dpad, a.codes + (size_t)vec * a.dpad, a.dpad);
+                    }
+                    base += (uint32_t)__builtin_popcountll(kb);
+                }
+            }
+        }
+    }  // items
+}
+
+void launch_scan_filter(const FilterScanArgs& a, hipStream_t s) {
+    if (a.nitems == 0 && !a.dev_nitems) return;
+    const unsigned nwg = (a.nitems + 3) / 4;
+    const int J = (int)filter_steps(a.d);
+    auto go = [&](auto kern, auto resc) {
+        static const unsigned per_cu = 3;
+        const size_t hwg = ((size_t)a.hint_nitems + a.hint_nitems / 8 + 3) / 4;
+        const unsigned hinted = (unsigned)((hwg + 7) / 8) * 8 + 8;
+        const dim3 grid(a.dev_nitems ? (a.hint_nitems ? hinted : resident_grid(per_cu)) : (a.xcd_chunks ? ((nwg + 7) / 8) * 8 : nwg)), block(256);
+        LAUNCH(kern, grid, block, 0, s, a);
+        LAUNCH(resc, dim3(resident_grid(4)), dim3(256), 0, s, a);
+    };
+    auto pick = [&](auto metric) {
+        constexpr int M = decltype(metric)::value;
+        if (J <= 4) return go(scan_filter_kernel<M, 4>, rescore_kernel<M>);
+        if (J <= 8) return go(scan_filter_kernel<M, 8>, rescore_kernel<M>);
+        if (J <= 12) return go(scan_filter_kernel<M, 12>, rescore_kernel<M>);
+        if (J <= 16) return go(scan_filter_kernel<M, 16>, rescore_kernel<M>);
+        return go(scan_filter_kernel<M, 0>, rescore_kernel<M>);
+    };
+    if (a.metric == METRIC_L2) pick(std::integral_constant<int, METRIC_L2>{});
+    else pick(std::integral_constant<int, METRIC_IP>{});
+}
+
+}  // namespace amdivf

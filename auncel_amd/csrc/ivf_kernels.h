@@ -138,6 +138,41 @@ void launch_frag_from_f32(const float* codes, const uint64_t* list_off, const ui
                           int dpad, int metric, uint8_t* out, int32_t* cy, hipStream_t s);
 // fp32 query rows (integers 0..255) -> signed byte rows (row stride ks * 32, zero padded) + query_cx
 void launch_sbytes_from_f32(const float* x, size_t n, int d, int dpad, int metric, int8_t* out, int32_t* cx, hipStream_t s);
+// ---------------------------------------------------------------------------- fp32 filter + exact rescoring (ivf_filter.hip)
+// pieces of 8 dimensions per vector in the fragment-ordered fp32 copy: d / 8 rounded up to the step counts the kernel is built
+// for (4, 8, 12, 16: the query operand stays in registers) or as it is beyond 128 dimensions
+inline __host__ __device__ uint32_t filter_steps(int d) {
+    const uint32_t j = (uint32_t)(d + 7) / 8;
+    return j <= 4 ? 4u : j <= 8 ? 8u : j <= 12 ? 12u : j <= 16 ? 16u : j;
+}
+struct FilterScanArgs {
+    const float* codes_frag;      // lists in fragment order (launch_frag32_from_f32)
+    const float* yn;              // per stored slot: |y|^2 (L2) / |y| (IP)
+    const float* xf;              // packed queries, row stride 8 filter_steps(d) (launch_filter_queries)
+    const float* xn;              // per query row: |x|^2 (L2) / |x| (IP)
+    const float* codes;           // the lists as stored (CSR rows, stride dpad): the exact distance is computed from these
+    const float* queries;         // the query rows as passed (stride dpad)
+    const ScanItem* items;        // as for scan_mfma_kernel; qgroup = global index of the chunk's first vector
+    const uint32_t* pair_query;
+    const uint64_t* pair_out;
+    float* dist;
+    const float* thr;
+    unsigned long long* mask;
+    uint4* surv;                  // survivors of the filter: (distance row position, query row, vector, -)
+    uint32_t* surv_count;
+    uint32_t surv_cap;
+    int d, dpad;
+    int metric;
+    int xcd_chunks;
+    uint32_t nitems;
+    const uint32_t* dev_nitems;
+    uint32_t hint_nitems;
+};
+void launch_scan_filter(const FilterScanArgs& a, hipStream_t s);  // filter + rescoring, two launches
+void launch_frag32_from_f32(const float* codes, const uint64_t* list_off, const uint64_t* block_off, uint32_t nlist, uint64_t nblocks, int d,
+                            int dpad, int metric, float* out, float* yn, hipStream_t s);
+void launch_filter_queries(const float* x, size_t n, int d, int dpad, int metric, float* xf, float* xn, hipStream_t s);
+
 inline __host__ __device__ int scan_qg_class(uint32_t qg) { return qg == 1 ? 0 : qg == 2 ? 1 : qg == 4 ? 2 : 3; }
 // The queries of a list go into blocks of `qblock` (64: 8-wave tiles, the byte-code scan, which is short of HBM and
 // issue slots rather than of VALU; 32: 4-wave tiles, the fp32 scans); the last block takes the narrowest shape that holds it.

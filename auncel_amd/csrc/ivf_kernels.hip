@@ -238,27 +238,6 @@ __device__ __forceinline__ void scan_tile_one(const ScanArgs& a, const ScanItem 
     }
 }
 
-// Which items a workgroup walks.  Host-sized launches: one item per workgroup (the grid is the item count).  Chained rounds
-// (a.dev_counts): a resident grid, every workgroup strides over the items of its shape, whose count the planning kernels
-// left on the device.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2); consecutive items are the
-// tiles of one list for one block of queries, so with xcd_chunks XCD x takes the x-th eighth of the item list and a block's
-// tiles (and its packed query operands) stay in one L2.
-struct ItemWalk {
-    uint32_t cur, end, step;
-    __device__ ItemWalk(uint32_t n, int xcd_chunks) {
-        if (xcd_chunks) {
-            const uint32_t per = (n + 7) >> 3, x = blockIdx.x & 7;
-            cur = x * per + (blockIdx.x >> 3);
-            end = (x + 1) * per < n ? (x + 1) * per : n;
-            step = gridDim.x >> 3;
-        } else {
-            cur = blockIdx.x;
-            end = n;
-            step = gridDim.x;
-        }
-    }
-};
-
 template <int METRIC, int QG, int ARITH>
 __global__ __launch_bounds__(QG == 8 ? 512 : 256) void scan_tiles_kernel(ScanArgs a) {
     // two staging buffers: chunk c+1 is fetched into registers while chunk c is being consumed, and written
@@ -373,14 +352,6 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 #else
 #define MFMA_BLOAD(p) (*(p))
 #endif
-
-// reg[lane LANE] = val (val wave-uniform, LANE a compile-time constant: an inline operand, so the one SGPR slot is val's)
-template <int LANE> __device__ __forceinline__ void writelane_c(int& reg, uint32_t val) {
-    asm("v_writelane_b32 %0, %1, %2" : "+v"(reg) : "s"(val), "n"(LANE));
-}
-template <int... I, class F> __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
 
 // NKS = K-steps (d <= 32 NKS) with the query operand resident in registers; 0 = any d, query pieces re-read per block pair
 template <int METRIC, bool MASKED, int NKS>

@@ -345,7 +345,7 @@ __device__ inline void items_of_list(const PlanArgs& a, uint32_t l, uint32_t c, 
                 it.pair_begin = p0 + qb;
                 it.npair = c - qb < MFMA_QBLOCK ? c - qb : MFMA_QBLOCK;
                 it.qg = 0;
-                it.qgroup = 0;
+                it.qgroup = (uint32_t)(vb0 + vb);  // global index of the chunk's first vector (the fp32 filter's exact rescoring)
                 if (ni < a.item_cap) a.items[ni] = it;
                 ni++;
                 slots += (unsigned long long)MFMA_QBLOCK * (((it.nvec + 63) / 64) * 64);
