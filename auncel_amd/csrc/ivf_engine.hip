@@ -423,6 +423,14 @@ bool filter_available(const amd_ivf* ws, const amd_ivf* index, bool bytes) {
     if (e && atoi(e) == 0) return false;
     return !bytes && index->have_frag32 && ws->allow_filter;
 }
+// Dense probes ahead of the filter: the k-th best of the first f lists is the threshold everything else is filtered with, and
+// about k / (f x mean list length) of the later candidates get under it; f is chosen to keep that near 1.5 % (the survivors are
+// rescored one lane each)
+size_t filter_first_probes(const amd_ivf* index, size_t k, size_t nprobe) {
+    const double mean_len = std::max<double>(1.0, (double)index->h_list_off[index->nlist] / (double)std::max<size_t>(index->nlist, 1));
+    const size_t f = (size_t)std::ceil((double)k / (0.015 * mean_len));
+    return std::max<size_t>(1, std::min<size_t>(f, std::max<size_t>(1, nprobe / 4)));
+}
 
 // copy n x d host rows into a device matrix with row stride dpad (zero padded)
 void upload_rows(amd_ivf* h, float* dst, const float* src, size_t n) {
@@ -1225,7 +1233,7 @@ void search_fixed_device(amd_ivf* h, const float* d_x, size_t n, size_t k, size_
     const bool filt = filter_available(h, ix(h), base.bytes);
     const bool two = two_env ? two_env == 2 : filt ? (nprobe >= 4 && n * nprobe >= 1024) : (nprobe >= 16 && n * nprobe >= 4096);
     base.fixed_two = two;
-    const size_t first = two ? (filt ? 1 : std::max<size_t>(1, nprobe / 8)) : nprobe;
+    const size_t first = two ? (filt ? filter_first_probes(ix(h), k, nprobe) : std::max<size_t>(1, nprobe / 8)) : nprobe;
     base.caller_checks_error = true;
     with_select_fallback(h, [&] {
         if (h->force_heap_select) init_state(h, n, k, false);
@@ -1339,7 +1347,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     // fp32 lists with the matrix-core filter (ivf_filter.hip): threshold rounds cost their list bytes too, and the first round --
     // the only one computed on the vector ALU in the reference's rounding sequence -- shrinks to one probe per query
     const bool filter_ok = filter_available(h, I, base.bytes) && !base.range;
-    if (filter_ok && base.tuner.enabled) first_round = 1;
+    if (filter_ok && base.tuner.enabled) first_round = filter_first_probes(I, (size_t)base.k, 64);
     const double grow = grow_env > 0 ? grow_env : (base.bytes || filter_ok) ? 12.0 : 3.5;
     // pairs of a round: the packed query tiles of the fp32 scans (8 queries x dpad floats per group) must fit 4 GiB
     size_t seg_cap = (size_t)2 << 20;
@@ -1427,7 +1435,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         pa.mfma_chunk = mfma_chunk();
         pa.block_off = I->d_block_off.as<uint64_t>();
     }
-    constexpr size_t SURV_CAP = (size_t)8 << 20;
+    constexpr size_t SURV_CAP = (size_t)16 << 20;
     if (filter_ok) {
         h->w_xf.ensure(n * (size_t)filter_steps(h->d) * 8 * sizeof(float));
         h->w_xn.ensure(n * sizeof(float));

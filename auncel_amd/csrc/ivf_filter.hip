@@ -35,6 +35,8 @@ namespace amdivf {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
+// (explicitly global: a generic pointer makes these flat loads, which count on both wait counters and force full waits)
+typedef const v4f __attribute__((address_space(1)))* gv4f;
 
 // ---------------------------------------------------------------------------------------------
 // fp32 lists (CSR rows, row stride dpad) -> fragment order: a list is a run of 32-vector blocks (block_off[l] = its first, an
@@ -201,49 +203,9 @@ template <int METRIC, int NJ> __global__ __launch_bounds__(256) void scan_filter
         uint32_t* mask32 = reinterpret_cast<uint32_t*>(a.mask);
         const float* bbase = a.codes_frag + (size_t)it.vec_base * (size_t)J * 256 + (size_t)lane * 4;
 
-        for (uint32_t i = 0; i < nblk; i++) {
-            v16f acc;
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[r] = 0.f;
-            const float* bp = bbase + (size_t)i * (size_t)J * 256;
+        // ---- the tile's verdicts: mask words + survivor entries of block i, whose 32 x 32 dot products are in acc
+        auto finish_block = [&](uint32_t i, const v16f& acc) {
             const float yn = a.yn[(it.vec_base + i) * 32 + m];
-            if constexpr (NJ != 0) {
-                // P pieces in flight: registers bq[j % P] (static indices: the loop is fully unrolled)
-                constexpr int P = NJ >= 8 ? 8 : NJ;
-                v4f bq[P];
-#pragma unroll
-                for (int j = 0; j < P; j++) bq[j] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(bp + (size_t)j * 256));
-#pragma unroll
-                for (int j = 0; j < NJ; j++) {
-                    const v4f b4 = bq[j % P];
-                    if (j + P < NJ) bq[j % P] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(bp + (size_t)(j + P) * 256));
-#pragma unroll
-                    for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][e], b4[e], acc, 0, 0, 0);
-                }
-            } else {
-                constexpr int P = 4;
-                v4f bq[P], aq[P];
-#pragma unroll
-                for (int j = 0; j < P; j++) {
-                    bq[j] = j < J ? __builtin_nontemporal_load(reinterpret_cast<const v4f*>(bp + (size_t)j * 256)) : v4f{0.f, 0.f, 0.f, 0.f};
-                    aq[j] = j < J && qok ? *reinterpret_cast<const v4f*>(qp + 8 * j) : v4f{0.f, 0.f, 0.f, 0.f};
-                }
-                for (int j0 = 0; j0 < J; j0 += P) {
-#pragma unroll
-                    for (int jj = 0; jj < P; jj++) {
-                        const int j = j0 + jj;
-                        const v4f b4 = bq[jj], a4 = aq[jj];
-                        if (j + P < J) {
-                            bq[jj] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(bp + (size_t)(j + P) * 256));
-                            aq[jj] = qok ? *reinterpret_cast<const v4f*>(qp + 8 * (j + P)) : v4f{0.f, 0.f, 0.f, 0.f};
-                        }
-                        if (j < J) {
-#pragma unroll
-                            for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc, 0, 0, 0);
-                        }
-                    }
-                }
-            }
             const uint32_t lv = i * 32 + m;           // position of this lane's vector in the chunk
             const bool vok = lv < it.nvec;
             const unsigned long long vmask = __ballot(vok);
@@ -285,6 +247,86 @@ template <int METRIC, int NJ> __global__ __launch_bounds__(256) void scan_filter
                     }
                     base += (uint32_t)__builtin_popcountll(kb);
                 }
+            }
+        };
+
+        if constexpr (NJ != 0) {
+            // P pieces of the list in flight, across block boundaries: piece t of the chunk's linear sequence lives in register
+            // bq[t % P] (P divides NJ, so the index is static in the unrolled block body); the scheduling barriers keep every
+            // load where it is written -- right behind the MFMAs that freed its register
+            constexpr int P = NJ == 12 ? 6 : NJ >= 8 ? 8 : 4;
+            v4f bq[P];
+#pragma unroll
+            for (int j = 0; j < P; j++) bq[j] = *(gv4f)(uintptr_t)(bbase + (size_t)j * 256);
+            for (uint32_t i = 0; i < nblk; i++) {
+                v16f acc;
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[r] = 0.f;
+                const float* bp = bbase + (size_t)i * (size_t)NJ * 256;
+                const float* bn = i + 1 < nblk ? bp + (size_t)NJ * 256 : bp;  // (past the chunk's end: re-read this block, unused)
+#pragma unroll
+                for (int j = 0; j < NJ; j++) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][e], bq[j % P][e], acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const float* src = j + P < NJ ? bp + (size_t)(j + P) * 256 : bn + (size_t)(j + P - NJ) * 256;
+                    bq[j % P] = *(gv4f)(uintptr_t)src;  // (cached: the chunk's other query blocks read it too)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                finish_block(i, acc);
+            }
+        } else {
+            // d > 128: the query operand does not fit the registers; it is re-read (L2) piece by piece, and every piece serves
+            // four blocks of the list at once (four accumulator tiles), two pieces in flight
+            constexpr int G = 4;
+            for (uint32_t i0 = 0; i0 < nblk; i0 += G) {
+                v16f acc[G];
+#pragma unroll
+                for (int g = 0; g < G; g++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[g][r] = 0.f;
+                const uint32_t ng = nblk - i0 < (uint32_t)G ? nblk - i0 : (uint32_t)G;  // (2 or 4: lists come in pairs of blocks)
+                const float* bp = bbase + (size_t)i0 * (size_t)J * 256;
+                const size_t bstep = (size_t)J * 256;  // floats from a block's piece j to the next block's
+                // straight-line loads (no predicates: an absent query reads query row 0 and a block past the chunk's end re-reads
+                // the last one; neither result is looked at); the scheduling barriers keep the loads of step j + 2 where they are
+                // written -- behind the MFMAs of step j, in flight under those of step j + 1
+                const float* bpg[G];
+#pragma unroll
+                for (int g = 0; g < G; g++) bpg[g] = bp + (size_t)((uint32_t)g < ng ? (uint32_t)g : ng - 1) * bstep;
+                v4f a0, a1, b0[G], b1[G];
+#define FILTER_FETCH(JJ, AV, BV)                                                                                 \
+    {                                                                                                            \
+        const int jj_ = (JJ);                                                                                    \
+        AV = *(gv4f)(uintptr_t)(qp + 8 * jj_);                                                                   \
+        _Pragma("unroll") for (int g = 0; g < G; g++)                                                            \
+            BV[g] = *(gv4f)(uintptr_t)(bpg[g] + (size_t)jj_ * 256);                                            \
+    }
+#define FILTER_MAC(AV, BV)                                                                                       \
+    {                                                                                                            \
+        _Pragma("unroll") for (int g = 0; g < G; g++)                                                            \
+            _Pragma("unroll") for (int e = 0; e < 4; e++)                                                        \
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[e], BV[g][e], acc[g], 0, 0, 0);                 \
+    }
+                FILTER_FETCH(0, a0, b0)
+                FILTER_FETCH(1, a1, b1)
+                for (int j = 0; j < J; j += 2) {  // (J is even beyond 128 dimensions: filter_steps)
+                    __builtin_amdgcn_sched_barrier(0);
+                    FILTER_MAC(a0, b0)
+                    __builtin_amdgcn_sched_barrier(0);
+                    FILTER_FETCH(j + 2 < J ? j + 2 : j, a0, b0)
+                    __builtin_amdgcn_sched_barrier(0);
+                    FILTER_MAC(a1, b1)
+                    __builtin_amdgcn_sched_barrier(0);
+                    FILTER_FETCH(j + 3 < J ? j + 3 : j + 1, a1, b1)
+                }
+#undef FILTER_FETCH
+#undef FILTER_MAC
+                static_for(std::make_integer_sequence<int, G>{}, [&](auto Gi) {
+                    constexpr int g = decltype(Gi)::value;
+                    if ((uint32_t)g < ng) finish_block(i0 + g, acc[g]);
+                });
             }
         }
     }  // items

@@ -143,7 +143,7 @@ void launch_sbytes_from_f32(const float* x, size_t n, int d, int dpad, int metri
 // for (4, 8, 12, 16: the query operand stays in registers) or as it is beyond 128 dimensions
 inline __host__ __device__ uint32_t filter_steps(int d) {
     const uint32_t j = (uint32_t)(d + 7) / 8;
-    return j <= 4 ? 4u : j <= 8 ? 8u : j <= 12 ? 12u : j <= 16 ? 16u : j;
+    return j <= 4 ? 4u : j <= 8 ? 8u : j <= 12 ? 12u : j <= 16 ? 16u : (j + 1u) & ~1u;  // (beyond 128 dimensions: an even count)
 }
 struct FilterScanArgs {
     const float* codes_frag;      // lists in fragment order (launch_frag32_from_f32)
