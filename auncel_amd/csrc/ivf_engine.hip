@@ -217,7 +217,7 @@ struct amd_ivf {
     // fp32 copy of the lists in fragment order + |y|^2 / |y| per slot (ivf_filter.hip), kept when the data does not qualify for
     // byte codes: threshold rounds run as a matrix-core filter over it, the exact distance only for what the filter keeps
     DevBuf d_frag32, d_yn;
-    bool have_frag32 = false;
+    bool have_frag32 = false, frag32_possible = false;
     int allow_filter = 1;
     DevBuf w_xf, w_xn, w_surv, w_surv_cnt;  // packed queries + norms of the current search, the filter's survivors
 
@@ -370,7 +370,9 @@ void upload_lists(amd_ivf* h) {
     HIP_CHECK(hipMemcpyAsync(h->d_list_off.p, h->h_list_off.data(), (h->nlist + 1) * sizeof(uint64_t),
                              hipMemcpyHostToDevice, h->stream));
     h->have_codes8 = h->allow_bytes && nt > 0 && h->db_range.bytes() && (double)h->d * 255.0 * 255.0 < 2147483648.0;
+    // (byte-valued lists get their fp32 fragment copy only when a search asks for the fp32 path: ensure_frag32)
     h->have_frag32 = !h->have_codes8 && h->allow_filter && nt > 0 && nt < 0xffffffffull;
+    h->frag32_possible = h->allow_filter && nt > 0 && nt < 0xffffffffull;
     if (h->have_codes8 || h->have_frag32) {
         h->h_block_off.assign(h->nlist + 1, 0);
         for (size_t l = 0; l < h->nlist; l++) h->h_block_off[l + 1] = h->h_block_off[l] + mfma_list_blocks(h->h_ids[l].size());
@@ -421,7 +423,21 @@ bool byte_queries(amd_ivf* ws, const amd_ivf* index, const float* d_x, size_t n,
 bool filter_available(const amd_ivf* ws, const amd_ivf* index, bool bytes) {
     const char* e = getenv("AUNCEL_AMD_FILTER");
     if (e && atoi(e) == 0) return false;
-    return !bytes && index->have_frag32 && ws->allow_filter;
+    return !bytes && (index->have_frag32 || index->frag32_possible) && ws->allow_filter;
+}
+// the fragment-ordered fp32 copy of lists that also have byte codes is built the first time an fp32 search runs over them
+void ensure_frag32(amd_ivf* index) {
+    if (index->have_frag32) return;
+    std::lock_guard<std::mutex> lock(index->upload_mu);
+    if (index->have_frag32 || !index->frag32_possible) return;
+    use_device(index);
+    const uint64_t nblk = index->h_block_off[index->nlist];
+    index->d_frag32.ensure(nblk * filter_steps(index->d) * 1024);
+    index->d_yn.ensure(nblk * 32 * sizeof(float));
+    launch_frag32_from_f32(index->d_codes.as<float>(), index->d_list_off.as<uint64_t>(), index->d_block_off.as<uint64_t>(), (uint32_t)index->nlist,
+                           nblk, index->d, index->dpad, index->metric, index->d_frag32.as<float>(), index->d_yn.as<float>(), index->stream);
+    HIP_CHECK(stream_sync(index->stream));
+    index->have_frag32 = true;
 }
 // Dense probes ahead of the filter: the k-th best of the first f lists is the threshold everything else is filtered with, and
 // about k / (f x mean list length) of the later candidates get under it; f is chosen to keep that near 1.5 % (the survivors are
@@ -1347,6 +1363,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     // fp32 lists with the matrix-core filter (ivf_filter.hip): threshold rounds cost their list bytes too, and the first round --
     // the only one computed on the vector ALU in the reference's rounding sequence -- shrinks to one probe per query
     const bool filter_ok = filter_available(h, I, base.bytes) && !base.range;
+    if (filter_ok) ensure_frag32(I);
     if (filter_ok && base.tuner.enabled) first_round = filter_first_probes(I, (size_t)base.k, 64);
     const double grow = grow_env > 0 ? grow_env : (base.bytes || filter_ok) ? 12.0 : 3.5;
     // pairs of a round: the packed query tiles of the fp32 scans (8 queries x dpad floats per group) must fit 4 GiB
