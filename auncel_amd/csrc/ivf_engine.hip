@@ -259,6 +259,7 @@ struct amd_ivf {
     uint64_t hint_sig = 0;
     uint64_t hinted_rounds = 0, short_rounds = 0;  // last search: scan launches sized by a hint / of those, grids smaller than the work
     std::atomic<int> live_contexts{1};  // on the index owner: itself + its clones (amd_ivf_clone / amd_ivf_destroy)
+    std::atomic<int> active_searches{0};  // on the index owner: searches inside run_rounds_device right now
     bool force_heap_select = false;  // (set while a search is repeated after ERR_LOG_OVERFLOW)
     // tune / train search over a coarse ranking the caller supplies (amd_ivf_search_adaptive_pre, amd_ivf_train_samples_pre):
     // host rows of this call's (or slice's) queries, given_nprobe entries each; null: the engine ranks the centroids itself
@@ -1209,8 +1210,13 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
                     HIP_CHECK(hipMemsetAsync(h->w_tie_rows.p, 0, 8, s));
                 }
                 const size_t nout = prefix && prefix < nprobe ? prefix : nprobe;
-                (void)launch_heap_tie_order(h->w_dist.as<float>(), (uint32_t)m, (uint32_t)nlist, (uint32_t)nprobe, (uint32_t)nout, h->metric,
-                                            d_out_dis + c0 * nprobe, d_out_keys + c0 * nprobe, h->w_tie_rows.as<unsigned long long>(), s);
+                const bool ran = launch_heap_tie_order(h->w_dist.as<float>(), (uint32_t)m, (uint32_t)nlist, (uint32_t)nprobe, (uint32_t)nout,
+                                                       h->metric, d_out_dis + c0 * nprobe, d_out_keys + c0 * nprobe,
+                                                       h->w_tie_rows.as<unsigned long long>(), s);
+                // the heap and a row must fit one workgroup's LDS (nlist up to ~13 000): beyond that the reference's tie order is
+                // not available -- say so when it was asked for explicitly instead of silently ranking by centroid number
+                if (!ran && (h->ties_override == 1 || (ties_env && !strcmp(ties_env, "heap"))))
+                    throw EngineError("coarse tie order by the reference's heap needs nlist x 12 bytes of LDS (nlist <= ~13 000)");
             }
         }
         h->timer.end(t, s);
@@ -1640,11 +1646,17 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
 
     bool fix_pending = false, sorted_any = false;
     size_t last_fix_round = 0;
-    // tie_fix_kernel: behind every round on a side stream when this context has the GPU to itself (latency), one pass at the end
-    // when the index has several search contexts (their kernels fill the GPU while it runs; more streams would only crowd the
-    // hardware queues)
+    // tie_fix_kernel: behind every round on a side stream when this search has the index to itself (latency), one pass at the end
+    // when other searches are running on it (their kernels fill the GPU while it runs; more streams would only crowd the hardware
+    // queues)
     static const char* fix_env = getenv("AUNCEL_AMD_TIE_FIX");
-    const bool eager_fix = fix_env ? !strcmp(fix_env, "eager") : I->live_contexts.load() <= 1;
+    struct Active {
+        std::atomic<int>& c;
+        int before;
+        explicit Active(std::atomic<int>& cc) : c(cc), before(cc.fetch_add(1)) {}
+        ~Active() { c.fetch_sub(1); }
+    } active(I->active_searches);
+    const bool eager_fix = fix_env ? !strcmp(fix_env, "eager") : active.before == 0;
     auto tie_fix_args = [&](uint32_t round, int final_pass) {
         TieFixArgs ta{};
         ta.metric = h->metric;

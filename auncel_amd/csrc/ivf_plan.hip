@@ -291,7 +291,13 @@ __global__ __launch_bounds__(1024) void plan_lists_kernel(PlanArgs a) {
         for (int k = 0; k < 6; k++) ex[k] += v[k];
     }
     if (t == 0) {
-        if (tot[2] + tot[3] + tot[4] + tot[5] > a.item_cap) atomicMax(a.error, ERR_ITEM_OVERFLOW);
+        // more tiles than the item list holds: the search fails with ERR_ITEM_OVERFLOW when its error word is read; until then
+        // the scans of this round, already enqueued, must find nothing to do (the items past the capacity were never written)
+        const bool over = (unsigned long long)tot[2] + tot[3] + tot[4] + tot[5] > (unsigned long long)a.item_cap;
+        if (over) {
+            atomicMax(a.error, ERR_ITEM_OVERFLOW);
+            tot[2] = tot[3] = tot[4] = tot[5] = 0;
+        }
         a.counters[2] = tot[0];  // pairs
         a.counters[3] = tot[1];  // query groups
         a.counters[4] = tot[2];  // tiles of shape 1

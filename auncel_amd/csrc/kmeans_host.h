@@ -28,36 +28,40 @@ inline void rand_perm(int* perm, size_t n, long seed) {
     }
 }
 
-// the tail of km_update_centroids: every cluster without points is re-seeded from a bigger one
-// (centroids: k x d means, hassign: points per cluster, both updated); returns the number of splits
-inline int split_void_clusters(float* centroids, std::vector<size_t>& hassign, size_t d, size_t k, size_t n) {
-    size_t nsplit = 0;
-    RefRng rng(1234);
-    const double EPS = 1 / 1024.;
-    for (size_t ci = 0; ci < k; ci++) {
-        if (hassign[ci] == 0) {
-            size_t cj;
-            for (cj = 0; 1; cj = (cj + 1) % k) {
-                float p = (hassign[cj] - 1.0) / (float)(n - k);
-                float r = rng.rand_float();
-                if (r < p) break;
-            }
-            memcpy(centroids + ci * d, centroids + cj * d, sizeof(*centroids) * d);
-            for (size_t j = 0; j < d; j++) {
-                if (j % 2 == 0) {
-                    centroids[ci * d + j] *= 1 + EPS;
-                    centroids[cj * d + j] *= 1 - EPS;
-                } else {
-                    centroids[ci * d + j] *= 1 - EPS;
-                    centroids[cj * d + j] *= 1 + EPS;
-                }
-            }
-            hassign[ci] = hassign[cj] / 2;
-            hassign[cj] -= hassign[ci];
-            nsplit++;
+// Empty clusters after an update step (the reference's rule, utils.cpp:1126-1159, as a specification: which cluster donates is
+// decided by a fixed-seed generator, so the draws -- one per candidate donor, candidates cycling from cluster 0 -- and the
+// arithmetic have to be these):
+//   for every empty cluster e, in index order:
+//     walk the clusters round-robin from 0; candidate c donates when a fresh draw u in [0, 1] falls below (size_c - 1) / (n - k);
+//     e becomes a copy of the donor, then the two are pushed apart: even coordinates of e are scaled by 1 + 2^-10 and the donor's by
+//     1 - 2^-10, odd coordinates the other way round; e takes half of the donor's points (rounded down).
+// means: k x d, updated in place; population: points per cluster, updated.  Returns how many clusters were re-seeded.
+inline int split_void_clusters(float* means, std::vector<size_t>& population, size_t d, size_t k, size_t n) {
+    RefRng draws(1234);
+    const double nudge = 1.0 / 1024.0;
+    int reseeded = 0;
+    for (size_t empty = 0; empty < k; empty++) {
+        if (population[empty] != 0) continue;
+        size_t donor = 0;
+        for (;;) {
+            const float share = (population[donor] - 1.0) / (float)(n - k);  // (double arithmetic, rounded to float: as specified)
+            const float u = draws.rand_float();
+            if (u < share) break;
+            donor = donor + 1 == k ? 0 : donor + 1;
         }
+        float* into = means + empty * d;
+        float* from = means + donor * d;
+        for (size_t j = 0; j < d; j++) {
+            into[j] = from[j];
+            const bool even = (j & 1) == 0;
+            into[j] *= even ? 1 + nudge : 1 - nudge;  // (float *= double: one rounding)
+            from[j] *= even ? 1 - nudge : 1 + nudge;
+        }
+        population[empty] = population[donor] / 2;
+        population[donor] -= population[empty];
+        reseeded++;
     }
-    return (int)nsplit;
+    return reseeded;
 }
 
 // fvec_norm_L2sqr in the reference's SSE order (utils_simd.cpp:137-155)
