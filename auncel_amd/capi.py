@@ -24,7 +24,7 @@ SYMBOLS = [
     "amd_ivf_set_tuner", "amd_ivf_search_adaptive", "amd_ivf_search_adaptive_x", "amd_ivf_search_adaptive_pre", "amd_ivf_search_timed", "amd_ivf_search_timed_x",
     "amd_ivf_train_samples",
     "amd_ivf_train_samples_x", "amd_ivf_train_samples_pre", "amd_ivf_trace_sb", "amd_ivf_arcos_table", "amd_ivf_merge_tables",
-    "amd_ivf_last_timing", "amd_ivf_last_scan_min_bytes", "amd_ivf_coarse_tie_rows", "amd_ivf_last_tie_fixed", "amd_ivf_last_round_hints", "amd_ivf_set_byte_codes",
+    "amd_ivf_last_timing", "amd_ivf_last_scan_min_bytes", "amd_ivf_coarse_tie_rows", "amd_ivf_last_tie_fixed", "amd_ivf_last_tie_redone", "amd_ivf_last_round_hints", "amd_ivf_set_byte_codes",
     "amd_ivf_kmeans",
     "amd_ivf_range_search_preassigned", "amd_ivf_range_search", "amd_ivf_range_results",
     "amd_ivf_scan_arith",
@@ -456,6 +456,12 @@ class Handle:
         v = (C.c_uint64 * 2)()
         _chk(lib().amd_ivf_last_round_hints(self._h, v))
         return int(v[0]), int(v[1])
+
+    def last_tie_redone(self):
+        """queries the last adaptive call searched again with the reference's coarse tie order (AUNCEL_AMD_COARSE_TIES=redo)"""
+        v = C.c_uint64(0)
+        _chk(lib().amd_ivf_last_tie_redone(self._h, C.byref(v)))
+        return int(v.value)
 
     def last_tie_fixed(self):
         """queries of the last search whose result came from the heap replayed over their admission log (include/auncel_amd.h)"""

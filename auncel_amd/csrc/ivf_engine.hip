@@ -248,6 +248,8 @@ struct amd_ivf {
     PinnedBuf p_items, p_pair_query, p_pair_out, p_seg_off, p_seg_list, p_seg_count, p_qsel, p_seg_begin;
     DevBuf w_seg_begin;
     DevBuf w_log, w_log_cnt, w_amb, w_tie_flag;  // sorted-array selection: admission logs, ambiguity marks, tie_fix flags
+    DevBuf w_qstat;     // per query: lists scanned, heap updates (what a query searched again takes out of the statistics)
+    DevBuf w_redo_x;    // rows of the queries searched again with the reference's coarse tie order (adaptive_core)
     DevBuf w_log_snap, w_fin_round, w_fix_pos, w_fix_val, w_fix_ref;  // tie_fix_kernel: per-round log counts, heaps replayed so far
     hipStream_t fix_stream = nullptr;            // tie_fix_kernel runs here, under the next round
     hipEvent_t ev_sel = nullptr, ev_fix[2] = {nullptr, nullptr};
@@ -257,6 +259,7 @@ struct amd_ivf {
     PinnedBuf p_hist;
     std::vector<uint32_t> round_hint;  // [round][16]
     uint64_t hint_sig = 0;
+    uint64_t last_tie_redone = 0;  // queries the last adaptive call searched again for the coarse tie order (AUNCEL_AMD_COARSE_TIES=redo)
     uint64_t hinted_rounds = 0, short_rounds = 0;  // last search: scan launches sized by a hint / of those, grids smaller than the work
     std::atomic<int> live_contexts{1};  // on the index owner: itself + its clones (amd_ivf_clone / amd_ivf_destroy)
     std::atomic<int> active_searches{0};  // on the index owner: searches inside run_rounds_device right now
@@ -489,6 +492,7 @@ void init_state(amd_ivf* h, size_t n, size_t k, bool tune_or_train) {
     h->w_log_snap.ensure(2 * n * 4);
     h->w_fin_round.ensure(n * 4);
     h->w_fix_pos.ensure(n * 4);
+    h->w_qstat.ensure(n * sizeof(uint2));
     const bool fix_state = k <= 128 && !h->force_heap_select;  // (the heaps tie_fix_kernel replays: sorted-array selection only)
     if (fix_state) {
         h->w_fix_val.ensure(n * k * sizeof(float));
@@ -515,6 +519,7 @@ void init_state(amd_ivf* h, size_t n, size_t k, bool tune_or_train) {
     ia.log_snap = h->w_log_snap.as<uint32_t>();
     ia.fin_round = h->w_fin_round.as<uint32_t>();
     ia.fix_pos = h->w_fix_pos.as<uint32_t>();
+    ia.qstat = h->w_qstat.as<uint2>();
     if (fix_state) {
         ia.fix_val = h->w_fix_val.as<float>();
         ia.fix_ref = h->w_fix_ref.as<int64_t>();
@@ -1725,6 +1730,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         ra.tuner = base.tuner;
         ra.train = base.train;
         ra.limit = base.d_budget_ms ? h->w_limit.as<uint32_t>() : nullptr;
+        ra.qstat = h->w_qstat.as<uint2>();
         if (sorted_ok) {
             ra.log = h->w_log.as<uint2>();
             ra.log_cap = (uint32_t)log_cap;
@@ -2855,6 +2861,80 @@ static void adaptive_core_once(amd_ivf_t* h, const float* d_x, size_t start, siz
     h->timing[7] = ln[CAT_SELECT];
 }
 
+// A call of n >= 20 queries with the reference's exact-distance tie order: the whole call is searched with runs of equal
+// coarse distances in centroid-number order (sorting; no heap), then the queries whose first run starts below what they read
+// (entries < 2 my_nprobe + 14, see adaptive_core) are searched again as one small call with the heap's order, and their rows,
+// my_nprobe, t_recalls and share of the statistics are replaced.
+static void adaptive_redo_ties(amd_ivf_t* h, const float* d_x, size_t start, size_t n, size_t query_topk, float multipler, float std_m,
+                               const float* require_acc, const float* gt_D, int profile, int coarse_mode, uint64_t* my_nprobe,
+                               float* t_recalls, float* D, int64_t* I, const IntRange& qr) {
+    const size_t K = ix(h)->tuner_max_topk, nlist = h->nlist;
+    const std::vector<uint64_t> np0(my_nprobe + start, my_nprobe + start + n);
+    const std::vector<float> tr0(t_recalls + start, t_recalls + start + n);
+    size_t nreal = std::max<size_t>(nlist / 8 + 21, (size_t)((double)(nlist / 8) * (double)multipler) + 2);
+    for (size_t i = 0; i < n; i++) nreal = std::max<size_t>(nreal, (size_t)np0[i] + 1);
+    nreal = std::min(nreal + 16, nlist);
+    struct Restore {
+        amd_ivf_t* h;
+        ~Restore() {
+            h->ties_override = -1;
+            h->want_first_tie = false;
+        }
+    } restore{h};
+    h->ties_override = 0;
+    h->want_first_tie = true;
+    h->first_tie_nreal = nreal;
+    with_select_fallback(h, [&] { adaptive_core_once(h, d_x, start, n, query_topk, multipler, std_m, require_acc, gt_D, profile, coarse_mode, my_nprobe, t_recalls, D, I, qr); });
+    h->want_first_tie = false;
+    std::vector<uint32_t> again;
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t bound = 2 * my_nprobe[start + i] + 14;
+        if (h->first_tie_host[i] < bound || bound + 1 >= nreal) again.push_back((uint32_t)i);
+    }
+    h->last_tie_redone = again.size();
+    if (again.empty()) return;
+    const size_t m = again.size();
+    // what the first pass counted for these queries leaves the statistics (the device arrays are about to be reused)
+    std::vector<unsigned long long> nscan(n);
+    std::vector<uint2> qstat(n);
+    HIP_CHECK(hipMemcpyAsync(nscan.data(), h->w_nscan.p, n * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipMemcpyAsync(qstat.data(), h->w_qstat.p, n * sizeof(uint2), hipMemcpyDeviceToHost, h->stream));
+    h->w_redo_x.ensure(m * h->dpad * sizeof(float));
+    for (size_t j = 0; j < m; j++)
+        HIP_CHECK(hipMemcpyAsync(h->w_redo_x.as<float>() + j * h->dpad, d_x + (size_t)again[j] * h->dpad, h->dpad * sizeof(float),
+                                 hipMemcpyDeviceToDevice, h->stream));
+    HIP_CHECK(stream_sync(h->stream));
+    for (size_t j = 0; j < m; j++) {
+        h->stats_host[0] -= 1;
+        h->stats_host[1] -= qstat[again[j]].x;
+        h->stats_host[2] -= nscan[again[j]];
+        h->stats_host[3] -= qstat[again[j]].y;
+    }
+    std::vector<float> req(m), tr(m), Dc(m * K), gt;
+    std::vector<uint64_t> np(m);
+    std::vector<int64_t> Ic(m * K);
+    if (gt_D) gt.resize(m * K);
+    for (size_t j = 0; j < m; j++) {
+        const size_t id = start + again[j];
+        req[j] = require_acc[id];
+        np[j] = np0[again[j]];
+        tr[j] = tr0[again[j]];
+        if (gt_D) std::copy(gt_D + id * K, gt_D + (id + 1) * K, gt.begin() + j * K);
+    }
+    h->ties_override = 1;
+    with_select_fallback(h, [&] {
+        adaptive_core_once(h, h->w_redo_x.as<float>(), 0, m, query_topk, multipler, std_m, req.data(), gt_D ? gt.data() : nullptr, profile,
+                           coarse_mode, np.data(), tr.data(), Dc.data(), Ic.data(), qr);
+    });
+    for (size_t j = 0; j < m; j++) {
+        const size_t i = again[j];
+        my_nprobe[start + i] = np[j];
+        t_recalls[start + i] = tr[j];
+        std::copy(Dc.begin() + j * K, Dc.begin() + (j + 1) * K, D + i * K);
+        std::copy(Ic.begin() + j * K, Ic.begin() + (j + 1) * K, I + i * K);
+    }
+}
+
 // Fewer than 20 queries per call is the regime in which the reference ranks exact coarse distances (utils.cpp:624-655), so
 // there the order inside runs of bit-equal distances has to be its heap's.  Re-running that heap costs up to 2.8 ms a
 // ranking (nlist 4096) and one ranking in eight holds such a run somewhere in the prefix that may be read -- but a query
@@ -2865,7 +2945,16 @@ static void adaptive_core_once(amd_ivf_t* h, const float* d_x, size_t start, siz
 static void adaptive_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n, size_t query_topk, float multipler, float std_m,
                           const float* require_acc, const float* gt_D, int profile, int coarse_mode,
                           uint64_t* my_nprobe, float* t_recalls, float* D, int64_t* I, const IntRange& qr) {
-    const bool speculate = !h->given_keys && n > 0 && n < 20 && !getenv("AUNCEL_AMD_COARSE_TIES") && h->nlist > 128 && multipler >= 1.f && !(profile & 2);
+    const char* ties_env = getenv("AUNCEL_AMD_COARSE_TIES");
+    const bool can_speculate = !h->given_keys && n > 0 && h->nlist > 128 && multipler >= 1.f && !(profile & 2) && h->kids.empty();
+    const bool speculate = can_speculate && n < 20 && !ties_env;
+    // larger calls: "redo" searches again, with the heap's order, exactly the queries whose first run of equal coarse distances
+    // lies within what they read (a handful in thousands) -- the reference's exact-distance result for every query of the call
+    const bool redo_some = can_speculate && n >= 20 && ties_env && !strcmp(ties_env, "redo");
+    if (redo_some) {
+        adaptive_redo_ties(h, d_x, start, n, query_topk, multipler, std_m, require_acc, gt_D, profile, coarse_mode, my_nprobe, t_recalls, D, I, qr);
+        return;
+    }
     if (!speculate) {
         with_select_fallback(h, [&] { adaptive_core_once(h, d_x, start, n, query_topk, multipler, std_m, require_acc, gt_D, profile, coarse_mode, my_nprobe, t_recalls, D, I, qr); });
         return;
@@ -3292,6 +3381,11 @@ int amd_ivf_last_round_hints(amd_ivf_t* h, uint64_t out[2]) {
         out[0] += kid->hinted_rounds;
         out[1] += kid->short_rounds;
     }
+    return 0;
+}
+
+int amd_ivf_last_tie_redone(amd_ivf_t* h, uint64_t* queries) {
+    *queries = h->last_tie_redone;
     return 0;
 }
 

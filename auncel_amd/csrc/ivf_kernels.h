@@ -269,6 +269,7 @@ struct ReplayArgs {
                                //               while the next round's selection already appends)
     uint32_t nq_total;
     uint32_t* fin_round;       // [slot] the round in which the query got its final state (0xffffffff: not yet)
+    uint2* qstat;              // [slot] (lists scanned, heap updates) of this query so far (null: not kept)
 };
 
 bool replay_sorted_applies(const ReplayArgs& a);
@@ -449,6 +450,7 @@ struct InitStateArgs {
     uint32_t* error;
     uint32_t *log_cnt, *amb, *tie_flag;  // sorted-array selection (may be null)
     uint32_t *log_snap, *fin_round, *fix_pos;
+    uint2* qstat;
     float* fix_val;
     int64_t* fix_ref;
 };

@@ -1302,6 +1302,7 @@ __global__ __launch_bounds__(256) void init_state_kernel(InitStateArgs a) {
         a.done[i] = 0;
         a.pre_val[i] = 0.f;
         a.stoped[i] = 0;
+        if (a.qstat) a.qstat[i] = make_uint2(0u, 0u);
         if (a.log_cnt) {
             a.log_cnt[i] = 0;
             a.amb[i] = 0xffffffffu;

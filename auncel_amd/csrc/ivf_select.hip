@@ -928,6 +928,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
         if (a.pre_val) a.pre_val[qi] = pre_val;
         if (a.stoped) a.stoped[qi] = stoped;
         if (tune && np != np_in) a.tuner.my_nprobe[id_q] = np;
+        if (a.qstat) {
+            uint2 qs = a.qstat[qi];
+            qs.x += (uint32_t)st_nlist;
+            qs.y += (uint32_t)st_nheap;
+            a.qstat[qi] = qs;
+        }
         if (st_nlist) atomicAdd(&a.stats[0], st_nlist);
         if (st_ndis) atomicAdd(&a.stats[1], st_ndis);
         if (st_nheap) atomicAdd(&a.stats[2], st_nheap);
@@ -1482,6 +1488,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 
         a.pre_val[qi] = pre_val;
         a.stoped[qi] = stoped;
         if (TUNE && np != np_in) a.tuner.my_nprobe[id_q] = np;
+        if (a.qstat) {
+            uint2 qs = a.qstat[qi];
+            qs.x += (uint32_t)st_nlist;
+            qs.y += (uint32_t)st_nheap;
+            a.qstat[qi] = qs;
+        }
         if (st_nlist) atomicAdd(&a.stats[0], st_nlist);
         if (st_ndis) atomicAdd(&a.stats[1], st_ndis);
         if (st_nheap) atomicAdd(&a.stats[2], (unsigned long long)st_nheap);

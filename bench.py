@@ -612,6 +612,19 @@ def main():
                                                    np.array_equal(f_np[q_start:q_start + ses], my_sl))}
         for c in ctxs:
             c.set_byte_codes(True)
+    # the same steps with the reference's exact-distance tie order for every query (AUNCEL_AMD_COARSE_TIES=redo: the queries whose
+    # first run of equal coarse distances lies within what they read are searched again with the heap's order)
+    exact_ties = None
+    if not args.no_legs and "AUNCEL_AMD_COARSE_TIES" not in os.environ:
+        os.environ["AUNCEL_AMD_COARSE_TIES"] = "redo"
+        try:
+            nst = max(4, args.steps // 3)
+            leg = timed_leg(nst)
+            exact_ties = {"value": ses * nst / leg["elapsed"], "unit": "queries/s", "ms_per_step": 1000.0 * leg["elapsed"] / nst,
+                          "queries_searched_again_last_step": int(sum(c.last_tie_redone() for c in ctxs) / max(1, min(nfl, nst))),
+                          "setting": "AUNCEL_AMD_COARSE_TIES=redo"}
+        finally:
+            del os.environ["AUNCEL_AMD_COARSE_TIES"]
     # the reference's acceptance check at the operating point chosen for it on the training half
     guar = {"validation_min_recall_best": best_min[0], "validation_best_point": best_min[1]}
     if guaranteed is not None and not args.no_legs:
@@ -746,6 +759,8 @@ def main():
         }
     if fp32 is not None:
         out["fp32_path"] = fp32
+    if exact_ties is not None:
+        out["exact_tie_order"] = exact_ties
     out["guaranteed_bound_point"] = guar
 
     # ---- CPU baseline: the pinned CPU restatement of the reference path, all host cores, bounded sample
@@ -788,7 +803,7 @@ def main():
         timed_same = same_as(oD, oI, tun.my_nprobe[q_start:q_start + S], D[:S], I[:S], my_np[q_start:q_start + S])
         timed_diff = int(((oI != I[:S]).any(1) | (oD != D[:S]).any(1) | (tun.my_nprobe[q_start:q_start + S] != my_np[q_start:q_start + S])).sum())
         prev_ties = os.environ.get("AUNCEL_AMD_COARSE_TIES")
-        os.environ["AUNCEL_AMD_COARSE_TIES"] = "heap"
+        os.environ["AUNCEL_AMD_COARSE_TIES"] = "redo"
         rows0 = h.coarse_tie_rows()
         xnp, xtr = np.zeros(nall, dtype=np.uint64), np.zeros(nall, dtype=np.float32)
         xD, xI = h.search_adaptive(q_start, S, topk, chosen, args.std_m, req, xnp, xtr)
@@ -799,11 +814,13 @@ def main():
             os.environ["AUNCEL_AMD_COARSE_TIES"] = prev_ties
         xD, xI, xnp = xD.copy(), xI.copy(), xnp[q_start:q_start + S].copy()
         same = same_as(oD, oI, tun.my_nprobe[q_start:q_start + S], xD, xI, xnp)
-        parity = {"exact_regime": "AUNCEL_AMD_COARSE_TIES=heap: runs of bit-equal coarse distances ordered by the reference's heap "
-                                  "(the default below 20 queries per call)",
-                  "coarse_rankings_with_such_runs": int(tie_rows), "queries": S,
+        parity = {"exact_regime": "AUNCEL_AMD_COARSE_TIES=redo: the queries whose first run of bit-equal coarse distances lies within what "
+                                  "they read are searched again with the reference's heap order (the default below 20 queries per call "
+                                  "does the same for the whole call)",
+                  "queries_searched_again": int(h.last_tie_redone()), "coarse_rankings_re_run_through_the_heap": int(tie_rows), "queries": S,
                   "timed_configuration": "one call per batch; such runs stay in centroid-number order (re-running the heap costs "
-                                         "2.8 ms a row at nlist 4096)" if prev_ties != "heap" else "same as the exact regime",
+                                         "2.8 ms a row at nlist 4096: exact_tie_order has the throughput with it)"
+                                         if prev_ties not in ("heap", "redo") else "same as the exact regime",
                   "timed_configuration_queries_differing": timed_diff}
         if not same:
             log("PARITY MISMATCH vs the CPU restatement: rows differing in I / D / my_nprobe:", int((oI != xI).any(1).sum()),

@@ -73,7 +73,10 @@ def test_adaptive_search_with_coarse_ties(capi, oracle, monkeypatch, seed):
     rs = np.random.RandomState(8000 + seed)
     nlist, d, K = int(rs.choice([136, 256])), 16, int(rs.choice([10, 100]))
     nq = int(rs.choice([5, 60]))
-    monkeypatch.setenv("AUNCEL_AMD_COARSE_TIES", "heap" if nq >= 20 else "auto")
+    # calls of 20 queries and more: the heap's order for every ranking ("heap"), or the whole call in centroid-number order and
+    # then, again and with the heap's order, just the queries whose first run of equal distances lies within what they read ("redo")
+    ties = ("redo" if seed % 2 else "heap") if nq >= 20 else "auto"
+    monkeypatch.setenv("AUNCEL_AMD_COARSE_TIES", ties)
     nb = 20000
     xb, xq = grid_points(rs, nb, d, 12), grid_points(rs, nq, d, 12)
     cen = xb[rs.choice(nb, nlist, replace=False)].copy()
@@ -117,4 +120,7 @@ def test_adaptive_search_with_coarse_ties(capi, oracle, monkeypatch, seed):
     assert np.array_equal(bits(D), bits(eD))
     st = h.stats()
     assert [st["nlist"], st["ndis"], st["nheap_updates"]] == list(est)
+    assert st["nq"] == nq
     assert h.coarse_tie_rows() > 0
+    if ties == "redo":
+        assert 0 < h.last_tie_redone() <= nq
