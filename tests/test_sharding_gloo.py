@@ -23,11 +23,18 @@ def _worker(rank, world, port, name, q):
     try:
         case, gold = load_case(name)
         owner = np.arange(case["nlist"]) % world  # the golden shards are owner(l) = l % nshard
-        ok = True
+        # the coarse ranking is computed once: rank r holds the key rows of queries [r n / N, (r + 1) n / N) only and
+        # the ranks all-gather them (ragged shares: 7 queries over 2 ranks would be 3 + 4)
+        nq = case["xq"].shape[0]
+        counts = [(r + 1) * nq // world - r * nq // world for r in range(world)]
+        q0 = rank * nq // world
+        keys = sharding.allgather_rows(gold["coarse_keys_sse"][q0:q0 + counts[rank]], counts, dist)
+        cdis = sharding.allgather_rows(gold["coarse_dis_sse"][q0:q0 + counts[rank]], counts, dist)
+        ok = np.array_equal(keys, gold["coarse_keys_sse"]) and np.array_equal(cdis.view(np.uint32), gold["coarse_dis_sse"].view(np.uint32))
         for k in case["ks"]:
             la = sharding.local_assignment(gold["assign"], owner, rank)
             sub = pyoracle.Lists(case["metric"], case["centroids"], case["xb"], la)
-            D, I, _ = pyoracle.search_preassigned(sub, case["xq"], int(k), gold["coarse_keys_sse"], gold["coarse_dis_sse"])
+            D, I, _ = pyoracle.search_preassigned(sub, case["xq"], int(k), keys, cdis)
             out = sharding.gather_and_merge(D, I, case["metric"], capi.merge_tables, dist)
             if rank == 0:
                 ok &= np.array_equal(out[1], gold[f"I_shards_k{k}"]) and np.array_equal(out[0].view(np.uint32), gold[f"D_shards_k{k}"].view(np.uint32))
