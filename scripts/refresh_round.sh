@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything the round's committed numbers come from, in one gpurun call:
 #   gpurun --timeout 2700 -- 'bash scripts/refresh_round.sh r02'
-tag=${1:-r02}
+tag=${1:-r03}
 bash profiles/collect.sh $tag > gpurun_out/collect_$tag.log 2>&1
 python bench.py > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.log
 python scratch/perf_scan.py > gpurun_out/perf_scan_$tag.txt 2> gpurun_out/perf_scan_$tag.log
@@ -9,4 +9,6 @@ python scripts/bench_configs.py > gpurun_out/configs_$tag.jsonl 2> gpurun_out/co
 python bench.py --mode shards --test 10000 > gpurun_out/shards_$tag.json 2> gpurun_out/shards_$tag.log
 python scripts/effect_time.py > gpurun_out/effect_time_$tag.jsonl 2> gpurun_out/effect_time_$tag.log
 python scratch/latency1.py > gpurun_out/latency1_$tag.txt 2> gpurun_out/latency1_$tag.log
+python scratch/bw_probe.py > gpurun_out/bw_probe_$tag.txt 2> gpurun_out/bw_probe_$tag.log
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -5 > gpurun_out/gpu_tests_$tag.txt
 tail -3 gpurun_out/bench_$tag.log; cat gpurun_out/effect_time_$tag.jsonl; du -sh gpurun_out
