@@ -1459,6 +1459,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     pa.pad = h->w_pl_pad.as<uint32_t>();
     pa.row_align = sorted_ok ? 1024 : 64;  // (select_sorted_kernel reads dense rows in groups of four blocks of 256 candidates)
     pa.qblock = scan_qblock(base.bytes);
+    pa.mfma_qblock = MFMA_QBLOCK;
     if (base.bytes) {
         pa.mfma_chunk = mfma_chunk();
         pa.block_off = I->d_block_off.as<uint64_t>();

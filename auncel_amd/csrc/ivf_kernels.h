@@ -364,6 +364,7 @@ struct PlanArgs {
     uint32_t row_align;              // 1 or 64
     uint32_t qblock;                 // queries per full block of a list: 64 (8-wave tiles) or 32 (4-wave tiles)
     uint32_t mfma_chunk;             // != 0: items for scan_mfma_kernel (vectors per item); counted as tiles of shape 8
+    uint32_t mfma_qblock;            // queries per item in that form (MFMA_QBLOCK: one tile)
     const uint64_t* block_off;       // mfma: first 32-vector block of every list in the fragment-order storage
     uint32_t* seg_begin;             // [nq]
     unsigned long long* dist_base;   // [nq]

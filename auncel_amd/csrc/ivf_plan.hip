@@ -248,7 +248,7 @@ __global__ __launch_bounds__(1024) void plan_lists_kernel(PlanArgs a) {
         v[0] = c;
         v[1] = (c + SCAN_RQ - 1) / SCAN_RQ;
         if (a.mfma_chunk) {  // byte codes: one item per (chunk of the list, block of 32 queries), all in the last class
-            v[5] = ((c + MFMA_QBLOCK - 1) / MFMA_QBLOCK) * (uint32_t)((sz + a.mfma_chunk - 1) / a.mfma_chunk);
+            v[5] = ((c + a.mfma_qblock - 1) / a.mfma_qblock) * (uint32_t)((sz + a.mfma_chunk - 1) / a.mfma_chunk);
             return;
         }
         const uint32_t full = c / a.qblock, rem = c % a.qblock;
@@ -343,18 +343,18 @@ __device__ inline void items_of_list(const PlanArgs& a, uint32_t l, uint32_t c, 
         uint32_t ni = cur[3];
         const uint64_t b0 = a.block_off[l];
         for (uint32_t vb = 0; vb < sz; vb += a.mfma_chunk)
-            for (uint32_t qb = 0; qb < c; qb += MFMA_QBLOCK) {
+            for (uint32_t qb = 0; qb < c; qb += a.mfma_qblock) {
                 ScanItem it;
                 it.vec_base = b0 + vb / MFMA_BLOCK;
                 it.nvec = sz - vb < a.mfma_chunk ? sz - vb : a.mfma_chunk;
                 it.vec_off = vb;
                 it.pair_begin = p0 + qb;
-                it.npair = c - qb < MFMA_QBLOCK ? c - qb : MFMA_QBLOCK;
+                it.npair = c - qb < a.mfma_qblock ? c - qb : a.mfma_qblock;
                 it.qg = 0;
                 it.qgroup = (uint32_t)(vb0 + vb);  // global index of the chunk's first vector (the fp32 filter's exact rescoring)
                 if (ni < a.item_cap) a.items[ni] = it;
                 ni++;
-                slots += (unsigned long long)MFMA_QBLOCK * (((it.nvec + 63) / 64) * 64);
+                slots += (unsigned long long)(((it.npair + MFMA_QBLOCK - 1) / MFMA_QBLOCK) * MFMA_QBLOCK) * (((it.nvec + 63) / 64) * 64);
                 useful += (unsigned long long)it.npair * it.nvec;
             }
         return;
