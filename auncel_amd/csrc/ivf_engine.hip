@@ -260,8 +260,10 @@ struct amd_ivf {
     std::vector<uint32_t> round_hint;  // [round][16]
     uint64_t hint_sig = 0;
     uint64_t last_tie_redone = 0;  // queries the last adaptive call searched again for the coarse tie order (AUNCEL_AMD_COARSE_TIES=redo)
+    uint64_t filter_launches = 0;  // last search: threshold rounds that went through the matrix-core filter (ivf_filter.hip)
     uint64_t hinted_rounds = 0, short_rounds = 0;  // last search: scan launches sized by a hint / of those, grids smaller than the work
     std::atomic<int> live_contexts{1};  // on the index owner: itself + its clones (amd_ivf_clone / amd_ivf_destroy)
+    std::atomic<float> tie_rate{-1.f};  // on the index owner: share of the last search's queries in which equal distances met (-1: none yet)
     std::atomic<int> active_searches{0};  // on the index owner: searches inside run_rounds_device right now
     bool force_heap_select = false;  // (set while a search is repeated after ERR_LOG_OVERFLOW)
     // tune / train search over a coarse ranking the caller supplies (amd_ivf_search_adaptive_pre, amd_ivf_train_samples_pre):
@@ -1012,10 +1014,11 @@ template <class F> static void with_select_fallback(amd_ivf* h, F&& body) {
 }
 
 void fold_stats(amd_ivf* h, size_t nq) {
-    unsigned long long st[3];
+    unsigned long long st[4];
     SmallCopies guard(h);
-    d2h_small(h, st, h->w_stats.p, 24, h->stream);
+    d2h_small(h, st, h->w_stats.p, 32, h->stream);
     sync_and_flush(h, h->stream);
+    if (nq) ix(h)->tie_rate.store((float)((double)st[3] / (double)nq));
     h->stats_host[0] += nq;
     h->stats_host[1] += st[0];
     h->stats_host[2] += st[1];
@@ -1026,15 +1029,16 @@ void fold_stats(amd_ivf* h, size_t nq) {
 // copies (the reference throws in the middle of its loop and leaves partial output behind as well).
 void finish_results(amd_ivf* h, size_t n, size_t k, float* D, int64_t* I, uint32_t* stage_out = nullptr) {
     uint32_t err = 0;
-    unsigned long long st[3];
+    unsigned long long st[4];
     SmallCopies guard(h);
     d2h_small(h, &err, h->w_error.p, 4, h->stream);
-    d2h_small(h, st, h->w_stats.p, 24, h->stream);
+    d2h_small(h, st, h->w_stats.p, 32, h->stream);
     if (stage_out) d2h_small(h, stage_out, h->w_stage.p, n * 4, h->stream);
     d2h_small(h, D, h->w_D.p, n * k * sizeof(float), h->stream);
     d2h_small(h, I, h->w_I.p, n * k * sizeof(int64_t), h->stream);
     sync_and_flush(h, h->stream);
     throw_device_error(err);
+    if (n) ix(h)->tie_rate.store((float)((double)st[3] / (double)n));
     h->stats_host[0] += n;
     h->stats_host[1] += st[0];
     h->stats_host[2] += st[1];
@@ -1524,13 +1528,15 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     };
     const std::vector<uint32_t> hints_used = chained ? h->round_hint : std::vector<uint32_t>();  // (compared with what the rounds needed)
     h->hinted_rounds = h->short_rounds = 0;
+    h->filter_launches = 0;
     size_t planned_rounds = 0;  // plans launched so far (round r's counters reach history[r] when round r + 1 is planned)
     auto plan_round = [&](size_t round_len) {
         pa.round_len = (uint32_t)round_len;
         pa.dense_round = !(base.range || (planned_rounds > 0 && !no_thr));
         if (filter_ok) {  // threshold rounds of an fp32 search: items in the matrix-core form (a chunk x a block of 32 queries)
             const bool mf = !pa.dense_round;
-            pa.mfma_chunk = mf ? mfma_chunk() : 0;
+            pa.mfma_chunk = mf ? filter_item_vectors(h->d) : 0;
+            pa.mfma_qblock = mf ? filter_item_queries(h->d) : MFMA_QBLOCK;
             pa.block_off = mf ? I->d_block_off.as<uint64_t>() : nullptr;
             pa.qblock = scan_qblock(mf);
             pa.row_bytes = (uint32_t)h->dpad * 4;
@@ -1601,6 +1607,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             HIP_CHECK(hipEventRecord(h->ev_fork, s));
             HIP_CHECK(hipStreamWaitEvent(h->aux[3], h->ev_fork, 0));
             launch_scan_filter(fa, h->aux[3]);
+            h->filter_launches++;
             HIP_CHECK(hipEventRecord(h->ev_join[3], h->aux[3]));
             HIP_CHECK(hipStreamWaitEvent(s, h->ev_join[3], 0));
         } else {
@@ -1662,7 +1669,13 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         explicit Active(std::atomic<int>& cc) : c(cc), before(cc.fetch_add(1)) {}
         ~Active() { c.fetch_sub(1); }
     } active(I->active_searches);
-    const bool eager_fix = fix_env ? !strcmp(fix_env, "eager") : active.before == 0;
+    // ... and only where equal distances are common (integer-valued data: a third of the bench workload's queries): replaying
+    // every unfinished query's admissions after every round is then cheaper than replaying the flagged queries' whole logs at the
+    // end.  Where they are rare (float data: a query in a few hundred) the end pass is a handful of waves and the per-round one
+    // would only compete with the next round's planning and scan (DEEP-like configuration: 1.2 ms of it per search).
+    const float seen_rate = I->tie_rate.load();
+    const bool ties_common = seen_rate >= 0.f ? seen_rate > 0.02f : (base.bytes || base.fused);
+    const bool eager_fix = fix_env ? !strcmp(fix_env, "eager") : (active.before == 0 && ties_common);
     auto tie_fix_args = [&](uint32_t round, int final_pass) {
         TieFixArgs ta{};
         ta.metric = h->metric;
@@ -3403,6 +3416,19 @@ int amd_ivf_last_tie_fixed(amd_ivf_t* h, uint64_t* queries) {
     };
     add(h);
     for (auto& kid : h->kids) add(kid.get());
+    API_END
+}
+int amd_ivf_last_filter(amd_ivf_t* h, uint64_t out[2]) {
+    API_BEGIN
+    use_device(h);
+    out[0] = h->filter_launches;
+    out[1] = 0;
+    if (h->filter_launches && h->w_surv_cnt.p) {
+        uint32_t v = 0;
+        HIP_CHECK(stream_sync(h->stream));
+        HIP_CHECK(hipMemcpy(&v, h->w_surv_cnt.p, 4, hipMemcpyDeviceToHost));
+        out[1] = v;
+    }
     API_END
 }
 int amd_ivf_coarse_tie_rows(amd_ivf_t* h, uint64_t* rows) {

@@ -332,6 +332,232 @@ template <int METRIC, int NJ> __global__ __launch_bounds__(256) void scan_filter
     }  // items
 }
 
+// ---------------------------------------------------------------------------------------------
+// d > 128, the workgroup form: one work item = a chunk of <= 128 consecutive vectors of a list (FILTER_WIDE_VECTORS) x up to
+// 128 of the queries probing it (FILTER_WIDE_QUERIES), computed by the four waves of a workgroup together.  Wave w owns block
+// w of the chunk -- its 32 vectors stream from HBM once, straight into its registers, through a ring of FILTER_WIDE_SP pieces --
+// against ALL the item's query blocks (up to 4 accumulator tiles); the query operand, which every wave needs, goes through
+// LDS in stages of FILTER_WIDE_SP pieces (wave w fetches the rows of query block w: register staging, the write of stage
+// s + 1 behind the MFMAs of stage s, one barrier per stage).  Two workgroups per CU: one's barriers, prologue and epilogue
+// run under the other's MFMAs.  Against the one-wave form (32 queries x 128 vectors per pass) this reads the list once
+// instead of once per query block and the query rows once per chunk instead of once per wave: PMC on the GIST-like
+// configuration (d = 960, 71 queries per list): 16 GB fetched per pass over 3.84 GB of lists before.
+constexpr int FILTER_WIDE_QB = FILTER_WIDE_QUERIES / 32;
+constexpr int FILTER_WIDE_SP = 8;
+constexpr size_t FILTER_WIDE_STAGE_FLOATS = (size_t)FILTER_WIDE_QB * FILTER_WIDE_SP * 256;
+constexpr size_t FILTER_WIDE_LDS = 2 * FILTER_WIDE_STAGE_FLOATS * sizeof(float) + 4 * FILTER_WIDE_QUERIES * sizeof(float);
+static_assert(FILTER_WIDE_VECTORS == 128, "one 32-vector block per wave of the workgroup");
+
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global load in flight (one counter for
+// loads and stores on this ISA), which would drain the list prefetch ring at every stage
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void scan_filter_wide_kernel(FilterScanArgs a) {
+    extern __shared__ __align__(16) unsigned char wide_smem[];
+    float* s_a = reinterpret_cast<float*>(wide_smem);  // [2 buffers][query block][piece of the stage][lane][4]
+    float* s_u = s_a + 2 * FILTER_WIDE_STAGE_FLOATS;
+    float* s_c = s_u + FILTER_WIDE_QUERIES;
+    uint32_t* s_row = reinterpret_cast<uint32_t*>(s_c + FILTER_WIDE_QUERIES);
+    uint32_t* s_q = s_row + FILTER_WIDE_QUERIES;
+    constexpr int QB = FILTER_WIDE_QB, SP = FILTER_WIDE_SP;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = lane & 31, h = lane >> 5;
+    const int J = (int)filter_steps(a.d);
+    const int S = (J + SP - 1) / SP;
+    const size_t qstride = (size_t)J * 8;
+    const float C = (float)(2 * a.d + 32) * 5.9604644775390625e-08f;  // (2 d + 32) 2^-24
+    const uint32_t nitems = a.dev_nitems ? *a.dev_nitems : a.nitems;
+    uint32_t* mask32 = reinterpret_cast<uint32_t*>(a.mask);
+    ItemWalk w(nitems, a.xcd_chunks);
+    for (uint32_t wi = w.cur; wi < w.end; wi += w.step) {
+        const ScanItem it = a.items[wi];
+        const int nqb = (int)((it.npair + 31) >> 5);
+        // ---- per-query operands of query block `wave`, lane m (both halves) for its query m
+        const bool qok = (uint32_t)(wave * 32 + m) < it.npair;
+        uint32_t qrow = 0;
+        unsigned long long row = 0;
+        float u = __builtin_inff(), cq = 0.f;  // kept iff t > u: nothing passes for an absent query
+        if (qok) {
+            qrow = a.pair_query[it.pair_begin + wave * 32 + m];
+            row = a.pair_out[it.pair_begin + wave * 32 + m] + it.vec_off;
+            const float thr = a.thr[qrow], xn = a.xn[qrow];
+            if (METRIC == METRIC_L2) {
+                u = (1.f - C) * xn - thr;
+                if (!(thr == thr)) u = __builtin_inff();
+            } else {
+                u = thr;
+                if (!(thr == thr)) u = __builtin_inff();
+                cq = C * xn;
+            }
+        }
+        lds_barrier();  // the previous item's readers of the LDS tables and stages are done
+        if (h == 0) {
+            s_u[wave * 32 + m] = u;
+            s_c[wave * 32 + m] = cq;
+            s_row[wave * 32 + m] = (uint32_t)row;
+            s_q[wave * 32 + m] = qrow;
+        }
+        // Every wave runs the same sequence of loads, stages and barriers whatever its share of the item (a wave without a
+        // query block stages row 0, one without a block of the chunk recomputes the first and drops the result): the
+        // compiler's wait counts are exact only in straight-line code -- with the loads under conditions it waited for the
+        // youngest load of the prefetch ring at every stage.
+        const float* qp = a.xf + (size_t)qrow * qstride + (size_t)h * 4;
+        v4f st[SP];
+        auto stage_load = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+            for (int jj = 0; jj < SP; jj++) {
+                const int j = s * SP + jj;
+                st[jj] = *(gv4f)(uintptr_t)(qp + 8 * (j < J ? j : J - 1));
+            }
+        };
+        auto stage_write = [&](int s, int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int jj = 0; jj < SP; jj++)  // (pieces that pad the last stage contribute 0 x y)
+                *reinterpret_cast<v4f*>(s_a + ((size_t)(buf * QB + wave) * SP + jj) * 256 + (size_t)lane * 4) =
+                    s * SP + jj < J ? st[jj] : v4f{0.f, 0.f, 0.f, 0.f};
+        };
+        stage_load(0);
+        stage_write(0, 0);
+        const uint32_t nblk = ((it.nvec + 63) >> 6) * 2;  // (pairs of blocks, as the lists are stored)
+        const bool active = (uint32_t)wave < nblk;
+        const float* bbase = a.codes_frag + ((size_t)it.vec_base + (active ? (uint32_t)wave : 0u)) * (size_t)J * 256 + (size_t)lane * 4;
+
+        // ---- verdicts of this wave's block against query block qb, whose 32 x 32 dot products are in acc
+        auto finish_block = [&](uint32_t i, int qb, const v16f& acc) __attribute__((always_inline)) {
+            float ur[16], cr[16];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const v4f tu = *reinterpret_cast<const v4f*>(&s_u[qb * 32 + 8 * g + 4 * h]);
+                const v4f tc = *reinterpret_cast<const v4f*>(&s_c[qb * 32 + 8 * g + 4 * h]);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    ur[4 * g + e] = tu[e];
+                    cr[4 * g + e] = tc[e];
+                }
+            }
+            const float yn = a.yn[(it.vec_base + i) * 32 + m];
+            const uint32_t lv = i * 32 + m;           // position of this lane's vector in the chunk
+            const bool vok = lv < it.nvec;
+            const unsigned long long vmask = __ballot(vok);
+            const float c1yn = (1.f - C) * yn;
+            int word = 0;  // lane q (< 32) collects the 32-candidate mask word of query q of the block
+            unsigned long long kept[16];
+            uint32_t total = 0;
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                const float t = METRIC == METRIC_L2 ? fmaf(2.f, acc[reg], -c1yn) : fmaf(cr[reg], yn, acc[reg]);
+                const bool keep = t > ur[reg];
+                kept[reg] = __ballot(keep) & vmask;
+                total += (uint32_t)__builtin_popcountll(kept[reg]);
+            }
+            static_for(std::make_integer_sequence<int, 16>{}, [&](auto R) {
+                constexpr int reg = decltype(R)::value;
+                constexpr int q0 = (reg & 3) + 8 * (reg >> 2);  // query of lane half 0; half 1: q0 + 4
+                writelane_c<q0>(word, (uint32_t)kept[reg]);
+                writelane_c<q0 + 4>(word, (uint32_t)(kept[reg] >> 32));
+            });
+            if (lane < 32 && (uint32_t)(qb * 32 + lane) < it.npair) mask32[(s_row[qb * 32 + lane] + i * 32) >> 5] = (uint32_t)word;
+            if (total) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(a.surv_count, total);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+                for (int reg = 0; reg < 16; reg++) {
+                    const unsigned long long kb = kept[reg];
+                    if (kb == 0) continue;
+                    if ((kb >> lane) & 1) {
+                        const int q = qb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                        const uint32_t slot = base + (uint32_t)__builtin_popcountll(kb & lt);
+                        const uint32_t off = s_row[q] + lv, qr = s_q[q], vec = it.qgroup + lv;
+                        if (slot < a.surv_cap) a.surv[slot] = make_uint4(off, qr, vec, 0u);
+                        else a.dist[off] = exact_distance<METRIC>(a.queries + (size_t)qr * a.dpad, a.codes + (size_t)vec * a.dpad, a.dpad);
+                    }
+                    base += (uint32_t)__builtin_popcountll(kb);
+                }
+            }
+        };
+
+        // ---- the contraction; the K loop is compiled per count of query blocks (their accumulator tiles are registers)
+        v16f acc[QB];
+#pragma unroll
+        for (int q = 0; q < QB; q++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[q][r] = 0.f;
+        // this wave's block, a ring of SP pieces: the slot of piece j is refilled with piece j + SP right behind its MFMAs, so
+        // SP KB per wave are on their way from HBM at any time (one piece ahead left the matrix cores 3/4 idle: that covers a
+        // fraction of the memory latency)
+        v4f br[SP];
+        auto fetch_b = [&](int j, v4f& bv) __attribute__((always_inline)) {
+            bv = *(gv4f)(uintptr_t)(bbase + (size_t)(j < J ? j : J - 1) * 256);
+        };
+#pragma unroll
+        for (int jj = 0; jj < SP; jj++) fetch_b(jj, br[jj]);
+        lds_barrier();  // stage 0 is in LDS
+        auto run = [&](auto NQBc) __attribute__((always_inline)) {
+            constexpr int NQB = decltype(NQBc)::value;
+            v4f afA[NQB], afB[NQB];  // the query blocks' operands of an even and an odd piece, read from LDS one MFMA group ahead
+            auto load_a = [&](int buf, int jj, v4f (&af)[NQB]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int q = 0; q < NQB; q++)
+                    af[q] = *reinterpret_cast<const v4f*>(s_a + ((size_t)(buf * QB + q) * SP + jj) * 256 + (size_t)lane * 4);
+            };
+            auto mac = [&](const v4f (&af)[NQB], const v4f& bv) __attribute__((always_inline)) {
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+#pragma unroll
+                    for (int q = 0; q < NQB; q++) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][e], bv[e], acc[q], 0, 0, 0);
+            };
+            for (int s = 0; s < S; s++) {
+                const int buf = s & 1;
+                stage_load(s + 1);  // (behind the last stage: padding, written to the idle buffer and never read)
+#pragma unroll
+                for (int jj = 0; jj < SP; jj += 2) {
+                    const int j = s * SP + jj;
+                    if (jj == 0) load_a(buf, 0, afA);
+                    load_a(buf, jj + 1, afB);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mac(afA, br[jj]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    fetch_b(j + SP, br[jj]);
+                    if (jj + 2 < SP) load_a(buf, jj + 2, afA);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mac(afB, br[jj + 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    fetch_b(j + 1 + SP, br[jj + 1]);
+                }
+                stage_write(s + 1, buf ^ 1);  // (last read in stage s - 1: every wave is past that barrier)
+                lds_barrier();
+            }
+        };
+        switch (nqb) {
+            case 1: run(std::integral_constant<int, 1>{}); break;
+            case 2: run(std::integral_constant<int, 2>{}); break;
+            case 3: run(std::integral_constant<int, 3>{}); break;
+            default: run(std::integral_constant<int, 4>{}); break;
+        }
+        if (active) {
+            static_for(std::make_integer_sequence<int, QB>{}, [&](auto T) __attribute__((always_inline)) {
+                constexpr int q = decltype(T)::value;
+                if (q < nqb) finish_block((uint32_t)wave, q, acc[q]);
+            });
+        }
+    }  // items
+}
+
+uint32_t filter_item_queries(int d) {
+    return filter_steps(d) > 16 && !getenv("AUNCEL_AMD_FILTER_NARROW") ? FILTER_WIDE_QUERIES : MFMA_QBLOCK;
+}
+uint32_t filter_item_vectors(int d) {
+    return filter_steps(d) > 16 && !getenv("AUNCEL_AMD_FILTER_NARROW") ? FILTER_WIDE_VECTORS : mfma_chunk();
+}
+
 void launch_scan_filter(const FilterScanArgs& a, hipStream_t s) {
     if (a.nitems == 0 && !a.dev_nitems) return;
     const unsigned nwg = (a.nitems + 3) / 4;
@@ -344,13 +570,23 @@ void launch_scan_filter(const FilterScanArgs& a, hipStream_t s) {
         LAUNCH(kern, grid, block, 0, s, a);
         LAUNCH(resc, dim3(resident_grid(4)), dim3(256), 0, s, a);
     };
+    auto go_wide = [&](auto kern, auto resc) {  // one workgroup per item
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FILTER_WIDE_LDS);
+        if (e != hipSuccess) throw std::runtime_error(std::string("filter kernel: cannot reserve LDS: ") + hipGetErrorString(e));
+        const size_t hwg = (size_t)a.hint_nitems + a.hint_nitems / 8;
+        const unsigned hinted = (unsigned)((hwg + 7) / 8) * 8 + 8;
+        const dim3 grid(a.dev_nitems ? (a.hint_nitems ? hinted : resident_grid(2)) : (a.xcd_chunks ? ((a.nitems + 7) / 8) * 8 : a.nitems)), block(256);
+        LAUNCH(kern, grid, block, FILTER_WIDE_LDS, s, a);
+        LAUNCH(resc, dim3(resident_grid(4)), dim3(256), 0, s, a);
+    };
     auto pick = [&](auto metric) {
         constexpr int M = decltype(metric)::value;
         if (J <= 4) return go(scan_filter_kernel<M, 4>, rescore_kernel<M>);
         if (J <= 8) return go(scan_filter_kernel<M, 8>, rescore_kernel<M>);
         if (J <= 12) return go(scan_filter_kernel<M, 12>, rescore_kernel<M>);
         if (J <= 16) return go(scan_filter_kernel<M, 16>, rescore_kernel<M>);
-        return go(scan_filter_kernel<M, 0>, rescore_kernel<M>);
+        if (getenv("AUNCEL_AMD_FILTER_NARROW")) return go(scan_filter_kernel<M, 0>, rescore_kernel<M>);
+        return go_wide(scan_filter_wide_kernel<M>, rescore_kernel<M>);
     };
     if (a.metric == METRIC_L2) pick(std::integral_constant<int, METRIC_L2>{});
     else pick(std::integral_constant<int, METRIC_IP>{});

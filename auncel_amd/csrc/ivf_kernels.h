@@ -169,6 +169,11 @@ struct FilterScanArgs {
     uint32_t hint_nitems;
 };
 void launch_scan_filter(const FilterScanArgs& a, hipStream_t s);  // filter + rescoring, two launches
+// beyond 128 dimensions (the query operand no longer fits a wave's registers) an item of the filter is up to this many queries, computed by a whole workgroup (scan_filter_wide_kernel); AUNCEL_AMD_FILTER_NARROW=1 keeps the one-wave form
+constexpr uint32_t FILTER_WIDE_QUERIES = 128;
+constexpr uint32_t FILTER_WIDE_VECTORS = 128;  // ... x a chunk of this many vectors (one 32-vector block per wave)
+uint32_t filter_item_queries(int d);
+uint32_t filter_item_vectors(int d);
 void launch_frag32_from_f32(const float* codes, const uint64_t* list_off, const uint64_t* block_off, uint32_t nlist, uint64_t nblocks, int d,
                             int dpad, int metric, float* out, float* yn, hipStream_t s);
 void launch_filter_queries(const float* x, size_t n, int d, int dpad, int metric, float* xf, float* xn, hipStream_t s);

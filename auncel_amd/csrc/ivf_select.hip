@@ -1522,7 +1522,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 
         const bool dup = (in0 && lane >= 1 && sr.k0 == p0 && sr.k0 != SKEY_SENT) || (in1 && sr.k1 == p1 && sr.k1 != SKEY_SENT);
         const bool tainted = __ballot(dup) != 0 || worst_key() == amb;
         if (tainted && !err) {
-            if (lane == 0) a.tie_flag[qi] = 1;  // tie_fix_kernel writes this query's (D, I)
+            if (lane == 0) {
+                a.tie_flag[qi] = 1;  // tie_fix_kernel writes this query's (D, I)
+                atomicAdd(&a.stats[3], 1ull);  // (how common that is decides when tie_fix_kernel runs: run_rounds_device)
+            }
         } else {
             auto put = [&](int i, uint32_t key, uint32_t g) {
                 const bool empty = key == SKEY_SENT && g == SPOS_NONE;

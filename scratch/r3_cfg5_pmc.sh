@@ -1,9 +1,10 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY" "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" ; do
+for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE" "FETCH_SIZE" ; do
 out=gpurun_out/r3_c5pmc
 rm -rf $out && mkdir -p $out
-rocprofv3 --pmc $grp --output-format csv -d $out/p -- python scratch/r3_cfg5_trace.py gist > $out/log.txt 2>&1
+timeout 600 rocprofv3 --pmc $grp --output-format csv -d $out/p -- python3 scratch/r3_cfg5_trace.py gist > $out/log.txt 2>&1
+grep MARK $out/log.txt | head -3
 python - <<'PY'
 import csv, glob, collections
 f = glob.glob("gpurun_out/r3_c5pmc/p/*/*_counter_collection.csv")

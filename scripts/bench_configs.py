@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--cfg", default="1,3,5")
     ap.add_argument("--sample", type=int, default=64)
     ap.add_argument("--ref-sample", type=int, default=2000, help="queries the compiled reference runs (oracle/_ref/ref_harness fixedbench)")
+    ap.add_argument("--nprobes", default="", help="comma list: only these nprobe values")
     args = ap.parse_args()
     import torch
     from auncel_amd import capi
@@ -126,6 +127,8 @@ def main():
         lists.off, lists.codes, lists.ids = off, np.concatenate(codes), np.concatenate(ids)
         del codes, ids
         lists.struct = pyoracle.OrcIndex(metric, d, nlist, pyoracle._s(lists.off), pyoracle._f(lists.codes), pyoracle._i(lists.ids))
+        if args.nprobes:
+            nprobes = tuple(int(v) for v in args.nprobes.split(","))
         for nprobe in nprobes:
             h.search_resident(0, nq, k, nprobe)
             best = None

@@ -1,0 +1,99 @@
+"""fp32 lists: threshold rounds as matrix-core filter + exact recomputation (auncel_amd/csrc/ivf_filter.hip) against the
+pinned CPU oracle.  The filter may keep too much, never too little: every (D, I) and every statistic must be the oracle's,
+bit for bit, in every kernel shape (4 / 8 / 12 / 16 register-resident pieces up to 128 dimensions; the workgroup form and
+the one-wave form beyond), with 1 to 4 query blocks per item, ragged lists, and candidates that sit on or within an ulp of
+the thresholds."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from auncel_amd import capi
+    capi.lib()
+    return capi
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def clustered(rs, nb, nq, d, nlist, spread=0.35):
+    cen = rs.randn(nlist, d).astype(np.float32)
+    assign = rs.randint(0, nlist, size=nb)
+    if nlist > 3:
+        assign[assign == 1] = 0          # an empty list and a long one
+    xb = (cen[assign] + spread * rs.randn(nb, d)).astype(np.float32)
+    xq = (cen[rs.randint(0, nlist, size=nq)] + spread * rs.randn(nq, d)).astype(np.float32)
+    return cen, assign, xb, xq
+
+
+def run_and_compare(capi, oracle, metric, cen, assign, xb, xq, k, nprobe, expect_filter=True):
+    nlist, d = cen.shape
+    lists = oracle.Lists(metric, cen, xb, assign)
+    npq = min(nprobe, nlist)
+    cd, ck = oracle.knn(metric, xq, cen, npq)
+    eD, eI, est = oracle.search_preassigned(lists, xq, k, ck, cd)
+    h = capi.Handle(d, nlist, metric, 0)
+    h.set_centroids(cen)
+    h.set_lists_from_assign(xb, assign)
+    h.stats(reset=True)
+    D, I = h.search_preassigned(xq, k, ck, cd)
+    launches, kept = h.last_filter()
+    assert h.scan_arith() == 0
+    if expect_filter:
+        assert launches >= 1, "the search did not go through the filter"
+    assert np.array_equal(I, eI)
+    assert np.array_equal(bits(D), bits(eD))
+    st = h.stats()
+    assert [st["nlist"], st["ndis"], st["nheap_updates"]] == list(est)
+    h.close()
+    return launches, kept
+
+
+@pytest.mark.parametrize("metric", [1, 0])
+@pytest.mark.parametrize("d", [20, 64, 96, 128, 136, 200, 520, 960])
+def test_filter_rounds_equal_the_oracle(capi, oracle, d, metric):
+    rs = np.random.RandomState(7000 + d + metric)
+    nb = 5000 if d <= 200 else 2500
+    # queries per list (= per item, up to 128): ~19, ~37, ~75, ~130 -> 1, 2, 3, 4 (+ 1) query blocks in the workgroup form
+    for nlist, nq in ((64, 150), (32, 150), (16, 150), (16, 260)):
+        cen, assign, xb, xq = clustered(rs, nb, nq, d, nlist)
+        run_and_compare(capi, oracle, metric, cen, assign, xb, xq, k=10, nprobe=8)
+
+
+@pytest.mark.parametrize("d", [136, 960])
+def test_one_wave_form_beyond_128_dimensions(capi, oracle, monkeypatch, d):
+    monkeypatch.setenv("AUNCEL_AMD_FILTER_NARROW", "1")
+    rs = np.random.RandomState(7100 + d)
+    cen, assign, xb, xq = clustered(rs, 2500, 150, d, 16)
+    run_and_compare(capi, oracle, 1, cen, assign, xb, xq, k=10, nprobe=8)
+
+
+@pytest.mark.parametrize("metric", [1, 0])
+@pytest.mark.parametrize("d", [32, 96, 200])
+def test_candidates_on_and_next_to_the_threshold(capi, oracle, d, metric):
+    """Every vector exists several times, spread over the lists, next to copies that differ by one ulp in one coordinate: the
+    k-th best distance of every query is shared by, or within an ulp of, candidates in later probes.  A filter bound that is
+    too tight, a rescoring that rounds differently, or a selection that orders equal values differently shows up here."""
+    rs = np.random.RandomState(7200 + d + metric)
+    nlist, nq, k = 16, 160, 12
+    cen = rs.randn(nlist, d).astype(np.float32)
+    seeds = (cen[rs.randint(0, nlist, size=300)] + 0.3 * rs.randn(300, d)).astype(np.float32)
+    rows = []
+    for v in seeds:
+        for _ in range(3):
+            rows.append(v)                                   # exact copies
+        for _ in range(4):
+            w = v.copy()
+            c = rs.randint(0, d)
+            w[c] = np.nextafter(w[c], np.float32(np.inf if rs.rand() < 0.5 else -np.inf), dtype=np.float32)
+            rows.append(w)                                   # one ulp away in one coordinate
+    xb = np.stack(rows).astype(np.float32)
+    xb = xb[rs.permutation(len(xb))]
+    assign = rs.randint(0, nlist, size=len(xb))              # copies land in different lists: ties across probes
+    xq = (seeds[rs.randint(0, len(seeds), size=nq)] + 0.05 * rs.randn(nq, d)).astype(np.float32)
+    launches, kept = run_and_compare(capi, oracle, metric, cen, assign, xb, xq, k=k, nprobe=nlist)
+    assert kept > 0
