@@ -207,6 +207,17 @@ struct amd_ivf {
     size_t first_tie_nreal = 0;
     DevBuf w_first_tie;
     std::vector<uint32_t> first_tie_host;
+    // AUNCEL_AMD_COARSE_TIES=redo: the rankings that may need the reference's heap order (first run of equal distances within
+    // the window a query can read in its first two rounds) are set aside and re-ranked on a side stream WHILE the first pass
+    // searches; the second pass takes its rankings from those slots instead of running the heap (2.75 ms at nlist 4096) itself
+    DevBuf w_spec_full, w_spec_dis, w_spec_keys, w_spec_count, w_spec_slot, w_spec_pick, w_redo_idx;
+    hipStream_t spec_stream = nullptr;
+    hipEvent_t ev_spec_go = nullptr, ev_spec_done = nullptr;
+    bool spec_valid = false;  // the slots of the last first pass are (being) re-ranked
+    bool spec_use = false;    // second pass: ranking row j comes from slot w_spec_pick[j]
+    size_t spec_ncopy = 0;    // leading entries of a ranking the slots hold
+    std::vector<int32_t> spec_slot_host;
+    uint64_t tie_rows_host = 0;  // rankings taken from re-ranked slots (amd_ivf_coarse_tie_rows adds them)
     int ties_override = -1;  // coarse_dev: -1 as AUNCEL_AMD_COARSE_TIES / the call size say, 0 centroid-number order, 1 the reference's heap
     int last_arith = 0;  // scan arithmetic of the last search: 0 reference order, 1 fused, 2 byte codes
     // byte copy of the lists in MFMA fragment order (ivf_kernels.h) + per-slot constants, kept while the data qualifies
@@ -300,6 +311,9 @@ struct amd_ivf {
         }
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (fix_stream) (void)hipStreamDestroy(fix_stream);
+        if (spec_stream) (void)hipStreamDestroy(spec_stream);
+        if (ev_spec_go) (void)hipEventDestroy(ev_spec_go);
+        if (ev_spec_done) (void)hipEventDestroy(ev_spec_done);
         if (ev_sel) (void)hipEventDestroy(ev_sel);
         for (int i = 0; i < 2; i++)
             if (ev_fix[i]) (void)hipEventDestroy(ev_fix[i]);
@@ -1675,7 +1689,8 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     // would only compete with the next round's planning and scan (DEEP-like configuration: 1.2 ms of it per search).
     const float seen_rate = I->tie_rate.load();
     const bool ties_common = seen_rate >= 0.f ? seen_rate > 0.02f : (base.bytes || base.fused);
-    const bool eager_fix = fix_env ? !strcmp(fix_env, "eager") : (active.before == 0 && ties_common);
+    // (a handful of queries: the per-round replay is one wave's serial work on the critical path of a search that is all latency)
+    const bool eager_fix = fix_env ? !strcmp(fix_env, "eager") : (active.before == 0 && ties_common && n >= 512);
     auto tie_fix_args = [&](uint32_t round, int final_pass) {
         TieFixArgs ta{};
         ta.metric = h->metric;
@@ -2697,6 +2712,15 @@ int amd_ivf_set_tuner(amd_ivf_t* h, size_t max_topk, size_t ntraces, const size_
 // (Auncel/IndexIVF.cpp:382-386).  Returns the row length = the length of the probe loop.
 static size_t coarse_or_given(amd_ivf_t* L, const float* d_x, size_t n, int coarse_mode, bool fused_ok, size_t coarse_prefix) {
     const size_t nlist = L->nlist;
+    if (L->spec_use) {  // second pass of the "redo" regime: these queries' rankings were re-ranked while the first pass ran
+        L->w_cdis.ensure(n * nlist * 4);
+        L->w_ckeys.ensure(n * nlist * 8);
+        HIP_CHECK(hipStreamWaitEvent(L->stream, L->ev_spec_done, 0));
+        launch_spec_gather(L->w_spec_pick.as<int32_t>(), (uint32_t)n, (uint32_t)nlist, (uint32_t)L->spec_ncopy, L->w_spec_dis.as<float>(),
+                           L->w_spec_keys.as<int64_t>(), L->w_cdis.as<float>(), L->w_ckeys.as<int64_t>(), L->stream);
+        L->tie_rows_host += n;
+        return nlist;
+    }
     if (!L->given_keys) {
         L->w_cdis.ensure(n * nlist * 4);
         L->w_ckeys.ensure(n * nlist * 8);
@@ -2722,6 +2746,46 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
     if (L->want_first_tie) {
         L->w_first_tie.ensure(n * 4);
         launch_first_tie(L->w_cdis.as<float>(), (uint32_t)n, (uint32_t)nlist, (uint32_t)L->first_tie_nreal, L->w_first_tie.as<uint32_t>(), L->stream);
+        // Which queries will have to be searched again is known only when this pass ends (first run < 2 my_nprobe + 14), but the
+        // expensive part of searching them again -- the reference's heap over all nlist centroids, a serial 4096-element heap
+        // sort per query -- needs nothing from this pass.  Every query that could qualify with the probes of the first two
+        // rounds gets its rows set aside now (the distance table lives in w_dist, which round 0 overwrites) and the heap runs on
+        // a side stream under this pass.
+        static const bool no_spec = getenv("AUNCEL_AMD_NO_TIE_SPECULATION") != nullptr;
+        constexpr uint32_t SPEC_CAP = 512, SPEC_NEAR = 64, SPEC_WINDOW = 2 * (12 + 144) + 14;
+        L->spec_valid = false;
+        if (!no_spec && !L->given_keys && np_row == nlist && n <= L->dist_budget_floats / std::max<size_t>(nlist, 1) &&
+            heap_tie_order_lds((uint32_t)nlist, (uint32_t)nlist) <= 160 * 1024) {
+            const size_t ncopy = std::min(L->first_tie_nreal, nlist);
+            L->w_spec_full.ensure((size_t)SPEC_CAP * nlist * 4);
+            L->w_spec_dis.ensure((size_t)SPEC_CAP * nlist * 4);
+            L->w_spec_keys.ensure((size_t)SPEC_CAP * nlist * 8);
+            L->w_spec_count.ensure(16);  // count | - | rows the heap re-ranked (not reported: most are never used)
+            L->w_spec_slot.ensure(n * 4);
+            if (!L->spec_stream) {
+                HIP_CHECK(hipStreamCreateWithFlags(&L->spec_stream, hipStreamNonBlocking));
+                HIP_CHECK(hipEventCreateWithFlags(&L->ev_spec_go, hipEventDisableTiming));
+                HIP_CHECK(hipEventCreateWithFlags(&L->ev_spec_done, hipEventDisableTiming));
+            } else {
+                HIP_CHECK(hipStreamWaitEvent(L->stream, L->ev_spec_done, 0));  // (the previous search's slots are no longer being written)
+            }
+            HIP_CHECK(hipMemsetAsync(L->w_spec_count.p, 0, 16, L->stream));
+            // (slots go to the nearest runs first: a query that stops in round 0 -- most do -- reads 2 x 12 + 14 entries)
+            for (uint32_t lo = 0, hi = SPEC_NEAR; lo < SPEC_WINDOW; lo = hi, hi = SPEC_WINDOW)
+                launch_spec_collect(L->w_first_tie.as<uint32_t>(), (uint32_t)n, lo, hi, SPEC_CAP, (uint32_t)nlist, (uint32_t)ncopy,
+                                    L->w_dist.as<float>(), L->w_cdis.as<float>(), L->w_ckeys.as<int64_t>(), L->w_spec_count.as<uint32_t>(),
+                                    L->w_spec_slot.as<int32_t>(), L->w_spec_full.as<float>(), L->w_spec_dis.as<float>(),
+                                    L->w_spec_keys.as<int64_t>(), L->stream);
+            HIP_CHECK(hipEventRecord(L->ev_spec_go, L->stream));
+            HIP_CHECK(hipStreamWaitEvent(L->spec_stream, L->ev_spec_go, 0));
+            launch_heap_tie_order(L->w_spec_full.as<float>(), SPEC_CAP, (uint32_t)nlist, (uint32_t)nlist, (uint32_t)ncopy, L->metric,
+                                  L->w_spec_dis.as<float>(), L->w_spec_keys.as<int64_t>(),
+                                  reinterpret_cast<unsigned long long*>(L->w_spec_count.as<uint32_t>() + 2), L->spec_stream,
+                                  L->w_spec_count.as<uint32_t>());
+            HIP_CHECK(hipEventRecord(L->ev_spec_done, L->spec_stream));
+            L->spec_valid = true;
+            L->spec_ncopy = ncopy;
+        }
     }
     init_state(L, n, K, true);
     launch_set_online(L->metric, (uint32_t)nlist, (uint32_t)n, L->w_cdis.as<float>(), L->w_ckeys.as<int64_t>(), (uint32_t)np_row,
@@ -2846,6 +2910,12 @@ static void adaptive_core_once(amd_ivf_t* h, const float* d_x, size_t start, siz
     if (h->want_first_tie) {
         h->first_tie_host.assign(n, 0);
         d2h_small(h, h->first_tie_host.data(), h->w_first_tie.p, n * 4, h->stream);
+        if (h->spec_valid && nl == 1) {
+            h->spec_slot_host.assign(n, -1);
+            d2h_small(h, h->spec_slot_host.data(), h->w_spec_slot.p, n * 4, h->stream);
+        } else {
+            h->spec_valid = false;
+        }
     }
     sync_and_flush(h, h->stream);
     // fold the kids' counters and kernel timings into the handle
@@ -2893,11 +2963,13 @@ static void adaptive_redo_ties(amd_ivf_t* h, const float* d_x, size_t start, siz
         ~Restore() {
             h->ties_override = -1;
             h->want_first_tie = false;
+            h->spec_use = false;
         }
     } restore{h};
     h->ties_override = 0;
     h->want_first_tie = true;
     h->first_tie_nreal = nreal;
+    h->spec_valid = false;
     with_select_fallback(h, [&] { adaptive_core_once(h, d_x, start, n, query_topk, multipler, std_m, require_acc, gt_D, profile, coarse_mode, my_nprobe, t_recalls, D, I, qr); });
     h->want_first_tie = false;
     std::vector<uint32_t> again;
@@ -2913,10 +2985,28 @@ static void adaptive_redo_ties(amd_ivf_t* h, const float* d_x, size_t start, siz
     std::vector<uint2> qstat(n);
     HIP_CHECK(hipMemcpyAsync(nscan.data(), h->w_nscan.p, n * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipMemcpyAsync(qstat.data(), h->w_qstat.p, n * sizeof(uint2), hipMemcpyDeviceToHost, h->stream));
+    // their query rows, gathered on the device; their rankings from the slots re-ranked during the first pass if every one has one
+    bool spec = h->spec_valid && h->spec_slot_host.size() == n;
+    std::vector<int32_t> pick(m, -1);
+    for (size_t j = 0; j < m && spec; j++) {
+        pick[j] = h->spec_slot_host[again[j]];
+        spec = pick[j] >= 0;
+    }
+    if (getenv("AUNCEL_AMD_DEBUG_REDO")) {
+        size_t have = 0, nslots = 0;
+        for (size_t j = 0; j < m; j++) have += h->spec_valid && h->spec_slot_host.size() == n && h->spec_slot_host[again[j]] >= 0;
+        for (int32_t v : h->spec_slot_host) nslots += v >= 0;
+        fprintf(stderr, "[redo] n %zu again %zu spec_valid %d slots given %zu, of the queries searched again %zu have one -> %s\n", n, m,
+                (int)h->spec_valid, nslots, have, spec ? "slots" : "heap in the second pass");
+    }
     h->w_redo_x.ensure(m * h->dpad * sizeof(float));
-    for (size_t j = 0; j < m; j++)
-        HIP_CHECK(hipMemcpyAsync(h->w_redo_x.as<float>() + j * h->dpad, d_x + (size_t)again[j] * h->dpad, h->dpad * sizeof(float),
-                                 hipMemcpyDeviceToDevice, h->stream));
+    h->w_redo_idx.ensure(m * 4);
+    HIP_CHECK(hipMemcpyAsync(h->w_redo_idx.p, again.data(), m * 4, hipMemcpyHostToDevice, h->stream));
+    launch_gather_rows(d_x, h->w_redo_idx.as<uint32_t>(), (uint32_t)m, (uint32_t)h->dpad, h->w_redo_x.as<float>(), h->stream);
+    if (spec) {
+        h->w_spec_pick.ensure(m * 4);
+        HIP_CHECK(hipMemcpyAsync(h->w_spec_pick.p, pick.data(), m * 4, hipMemcpyHostToDevice, h->stream));
+    }
     HIP_CHECK(stream_sync(h->stream));
     for (size_t j = 0; j < m; j++) {
         h->stats_host[0] -= 1;
@@ -2936,6 +3026,7 @@ static void adaptive_redo_ties(amd_ivf_t* h, const float* d_x, size_t start, siz
         if (gt_D) std::copy(gt_D + id * K, gt_D + (id + 1) * K, gt.begin() + j * K);
     }
     h->ties_override = 1;
+    h->spec_use = spec;
     with_select_fallback(h, [&] {
         adaptive_core_once(h, h->w_redo_x.as<float>(), 0, m, query_topk, multipler, std_m, req.data(), gt_D ? gt.data() : nullptr, profile,
                            coarse_mode, np.data(), tr.data(), Dc.data(), Ic.data(), qr);
@@ -3436,6 +3527,7 @@ int amd_ivf_coarse_tie_rows(amd_ivf_t* h, uint64_t* rows) {
     use_device(h);
     *rows = 0;
     auto add = [&](amd_ivf* c) {
+        *rows += c->tie_rows_host;
         if (!c->w_tie_rows.p) return;
         uint64_t v = 0;
         HIP_CHECK(stream_sync(c->stream));

@@ -419,7 +419,22 @@ void launch_sort_rows(const float* dis, uint32_t nq, uint32_t nlist, uint32_t np
 // own heap (utils.cpp:417-490, Heap.h:88-142,295-322), whose order inside such a run depends on its history; *nrows
 // counts them.  false = heap + row exceed one workgroup's LDS, nothing launched.
 bool launch_heap_tie_order(const float* dis, uint32_t nq, uint32_t nlist, uint32_t nprobe, uint32_t nout, int metric, float* out_dis,
-                           int64_t* out_keys, unsigned long long* nrows, hipStream_t s);
+                           int64_t* out_keys, unsigned long long* nrows, hipStream_t s, const uint32_t* dev_nq = nullptr);
+
+size_t heap_tie_order_lds(uint32_t nlist, uint32_t nprobe);  // LDS bytes of one row's workgroup
+
+// Rankings that may need the heap's order, set aside while the search runs (AUNCEL_AMD_COARSE_TIES=redo): every query whose
+// first run of equal distances starts in [lo, window) gets a slot (at most cap; *count keeps counting beyond) holding copies of
+// its distance row (nlist floats) and of the first ncopy entries of its ranking (slot rows of nlist entries);
+// slot_of[q] = its slot or -1.  launch_heap_tie_order(dev_nq = count) then re-ranks the slots on a side stream.
+void launch_spec_collect(const uint32_t* first, uint32_t nq, uint32_t lo, uint32_t window, uint32_t cap, uint32_t nlist, uint32_t ncopy,
+                         const float* full, const float* cdis, const int64_t* ckeys, uint32_t* count, int32_t* slot_of, float* s_full,
+                         float* s_dis, int64_t* s_keys, hipStream_t s);
+// rows of a second search from those slots: ranking row j <- slot slots[j] (ncopy leading entries, rows of nlist entries)
+void launch_spec_gather(const int32_t* slots, uint32_t m, uint32_t nlist, uint32_t ncopy, const float* s_dis, const int64_t* s_keys,
+                        float* cdis, int64_t* ckeys, hipStream_t s);
+// out row j <- x row idx[j] (rows of dpad floats)
+void launch_gather_rows(const float* x, const uint32_t* idx, uint32_t m, uint32_t dpad, float* out, hipStream_t s);
 
 // position of the first pair of equal neighbours among the first nreal entries of every sorted ranking (row stride `stride`
 // floats), 0xffffffff if there is none

@@ -1153,8 +1153,10 @@ template <bool IsMax> __device__ inline void heapsort_pipelined(HeapEnt* a, uint
 
 template <bool IsMax>
 __global__ __launch_bounds__(64) void heap_tie_order_kernel(const float* dis, uint32_t nlist, uint32_t nprobe, uint32_t nout,
-                                                            float* out_dis, int64_t* out_keys, unsigned long long* nrows) {
+                                                            float* out_dis, int64_t* out_keys, unsigned long long* nrows,
+                                                            const uint32_t* dev_nq) {
     extern __shared__ __align__(16) unsigned char smem[];
+    if (dev_nq && blockIdx.x >= *dev_nq) return;  // (rows set aside on the device: launch_spec_collect)
     HeapEnt* h = reinterpret_cast<HeapEnt*>(smem);                           // nprobe + 2 entries, [0] unused
     float* row = reinterpret_cast<float*>(smem + (size_t)(nprobe + 2) * 8);  // nlist
     const uint32_t q = blockIdx.x, lane = threadIdx.x;
@@ -1239,21 +1241,74 @@ void launch_first_tie(const float* sorted_dis, uint32_t nq, uint32_t stride, uin
     if (nq) LAUNCH(first_tie_kernel, dim3(nq), dim3(64), 0, s, sorted_dis, stride, nreal, out);
 }
 
+__global__ __launch_bounds__(64) void spec_collect_kernel(const uint32_t* first, uint32_t lo, uint32_t window, uint32_t cap, uint32_t nlist, uint32_t ncopy,
+                                                          const float* full, const float* cdis, const int64_t* ckeys, uint32_t* count,
+                                                          int32_t* slot_of, float* s_full, float* s_dis, int64_t* s_keys) {
+    const uint32_t q = blockIdx.x, lane = threadIdx.x;
+    uint32_t slot = 0xffffffffu;
+    if (first[q] < lo) return;  // (dealt with by the launch for the nearer runs)
+    if (lane == 0 && first[q] < window) slot = atomicAdd(count, 1u);
+    slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
+    if (slot >= cap) {
+        if (lane == 0) slot_of[q] = -1;
+        return;
+    }
+    if (lane == 0) slot_of[q] = (int32_t)slot;
+    const float* fr = full + (size_t)q * nlist;
+    float* fo = s_full + (size_t)slot * nlist;
+    for (uint32_t j = lane; j < nlist; j += 64) fo[j] = fr[j];
+    for (uint32_t j = lane; j < ncopy; j += 64) {
+        s_dis[(size_t)slot * nlist + j] = cdis[(size_t)q * nlist + j];
+        s_keys[(size_t)slot * nlist + j] = ckeys[(size_t)q * nlist + j];
+    }
+}
+
+void launch_spec_collect(const uint32_t* first, uint32_t nq, uint32_t lo, uint32_t window, uint32_t cap, uint32_t nlist, uint32_t ncopy,
+                         const float* full, const float* cdis, const int64_t* ckeys, uint32_t* count, int32_t* slot_of, float* s_full,
+                         float* s_dis, int64_t* s_keys, hipStream_t s) {
+    if (nq) LAUNCH(spec_collect_kernel, dim3(nq), dim3(64), 0, s, first, lo, window, cap, nlist, ncopy, full, cdis, ckeys, count, slot_of, s_full, s_dis, s_keys);
+}
+
+__global__ __launch_bounds__(64) void spec_gather_kernel(const int32_t* slots, uint32_t nlist, uint32_t ncopy, const float* s_dis,
+                                                         const int64_t* s_keys, float* cdis, int64_t* ckeys) {
+    const uint32_t j = blockIdx.x;
+    const size_t src = (size_t)slots[j] * nlist, dst = (size_t)j * nlist;
+    for (uint32_t i = threadIdx.x; i < ncopy; i += 64) {
+        cdis[dst + i] = s_dis[src + i];
+        ckeys[dst + i] = s_keys[src + i];
+    }
+}
+
+void launch_spec_gather(const int32_t* slots, uint32_t m, uint32_t nlist, uint32_t ncopy, const float* s_dis, const int64_t* s_keys,
+                        float* cdis, int64_t* ckeys, hipStream_t s) {
+    if (m) LAUNCH(spec_gather_kernel, dim3(m), dim3(64), 0, s, slots, nlist, ncopy, s_dis, s_keys, cdis, ckeys);
+}
+
+__global__ __launch_bounds__(64) void gather_rows_kernel(const float* x, const uint32_t* idx, uint32_t dpad, float* out) {
+    const float* src = x + (size_t)idx[blockIdx.x] * dpad;
+    float* dst = out + (size_t)blockIdx.x * dpad;
+    for (uint32_t i = threadIdx.x; i < dpad; i += 64) dst[i] = src[i];
+}
+
+void launch_gather_rows(const float* x, const uint32_t* idx, uint32_t m, uint32_t dpad, float* out, hipStream_t s) {
+    if (m) LAUNCH(gather_rows_kernel, dim3(m), dim3(64), 0, s, x, idx, dpad, out);
+}
+
 size_t heap_tie_order_lds(uint32_t nlist, uint32_t nprobe) { return (size_t)(nprobe + 2) * 8 + (size_t)nlist * 4; }
 
 // nout: leading entries of each ranking the caller reads (<= nprobe); rows without a run of equal distances there are left
 // as they are.  Returns false (nothing launched) when heap and row do not fit one workgroup's LDS.
 bool launch_heap_tie_order(const float* dis, uint32_t nq, uint32_t nlist, uint32_t nprobe, uint32_t nout, int metric, float* out_dis,
-                           int64_t* out_keys, unsigned long long* nrows, hipStream_t s) {
+                           int64_t* out_keys, unsigned long long* nrows, hipStream_t s, const uint32_t* dev_nq) {
     if (nq == 0) return true;
     const size_t shmem = heap_tie_order_lds(nlist, nprobe);
     if (shmem > 160 * 1024) return false;
     if (metric == METRIC_L2) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(heap_tie_order_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        LAUNCH(heap_tie_order_kernel<true>, dim3(nq), dim3(64), shmem, s, dis, nlist, nprobe, nout, out_dis, out_keys, nrows);
+        LAUNCH(heap_tie_order_kernel<true>, dim3(nq), dim3(64), shmem, s, dis, nlist, nprobe, nout, out_dis, out_keys, nrows, dev_nq);
     } else {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(heap_tie_order_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        LAUNCH(heap_tie_order_kernel<false>, dim3(nq), dim3(64), shmem, s, dis, nlist, nprobe, nout, out_dis, out_keys, nrows);
+        LAUNCH(heap_tie_order_kernel<false>, dim3(nq), dim3(64), shmem, s, dis, nlist, nprobe, nout, out_dis, out_keys, nrows, dev_nq);
     }
     return true;
 }
