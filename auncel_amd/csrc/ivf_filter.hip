@@ -127,7 +127,94 @@ template <int METRIC> __global__ __launch_bounds__(256) void rescore_kernel(Filt
     const uint32_t n = *a.surv_count < a.surv_cap ? *a.surv_count : a.surv_cap;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const uint4 e = a.surv[i];  // (distance row position, query row, vector, -)
+        if (e.x == 0xffffffffu) continue;  // (an unused slot of a wave's chunk)
         a.dist[e.x] = exact_distance<METRIC>(a.queries + (size_t)e.y * a.dpad, a.codes + (size_t)e.z * a.dpad, a.dpad);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Survivor slots are handed out in chunks per wave: one returning atomic per SURV_CHUNK survivors instead of one per tile (a
+// tile of 32 x 32 pairs keeps ~15 candidates in a round that lets 1.5 % through, so every tile paid the atomic's round trip --
+// about as long as the tile's 64 MFMAs).  Slots of a chunk that stay unused are marked (rescore_kernel skips them).
+constexpr uint32_t SURV_CHUNK = 64;  // (a wave of the one-wave form runs one item: what it leaves unused of its last chunk is scanned by rescore_kernel)
+constexpr uint32_t SURV_NONE = 0xffffffffu;
+struct SurvChunk {
+    uint32_t base = 0, left = 0;  // wave-uniform
+};
+__device__ __forceinline__ void surv_retire(const FilterScanArgs& a, SurvChunk& sc, int lane) {
+    for (uint32_t s = (uint32_t)lane; s < sc.left; s += 64)
+        if (sc.base + s < a.surv_cap) a.surv[sc.base + s] = make_uint4(SURV_NONE, 0u, 0u, 0u);
+    sc.left = 0;
+}
+
+// ---- verdicts of block i of an item against its query block qb, whose 32 x 32 dot products are in acc; per-query operands
+// of the item's queries in LDS tables (u, c, row position, query row: entry qb * 32 + query of the block); yn = this lane's
+// vector's |y|^2 (L2) / |y| (IP), loaded by the caller ahead of the block's MFMAs
+template <int METRIC>
+__device__ __forceinline__ void filter_verdicts(const FilterScanArgs& a, const ScanItem& it, float C, uint32_t i, int qb, const v16f& acc,
+                                                float yn, const float* s_u, const float* s_c, const uint32_t* s_row,
+                                                const uint32_t* s_q, uint32_t* mask32, int lane, SurvChunk& sc) {
+    const int m = lane & 31, h = lane >> 5;
+    float ur[16], cr[16];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const v4f tu = *reinterpret_cast<const v4f*>(&s_u[qb * 32 + 8 * g + 4 * h]);
+        const v4f tc = *reinterpret_cast<const v4f*>(&s_c[qb * 32 + 8 * g + 4 * h]);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            ur[4 * g + e] = tu[e];
+            cr[4 * g + e] = tc[e];
+        }
+    }
+    const uint32_t lv = i * 32 + m;           // position of this lane's vector in the chunk
+    const bool vok = lv < it.nvec;
+    const unsigned long long vmask = __ballot(vok);
+    const float c1yn = (1.f - C) * yn;
+    int word = 0;  // lane q (< 32) collects the 32-candidate mask word of query q of the block
+    unsigned long long kept[16];
+    uint32_t total = 0;
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+        const float t = METRIC == METRIC_L2 ? fmaf(2.f, acc[reg], -c1yn) : fmaf(cr[reg], yn, acc[reg]);
+        const bool keep = t > ur[reg];
+        kept[reg] = __ballot(keep) & vmask;
+        total += (uint32_t)__builtin_popcountll(kept[reg]);
+    }
+    static_for(std::make_integer_sequence<int, 16>{}, [&](auto R) {
+        constexpr int reg = decltype(R)::value;
+        constexpr int q0 = (reg & 3) + 8 * (reg >> 2);  // query of lane half 0; half 1: q0 + 4
+        writelane_c<q0>(word, (uint32_t)kept[reg]);
+        writelane_c<q0 + 4>(word, (uint32_t)(kept[reg] >> 32));
+    });
+    if (lane < 32 && (uint32_t)(qb * 32 + lane) < it.npair) mask32[(s_row[qb * 32 + lane] + i * 32) >> 5] = (uint32_t)word;
+    if (total) {
+        // survivors: (distance row position, query row, vector) for rescore_kernel; beyond the list's capacity the exact
+        // distance is computed here (slow, never wrong)
+        if (total > sc.left) {
+            surv_retire(a, sc, lane);
+            const uint32_t want = total > SURV_CHUNK ? total : SURV_CHUNK;
+            uint32_t nb = 0;
+            if (lane == 0) nb = atomicAdd(a.surv_count, want);
+            sc.base = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);
+            sc.left = want;
+        }
+        uint32_t base = sc.base;
+        sc.base += total;
+        sc.left -= total;
+        const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            const unsigned long long kb = kept[reg];
+            if (kb == 0) continue;
+            if ((kb >> lane) & 1) {
+                const int q = qb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                const uint32_t slot = base + (uint32_t)__builtin_popcountll(kb & lt);
+                const uint32_t off = s_row[q] + lv, qr = s_q[q], vec = it.qgroup + lv;
+                if (slot < a.surv_cap) a.surv[slot] = make_uint4(off, qr, vec, 0u);
+                else a.dist[off] = exact_distance<METRIC>(a.queries + (size_t)qr * a.dpad, a.codes + (size_t)vec * a.dpad, a.dpad);
+            }
+            base += (uint32_t)__builtin_popcountll(kb);
+        }
     }
 }
 
@@ -148,6 +235,7 @@ template <int METRIC, int NJ> __global__ __launch_bounds__(256) void scan_filter
     const size_t qstride = (size_t)J * 8;
     const float C = (float)(2 * a.d + 32) * 5.9604644775390625e-08f;  // (2 d + 32) 2^-24
     const uint32_t nitems = a.dev_nitems ? *a.dev_nitems : a.nitems;
+    SurvChunk sc;
     ItemWalk w((nitems + 3) >> 2, a.xcd_chunks);
     for (uint32_t wi = w.cur; wi < w.end; wi += w.step) {
         const uint32_t item_no = wi * 4 + wave;
@@ -204,51 +292,10 @@ template <int METRIC, int NJ> __global__ __launch_bounds__(256) void scan_filter
         const float* bbase = a.codes_frag + (size_t)it.vec_base * (size_t)J * 256 + (size_t)lane * 4;
 
         // ---- the tile's verdicts: mask words + survivor entries of block i, whose 32 x 32 dot products are in acc
-        auto finish_block = [&](uint32_t i, const v16f& acc) {
-            const float yn = a.yn[(it.vec_base + i) * 32 + m];
-            const uint32_t lv = i * 32 + m;           // position of this lane's vector in the chunk
-            const bool vok = lv < it.nvec;
-            const unsigned long long vmask = __ballot(vok);
-            const float c1yn = (1.f - C) * yn;
-            int word = 0;  // lane q (< 32) collects the 32-candidate mask word of query q
-            unsigned long long kept[16];
-            uint32_t total = 0;
-#pragma unroll
-            for (int reg = 0; reg < 16; reg++) {
-                const float t = METRIC == METRIC_L2 ? fmaf(2.f, acc[reg], -c1yn) : fmaf(cr[reg], yn, acc[reg]);
-                const bool keep = t > ur[reg];
-                kept[reg] = __ballot(keep) & vmask;
-                total += (uint32_t)__builtin_popcountll(kept[reg]);
-            }
-            static_for(std::make_integer_sequence<int, 16>{}, [&](auto R) {
-                constexpr int reg = decltype(R)::value;
-                constexpr int q0 = (reg & 3) + 8 * (reg >> 2);  // query of lane half 0; half 1: q0 + 4
-                writelane_c<q0>(word, (uint32_t)kept[reg]);
-                writelane_c<q0 + 4>(word, (uint32_t)(kept[reg] >> 32));
-            });
-            if (lane < 32 && qok) mask32[(row + i * 32) >> 5] = (uint32_t)word;
-            if (total) {
-                // survivors: (distance row position, query row, vector) for rescore_kernel; beyond the list's capacity the exact
-                // distance is computed here (slow, never wrong)
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(a.surv_count, total);
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-#pragma unroll
-                for (int reg = 0; reg < 16; reg++) {
-                    const unsigned long long kb = kept[reg];
-                    if (kb == 0) continue;
-                    if ((kb >> lane) & 1) {
-                        const int q = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                        const uint32_t slot = base + (uint32_t)__builtin_popcountll(kb & lt);
-                        const uint32_t off = s_row[wave][q] + lv, qr = s_q[wave][q], vec = it.qgroup + lv;
-                        if (slot < a.surv_cap) a.surv[slot] = make_uint4(off, qr, vec, 0u);
-                        else a.dist[off] = exact_distance<METRIC>(a.queries + (size_t)qr * a.dpad, a.codes + (size_t)vec * a.dpad, a.dpad);
-                    }
-                    base += (uint32_t)__builtin_popcountll(kb);
-                }
-            }
+        auto finish_block = [&](uint32_t i, const v16f& acc, float yn) __attribute__((always_inline)) {
+            filter_verdicts<METRIC>(a, it, C, i, 0, acc, yn, s_u[wave], s_c[wave], s_row[wave], s_q[wave], mask32, lane, sc);
         };
+        auto load_yn = [&](uint32_t i) __attribute__((always_inline)) { return a.yn[(it.vec_base + i) * 32 + m]; };
 
         if constexpr (NJ != 0) {
             // P pieces of the list in flight, across block boundaries: piece t of the chunk's linear sequence lives in register
@@ -259,6 +306,7 @@ template <int METRIC, int NJ> __global__ __launch_bounds__(256) void scan_filter
 #pragma unroll
             for (int j = 0; j < P; j++) bq[j] = *(gv4f)(uintptr_t)(bbase + (size_t)j * 256);
             for (uint32_t i = 0; i < nblk; i++) {
+                const float yn = load_yn(i);  // (needed behind the block's MFMAs: its latency hides under them)
                 v16f acc;
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[r] = 0.f;
@@ -274,7 +322,7 @@ template <int METRIC, int NJ> __global__ __launch_bounds__(256) void scan_filter
                     bq[j % P] = *(gv4f)(uintptr_t)src;  // (cached: the chunk's other query blocks read it too)
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                finish_block(i, acc);
+                finish_block(i, acc, yn);
             }
         } else {
             // d > 128: the query operand does not fit the registers; it is re-read (L2) piece by piece, and every piece serves
@@ -287,6 +335,9 @@ template <int METRIC, int NJ> __global__ __launch_bounds__(256) void scan_filter
 #pragma unroll
                     for (int r = 0; r < 16; r++) acc[g][r] = 0.f;
                 const uint32_t ng = nblk - i0 < (uint32_t)G ? nblk - i0 : (uint32_t)G;  // (2 or 4: lists come in pairs of blocks)
+                float yng[G];
+#pragma unroll
+                for (int g = 0; g < G; g++) yng[g] = load_yn(i0 + ((uint32_t)g < ng ? (uint32_t)g : ng - 1));
                 const float* bp = bbase + (size_t)i0 * (size_t)J * 256;
                 const size_t bstep = (size_t)J * 256;  // floats from a block's piece j to the next block's
                 // straight-line loads (no predicates: an absent query reads query row 0 and a block past the chunk's end re-reads
@@ -325,11 +376,12 @@ template <int METRIC, int NJ> __global__ __launch_bounds__(256) void scan_filter
 #undef FILTER_MAC
                 static_for(std::make_integer_sequence<int, G>{}, [&](auto Gi) {
                     constexpr int g = decltype(Gi)::value;
-                    if ((uint32_t)g < ng) finish_block(i0 + g, acc[g]);
+                    if ((uint32_t)g < ng) finish_block(i0 + g, acc[g], yng[g]);
                 });
             }
         }
     }  // items
+    surv_retire(a, sc, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -374,6 +426,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float C = (float)(2 * a.d + 32) * 5.9604644775390625e-08f;  // (2 d + 32) 2^-24
     const uint32_t nitems = a.dev_nitems ? *a.dev_nitems : a.nitems;
     uint32_t* mask32 = reinterpret_cast<uint32_t*>(a.mask);
+    SurvChunk sc;
     ItemWalk w(nitems, a.xcd_chunks);
     for (uint32_t wi = w.cur; wi < w.end; wi += w.step) {
         const ScanItem it = a.items[wi];
@@ -428,60 +481,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const bool active = (uint32_t)wave < nblk;
         const float* bbase = a.codes_frag + ((size_t)it.vec_base + (active ? (uint32_t)wave : 0u)) * (size_t)J * 256 + (size_t)lane * 4;
 
-        // ---- verdicts of this wave's block against query block qb, whose 32 x 32 dot products are in acc
+        const float yn = a.yn[((size_t)it.vec_base + (active ? (uint32_t)wave : 0u)) * 32 + m];
         auto finish_block = [&](uint32_t i, int qb, const v16f& acc) __attribute__((always_inline)) {
-            float ur[16], cr[16];
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const v4f tu = *reinterpret_cast<const v4f*>(&s_u[qb * 32 + 8 * g + 4 * h]);
-                const v4f tc = *reinterpret_cast<const v4f*>(&s_c[qb * 32 + 8 * g + 4 * h]);
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    ur[4 * g + e] = tu[e];
-                    cr[4 * g + e] = tc[e];
-                }
-            }
-            const float yn = a.yn[(it.vec_base + i) * 32 + m];
-            const uint32_t lv = i * 32 + m;           // position of this lane's vector in the chunk
-            const bool vok = lv < it.nvec;
-            const unsigned long long vmask = __ballot(vok);
-            const float c1yn = (1.f - C) * yn;
-            int word = 0;  // lane q (< 32) collects the 32-candidate mask word of query q of the block
-            unsigned long long kept[16];
-            uint32_t total = 0;
-#pragma unroll
-            for (int reg = 0; reg < 16; reg++) {
-                const float t = METRIC == METRIC_L2 ? fmaf(2.f, acc[reg], -c1yn) : fmaf(cr[reg], yn, acc[reg]);
-                const bool keep = t > ur[reg];
-                kept[reg] = __ballot(keep) & vmask;
-                total += (uint32_t)__builtin_popcountll(kept[reg]);
-            }
-            static_for(std::make_integer_sequence<int, 16>{}, [&](auto R) {
-                constexpr int reg = decltype(R)::value;
-                constexpr int q0 = (reg & 3) + 8 * (reg >> 2);  // query of lane half 0; half 1: q0 + 4
-                writelane_c<q0>(word, (uint32_t)kept[reg]);
-                writelane_c<q0 + 4>(word, (uint32_t)(kept[reg] >> 32));
-            });
-            if (lane < 32 && (uint32_t)(qb * 32 + lane) < it.npair) mask32[(s_row[qb * 32 + lane] + i * 32) >> 5] = (uint32_t)word;
-            if (total) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(a.surv_count, total);
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-#pragma unroll
-                for (int reg = 0; reg < 16; reg++) {
-                    const unsigned long long kb = kept[reg];
-                    if (kb == 0) continue;
-                    if ((kb >> lane) & 1) {
-                        const int q = qb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                        const uint32_t slot = base + (uint32_t)__builtin_popcountll(kb & lt);
-                        const uint32_t off = s_row[q] + lv, qr = s_q[q], vec = it.qgroup + lv;
-                        if (slot < a.surv_cap) a.surv[slot] = make_uint4(off, qr, vec, 0u);
-                        else a.dist[off] = exact_distance<METRIC>(a.queries + (size_t)qr * a.dpad, a.codes + (size_t)vec * a.dpad, a.dpad);
-                    }
-                    base += (uint32_t)__builtin_popcountll(kb);
-                }
-            }
+            filter_verdicts<METRIC>(a, it, C, i, qb, acc, yn, s_u, s_c, s_row, s_q, mask32, lane, sc);
         };
 
         // ---- the contraction; the K loop is compiled per count of query blocks (their accumulator tiles are registers)
@@ -549,13 +551,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             });
         }
     }  // items
+    surv_retire(a, sc, lane);
 }
 
+// Up to 128 dimensions the one-wave form stays: the same workgroup scheme with the whole query operand in LDS (64 KB at d = 128)
+// was measured slower in both rounds of an adaptive fp32 search (15 queries per list: 2.36 vs 1.25 ms; 70 per list: 3.90 vs
+// 2.95 ms) -- a wave that holds its 32 queries in registers needs no barrier and no LDS traffic, and the re-reads of a chunk by
+// the list's other query blocks are L2 hits of neighbouring waves.
+static bool filter_narrow() { return getenv("AUNCEL_AMD_FILTER_NARROW") != nullptr; }
 uint32_t filter_item_queries(int d) {
-    return filter_steps(d) > 16 && !getenv("AUNCEL_AMD_FILTER_NARROW") ? FILTER_WIDE_QUERIES : MFMA_QBLOCK;
+    return filter_steps(d) > 16 && !filter_narrow() ? FILTER_WIDE_QUERIES : MFMA_QBLOCK;
 }
 uint32_t filter_item_vectors(int d) {
-    return filter_steps(d) > 16 && !getenv("AUNCEL_AMD_FILTER_NARROW") ? FILTER_WIDE_VECTORS : mfma_chunk();
+    return filter_steps(d) > 16 && !filter_narrow() ? FILTER_WIDE_VECTORS : mfma_chunk();
 }
 
 void launch_scan_filter(const FilterScanArgs& a, hipStream_t s) {
@@ -585,7 +593,7 @@ void launch_scan_filter(const FilterScanArgs& a, hipStream_t s) {
         if (J <= 8) return go(scan_filter_kernel<M, 8>, rescore_kernel<M>);
         if (J <= 12) return go(scan_filter_kernel<M, 12>, rescore_kernel<M>);
         if (J <= 16) return go(scan_filter_kernel<M, 16>, rescore_kernel<M>);
-        if (getenv("AUNCEL_AMD_FILTER_NARROW")) return go(scan_filter_kernel<M, 0>, rescore_kernel<M>);
+        if (filter_narrow()) return go(scan_filter_kernel<M, 0>, rescore_kernel<M>);
         return go_wide(scan_filter_wide_kernel<M>, rescore_kernel<M>);
     };
     if (a.metric == METRIC_L2) pick(std::integral_constant<int, METRIC_L2>{});

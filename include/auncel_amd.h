@@ -264,7 +264,8 @@ int amd_ivf_last_tie_fixed(amd_ivf_t* h, uint64_t* queries);
 /* fp32 lists: threshold rounds compute x.y on the matrix cores and keep a candidate iff its distance, widened by a rigorous
  * bound on the difference to the reference's value (utils_simd.cpp:391-443 rounding sequence), can beat the query's threshold;
  * the kept ones are recomputed in the reference's rounding sequence, so (D, I) stay bit-identical.  out[0] = rounds of the last
- * search on this handle that ran that way, out[1] = candidates the last of them kept for the exact recomputation. */
+ * search on this handle that ran that way, out[1] = survivor slots the last of them handed out (>= the candidates it kept for the
+ * exact recomputation: a wave takes slots 64 at a time and marks the ones it leaves unused). */
 int amd_ivf_last_filter(amd_ivf_t* h, uint64_t out[2]);
 
 /* Arithmetic the list scan of the last search ran in.  All three produce the reference's fp32 distance bit for
