@@ -271,6 +271,11 @@ struct amd_ivf {
     std::vector<uint32_t> round_hint;  // [round][16]
     uint64_t hint_sig = 0;
     uint64_t last_tie_redone = 0;  // queries the last adaptive call searched again for the coarse tie order (AUNCEL_AMD_COARSE_TIES=redo)
+    // run_rounds_device: the selection kernels write (D, I) straight into the caller's buffers when those are page-locked and
+    // device-visible (rows leave as their queries finish, under the later rounds; no copy at the end); null: w_D / w_I + a copy
+    float* out_D = nullptr;
+    int64_t* out_I = nullptr;
+    int last_direct_out = 0;  // whether the last search did
     uint64_t filter_launches = 0;  // last search: threshold rounds that went through the matrix-core filter (ivf_filter.hip)
     uint64_t hinted_rounds = 0, short_rounds = 0;  // last search: scan launches sized by a hint / of those, grids smaller than the work
     std::atomic<int> live_contexts{1};  // on the index owner: itself + its clones (amd_ivf_clone / amd_ivf_destroy)
@@ -1039,6 +1044,29 @@ void fold_stats(amd_ivf* h, size_t nq) {
     h->stats_host[3] += st[2];
 }
 
+// device view of a page-locked host buffer (hipHostMalloc / hipHostRegister, e.g. torch's pin_memory), else null
+static void* device_view(const void* host) {
+    static const bool off = getenv("AUNCEL_AMD_DIRECT_OUT") && !strcmp(getenv("AUNCEL_AMD_DIRECT_OUT"), "0");
+    if (off || !host) return nullptr;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, host) != hipSuccess) {
+        (void)hipGetLastError();  // (pageable memory: not an error of ours)
+        return nullptr;
+    }
+    return at.type == hipMemoryTypeHost ? at.devicePointer : nullptr;
+}
+struct DirectOut {
+    amd_ivf* h;
+    DirectOut(amd_ivf* h_, float* D, int64_t* I) : h(h_) {
+        void* d = device_view(D);
+        void* i = d ? device_view(I) : nullptr;
+        h->out_D = i ? static_cast<float*>(d) : nullptr;
+        h->out_I = i ? static_cast<int64_t*>(i) : nullptr;
+        h->last_direct_out = h->out_D != nullptr;
+    }
+    ~DirectOut() { h->out_D = nullptr, h->out_I = nullptr; }
+};
+
 // Final read-back of a search: results, error word and counters behind one synchronisation.  An error is raised after the
 // copies (the reference throws in the middle of its loop and leaves partial output behind as well).
 void finish_results(amd_ivf* h, size_t n, size_t k, float* D, int64_t* I, uint32_t* stage_out = nullptr) {
@@ -1048,8 +1076,10 @@ void finish_results(amd_ivf* h, size_t n, size_t k, float* D, int64_t* I, uint32
     d2h_small(h, &err, h->w_error.p, 4, h->stream);
     d2h_small(h, st, h->w_stats.p, 32, h->stream);
     if (stage_out) d2h_small(h, stage_out, h->w_stage.p, n * 4, h->stream);
-    d2h_small(h, D, h->w_D.p, n * k * sizeof(float), h->stream);
-    d2h_small(h, I, h->w_I.p, n * k * sizeof(int64_t), h->stream);
+    if (!h->out_D) {  // (else the kernels wrote the caller's buffers themselves)
+        d2h_small(h, D, h->w_D.p, n * k * sizeof(float), h->stream);
+        d2h_small(h, I, h->w_I.p, n * k * sizeof(int64_t), h->stream);
+    }
     sync_and_flush(h, h->stream);
     throw_device_error(err);
     if (n) ix(h)->tie_rate.store((float)((double)st[3] / (double)n));
@@ -1282,6 +1312,7 @@ void search_fixed_device(amd_ivf* h, const float* d_x, size_t n, size_t k, size_
     base.caller_checks_error = true;
     with_select_fallback(h, [&] {
         if (h->force_heap_select) init_state(h, n, k, false);
+        DirectOut direct(h, D, I);
         run_rounds_device(h, base, n, first, nprobe, nullptr);
         finish_results(h, n, k, D, I);
     });
@@ -1711,8 +1742,8 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         ta.list_off = I->d_list_off.as<uint64_t>();
         ta.ids = I->d_ids.as<int64_t>();
         ta.store_pairs = base.store_pairs;
-        ta.D = h->w_D.as<float>();
-        ta.I = h->w_I.as<int64_t>();
+        ta.D = h->out_D ? h->out_D : h->w_D.as<float>();
+        ta.I = h->out_I ? h->out_I : h->w_I.as<int64_t>();
         return ta;
     };
     // ---- ordered selection of a scanned round.  nact: active queries (sync) or the bound n with the count on the device.
@@ -1752,8 +1783,8 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         ra.coarse_keys = base.d_ckeys;
         ra.coarse_stride = base.coarse_stride;
         ra.trace_cap = (uint32_t)I->tuner_trace_cap;
-        ra.D = h->w_D.as<float>();
-        ra.I = h->w_I.as<int64_t>();
+        ra.D = h->out_D ? h->out_D : h->w_D.as<float>();
+        ra.I = h->out_I ? h->out_I : h->w_I.as<int64_t>();
         ra.stats = h->w_stats.as<unsigned long long>();
         ra.error = h->w_error.as<uint32_t>();
         ra.tuner = base.tuner;
@@ -2812,6 +2843,7 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
         return;
     }
     base.caller_checks_error = true;
+    DirectOut direct(L, D, I);
     run_rounds_device(L, base, n, first_env, np_row, dnp);
     finish_results(L, n, K, D, I);
 }
@@ -3509,6 +3541,7 @@ int amd_ivf_last_tie_fixed(amd_ivf_t* h, uint64_t* queries) {
     for (auto& kid : h->kids) add(kid.get());
     API_END
 }
+int amd_ivf_last_direct_out(amd_ivf_t* h) { return h ? h->last_direct_out : 0; }
 int amd_ivf_last_filter(amd_ivf_t* h, uint64_t out[2]) {
     API_BEGIN
     use_device(h);

@@ -267,6 +267,11 @@ int amd_ivf_last_tie_fixed(amd_ivf_t* h, uint64_t* queries);
  * search on this handle that ran that way, out[1] = survivor slots the last of them handed out (>= the candidates it kept for the
  * exact recomputation: a wave takes slots 64 at a time and marks the ones it leaves unused). */
 int amd_ivf_last_filter(amd_ivf_t* h, uint64_t out[2]);
+/* 1 if the last search on this handle wrote (D, I) straight into the caller's buffers: when both are page-locked, device-visible
+ * host memory (hipHostMalloc / hipHostRegister; torch's pin_memory) the selection kernels store each query's row there as the
+ * query finishes, under the later rounds, and the call ends without a copy; pageable buffers are filled by a copy at the end.
+ * AUNCEL_AMD_DIRECT_OUT=0 always copies. */
+int amd_ivf_last_direct_out(amd_ivf_t* h);
 
 /* Arithmetic the list scan of the last search ran in.  All three produce the reference's fp32 distance bit for
  * bit (utils_simd.cpp:391-443 order); the engine picks the cheapest one the data allows:

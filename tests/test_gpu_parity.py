@@ -555,3 +555,45 @@ def test_training_over_the_references_blas_ranking(capi, name):
     h.train_samples_pre(case["xq"][:ts], 0, gold["coarse_keys_blas_train"], gold["coarse_dis_blas_train"], K, gold["gtD"], ts, raw)
     for i in range(ntr):
         assert np.array_equal(bits(raw[i]), bits(gold[f"raw_trace{i}"])), i
+
+
+@pytest.mark.parametrize("select", ["sorted", "heap"])
+@pytest.mark.parametrize("name", AUNCEL[:2])
+def test_results_written_straight_into_page_locked_buffers(capi, monkeypatch, name, select):
+    """a caller that hands over page-locked (D, I) gets its rows written by the selection kernels themselves as queries finish
+    (no copy at the end): same bits as the golden outputs, for the sorted-array selection, its tie replay and the heap kernels"""
+    import ctypes
+    monkeypatch.setenv("AUNCEL_AMD_SELECT", select)
+    case, gold = load_case(name)
+    K, ts, ses = case["max_topk"], case["train_num"], case["test_num"]
+    h = make_index(capi, case, gold, gold["centroids"])
+    h.set_interdis(None)
+    h.set_tuner(K, traces_from_gold(gold), gold["arcos_list"])
+    h.set_queries(case["xq"])
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def pinned(shape, dtype):
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        ptr = ctypes.c_void_p()
+        assert hip.hipHostMalloc(ctypes.byref(ptr), ctypes.c_size_t(nbytes), ctypes.c_uint(0)) == 0
+        buf = (ctypes.c_char * nbytes).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape), ptr
+
+    Dp, dptr = pinned((ses, K), np.float32)
+    Ip, iptr = pinned((ses, K), np.int64)
+    for r in range(len(case["topks"])):
+        req = np.full(ts + ses, case["require_acc"][r], dtype=np.float32)
+        my_np = np.zeros(ts + ses, dtype=np.uint64)
+        t_rec = np.zeros(ts + ses, dtype=np.float32)
+        Dp.fill(np.nan)
+        Ip.fill(-7)
+        D, I = h.search_adaptive(ts, ses, int(case["topks"][r]), float(case["multipler"][r]), float(case["std_m"][r]),
+                                 req, my_np, t_rec, gt_D=gold["gtD"], out=(Dp, Ip))
+        assert D is Dp and I is Ip
+        assert h.last_direct_out()
+        assert np.array_equal(I, gold[f"I_r{r}"])
+        assert np.array_equal(bits(D), bits(gold[f"D_r{r}"]))
+        assert np.array_equal(my_np[ts:], gold[f"my_nprobe_r{r}"])
+    del Dp, Ip, D, I
+    hip.hipHostFree(dptr)
+    hip.hipHostFree(iptr)
