@@ -10,3 +10,4 @@ cp gpurun_out/effect_time_$tag.jsonl profiles/${tag}_effect_time.jsonl
 cp gpurun_out/latency1_$tag.txt profiles/${tag}_latency_batch1.txt
 cp gpurun_out/bw_probe_$tag.txt profiles/${tag}_bw_probe.txt
 cp gpurun_out/gpu_tests_$tag.txt profiles/${tag}_gpu_tests.txt
+for n in fp32_path exact_ties cfg5; do cp gpurun_out/timeline_${n}_$tag.txt profiles/${tag}_timeline_$n.txt; done

@@ -3,6 +3,8 @@
 #   gpurun --timeout 2700 -- 'bash scripts/refresh_round.sh r02'
 tag=${1:-r03}
 bash profiles/collect.sh $tag > gpurun_out/collect_$tag.log 2>&1
+# (bench.py takes roofline.traffic from the newest profiles/r*_pmc.json: the one this run just measured)
+cp gpurun_out/summary_$tag/${tag}_pmc.json profiles/ 2>/dev/null
 python bench.py > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.log
 python scratch/perf_scan.py > gpurun_out/perf_scan_$tag.txt 2> gpurun_out/perf_scan_$tag.log
 python scripts/bench_configs.py > gpurun_out/configs_$tag.jsonl 2> gpurun_out/configs_$tag.log
@@ -10,5 +12,6 @@ python bench.py --mode shards --test 10000 > gpurun_out/shards_$tag.json 2> gpur
 python scripts/effect_time.py > gpurun_out/effect_time_$tag.jsonl 2> gpurun_out/effect_time_$tag.log
 python scratch/latency1.py > gpurun_out/latency1_$tag.txt 2> gpurun_out/latency1_$tag.log
 python scratch/bw_probe.py > gpurun_out/bw_probe_$tag.txt 2> gpurun_out/bw_probe_$tag.log
+bash scripts/timelines.sh $tag > gpurun_out/timelines_$tag.log 2>&1
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -5 > gpurun_out/gpu_tests_$tag.txt
 tail -3 gpurun_out/bench_$tag.log; cat gpurun_out/effect_time_$tag.jsonl; du -sh gpurun_out
