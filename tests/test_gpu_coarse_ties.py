@@ -25,7 +25,8 @@ def grid_points(rs, n, d, span):
 
 
 @pytest.mark.parametrize("metric", [1, 0])
-@pytest.mark.parametrize("nlist,nprobe", [(300, 129), (300, 300), (300, 307), (1024, 200), (1024, 1024), (4096, 4096), (4096, 549), (8192, 8192)])
+@pytest.mark.parametrize("nlist,nprobe", [(300, 8), (1024, 32), (4096, 100), (4096, 128), (300, 129), (300, 300), (300, 307), (1024, 200), (1024, 1024),
+                                          (4096, 4096), (4096, 549), (8192, 8192)])
 @pytest.mark.parametrize("nq,mode", [(1, None), (19, None), (40, "heap")])
 def test_ranking_equals_reference_heap(capi, oracle, monkeypatch, metric, nlist, nprobe, nq, mode):
     rs = np.random.RandomState(nlist * 7 + nprobe + metric)
