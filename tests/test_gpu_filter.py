@@ -97,3 +97,19 @@ def test_candidates_on_and_next_to_the_threshold(capi, oracle, d, metric):
     xq = (seeds[rs.randint(0, len(seeds), size=nq)] + 0.05 * rs.randn(nq, d)).astype(np.float32)
     launches, kept = run_and_compare(capi, oracle, metric, cen, assign, xb, xq, k=k, nprobe=nlist)
     assert kept > 0
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_shapes_beyond_128_dimensions(capi, oracle, seed):
+    """the workgroup form on random shapes: dimensions that are no multiple of 8 (the last piece is zero-padded) or of the stage
+    length, one to several chunks per list, k up to the register-array limit, both metrics"""
+    rs = np.random.RandomState(7300 + seed)
+    d = int(rs.choice([130, 132, 136, 190, 250, 333, 512, 700, 1000]))
+    nlist = int(rs.choice([8, 16, 40]))
+    nb = int(rs.choice([1500, 4000]))
+    nq = int(rs.choice([140, 300]))
+    k = int(rs.choice([1, 10, 50, 128]))
+    nprobe = int(rs.choice([4, 8, nlist]))
+    metric = int(rs.choice([0, 1]))
+    cen, assign, xb, xq = clustered(rs, nb, nq, d, nlist, spread=float(rs.choice([0.2, 0.5])))
+    run_and_compare(capi, oracle, metric, cen, assign, xb, xq, k=k, nprobe=nprobe, expect_filter=nq * nprobe >= 1024)
