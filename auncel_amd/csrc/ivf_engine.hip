@@ -213,6 +213,7 @@ struct amd_ivf {
     DevBuf w_spec_full, w_spec_dis, w_spec_keys, w_spec_count, w_spec_slot, w_spec_pick, w_redo_idx;
     hipStream_t spec_stream = nullptr;
     hipEvent_t ev_spec_go = nullptr, ev_spec_done = nullptr;
+    bool spec_wanted = false;  // set by adaptive_redo_ties around its first pass (small calls repeat as a whole: no slots)
     bool spec_valid = false;  // the slots of the last first pass are (being) re-ranked
     bool spec_use = false;    // second pass: ranking row j comes from slot w_spec_pick[j]
     size_t spec_ncopy = 0;    // leading entries of a ranking the slots hold
@@ -2785,7 +2786,7 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
         static const bool no_spec = getenv("AUNCEL_AMD_NO_TIE_SPECULATION") != nullptr;
         constexpr uint32_t SPEC_CAP = 512, SPEC_NEAR = 64, SPEC_WINDOW = 2 * (12 + 144) + 14;
         L->spec_valid = false;
-        if (!no_spec && !L->given_keys && np_row == nlist && n <= L->dist_budget_floats / std::max<size_t>(nlist, 1) &&
+        if (!no_spec && L->spec_wanted && !L->given_keys && np_row == nlist && n <= L->dist_budget_floats / std::max<size_t>(nlist, 1) &&
             heap_tie_order_lds((uint32_t)nlist, (uint32_t)nlist) <= 160 * 1024) {
             const size_t ncopy = std::min(L->first_tie_nreal, nlist);
             L->w_spec_full.ensure((size_t)SPEC_CAP * nlist * 4);
@@ -2996,14 +2997,17 @@ static void adaptive_redo_ties(amd_ivf_t* h, const float* d_x, size_t start, siz
             h->ties_override = -1;
             h->want_first_tie = false;
             h->spec_use = false;
+            h->spec_wanted = false;
         }
     } restore{h};
     h->ties_override = 0;
     h->want_first_tie = true;
     h->first_tie_nreal = nreal;
     h->spec_valid = false;
+    h->spec_wanted = true;
     with_select_fallback(h, [&] { adaptive_core_once(h, d_x, start, n, query_topk, multipler, std_m, require_acc, gt_D, profile, coarse_mode, my_nprobe, t_recalls, D, I, qr); });
     h->want_first_tie = false;
+    h->spec_wanted = false;
     std::vector<uint32_t> again;
     for (size_t i = 0; i < n; i++) {
         const uint64_t bound = 2 * my_nprobe[start + i] + 14;

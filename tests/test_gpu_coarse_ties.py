@@ -45,7 +45,8 @@ def test_ranking_equals_reference_heap(capi, oracle, monkeypatch, metric, nlist,
     assert np.array_equal(bits(D), bits(eD))
     assert np.array_equal(I, eI)
     assert (I[:, min(nprobe, nlist):] == -1).all()
-    assert h.coarse_tie_rows() - before == nq  # every row of this data holds runs of equal distances
+    if nprobe > 128:  # (shorter rankings come from the reference's heap replayed for every row: nothing to re-run)
+        assert h.coarse_tie_rows() - before == nq  # every row of this data holds runs of equal distances
 
 
 def test_id_order_without_the_heap(capi, oracle, monkeypatch):
