@@ -5,10 +5,12 @@
 // to the vector ALU (scan_tiles_kernel: 3 packed instructions per 2 elements).  In a threshold round only the candidates
 // that beat the query's threshold matter -- typically a per cent of the pairs.  So:
 //   1. scan_filter_kernel   x.y of 32 queries x 32 vectors per v_mfma_f32_32x32x2_f32 chain, lists streamed once from a
-//                           fragment-ordered fp32 copy (coalesced 16-byte loads, no LDS); with the exact |x|^2, |y|^2 this
-//                           gives the distance up to a rigorous error bound eps(x, y) (below); a candidate is kept iff even
-//                           its most favourable value, approx -/+ eps, beats the threshold.  Kept candidates get their mask
-//                           bit and an entry in the survivor list.
+//      (d <= 128)           fragment-ordered fp32 copy (coalesced 16-byte loads, no LDS); with the exact |x|^2, |y|^2 this
+//      scan_filter_wide_    gives the distance up to a rigorous error bound eps(x, y) (below); a candidate is kept iff even
+//      kernel (d > 128)     its most favourable value, approx -/+ eps, beats the threshold.  Kept candidates get their mask
+//                           bit and an entry in the survivor list (slots handed out per wave in chunks: SurvChunk).  Beyond
+//                           128 dimensions a workgroup shares one chunk of the list among up to 128 queries (operand
+//                           through LDS), so that the list is read once however many queries probe it.
 //   2. rescore_kernel       one lane per survivor: the reference's own rounding sequence on the two fp32 rows; the exact
 //                           distance goes into the distance row.  A survivor whose exact distance does not beat the threshold
 //                           keeps its mask bit: the selection re-tests every candidate against the query's current worst
