@@ -24,7 +24,7 @@ SYMBOLS = [
     "amd_ivf_set_tuner", "amd_ivf_search_adaptive", "amd_ivf_search_adaptive_x", "amd_ivf_search_adaptive_pre", "amd_ivf_search_timed", "amd_ivf_search_timed_x",
     "amd_ivf_train_samples",
     "amd_ivf_train_samples_x", "amd_ivf_train_samples_pre", "amd_ivf_trace_sb", "amd_ivf_arcos_table", "amd_ivf_merge_tables",
-    "amd_ivf_last_timing", "amd_ivf_last_scan_min_bytes", "amd_ivf_coarse_tie_rows", "amd_ivf_last_tie_fixed", "amd_ivf_last_filter", "amd_ivf_last_direct_out", "amd_ivf_last_tie_redone", "amd_ivf_last_round_hints", "amd_ivf_set_byte_codes",
+    "amd_ivf_last_timing", "amd_ivf_last_scan_min_bytes", "amd_ivf_coarse_tie_rows", "amd_ivf_last_tie_fixed", "amd_ivf_last_filter", "amd_ivf_last_direct_out", "amd_ivf_set_async_depth", "amd_ivf_submit_adaptive", "amd_ivf_wait", "amd_ivf_last_tie_redone", "amd_ivf_last_round_hints", "amd_ivf_set_byte_codes",
     "amd_ivf_kmeans",
     "amd_ivf_range_search_preassigned", "amd_ivf_range_search", "amd_ivf_range_results",
     "amd_ivf_scan_arith",
@@ -352,6 +352,46 @@ class Handle:
                                            C.c_float(multipler), C.c_float(std_m), _f(req), _f(gt), int(profile), coarse_mode,
                                            my_nprobe.ctypes.data_as(_u64p), _f(t_recalls), _f(D), _i(I)))
         return D, I
+
+    def set_async_depth(self, depth):
+        """searches amd_ivf_submit_adaptive keeps running at a time (internal contexts; fixed by the first submit)"""
+        _chk(lib().amd_ivf_set_async_depth(self._h, int(depth)))
+
+    def submit_adaptive(self, start, n, query_topk, multipler, std_m, require_acc, my_nprobe, t_recalls, gt_D=None, profile=False,
+                        coarse_mode=0, out=None):
+        """asynchronous search_adaptive: returns a ticket for wait(); every array passed stays referenced until then"""
+        req = f32(require_acc)
+        gt = f32(gt_D) if gt_D is not None else None
+        assert my_nprobe.dtype == np.uint64 and t_recalls.dtype == np.float32
+        K = self.max_topk
+        if out is not None:
+            D, I = out
+            assert D.shape == (n, K) and D.dtype == np.float32 and D.flags.c_contiguous
+            assert I.shape == (n, K) and I.dtype == np.int64 and I.flags.c_contiguous
+        else:
+            D = np.empty((n, K), np.float32)
+            I = np.empty((n, K), np.int64)
+        t = C.c_uint64(0)
+        _chk(lib().amd_ivf_submit_adaptive(self._h, C.c_size_t(start), C.c_size_t(n), C.c_size_t(query_topk), C.c_float(multipler),
+                                           C.c_float(std_m), _f(req), _f(gt), int(profile), coarse_mode,
+                                           my_nprobe.ctypes.data_as(_u64p), _f(t_recalls), _f(D), _i(I), C.byref(t)))
+        if not hasattr(self, "_tickets"):
+            self._tickets = {}
+        self._tickets[int(t.value)] = (req, gt, my_nprobe, t_recalls, D, I)
+        return int(t.value)
+
+    def wait(self, ticket):
+        """blocks until the search of `ticket` has ended; returns (D, I, timing dict, diag dict); raises as the synchronous call"""
+        tm = (C.c_double * 9)()
+        dg = (C.c_uint64 * 4)()
+        rc = lib().amd_ivf_wait(self._h, C.c_uint64(ticket), tm, dg)
+        held = self._tickets.pop(ticket, None) if hasattr(self, "_tickets") else None
+        _chk(rc)
+        keys = ("coarse_ms", "scan_ms", "select_ms", "total_ms", "scan_launches", "scan_bytes", "slot_efficiency", "rounds", "scan_min_bytes")
+        timing = {k: float(tm[i]) for i, k in enumerate(keys)}
+        diag = {"hinted_launches": int(dg[0]), "short_hints": int(dg[1]), "tie_redone": int(dg[2]), "direct_out": bool(dg[3])}
+        D, I = (held[4], held[5]) if held else (None, None)
+        return D, I, timing, diag
 
     def search_adaptive_pre(self, x, id_offset, keys, coarse_dis, query_topk, multipler, std_m, require_acc, my_nprobe, t_recalls,
                             gt_D=None, profile=False):

@@ -10,6 +10,10 @@
 #include <cmath>
 #include <cstdlib>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <map>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -174,6 +178,9 @@ enum { CAT_COARSE = 0, CAT_SCAN = 1, CAT_SELECT = 2, NCAT = 3 };
 
 }  // namespace
 
+struct amd_ivf;
+static void async_shutdown(amd_ivf* h);  // (stops the handle's worker threads and frees their contexts)
+
 struct amd_ivf {
     int d = 0, dpad = 0, metric = METRIC_L2, device = 0;
     size_t nlist = 0, ntotal = 0;
@@ -301,6 +308,9 @@ struct amd_ivf {
     // Query lanes: a large adaptive batch is cut into slices that run their rounds concurrently, each on
     // its own stream with its own workspaces (kids borrow the index data of `parent`), so that one
     // slice's latency-bound selection and host-side round planning overlap another slice's VALU-bound scan.
+    struct AsyncPool* async = nullptr;  // owner only: internal search contexts + worker threads of amd_ivf_submit_* (below)
+    std::vector<amd_ivf*> async_ctx;    // those contexts (statistics and settings of the owner cover them)
+    int async_depth = 4;
     amd_ivf* parent = nullptr;
     bool is_clone = false;  // made by amd_ivf_clone: a search context of its own over the parent's index data
     std::mutex upload_mu;   // owner only: serialises the first upload of the lists
@@ -310,6 +320,7 @@ struct amd_ivf {
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
 
     ~amd_ivf() {
+        async_shutdown(this);
         kids.clear();
         for (int i = 0; i < 4; i++) {
             if (aux[i]) (void)hipStreamDestroy(aux[i]);
@@ -2625,6 +2636,11 @@ int amd_ivf_stats(amd_ivf_t* h, size_t stats[4], int reset) {
     for (int i = 0; i < 4; i++) stats[i] = h->stats_host[i];
     if (reset)
         for (int i = 0; i < 4; i++) h->stats_host[i] = 0;
+    for (amd_ivf* c : h->async_ctx) {  // searches submitted with amd_ivf_submit_* count on their owner (call with none in flight)
+        for (int i = 0; i < 4; i++) stats[i] += c->stats_host[i];
+        if (reset)
+            for (int i = 0; i < 4; i++) c->stats_host[i] = 0;
+    }
     return 0;
 }
 
@@ -3147,9 +3163,11 @@ int amd_ivf_search_adaptive(amd_ivf_t* h, size_t start, size_t n, size_t query_t
                             uint64_t* my_nprobe, float* t_recalls, float* D, int64_t* I) {
     API_BEGIN
     use_device(h);
-    if (start + n > h->n_resident) throw EngineError("resident query range out of bounds");
-    adaptive_core(h, h->d_resident.as<float>() + start * h->dpad, start, n, query_topk, multipler, std_m, require_acc, gt_D,
-                  profile, coarse_mode, my_nprobe, t_recalls, D, I, h->resident_range);
+    // a search context that was never given resident queries of its own searches its owner's (amd_ivf_submit_adaptive's contexts)
+    const amd_ivf* src = h->is_clone && h->n_resident == 0 && h->parent ? h->parent : h;
+    if (start + n > src->n_resident) throw EngineError("resident query range out of bounds");
+    adaptive_core(h, src->d_resident.as<float>() + start * h->dpad, start, n, query_topk, multipler, std_m, require_acc, gt_D,
+                  profile, coarse_mode, my_nprobe, t_recalls, D, I, src->resident_range);
     API_END
 }
 
@@ -3507,6 +3525,7 @@ int amd_ivf_scan_arith(amd_ivf_t* h) { return ix(h)->last_arith; }
 
 int amd_ivf_set_byte_codes(amd_ivf_t* h, int enable) {
     h->allow_bytes = enable ? 1 : 0;
+    for (amd_ivf* c : h->async_ctx) c->allow_bytes = h->allow_bytes;
     return 0;
 }
 
@@ -3574,6 +3593,177 @@ int amd_ivf_coarse_tie_rows(amd_ivf_t* h, uint64_t* rows) {
     add(h);
     for (auto& kid : h->kids) add(kid.get());  // the slices of an adaptive batch run on these
     API_END
+}
+
+int amd_ivf_last_timing(amd_ivf_t* h, double out[8]);
+int amd_ivf_last_scan_min_bytes(amd_ivf_t* h, double* bytes);
+int amd_ivf_last_round_hints(amd_ivf_t* h, uint64_t out[2]);
+int amd_ivf_last_tie_redone(amd_ivf_t* h, uint64_t* queries);
+int amd_ivf_last_direct_out(amd_ivf_t* h);
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// Asynchronous searches.  One synchronous call leaves the GPU to one search at a time, whose selection and planning phases are
+// latency-bound; several searches in flight fill those phases with each other's scans (1.6 x the throughput on the bench
+// workload).  A caller with more than one batch at hand gets that without threads of its own: submit returns a ticket at
+// once, the search runs on one of the handle's internal contexts (amd_ivf_clone: own stream and workspaces, the owner's index
+// data and resident queries), wait returns its status.  At most `depth` searches run at a time; further tickets queue.
+struct AsyncJob {
+    std::function<int(amd_ivf_t*)> run;
+    int rc = 0;
+    bool done = false;
+    std::string error;
+    double timing[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // amd_ivf_last_timing's eight + amd_ivf_last_scan_min_bytes
+    uint64_t diag[4] = {0, 0, 0, 0};  // launches sized by a hint | hints too small | queries searched again (redo) | direct out
+};
+struct AsyncPool {
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    std::deque<AsyncJob*> queue;
+    std::map<uint64_t, std::unique_ptr<AsyncJob>> jobs;
+    std::vector<std::thread> workers;
+    std::vector<amd_ivf_t*> ctx;
+    uint64_t next = 1;
+    bool stop = false;
+};
+
+static void async_worker(AsyncPool* p, size_t i) {
+    for (;;) {
+        AsyncJob* j = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(p->mu);
+            p->cv_job.wait(lk, [&] { return p->stop || !p->queue.empty(); });
+            if (p->queue.empty()) return;
+            j = p->queue.front();
+            p->queue.pop_front();
+        }
+        amd_ivf_t* c = p->ctx[i];
+        const int rc = j->run(c);
+        std::string err = rc ? std::string(amd_ivf_last_error()) : std::string();
+        amd_ivf_last_timing(c, j->timing);
+        amd_ivf_last_scan_min_bytes(c, &j->timing[8]);
+        amd_ivf_last_round_hints(c, j->diag);
+        amd_ivf_last_tie_redone(c, &j->diag[2]);
+        j->diag[3] = (uint64_t)amd_ivf_last_direct_out(c);
+        {
+            std::lock_guard<std::mutex> lk(p->mu);
+            j->error = std::move(err);
+            j->rc = rc;
+            j->done = true;
+        }
+        p->cv_done.notify_all();
+    }
+}
+
+static AsyncPool* async_pool(amd_ivf* h) {
+    if (h->async) return h->async;
+    std::unique_ptr<AsyncPool> p(new AsyncPool);
+    const int depth = std::min(std::max(h->async_depth, 1), 16);
+    for (int i = 0; i < depth; i++) {
+        amd_ivf_t* c = nullptr;
+        if (amd_ivf_clone(h, &c) != 0) {
+            for (amd_ivf_t* made : p->ctx) amd_ivf_destroy(made);
+            throw std::runtime_error(std::string("asynchronous search contexts: ") + amd_ivf_last_error());
+        }
+        p->ctx.push_back(c);
+    }
+    for (int i = 0; i < depth; i++) p->workers.emplace_back(async_worker, p.get(), (size_t)i);
+    h->async_ctx.assign(p->ctx.begin(), p->ctx.end());
+    h->async = p.release();
+    return h->async;
+}
+
+static void async_shutdown(amd_ivf* h) {
+    AsyncPool* p = h->async;
+    if (!p) return;
+    h->async = nullptr;
+    h->async_ctx.clear();
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->stop = true;
+    }
+    p->cv_job.notify_all();
+    for (auto& t : p->workers) t.join();  // (queued searches still run: their callers hold tickets)
+    for (amd_ivf_t* c : p->ctx) amd_ivf_destroy(c);
+    delete p;
+}
+
+static uint64_t async_enqueue(amd_ivf* h, std::function<int(amd_ivf_t*)> run) {
+    AsyncPool* p = async_pool(h);
+    std::unique_ptr<AsyncJob> j(new AsyncJob);
+    j->run = std::move(run);
+    uint64_t id;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        id = p->next++;
+        p->queue.push_back(j.get());
+        p->jobs[id] = std::move(j);
+    }
+    p->cv_job.notify_one();
+    return id;
+}
+
+extern "C" {
+
+int amd_ivf_set_async_depth(amd_ivf_t* h, int depth) {
+    API_BEGIN
+    OWNER_ONLY(h);
+    if (depth == 0) {  // give the internal contexts (streams, workspaces) and their threads back
+        if (h->async) {
+            std::lock_guard<std::mutex> lk(h->async->mu);
+            if (!h->async->jobs.empty()) throw EngineError("tickets are still out");
+        }
+        async_shutdown(h);
+        return 0;
+    }
+    if (depth < 1 || depth > 16) throw EngineError("asynchronous depth must be 1..16");
+    if (h->async && depth != (int)h->async->ctx.size()) throw EngineError("asynchronous depth is fixed by the first submit");
+    h->async_depth = depth;
+    API_END
+}
+
+int amd_ivf_submit_adaptive(amd_ivf_t* h, size_t start, size_t n, size_t query_topk, float multipler, float std_m,
+                            const float* require_acc, const float* gt_D, int profile, int coarse_mode, uint64_t* my_nprobe,
+                            float* t_recalls, float* D, int64_t* I, uint64_t* ticket) {
+    API_BEGIN
+    OWNER_ONLY(h);
+    use_device(h);
+    if (start + n > h->n_resident) throw EngineError("resident query range out of bounds");
+    *ticket = async_enqueue(h, [=](amd_ivf_t* c) {
+        return amd_ivf_search_adaptive(c, start, n, query_topk, multipler, std_m, require_acc, gt_D, profile, coarse_mode, my_nprobe,
+                                       t_recalls, D, I);
+    });
+    API_END
+}
+
+int amd_ivf_wait(amd_ivf_t* h, uint64_t ticket, double timing[9], uint64_t diag[4]) {
+    int rc = 0;
+    try {
+        if (!h || !h->async) throw EngineError("no asynchronous search was submitted on this handle");
+        AsyncPool* p = h->async;
+        std::unique_ptr<AsyncJob> j;
+        {
+            std::unique_lock<std::mutex> lk(p->mu);
+            auto it = p->jobs.find(ticket);
+            if (it == p->jobs.end()) throw EngineError("unknown ticket");
+            AsyncJob* raw = it->second.get();
+            p->cv_done.wait(lk, [&] { return raw->done; });
+            j = std::move(it->second);
+            p->jobs.erase(it);
+        }
+        if (timing) std::copy(j->timing, j->timing + 9, timing);
+        if (diag) std::copy(j->diag, j->diag + 4, diag);
+        rc = j->rc;
+        if (rc) g_last_error = j->error;
+    } catch (const EngineError& e) {
+        g_last_error = e.what();
+        return -2;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return -4;
+    }
+    return rc;
 }
 
 int amd_ivf_last_timing(amd_ivf_t* h, double out[8]) {

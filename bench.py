@@ -325,6 +325,9 @@ def main():
                     help="directory with base / query / ground-truth files in the reference harness's layouts (.fvecs/.ivecs, .fbin/.ibin, "
                          ".u8bin): the same pipeline on real data instead of the synthetic blobs")
     ap.add_argument("--data-rows", type=int, default=0, help="--data: base vectors to read (0: the whole file)")
+    ap.add_argument("--runner", choices=["async", "threads"], default="threads",
+                    help="how --in-flight batches are kept in flight: async = ONE caller thread through amd_ivf_submit_adaptive / "
+                         "amd_ivf_wait (the engine's internal contexts), threads = one host thread + amd_ivf_clone context per batch")
     ap.add_argument("--in-flight", type=int, default=4,
                     help="batches kept in flight per GPU, each from its own host thread on its own search context "
                          "(amd_ivf_clone); 1 = one batch at a time")
@@ -481,30 +484,46 @@ def main():
     # another batch's scans.  Every step is a complete, independent search either way.
     import threading
     nfl = max(1, min(args.in_flight, args.steps))
-    ctxs = [h] + [h.clone() for _ in range(nfl - 1)]
-    for c in ctxs[1:]:
-        c.set_queries(xq)
+    use_async = args.runner == "async" and nfl > 1
+    if use_async:
+        # one caller thread: submit returns a ticket at once, the engine runs up to nfl searches at a time on internal contexts
+        # (its statistics and settings cover them), wait collects a result
+        h.set_async_depth(nfl)
+        ctxs = [h]
+    else:
+        ctxs = [h] + [h.clone() for _ in range(nfl - 1)]
+        for c in ctxs[1:]:
+            c.set_queries(xq)
 
     stagger_s = float(os.environ.get("BENCH_STAGGER_MS", args.stagger_ms)) / 1e3
 
     # result buffers of every context: page-locked host memory (the caller's choice in the reference's API too), so that
     # the 6 MB of (D, I) of a step come back by direct DMA instead of through the runtime's staging copies
-    outs = {}
-    for c in ctxs:
-        if args.pinned_out:
-            outs[id(c)] = (torch.empty((ses, K), dtype=torch.float32).pin_memory().numpy(),
-                           torch.empty((ses, K), dtype=torch.int64).pin_memory().numpy())
-        else:
-            outs[id(c)] = None
+    # (async: as many tickets again as searches run at a time wait in the engine's queue, so that a context that finishes out of
+    # order finds its next search there instead of idling until the caller has collected the oldest)
+    nslots = 2 * nfl if use_async else nfl
+
+    def result_buffers(count):
+        bufs = []
+        for _ in range(count):
+            if args.pinned_out:
+                bufs.append((torch.empty((ses, K), dtype=torch.float32).pin_memory().numpy(),
+                             torch.empty((ses, K), dtype=torch.int64).pin_memory().numpy()))
+            else:
+                bufs.append(None)
+        return bufs
+
+    outs = result_buffers(nslots)  # one pair per batch in flight (or queued)
+    async_outs = outs if use_async else None  # (the single-caller leg of a threads run makes its own)
 
     hyper = {"mult": chosen, "std_m": chosen_std}
 
-    def step(ctx, stepno):
+    def step(ctx, stepno, slot=0):
         """step s searches slice s mod nsl of the resident queries: consecutive steps never see the same batch"""
         start = ts + (stepno % nsl) * ses
         np_ = np.zeros(nall, dtype=np.uint64)
         tr_ = np.zeros(nall, dtype=np.float32)
-        D, I = ctx.search_adaptive(start, ses, topk, hyper["mult"], hyper["std_m"], req, np_, tr_, out=outs[id(ctx)])
+        D, I = ctx.search_adaptive(start, ses, topk, hyper["mult"], hyper["std_m"], req, np_, tr_, out=outs[slot])
         return D, I, np_, start
 
     def barrier():
@@ -512,8 +531,42 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def account(acc, tm, hinted, short, redone, res):
+        acc["hinted_launches"] = acc.get("hinted_launches", 0) + hinted
+        acc["short_hints"] = acc.get("short_hints", 0) + short
+        acc["tie_redone"] = acc.get("tie_redone", 0) + redone
+        for key in ("scan_ms", "scan_bytes", "scan_launches", "coarse_ms", "select_ms", "scan_min_bytes"):
+            acc[key] = acc.get(key, 0.0) + tm[key]
+        acc["slot_eff"] = acc.get("slot_eff", 0.0) + tm["slot_efficiency"]
+        acc["last"] = res
+
+    def run_steps_async(nsteps, acc):
+        """one caller thread keeps up to nfl steps in flight: submit step s, and once nfl are out wait for the oldest first"""
+        pending = []
+
+        def finish():
+            ticket, np_, start = pending.pop(0)
+            D, I, tm, dg = h.wait(ticket)
+            account(acc, tm, dg["hinted_launches"], dg["short_hints"], dg["tie_redone"], (D, I, np_, start))
+
+        aslots = len(async_outs)
+        for sn in range(nsteps):
+            if len(pending) == aslots:
+                finish()
+            elif sn and sn < nfl and stagger_s:
+                time.sleep(stagger_s)  # the first nfl submissions start out of phase (scan of one under selection of the other)
+            start = ts + (sn % nsl) * ses
+            np_ = np.zeros(nall, dtype=np.uint64)
+            tr_ = np.zeros(nall, dtype=np.float32)
+            pending.append((h.submit_adaptive(start, ses, topk, hyper["mult"], hyper["std_m"], req, np_, tr_, out=async_outs[sn % aslots]),
+                            np_, start))
+        while pending:
+            finish()
+
     def run_steps(nsteps, acc):
         """steps j, j + nfl, ... on context j; acc collects per-step kernel timings and the last result"""
+        if use_async and nfl > 1:
+            return run_steps_async(nsteps, acc)
         errs = []
 
         def worker(j):
@@ -521,16 +574,11 @@ def main():
                 if j and stagger_s:
                     time.sleep(j * stagger_s)  # start the contexts out of phase (scan of one under selection of the other)
                 for sn in range(j, nsteps, nfl):
-                    res = step(ctxs[j], sn)
+                    res = step(ctxs[j], sn, j)
                     tm = ctxs[j].last_timing()
                     hints = ctxs[j].last_round_hints()
                     with lock:
-                        acc["hinted_launches"] = acc.get("hinted_launches", 0) + hints[0]
-                        acc["short_hints"] = acc.get("short_hints", 0) + hints[1]
-                        for key in ("scan_ms", "scan_bytes", "scan_launches", "coarse_ms", "select_ms", "scan_min_bytes"):
-                            acc[key] = acc.get(key, 0.0) + tm[key]
-                        acc["slot_eff"] = acc.get("slot_eff", 0.0) + tm["slot_efficiency"]
-                        acc["last"] = res
+                        account(acc, tm, hints[0], hints[1], ctxs[j].last_tie_redone(), res)
             except Exception as e:  # noqa: BLE001
                 errs.append(e)
 
@@ -621,7 +669,7 @@ def main():
             nst = max(4, args.steps // 3)
             leg = timed_leg(nst)
             exact_ties = {"value": ses * nst / leg["elapsed"], "unit": "queries/s", "ms_per_step": 1000.0 * leg["elapsed"] / nst,
-                          "queries_searched_again_last_step": int(sum(c.last_tie_redone() for c in ctxs) / max(1, min(nfl, nst))),
+                          "queries_searched_again_per_step": leg.get("tie_redone", 0) / nst,
                           "setting": "AUNCEL_AMD_COARSE_TIES=redo"}
         finally:
             del os.environ["AUNCEL_AMD_COARSE_TIES"]
@@ -639,6 +687,24 @@ def main():
         hyper["mult"], hyper["std_m"] = chosen, chosen_std
     elif guaranteed is None:
         guar["note"] = "no grid point up to multipler 24 holds the bound for every validation query"
+    # the same steps kept in flight by ONE caller thread through the asynchronous entry points (amd_ivf_submit_adaptive /
+    # amd_ivf_wait: the engine's own contexts and worker threads) instead of one host thread + context per batch
+    single_caller = None
+    if nfl > 1 and not args.no_legs and not use_async:
+        h.set_async_depth(nfl)
+        async_outs = result_buffers(2 * nfl)
+        run_steps_async(max(2 * nfl, 8), {})
+        barrier()
+        ta0 = time.perf_counter()
+        aleg = {}
+        run_steps_async(args.steps, aleg)
+        barrier()
+        a_el = time.perf_counter() - ta0
+        aD, aI, a_np, a_start = aleg["last"]
+        single_caller = {"value": ses * args.steps / a_el, "unit": "queries/s", "ms_per_step": 1000.0 * a_el / args.steps,
+                         "how": f"one caller thread, amd_ivf_submit_adaptive / amd_ivf_wait, {nfl} searches at a time on the engine's "
+                                f"internal contexts, {2 * nfl} tickets out; last leg of the run"}
+        h.set_async_depth(0)  # (the contexts' streams would crowd the hardware queues of anything run after)
     scan_ms, scan_bytes, scan_launches = acc["scan_ms"], acc["scan_bytes"], acc["scan_launches"]
     coarse_ms, select_ms, slot_eff = acc["coarse_ms"], acc["select_ms"], acc["slot_eff"] / args.steps
 
@@ -698,7 +764,10 @@ def main():
             # scan grids of the device-chained rounds are sized from the previous search's counts (+ 12 %); a round that needs
             # more runs on fewer workgroups than it would have been given (it is still complete: the workgroups stride)
             "round_hint": {"launches_sized_by_a_hint": int(acc.get("hinted_launches", 0)), "hint_too_small": int(acc.get("short_hints", 0))},
-            "in_flight": nfl, "host_wait": "blocking events" if os.environ.get("AUNCEL_AMD_BLOCKING_SYNC", "0") not in ("", "0") else "spin", "host_cores": host_cores(), "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "stagger_ms": stagger_s * 1e3,
+            "in_flight": nfl,
+            "runner": ("one caller thread: amd_ivf_submit_adaptive / amd_ivf_wait, the engine's internal contexts" if use_async
+                       else "one host thread and one amd_ivf_clone context per batch in flight" if nfl > 1 else "one synchronous call at a time"),
+            "host_wait": "blocking events" if os.environ.get("AUNCEL_AMD_BLOCKING_SYNC", "0") not in ("", "0") else "spin", "host_cores": host_cores(), "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "stagger_ms": stagger_s * 1e3,
             "scan_arith": {0: "fp32 reference order", 1: "fp32 fused", 2: "byte codes, v_mfma_i32_32x32x32_i8"}[arith],
             "nb": args.nb, "sigma": args.sigma, "multipler": chosen, "std_m": args.std_m,
             "hyper_parameters_chosen_on": "validation fifth of the training half (mean recall@%d - 1 s.e. >= %.2f); traces from the other four fifths" % (topk, args.bound),
@@ -757,6 +826,8 @@ def main():
             "scan_G_distances_per_s": (solo["scan_bytes"] / (4.0 * d)) / (s_ms / 1e3) / 1e9,
             "other_kernels_ms_per_step": {"coarse": solo["coarse_ms"] / args.steps, "select": solo["select_ms"] / args.steps},
         }
+    if single_caller is not None:
+        out["single_caller_async"] = single_caller
     if fp32 is not None:
         out["fp32_path"] = fp32
     if exact_ties is not None:

@@ -273,6 +273,22 @@ int amd_ivf_last_filter(amd_ivf_t* h, uint64_t out[2]);
  * AUNCEL_AMD_DIRECT_OUT=0 always copies. */
 int amd_ivf_last_direct_out(amd_ivf_t* h);
 
+/* ------------------------------------------------------------------------------------------------
+ * Asynchronous form of amd_ivf_search_adaptive (same arguments, same results).  submit returns at once with a ticket; the
+ * search runs on one of `depth` internal search contexts of the handle (amd_ivf_set_async_depth, 1..16, default 4, fixed by
+ * the first submit; depth 0 with no ticket out releases them: their streams and workspaces are the price of the mode; each is an amd_ivf_clone: own stream and workspaces, the owner's lists, traces and resident queries);
+ * further tickets queue.  wait blocks until that search has ended and returns its status (0 / -2 / -4 as the synchronous
+ * call; amd_ivf_last_error() then holds its message); timing (amd_ivf_last_timing's 8 doubles + amd_ivf_last_scan_min_bytes) and diag (launches sized by a
+ * hint, hints too small, queries searched again for the tie order, 1 if (D, I) were written directly) may be null.  Every
+ * buffer passed to submit must stay valid, and the index and its resident queries unchanged, until the ticket has been waited
+ * for; every ticket must be waited for exactly once.  One caller thread that keeps four 5000-query batches in flight this way
+ * reaches what four threads with a context each reach (the reference's callers would use threads: IndexShards.cpp:48-120). */
+int amd_ivf_set_async_depth(amd_ivf_t* h, int depth);
+int amd_ivf_submit_adaptive(amd_ivf_t* h, size_t start, size_t n, size_t query_topk, float multipler, float std_m,
+                            const float* require_acc, const float* gt_D, int profile, int coarse_mode, uint64_t* my_nprobe,
+                            float* t_recalls, float* D, int64_t* I, uint64_t* ticket);
+int amd_ivf_wait(amd_ivf_t* h, uint64_t ticket, double timing[9], uint64_t diag[4]);
+
 /* Arithmetic the list scan of the last search ran in.  All three produce the reference's fp32 distance bit for
  * bit (utils_simd.cpp:391-443 order); the engine picks the cheapest one the data allows:
  *   0  fp32, the reference's four running sums, separate multiply and add

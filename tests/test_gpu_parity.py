@@ -597,3 +597,57 @@ def test_results_written_straight_into_page_locked_buffers(capi, monkeypatch, na
     del Dp, Ip, D, I
     hip.hipHostFree(dptr)
     hip.hipHostFree(iptr)
+
+
+@pytest.mark.parametrize("name", AUNCEL[:2])
+def test_asynchronous_searches_equal_the_synchronous_ones(capi, name):
+    """amd_ivf_submit_adaptive / amd_ivf_wait: several searches in flight from one caller thread, each on one of the handle's
+    internal contexts; results, my_nprobe and t_recalls as the golden outputs, whatever the order the tickets are waited in;
+    an error of a search comes back from its wait()"""
+    case, gold = load_case(name)
+    K, ts, ses = case["max_topk"], case["train_num"], case["test_num"]
+    h = make_index(capi, case, gold, gold["centroids"])
+    h.set_interdis(None)
+    h.set_tuner(K, traces_from_gold(gold), gold["arcos_list"])
+    h.set_queries(case["xq"])
+    h.set_async_depth(3)
+    jobs = []
+    for rep in range(2):
+        for r in range(len(case["topks"])):
+            req = np.full(ts + ses, case["require_acc"][r], dtype=np.float32)
+            my_np = np.zeros(ts + ses, dtype=np.uint64)
+            t_rec = np.zeros(ts + ses, dtype=np.float32)
+            t = h.submit_adaptive(ts, ses, int(case["topks"][r]), float(case["multipler"][r]), float(case["std_m"][r]), req, my_np, t_rec,
+                                  gt_D=gold["gtD"])
+            jobs.append((t, r, my_np, t_rec))
+    for t, r, my_np, t_rec in reversed(jobs):
+        D, I, timing, diag = h.wait(t)
+        assert np.array_equal(my_np[ts:], gold[f"my_nprobe_r{r}"])
+        assert np.array_equal(I, gold[f"I_r{r}"])
+        assert np.array_equal(bits(D), bits(gold[f"D_r{r}"]))
+        assert np.array_equal(bits(t_rec[ts:]), bits(gold[f"t_recalls_r{r}"]))
+        assert timing["total_ms"] > 0 and timing["rounds"] >= 1
+    # a failing search: query_topk beyond max_topk is the engine's error, delivered by wait()
+    bad = h.submit_adaptive(ts, ses, K + 1, 1.0, 1.0, np.full(ts + ses, 0.9, np.float32), np.zeros(ts + ses, np.uint64),
+                            np.zeros(ts + ses, np.float32), gt_D=gold["gtD"])
+    with pytest.raises(capi.EngineError, match="query_topk"):
+        h.wait(bad)
+    with pytest.raises(capi.EngineError, match="ticket"):
+        h.wait(bad)
+    # the synchronous entry point still works next to it
+    req = np.full(ts + ses, case["require_acc"][0], dtype=np.float32)
+    my_np = np.zeros(ts + ses, dtype=np.uint64)
+    t_rec = np.zeros(ts + ses, dtype=np.float32)
+    D, I = h.search_adaptive(ts, ses, int(case["topks"][0]), float(case["multipler"][0]), float(case["std_m"][0]), req, my_np, t_rec,
+                             gt_D=gold["gtD"])
+    assert np.array_equal(I, gold["I_r0"])
+    # depth 0 releases the internal contexts (no ticket out); the next submit starts a pool of the new depth
+    h.set_async_depth(0)
+    h.set_async_depth(2)
+    t = h.submit_adaptive(ts, ses, int(case["topks"][0]), float(case["multipler"][0]), float(case["std_m"][0]), req, my_np, t_rec,
+                          gt_D=gold["gtD"])
+    with pytest.raises(capi.EngineError, match="tickets"):
+        h.set_async_depth(0)
+    D2, I2, _, _ = h.wait(t)
+    assert np.array_equal(I2, gold["I_r0"]) and np.array_equal(bits(D2), bits(gold["D_r0"]))
+    h.close()
