@@ -2473,12 +2473,14 @@ int amd_ivf_search_resident_preassigned(amd_ivf_t* h, size_t start, size_t n, si
 int amd_ivf_search_resident(amd_ivf_t* h, size_t start, size_t n, size_t k, size_t nprobe, int coarse_mode, float* D, int64_t* I) {
     API_BEGIN
     use_device(h);
-    if (start + n > h->n_resident) throw EngineError("resident query range out of bounds");
+    // (a search context without resident queries of its own searches its owner's: amd_ivf_submit_search_resident's contexts)
+    const amd_ivf* src = h->is_clone && h->n_resident == 0 && h->parent ? h->parent : h;
+    if (start + n > src->n_resident) throw EngineError("resident query range out of bounds");
     if (n == 0 || k == 0) return 0;
     WallClock wc(h->stream);
     h->scan_bytes = h->scan_min_bytes = 0;
     h->scan_slots = h->scan_useful = 0;
-    search_full(h, h->d_resident.as<float>() + start * h->dpad, n, k, nprobe, coarse_mode, D, I, h->resident_range);
+    search_full(h, src->d_resident.as<float>() + start * h->dpad, n, k, nprobe, coarse_mode, D, I, src->resident_range);
     finish_timing(h, wc.stop());
     API_END
 }
@@ -3734,6 +3736,16 @@ int amd_ivf_submit_adaptive(amd_ivf_t* h, size_t start, size_t n, size_t query_t
         return amd_ivf_search_adaptive(c, start, n, query_topk, multipler, std_m, require_acc, gt_D, profile, coarse_mode, my_nprobe,
                                        t_recalls, D, I);
     });
+    API_END
+}
+
+int amd_ivf_submit_search_resident(amd_ivf_t* h, size_t start, size_t n, size_t k, size_t nprobe, int coarse_mode, float* D, int64_t* I,
+                                   uint64_t* ticket) {
+    API_BEGIN
+    OWNER_ONLY(h);
+    use_device(h);
+    if (start + n > h->n_resident) throw EngineError("resident query range out of bounds");
+    *ticket = async_enqueue(h, [=](amd_ivf_t* c) { return amd_ivf_search_resident(c, start, n, k, nprobe, coarse_mode, D, I); });
     API_END
 }
 

@@ -287,6 +287,9 @@ int amd_ivf_set_async_depth(amd_ivf_t* h, int depth);
 int amd_ivf_submit_adaptive(amd_ivf_t* h, size_t start, size_t n, size_t query_topk, float multipler, float std_m,
                             const float* require_acc, const float* gt_D, int profile, int coarse_mode, uint64_t* my_nprobe,
                             float* t_recalls, float* D, int64_t* I, uint64_t* ticket);
+/* the same for amd_ivf_search_resident (IndexIVF::search with a fixed nprobe over resident queries [start, start + n)) */
+int amd_ivf_submit_search_resident(amd_ivf_t* h, size_t start, size_t n, size_t k, size_t nprobe, int coarse_mode, float* D, int64_t* I,
+                                   uint64_t* ticket);
 int amd_ivf_wait(amd_ivf_t* h, uint64_t ticket, double timing[9], uint64_t diag[4]);
 
 /* Arithmetic the list scan of the last search ran in.  All three produce the reference's fp32 distance bit for

@@ -651,3 +651,19 @@ def test_asynchronous_searches_equal_the_synchronous_ones(capi, name):
     D2, I2, _, _ = h.wait(t)
     assert np.array_equal(I2, gold["I_r0"]) and np.array_equal(bits(D2), bits(gold["D_r0"]))
     h.close()
+
+
+@pytest.mark.parametrize("name", ["fixed_sift_l2", "fixed_deep_ip_d96"])
+def test_asynchronous_fixed_nprobe_searches(capi, name):
+    """amd_ivf_submit_search_resident: fixed-nprobe searches in flight from one caller; same bits as the synchronous call"""
+    case, gold = load_case(name)
+    h = make_index(capi, case, gold)
+    h.set_queries(case["xq"])
+    nq, k = case["xq"].shape[0], int(case["ks"][0])
+    eD, eI = h.search_resident(0, nq, k, case["nprobe"])
+    h.set_async_depth(2)
+    tickets = [h.submit_search_resident(0, nq, k, case["nprobe"]) for _ in range(5)]
+    for t in tickets:
+        D, I, timing, diag = h.wait(t)
+        assert np.array_equal(I, eI) and np.array_equal(bits(D), bits(eD))
+    h.close()
