@@ -3636,7 +3636,7 @@ static void async_worker(AsyncPool* p, size_t i) {
         {
             std::unique_lock<std::mutex> lk(p->mu);
             p->cv_job.wait(lk, [&] { return p->stop || !p->queue.empty(); });
-            if (p->queue.empty()) return;
+            if (p->stop || p->queue.empty()) return;  // (the handle is going away: searches not yet started are dropped)
             j = p->queue.front();
             p->queue.pop_front();
         }
@@ -3686,7 +3686,7 @@ static void async_shutdown(amd_ivf* h) {
         p->stop = true;
     }
     p->cv_job.notify_all();
-    for (auto& t : p->workers) t.join();  // (queued searches still run: their callers hold tickets)
+    for (auto& t : p->workers) t.join();  // (searches that are running finish; nobody can wait for the queued ones any more)
     for (amd_ivf_t* c : p->ctx) amd_ivf_destroy(c);
     delete p;
 }
