@@ -237,7 +237,7 @@ int amd_ivf_last_scan_min_bytes(amd_ivf_t* h, double* bytes);
  * (knn_L2sqr_sse / knn_inner_product_sse, Auncel/utils.cpp:417-490: a binary heap over centroids 0..nlist-1, heap-sorted
  * at the end, Heap.h:295-322) depends on the heap's history.  Rankings that hold such a run in the part that is read can
  * be re-run through that heap on the device (up to 2.8 ms each at nlist 4096).  Policy:
- *   calls of fewer than 20 queries (the reference's exact regime; what eval/ *.cpp issue) -- fixed-nprobe search, coarse,
+ *   calls of fewer than 20 queries (the reference's exact regime; what the eval/ harnesses issue) -- fixed-nprobe search, coarse,
  *     training: re-run.  Adaptive search: searched with such runs in centroid-number order first; a query reads only
  *     entries below 2 my_nprobe + 14, so if no run starts below that the result is the reference's, else the call is
  *     repeated with the heap's order -- same results as always re-running, at a hundredth of the cost.  Time-bounded
