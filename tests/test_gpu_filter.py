@@ -30,17 +30,17 @@ def clustered(rs, nb, nq, d, nlist, spread=0.35):
     return cen, assign, xb, xq
 
 
-def run_and_compare(capi, oracle, metric, cen, assign, xb, xq, k, nprobe, expect_filter=True):
+def run_and_compare(capi, oracle, metric, cen, assign, xb, xq, k, nprobe, expect_filter=True, store_pairs=False, max_codes=0):
     nlist, d = cen.shape
     lists = oracle.Lists(metric, cen, xb, assign)
     npq = min(nprobe, nlist)
     cd, ck = oracle.knn(metric, xq, cen, npq)
-    eD, eI, est = oracle.search_preassigned(lists, xq, k, ck, cd)
+    eD, eI, est = oracle.search_preassigned(lists, xq, k, ck, cd, store_pairs=store_pairs, max_codes=max_codes)
     h = capi.Handle(d, nlist, metric, 0)
     h.set_centroids(cen)
     h.set_lists_from_assign(xb, assign)
     h.stats(reset=True)
-    D, I = h.search_preassigned(xq, k, ck, cd)
+    D, I = h.search_preassigned(xq, k, ck, cd, store_pairs=store_pairs, max_codes=max_codes)
     launches, kept = h.last_filter()
     assert h.scan_arith() == 0
     if expect_filter:
@@ -113,3 +113,6 @@ def test_random_shapes_beyond_128_dimensions(capi, oracle, seed):
     metric = int(rs.choice([0, 1]))
     cen, assign, xb, xq = clustered(rs, nb, nq, d, nlist, spread=float(rs.choice([0.2, 0.5])))
     run_and_compare(capi, oracle, metric, cen, assign, xb, xq, k=k, nprobe=nprobe, expect_filter=nq * nprobe >= 1024)
+    # (list, position) pairs instead of ids; a cap on the codes a query may visit (the reference's loop breaks mid-ranking)
+    run_and_compare(capi, oracle, metric, cen, assign, xb, xq, k=k, nprobe=nprobe, expect_filter=False, store_pairs=True)
+    run_and_compare(capi, oracle, metric, cen, assign, xb, xq, k=k, nprobe=nprobe, expect_filter=False, max_codes=max(1, nb // 6))
