@@ -1437,7 +1437,10 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     const bool filter_ok = filter_available(h, I, base.bytes) && !base.range;
     if (filter_ok) ensure_frag32(I);
     if (filter_ok && base.tuner.enabled) first_round = filter_first_probes(I, (size_t)base.k, 64);
-    const double grow = grow_env > 0 ? grow_env : (base.bytes || filter_ok) ? 12.0 : 3.5;
+    // (byte codes: a round is bound by its one pass over the lists, x 12; the fp32 filter's rounds are bound by matrix-core issue
+    // from ~50 queries per list on, so what a round scans past the queries' stop points is paid for: x 6 measured best --
+    // fp32_path 0.69 / 0.88 / 0.90 / 0.84 M q/s at x 12 / 8 / 6 / 4)
+    const double grow = grow_env > 0 ? grow_env : base.bytes ? 12.0 : filter_ok ? 6.0 : 3.5;
     // pairs of a round: the packed query tiles of the fp32 scans (8 queries x dpad floats per group) must fit 4 GiB
     size_t seg_cap = (size_t)2 << 20;
     if (!base.bytes) {
