@@ -24,7 +24,7 @@ SYMBOLS = [
     "amd_ivf_set_tuner", "amd_ivf_search_adaptive", "amd_ivf_search_adaptive_x", "amd_ivf_search_adaptive_pre", "amd_ivf_search_timed", "amd_ivf_search_timed_x",
     "amd_ivf_train_samples",
     "amd_ivf_train_samples_x", "amd_ivf_train_samples_pre", "amd_ivf_trace_sb", "amd_ivf_arcos_table", "amd_ivf_merge_tables",
-    "amd_ivf_last_timing", "amd_ivf_last_scan_min_bytes", "amd_ivf_coarse_tie_rows", "amd_ivf_last_tie_fixed", "amd_ivf_last_filter", "amd_ivf_last_direct_out", "amd_ivf_set_async_depth", "amd_ivf_submit_adaptive", "amd_ivf_submit_search_resident", "amd_ivf_wait", "amd_ivf_last_tie_redone", "amd_ivf_last_round_hints", "amd_ivf_set_byte_codes",
+    "amd_ivf_last_timing", "amd_ivf_last_scan_min_bytes", "amd_ivf_coarse_tie_rows", "amd_ivf_last_tie_fixed", "amd_ivf_last_filter", "amd_ivf_last_direct_out", "amd_ivf_set_async_depth", "amd_ivf_submit_adaptive", "amd_ivf_submit_search_resident", "amd_ivf_wait", "amd_ivf_last_tie_redone", "amd_ivf_last_round_hints", "amd_ivf_set_byte_codes", "amd_ivf_set_option", "amd_ivf_get_option",
     "amd_ivf_kmeans",
     "amd_ivf_range_search_preassigned", "amd_ivf_range_search", "amd_ivf_range_results",
     "amd_ivf_scan_arith",
@@ -537,3 +537,12 @@ class Handle:
     def set_byte_codes(self, enable):
         """False: scan the fp32 lists even where the byte codes qualify (same results)"""
         lib().amd_ivf_set_byte_codes(self._h, int(bool(enable)))
+
+    def set_option(self, key, value):
+        """include/auncel_amd.h: amd_ivf_set_option (None returns the key to "unset")"""
+        _chk(lib().amd_ivf_set_option(self._h, key.encode(), C.c_double(float("nan") if value is None else float(value))))
+
+    def get_option(self, key):
+        v = C.c_double(0)
+        _chk(lib().amd_ivf_get_option(self._h, key.encode(), C.byref(v)))
+        return v.value

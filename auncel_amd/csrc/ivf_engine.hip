@@ -43,6 +43,73 @@ struct EngineError : std::runtime_error {  // what the reference raises as Faiss
             throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " at " #expr); \
     } while (0)
 
+// ------------------------------------------------------------------------------------ options
+// Policy and tuning choices of an index, set through the ABI (amd_ivf_set_option / amd_ivf_get_option; the reference exposes
+// such choices as index fields, Auncel/IndexIVF.h:97-143, and through ParameterSpace / c_api/IndexIVF_c.h:82-85).  A value that
+// was never set is OPT_UNSET: the debugging environment variable of the same meaning decides then, and after it the built-in
+// default -- the environment is a debugging aid, never the only way to a behaviour.
+constexpr double OPT_UNSET = -1e300;
+enum OptId {
+    OPT_COARSE_TIES,    // order inside runs of bit-equal coarse distances: 0 centroid number, 1 the reference's heap, 2 "redo"
+                        // (search again the queries that read such a run); unset: heap for calls of < 20 queries, else 0
+    OPT_SELECT,         // 0 the reference's heap replayed for every query, 1 sorted arrays + tie_fix_kernel (k <= 128)
+    OPT_TIE_FIX,        // 0 one pass at the end, 1 behind every round on a side stream; unset: by call size and concurrency
+    OPT_FILTER,         // fp32 threshold rounds through the matrix-core filter + exact rescoring (1) or on the vector ALU (0)
+    OPT_FIXED_ROUNDS,   // fixed-nprobe searches: 1 one dense round, 2 dense + threshold round; unset: by nprobe
+    OPT_ROUND_FIRST,    // adaptive search: probes of the first round (12)
+    OPT_ROUND_GROW,     // ... factor by which later rounds grow (12 byte codes, 6 fp32 filter, 3.5 fp32)
+    OPT_ROUND_INC,      // ... probes a later round adds at least
+    OPT_DIRECT_OUT,     // results written straight into page-locked caller buffers (1) or copied at the end (0)
+    OPT_SCAN_PIPELINED, // byte-code scan through scan_mfma_thr_kernel: bit 0 dense rounds, bit 1 threshold rounds (3: both; 0: scan_mfma_kernel)
+    OPT_PLAN_FUSED,     // round planning in three launches (1) or seven (0)
+    OPT_PINNED_IO,      // per-call inputs / outputs through one page-locked block read and written by kernels (1) or by copies (0)
+    N_OPT
+};
+struct OptSpec {
+    const char* key;
+    const char* env;
+    const char* words;  // "name=value,..." for environment variables that hold a word
+};
+const OptSpec OPT_TABLE[N_OPT] = {
+    {"coarse_ties", "AUNCEL_AMD_COARSE_TIES", "id=0,heap=1,redo=2"},
+    {"select", "AUNCEL_AMD_SELECT", "heap=0,sorted=1"},
+    {"tie_fix", "AUNCEL_AMD_TIE_FIX", "final=0,eager=1"},
+    {"filter", "AUNCEL_AMD_FILTER", nullptr},
+    {"fixed_rounds", "AUNCEL_AMD_FIXED_ROUNDS", nullptr},
+    {"round_first", "AUNCEL_AMD_ROUND_FIRST", nullptr},
+    {"round_grow", "AUNCEL_AMD_ROUND_GROW", nullptr},
+    {"round_inc", "AUNCEL_AMD_ROUND_INC", nullptr},
+    {"direct_out", "AUNCEL_AMD_DIRECT_OUT", nullptr},
+    {"scan_pipelined", "AUNCEL_AMD_SCAN_PIPELINED", nullptr},
+    {"plan_fused", "AUNCEL_AMD_PLAN_FUSED", nullptr},
+    {"pinned_io", "AUNCEL_AMD_PINNED_IO", nullptr},
+};
+struct Options {
+    double v[N_OPT];
+    Options() {
+        for (double& x : v) x = OPT_UNSET;
+    }
+    // the value set through the ABI, else the environment's (read per call: the tests flip it inside one process), else `dflt`
+    double get(OptId id, double dflt) const {
+        if (v[id] != OPT_UNSET) return v[id];
+        const char* e = getenv(OPT_TABLE[id].env);
+        if (!e || !*e) return dflt;
+        if (const char* w = OPT_TABLE[id].words) {
+            const size_t n = strlen(e);
+            for (const char* p = w; *p;) {
+                const char* eq = strchr(p, '=');
+                if ((size_t)(eq - p) == n && !strncmp(p, e, n)) return atof(eq + 1);
+                const char* c = strchr(eq, ',');
+                if (!c) break;
+                p = c + 1;
+            }
+            return dflt;  // an unknown word
+        }
+        return atof(e);
+    }
+    bool is_set(OptId id) const { return v[id] != OPT_UNSET || (getenv(OPT_TABLE[id].env) && *getenv(OPT_TABLE[id].env)); }
+};
+
 // Range of a set of fp32 values when all of them are integers (else ok = false).  When every operand of a
 // scan is an integer of magnitude <= 4095, x - y and (x - y)^2 (or x * y) are exactly representable, so
 // fma(t, t, acc) and acc + t * t round identically: the scan kernel may then fuse (2 VALU ops per element
@@ -201,6 +268,7 @@ struct amd_ivf {
     IntRange db_range, centroid_range, resident_range, call_range;  // see IntRange
     int allow_fused = 1;
     int allow_bytes = 1;
+    Options opt;  // on the index owner (search contexts read their owner's): amd_ivf_set_option
     // small device-to-host copies go through page-locked staging and are handed out after the call's synchronisation: a copy
     // into pageable memory blocks the host for ~20 us each, and a search ends with up to nine of them (d2h_small / flush_small)
     PinnedBuf p_small;
@@ -340,6 +408,7 @@ struct amd_ivf {
 
 static inline amd_ivf* ix(amd_ivf* h) { return h->parent ? h->parent : h; }
 static inline const amd_ivf* ix(const amd_ivf* h) { return h->parent ? h->parent : h; }
+static inline double opt(const amd_ivf* h, OptId id, double dflt) { return ix(h)->opt.get(id, dflt); }
 
 namespace {
 
@@ -458,8 +527,7 @@ bool byte_queries(amd_ivf* ws, const amd_ivf* index, const float* d_x, size_t n,
 // fp32 searches: threshold rounds as matrix-core filter + exact rescoring (ivf_filter.hip) when the index keeps the
 // fragment-ordered fp32 copy.  AUNCEL_AMD_FILTER=0 (read per search: the tests run both ways) keeps scan_tiles_kernel throughout.
 bool filter_available(const amd_ivf* ws, const amd_ivf* index, bool bytes) {
-    const char* e = getenv("AUNCEL_AMD_FILTER");
-    if (e && atoi(e) == 0) return false;
+    if (index->opt.get(OPT_FILTER, 1) == 0) return false;
     return !bytes && (index->have_frag32 || index->frag32_possible) && ws->allow_filter;
 }
 // the fragment-ordered fp32 copy of lists that also have byte codes is built the first time an fp32 search runs over them
@@ -1058,8 +1126,7 @@ void fold_stats(amd_ivf* h, size_t nq) {
 
 // device view of a page-locked host buffer (hipHostMalloc / hipHostRegister, e.g. torch's pin_memory), else null
 static void* device_view(const void* host) {
-    static const bool off = getenv("AUNCEL_AMD_DIRECT_OUT") && !strcmp(getenv("AUNCEL_AMD_DIRECT_OUT"), "0");
-    if (off || !host) return nullptr;
+    if (!host) return nullptr;
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, host) != hipSuccess) {
         (void)hipGetLastError();  // (pageable memory: not an error of ours)
@@ -1070,7 +1137,7 @@ static void* device_view(const void* host) {
 struct DirectOut {
     amd_ivf* h;
     DirectOut(amd_ivf* h_, float* D, int64_t* I) : h(h_) {
-        void* d = device_view(D);
+        void* d = opt(h, OPT_DIRECT_OUT, 1) != 0 ? device_view(D) : nullptr;
         void* i = d ? device_view(I) : nullptr;
         h->out_D = i ? static_cast<float*>(d) : nullptr;
         h->out_I = i ? static_cast<int64_t*>(i) : nullptr;
@@ -1154,9 +1221,8 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
     // "heap" always, "id" never (such runs stay in centroid-number order), default: calls of fewer than 20 queries, the
     // regime in which the reference ranks exact distances at all (utils.cpp:624-655; from 20 queries on it ranks sgemm
     // output, whose low bits -- and with them which distances coincide -- belong to the BLAS library).
-    const char* ties_env = getenv("AUNCEL_AMD_COARSE_TIES");
-    const bool heap_ties = !use_heap && (h->ties_override >= 0 ? h->ties_override == 1
-                                         : ties_env ? !strcmp(ties_env, "heap") || (strcmp(ties_env, "id") && n < 20) : n < 20);
+    const int ties_opt = (int)opt(h, OPT_COARSE_TIES, -1);  // 0 centroid number, 1 heap, 2 redo (a matter of the adaptive search), -1 unset
+    const bool heap_ties = !use_heap && (h->ties_override >= 0 ? h->ties_override == 1 : ties_opt == 1 || (ties_opt != 0 && n < 20));
     for (size_t c0 = 0; c0 < n; c0 += chunk) {
         const size_t m = std::min(chunk, n - c0);
         // pairs: every query of the chunk against the single "list" = centroid table
@@ -1280,7 +1346,7 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
                                                        h->w_tie_rows.as<unsigned long long>(), s);
                 // the heap and a row must fit one workgroup's LDS (nlist up to ~13 000): beyond that the reference's tie order is
                 // not available -- say so when it was asked for explicitly instead of silently ranking by centroid number
-                if (!ran && (h->ties_override == 1 || (ties_env && !strcmp(ties_env, "heap"))))
+                if (!ran && (h->ties_override == 1 || ties_opt == 1))
                     throw EngineError("coarse tie order by the reference's heap needs nlist x 12 bytes of LDS (nlist <= ~13 000)");
             }
         }
@@ -1312,8 +1378,7 @@ void search_fixed_device(amd_ivf* h, const float* d_x, size_t n, size_t k, size_
     base.fused = h->allow_fused && ix(h)->db_range.fusable_with(qr, h->metric);
     base.bytes = byte_queries(h, ix(h), d_x, n, qr);
     ix(h)->last_arith = base.bytes ? 2 : base.fused ? 1 : 0;
-    const char* two_s = getenv("AUNCEL_AMD_FIXED_ROUNDS");  // read per call: the tests run both ways in one process
-    const int two_env = two_s ? atoi(two_s) : 0;
+    const int two_env = (int)opt(h, OPT_FIXED_ROUNDS, 0);
     // a handful of queries: the second round's planning + synchronisation costs more than threshold mode saves
     // (fp32 lists with the matrix-core filter: a threshold round costs its list bytes, not its distances -- one dense probe gives
     // the thresholds, everything else goes through the filter)
@@ -1431,7 +1496,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     const bool chained = !(base.range || base.d_budget_ms || sync_env);
     // over-scan against rounds: the byte-code scan is bound by its one pass over the lists, not by the pairs it computes, so
     // its rounds grow fast (12 -> 144 -> all); the fp32 scans pay for every distance (12 -> 42 -> 147)
-    static const double grow_env = getenv("AUNCEL_AMD_ROUND_GROW") ? atof(getenv("AUNCEL_AMD_ROUND_GROW")) : 0.0;
+    const double grow_env = opt(h, OPT_ROUND_GROW, 0.0);
     // fp32 lists with the matrix-core filter (ivf_filter.hip): threshold rounds cost their list bytes too, and the first round --
     // the only one computed on the vector ALU in the reference's rounding sequence -- shrinks to one probe per query
     const bool filter_ok = filter_available(h, I, base.bytes) && !base.range;
@@ -1491,7 +1556,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     // are expected: ~5 k for a million candidates), beyond which the call is repeated with the heap kernels
     const size_t log_cap = std::min<size_t>(4096, (std::max<size_t>(256, 32 * (size_t)base.k) + 63) & ~(size_t)63);
     const bool sorted_ok = !base.range && !base.train.enabled && !base.raw_heap_out && base.k <= 128 && I->h_list_off[nlist] < 0xffffffffull &&
-                           !h->force_heap_select;
+                           !h->force_heap_select && opt(h, OPT_SELECT, 1) != 0;
     if (sorted_ok) h->w_log.ensure(n * log_cap * 8);
     // groups of 8 pairs never cross a list: at most pairs / 8 + one partial group per list
     const size_t group_cap = seg_cap / SCAN_RQ + nlist;
@@ -1504,7 +1569,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     pa.key_stride = base.coarse_stride;
     pa.slot_base = 0;
     pa.first_round = (uint32_t)first_round;
-    static const size_t inc_env = getenv("AUNCEL_AMD_ROUND_INC") ? (size_t)atoi(getenv("AUNCEL_AMD_ROUND_INC")) : 0;
+    const size_t inc_env = (size_t)opt(h, OPT_ROUND_INC, 0);
     pa.min_inc = (uint32_t)(inc_env ? inc_env : filter_ok && base.tuner.enabled ? 12 : first_round);
     pa.tune = base.tuner.enabled;
     pa.d = h->d;
@@ -1629,9 +1694,11 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             ma.nitems = counts ? counts[CNT_QG8] : 0;
             ma.dev_nitems = counts ? nullptr : dcnt + CNT_QG8;
             ma.hint_nitems = hint_of(round, CNT_QG8);
+            ma.pipelined = (int)opt(h, OPT_SCAN_PIPELINED, 3);
             if (thr_mode) {
                 ma.thr = h->w_thr.as<float>();
                 ma.mask = h->w_mask.as<unsigned long long>();
+                ma.exact_mask = base.range;  // (range search counts the mask bits)
             }
             // the scan runs on a normal-priority side stream (see make_main_stream)
             HIP_CHECK(hipEventRecord(h->ev_fork, s));
@@ -1722,7 +1789,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     // tie_fix_kernel: behind every round on a side stream when this search has the index to itself (latency), one pass at the end
     // when other searches are running on it (their kernels fill the GPU while it runs; more streams would only crowd the hardware
     // queues)
-    static const char* fix_env = getenv("AUNCEL_AMD_TIE_FIX");
+    const int fix_opt = (int)opt(h, OPT_TIE_FIX, -1);
     struct Active {
         std::atomic<int>& c;
         int before;
@@ -1736,7 +1803,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     const float seen_rate = I->tie_rate.load();
     const bool ties_common = seen_rate >= 0.f ? seen_rate > 0.02f : (base.bytes || base.fused);
     // (a handful of queries: the per-round replay is one wave's serial work on the critical path of a search that is all latency)
-    const bool eager_fix = fix_env ? !strcmp(fix_env, "eager") : (active.before == 0 && ties_common && n >= 512);
+    const bool eager_fix = fix_opt >= 0 ? fix_opt == 1 : (active.before == 0 && ties_common && n >= 512);
     auto tie_fix_args = [&](uint32_t round, int final_pass) {
         TieFixArgs ta{};
         ta.metric = h->metric;
@@ -2503,10 +2570,7 @@ static void timed_core(amd_ivf* h, const float* d_x, size_t start, size_t n, siz
     // Runs of equal coarse distances stay in centroid-number order here unless AUNCEL_AMD_COARSE_TIES=heap: where the
     // clock decides how deep a query goes, which of two equidistant lists comes first is immaterial, and re-running the
     // reference's heap over all nlist entries (2.8 ms at 4096) would cost more than most budgets.
-    {
-        const char* te = getenv("AUNCEL_AMD_COARSE_TIES");
-        h->ties_override = te && !strcmp(te, "heap") ? 1 : 0;
-    }
+    h->ties_override = (int)opt(h, OPT_COARSE_TIES, -1) == 1 ? 1 : 0;
     coarse_dev(h, d_x, n, nprobe, coarse_mode, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>(),
                h->allow_fused && ix(h)->centroid_range.fusable_with(qr, h->metric));
     h->ties_override = -1;
@@ -2854,7 +2918,7 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
     base.d_ckeys = L->w_ckeys.as<int64_t>();
     base.coarse_stride = (uint32_t)np_row;
     base.tuner = make_tuner(L, query_topk, multipler, std_m, dreq, dgt, dnp, dtr, profile);
-    static const size_t first_env = getenv("AUNCEL_AMD_ROUND_FIRST") ? (size_t)atoi(getenv("AUNCEL_AMD_ROUND_FIRST")) : 12;
+    const size_t first_env = std::max<size_t>(1, (size_t)opt(L, OPT_ROUND_FIRST, 12));
     static const bool host_plan = getenv("AUNCEL_AMD_HOST_PLAN") != nullptr;
     if (host_plan) {
         run_rounds(L, base, n, first_env, np_row, dnp, id0);
@@ -3107,12 +3171,12 @@ static void adaptive_redo_ties(amd_ivf_t* h, const float* d_x, size_t start, siz
 static void adaptive_core(amd_ivf_t* h, const float* d_x, size_t start, size_t n, size_t query_topk, float multipler, float std_m,
                           const float* require_acc, const float* gt_D, int profile, int coarse_mode,
                           uint64_t* my_nprobe, float* t_recalls, float* D, int64_t* I, const IntRange& qr) {
-    const char* ties_env = getenv("AUNCEL_AMD_COARSE_TIES");
+    const int ties_opt = (int)opt(h, OPT_COARSE_TIES, -1);
     const bool can_speculate = !h->given_keys && n > 0 && h->nlist > 128 && multipler >= 1.f && !(profile & 2) && h->kids.empty();
-    const bool speculate = can_speculate && n < 20 && !ties_env;
+    const bool speculate = can_speculate && n < 20 && ties_opt < 0;
     // larger calls: "redo" searches again, with the heap's order, exactly the queries whose first run of equal coarse distances
     // lies within what they read (a handful in thousands) -- the reference's exact-distance result for every query of the call
-    const bool redo_some = can_speculate && n >= 20 && ties_env && !strcmp(ties_env, "redo");
+    const bool redo_some = can_speculate && n >= 20 && ties_opt == 2;
     if (redo_some) {
         adaptive_redo_ties(h, d_x, start, n, query_topk, multipler, std_m, require_acc, gt_D, profile, coarse_mode, my_nprobe, t_recalls, D, I, qr);
         return;
@@ -3532,6 +3596,35 @@ int amd_ivf_set_byte_codes(amd_ivf_t* h, int enable) {
     h->allow_bytes = enable ? 1 : 0;
     for (amd_ivf* c : h->async_ctx) c->allow_bytes = h->allow_bytes;
     return 0;
+}
+
+static int opt_id(const char* key) {
+    if (key)
+        for (int i = 0; i < N_OPT; i++)
+            if (!strcmp(key, OPT_TABLE[i].key)) return i;
+    throw EngineError(std::string("unknown option: ") + (key ? key : "(null)"));
+}
+static double opt_default(OptId id) {
+    switch (id) {
+        case OPT_COARSE_TIES: case OPT_TIE_FIX: return -1;
+        case OPT_FIXED_ROUNDS: case OPT_ROUND_INC: case OPT_ROUND_GROW: return 0;  // (0: chosen per search)
+        case OPT_ROUND_FIRST: return 12;
+        case OPT_SCAN_PIPELINED: return 3;
+        default: return 1;
+    }
+}
+int amd_ivf_set_option(amd_ivf_t* h, const char* key, double value) {
+    API_BEGIN
+    if (!h) throw EngineError("null handle");
+    ix(h)->opt.v[opt_id(key)] = std::isnan(value) ? OPT_UNSET : value;
+    API_END
+}
+int amd_ivf_get_option(amd_ivf_t* h, const char* key, double* value) {
+    API_BEGIN
+    if (!h || !value) throw EngineError("null argument");
+    const OptId id = (OptId)opt_id(key);
+    *value = opt(h, id, opt_default(id));
+    API_END
 }
 
 int amd_ivf_last_scan_min_bytes(amd_ivf_t* h, double* bytes) {

@@ -131,6 +131,10 @@ struct MfmaScanArgs {
     uint32_t nitems;
     const uint32_t* dev_nitems;   // chained rounds: the item count lives on the device; the grid is a hint (see ScanArgs)
     uint32_t hint_nitems;         // items the same round had last time (0: unknown -> a resident grid)
+    int exact_mask;               // threshold mode: the mask bits are counted as results (range search), not re-tested by a selection
+    int pipelined;                // 1: dense rounds, 2: threshold rounds, 3: both through scan_mfma_thr_kernel (two blocks in flight
+                                  // per wave; threshold rounds: threshold folded into the accumulator, the mask a superset of
+                                  // the exact one -- where exact_mask allows it)
 };
 void launch_scan_mfma(const MfmaScanArgs& a, hipStream_t s);
 // fp32 lists (CSR rows, row stride dpad floats, integers 0..255) -> fragment order + code_cy; block_off[l] = first block of list l

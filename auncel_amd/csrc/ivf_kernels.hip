@@ -512,6 +512,214 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AUNCEL_MFMA
     }  // items
 }
 
+// ---- threshold rounds, pipelined form (round 4).  The kernel above keeps ONE list block in flight per wave (its loop top is
+// `s_waitcnt vmcnt(0)`) and starts every item with three dependent round trips (item -> pair rows -> per-query operands): with
+// four waves per SIMD that is 64 KB in flight per CU only while every wave happens to be waiting, and a launch streamed at 0.30
+// of the HBM peak with the waves parked in s_waitcnt for half their cycles (profiles/r03_summary.md).  Here
+//   * two blocks are in flight per wave at all times, across block AND item boundaries: block i + 2 is requested right behind
+//     the MFMAs of block i, and past the item's end that is block 0 / 1 of the wave's NEXT item (its header came in through the
+//     scalar cache two items ahead, its pair rows one item ahead), so a wave's list stream never drains between items;
+//   * every load of the stream is unconditional straight-line code (a wave without a next item re-requests its own first block),
+//     which lets the compiler wait with a count (the stores of an epilogue are younger than the loads it runs under);
+//   * the per-query threshold is folded into the contraction: the accumulator starts at -floor(u / 2) (L2; u = |x|^2 - T made
+//     even, i.e. T loosened by at most one -- the selection re-tests every marked candidate against the query's current worst
+//     anyway) or -u (IP), so a register's test is ONE v_cmp against floor(|y|^2 / 2) (-cy for IP) and the 48 registers of
+//     per-query operands in accumulator layout (thresholds, |x|^2, row offsets) shrink to the 16 start values; |x|^2, u and the
+//     row offset of a query are read from LDS by the rare register that stores a distance.
+// The mask it leaves is a superset of the exact one (never a subset): callers that COUNT mask bits (range search) keep the
+// kernel above (MfmaScanArgs::exact_mask).
+// DENSE: the same stream for rounds that store every distance (round 0): accumulators start at zero, |x|^2 and the row offset of a
+// register's query come from LDS four registers at a time.
+template <int METRIC, int NKS, bool DENSE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void scan_mfma_thr_kernel(MfmaScanArgs a) {
+    static_assert(NKS >= 1 && NKS <= 4, "query operand resident in registers");
+    __shared__ int s_init[4][32];
+    __shared__ int s_cx[4][32];
+    __shared__ int s_u[4][32];
+    __shared__ uint32_t s_row[4][32];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = lane & 31, h = lane >> 5;
+    constexpr size_t qstride = (size_t)NKS * 32;
+    constexpr size_t block_bytes = (size_t)NKS * 1024;
+    // item headers through the scalar cache (constant address space: nothing this kernel stores aliases them)
+    typedef int v8i __attribute__((ext_vector_type(8)));
+    typedef const v8i __attribute__((address_space(4)))* item_cp;
+    static_assert(sizeof(ScanItem) == 32, "one s_load_dwordx8 per item header");
+    const item_cp items_c = (item_cp)(uintptr_t)a.items;
+    struct Hdr {  // the fields of a ScanItem this kernel reads (wave-uniform: SGPRs)
+        uint64_t vec_base;
+        uint32_t nvec, vec_off, pair_begin, npair;
+    };
+    auto load_item = [&](uint32_t n) {
+        const v8i t = items_c[n];
+        Hdr r;
+        r.vec_base = (uint64_t)(uint32_t)t[0] | ((uint64_t)(uint32_t)t[1] << 32);
+        r.nvec = (uint32_t)t[2];
+        r.vec_off = (uint32_t)t[3];
+        r.pair_begin = (uint32_t)t[4];
+        r.npair = (uint32_t)t[5];
+        return r;
+    };
+    const uint32_t nitems = a.dev_nitems ? *a.dev_nitems : a.nitems;
+    ItemWalk w((nitems + 3) >> 2, a.xcd_chunks);
+    uint32_t wi = w.cur;
+    if (wi >= w.end || wi * 4 + (uint32_t)wave >= nitems) return;  // (no workgroup barrier anywhere below)
+    auto item_of = [&](uint32_t walk) { return walk * 4 + (uint32_t)wave; };
+    auto exists = [&](uint32_t walk) { return walk < w.end && item_of(walk) < nitems; };
+
+    v4i b0[NKS], b1[NKS];
+    int cy0 = 0, cy1 = 0;
+    auto fetch = [&](v4i (&b)[NKS], int& cy, uint64_t blk) {
+        const uint8_t* bp = a.codes_frag + blk * block_bytes + (size_t)lane * 16;
+#pragma unroll
+        for (int s = 0; s < NKS; s++) b[s] = MFMA_BLOAD(reinterpret_cast<const v4i*>(bp + (size_t)s * 1024));
+        cy = a.code_cy[blk * 32 + m];
+    };
+
+    Hdr cur = load_item(item_of(wi));
+    Hdr nxt = load_item(exists(wi + w.step) ? item_of(wi + w.step) : item_of(wi));
+    // (every load of the stream below is unconditional: a slot without a query reads entry 0 of the item and masks the result,
+    // so that the compiler's wait counts stay exact)
+    uint32_t pq, po;  // query row and distance row (at most 2^31 floats) of this lane's query slot
+    {
+        const uint32_t e = cur.pair_begin + ((uint32_t)m < cur.npair ? (uint32_t)m : 0u);
+        pq = a.pair_query[e];
+        po = (uint32_t)a.pair_out[e];
+    }
+    fetch(b0, cy0, cur.vec_base);
+    fetch(b1, cy1, cur.vec_base + 1);
+    uint32_t* mask32 = reinterpret_cast<uint32_t*>(a.mask);
+
+    for (;;) {
+        const uint32_t wn = wi + w.step;
+        const bool has_next = exists(wn);
+        // (header two items ahead: consumed when `nxt` becomes `cur`)
+        const Hdr nn = load_item(exists(wn + w.step) ? item_of(wn + w.step) : item_of(wi));
+        const bool qok = (uint32_t)m < cur.npair;
+        const uint32_t row = po + cur.vec_off;
+        const int8_t* qp = a.queries8 + (size_t)pq * qstride + (size_t)h * (size_t)(16 * NKS);
+        v4i af[NKS];
+#pragma unroll
+        for (int s = 0; s < NKS; s++) af[s] = *reinterpret_cast<const v4i*>(qp + 16 * s);
+        const int cx = a.query_cx[pq];
+        const float thr = DENSE ? 0.f : a.thr[pq];
+        // pair rows of the next item (in flight for the whole of this one)
+        const uint32_t en = has_next ? nxt.pair_begin + ((uint32_t)m < nxt.npair ? (uint32_t)m : 0u) : cur.pair_begin;
+        const uint32_t pqn = a.pair_query[en];
+        const uint32_t pon = (uint32_t)a.pair_out[en];
+        if (!qok) {
+#pragma unroll
+            for (int s = 0; s < NKS; s++) af[s] = v4i{0, 0, 0, 0};
+        }
+        // start value of the accumulators: see the head comment.  Invalid query slots never pass.
+        int u = 0, init = -1073741824;
+        if (qok && !DENSE) {
+            if (METRIC == METRIC_L2) {
+                const float c = ceilf(thr);
+                const int T = !(c > 0.f) ? 0 : (c >= 1073741824.f ? 1073741824 : (int)c);  // NaN -> nothing passes the selection
+                u = (cx - T) & ~1;
+                init = -(u >> 1);
+            } else {
+                const float f = floorf(thr);
+                const int T = !(f < 1073741824.f) ? 0x7fffffff : (f <= -1073741824.f ? -1073741824 : (int)f);
+                if (T != 0x7fffffff) {  // (else nothing passes: the start value of an invalid slot)
+                    u = T - cx;
+                    init = -u;
+                }
+            }
+        }
+        // (the next item's pair rows are awaited here, with this item's operands: a load left pending across the block loop
+        // ages without bound there, the compiler's wait-count analysis does not converge and falls back to vmcnt(0) at the
+        // loop head -- one block in flight again)
+        asm volatile("" ::"v"(pqn), "v"(pon));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the previous item's reads of this wave's LDS rows are done
+        __builtin_amdgcn_wave_barrier();
+        if (h == 0) {
+            s_init[wave][m] = init;
+            s_cx[wave][m] = cx;
+            s_u[wave][m] = u;
+            s_row[wave][m] = row;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        v16i cinit;  // register 4 g + i of lane half h belongs to query 8 g + 4 h + i
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const v4i t = DENSE ? v4i{0, 0, 0, 0} : *reinterpret_cast<const v4i*>(&s_init[wave][8 * g + 4 * h]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) cinit[4 * g + i] = t[i];
+        }
+
+        const uint32_t nblk = ((cur.nvec + 63) >> 6) * 2;  // lists are stored in pairs of blocks: a 64-candidate mask word is two of ours
+        auto step = [&](v4i (&b)[NKS], int& cyv, uint32_t i) {
+            __builtin_amdgcn_sched_barrier(0);
+            v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], b[0], cinit, 0, 0, 0);
+#pragma unroll
+            for (int s = 1; s < NKS; s++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[s], b[s], acc, 0, 0, 0);
+            // (what the epilogue needs of |y|^2 is taken before the register is requested again: the old and the new value never
+            // live side by side, so the loop carries no copy -- a copy behind the load would wait for it)
+            const uint32_t lv = i * 32 + m;  // position of this lane's vector in the chunk
+            const bool vok = lv < cur.nvec;
+            int hc = !vok ? 0x7fffffff : METRIC == METRIC_L2 ? cyv >> 1 : -cyv;
+            int cy;  // (an explicit move: a plain copy would be coalesced with the register the next request writes)
+            asm volatile("v_mov_b32 %0, %1" : "=v"(cy) : "v"(cyv));
+            asm volatile("" : "+v"(hc));
+            __builtin_amdgcn_sched_barrier(0);
+            // block i + 2 of the stream: of this item, else block 0 / 1 of the next (nblk is even), else anything valid
+            const uint32_t in = i + 2;
+            const uint64_t nb = in < nblk ? cur.vec_base + in : has_next ? nxt.vec_base + (in - nblk) : cur.vec_base;
+            fetch(b, cyv, nb);
+            __builtin_amdgcn_sched_barrier(0);
+            if (DENSE) {
+                // every distance of the tile: register 4 g + i = (query 8 g + 4 h + i, vector lv): two 128-byte runs per register
+                static_for(std::make_integer_sequence<int, 4>{}, [&](auto G) {
+                    constexpr int g = decltype(G)::value;
+                    const v4i c4 = *reinterpret_cast<const v4i*>(&s_cx[wave][8 * g + 4 * h]);
+                    const v4i r4 = *reinterpret_cast<const v4i*>(&s_row[wave][8 * g + 4 * h]);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int t = METRIC == METRIC_L2 ? 2 * acc[4 * g + i] - cy : acc[4 * g + i] + cy;
+                        const int res = METRIC == METRIC_L2 ? c4[i] - t : c4[i] + t;
+                        uint32_t off = (uint32_t)r4[i] + lv;
+                        asm volatile("" : "+v"(off));  // 64-bit addresses are formed here, not hoisted as register pairs
+                        if (vok && (uint32_t)(8 * g + 4 * h + i) < cur.npair) a.dist[off] = (float)res;
+                    }
+                });
+                return;
+            }
+            int word = 0;  // lane q (< 32) collects the 32-candidate mask word of query q
+            static_for(std::make_integer_sequence<int, 16>{}, [&](auto R) {
+                constexpr int reg = decltype(R)::value;
+                constexpr int q0 = (reg & 3) + 8 * (reg >> 2);  // query of lane half 0; half 1: q0 + 4
+                const bool keep = acc[reg] > hc;
+                const unsigned long long bal = __ballot(keep);
+                writelane_c<q0>(word, (uint32_t)bal);
+                writelane_c<q0 + 4>(word, (uint32_t)(bal >> 32));
+                if (bal && keep) {
+                    const int cq = s_cx[wave][q0 + 4 * h], uq = s_u[wave][q0 + 4 * h];
+                    const uint32_t off = s_row[wave][q0 + 4 * h] + lv;
+                    // the contraction itself: acc = x.y - floor(u / 2) (L2) | x.y - u (IP)
+                    const int t = METRIC == METRIC_L2 ? 2 * (acc[reg] + (uq >> 1)) - cy : acc[reg] + uq + cy;
+                    a.dist[off] = (float)(METRIC == METRIC_L2 ? cq - t : cq + t);
+                }
+            });
+            // rows start on multiples of 64 floats, chunks on multiples of 64 vectors: word index = (row + position) / 32
+            if (lane < 32 && qok) mask32[(row + i * 32) >> 5] = (uint32_t)word;
+        };
+        for (uint32_t i = 0; i < nblk; i += 2) {
+            step(b0, cy0, i);
+            step(b1, cy1, i + 1);
+        }
+        if (!has_next) break;
+        cur = nxt;
+        nxt = nn;
+        pq = pqn;
+        po = pon;
+        wi = wn;
+    }
+}
+
 uint32_t mfma_chunk() {
     static const uint32_t v = [] {
         const char* e = getenv("AUNCEL_AMD_MFMA_CHUNK");
@@ -548,6 +756,27 @@ void launch_scan_mfma(const MfmaScanArgs& a, hipStream_t s) {
             default: return go(scan_mfma_kernel<M, K, 0>);
         }
     };
+    // threshold rounds whose mask may be a superset of the exact one: the pipelined form (scan_mfma_thr_kernel)
+    if ((a.pipelined & (masked ? 2 : 1)) && !(masked && a.exact_mask) && ks >= 1 && ks <= 4) {
+        auto pick_thr = [&](auto metric, auto dense) {
+            constexpr int M = decltype(metric)::value;
+            constexpr bool D = decltype(dense)::value;
+            switch (ks) {
+                case 1: return go(scan_mfma_thr_kernel<M, 1, D>);
+                case 2: return go(scan_mfma_thr_kernel<M, 2, D>);
+                case 3: return go(scan_mfma_thr_kernel<M, 3, D>);
+                default: return go(scan_mfma_thr_kernel<M, 4, D>);
+            }
+        };
+        if (a.metric == METRIC_L2) {
+            if (masked) pick_thr(std::integral_constant<int, METRIC_L2>{}, std::false_type{});
+            else pick_thr(std::integral_constant<int, METRIC_L2>{}, std::true_type{});
+        } else {
+            if (masked) pick_thr(std::integral_constant<int, METRIC_IP>{}, std::false_type{});
+            else pick_thr(std::integral_constant<int, METRIC_IP>{}, std::true_type{});
+        }
+        return;
+    }
     if (a.metric == METRIC_L2) {
         if (masked) pick_ks(std::integral_constant<int, METRIC_L2>{}, std::true_type{});
         else pick_ks(std::integral_constant<int, METRIC_L2>{}, std::false_type{});

@@ -1583,8 +1583,7 @@ void launch_select_sorted(const ReplayArgs& a, hipStream_t s) {
 // the sorted-array selection applies when positions fit 32 bits (the caller checks ntotal) and the result is the
 // reordered one; the heap kernels remain for the scanner API (raw heap out), trace training, k > 128 and on request
 bool replay_sorted_applies(const ReplayArgs& a) {
-    const char* e = getenv("AUNCEL_AMD_SELECT");  // read per launch: the tests run both selections in one process
-    if (e && !strcmp(e, "heap")) return false;
+    // (the engine passes a log only where its "select" option allows the sorted form)
     return a.log != nullptr && a.k >= 1 && a.k <= 128 && !a.train.enabled && !a.raw_heap_out;
 }
 

@@ -303,6 +303,35 @@ int amd_ivf_scan_arith(amd_ivf_t* h);
  * codes qualify (same results; bench.py's fp32_path leg).  enable = 1 restores the default. */
 int amd_ivf_set_byte_codes(amd_ivf_t* h, int enable);
 
+/* Options of an index: policy that can change a result's tie order, and tuning that cannot change a result at all.  The
+ * reference exposes such choices as public fields of the index (nprobe, max_codes, parallel_mode ..., IndexIVF.h:97-143) and
+ * through ParameterSpace::set_index_parameter(index, "name", value) (AutoTune.h) / c_api/IndexIVF_c.h:82-85 getter-setter
+ * pairs; this is the same thing in C.  `h` may be the index or one of its search contexts (the option is the index's either
+ * way); set it while no search is running.  get returns the effective value: what was set, else the value of the debugging
+ * environment variable of the same meaning (AUNCEL_AMD_<KEY>), else the built-in default.  Unknown key: -2.
+ *
+ *   key               values                                                                 default
+ *   "coarse_ties"     order inside runs of bit-equal coarse distances (knn_L2sqr_sse's heap   unset (-1): heap for calls of
+ *                     history, utils.cpp:454-490): 0 centroid number, 1 the reference's       fewer than 20 queries (the regime
+ *                     heap for every ranking, 2 search again exactly the queries whose        in which the reference ranks exact
+ *                     result could depend on it                                               distances, utils.cpp:644-655), else 0
+ *                     -- the ONLY option that can change returned ids (of queries whose probe order crosses such a run)
+ *   "select"          0 the reference's binary heap replayed for every query, 1 sorted        1
+ *                     arrays + heap replay of the queries in which equal distances met
+ *   "tie_fix"         0 that replay once at the end of a search, 1 behind every round         unset: by call size / concurrency
+ *   "filter"          fp32 threshold rounds: 1 matrix-core filter + exact recomputation, 0    1
+ *                     vector ALU only
+ *   "fixed_rounds"    fixed-nprobe search: 1 one dense round, 2 dense + threshold round       unset (0): by nprobe
+ *   "round_first", "round_grow", "round_inc"   round schedule of the adaptive search           12, 12 (bytes) / 6 / 3.5, = first
+ *   "direct_out"      1 results stored straight into page-locked (D, I), 0 copied at the end  1
+ *   "scan_pipelined"  byte-code scan through scan_mfma_thr_kernel (two list blocks in flight per   3
+ *                     wave): bit 0 dense rounds, bit 1 threshold rounds; 0: scan_mfma_kernel
+ *   "plan_fused"      round planning in 3 launches (1) or 7 (0)                               1
+ *   "pinned_io"       per-call inputs / outputs through one page-locked block (1) or copies (0)                 1
+ * amd_ivf_set_option(h, key, NAN) returns the key to "unset". */
+int amd_ivf_set_option(amd_ivf_t* h, const char* key, double value);
+int amd_ivf_get_option(amd_ivf_t* h, const char* key, double* value);
+
 /* ------------------------------------------------------------------------------------------------
  * Dataset files of the reference's harness (Auncel/eval/bound.cpp:29-113; host only).  Buffers are malloc'ed
  * here and released with amd_ivf_free.  Where the harness aborts (missing file, size that is not a whole number of rows,
