@@ -189,6 +189,12 @@ struct PinnedBuf {
         cap = want;
     }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+    // the address kernels use for this memory (page-locked host memory is mapped into the device's address space)
+    void* dev() const {
+        void* d = nullptr;
+        HIP_CHECK(hipHostGetDevicePointer(&d, p, 0));
+        return d;
+    }
     ~PinnedBuf() {
         if (p) (void)hipHostFree(p);
     }
@@ -276,8 +282,14 @@ struct amd_ivf {
     struct SmallCopy {
         void* dst;
         size_t off, bytes;
+        const void* src;  // device source still to be gathered into the staging block by copy_segs_kernel (null: copied already)
     };
     std::vector<SmallCopy> small;
+    // host-to-device counterpart: inputs of a call are packed into page-locked staging and scattered by one kernel (h2d_small)
+    PinnedBuf p_stage;
+    size_t stage_used = 0;
+    CopySegs h2d_pending{};
+    std::vector<std::function<void()>> after_flush;  // run by sync_and_flush behind the synchronisation (deferred epilogues)
     bool want_first_tie = false;        // adaptive_slice: also leave the start of each ranking's first run of equal distances
     size_t first_tie_nreal = 0;
     DevBuf w_first_tie;
@@ -332,6 +344,9 @@ struct amd_ivf {
     DevBuf w_heap_val, w_heap_ref, w_stage, w_nscan, w_done, w_pre_val, w_stoped, w_dtb, w_D, w_I;
     DevBuf w_cdis, w_ckeys, w_stats, w_error, w_misc, w_misc2, w_misc3, w_rawptrs;
     DevBuf c_heap_val, c_heap_ref, c_stage, c_nscan, c_done, c_seg_off, c_seg_list, c_seg_count;
+    DevBuf c_pair_query, c_pair_out, c_items, c_group_p0, c_group_cnt;  // the coarse quantiser's work list (coarse_dev), kept
+    uint64_t coarse_sig = 0;                                             // while its signature (chunk, queries, nlist) repeats
+    bool coarse_sig_valid = false;
     PinnedBuf p_items, p_pair_query, p_pair_out, p_seg_off, p_seg_list, p_seg_count, p_qsel, p_seg_begin;
     DevBuf w_seg_begin;
     DevBuf w_log, w_log_cnt, w_amb, w_tie_flag;  // sorted-array selection: admission logs, ambiguity marks, tie_fix flags
@@ -1030,6 +1045,8 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
     }
 }
 
+static bool pinned_io(const amd_ivf* h) { return opt(h, OPT_PINNED_IO, 1) != 0; }
+
 static void d2h_small(amd_ivf* h, void* dst, const void* src, size_t bytes, hipStream_t s) {
     constexpr size_t LIMIT = (size_t)64 << 10, CAP = (size_t)1 << 20;
     const size_t off = (h->small_used + 63) & ~(size_t)63;
@@ -1040,26 +1057,86 @@ static void d2h_small(amd_ivf* h, void* dst, const void* src, size_t bytes, hipS
     }
     h->p_small.ensure(CAP);
     if (h->small.empty()) h->small_used = 0;
-    HIP_CHECK(hipMemcpyAsync(h->p_small.as<unsigned char>() + off, src, bytes, hipMemcpyDeviceToHost, s));
-    h->small.push_back({dst, off, bytes});
+    // (page-locked staging either way; with pinned_io the gathers of a whole batch are ONE kernel, launched by sync_and_flush)
+    const bool by_kernel = pinned_io(h) && bytes % 4 == 0;
+    if (!by_kernel) HIP_CHECK(hipMemcpyAsync(h->p_small.as<unsigned char>() + off, src, bytes, hipMemcpyDeviceToHost, s));
+    h->small.push_back({dst, off, bytes, by_kernel ? src : nullptr});
     h->small_used = off + bytes;
+}
+// the gathers recorded by d2h_small, on the stream their sources are produced on
+static void launch_small_gathers(amd_ivf* h, hipStream_t s) {
+    CopySegs c{};
+    unsigned char* base = nullptr;
+    for (auto& e : h->small) {
+        if (!e.src) continue;
+        if (!base) base = static_cast<unsigned char*>(h->p_small.dev());
+        c.src[c.n] = e.src;
+        c.dst[c.n] = base + e.off;
+        c.words[c.n] = (uint32_t)(e.bytes / 4);
+        e.src = nullptr;
+        if (++c.n == CopySegs::MAX) {
+            launch_copy_segs(c, s);
+            c.n = 0;
+        }
+    }
+    launch_copy_segs(c, s);
 }
 // after the stream the copies were queued on has been synchronised
 static void flush_small(amd_ivf* h) {
     for (const auto& c : h->small) memcpy(c.dst, h->p_small.as<unsigned char>() + c.off, c.bytes);
     h->small.clear();
     h->small_used = 0;
+    h->stage_used = 0;  // (the scatter kernels that read the host-to-device staging have run)
 }
 
 // a failed synchronisation must not leave copies pending: their destinations may be the caller's stack
 static void sync_and_flush(amd_ivf* h, hipStream_t s) {
-    const hipError_t e = stream_sync(s);
+    hipError_t e = hipSuccess;
+    try {
+        launch_small_gathers(h, s);
+    } catch (...) {
+        h->small.clear();
+        h->small_used = 0;
+        h->after_flush.clear();
+        throw;
+    }
+    e = stream_sync(s);
     if (e != hipSuccess) {
         h->small.clear();
         h->small_used = 0;
+        h->after_flush.clear();
         HIP_CHECK(e);
     }
     flush_small(h);
+    // epilogues that were waiting for this synchronisation (they may throw: the first one that does ends the call)
+    std::vector<std::function<void()>> fs;
+    fs.swap(h->after_flush);
+    for (auto& f : fs) f();
+}
+
+// Host-to-device counterpart of d2h_small: the bytes are packed into page-locked staging now and scattered to their device
+// destinations by one kernel (flush_h2d), instead of one blit per array.  The staging is reused once a synchronisation has
+// shown the scatter to be done (flush_small).
+static void flush_h2d(amd_ivf* h, hipStream_t s) {
+    launch_copy_segs(h->h2d_pending, s);
+    h->h2d_pending.n = 0;
+}
+static void h2d_small(amd_ivf* h, void* dst_dev, const void* src_host, size_t bytes, hipStream_t s) {
+    constexpr size_t LIMIT = (size_t)256 << 10, CAP = (size_t)2 << 20;
+    if (bytes == 0) return;
+    const size_t off = (h->stage_used + 63) & ~(size_t)63;
+    if (!pinned_io(h) || bytes % 4 != 0 || bytes > LIMIT || off + bytes > CAP) {
+        HIP_CHECK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, s));
+        return;
+    }
+    h->p_stage.ensure(CAP);
+    memcpy(h->p_stage.as<unsigned char>() + off, src_host, bytes);
+    CopySegs& c = h->h2d_pending;
+    c.src[c.n] = static_cast<unsigned char*>(h->p_stage.dev()) + off;
+    c.dst[c.n] = dst_dev;
+    c.words[c.n] = (uint32_t)(bytes / 4);
+    h->stage_used = off + bytes;
+    if (++c.n == CopySegs::MAX) flush_h2d(h, s);
 }
 
 // a query admitted more candidates than its admission log holds: the search is repeated with the heap kernels
@@ -1084,6 +1161,7 @@ struct SmallCopies {
     ~SmallCopies() {
         h->small.clear();
         h->small_used = 0;
+        h->after_flush.clear();
     }
 };
 
@@ -1148,24 +1226,40 @@ struct DirectOut {
 
 // Final read-back of a search: results, error word and counters behind one synchronisation.  An error is raised after the
 // copies (the reference throws in the middle of its loop and leaves partial output behind as well).
-void finish_results(amd_ivf* h, size_t n, size_t k, float* D, int64_t* I, uint32_t* stage_out = nullptr) {
-    uint32_t err = 0;
-    unsigned long long st[4];
-    SmallCopies guard(h);
-    d2h_small(h, &err, h->w_error.p, 4, h->stream);
-    d2h_small(h, st, h->w_stats.p, 32, h->stream);
-    if (stage_out) d2h_small(h, stage_out, h->w_stage.p, n * 4, h->stream);
-    if (!h->out_D) {  // (else the kernels wrote the caller's buffers themselves)
-        d2h_small(h, D, h->w_D.p, n * k * sizeof(float), h->stream);
-        d2h_small(h, I, h->w_I.p, n * k * sizeof(int64_t), h->stream);
+// defer: the caller has more to read back and synchronises (sync_and_flush) itself; error check and statistics then run behind
+// that synchronisation (amd_ivf::after_flush), and the caller guards the pending copies (SmallCopies).
+void finish_results(amd_ivf* h, size_t n, size_t k, float* D, int64_t* I, uint32_t* stage_out = nullptr, bool defer = false) {
+    struct Back {
+        uint32_t err = 0;
+        unsigned long long st[4] = {0, 0, 0, 0};
+    };
+    auto back = std::make_shared<Back>();
+    auto epilogue = [h, n, back]() {
+        throw_device_error(back->err);
+        if (n) ix(h)->tie_rate.store((float)((double)back->st[3] / (double)n));
+        h->stats_host[0] += n;
+        h->stats_host[1] += back->st[0];
+        h->stats_host[2] += back->st[1];
+        h->stats_host[3] += back->st[2];
+    };
+    auto queue = [&] {
+        d2h_small(h, &back->err, h->w_error.p, 4, h->stream);
+        d2h_small(h, back->st, h->w_stats.p, 32, h->stream);
+        if (stage_out) d2h_small(h, stage_out, h->w_stage.p, n * 4, h->stream);
+        if (!h->out_D) {  // (else the kernels wrote the caller's buffers themselves)
+            d2h_small(h, D, h->w_D.p, n * k * sizeof(float), h->stream);
+            d2h_small(h, I, h->w_I.p, n * k * sizeof(int64_t), h->stream);
+        }
+    };
+    if (defer) {
+        queue();
+        h->after_flush.push_back(epilogue);
+        return;
     }
+    SmallCopies guard(h);
+    queue();
     sync_and_flush(h, h->stream);
-    throw_device_error(err);
-    if (n) ix(h)->tie_rate.store((float)((double)st[3] / (double)n));
-    h->stats_host[0] += n;
-    h->stats_host[1] += st[0];
-    h->stats_host[2] += st[1];
-    h->stats_host[3] += st[2];
+    epilogue();
 }
 
 void finish_timing(amd_ivf* h, double wall_ms) {
@@ -1229,43 +1323,65 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
         const uint32_t qg = scan_shape_of((uint32_t)std::min<size_t>(m, scan_qblock(false)));
         const uint32_t tv = scan_tile_vecs(qg);
         const size_t nitems = ((m + qg * SCAN_RQ - 1) / (qg * SCAN_RQ)) * ((nlist + tv - 1) / tv);
-        h->p_pair_query.ensure(m * 4);
-        h->p_pair_out.ensure(m * 8);
-        h->p_items.ensure(nitems * sizeof(ScanItem));
-        uint32_t* pq = h->p_pair_query.as<uint32_t>();
-        uint64_t* po = h->p_pair_out.as<uint64_t>();
-        ScanItem* items = h->p_items.as<ScanItem>();
-        for (size_t i = 0; i < m; i++) {
-            pq[i] = (uint32_t)(c0 + i);
-            po[i] = (uint64_t)i * nlist;
-        }
-        size_t ni = 0;
-        for (uint32_t vb = 0; vb < nlist; vb += tv)
-            for (uint32_t qb = 0; qb < m; qb += qg * SCAN_RQ) {
-                ScanItem& it = items[ni++];
-                it.vec_base = vb;
-                it.nvec = std::min<uint32_t>(tv, (uint32_t)nlist - vb);
-                it.vec_off = vb;
-                it.pair_begin = qb;
-                it.npair = std::min<uint32_t>(qg * SCAN_RQ, (uint32_t)m - qb);
-                it.qg = qg;
-                it.qgroup = qb / SCAN_RQ;
+        // The work list of a chunk (every query of the chunk against the one "list" of centroids) depends on (c0, m, nlist)
+        // only: it lives in buffers of its own (the rounds' planning kernels write the w_* ones) and is uploaded when that
+        // signature changes -- a caller that searches batch after batch of one size pays for it once (it was five blits and,
+        // for the staging buffers' sake, a host synchronisation per call).
+        const uint64_t csig = ((uint64_t)c0 << 40) ^ ((uint64_t)m << 20) ^ (uint64_t)nlist ^ ((uint64_t)qg << 60);
+        const size_t ng = (m + SCAN_RQ - 1) / SCAN_RQ;
+        const bool cached = h->coarse_sig_valid && h->coarse_sig == csig;
+        if (!cached) {
+            h->p_pair_query.ensure(m * 4);
+            h->p_pair_out.ensure(m * 8);
+            h->p_items.ensure(nitems * sizeof(ScanItem));
+            h->p_group_p0.ensure(ng * 4);
+            h->p_group_cnt.ensure(ng * 4);
+            uint32_t* pq = h->p_pair_query.as<uint32_t>();
+            uint64_t* po = h->p_pair_out.as<uint64_t>();
+            ScanItem* items = h->p_items.as<ScanItem>();
+            for (size_t i = 0; i < m; i++) {
+                pq[i] = (uint32_t)(c0 + i);
+                po[i] = (uint64_t)i * nlist;
             }
+            size_t ni = 0;
+            for (uint32_t vb = 0; vb < nlist; vb += tv)
+                for (uint32_t qb = 0; qb < m; qb += qg * SCAN_RQ) {
+                    ScanItem& it = items[ni++];
+                    it.vec_base = vb;
+                    it.nvec = std::min<uint32_t>(tv, (uint32_t)nlist - vb);
+                    it.vec_off = vb;
+                    it.pair_begin = qb;
+                    it.npair = std::min<uint32_t>(qg * SCAN_RQ, (uint32_t)m - qb);
+                    it.qg = qg;
+                    it.qgroup = qb / SCAN_RQ;
+                }
+            for (size_t g = 0; g < ng; g++) {
+                h->p_group_p0.as<uint32_t>()[g] = (uint32_t)(g * SCAN_RQ);
+                h->p_group_cnt.as<uint32_t>()[g] = (uint32_t)std::min<size_t>(SCAN_RQ, m - g * SCAN_RQ);
+            }
+            h->c_pair_query.ensure(m * 4);
+            h->c_pair_out.ensure(m * 8);
+            h->c_items.ensure(nitems * sizeof(ScanItem));
+            h->c_group_p0.ensure(ng * 4);
+            h->c_group_cnt.ensure(ng * 4);
+            HIP_CHECK(hipMemcpyAsync(h->c_pair_query.p, pq, m * 4, hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipMemcpyAsync(h->c_pair_out.p, po, m * 8, hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipMemcpyAsync(h->c_items.p, items, nitems * sizeof(ScanItem), hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipMemcpyAsync(h->c_group_p0.p, h->p_group_p0.p, ng * 4, hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipMemcpyAsync(h->c_group_cnt.p, h->p_group_cnt.p, ng * 4, hipMemcpyHostToDevice, s));
+            h->coarse_sig_valid = false;  // (valid once the uploads are known to have left the staging buffers: below)
+        }
         h->w_dist.ensure(m * nlist * sizeof(float));
-        h->w_pair_query.ensure(m * 4);
-        h->w_pair_out.ensure(m * 8);
-        h->w_items.ensure(nitems * sizeof(ScanItem));
-        HIP_CHECK(hipMemcpyAsync(h->w_pair_query.p, pq, m * 4, hipMemcpyHostToDevice, s));
-        HIP_CHECK(hipMemcpyAsync(h->w_pair_out.p, po, m * 8, hipMemcpyHostToDevice, s));
-        HIP_CHECK(hipMemcpyAsync(h->w_items.p, items, nitems * sizeof(ScanItem), hipMemcpyHostToDevice, s));
-        pack_query_tiles(h, d_x, {{0u, (uint32_t)m}});
+        h->w_qtile.ensure(std::max<size_t>(ng, 1) * (size_t)h->dpad * SCAN_RQ * sizeof(float));
+        launch_pack_queries(d_x, h->c_pair_query.as<uint32_t>(), h->c_group_p0.as<uint32_t>(), h->c_group_cnt.as<uint32_t>(), ng, h->dpad,
+                            h->w_qtile.as<float>(), s);
         ScanArgs sa{};
         sa.qtile = h->w_qtile.as<float>();
         sa.codes = ix(h)->d_centroids.as<float>();
         sa.queries = d_x;
-        sa.items = h->w_items.as<ScanItem>();
-        sa.pair_query = h->w_pair_query.as<uint32_t>();
-        sa.pair_out = h->w_pair_out.as<uint64_t>();
+        sa.items = h->c_items.as<ScanItem>();
+        sa.pair_query = h->c_pair_query.as<uint32_t>();
+        sa.pair_out = h->c_pair_out.as<uint64_t>();
         sa.dist = h->w_dist.as<float>();
         sa.d = h->dpad;
         sa.metric = h->metric;
@@ -1351,7 +1467,15 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
             }
         }
         h->timer.end(t, s);
-        HIP_CHECK(stream_sync(s));
+        // (the staging buffers of this chunk are rewritten by the next chunk / call unless the work list is the cached one; the
+        // heap form also stages per call)
+        if (!cached || use_heap || c0 + m < n) {
+            HIP_CHECK(stream_sync(s));
+            if (!use_heap && c0 == 0 && m == n) {
+                h->coarse_sig = csig;
+                h->coarse_sig_valid = true;
+            }
+        }
     }
 }
 
@@ -1548,10 +1672,10 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     h->w_pl_gbase.ensure(nlist * 4);
     h->w_pl_ibase.ensure(4 * nlist * 4);
     h->w_pl_fill.ensure(nlist * 4);
-    h->w_pl_counters.ensure(96);  // 16 uint32 counters | double bytes | 2 x u64 slot bookkeeping
-    h->p_counters.ensure(96);
+    h->w_pl_counters.ensure(96 + PLAN_MAX_ROUNDS * 4);  // 16 uint32 counters | double bytes | 2 x u64 slot bookkeeping | per-round unfinished
+    h->p_counters.ensure(96 + PLAN_MAX_ROUNDS * 4);
     h->w_dist.ensure((budget + 4096) * sizeof(float));  // (+ the blocks the selection's stream requests past a region's end)
-    HIP_CHECK(hipMemsetAsync(h->w_pl_counters.p, 0, 96, s));
+    // (the counters need no memset: the first planning pass of the search zeroes what accumulates, PlanArgs::first_plan)
     // sorted-array selection: global positions must fit 32 bits; a query's admission log holds 32 k entries (k (1 + ln(N / k))
     // are expected: ~5 k for a million candidates), beyond which the call is repeated with the heap kernels
     const size_t log_cap = std::min<size_t>(4096, (std::max<size_t>(256, 32 * (size_t)base.k) + 63) & ~(size_t)63);
@@ -1623,6 +1747,8 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     pa.min_bytes = reinterpret_cast<double*>(h->w_pl_counters.as<uint32_t>() + 22);
     pa.row_bytes = base.bytes ? mfma_ksteps(h->d) * 32 : (uint32_t)h->dpad * 4;
     pa.error = h->w_error.as<uint32_t>();
+    uint32_t* const d_unfinished = h->w_pl_counters.as<uint32_t>() + 24;  // [PLAN_MAX_ROUNDS]
+    pa.round_unfinished = d_unfinished;
     if (base.d_budget_ms) {
         h->w_limit.ensure(n * 4);
         pa.budget_ms = base.d_budget_ms;
@@ -1667,6 +1793,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             pa.row_bytes = (uint32_t)h->dpad * 4;
         }
         pa.history = chained && planned_rounds >= 1 && planned_rounds <= MAX_HIST ? h->w_pl_hist.as<uint32_t>() + (planned_rounds - 1) * 16 : nullptr;
+        pa.first_plan = planned_rounds == 0;
         launch_plan(pa, s);
         planned_rounds++;
     };
@@ -1873,6 +2000,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         ra.train = base.train;
         ra.limit = base.d_budget_ms ? h->w_limit.as<uint32_t>() : nullptr;
         ra.qstat = h->w_qstat.as<uint2>();
+        ra.unfinished = round < PLAN_MAX_ROUNDS ? d_unfinished + round : nullptr;
         if (sorted_ok) {
             ra.log = h->w_log.as<uint2>();
             ra.log_cap = (uint32_t)log_cap;
@@ -1923,9 +2051,29 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         }
     };
     auto next_round_len = [&](size_t round_len) { return base.fixed_two ? total_nprobe : std::min<size_t>(round_len * 2, 64); };
+    // the planning counters (and, at the end, the per-round history) into their page-locked mirrors: one kernel, or blits
+    auto fetch_counters = [&](size_t nhist) {
+        if (pinned_io(h)) {
+            CopySegs c{};
+            c.src[0] = h->w_pl_counters.p;
+            c.dst[0] = h->p_counters.dev();
+            c.words[0] = 24 + PLAN_MAX_ROUNDS;
+            c.n = 1;
+            if (nhist) {
+                c.src[1] = h->w_pl_hist.p;
+                c.dst[1] = h->p_hist.dev();
+                c.words[1] = (uint32_t)(nhist * 16);
+                c.n = 2;
+            }
+            launch_copy_segs(c, s);
+        } else {
+            HIP_CHECK(hipMemcpyAsync(hc, h->w_pl_counters.p, 96 + PLAN_MAX_ROUNDS * 4, hipMemcpyDeviceToHost, s));
+            if (nhist) HIP_CHECK(hipMemcpyAsync(h->p_hist.p, h->w_pl_hist.p, nhist * 64, hipMemcpyDeviceToHost, s));
+        }
+    };
     auto plan_and_look = [&](size_t round_len) {
         plan_round(round_len);
-        HIP_CHECK(hipMemcpyAsync(hc, h->w_pl_counters.p, 96, hipMemcpyDeviceToHost, s));
+        fetch_counters(0);
         HIP_CHECK(stream_sync(s));
     };
     static const bool no_skip = getenv("AUNCEL_AMD_NO_LAST_PLAN_SKIP") != nullptr;
@@ -1951,11 +2099,24 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
                 round_len = next_round_len(round_len);
             }
             if (fixed_complete) break;
-            plan_and_look(round_len);
-            if (dbg_timing())
-                fprintf(stderr, "[rounds/chained] after round %zu: active %u pairs %u items %u may-continue %u MiB %u\n", round, hc[CNT_ACTIVE],
-                        hc[CNT_PAIRS], hc[CNT_QG1] + hc[CNT_QG2] + hc[CNT_QG4] + hc[CNT_QG8], hc[10], hc[7]);
-            if (hc[CNT_ACTIVE] == 0) break;
+            // Is anything left?  The selection of the last round counted the queries it left unfinished, the planning of that
+            // round the ones it deferred: one look at those two numbers, and a search that has ended (the common case after
+            // two rounds) needs no further planning pass -- round 3 planned the next round first and looked at its count.
+            static const bool plan_look = getenv("AUNCEL_AMD_PLAN_LOOK") != nullptr;
+            if (!plan_look && round >= 1 && round - 1 < PLAN_MAX_ROUNDS) {
+                fetch_counters(0);
+                HIP_CHECK(stream_sync(s));
+                const uint32_t left = hc[24 + round - 1] + hc[11];
+                if (dbg_timing()) fprintf(stderr, "[rounds/chained] after round %zu: unfinished %u deferred %u\n", round, hc[24 + round - 1], hc[11]);
+                if (left == 0) break;
+                plan_round(round_len);
+            } else {
+                plan_and_look(round_len);
+                if (dbg_timing())
+                    fprintf(stderr, "[rounds/chained] after round %zu: active %u pairs %u items %u may-continue %u MiB %u\n", round, hc[CNT_ACTIVE],
+                            hc[CNT_PAIRS], hc[CNT_QG1] + hc[CNT_QG2] + hc[CNT_QG4] + hc[CNT_QG8], hc[10], hc[7]);
+                if (hc[CNT_ACTIVE] == 0) break;
+            }
             planned = true;
             batch = ahead_env ? ahead_env : 2;
         }
@@ -2045,28 +2206,37 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         h->timer.end(t, s);
     }
     if (!base.caller_checks_error) check_device_error(h);
-    if (chained) {  // the bookkeeping counters of the last round (bytes, slots) have not been read yet; nor has the history
-        const size_t nh = std::min(planned_rounds ? planned_rounds - 1 : 0, MAX_HIST);
-        HIP_CHECK(hipMemcpyAsync(hc, h->w_pl_counters.p, 96, hipMemcpyDeviceToHost, s));
-        if (nh) HIP_CHECK(hipMemcpyAsync(h->p_hist.p, h->w_pl_hist.p, nh * 64, hipMemcpyDeviceToHost, s));
-        HIP_CHECK(stream_sync(s));
-        h->round_hint.assign(h->p_hist.as<uint32_t>(), h->p_hist.as<uint32_t>() + nh * 16);
-        h->round_hint.insert(h->round_hint.end(), hc, hc + 16);  // the last planned round
-        // a scan grid is its hint + 12 %; a round that needed more still covers its items (the workgroups stride over the
-        // device-side count), only with fewer workgroups than it would have been given
-        for (size_t r = 0; (r + 1) * 16 <= hints_used.size() && (r + 1) * 16 <= h->round_hint.size(); r++)
-            for (int c : {CNT_QG1, CNT_QG2, CNT_QG4, CNT_QG8}) {
-                const uint32_t used = hints_used[r * 16 + c], need = h->round_hint[r * 16 + c];
-                if (!used) continue;
-                h->hinted_rounds++;
-                if (need > used + used / 8 + 8) h->short_rounds++;
-            }
+    // The bookkeeping counters of the last round (bytes, slots) have not been read yet; nor has the history.  What is done with
+    // them needs a synchronisation: the caller's, when it is about to read its results back anyway (caller_checks_error: the
+    // epilogue below then runs behind that one, sync_and_flush), else one of our own.
+    const size_t nh = chained ? std::min(planned_rounds ? planned_rounds - 1 : 0, MAX_HIST) : 0;
+    if (chained) fetch_counters(nh);
+    auto epilogue = [h, hc, nh, chained, hints_used]() {
+        if (chained) {
+            h->round_hint.assign(h->p_hist.as<uint32_t>(), h->p_hist.as<uint32_t>() + nh * 16);
+            h->round_hint.insert(h->round_hint.end(), hc, hc + 16);  // the last planned round
+            // a scan grid is its hint + 12 %; a round that needed more still covers its items (the workgroups stride over the
+            // device-side count), only with fewer workgroups than it would have been given
+            for (size_t r = 0; (r + 1) * 16 <= hints_used.size() && (r + 1) * 16 <= h->round_hint.size(); r++)
+                for (int c : {CNT_QG1, CNT_QG2, CNT_QG4, CNT_QG8}) {
+                    const uint32_t used = hints_used[r * 16 + c], need = h->round_hint[r * 16 + c];
+                    if (!used) continue;
+                    h->hinted_rounds++;
+                    if (need > used + used / 8 + 8) h->short_rounds++;
+                }
+        }
+        h->scan_bytes += *reinterpret_cast<double*>(hc + 16);
+        h->scan_min_bytes += *reinterpret_cast<double*>(hc + 22);
+        const unsigned long long* acc = reinterpret_cast<const unsigned long long*>(hc + 18);
+        h->scan_slots += (double)acc[0];
+        h->scan_useful += (double)acc[1];
+    };
+    if (chained && base.caller_checks_error) {
+        h->after_flush.push_back(epilogue);
+    } else {
+        if (chained) HIP_CHECK(stream_sync(s));
+        epilogue();
     }
-    h->scan_bytes += *reinterpret_cast<double*>(hc + 16);
-    h->scan_min_bytes += *reinterpret_cast<double*>(hc + 22);
-    const unsigned long long* acc = reinterpret_cast<const unsigned long long*>(hc + 18);
-    h->scan_slots += (double)acc[0];
-    h->scan_useful += (double)acc[1];
 }
 
 // multi-round driver shared by the adaptive search and the trace training (host-side planning: kept for reference /
@@ -2855,7 +3025,7 @@ static size_t coarse_or_given(amd_ivf_t* L, const float* d_x, size_t n, int coar
 
 static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n, size_t query_topk, float multipler, float std_m,
                            const float* dreq, const float* dgt, unsigned long long* dnp, float* dtr, int profile, int coarse_mode,
-                           float* D, int64_t* I, const IntRange& qr, size_t coarse_prefix) {
+                           float* D, int64_t* I, const IntRange& qr, size_t coarse_prefix, bool defer_finish) {
     use_device(L);
     const size_t K = ix(L)->tuner_max_topk, nlist = L->nlist;
     // full coarse ranking (Error_sys::search sets nprobe = nlist, profile.cpp:220), or the caller's
@@ -2931,7 +3101,7 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
     base.caller_checks_error = true;
     DirectOut direct(L, D, I);
     run_rounds_device(L, base, n, first_env, np_row, dnp);
-    finish_results(L, n, K, D, I);
+    finish_results(L, n, K, D, I, nullptr, defer_finish);
 }
 
 static size_t lane_count(size_t n) {
@@ -2967,10 +3137,11 @@ static void adaptive_core_once(amd_ivf_t* h, const float* d_x, size_t start, siz
     float* dgt = gt_D ? dtr + nabs : nullptr;
     d_np.ensure(nabs * 8);
     // only the entries of this call's queries are read or written on the device (everything is indexed by absolute id)
-    HIP_CHECK(hipMemcpyAsync(dreq + start, require_acc + start, n * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_CHECK(hipMemcpyAsync(dtr + start, t_recalls + start, n * 4, hipMemcpyHostToDevice, h->stream));
+    h2d_small(h, dreq + start, require_acc + start, n * 4, h->stream);
+    h2d_small(h, dtr + start, t_recalls + start, n * 4, h->stream);
     if (gt_D) HIP_CHECK(hipMemcpyAsync(dgt + start * K, gt_D + start * K, n * K * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_CHECK(hipMemcpyAsync(d_np.as<unsigned long long>() + start, my_nprobe + start, n * 8, hipMemcpyHostToDevice, h->stream));
+    h2d_small(h, d_np.as<unsigned long long>() + start, my_nprobe + start, n * 8, h->stream);
+    flush_h2d(h, h->stream);
 
     // How much of the coarse ranking can be consumed: set_online reads entries 0 .. nlist/8+20, and the probe loop ends at
     // my_nprobe <= floor((nlist/8) * multipler) (IndexIVF.cpp:615-632) or at a value the caller passed in.  When that is
@@ -3011,12 +3182,14 @@ static void adaptive_core_once(amd_ivf_t* h, const float* d_x, size_t start, siz
     auto run = [&](size_t i) {
         const size_t q0 = n * i / nl, q1 = n * (i + 1) / nl;
         try {
+            // (one lane: the slice's read-back joins this function's own, one synchronisation ends the call)
             adaptive_slice(lanes[i], d_x + q0 * h->dpad, start + q0, q1 - q0, query_topk, multipler, std_m, dreq, dgt,
-                           d_np.as<unsigned long long>(), dtr, profile, coarse_mode, D + q0 * K, I + q0 * K, qr, coarse_prefix);
+                           d_np.as<unsigned long long>(), dtr, profile, coarse_mode, D + q0 * K, I + q0 * K, qr, coarse_prefix, nl == 1);
         } catch (...) {
             errs[i] = std::current_exception();
         }
     };
+    SmallCopies pending(h);  // (whatever is still queued when this scope is left by an exception names memory of this call)
     std::vector<std::thread> th;
     for (size_t i = 1; i < nl; i++) th.emplace_back(run, i);
     run(0);

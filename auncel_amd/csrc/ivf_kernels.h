@@ -279,6 +279,9 @@ struct ReplayArgs {
     uint32_t nq_total;
     uint32_t* fin_round;       // [slot] the round in which the query got its final state (0xffffffff: not yet)
     uint2* qstat;              // [slot] (lists scanned, heap updates) of this query so far (null: not kept)
+    uint32_t* unfinished;      // null or a counter: += 1 for every query of this launch that goes on to another round (with the
+                               // queries the planning deferred, PlanArgs counters[11], what is left after the round: the host
+                               // needs no further planning pass to learn that a search has ended)
 };
 
 bool replay_sorted_applies(const ReplayArgs& a);
@@ -394,9 +397,12 @@ struct PlanArgs {
     uint32_t* error;                 // device error word (ERR_ITEM_OVERFLOW: the round needs more tiles than item_cap)
     unsigned long long* acc64;       // [0] += (query, vector) slots computed, [1] += pairs wanted (tile bookkeeping)
     uint32_t* history;               // null or 16 uint32: receives the counters as the previous round's planning left them
+    int first_plan;                  // first planning pass of a search: the accumulators below and round_unfinished start from zero
+    uint32_t* round_unfinished;      // null or [PLAN_MAX_ROUNDS]: per round, queries its selection left unfinished (ReplayArgs::unfinished)
     uint32_t* counters;              // [0] active queries [1] segments [2] pairs [3] groups [4] tiles qg1 [5] tiles qg2
                                      // [6] scratch (compaction cursor, zeroed by host) [7] MiB of distances [8] tiles qg4 [9] tiles qg8
-                                     // [10] queries that may still be unfinished after this round (zeroed by host)
+                                     // [10] queries that may still be unfinished after this round, [11] of those: deferred by the
+                                     //      budget cut
     double* bytes;                   // [0] += algorithmic bytes of the round's distances
     // [0] += bytes the round cannot avoid moving through HBM: every probed list once (row_bytes per stored vector) and the
     // rows it writes (4 bytes per distance of a dense round, one mask bit per distance in threshold mode)
@@ -405,6 +411,7 @@ struct PlanArgs {
     int dense_round;
 };
 
+constexpr uint32_t PLAN_MAX_ROUNDS = 64;
 void launch_plan(const PlanArgs& a, hipStream_t s);
 
 constexpr uint32_t ERR_ARCOS_DOMAIN = 1;
@@ -458,6 +465,19 @@ void launch_kmeans_group(const int64_t* assign, size_t n, uint32_t k, uint32_t* 
                          uint32_t* idx_out, uint32_t* counts, void* temp, size_t temp_bytes, hipStream_t s);
 void launch_kmeans_sums(const float* x, size_t stride, int d, const uint32_t* idx_sorted, const uint32_t* seg_off, uint32_t k, float* centroids,
                         hipStream_t s);
+
+// Up to MAX small copies in ONE launch (one workgroup row per segment; sizes in 4-byte words).  A search starts and ends with a
+// dozen copies of a few bytes to a few tens of KB (per-call inputs, error word, counters, my_nprobe, t_recalls ...): as
+// hipMemcpyAsync each of them is a blit kernel of its own on the stream (18 % of the four-in-flight span in round 3's trace);
+// through page-locked staging they are one kernel before the first round and one behind the last.
+struct CopySegs {
+    static constexpr int MAX = 12;
+    const void* src[MAX];
+    void* dst[MAX];
+    uint32_t words[MAX];
+    uint32_t n;
+};
+void launch_copy_segs(const CopySegs& c, hipStream_t s);
 
 // fill helpers
 struct InitStateArgs {

@@ -1601,6 +1601,20 @@ __global__ __launch_bounds__(256) void init_state_kernel(InitStateArgs a) {
     if (blockIdx.x == 0 && threadIdx.x == 4) *a.error = 0;
 }
 
+__global__ __launch_bounds__(256) void copy_segs_kernel(CopySegs c) {
+    const uint32_t seg = blockIdx.y;
+    const uint32_t* src = static_cast<const uint32_t*>(c.src[seg]);
+    uint32_t* dst = static_cast<uint32_t*>(c.dst[seg]);
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < c.words[seg]; i += gridDim.x * 256) dst[i] = src[i];
+}
+void launch_copy_segs(const CopySegs& c, hipStream_t s) {
+    if (c.n == 0) return;
+    uint32_t mx = 0;
+    for (uint32_t i = 0; i < c.n; i++) mx = c.words[i] > mx ? c.words[i] : mx;
+    const unsigned gx = mx <= 256 ? 1u : mx <= 4096 ? 4u : 16u;
+    LAUNCH(copy_segs_kernel, dim3(gx, c.n), dim3(256), 0, s, c);
+}
+
 void launch_init_state(const InitStateArgs& a, hipStream_t s) {
     const size_t work = std::max<size_t>(a.n * a.k, 1);
     const unsigned grid = (unsigned)std::min<size_t>((work + 255) / 256, 4096);

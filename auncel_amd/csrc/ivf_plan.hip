@@ -14,15 +14,19 @@ namespace amdivf {
 __global__ __launch_bounds__(256) void plan_counts_kernel(PlanArgs a) {
     // the per-list pair histogram of the round starts from zero (plan_segments_kernel, next on the stream, fills it)
     for (uint32_t l = blockIdx.x * 256 + threadIdx.x; l < a.nlist; l += gridDim.x * 256) a.lcount[l] = 0;
+    // (what used to be a launch of its own: nothing in this kernel writes the counters, the next one -- one block -- does)
+    if (blockIdx.x == 0 && threadIdx.x < 16 && a.history) a.history[threadIdx.x] = a.counters[threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.first_plan) {  // the accumulators of a search (bytes, tile slots) and its per-round marks
+        a.bytes[0] = 0.0;
+        a.acc64[0] = a.acc64[1] = 0ull;
+        if (a.min_bytes) a.min_bytes[0] = 0.0;
+    }
+    if (blockIdx.x == 0 && a.first_plan && a.round_unfinished)
+        for (uint32_t r = threadIdx.x; r < PLAN_MAX_ROUNDS; r += 256) a.round_unfinished[r] = 0;
     const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
-    // queries that may need another round are counted per workgroup first: one atomic per query on the one counter
-    // serialises thousands of waves in the L2
-    __shared__ uint32_t s_more;
-    if (threadIdx.x == 0) s_more = 0;
-    __syncthreads();
     const bool have = i < a.nq;
-    uint32_t cnt = 0, pad = 0;
+    uint32_t cnt = 0, pad = 0, more = 0;
     unsigned long long need = 0;
     const unsigned long long ra = a.row_align - 1;
     if (have && !a.done[i]) {
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(256) void plan_counts_kernel(PlanArgs a) {
         cnt = (uint32_t)(target - stage);
         // queries this round cannot be the last one for: the host skips the next planning pass when there are none
         const bool ends = target >= a.total_nprobe || last || (a.tune && np != 0);
-        if (!ends && lane == 0) atomicAdd(&s_more, 1u);
+        more = ends ? 0u : 1u;
         const int64_t* kq = a.keys + (size_t)i * a.key_stride + stage;
         for (uint32_t p = lane; p < cnt; p += 64) {
             const int64_t key = kq[p];
@@ -80,10 +84,8 @@ __global__ __launch_bounds__(256) void plan_counts_kernel(PlanArgs a) {
     if (have && lane == 0) {
         a.cnt[i] = cnt;
         a.need[i] = need;
-        a.pad[i] = pad;
+        a.pad[i] = pad | (more << 31);  // (top bit: this round cannot be the query's last; plan_prefix_kernel counts and clears it)
     }
-    __syncthreads();
-    if (threadIdx.x == 0 && s_more) atomicAdd(&a.counters[10], s_more);
 }
 
 // exclusive prefix sum of one value per thread over a block of 1024 threads (16 waves): shuffles inside the waves, one LDS
@@ -150,34 +152,45 @@ __global__ __launch_bounds__(1024) void plan_prefix_kernel(PlanArgs a) {
     }
     __syncthreads();
     // queries at or after the cut are deferred; everything before keeps its prefix values
-    uint32_t nact = 0, nseg = 0;
+    uint32_t nact = 0, nseg = 0, nmore = 0, ndef = 0;
     unsigned long long ndist = 0;
-    __shared__ uint32_t s_nact, s_nseg;
+    __shared__ uint32_t s_nact, s_nseg, s_more, s_def;
     __shared__ unsigned long long s_ndist;
     if (t == 0) {
         s_nact = 0;
         s_nseg = 0;
+        s_more = 0;
+        s_def = 0;
         s_ndist = 0;
     }
     __syncthreads();
     for (uint32_t i = t; i < a.nq; i += 1024) {
-        if (i >= cut && a.cnt[i]) {
-            a.cnt[i] = 0;
-            atomicAdd(&a.counters[10], 1u);  // deferred to the next round
+        uint32_t c = a.cnt[i];
+        const uint32_t pm = a.pad[i], pad = pm & 0x7fffffffu;
+        if (pm >> 31) a.pad[i] = pad;
+        if (i >= cut && c) {
+            a.cnt[i] = c = 0;
+            ndef++;  // deferred to the next round
         }
-        if (a.cnt[i]) {
+        if (c) {
             nact++;
-            nseg += a.cnt[i];
-            ndist += a.need[i] - a.pad[i];
+            nseg += c;
+            ndist += a.need[i] - pad;
+            nmore += pm >> 31;
         }
     }
     atomicAdd(&s_nact, nact);
     atomicAdd(&s_nseg, nseg);
+    atomicAdd(&s_more, nmore);
+    atomicAdd(&s_def, ndef);
     atomicAdd(&s_ndist, ndist);
     __syncthreads();
     if (t == 0) {
         a.counters[0] = s_nact;
         a.counters[1] = s_nseg;
+        a.counters[6] = 0;                   // compaction cursor of plan_segments_kernel
+        a.counters[10] = s_more + s_def;     // queries that may still be unfinished after this round
+        a.counters[11] = s_def;              // of those: deferred by the budget cut (the selection of this round does not see them)
         a.counters[7] = (uint32_t)(s_ndist >> 20);  // MiB of distances, for bookkeeping
         a.bytes[0] += (double)s_ndist * (double)a.d * 4.0;
         if (a.min_bytes) a.min_bytes[0] += a.dense_round ? (double)s_ndist * 4.0 : (double)s_ndist / 8.0;
@@ -308,8 +321,8 @@ __global__ __launch_bounds__(1024) void plan_lists_kernel(PlanArgs a) {
 }
 
 // ---- 5. pairs into their list's range (one wave per query)
-__global__ __launch_bounds__(256) void plan_scatter_kernel(PlanArgs a) {
-    const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+__device__ __forceinline__ void plan_scatter_block(const PlanArgs& a, uint32_t block) {
+    const uint32_t i = block * 4 + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
     if (i >= a.nq) return;
     const uint32_t c = a.cnt[i];
@@ -382,8 +395,14 @@ __device__ inline void items_of_list(const PlanArgs& a, uint32_t l, uint32_t c, 
 }
 
 
-__global__ __launch_bounds__(256) void plan_items_kernel(PlanArgs a) {
-    const uint32_t l = blockIdx.x * 256 + threadIdx.x;
+// ---- 5 + 6 in one launch (both read what plan_lists_kernel left, neither reads the other's output): the first gq workgroups
+//      scatter the pairs of four queries each, the rest make the items of 256 lists each
+__global__ __launch_bounds__(256) void plan_scatter_items_kernel(PlanArgs a, uint32_t gq) {
+    if (blockIdx.x < gq) {
+        plan_scatter_block(a, blockIdx.x);
+        return;
+    }
+    const uint32_t l = (blockIdx.x - gq) * 256 + threadIdx.x;
     const uint32_t c = l < a.nlist ? a.lcount[l] : 0u;
     unsigned long long slots = 0, useful = 0;
     if (c) items_of_list(a, l, c, slots, useful);
@@ -398,24 +417,15 @@ __global__ __launch_bounds__(256) void plan_items_kernel(PlanArgs a) {
     }
 }
 
-// counters a round accumulates into with atomics
-__global__ void plan_reset_kernel(uint32_t* counters, uint32_t* history) {
-    if (history)
-        for (int i = 0; i < 16; i++) history[i] = counters[i];
-    counters[6] = 0;
-    counters[10] = 0;
-}
-
+// five launches a round (round 3: seven -- a reset kernel of one thread, and scatter / items apart)
 void launch_plan(const PlanArgs& a, hipStream_t s) {
     if (a.nq == 0) return;
-    LAUNCH(plan_reset_kernel, dim3(1), dim3(1), 0, s, a.counters, a.history);
     const unsigned gq = (a.nq + 3) / 4 /* one wave per query */, gl = (a.nlist + 255) / 256;
     LAUNCH(plan_counts_kernel, dim3(gq), dim3(256), 0, s, a);
     LAUNCH(plan_prefix_kernel, dim3(1), dim3(1024), 0, s, a);
     LAUNCH(plan_segments_kernel, dim3(gq), dim3(256), 0, s, a);
     LAUNCH(plan_lists_kernel, dim3(1), dim3(1024), 0, s, a);
-    LAUNCH(plan_scatter_kernel, dim3(gq), dim3(256), 0, s, a);
-    LAUNCH(plan_items_kernel, dim3(gl), dim3(256), 0, s, a);
+    LAUNCH(plan_scatter_items_kernel, dim3(gq + gl), dim3(256), 0, s, a, (uint32_t)gq);
 }
 
 }  // namespace amdivf

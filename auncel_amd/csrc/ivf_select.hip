@@ -1000,6 +1000,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
             a.heap_val[(size_t)qi * k + i] = hval[i];
             a.heap_ref[(size_t)qi * k + i] = href[i];
         }
+        if (lane == 0 && a.unfinished) atomicAdd(a.unfinished, 1u);
     }
 }
 
@@ -1547,7 +1548,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 
             a.heap_val[(size_t)qi * k + lane + 64] = okey_inv<IsMax>(sr.k1);
             a.heap_ref[(size_t)qi * k + lane + 64] = sr.g1 == SPOS_NONE ? -1 : (int64_t)sr.g1;
         }
-        if (lane == 0) a.amb[qi] = amb;
+        if (lane == 0) {
+            a.amb[qi] = amb;
+            if (a.unfinished) atomicAdd(a.unfinished, 1u);
+        }
     }
 }
 
