@@ -24,7 +24,7 @@ SYMBOLS = [
     "amd_ivf_set_tuner", "amd_ivf_search_adaptive", "amd_ivf_search_adaptive_x", "amd_ivf_search_adaptive_pre", "amd_ivf_search_timed", "amd_ivf_search_timed_x",
     "amd_ivf_train_samples",
     "amd_ivf_train_samples_x", "amd_ivf_train_samples_pre", "amd_ivf_trace_sb", "amd_ivf_arcos_table", "amd_ivf_merge_tables",
-    "amd_ivf_last_timing", "amd_ivf_last_scan_min_bytes", "amd_ivf_coarse_tie_rows", "amd_ivf_last_tie_fixed", "amd_ivf_last_filter", "amd_ivf_last_direct_out", "amd_ivf_set_async_depth", "amd_ivf_submit_adaptive", "amd_ivf_submit_search_resident", "amd_ivf_wait", "amd_ivf_last_tie_redone", "amd_ivf_last_round_hints", "amd_ivf_set_byte_codes", "amd_ivf_set_option", "amd_ivf_get_option",
+    "amd_ivf_last_timing", "amd_ivf_last_timing_detail", "amd_ivf_last_scan_min_bytes", "amd_ivf_coarse_tie_rows", "amd_ivf_last_tie_fixed", "amd_ivf_last_filter", "amd_ivf_last_direct_out", "amd_ivf_set_async_depth", "amd_ivf_submit_adaptive", "amd_ivf_submit_search_resident", "amd_ivf_wait", "amd_ivf_last_tie_redone", "amd_ivf_last_round_hints", "amd_ivf_set_byte_codes", "amd_ivf_set_option", "amd_ivf_get_option",
     "amd_ivf_kmeans",
     "amd_ivf_range_search_preassigned", "amd_ivf_range_search", "amd_ivf_range_results",
     "amd_ivf_scan_arith",
@@ -479,6 +479,16 @@ class Handle:
         lib().amd_ivf_last_scan_min_bytes(self._h, C.byref(mb))
         return dict(coarse_ms=t[0], scan_ms=t[1], select_ms=t[2], total_ms=t[3], scan_launches=t[4], scan_bytes=t[5],
                     slot_efficiency=t[6], rounds=t[7], scan_min_bytes=mb.value)
+
+    PHASES = ("coarse", "scan_dense", "select_dense", "scan_thr", "select_thr", "tie_fix", "plan")
+
+    def last_timing_detail(self):
+        """{phase: (ms, launches)} of the last search on this handle (include/auncel_amd.h: amd_ivf_last_timing_detail)"""
+        t = (C.c_double * 16)()
+        lib().amd_ivf_last_timing_detail(self._h, t)
+        d = {p: (t[2 * i], t[2 * i + 1]) for i, p in enumerate(self.PHASES)}
+        d["min_bytes_dense"], d["min_bytes_thr"] = t[14], t[15]
+        return d
 
     def coarse_tie_rows(self):
         """coarse rankings re-run through the reference's heap so far (runs of equal distances, include/auncel_amd.h)"""

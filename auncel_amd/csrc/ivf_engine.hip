@@ -247,7 +247,9 @@ struct EventTimer {
     }
 };
 
-enum { CAT_COARSE = 0, CAT_SCAN = 1, CAT_SELECT = 2, NCAT = 3 };
+// phases timed by HIP events on the streams they run on (amd_ivf_last_timing: coarse, scan = dense + threshold rounds,
+// select = both selections + tie_fix_kernel; amd_ivf_last_timing_detail: every phase by itself)
+enum { CAT_COARSE = 0, CAT_SCAN = 1, CAT_SELECT = 2, CAT_SCAN_THR = 3, CAT_SELECT_THR = 4, CAT_TIE_FIX = 5, CAT_PLAN = 6, NCAT = 7 };
 
 }  // namespace
 
@@ -384,8 +386,9 @@ struct amd_ivf {
     size_t dist_budget_floats = (size_t)768 << 20;  // 3 GiB of distances per scan launch
     size_t stats_host[4] = {0, 0, 0, 0};
     double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double timing_detail[2 * 7 + 2] = {0};  // (ms, launches) per phase of the last search (CAT_*) | min bytes of dense / threshold rounds
     double last_min_bytes = 0;
-    double scan_bytes = 0, scan_slots = 0, scan_useful = 0, scan_min_bytes = 0;
+    double scan_bytes = 0, scan_slots = 0, scan_useful = 0, scan_min_bytes = 0, scan_min_bytes_thr = 0;
     EventTimer timer;
 
     // Query lanes: a large adaptive batch is cut into slices that run their rounds concurrently, each on
@@ -1262,18 +1265,24 @@ void finish_results(amd_ivf* h, size_t n, size_t k, float* D, int64_t* I, uint32
     epilogue();
 }
 
+static void fill_timing(amd_ivf* h, const double* ms, const double* ln) {
+    h->timing[0] = ms[CAT_COARSE];
+    h->timing[1] = ms[CAT_SCAN] + ms[CAT_SCAN_THR];
+    h->timing[2] = ms[CAT_SELECT] + ms[CAT_SELECT_THR] + ms[CAT_TIE_FIX];
+    h->timing[4] = ln[CAT_SCAN] + ln[CAT_SCAN_THR];
+    h->timing[7] = ln[CAT_SELECT] + ln[CAT_SELECT_THR] + ln[CAT_TIE_FIX];
+    for (int c = 0; c < NCAT; c++) h->timing_detail[2 * c] = ms[c], h->timing_detail[2 * c + 1] = ln[c];
+    h->timing_detail[2 * NCAT] = h->scan_min_bytes - h->scan_min_bytes_thr;
+    h->timing_detail[2 * NCAT + 1] = h->scan_min_bytes_thr;
+}
 void finish_timing(amd_ivf* h, double wall_ms) {
     double ms[NCAT], ln[NCAT];
     h->timer.collect(ms, NCAT, ln);
-    h->timing[0] = ms[CAT_COARSE];
-    h->timing[1] = ms[CAT_SCAN];
-    h->timing[2] = ms[CAT_SELECT];
+    fill_timing(h, ms, ln);
     h->timing[3] = wall_ms;
-    h->timing[4] = ln[CAT_SCAN];
     h->timing[5] = h->scan_bytes;
     h->last_min_bytes = h->scan_min_bytes;
     h->timing[6] = h->scan_slots > 0 ? h->scan_useful / h->scan_slots : 0;
-    h->timing[7] = ln[CAT_SELECT];
 }
 
 struct WallClock {
@@ -1672,8 +1681,10 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     h->w_pl_gbase.ensure(nlist * 4);
     h->w_pl_ibase.ensure(4 * nlist * 4);
     h->w_pl_fill.ensure(nlist * 4);
-    h->w_pl_counters.ensure(96 + PLAN_MAX_ROUNDS * 4);  // 16 uint32 counters | double bytes | 2 x u64 slot bookkeeping | per-round unfinished
-    h->p_counters.ensure(96 + PLAN_MAX_ROUNDS * 4);
+    // 16 uint32 counters | double bytes | 2 x u64 slot bookkeeping | double min_bytes | per-round unfinished | double min_bytes of threshold rounds
+    constexpr size_t CNT_WORDS = 24 + PLAN_MAX_ROUNDS + 2;
+    h->w_pl_counters.ensure(CNT_WORDS * 4);
+    h->p_counters.ensure(CNT_WORDS * 4);
     h->w_dist.ensure((budget + 4096) * sizeof(float));  // (+ the blocks the selection's stream requests past a region's end)
     // (the counters need no memset: the first planning pass of the search zeroes what accumulates, PlanArgs::first_plan)
     // sorted-array selection: global positions must fit 32 bits; a query's admission log holds 32 k entries (k (1 + ln(N / k))
@@ -1713,6 +1724,8 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     pa.row_align = sorted_ok ? 1024 : 64;  // (select_sorted_kernel reads dense rows in groups of four blocks of 256 candidates)
     pa.qblock = scan_qblock(base.bytes);
     pa.mfma_qblock = MFMA_QBLOCK;
+    static const int item_order_env = getenv("AUNCEL_AMD_ITEM_ORDER") ? atoi(getenv("AUNCEL_AMD_ITEM_ORDER")) : 0;
+    pa.item_order = item_order_env;
     if (base.bytes) {
         pa.mfma_chunk = mfma_chunk();
         pa.block_off = I->d_block_off.as<uint64_t>();
@@ -1745,6 +1758,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     pa.bytes = reinterpret_cast<double*>(h->w_pl_counters.as<uint32_t>() + 16);
     pa.acc64 = reinterpret_cast<unsigned long long*>(h->w_pl_counters.as<uint32_t>() + 18);
     pa.min_bytes = reinterpret_cast<double*>(h->w_pl_counters.as<uint32_t>() + 22);
+    pa.min_bytes_thr = reinterpret_cast<double*>(h->w_pl_counters.as<uint32_t>() + 24 + PLAN_MAX_ROUNDS);
     pa.row_bytes = base.bytes ? mfma_ksteps(h->d) * 32 : (uint32_t)h->dpad * 4;
     pa.error = h->w_error.as<uint32_t>();
     uint32_t* const d_unfinished = h->w_pl_counters.as<uint32_t>() + 24;  // [PLAN_MAX_ROUNDS]
@@ -1794,7 +1808,9 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         }
         pa.history = chained && planned_rounds >= 1 && planned_rounds <= MAX_HIST ? h->w_pl_hist.as<uint32_t>() + (planned_rounds - 1) * 16 : nullptr;
         pa.first_plan = planned_rounds == 0;
+        size_t t = h->timer.begin(CAT_PLAN, s);
         launch_plan(pa, s);
+        h->timer.end(t, s);
         planned_rounds++;
     };
     static const bool xcd_off = getenv("AUNCEL_AMD_NO_XCD_CHUNKS") != nullptr;
@@ -1803,7 +1819,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     // ---- the scan of a planned round.  counts == nullptr: sizes on the device (chained); else the counters read back.
     auto enqueue_scan = [&](bool thr_mode, const uint32_t* counts, size_t round) {
         if (counts && counts[CNT_PAIRS] == 0) return;
-        size_t t = h->timer.begin(CAT_SCAN, s);
+        size_t t = h->timer.begin(thr_mode ? CAT_SCAN_THR : CAT_SCAN, s);
         if (base.bytes) {
             // byte codes: one launch of scan_mfma_kernel (no query packing: the A operand is gathered from the query matrix)
             MfmaScanArgs ma{};
@@ -1822,6 +1838,8 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             ma.dev_nitems = counts ? nullptr : dcnt + CNT_QG8;
             ma.hint_nitems = hint_of(round, CNT_QG8);
             ma.pipelined = (int)opt(h, OPT_SCAN_PIPELINED, 3);
+            static const int scan_debug = getenv("AUNCEL_AMD_SCAN_DEBUG") ? atoi(getenv("AUNCEL_AMD_SCAN_DEBUG")) : 0;
+            ma.debug = scan_debug;
             if (thr_mode) {
                 ma.thr = h->w_thr.as<float>();
                 ma.mask = h->w_mask.as<unsigned long long>();
@@ -2022,7 +2040,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             ra.dbg = h->w_misc.as<unsigned long long>();
         }
         {
-            size_t t = h->timer.begin(CAT_SELECT, s);
+            size_t t = h->timer.begin(thr_mode ? CAT_SELECT_THR : CAT_SELECT, s);
             launch_replay(ra, s);
             h->timer.end(t, s);
         }
@@ -2038,7 +2056,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             TieFixArgs ta = tie_fix_args((uint32_t)round, 0);
             HIP_CHECK(hipEventRecord(h->ev_sel, s));
             HIP_CHECK(hipStreamWaitEvent(h->fix_stream, h->ev_sel, 0));
-            size_t t = h->timer.begin(CAT_SELECT, h->fix_stream);
+            size_t t = h->timer.begin(CAT_TIE_FIX, h->fix_stream);
             launch_tie_fix(ta, h->fix_stream);
             h->timer.end(t, h->fix_stream);
             HIP_CHECK(hipEventRecord(h->ev_fix[round & 1], h->fix_stream));
@@ -2057,7 +2075,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             CopySegs c{};
             c.src[0] = h->w_pl_counters.p;
             c.dst[0] = h->p_counters.dev();
-            c.words[0] = 24 + PLAN_MAX_ROUNDS;
+            c.words[0] = (uint32_t)CNT_WORDS;
             c.n = 1;
             if (nhist) {
                 c.src[1] = h->w_pl_hist.p;
@@ -2067,7 +2085,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             }
             launch_copy_segs(c, s);
         } else {
-            HIP_CHECK(hipMemcpyAsync(hc, h->w_pl_counters.p, 96 + PLAN_MAX_ROUNDS * 4, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipMemcpyAsync(hc, h->w_pl_counters.p, CNT_WORDS * 4, hipMemcpyDeviceToHost, s));
             if (nhist) HIP_CHECK(hipMemcpyAsync(h->p_hist.p, h->w_pl_hist.p, nhist * 64, hipMemcpyDeviceToHost, s));
         }
     };
@@ -2201,7 +2219,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     }
     if (fix_pending) HIP_CHECK(hipStreamWaitEvent(s, h->ev_fix[last_fix_round & 1], 0));  // the last round's tie_fix_kernel
     if (sorted_any && !eager_fix) {
-        size_t t = h->timer.begin(CAT_SELECT, s);
+        size_t t = h->timer.begin(CAT_TIE_FIX, s);
         launch_tie_fix(tie_fix_args(0, 1), s);
         h->timer.end(t, s);
     }
@@ -2227,6 +2245,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         }
         h->scan_bytes += *reinterpret_cast<double*>(hc + 16);
         h->scan_min_bytes += *reinterpret_cast<double*>(hc + 22);
+        h->scan_min_bytes_thr += *reinterpret_cast<double*>(hc + 24 + PLAN_MAX_ROUNDS);
         const unsigned long long* acc = reinterpret_cast<const unsigned long long*>(hc + 18);
         h->scan_slots += (double)acc[0];
         h->scan_useful += (double)acc[1];
@@ -2516,7 +2535,7 @@ int amd_ivf_coarse(amd_ivf_t* h, size_t n, const float* x, size_t nprobe, float*
     use_device(h);
     if (n == 0) return 0;
     WallClock wc(h->stream);
-    h->scan_bytes = h->scan_min_bytes = 0;
+    h->scan_bytes = h->scan_min_bytes = h->scan_min_bytes_thr = 0;
     h->scan_slots = h->scan_useful = 0;
     h->w_x.ensure(n * h->dpad * sizeof(float));
     upload_rows(h, h->w_x.as<float>(), x, n);
@@ -2539,7 +2558,7 @@ int amd_ivf_coarse_resident(amd_ivf_t* h, size_t start, size_t n, size_t nprobe,
     if (start + n > h->n_resident) throw EngineError("resident query range out of bounds");
     if (n == 0) return 0;
     WallClock wc(h->stream);
-    h->scan_bytes = h->scan_min_bytes = 0;
+    h->scan_bytes = h->scan_min_bytes = h->scan_min_bytes_thr = 0;
     h->scan_slots = h->scan_useful = 0;
     h->w_cdis.ensure(n * nprobe * 4);
     h->w_ckeys.ensure(n * nprobe * 8);
@@ -2559,7 +2578,7 @@ int amd_ivf_search_preassigned(amd_ivf_t* h, size_t n, const float* x, size_t k,
     use_device(h);
     if (n == 0 || k == 0) return 0;
     WallClock wc(h->stream);
-    h->scan_bytes = h->scan_min_bytes = 0;
+    h->scan_bytes = h->scan_min_bytes = h->scan_min_bytes_thr = 0;
     h->scan_slots = h->scan_useful = 0;
     h->w_x.ensure(n * h->dpad * sizeof(float));
     upload_rows(h, h->w_x.as<float>(), x, n);
@@ -2582,7 +2601,7 @@ int amd_ivf_search(amd_ivf_t* h, size_t n, const float* x, size_t k, size_t npro
     use_device(h);
     if (n == 0 || k == 0) return 0;
     WallClock wc(h->stream);
-    h->scan_bytes = h->scan_min_bytes = 0;
+    h->scan_bytes = h->scan_min_bytes = h->scan_min_bytes_thr = 0;
     h->scan_slots = h->scan_useful = 0;
     h->w_x.ensure(n * h->dpad * sizeof(float));
     upload_rows(h, h->w_x.as<float>(), x, n);
@@ -2649,7 +2668,7 @@ int amd_ivf_range_search_preassigned(amd_ivf_t* h, size_t n, const float* x, flo
         lims[0] = 0;
         return 0;
     }
-    h->scan_bytes = h->scan_min_bytes = 0;
+    h->scan_bytes = h->scan_min_bytes = h->scan_min_bytes_thr = 0;
     h->scan_slots = h->scan_useful = 0;
     range_core(h, h->w_x.as<float>(), n, radius, nprobe, h->w_ckeys.as<int64_t>(), qr, lims);
     finish_timing(h, wc.stop());
@@ -2677,7 +2696,7 @@ int amd_ivf_range_search(amd_ivf_t* h, size_t n, const float* x, float radius, s
     h->w_ckeys.ensure(n * nprobe * 8);
     coarse_dev(h, h->w_x.as<float>(), n, nprobe, coarse_mode, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>(),
                h->allow_fused && ix(h)->centroid_range.fusable_with(qr, h->metric));
-    h->scan_bytes = h->scan_min_bytes = 0;
+    h->scan_bytes = h->scan_min_bytes = h->scan_min_bytes_thr = 0;
     h->scan_slots = h->scan_useful = 0;
     range_core(h, h->w_x.as<float>(), n, radius, nprobe, h->w_ckeys.as<int64_t>(), qr, lims);
     finish_timing(h, wc.stop());
@@ -2701,7 +2720,7 @@ int amd_ivf_search_resident_preassigned(amd_ivf_t* h, size_t start, size_t n, si
     if (n == 0 || k == 0) return 0;
     if (!keys) throw EngineError("keys are required");
     WallClock wc(h->stream);
-    h->scan_bytes = h->scan_min_bytes = 0;
+    h->scan_bytes = h->scan_min_bytes = h->scan_min_bytes_thr = 0;
     h->scan_slots = h->scan_useful = 0;
     h->w_ckeys.ensure(n * nprobe * 8);
     HIP_CHECK(hipMemcpyAsync(h->w_ckeys.p, keys, n * nprobe * 8, hipMemcpyHostToDevice, h->stream));
@@ -2718,7 +2737,7 @@ int amd_ivf_search_resident(amd_ivf_t* h, size_t start, size_t n, size_t k, size
     if (start + n > src->n_resident) throw EngineError("resident query range out of bounds");
     if (n == 0 || k == 0) return 0;
     WallClock wc(h->stream);
-    h->scan_bytes = h->scan_min_bytes = 0;
+    h->scan_bytes = h->scan_min_bytes = h->scan_min_bytes_thr = 0;
     h->scan_slots = h->scan_useful = 0;
     search_full(h, src->d_resident.as<float>() + start * h->dpad, n, k, nprobe, coarse_mode, D, I, src->resident_range);
     finish_timing(h, wc.stop());
@@ -2774,7 +2793,7 @@ int amd_ivf_search_timed(amd_ivf_t* h, size_t start, size_t n, size_t k, size_t 
     if (start + n > h->n_resident) throw EngineError("resident query range out of bounds");
     if (n == 0 || k == 0 || nprobe == 0) return 0;
     WallClock wc(h->stream);
-    h->scan_bytes = h->scan_min_bytes = 0;
+    h->scan_bytes = h->scan_min_bytes = h->scan_min_bytes_thr = 0;
     h->scan_slots = h->scan_useful = 0;
     timed_core(h, h->d_resident.as<float>() + start * h->dpad, start, n, k, nprobe, budget_ms, coarse_mode, nprobe_used, D, I,
                h->resident_range);
@@ -2788,7 +2807,7 @@ int amd_ivf_search_timed_x(amd_ivf_t* h, size_t n, const float* x, size_t id_off
     use_device(h);
     if (n == 0 || k == 0) return 0;
     WallClock wc(h->stream);
-    h->scan_bytes = h->scan_min_bytes = 0;
+    h->scan_bytes = h->scan_min_bytes = h->scan_min_bytes_thr = 0;
     h->scan_slots = h->scan_useful = 0;
     h->w_x.ensure(n * h->dpad * sizeof(float));
     upload_rows(h, h->w_x.as<float>(), x, n);
@@ -3175,7 +3194,7 @@ static void adaptive_core_once(amd_ivf_t* h, const float* d_x, size_t start, siz
     }
     for (amd_ivf* L : lanes) {
         L->force_heap_select = h->force_heap_select;
-        L->scan_bytes = L->scan_min_bytes = 0;
+        L->scan_bytes = L->scan_min_bytes = L->scan_min_bytes_thr = 0;
         L->scan_slots = L->scan_useful = 0;
     }
     std::vector<std::exception_ptr> errs(nl);
@@ -3211,7 +3230,7 @@ static void adaptive_core_once(amd_ivf_t* h, const float* d_x, size_t start, siz
     sync_and_flush(h, h->stream);
     // fold the kids' counters and kernel timings into the handle
     const double wall = wc.stop();
-    double ms[NCAT] = {0, 0, 0}, ln[NCAT] = {0, 0, 0};
+    double ms[NCAT] = {0}, ln[NCAT] = {0};
     double bytes = 0, slots = 0, useful = 0, min_bytes = 0;
     for (amd_ivf* L : lanes) {
         double m[NCAT], c[NCAT];
@@ -3225,15 +3244,11 @@ static void adaptive_core_once(amd_ivf_t* h, const float* d_x, size_t start, siz
             for (int k = 0; k < 4; k++) h->stats_host[k] += L->stats_host[k], L->stats_host[k] = 0;
         }
     }
-    h->timing[0] = ms[CAT_COARSE];
-    h->timing[1] = ms[CAT_SCAN];
-    h->timing[2] = ms[CAT_SELECT];
+    fill_timing(h, ms, ln);
     h->timing[3] = wall;
-    h->timing[4] = ln[CAT_SCAN];
     h->timing[5] = bytes;
     h->last_min_bytes = min_bytes;
     h->timing[6] = slots > 0 ? useful / slots : 0;
-    h->timing[7] = ln[CAT_SELECT];
 }
 
 // A call of n >= 20 queries with the reference's exact-distance tie order: the whole call is searched with runs of equal
@@ -4049,6 +4064,10 @@ int amd_ivf_wait(amd_ivf_t* h, uint64_t ticket, double timing[9], uint64_t diag[
 
 int amd_ivf_last_timing(amd_ivf_t* h, double out[8]) {
     for (int i = 0; i < 8; i++) out[i] = h->timing[i];
+    return 0;
+}
+int amd_ivf_last_timing_detail(amd_ivf_t* h, double out[16]) {
+    for (int i = 0; i < 2 * NCAT + 2; i++) out[i] = h->timing_detail[i];
     return 0;
 }
 

@@ -131,6 +131,7 @@ struct MfmaScanArgs {
     uint32_t nitems;
     const uint32_t* dev_nitems;   // chained rounds: the item count lives on the device; the grid is a hint (see ScanArgs)
     uint32_t hint_nitems;         // items the same round had last time (0: unknown -> a resident grid)
+    int debug;                    // timing experiments only (results are wrong): 1 no mask stores, 2 no distance stores (threshold rounds)
     int exact_mask;               // threshold mode: the mask bits are counted as results (range search), not re-tested by a selection
     int pipelined;                // 1: dense rounds, 2: threshold rounds, 3: both through scan_mfma_thr_kernel (two blocks in flight
                                   // per wave; threshold rounds: threshold folded into the accumulator, the mask a superset of
@@ -377,6 +378,7 @@ struct PlanArgs {
     uint32_t qblock;                 // queries per full block of a list: 64 (8-wave tiles) or 32 (4-wave tiles)
     uint32_t mfma_chunk;             // != 0: items for scan_mfma_kernel (vectors per item); counted as tiles of shape 8
     uint32_t mfma_qblock;            // queries per item in that form (MFMA_QBLOCK: one tile)
+    int item_order;                  // ... items of a list: 0 chunk major (a chunk's query blocks are neighbours), 1 query block major
     const uint64_t* block_off;       // mfma: first 32-vector block of every list in the fragment-order storage
     uint32_t* seg_begin;             // [nq]
     unsigned long long* dist_base;   // [nq]
@@ -407,6 +409,7 @@ struct PlanArgs {
     // [0] += bytes the round cannot avoid moving through HBM: every probed list once (row_bytes per stored vector) and the
     // rows it writes (4 bytes per distance of a dense round, one mask bit per distance in threshold mode)
     double* min_bytes;
+    double* min_bytes_thr;           // the same for the threshold rounds alone (null: not kept)
     uint32_t row_bytes;
     int dense_round;
 };

@@ -696,7 +696,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 const unsigned long long bal = __ballot(keep);
                 writelane_c<q0>(word, (uint32_t)bal);
                 writelane_c<q0 + 4>(word, (uint32_t)(bal >> 32));
-                if (bal && keep) {
+                if (bal && keep && !(a.debug & 2)) {
                     const int cq = s_cx[wave][q0 + 4 * h], uq = s_u[wave][q0 + 4 * h];
                     const uint32_t off = s_row[wave][q0 + 4 * h] + lv;
                     // the contraction itself: acc = x.y - floor(u / 2) (L2) | x.y - u (IP)
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 }
             });
             // rows start on multiples of 64 floats, chunks on multiples of 64 vectors: word index = (row + position) / 32
-            if (lane < 32 && qok) mask32[(row + i * 32) >> 5] = (uint32_t)word;
+            if (lane < 32 && qok && !(a.debug & 1)) mask32[(row + i * 32) >> 5] = (uint32_t)word;
         };
         for (uint32_t i = 0; i < nblk; i += 2) {
             step(b0, cy0, i);

@@ -20,6 +20,7 @@ __global__ __launch_bounds__(256) void plan_counts_kernel(PlanArgs a) {
         a.bytes[0] = 0.0;
         a.acc64[0] = a.acc64[1] = 0ull;
         if (a.min_bytes) a.min_bytes[0] = 0.0;
+        if (a.min_bytes_thr) a.min_bytes_thr[0] = 0.0;
     }
     if (blockIdx.x == 0 && a.first_plan && a.round_unfinished)
         for (uint32_t r = threadIdx.x; r < PLAN_MAX_ROUNDS; r += 256) a.round_unfinished[r] = 0;
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(1024) void plan_prefix_kernel(PlanArgs a) {
         a.counters[7] = (uint32_t)(s_ndist >> 20);  // MiB of distances, for bookkeeping
         a.bytes[0] += (double)s_ndist * (double)a.d * 4.0;
         if (a.min_bytes) a.min_bytes[0] += a.dense_round ? (double)s_ndist * 4.0 : (double)s_ndist / 8.0;
+        if (a.min_bytes_thr && !a.dense_round) a.min_bytes_thr[0] += (double)s_ndist / 8.0;
     }
 }
 
@@ -287,6 +289,7 @@ __global__ __launch_bounds__(1024) void plan_lists_kernel(PlanArgs a) {
         if (v[0]) list_bytes += (double)(a.list_off[l + 1] - a.list_off[l]) * (double)a.row_bytes;
     }
     if (a.min_bytes && list_bytes > 0) atomicAdd(a.min_bytes, list_bytes);
+    if (a.min_bytes_thr && !a.dense_round && list_bytes > 0) atomicAdd(a.min_bytes_thr, list_bytes);
     uint32_t ex[6], tot[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) ex[k] = block_scan_1024(mine[k], s_w, tot[k]);
@@ -355,8 +358,12 @@ __device__ inline void items_of_list(const PlanArgs& a, uint32_t l, uint32_t c, 
         // item order), so a chunk fetched for one query block is still in that L2 for the next
         uint32_t ni = cur[3];
         const uint64_t b0 = a.block_off[l];
-        for (uint32_t vb = 0; vb < sz; vb += a.mfma_chunk)
-            for (uint32_t qb = 0; qb < c; qb += a.mfma_qblock) {
+        // (item_order 1: query block major -- the query blocks of a list pass over it one after the other, each finding it in
+        // the L2 / Infinity Cache the previous one left it in, instead of three waves requesting the same lines at once)
+        const uint32_t nvb = (sz + a.mfma_chunk - 1) / a.mfma_chunk, nqb = (c + a.mfma_qblock - 1) / a.mfma_qblock;
+        for (uint32_t o = 0; o < nvb * nqb; o++) {
+            const uint32_t vb = (a.item_order ? o % nvb : o / nqb) * a.mfma_chunk, qb = (a.item_order ? o / nvb : o % nqb) * a.mfma_qblock;
+            {
                 ScanItem it;
                 it.vec_base = b0 + vb / MFMA_BLOCK;
                 it.nvec = sz - vb < a.mfma_chunk ? sz - vb : a.mfma_chunk;
@@ -370,6 +377,7 @@ __device__ inline void items_of_list(const PlanArgs& a, uint32_t l, uint32_t c, 
                 slots += (unsigned long long)(((it.npair + MFMA_QBLOCK - 1) / MFMA_QBLOCK) * MFMA_QBLOCK) * (((it.nvec + 63) / 64) * 64);
                 useful += (unsigned long long)it.npair * it.nvec;
             }
+        }
         return;
     }
     for (uint32_t qb = 0; qb < c; qb += a.qblock) {

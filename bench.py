@@ -531,7 +531,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def account(acc, tm, hinted, short, redone, res):
+    def account(acc, tm, hinted, short, redone, res, det=None):
+        if det:  # per phase: (ms by HIP events on the phase's own stream, launches); bytes the dense / threshold rounds had to move
+            ph = acc.setdefault("phases", {})
+            for key, val in det.items():
+                if isinstance(val, tuple):
+                    cur = ph.get(key, (0.0, 0.0))
+                    ph[key] = (cur[0] + val[0], cur[1] + val[1])
+                else:
+                    ph[key] = ph.get(key, 0.0) + val
         acc["hinted_launches"] = acc.get("hinted_launches", 0) + hinted
         acc["short_hints"] = acc.get("short_hints", 0) + short
         acc["tie_redone"] = acc.get("tie_redone", 0) + redone
@@ -577,8 +585,9 @@ def main():
                     res = step(ctxs[j], sn, j)
                     tm = ctxs[j].last_timing()
                     hints = ctxs[j].last_round_hints()
+                    det = ctxs[j].last_timing_detail()
                     with lock:
-                        account(acc, tm, hints[0], hints[1], ctxs[j].last_tie_redone(), res)
+                        account(acc, tm, hints[0], hints[1], ctxs[j].last_tie_redone(), res, det)
             except Exception as e:  # noqa: BLE001
                 errs.append(e)
 
@@ -723,15 +732,19 @@ def main():
     # workload.  Without it the engine's own lower bound stands in (every probed list once per round + the rows written,
     # counted by the planning kernels): `achieved` is then a lower bound of the kernel's real rate.
     traffic, traffic_source = None, None
+    cands = []
     try:
         import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
         if cands:
             pj = json.load(open(cands[-1]))
-            key = scan_kernel + " [lists]"
-            if pj.get("_workload") == workload and key in pj:
-                traffic = pj[key]["hbm_bytes_per_launch"]
-                traffic_source = os.path.relpath(cands[-1], ROOT)
+            if pj.get("_workload") == workload:
+                # (average over the scan launches of a step: dense and threshold rounds; roofline.per_launch has them apart)
+                ks_ = [k for k in pj if k.startswith(("scan_mfma", "scan_tiles_kernel")) and not k.endswith("[coarse]")]
+                nd_ = sum(pj[k]["dispatches"] for k in ks_)
+                if nd_:
+                    traffic = sum(pj[k]["hbm_bytes_per_dispatch"] * pj[k]["dispatches"] for k in ks_) / nd_
+                    traffic_source = os.path.relpath(cands[-1], ROOT)
     except Exception as e:  # a missing or stale profile leaves traffic null
         log("no PMC traffic figure:", e)
     launches = max(scan_launches, 1)
@@ -814,6 +827,44 @@ def main():
     }
     rf = out["roofline"]
     rf["frac"] = rf["achieved"] / rf["peak"] if rf["achieved"] else None
+    # ---- the two scan launches of a step, each by itself (an average over a dense and a threshold launch hides
+    # the worse one): ms = HIP events around the launch on the stream it runs on (one batch at a time), bytes = the committed
+    # per-dispatch PMC figure of that kernel (FETCH_SIZE x 2 for its 16-byte-per-lane streams + WRITE_SIZE) when the profile
+    # was taken on this workload, else the engine's lower bound for the round (every probed list once + rows / mask bits written)
+    pipe = int(h.get_option("scan_pipelined")) if arith == 2 else 0
+    ksn = (d + 31) // 32
+    knames = {"scan_dense": (f"scan_mfma_thr_kernel<1, {ksn}, true>" if pipe & 1 else f"scan_mfma_kernel<1, false, {ksn}>") if arith == 2 else "scan_tiles_kernel",
+              "scan_thr": (f"scan_mfma_thr_kernel<1, {ksn}, false>" if pipe & 2 else f"scan_mfma_kernel<1, true, {ksn}>") if arith == 2 else "scan_filter_kernel"}
+    prof = {}
+    try:
+        if cands:
+            pj2 = json.load(open(cands[-1]))
+            if pj2.get("_workload") == workload:
+                prof = pj2
+    except Exception:  # noqa: BLE001
+        prof = {}
+    phases = alone.get("phases", {})
+    per_launch = []
+    for ph, kind in (("scan_dense", "dense round (round 0: every distance stored)"), ("scan_thr", "threshold rounds (mask bits + the distances that beat the threshold)")):
+        ms_l, n_l = phases.get(ph, (0.0, 0.0))
+        if not n_l:
+            continue
+        lb = phases.get("min_bytes_dense" if ph == "scan_dense" else "min_bytes_thr", 0.0) / n_l
+        pm = prof.get(knames[ph], {})
+        by = pm.get("hbm_bytes_per_dispatch")
+        per_launch.append({"kernel": knames[ph], "what": kind, "launches_per_step": n_l / args.steps, "ms": ms_l / n_l,
+                           "bytes": by if by else lb, "bytes_source": (os.path.relpath(cands[-1], ROOT) + " (PMC per dispatch)") if by else "engine lower bound",
+                           "min_bytes": lb, "GBps": (by if by else lb) / 1e9 / (ms_l / n_l / 1e3),
+                           "frac": (by if by else lb) / 1e9 / (ms_l / n_l / 1e3) / 8000.0})
+    rf["per_launch"] = per_launch
+    # every phase of a step, one batch at a time (events on the phases' own streams; tie_fix_kernel runs beside the next round)
+    rf["phases_ms_per_step"] = {k: v[0] / args.steps for k, v in phases.items() if isinstance(v, tuple)}
+    rf["phase_launches_per_step"] = {k: v[1] / args.steps for k, v in phases.items() if isinstance(v, tuple)}
+    # the whole timed region against the HBM peak: the bytes a step moves through HBM by the committed PMC profile (all kernels) /
+    # the step time of the TIMED region
+    if prof.get("_hbm_bytes_per_step"):
+        rf["step_hbm_bytes"] = prof["_hbm_bytes_per_step"]
+        rf["step_hbm_frac"] = prof["_hbm_bytes_per_step"] / 1e9 / (elapsed / args.steps) / 8000.0
     cp = rf["compute"]
     cp["frac"] = cp["achieved"] / cp["peak"] if cp["achieved"] else None
     if solo:

@@ -229,6 +229,11 @@ int amd_ivf_range_results(amd_ivf_t* h, int64_t* labels, float* distances);
  *      bytes of the distances the scan tiles computed (x d x 4), fraction of the computed (query, vector)
  *      slots that were wanted pairs, select launches (= rounds x sub-batches)} */
 int amd_ivf_last_timing(amd_ivf_t* h, double out[8]);
+/* the same by phase, (ms, launches) pairs: coarse ranking, dense scan (round 0), selection of dense rounds, threshold scan,
+ * selection of threshold rounds, tie_fix_kernel (its own stream), round planning; then the bytes the dense and the threshold
+ * rounds of the search could not avoid moving (every probed list once per round + rows / mask bits written) -- bench.py's
+ * roofline.per_launch */
+int amd_ivf_last_timing_detail(amd_ivf_t* h, double out[16]);
 /* bytes the scans of the last search could not avoid moving through HBM: every probed list once per round (as stored:
  * d bytes per vector in byte-code mode, 4 d in fp32) plus the rows written (4 bytes per distance of a dense round, one
  * mask bit per distance in threshold mode).  A lower bound of the traffic, counted on the device by the planning kernels. */

@@ -83,8 +83,6 @@ for seq in timed_sequences(tr, tj, "Kernel_Name"):
         n = short(r["Kernel_Name"])
         if n.startswith("scan_tiles_kernel"):
             n += " [lists]" if is_list_scan(seq, i, "Kernel_Name") else " [coarse]"
-        elif n.startswith("scan_mfma_kernel"):
-            n += " [lists]"
         agg[n].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
 lines.append(f"# {tag}: bench.py under rocprofv3 (MI355X), timed region = last {steps} steps\n")
 lines.append("## kernel trace (`rocprofv3 --kernel-trace --stats`)\n")
@@ -92,8 +90,11 @@ lines.append("| kernel | calls | calls/step | total ms | ms/step | avg ms | max 
 lines.append("|---|---|---|---|---|---|---|")
 for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
     lines.append(f"| {k} | {len(v)} | {len(v)/steps:.1f} | {sum(v):.3f} | {sum(v)/steps:.3f} | {sum(v)/len(v):.4f} | {max(v):.4f} |")
-scan_ms = sum(sum(v) for k, v in agg.items() if k.endswith("[lists]"))
-lines_scan = {k: v for k, v in agg.items() if k.endswith("[lists]")}
+def is_scan(k):
+    return k.endswith("[lists]") or k.startswith("scan_mfma")
+
+
+scan_ms = sum(sum(v) for k, v in agg.items() if is_scan(k))
 rf = tj["roofline"]
 nl = rf["launches_per_step"] * steps
 lines.append("")
@@ -106,7 +107,7 @@ lines.append(f"bench line of this run: value {tj['value']:.0f} q/s, {tj['ms_per_
              f"nprobe mean {tj['config']['nprobe_mean']:.1f}")
 
 pmc = {}
-for grp in ("fetch", "write", "sq", "misc"):
+for grp in ("fetch", "write", "sq", "misc", "l2", "l1", "sq2"):
     f = glob.glob(os.path.join(root, grp, "*", "*_counter_collection.csv"))
     if not f:
         continue
@@ -124,48 +125,67 @@ for grp in ("fetch", "write", "sq", "misc"):
             n = short(r["Kernel_Name"])
             if n.startswith("scan_tiles_kernel"):
                 n = "scan_tiles_kernel [lists]" if is_list_scan(seq, i, "Kernel_Name") else "scan_tiles_kernel [coarse]"
-            elif n.startswith("scan_mfma_kernel"):
-                n = "scan_mfma_kernel [lists]"  # dense (round 0) and threshold-mode launches together
-            e = pmc.setdefault(n, defaultdict(float))
+            e = pmc.setdefault(n, defaultdict(float))  # (every kernel by its full name: dense and threshold scans apart)
             for c, v in r["c"].items():
                 e[c] += v
             e["_dispatches_" + grp] += 1
             e["_ns_" + grp] += r["t"]
             e["_steps_" + grp] = j["steps"]
-            if n.endswith("[lists]"):
-                e["_launches_" + grp] = j["roofline"]["launches_per_step"] * j["steps"]
+            if is_scan(n):
                 e["_alg_bytes_per_launch"] = j["roofline"]["algorithmic_bytes_per_launch"]
 lines.append("\n## PMC (separate passes: FETCH_SIZE | WRITE_SIZE | SQ_* | GRBM/LDS)\n")
 lines.append("| kernel | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM GB/step (reads x2 for the scan) | VALU insts | wave cycles: active / wait_inst / wait_any | LDS bank conflicts | clock GHz |")
 lines.append("|---|---|---|---|---|---|---|---|")
 out = {}
+step_bytes = 0.0
+
+
+def wide_reader(k):
+    """kernels whose reads are 16-byte-per-lane coalesced streams (FETCH_SIZE counts those at half their bytes on gfx950,
+    MI355X_MICROARCH.md HBM): the scans, the fp32 filter, the selection of a dense round (rows of distances)"""
+    return k.startswith(("scan_tiles_kernel", "scan_mfma", "scan_filter")) or k.startswith("select_sorted_kernel<true, false") \
+        or k.startswith("select_sorted_kernel<false, false")
+
+
 for k, e in sorted(pmc.items(), key=lambda kv: -kv[1].get("FETCH_SIZE", 0)):
     st = e.get("_steps_fetch", steps)
-    corr = 2.0 if k.startswith("scan_tiles_kernel") or k.startswith("scan_mfma_kernel") else 1.0
+    corr = 2.0 if wide_reader(k) else 1.0
     hbm = (e.get("FETCH_SIZE", 0) * corr + e.get("WRITE_SIZE", 0)) * 1024
     wc = e.get("SQ_WAVE_CYCLES", 0)
     frac = (f"{e.get('SQ_ACTIVE_INST_ANY', 0)/wc:.2f} / {e.get('SQ_WAIT_INST_ANY', 0)/wc:.2f} / {e.get('SQ_WAIT_ANY', 0)/wc:.2f}" if wc else "-")
     clk = e.get("GRBM_GUI_ACTIVE", 0) / 8 / e["_ns_misc"] if e.get("_ns_misc") else 0
     lines.append(f"| {k} | {e.get('FETCH_SIZE', 0):.4g} | {e.get('WRITE_SIZE', 0):.4g} | {hbm/st/1e9:.3f} | {e.get('SQ_INSTS_VALU', 0):.4g} | {frac} | "
                  f"{e.get('SQ_LDS_BANK_CONFLICT', 0):.3g} | {clk:.2f} |")
+    nd = max(e.get("_dispatches_fetch", 0), 1)
+    step_bytes += hbm / st
     out[k] = {"fetch_size_kib": e.get("FETCH_SIZE", 0), "write_size_kib": e.get("WRITE_SIZE", 0), "read_correction": corr,
-              "hbm_bytes_per_step": hbm / st, "steps": st}
-    if k.endswith("[lists]"):
-        out[k]["launches"] = e.get("_launches_fetch", 0)
-        out[k]["hbm_bytes_per_launch"] = hbm / max(e.get("_launches_fetch", 1), 1)
+              "hbm_bytes_per_step": hbm / st, "steps": st, "dispatches": nd, "hbm_bytes_per_dispatch": hbm / nd,
+              "avg_ms_fetch_pass": e.get("_ns_fetch", 0) / nd / 1e6}
+    if is_scan(k):
         out[k]["algorithmic_bytes_per_launch"] = e.get("_alg_bytes_per_launch", 0)
-ls = out.get("scan_mfma_kernel [lists]") or out.get("scan_tiles_kernel [lists]")
-if ls:
-    lines.append("")
-    ns_ = pmc[[k for k in pmc if k.endswith("[lists]")][0]]
-    if ns_.get("_ns_fetch") and ns_.get("_launches_fetch"):
-        per_launch_ms = ns_["_ns_fetch"] / ns_["_launches_fetch"] / 1e6
-        lines.append(f"scan [lists]: {ls['hbm_bytes_per_launch']/1e9:.3f} GB per launch in {per_launch_ms:.3f} ms (the FETCH_SIZE pass) = "
-                     f"{ls['hbm_bytes_per_launch']/1e9/per_launch_ms*1e3:.0f} GB/s = {ls['hbm_bytes_per_launch']/1e9/per_launch_ms*1e3/8000:.2f} of the 8 TB/s HBM peak")
-    lines.append(f"scan [lists]: {ls['hbm_bytes_per_launch']/1e9:.3f} GB of HBM traffic per launch against "
-                 f"{ls['algorithmic_bytes_per_launch']/1e9:.2f} GB algorithmic (ndis x d x 4 B) = "
-                 f"{ls['hbm_bytes_per_launch']/ls['algorithmic_bytes_per_launch']:.3f}x: every list byte fetched once is used by "
-                 f"~{ls['algorithmic_bytes_per_launch']/ls['hbm_bytes_per_launch']:.0f} queries of the round")
+lines.append("")
+for k, o in out.items():
+    if is_scan(k) and o["avg_ms_fetch_pass"] > 0:
+        gbps = o["hbm_bytes_per_dispatch"] / 1e9 / (o["avg_ms_fetch_pass"] / 1e3)
+        lines.append(f"{k}: {o['hbm_bytes_per_dispatch']/1e9:.3f} GB per dispatch (FETCH x {o['read_correction']:.0f} + WRITE) in "
+                     f"{o['avg_ms_fetch_pass']:.3f} ms (the FETCH_SIZE pass) = {gbps:.0f} GB/s = {gbps/8000:.2f} of the 8 TB/s HBM peak")
+lines.append(f"all kernels of a step: {step_bytes/1e9:.3f} GB through HBM")
+extra = ("TCC_HIT_sum", "TCC_MISS_sum", "TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_LATENCY_sum",
+         "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SALU", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES",
+         "SQ_INST_CYCLES_VMEM", "SQ_INSTS_VALU", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES")
+lines.append("\n## further counters of the list scans, per dispatch\n")
+for k, e in pmc.items():
+    if not is_scan(k):
+        continue
+    parts = []
+    for c in extra:
+        if c in e:
+            grp_n = max(max(v for kk, v in e.items() if kk.startswith("_dispatches_")), 1)
+            parts.append(f"{c} {e[c] / grp_n:.4g}")
+    if e.get("TCC_HIT_sum", 0) + e.get("TCC_MISS_sum", 0) > 0:
+        parts.append(f"L2 hit rate {e['TCC_HIT_sum'] / (e['TCC_HIT_sum'] + e['TCC_MISS_sum']):.3f}")
+    lines.append(f"* {k}: " + ", ".join(parts))
+out["_hbm_bytes_per_step"] = step_bytes
 out["_workload"] = tj["config"]["workload"]
 open(os.path.join(here, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
 json.dump(out, open(os.path.join(here, f"{tag}_pmc.json"), "w"), indent=1)
