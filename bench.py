@@ -246,6 +246,7 @@ def run_shards(args, torch, dist, capi, rank, world, local, dev, red_dev):
             "config": {"workload": f"SIFT-{args.nb // 1000000}M-like d={d} IVF{nlist},Flat k={k} nprobe={args.nprobe}, IndexShards over {world} GPU(s): "
                                    f"lists sharded by list id, batch {nq} resident queries searched by every shard, host merge_tables on rank 0",
                        "nb": args.nb, "sigma": args.sigma, "nprobe": args.nprobe, "recall_at_k_mean": float(rec.mean()),
+                       "ranks_seen": getattr(args, "ranks_seen", world), "collective_backend": os.environ.get("BENCH_DIST_BACKEND", "nccl") if world > 1 else None,
                        "per_rank_ms_per_step": {"columns": ["coarse (own share of the batch)", "all-gather of the key rows (host wall)", "scan", "select"],
                                                 "rows": per_rank},
                        # distances of the merged result (sorted rows: identical for any number of shards, whatever the order
@@ -332,6 +333,25 @@ def main():
                     help="batches kept in flight per GPU, each from its own host thread on its own search context "
                          "(amd_ivf_clone); 1 = one batch at a time")
     args = ap.parse_args()
+    # --gpus N > 1 without a launcher: start the N ranks ourselves, exactly as the driver would (one process per GPU, RCCL),
+    # BEFORE anything in this process touches the GPU (the parent only counts devices, which does not initialise HIP), wait for
+    # them and leave with their exit code.  A run that was asked for N GPUs never degrades to fewer silently: too few visible
+    # devices is an error here, and a rank whose process group has another size than --gpus is an error below.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        if "BENCH_DEVICE" not in os.environ:  # (BENCH_DEVICE: the rehearsal with every rank on one device, gloo)
+            import torch
+            ndev = torch.cuda.device_count()
+            if ndev < args.gpus:
+                sys.exit(f"bench.py --gpus {args.gpus}: only {ndev} GPU(s) visible on this node")
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        log(f"--gpus {args.gpus} without a launcher: starting {' '.join(cmd[1:8])} ...")
+        sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
     # hardware queues the HIP runtime maps its streams onto (ROCm's default, pinned here because the figure is sensitive to it:
     # with 8 queues four batches in flight lose 8 % and six collapse, profiles/r01_in_flight_sweep.txt); must precede HIP start-up
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
@@ -348,13 +368,20 @@ def main():
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     if "BENCH_DEVICE" in os.environ:
         local = int(os.environ["BENCH_DEVICE"])
+    if world != args.gpus:
+        sys.exit(f"bench.py --gpus {args.gpus}: launched with WORLD_SIZE {world}")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
+    ranks_seen = dist.get_world_size() if world > 1 else 1
+    if world != args.gpus or ranks_seen != args.gpus:
+        sys.exit(f"bench.py --gpus {args.gpus}: WORLD_SIZE is {world} and the process group has {ranks_seen} rank(s)")
+    if backend == "nccl" and "BENCH_DEVICE" not in os.environ and torch.cuda.device_count() < world:
+        sys.exit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible on this node")
+    args.ranks_seen = ranks_seen
     # Host waits: every batch in flight has a host thread waiting on its stream between rounds.  Spinning waits (the HIP default)
     # are ~2 % faster but need a core each; when the ranks' threads outnumber the cores this process tree may use (cgroup quota),
     # the engine sleeps on blocking events instead (include/auncel_amd.h: AUNCEL_AMD_BLOCKING_SYNC).
@@ -774,6 +801,7 @@ def main():
         "config": {
             "workload": workload,
             "query_slices": nsl, "queries_per_slice": ses,
+            "ranks_seen": args.ranks_seen, "collective_backend": backend if world > 1 else None,
             # scan grids of the device-chained rounds are sized from the previous search's counts (+ 12 %); a round that needs
             # more runs on fewer workgroups than it would have been given (it is still complete: the workgroups stride)
             "round_hint": {"launches_sized_by_a_hint": int(acc.get("hinted_launches", 0)), "hint_too_small": int(acc.get("short_hints", 0))},
@@ -1010,6 +1038,7 @@ def main():
             out["shards"] = {"metric": sl["metric"], "value": sl["value"], "unit": sl["unit"], "ms_per_step": sl["ms_per_step"],
                              "scaling": sl["scaling"], "n_gpus": sl["n_gpus"], "nprobe": sargs.nprobe, "batch": sargs.test,
                              "distances_sha256": sl["config"]["distances_sha256"], "recall_at_k_mean": sl["config"]["recall_at_k_mean"],
+                             "ranks_seen": sl["config"]["ranks_seen"],
                              "per_rank_ms_per_step": sl["config"]["per_rank_ms_per_step"],
                              "shard_bytes_max_over_min": sl["config"]["shard_bytes_max_over_min"], "roofline": sl["roofline"]}
     if rank == 0:

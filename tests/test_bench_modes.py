@@ -41,6 +41,29 @@ def test_shards_mode_two_ranks_equals_one():
 
 
 @pytest.mark.gpu
+def test_gpus_n_without_a_launcher_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself (before touching the GPU), records how many
+    ranks the process group saw, and gives the result of the launcher-started run: the merged distances of two list-id shards
+    equal the single index's.  (Rehearsal on one device: gloo, both ranks on GPU 0.)"""
+    one = _run([sys.executable, "bench.py", "--mode", "shards", "--gpus", "1"] + SMALL, {})
+    two = _run([sys.executable, "bench.py", "--mode", "shards", "--gpus", "2"] + SMALL, {"BENCH_DIST_BACKEND": "gloo", "BENCH_DEVICE": "0"})
+    assert two["n_gpus"] == 2 and two["config"]["ranks_seen"] == 2 and two["config"]["collective_backend"] == "gloo"
+    assert one["config"]["ranks_seen"] == 1
+    assert one["config"]["distances_sha256"] == two["config"]["distances_sha256"]
+
+
+def test_gpus_n_refuses_to_degrade():
+    """more GPUs asked for than the node shows: an error before anything is measured, never a one-GPU run that says n_gpus 1"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BENCH_DEVICE")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "64"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "GPU(s) visible" in r.stderr and '{"metric"' not in r.stdout
+    # a launcher whose world size differs from --gpus is refused as well
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1"], cwd=ROOT, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29433", BENCH_DIST_BACKEND="gloo"),
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0
+
+
+@pytest.mark.gpu
 def test_default_mode_two_ranks_records_both_splits(tmp_path):
     """the command the driver issues for N > 1 (no --mode): replicas of the adaptive search, and behind them the list-id shards of
     north_star / BASELINE config 4 as a `shards` block of the same line; query slices rotate; real-data files are taken when given"""
