@@ -537,6 +537,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     __shared__ int s_cx[4][32];
     __shared__ int s_u[4][32];
     __shared__ uint32_t s_row[4][32];
+    // the mask words of an item, [block][query]: a block's 32 words are 32 different rows of the mask -- stored per block that
+    // is one 4-byte write to each of 32 cache lines per tile, 0.15 of a 0.56 ms launch (measured with the stores left out);
+    // gathered here they leave as 16- / 8-byte pieces per query when the item ends
+    constexpr uint32_t MAX_BLK = 16;  // (items of up to 512 vectors: launch_scan_mfma)
+    __shared__ uint32_t s_mask[DENSE ? 1 : 4][DENSE ? 1 : MAX_BLK][32];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = lane & 31, h = lane >> 5;
@@ -704,12 +709,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                     a.dist[off] = (float)(METRIC == METRIC_L2 ? cq - t : cq + t);
                 }
             });
-            // rows start on multiples of 64 floats, chunks on multiples of 64 vectors: word index = (row + position) / 32
-            if (lane < 32 && qok && !(a.debug & 1)) mask32[(row + i * 32) >> 5] = (uint32_t)word;
+            if (lane < 32) s_mask[DENSE ? 0 : wave][DENSE ? 0 : i][lane] = (uint32_t)word;
         };
         for (uint32_t i = 0; i < nblk; i += 2) {
             step(b0, cy0, i);
             step(b1, cy1, i + 1);
+        }
+        if (!DENSE) {
+            // rows start on multiples of 64 floats, chunks on multiples of 64 vectors: word index = (row + position) / 32; the
+            // item's words of a query are consecutive there (nblk of them, an even number: 8-byte pieces at least)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 32 && qok && !(a.debug & 1)) {
+                uint32_t* dst = mask32 + (row >> 5);
+                for (uint32_t i = 0; i < nblk; i += 4) {
+                    if (i + 4 <= nblk) {
+                        typedef int v4i8 __attribute__((ext_vector_type(4), aligned(8)));  // (rows start on multiples of 64 floats)
+                        v4i8 t;
+#pragma unroll
+                        for (int c = 0; c < 4; c++) t[c] = (int)s_mask[DENSE ? 0 : wave][DENSE ? 0 : i + c][lane];
+                        *reinterpret_cast<v4i8*>(dst + i) = t;
+                    } else {
+                        typedef int v2i __attribute__((ext_vector_type(2)));
+                        v2i t;
+                        t[0] = (int)s_mask[DENSE ? 0 : wave][DENSE ? 0 : i][lane];
+                        t[1] = (int)s_mask[DENSE ? 0 : wave][DENSE ? 0 : i + 1][lane];
+                        *reinterpret_cast<v2i*>(dst + i) = t;
+                    }
+                }
+            }
         }
         if (!has_next) break;
         cur = nxt;
@@ -757,7 +785,7 @@ void launch_scan_mfma(const MfmaScanArgs& a, hipStream_t s) {
         }
     };
     // threshold rounds whose mask may be a superset of the exact one: the pipelined form (scan_mfma_thr_kernel)
-    if ((a.pipelined & (masked ? 2 : 1)) && !(masked && a.exact_mask) && ks >= 1 && ks <= 4) {
+    if ((a.pipelined & (masked ? 2 : 1)) && !(masked && a.exact_mask) && ks >= 1 && ks <= 4 && mfma_chunk() <= 512) {
         auto pick_thr = [&](auto metric, auto dense) {
             constexpr int M = decltype(metric)::value;
             constexpr bool D = decltype(dense)::value;

@@ -1228,6 +1228,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 
         const uint32_t m = n < (uint32_t)k ? n : (uint32_t)k;
         uint32_t *fk = fill, *fv = fill + 128, *fg = fill + 256, *sk = fill + 384, *sg = fill + 512;
         const float xs[4] = {x.x, x.y, x.z, x.w};
+        // A candidate that is not strictly better than the empty heap's (+/-)FLT_MAX -- +inf, NaN, FLT_MAX itself -- does not
+        // enter the reference's heap either (IndexIVFFlat.cpp:129: C::cmp(simi[0], dis)): with one among the first m nothing is
+        // taken here and the block goes through the one-by-one admission like any other.
+        bool bad = false;
+#pragma unroll
+        for (int c = 0; c < 4; c++) bad = bad || (4u * lane + c < m && okey<IsMax>(xs[c]) >= SKEY_SENT);
+        if (__ballot(bad) != 0) return 0u;
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const uint32_t j = 4u * lane + c;

@@ -667,3 +667,51 @@ def test_asynchronous_fixed_nprobe_searches(capi, name):
         D, I, timing, diag = h.wait(t)
         assert np.array_equal(I, eI) and np.array_equal(bits(D), bits(eD))
     h.close()
+
+
+@pytest.mark.parametrize("metric", [1, 0])
+@pytest.mark.parametrize("select", [1, 0])
+def test_non_finite_distances_in_the_first_list(capi, metric, select):
+    """Distances that are +inf / NaN / beyond FLT_MAX among the FIRST candidates of a search: the reference admits a candidate
+    only if it is strictly better than the heap top, which starts at (+/-)FLT_MAX (IndexIVFFlat.cpp:129, Heap.h:317-320), so
+    such a candidate never enters -- not even into the empty heap (the block-wise fill of the first k did not
+    test).  k below and above the number of candidates; both selection forms; stats included."""
+    from oracle import pyoracle
+    rs = np.random.RandomState(5)
+    d, nlist, per = 8, 4, 300
+    cen = (rs.rand(nlist, d) * 10).astype(np.float32)
+    xb = (cen[np.repeat(np.arange(nlist), per)] + rs.randn(nlist * per, d)).astype(np.float32)
+    assign = np.repeat(np.arange(nlist), per).astype(np.int64)
+    # the first vectors of every list: overflowing, infinite and NaN distances between finite ones
+    for l in range(nlist):
+        b = l * per
+        xb[b + 0] = 3e19 if metric == 1 else -3e38      # L2: (x - y)^2 overflows to +inf | IP: sum overflows to -inf
+        xb[b + 2, 0] = np.nan
+        xb[b + 3, 1] = np.inf if metric == 1 else -np.inf
+        xb[b + 7] = xb[b + 0]
+        xb[b + 150, 3] = np.nan
+    xq = (cen[rs.randint(0, nlist, 40)] + rs.randn(40, d)).astype(np.float32)
+    if metric == 0:
+        xq = np.abs(xq)
+    h = capi.Handle(d, nlist, metric, 0)
+    h.set_centroids(cen)
+    h.set_lists_from_assign(xb, assign)
+    h.set_option("select", select)
+    lists = pyoracle.Lists(metric, cen, xb, assign)
+    od, ok = pyoracle.knn(metric, xq, cen, 3)
+    with np.errstate(all="ignore"):
+        for k in (10, 100, 128):     # 128 > the 100-candidate log block; all below the 300 candidates of a list
+            OD, OI, ost = pyoracle.search_preassigned(lists, xq, k, ok, od)
+            h.stats(reset=True)
+            D, I = h.search_preassigned(xq, k, ok, od)
+            assert np.array_equal(I, OI), (k, np.nonzero((I != OI).any(1))[0][:5])
+            assert np.array_equal(bits(D), bits(OD)), k
+            st = h.stats()
+            assert [st["nlist"], st["ndis"], st["nheap_updates"]] == list(ost), k
+        # more neighbours asked for than one probe holds finite candidates for (k > n of the first list)
+        OD, OI, ost = pyoracle.search_preassigned(lists, xq, 128, ok[:, :1], od[:, :1])
+        h.stats(reset=True)
+        D, I = h.search_preassigned(xq, 128, ok[:, :1], od[:, :1])
+        assert np.array_equal(I, OI) and np.array_equal(bits(D), bits(OD))
+        st = h.stats()
+        assert [st["nlist"], st["ndis"], st["nheap_updates"]] == list(ost)
