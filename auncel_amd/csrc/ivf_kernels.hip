@@ -693,21 +693,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 });
                 return;
             }
+            // One v_cmp per register is the ballot of its 64 candidates.  Everything else -- the two lane writes that park the
+            // mask words, the store of a distance -- happens only for a register that HAS a candidate (a few in a hundred), behind
+            // a scalar branch on the ballot: the epilogue of a tile was 72 vector + 129 scalar instructions when every register
+            // wrote its lanes and walked an exec-masked branch (PMC, profiles/r04a_summary.md: the waves of this kernel were
+            // issuing or stalled on issue for 2/3 of their cycles), it is 16 + 32 on the common path now.  Ballots are taken eight
+            // registers at a time (16 SGPRs) ahead of their branches, so that the compares issue back to back.
             int word = 0;  // lane q (< 32) collects the 32-candidate mask word of query q
-            static_for(std::make_integer_sequence<int, 16>{}, [&](auto R) {
-                constexpr int reg = decltype(R)::value;
-                constexpr int q0 = (reg & 3) + 8 * (reg >> 2);  // query of lane half 0; half 1: q0 + 4
-                const bool keep = acc[reg] > hc;
-                const unsigned long long bal = __ballot(keep);
-                writelane_c<q0>(word, (uint32_t)bal);
-                writelane_c<q0 + 4>(word, (uint32_t)(bal >> 32));
-                if (bal && keep && !(a.debug & 2)) {
-                    const int cq = s_cx[wave][q0 + 4 * h], uq = s_u[wave][q0 + 4 * h];
-                    const uint32_t off = s_row[wave][q0 + 4 * h] + lv;
-                    // the contraction itself: acc = x.y - floor(u / 2) (L2) | x.y - u (IP)
-                    const int t = METRIC == METRIC_L2 ? 2 * (acc[reg] + (uq >> 1)) - cy : acc[reg] + uq + cy;
-                    a.dist[off] = (float)(METRIC == METRIC_L2 ? cq - t : cq + t);
-                }
+            static_for(std::make_integer_sequence<int, 2>{}, [&](auto H) {
+                constexpr int r0 = decltype(H)::value * 8;
+                unsigned long long bal[8];
+#pragma unroll
+                for (int r = 0; r < 8; r++) bal[r] = __ballot(acc[r0 + r] > hc);
+                static_for(std::make_integer_sequence<int, 8>{}, [&](auto R) {
+                    constexpr int reg = r0 + decltype(R)::value;
+                    constexpr int q0 = (reg & 3) + 8 * (reg >> 2);  // query of lane half 0; half 1: q0 + 4
+                    const unsigned long long b = bal[reg - r0];
+                    if (b != 0) {  // (wave-uniform: a scalar compare and branch)
+                        writelane_c<q0>(word, (uint32_t)b);
+                        writelane_c<q0 + 4>(word, (uint32_t)(b >> 32));
+                        if (acc[reg] > hc && !(a.debug & 2)) {
+                            const int cq = s_cx[wave][q0 + 4 * h], uq = s_u[wave][q0 + 4 * h];
+                            const uint32_t off = s_row[wave][q0 + 4 * h] + lv;
+                            // the contraction itself: acc = x.y - floor(u / 2) (L2) | x.y - u (IP)
+                            const int t = METRIC == METRIC_L2 ? 2 * (acc[reg] + (uq >> 1)) - cy : acc[reg] + uq + cy;
+                            a.dist[off] = (float)(METRIC == METRIC_L2 ? cq - t : cq + t);
+                        }
+                    }
+                });
             });
             if (lane < 32) s_mask[DENSE ? 0 : wave][DENSE ? 0 : i][lane] = (uint32_t)word;
         };

@@ -311,6 +311,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-legs", action="store_true",
                     help="skip the untimed extra legs (one batch at a time, fp32 path, guaranteed-bound point): profiling runs")
+    ap.add_argument("--no-other", action="store_true",
+                    help="skip the other_configs block (BASELINE configs 1, 3, 5 at fixed nprobe, each compared with the compiled reference)")
     ap.add_argument("--no-ref", action="store_true", help="cpu_baseline from the CPU restatement only (skip oracle/_ref/ref_harness)")
     ap.add_argument("--kmeans", choices=["engine", "torch"], default="engine",
                     help="coarse centroids: the engine's Clustering::train restatement (amd_ivf_kmeans, the reference's IVF "
@@ -1024,6 +1026,29 @@ def main():
                 log("reference harness not usable here:", repr(e))
     if gt_check is not None:
         out["config"]["ground_truth_file"] = gt_check
+    # ---- BASELINE configs 1, 3, 5 under the same clock: fixed nprobe, one batch of 10 000 resident queries per
+    # call, value / per-phase times / roofline of the scan, and ids + distances compared bit for bit with the compiled reference
+    # (oracle/_ref/ref_harness fixedbench, 2000 queries each) and the pinned CPU restatement.  After the headline: never part of it.
+    if rank == 0 and world == 1 and not args.no_legs and not args.no_other and not args.data:
+        try:
+            while len(ctxs) > 1:  # (the search contexts go before the index they were cloned from)
+                ctxs.pop()
+            del ctxs, h
+            torch.cuda.empty_cache()
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            import bench_configs
+            oc = []
+            for c, npb in (("1", (8,)), ("3", (32,)), ("5", (32,))):
+                t0 = time.time()
+                for line in bench_configs.run_config(torch, capi, dev, c, npb, 64, 0 if args.no_cpu or args.no_ref else 2000, log):
+                    oc.append(line)
+                    log(f"other config {c} nprobe {line['nprobe']}: {line['value'] / 1e6:.3f} M q/s, {line['ms_per_batch']:.2f} ms per batch of {line['batch']}, "
+                        f"recall@{line['k']} {line['recall_at_k']:.4f}, == reference: {line['gpu_equals_reference']}, == CPU restatement: "
+                        f"{line['gpu_equals_cpu_on_sample']} ({time.time() - t0:.0f}s)")
+            out["other_configs"] = oc
+        except Exception as e:  # noqa: BLE001 -- the headline stands without them
+            log("other_configs failed:", repr(e))
+            out["other_configs"] = {"error": repr(e)}
     if world > 1:
         # north_star's split next to the replicas: the inverted lists sharded by list id over the same N GPUs (BASELINE config 4,
         # Auncel/IndexShards.cpp:261-311), fixed nprobe, run after the replica timing; one driver command records both

@@ -82,6 +82,101 @@ def gt_ids(torch, xb, xq, k, ip):
     return outI.cpu().numpy()
 
 
+CFGS = {"1": ("sift", 1_000_000, 10000, 1024, 10, (8,), 1),
+        "3": ("deep", 10_000_000, 10000, 4096, 100, (16, 32, 64), 0),
+        "5": ("gist", 1_000_000, 10000, 4096, 10, (32, 64), 1)}
+
+
+def run_config(torch, capi, dev, c, nprobes=None, sample=64, ref_sample=2000, log=None):
+    """one BASELINE config (build + timed fixed-nprobe searches + parity against the pinned oracle and, where its harness is
+    present, the compiled reference): yields one dict per nprobe"""
+    from oracle import pyoracle, refbench
+    kind, nb, nq, nlist, k, default_nprobes, metric = CFGS[c]
+    nprobes = tuple(nprobes) if nprobes else default_nprobes
+    t0 = time.time()
+    xb_t, xq_t = gen(torch, dev, kind, nb, nq)
+    d = xb_t.shape[1]
+    gtI = gt_ids(torch, xb_t, xq_t, k, metric == capi.METRIC_IP)
+    xb, xq = xb_t.cpu().numpy(), xq_t.cpu().numpy()
+    del xb_t, xq_t
+    torch.cuda.empty_cache()
+    # coarse centroids by the reference's IVF training (Clustering::train, 25 iterations) on the GPU
+    cen, _ = capi.kmeans(metric, xb, nlist, niter=25)
+    h = capi.Handle(d, nlist, metric, 0)
+    h.set_centroids(cen)
+    h.add(xb)  # (assigns by the index metric, like the reference's quantizer->assign)
+    del xb
+    h.set_queries(xq)
+    # oracle lists for the parity sample
+    codes, ids, off = [], [], np.zeros(nlist + 1, dtype=np.uintp)
+    for l in range(nlist):
+        cc, ii = h.get_list(l)
+        codes.append(cc)
+        ids.append(ii)
+        off[l + 1] = off[l] + len(ii)
+    lists = pyoracle.Lists.__new__(pyoracle.Lists)
+    lists.metric, lists.centroids, lists.nlist, lists.d = metric, cen, nlist, d
+    lists.off, lists.codes, lists.ids = off, np.concatenate(codes), np.concatenate(ids)
+    del codes, ids
+    lists.struct = pyoracle.OrcIndex(metric, d, nlist, pyoracle._s(lists.off), pyoracle._f(lists.codes), pyoracle._i(lists.ids))
+    if log:
+        log(f"config {c}: data, ground truth, k-means, add: {time.time() - t0:.1f}s")
+    for nprobe in nprobes:
+        h.search_resident(0, nq, k, nprobe)
+        best = None
+        for _ in range(3):
+            h.stats(reset=True)
+            t0 = time.perf_counter()
+            D, I = h.search_resident(0, nq, k, nprobe)
+            dt = time.perf_counter() - t0
+            if best is None or dt < best[0]:
+                best = (dt, h.last_timing(), h.stats(), h.last_timing_detail())
+        dt, tm, st, det = best
+        recall = np.mean([len(set(I[i]) & set(gtI[i])) / k for i in range(0, nq, 10)])
+        S = sample
+        cores = bench.host_cores()
+        tc = time.perf_counter()
+        cd, ck = pyoracle.knn(metric, xq[:S], cen, nprobe, nthreads=cores)
+        oD, oI, _ = pyoracle.search_preassigned(lists, xq[:S], k, ck, cd, nthreads=cores)
+        cpu = S / (time.perf_counter() - tc)
+        same = bool(np.array_equal(oI, I[:S]) and np.array_equal(oD.view(np.uint32), D[:S].view(np.uint32)))
+        # the compiled reference itself, where its harness is present (oracle/_ref): IndexIVF::search, one query per call
+        ref = None
+        if refbench.available() and ref_sample:
+            try:
+                SR = min(nq, ref_sample)
+                ro = refbench.run_fixed(metric, cen, lists.off, lists.codes, lists.ids, xq[:SR], k, nprobe, threads=cores)
+                ref = {"qps": SR / ro["seconds_all_threads"], "threads": ro["threads"], "queries": SR,
+                       "gpu_equals_reference": bool(np.array_equal(ro["I"], I[:SR]) and np.array_equal(ro["D"].view(np.uint32), D[:SR].view(np.uint32)))}
+            except Exception as e:  # noqa: BLE001
+                ref = {"error": repr(e)}
+        alg = st["ndis"] * d * 4.0
+        arith = h.scan_arith()
+        filt = h.last_filter()[0]
+        # roofline of the run's scan: the bytes its rounds could not avoid moving (every probed list once per round + rows / mask
+        # bits written; dense and threshold rounds apart) over the HIP-event time of their launches
+        phases = {p: {"ms": det[p][0], "launches": det[p][1]} for p in capi.Handle.PHASES if det[p][1]}
+        roof = {"bound": "hbm", "unit": "GB/s", "peak": 8000.0, "traffic": None, "per_launch": []}
+        for ph, mb in (("scan_dense", det["min_bytes_dense"]), ("scan_thr", det["min_bytes_thr"])):
+            if det[ph][1] and det[ph][0] > 0:
+                roof["per_launch"].append({"phase": ph, "launches": det[ph][1], "ms": det[ph][0] / det[ph][1], "min_bytes": mb / det[ph][1],
+                                           "GBps": mb / 1e9 / (det[ph][0] / 1e3), "frac": mb / 1e9 / (det[ph][0] / 1e3) / 8000.0})
+        tot_ms = det["scan_dense"][0] + det["scan_thr"][0]
+        tot_b = det["min_bytes_dense"] + det["min_bytes_thr"]
+        roof["achieved"] = tot_b / 1e9 / (tot_ms / 1e3) if tot_ms > 0 else None
+        roof["frac"] = roof["achieved"] / 8000.0 if roof["achieved"] else None
+        yield {"config": c, "data": kind + "-like synthetic", "nb": nb, "d": d, "nlist": nlist, "k": k, "nprobe": nprobe,
+               "metric": "IP" if metric == 0 else "L2", "batch": nq, "value": nq / dt, "unit": "queries/s", "ms_per_batch": dt * 1e3, "qps": nq / dt,
+               "recall_at_k": float(recall),
+               "dtype": {0: "f32", 1: "f32", 2: "u8"}[arith], "threshold_rounds_through_the_fp32_filter": int(filt),
+               "scan_ms": tm["scan_ms"], "select_ms": tm["select_ms"], "coarse_ms": tm["coarse_ms"], "phases": phases, "roofline": roof,
+               "scan_algorithmic_GBps": alg / 1e6 / max(tm["scan_ms"], 1e-9), "tile_slot_efficiency": tm["slot_efficiency"],
+               "cpu_oracle_qps": cpu, "cpu_threads": cores, "gpu_equals_cpu_on_sample": same, "reference": ref,
+               "gpu_equals_reference": (ref or {}).get("gpu_equals_reference")}
+    h.close()
+    del lists
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cfg", default="1,3,5")
@@ -91,81 +186,11 @@ def main():
     args = ap.parse_args()
     import torch
     from auncel_amd import capi
-    from oracle import pyoracle, refbench
     dev = torch.device("cuda", 0)
-    cfgs = {"1": ("sift", 1_000_000, 10000, 1024, 10, (8,), capi.METRIC_L2),
-            "3": ("deep", 10_000_000, 10000, 4096, 100, (16, 32, 64), capi.METRIC_IP),
-            "5": ("gist", 1_000_000, 10000, 4096, 10, (32, 64), capi.METRIC_L2)}
     for c in args.cfg.split(","):
-        kind, nb, nq, nlist, k, nprobes, metric = cfgs[c]
-        xb_t, xq_t = gen(torch, dev, kind, nb, nq)
-        d = xb_t.shape[1]
-        gtI = gt_ids(torch, xb_t, xq_t, k, metric == capi.METRIC_IP)
-        xb, xq = xb_t.cpu().numpy(), xq_t.cpu().numpy()
-        del xb_t, xq_t
-        torch.cuda.empty_cache()
-        # coarse centroids by the reference's IVF training (Clustering::train, 25 iterations) on the GPU
-        cen, _ = capi.kmeans(metric, xb, nlist, niter=25)
-        h = capi.Handle(d, nlist, metric, 0)
-        h.set_centroids(cen)
-        if metric == capi.METRIC_IP:
-            # add() assigns by the index metric (max inner product), like the reference's quantizer->assign
-            h.add(xb)
-        else:
-            h.add(xb)
-        del xb
-        h.set_queries(xq)
-        # oracle lists for the parity sample
-        codes, ids, off = [], [], np.zeros(nlist + 1, dtype=np.uintp)
-        for l in range(nlist):
-            cc, ii = h.get_list(l)
-            codes.append(cc)
-            ids.append(ii)
-            off[l + 1] = off[l] + len(ii)
-        lists = pyoracle.Lists.__new__(pyoracle.Lists)
-        lists.metric, lists.centroids, lists.nlist, lists.d = metric, cen, nlist, d
-        lists.off, lists.codes, lists.ids = off, np.concatenate(codes), np.concatenate(ids)
-        del codes, ids
-        lists.struct = pyoracle.OrcIndex(metric, d, nlist, pyoracle._s(lists.off), pyoracle._f(lists.codes), pyoracle._i(lists.ids))
-        if args.nprobes:
-            nprobes = tuple(int(v) for v in args.nprobes.split(","))
-        for nprobe in nprobes:
-            h.search_resident(0, nq, k, nprobe)
-            best = None
-            for _ in range(3):
-                h.stats(reset=True)
-                t0 = time.perf_counter()
-                D, I = h.search_resident(0, nq, k, nprobe)
-                dt = time.perf_counter() - t0
-                if best is None or dt < best[0]:
-                    best = (dt, h.last_timing(), h.stats())
-            dt, tm, st = best
-            recall = np.mean([len(set(I[i]) & set(gtI[i])) / k for i in range(0, nq, 10)])
-            S = args.sample
-            cores = bench.host_cores()
-            tc = time.perf_counter()
-            cd, ck = pyoracle.knn(metric, xq[:S], cen, nprobe, nthreads=cores)
-            oD, oI, _ = pyoracle.search_preassigned(lists, xq[:S], k, ck, cd, nthreads=cores)
-            cpu = S / (time.perf_counter() - tc)
-            same = bool(np.array_equal(oI, I[:S]) and np.array_equal(oD.view(np.uint32), D[:S].view(np.uint32)))
-            # the compiled reference itself, where its harness is present (oracle/_ref): IndexIVF::search, one query per call
-            ref = None
-            if refbench.available():
-                try:
-                    SR = min(nq, args.ref_sample)
-                    ro = refbench.run_fixed(metric, cen, lists.off, lists.codes, lists.ids, xq[:SR], k, nprobe, threads=cores)
-                    ref = {"qps": SR / ro["seconds_all_threads"], "threads": ro["threads"], "queries": SR,
-                           "gpu_equals_reference": bool(np.array_equal(ro["I"], I[:SR]) and np.array_equal(ro["D"].view(np.uint32), D[:SR].view(np.uint32)))}
-                except Exception as e:  # noqa: BLE001
-                    ref = {"error": repr(e)}
-            alg = st["ndis"] * d * 4.0
-            print(json.dumps({"config": c, "data": kind + "-like synthetic", "nb": nb, "d": d, "nlist": nlist, "k": k, "nprobe": nprobe,
-                              "metric": "IP" if metric == 0 else "L2", "batch": nq, "qps": nq / dt, "recall_at_k": float(recall),
-                              "scan_ms": tm["scan_ms"], "select_ms": tm["select_ms"], "coarse_ms": tm["coarse_ms"],
-                              "scan_algorithmic_GBps": alg / 1e6 / max(tm["scan_ms"], 1e-9), "tile_slot_efficiency": tm["slot_efficiency"],
-                              "cpu_oracle_qps": cpu, "cpu_threads": cores, "gpu_equals_cpu_on_sample": same, "reference": ref}), flush=True)
-        h.close()
-        del lists
+        nprobes = tuple(int(v) for v in args.nprobes.split(",")) if args.nprobes else None
+        for line in run_config(torch, capi, dev, c, nprobes, args.sample, args.ref_sample):
+            print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
