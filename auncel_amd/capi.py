@@ -24,7 +24,7 @@ SYMBOLS = [
     "amd_ivf_set_tuner", "amd_ivf_search_adaptive", "amd_ivf_search_adaptive_x", "amd_ivf_search_adaptive_pre", "amd_ivf_search_timed", "amd_ivf_search_timed_x",
     "amd_ivf_train_samples",
     "amd_ivf_train_samples_x", "amd_ivf_train_samples_pre", "amd_ivf_trace_sb", "amd_ivf_arcos_table", "amd_ivf_merge_tables",
-    "amd_ivf_last_timing", "amd_ivf_last_timing_detail", "amd_ivf_last_scan_min_bytes", "amd_ivf_coarse_tie_rows", "amd_ivf_last_tie_fixed", "amd_ivf_last_filter", "amd_ivf_last_direct_out", "amd_ivf_set_async_depth", "amd_ivf_submit_adaptive", "amd_ivf_submit_search_resident", "amd_ivf_wait", "amd_ivf_last_tie_redone", "amd_ivf_last_round_hints", "amd_ivf_set_byte_codes", "amd_ivf_set_option", "amd_ivf_get_option",
+    "amd_ivf_last_timing", "amd_ivf_last_timing_detail", "amd_ivf_last_scan_min_bytes", "amd_ivf_coarse_tie_rows", "amd_ivf_last_tie_fixed", "amd_ivf_last_filter", "amd_ivf_last_direct_out", "amd_ivf_last_coarse_pick", "amd_ivf_set_async_depth", "amd_ivf_submit_adaptive", "amd_ivf_submit_search_resident", "amd_ivf_wait", "amd_ivf_last_tie_redone", "amd_ivf_last_round_hints", "amd_ivf_set_byte_codes", "amd_ivf_set_option", "amd_ivf_get_option",
     "amd_ivf_kmeans",
     "amd_ivf_range_search_preassigned", "amd_ivf_range_search", "amd_ivf_range_results",
     "amd_ivf_scan_arith",
@@ -543,6 +543,12 @@ class Handle:
     def last_direct_out(self):
         """True if the last search wrote (D, I) straight into the caller's (page-locked) buffers (include/auncel_amd.h)"""
         return bool(lib().amd_ivf_last_direct_out(self._h))
+
+    def last_coarse_pick(self):
+        """rankings of the last coarse call that came from matrix-core distances + exact recomputation (include/auncel_amd.h)"""
+        v = C.c_uint64(0)
+        _chk(lib().amd_ivf_last_coarse_pick(self._h, C.byref(v)))
+        return int(v.value)
 
     def set_byte_codes(self, enable):
         """False: scan the fp32 lists even where the byte codes qualify (same results)"""

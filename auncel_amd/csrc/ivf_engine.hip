@@ -62,6 +62,8 @@ enum OptId {
     OPT_DIRECT_OUT,     // results written straight into page-locked caller buffers (1) or copied at the end (0)
     OPT_SCAN_PIPELINED, // byte-code scan through scan_mfma_thr_kernel: bit 0 dense rounds, bit 1 threshold rounds (3: both; 0: scan_mfma_kernel)
     OPT_PLAN_FUSED,     // round planning in three launches (1) or seven (0)
+    OPT_COARSE_PICK,    // exact coarse top-nprobe of large calls from matrix-core distances + exact recomputation of the candidates (1) or
+                        // from exact distances to every centroid (0)
     OPT_PINNED_IO,      // per-call inputs / outputs through one page-locked block read and written by kernels (1) or by copies (0)
     N_OPT
 };
@@ -82,6 +84,7 @@ const OptSpec OPT_TABLE[N_OPT] = {
     {"direct_out", "AUNCEL_AMD_DIRECT_OUT", nullptr},
     {"scan_pipelined", "AUNCEL_AMD_SCAN_PIPELINED", nullptr},
     {"plan_fused", "AUNCEL_AMD_PLAN_FUSED", nullptr},
+    {"coarse_pick", "AUNCEL_AMD_COARSE_PICK", nullptr},
     {"pinned_io", "AUNCEL_AMD_PINNED_IO", nullptr},
 };
 struct Options {
@@ -346,6 +349,11 @@ struct amd_ivf {
     DevBuf w_heap_val, w_heap_ref, w_stage, w_nscan, w_done, w_pre_val, w_stoped, w_dtb, w_D, w_I;
     DevBuf w_cdis, w_ckeys, w_stats, w_error, w_misc, w_misc2, w_misc3, w_rawptrs;
     DevBuf c_heap_val, c_heap_ref, c_stage, c_nscan, c_done, c_seg_off, c_seg_list, c_seg_count;
+    float centroid_norm_max = 0.f;  // max |c|^2 over the centroids, rounded up
+    bool in_coarse_pick = false;    // (the exact re-run of flagged queries is inside coarse_dev)
+    size_t coarse_picked = 0;       // rankings of the last coarse_dev call that came from coarse_pick_kernel
+    DevBuf c_pick_flag, c_pick_x, c_pick_dis, c_pick_keys;  // coarse_pick_kernel: flagged queries and their exact re-run
+    PinnedBuf p_pick;
     DevBuf c_pair_query, c_pair_out, c_items, c_group_p0, c_group_cnt;  // the coarse quantiser's work list (coarse_dev), kept
     uint64_t coarse_sig = 0;                                             // while its signature (chunk, queries, nlist) repeats
     bool coarse_sig_valid = false;
@@ -1317,6 +1325,51 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
     const bool gemm = mode == 1 || (mode < 0 && !(n < 20 && h->d % 4 == 0));
     const size_t nlist = h->nlist;
     hipStream_t s = h->stream;
+    // Exact rankings of a large call that reads few entries of each (fixed nprobe): the matrix cores rank approximately, the
+    // candidates that can be among the nprobe best are recomputed exactly (coarse_pick_kernel); queries in which exactly equal
+    // distances meet -- where the reference's order is its heap's history -- come back flagged and take the path below.
+    if (!gemm && !h->in_coarse_pick && opt(h, OPT_COARSE_PICK, 1) != 0 && n >= 256 && nprobe <= 128 && nlist <= 4096 && nlist >= 4 * nprobe + 64 &&
+        prefix == 0 && h->ties_override < 0 && n * nlist <= h->dist_budget_floats) {
+        size_t t = h->timer.begin(CAT_COARSE, s);
+        h->w_xnorms.ensure(n * sizeof(float));
+        h->w_dist.ensure(n * nlist * sizeof(float));
+        h->c_pick_flag.ensure((n + 1) * 4);
+        h->p_pick.ensure((n + 1) * 4);
+        HIP_CHECK(hipMemsetAsync(h->c_pick_flag.p, 0, 4, s));
+        launch_row_norms(d_x, n, h->dpad, h->w_xnorms.as<float>(), s);
+        launch_coarse_gemm(h->metric, d_x, ix(h)->d_centroids.as<float>(), h->w_xnorms.as<float>(), ix(h)->d_centroid_norms.as<float>(), (int)n,
+                           (int)nlist, h->dpad, h->w_dist.as<float>(), s);
+        launch_coarse_pick(h->metric, h->w_dist.as<float>(), d_x, ix(h)->d_centroids.as<float>(), h->w_xnorms.as<float>(), ix(h)->centroid_norm_max,
+                           (uint32_t)n, (uint32_t)nlist, (uint32_t)nprobe, h->dpad, d_out_dis, d_out_keys, h->c_pick_flag.as<uint32_t>(),
+                           h->c_pick_flag.as<uint32_t>() + 1, s);
+        h->timer.end(t, s);
+        // (the flagged queries: how many, which)
+        CopySegs c{};
+        c.src[0] = h->c_pick_flag.p;
+        c.dst[0] = h->p_pick.dev();
+        c.words[0] = (uint32_t)(n + 1);
+        c.n = 1;
+        launch_copy_segs(c, s);
+        HIP_CHECK(stream_sync(s));
+        const uint32_t m = h->p_pick.as<uint32_t>()[0];
+        if (m) {
+            h->c_pick_x.ensure((size_t)m * h->dpad * sizeof(float));
+            h->c_pick_dis.ensure((size_t)m * nprobe * 4);
+            h->c_pick_keys.ensure((size_t)m * nprobe * 8);
+            launch_gather_rows(d_x, h->c_pick_flag.as<uint32_t>() + 1, m, (uint32_t)h->dpad, h->c_pick_x.as<float>(), s);
+            struct Guard {
+                bool& f;
+                ~Guard() { f = false; }
+            } guard{h->in_coarse_pick};
+            h->in_coarse_pick = true;
+            coarse_dev(h, h->c_pick_x.as<float>(), m, nprobe, mode, h->c_pick_dis.as<float>(), h->c_pick_keys.as<int64_t>(), fused, 0);
+            launch_scatter_rows(h->c_pick_dis.p, h->c_pick_flag.as<uint32_t>() + 1, m, (uint32_t)nprobe, d_out_dis, s);
+            launch_scatter_rows(h->c_pick_keys.p, h->c_pick_flag.as<uint32_t>() + 1, m, (uint32_t)(2 * nprobe), d_out_keys, s);
+        }
+        h->coarse_picked = n - m;
+        return;
+    }
+    h->coarse_picked = 0;
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(n, h->dist_budget_floats / std::max<size_t>(nlist, 1)));
     const bool use_heap = nprobe <= 128;
     // Longer rankings are sorted; between exactly equal distances the reference's order is an artefact of its heap's
@@ -1798,6 +1851,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     auto plan_round = [&](size_t round_len) {
         pa.round_len = (uint32_t)round_len;
         pa.dense_round = !(base.range || (planned_rounds > 0 && !no_thr));
+        if (base.bytes) pa.mfma_chunk = pa.dense_round || base.range ? mfma_chunk() : mfma_chunk_thr();
         if (filter_ok) {  // threshold rounds of an fp32 search: items in the matrix-core form (a chunk x a block of 32 queries)
             const bool mf = !pa.dense_round;
             pa.mfma_chunk = mf ? filter_item_vectors(h->d) : 0;
@@ -2435,6 +2489,15 @@ int amd_ivf_set_centroids(amd_ivf_t* h, const float* centroids) {
     HIP_CHECK(stream_sync(h->stream));
     h->have_centroids = true;
     h->have_interdis = false;
+    {
+        double mx = 0;  // max |c|^2: the error bound of the approximate coarse ranking (coarse_pick_kernel)
+        for (size_t i = 0; i < h->nlist; i++) {
+            double sq = 0;
+            for (int c = 0; c < h->d; c++) sq += (double)h->h_centroids[i * h->dpad + c] * (double)h->h_centroids[i * h->dpad + c];
+            mx = std::max(mx, sq);
+        }
+        h->centroid_norm_max = (float)(mx * (1.0 + 1e-6));
+    }
     h->centroid_range = IntRange();
     h->centroid_range.add(centroids, h->nlist * (size_t)h->d);
     API_END
@@ -3851,6 +3914,10 @@ int amd_ivf_last_tie_fixed(amd_ivf_t* h, uint64_t* queries) {
     API_END
 }
 int amd_ivf_last_direct_out(amd_ivf_t* h) { return h ? h->last_direct_out : 0; }
+int amd_ivf_last_coarse_pick(amd_ivf_t* h, uint64_t* rankings) {
+    *rankings = h ? h->coarse_picked : 0;
+    return 0;
+}
 int amd_ivf_last_filter(amd_ivf_t* h, uint64_t out[2]) {
     API_BEGIN
     use_device(h);

@@ -102,28 +102,6 @@ void launch_filter_queries(const float* x, size_t n, int d, int dpad, int metric
 }
 
 // ---------------------------------------------------------------------------------------------
-// the reference's distance between two fp32 rows (utils_simd.cpp:391-443): sums 0..3 over elements 4 i + l, products and sums
-// rounded separately (this file is built with -ffp-contract=off), (s0 + s1) + (s2 + s3); rows are zero-padded to dpad (% 4)
-template <int METRIC> __device__ __forceinline__ float exact_distance(const float* x, const float* y, int dpad) {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    for (int c = 0; c < dpad; c += 4) {
-        const v4f a = *reinterpret_cast<const v4f*>(x + c), b = *reinterpret_cast<const v4f*>(y + c);
-        if (METRIC == METRIC_L2) {
-            const float t0 = b.x - a.x, t1 = b.y - a.y, t2 = b.z - a.z, t3 = b.w - a.w;
-            s0 += t0 * t0;
-            s1 += t1 * t1;
-            s2 += t2 * t2;
-            s3 += t3 * t3;
-        } else {
-            s0 += b.x * a.x;
-            s1 += b.y * a.y;
-            s2 += b.z * a.z;
-            s3 += b.w * a.w;
-        }
-    }
-    return (s0 + s1) + (s2 + s3);
-}
-
 // one lane per survivor of the filter: exact distance into the distance row
 template <int METRIC> __global__ __launch_bounds__(256) void rescore_kernel(FilterScanArgs a) {
     const uint32_t n = *a.surv_count < a.surv_cap ? *a.surv_count : a.surv_cap;

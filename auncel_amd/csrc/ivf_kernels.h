@@ -110,6 +110,7 @@ void launch_pack_queries(const float* queries, const uint32_t* pair_query, const
 constexpr uint32_t MFMA_BLOCK = 32;        // vectors per block = N of the MFMA
 constexpr uint32_t MFMA_QBLOCK = 32;       // queries per item = M of the MFMA
 uint32_t mfma_chunk();                     // vectors per work item (a multiple of 64; AUNCEL_AMD_MFMA_CHUNK, default 256)
+uint32_t mfma_chunk_thr();                 // ... of a threshold round (AUNCEL_AMD_MFMA_CHUNK_THR, default 512)
 inline __host__ __device__ uint32_t mfma_ksteps(int d) { return (uint32_t)(d + 31) / 32; }
 inline __host__ __device__ uint64_t mfma_list_blocks(uint64_t size) { return ((size + 63) / 64) * 2; }
 
@@ -458,6 +459,14 @@ void launch_first_tie(const float* sorted_dis, uint32_t nq, uint32_t stride, uin
 void launch_row_norms(const float* x, size_t n, int d, float* out, hipStream_t s);
 void launch_coarse_gemm(int metric, const float* X, const float* Y, const float* xn, const float* yn, int nq, int ny, int d, float* out,
                         hipStream_t s);
+
+// exact top-nprobe (nprobe << nlist <= 4096) from approximate distances + exact recomputation of the candidates (see
+// coarse_pick_kernel); queries whose result could depend on the reference's heap history are counted in *nflag / listed in
+// flagged[] and left to the caller
+void launch_coarse_pick(int metric, const float* approx, const float* x, const float* centroids, const float* xn, float cmax, uint32_t n,
+                        uint32_t nlist, uint32_t nprobe, int dpad, float* out_dis, int64_t* out_keys, uint32_t* nflag, uint32_t* flagged,
+                        hipStream_t s);
+void launch_scatter_rows(const void* in, const uint32_t* idx, uint32_t m, uint32_t words, void* out, hipStream_t s);
 
 // packed upper triangle (IVF_pro.cpp:21-39 layout) of a full nlist x nlist distance matrix
 void launch_pack_upper(const float* full, uint32_t nlist, float* out, hipStream_t s);

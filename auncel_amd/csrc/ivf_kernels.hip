@@ -770,6 +770,18 @@ uint32_t mfma_chunk() {
     return v;
 }
 
+// ... of a threshold round: an item is longer there (512), where nothing is stored per candidate and the per-item prologue and
+// the scattered stores of the mask words weigh more (0.450 -> 0.407 ms per launch on the bench workload; the dense round
+// prefers 256: 0.529 vs 0.549)
+uint32_t mfma_chunk_thr() {
+    static const uint32_t v = [] {
+        const char* e = getenv("AUNCEL_AMD_MFMA_CHUNK_THR");
+        const long x = e ? atol(e) : 0;
+        return x >= 64 ? (uint32_t)((x + 63) / 64 * 64) : (getenv("AUNCEL_AMD_MFMA_CHUNK") ? mfma_chunk() : 512u);
+    }();
+    return v;
+}
+
 void launch_scan_mfma(const MfmaScanArgs& a, hipStream_t s) {
     if (a.nitems == 0 && !a.dev_nitems) return;
     const unsigned nwg = (a.nitems + 3) / 4;
@@ -798,7 +810,7 @@ void launch_scan_mfma(const MfmaScanArgs& a, hipStream_t s) {
         }
     };
     // threshold rounds whose mask may be a superset of the exact one: the pipelined form (scan_mfma_thr_kernel)
-    if ((a.pipelined & (masked ? 2 : 1)) && !(masked && a.exact_mask) && ks >= 1 && ks <= 4 && mfma_chunk() <= 512) {
+    if ((a.pipelined & (masked ? 2 : 1)) && !(masked && a.exact_mask) && ks >= 1 && ks <= 4 && mfma_chunk() <= 512 && mfma_chunk_thr() <= 512) {
         auto pick_thr = [&](auto metric, auto dense) {
             constexpr int M = decltype(metric)::value;
             constexpr bool D = decltype(dense)::value;
@@ -1262,6 +1274,160 @@ __global__ __launch_bounds__(256) void sort_prefix_kernel(const float* dis, uint
         out_dis[(size_t)q * nprobe + i] = dv;
         out_keys[(size_t)q * nprobe + i] = id;
     }
+}
+
+// ---- exact top-nprobe of every ranking from APPROXIMATE distances (coarse_gemm_kernel) + exact recomputation of the few
+// centroids that can be among them.  The exact coarse distances of a call cost n x nlist x d operations in the reference's
+// rounding sequence on the vector ALU (2.98 ms of a 12.5 ms search at d = 960, 10 000 queries); a fixed-nprobe search reads
+// nprobe << nlist of them.  Here the matrix cores rank all centroids approximately, and one workgroup per query
+//   1. finds a threshold T with at least nprobe approximate distances at or below it (bisection on order keys, as
+//      sort_prefix_kernel), and widens it by 2 eps: |approx - exact| <= eps = C (|x|^2 + max |c|^2) (L2) / C |x| max |c| (IP) with
+//      C = (2 d + 32) 2^-24, the bound of the fp32 filter (ivf_filter.hip) -- every centroid whose EXACT distance is among the
+//      nprobe best has its approximate one within the widened threshold (exact_(nprobe) <= T + eps, approx <= exact + eps);
+//   2. recomputes those candidates' distances in the reference's sequence (exact_distance, one candidate per thread) and
+//      sorts them;
+//   3. writes the first nprobe -- unless two of the first nprobe + 1 are exactly equal (their order in the reference is its
+//      heap's history, utils.cpp:454-490), a distance is not finite, or the candidates overflow the buffer: such a query is
+//      FLAGGED and recomputed by the caller the old way (exact tile kernel + the reference's heap).
+// Distinct finite distances leave the reference's heap in ascending (L2) / descending (IP) order, so what is written is its
+// result bit for bit.
+struct CoarsePickArgs {
+    const float* approx;      // n x nlist
+    const float* x;           // n x dpad
+    const float* centroids;   // nlist x dpad
+    const float* xn;          // n: |x|^2 (row_norms_kernel)
+    float cmax;               // max over centroids of |c|^2
+    float C;
+    uint32_t nlist, nprobe;
+    int dpad;
+    float* out_dis;           // n x nprobe
+    int64_t* out_keys;
+    uint32_t* nflag;          // += 1 per flagged query
+    uint32_t* flagged;        // [n] their numbers
+};
+constexpr uint32_t PICK_CAP = 1024;
+template <int METRIC>
+__global__ __launch_bounds__(256) void coarse_pick_kernel(CoarsePickArgs a) {
+    constexpr bool Ascending = METRIC == METRIC_L2;
+    __shared__ unsigned long long buf[PICK_CAP];
+    __shared__ uint32_t red[2][4];
+    __shared__ uint32_t s_cnt, s_bad;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* row = a.approx + (size_t)q * a.nlist;
+    constexpr int E = 16;  // nlist <= 4096
+    uint32_t key[E];
+#pragma unroll
+    for (int j = 0; j < E; j++) {
+        const uint32_t i = tid + 256 * j;
+        key[j] = 0xffffffffu;
+        if (i < a.nlist) key[j] = Ascending ? fkey(row[i]) : ~fkey(row[i]);
+    }
+    if (tid == 0) s_cnt = 0, s_bad = 0;
+    int par = 0;
+    auto block_count = [&](uint32_t thr) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int j = 0; j < E; j++) c += __builtin_popcountll(__ballot(key[j] <= thr));
+        if (lane == 0) red[par][wave] = c;
+        __syncthreads();
+        const uint32_t tot = red[par][0] + red[par][1] + red[par][2] + red[par][3];
+        par ^= 1;
+        return tot;
+    };
+    // a threshold with nprobe .. 2 nprobe + 16 approximate distances at or below it (any such T is >= the nprobe-th smallest)
+    uint32_t lo = 0, hi = 0xffffffffu;
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        const uint32_t c = block_count(mid);
+        if (c >= a.nprobe) {
+            hi = mid;
+            if (c <= 2 * a.nprobe + 16) break;
+        } else {
+            lo = mid + 1;
+        }
+    }
+    const float Tv = fkey_inv(Ascending ? hi : ~hi);
+    const float xn = a.xn[q];
+    const float eps = METRIC == METRIC_L2 ? a.C * (xn + a.cmax) : a.C * sqrtf(xn) * sqrtf(a.cmax);
+    const float Tw = Ascending ? Tv + 2.f * eps : Tv - 2.f * eps;
+    bool bad = !(fabsf(Tw) < 3.0e38f);  // (NaN, infinities: the caller's exact path deals with them)
+    const uint32_t kw = Ascending ? fkey(Tw) : ~fkey(Tw);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < E; j++) {
+        const uint32_t i = tid + 256 * j;
+        const bool take = key[j] <= kw && i < a.nlist;
+        const unsigned long long m = __ballot(take);
+        uint32_t base = 0;
+        if (lane == 0 && m) base = atomicAdd(&s_cnt, (uint32_t)__builtin_popcountll(m));
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        const uint32_t slot = base + __builtin_popcountll(m & ((1ull << lane) - 1));
+        if (take && slot < PICK_CAP) buf[slot] = i;
+    }
+    __syncthreads();
+    const uint32_t C = s_cnt;
+    if (C > PICK_CAP || C < a.nprobe) bad = true;
+    const uint32_t n = C < PICK_CAP ? C : PICK_CAP;
+    uint32_t S = 64;
+    while (S < n) S <<= 1;
+    const float* xq = a.x + (size_t)q * a.dpad;
+    for (uint32_t c = tid; c < S; c += 256) {
+        unsigned long long e = ~0ull;
+        if (c < n) {
+            const uint32_t i = (uint32_t)buf[c];
+            const float ex = exact_distance<METRIC>(xq, a.centroids + (size_t)i * a.dpad, a.dpad);
+            if (!(fabsf(ex) < 3.0e38f)) bad = true;
+            e = ((unsigned long long)(Ascending ? fkey(ex) : ~fkey(ex)) << 32) | i;
+        }
+        buf[c] = e;
+    }
+    __syncthreads();
+    for (uint32_t size = 2; size <= S; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = tid; t < S / 2; t += 256) {
+                const uint32_t l = 2 * t - (t & (stride - 1)), h = l + stride;
+                const bool up = (l & size) == 0;
+                const unsigned long long x = buf[l], y = buf[h];
+                if ((x < y) != up) {
+                    buf[l] = y;
+                    buf[h] = x;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // equal neighbours among the first nprobe + 1: the reference's order there is its heap's
+    for (uint32_t i = tid; i < a.nprobe && i + 1 < n; i += 256)
+        if ((uint32_t)(buf[i] >> 32) == (uint32_t)(buf[i + 1] >> 32)) bad = true;
+    if (bad) atomicOr(&s_bad, 1u);
+    __syncthreads();
+    if (s_bad) {
+        if (tid == 0) a.flagged[atomicAdd(a.nflag, 1u)] = q;
+        return;
+    }
+    for (uint32_t i = tid; i < a.nprobe; i += 256) {
+        const unsigned long long e = buf[i];
+        const uint32_t k = (uint32_t)(e >> 32);
+        a.out_dis[(size_t)q * a.nprobe + i] = fkey_inv(Ascending ? k : ~k);
+        a.out_keys[(size_t)q * a.nprobe + i] = (int64_t)(uint32_t)e;
+    }
+}
+void launch_coarse_pick(int metric, const float* approx, const float* x, const float* centroids, const float* xn, float cmax, uint32_t n,
+                        uint32_t nlist, uint32_t nprobe, int dpad, float* out_dis, int64_t* out_keys, uint32_t* nflag, uint32_t* flagged,
+                        hipStream_t s) {
+    if (n == 0) return;
+    CoarsePickArgs a{approx, x, centroids, xn, cmax, (2.f * (float)dpad + 32.f) * 5.9604645e-8f, nlist, nprobe, dpad, out_dis, out_keys, nflag, flagged};
+    if (metric == METRIC_L2) LAUNCH(coarse_pick_kernel<METRIC_L2>, dim3(n), dim3(256), 0, s, a);
+    else LAUNCH(coarse_pick_kernel<METRIC_IP>, dim3(n), dim3(256), 0, s, a);
+}
+// out row idx[j] <- in row j (rows of `words` 4-byte words)
+__global__ void scatter_rows_kernel(const uint32_t* in, const uint32_t* idx, uint32_t words, uint32_t* out) {
+    const uint32_t j = blockIdx.x;
+    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) out[(size_t)idx[j] * words + i] = in[(size_t)j * words + i];
+}
+void launch_scatter_rows(const void* in, const uint32_t* idx, uint32_t m, uint32_t words, void* out, hipStream_t s) {
+    if (m == 0) return;
+    LAUNCH(scatter_rows_kernel, dim3(m), dim3(64), 0, s, static_cast<const uint32_t*>(in), idx, words, static_cast<uint32_t*>(out));
 }
 
 // prefix: 0 = rank all nprobe entries; else only the first `prefix` are needed (see sort_prefix_kernel)

@@ -11,21 +11,21 @@ namespace amdivf {
 
 // ---- 1. how many probes does each query run this round, and how many distances is that (one wave per query:
 //         the probes of a query are spread over the lanes)
-__global__ __launch_bounds__(256) void plan_counts_kernel(PlanArgs a) {
-    // the per-list pair histogram of the round starts from zero (plan_segments_kernel, next on the stream, fills it)
-    for (uint32_t l = blockIdx.x * 256 + threadIdx.x; l < a.nlist; l += gridDim.x * 256) a.lcount[l] = 0;
-    // (what used to be a launch of its own: nothing in this kernel writes the counters, the next one -- one block -- does)
-    if (blockIdx.x == 0 && threadIdx.x < 16 && a.history) a.history[threadIdx.x] = a.counters[threadIdx.x];
-    if (blockIdx.x == 0 && threadIdx.x == 0 && a.first_plan) {  // the accumulators of a search (bytes, tile slots) and its per-round marks
+// (the first workgroup, before anything else of a planning pass: what used to be a launch of its own -- nothing in the counts
+// phase writes the counters, the prefix phase, one block, does)
+__device__ __forceinline__ void plan_begin(const PlanArgs& a, uint32_t tid, uint32_t nthreads) {
+    if (tid < 16 && a.history) a.history[tid] = a.counters[tid];
+    if (tid == 0 && a.first_plan) {  // the accumulators of a search (bytes, tile slots) and its per-round marks
         a.bytes[0] = 0.0;
         a.acc64[0] = a.acc64[1] = 0ull;
         if (a.min_bytes) a.min_bytes[0] = 0.0;
         if (a.min_bytes_thr) a.min_bytes_thr[0] = 0.0;
     }
-    if (blockIdx.x == 0 && a.first_plan && a.round_unfinished)
-        for (uint32_t r = threadIdx.x; r < PLAN_MAX_ROUNDS; r += 256) a.round_unfinished[r] = 0;
-    const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const uint32_t lane = threadIdx.x & 63;
+    if (a.first_plan && a.round_unfinished)
+        for (uint32_t r = tid; r < PLAN_MAX_ROUNDS; r += nthreads) a.round_unfinished[r] = 0;
+}
+// one wave: query i
+__device__ __forceinline__ void plan_counts_query(const PlanArgs& a, uint32_t i, uint32_t lane) {
     const bool have = i < a.nq;
     uint32_t cnt = 0, pad = 0, more = 0;
     unsigned long long need = 0;
@@ -88,6 +88,12 @@ __global__ __launch_bounds__(256) void plan_counts_kernel(PlanArgs a) {
         a.pad[i] = pad | (more << 31);  // (top bit: this round cannot be the query's last; plan_prefix_kernel counts and clears it)
     }
 }
+__global__ __launch_bounds__(256) void plan_counts_kernel(PlanArgs a) {
+    // the per-list pair histogram of the round starts from zero (plan_segments_kernel, next on the stream, fills it)
+    for (uint32_t l = blockIdx.x * 256 + threadIdx.x; l < a.nlist; l += gridDim.x * 256) a.lcount[l] = 0;
+    if (blockIdx.x == 0) plan_begin(a, threadIdx.x, 256);
+    plan_counts_query(a, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+}
 
 // exclusive prefix sum of one value per thread over a block of 1024 threads (16 waves): shuffles inside the waves, one LDS
 // hop for the wave totals; `total` receives the block's sum.  s_wave: 17 entries of shared memory, reusable on return.
@@ -119,7 +125,7 @@ template <typename T> __device__ __forceinline__ T block_scan_1024(T v, T* s_wav
 
 // ---- 2. one block: prefix sums over the queries, budget cut, list of active queries.  Thread t owns the queries
 //         [t * per, (t + 1) * per): sums of its own, one block scan of the 1024 sums, then its queries again.
-__global__ __launch_bounds__(1024) void plan_prefix_kernel(PlanArgs a) {
+__device__ __forceinline__ void plan_prefix_body(const PlanArgs& a) {
     __shared__ unsigned long long s_w64[17];
     __shared__ uint32_t s_w32[17];
     __shared__ uint32_t cut;
@@ -198,24 +204,12 @@ __global__ __launch_bounds__(1024) void plan_prefix_kernel(PlanArgs a) {
         if (a.min_bytes_thr && !a.dense_round) a.min_bytes_thr[0] += (double)s_ndist / 8.0;
     }
 }
+__global__ __launch_bounds__(1024) void plan_prefix_kernel(PlanArgs a) { plan_prefix_body(a); }
 
 // ---- 3. segments of every active query + histogram of pairs per list (one wave per query)
-__global__ __launch_bounds__(256) void plan_segments_kernel(PlanArgs a) {
-    const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const uint32_t lane = threadIdx.x & 63;
-    // launch positions of the active queries (compaction order is irrelevant): one atomic per workgroup on the shared counter,
-    // not one per query -- thousands of waves on one address queue up in the L2
-    __shared__ uint32_t s_n, s_base;
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    const uint32_t c = i < a.nq ? a.cnt[i] : 0u;
-    uint32_t local = 0;
-    if (c && lane == 0) local = atomicAdd(&s_n, 1u);
-    __syncthreads();
-    if (threadIdx.x == 0 && s_n) s_base = atomicAdd(&a.counters[6], s_n);
-    __syncthreads();
-    if (!c) return;
-    if (lane == 0) a.qsel[s_base + local] = i;
+// one wave: the segments of active query i (c probes), whose launch position is `slot`
+__device__ __forceinline__ void plan_segments_query(const PlanArgs& a, uint32_t i, uint32_t c, uint32_t slot, uint32_t lane) {
+    if (lane == 0) a.qsel[slot] = i;
     const uint32_t stage = a.stage[i];
     const int64_t* kq = a.keys + (size_t)i * a.key_stride + stage;
     unsigned long long cur = a.dist_base[i];  // wave-uniform running offset
@@ -247,10 +241,27 @@ __global__ __launch_bounds__(256) void plan_segments_kernel(PlanArgs a) {
         cur += __shfl(incl, 63);
     }
 }
+__global__ __launch_bounds__(256) void plan_segments_kernel(PlanArgs a) {
+    const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    // launch positions of the active queries (compaction order is irrelevant): one atomic per workgroup on the shared counter,
+    // not one per query -- thousands of waves on one address queue up in the L2
+    __shared__ uint32_t s_n, s_base;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const uint32_t c = i < a.nq ? a.cnt[i] : 0u;
+    uint32_t local = 0;
+    if (c && lane == 0) local = atomicAdd(&s_n, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n) s_base = atomicAdd(&a.counters[6], s_n);
+    __syncthreads();
+    if (!c) return;
+    plan_segments_query(a, i, c, s_base + (uint32_t)__shfl((int)local, 0), lane);
+}
 
 // ---- 4. one block: per-list pair offsets, query-group bases, tile counts per workgroup shape (thread t owns a run of lists)
 
-__global__ __launch_bounds__(1024) void plan_lists_kernel(PlanArgs a) {
+__device__ __forceinline__ void plan_lists_body(const PlanArgs& a) {
     __shared__ uint32_t s_w[17];
     const uint32_t t = threadIdx.x;
     // pairs, groups, tiles of shape 1, 2, 4, 8 of list l

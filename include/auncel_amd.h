@@ -277,6 +277,14 @@ int amd_ivf_last_filter(amd_ivf_t* h, uint64_t out[2]);
  * query finishes, under the later rounds, and the call ends without a copy; pageable buffers are filled by a copy at the end.
  * AUNCEL_AMD_DIRECT_OUT=0 always copies. */
 int amd_ivf_last_direct_out(amd_ivf_t* h);
+/* Exact coarse rankings of a large fixed-nprobe call (>= 256 queries, nprobe <= 128 << nlist <= 4096; IndexFlat::search in the
+ * arithmetic of knn_L2sqr_sse / knn_inner_product_sse, utils.cpp:417-490): the matrix cores rank every centroid approximately, the
+ * centroids that can be among the nprobe best -- by a rigorous bound on the difference to the reference's value -- are recomputed
+ * in the reference's rounding sequence and sorted; a query in which exactly equal distances meet (the reference's order there is
+ * its heap's history) is recomputed from exact distances to every centroid through that heap.  Returned distances and ids are
+ * the reference's bit for bit either way.  *rankings = how many of the last coarse call's came the first way.
+ * amd_ivf_set_option(h, "coarse_pick", 0) keeps the exact distances to every centroid for all queries. */
+int amd_ivf_last_coarse_pick(amd_ivf_t* h, uint64_t* rankings);
 
 /* ------------------------------------------------------------------------------------------------
  * Asynchronous form of amd_ivf_search_adaptive (same arguments, same results).  submit returns at once with a ticket; the
@@ -332,6 +340,8 @@ int amd_ivf_set_byte_codes(amd_ivf_t* h, int enable);
  *   "scan_pipelined"  byte-code scan through scan_mfma_thr_kernel (two list blocks in flight per   3
  *                     wave): bit 0 dense rounds, bit 1 threshold rounds; 0: scan_mfma_kernel
  *   "plan_fused"      round planning in 3 launches (1) or 7 (0)                               1
+ *   "coarse_pick"     large fixed-nprobe calls: 1 coarse rankings from matrix-core distances + exact   1
+ *                     recomputation of the candidates (amd_ivf_last_coarse_pick), 0 exact distances to every centroid
  *   "pinned_io"       per-call inputs / outputs through one page-locked block (1) or copies (0)                 1
  * amd_ivf_set_option(h, key, NAN) returns the key to "unset". */
 int amd_ivf_set_option(amd_ivf_t* h, const char* key, double value);

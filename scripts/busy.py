@@ -2,7 +2,7 @@ import sqlite3, sys
 c=sqlite3.connect(sys.argv[1])
 rows=list(c.execute("select name, start, end from kernels order by start"))
 # timed region: last 60% of the trace by time
-scans=[r for r in rows if 'scan_mfma_kernel' in r[0]]
+scans=[r for r in rows if 'scan_mfma' in r[0]]
 back=int(sys.argv[2]) if len(sys.argv)>2 else 80
 skip=int(sys.argv[3]) if len(sys.argv)>3 else 0
 lo=scans[-back-skip][1]; hi=scans[-1-skip][2] if skip else rows[-1][2]
