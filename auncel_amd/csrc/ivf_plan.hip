@@ -333,11 +333,10 @@ __device__ __forceinline__ void plan_lists_body(const PlanArgs& a) {
         a.counters[9] = tot[5];  // tiles of shape 8
     }
 }
+__global__ __launch_bounds__(1024) void plan_lists_kernel(PlanArgs a) { plan_lists_body(a); }
 
 // ---- 5. pairs into their list's range (one wave per query)
-__device__ __forceinline__ void plan_scatter_block(const PlanArgs& a, uint32_t block) {
-    const uint32_t i = block * 4 + (threadIdx.x >> 6);
-    const uint32_t lane = threadIdx.x & 63;
+__device__ __forceinline__ void plan_scatter_query(const PlanArgs& a, uint32_t i, uint32_t lane) {
     if (i >= a.nq) return;
     const uint32_t c = a.cnt[i];
     if (!c) return;
@@ -414,18 +413,11 @@ __device__ inline void items_of_list(const PlanArgs& a, uint32_t l, uint32_t c, 
 }
 
 
-// ---- 5 + 6 in one launch (both read what plan_lists_kernel left, neither reads the other's output): the first gq workgroups
-//      scatter the pairs of four queries each, the rest make the items of 256 lists each
-__global__ __launch_bounds__(256) void plan_scatter_items_kernel(PlanArgs a, uint32_t gq) {
-    if (blockIdx.x < gq) {
-        plan_scatter_block(a, blockIdx.x);
-        return;
-    }
-    const uint32_t l = (blockIdx.x - gq) * 256 + threadIdx.x;
+// the items of list l (one thread per list; the tile bookkeeping of a wave in one pair of atomics)
+__device__ __forceinline__ void plan_items_lists(const PlanArgs& a, uint32_t l) {
     const uint32_t c = l < a.nlist ? a.lcount[l] : 0u;
     unsigned long long slots = 0, useful = 0;
     if (c) items_of_list(a, l, c, slots, useful);
-    // one pair of atomics per wave, not per list
     for (int off = 32; off; off >>= 1) {
         slots += __shfl_xor(slots, off);
         useful += __shfl_xor(useful, off);
@@ -436,9 +428,52 @@ __global__ __launch_bounds__(256) void plan_scatter_items_kernel(PlanArgs a, uin
     }
 }
 
+// ---- 5 + 6 in one launch (both read what plan_lists_kernel left, neither reads the other's output): the first gq workgroups
+//      scatter the pairs of four queries each, the rest make the items of 256 lists each
+__global__ __launch_bounds__(256) void plan_scatter_items_kernel(PlanArgs a, uint32_t gq) {
+    if (blockIdx.x < gq) {
+        plan_scatter_query(a, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+        return;
+    }
+    plan_items_lists(a, (blockIdx.x - gq) * 256 + threadIdx.x);
+}
+
+// ---- a call of a few queries (the reference's callers issue one search per query, eval/bound.cpp:391-396): the whole pass in ONE
+//      workgroup of 16 waves -- the five launches above are five dependent kernel boundaries and five dispatch latencies for a
+//      few hundred pairs; here the phases are separated by workgroup barriers
+constexpr uint32_t PLAN_SMALL_NQ = 32;
+__global__ __launch_bounds__(1024) void plan_small_kernel(PlanArgs a) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ uint32_t s_slot;
+    for (uint32_t l = tid; l < a.nlist; l += 1024) a.lcount[l] = 0;
+    plan_begin(a, tid, 1024);
+    if (tid == 0) s_slot = 0;
+    __syncthreads();  // (the history copy reads the counters before the prefix phase writes them)
+    for (uint32_t i = wave; i < a.nq; i += 16) plan_counts_query(a, i, lane);
+    __syncthreads();
+    plan_prefix_body(a);
+    __syncthreads();
+    for (uint32_t i = wave; i < a.nq; i += 16) {
+        const uint32_t c = a.cnt[i];
+        if (!c) continue;
+        uint32_t slot = 0;
+        if (lane == 0) slot = atomicAdd(&s_slot, 1u);
+        plan_segments_query(a, i, c, (uint32_t)__shfl((int)slot, 0), lane);
+    }
+    __syncthreads();
+    plan_lists_body(a);
+    __syncthreads();
+    for (uint32_t i = wave; i < a.nq; i += 16) plan_scatter_query(a, i, lane);
+    for (uint32_t l0 = 0; l0 < a.nlist; l0 += 1024) plan_items_lists(a, l0 + tid);
+}
+
 // five launches a round (round 3: seven -- a reset kernel of one thread, and scatter / items apart)
 void launch_plan(const PlanArgs& a, hipStream_t s) {
     if (a.nq == 0) return;
+    if (a.nq <= PLAN_SMALL_NQ && a.nlist <= 65536) {
+        LAUNCH(plan_small_kernel, dim3(1), dim3(1024), 0, s, a);
+        return;
+    }
     const unsigned gq = (a.nq + 3) / 4 /* one wave per query */, gl = (a.nlist + 255) / 256;
     LAUNCH(plan_counts_kernel, dim3(gq), dim3(256), 0, s, a);
     LAUNCH(plan_prefix_kernel, dim3(1), dim3(1024), 0, s, a);
