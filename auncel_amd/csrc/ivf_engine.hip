@@ -64,6 +64,7 @@ enum OptId {
     OPT_PLAN_FUSED,     // round planning in three launches (1) or seven (0)
     OPT_COARSE_PICK,    // exact coarse top-nprobe of large calls from matrix-core distances + exact recomputation of the candidates (1) or
                         // from exact distances to every centroid (0)
+    OPT_PHASE_TIMING,   // HIP events around every phase of a search (amd_ivf_last_timing): 1 always, 0 never; unset: calls of >= 20 queries
     OPT_PINNED_IO,      // per-call inputs / outputs through one page-locked block read and written by kernels (1) or by copies (0)
     N_OPT
 };
@@ -85,6 +86,7 @@ const OptSpec OPT_TABLE[N_OPT] = {
     {"scan_pipelined", "AUNCEL_AMD_SCAN_PIPELINED", nullptr},
     {"plan_fused", "AUNCEL_AMD_PLAN_FUSED", nullptr},
     {"coarse_pick", "AUNCEL_AMD_COARSE_PICK", nullptr},
+    {"phase_timing", "AUNCEL_AMD_PHASE_TIMING", nullptr},
     {"pinned_io", "AUNCEL_AMD_PINNED_IO", nullptr},
 };
 struct Options {
@@ -220,13 +222,20 @@ struct EventTimer {
         HIP_CHECK(hipEventCreate(&e));
         return e;
     }
+    // off: a call of a few queries is all launch latency, and a pair of event records around every phase is a dozen stream
+    // operations more (the "phase_timing" option; amd_ivf_last_timing then reports zeros for the phases)
+    bool off = false;
+    static constexpr size_t NONE = ~(size_t)0;
     size_t begin(int cat, hipStream_t s) {
+        if (off) return NONE;
         Span sp{get(), get(), cat};
         HIP_CHECK(hipEventRecord(sp.a, s));
         spans.push_back(sp);
         return spans.size() - 1;
     }
-    void end(size_t i, hipStream_t s) { HIP_CHECK(hipEventRecord(spans[i].b, s)); }
+    void end(size_t i, hipStream_t s) {
+        if (i != NONE) HIP_CHECK(hipEventRecord(spans[i].b, s));
+    }
     // call after the stream has been synchronised
     void collect(double* ms_by_cat, int ncat, double* launches_by_cat) {
         for (int c = 0; c < ncat; c++) ms_by_cat[c] = 0, launches_by_cat[c] = 0;
@@ -3208,6 +3217,10 @@ static void adaptive_core_once(amd_ivf_t* h, const float* d_x, size_t start, siz
     while (((size_t)1 << ntr) <= nlist / 8) ntr++;
     if (owner->tuner_ntraces < ntr) throw EngineError("not enough traces for this nlist");
     if (query_topk == 0 || query_topk > K) throw EngineError("query_topk out of range");
+    {
+        const int pt = (int)opt(h, OPT_PHASE_TIMING, -1);
+        h->timer.off = pt >= 0 ? pt == 0 : n < 20;
+    }
     WallClock wc(h->stream);
     upload_lists(h);
     const size_t nabs = start + n;
@@ -3308,6 +3321,7 @@ static void adaptive_core_once(amd_ivf_t* h, const float* d_x, size_t start, siz
         }
     }
     fill_timing(h, ms, ln);
+    h->timer.off = false;
     h->timing[3] = wall;
     h->timing[5] = bytes;
     h->last_min_bytes = min_bytes;
@@ -3857,7 +3871,7 @@ static int opt_id(const char* key) {
 }
 static double opt_default(OptId id) {
     switch (id) {
-        case OPT_COARSE_TIES: case OPT_TIE_FIX: return -1;
+        case OPT_COARSE_TIES: case OPT_TIE_FIX: case OPT_PHASE_TIMING: return -1;
         case OPT_FIXED_ROUNDS: case OPT_ROUND_INC: case OPT_ROUND_GROW: return 0;  // (0: chosen per search)
         case OPT_ROUND_FIRST: return 12;
         case OPT_SCAN_PIPELINED: return 3;

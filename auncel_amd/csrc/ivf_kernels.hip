@@ -1370,16 +1370,41 @@ __global__ __launch_bounds__(256) void coarse_pick_kernel(CoarsePickArgs a) {
     const uint32_t n = C < PICK_CAP ? C : PICK_CAP;
     uint32_t S = 64;
     while (S < n) S <<= 1;
+    // Exact distances of the candidates in the reference's sequence (utils_simd.cpp:391-443): four running sums over the elements
+    // 4 i + l, each accumulated in order, then (s0 + s1) + (s2 + s3).  The four sums are independent chains, so four
+    // neighbouring lanes take one candidate (lane l its sum l: same rounding sequence) and a wave-instruction touches 16 rows
+    // instead of 64 -- with one thread per candidate the 3840-byte rows of d = 960 made this loop, not the matrix product, the
+    // coarse ranking's time.
     const float* xq = a.x + (size_t)q * a.dpad;
-    for (uint32_t c = tid; c < S; c += 256) {
-        unsigned long long e = ~0ull;
-        if (c < n) {
-            const uint32_t i = (uint32_t)buf[c];
-            const float ex = exact_distance<METRIC>(xq, a.centroids + (size_t)i * a.dpad, a.dpad);
-            if (!(fabsf(ex) < 3.0e38f)) bad = true;
-            e = ((unsigned long long)(Ascending ? fkey(ex) : ~fkey(ex)) << 32) | i;
+    const uint32_t sub = tid & 3;
+    for (uint32_t c0 = 0; c0 < S; c0 += 64) {
+        const uint32_t c = c0 + (tid >> 2);
+        const bool have = c < n;
+        const uint32_t i = have ? (uint32_t)buf[c] : 0u;
+        const float* y = a.centroids + (size_t)i * a.dpad;
+        float sl = 0.f;
+        if (have) {
+            for (int e = (int)sub; e < a.dpad; e += 4) {
+                if (METRIC == METRIC_L2) {
+                    const float t = y[e] - xq[e];
+                    sl += t * t;
+                } else {
+                    sl += y[e] * xq[e];
+                }
+            }
         }
-        buf[c] = e;
+        const float s1 = __shfl_xor(sl, 1);           // lanes 0/1: s0 + s1, lanes 2/3: s2 + s3 (the sum is commutative bit for bit)
+        const float pair = sl + s1;
+        const float ex = pair + __shfl_xor(pair, 2);  // (s0 + s1) + (s2 + s3)
+        __syncthreads();  // (every thread has read its candidate number before the slots are rewritten)
+        if (sub == 0) {
+            unsigned long long e = ~0ull;
+            if (have) {
+                if (!(fabsf(ex) < 3.0e38f)) bad = true;
+                e = ((unsigned long long)(Ascending ? fkey(ex) : ~fkey(ex)) << 32) | i;
+            }
+            buf[c] = e;
+        }
     }
     __syncthreads();
     for (uint32_t size = 2; size <= S; size <<= 1) {

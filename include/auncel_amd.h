@@ -342,6 +342,7 @@ int amd_ivf_set_byte_codes(amd_ivf_t* h, int enable);
  *   "plan_fused"      round planning in 3 launches (1) or 7 (0)                               1
  *   "coarse_pick"     large fixed-nprobe calls: 1 coarse rankings from matrix-core distances + exact   1
  *                     recomputation of the candidates (amd_ivf_last_coarse_pick), 0 exact distances to every centroid
+ *   "phase_timing"    HIP events around every phase (amd_ivf_last_timing): 1 always, 0 never          unset: calls of >= 20 queries
  *   "pinned_io"       per-call inputs / outputs through one page-locked block (1) or copies (0)                 1
  * amd_ivf_set_option(h, key, NAN) returns the key to "unset". */
 int amd_ivf_set_option(amd_ivf_t* h, const char* key, double value);

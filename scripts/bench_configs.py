@@ -169,6 +169,7 @@ def run_config(torch, capi, dev, c, nprobes=None, sample=64, ref_sample=2000, lo
                "metric": "IP" if metric == 0 else "L2", "batch": nq, "value": nq / dt, "unit": "queries/s", "ms_per_batch": dt * 1e3, "qps": nq / dt,
                "recall_at_k": float(recall),
                "dtype": {0: "f32", 1: "f32", 2: "u8"}[arith], "threshold_rounds_through_the_fp32_filter": int(filt),
+               "coarse_rankings_from_matrix_core_distances": int(h.last_coarse_pick()),
                "scan_ms": tm["scan_ms"], "select_ms": tm["select_ms"], "coarse_ms": tm["coarse_ms"], "phases": phases, "roofline": roof,
                "scan_algorithmic_GBps": alg / 1e6 / max(tm["scan_ms"], 1e-9), "tile_slot_efficiency": tm["slot_efficiency"],
                "cpu_oracle_qps": cpu, "cpu_threads": cores, "gpu_equals_cpu_on_sample": same, "reference": ref,
