@@ -488,6 +488,20 @@ hipStream_t make_main_stream() {
     return s;
 }
 
+// Side streams of a context, created one by one on first use.  The runtime attaches a new stream to the hardware queue with the
+// fewest streams (GPU_MAX_HW_QUEUES of them): a context that creates its four side streams together puts stream i on queue i, so
+// the stream the byte-code scans use -- aux[3] -- of EVERY context lands on the same hardware queue, where the scans of four
+// searches in flight wait for each other (the dense launch's event span swung between 1.1 and 5 ms from run to run).  Created on
+// demand, a byte-code context has one side stream, and four contexts spread over four queues.
+void ensure_aux(amd_ivf* h, int lo, int hi) {
+    if (!h->ev_fork) {
+        HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        for (int i = 0; i < 4; i++) HIP_CHECK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+    }
+    for (int i = lo; i <= hi; i++)
+        if (!h->aux[i]) HIP_CHECK(hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
+}
+
 // ------------------------------------------------------------------------------------ lists
 void upload_lists(amd_ivf* h) {
     h = ix(h);
@@ -982,13 +996,7 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
             launch_scan_mfma(ma, s);
             h->timer.end(t, s);
         } else if (nitems) {
-            if (!h->aux[0]) {
-                for (int i = 0; i < 4; i++) {
-                    HIP_CHECK(hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
-                    HIP_CHECK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
-                }
-                HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-            }
+            ensure_aux(h, 0, 3);
             size_t t = h->timer.begin(CAT_SCAN, s);
             const bool fork = true;  // every shape on a side stream (see make_main_stream)
             if (fork) {
@@ -1831,13 +1839,6 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         pa.limit = h->w_limit.as<uint32_t>();
     }
 
-    if (!h->aux[0]) {
-        for (int i = 0; i < 4; i++) {
-            HIP_CHECK(hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
-            HIP_CHECK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
-        }
-        HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    }
     uint32_t* hc = h->p_counters.as<uint32_t>();
     const uint32_t* dcnt = h->w_pl_counters.as<uint32_t>();
     // grid hints: what each round of the previous search of this shape needed
@@ -1909,11 +1910,17 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
                 ma.exact_mask = base.range;  // (range search counts the mask bits)
             }
             // the scan runs on a normal-priority side stream (see make_main_stream)
-            HIP_CHECK(hipEventRecord(h->ev_fork, s));
-            HIP_CHECK(hipStreamWaitEvent(h->aux[3], h->ev_fork, 0));
-            launch_scan_mfma(ma, h->aux[3]);
-            HIP_CHECK(hipEventRecord(h->ev_join[3], h->aux[3]));
-            HIP_CHECK(hipStreamWaitEvent(s, h->ev_join[3], 0));
+            static const bool scan_on_main = getenv("AUNCEL_AMD_SCAN_ON_MAIN") != nullptr;  // (experiment: no side stream at all)
+            if (scan_on_main) {
+                launch_scan_mfma(ma, s);
+            } else {
+                ensure_aux(h, 3, 3);
+                HIP_CHECK(hipEventRecord(h->ev_fork, s));
+                HIP_CHECK(hipStreamWaitEvent(h->aux[3], h->ev_fork, 0));
+                launch_scan_mfma(ma, h->aux[3]);
+                HIP_CHECK(hipEventRecord(h->ev_join[3], h->aux[3]));
+                HIP_CHECK(hipStreamWaitEvent(s, h->ev_join[3], 0));
+            }
         } else if (filter_ok && thr_mode) {
             FilterScanArgs fa{};
             fa.codes_frag = I->d_frag32.as<float>();
@@ -1939,6 +1946,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             fa.dev_nitems = counts ? nullptr : dcnt + CNT_QG8;
             fa.hint_nitems = hint_of(round, CNT_QG8);
             HIP_CHECK(hipMemsetAsync(h->w_surv_cnt.p, 0, 4, s));
+            ensure_aux(h, 3, 3);
             HIP_CHECK(hipEventRecord(h->ev_fork, s));
             HIP_CHECK(hipStreamWaitEvent(h->aux[3], h->ev_fork, 0));
             launch_scan_filter(fa, h->aux[3]);
@@ -1979,6 +1987,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
                 n_qg[3] = counts[CNT_QG8];
             }
             // every shape on a side stream (see make_main_stream)
+            ensure_aux(h, 0, 3);
             HIP_CHECK(hipEventRecord(h->ev_fork, s));
             for (int i = 0; i < 4; i++) HIP_CHECK(hipStreamWaitEvent(h->aux[i], h->ev_fork, 0));
             if (nstreams == 1) launch_scan(sa, n_qg, h->aux[3], h->aux[3], h->aux[3], h->aux[3]);
