@@ -401,6 +401,8 @@ struct amd_ivf {
     DevBuf w_tie_rows;  // rankings re-run through the reference's heap because of equal distances (launch_heap_tie_order)
 
     size_t dist_budget_floats = (size_t)768 << 20;  // 3 GiB of distances per scan launch
+    uint64_t dist_want_sig = 0;                      // run_rounds_device: row space the rounds of the last search of this shape wanted
+    size_t dist_want_floats = 0;
     size_t stats_host[4] = {0, 0, 0, 0};
     double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     double timing_detail[2 * 7 + 2] = {0};  // (ms, launches) per phase of the last search (CAT_*) | min bytes of dense / threshold rounds
@@ -1726,7 +1728,27 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     static const size_t budget_env = getenv("AUNCEL_AMD_DIST_BUDGET_MB") ? (size_t)atol(getenv("AUNCEL_AMD_DIST_BUDGET_MB")) << 18 : 0;
     const size_t padded_max = (maxlist + 1023) & ~(size_t)1023;
     const double all_rows = (double)n * (double)std::min<size_t>(total_nprobe, nlist) * (double)padded_max;
+    // The workspace follows the round schedule instead of a flat 8 GiB per context: what the rounds of the last
+    // search of this shape wanted (plan counters[12], + an eighth), and before any history the first round's rows -- a round
+    // that wants more than it gets defers the queries that do not fit (another pass, same results) and the next search of the
+    // shape is sized for it.  Upper limit as before: 2^31 floats.
     size_t budget = budget_env ? budget_env : std::max<size_t>(h->dist_budget_floats, (size_t)2 << 30);
+    const uint64_t bsig = (uint64_t)n * 1000003u ^ (uint64_t)first_round_in * 10007u ^ (uint64_t)total_nprobe * 101u ^ (base.bytes ? 1u : 0u) ^
+                          (base.tuner.enabled ? 2u : 0u) ^ (base.train.enabled ? 4u : 0u) ^ ((uint64_t)base.k << 40);
+    // (adaptive searches: a fixed-nprobe search knows its rows exactly and takes them -- its rounds are enqueued without a look
+    // only if nothing can be deferred)
+    if (!budget_env && chained && base.tuner.enabled) {
+        size_t want;
+        if (h->dist_want_sig == bsig && h->dist_want_floats) {
+            want = h->dist_want_floats + h->dist_want_floats / 8;
+        } else {
+            // no history: the first round's rows, and for the round behind it a quarter of the queries going on for `grow` times as
+            // many probes (what the bench workload does; a shape that wants more defers queries once and is sized for it next time)
+            const double first = (double)n * (double)std::min<size_t>(std::max<size_t>(first_round_in, 1), std::min<size_t>(total_nprobe, nlist)) * (double)padded_max;
+            want = (size_t)std::min<double>(first * (1.0 + 0.25 * grow), (double)budget);
+        }
+        budget = std::min(budget, std::max<size_t>(want, (size_t)16 << 20));
+    }
     if (all_rows < (double)budget) budget = (size_t)all_rows + 64;
     budget = std::max<size_t>(budget, I->h_list_off[nlist] + 1024 * nlist + 1024);
     if (filter_ok && budget > ((size_t)1 << 31)) budget = (size_t)1 << 31;  // (the filter's survivor entries hold 32-bit row positions)
@@ -2301,7 +2323,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     // epilogue below then runs behind that one, sync_and_flush), else one of our own.
     const size_t nh = chained ? std::min(planned_rounds ? planned_rounds - 1 : 0, MAX_HIST) : 0;
     if (chained) fetch_counters(nh);
-    auto epilogue = [h, hc, nh, chained, hints_used]() {
+    auto epilogue = [h, hc, nh, chained, hints_used, bsig]() {
         if (chained) {
             h->round_hint.assign(h->p_hist.as<uint32_t>(), h->p_hist.as<uint32_t>() + nh * 16);
             h->round_hint.insert(h->round_hint.end(), hc, hc + 16);  // the last planned round
@@ -2314,6 +2336,14 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
                     h->hinted_rounds++;
                     if (need > used + used / 8 + 8) h->short_rounds++;
                 }
+        }
+        if (chained) {  // (the most row space a round of this shape has wanted so far)
+            uint32_t want_mi = hc[12];
+            for (size_t r = 0; r < nh; r++) want_mi = std::max(want_mi, h->p_hist.as<uint32_t>()[r * 16 + 12]);
+            size_t want = (size_t)want_mi << 20;
+            if (h->dist_want_sig == bsig) want = std::max(want, h->dist_want_floats);
+            h->dist_want_sig = bsig;
+            h->dist_want_floats = want;
         }
         h->scan_bytes += *reinterpret_cast<double*>(hc + 16);
         h->scan_min_bytes += *reinterpret_cast<double*>(hc + 22);

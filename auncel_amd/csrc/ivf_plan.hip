@@ -199,6 +199,9 @@ __device__ __forceinline__ void plan_prefix_body(const PlanArgs& a) {
         a.counters[10] = s_more + s_def;     // queries that may still be unfinished after this round
         a.counters[11] = s_def;              // of those: deferred by the budget cut (the selection of this round does not see them)
         a.counters[7] = (uint32_t)(s_ndist >> 20);  // MiB of distances, for bookkeeping
+        // Mi-floats of row space the round WANTED (its queries' padded rows, deferred ones included): what the engine sizes its
+        // distance workspace by for the next search of the same shape
+        a.counters[12] = (uint32_t)((tot_need + (1u << 20) - 1) >> 20);
         a.bytes[0] += (double)s_ndist * (double)a.d * 4.0;
         if (a.min_bytes) a.min_bytes[0] += a.dense_round ? (double)s_ndist * 4.0 : (double)s_ndist / 8.0;
         if (a.min_bytes_thr && !a.dense_round) a.min_bytes_thr[0] += (double)s_ndist / 8.0;

@@ -32,17 +32,23 @@ struct RegHeap {
     uint32_t s0, s1;  // id slots
 };
 
-// reg[lane l] = val (val and l wave-uniform).  The lane select goes through M0: v_writelane_b32 may name one SGPR.
+// reg[lane l] = val (val and l wave-uniform).  The lane select goes through M0: v_writelane_b32 may name one SGPR.  M0 is a
+// register the compiler reserves for itself (it cannot be named as clobbered: "reserved registers on the clobber list may not
+// be preserved"), so every block below saves it into a scratch SGPR and puts it back -- two scalar moves per block.
 __device__ __forceinline__ void wl_u(uint32_t& reg, uint32_t val, int l) {
-    asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(reg) : "s"(val), "s"(l) : "m0");
+    uint32_t m0s;
+    asm("s_mov_b32 %[m], m0\n\ts_mov_b32 m0, %[l]\n\ts_nop 0\n\tv_writelane_b32 %[r], %[v], m0\n\ts_mov_b32 m0, %[m]"
+        : [r] "+v"(reg), [m] "=&s"(m0s)
+        : [v] "s"(val), [l] "s"(l));
 }
 
 // two registers, same lane: one M0 set-up
 __device__ __forceinline__ void wl2_u(uint32_t& r0, uint32_t v0, uint32_t& r1, uint32_t v1, int l) {
-    asm("s_mov_b32 m0, %4\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
-        : "+v"(r0), "+v"(r1)
-        : "s"(v0), "s"(v1), "s"(l)
-        : "m0");
+    uint32_t m0s;
+    asm("s_mov_b32 %[m], m0\n\ts_mov_b32 m0, %[l]\n\ts_nop 0\n\tv_writelane_b32 %[r0], %[v0], m0\n\tv_writelane_b32 %[r1], %[v1], m0\n\t"
+        "s_mov_b32 m0, %[m]"
+        : [r0] "+v"(r0), [r1] "+v"(r1), [m] "=&s"(m0s)
+        : [v0] "s"(v0), [v1] "s"(v1), [l] "s"(l));
 }
 
 __device__ __forceinline__ uint32_t rh_key(const RegHeap& h, int node) {
@@ -55,14 +61,16 @@ __device__ __forceinline__ uint32_t rh_slot(const RegHeap& h, int node) {
 }
 // node <- (key, slot); the register is picked by one branch (in C++ the compiler copies both registers around it)
 __device__ __forceinline__ void rh_set(RegHeap& h, int node, uint32_t key, uint32_t slot) {
+    uint32_t m0s;
     asm volatile(
+        "s_mov_b32 %[m], m0\n\t"
         "s_cmp_gt_u32 %[n], 63\n\ts_cbranch_scc1 1f\n\t"
         "s_mov_b32 m0, %[n]\n\ts_nop 0\n\tv_writelane_b32 %[v0], %[k], m0\n\tv_writelane_b32 %[s0], %[s], m0\n\ts_branch 2f\n"
         "1:\n\ts_sub_u32 m0, %[n], 64\n\ts_nop 0\n\tv_writelane_b32 %[v1], %[k], m0\n\tv_writelane_b32 %[s1], %[s], m0\n"
-        "2:\n\t"
-        : [v0] "+v"(h.v0), [s0] "+v"(h.s0), [v1] "+v"(h.v1), [s1] "+v"(h.s1)
+        "2:\n\ts_mov_b32 m0, %[m]\n\t"
+        : [v0] "+v"(h.v0), [s0] "+v"(h.s0), [v1] "+v"(h.v1), [s1] "+v"(h.s1), [m] "=&s"(m0s)
         : [n] "s"(node), [k] "s"(key), [s] "s"(slot)
-        : "m0", "scc");
+        : "scc");
 }
 
 // Heap.h:88-118 (the node being removed, k, still takes part in the child comparisons, as there).
@@ -114,21 +122,23 @@ template <bool IsMax> __device__ __forceinline__ void rh_pop_k100(RegHeap& h) {
     const uint32_t v = rl_u(h.v1, 100 - 64);
     const uint32_t sv = rl_u(h.s1, 100 - 64);
     int i = 1;
-    uint32_t a, b, k1, k2, c, cs;
+    uint32_t a, b, k1, k2, c, cs, m0s;
     if (IsMax) {
-        asm volatile(RH_ASM_LEVEL("s_max_u32", "s_cmp_gt_u32") RH_ASM_LEVEL("s_max_u32", "s_cmp_gt_u32") RH_ASM_LEVEL("s_max_u32", "s_cmp_gt_u32")
+        asm volatile("s_mov_b32 %[m], m0\n\t" RH_ASM_LEVEL("s_max_u32", "s_cmp_gt_u32") RH_ASM_LEVEL("s_max_u32", "s_cmp_gt_u32") RH_ASM_LEVEL("s_max_u32", "s_cmp_gt_u32")
                          RH_ASM_LEVEL("s_max_u32", "s_cmp_gt_u32") RH_ASM_LEVEL("s_max_u32", "s_cmp_gt_u32") RH_ASM_LAST("s_max_u32", "s_cmp_gt_u32")
+                     "s_mov_b32 m0, %[m]\n\t"
                      : [i] "+s"(i), [v0] "+v"(h.v0), [s0] "+v"(h.s0), [a] "=&s"(a), [b] "=&s"(b), [k1] "=&s"(k1), [k2] "=&s"(k2),
-                       [c] "=&s"(c), [cs] "=&s"(cs)
+                       [c] "=&s"(c), [cs] "=&s"(cs), [m] "=&s"(m0s)
                      : [v] "s"(v), [v1] "v"(h.v1), [s1] "v"(h.s1)
-                     : "m0", "scc");
+                     : "scc");
     } else {
-        asm volatile(RH_ASM_LEVEL("s_min_u32", "s_cmp_lt_u32") RH_ASM_LEVEL("s_min_u32", "s_cmp_lt_u32") RH_ASM_LEVEL("s_min_u32", "s_cmp_lt_u32")
+        asm volatile("s_mov_b32 %[m], m0\n\t" RH_ASM_LEVEL("s_min_u32", "s_cmp_lt_u32") RH_ASM_LEVEL("s_min_u32", "s_cmp_lt_u32") RH_ASM_LEVEL("s_min_u32", "s_cmp_lt_u32")
                          RH_ASM_LEVEL("s_min_u32", "s_cmp_lt_u32") RH_ASM_LEVEL("s_min_u32", "s_cmp_lt_u32") RH_ASM_LAST("s_min_u32", "s_cmp_lt_u32")
+                     "s_mov_b32 m0, %[m]\n\t"
                      : [i] "+s"(i), [v0] "+v"(h.v0), [s0] "+v"(h.s0), [a] "=&s"(a), [b] "=&s"(b), [k1] "=&s"(k1), [k2] "=&s"(k2),
-                       [c] "=&s"(c), [cs] "=&s"(cs)
+                       [c] "=&s"(c), [cs] "=&s"(cs), [m] "=&s"(m0s)
                      : [v] "s"(v), [v1] "v"(h.v1), [s1] "v"(h.s1)
-                     : "m0", "scc");
+                     : "scc");
     }
     rh_set(h, i, v, sv);
 }
