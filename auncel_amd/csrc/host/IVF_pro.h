@@ -4,6 +4,7 @@
 // kernel; what stays on the host is bookkeeping, Trace::SB and the acos table (host libm).
 #pragma once
 #include <string>
+#include <sys/time.h>
 #include <utility>
 #include <vector>
 

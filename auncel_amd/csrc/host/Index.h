@@ -3,6 +3,10 @@
 // compute method of the concrete classes goes to the MI355X engine through include/auncel_amd.h.
 #pragma once
 #include <cstddef>
+// (the system headers the reference's Index.h brings in: callers such as eval/bound.cpp rely on them, Auncel/Index.h:14-17)
+#include <cstdio>
+#include <sstream>
+#include <typeinfo>
 #include <cstdint>
 #include <string>
 

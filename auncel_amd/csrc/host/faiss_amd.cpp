@@ -15,6 +15,7 @@
 #include <stdexcept>
 #include <thread>
 #include <exception>
+#include <typeinfo>
 #include <vector>
 
 #include "../../../include/auncel_amd.h"
@@ -1260,7 +1261,7 @@ void write_any(const Index* idx, Writer& w) {
         w.vec(ivf->direct_map);
         write_invlists(ivf->invlists, w);
     } else {
-        FAISS_THROW_MSG("write_index: only IndexFlat and IndexIVFFlat are on this path");
+        FAISS_THROW_FMT("write_index: only IndexFlat and IndexIVFFlat are on this path (got %s)", idx ? typeid(*idx).name() : "null");
     }
 }
 

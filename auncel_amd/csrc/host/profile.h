@@ -1,6 +1,14 @@
 // faiss::Error_sys (Auncel/profile.h:29-91): offline trace training + online error-bounded search driver.
 #pragma once
 #include <string>
+// (as Auncel/profile.h:18-25)
+#include <condition_variable>
+#include <stdint.h>
+#include <sys/stat.h>
+#include <sys/time.h>
+#include <sys/types.h>
+#include <unistd.h>
+#include <unordered_map>
 #include <vector>
 
 #include "IndexIVF.h"

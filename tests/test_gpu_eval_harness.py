@@ -63,7 +63,7 @@ def world(tmp_path_factory):
 
 
 def _go(world, name, args):
-    r = subprocess.run([BINS[name]] + [str(a) for a in args], cwd=world["run"], env=world["env"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run(["stdbuf", "-o0", BINS[name]] + [str(a) for a in args], cwd=world["run"], env=world["env"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     return r.stdout
 

@@ -107,7 +107,11 @@ def test_reference_harness_builds_against_mirror(tmp_path):
     build.build_host()
     root = tmp_path / "Auncel"
     root.mkdir()
-    os.symlink("/root/reference/Auncel/eval", root / "eval")  # the sources stay where they are
+    # the sources stay where they are; the directory is a real one (through a symlinked directory "../IndexIVF.h" would resolve
+    # next to the link's target: to the reference's own headers, not to the mirror's)
+    (root / "eval").mkdir()
+    for src in ("bound", "effect_error", "overhead", "effect_time"):
+        os.symlink(f"/root/reference/Auncel/eval/{src}.cpp", root / "eval" / f"{src}.cpp")
     for f in os.listdir(build.HOST_DIR):
         if f.endswith(".h"):
             os.symlink(os.path.join(build.HOST_DIR, f), root / f)
