@@ -49,6 +49,12 @@ struct IndexIVF : Index, Level1Quantizer {
     /// coarse quantisation inside search(): -1 = the reference's switch (exact kernel below 20 queries, GEMM
     /// formulation on the matrix cores from 20 on, utils.cpp:644-655), 0 = always exact, 1 = always GEMM
     int coarse_mode = -1;
+    /// Engine policy as fields (the reference exposes nprobe / max_codes / parallel_mode the same way, IndexIVF.h:97-143); they
+    /// reach the engine through amd_ivf_set_option before the next search.  -1 = the engine's default.
+    int coarse_tie_order = -1;  ///< inside runs of bit-equal coarse distances: 0 centroid number, 1 the reference's heap, 2 redo
+    int selection = -1;         ///< 0 the reference's heap replayed for every query, 1 sorted arrays + tie replay
+    /// any other option of include/auncel_amd.h by name ("filter", "round_first", "scan_pipelined", ...)
+    void set_engine_option(const char* key, double value);
 
     IndexIVF(Index* quantizer, size_t d, size_t nlist, size_t code_size, MetricType metric = METRIC_L2);
     IndexIVF();
@@ -110,6 +116,7 @@ struct IndexIVF : Index, Level1Quantizer {
     mutable size_t interdis_size_ = 0;
     mutable const float* resident_ptr_ = nullptr;
     mutable size_t resident_n_ = 0;
+    mutable int applied_ties_ = -2, applied_select_ = -2;
     void sync_engine(bool need_tuner) const;
     void fold_stats() const;
 };

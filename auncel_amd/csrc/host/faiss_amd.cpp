@@ -461,8 +461,19 @@ amd_ivf* IndexIVF::engine() const {
     return gpu_;
 }
 
+void IndexIVF::set_engine_option(const char* key, double value) {
+    if (!gpu_) AMD(amd_ivf_create(d, nlist, (int)metric_type, device_id(amd_device), &gpu_));
+    AMD(amd_ivf_set_option(gpu_, key, value));
+}
+
 void IndexIVF::sync_engine(bool need_tuner) const {
     if (!gpu_) AMD(amd_ivf_create(d, nlist, (int)metric_type, device_id(amd_device), &gpu_));
+    if (applied_ties_ != coarse_tie_order || applied_select_ != selection) {
+        AMD(amd_ivf_set_option(gpu_, "coarse_ties", coarse_tie_order < 0 ? std::nan("") : (double)coarse_tie_order));
+        AMD(amd_ivf_set_option(gpu_, "select", selection < 0 ? std::nan("") : (double)selection));
+        applied_ties_ = coarse_tie_order;
+        applied_select_ = selection;
+    }
     const IndexFlat* qf = dynamic_cast<const IndexFlat*>(quantizer);
     FAISS_THROW_IF_NOT_MSG(qf != nullptr, "the MI355X engine needs a flat coarse quantizer");
     FAISS_THROW_IF_NOT_MSG((size_t)qf->ntotal == nlist, "quantizer is not trained (ntotal != nlist)");

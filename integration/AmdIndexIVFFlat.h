@@ -6,12 +6,14 @@
 #ifndef AMD_INDEX_IVF_FLAT_H
 #define AMD_INDEX_IVF_FLAT_H
 
+#include <cmath>
+#include <condition_variable>
 #include <cstdint>
 #include <cstring>
 #include <map>
 #include <mutex>
 #include <stdexcept>
-#include <thread>
+#include <string>
 #include <vector>
 
 #include "../IndexFlat.h"
@@ -27,12 +29,23 @@ struct AmdIndexIVFFlat : IndexIVFFlat {
     // of fewer than 20 queries, exact distances in centroid order inside runs of equal ones otherwise); false = the keys and
     // coarse_dis the caller passes to search_preassigned are uploaded and used as they are (the reference's quantizer, its BLAS)
     bool device_coarse = true;
+    // Engine policy as fields, the way the reference exposes nprobe / max_codes / parallel_mode (IndexIVF.h:97-143); they reach
+    // the engine through amd_ivf_set_option before the next search.  -1 = the engine's default.
+    int coarse_tie_order = -1;           // inside runs of bit-equal coarse distances: 0 centroid number, 1 the reference's heap, 2 redo
+    int selection = -1;                  // 0 the reference's heap replayed for every query, 1 sorted arrays + tie replay
+    /// any other option of include/auncel_amd.h by name ("filter", "round_first", "scan_pipelined", ...)
+    void set_engine_option(const char* key, double value) {
+        std::lock_guard<std::mutex> lock(mu);
+        extra_options[key] = value;
+        options_stale = true;
+    }
+    size_t max_contexts = 8;             // search contexts kept for concurrent callers (each owns a stream and work buffers)
 
     AmdIndexIVFFlat(Index* quantizer, size_t d, size_t nlist, MetricType metric = METRIC_L2, int device_ = 0)
         : IndexIVFFlat(quantizer, d, nlist, metric), device(device_) {}
     ~AmdIndexIVFFlat() override {
-        // the per-thread search contexts are clones of h and must go first (include/auncel_amd.h: "h must outlive its clones")
-        for (auto& c : contexts) amd_ivf_destroy(c.second);
+        // the search contexts are clones of h and must go first (include/auncel_amd.h: "h must outlive its clones")
+        for (amd_ivf_t* c : all_contexts) amd_ivf_destroy(c);
         if (h) amd_ivf_destroy(h);
     }
     AmdIndexIVFFlat(const AmdIndexIVFFlat&) = delete;
@@ -56,7 +69,10 @@ struct AmdIndexIVFFlat : IndexIVFFlat {
 
     void search_preassigned(idx_t n, const float* x, idx_t k, const idx_t* keys, const float* coarse_dis, float* D, idx_t* I,
                             bool store_pairs, const IVFSearchParameters* params = nullptr) const override {
-        amd_ivf_t* ctx = prepare(tune);
+        // a context for the duration of the call (returned to the pool by the lease); a trace-training pass runs on the index's
+        // own handle and has it to itself
+        Lease lease(this, tune, training && !tune);
+        amd_ivf_t* ctx = lease.ctx;
         const size_t offset = ((size_t)k >> 32) & 0xffffffffu;  // Auncel packs the query offset into k (IndexIVF.cpp:371-373)
         k &= 0xffffffff;
         const size_t np = params ? params->nprobe : nprobe;
@@ -74,8 +90,6 @@ struct AmdIndexIVFFlat : IndexIVFFlat {
         } else if (training) {  // Error_sys::sys_train: (sum_angle, kscaling) samples into the traces' raw storage
             std::vector<float*> raw;
             for (Trace& tr : t->traces) raw.push_back(&tr.trace[0].first);
-            std::lock_guard<std::mutex> lock(mu);  // (runs on the index's own handle: one training pass at a time)
-            ctx = h;
             if (device_coarse)
                 check(amd_ivf_train_samples_x(h, n, x, offset, k, t->train_D, t->train_num, -1, raw.data(), D, reinterpret_cast<int64_t*>(I)));
             else
@@ -96,11 +110,20 @@ struct AmdIndexIVFFlat : IndexIVFFlat {
     }
 
    private:
-    // Device state.  search_preassigned is const and re-entrant like the reference's: everything below is guarded by `mu`,
-    // and every calling thread searches on its own context (a clone of h: own stream and work buffers, same lists).
+    // Device state.  search_preassigned is const and re-entrant like the reference's.  Everything below is guarded by `mu`.
+    // A call checks a search context out of a bounded pool (clones of h: own stream and work buffers, same lists) and gives it
+    // back when it ends -- callers that spawn a thread per search (the reference's IndexShards does) no longer leave a context
+    // per thread id behind.  Searches hold the index "shared"; re-uploading lists / traces (after an add, a retraining) and a
+    // trace-training pass on h itself wait for the searches in flight to drain and hold it "exclusive" (ADVICE round 3).
     mutable std::mutex mu;
+    mutable std::condition_variable cv;
+    mutable int searching = 0;           // calls holding the index shared
+    mutable bool exclusive = false;
     mutable amd_ivf_t* h = nullptr;
-    mutable std::map<std::thread::id, amd_ivf_t*> contexts;  // owned: destroyed before h
+    mutable std::vector<amd_ivf_t*> all_contexts, free_contexts;  // owned: destroyed before h
+    mutable std::map<std::string, double> extra_options;
+    mutable bool options_stale = true;
+    mutable int applied_ties = -2, applied_select = -2;
     mutable bool lists_stale = true;     // set by every add: the device copy is rebuilt before the next search
     mutable bool traces_known = false;
     mutable uint64_t traces_digest = 0;  // of what the device holds
@@ -128,10 +151,76 @@ struct AmdIndexIVFFlat : IndexIVFFlat {
         return hsh;
     }
 
-    // centroids, lists, centroid table and (tune mode) traces -> device, once per change; returns the caller's context
-    amd_ivf_t* prepare(bool need_traces) const {
-        std::lock_guard<std::mutex> lock(mu);
+    struct Lease {
+        const AmdIndexIVFFlat* ix;
+        amd_ivf_t* ctx = nullptr;
+        bool excl;
+        Lease(const AmdIndexIVFFlat* ix_, bool need_traces, bool exclusive_) : ix(ix_), excl(exclusive_) {
+            std::unique_lock<std::mutex> lock(ix->mu);
+            for (;;) {
+                ix->cv.wait(lock, [&] { return !ix->exclusive; });
+                if (!excl && !ix->needs_upload(need_traces)) break;
+                // uploads and training passes wait for the searches in flight, then have the index to themselves
+                ix->exclusive = true;
+                ix->cv.wait(lock, [&] { return ix->searching == 0; });
+                try {
+                    ix->upload(need_traces);
+                } catch (...) {
+                    ix->exclusive = false;
+                    ix->cv.notify_all();
+                    throw;
+                }
+                if (excl) {  // (stays exclusive until the lease ends; the training pass runs on h)
+                    ctx = ix->h;
+                    return;
+                }
+                ix->exclusive = false;
+                ix->cv.notify_all();
+            }
+            ix->cv.wait(lock, [&] { return !ix->free_contexts.empty() || ix->all_contexts.size() < ix->max_contexts; });
+            if (ix->free_contexts.empty()) {
+                amd_ivf_t* c = nullptr;
+                check(amd_ivf_clone(ix->h, &c));
+                ix->all_contexts.push_back(c);
+                ix->free_contexts.push_back(c);
+            }
+            ctx = ix->free_contexts.back();
+            ix->free_contexts.pop_back();
+            ix->searching++;
+        }
+        ~Lease() {
+            std::lock_guard<std::mutex> lock(ix->mu);
+            if (excl) {
+                if (ctx) ix->exclusive = false;
+            } else if (ctx) {
+                ix->free_contexts.push_back(ctx);
+                ix->searching--;
+            }
+            ix->cv.notify_all();
+        }
+        Lease(const Lease&) = delete;
+        Lease& operator=(const Lease&) = delete;
+    };
+
+    // (mu held) does the device copy lag behind the index?
+    bool needs_upload(bool need_traces) const {
+        if (!h || lists_stale || options_stale || applied_ties != coarse_tie_order || applied_select != selection) return true;
+        if (need_traces) return !traces_known || digest_of_traces() != traces_digest;
+        return false;
+    }
+
+    // (mu held, no search in flight) centroids, lists, centroid table, options and (tune mode) traces -> device, once per change
+    void upload(bool need_traces) const {
         if (!h) check(amd_ivf_create((int)d, nlist, metric_type == METRIC_L2 ? 1 : 0, device, &h));
+        if (options_stale || applied_ties != coarse_tie_order || applied_select != selection) {
+            const double unset = std::nan("");
+            check(amd_ivf_set_option(h, "coarse_ties", coarse_tie_order < 0 ? unset : (double)coarse_tie_order));
+            check(amd_ivf_set_option(h, "select", selection < 0 ? unset : (double)selection));
+            for (const auto& kv : extra_options) check(amd_ivf_set_option(h, kv.first.c_str(), kv.second));
+            applied_ties = coarse_tie_order;
+            applied_select = selection;
+            options_stale = false;
+        }
         if (lists_stale) {
             const IndexFlat* q = dynamic_cast<const IndexFlat*>(quantizer);
             FAISS_THROW_IF_NOT_MSG(q, "AmdIndexIVFFlat needs an IndexFlat quantizer");
@@ -179,9 +268,6 @@ struct AmdIndexIVFFlat : IndexIVFFlat {
                 traces_digest = dg;
             }
         }
-        amd_ivf_t*& c = contexts[std::this_thread::get_id()];
-        if (!c) check(amd_ivf_clone(h, &c));
-        return c;
     }
 };
 

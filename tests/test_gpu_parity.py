@@ -715,3 +715,31 @@ def test_non_finite_distances_in_the_first_list(capi, metric, select):
         assert np.array_equal(I, OI) and np.array_equal(bits(D), bits(OD))
         st = h.stats()
         assert [st["nlist"], st["ndis"], st["nheap_updates"]] == list(ost)
+
+
+def test_options_through_the_abi(capi, monkeypatch):
+    """amd_ivf_set_option / amd_ivf_get_option: what was set wins over the debugging environment variable of the same meaning,
+    which wins over the default; an unknown key is an engine error (-2); a search context answers for its index"""
+    case, gold = load_case(FIXED[0])
+    h = make_index(capi, case, gold)
+    assert h.get_option("select") == 1 and h.get_option("coarse_ties") == -1 and h.get_option("scan_pipelined") == 3
+    monkeypatch.setenv("AUNCEL_AMD_SELECT", "heap")
+    assert h.get_option("select") == 0
+    h.set_option("select", 1)
+    assert h.get_option("select") == 1
+    c = h.clone()
+    assert c.get_option("select") == 1
+    c.set_option("round_first", 6)
+    assert h.get_option("round_first") == 6
+    h.set_option("select", None)
+    assert h.get_option("select") == 0
+    monkeypatch.delenv("AUNCEL_AMD_SELECT")
+    assert h.get_option("select") == 1
+    with pytest.raises(capi.EngineError) as e:
+        h.set_option("no_such_option", 1)
+    assert e.value.code == -2
+    k = int(case["ks"][0])
+    for sel in (0, 1):  # both selections give the golden result
+        h.set_option("select", sel)
+        D, I = h.search_preassigned(case["xq"], k, gold["coarse_keys_sse"], gold["coarse_dis_sse"])
+        assert np.array_equal(I, gold[f"I_k{k}"]) and np.array_equal(bits(D), bits(gold[f"D_k{k}"]))
