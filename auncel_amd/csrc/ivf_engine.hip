@@ -330,7 +330,8 @@ struct amd_ivf {
     // fp32 copy of the lists in fragment order + |y|^2 / |y| per slot (ivf_filter.hip), kept when the data does not qualify for
     // byte codes: threshold rounds run as a matrix-core filter over it, the exact distance only for what the filter keeps
     DevBuf d_frag32, d_yn;
-    bool have_frag32 = false, frag32_possible = false;
+    std::atomic<bool> have_frag32{false};  // (read without the lock by search contexts: ensure_frag32's double-checked creation)
+    bool frag32_possible = false;
     int allow_filter = 1;
     DevBuf w_xf, w_xn, w_surv, w_surv_cnt;  // packed queries + norms of the current search, the filter's survivors
 
@@ -419,6 +420,7 @@ struct amd_ivf {
     amd_ivf* parent = nullptr;
     bool is_clone = false;  // made by amd_ivf_clone: a search context of its own over the parent's index data
     std::mutex upload_mu;   // owner only: serialises the first upload of the lists
+    std::mutex async_mu;    // owner only: serialises the creation of the asynchronous pool
     std::vector<std::unique_ptr<amd_ivf>> kids;
     // side streams for the sparse tile shapes of a round (fork / join around the dense launch)
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1251,7 +1253,15 @@ struct DirectOut {
         h->out_I = i ? static_cast<int64_t*>(i) : nullptr;
         h->last_direct_out = h->out_D != nullptr;
     }
-    ~DirectOut() { h->out_D = nullptr, h->out_I = nullptr; }
+    // Leaving by an exception (a failed HIP call, ERR_LOG_OVERFLOW from the selection) while kernels that store into the caller's
+    // buffers may still be in flight: wait for them, the caller is about to get its buffers back with an error.
+    ~DirectOut() {
+        if (h->out_D && std::uncaught_exceptions() > 0) {
+            (void)hipStreamSynchronize(h->stream);
+            if (h->fix_stream) (void)hipStreamSynchronize(h->fix_stream);
+        }
+        h->out_D = nullptr, h->out_I = nullptr;
+    }
 };
 
 // Final read-back of a search: results, error word and counters behind one synchronisation.  An error is raised after the
@@ -4063,6 +4073,9 @@ static void async_worker(AsyncPool* p, size_t i) {
 }
 
 static AsyncPool* async_pool(amd_ivf* h) {
+    // (two threads submitting on one handle for the first time must not both build a pool: ADVICE round 3; a mutex of its own --
+    // amd_ivf_clone below takes the upload mutex)
+    std::lock_guard<std::mutex> lock(h->async_mu);
     if (h->async) return h->async;
     std::unique_ptr<AsyncPool> p(new AsyncPool);
     const int depth = std::min(std::max(h->async_depth, 1), 16);
