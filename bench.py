@@ -601,16 +601,30 @@ def main():
             finish()
 
     def run_steps(nsteps, acc):
-        """steps j, j + nfl, ... on context j; acc collects per-step kernel timings and the last result"""
+        """nsteps steps over the nfl contexts (each pulls its next step when it is done with one); acc collects per-step kernel
+        timings and the result of the step accounted last"""
         if use_async and nfl > 1:
             return run_steps_async(nsteps, acc)
         errs = []
+
+        counter = [0]
+
+        def next_step():
+            # (steps are pulled, not dealt: a context that falls behind -- it started later, or its queue neighbours were busier --
+            # does one step fewer instead of holding the end of the region for a step of its own)
+            with lock:
+                sn = counter[0]
+                counter[0] += 1
+            return sn
 
         def worker(j):
             try:
                 if j and stagger_s:
                     time.sleep(j * stagger_s)  # start the contexts out of phase (scan of one under selection of the other)
-                for sn in range(j, nsteps, nfl):
+                while True:
+                    sn = next_step()
+                    if sn >= nsteps:
+                        break
                     res = step(ctxs[j], sn, j)
                     tm = ctxs[j].last_timing()
                     hints = ctxs[j].last_round_hints()
