@@ -549,7 +549,8 @@ def main():
 
     def step(ctx, stepno, slot=0):
         """step s searches slice s mod nsl of the resident queries: consecutive steps never see the same batch"""
-        start = ts + (stepno % nsl) * ses
+        # (stepno // nfl: with as many slices as contexts, stepno % nsl alone would hand a context the same slice every time)
+        start = ts + ((stepno + stepno // nfl) % nsl) * ses
         np_ = np.zeros(nall, dtype=np.uint64)
         tr_ = np.zeros(nall, dtype=np.float32)
         D, I = ctx.search_adaptive(start, ses, topk, hyper["mult"], hyper["std_m"], req, np_, tr_, out=outs[slot])
@@ -601,30 +602,19 @@ def main():
             finish()
 
     def run_steps(nsteps, acc):
-        """nsteps steps over the nfl contexts (each pulls its next step when it is done with one); acc collects per-step kernel
-        timings and the result of the step accounted last"""
+        """steps j, j + nfl, ... on context j; acc collects per-step kernel timings and the last result"""
         if use_async and nfl > 1:
             return run_steps_async(nsteps, acc)
         errs = []
-
-        counter = [0]
-
-        def next_step():
-            # (steps are pulled, not dealt: a context that falls behind -- it started later, or its queue neighbours were busier --
-            # does one step fewer instead of holding the end of the region for a step of its own)
-            with lock:
-                sn = counter[0]
-                counter[0] += 1
-            return sn
 
         def worker(j):
             try:
                 if j and stagger_s:
                     time.sleep(j * stagger_s)  # start the contexts out of phase (scan of one under selection of the other)
-                while True:
-                    sn = next_step()
-                    if sn >= nsteps:
-                        break
+                # (dealt, not pulled: with steps pulled from a shared counter a context can come out of a short warm-up without
+                # having searched at all, and its first search -- workspaces, streams -- lands in the timed region: 2.4-2.5 vs
+                # 2.7 M q/s at --steps 20 --warmup 5)
+                for sn in range(j, nsteps, nfl):
                     res = step(ctxs[j], sn, j)
                     tm = ctxs[j].last_timing()
                     hints = ctxs[j].last_round_hints()
