@@ -3275,11 +3275,16 @@ static void adaptive_core_once(amd_ivf_t* h, const float* d_x, size_t start, siz
     const size_t nabs = start + n;
     // per-absolute-query arrays on the device, shared by all lanes
     DevBuf &d_req = h->w_misc2, &d_np = h->w_misc3;
-    d_req.ensure(nabs * 4 * 2 + (gt_D ? nabs * K * 4 : 0) + 64);
+    // (sized for every resident query at once: a caller that walks through slices of its resident queries would otherwise grow
+    // these arrays slice by slice -- and a reallocation frees device memory, which waits for every stream of the device: with
+    // four searches in flight the first visit of a context to a later slice cost a fifth of a step)
+    const amd_ivf* rsrc = h->is_clone && h->n_resident == 0 && h->parent ? h->parent : h;
+    const size_t ncap = std::max(nabs, rsrc->n_resident);
+    d_req.ensure(ncap * 4 * 2 + (gt_D ? ncap * K * 4 : 0) + 64);
     float* dreq = d_req.as<float>();
-    float* dtr = dreq + nabs;
-    float* dgt = gt_D ? dtr + nabs : nullptr;
-    d_np.ensure(nabs * 8);
+    float* dtr = dreq + ncap;
+    float* dgt = gt_D ? dtr + ncap : nullptr;
+    d_np.ensure(ncap * 8);
     // only the entries of this call's queries are read or written on the device (everything is indexed by absolute id)
     h2d_small(h, dreq + start, require_acc + start, n * 4, h->stream);
     h2d_small(h, dtr + start, t_recalls + start, n * 4, h->stream);
