@@ -1,6 +1,6 @@
 #!/bin/bash
 # copy what scripts/refresh_round.sh brought back under gpurun_out/ into the tracked profiles/ directory
-tag=${1:-r03}
+tag=${1:-r04}
 cp gpurun_out/summary_$tag/${tag}_summary.md gpurun_out/summary_$tag/${tag}_pmc.json gpurun_out/summary_$tag/${tag}_kernel_stats.csv profiles/
 cp gpurun_out/bench_$tag.json profiles/${tag}_bench_line.json
 cp gpurun_out/perf_scan_$tag.txt profiles/${tag}_fixed_nprobe.txt
@@ -10,4 +10,6 @@ cp gpurun_out/effect_time_$tag.jsonl profiles/${tag}_effect_time.jsonl
 cp gpurun_out/latency1_$tag.txt profiles/${tag}_latency_batch1.txt
 cp gpurun_out/bw_probe_$tag.txt profiles/${tag}_bw_probe.txt
 cp gpurun_out/gpu_tests_$tag.txt profiles/${tag}_gpu_tests.txt
+grep -v "rocprofv3\|^W2026\|^E2026" gpurun_out/in_flight_busy_$tag.txt > profiles/${tag}_in_flight_busy.txt
+cp gpurun_out/bench_driver_flags_$tag.json profiles/${tag}_bench_line_driver_flags.json
 for n in fp32_path exact_ties cfg5; do cp gpurun_out/timeline_${n}_$tag.txt profiles/${tag}_timeline_$n.txt; done
