@@ -530,6 +530,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AUNCEL_MFMA
 // kernel above (MfmaScanArgs::exact_mask).
 // DENSE: the same stream for rounds that store every distance (round 0): accumulators start at zero, |x|^2 and the row offset of a
 // register's query come from LDS four registers at a time.
+// Cycle accounting of the waves of the kernel below (an experiment build: AUNCEL_AMD_CXXFLAGS=-DAUNCEL_AMD_SCAN_PROF; the counters
+// are printed per launch by launch_scan_mfma).  [0] waves, [1] lifetime, [2] start -> first block's operands ready, [3] waiting
+// for list blocks, [4] MFMAs + epilogue of the blocks, [5] per-item prologue after the first, [6] mask stores, [7] items
+#ifdef AUNCEL_AMD_SCAN_PROF
+__device__ unsigned long long g_scan_prof[8];
+#define SCAN_PROF_NOW() __builtin_amdgcn_s_memtime()
+#else
+#define SCAN_PROF_NOW() 0ull
+#endif
 template <int METRIC, int NKS, bool DENSE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void scan_mfma_thr_kernel(MfmaScanArgs a) {
     static_assert(NKS >= 1 && NKS <= 4, "query operand resident in registers");
@@ -547,6 +556,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const int m = lane & 31, h = lane >> 5;
     constexpr size_t qstride = (size_t)NKS * 32;
     constexpr size_t block_bytes = (size_t)NKS * 1024;
+    [[maybe_unused]] const unsigned long long pt_start = SCAN_PROF_NOW();
+    [[maybe_unused]] unsigned long long pt_wait = 0, pt_work = 0, pt_first = 0, pt_pro = 0, pt_mask = 0, pt_items = 0;
     // item headers through the scalar cache (constant address space: nothing this kernel stores aliases them)
     typedef int v8i __attribute__((ext_vector_type(8)));
     typedef const v8i __attribute__((address_space(4)))* item_cp;
@@ -597,6 +608,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     uint32_t* mask32 = reinterpret_cast<uint32_t*>(a.mask);
 
     for (;;) {
+        [[maybe_unused]] const unsigned long long pt_item = SCAN_PROF_NOW();
         const uint32_t wn = wi + w.step;
         const bool has_next = exists(wn);
         // (header two items ahead: consumed when `nxt` becomes `cur`)
@@ -657,8 +669,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         }
 
         const uint32_t nblk = ((cur.nvec + 63) >> 6) * 2;  // lists are stored in pairs of blocks: a 64-candidate mask word is two of ours
+#ifdef AUNCEL_AMD_SCAN_PROF
+        {
+            asm volatile("" ::"v"(cinit), "v"(af[0]), "v"(af[NKS - 1]));
+            const unsigned long long t = SCAN_PROF_NOW();
+            if (pt_items == 0) pt_first = t - pt_start;
+            else pt_pro += t - pt_item;
+            pt_items++;
+        }
+#endif
         auto step = [&](v4i (&b)[NKS], int& cyv, uint32_t i) {
             __builtin_amdgcn_sched_barrier(0);
+#ifdef AUNCEL_AMD_SCAN_PROF
+            const unsigned long long t_a = SCAN_PROF_NOW();
+            asm volatile("" ::"v"(b[0]), "v"(b[NKS - 1]), "v"(cyv));
+            const unsigned long long t_b = SCAN_PROF_NOW();
+            pt_wait += t_b - t_a;
+#endif
             v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[0], b[0], cinit, 0, 0, 0);
 #pragma unroll
             for (int s = 1; s < NKS; s++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[s], b[s], acc, 0, 0, 0);
@@ -691,6 +718,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                         if (vok && (uint32_t)(8 * g + 4 * h + i) < cur.npair) a.dist[off] = (float)res;
                     }
                 });
+#ifdef AUNCEL_AMD_SCAN_PROF
+                pt_work += SCAN_PROF_NOW() - t_b;
+#endif
                 return;
             }
             // One v_cmp per register is the ballot of its 64 candidates.  Everything else -- the two lane writes that park the
@@ -723,11 +753,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 });
             });
             if (lane < 32) s_mask[DENSE ? 0 : wave][DENSE ? 0 : i][lane] = (uint32_t)word;
+#ifdef AUNCEL_AMD_SCAN_PROF
+            asm volatile("" ::"v"(word));
+            pt_work += SCAN_PROF_NOW() - t_b;
+#endif
         };
         for (uint32_t i = 0; i < nblk; i += 2) {
             step(b0, cy0, i);
             step(b1, cy1, i + 1);
         }
+        [[maybe_unused]] const unsigned long long pt_m0 = SCAN_PROF_NOW();
         if (!DENSE) {
             // rows start on multiples of 64 floats, chunks on multiples of 64 vectors: word index = (row + position) / 32; the
             // item's words of a query are consecutive there (nblk of them, an even number: 8-byte pieces at least)
@@ -752,6 +787,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 }
             }
         }
+#ifdef AUNCEL_AMD_SCAN_PROF
+        pt_mask += SCAN_PROF_NOW() - pt_m0;
+#endif
         if (!has_next) break;
         cur = nxt;
         nxt = nn;
@@ -759,6 +797,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         po = pon;
         wi = wn;
     }
+#ifdef AUNCEL_AMD_SCAN_PROF
+    if (lane == 0) {
+        atomicAdd(&g_scan_prof[0], 1ull);
+        atomicAdd(&g_scan_prof[1], SCAN_PROF_NOW() - pt_start);
+        atomicAdd(&g_scan_prof[2], pt_first);
+        atomicAdd(&g_scan_prof[3], pt_wait);
+        atomicAdd(&g_scan_prof[4], pt_work);
+        atomicAdd(&g_scan_prof[5], pt_pro);
+        atomicAdd(&g_scan_prof[6], pt_mask);
+        atomicAdd(&g_scan_prof[7], pt_items);
+    }
+#endif
 }
 
 uint32_t mfma_chunk() {
@@ -797,6 +847,18 @@ void launch_scan_mfma(const MfmaScanArgs& a, hipStream_t s) {
                                      : a.xcd_chunks ? ((nwg + 7) / 8) * 8 : nwg),
                         block(256);
         LAUNCH(kern, grid, block, 0, s, a);
+#ifdef AUNCEL_AMD_SCAN_PROF
+        if (getenv("AUNCEL_AMD_SCAN_PROF")) {
+            unsigned long long c[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(g_scan_prof), sizeof c);
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_scan_prof), z, sizeof z);
+            if (c[0])
+                fprintf(stderr, "[scan prof] %s grid %u waves %llu items %llu | per wave (cycles of s_memtime): life %.0f first %.0f wait %.0f work %.0f "
+                        "item-prologue %.0f mask %.0f\n", masked ? "thr" : "dense", grid.x, c[0], c[7], (double)c[1] / c[0], (double)c[2] / c[0],
+                        (double)c[3] / c[0], (double)c[4] / c[0], (double)c[5] / c[0], (double)c[6] / c[0]);
+        }
+#endif
     };
     auto pick_ks = [&](auto metric, auto msk) {
         constexpr int M = decltype(metric)::value;
