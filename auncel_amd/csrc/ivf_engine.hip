@@ -54,13 +54,15 @@ enum OptId {
                         // (search again the queries that read such a run); unset: heap for calls of < 20 queries, else 0
     OPT_SELECT,         // 0 the reference's heap replayed for every query, 1 sorted arrays + tie_fix_kernel (k <= 128)
     OPT_TIE_FIX,        // 0 one pass at the end, 1 behind every round on a side stream; unset: by call size and concurrency
-    OPT_FILTER,         // fp32 threshold rounds through the matrix-core filter + exact rescoring (1) or on the vector ALU (0)
+    OPT_FILTER,         // fp32 threshold rounds: matrix-core filter + exact rescoring over fp16 (2) or fp32 (1) copies of the lists, or the
+                        // vector ALU throughout (0)
     OPT_FIXED_ROUNDS,   // fixed-nprobe searches: 1 one dense round, 2 dense + threshold round; unset: by nprobe
     OPT_ROUND_FIRST,    // adaptive search: probes of the first round (12)
     OPT_ROUND_GROW,     // ... factor by which later rounds grow (12 byte codes, 6 fp32 filter, 3.5 fp32)
     OPT_ROUND_INC,      // ... probes a later round adds at least
     OPT_DIRECT_OUT,     // results written straight into page-locked caller buffers (1) or copied at the end (0)
-    OPT_SCAN_PIPELINED, // byte-code scan through scan_mfma_thr_kernel: bit 0 dense rounds, bit 1 threshold rounds (3: both; 0: scan_mfma_kernel)
+    OPT_SCAN_PIPELINED, // byte-code scan: bit 0 dense, bit 1 threshold rounds through scan_mfma_thr_kernel, bit 2 threshold rounds with 64 queries
+                        // per item through scan_mfma_pair_kernel (7: all; 0: scan_mfma_kernel)
     OPT_PLAN_FUSED,     // round planning in three launches (1) or seven (0)
     OPT_COARSE_PICK,    // exact coarse top-nprobe of large calls from matrix-core distances + exact recomputation of the candidates (1) or
                         // from exact distances to every centroid (0)
@@ -332,8 +334,12 @@ struct amd_ivf {
     DevBuf d_frag32, d_yn;
     std::atomic<bool> have_frag32{false};  // (read without the lock by search contexts: ensure_frag32's double-checked creation)
     bool frag32_possible = false;
+    // the fp16 form of the filter's list copy (ivf_filter.hip): scaled halves in fragment order + the range they were scaled by
+    DevBuf d_frag16, d_yinfo;
+    std::atomic<int> frag16_state{0};      // 0 not built yet, 1 there, -1 the lists have no usable scale (the fp32 form serves)
     int allow_filter = 1;
     DevBuf w_xf, w_xn, w_surv, w_surv_cnt;  // packed queries + norms of the current search, the filter's survivors
+    DevBuf w_qinfo, w_fparams;              // fp16 form: the queries' range, the search's FilterParams
 
     // Auncel state
     DevBuf d_interdis;
@@ -530,24 +536,20 @@ void upload_lists(amd_ivf* h) {
                              hipMemcpyHostToDevice, h->stream));
     h->have_codes8 = h->allow_bytes && nt > 0 && h->db_range.bytes() && (double)h->d * 255.0 * 255.0 < 2147483648.0;
     // (byte-valued lists get their fp32 fragment copy only when a search asks for the fp32 path: ensure_frag32)
-    h->have_frag32 = !h->have_codes8 && h->allow_filter && nt > 0 && nt < 0xffffffffull;
+    // (the filter's copy of the lists -- fp16 or fp32 fragment order, by the "filter" option -- is built by the first fp32 search
+    // that wants it: ensure_frag16 / ensure_frag32)
+    h->have_frag32 = false;
+    h->frag16_state = 0;
     h->frag32_possible = h->allow_filter && nt > 0 && nt < 0xffffffffull;
-    if (h->have_codes8 || h->have_frag32) {
+    if (h->have_codes8 || h->frag32_possible) {
         h->h_block_off.assign(h->nlist + 1, 0);
         for (size_t l = 0; l < h->nlist; l++) h->h_block_off[l + 1] = h->h_block_off[l] + mfma_list_blocks(h->h_ids[l].size());
         h->d_block_off.ensure((h->nlist + 1) * sizeof(uint64_t));
         HIP_CHECK(hipMemcpyAsync(h->d_block_off.p, h->h_block_off.data(), (h->nlist + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
     }
-    if (h->have_frag32) {
-        const uint64_t nblk = h->h_block_off[h->nlist];
-        h->d_frag32.ensure(nblk * filter_steps(h->d) * 1024);
-        h->d_yn.ensure(nblk * 32 * sizeof(float));
-        launch_frag32_from_f32(h->d_codes.as<float>(), h->d_list_off.as<uint64_t>(), h->d_block_off.as<uint64_t>(), (uint32_t)h->nlist, nblk, h->d,
-                               h->dpad, h->metric, h->d_frag32.as<float>(), h->d_yn.as<float>(), h->stream);
-    } else {
-        h->d_frag32.release();
-        h->d_yn.release();
-    }
+    h->d_frag32.release();
+    h->d_frag16.release();
+    h->d_yn.release();
     if (h->have_codes8) {
         const uint64_t nblk = h->h_block_off[h->nlist];
         h->d_frag.ensure(nblk * mfma_ksteps(h->d) * 1024);
@@ -580,8 +582,38 @@ bool byte_queries(amd_ivf* ws, const amd_ivf* index, const float* d_x, size_t n,
 // fp32 searches: threshold rounds as matrix-core filter + exact rescoring (ivf_filter.hip) when the index keeps the
 // fragment-ordered fp32 copy.  AUNCEL_AMD_FILTER=0 (read per search: the tests run both ways) keeps scan_tiles_kernel throughout.
 bool filter_available(const amd_ivf* ws, const amd_ivf* index, bool bytes) {
-    if (index->opt.get(OPT_FILTER, 1) == 0) return false;
+    if (index->opt.get(OPT_FILTER, 2) == 0) return false;
     return !bytes && (index->have_frag32 || index->frag32_possible) && ws->allow_filter;
+}
+// ... in fp16 (option "filter" = 2, the default): half the bytes of a pass and fp16 matrix-core rates; false where the lists have
+// no usable scale (a non-finite element, magnitudes outside 2^+-24, a row tiny beside the largest) or the fp32 form was asked for
+bool ensure_frag16(amd_ivf* index) {
+    if (index->opt.get(OPT_FILTER, 2) != 2) return false;
+    if (index->frag16_state != 0) return index->frag16_state > 0;
+    std::lock_guard<std::mutex> lock(index->upload_mu);
+    if (index->frag16_state != 0) return index->frag16_state > 0;
+    if (!index->frag32_possible) return false;
+    use_device(index);
+    const uint64_t nblk = index->h_block_off[index->nlist];
+    const size_t nt = index->h_list_off[index->nlist];
+    index->d_yinfo.ensure(16);
+    HIP_CHECK(hipMemsetAsync(index->d_yinfo.p, 0, 16, index->stream));
+    launch_amax(index->d_codes.as<float>(), nt, index->dpad, index->d_yinfo.as<uint32_t>(), index->stream);
+    uint32_t info[4] = {0, 0, 0, 0};
+    HIP_CHECK(hipMemcpyAsync(info, index->d_yinfo.p, 16, hipMemcpyDeviceToHost, index->stream));
+    HIP_CHECK(stream_sync(index->stream));
+    if (filter_half_scale(info, index->d) == 0.f) {
+        index->frag16_state = -1;
+        return false;
+    }
+    index->d_frag16.ensure(nblk * filter_steps16(index->d) * 1024);
+    index->d_yn.ensure(nblk * 32 * sizeof(float));
+    launch_frag16_from_f32(index->d_codes.as<float>(), index->d_list_off.as<uint64_t>(), index->d_block_off.as<uint64_t>(), (uint32_t)index->nlist,
+                           nblk, index->d, index->dpad, index->metric, index->d_yinfo.as<uint32_t>(), index->d_frag16.as<float>(),
+                           index->d_yn.as<float>(), index->stream);
+    HIP_CHECK(stream_sync(index->stream));
+    index->frag16_state = 1;
+    return true;
 }
 // the fragment-ordered fp32 copy of lists that also have byte codes is built the first time an fp32 search runs over them
 void ensure_frag32(amd_ivf* index) {
@@ -1715,7 +1747,8 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     // fp32 lists with the matrix-core filter (ivf_filter.hip): threshold rounds cost their list bytes too, and the first round --
     // the only one computed on the vector ALU in the reference's rounding sequence -- shrinks to one probe per query
     const bool filter_ok = filter_available(h, I, base.bytes) && !base.range;
-    if (filter_ok) ensure_frag32(I);
+    const bool filter_half = filter_ok && ensure_frag16(I);
+    if (filter_ok && !filter_half) ensure_frag32(I);
     if (filter_ok && base.tuner.enabled) first_round = filter_first_probes(I, (size_t)base.k, 64);
     // (byte codes: a round is bound by its one pass over the lists, x 12; the fp32 filter's rounds are bound by matrix-core issue
     // from ~50 queries per list on, so what a round scans past the queries' stop points is paid for: x 6 measured best --
@@ -1834,11 +1867,20 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     }
     constexpr size_t SURV_CAP = (size_t)16 << 20;
     if (filter_ok) {
-        h->w_xf.ensure(n * (size_t)filter_steps(h->d) * 8 * sizeof(float));
+        h->w_xf.ensure(n * (size_t)filter_steps(h->d) * 8 * sizeof(float));  // (the fp16 rows are shorter)
         h->w_xn.ensure(n * sizeof(float));
         h->w_surv.ensure(SURV_CAP * sizeof(uint4));
         h->w_surv_cnt.ensure(4);
-        launch_filter_queries(base.d_x, n, h->d, h->dpad, h->metric, h->w_xf.as<float>(), h->w_xn.as<float>(), s);
+        if (filter_half) {
+            h->w_qinfo.ensure(16);
+            h->w_fparams.ensure(sizeof(FilterParams));
+            HIP_CHECK(hipMemsetAsync(h->w_qinfo.p, 0, 16, s));
+            launch_amax(base.d_x, n, h->dpad, h->w_qinfo.as<uint32_t>(), s);
+            launch_filter_queries16(base.d_x, n, h->d, h->dpad, h->metric, h->w_qinfo.as<uint32_t>(), I->d_yinfo.as<uint32_t>(),
+                                    h->w_xf.as<float>(), h->w_xn.as<float>(), h->w_fparams.as<FilterParams>(), s);
+        } else {
+            launch_filter_queries(base.d_x, n, h->d, h->dpad, h->metric, h->w_xf.as<float>(), h->w_xn.as<float>(), s);
+        }
     }
     pa.seg_begin = h->w_seg_begin.as<uint32_t>();
     pa.dist_base = h->w_pl_dist_base.as<unsigned long long>();
@@ -1893,14 +1935,17 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     auto plan_round = [&](size_t round_len) {
         pa.round_len = (uint32_t)round_len;
         pa.dense_round = !(base.range || (planned_rounds > 0 && !no_thr));
-        if (base.bytes) pa.mfma_chunk = pa.dense_round || base.range ? mfma_chunk() : mfma_chunk_thr();
+        if (base.bytes) {
+            pa.mfma_chunk = pa.dense_round || base.range ? mfma_chunk() : mfma_chunk_thr();
+            pa.mfma_qblock = pa.dense_round ? MFMA_QBLOCK : mfma_thr_qblock(h->d, (int)opt(h, OPT_SCAN_PIPELINED, 7), base.range);
+        }
         if (filter_ok) {  // threshold rounds of an fp32 search: items in the matrix-core form (a chunk x a block of 32 queries)
             const bool mf = !pa.dense_round;
             pa.mfma_chunk = mf ? filter_item_vectors(h->d) : 0;
             pa.mfma_qblock = mf ? filter_item_queries(h->d) : MFMA_QBLOCK;
             pa.block_off = mf ? I->d_block_off.as<uint64_t>() : nullptr;
             pa.qblock = scan_qblock(mf);
-            pa.row_bytes = (uint32_t)h->dpad * 4;
+            pa.row_bytes = mf && filter_half ? filter_steps16(h->d) * 32u : (uint32_t)h->dpad * 4;  // (what a pass streams per vector)
         }
         pa.history = chained && planned_rounds >= 1 && planned_rounds <= MAX_HIST ? h->w_pl_hist.as<uint32_t>() + (planned_rounds - 1) * 16 : nullptr;
         pa.first_plan = planned_rounds == 0;
@@ -1933,7 +1978,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             ma.nitems = counts ? counts[CNT_QG8] : 0;
             ma.dev_nitems = counts ? nullptr : dcnt + CNT_QG8;
             ma.hint_nitems = hint_of(round, CNT_QG8);
-            ma.pipelined = (int)opt(h, OPT_SCAN_PIPELINED, 3);
+            ma.pipelined = (int)opt(h, OPT_SCAN_PIPELINED, 7);
             static const int scan_debug = getenv("AUNCEL_AMD_SCAN_DEBUG") ? atoi(getenv("AUNCEL_AMD_SCAN_DEBUG")) : 0;
             ma.debug = scan_debug;
             if (thr_mode) {
@@ -1955,7 +2000,9 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             }
         } else if (filter_ok && thr_mode) {
             FilterScanArgs fa{};
-            fa.codes_frag = I->d_frag32.as<float>();
+            fa.codes_frag = filter_half ? I->d_frag16.as<float>() : I->d_frag32.as<float>();
+            fa.half = filter_half ? 1 : 0;
+            fa.params = filter_half ? h->w_fparams.as<float>() : nullptr;
             fa.yn = I->d_yn.as<float>();
             fa.xf = h->w_xf.as<float>();
             fa.xn = h->w_xn.as<float>();
@@ -3928,7 +3975,8 @@ static double opt_default(OptId id) {
         case OPT_COARSE_TIES: case OPT_TIE_FIX: case OPT_PHASE_TIMING: return -1;
         case OPT_FIXED_ROUNDS: case OPT_ROUND_INC: case OPT_ROUND_GROW: return 0;  // (0: chosen per search)
         case OPT_ROUND_FIRST: return 12;
-        case OPT_SCAN_PIPELINED: return 3;
+        case OPT_SCAN_PIPELINED: return 7;
+        case OPT_FILTER: return 2;
         default: return 1;
     }
 }

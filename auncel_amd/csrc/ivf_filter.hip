@@ -24,11 +24,27 @@
 //   approx = xn + yn - 2 p in fp32:             three more roundings, each <= u * 2 S
 //   =>  |approx - r| <= (1.5 d + 20) u S.  The kernel uses C = (2 d + 32) u (a quarter more, and the rounding of the test
 //   itself) and keeps iff (1 - C)(xn + yn) - 2 p < thr.  Inner product: |p - r| <= 2 d u |x||y|; kept iff p + C |x||y| > thr.
+//
+// The fp16 form (HALF: round 4).  The filter only has to be *safe*, so its operands need not be the fp32 values: lists and
+// queries are also kept as fp16, scaled by powers of two s_y, s_x that bring their largest magnitudes into [2^14, 2^15) (no
+// overflow), 16 dimensions per piece in the operand order of v_mfma_f32_32x32x16_f16.  An element that lands below 2^-14 is
+// off by at most 2^-25 absolutely; for a pair whose rows' largest scaled elements are a, b that adds at most 2^-25 d (a + b) to
+// the sum, i.e. 2^-25 d (1 / a + 1 / b) of |x16||y16| >= a b -- so one scale per matrix is used only while every row that is not
+// all zero keeps its largest element above max(1, d / 1024) after scaling (half_scale_of: rows within 2^-12 of the largest), which
+// keeps that term below 2^-14 of |x||y|.  That halves the bytes of a pass and
+// replaces sixteen fp32 MFMAs per 32 dimensions by two fp16 ones (a 70-queries-per-list pass was bound by the fp32 matrix pipe).
+// Products of two fp16 values are exact in fp32, so the only new error is the operands' rounding: |fl16(x_i) fl16(y_i) - x_i y_i|
+// <= (2^-10 + 2^-22) |x_i y_i|, summed <= (2^-10 + 2^-22) |x||y| <= (2^-10 + 2^-22) S / 2, twice that in an L2 distance.  The keep
+// test is the same with C16 = C + 2^-10 + 2^-12 and p = ps * (the MFMA sum), ps = 1 / (s_x s_y) (a power of two: exact).
+// Where every element on both sides is an integer of magnitude <= 2048 fp16 holds it exactly: s = 1 and C16 = C.  Queries
+// with a non-finite element (no usable scale) make the whole call keep every candidate (C < 0 in FilterParams): slow, never wrong.
+// Survivors are recomputed from the fp32 rows as before, so results do not depend on which form filtered.
 #include "ivf_dev.h"
 
 #include <algorithm>
 #include <stdexcept>
 #include <stdlib.h>
+#include <string.h>
 #include <string>
 #include <type_traits>
 #include <utility>
@@ -37,6 +53,7 @@ namespace amdivf {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 // (explicitly global: a generic pointer makes these flat loads, which count on both wait counters and force full waits)
 typedef const v4f __attribute__((address_space(1)))* gv4f;
 
@@ -102,6 +119,138 @@ void launch_filter_queries(const float* x, size_t n, int d, int dpad, int metric
 }
 
 // ---------------------------------------------------------------------------------------------
+// fp16 form: ranges, lists, queries
+// info[0] = max |v| over all rows (bits of a non-negative float; an infinity if a NaN or an infinity was seen), info[1] != 0: some
+// element is not an integer of magnitude <= 2048, info[2] = 0x7f800000 - (bits of the smallest row maximum among rows that are not
+// all zero): one scale serves a whole matrix only while no row is tiny beside the largest (its elements would underflow)
+__global__ __launch_bounds__(256) void amax_kernel(const float* x, size_t rows, int stride, uint32_t* info) {
+    const int lane = threadIdx.x & 63;
+    uint32_t mx_all = 0, bad = 0, inv_min = 0;
+    for (size_t r = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (size_t)gridDim.x * 4) {
+        uint32_t mx = 0;
+        for (int c = lane; c < stride; c += 64) {
+            const float v = x[r * (size_t)stride + c], av = fabsf(v);
+            const uint32_t bits = av == av ? __float_as_uint(av) : 0x7f800000u;  // (NaN counts as an infinity)
+            mx = bits > mx ? bits : mx;
+            bad |= !(v == (float)(int)v && av <= 2048.f);
+        }
+        for (int off = 32; off; off >>= 1) {
+            const uint32_t o = (uint32_t)__shfl_xor((int)mx, off);
+            mx = o > mx ? o : mx;
+        }
+        mx_all = mx > mx_all ? mx : mx_all;
+        if (mx != 0 && 0x7f800000u - mx > inv_min) inv_min = 0x7f800000u - mx;
+    }
+    for (int off = 32; off; off >>= 1) bad |= (uint32_t)__shfl_xor((int)bad, off);
+    if (lane == 0) {
+        atomicMax(&info[0], mx_all);
+        if (bad) atomicOr(&info[1], 1u);
+        atomicMax(&info[2], inv_min);
+    }
+}
+void launch_amax(const float* x, size_t rows, int stride, uint32_t* info, hipStream_t s) {  // (info: 4 words, zeroed by the caller)
+    if (rows == 0) return;
+    const unsigned grid = (unsigned)std::min<size_t>((rows + 3) / 4, 2048);
+    LAUNCH(amax_kernel, dim3(grid), dim3(256), 0, s, x, rows, stride, info);
+}
+// the power of two that brings a matrix's largest magnitude into [2^14, 2^15); 1 where every element is held exactly as it is, and
+// where there is nothing to scale; 0 where no one scale is usable: a non-finite element, magnitudes outside 2^+-24, or a row
+// whose largest element is below 2^-12 max(1, d / 1024) of the matrix's (scaled, its largest element must stay above
+// max(1, d / 1024) for the absolute error of elements that underflow to be covered: head comment)
+__host__ __device__ inline float half_scale_of(uint32_t amax_bits, uint32_t nonexact, uint32_t inv_min, int d) {
+    float amax;
+    memcpy(&amax, &amax_bits, 4);
+    if (!nonexact || amax == 0.f) return 1.f;
+    if (!(amax < __builtin_inff())) return 0.f;
+    int e;
+    (void)frexpf(amax, &e);  // amax in [2^(e-1), 2^e)
+    if (e > 24 || e < -24) return 0.f;
+    if (inv_min) {
+        const uint32_t min_bits = 0x7f800000u - inv_min;
+        float minrow;
+        memcpy(&minrow, &min_bits, 4);
+        const float need = amax * 0.000244140625f * (d > 1024 ? (float)d / 1024.f : 1.f);
+        if (minrow < need) return 0.f;
+    }
+    return ldexpf(1.f, 15 - e);
+}
+__device__ __forceinline__ float half_scale(const uint32_t* info, int d) { return half_scale_of(info[0], info[1], info[2], d); }
+float filter_half_scale(const uint32_t info[4], int d) { return half_scale_of(info[0], info[1], info[2], d); }
+
+// a block = filter_steps16(d) pieces of 64 lanes x 16 bytes, lane (v = l & 31, h = l >> 5) of piece j holding elements
+// 16 j + 8 h .. + 7 of vector v as fp16(s_y * value) (zero beyond d); yn as in the fp32 form (from the fp32 values)
+__global__ __launch_bounds__(64) void frag16_from_f32_kernel(const float* codes, const uint64_t* list_off, const uint64_t* block_off, uint32_t nlist,
+                                                             int d, int dpad, int metric, const uint32_t* info, float* out, float* yn) {
+    const uint64_t blk = blockIdx.x;
+    const int lane = threadIdx.x, v = lane & 31, h = lane >> 5;
+    uint32_t lo = 0, hi = nlist;  // largest l with block_off[l] <= blk
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (block_off[mid] <= blk) lo = mid;
+        else hi = mid;
+    }
+    const uint64_t pos = (blk - block_off[lo]) * 32 + v, size = list_off[lo + 1] - list_off[lo];
+    const bool ok = pos < size;
+    const float* src = codes + (list_off[lo] + (ok ? pos : 0)) * (uint64_t)dpad;
+    const int J = (int)filter_steps16(d);
+    const float sy = half_scale(info, d);
+    double sq = 0.0;
+    for (int j = 0; j < J; j++) {
+        v8h piece;
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+            const int c = 16 * j + 8 * h + w;
+            const float val = ok && c < d ? src[c] : 0.f;
+            piece[w] = (_Float16)(val * sy);
+            sq += (double)val * (double)val;
+        }
+        *reinterpret_cast<v8h*>(out + (blk * (uint64_t)J + (uint64_t)j) * 256 + (uint64_t)lane * 4) = piece;
+    }
+    sq += __shfl_xor(sq, 32);
+    if (h == 0) yn[blk * 32 + v] = !ok ? 0.f : metric == METRIC_L2 ? (float)sq : (float)sqrt(sq);
+}
+void launch_frag16_from_f32(const float* codes, const uint64_t* list_off, const uint64_t* block_off, uint32_t nlist, uint64_t nblocks, int d,
+                            int dpad, int metric, const uint32_t* info, float* out, float* yn, hipStream_t s) {
+    if (nblocks == 0) return;
+    LAUNCH(frag16_from_f32_kernel, dim3((unsigned)nblocks), dim3(64), 0, s, codes, list_off, block_off, nlist, d, dpad, metric, info, out, yn);
+}
+
+// query rows (stride dpad) -> rows of 16 J halves (J = filter_steps16(d); row stride 8 J floats) + xn; one wave per row; the first
+// thread also leaves the search's FilterParams
+__global__ __launch_bounds__(256) void filter_queries16_kernel(const float* x, size_t n, int d, int dpad, int metric, const uint32_t* qinfo,
+                                                               const uint32_t* yinfo, float* xf, float* xn, FilterParams* params) {
+    const float sx = half_scale(qinfo, d), sy = half_scale(yinfo, d);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        FilterParams p;
+        p.sx = sx;
+        p.pad = 0.f;
+        const float C = (float)(2 * d + 32) * 5.9604644775390625e-08f;  // (2 d + 32) 2^-24
+        const bool exact = !qinfo[1] && !yinfo[1];                       // every element on both sides held exactly
+        p.C = sx == 0.f || sy == 0.f ? -1.f : exact ? C : C + 0.0009765625f + 0.000244140625f;
+        p.ps = sx == 0.f || sy == 0.f ? 0.f : 1.f / (sx * sy);
+        *params = p;
+    }
+    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const int stride = (int)filter_steps16(d) * 16;
+    _Float16* dst = reinterpret_cast<_Float16*>(xf) + row * (size_t)stride;
+    double sq = 0.0;
+    for (int c = lane; c < stride; c += 64) {
+        const float val = c < d ? x[row * (size_t)dpad + c] : 0.f;
+        dst[c] = (_Float16)(val * sx);
+        sq += (double)val * (double)val;
+    }
+    for (int off = 32; off; off >>= 1) sq += __shfl_xor(sq, off);
+    if (lane == 0) xn[row] = metric == METRIC_L2 ? (float)sq : (float)sqrt(sq);
+}
+void launch_filter_queries16(const float* x, size_t n, int d, int dpad, int metric, const uint32_t* qinfo, const uint32_t* yinfo, float* xf,
+                             float* xn, FilterParams* params, hipStream_t s) {
+    LAUNCH(filter_queries16_kernel, dim3((unsigned)std::max<size_t>((n + 3) / 4, 1)), dim3(256), 0, s, x, n, d, dpad, metric, qinfo, yinfo, xf, xn,
+           params);
+}
+
+// ---------------------------------------------------------------------------------------------
 // one lane per survivor of the filter: exact distance into the distance row
 template <int METRIC> __global__ __launch_bounds__(256) void rescore_kernel(FilterScanArgs a) {
     const uint32_t n = *a.surv_count < a.surv_cap ? *a.surv_count : a.surv_cap;
@@ -130,8 +279,9 @@ __device__ __forceinline__ void surv_retire(const FilterScanArgs& a, SurvChunk& 
 // ---- verdicts of block i of an item against its query block qb, whose 32 x 32 dot products are in acc; per-query operands
 // of the item's queries in LDS tables (u, c, row position, query row: entry qb * 32 + query of the block); yn = this lane's
 // vector's |y|^2 (L2) / |y| (IP), loaded by the caller ahead of the block's MFMAs
-template <int METRIC>
-__device__ __forceinline__ void filter_verdicts(const FilterScanArgs& a, const ScanItem& it, float C, uint32_t i, int qb, const v16f& acc,
+// ps: what the accumulators are multiplied by to give x.y (1 in the fp32 form); C < 0: keep every candidate
+template <int METRIC, bool HALF>
+__device__ __forceinline__ void filter_verdicts(const FilterScanArgs& a, const ScanItem& it, float C, float ps, uint32_t i, int qb, const v16f& acc,
                                                 float yn, const float* s_u, const float* s_c, const uint32_t* s_row,
                                                 const uint32_t* s_q, uint32_t* mask32, int lane, SurvChunk& sc) {
     const int m = lane & 31, h = lane >> 5;
@@ -155,8 +305,10 @@ __device__ __forceinline__ void filter_verdicts(const FilterScanArgs& a, const S
     uint32_t total = 0;
 #pragma unroll
     for (int reg = 0; reg < 16; reg++) {
-        const float t = METRIC == METRIC_L2 ? fmaf(2.f, acc[reg], -c1yn) : fmaf(cr[reg], yn, acc[reg]);
-        const bool keep = t > ur[reg];
+        const float p = HALF ? ps * acc[reg] : acc[reg];  // (a power of two: exact)
+        const float t = METRIC == METRIC_L2 ? fmaf(2.f, p, -c1yn) : fmaf(cr[reg], yn, p);
+        // (keep-all leaves out what nothing can pass: an absent query slot, a NaN threshold -- their u is +inf)
+        const bool keep = HALF ? ((C < 0.f) & (ur[reg] < __builtin_inff())) | (t > ur[reg]) : t > ur[reg];
         kept[reg] = __ballot(keep) & vmask;
         total += (uint32_t)__builtin_popcountll(kept[reg]);
     }
@@ -203,7 +355,17 @@ __device__ __forceinline__ void filter_verdicts(const FilterScanArgs& a, const S
 // A operand: the queries' rows (lane (m, h): elements 8 j + 4 h .. + 3 of query m, piece j), resident in registers when
 // NJ != 0 (d <= 128), re-read from the (L2-resident) packed query matrix otherwise; B operand: the list in fragment order,
 // P pieces in flight.  Piece j feeds four v_mfma_f32_32x32x2_f32 (element i of both 4-vectors: k = lane half).
-template <int METRIC, int NJ> __global__ __launch_bounds__(256) void scan_filter_kernel(FilterScanArgs a) {
+// HALF: the fp16 form -- a piece is 16 dimensions (lane (m, h): elements 16 j + 8 h .. + 7) and feeds ONE
+// v_mfma_f32_32x32x16_f16; the bytes of a piece, and so every address below, are the same.
+template <bool HALF> __device__ __forceinline__ void filter_mac(v16f& acc, const v4f& av, const v4f& bv) {
+    if constexpr (HALF) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, av), __builtin_bit_cast(v8h, bv), acc, 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc, 0, 0, 0);
+    }
+}
+template <int METRIC, int NJ, bool HALF> __global__ __launch_bounds__(256) void scan_filter_kernel(FilterScanArgs a) {
     __shared__ float s_u[4][32];
     __shared__ float s_c[4][32];
     __shared__ uint32_t s_row[4][32];
@@ -211,9 +373,11 @@ template <int METRIC, int NJ> __global__ __launch_bounds__(256) void scan_filter
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = lane & 31, h = lane >> 5;
-    const int J = NJ ? NJ : (int)filter_steps(a.d);
+    const int J = NJ ? NJ : (int)(HALF ? filter_steps16(a.d) : filter_steps(a.d));
     const size_t qstride = (size_t)J * 8;
-    const float C = (float)(2 * a.d + 32) * 5.9604644775390625e-08f;  // (2 d + 32) 2^-24
+    const FilterParams fp = HALF ? *reinterpret_cast<const FilterParams*>(a.params) : FilterParams{1.f, 1.f, 0.f, 0.f};
+    const float C = HALF ? fp.C : (float)(2 * a.d + 32) * 5.9604644775390625e-08f;  // (2 d + 32) 2^-24
+    const float ps = fp.ps;
     const uint32_t nitems = a.dev_nitems ? *a.dev_nitems : a.nitems;
     SurvChunk sc;
     ItemWalk w((nitems + 3) >> 2, a.xcd_chunks);
@@ -273,7 +437,7 @@ template <int METRIC, int NJ> __global__ __launch_bounds__(256) void scan_filter
 
         // ---- the tile's verdicts: mask words + survivor entries of block i, whose 32 x 32 dot products are in acc
         auto finish_block = [&](uint32_t i, const v16f& acc, float yn) __attribute__((always_inline)) {
-            filter_verdicts<METRIC>(a, it, C, i, 0, acc, yn, s_u[wave], s_c[wave], s_row[wave], s_q[wave], mask32, lane, sc);
+            filter_verdicts<METRIC, HALF>(a, it, C, ps, i, 0, acc, yn, s_u[wave], s_c[wave], s_row[wave], s_q[wave], mask32, lane, sc);
         };
         auto load_yn = [&](uint32_t i) __attribute__((always_inline)) { return a.yn[(it.vec_base + i) * 32 + m]; };
 
@@ -281,7 +445,7 @@ template <int METRIC, int NJ> __global__ __launch_bounds__(256) void scan_filter
             // P pieces of the list in flight, across block boundaries: piece t of the chunk's linear sequence lives in register
             // bq[t % P] (P divides NJ, so the index is static in the unrolled block body); the scheduling barriers keep every
             // load where it is written -- right behind the MFMAs that freed its register
-            constexpr int P = NJ == 12 ? 6 : NJ >= 8 ? 8 : 4;
+            constexpr int P = NJ == 12 || NJ == 6 ? 6 : NJ >= 8 ? 8 : 4;
             v4f bq[P];
 #pragma unroll
             for (int j = 0; j < P; j++) bq[j] = *(gv4f)(uintptr_t)(bbase + (size_t)j * 256);
@@ -295,8 +459,7 @@ template <int METRIC, int NJ> __global__ __launch_bounds__(256) void scan_filter
 #pragma unroll
                 for (int j = 0; j < NJ; j++) {
                     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][e], bq[j % P][e], acc, 0, 0, 0);
+                    filter_mac<HALF>(acc, af[j], bq[j % P]);
                     __builtin_amdgcn_sched_barrier(0);
                     const float* src = j + P < NJ ? bp + (size_t)(j + P) * 256 : bn + (size_t)(j + P - NJ) * 256;
                     bq[j % P] = *(gv4f)(uintptr_t)src;  // (cached: the chunk's other query blocks read it too)
@@ -336,9 +499,7 @@ template <int METRIC, int NJ> __global__ __launch_bounds__(256) void scan_filter
     }
 #define FILTER_MAC(AV, BV)                                                                                       \
     {                                                                                                            \
-        _Pragma("unroll") for (int g = 0; g < G; g++)                                                            \
-            _Pragma("unroll") for (int e = 0; e < 4; e++)                                                        \
-                acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[e], BV[g][e], acc[g], 0, 0, 0);                 \
+        _Pragma("unroll") for (int g = 0; g < G; g++) filter_mac<HALF>(acc[g], AV, BV[g]);                       \
     }
                 FILTER_FETCH(0, a0, b0)
                 FILTER_FETCH(1, a1, b1)
@@ -388,7 +549,7 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <int METRIC>
+template <int METRIC, bool HALF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void scan_filter_wide_kernel(FilterScanArgs a) {
     extern __shared__ __align__(16) unsigned char wide_smem[];
     float* s_a = reinterpret_cast<float*>(wide_smem);  // [2 buffers][query block][piece of the stage][lane][4]
@@ -400,10 +561,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int m = lane & 31, h = lane >> 5;
-    const int J = (int)filter_steps(a.d);
+    const int J = (int)(HALF ? filter_steps16(a.d) : filter_steps(a.d));
     const int S = (J + SP - 1) / SP;
     const size_t qstride = (size_t)J * 8;
-    const float C = (float)(2 * a.d + 32) * 5.9604644775390625e-08f;  // (2 d + 32) 2^-24
+    const FilterParams fp = HALF ? *reinterpret_cast<const FilterParams*>(a.params) : FilterParams{1.f, 1.f, 0.f, 0.f};
+    const float C = HALF ? fp.C : (float)(2 * a.d + 32) * 5.9604644775390625e-08f;  // (2 d + 32) 2^-24
+    const float ps = fp.ps;
     const uint32_t nitems = a.dev_nitems ? *a.dev_nitems : a.nitems;
     uint32_t* mask32 = reinterpret_cast<uint32_t*>(a.mask);
     SurvChunk sc;
@@ -463,7 +626,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
         const float yn = a.yn[((size_t)it.vec_base + (active ? (uint32_t)wave : 0u)) * 32 + m];
         auto finish_block = [&](uint32_t i, int qb, const v16f& acc) __attribute__((always_inline)) {
-            filter_verdicts<METRIC>(a, it, C, i, qb, acc, yn, s_u, s_c, s_row, s_q, mask32, lane, sc);
+            filter_verdicts<METRIC, HALF>(a, it, C, ps, i, qb, acc, yn, s_u, s_c, s_row, s_q, mask32, lane, sc);
         };
 
         // ---- the contraction; the K loop is compiled per count of query blocks (their accumulator tiles are registers)
@@ -491,10 +654,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     af[q] = *reinterpret_cast<const v4f*>(s_a + ((size_t)(buf * QB + q) * SP + jj) * 256 + (size_t)lane * 4);
             };
             auto mac = [&](const v4f (&af)[NQB], const v4f& bv) __attribute__((always_inline)) {
+                if constexpr (HALF) {
 #pragma unroll
-                for (int e = 0; e < 4; e++)
+                    for (int q = 0; q < NQB; q++) filter_mac<true>(acc[q], af[q], bv);
+                } else {
 #pragma unroll
-                    for (int q = 0; q < NQB; q++) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][e], bv[e], acc[q], 0, 0, 0);
+                    for (int e = 0; e < 4; e++)
+#pragma unroll
+                        for (int q = 0; q < NQB; q++) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][e], bv[e], acc[q], 0, 0, 0);
+                }
             };
             for (int s = 0; s < S; s++) {
                 const int buf = s & 1;
@@ -549,7 +717,7 @@ uint32_t filter_item_vectors(int d) {
 void launch_scan_filter(const FilterScanArgs& a, hipStream_t s) {
     if (a.nitems == 0 && !a.dev_nitems) return;
     const unsigned nwg = (a.nitems + 3) / 4;
-    const int J = (int)filter_steps(a.d);
+    const int J = (int)(a.half ? filter_steps16(a.d) : filter_steps(a.d));
     auto go = [&](auto kern, auto resc) {
         static const unsigned per_cu = 3;
         const size_t hwg = ((size_t)a.hint_nitems + a.hint_nitems / 8 + 3) / 4;
@@ -567,14 +735,22 @@ void launch_scan_filter(const FilterScanArgs& a, hipStream_t s) {
         LAUNCH(kern, grid, block, FILTER_WIDE_LDS, s, a);
         LAUNCH(resc, dim3(resident_grid(4)), dim3(256), 0, s, a);
     };
+    const bool wide = filter_steps(a.d) > 16 && !filter_narrow();  // (as the planner shaped the items: filter_item_queries)
     auto pick = [&](auto metric) {
         constexpr int M = decltype(metric)::value;
-        if (J <= 4) return go(scan_filter_kernel<M, 4>, rescore_kernel<M>);
-        if (J <= 8) return go(scan_filter_kernel<M, 8>, rescore_kernel<M>);
-        if (J <= 12) return go(scan_filter_kernel<M, 12>, rescore_kernel<M>);
-        if (J <= 16) return go(scan_filter_kernel<M, 16>, rescore_kernel<M>);
-        if (filter_narrow()) return go(scan_filter_kernel<M, 0>, rescore_kernel<M>);
-        return go_wide(scan_filter_wide_kernel<M>, rescore_kernel<M>);
+        if (a.half) {
+            if (wide) return go_wide(scan_filter_wide_kernel<M, true>, rescore_kernel<M>);
+            if (J <= 4) return go(scan_filter_kernel<M, 4, true>, rescore_kernel<M>);
+            if (J <= 6) return go(scan_filter_kernel<M, 6, true>, rescore_kernel<M>);
+            if (J <= 8) return go(scan_filter_kernel<M, 8, true>, rescore_kernel<M>);
+            return go(scan_filter_kernel<M, 0, true>, rescore_kernel<M>);
+        }
+        if (J <= 4) return go(scan_filter_kernel<M, 4, false>, rescore_kernel<M>);
+        if (J <= 8) return go(scan_filter_kernel<M, 8, false>, rescore_kernel<M>);
+        if (J <= 12) return go(scan_filter_kernel<M, 12, false>, rescore_kernel<M>);
+        if (J <= 16) return go(scan_filter_kernel<M, 16, false>, rescore_kernel<M>);
+        if (!wide) return go(scan_filter_kernel<M, 0, false>, rescore_kernel<M>);
+        return go_wide(scan_filter_wide_kernel<M, false>, rescore_kernel<M>);
     };
     if (a.metric == METRIC_L2) pick(std::integral_constant<int, METRIC_L2>{});
     else pick(std::integral_constant<int, METRIC_IP>{});

@@ -132,13 +132,16 @@ struct MfmaScanArgs {
     uint32_t nitems;
     const uint32_t* dev_nitems;   // chained rounds: the item count lives on the device; the grid is a hint (see ScanArgs)
     uint32_t hint_nitems;         // items the same round had last time (0: unknown -> a resident grid)
-    int debug;                    // timing experiments only (results are wrong): 1 no mask stores, 2 no distance stores (threshold rounds)
+    int debug;                    // timing experiments only (results are wrong): 1 no mask stores, 2 no distance stores, 4 no epilogue,
+                                  // 8 no contraction (threshold rounds)
     int exact_mask;               // threshold mode: the mask bits are counted as results (range search), not re-tested by a selection
-    int pipelined;                // 1: dense rounds, 2: threshold rounds, 3: both through scan_mfma_thr_kernel (two blocks in flight
+    int pipelined;                // bit 0: dense rounds, bit 1: threshold rounds through scan_mfma_thr_kernel (two blocks in flight
                                   // per wave; threshold rounds: threshold folded into the accumulator, the mask a superset of
-                                  // the exact one -- where exact_mask allows it)
+                                  // the exact one -- where exact_mask allows it); bit 2: threshold rounds with up to 64
+                                  // queries per item through scan_mfma_pair_kernel (mfma_thr_qblock)
 };
 void launch_scan_mfma(const MfmaScanArgs& a, hipStream_t s);
+uint32_t mfma_thr_qblock(int d, int pipelined, bool exact_mask);  // queries per item the planner gives a threshold round (32 | 64)
 // fp32 lists (CSR rows, row stride dpad floats, integers 0..255) -> fragment order + code_cy; block_off[l] = first block of list l
 void launch_frag_from_f32(const float* codes, const uint64_t* list_off, const uint64_t* block_off, uint32_t nlist, uint64_t nblocks, int d,
                           int dpad, int metric, uint8_t* out, int32_t* cy, hipStream_t s);
@@ -173,8 +176,34 @@ struct FilterScanArgs {
     uint32_t nitems;
     const uint32_t* dev_nitems;
     uint32_t hint_nitems;
+    int half;                     // 1: codes_frag / xf hold scaled fp16 values in the fp16 fragment order (launch_frag16_from_f32,
+                                  // launch_filter_queries16) and `params` the scales and the error constant that go with them
+    const float* params;          // half: FilterParams on the device (written by launch_filter_queries16)
+};
+// what the fp16 form of the filter needs besides its operands (device memory, one per search): the dot product of the scaled
+// halves times `ps` is x.y up to C16 (|x|^2 + |y|^2) / 2; C = the constant of the keep test (ivf_filter.hip)
+struct FilterParams {
+    float sx, ps, C, pad;
 };
 void launch_scan_filter(const FilterScanArgs& a, hipStream_t s);  // filter + rescoring, two launches
+// pieces of 16 dimensions per vector in the fp16 fragment order: the step counts the one-wave kernel is built for (4, 6, 8) or an
+// even count beyond 128 dimensions
+inline __host__ __device__ uint32_t filter_steps16(int d) {
+    const uint32_t j = (uint32_t)(d + 15) / 16;
+    return j <= 4 ? 4u : j <= 6 ? 6u : j <= 8 ? 8u : (j + 1u) & ~1u;
+}
+// range of a row-major matrix for the fp16 form: info[0] = max |v| (bits of a non-negative float; +inf if a NaN or an infinity was
+// seen), info[1] != 0: some element is not an integer of magnitude <= 2048 (fp16 holds those exactly), info[2] = 0x7f800000 - bits
+// of the smallest row maximum among rows that are not all zero; info (4 words) zeroed by the caller
+void launch_amax(const float* x, size_t rows, int stride, uint32_t* info, hipStream_t s);
+// the scale that goes with such a range (0: none usable) -- ivf_filter.hip
+float filter_half_scale(const uint32_t info[4], int d);
+// fp32 lists -> fp16 fragment order, scaled by the power of two that brings info[0] into [2^14, 2^15); yn as launch_frag32_from_f32
+void launch_frag16_from_f32(const float* codes, const uint64_t* list_off, const uint64_t* block_off, uint32_t nlist, uint64_t nblocks, int d,
+                            int dpad, int metric, const uint32_t* info, float* out, float* yn, hipStream_t s);
+// query rows -> scaled fp16 rows (stride 16 filter_steps16(d) halves) + xn + the search's FilterParams
+void launch_filter_queries16(const float* x, size_t n, int d, int dpad, int metric, const uint32_t* qinfo, const uint32_t* yinfo, float* xf,
+                             float* xn, FilterParams* params, hipStream_t s);
 // beyond 128 dimensions (the query operand no longer fits a wave's registers) an item of the filter is up to this many queries, computed by a whole workgroup (scan_filter_wide_kernel); AUNCEL_AMD_FILTER_NARROW=1 keeps the one-wave form
 constexpr uint32_t FILTER_WIDE_QUERIES = 128;
 constexpr uint32_t FILTER_WIDE_VECTORS = 128;  // ... x a chunk of this many vectors (one 32-vector block per wave)

@@ -811,6 +811,239 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 #endif
 }
 
+// ---- threshold rounds, TWO query blocks per wave.  A round in which a list is probed by more than 32 queries runs one item per
+// (chunk, query block) above, and every one of them fetches the chunk: on the bench workload 3.1 query blocks per chunk, 4.2 GB
+// through L2 -> L1 for 1.3 GB of lists, and a CU's stream is served at the HBM rate for the first fetch of a chunk and at the L2
+// rate for the others, one after the other (0.38 ms = 0.22 + 0.16: profiles/r04_summary.md).  Here an item carries up to 64
+// queries (the planner's mfma_qblock): the list block that is in registers is contracted with both query blocks before it is let
+// go, so a chunk is fetched once per 64 queries.  The start values of the accumulators come straight from LDS into the
+// accumulator registers (no second copy in registers); everything else is the kernel above with two of each.
+template <int METRIC, int NKS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void scan_mfma_pair_kernel(MfmaScanArgs a) {
+    static_assert(NKS >= 1 && NKS <= 4, "query operands resident in registers");
+    constexpr uint32_t MAX_BLK = 16;  // (items of up to 512 vectors: launch_scan_mfma)
+    __shared__ int s_init[4][64];
+    __shared__ int s_cx[4][64];
+    __shared__ int s_u[4][64];
+    __shared__ uint32_t s_row[4][64];
+    __shared__ uint32_t s_mask[4][MAX_BLK][64];  // [block][query slot]: leave as 16- / 8-byte pieces per query when the item ends
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = lane & 31, h = lane >> 5;
+    constexpr size_t qstride = (size_t)NKS * 32;
+    constexpr size_t block_bytes = (size_t)NKS * 1024;
+    typedef int v8i __attribute__((ext_vector_type(8)));
+    typedef const v8i __attribute__((address_space(4)))* item_cp;
+    const item_cp items_c = (item_cp)(uintptr_t)a.items;
+    struct Hdr {
+        uint64_t vec_base;
+        uint32_t nvec, vec_off, pair_begin, npair;
+    };
+    auto load_item = [&](uint32_t n) {
+        const v8i t = items_c[n];
+        Hdr r;
+        r.vec_base = (uint64_t)(uint32_t)t[0] | ((uint64_t)(uint32_t)t[1] << 32);
+        r.nvec = (uint32_t)t[2];
+        r.vec_off = (uint32_t)t[3];
+        r.pair_begin = (uint32_t)t[4];
+        r.npair = (uint32_t)t[5];
+        return r;
+    };
+    const uint32_t nitems = a.dev_nitems ? *a.dev_nitems : a.nitems;
+    ItemWalk w((nitems + 3) >> 2, a.xcd_chunks);
+    uint32_t wi = w.cur;
+    if (wi >= w.end || wi * 4 + (uint32_t)wave >= nitems) return;  // (no workgroup barrier anywhere below)
+    auto item_of = [&](uint32_t walk) { return walk * 4 + (uint32_t)wave; };
+    auto exists = [&](uint32_t walk) { return walk < w.end && item_of(walk) < nitems; };
+
+    v4i b0[NKS], b1[NKS];
+    int cy0 = 0, cy1 = 0;
+    auto fetch = [&](v4i (&b)[NKS], int& cy, uint64_t blk) {
+        const uint8_t* bp = a.codes_frag + blk * block_bytes + (size_t)lane * 16;
+#pragma unroll
+        for (int s = 0; s < NKS; s++) b[s] = MFMA_BLOAD(reinterpret_cast<const v4i*>(bp + (size_t)s * 1024));
+        cy = a.code_cy[blk * 32 + m];
+    };
+
+    Hdr cur = load_item(item_of(wi));
+    Hdr nxt = load_item(exists(wi + w.step) ? item_of(wi + w.step) : item_of(wi));
+    uint32_t pq, po;  // query row and distance row of query slot `lane` (every load of the stream is unconditional: see above)
+    {
+        const uint32_t e = cur.pair_begin + ((uint32_t)lane < cur.npair ? (uint32_t)lane : 0u);
+        pq = a.pair_query[e];
+        po = (uint32_t)a.pair_out[e];
+    }
+    fetch(b0, cy0, cur.vec_base);
+    fetch(b1, cy1, cur.vec_base + 1);
+    uint32_t* mask32 = reinterpret_cast<uint32_t*>(a.mask);
+
+    for (;;) {
+        const uint32_t wn = wi + w.step;
+        const bool has_next = exists(wn);
+        const Hdr nn = load_item(exists(wn + w.step) ? item_of(wn + w.step) : item_of(wi));
+        const bool sok = (uint32_t)lane < cur.npair;
+        const bool two = cur.npair > 32;  // (wave-uniform)
+        const uint32_t row = po + cur.vec_off;
+        // the A operands: lane (m, h) of query block g holds the bytes of query slot 32 g + m
+        const uint32_t pq0 = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * m, (int)pq);
+        const uint32_t pq1 = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (32 + m), (int)pq);
+        const bool qok0 = (uint32_t)m < cur.npair, qok1 = (uint32_t)(32 + m) < cur.npair;
+        v4i af0[NKS], af1[NKS];
+        {
+            const int8_t* q0p = a.queries8 + (size_t)pq0 * qstride + (size_t)h * (size_t)(16 * NKS);
+            const int8_t* q1p = a.queries8 + (size_t)pq1 * qstride + (size_t)h * (size_t)(16 * NKS);
+#pragma unroll
+            for (int s = 0; s < NKS; s++) af0[s] = *reinterpret_cast<const v4i*>(q0p + 16 * s);
+#pragma unroll
+            for (int s = 0; s < NKS; s++) af1[s] = *reinterpret_cast<const v4i*>(q1p + 16 * s);
+        }
+        const int cx = a.query_cx[pq];
+        const float thr = a.thr[pq];
+        const uint32_t en = has_next ? nxt.pair_begin + ((uint32_t)lane < nxt.npair ? (uint32_t)lane : 0u) : cur.pair_begin;
+        const uint32_t pqn = a.pair_query[en];
+        const uint32_t pon = (uint32_t)a.pair_out[en];
+        if (!qok0) {
+#pragma unroll
+            for (int s = 0; s < NKS; s++) af0[s] = v4i{0, 0, 0, 0};
+        }
+        if (!qok1) {
+#pragma unroll
+            for (int s = 0; s < NKS; s++) af1[s] = v4i{0, 0, 0, 0};
+        }
+        int u = 0, init = -1073741824;  // (start values: scan_mfma_thr_kernel; invalid query slots never pass)
+        if (sok) {
+            if (METRIC == METRIC_L2) {
+                const float c = ceilf(thr);
+                const int T = !(c > 0.f) ? 0 : (c >= 1073741824.f ? 1073741824 : (int)c);
+                u = (cx - T) & ~1;
+                init = -(u >> 1);
+            } else {
+                const float f = floorf(thr);
+                const int T = !(f < 1073741824.f) ? 0x7fffffff : (f <= -1073741824.f ? -1073741824 : (int)f);
+                if (T != 0x7fffffff) {
+                    u = T - cx;
+                    init = -u;
+                }
+            }
+        }
+        asm volatile("" ::"v"(pqn), "v"(pon));  // (awaited here, not across the block loop: see scan_mfma_thr_kernel)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the previous item's reads of this wave's LDS rows are done
+        __builtin_amdgcn_wave_barrier();
+        s_init[wave][lane] = init;
+        s_cx[wave][lane] = cx;
+        s_u[wave][lane] = u;
+        s_row[wave][lane] = row;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        const uint32_t nblk = ((cur.nvec + 63) >> 6) * 2;
+        auto step = [&](v4i (&b)[NKS], int& cyv, uint32_t i) {
+            __builtin_amdgcn_sched_barrier(0);
+            // register 4 g + i of lane half h belongs to query 8 g + 4 h + i of its block: the start values, LDS -> accumulator
+            v16i acc0, acc1;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const v4i t0 = *reinterpret_cast<const v4i*>(&s_init[wave][8 * g + 4 * h]);
+                const v4i t1 = *reinterpret_cast<const v4i*>(&s_init[wave][32 + 8 * g + 4 * h]);
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    acc0[4 * g + c] = t0[c];
+                    acc1[4 * g + c] = t1[c];
+                }
+            }
+            if (!(a.debug & 8)) {
+#pragma unroll
+                for (int s = 0; s < NKS; s++) acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(af0[s], b[s], acc0, 0, 0, 0);
+                if (two) {
+#pragma unroll
+                    for (int s = 0; s < NKS; s++) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(af1[s], b[s], acc1, 0, 0, 0);
+                }
+            } else {
+                asm volatile("" ::"v"(b[0]), "v"(b[NKS - 1]));  // (the blocks are still awaited)
+            }
+            const uint32_t lv = i * 32 + m;
+            const bool vok = lv < cur.nvec;
+            int hc = !vok ? 0x7fffffff : METRIC == METRIC_L2 ? cyv >> 1 : -cyv;
+            int cy;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(cy) : "v"(cyv));
+            asm volatile("" : "+v"(hc));
+            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t in = i + 2;
+            const uint64_t nb = in < nblk ? cur.vec_base + in : has_next ? nxt.vec_base + (in - nblk) : cur.vec_base;
+            fetch(b, cyv, nb);
+            __builtin_amdgcn_sched_barrier(0);
+            int word = 0;  // lane 32 g + q collects the 32-candidate mask word of query q of block g
+            auto epilogue = [&](const v16i& acc, auto QB) {
+                constexpr int qb = decltype(QB)::value;
+                static_for(std::make_integer_sequence<int, 2>{}, [&](auto H) {
+                    constexpr int r0 = decltype(H)::value * 8;
+                    // eight registers at a time: their largest value against the bound first (four v_max3 / v_max and one compare:
+                    // most groups of eight hold no candidate, and sixteen compare-and-branch pairs per tile, the branch taken,
+                    // were most of a tile's issue time)
+                    int mx = max(max(acc[r0], acc[r0 + 1]), acc[r0 + 2]);
+                    mx = max(max(mx, acc[r0 + 3]), acc[r0 + 4]);
+                    mx = max(max(mx, acc[r0 + 5]), acc[r0 + 6]);
+                    mx = max(mx, acc[r0 + 7]);
+                    if (__ballot(mx > hc) == 0) return;
+                    unsigned long long bal[8];
+#pragma unroll
+                    for (int r = 0; r < 8; r++) bal[r] = __ballot(acc[r0 + r] > hc);
+                    static_for(std::make_integer_sequence<int, 8>{}, [&](auto R) {
+                        constexpr int reg = r0 + decltype(R)::value;
+                        constexpr int q0 = qb + (reg & 3) + 8 * (reg >> 2);  // query slot of lane half 0; half 1: q0 + 4
+                        const unsigned long long bb = bal[reg - r0];
+                        if (bb != 0) {  // (wave-uniform: a scalar compare and branch)
+                            writelane_c<q0>(word, (uint32_t)bb);
+                            writelane_c<q0 + 4>(word, (uint32_t)(bb >> 32));
+                            if (acc[reg] > hc && !(a.debug & 2)) {
+                                const int cq = s_cx[wave][q0 + 4 * h], uq = s_u[wave][q0 + 4 * h];
+                                const uint32_t off = s_row[wave][q0 + 4 * h] + lv;
+                                const int t = METRIC == METRIC_L2 ? 2 * (acc[reg] + (uq >> 1)) - cy : acc[reg] + uq + cy;
+                                a.dist[off] = (float)(METRIC == METRIC_L2 ? cq - t : cq + t);
+                            }
+                        }
+                    });
+                });
+            };
+            if (!(a.debug & 4)) {  // (timing experiments: 4 = no epilogue, 8 = no contraction; results are wrong)
+                epilogue(acc0, std::integral_constant<int, 0>{});
+                if (two) epilogue(acc1, std::integral_constant<int, 32>{});
+            }
+            s_mask[wave][i][lane] = (uint32_t)word;
+        };
+        for (uint32_t i = 0; i < nblk; i += 2) {
+            step(b0, cy0, i);
+            step(b1, cy1, i + 1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (sok && !(a.debug & 1)) {
+            uint32_t* dst = mask32 + (row >> 5);
+            for (uint32_t i = 0; i < nblk; i += 4) {
+                if (i + 4 <= nblk) {
+                    typedef int v4i8 __attribute__((ext_vector_type(4), aligned(8)));  // (rows start on multiples of 64 floats)
+                    v4i8 t;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) t[c] = (int)s_mask[wave][i + c][lane];
+                    *reinterpret_cast<v4i8*>(dst + i) = t;
+                } else {
+                    typedef int v2i __attribute__((ext_vector_type(2)));
+                    v2i t;
+                    t[0] = (int)s_mask[wave][i][lane];
+                    t[1] = (int)s_mask[wave][i + 1][lane];
+                    *reinterpret_cast<v2i*>(dst + i) = t;
+                }
+            }
+        }
+        if (!has_next) break;
+        cur = nxt;
+        nxt = nn;
+        pq = pqn;
+        po = pon;
+        wi = wn;
+    }
+}
+
 uint32_t mfma_chunk() {
     static const uint32_t v = [] {
         const char* e = getenv("AUNCEL_AMD_MFMA_CHUNK");
@@ -830,6 +1063,13 @@ uint32_t mfma_chunk_thr() {
         return x >= 64 ? (uint32_t)((x + 63) / 64 * 64) : (getenv("AUNCEL_AMD_MFMA_CHUNK") ? mfma_chunk() : 512u);
     }();
     return v;
+}
+
+// queries per item of a threshold round over byte codes: 64 where scan_mfma_pair_kernel runs it (bit 2 of `pipelined`; masks that
+// may be supersets; the query operands of two blocks fit the registers), else one tile's 32
+uint32_t mfma_thr_qblock(int d, int pipelined, bool exact_mask) {
+    const int ks = (int)mfma_ksteps(d);
+    return (pipelined & 4) && !exact_mask && ks >= 1 && ks <= 4 && mfma_chunk() <= 512 && mfma_chunk_thr() <= 512 ? 2 * MFMA_QBLOCK : MFMA_QBLOCK;
 }
 
 void launch_scan_mfma(const MfmaScanArgs& a, hipStream_t s) {
@@ -871,6 +1111,24 @@ void launch_scan_mfma(const MfmaScanArgs& a, hipStream_t s) {
             default: return go(scan_mfma_kernel<M, K, 0>);
         }
     };
+    // ... with up to 64 queries per item (the planner was told so: mfma_thr_qblock)
+    if (masked && mfma_thr_qblock(a.d, a.pipelined, a.exact_mask != 0) == 2 * MFMA_QBLOCK) {
+        if (a.metric == METRIC_L2) {
+            switch (ks) {
+                case 1: return go(scan_mfma_pair_kernel<METRIC_L2, 1>);
+                case 2: return go(scan_mfma_pair_kernel<METRIC_L2, 2>);
+                case 3: return go(scan_mfma_pair_kernel<METRIC_L2, 3>);
+                default: return go(scan_mfma_pair_kernel<METRIC_L2, 4>);
+            }
+        } else {
+            switch (ks) {
+                case 1: return go(scan_mfma_pair_kernel<METRIC_IP, 1>);
+                case 2: return go(scan_mfma_pair_kernel<METRIC_IP, 2>);
+                case 3: return go(scan_mfma_pair_kernel<METRIC_IP, 3>);
+                default: return go(scan_mfma_pair_kernel<METRIC_IP, 4>);
+            }
+        }
+    }
     // threshold rounds whose mask may be a superset of the exact one: the pipelined form (scan_mfma_thr_kernel)
     if ((a.pipelined & (masked ? 2 : 1)) && !(masked && a.exact_mask) && ks >= 1 && ks <= 4 && mfma_chunk() <= 512 && mfma_chunk_thr() <= 512) {
         auto pick_thr = [&](auto metric, auto dense) {

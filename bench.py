@@ -698,6 +698,7 @@ def main():
         fp32 = {"value": ses * nst / leg["elapsed"], "unit": "queries/s", "ms_per_step": 1000.0 * leg["elapsed"] / nst,
                 "scan_arith": {0: "fp32 reference order", 1: "fp32 fused"}.get(ctxs[0].scan_arith(), "?"),
                 "scan_avg_launch_ms": leg["scan_ms"] / max(leg["scan_launches"], 1),
+                "filter_copy": {2: "fp16", 1: "fp32", 0: "none"}.get(int(h.get_option("filter")), "?"),
                 "same_results_as_byte_codes": bool(np.array_equal(fD, D) and np.array_equal(fI, I) and
                                                    np.array_equal(f_np[q_start:q_start + ses], my_sl))}
         # its own roofline: the fp32 lists are four times the byte codes, and every round is a pass over them -- the dense round on the
@@ -708,7 +709,8 @@ def main():
         fr = {"bound": "hbm", "peak": 8000.0, "unit": "GB/s", "measured": f"{nfl} batches in flight", "per_launch": []}
         tot_b = tot_ms = 0.0
         for key, what in (("scan_dense", "dense round: scan_tiles_kernel (vector ALU, reference order)"),
-                          ("scan_thr", "threshold rounds: scan_filter_kernel (fp32 matrix cores) + rescore_kernel")):
+                          ("scan_thr", "threshold rounds: scan_filter_kernel (matrix cores over the fp16 copy of the lists; option filter = 1: the "
+                                       "fp32 copy) + rescore_kernel (exact recomputation of what it keeps)")):
             ms_l, n_l = ph.get(key, (0.0, 0.0))
             if not n_l:
                 continue

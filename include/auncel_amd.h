@@ -332,13 +332,14 @@ int amd_ivf_set_byte_codes(amd_ivf_t* h, int enable);
  *   "select"          0 the reference's binary heap replayed for every query, 1 sorted        1
  *                     arrays + heap replay of the queries in which equal distances met
  *   "tie_fix"         0 that replay once at the end of a search, 1 behind every round         unset: by call size / concurrency
- *   "filter"          fp32 threshold rounds: 1 matrix-core filter + exact recomputation, 0    1
- *                     vector ALU only
+ *   "filter"          fp32 threshold rounds: matrix-core filter + exact recomputation of what  2
+ *                     it keeps, over an fp16 (2) or fp32 (1) copy of the lists; 0 vector ALU only
  *   "fixed_rounds"    fixed-nprobe search: 1 one dense round, 2 dense + threshold round       unset (0): by nprobe
  *   "round_first", "round_grow", "round_inc"   round schedule of the adaptive search           12, 12 (bytes) / 6 / 3.5, = first
  *   "direct_out"      1 results stored straight into page-locked (D, I), 0 copied at the end  1
- *   "scan_pipelined"  byte-code scan through scan_mfma_thr_kernel (two list blocks in flight per   3
- *                     wave): bit 0 dense rounds, bit 1 threshold rounds; 0: scan_mfma_kernel
+ *   "scan_pipelined"  byte-code scan through scan_mfma_thr_kernel (two list blocks in flight per   7
+ *                     wave): bit 0 dense rounds, bit 1 threshold rounds, bit 2 threshold rounds with up to 64
+ *                     queries per item (scan_mfma_pair_kernel: a chunk is fetched once per 64 queries); 0: scan_mfma_kernel
  *   "plan_fused"      round planning in 3 launches (1) or 7 (0)                               1
  *   "coarse_pick"     large fixed-nprobe calls: 1 coarse rankings from matrix-core distances + exact   1
  *                     recomputation of the candidates (amd_ivf_last_coarse_pick), 0 exact distances to every centroid

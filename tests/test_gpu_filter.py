@@ -2,11 +2,18 @@
 pinned CPU oracle.  The filter may keep too much, never too little: every (D, I) and every statistic must be the oracle's,
 bit for bit, in every kernel shape (4 / 8 / 12 / 16 register-resident pieces up to 128 dimensions; the workgroup form and
 the one-wave form beyond), with 1 to 4 query blocks per item, ragged lists, and candidates that sit on or within an ulp of
-the thresholds."""
+the thresholds.  Every case runs over both copies the filter can stream: scaled fp16 (option "filter" = 2, the default) and
+fp32 (1)."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=[2, 1], ids=["fp16", "fp32"], autouse=True)
+def form(request, monkeypatch):
+    monkeypatch.setenv("AUNCEL_AMD_FILTER", str(request.param))
+    return request.param
 
 
 @pytest.fixture(scope="module")
@@ -30,7 +37,7 @@ def clustered(rs, nb, nq, d, nlist, spread=0.35):
     return cen, assign, xb, xq
 
 
-def run_and_compare(capi, oracle, metric, cen, assign, xb, xq, k, nprobe, expect_filter=True, store_pairs=False, max_codes=0):
+def run_and_compare(capi, oracle, metric, cen, assign, xb, xq, k, nprobe, expect_filter=True, store_pairs=False, max_codes=0, arith=0):
     nlist, d = cen.shape
     lists = oracle.Lists(metric, cen, xb, assign)
     npq = min(nprobe, nlist)
@@ -42,7 +49,7 @@ def run_and_compare(capi, oracle, metric, cen, assign, xb, xq, k, nprobe, expect
     h.stats(reset=True)
     D, I = h.search_preassigned(xq, k, ck, cd, store_pairs=store_pairs, max_codes=max_codes)
     launches, kept = h.last_filter()
-    assert h.scan_arith() == 0
+    assert h.scan_arith() == arith
     if expect_filter:
         assert launches >= 1, "the search did not go through the filter"
     assert np.array_equal(I, eI)
@@ -116,3 +123,41 @@ def test_random_shapes_beyond_128_dimensions(capi, oracle, seed):
     # (list, position) pairs instead of ids; a cap on the codes a query may visit (the reference's loop breaks mid-ranking)
     run_and_compare(capi, oracle, metric, cen, assign, xb, xq, k=k, nprobe=nprobe, expect_filter=False, store_pairs=True)
     run_and_compare(capi, oracle, metric, cen, assign, xb, xq, k=k, nprobe=nprobe, expect_filter=False, max_codes=max(1, nb // 6))
+
+
+@pytest.mark.parametrize("metric", [1, 0])
+@pytest.mark.parametrize("scale", [1e-3, 1.0, 3e4])
+def test_fp16_form_scales_the_operands(capi, oracle, form, scale, metric):
+    """magnitudes far from 1 on the two sides (the fp16 copies are scaled by powers of two into [2^14, 2^15)), lists and queries
+    scaled differently"""
+    rs = np.random.RandomState(7400 + metric)
+    cen, assign, xb, xq = clustered(rs, 5000, 150, 96, 32)
+    s = np.float32(scale)
+    run_and_compare(capi, oracle, metric, cen * s, assign, xb * s, xq * s * np.float32(0.37), k=10, nprobe=8)
+
+
+@pytest.mark.parametrize("metric", [1, 0])
+def test_fp16_form_on_integers_it_holds_exactly(capi, oracle, form, metric):
+    """integers of magnitude <= 2048 that are no bytes (negative values): the fp32 path, fp16 copies exact, no extra margin"""
+    rs = np.random.RandomState(7500 + metric)
+    nlist, d = 32, 64
+    cen = rs.randint(-200, 200, size=(nlist, d)).astype(np.float32)
+    assign = rs.randint(0, nlist, size=5000)
+    xb = (cen[assign] + rs.randint(-40, 40, size=(5000, d))).astype(np.float32)
+    xq = (cen[rs.randint(0, nlist, size=150)] + rs.randint(-40, 40, size=(150, d))).astype(np.float32)
+    run_and_compare(capi, oracle, metric, cen, assign, xb, xq, k=10, nprobe=8, arith=1)  # (small integers: fused arithmetic is exact)
+
+
+def test_fp16_form_without_a_usable_scale(capi, oracle, form):
+    """one scale per matrix is only safe while no row is tiny beside the largest (its elements would underflow in fp16) and the
+    magnitudes are within 2^+-24: a call whose queries break that keeps every candidate and recomputes it exactly, lists that break
+    it are filtered over their fp32 copy; rows of zeros are exact in any scale"""
+    rs = np.random.RandomState(7600)
+    cen, assign, xb, xq = clustered(rs, 4000, 150, 64, 16)
+    for factor in (2.0 ** 50, 2.0 ** -20, 0.0):
+        xq2 = xq.copy()
+        xq2[17] *= np.float32(factor)
+        run_and_compare(capi, oracle, 1, cen, assign, xb, xq2, k=10, nprobe=8)
+        xb2 = xb.copy()
+        xb2[123] *= np.float32(factor if factor < 1 else 2.0 ** 40)
+        run_and_compare(capi, oracle, 1, cen, assign, xb2, xq, k=10, nprobe=8)

@@ -722,7 +722,7 @@ def test_options_through_the_abi(capi, monkeypatch):
     which wins over the default; an unknown key is an engine error (-2); a search context answers for its index"""
     case, gold = load_case(FIXED[0])
     h = make_index(capi, case, gold)
-    assert h.get_option("select") == 1 and h.get_option("coarse_ties") == -1 and h.get_option("scan_pipelined") == 3
+    assert h.get_option("select") == 1 and h.get_option("coarse_ties") == -1 and h.get_option("scan_pipelined") == 7
     monkeypatch.setenv("AUNCEL_AMD_SELECT", "heap")
     assert h.get_option("select") == 0
     h.set_option("select", 1)
