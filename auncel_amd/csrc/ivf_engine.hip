@@ -785,6 +785,18 @@ static bool dbg_timing() {
     return on;
 }
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// AUNCEL_AMD_DEBUG_TIMING: host-side time stamps of a search (what the calling thread spends between its launches)
+static thread_local std::vector<std::pair<const char*, double>> g_stamps;
+static inline void host_stamp(const char* what) {
+    if (dbg_timing()) g_stamps.emplace_back(what, now_us());
+}
+static void print_stamps() {
+    if (!dbg_timing() || g_stamps.empty()) return;
+    fprintf(stderr, "[host]");
+    for (size_t i = 1; i < g_stamps.size(); i++) fprintf(stderr, " %s +%.0f", g_stamps[i].first, g_stamps[i].second - g_stamps[i - 1].second);
+    fprintf(stderr, " | total %.0f us\n", g_stamps.back().second - g_stamps.front().second);
+    g_stamps.clear();
+}
 
 // queries per full block of a list (ivf_kernels.h): 64 for the byte-code scan, 32 for the fp32 scans
 static uint32_t scan_qblock(bool bytes) {
@@ -1357,12 +1369,20 @@ void finish_timing(amd_ivf* h, double wall_ms) {
 struct WallClock {
     hipEvent_t a = nullptr, b = nullptr;
     hipStream_t s;
-    explicit WallClock(hipStream_t st) : s(st) {
+    double t0 = 0;
+    // host_only: the calling thread's clock (a search whose phase timers are off ends with a synchronisation anyway; an event pair
+    // costs it two creations, two records and a second wait: 15 us of a 0.3 ms call)
+    explicit WallClock(hipStream_t st, bool host_only = false) : s(st) {
+        if (host_only) {
+            t0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+            return;
+        }
         HIP_CHECK(hipEventCreate(&a));
         HIP_CHECK(hipEventCreate(&b));
         HIP_CHECK(hipEventRecord(a, s));
     }
     double stop() {
+        if (!a) return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0;
         HIP_CHECK(hipEventRecord(b, s));
         HIP_CHECK(hipEventSynchronize(b));
         float ms = 0;
@@ -1987,8 +2007,10 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
                 ma.exact_mask = base.range;  // (range search counts the mask bits)
             }
             // the scan runs on a normal-priority side stream (see make_main_stream)
+            // (a handful of queries: the launch is a few microseconds of work, the fork and join around it two event waits of
+            // ~13 us each -- it stays on the search's own stream)
             static const bool scan_on_main = getenv("AUNCEL_AMD_SCAN_ON_MAIN") != nullptr;  // (experiment: no side stream at all)
-            if (scan_on_main) {
+            if (scan_on_main || n < 20) {
                 launch_scan_mfma(ma, s);
             } else {
                 ensure_aux(h, 3, 3);
@@ -2274,7 +2296,9 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             static const bool plan_look = getenv("AUNCEL_AMD_PLAN_LOOK") != nullptr;
             if (!plan_look && round >= 1 && round - 1 < PLAN_MAX_ROUNDS) {
                 fetch_counters(0);
+                host_stamp("enqueued");
                 HIP_CHECK(stream_sync(s));
+                host_stamp("look-sync");
                 const uint32_t left = hc[24 + round - 1] + hc[11];
                 if (dbg_timing()) fprintf(stderr, "[rounds/chained] after round %zu: unfinished %u deferred %u\n", round, hc[24 + round - 1], hc[11]);
                 if (left == 0) break;
@@ -3217,6 +3241,7 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
     const size_t K = ix(L)->tuner_max_topk, nlist = L->nlist;
     // full coarse ranking (Error_sys::search sets nprobe = nlist, profile.cpp:220), or the caller's
     const size_t np_row = coarse_or_given(L, d_x, n, coarse_mode, ix(L)->allow_fused && ix(L)->centroid_range.fusable_with(qr, L->metric), coarse_prefix);
+    host_stamp("coarse");
     if (L->want_first_tie) {
         L->w_first_tie.ensure(n * 4);
         launch_first_tie(L->w_cdis.as<float>(), (uint32_t)n, (uint32_t)nlist, (uint32_t)L->first_tie_nreal, L->w_first_tie.as<uint32_t>(), L->stream);
@@ -3287,7 +3312,9 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
     }
     base.caller_checks_error = true;
     DirectOut direct(L, D, I);
+    host_stamp("state");
     run_rounds_device(L, base, n, first_env, np_row, dnp);
+    host_stamp("rounds");
     finish_results(L, n, K, D, I, nullptr, defer_finish);
 }
 
@@ -3317,8 +3344,11 @@ static void adaptive_core_once(amd_ivf_t* h, const float* d_x, size_t start, siz
         const int pt = (int)opt(h, OPT_PHASE_TIMING, -1);
         h->timer.off = pt >= 0 ? pt == 0 : n < 20;
     }
-    WallClock wc(h->stream);
+    g_stamps.clear();
+    host_stamp("begin");
+    WallClock wc(h->stream, h->timer.off);
     upload_lists(h);
+    host_stamp("clock+lists");
     const size_t nabs = start + n;
     // per-absolute-query arrays on the device, shared by all lanes
     DevBuf &d_req = h->w_misc2, &d_np = h->w_misc3;
@@ -3338,6 +3368,7 @@ static void adaptive_core_once(amd_ivf_t* h, const float* d_x, size_t start, siz
     if (gt_D) HIP_CHECK(hipMemcpyAsync(dgt + start * K, gt_D + start * K, n * K * 4, hipMemcpyHostToDevice, h->stream));
     h2d_small(h, d_np.as<unsigned long long>() + start, my_nprobe + start, n * 8, h->stream);
     flush_h2d(h, h->stream);
+    host_stamp("inputs");
 
     // How much of the coarse ranking can be consumed: set_online reads entries 0 .. nlist/8+20, and the probe loop ends at
     // my_nprobe <= floor((nlist/8) * multipler) (IndexIVF.cpp:615-632) or at a value the caller passed in.  When that is
@@ -3405,8 +3436,11 @@ static void adaptive_core_once(amd_ivf_t* h, const float* d_x, size_t start, siz
         }
     }
     sync_and_flush(h, h->stream);
+    host_stamp("final-sync");
     // fold the kids' counters and kernel timings into the handle
     const double wall = wc.stop();
+    host_stamp("clock");
+    print_stamps();
     double ms[NCAT] = {0}, ln[NCAT] = {0};
     double bytes = 0, slots = 0, useful = 0, min_bytes = 0;
     for (amd_ivf* L : lanes) {

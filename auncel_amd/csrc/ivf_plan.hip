@@ -95,39 +95,53 @@ __global__ __launch_bounds__(256) void plan_counts_kernel(PlanArgs a) {
     plan_counts_query(a, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
 }
 
-// exclusive prefix sum of one value per thread over a block of 1024 threads (16 waves): shuffles inside the waves, one LDS
-// hop for the wave totals; `total` receives the block's sum.  s_wave: 17 entries of shared memory, reusable on return.
-template <typename T> __device__ __forceinline__ T block_scan_1024(T v, T* s_wave, T& total) {
+// exclusive prefix sums of N values per thread over a block of 1024 threads (16 waves): shuffles inside the waves, one LDS hop
+// for the wave totals; `total` receives the block's sums.  s_wave: 17 x N entries of shared memory, reusable on return.  All N at
+// once: the three barriers are what a scan costs a single workgroup that has nothing else to run (six scans one after the other
+// were 18 of the ~35 barriers of a planning pass)
+template <int N> __device__ __forceinline__ void block_scan_1024_n(const uint32_t (&v)[N], uint32_t (&excl)[N], uint32_t (&total)[N],
+                                                                    uint32_t (*s_wave)[N]) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    T incl = v;
+    uint32_t incl[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) incl[k] = v[k];
     for (int off = 1; off < 64; off <<= 1) {
-        const T o = __shfl_up(incl, off);
-        if (lane >= off) incl += o;
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const uint32_t o = (uint32_t)__shfl_up((int)incl[k], off);
+            if (lane >= off) incl[k] += o;
+        }
     }
-    if (lane == 63) s_wave[w] = incl;
+    if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < N; k++) s_wave[w][k] = incl[k];
+    }
     __syncthreads();
     if (w == 0) {
-        const T x = lane < 16 ? s_wave[lane] : (T)0;
-        T inc = x;
-        for (int off = 1; off < 16; off <<= 1) {
-            const T o = __shfl_up(inc, off);
-            if (lane >= off) inc += o;
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const uint32_t x = lane < 16 ? s_wave[lane][k] : 0u;
+            uint32_t inc = x;
+            for (int off = 1; off < 16; off <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_up((int)inc, off);
+                if (lane >= off) inc += o;
+            }
+            if (lane < 16) s_wave[lane][k] = inc - x;
+            if (lane == 15) s_wave[16][k] = inc;
         }
-        if (lane < 16) s_wave[lane] = inc - x;
-        if (lane == 15) s_wave[16] = inc;
     }
     __syncthreads();
-    const T res = s_wave[w] + incl - v;
-    total = s_wave[16];
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        excl[k] = s_wave[w][k] + incl[k] - v[k];
+        total[k] = s_wave[16][k];
+    }
     __syncthreads();
-    return res;
 }
 
 // ---- 2. one block: prefix sums over the queries, budget cut, list of active queries.  Thread t owns the queries
 //         [t * per, (t + 1) * per): sums of its own, one block scan of the 1024 sums, then its queries again.
 __device__ __forceinline__ void plan_prefix_body(const PlanArgs& a) {
-    __shared__ unsigned long long s_w64[17];
-    __shared__ uint32_t s_w32[17];
     __shared__ uint32_t cut;
     const uint32_t t = threadIdx.x;
     if (t == 0) cut = 0xffffffffu;
@@ -140,11 +154,21 @@ __device__ __forceinline__ void plan_prefix_body(const PlanArgs& a) {
         my_act += c ? 1u : 0u;
         my_need += a.need[i];
     }
+    // one scan for all three; the 64-bit row need travels as (low 20 bits | the rest): the parts' sums over 1024 threads stay
+    // below 2^30 and (total >> 20) + 1024, and the sum is linear in the parts
     unsigned long long tot_need;
-    uint32_t tot32;
-    unsigned long long eneed = block_scan_1024(my_need, s_w64, tot_need);
-    uint32_t ecnt = block_scan_1024(my_cnt, s_w32, tot32);
-    uint32_t eact = block_scan_1024(my_act, s_w32, tot32);
+    uint32_t ecnt, eact;
+    unsigned long long eneed;
+    {
+        __shared__ uint32_t s_w4[17][4];
+        const uint32_t v4[4] = {(uint32_t)(my_need & 0xfffffu), (uint32_t)(my_need >> 20), my_cnt, my_act};
+        uint32_t e4[4], t4[4];
+        block_scan_1024_n<4>(v4, e4, t4, s_w4);
+        eneed = (unsigned long long)e4[0] + ((unsigned long long)e4[1] << 20);
+        tot_need = (unsigned long long)t4[0] + ((unsigned long long)t4[1] << 20);
+        ecnt = e4[2];
+        eact = e4[3];
+    }
     for (uint32_t i = q0; i < q1; i++) {
         const uint32_t c = a.cnt[i];
         const unsigned long long nd = a.need[i];
@@ -265,7 +289,7 @@ __global__ __launch_bounds__(256) void plan_segments_kernel(PlanArgs a) {
 // ---- 4. one block: per-list pair offsets, query-group bases, tile counts per workgroup shape (thread t owns a run of lists)
 
 __device__ __forceinline__ void plan_lists_body(const PlanArgs& a) {
-    __shared__ uint32_t s_w[17];
+    __shared__ uint32_t s_w[17][6];
     const uint32_t t = threadIdx.x;
     // pairs, groups, tiles of shape 1, 2, 4, 8 of list l
     auto values = [&](uint32_t l, uint32_t (&v)[6]) {
@@ -305,8 +329,7 @@ __device__ __forceinline__ void plan_lists_body(const PlanArgs& a) {
     if (a.min_bytes && list_bytes > 0) atomicAdd(a.min_bytes, list_bytes);
     if (a.min_bytes_thr && !a.dense_round && list_bytes > 0) atomicAdd(a.min_bytes_thr, list_bytes);
     uint32_t ex[6], tot[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) ex[k] = block_scan_1024(mine[k], s_w, tot[k]);
+    block_scan_1024_n<6>(mine, ex, tot, s_w);
     for (uint32_t l = l0; l < l1; l++) {
         uint32_t v[6];
         values(l, v);

@@ -24,7 +24,7 @@ traces = [capi.trace_sb(r) for r in raw]
 h.set_tuner(K, traces, capi.arcos_table())
 req = np.full(ts + ses, 0.95, dtype=np.float32)
 
-def lat(fn, n=200):
+def lat(fn, n=int(os.environ.get('CALLS', 200))):
     for i in range(10): fn(ts + i)
     t = np.zeros(n)
     for i in range(n):
@@ -40,6 +40,8 @@ for name, fn in (("search_resident k=10 nprobe=16", lambda i: h.search_resident(
                  ("search_resident k=100 nprobe=16", lambda i: h.search_resident(i, 1, 100, 16)),
                  ("search_adaptive (bound 0.95)", adaptive),
                  ("search_timed budget 2 ms", lambda i: h.search_timed(i, 1, K, nlist, bud))):
+    if os.environ.get('ONLY') and os.environ['ONLY'] not in name:
+        continue
     rows0 = h.coarse_tie_rows()
     t = lat(fn)
     tm = h.last_timing()
