@@ -253,7 +253,7 @@ def run_shards(args, torch, dist, capi, rank, world, local, dev, red_dev):
                        # the merge gives equal distances)
                        "distances_sha256": __import__("hashlib").sha256(np.ascontiguousarray(D).tobytes()).hexdigest(),
                        "shard_bytes_max_over_min": float(load.max() / max(load.min(), 1))},
-            "roofline": {"bound": "hbm", "kernel": "scan_mfma_kernel" if h.scan_arith() == 2 else "scan_tiles_kernel", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "scan_mfma_thr_kernel + scan_mfma_pair_kernel" if h.scan_arith() == 2 else "scan_tiles_kernel", "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0 if achieved else None, "traffic": None,
                          "traffic_source": "engine's lower bound (every probed list once per round + rows written), rank 0's shard",
                          "min_bytes_per_launch": per_launch, "avg_launch_ms": acc["scan_ms"] / launches, "launches_per_step": launches / args.steps,
@@ -784,7 +784,7 @@ def main():
     # IndexIVF.cpp:676,733) x d x 4; `scan_bytes` (distances the tiles computed, incl. the probes a round
     # ran past a query's stop point) is reported beside it as computed_over_algorithmic
     alg_bytes = float(st["ndis"]) * d * 4.0
-    scan_kernel = "scan_mfma_kernel" if arith == 2 else "scan_tiles_kernel"
+    scan_kernel = "scan_mfma_thr_kernel (dense round) + scan_mfma_pair_kernel (threshold round): see per_launch" if arith == 2 else "scan_tiles_kernel"
     min_bytes = acc["scan_min_bytes"]
     # HBM traffic of the scan per launch.  PMC counters cannot be read from inside this process: the measured figure comes
     # from the committed rocprofv3 --pmc passes over this same command (profiles/collect.sh -> summarize.py; FETCH_SIZE
@@ -895,7 +895,8 @@ def main():
     pipe = int(h.get_option("scan_pipelined")) if arith == 2 else 0
     ksn = (d + 31) // 32
     knames = {"scan_dense": (f"scan_mfma_thr_kernel<1, {ksn}, true>" if pipe & 1 else f"scan_mfma_kernel<1, false, {ksn}>") if arith == 2 else "scan_tiles_kernel",
-              "scan_thr": (f"scan_mfma_thr_kernel<1, {ksn}, false>" if pipe & 2 else f"scan_mfma_kernel<1, true, {ksn}>") if arith == 2 else "scan_filter_kernel"}
+              "scan_thr": (f"scan_mfma_pair_kernel<1, {ksn}>" if pipe & 4 else f"scan_mfma_thr_kernel<1, {ksn}, false>" if pipe & 2
+                           else f"scan_mfma_kernel<1, true, {ksn}>") if arith == 2 else "scan_filter_kernel"}
     prof = {}
     try:
         if cands:

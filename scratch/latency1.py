@@ -26,9 +26,11 @@ req = np.full(ts + ses, 0.95, dtype=np.float32)
 
 def lat(fn, n=int(os.environ.get('CALLS', 200))):
     for i in range(10): fn(ts + i)
-    t = np.zeros(n)
+    t, e = np.zeros(n), np.zeros(n)
     for i in range(n):
         t0 = time.perf_counter(); fn(ts + i); t[i] = (time.perf_counter() - t0) * 1e3
+        e[i] = h.last_timing()['total_ms']  # inside the C entry point (what a C / C++ caller such as eval/bound.cpp sees)
+    lat.engine = e
     return t
 
 def adaptive(i):
@@ -47,6 +49,6 @@ for name, fn in (("search_resident k=10 nprobe=16", lambda i: h.search_resident(
     tm = h.last_timing()
     if "adaptive" in name:
         print(f"  ({h.coarse_tie_rows() - rows0} of the {len(t)} adaptive calls were repeated with the reference's heap order: a run of equal coarse distances below 2 my_nprobe + 14)")
-    print(f"{name}: median {np.median(t):.3f} ms p90 {np.percentile(t, 90):.3f} min {t.min():.3f} | last call kernels: coarse {tm['coarse_ms']:.3f} scan {tm['scan_ms']:.3f} select {tm['select_ms']:.3f} total {tm['total_ms']:.3f} rounds {tm['rounds']:.0f}", flush=True)
+    print(f"{name}: median {np.median(t):.3f} ms p90 {np.percentile(t, 90):.3f} min {t.min():.3f} through ctypes; inside the C entry point median {np.median(lat.engine):.3f} p90 {np.percentile(lat.engine, 90):.3f} | last call kernels: coarse {tm['coarse_ms']:.3f} scan {tm['scan_ms']:.3f} select {tm['select_ms']:.3f} total {tm['total_ms']:.3f} rounds {tm['rounds']:.0f}", flush=True)
 if os.environ.get('AUNCEL_AMD_DEBUG_TIMING'):
     adaptive(ts + 300)
