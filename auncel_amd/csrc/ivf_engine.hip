@@ -351,7 +351,7 @@ struct amd_ivf {
     // workspaces (grow only)
     DevBuf w_qtile, w_group_p0, w_group_cnt, w_xnorms;
     PinnedBuf p_group_p0, p_group_cnt, p_counters;
-    DevBuf w_pl_cnt, w_pl_need, w_pl_dist_base, w_pl_lcount, w_pl_lstart, w_pl_gbase, w_pl_ibase, w_pl_fill, w_pl_counters;
+    DevBuf w_pl_cnt, w_pl_need, w_pl_dist_base, w_pl_lcount, w_pl_lstart, w_pl_gbase, w_pl_ibase, w_pl_fill, w_pl_counters, w_seg_slot;
     DevBuf w_x8, w_xnorm8;  // signed byte copy of the current queries + per-query constants (launch_sbytes_from_f32)
     const float* x8_src = nullptr;  // what w_x8 holds when it is a slice of the resident queries (byte_queries)
     size_t x8_n = 0;
@@ -1835,7 +1835,8 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     h->w_pl_lstart.ensure(nlist * 4);
     h->w_pl_gbase.ensure(nlist * 4);
     h->w_pl_ibase.ensure(4 * nlist * 4);
-    h->w_pl_fill.ensure(nlist * 4);
+    h->w_pl_fill.ensure(8 * nlist * 4);  // (per-XCD pair counts)
+    h->w_seg_slot.ensure(seg_cap * 4);
     // 16 uint32 counters | double bytes | 2 x u64 slot bookkeeping | double min_bytes | per-round unfinished | double min_bytes of threshold rounds
     constexpr size_t CNT_WORDS = 24 + PLAN_MAX_ROUNDS + 2;
     h->w_pl_counters.ensure(CNT_WORDS * 4);
@@ -1911,7 +1912,8 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     pa.lstart = h->w_pl_lstart.as<uint32_t>();
     pa.gbase = h->w_pl_gbase.as<uint32_t>();
     pa.ibase = h->w_pl_ibase.as<uint32_t>();
-    pa.fill = h->w_pl_fill.as<uint32_t>();
+    pa.xcount = h->w_pl_fill.as<uint32_t>();
+    pa.seg_slot = h->w_seg_slot.as<uint32_t>();
     pa.pair_query = h->w_pair_query.as<uint32_t>();
     pa.pair_out = h->w_pair_out.as<uint64_t>();
     pa.group_p0 = h->w_group_p0.as<uint32_t>();

@@ -126,13 +126,32 @@ void launch_filter_queries(const float* x, size_t n, int d, int dpad, int metric
 __global__ __launch_bounds__(256) void amax_kernel(const float* x, size_t rows, int stride, uint32_t* info) {
     const int lane = threadIdx.x & 63;
     uint32_t mx_all = 0, bad = 0, inv_min = 0;
+    auto take = [&](float v, uint32_t& mx) {
+        const float av = fabsf(v);
+        const uint32_t bits = av == av ? __float_as_uint(av) : 0x7f800000u;  // (NaN counts as an infinity)
+        mx = bits > mx ? bits : mx;
+        bad |= !(v == (float)(int)v && av <= 2048.f);
+    };
     for (size_t r = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (size_t)gridDim.x * 4) {
         uint32_t mx = 0;
-        for (int c = lane; c < stride; c += 64) {
-            const float v = x[r * (size_t)stride + c], av = fabsf(v);
-            const uint32_t bits = av == av ? __float_as_uint(av) : 0x7f800000u;  // (NaN counts as an infinity)
-            mx = bits > mx ? bits : mx;
-            bad |= !(v == (float)(int)v && av <= 2048.f);
+        const float* row = x + r * (size_t)stride;
+        if ((stride & 3) == 0) {  // (rows are padded to multiples of four floats: 16 bytes per lane, four pieces in flight)
+            const v4f* row4 = reinterpret_cast<const v4f*>(row);
+            const int n4 = stride >> 2;
+            for (int c0 = 0; c0 < n4; c0 += 256) {
+                v4f t[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int c = c0 + u * 64 + lane;
+                    t[u] = c < n4 ? row4[c] : v4f{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) take(t[u][e], mx);
+            }
+        } else {
+            for (int c = lane; c < stride; c += 64) take(row[c], mx);
         }
         for (int off = 32; off; off >>= 1) {
             const uint32_t o = (uint32_t)__shfl_xor((int)mx, off);
@@ -150,7 +169,7 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* x, size_t rows, 
 }
 void launch_amax(const float* x, size_t rows, int stride, uint32_t* info, hipStream_t s) {  // (info: 4 words, zeroed by the caller)
     if (rows == 0) return;
-    const unsigned grid = (unsigned)std::min<size_t>((rows + 3) / 4, 2048);
+    const unsigned grid = (unsigned)std::min<size_t>((rows + 3) / 4, 8192);
     LAUNCH(amax_kernel, dim3(grid), dim3(256), 0, s, x, rows, stride, info);
 }
 // the power of two that brings a matrix's largest magnitude into [2^14, 2^15); 1 where every element is held exactly as it is, and

@@ -415,11 +415,12 @@ struct PlanArgs {
     uint32_t* qsel;                  // active slots, compacted
     int32_t* seg_list;
     uint64_t* seg_off;
-    uint32_t* lcount;                // [nlist] zeroed by the host before the round
+    uint32_t* lcount;                // [nlist] pairs per list (written by plan_lists_kernel)
     uint32_t* lstart;
     uint32_t* gbase;
     uint32_t* ibase;                 // [4][nlist]
-    uint32_t* fill;
+    uint32_t* xcount;                // [8 x nlist] pairs per (XCD that counted them, list); after plan_lists_kernel: the XCDs' offsets inside a list
+    uint32_t* seg_slot;              // [seg_cap] per pair: XCD << 28 | its place among that XCD's pairs of the list
     uint32_t* pair_query;
     uint64_t* pair_out;
     uint32_t* group_p0;

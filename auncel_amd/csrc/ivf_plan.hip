@@ -89,10 +89,24 @@ __device__ __forceinline__ void plan_counts_query(const PlanArgs& a, uint32_t i,
     }
 }
 __global__ __launch_bounds__(256) void plan_counts_kernel(PlanArgs a) {
-    // the per-list pair histogram of the round starts from zero (plan_segments_kernel, next on the stream, fills it)
-    for (uint32_t l = blockIdx.x * 256 + threadIdx.x; l < a.nlist; l += gridDim.x * 256) a.lcount[l] = 0;
+    // the per-(XCD, list) pair histogram of the round starts from zero (plan_segments_kernel, next on the stream, fills it)
+    for (uint32_t l = blockIdx.x * 256 + threadIdx.x; l < 8 * a.nlist; l += gridDim.x * 256) a.xcount[l] = 0;
     if (blockIdx.x == 0) plan_begin(a, threadIdx.x, 256);
     plan_counts_query(a, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+}
+
+// The XCD this wave runs on, and an add that is served by that XCD's L2 (workgroup scope: no trip to the memory side).  Pairs are
+// counted per (XCD, list): thousands of returning adds on ONE address from all eight XCDs are served one after the other at the
+// memory side, ~50 ns each -- a list probed by half the batch (skewed data), or a cursor every workgroup bumps, cost a planning
+// kernel 0.3 ms that way (cfg 5: profiles/r04_timeline_cfg5.txt); eight tables that no two XCDs share are coherent in their L2s
+// (scratch/ubench/xcc_atomic.hip: exact slot sets, 0.6 of the time even without contention).
+__device__ __forceinline__ uint32_t xcc_id() {
+    uint32_t v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 7u;
+}
+__device__ __forceinline__ uint32_t xcd_local_add(uint32_t* p, uint32_t v) {
+    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // exclusive prefix sums of N values per thread over a block of 1024 threads (16 waves): shuffles inside the waves, one LDS hop
@@ -177,6 +191,9 @@ __device__ __forceinline__ void plan_prefix_body(const PlanArgs& a) {
         if (c && !fits) atomicMin(&cut, i);
         a.seg_begin[i] = ecnt;
         a.dist_base[i] = eneed;
+        // launch positions of the active queries: their rank among the active ones (the deferred ones, all behind the cut, land
+        // behind every kept one and are not launched)
+        if (c) a.qsel[eact] = i;
         eneed += nd;
         ecnt += c;
         eact += c ? 1u : 0u;
@@ -219,7 +236,6 @@ __device__ __forceinline__ void plan_prefix_body(const PlanArgs& a) {
     if (t == 0) {
         a.counters[0] = s_nact;
         a.counters[1] = s_nseg;
-        a.counters[6] = 0;                   // compaction cursor of plan_segments_kernel
         a.counters[10] = s_more + s_def;     // queries that may still be unfinished after this round
         a.counters[11] = s_def;              // of those: deferred by the budget cut (the selection of this round does not see them)
         a.counters[7] = (uint32_t)(s_ndist >> 20);  // MiB of distances, for bookkeeping
@@ -235,9 +251,9 @@ __global__ __launch_bounds__(1024) void plan_prefix_kernel(PlanArgs a) { plan_pr
 
 // ---- 3. segments of every active query + histogram of pairs per list (one wave per query)
 // one wave: the segments of active query i (c probes), whose launch position is `slot`
-__device__ __forceinline__ void plan_segments_query(const PlanArgs& a, uint32_t i, uint32_t c, uint32_t slot, uint32_t lane) {
-    if (lane == 0) a.qsel[slot] = i;
+__device__ __forceinline__ void plan_segments_query(const PlanArgs& a, uint32_t i, uint32_t c, uint32_t lane) {
     const uint32_t stage = a.stage[i];
+    const uint32_t xcc = xcc_id();
     const int64_t* kq = a.keys + (size_t)i * a.key_stride + stage;
     unsigned long long cur = a.dist_base[i];  // wave-uniform running offset
     const unsigned long long ra = a.row_align - 1;
@@ -251,7 +267,9 @@ __device__ __forceinline__ void plan_segments_query(const PlanArgs& a, uint32_t 
             if (key >= 0 && (unsigned long long)key < a.nlist) {
                 const unsigned long long sz = a.list_off[key + 1] - a.list_off[key];
                 if (sz) {
-                    atomicAdd(&a.lcount[key], 1u);
+                    // this pair's place among the pairs of its list that were counted on this XCD (plan_scatter_query adds the
+                    // list's start and the XCD's offset inside the list)
+                    a.seg_slot[sb + p] = (xcc << 28) | xcd_local_add(&a.xcount[xcc * a.nlist + (uint32_t)key], 1u);
                     psz = (sz + ra) & ~ra;
                 }
             }
@@ -270,20 +288,8 @@ __device__ __forceinline__ void plan_segments_query(const PlanArgs& a, uint32_t 
 }
 __global__ __launch_bounds__(256) void plan_segments_kernel(PlanArgs a) {
     const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const uint32_t lane = threadIdx.x & 63;
-    // launch positions of the active queries (compaction order is irrelevant): one atomic per workgroup on the shared counter,
-    // not one per query -- thousands of waves on one address queue up in the L2
-    __shared__ uint32_t s_n, s_base;
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
     const uint32_t c = i < a.nq ? a.cnt[i] : 0u;
-    uint32_t local = 0;
-    if (c && lane == 0) local = atomicAdd(&s_n, 1u);
-    __syncthreads();
-    if (threadIdx.x == 0 && s_n) s_base = atomicAdd(&a.counters[6], s_n);
-    __syncthreads();
-    if (!c) return;
-    plan_segments_query(a, i, c, s_base + (uint32_t)__shfl((int)local, 0), lane);
+    if (c) plan_segments_query(a, i, c, threadIdx.x & 63);
 }
 
 // ---- 4. one block: per-list pair offsets, query-group bases, tile counts per workgroup shape (thread t owns a run of lists)
@@ -292,10 +298,9 @@ __device__ __forceinline__ void plan_lists_body(const PlanArgs& a) {
     __shared__ uint32_t s_w[17][6];
     const uint32_t t = threadIdx.x;
     // pairs, groups, tiles of shape 1, 2, 4, 8 of list l
-    auto values = [&](uint32_t l, uint32_t (&v)[6]) {
+    auto values = [&](uint32_t l, uint32_t c, uint32_t (&v)[6]) {
 #pragma unroll
         for (int k = 0; k < 6; k++) v[k] = 0;
-        const uint32_t c = a.lcount[l];
         if (!c) return;
         const unsigned long long sz = a.list_off[l + 1] - a.list_off[l];
         v[0] = c;
@@ -320,8 +325,17 @@ __device__ __forceinline__ void plan_lists_body(const PlanArgs& a) {
     uint32_t mine[6] = {0, 0, 0, 0, 0, 0};
     double list_bytes = 0;
     for (uint32_t l = l0; l < l1; l++) {
+        // the list's pairs = the sum of its eight per-XCD counts, which become the XCDs' offsets inside the list
+        uint32_t c = 0;
+#pragma unroll
+        for (uint32_t x = 0; x < 8; x++) {
+            const uint32_t cx = a.xcount[x * a.nlist + l];
+            a.xcount[x * a.nlist + l] = c;
+            c += cx;
+        }
+        a.lcount[l] = c;
         uint32_t v[6];
-        values(l, v);
+        values(l, c, v);
 #pragma unroll
         for (int k = 0; k < 6; k++) mine[k] += v[k];
         if (v[0]) list_bytes += (double)(a.list_off[l + 1] - a.list_off[l]) * (double)a.row_bytes;
@@ -332,14 +346,13 @@ __device__ __forceinline__ void plan_lists_body(const PlanArgs& a) {
     block_scan_1024_n<6>(mine, ex, tot, s_w);
     for (uint32_t l = l0; l < l1; l++) {
         uint32_t v[6];
-        values(l, v);
+        values(l, a.lcount[l], v);
         a.lstart[l] = ex[0];
         a.gbase[l] = ex[1];
         a.ibase[0 * a.nlist + l] = ex[2];
         a.ibase[1 * a.nlist + l] = ex[3];
         a.ibase[2 * a.nlist + l] = ex[4];
         a.ibase[3 * a.nlist + l] = ex[5];
-        a.fill[l] = 0;
 #pragma unroll
         for (int k = 0; k < 6; k++) ex[k] += v[k];
     }
@@ -371,7 +384,8 @@ __device__ __forceinline__ void plan_scatter_query(const PlanArgs& a, uint32_t i
         const int32_t key = a.seg_list[sb + p];
         if (key < 0 || (uint32_t)key >= a.nlist) continue;
         if (a.list_off[key + 1] == a.list_off[key]) continue;
-        const uint32_t pos = a.lstart[key] + atomicAdd(&a.fill[key], 1u);
+        const uint32_t ss = a.seg_slot[sb + p];
+        const uint32_t pos = a.lstart[key] + a.xcount[(ss >> 28) * a.nlist + (uint32_t)key] + (ss & 0x0fffffffu);
         a.pair_query[pos] = a.slot_base + i;
         a.pair_out[pos] = a.seg_off[sb + p];
     }
@@ -470,10 +484,8 @@ __global__ __launch_bounds__(256) void plan_scatter_items_kernel(PlanArgs a, uin
 constexpr uint32_t PLAN_SMALL_NQ = 32;
 __global__ __launch_bounds__(1024) void plan_small_kernel(PlanArgs a) {
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    __shared__ uint32_t s_slot;
-    for (uint32_t l = tid; l < a.nlist; l += 1024) a.lcount[l] = 0;
+    for (uint32_t l = tid; l < 8 * a.nlist; l += 1024) a.xcount[l] = 0;
     plan_begin(a, tid, 1024);
-    if (tid == 0) s_slot = 0;
     __syncthreads();  // (the history copy reads the counters before the prefix phase writes them)
     for (uint32_t i = wave; i < a.nq; i += 16) plan_counts_query(a, i, lane);
     __syncthreads();
@@ -481,10 +493,7 @@ __global__ __launch_bounds__(1024) void plan_small_kernel(PlanArgs a) {
     __syncthreads();
     for (uint32_t i = wave; i < a.nq; i += 16) {
         const uint32_t c = a.cnt[i];
-        if (!c) continue;
-        uint32_t slot = 0;
-        if (lane == 0) slot = atomicAdd(&s_slot, 1u);
-        plan_segments_query(a, i, c, (uint32_t)__shfl((int)slot, 0), lane);
+        if (c) plan_segments_query(a, i, c, lane);
     }
     __syncthreads();
     plan_lists_body(a);
