@@ -321,9 +321,36 @@ __device__ __forceinline__ void plan_lists_body(const PlanArgs& a) {
             v[2 + scan_qg_class(qg)] += (uint32_t)((sz + tv - 1) / tv);
         }
     };
+    // tile bookkeeping of a list in closed form (what its items will compute / what was asked for): (sum over its query blocks) x
+    // (sum over its chunks) -- here, by the one workgroup that walks every list anyway, not by one atomic pair per wave of the
+    // item kernel
+    auto book = [&](uint32_t l, uint32_t c, unsigned long long& slots, unsigned long long& useful) {
+        if (!c) return;
+        const unsigned long long sz = a.list_off[l + 1] - a.list_off[l];
+        useful += (unsigned long long)c * sz;
+        if (a.mfma_chunk) {
+            const unsigned long long nvb = (sz + a.mfma_chunk - 1) / a.mfma_chunk, lastv = sz - (nvb - 1) * a.mfma_chunk;
+            const unsigned long long vsum = (nvb - 1) * (((unsigned long long)a.mfma_chunk + 63) / 64 * 64) + (lastv + 63) / 64 * 64;
+            const unsigned long long nqb = (c + a.mfma_qblock - 1) / a.mfma_qblock, lastq = c - (nqb - 1) * a.mfma_qblock;
+            const unsigned long long qsum = (nqb - 1) * (((unsigned long long)a.mfma_qblock + MFMA_QBLOCK - 1) / MFMA_QBLOCK * MFMA_QBLOCK) +
+                                            (lastq + MFMA_QBLOCK - 1) / MFMA_QBLOCK * MFMA_QBLOCK;
+            slots += qsum * vsum;
+            return;
+        }
+        const uint32_t full = c / a.qblock, rem = c % a.qblock;
+        if (full) {
+            const uint32_t tv = scan_tile_vecs(scan_shape_of(a.qblock));
+            slots += (unsigned long long)full * ((a.qblock + SCAN_RQ - 1) / SCAN_RQ * SCAN_RQ) * ((sz + tv - 1) / tv) * tv;
+        }
+        if (rem) {
+            const uint32_t tv = scan_tile_vecs(scan_shape_of(rem));
+            slots += (unsigned long long)((rem + SCAN_RQ - 1) / SCAN_RQ * SCAN_RQ) * ((sz + tv - 1) / tv) * tv;
+        }
+    };
     const uint32_t per = (a.nlist + 1023) / 1024, l0 = t * per, l1 = l0 + per < a.nlist ? l0 + per : a.nlist;
     uint32_t mine[6] = {0, 0, 0, 0, 0, 0};
     double list_bytes = 0;
+    unsigned long long my_slots = 0, my_useful = 0;
     for (uint32_t l = l0; l < l1; l++) {
         // the list's pairs = the sum of its eight per-XCD counts, which become the XCDs' offsets inside the list
         uint32_t c = 0;
@@ -334,11 +361,20 @@ __device__ __forceinline__ void plan_lists_body(const PlanArgs& a) {
             c += cx;
         }
         a.lcount[l] = c;
+        book(l, c, my_slots, my_useful);
         uint32_t v[6];
         values(l, c, v);
 #pragma unroll
         for (int k = 0; k < 6; k++) mine[k] += v[k];
         if (v[0]) list_bytes += (double)(a.list_off[l + 1] - a.list_off[l]) * (double)a.row_bytes;
+    }
+    for (int off = 32; off; off >>= 1) {
+        my_slots += __shfl_xor(my_slots, off);
+        my_useful += __shfl_xor(my_useful, off);
+    }
+    if ((t & 63) == 0 && my_slots) {  // (16 waves)
+        atomicAdd(&a.acc64[0], my_slots);
+        atomicAdd(&a.acc64[1], my_useful);
     }
     if (a.min_bytes && list_bytes > 0) atomicAdd(a.min_bytes, list_bytes);
     if (a.min_bytes_thr && !a.dense_round && list_bytes > 0) atomicAdd(a.min_bytes_thr, list_bytes);
@@ -392,7 +428,7 @@ __device__ __forceinline__ void plan_scatter_query(const PlanArgs& a, uint32_t i
 }
 
 // ---- 6. tiles and query groups of every list (one thread per list), shapes 1 | 2 | 4 in three item ranges
-__device__ inline void items_of_list(const PlanArgs& a, uint32_t l, uint32_t c, unsigned long long& slots, unsigned long long& useful) {
+__device__ inline void items_of_list(const PlanArgs& a, uint32_t l, uint32_t c) {
     const uint32_t p0 = a.lstart[l], g0 = a.gbase[l];
     for (uint32_t o = 0, g = 0; o < c; o += SCAN_RQ, g++) {
         a.group_p0[g0 + g] = p0 + o;
@@ -424,8 +460,6 @@ __device__ inline void items_of_list(const PlanArgs& a, uint32_t l, uint32_t c, 
                 it.qgroup = (uint32_t)(vb0 + vb);  // global index of the chunk's first vector (the fp32 filter's exact rescoring)
                 if (ni < a.item_cap) a.items[ni] = it;
                 ni++;
-                slots += (unsigned long long)(((it.npair + MFMA_QBLOCK - 1) / MFMA_QBLOCK) * MFMA_QBLOCK) * (((it.nvec + 63) / 64) * 64);
-                useful += (unsigned long long)it.npair * it.nvec;
             }
         }
         return;
@@ -446,36 +480,94 @@ __device__ inline void items_of_list(const PlanArgs& a, uint32_t l, uint32_t c, 
             it.qgroup = g0 + qb / SCAN_RQ;
             if (ni < a.item_cap) a.items[ni] = it;
             ni++;
-            slots += (unsigned long long)((nq_blk + SCAN_RQ - 1) / SCAN_RQ) * SCAN_RQ * tv;
-            useful += (unsigned long long)nq_blk * it.nvec;
         }
     }
 }
 
 
-// the items of list l (one thread per list; the tile bookkeeping of a wave in one pair of atomics)
+// the items of list l, one thread (a call of a few queries: plan_small_kernel)
 __device__ __forceinline__ void plan_items_lists(const PlanArgs& a, uint32_t l) {
     const uint32_t c = l < a.nlist ? a.lcount[l] : 0u;
-    unsigned long long slots = 0, useful = 0;
-    if (c) items_of_list(a, l, c, slots, useful);
-    for (int off = 32; off; off >>= 1) {
-        slots += __shfl_xor(slots, off);
-        useful += __shfl_xor(useful, off);
+    if (c) items_of_list(a, l, c);
+}
+
+// ... one WAVE per list, the lanes striding over its query groups and items: with one thread per list the launch took as long as
+// its busiest list (a list probed by a fifth of a 10000-query batch: 2500 items written one after the other, 0.29 ms of cfg 1's
+// 1.6 ms step).  Same items at the same positions as items_of_list.
+__device__ inline void items_of_list_wave(const PlanArgs& a, uint32_t l, uint32_t c, uint32_t lane) {
+    const uint32_t p0 = a.lstart[l], g0 = a.gbase[l];
+    for (uint32_t g = lane; g * SCAN_RQ < c; g += 64) {
+        const uint32_t o = g * SCAN_RQ;
+        a.group_p0[g0 + g] = p0 + o;
+        a.group_cnt[g0 + g] = c - o < (uint32_t)SCAN_RQ ? c - o : (uint32_t)SCAN_RQ;
     }
-    if ((threadIdx.x & 63) == 0 && slots) {
-        atomicAdd(&a.acc64[0], slots);
-        atomicAdd(&a.acc64[1], useful);
+    const uint32_t n1 = a.counters[4], n2 = a.counters[5], n4 = a.counters[8];
+    const uint32_t cur[4] = {a.ibase[l], n1 + a.ibase[a.nlist + l], n1 + n2 + a.ibase[2 * a.nlist + l],
+                             n1 + n2 + n4 + a.ibase[3 * a.nlist + l]};
+    const uint32_t sz = (uint32_t)(a.list_off[l + 1] - a.list_off[l]);
+    const uint64_t vb0 = a.list_off[l];
+    if (a.mfma_chunk) {
+        const uint64_t b0 = a.block_off[l];
+        const uint32_t nvb = (sz + a.mfma_chunk - 1) / a.mfma_chunk, nqb = (c + a.mfma_qblock - 1) / a.mfma_qblock;
+        for (uint32_t o = lane; o < nvb * nqb; o += 64) {
+            const uint32_t vb = (a.item_order ? o % nvb : o / nqb) * a.mfma_chunk, qb = (a.item_order ? o / nvb : o % nqb) * a.mfma_qblock;
+            ScanItem it;
+            it.vec_base = b0 + vb / MFMA_BLOCK;
+            it.nvec = sz - vb < a.mfma_chunk ? sz - vb : a.mfma_chunk;
+            it.vec_off = vb;
+            it.pair_begin = p0 + qb;
+            it.npair = c - qb < a.mfma_qblock ? c - qb : a.mfma_qblock;
+            it.qg = 0;
+            it.qgroup = (uint32_t)(vb0 + vb);
+            if (cur[3] + o < a.item_cap) a.items[cur[3] + o] = it;
+        }
+        return;
+    }
+    // fp32 tiles: the full query blocks (all of one shape) come first, each with its tiles; then the remainder block's
+    const uint32_t full = c / a.qblock, rem = c % a.qblock;
+    const uint32_t qg_f = scan_shape_of(a.qblock), tv_f = scan_tile_vecs(qg_f), nt_f = (sz + tv_f - 1) / tv_f;
+    const int cls_f = scan_qg_class(qg_f);
+    for (uint32_t o = lane; o < full * nt_f; o += 64) {
+        const uint32_t qb = (o / nt_f) * a.qblock, vb = (o % nt_f) * tv_f;
+        ScanItem it;
+        it.vec_base = vb0 + vb;
+        it.nvec = sz - vb < tv_f ? sz - vb : tv_f;
+        it.vec_off = vb;
+        it.pair_begin = p0 + qb;
+        it.npair = a.qblock;
+        it.qg = qg_f;
+        it.qgroup = g0 + qb / SCAN_RQ;
+        if (cur[cls_f] + o < a.item_cap) a.items[cur[cls_f] + o] = it;
+    }
+    if (rem) {
+        const uint32_t qg_r = scan_shape_of(rem), tv_r = scan_tile_vecs(qg_r), nt_r = (sz + tv_r - 1) / tv_r;
+        const int cls_r = scan_qg_class(qg_r);
+        const uint32_t base = cur[cls_r] + (cls_r == cls_f ? full * nt_f : 0u), qb = full * a.qblock;
+        for (uint32_t o = lane; o < nt_r; o += 64) {
+            const uint32_t vb = o * tv_r;
+            ScanItem it;
+            it.vec_base = vb0 + vb;
+            it.nvec = sz - vb < tv_r ? sz - vb : tv_r;
+            it.vec_off = vb;
+            it.pair_begin = p0 + qb;
+            it.npair = rem;
+            it.qg = qg_r;
+            it.qgroup = g0 + qb / SCAN_RQ;
+            if (base + o < a.item_cap) a.items[base + o] = it;
+        }
     }
 }
 
 // ---- 5 + 6 in one launch (both read what plan_lists_kernel left, neither reads the other's output): the first gq workgroups
-//      scatter the pairs of four queries each, the rest make the items of 256 lists each
+//      scatter the pairs of four queries each, the rest make the items of four lists each (a wave per list)
 __global__ __launch_bounds__(256) void plan_scatter_items_kernel(PlanArgs a, uint32_t gq) {
     if (blockIdx.x < gq) {
         plan_scatter_query(a, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
         return;
     }
-    plan_items_lists(a, (blockIdx.x - gq) * 256 + threadIdx.x);
+    const uint32_t l = (blockIdx.x - gq) * 4 + (threadIdx.x >> 6);
+    const uint32_t c = l < a.nlist ? a.lcount[l] : 0u;
+    if (c) items_of_list_wave(a, l, c, threadIdx.x & 63);
 }
 
 // ---- a call of a few queries (the reference's callers issue one search per query, eval/bound.cpp:391-396): the whole pass in ONE
@@ -509,7 +601,7 @@ void launch_plan(const PlanArgs& a, hipStream_t s) {
         LAUNCH(plan_small_kernel, dim3(1), dim3(1024), 0, s, a);
         return;
     }
-    const unsigned gq = (a.nq + 3) / 4 /* one wave per query */, gl = (a.nlist + 255) / 256;
+    const unsigned gq = (a.nq + 3) / 4 /* one wave per query */, gl = (a.nlist + 3) / 4 /* one wave per list */;
     LAUNCH(plan_counts_kernel, dim3(gq), dim3(256), 0, s, a);
     LAUNCH(plan_prefix_kernel, dim3(1), dim3(1024), 0, s, a);
     LAUNCH(plan_segments_kernel, dim3(gq), dim3(256), 0, s, a);
