@@ -116,6 +116,20 @@ struct ItemWalk {
 };
 
 
+// The XCD this wave runs on, and adds that are served by that XCD's L2 (workgroup scope: no trip to the memory side).  Only for
+// words that no other XCD touches during the launch (per-XCD tables: ivf_plan.hip, STATS_ROWS).
+__device__ __forceinline__ uint32_t xcc_id() {
+    uint32_t v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 7u;
+}
+__device__ __forceinline__ uint32_t xcd_local_add(uint32_t* p, uint32_t v) {
+    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void xcd_local_add64(unsigned long long* p, unsigned long long v) {
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // reg[lane LANE] = val (val wave-uniform, LANE a compile-time constant: an inline operand, so the one SGPR slot is val's)
 template <int LANE> __device__ __forceinline__ void writelane_c(int& reg, uint32_t val) {
     asm("v_writelane_b32 %0, %1, %2" : "+v"(reg) : "s"(val), "n"(LANE));

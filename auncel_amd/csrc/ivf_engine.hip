@@ -669,7 +669,7 @@ void init_state(amd_ivf* h, size_t n, size_t k, bool tune_or_train) {
     h->w_stoped.ensure(n * 4);
     h->w_D.ensure(n * k * sizeof(float));
     h->w_I.ensure(n * k * sizeof(int64_t));
-    h->w_stats.ensure(4 * 8);
+    h->w_stats.ensure(STATS_ROWS * 4 * 8);
     h->w_error.ensure(4);
     h->w_thr.ensure(n * sizeof(float));
     h->w_log_cnt.ensure(n * 4);
@@ -1266,11 +1266,18 @@ template <class F> static void with_select_fallback(amd_ivf* h, F&& body) {
     }
 }
 
+// the device statistics of a call: the sum of the per-XCD rows (STATS_ROWS)
+static void sum_stat_rows(const unsigned long long* rows, unsigned long long out[4]) {
+    for (int k = 0; k < 4; k++) out[k] = 0;
+    for (uint32_t r = 0; r < STATS_ROWS; r++)
+        for (int k = 0; k < 4; k++) out[k] += rows[4 * r + k];
+}
 void fold_stats(amd_ivf* h, size_t nq) {
-    unsigned long long st[4];
+    unsigned long long rows[4 * STATS_ROWS], st[4];
     SmallCopies guard(h);
-    d2h_small(h, st, h->w_stats.p, 32, h->stream);
+    d2h_small(h, rows, h->w_stats.p, sizeof rows, h->stream);
     sync_and_flush(h, h->stream);
+    sum_stat_rows(rows, st);
     if (nq) ix(h)->tie_rate.store((float)((double)st[3] / (double)nq));
     h->stats_host[0] += nq;
     h->stats_host[1] += st[0];
@@ -1315,11 +1322,13 @@ struct DirectOut {
 void finish_results(amd_ivf* h, size_t n, size_t k, float* D, int64_t* I, uint32_t* stage_out = nullptr, bool defer = false) {
     struct Back {
         uint32_t err = 0;
+        unsigned long long rows[4 * STATS_ROWS];
         unsigned long long st[4] = {0, 0, 0, 0};
     };
     auto back = std::make_shared<Back>();
     auto epilogue = [h, n, back]() {
         throw_device_error(back->err);
+        sum_stat_rows(back->rows, back->st);
         if (n) ix(h)->tie_rate.store((float)((double)back->st[3] / (double)n));
         h->stats_host[0] += n;
         h->stats_host[1] += back->st[0];
@@ -1328,7 +1337,7 @@ void finish_results(amd_ivf* h, size_t n, size_t k, float* D, int64_t* I, uint32
     };
     auto queue = [&] {
         d2h_small(h, &back->err, h->w_error.p, 4, h->stream);
-        d2h_small(h, back->st, h->w_stats.p, 32, h->stream);
+        d2h_small(h, back->rows, h->w_stats.p, sizeof back->rows, h->stream);
         if (stage_out) d2h_small(h, stage_out, h->w_stage.p, n * 4, h->stream);
         if (!h->out_D) {  // (else the kernels wrote the caller's buffers themselves)
             d2h_small(h, D, h->w_D.p, n * k * sizeof(float), h->stream);
@@ -1838,7 +1847,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     h->w_pl_fill.ensure(8 * nlist * 4);  // (per-XCD pair counts)
     h->w_seg_slot.ensure(seg_cap * 4);
     // 16 uint32 counters | double bytes | 2 x u64 slot bookkeeping | double min_bytes | per-round unfinished | double min_bytes of threshold rounds
-    constexpr size_t CNT_WORDS = 24 + PLAN_MAX_ROUNDS + 2;
+    constexpr size_t CNT_WORDS = 24 + PLAN_MAX_ROUNDS * 8 + 2;  // (... | per round and XCD: unfinished | ...)
     h->w_pl_counters.ensure(CNT_WORDS * 4);
     h->p_counters.ensure(CNT_WORDS * 4);
     h->w_dist.ensure((budget + 4096) * sizeof(float));  // (+ the blocks the selection's stream requests past a region's end)
@@ -1924,10 +1933,10 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     pa.bytes = reinterpret_cast<double*>(h->w_pl_counters.as<uint32_t>() + 16);
     pa.acc64 = reinterpret_cast<unsigned long long*>(h->w_pl_counters.as<uint32_t>() + 18);
     pa.min_bytes = reinterpret_cast<double*>(h->w_pl_counters.as<uint32_t>() + 22);
-    pa.min_bytes_thr = reinterpret_cast<double*>(h->w_pl_counters.as<uint32_t>() + 24 + PLAN_MAX_ROUNDS);
+    pa.min_bytes_thr = reinterpret_cast<double*>(h->w_pl_counters.as<uint32_t>() + 24 + PLAN_MAX_ROUNDS * 8);
     pa.row_bytes = base.bytes ? mfma_ksteps(h->d) * 32 : (uint32_t)h->dpad * 4;
     pa.error = h->w_error.as<uint32_t>();
-    uint32_t* const d_unfinished = h->w_pl_counters.as<uint32_t>() + 24;  // [PLAN_MAX_ROUNDS]
+    uint32_t* const d_unfinished = h->w_pl_counters.as<uint32_t>() + 24;  // [PLAN_MAX_ROUNDS][8 XCDs]
     pa.round_unfinished = d_unfinished;
     if (base.d_budget_ms) {
         h->w_limit.ensure(n * 4);
@@ -2193,7 +2202,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         ra.train = base.train;
         ra.limit = base.d_budget_ms ? h->w_limit.as<uint32_t>() : nullptr;
         ra.qstat = h->w_qstat.as<uint2>();
-        ra.unfinished = round < PLAN_MAX_ROUNDS ? d_unfinished + round : nullptr;
+        ra.unfinished = round < PLAN_MAX_ROUNDS ? d_unfinished + round * 8 : nullptr;
         if (sorted_ok) {
             ra.log = h->w_log.as<uint2>();
             ra.log_cap = (uint32_t)log_cap;
@@ -2301,8 +2310,10 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
                 host_stamp("enqueued");
                 HIP_CHECK(stream_sync(s));
                 host_stamp("look-sync");
-                const uint32_t left = hc[24 + round - 1] + hc[11];
-                if (dbg_timing()) fprintf(stderr, "[rounds/chained] after round %zu: unfinished %u deferred %u\n", round, hc[24 + round - 1], hc[11]);
+                uint32_t unf = 0;
+                for (int x = 0; x < 8; x++) unf += hc[24 + (round - 1) * 8 + x];
+                const uint32_t left = unf + hc[11];
+                if (dbg_timing()) fprintf(stderr, "[rounds/chained] after round %zu: unfinished %u deferred %u\n", round, unf, hc[11]);
                 if (left == 0) break;
                 plan_round(round_len);
             } else {
@@ -2349,7 +2360,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
                 ga.out_off = h->w_roff.as<unsigned long long>();
                 ga.stage = h->w_stage.as<uint32_t>();
                 ga.done = h->w_done.as<uint32_t>();
-                ga.stats = h->w_stats.as<unsigned long long>();
+                ga.stats = h->w_stats.as<unsigned long long>() + 4 * (STATS_ROWS - 1);  // (ordinary atomics: the last row)
                 ga.error = h->w_error.as<uint32_t>();
                 size_t t = h->timer.begin(CAT_SELECT, s);
                 launch_range_count(ga, s);
@@ -2430,7 +2441,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         }
         h->scan_bytes += *reinterpret_cast<double*>(hc + 16);
         h->scan_min_bytes += *reinterpret_cast<double*>(hc + 22);
-        h->scan_min_bytes_thr += *reinterpret_cast<double*>(hc + 24 + PLAN_MAX_ROUNDS);
+        h->scan_min_bytes_thr += *reinterpret_cast<double*>(hc + 24 + PLAN_MAX_ROUNDS * 8);
         const unsigned long long* acc = reinterpret_cast<const unsigned long long*>(hc + 18);
         h->scan_slots += (double)acc[0];
         h->scan_useful += (double)acc[1];
@@ -3046,9 +3057,10 @@ int amd_ivf_scan_codes(amd_ivf_t* h, const float* query, size_t list_no, int sto
     check_device_error(h);
     HIP_CHECK(hipMemcpyAsync(simi, h->w_D.p, k * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipMemcpyAsync(idxi, h->w_I.p, k * 8, hipMemcpyDeviceToHost, h->stream));
-    unsigned long long st[3];
-    HIP_CHECK(hipMemcpyAsync(st, h->w_stats.p, 24, hipMemcpyDeviceToHost, h->stream));
+    unsigned long long rows[4 * STATS_ROWS], st[4];
+    HIP_CHECK(hipMemcpyAsync(rows, h->w_stats.p, sizeof rows, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(stream_sync(h->stream));
+    sum_stat_rows(rows, st);
     if (nup) *nup = st[2];
     double ms[NCAT], ln[NCAT];
     h->timer.collect(ms, NCAT, ln);

@@ -161,15 +161,26 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* x, size_t rows, 
         if (mx != 0 && 0x7f800000u - mx > inv_min) inv_min = 0x7f800000u - mx;
     }
     for (int off = 32; off; off >>= 1) bad |= (uint32_t)__shfl_xor((int)bad, off);
+    // one set of atomics per workgroup, and few workgroups (launch_amax): thousands of waves adding to the same three words are
+    // served one after the other at the memory side -- 0.35 ms for 10000 rows when every wave did
+    __shared__ uint32_t s_mx, s_bad, s_inv;
+    if (threadIdx.x == 0) s_mx = s_bad = s_inv = 0;
+    __syncthreads();
     if (lane == 0) {
-        atomicMax(&info[0], mx_all);
-        if (bad) atomicOr(&info[1], 1u);
-        atomicMax(&info[2], inv_min);
+        atomicMax(&s_mx, mx_all);
+        if (bad) atomicOr(&s_bad, 1u);
+        atomicMax(&s_inv, inv_min);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMax(&info[0], s_mx);
+        if (s_bad) atomicOr(&info[1], 1u);
+        atomicMax(&info[2], s_inv);
     }
 }
 void launch_amax(const float* x, size_t rows, int stride, uint32_t* info, hipStream_t s) {  // (info: 4 words, zeroed by the caller)
     if (rows == 0) return;
-    const unsigned grid = (unsigned)std::min<size_t>((rows + 3) / 4, 8192);
+    const unsigned grid = (unsigned)std::min<size_t>((rows + 3) / 4, 512);
     LAUNCH(amax_kernel, dim3(grid), dim3(256), 0, s, x, rows, stride, info);
 }
 // the power of two that brings a matrix's largest magnitude into [2^14, 2^15); 1 where every element is held exactly as it is, and

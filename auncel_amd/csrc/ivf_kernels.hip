@@ -2149,7 +2149,7 @@ __global__ __launch_bounds__(256) void init_state_kernel(InitStateArgs a) {
             a.fix_pos[i] = 0;
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x < 4) a.stats[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < 4 * STATS_ROWS) a.stats[threadIdx.x] = 0;
     if (blockIdx.x == 0 && threadIdx.x == 4) *a.error = 0;
 }
 

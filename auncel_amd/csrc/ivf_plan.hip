@@ -5,7 +5,7 @@
 // pairs grouped by inverted list, the packed query groups and the tile list -- is derived here on the GPU from
 // the per-query state the replay kernel left behind, so that a round costs the host one 32-byte read-back
 // instead of a pass over every pair.
-#include "ivf_kernels.h"
+#include "ivf_dev.h"
 
 namespace amdivf {
 
@@ -22,7 +22,7 @@ __device__ __forceinline__ void plan_begin(const PlanArgs& a, uint32_t tid, uint
         if (a.min_bytes_thr) a.min_bytes_thr[0] = 0.0;
     }
     if (a.first_plan && a.round_unfinished)
-        for (uint32_t r = tid; r < PLAN_MAX_ROUNDS; r += nthreads) a.round_unfinished[r] = 0;
+        for (uint32_t r = tid; r < PLAN_MAX_ROUNDS * 8; r += nthreads) a.round_unfinished[r] = 0;
 }
 // one wave: query i
 __device__ __forceinline__ void plan_counts_query(const PlanArgs& a, uint32_t i, uint32_t lane) {
@@ -100,15 +100,6 @@ __global__ __launch_bounds__(256) void plan_counts_kernel(PlanArgs a) {
 // memory side, ~50 ns each -- a list probed by half the batch (skewed data), or a cursor every workgroup bumps, cost a planning
 // kernel 0.3 ms that way (cfg 5: profiles/r04_timeline_cfg5.txt); eight tables that no two XCDs share are coherent in their L2s
 // (scratch/ubench/xcc_atomic.hip: exact slot sets, 0.6 of the time even without contention).
-__device__ __forceinline__ uint32_t xcc_id() {
-    uint32_t v;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
-    return v & 7u;
-}
-__device__ __forceinline__ uint32_t xcd_local_add(uint32_t* p, uint32_t v) {
-    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
 // exclusive prefix sums of N values per thread over a block of 1024 threads (16 waves): shuffles inside the waves, one LDS hop
 // for the wave totals; `total` receives the block's sums.  s_wave: 17 x N entries of shared memory, reusable on return.  All N at
 // once: the three barriers are what a scan costs a single workgroup that has nothing else to run (six scans one after the other

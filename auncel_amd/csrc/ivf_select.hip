@@ -944,9 +944,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
             qs.y += (uint32_t)st_nheap;
             a.qstat[qi] = qs;
         }
-        if (st_nlist) atomicAdd(&a.stats[0], st_nlist);
-        if (st_ndis) atomicAdd(&a.stats[1], st_ndis);
-        if (st_nheap) atomicAdd(&a.stats[2], st_nheap);
+        {
+            unsigned long long* st = a.stats + 4 * xcc_id();  // (this XCD's row: STATS_ROWS)
+            if (st_nlist) xcd_local_add64(&st[0], st_nlist);
+            if (st_ndis) xcd_local_add64(&st[1], st_ndis);
+            if (st_nheap) xcd_local_add64(&st[2], st_nheap);
+        }
         if (err) atomicMax(a.error, err);
         if (a.dbg) {
             a.dbg[(size_t)li * 8 + 0] = __builtin_readcyclecounter() - dbg_t0;
@@ -1010,7 +1013,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
             a.heap_val[(size_t)qi * k + i] = hval[i];
             a.heap_ref[(size_t)qi * k + i] = href[i];
         }
-        if (lane == 0 && a.unfinished) atomicAdd(a.unfinished, 1u);
+        if (lane == 0 && a.unfinished) (void)xcd_local_add(&a.unfinished[xcc_id()], 1u);
     }
 }
 
@@ -1512,9 +1515,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 
             qs.y += (uint32_t)st_nheap;
             a.qstat[qi] = qs;
         }
-        if (st_nlist) atomicAdd(&a.stats[0], st_nlist);
-        if (st_ndis) atomicAdd(&a.stats[1], st_ndis);
-        if (st_nheap) atomicAdd(&a.stats[2], (unsigned long long)st_nheap);
+        {
+            unsigned long long* st = a.stats + 4 * xcc_id();  // (this XCD's row: STATS_ROWS)
+            if (st_nlist) xcd_local_add64(&st[0], st_nlist);
+            if (st_ndis) xcd_local_add64(&st[1], st_ndis);
+            if (st_nheap) xcd_local_add64(&st[2], (unsigned long long)st_nheap);
+        }
         if (err) atomicMax(a.error, err);
         if (a.dbg) {
             a.dbg[(size_t)li * 8 + 0] = __builtin_readcyclecounter() - dbg_t0;
@@ -1542,7 +1548,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 
         if (tainted && !err) {
             if (lane == 0) {
                 a.tie_flag[qi] = 1;  // tie_fix_kernel writes this query's (D, I)
-                atomicAdd(&a.stats[3], 1ull);  // (how common that is decides when tie_fix_kernel runs: run_rounds_device)
+                xcd_local_add64(&a.stats[4 * xcc_id() + 3], 1ull);  // (how common that is decides when tie_fix_kernel runs: run_rounds_device)
             }
         } else {
             auto put = [&](int i, uint32_t key, uint32_t g) {
@@ -1567,7 +1573,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 
         }
         if (lane == 0) {
             a.amb[qi] = amb;
-            if (a.unfinished) atomicAdd(a.unfinished, 1u);
+            if (a.unfinished) (void)xcd_local_add(&a.unfinished[xcc_id()], 1u);
         }
     }
 }
