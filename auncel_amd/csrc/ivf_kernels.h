@@ -218,7 +218,7 @@ inline __host__ __device__ int scan_qg_class(uint32_t qg) { return qg == 1 ? 0 :
 // issue slots rather than of VALU; 32: 4-wave tiles, the fp32 scans); the last block takes the narrowest shape that holds it.
 constexpr uint32_t SCAN_QBLOCK = 8 * SCAN_RQ;  // the largest block
 inline __host__ __device__ uint32_t scan_shape_of(uint32_t r) { return r <= SCAN_RQ ? 1u : r <= 2 * SCAN_RQ ? 2u : r <= 4 * SCAN_RQ ? 4u : 8u; }
-inline __host__ __device__ uint32_t scan_tile_vecs(uint32_t qg) { return (qg >= 4 ? 1u : 4u / qg) * SCAN_WAVE_VECS; }
+inline __host__ __device__ uint32_t scan_tile_vecs(uint32_t qg) { return (qg >= 4 || qg == 1 ? 1u : 4u / qg) * SCAN_WAVE_VECS; }  // (ScanShape)
 
 // ---------------------------------------------------------------------------- ordered selection
 // One wave per query replays the reference's sequential heap (Heap.h) over the distance rows in

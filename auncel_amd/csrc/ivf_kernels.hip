@@ -37,15 +37,18 @@ constexpr int LDS_ROW = SCAN_DC + 4;                 // dwords per staged row (p
 
 // QG = query groups per workgroup (1, 2, 4 or 8): QG groups of 8 queries x VG blocks of 128 vectors, one wave
 // each.  QG 8: 8 waves share one 128-vector tile (64 queries per pass over the list); QG 4: 4 waves, 128 vectors;
-// QG 2 / 1: 4 waves over 256 / 512 vectors.  The staged tile (and the LDS footprint) follows.
+// QG 2: 4 waves over 256 vectors; QG 1: one wave, 128 vectors.  The staged tile (and the LDS footprint) follows.
 //
 // ARITH selects the arithmetic (the result is the same fp32 number either way):
 //   0  the reference's SSE order: four running sums over elements 4i+l, separate multiply and add
 //   1  the same order with fma, legal when operands are small integers (see IntRange in the engine)
 // (uint8-valued data takes scan_mfma_kernel below instead: exact integer contraction on the i8 matrix cores)
+// QG 1 (at most 8 queries on the list): ONE wave per workgroup over 128 vectors -- four waves over 512 vectors left half of
+// them staging and waiting at barriers for nothing on lists shorter than that (cfg 5: 244 vectors a list, 7 queries each; the
+// dense round of its fp32 search ran at 12 % of the vector ALU's rate), and nothing is shared between waves at QG 1.
 template <int QG> struct ScanShape {
-    static constexpr int NT = QG == 8 ? 512 : 256;
-    static constexpr int vg = QG >= 4 ? 1 : 4 / QG;
+    static constexpr int NT = QG == 8 ? 512 : QG == 1 ? 64 : 256;
+    static constexpr int vg = QG >= 4 || QG == 1 ? 1 : 4 / QG;
     static constexpr int tile_vecs = vg * SCAN_WAVE_VECS;
     static constexpr int lds_floats = tile_vecs * LDS_ROW;
 };
@@ -239,7 +242,7 @@ __device__ __forceinline__ void scan_tile_one(const ScanArgs& a, const ScanItem 
 }
 
 template <int METRIC, int QG, int ARITH>
-__global__ __launch_bounds__(QG == 8 ? 512 : 256) void scan_tiles_kernel(ScanArgs a) {
+__global__ __launch_bounds__(ScanShape<QG>::NT) void scan_tiles_kernel(ScanArgs a) {
     // two staging buffers: chunk c+1 is fetched into registers while chunk c is being consumed, and written
     // to the other buffer, so a workgroup needs one barrier per chunk and hides its own fetch latency
     __shared__ float lds[2][ScanShape<QG>::lds_floats];
@@ -303,7 +306,7 @@ template <int QG> static void launch_scan_qg(ScanArgs a, size_t first, size_t n,
     if (!a.dev_counts) a.items += first;
     a.nitems = (uint32_t)n;
     // chained rounds: n is only a bound; a resident grid walks the device-side count
-    const int threads = QG == 8 ? 512 : 256;
+    const int threads = ScanShape<QG>::NT;
     const uint32_t hint = a.hint_qg[scan_qg_class(QG)];
     auto go = [&](auto kern) {
         static const unsigned per_cu = blocks_per_cu(kern, threads);
