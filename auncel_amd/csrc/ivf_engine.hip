@@ -64,7 +64,7 @@ enum OptId {
     OPT_SCAN_PIPELINED, // byte-code scan: bit 0 dense, bit 1 threshold rounds through scan_mfma_thr_kernel, bit 2 threshold rounds with 64 queries
                         // per item through scan_mfma_pair_kernel (7: all; 0: scan_mfma_kernel)
     OPT_PLAN_FUSED,     // round planning in three launches (1) or seven (0)
-    OPT_COARSE_PICK,    // exact coarse top-nprobe of large calls from matrix-core distances + exact recomputation of the candidates (1) or
+    OPT_COARSE_PICK,    // exact coarse top-nprobe of large calls from matrix-core distances (2: fp16 operands, 1: fp32) + exact recomputation of the candidates, or
                         // from exact distances to every centroid (0)
     OPT_PHASE_TIMING,   // HIP events around every phase of a search (amd_ivf_last_timing): 1 always, 0 never; unset: calls of >= 20 queries
     OPT_PINNED_IO,      // per-call inputs / outputs through one page-locked block read and written by kernels (1) or by copies (0)
@@ -366,6 +366,7 @@ struct amd_ivf {
     DevBuf w_cdis, w_ckeys, w_stats, w_error, w_misc, w_misc2, w_misc3, w_rawptrs;
     DevBuf c_heap_val, c_heap_ref, c_stage, c_nscan, c_done, c_seg_off, c_seg_list, c_seg_count;
     float centroid_norm_max = 0.f;  // max |c|^2 over the centroids, rounded up
+    DevBuf d_cinfo;                 // range of the centroid table (launch_amax): the fp16 form of the approximate coarse ranking
     bool in_coarse_pick = false;    // (the exact re-run of flagged queries is inside coarse_dev)
     size_t coarse_picked = 0;       // rankings of the last coarse_dev call that came from coarse_pick_kernel
     DevBuf c_pick_flag, c_pick_x, c_pick_dis, c_pick_keys;  // coarse_pick_kernel: flagged queries and their exact re-run
@@ -1418,7 +1419,7 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
     // Exact rankings of a large call that reads few entries of each (fixed nprobe): the matrix cores rank approximately, the
     // candidates that can be among the nprobe best are recomputed exactly (coarse_pick_kernel); queries in which exactly equal
     // distances meet -- where the reference's order is its heap's history -- come back flagged and take the path below.
-    if (!gemm && !h->in_coarse_pick && opt(h, OPT_COARSE_PICK, 1) != 0 && n >= 256 && nprobe <= 128 && nlist <= 4096 && nlist >= 4 * nprobe + 64 &&
+    if (!gemm && !h->in_coarse_pick && opt(h, OPT_COARSE_PICK, 2) != 0 && n >= 256 && nprobe <= 128 && nlist <= 4096 && nlist >= 4 * nprobe + 64 &&
         prefix == 0 && h->ties_override < 0 && n * nlist <= h->dist_budget_floats) {
         size_t t = h->timer.begin(CAT_COARSE, s);
         h->w_xnorms.ensure(n * sizeof(float));
@@ -1427,11 +1428,26 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
         h->p_pick.ensure((n + 1) * 4);
         HIP_CHECK(hipMemsetAsync(h->c_pick_flag.p, 0, 4, s));
         launch_row_norms(d_x, n, h->dpad, h->w_xnorms.as<float>(), s);
-        launch_coarse_gemm(h->metric, d_x, ix(h)->d_centroids.as<float>(), h->w_xnorms.as<float>(), ix(h)->d_centroid_norms.as<float>(), (int)n,
-                           (int)nlist, h->dpad, h->w_dist.as<float>(), s);
+        const FilterParams* prm = nullptr;
+        if (opt(h, OPT_COARSE_PICK, 2) >= 2 && ix(h)->d_cinfo.p) {
+            // the approximate distances from fp16 operands (option coarse_pick = 2, the default): scales and error constant from the
+            // two matrices' ranges, on the device; without a usable scale every query comes back flagged (the exact path below)
+            h->w_qinfo.ensure(16);
+            h->w_fparams.ensure(2 * sizeof(FilterParams));
+            HIP_CHECK(hipMemsetAsync(h->w_qinfo.p, 0, 16, s));
+            launch_amax(d_x, n, h->dpad, h->w_qinfo.as<uint32_t>(), s);
+            FilterParams* p = h->w_fparams.as<FilterParams>() + 1;  // (slot 0: the list filter's, of the same search)
+            launch_half_params(h->w_qinfo.as<uint32_t>(), ix(h)->d_cinfo.as<uint32_t>(), h->d, p, s);
+            launch_coarse_gemm16(h->metric, d_x, ix(h)->d_centroids.as<float>(), h->w_xnorms.as<float>(), ix(h)->d_centroid_norms.as<float>(),
+                                 (int)n, (int)nlist, h->dpad, h->w_dist.as<float>(), p, s);
+            prm = p;
+        } else {
+            launch_coarse_gemm(h->metric, d_x, ix(h)->d_centroids.as<float>(), h->w_xnorms.as<float>(), ix(h)->d_centroid_norms.as<float>(),
+                               (int)n, (int)nlist, h->dpad, h->w_dist.as<float>(), s);
+        }
         launch_coarse_pick(h->metric, h->w_dist.as<float>(), d_x, ix(h)->d_centroids.as<float>(), h->w_xnorms.as<float>(), ix(h)->centroid_norm_max,
                            (uint32_t)n, (uint32_t)nlist, (uint32_t)nprobe, h->dpad, d_out_dis, d_out_keys, h->c_pick_flag.as<uint32_t>(),
-                           h->c_pick_flag.as<uint32_t>() + 1, s);
+                           h->c_pick_flag.as<uint32_t>() + 1, s, prm);
         h->timer.end(t, s);
         // (the flagged queries: how many, which)
         CopySegs c{};
@@ -1903,7 +1919,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         h->w_surv_cnt.ensure(4);
         if (filter_half) {
             h->w_qinfo.ensure(16);
-            h->w_fparams.ensure(sizeof(FilterParams));
+            h->w_fparams.ensure(2 * sizeof(FilterParams));
             HIP_CHECK(hipMemsetAsync(h->w_qinfo.p, 0, 16, s));
             launch_amax(base.d_x, n, h->dpad, h->w_qinfo.as<uint32_t>(), s);
             launch_filter_queries16(base.d_x, n, h->d, h->dpad, h->metric, h->w_qinfo.as<uint32_t>(), I->d_yinfo.as<uint32_t>(),
@@ -2628,6 +2644,9 @@ int amd_ivf_set_centroids(amd_ivf_t* h, const float* centroids) {
                              hipMemcpyHostToDevice, h->stream));
     h->d_centroid_norms.ensure(h->nlist * sizeof(float));
     launch_row_norms(h->d_centroids.as<float>(), h->nlist, h->dpad, h->d_centroid_norms.as<float>(), h->stream);
+    h->d_cinfo.ensure(16);
+    HIP_CHECK(hipMemsetAsync(h->d_cinfo.p, 0, 16, h->stream));
+    launch_amax(h->d_centroids.as<float>(), h->nlist, h->dpad, h->d_cinfo.as<uint32_t>(), h->stream);
     HIP_CHECK(stream_sync(h->stream));
     h->have_centroids = true;
     h->have_interdis = false;
@@ -4024,7 +4043,7 @@ static double opt_default(OptId id) {
         case OPT_FIXED_ROUNDS: case OPT_ROUND_INC: case OPT_ROUND_GROW: return 0;  // (0: chosen per search)
         case OPT_ROUND_FIRST: return 12;
         case OPT_SCAN_PIPELINED: return 7;
-        case OPT_FILTER: return 2;
+        case OPT_FILTER: case OPT_COARSE_PICK: return 2;
         default: return 1;
     }
 }

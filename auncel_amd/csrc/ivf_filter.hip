@@ -245,6 +245,23 @@ void launch_frag16_from_f32(const float* codes, const uint64_t* list_off, const 
     LAUNCH(frag16_from_f32_kernel, dim3((unsigned)nblocks), dim3(64), 0, s, codes, list_off, block_off, nlist, d, dpad, metric, info, out, yn);
 }
 
+// FilterParams of a pair of matrices by themselves (the approximate coarse ranking on fp16 operands: coarse_gemm16_kernel): pad =
+// the second matrix's scale
+__global__ void half_params_kernel(const uint32_t* qinfo, const uint32_t* yinfo, int d, FilterParams* params) {
+    const float sx = half_scale(qinfo, d), sy = half_scale(yinfo, d);
+    FilterParams p;
+    p.sx = sx;
+    p.pad = sy;
+    const float C = (float)(2 * d + 32) * 5.9604644775390625e-08f;
+    const bool exact = !qinfo[1] && !yinfo[1];
+    p.C = sx == 0.f || sy == 0.f ? -1.f : exact ? C : C + 0.0009765625f + 0.000244140625f;
+    p.ps = sx == 0.f || sy == 0.f ? 0.f : 1.f / (sx * sy);
+    *params = p;
+}
+void launch_half_params(const uint32_t* qinfo, const uint32_t* yinfo, int d, FilterParams* params, hipStream_t s) {
+    LAUNCH(half_params_kernel, dim3(1), dim3(1), 0, s, qinfo, yinfo, d, params);
+}
+
 // query rows (stride dpad) -> rows of 16 J halves (J = filter_steps16(d); row stride 8 J floats) + xn; one wave per row; the first
 // thread also leaves the search's FilterParams
 __global__ __launch_bounds__(256) void filter_queries16_kernel(const float* x, size_t n, int d, int dpad, int metric, const uint32_t* qinfo,

@@ -198,6 +198,8 @@ inline __host__ __device__ uint32_t filter_steps16(int d) {
 void launch_amax(const float* x, size_t rows, int stride, uint32_t* info, hipStream_t s);
 // the scale that goes with such a range (0: none usable) -- ivf_filter.hip
 float filter_half_scale(const uint32_t info[4], int d);
+// FilterParams from the ranges of two matrices (sx, ps, C as above; pad = the second matrix's scale)
+void launch_half_params(const uint32_t* qinfo, const uint32_t* yinfo, int d, FilterParams* params, hipStream_t s);
 // fp32 lists -> fp16 fragment order, scaled by the power of two that brings info[0] into [2^14, 2^15); yn as launch_frag32_from_f32
 void launch_frag16_from_f32(const float* codes, const uint64_t* list_off, const uint64_t* block_off, uint32_t nlist, uint64_t nblocks, int d,
                             int dpad, int metric, const uint32_t* info, float* out, float* yn, hipStream_t s);
@@ -492,6 +494,10 @@ void launch_first_tie(const float* sorted_dis, uint32_t nq, uint32_t stride, uin
 
 // GEMM-formulated coarse distances on the fp32 matrix cores (row stride d, d % 4 == 0)
 void launch_row_norms(const float* x, size_t n, int d, float* out, hipStream_t s);
+// approximate distances from fp16 operands (the rows are scaled and rounded while they are staged; the error constant that goes
+// with them is params->C: |approx - exact| <= C (|x|^2 + |y|^2), C < 0: no usable scale, the result means nothing)
+void launch_coarse_gemm16(int metric, const float* X, const float* Y, const float* xn, const float* yn, int nq, int ny, int d, float* out,
+                          const FilterParams* params, hipStream_t s);
 void launch_coarse_gemm(int metric, const float* X, const float* Y, const float* xn, const float* yn, int nq, int ny, int d, float* out,
                         hipStream_t s);
 
@@ -500,7 +506,7 @@ void launch_coarse_gemm(int metric, const float* X, const float* Y, const float*
 // flagged[] and left to the caller
 void launch_coarse_pick(int metric, const float* approx, const float* x, const float* centroids, const float* xn, float cmax, uint32_t n,
                         uint32_t nlist, uint32_t nprobe, int dpad, float* out_dis, int64_t* out_keys, uint32_t* nflag, uint32_t* flagged,
-                        hipStream_t s);
+                        hipStream_t s, const FilterParams* params = nullptr);  // params: the approximate distances came from launch_coarse_gemm16
 void launch_scatter_rows(const void* in, const uint32_t* idx, uint32_t m, uint32_t words, void* out, hipStream_t s);
 
 // packed upper triangle (IVF_pro.cpp:21-39 layout) of a full nlist x nlist distance matrix

@@ -1434,6 +1434,101 @@ __global__ __launch_bounds__(256) void coarse_gemm_kernel(const float* X, const 
             }
 }
 
+// ---- the approximate form of the product for coarse_pick_kernel: fp16 operands.  The ranking only has to be within a known
+// bound of the exact distances (the candidates are recomputed exactly), so the rows are scaled by the powers of two of
+// FilterParams (ivf_filter.hip: largest magnitudes into [2^14, 2^15), the rule for when one scale per matrix is safe) and rounded to
+// fp16 while they are staged; v_mfma_f32_32x32x16_f16 then does in two instructions what sixteen fp32 ones did (the fp32 matrix
+// product was 0.9 of the 1.9 ms a coarse ranking took at d = 960).  Same tiling: 128 x 128 per workgroup, 64 x 64 per wave, K in
+// chunks of 32 dimensions, double-buffered, one barrier per chunk.  An LDS row holds the chunk's 32 halves (+ 8 of padding: eight
+// lanes' 16-byte reads fall on disjoint banks); lane (m, h) of K-step s reads halves 16 s + 8 h .. + 7 of row m.
+constexpr int GEMM16_TK = 32, GEMM16_LD = 40;  // halves
+template <int METRIC>
+__global__ __launch_bounds__(256) void coarse_gemm16_kernel(const float* X, const float* Y, const float* xn, const float* yn, int nq, int ny,
+                                                            int d, float* out, const FilterParams* prm) {
+    typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+    typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+    __shared__ __align__(16) _Float16 As[2][128 * GEMM16_LD], Bs[2][128 * GEMM16_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q0 = blockIdx.y * 128, c0 = blockIdx.x * 128;
+    const int wq = wave >> 1, wc = wave & 1;
+    const int m = lane & 31, h = lane >> 5;
+    const float sx = prm->sx, sy = prm->pad, ps = prm->ps;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    // a chunk = 128 rows x 32 dimensions of each matrix = 1024 float4 each: four per thread and matrix
+    float4 pa[4], pb[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int idx = tid + i * 256, row = idx >> 3, c = idx & 7;
+            const bool kok = k0 + 4 * c < d;
+            pa[i] = q0 + row < nq && kok ? *reinterpret_cast<const float4*>(X + (size_t)(q0 + row) * d + k0 + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pb[i] = c0 + row < ny && kok ? *reinterpret_cast<const float4*>(Y + (size_t)(c0 + row) * d + k0 + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int idx = tid + i * 256, row = idx >> 3, c = idx & 7;
+            const v4h ha = {(_Float16)(pa[i].x * sx), (_Float16)(pa[i].y * sx), (_Float16)(pa[i].z * sx), (_Float16)(pa[i].w * sx)};
+            const v4h hb = {(_Float16)(pb[i].x * sy), (_Float16)(pb[i].y * sy), (_Float16)(pb[i].z * sy), (_Float16)(pb[i].w * sy)};
+            *reinterpret_cast<v4h*>(&As[buf][row * GEMM16_LD + 4 * c]) = ha;
+            *reinterpret_cast<v4h*>(&Bs[buf][row * GEMM16_LD + 4 * c]) = hb;
+        }
+    };
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < d; k0 += GEMM16_TK, buf ^= 1) {
+        const bool more = k0 + GEMM16_TK < d;
+        if (more) fetch(k0 + GEMM16_TK);
+        const _Float16* a_base = &As[buf][(wq * 64 + m) * GEMM16_LD + 8 * h];
+        const _Float16* b_base = &Bs[buf][(wc * 64 + m) * GEMM16_LD + 8 * h];
+#pragma unroll
+        for (int st = 0; st < 2; st++) {
+            const v8h a0 = *reinterpret_cast<const v8h*>(a_base + 16 * st), a1 = *reinterpret_cast<const v8h*>(a_base + 32 * GEMM16_LD + 16 * st);
+            const v8h b0 = *reinterpret_cast<const v8h*>(b_base + 16 * st), b1 = *reinterpret_cast<const v8h*>(b_base + 32 * GEMM16_LD + 16 * st);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) stage(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+        for (int tj = 0; tj < 2; tj++)
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h, col = m;
+                const int q = q0 + wq * 64 + ti * 32 + row, c = c0 + wc * 64 + tj * 32 + col;
+                if (q < nq && c < ny) {
+                    const float ip = ps * acc[ti][tj][reg];  // (a power of two: exact)
+                    float dis = ip;
+                    if (METRIC == METRIC_L2) {
+                        dis = xn[q] + yn[c] - 2 * ip;
+                        if (dis < 0) dis = 0;
+                    }
+                    out[(size_t)q * ny + c] = dis;
+                }
+            }
+}
+void launch_coarse_gemm16(int metric, const float* X, const float* Y, const float* xn, const float* yn, int nq, int ny, int d, float* out,
+                          const FilterParams* params, hipStream_t s) {
+    if (nq == 0 || ny == 0) return;
+    const dim3 grid((ny + 127) / 128, (nq + 127) / 128);
+    if (metric == METRIC_L2) LAUNCH(coarse_gemm16_kernel<METRIC_L2>, grid, dim3(256), 0, s, X, Y, xn, yn, nq, ny, d, out, params);
+    else LAUNCH(coarse_gemm16_kernel<METRIC_IP>, grid, dim3(256), 0, s, X, Y, xn, yn, nq, ny, d, out, params);
+}
+
 void launch_row_norms(const float* x, size_t n, int d, float* out, hipStream_t s) {
     if (n) LAUNCH(row_norms_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, d, out);
 }
@@ -1621,6 +1716,7 @@ struct CoarsePickArgs {
     const float* xn;          // n: |x|^2 (row_norms_kernel)
     float cmax;               // max over centroids of |c|^2
     float C;
+    const FilterParams* params;  // approximate distances from fp16 operands: C = params->C (< 0: they mean nothing, every query is flagged)
     uint32_t nlist, nprobe;
     int dpad;
     float* out_dis;           // n x nprobe
@@ -1671,9 +1767,10 @@ __global__ __launch_bounds__(256) void coarse_pick_kernel(CoarsePickArgs a) {
     }
     const float Tv = fkey_inv(Ascending ? hi : ~hi);
     const float xn = a.xn[q];
-    const float eps = METRIC == METRIC_L2 ? a.C * (xn + a.cmax) : a.C * sqrtf(xn) * sqrtf(a.cmax);
+    const float Cb = a.params ? a.params->C : a.C;
+    const float eps = METRIC == METRIC_L2 ? Cb * (xn + a.cmax) : Cb * sqrtf(xn) * sqrtf(a.cmax);
     const float Tw = Ascending ? Tv + 2.f * eps : Tv - 2.f * eps;
-    bool bad = !(fabsf(Tw) < 3.0e38f);  // (NaN, infinities: the caller's exact path deals with them)
+    bool bad = !(fabsf(Tw) < 3.0e38f) || Cb < 0.f;  // (NaN, infinities, no usable fp16 scale: the caller's exact path deals with them)
     const uint32_t kw = Ascending ? fkey(Tw) : ~fkey(Tw);
     __syncthreads();
 #pragma unroll
@@ -1762,9 +1859,9 @@ __global__ __launch_bounds__(256) void coarse_pick_kernel(CoarsePickArgs a) {
 }
 void launch_coarse_pick(int metric, const float* approx, const float* x, const float* centroids, const float* xn, float cmax, uint32_t n,
                         uint32_t nlist, uint32_t nprobe, int dpad, float* out_dis, int64_t* out_keys, uint32_t* nflag, uint32_t* flagged,
-                        hipStream_t s) {
+                        hipStream_t s, const FilterParams* params) {
     if (n == 0) return;
-    CoarsePickArgs a{approx, x, centroids, xn, cmax, (2.f * (float)dpad + 32.f) * 5.9604645e-8f, nlist, nprobe, dpad, out_dis, out_keys, nflag, flagged};
+    CoarsePickArgs a{approx, x, centroids, xn, cmax, (2.f * (float)dpad + 32.f) * 5.9604645e-8f, params, nlist, nprobe, dpad, out_dis, out_keys, nflag, flagged};
     if (metric == METRIC_L2) LAUNCH(coarse_pick_kernel<METRIC_L2>, dim3(n), dim3(256), 0, s, a);
     else LAUNCH(coarse_pick_kernel<METRIC_IP>, dim3(n), dim3(256), 0, s, a);
 }

@@ -341,8 +341,9 @@ int amd_ivf_set_byte_codes(amd_ivf_t* h, int enable);
  *                     wave): bit 0 dense rounds, bit 1 threshold rounds, bit 2 threshold rounds with up to 64
  *                     queries per item (scan_mfma_pair_kernel: a chunk is fetched once per 64 queries); 0: scan_mfma_kernel
  *   "plan_fused"      round planning in 3 launches (1) or 7 (0)                               1
- *   "coarse_pick"     large fixed-nprobe calls: 1 coarse rankings from matrix-core distances + exact   1
- *                     recomputation of the candidates (amd_ivf_last_coarse_pick), 0 exact distances to every centroid
+ *   "coarse_pick"     large fixed-nprobe calls: coarse rankings from matrix-core distances (2: fp16    2
+ *                     operands, 1: fp32) + exact recomputation of the candidates (amd_ivf_last_coarse_pick),
+ *                     0 exact distances to every centroid
  *   "phase_timing"    HIP events around every phase (amd_ivf_last_timing): 1 always, 0 never          unset: calls of >= 20 queries
  *   "pinned_io"       per-call inputs / outputs through one page-locked block (1) or copies (0)                 1
  * amd_ivf_set_option(h, key, NAN) returns the key to "unset". */

@@ -14,7 +14,7 @@ if not inits:
 lo = inits[-1]
 if len(inits) > 1 and (rows[inits[-1]][1] - rows[inits[-2]][1]) < 6e6 and len(sys.argv) < 3:
     lo = inits[-2]
-lo = max(0, lo - (14 if len(sys.argv) > 2 else 6))
+lo = max(0, lo - (int(sys.argv[3]) if len(sys.argv) > 3 else 14 if len(sys.argv) > 2 else 6))
 t0 = rows[lo][1]
 prev = None
 for n, s, e in rows[lo:]:

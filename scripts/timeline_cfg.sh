@@ -6,5 +6,5 @@ cd /tmp && export TMPDIR=/tmp
 cd $R
 out=/tmp/tl_cfg$cfg; rm -rf $out; mkdir -p $out
 timeout 900 rocprofv3 --kernel-trace -d $out -o t -- python3 scripts/bench_configs.py --cfg $cfg --nprobes $np --ref-sample 0 --sample 8 > $out/run.log 2>&1
-python3 scripts/timeline.py $out/t_results.db last > gpurun_out/timeline_cfg${cfg}_$tag.txt 2>&1
+python3 scripts/timeline.py $out/t_results.db last ${4:-14} > gpurun_out/timeline_cfg${cfg}_$tag.txt 2>&1
 cat gpurun_out/timeline_cfg${cfg}_$tag.txt
