@@ -656,7 +656,8 @@ def main():
     # the same steps one batch at a time (after the timed region, not part of `value`): per-launch kernel figures without
     # another batch sharing the chip
     solo = {}
-    if nfl > 1 and not args.no_legs:
+    skip_legs = set(filter(None, os.environ.get("AUNCEL_BENCH_SKIP_LEGS", "").split(",")))  # (diagnosis: one_batch, fp32, exact_ties)
+    if nfl > 1 and not args.no_legs and "one_batch" not in skip_legs:
         nfl_keep, nfl = nfl, 1
         barrier()
         ts0 = time.perf_counter()
@@ -686,7 +687,7 @@ def main():
     # not uint8-valued, and a cross-check of the byte-code path (results must be identical)
     fp32 = None
     arith = h.scan_arith()  # of the timed region
-    if arith == 2 and not args.no_legs:
+    if arith == 2 and not args.no_legs and "fp32" not in skip_legs:
         for c in ctxs:
             c.set_byte_codes(False)
         leg = timed_leg(max(4, args.steps // 3))
@@ -732,7 +733,7 @@ def main():
     # the same steps with the reference's exact-distance tie order for every query (AUNCEL_AMD_COARSE_TIES=redo: the queries whose
     # first run of equal coarse distances lies within what they read are searched again with the heap's order)
     exact_ties = None
-    if not args.no_legs and "AUNCEL_AMD_COARSE_TIES" not in os.environ:
+    if not args.no_legs and "AUNCEL_AMD_COARSE_TIES" not in os.environ and "exact_ties" not in skip_legs:
         os.environ["AUNCEL_AMD_COARSE_TIES"] = "redo"
         try:
             nst = max(4, args.steps // 3)
