@@ -162,6 +162,31 @@ struct IntRange {
     }
 };
 
+// the most row space the rounds of a search shape have wanted so far, for the last few shapes (a caller that alternates between
+// shapes -- byte codes and fp32, a large call and the small second pass of the exact tie order -- would otherwise size every
+// search as if it were the first of its kind, and grow its workspace again right after)
+struct WantHistory {
+    static constexpr int N = 8;
+    uint64_t sig[N] = {0, 0, 0, 0, 0, 0, 0, 0};
+    size_t want[N] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int next = 0;
+    size_t get(uint64_t s) const {
+        for (int i = 0; i < N; i++)
+            if (sig[i] == s && want[i]) return want[i];
+        return 0;
+    }
+    void raise(uint64_t s, size_t w) {
+        for (int i = 0; i < N; i++)
+            if (sig[i] == s && want[i]) {
+                want[i] = std::max(want[i], w);
+                return;
+            }
+        sig[next] = s;
+        want[next] = w;
+        next = (next + 1) % N;
+    }
+};
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -409,8 +434,12 @@ struct amd_ivf {
     DevBuf w_tie_rows;  // rankings re-run through the reference's heap because of equal distances (launch_heap_tie_order)
 
     size_t dist_budget_floats = (size_t)768 << 20;  // 3 GiB of distances per scan launch
-    uint64_t dist_want_sig = 0;                      // run_rounds_device: row space the rounds of the last search of this shape wanted
-    size_t dist_want_floats = 0;
+    WantHistory dist_want;                           // run_rounds_device: row space the rounds of the last searches wanted, by shape
+    // ... and on the index owner, shared by every context cloned from it: a context that has not met the largest slice yet is sized
+    // for it all the same (a workspace that grows frees device memory, which waits for every stream of the device: 20-40 ms in
+    // which nothing of any context runs -- two or three of those were a tenth of a 20-step timed region)
+    std::mutex want_mu;
+    WantHistory shared_want;
     size_t stats_host[4] = {0, 0, 0, 0};
     double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     double timing_detail[2 * 7 + 2] = {0};  // (ms, launches) per phase of the last search (CAT_*) | min bytes of dense / threshold rounds
@@ -496,6 +525,18 @@ hipStream_t make_main_stream() {
     } else {
         HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     }
+    return s;
+}
+
+// Streams of a context's long background kernels (tie replay beside the next round, the heap order of coarse ties), created at
+// first use.  Normal priority: at the lowest the tie replay fell behind and the next search waited for it (2.7 against 2.95 M q/s);
+// scans at the high priority of the main streams were worse still (2.1).  Which hardware queue such a stream shares with which
+// other context's scan stream is the runtime's choice at creation time (the least used of GPU_MAX_HW_QUEUES) and depends on every
+// stream the process created -- and destroyed -- before: bench.py's side legs (exact_tie_order, fp32_path) move by a factor of two
+// with the order they run in; creating these streams with the context did not make that steadier.
+hipStream_t make_background_stream() {
+    hipStream_t s = nullptr;
+    HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     return s;
 }
 
@@ -1827,8 +1868,14 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     // only if nothing can be deferred)
     if (!budget_env && chained && base.tuner.enabled) {
         size_t want;
-        if (h->dist_want_sig == bsig && h->dist_want_floats) {
-            want = h->dist_want_floats + h->dist_want_floats / 8;
+        size_t known = h->dist_want.get(bsig);
+        {
+            amd_ivf* owner = ix(h);
+            std::lock_guard<std::mutex> lock(owner->want_mu);
+            known = std::max(known, owner->shared_want.get(bsig));
+        }
+        if (known) {
+            want = known + known / 4;
         } else {
             // no history: the first round's rows, and for the round behind it a quarter of the queries going on for `grow` times as
             // many probes (what the bench workload does; a shape that wants more defers queries once and is sized for it next time)
@@ -2249,7 +2296,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             // the reference's heap over what this round admitted (and the results of the flagged queries that finished in it), on
             // a side stream: it runs under the next round's scan and selection
             if (!h->fix_stream) {
-                HIP_CHECK(hipStreamCreateWithFlags(&h->fix_stream, hipStreamNonBlocking));
+                h->fix_stream = make_background_stream();
                 HIP_CHECK(hipEventCreateWithFlags(&h->ev_sel, hipEventDisableTiming));
                 for (int i = 0; i < 2; i++) HIP_CHECK(hipEventCreateWithFlags(&h->ev_fix[i], hipEventDisableTiming));
             }
@@ -2451,9 +2498,10 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             uint32_t want_mi = hc[12];
             for (size_t r = 0; r < nh; r++) want_mi = std::max(want_mi, h->p_hist.as<uint32_t>()[r * 16 + 12]);
             size_t want = (size_t)want_mi << 20;
-            if (h->dist_want_sig == bsig) want = std::max(want, h->dist_want_floats);
-            h->dist_want_sig = bsig;
-            h->dist_want_floats = want;
+            h->dist_want.raise(bsig, want);
+            amd_ivf* owner = ix(h);
+            std::lock_guard<std::mutex> lock(owner->want_mu);
+            owner->shared_want.raise(bsig, want);
         }
         h->scan_bytes += *reinterpret_cast<double*>(hc + 16);
         h->scan_min_bytes += *reinterpret_cast<double*>(hc + 22);
@@ -3295,7 +3343,7 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
             L->w_spec_count.ensure(16);  // count | - | rows the heap re-ranked (not reported: most are never used)
             L->w_spec_slot.ensure(n * 4);
             if (!L->spec_stream) {
-                HIP_CHECK(hipStreamCreateWithFlags(&L->spec_stream, hipStreamNonBlocking));
+                L->spec_stream = make_background_stream();
                 HIP_CHECK(hipEventCreateWithFlags(&L->ev_spec_go, hipEventDisableTiming));
                 HIP_CHECK(hipEventCreateWithFlags(&L->ev_spec_done, hipEventDisableTiming));
             } else {

@@ -585,9 +585,12 @@ def main():
         def finish():
             ticket, np_, start = pending.pop(0)
             D, I, tm, dg = h.wait(ticket)
+            if os.environ.get("AUNCEL_BENCH_TRACE_ASYNC"):
+                log(f"async step done at {1e3 * (time.perf_counter() - t_async0):.2f} ms: engine wall {tm['total_ms']:.2f} ms")
             account(acc, tm, dg["hinted_launches"], dg["short_hints"], dg["tie_redone"], (D, I, np_, start))
 
         aslots = len(async_outs)
+        t_async0 = time.perf_counter()
         for sn in range(nsteps):
             if len(pending) == aslots:
                 finish()
@@ -653,25 +656,13 @@ def main():
     for c in ctxs:
         for key, val in c.stats().items():
             st[key] = st.get(key, 0) + val
-    # the same steps one batch at a time (after the timed region, not part of `value`): per-launch kernel figures without
-    # another batch sharing the chip
-    solo = {}
-    skip_legs = set(filter(None, os.environ.get("AUNCEL_BENCH_SKIP_LEGS", "").split(",")))  # (diagnosis: one_batch, fp32, exact_ties)
-    if nfl > 1 and not args.no_legs and "one_batch" not in skip_legs:
-        nfl_keep, nfl = nfl, 1
-        barrier()
-        ts0 = time.perf_counter()
-        run_steps(args.steps, solo)
-        barrier()
-        solo["elapsed"] = time.perf_counter() - ts0
-        nfl = nfl_keep
     workload = (f"SIFT-{args.nb // 1000000}M-like d={d} IVF{nlist},Flat max_topk={K} topk={topk} Auncel error-bound nprobe "
                 f"(bound {args.bound}), batch {ses} resident queries per GPU, index replicated per GPU")
     D, I, my_np, q_start = acc["last"]
     D, I, my_np = D.copy(), I.copy(), my_np.copy()  # (the result buffers are reused by the legs below)
     my_sl = my_np[q_start:q_start + ses]  # my_nprobe of the slice the last timed step searched
     gt_sl = gtD[q_start:q_start + ses]
-
+    skip_legs = set(filter(None, os.environ.get("AUNCEL_BENCH_SKIP_LEGS", "").split(",")))  # (diagnosis: one_batch, fp32, exact_ties)
     def timed_leg(nsteps):
         """nsteps more steps with the current settings, after the timed region (never part of `value`)"""
         leg = {}
@@ -683,6 +674,17 @@ def main():
         leg["elapsed"] = time.perf_counter() - tl
         return leg
 
+    # the same steps one batch at a time (after the timed region, not part of `value`): per-launch kernel figures without
+    # another batch sharing the chip
+    solo = {}
+    if nfl > 1 and not args.no_legs and "one_batch" not in skip_legs:
+        nfl_keep, nfl = nfl, 1
+        barrier()
+        ts0 = time.perf_counter()
+        run_steps(args.steps, solo)
+        barrier()
+        solo["elapsed"] = time.perf_counter() - ts0
+        nfl = nfl_keep
     # the same workload on the fp32 lists (byte codes switched off on every context): what the engine does on data that is
     # not uint8-valued, and a cross-check of the byte-code path (results must be identical)
     fp32 = None
@@ -758,14 +760,12 @@ def main():
     elif guaranteed is None:
         guar["note"] = "no grid point up to multipler 24 holds the bound for every validation query"
     # the same steps kept in flight by ONE caller thread through the asynchronous entry points (amd_ivf_submit_adaptive /
-    # amd_ivf_wait: the engine's own contexts and worker threads) instead of one host thread + context per batch
+    # amd_ivf_wait: the engine's own contexts and worker threads) instead of one host thread + context per batch.  Last of the legs, and
+    # the one that pays for it: which hardware queue a new stream shares with which is decided when it is created and depends on
+    # every stream the process created before -- right after the timed region this leg reaches 3.0 M q/s, here 2.0-2.8 (and
+    # whichever leg is put behind it instead loses as much: measured in every order)
     single_caller = None
     if nfl > 1 and not args.no_legs and not use_async:
-        # (the callers' contexts of the legs above go first: nothing below uses them, and their streams would share the device's
-        # four hardware queues with the streams of the engine's internal contexts -- 2.1 against 2.9 M q/s for this leg)
-        for c in ctxs[1:]:
-            c.close()
-        del ctxs[1:]
         h.set_async_depth(nfl)
         async_outs = result_buffers(2 * nfl)
         run_steps_async(max(2 * nfl, 8), {})
@@ -778,7 +778,7 @@ def main():
         aD, aI, a_np, a_start = aleg["last"]
         single_caller = {"value": ses * args.steps / a_el, "unit": "queries/s", "ms_per_step": 1000.0 * a_el / args.steps,
                          "how": f"one caller thread, amd_ivf_submit_adaptive / amd_ivf_wait, {nfl} searches at a time on the engine's "
-                                f"internal contexts, {2 * nfl} tickets out; last leg of the run"}
+                                f"internal contexts, {2 * nfl} tickets out; last leg of the run (see DESIGN.md section 5 on the order of the legs)"}
         h.set_async_depth(0)  # (the contexts' streams would crowd the hardware queues of anything run after)
     scan_ms, scan_bytes, scan_launches = acc["scan_ms"], acc["scan_bytes"], acc["scan_launches"]
     coarse_ms, select_ms, slot_eff = acc["coarse_ms"], acc["select_ms"], acc["slot_eff"] / args.steps
