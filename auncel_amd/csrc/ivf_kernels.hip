@@ -1804,7 +1804,27 @@ __global__ __launch_bounds__(256) void coarse_pick_kernel(CoarsePickArgs a) {
         const float* y = a.centroids + (size_t)i * a.dpad;
         float sl = 0.f;
         if (have) {
-            for (int e = (int)sub; e < a.dpad; e += 4) {
+            // (eight steps of the chain per trip: their loads are requested together, the sums still run in order -- one step at a
+            // time the loop paid a trip to L2 per step of a chain d / 4 steps long)
+            int e = (int)sub;
+            for (; e + 28 < a.dpad; e += 32) {
+                float yv[8], xv[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    yv[u] = y[e + 4 * u];
+                    xv[u] = xq[e + 4 * u];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    if (METRIC == METRIC_L2) {
+                        const float t = yv[u] - xv[u];
+                        sl += t * t;
+                    } else {
+                        sl += yv[u] * xv[u];
+                    }
+                }
+            }
+            for (; e < a.dpad; e += 4) {
                 if (METRIC == METRIC_L2) {
                     const float t = y[e] - xq[e];
                     sl += t * t;
