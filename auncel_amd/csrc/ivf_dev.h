@@ -138,8 +138,7 @@ template <int LANE> __device__ __forceinline__ void writelane_c(int& reg, uint32
 // rounded separately (this file is built with -ffp-contract=off), (s0 + s1) + (s2 + s3); rows are zero-padded to dpad (% 4)
 template <int METRIC> __device__ __forceinline__ float exact_distance(const float* x, const float* y, int dpad) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    for (int c = 0; c < dpad; c += 4) {
-        const float4 a = *reinterpret_cast<const float4*>(x + c), b = *reinterpret_cast<const float4*>(y + c);
+    auto step = [&](const float4& a, const float4& b) {
         if (METRIC == METRIC_L2) {
             const float t0 = b.x - a.x, t1 = b.y - a.y, t2 = b.z - a.z, t3 = b.w - a.w;
             s0 += t0 * t0;
@@ -152,7 +151,21 @@ template <int METRIC> __device__ __forceinline__ float exact_distance(const floa
             s2 += b.z * a.z;
             s3 += b.w * a.w;
         }
+    };
+    // four steps per trip: their eight loads are requested together, the sums run in order (a lane's rows are its own: one step at
+    // a time the loop paid a trip to memory per step)
+    int c = 0;
+    for (; c + 12 < dpad; c += 16) {
+        float4 av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            av[u] = *reinterpret_cast<const float4*>(x + c + 4 * u);
+            bv[u] = *reinterpret_cast<const float4*>(y + c + 4 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) step(av[u], bv[u]);
     }
+    for (; c < dpad; c += 4) step(*reinterpret_cast<const float4*>(x + c), *reinterpret_cast<const float4*>(y + c));
     return (s0 + s1) + (s2 + s3);
 }
 

@@ -1334,7 +1334,20 @@ __global__ __launch_bounds__(256) void row_norms_kernel(const float* x, size_t n
     if (i >= n) return;
     const float4* r = reinterpret_cast<const float4*>(x + i * d);
     float s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    for (int c = 0; c < d / 4; c++) {
+    int c = 0;
+    for (; c + 3 < d / 4; c += 4) {  // (four steps per trip: the loads together, the sums in order)
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = r[c + u];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            s0 += v[u].x * v[u].x;
+            s1 += v[u].y * v[u].y;
+            s2 += v[u].z * v[u].z;
+            s3 += v[u].w * v[u].w;
+        }
+    }
+    for (; c < d / 4; c++) {
         const float4 v = r[c];
         s0 += v.x * v.x;
         s1 += v.y * v.y;
