@@ -7,6 +7,8 @@
 // instead of a pass over every pair.
 #include "ivf_dev.h"
 
+#include <stdlib.h>
+
 namespace amdivf {
 
 // ---- 1. how many probes does each query run this round, and how many distances is that (one wave per query:
@@ -585,9 +587,134 @@ __global__ __launch_bounds__(1024) void plan_small_kernel(PlanArgs a) {
     for (uint32_t l0 = 0; l0 < a.nlist; l0 += 1024) plan_items_lists(a, l0 + tid);
 }
 
+// ---- ONE query (what the reference's callers issue: eval/bound.cpp:391-396).  plan_small_kernel is the general planner behind
+//      workgroup barriers: ~20 phases that each pay a trip to L2, 0.06 ms for a dozen pairs -- a quarter of such a call.  With one
+//      query every probed list has exactly one pair, so nothing needs counting per list: one wave walks the probes, 64 at a time, and
+//      writes segments, pairs (in probe order), query groups and items with running prefix sums.  Same arrays and counters as the
+//      general pass (any consistent layout serves: nothing downstream depends on the order of pairs or items).
+__global__ __launch_bounds__(64) void plan_one_kernel(PlanArgs a) {
+    const uint32_t lane = threadIdx.x;
+    plan_begin(a, lane, 64);
+    __syncthreads();  // (the history copy reads the counters before they are written below)
+    plan_counts_query(a, 0, lane);
+    __syncthreads();
+    const uint32_t c = a.cnt[0];
+    const unsigned long long nd = a.need[0];
+    const uint32_t pm = a.pad[0], pad = pm & 0x7fffffffu;
+    const unsigned long long ndist = c ? nd - pad : 0ull;
+    if (lane == 0) {
+        if (pm >> 31) a.pad[0] = pad;
+        a.seg_begin[0] = 0;
+        a.dist_base[0] = 0;
+        if (c) a.qsel[0] = 0;
+        a.counters[0] = c ? 1u : 0u;
+        a.counters[1] = c;
+        a.counters[10] = c ? pm >> 31 : 0u;
+        a.counters[11] = 0;
+        a.counters[7] = (uint32_t)(ndist >> 20);
+        a.counters[12] = (uint32_t)((nd + (1u << 20) - 1) >> 20);
+        a.bytes[0] += (double)ndist * (double)a.d * 4.0;
+        if (a.min_bytes) a.min_bytes[0] += a.dense_round ? (double)ndist * 4.0 : (double)ndist / 8.0;
+        if (a.min_bytes_thr && !a.dense_round) a.min_bytes_thr[0] += (double)ndist / 8.0;
+    }
+    const uint32_t stage = a.stage[0];
+    const int64_t* kq = a.keys + stage;
+    const unsigned long long ra = a.row_align - 1;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    unsigned long long cur = 0, slots = 0, useful = 0;  // wave-uniform running offset of the rows | tile bookkeeping (per lane)
+    uint32_t np = 0, ni = 0;                            // pairs (= query groups) and items so far
+    double list_bytes = 0;
+    const uint32_t tv1 = scan_tile_vecs(1);
+    for (uint32_t p0 = 0; p0 < c; p0 += 64) {
+        const uint32_t p = p0 + lane;
+        int64_t key = -1;
+        uint32_t sz = 0;
+        if (p < c) {
+            key = kq[p];
+            if (key >= 0 && (unsigned long long)key < a.nlist) sz = (uint32_t)(a.list_off[key + 1] - a.list_off[key]);
+        }
+        const bool valid = sz != 0;
+        const unsigned long long psz = valid ? ((unsigned long long)sz + ra) & ~ra : 0ull;
+        unsigned long long incl = psz;
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long o = __shfl_up(incl, off);
+            if ((int)lane >= off) incl += o;
+        }
+        const unsigned long long my_off = cur + incl - psz;
+        if (p < c) {
+            a.seg_list[p] = (int32_t)key;
+            a.seg_off[p] = my_off;
+        }
+        cur += __shfl(incl, 63);
+        const unsigned long long vm = __ballot(valid);
+        const uint32_t pidx = np + (uint32_t)__builtin_popcountll(vm & lt);
+        // items of this probe's list: one query block x its chunks (byte codes, fp32 filter) or its 128-vector tiles (fp32)
+        const uint32_t tile = a.mfma_chunk ? a.mfma_chunk : tv1;
+        const uint32_t n_it = valid ? (sz + tile - 1) / tile : 0u;
+        uint32_t iincl = n_it;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)iincl, off);
+            if ((int)lane >= off) iincl += o;
+        }
+        const uint32_t ibase = ni + iincl - n_it;
+        if (valid) {
+            a.pair_query[pidx] = a.slot_base;
+            a.pair_out[pidx] = my_off;
+            a.group_p0[pidx] = pidx;
+            a.group_cnt[pidx] = 1;
+            const uint64_t vb0 = a.list_off[key];
+            const uint64_t b0 = a.mfma_chunk ? a.block_off[key] : 0ull;
+            for (uint32_t o = 0; o < n_it; o++) {
+                const uint32_t vb = o * tile;
+                ScanItem it;
+                it.vec_base = a.mfma_chunk ? b0 + vb / MFMA_BLOCK : vb0 + vb;
+                it.nvec = sz - vb < tile ? sz - vb : tile;
+                it.vec_off = vb;
+                it.pair_begin = pidx;
+                it.npair = 1;
+                it.qg = a.mfma_chunk ? 0u : 1u;
+                it.qgroup = a.mfma_chunk ? (uint32_t)(vb0 + vb) : pidx;
+                if (ibase + o < a.item_cap) a.items[ibase + o] = it;
+                slots += a.mfma_chunk ? (unsigned long long)MFMA_QBLOCK * (((it.nvec + 63) / 64) * 64) : (unsigned long long)SCAN_RQ * tile;
+            }
+            useful += sz;
+            list_bytes += (double)sz * (double)a.row_bytes;
+        }
+        np += (uint32_t)__builtin_popcountll(vm);
+        ni += (uint32_t)__shfl((int)iincl, 63);
+    }
+    for (int off = 32; off; off >>= 1) {
+        slots += __shfl_xor(slots, off);
+        useful += __shfl_xor(useful, off);
+        list_bytes += __shfl_xor(list_bytes, off);
+    }
+    if (lane == 0) {
+        const bool over = ni > a.item_cap;
+        if (over) atomicMax(a.error, ERR_ITEM_OVERFLOW);
+        const uint32_t nit = over ? 0u : ni;
+        a.counters[2] = np;   // pairs
+        a.counters[3] = np;   // query groups (one query each)
+        a.counters[4] = a.mfma_chunk ? 0u : nit;  // tiles of shape 1
+        a.counters[5] = 0;
+        a.counters[8] = 0;
+        a.counters[9] = a.mfma_chunk ? nit : 0u;  // matrix-core items
+        if (a.min_bytes && list_bytes > 0) a.min_bytes[0] += list_bytes;
+        if (a.min_bytes_thr && !a.dense_round && list_bytes > 0) a.min_bytes_thr[0] += list_bytes;
+        if (slots) {
+            a.acc64[0] += slots;
+            a.acc64[1] += useful;
+        }
+    }
+}
+
 // five launches a round (round 3: seven -- a reset kernel of one thread, and scatter / items apart)
 void launch_plan(const PlanArgs& a, hipStream_t s) {
     if (a.nq == 0) return;
+    static const bool no_one = getenv("AUNCEL_AMD_NO_PLAN_ONE") != nullptr;  // (debugging)
+    if (a.nq == 1 && !no_one) {
+        LAUNCH(plan_one_kernel, dim3(1), dim3(64), 0, s, a);
+        return;
+    }
     if (a.nq <= PLAN_SMALL_NQ && a.nlist <= 65536) {
         LAUNCH(plan_small_kernel, dim3(1), dim3(1024), 0, s, a);
         return;
