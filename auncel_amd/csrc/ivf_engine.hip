@@ -342,6 +342,7 @@ struct amd_ivf {
     hipStream_t spec_stream = nullptr;
     hipEvent_t ev_spec_go = nullptr, ev_spec_done = nullptr;
     bool spec_wanted = false;  // set by adaptive_redo_ties around its first pass (small calls repeat as a whole: no slots)
+    bool spec_done = false;   // run_rounds_device: the search ended at its first look and the caller's read-backs came with it
     bool spec_valid = false;  // the slots of the last first pass are (being) re-ranked
     bool spec_use = false;    // second pass: ranking row j comes from slot w_spec_pick[j]
     size_t spec_ncopy = 0;    // leading entries of a ranking the slots hold
@@ -820,6 +821,9 @@ struct RoundSpec {
     const float* d_budget_ms = nullptr;
     double t_start_us = 0;
     bool caller_checks_error = false;  // the caller reads the error word back together with its results (finish_results)
+    // a call of a few queries: queues the caller's own read-backs (results, statistics, error word) so that the look after the first
+    // round can bring them along -- three calls in four end there, and then end with that one synchronisation
+    std::function<void()> spec_finish;
 };
 
 static bool dbg_timing() {
@@ -1911,8 +1915,9 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     h->w_seg_slot.ensure(seg_cap * 4);
     // 16 uint32 counters | double bytes | 2 x u64 slot bookkeeping | double min_bytes | per-round unfinished | double min_bytes of threshold rounds
     constexpr size_t CNT_WORDS = 24 + PLAN_MAX_ROUNDS * 8 + 2;  // (... | per round and XCD: unfinished | ...)
+    constexpr size_t STAT_WORDS = STATS_ROWS * 4 * 2;            // (the statistics rows ride along with a look: speculative finish)
     h->w_pl_counters.ensure(CNT_WORDS * 4);
-    h->p_counters.ensure(CNT_WORDS * 4);
+    h->p_counters.ensure((CNT_WORDS + STAT_WORDS) * 4);
     h->w_dist.ensure((budget + 4096) * sizeof(float));  // (+ the blocks the selection's stream requests past a region's end)
     // (the counters need no memset: the first planning pass of the search zeroes what accumulates, PlanArgs::first_plan)
     // sorted-array selection: global positions must fit 32 bits; a query's admission log holds 32 k entries (k (1 + ln(N / k))
@@ -2317,7 +2322,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     };
     auto next_round_len = [&](size_t round_len) { return base.fixed_two ? total_nprobe : std::min<size_t>(round_len * 2, 64); };
     // the planning counters (and, at the end, the per-round history) into their page-locked mirrors: one kernel, or blits
-    auto fetch_counters = [&](size_t nhist) {
+    auto fetch_counters = [&](size_t nhist, bool with_stats = false) {
         if (pinned_io(h)) {
             CopySegs c{};
             c.src[0] = h->w_pl_counters.p;
@@ -2325,10 +2330,16 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             c.words[0] = (uint32_t)CNT_WORDS;
             c.n = 1;
             if (nhist) {
-                c.src[1] = h->w_pl_hist.p;
-                c.dst[1] = h->p_hist.dev();
-                c.words[1] = (uint32_t)(nhist * 16);
-                c.n = 2;
+                c.src[c.n] = h->w_pl_hist.p;
+                c.dst[c.n] = h->p_hist.dev();
+                c.words[c.n] = (uint32_t)(nhist * 16);
+                c.n++;
+            }
+            if (with_stats) {
+                c.src[c.n] = h->w_stats.p;
+                c.dst[c.n] = static_cast<unsigned char*>(h->p_counters.dev()) + CNT_WORDS * 4;
+                c.words[c.n] = (uint32_t)STAT_WORDS;
+                c.n++;
             }
             launch_copy_segs(c, s);
         } else {
@@ -2340,6 +2351,37 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         plan_round(round_len);
         fetch_counters(0);
         HIP_CHECK(stream_sync(s));
+    };
+    // what is done with the counters of the last planned round once they are on the host (the end of the search, below)
+    auto epilogue = [h, hc, chained, hints_used, bsig](size_t nh) {
+        if (chained) {
+            h->round_hint.assign(h->p_hist.as<uint32_t>(), h->p_hist.as<uint32_t>() + nh * 16);
+            h->round_hint.insert(h->round_hint.end(), hc, hc + 16);  // the last planned round
+            // a scan grid is its hint + 12 %; a round that needed more still covers its items (the workgroups stride over the
+            // device-side count), only with fewer workgroups than it would have been given
+            for (size_t r = 0; (r + 1) * 16 <= hints_used.size() && (r + 1) * 16 <= h->round_hint.size(); r++)
+                for (int c : {CNT_QG1, CNT_QG2, CNT_QG4, CNT_QG8}) {
+                    const uint32_t used = hints_used[r * 16 + c], need = h->round_hint[r * 16 + c];
+                    if (!used) continue;
+                    h->hinted_rounds++;
+                    if (need > used + used / 8 + 8) h->short_rounds++;
+                }
+        }
+        if (chained) {  // (the most row space a round of this shape has wanted so far)
+            uint32_t want_mi = hc[12];
+            for (size_t r = 0; r < nh; r++) want_mi = std::max(want_mi, h->p_hist.as<uint32_t>()[r * 16 + 12]);
+            size_t want = (size_t)want_mi << 20;
+            h->dist_want.raise(bsig, want);
+            amd_ivf* owner = ix(h);
+            std::lock_guard<std::mutex> lock(owner->want_mu);
+            owner->shared_want.raise(bsig, want);
+        }
+        h->scan_bytes += *reinterpret_cast<double*>(hc + 16);
+        h->scan_min_bytes += *reinterpret_cast<double*>(hc + 22);
+        h->scan_min_bytes_thr += *reinterpret_cast<double*>(hc + 24 + PLAN_MAX_ROUNDS * 8);
+        const unsigned long long* acc = reinterpret_cast<const unsigned long long*>(hc + 18);
+        h->scan_slots += (double)acc[0];
+        h->scan_useful += (double)acc[1];
     };
     static const bool no_skip = getenv("AUNCEL_AMD_NO_LAST_PLAN_SKIP") != nullptr;
     size_t round_len = first_round;
@@ -2369,13 +2411,39 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             // two rounds) needs no further planning pass -- round 3 planned the next round first and looked at its count.
             static const bool plan_look = getenv("AUNCEL_AMD_PLAN_LOOK") != nullptr;
             if (!plan_look && round >= 1 && round - 1 < PLAN_MAX_ROUNDS) {
-                fetch_counters(0);
+                // A call of a few queries ends here three times in four: the caller's read-backs (results, statistics, error word)
+                // are queued with the look, and if nothing is left -- and no query needs its ties replayed -- this synchronisation
+                // is the call's last (else what was queued is dropped and the search goes on as before).
+                const bool speculate = base.spec_finish && pinned_io(h) && round == 1 && planned_rounds == 1 && !fix_pending && !eager_fix;
+                const size_t small_mark = h->small.size(), af_mark = h->after_flush.size(), used_mark = h->small_used;
+                fetch_counters(0, speculate);
+                if (speculate) {
+                    base.spec_finish();
+                    launch_small_gathers(h, s);
+                }
                 host_stamp("enqueued");
                 HIP_CHECK(stream_sync(s));
                 host_stamp("look-sync");
                 uint32_t unf = 0;
                 for (int x = 0; x < 8; x++) unf += hc[24 + (round - 1) * 8 + x];
                 const uint32_t left = unf + hc[11];
+                if (speculate) {
+                    const unsigned long long* rows = reinterpret_cast<const unsigned long long*>(hc + CNT_WORDS);
+                    unsigned long long flagged = 0;
+                    for (uint32_t r = 0; r < STATS_ROWS; r++) flagged += rows[4 * r + 3];
+                    if (left == 0 && flagged == 0) {
+                        flush_small(h);
+                        std::vector<std::function<void()>> fs;
+                        fs.swap(h->after_flush);
+                        h->spec_done = true;  // (the caller skips its own read-backs and synchronisation)
+                        for (auto& f : fs) f();
+                        epilogue(0);
+                        return;
+                    }
+                    h->small.resize(small_mark);
+                    h->after_flush.resize(af_mark);
+                    h->small_used = used_mark;
+                }
                 if (dbg_timing()) fprintf(stderr, "[rounds/chained] after round %zu: unfinished %u deferred %u\n", round, unf, hc[11]);
                 if (left == 0) break;
                 plan_round(round_len);
@@ -2480,41 +2548,11 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     // epilogue below then runs behind that one, sync_and_flush), else one of our own.
     const size_t nh = chained ? std::min(planned_rounds ? planned_rounds - 1 : 0, MAX_HIST) : 0;
     if (chained) fetch_counters(nh);
-    auto epilogue = [h, hc, nh, chained, hints_used, bsig]() {
-        if (chained) {
-            h->round_hint.assign(h->p_hist.as<uint32_t>(), h->p_hist.as<uint32_t>() + nh * 16);
-            h->round_hint.insert(h->round_hint.end(), hc, hc + 16);  // the last planned round
-            // a scan grid is its hint + 12 %; a round that needed more still covers its items (the workgroups stride over the
-            // device-side count), only with fewer workgroups than it would have been given
-            for (size_t r = 0; (r + 1) * 16 <= hints_used.size() && (r + 1) * 16 <= h->round_hint.size(); r++)
-                for (int c : {CNT_QG1, CNT_QG2, CNT_QG4, CNT_QG8}) {
-                    const uint32_t used = hints_used[r * 16 + c], need = h->round_hint[r * 16 + c];
-                    if (!used) continue;
-                    h->hinted_rounds++;
-                    if (need > used + used / 8 + 8) h->short_rounds++;
-                }
-        }
-        if (chained) {  // (the most row space a round of this shape has wanted so far)
-            uint32_t want_mi = hc[12];
-            for (size_t r = 0; r < nh; r++) want_mi = std::max(want_mi, h->p_hist.as<uint32_t>()[r * 16 + 12]);
-            size_t want = (size_t)want_mi << 20;
-            h->dist_want.raise(bsig, want);
-            amd_ivf* owner = ix(h);
-            std::lock_guard<std::mutex> lock(owner->want_mu);
-            owner->shared_want.raise(bsig, want);
-        }
-        h->scan_bytes += *reinterpret_cast<double*>(hc + 16);
-        h->scan_min_bytes += *reinterpret_cast<double*>(hc + 22);
-        h->scan_min_bytes_thr += *reinterpret_cast<double*>(hc + 24 + PLAN_MAX_ROUNDS * 8);
-        const unsigned long long* acc = reinterpret_cast<const unsigned long long*>(hc + 18);
-        h->scan_slots += (double)acc[0];
-        h->scan_useful += (double)acc[1];
-    };
     if (chained && base.caller_checks_error) {
-        h->after_flush.push_back(epilogue);
+        h->after_flush.push_back([epilogue, nh]() { epilogue(nh); });
     } else {
         if (chained) HIP_CHECK(stream_sync(s));
-        epilogue();
+        epilogue(nh);
     }
 }
 
@@ -3317,7 +3355,8 @@ static size_t coarse_or_given(amd_ivf_t* L, const float* d_x, size_t n, int coar
 
 static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n, size_t query_topk, float multipler, float std_m,
                            const float* dreq, const float* dgt, unsigned long long* dnp, float* dtr, int profile, int coarse_mode,
-                           float* D, int64_t* I, const IntRange& qr, size_t coarse_prefix, bool defer_finish) {
+                           float* D, int64_t* I, const IntRange& qr, size_t coarse_prefix, bool defer_finish,
+                           const std::function<void()>* tail_gathers = nullptr) {
     use_device(L);
     const size_t K = ix(L)->tuner_max_topk, nlist = L->nlist;
     // full coarse ranking (Error_sys::search sets nprobe = nlist, profile.cpp:220), or the caller's
@@ -3394,9 +3433,15 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
     base.caller_checks_error = true;
     DirectOut direct(L, D, I);
     host_stamp("state");
+    L->spec_done = false;
+    if (defer_finish && tail_gathers && n < 20)  // (one lane, a few queries: the read-backs may ride with the first look)
+        base.spec_finish = [&]() {
+            finish_results(L, n, K, D, I, nullptr, true);
+            (*tail_gathers)();
+        };
     run_rounds_device(L, base, n, first_env, np_row, dnp);
     host_stamp("rounds");
-    finish_results(L, n, K, D, I, nullptr, defer_finish);
+    if (!L->spec_done) finish_results(L, n, K, D, I, nullptr, defer_finish);
 }
 
 static size_t lane_count(size_t n) {
@@ -3486,13 +3531,31 @@ static void adaptive_core_once(amd_ivf_t* h, const float* d_x, size_t start, siz
         L->scan_bytes = L->scan_min_bytes = L->scan_min_bytes_thr = 0;
         L->scan_slots = L->scan_useful = 0;
     }
+    // what this function reads back once the slices are done (one lane: queued together with the slice's own read-backs, or --
+    // a few queries -- with the look after the first round)
+    const std::function<void()> tail_gathers = [&]() {
+        d2h_small(h, my_nprobe + start, d_np.as<unsigned long long>() + start, n * 8, h->stream);
+        d2h_small(h, t_recalls + start, dtr + start, n * 4, h->stream);
+        if (h->want_first_tie) {
+            h->first_tie_host.assign(n, 0);
+            d2h_small(h, h->first_tie_host.data(), h->w_first_tie.p, n * 4, h->stream);
+            if (h->spec_valid && nl == 1) {
+                h->spec_slot_host.assign(n, -1);
+                d2h_small(h, h->spec_slot_host.data(), h->w_spec_slot.p, n * 4, h->stream);
+            } else {
+                h->spec_valid = false;
+            }
+        }
+    };
+    h->spec_done = false;
     std::vector<std::exception_ptr> errs(nl);
     auto run = [&](size_t i) {
         const size_t q0 = n * i / nl, q1 = n * (i + 1) / nl;
         try {
             // (one lane: the slice's read-back joins this function's own, one synchronisation ends the call)
             adaptive_slice(lanes[i], d_x + q0 * h->dpad, start + q0, q1 - q0, query_topk, multipler, std_m, dreq, dgt,
-                           d_np.as<unsigned long long>(), dtr, profile, coarse_mode, D + q0 * K, I + q0 * K, qr, coarse_prefix, nl == 1);
+                           d_np.as<unsigned long long>(), dtr, profile, coarse_mode, D + q0 * K, I + q0 * K, qr, coarse_prefix, nl == 1,
+                           nl == 1 ? &tail_gathers : nullptr);
         } catch (...) {
             errs[i] = std::current_exception();
         }
@@ -3504,19 +3567,11 @@ static void adaptive_core_once(amd_ivf_t* h, const float* d_x, size_t start, siz
     for (auto& t : th) t.join();
     for (auto& e : errs)
         if (e) std::rethrow_exception(e);
-    d2h_small(h, my_nprobe + start, d_np.as<unsigned long long>() + start, n * 8, h->stream);
-    d2h_small(h, t_recalls + start, dtr + start, n * 4, h->stream);
-    if (h->want_first_tie) {
-        h->first_tie_host.assign(n, 0);
-        d2h_small(h, h->first_tie_host.data(), h->w_first_tie.p, n * 4, h->stream);
-        if (h->spec_valid && nl == 1) {
-            h->spec_slot_host.assign(n, -1);
-            d2h_small(h, h->spec_slot_host.data(), h->w_spec_slot.p, n * 4, h->stream);
-        } else {
-            h->spec_valid = false;
-        }
+    if (!(nl == 1 && h->spec_done)) {  // (else the look after the first round brought everything along)
+        tail_gathers();
+        sync_and_flush(h, h->stream);
     }
-    sync_and_flush(h, h->stream);
+    h->spec_done = false;
     host_stamp("final-sync");
     // fold the kids' counters and kernel timings into the handle
     const double wall = wc.stop();
