@@ -343,6 +343,15 @@ struct amd_ivf {
     hipEvent_t ev_spec_go = nullptr, ev_spec_done = nullptr;
     bool spec_wanted = false;  // set by adaptive_redo_ties around its first pass (small calls repeat as a whole: no slots)
     bool spec_done = false;   // run_rounds_device: the search ended at its first look and the caller's read-backs came with it
+    // a call of at most four queries: init_state / byte_queries record their launches here instead of making them, and adaptive_slice
+    // makes them as one (launch_small_state)
+    struct SmallFuse {
+        bool active = false, have_init = false, have_bytes = false;
+        InitStateArgs init{};
+        const float* bx = nullptr;
+        int8_t* bout = nullptr;
+        int32_t* bcx = nullptr;
+    } fuse;
     bool spec_valid = false;  // the slots of the last first pass are (being) re-ranked
     bool spec_use = false;    // second pass: ranking row j comes from slot w_spec_pick[j]
     size_t spec_ncopy = 0;    // leading entries of a ranking the slots hold
@@ -615,7 +624,14 @@ bool byte_queries(amd_ivf* ws, const amd_ivf* index, const float* d_x, size_t n,
     if (resident && ws->x8_src == d_x && ws->x8_n == n && ws->x8_gen == ws->resident_gen) return true;
     ws->w_x8.ensure(n * (size_t)mfma_ksteps(index->d) * 32);
     ws->w_xnorm8.ensure(n * sizeof(int32_t));
-    launch_sbytes_from_f32(d_x, n, index->d, index->dpad, index->metric, ws->w_x8.as<int8_t>(), ws->w_xnorm8.as<int32_t>(), ws->stream);
+    if (ws->fuse.active) {
+        ws->fuse.bx = d_x;
+        ws->fuse.bout = ws->w_x8.as<int8_t>();
+        ws->fuse.bcx = ws->w_xnorm8.as<int32_t>();
+        ws->fuse.have_bytes = true;
+    } else {
+        launch_sbytes_from_f32(d_x, n, index->d, index->dpad, index->metric, ws->w_x8.as<int8_t>(), ws->w_xnorm8.as<int32_t>(), ws->stream);
+    }
     ws->x8_src = resident ? d_x : nullptr;
     ws->x8_n = n;
     ws->x8_gen = ws->resident_gen;
@@ -753,7 +769,12 @@ void init_state(amd_ivf* h, size_t n, size_t k, bool tune_or_train) {
         ia.fix_val = h->w_fix_val.as<float>();
         ia.fix_ref = h->w_fix_ref.as<int64_t>();
     }
-    launch_init_state(ia, h->stream);
+    if (h->fuse.active) {
+        h->fuse.init = ia;
+        h->fuse.have_init = true;
+    } else {
+        launch_init_state(ia, h->stream);
+    }
     if (tune_or_train) h->w_dtb.ensure(n * (h->nlist / 8 + 20) * sizeof(float));
 }
 
@@ -3362,9 +3383,12 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
     // full coarse ranking (Error_sys::search sets nprobe = nlist, profile.cpp:220), or the caller's
     const size_t np_row = coarse_or_given(L, d_x, n, coarse_mode, ix(L)->allow_fused && ix(L)->centroid_range.fusable_with(qr, L->metric), coarse_prefix);
     host_stamp("coarse");
+    // (at most four queries: the four small launches between the coarse ranking and the first round are made as one)
+    const bool fuse_small = n <= 4 && !L->spec_wanted;
     if (L->want_first_tie) {
         L->w_first_tie.ensure(n * 4);
-        launch_first_tie(L->w_cdis.as<float>(), (uint32_t)n, (uint32_t)nlist, (uint32_t)L->first_tie_nreal, L->w_first_tie.as<uint32_t>(), L->stream);
+        if (!fuse_small)
+            launch_first_tie(L->w_cdis.as<float>(), (uint32_t)n, (uint32_t)nlist, (uint32_t)L->first_tie_nreal, L->w_first_tie.as<uint32_t>(), L->stream);
         // Which queries will have to be searched again is known only when this pass ends (first run < 2 my_nprobe + 14), but the
         // expensive part of searching them again -- the reference's heap over all nlist centroids, a serial 4096-element heap
         // sort per query -- needs nothing from this pass.  Every query that could qualify with the probes of the first two
@@ -3406,12 +3430,52 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
             L->spec_ncopy = ncopy;
         }
     }
+    struct FuseScope {  // (init_state and byte_queries record their launches while this is alive)
+        amd_ivf* h;
+        bool on;
+        FuseScope(amd_ivf* hh, bool o) : h(hh), on(o) {
+            if (on) {
+                h->fuse = amd_ivf::SmallFuse{};
+                h->fuse.active = true;
+            }
+        }
+        ~FuseScope() { h->fuse.active = false; }
+    } fuse_scope(L, fuse_small);
     init_state(L, n, K, true);
-    launch_set_online(L->metric, (uint32_t)nlist, (uint32_t)n, L->w_cdis.as<float>(), L->w_ckeys.as<int64_t>(), (uint32_t)np_row,
-                      ix(L)->d_interdis.as<float>(), ix(L)->d_arcos.as<float>(), L->w_dtb.as<float>(), L->w_error.as<uint32_t>(), L->stream);
+    if (!fuse_small)
+        launch_set_online(L->metric, (uint32_t)nlist, (uint32_t)n, L->w_cdis.as<float>(), L->w_ckeys.as<int64_t>(), (uint32_t)np_row,
+                          ix(L)->d_interdis.as<float>(), ix(L)->d_arcos.as<float>(), L->w_dtb.as<float>(), L->w_error.as<uint32_t>(), L->stream);
     RoundSpec base;
     base.fused = ix(L)->allow_fused && ix(L)->db_range.fusable_with(qr, L->metric);
     base.bytes = byte_queries(L, ix(L), d_x, n, qr);
+    if (fuse_small) {
+        L->fuse.active = false;
+        SmallStateArgs sa{};
+        sa.init = L->fuse.init;
+        sa.metric = L->metric;
+        sa.nlist = (uint32_t)nlist;
+        sa.nq = (uint32_t)n;
+        sa.coarse_dis = L->w_cdis.as<float>();
+        sa.coarse_keys = L->w_ckeys.as<int64_t>();
+        sa.coarse_stride = (uint32_t)np_row;
+        sa.interdis = ix(L)->d_interdis.as<float>();
+        sa.arcos = ix(L)->d_arcos.as<float>();
+        sa.dtb = L->w_dtb.as<float>();
+        if (L->want_first_tie) {
+            sa.ft_sorted_dis = L->w_cdis.as<float>();
+            sa.ft_stride = (uint32_t)nlist;
+            sa.ft_nreal = (uint32_t)L->first_tie_nreal;
+            sa.ft_out = L->w_first_tie.as<uint32_t>();
+        }
+        if (L->fuse.have_bytes) {
+            sa.bx = L->fuse.bx;
+            sa.bout = L->fuse.bout;
+            sa.bcx = L->fuse.bcx;
+        }
+        sa.d = L->d;
+        sa.dpad = L->dpad;
+        launch_small_state(sa, L->stream);
+    }
     ix(L)->last_arith = base.bytes ? 2 : base.fused ? 1 : 0;
     base.k = (int)K;
     base.id_offset = id0;

@@ -553,6 +553,29 @@ struct InitStateArgs {
     int64_t* fix_ref;
 };
 void launch_init_state(const InitStateArgs& a, hipStream_t s);
+// A call of at most four queries: the per-query state (init_state_kernel), the boundary distances of the stop rule
+// (set_online_kernel), the start of each ranking's first run of equal coarse distances (first_tie_kernel) and the signed-byte view of
+// the queries (sbytes_from_f32_kernel) in ONE launch -- four launches of a few microseconds of work each are four dispatch
+// latencies on the critical path of a 0.25 ms call.
+struct SmallStateArgs {
+    InitStateArgs init;
+    int metric;
+    uint32_t nlist, nq;
+    const float* coarse_dis;
+    const int64_t* coarse_keys;
+    uint32_t coarse_stride;
+    const float* interdis;
+    const float* arcos;
+    float* dtb;
+    const float* ft_sorted_dis;  // first tie: null = not wanted
+    uint32_t ft_stride, ft_nreal;
+    uint32_t* ft_out;
+    const float* bx;             // byte view: null = not wanted
+    int d, dpad;
+    int8_t* bout;
+    int32_t* bcx;
+};
+void launch_small_state(const SmallStateArgs& a, hipStream_t s);
 void launch_fill_f32(float* p, size_t n, float v, hipStream_t s);
 void launch_fill_i64(int64_t* p, size_t n, int64_t v, hipStream_t s);
 

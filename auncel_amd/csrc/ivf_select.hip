@@ -300,6 +300,89 @@ void launch_set_online(int metric, uint32_t nlist, uint32_t nq, const float* coa
                                coarse_stride, interdis, arcos, dtb, error);
 }
 
+// init_state_kernel + set_online_kernel + first_tie_kernel + sbytes_from_f32_kernel for at most four queries (SmallStateArgs)
+__global__ __launch_bounds__(256) void small_state_kernel(SmallStateArgs a) {
+    __shared__ float lut[500];
+    for (int i = threadIdx.x; i < 500; i += 256) lut[i] = a.arcos[i];
+    {
+        const InitStateArgs& ia = a.init;
+        const size_t nk = ia.n * ia.k;
+        for (size_t i = threadIdx.x; i < nk; i += 256) {
+            ia.heap_val[i] = ia.neutral;
+            ia.heap_ref[i] = -1;
+            if (ia.fix_val) {
+                ia.fix_val[i] = ia.neutral;
+                ia.fix_ref[i] = -1;
+            }
+        }
+        for (size_t i = threadIdx.x; i < ia.n; i += 256) {
+            ia.thr[i] = ia.neutral;
+            ia.stage[i] = 0;
+            ia.nscan[i] = 0;
+            ia.done[i] = 0;
+            ia.pre_val[i] = 0.f;
+            ia.stoped[i] = 0;
+            if (ia.qstat) ia.qstat[i] = make_uint2(0u, 0u);
+            if (ia.log_cnt) {
+                ia.log_cnt[i] = 0;
+                ia.amb[i] = 0xffffffffu;
+                ia.tie_flag[i] = 0;
+                ia.log_snap[i] = 0;
+                ia.log_snap[ia.n + i] = 0;
+                ia.fin_round[i] = 0xffffffffu;
+                ia.fix_pos[i] = 0;
+            }
+        }
+        if (threadIdx.x < 4 * STATS_ROWS) ia.stats[threadIdx.x] = 0;
+        if (threadIdx.x == 4 * STATS_ROWS) *ia.error = 0;
+    }
+    __syncthreads();  // (the error word is zeroed before set_online may raise it; the lookup table is in LDS)
+    const int lane = threadIdx.x & 63;
+    const uint32_t qi = threadIdx.x >> 6;
+    if (qi >= a.nq) return;
+    uint32_t err = 0;
+    set_online_dev(a.metric, a.nlist, a.coarse_dis + (size_t)qi * a.coarse_stride, a.coarse_keys + (size_t)qi * a.coarse_stride, a.interdis, lut,
+                   a.dtb + (size_t)qi * (a.nlist / 8 + 20), lane, &err);
+    err = wave_max_u32(err);
+    if (err && lane == 0) atomicMax(a.init.error, err);
+    if (a.ft_sorted_dis) {
+        const float* od = a.ft_sorted_dis + (size_t)qi * a.ft_stride;
+        uint32_t first = 0xffffffffu;
+        for (uint32_t i = (uint32_t)lane; i + 1 < a.ft_nreal; i += 64)
+            if (od[i] == od[i + 1] && i < first) first = i;
+        for (int off = 32; off; off >>= 1) {
+            const uint32_t o = (uint32_t)__shfl_xor((int)first, off);
+            first = o < first ? o : first;
+        }
+        if (lane == 0) a.ft_out[qi] = first;
+    }
+    if (a.bx) {
+        const int stride = (int)mfma_ksteps(a.d) * 32;
+        int sq = 0, sum = 0;
+        for (int c = lane * 4; c < stride; c += 256) {
+            uint32_t word = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                int sv = 0;
+                if (c + b < a.d) {
+                    const int uv = (int)a.bx[(size_t)qi * a.dpad + c + b];
+                    sv = uv - 128;
+                    sq += sv * sv;
+                    sum += uv;
+                }
+                word |= (uint32_t)(sv & 0xff) << (8 * b);
+            }
+            *reinterpret_cast<uint32_t*>(a.bout + (size_t)qi * stride + c) = word;
+        }
+        for (int off = 32; off; off >>= 1) {
+            sq += __shfl_xor(sq, off);
+            sum += __shfl_xor(sum, off);
+        }
+        if (lane == 0) a.bcx[qi] = a.metric == METRIC_L2 ? sq : 128 * sum - 16384 * a.d;
+    }
+}
+void launch_small_state(const SmallStateArgs& a, hipStream_t s) { LAUNCH(small_state_kernel, dim3(1), dim3(256), 0, s, a); }
+
 // best-first sort of the heap values into srt by ranking (values only matter)
 template <bool IsMax> __device__ inline void rank_sort_best_first(const float* src, float* dst, int k, int lane) {
     for (int i = lane; i < k; i += 64) {
