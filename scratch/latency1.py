@@ -33,9 +33,11 @@ def lat(fn, n=int(os.environ.get('CALLS', 200))):
     lat.engine = e
     return t
 
+np_all, tr_all = np.zeros(ts + ses, dtype=np.uint64), np.zeros(ts + ses, dtype=np.float32)  # (indexed by query id: a harness keeps them)
+
 def adaptive(i):
-    np_ = np.zeros(ts + ses, dtype=np.uint64); tr_ = np.zeros(ts + ses, dtype=np.float32)
-    return h.search_adaptive(i, 1, topk, 1.0, 0.5, req, np_, tr_)
+    np_all[i] = 0; tr_all[i] = 0
+    return h.search_adaptive(i, 1, topk, 1.0, 0.5, req, np_all, tr_all)
 
 bud = np.full(ts + ses, 2.0, np.float32)
 for name, fn in (("search_resident k=10 nprobe=16", lambda i: h.search_resident(i, 1, 10, 16)),
