@@ -540,7 +540,7 @@ hipStream_t make_main_stream() {
 
 // Streams of a context's long background kernels (tie replay beside the next round, the heap order of coarse ties), created at
 // first use.  Normal priority: at the lowest the tie replay fell behind and the next search waited for it (2.7 against 2.95 M q/s);
-// scans at the high priority of the main streams were worse still (2.1).  Which hardware queue such a stream shares with which
+// scans at the high priority of the main streams were worse still (2.1), and so were these streams at it (2.35 against 3.0).  Which hardware queue such a stream shares with which
 // other context's scan stream is the runtime's choice at creation time (the least used of GPU_MAX_HW_QUEUES) and depends on every
 // stream the process created -- and destroyed -- before: bench.py's side legs (exact_tie_order, fp32_path) move by a factor of two
 // with the order they run in; creating these streams with the context did not make that steadier.
