@@ -49,6 +49,8 @@ struct EngineError : std::runtime_error {  // what the reference raises as Faiss
 // was never set is OPT_UNSET: the debugging environment variable of the same meaning decides then, and after it the built-in
 // default -- the environment is a debugging aid, never the only way to a behaviour.
 constexpr double OPT_UNSET = -1e300;
+constexpr double ROW_LISTS_DEFAULT = -1;
+constexpr uint32_t CL_ARENA = 4u << 20;  // entries of CompactArgs::arena (32 MiB)
 enum OptId {
     OPT_COARSE_TIES,    // order inside runs of bit-equal coarse distances: 0 centroid number, 1 the reference's heap, 2 "redo"
                         // (search again the queries that read such a run); unset: heap for calls of < 20 queries, else 0
@@ -68,6 +70,9 @@ enum OptId {
                         // from exact distances to every centroid (0)
     OPT_PHASE_TIMING,   // HIP events around every phase of a search (amd_ivf_last_timing): 1 always, 0 never; unset: calls of >= 20 queries
     OPT_PINNED_IO,      // per-call inputs / outputs through one page-locked block read and written by kernels (1) or by copies (0)
+    OPT_ROW_LISTS,      // threshold rounds of calls of >= 256 queries: the rows' marked candidates compacted into short lists before the
+                        // selection (1, compact_rows_kernel) or found by the selection itself in the masks (0); unset: lists when no
+                        // other search of the index is running
     N_OPT
 };
 struct OptSpec {
@@ -90,6 +95,7 @@ const OptSpec OPT_TABLE[N_OPT] = {
     {"coarse_pick", "AUNCEL_AMD_COARSE_PICK", nullptr},
     {"phase_timing", "AUNCEL_AMD_PHASE_TIMING", nullptr},
     {"pinned_io", "AUNCEL_AMD_PINNED_IO", nullptr},
+    {"row_lists", "AUNCEL_AMD_ROW_LISTS", nullptr},
 };
 struct Options {
     double v[N_OPT];
@@ -395,7 +401,7 @@ struct amd_ivf {
     std::vector<size_t> r_lims;              // results of the last range search (amd_ivf_range_results)
     std::vector<int64_t> r_labels;
     std::vector<float> r_dist;
-    DevBuf w_thr, w_mask, w_pl_pad;  // threshold mode of the device-planned rounds: heap tops, candidate bit masks
+    DevBuf w_thr, w_mask, w_pl_pad, w_cl_cnt, w_cl_ent, w_cl_arena, w_cl_cursor;  // threshold mode of the device-planned rounds: heap tops, candidate bit masks
     DevBuf w_x, w_dist, w_items, w_pair_query, w_pair_out, w_seg_off, w_seg_list, w_seg_count, w_qsel;
     DevBuf w_heap_val, w_heap_ref, w_stage, w_nscan, w_done, w_pre_val, w_stoped, w_dtb, w_D, w_I;
     DevBuf w_cdis, w_ckeys, w_stats, w_error, w_misc, w_misc2, w_misc3, w_rawptrs;
@@ -876,7 +882,7 @@ static void print_replay_dbg(amd_ivf* h, size_t mb, hipStream_t s) {
     std::vector<unsigned long long> dbg(mb * 8);
     HIP_CHECK(hipMemcpyAsync(dbg.data(), h->w_misc.p, mb * 64, hipMemcpyDeviceToHost, s));
     HIP_CHECK(stream_sync(s));
-    static const char* nm_replay[8] = {"wave cycles", "heap updates", "candidates", "rule evaluations", "stream cycles", "rule cycles", "masked chunks", "probes"};
+    static const char* nm_replay[8] = {"wave cycles", "heap updates", "candidates", "rule evaluations", "stream cycles | rows walked", "rule cycles", "masked chunks", "probes"};
     const char* const* nm = nm_replay;
     for (int c = 0; c < 8; c++) {
         std::vector<unsigned long long> v(mb);
@@ -1916,6 +1922,17 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     static const bool no_thr = getenv("AUNCEL_AMD_NO_THRESHOLD") != nullptr;
     h->w_pl_pad.ensure(n * 4);
     h->w_mask.ensure((budget / 64 + 2 + 256) * 8);  // (+ the words the selection's stream requests past a region's end)
+    // (1 / 0: always / never; unset: when no other search of this index is running -- alone, a search is the latency of its chain
+    // and the lists take 0.06 ms off it; among others it is the sum of the work, to which compact_rows_kernel adds: -2 % at four
+    // batches in flight.  Decided below, where the searches are counted.)
+    const int row_lists_opt = (int)opt(h, OPT_ROW_LISTS, ROW_LISTS_DEFAULT);
+    const bool row_lists = row_lists_opt != 0 && n >= 256;
+    if (row_lists) {
+        h->w_cl_cnt.ensure(seg_cap * 4);
+        h->w_cl_ent.ensure((seg_cap + 64) * CL_CAP * sizeof(uint2));  // (+ a probe window's worth behind a query's last row)
+        h->w_cl_arena.ensure((size_t)CL_ARENA * sizeof(uint2));
+        h->w_cl_cursor.ensure(8 * 32 * 4);
+    }
     h->w_pl_cnt.ensure(n * 4);
     h->w_pl_need.ensure(n * 8);
     h->w_seg_begin.ensure(n * 4);
@@ -2019,6 +2036,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     pa.items = h->w_items.as<ScanItem>();
     pa.item_cap = (uint32_t)item_cap;
     pa.counters = h->w_pl_counters.as<uint32_t>();
+    pa.cl_cursor = row_lists ? h->w_cl_cursor.as<uint32_t>() : nullptr;
     pa.bytes = reinterpret_cast<double*>(h->w_pl_counters.as<uint32_t>() + 16);
     pa.acc64 = reinterpret_cast<unsigned long long*>(h->w_pl_counters.as<uint32_t>() + 18);
     pa.min_bytes = reinterpret_cast<double*>(h->w_pl_counters.as<uint32_t>() + 22);
@@ -2314,6 +2332,27 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         }
         {
             size_t t = h->timer.begin(thr_mode ? CAT_SELECT_THR : CAT_SELECT, s);
+            if (thr_mode && sorted_now && row_lists && (row_lists_opt > 0 || active.before == 0)) {
+                CompactArgs ca{};
+                ca.nseg_dev = dcnt + CNT_SEGMENTS;
+                ca.nseg_hint = (uint32_t)std::min<size_t>(seg_cap, (size_t)ra.nq_hint * std::min<size_t>(total_nprobe, 160));
+                ca.nlist = (uint32_t)nlist;
+                ca.seg_list = ra.seg_list;
+                ca.seg_off = ra.seg_off;
+                ca.list_off = ra.list_off;
+                ca.dist = ra.dist;
+                ca.mask = ra.mask;
+                ca.cl_cnt = h->w_cl_cnt.as<uint32_t>();
+                ca.cl_ent = h->w_cl_ent.as<uint2>();
+                ca.arena = h->w_cl_arena.as<uint2>();
+                const char* arena_env = getenv("AUNCEL_AMD_CL_ARENA");  // (tests: a small arena, so that rows fall back to the mask walk)
+                ca.arena_per_xcd = (arena_env ? std::min<uint32_t>((uint32_t)atoi(arena_env), CL_ARENA) : CL_ARENA) / 8;
+                ca.cursor = h->w_cl_cursor.as<uint32_t>();
+                launch_compact_rows(ca, s);
+                ra.cl_cnt = ca.cl_cnt;
+                ra.cl_ent = ca.cl_ent;
+                ra.cl_arena = ca.arena;
+            }
             launch_replay(ra, s);
             h->timer.end(t, s);
         }
@@ -4211,6 +4250,7 @@ static double opt_default(OptId id) {
         case OPT_ROUND_FIRST: return 12;
         case OPT_SCAN_PIPELINED: return 7;
         case OPT_FILTER: case OPT_COARSE_PICK: return 2;
+        case OPT_ROW_LISTS: return ROW_LISTS_DEFAULT;
         default: return 1;
     }
 }

@@ -89,7 +89,7 @@ struct ScanArgs {
 void launch_scan(const ScanArgs& a, const size_t n_qg[4], hipStream_t s, hipStream_t s2 = nullptr, hipStream_t s1 = nullptr,
                  hipStream_t s4 = nullptr);
 // counters of PlanArgs that the chained launches read
-constexpr int CNT_ACTIVE = 0, CNT_PAIRS = 2, CNT_GROUPS = 3, CNT_QG1 = 4, CNT_QG2 = 5, CNT_QG4 = 8, CNT_QG8 = 9;
+constexpr int CNT_ACTIVE = 0, CNT_SEGMENTS = 1, CNT_PAIRS = 2, CNT_GROUPS = 3, CNT_QG1 = 4, CNT_QG2 = 5, CNT_QG4 = 8, CNT_QG8 = 9;
 unsigned resident_grid(unsigned workgroups_per_cu);  // CUs of the current device x workgroups_per_cu
 
 // gather + interleave the query rows of every group of (up to) 8 pairs: group g holds pairs
@@ -315,10 +315,41 @@ struct ReplayArgs {
     uint32_t* unfinished;      // null or 8 counters (one per XCD): += 1 for every query of this launch that goes on to another round (with the
                                // queries the planning deferred, PlanArgs counters[11], what is left after the round: the host
                                // needs no further planning pass to learn that a search has ended)
+    // threshold rounds, optional: what compact_rows_kernel made of the masks (by launch position, like seg_off)
+    const uint32_t* cl_cnt;    // marked candidates of the row (CL_WALK: find them in the masks)
+    const uint2* cl_ent;       // [CL_CAP] per row: (position in the list, distance bits) in position order while cl_cnt <= CL_CAP; a longer
+                               // list is in the arena, and entry 0 says where: (first entry, -)
+    const uint2* cl_arena;
 };
 
 bool replay_sorted_applies(const ReplayArgs& a);
 void launch_replay(const ReplayArgs& a, hipStream_t s);
+
+// A threshold round leaves a mask bit in one candidate of two thousand: a query's selection walking its rows -- mask words, then
+// the marked chunks -- pays a trip to memory per row, one row after the other (132 rows: 0.35 ms with the chip nearly empty).
+// compact_rows_kernel does that walk for every row of the round at once (a wave per eight rows) and leaves each row's marked
+// candidates as a short list at an address the selection knows in advance: it requests 64 rows' lists with its probe table.
+// Rows with more candidates than a list holds (the first rows of a hard query: dozens) get a run of the arena: one eighth of it per
+// XCD, places handed out by an add that the XCD's L2 serves (ivf_dev.h: xcd_local_add); when that is full: CL_WALK.
+constexpr uint32_t CL_CAP = 8;
+constexpr uint32_t CL_WALK = 0xffffffffu;
+struct CompactArgs {
+    const uint32_t* nseg_dev;  // rows of the round (device count), or null: nseg
+    uint32_t nseg;
+    uint32_t nseg_hint;        // sizes the grid
+    uint32_t nlist;
+    const int32_t* seg_list;
+    const uint64_t* seg_off;
+    const uint64_t* list_off;
+    const float* dist;
+    const unsigned long long* mask;
+    uint32_t* cl_cnt;
+    uint2* cl_ent;
+    uint2* arena;
+    uint32_t arena_per_xcd;    // entries
+    uint32_t* cursor;          // [8 x 32] next free entry of every XCD's part (zeroed by the round's planning)
+};
+void launch_compact_rows(const CompactArgs& a, hipStream_t s);
 
 // see tie_fix_kernel (ivf_select.hip)
 struct TieFixArgs {
@@ -434,6 +465,7 @@ struct PlanArgs {
     uint32_t* history;               // null or 16 uint32: receives the counters as the previous round's planning left them
     int first_plan;                  // first planning pass of a search: the accumulators below and round_unfinished start from zero
     uint32_t* round_unfinished;      // null or [PLAN_MAX_ROUNDS][8]: per round and XCD, queries its selection left unfinished (ReplayArgs::unfinished)
+    uint32_t* cl_cursor;             // null or [8 x 32]: CompactArgs::cursor, zeroed with the counters
     uint32_t* counters;              // [0] active queries [1] segments [2] pairs [3] groups [4] tiles qg1 [5] tiles qg2
                                      // [6] scratch (compaction cursor, zeroed by host) [7] MiB of distances [8] tiles qg4 [9] tiles qg8
                                      // [10] queries that may still be unfinished after this round, [11] of those: deferred by the

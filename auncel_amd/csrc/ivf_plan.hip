@@ -229,6 +229,8 @@ __device__ __forceinline__ void plan_prefix_body(const PlanArgs& a) {
     if (t == 0) {
         a.counters[0] = s_nact;
         a.counters[1] = s_nseg;
+        if (a.cl_cursor)  // (compact_rows_kernel's per-XCD places in the arena of long candidate lists: every round starts at 0)
+            for (int x = 0; x < 8; x++) a.cl_cursor[32 * x] = 0;
         a.counters[10] = s_more + s_def;     // queries that may still be unfinished after this round
         a.counters[11] = s_def;              // of those: deferred by the budget cut (the selection of this round does not see them)
         a.counters[7] = (uint32_t)(s_ndist >> 20);  // MiB of distances, for bookkeeping

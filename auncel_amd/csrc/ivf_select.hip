@@ -1125,6 +1125,98 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #define AUNCEL_SEL_WAVES 5  // waves per SIMD the dense-round kernel is compiled for: 5 keeps a 5000-query batch resident at once
 #endif
 
+// ---------------------------------------------------------------------------- threshold rounds: the rows' marked candidates as lists
+// (CompactArgs, ivf_kernels.h).  A wave takes eight consecutive rows: their table entries one per lane, the first 64 mask words of
+// all eight requested together -- the words' population counts say how long each row's list is and where it goes -- then row by
+// row the marked chunks, four at a time.  Entries are written in position order (chunks ascending, lanes ascending), which is the
+// order the selection's own walk admits in.  (Requesting the first chunks of all eight rows together as well took 122 registers:
+// half the waves per SIMD, and the launch 0.12 instead of 0.07 ms.)
+__global__ __launch_bounds__(256) void compact_rows_kernel(CompactArgs a) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t nseg = a.nseg_dev ? *a.nseg_dev : a.nseg;
+    const uint32_t stride = gridDim.x * 32u;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (uint32_t s0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 8u; s0 < nseg; s0 += stride) {
+        uint32_t m_n = 0;
+        unsigned long long m_off = 0;
+        if (lane < 8 && s0 + lane < nseg) {
+            const int key = a.seg_list[s0 + lane];
+            m_off = a.seg_off[s0 + lane];
+            if (key >= 0 && (uint32_t)key < a.nlist) m_n = (uint32_t)(a.list_off[key + 1] - a.list_off[key]);
+        }
+        unsigned long long W[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t n = rl_u(m_n, r);
+            const unsigned long long off = ((unsigned long long)rl_u((uint32_t)(m_off >> 32), r) << 32) | rl_u((uint32_t)m_off, r);
+            W[r] = (uint32_t)lane < ((n + 63u) >> 6) ? __builtin_nontemporal_load(a.mask + (off >> 6) + lane) : 0ull;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            if (s0 + r >= nseg) break;
+            const uint32_t n = rl_u(m_n, r);
+            const unsigned long long off = ((unsigned long long)rl_u((uint32_t)(m_off >> 32), r) << 32) | rl_u((uint32_t)m_off, r);
+            const unsigned long long* mw = a.mask + (off >> 6) + lane;
+            const float* row = a.dist + off + lane;
+            const uint32_t words = (n + 63u) >> 6;
+            // how many: the bits of the row's words
+            uint32_t total = wave_sum_u32((uint32_t)__builtin_popcountll(W[r]));
+            for (uint32_t b = 64; b < words; b += 64u)
+                total += wave_sum_u32(b + lane < words ? (uint32_t)__builtin_popcountll(__builtin_nontemporal_load(mw + b)) : 0u);
+            total = (uint32_t)__builtin_amdgcn_readfirstlane((int)total);
+            uint2* ent = a.cl_ent + (size_t)(s0 + r) * CL_CAP;
+            uint32_t report = total;
+            if (total > CL_CAP) {
+                uint32_t start = 0;
+                if (lane == 0) start = xcd_local_add(&a.cursor[32u * xcc_id()], total);
+                start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
+                if (start + total > a.arena_per_xcd) {
+                    if (lane == 0) a.cl_cnt[s0 + r] = CL_WALK;
+                    continue;
+                }
+                start += xcc_id() * a.arena_per_xcd;
+                if (lane == 0) ent[0] = make_uint2(start, 0u);
+                ent = a.arena + start;
+            }
+            uint32_t count = 0;
+            auto put = [&](unsigned long long w, uint32_t b, int c, float x) {
+                const unsigned long long bits = ((unsigned long long)rl_u((uint32_t)(w >> 32), c) << 32) | rl_u((uint32_t)w, c);
+                const bool mine = (bits >> lane) & 1ull;
+                const unsigned long long bal = __ballot(mine);
+                if (mine) ent[count + (uint32_t)__builtin_popcountll(bal & lt)] = make_uint2((b + (uint32_t)c) * 64u + (uint32_t)lane, __float_as_uint(x));
+                count += (uint32_t)__builtin_popcountll(bal);
+            };
+            for (uint32_t b = 0; b < words; b += 64u) {
+                const unsigned long long w = b == 0 ? W[r] : (b + lane < words ? __builtin_nontemporal_load(mw + b) : 0ull);
+                unsigned long long nz = __ballot(w != 0ull);
+                while (nz) {
+                    int c[4] = {-1, -1, -1, -1};
+                    float x[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (nz) {
+                            c[u] = __builtin_ctzll(nz);
+                            nz &= nz - 1;
+                            x[u] = __builtin_nontemporal_load(row + (size_t)(b + c[u]) * 64);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (c[u] >= 0) put(w, b, c[u], x[u]);
+                }
+            }
+            if (lane == 0) a.cl_cnt[s0 + r] = report;
+        }
+    }
+}
+
+void launch_compact_rows(const CompactArgs& a, hipStream_t s) {
+    const uint32_t want = a.nseg_dev ? a.nseg_hint : a.nseg;
+    if (want == 0) return;
+    const uint32_t grid = std::min<uint32_t>((want + 31u) / 32u, 8192u);
+    LAUNCH(compact_rows_kernel, dim3(grid), dim3(256), 0, s, a);
+}
+
 template <bool IsMax, bool MASKED, bool TUNE, int KC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 : AUNCEL_SEL_WAVES))) void select_sorted_kernel(ReplayArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1196,7 +1288,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 
     uint32_t st_nheap = 0;
     const unsigned long long dbg_t0 = a.dbg ? __builtin_readcyclecounter() : 0;
     unsigned long long dbg_rule = 0;
-    uint32_t dbg_evals = 0, dbg_chunks = 0;
+    uint32_t dbg_evals = 0, dbg_chunks = 0, dbg_walked = 0;
 
     // ---- stop-rule state (IndexIVF.cpp:551-638)
     uint32_t query_k = 0;
@@ -1246,12 +1338,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 
     uint32_t win0 = 0;
     int m_key = -1;
     uint32_t m_n = 0, m_base = 0;  // list length, global position of the list's first vector
+    // masked rounds with compact lists (CompactArgs): the window's rows' counts, one per lane, and their lists -- register j, lane l:
+    // entry l & 7 of row 8 j + (l >> 3)
+    const bool lists = MASKED && a.cl_cnt != nullptr;
+    uint32_t m_cc = 0;
+    uint2 E[8];
     auto load_window = [&](uint32_t w0) {
         win0 = w0;
         m_key = -1;
         m_n = 0;
         m_base = 0;
         const uint32_t pi = w0 + lane;
+        if (lists) {
+            m_cc = pi < cnt ? a.cl_cnt[seg0 + pi] : 0u;
+            const uint2* ep = a.cl_ent + (seg0 + w0) * CL_CAP + lane;
+#pragma unroll
+            for (int j = 0; j < 8; j++) E[j] = w0 + 8u * j + ((uint32_t)lane >> 3) < cnt ? ep[64 * j] : make_uint2(0u, 0u);
+        }
         if (pi < cnt) {
             m_key = a.seg_list[seg0 + pi];
             if (m_key >= 0 && (uint32_t)m_key < nlist) {
@@ -1282,7 +1385,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 
         R1 = __builtin_nontemporal_load(region4 + 64);
         R2 = __builtin_nontemporal_load(region4 + 128);
         R3 = __builtin_nontemporal_load(region4 + 192);
-    } else {
+    } else if (!lists) {
         W = __builtin_nontemporal_load(rmask);
         Wn = __builtin_nontemporal_load(rmask + 64);
     }
@@ -1431,6 +1534,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 
                     // words [wpos, wend) of the region are this row's chunks (the scan leaves no bit behind the row's end); the
                     // words of the padding up to the next multiple of 256 candidates are never written and never read
                     const uint32_t row_w0 = wpos, wend = wpos + ((n + 63u) >> 6);
+                    if (lists) {
+                        const int r = (int)(p - win0);
+                        const uint32_t cc = rl_u(m_cc, r);
+                        if (cc <= CL_CAP) {
+                            // the row's marked candidates are in lanes 8 (r & 7) ... of register r >> 3, in position order
+                            if (cc) {
+                                uint2 e = E[0];
+#pragma unroll
+                                for (int j = 1; j < 8; j++)
+                                    if ((r >> 3) == j) e = E[j];
+                                const int l0 = (r & 7) * 8;
+                                for (uint32_t t = 0; t < cc; t++) {
+                                    const float val = __uint_as_float(rl_u(e.y, l0 + (int)t));
+                                    const uint32_t ck = okey<IsMax>(val);
+                                    if (hcmp<IsMax>(top, val) && ck < topk) admit(val, ck, lbase + rl_u(e.x, l0 + (int)t));
+                                }
+                            }
+                            wpos = wend;
+                        } else if (cc != CL_WALK) {
+                            // a long list: in the arena, from the entry the row's first slot names
+                            uint2 e = E[0];
+#pragma unroll
+                            for (int j = 1; j < 8; j++)
+                                if ((r >> 3) == j) e = E[j];
+                            const uint2* al = a.cl_arena + rl_u(e.x, (r & 7) * 8) + lane;
+                            for (uint32_t t0 = 0; t0 < cc; t0 += 64u) {
+                                const bool in = t0 + (uint32_t)lane < cc;
+                                const uint2 o = in ? al[t0] : make_uint2(0u, 0u);
+                                unsigned long long m = __ballot(in && hcmp<IsMax>(top, __uint_as_float(o.y)));
+                                while (m) {
+                                    const int l = __builtin_ctzll(m);
+                                    m &= m - 1;
+                                    const float val = __uint_as_float(rl_u(o.y, l));
+                                    const uint32_t ck = okey<IsMax>(val);
+                                    if (ck < topk) admit(val, ck, lbase + rl_u(o.x, l));
+                                }
+                            }
+                            wpos = wend;
+                        } else {
+                            // the arena was full: this row through the mask stream, which starts here
+                            if (a.dbg) dbg_walked++;
+                            wstep = wpos >> 6;
+                            W = __builtin_nontemporal_load(rmask + (size_t)wstep * 64);
+                            Wn = __builtin_nontemporal_load(rmask + (size_t)(wstep + 1) * 64);
+                        }
+                    }
                     while (wpos < wend) {
                         const uint32_t s0 = wstep * 64u;              // first word of the step in W
                         if (wpos >= s0 + 64u) {                       // next step
@@ -1610,7 +1759,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 
             a.dbg[(size_t)li * 8 + 1] = st_nheap;
             a.dbg[(size_t)li * 8 + 2] = st_ndis;
             a.dbg[(size_t)li * 8 + 3] = dbg_evals;
-            a.dbg[(size_t)li * 8 + 4] = 0;
+            a.dbg[(size_t)li * 8 + 4] = dbg_walked;  // (rows whose candidates did not fit a list)
             a.dbg[(size_t)li * 8 + 5] = dbg_rule;
             a.dbg[(size_t)li * 8 + 6] = dbg_chunks;
             a.dbg[(size_t)li * 8 + 7] = consumed;

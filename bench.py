@@ -317,7 +317,7 @@ def main():
     ap.add_argument("--kmeans", choices=["engine", "torch"], default="engine",
                     help="coarse centroids: the engine's Clustering::train restatement (amd_ivf_kmeans, the reference's IVF "
                          "training: 25 iterations, 256 points per centroid) or a 4-step torch Lloyd")
-    ap.add_argument("--stagger-ms", type=float, default=0.8,
+    ap.add_argument("--stagger-ms", type=float, default=0.4,
                     help="context j issues its first step j x this many ms after context 0 (inside the timed region): out of phase, the "
                          "scan of one batch runs under the selection of another; started together they tend to stay in step")
     ap.add_argument("--pinned-out", type=int, default=1, help="1: result buffers in page-locked host memory, 0: pageable")

@@ -346,6 +346,8 @@ int amd_ivf_set_byte_codes(amd_ivf_t* h, int enable);
  *                     0 exact distances to every centroid
  *   "phase_timing"    HIP events around every phase (amd_ivf_last_timing): 1 always, 0 never          unset: calls of >= 20 queries
  *   "pinned_io"       per-call inputs / outputs through one page-locked block (1) or copies (0)                 1
+ *   "row_lists"       threshold rounds of calls of >= 256 queries: 1 the rows' marked candidates are compacted    unset (-1): 1 when no other
+ *                     into short lists before the selection (compact_rows_kernel), 0 the selection walks the masks  search of the index is running
  * amd_ivf_set_option(h, key, NAN) returns the key to "unset". */
 int amd_ivf_set_option(amd_ivf_t* h, const char* key, double value);
 int amd_ivf_get_option(amd_ivf_t* h, const char* key, double* value);
