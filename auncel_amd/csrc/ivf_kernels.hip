@@ -1605,9 +1605,64 @@ __global__ __launch_bounds__(256) void sort_rows_kernel(const float* dis, uint32
     }
 }
 
+// Bitonic sort of S = EPT * 256 distinct 64-bit keys by one workgroup, thread t holding elements EPT t .. EPT t + EPT - 1 in
+// registers: compare-exchange distances below EPT stay inside the thread, up to 64 threads apart they are lane exchanges, and only
+// the last one or two distances of the last two or three merges cross waves, through `buf` (S slots).  (Every step through LDS
+// with a workgroup barrier, as the sort was written first, cost sort_prefix_kernel 0.126 ms per 5000 rankings: 55 barriers and
+// strided 8-byte accesses that collide on the banks.)  On return buf[] holds the keys in ascending order.
+template <int EPT>
+__device__ __forceinline__ void bitonic_sort_wg(unsigned long long* buf, uint32_t tid) {
+    constexpr uint32_t S = EPT * 256u;
+    unsigned long long x[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; j++) x[j] = buf[EPT * tid + j];
+    auto keep = [&](unsigned long long a, unsigned long long b, bool keep_min) { return (a < b) == keep_min ? a : b; };
+    for (uint32_t size = 2; size <= S; size <<= 1) {
+        const bool up = ((EPT * tid) & size) == 0;  // (merges shorter than EPT alternate inside the thread: upj below)
+        for (uint32_t stride = size >> 1; stride >= (uint32_t)EPT; stride >>= 1) {
+            if (stride >= EPT * 64u) {
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < EPT; j++) buf[EPT * tid + j] = x[j];
+                __syncthreads();
+                const uint32_t pt = tid ^ (stride / EPT);
+                const bool keep_min = ((tid & (stride / EPT)) == 0) == up;
+#pragma unroll
+                for (int j = 0; j < EPT; j++) x[j] = keep(x[j], buf[EPT * pt + j], keep_min);
+            } else {
+                const int lm = (int)(stride / EPT);
+                const bool keep_min = ((tid & (uint32_t)lm) == 0) == up;
+#pragma unroll
+                for (int j = 0; j < EPT; j++) {
+                    const unsigned long long y = ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(x[j] >> 32), lm) << 32) |
+                                                 (uint32_t)__shfl_xor((int)(uint32_t)x[j], lm);
+                    x[j] = keep(x[j], y, keep_min);
+                }
+            }
+        }
+        // inside the thread: element j with j | st; the merge's direction is that of element EPT t + j
+#pragma unroll
+        for (int st = EPT / 2; st >= 1; st >>= 1) {
+            if ((uint32_t)st >= size) continue;
+#pragma unroll
+            for (int j = 0; j < EPT; j++) {
+                if (j & st) continue;
+                const bool upj = size < (uint32_t)EPT ? (((uint32_t)j & size) == 0) : up;
+                const unsigned long long a = x[j], b = x[j | st];
+                x[j] = keep(a, b, upj);
+                x[j | st] = keep(a, b, !upj);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < EPT; j++) buf[EPT * tid + j] = x[j];
+    __syncthreads();
+}
+
 // Only the first `prefix` entries of the ranking (the adaptive search never probes past (nlist / 8) * multipler):
 // a workgroup keeps its row in registers (nlist <= 4096), finds by bisection on the order keys the threshold below
-// which at least `prefix` values lie, and sorts just those (S = 1024 or 2048 slots in LDS).  Same total order as
+// which at least `prefix` values lie, and sorts just those (S = 512, 1024 or 2048 slots).  Same total order as
 // sort_rows_kernel; entries [prefix, nprobe) come out as (neutral distance, -1).
 template <bool Ascending>
 __global__ __launch_bounds__(256) void sort_prefix_kernel(const float* dis, uint32_t nlist, uint32_t nprobe, uint32_t prefix, uint32_t S,
@@ -1679,20 +1734,9 @@ __global__ __launch_bounds__(256) void sort_prefix_kernel(const float* dis, uint
     const uint32_t C = s_cnt;  // prefix <= C <= S
     for (uint32_t i = C + tid; i < S; i += 256) buf[i] = ~0ull;
     __syncthreads();
-    for (uint32_t size = 2; size <= S; size <<= 1) {
-        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            for (uint32_t t = tid; t < S / 2; t += 256) {
-                const uint32_t l = 2 * t - (t & (stride - 1)), h = l + stride;
-                const bool up = (l & size) == 0;
-                const unsigned long long x = buf[l], y = buf[h];
-                if ((x < y) != up) {
-                    buf[l] = y;
-                    buf[h] = x;
-                }
-            }
-            __syncthreads();
-        }
-    }
+    if (S == 512) bitonic_sort_wg<2>(buf, tid);
+    else if (S == 1024) bitonic_sort_wg<4>(buf, tid);
+    else bitonic_sort_wg<8>(buf, tid);
     for (uint32_t i = tid; i < nprobe; i += 256) {
         float dv = Ascending ? FLT_MAX : -FLT_MAX;
         int64_t id = -1;
@@ -1913,7 +1957,7 @@ void launch_sort_rows(const float* dis, uint32_t nq, uint32_t nlist, uint32_t np
                       int64_t* out_keys, hipStream_t s, uint32_t prefix) {
     if (nq == 0) return;
     if (prefix && prefix < nprobe && prefix <= 2048 && prefix <= nlist && nlist <= 4096) {
-        const uint32_t S = prefix <= 1024 ? 1024u : 2048u;
+        const uint32_t S = prefix <= 384 ? 512u : prefix <= 1024 ? 1024u : 2048u;  // (slots sorted: >= prefix, with room for the bisection to stop early)
         if (metric == METRIC_L2) LAUNCH(sort_prefix_kernel<true>, dim3(nq), dim3(256), 0, s, dis, nlist, nprobe, prefix, S, out_dis, out_keys);
         else LAUNCH(sort_prefix_kernel<false>, dim3(nq), dim3(256), 0, s, dis, nlist, nprobe, prefix, S, out_dis, out_keys);
         return;
