@@ -2240,6 +2240,8 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     const bool ties_common = seen_rate >= 0.f ? seen_rate > 0.02f : (base.bytes || base.fused);
     // (a handful of queries: the per-round replay is one wave's serial work on the critical path of a search that is all latency)
     const bool eager_fix = fix_opt >= 0 ? fix_opt == 1 : (active.before == 0 && ties_common && n >= 512);
+    bool fix_due = false;
+    size_t fix_due_round = 0;
     auto tie_fix_args = [&](uint32_t round, int final_pass) {
         TieFixArgs ta{};
         ta.metric = h->metric;
@@ -2358,27 +2360,36 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         }
         sorted_any = sorted_any || sorted_now;
         if (sorted_now && eager_fix) {
-            // the reference's heap over what this round admitted (and the results of the flagged queries that finished in it), on
-            // a side stream: it runs under the next round's scan and selection
-            if (!h->fix_stream) {
-                h->fix_stream = make_background_stream();
-                HIP_CHECK(hipEventCreateWithFlags(&h->ev_sel, hipEventDisableTiming));
-                for (int i = 0; i < 2; i++) HIP_CHECK(hipEventCreateWithFlags(&h->ev_fix[i], hipEventDisableTiming));
-            }
-            TieFixArgs ta = tie_fix_args((uint32_t)round, 0);
-            HIP_CHECK(hipEventRecord(h->ev_sel, s));
-            HIP_CHECK(hipStreamWaitEvent(h->fix_stream, h->ev_sel, 0));
-            size_t t = h->timer.begin(CAT_TIE_FIX, h->fix_stream);
-            launch_tie_fix(ta, h->fix_stream);
-            h->timer.end(t, h->fix_stream);
-            HIP_CHECK(hipEventRecord(h->ev_fix[round & 1], h->fix_stream));
-            fix_pending = true;
-            last_fix_round = round;
+            fix_due = true;  // (launch_due_fix: behind the next round's planning)
+            fix_due_round = round;
         }
         if (dbg_replay_dev) {
             fprintf(stderr, "[replay] round %zu: %u queries\n", round, nact);
             print_replay_dbg(h, nact, s);
         }
+    };
+    // The reference's heap over what a round admitted (and the results of the flagged queries that finished in it), on a side
+    // stream: it runs under the next round's scan and selection.  It starts behind the next round's PLANNING: those kernels are
+    // single workgroups of 1024 threads on the search's critical path, and with the replay's workgroups already on every CU they
+    // waited for room (round 1's planning: 0.10 ms against round 0's 0.06).
+    auto launch_due_fix = [&]() {
+        if (!fix_due) return;
+        fix_due = false;
+        const size_t round = fix_due_round;
+        if (!h->fix_stream) {
+            h->fix_stream = make_background_stream();
+            HIP_CHECK(hipEventCreateWithFlags(&h->ev_sel, hipEventDisableTiming));
+            for (int i = 0; i < 2; i++) HIP_CHECK(hipEventCreateWithFlags(&h->ev_fix[i], hipEventDisableTiming));
+        }
+        TieFixArgs ta = tie_fix_args((uint32_t)round, 0);
+        HIP_CHECK(hipEventRecord(h->ev_sel, s));
+        HIP_CHECK(hipStreamWaitEvent(h->fix_stream, h->ev_sel, 0));
+        size_t t = h->timer.begin(CAT_TIE_FIX, h->fix_stream);
+        launch_tie_fix(ta, h->fix_stream);
+        h->timer.end(t, h->fix_stream);
+        HIP_CHECK(hipEventRecord(h->ev_fix[round & 1], h->fix_stream));
+        fix_pending = true;
+        last_fix_round = round;
     };
     auto next_round_len = [&](size_t round_len) { return base.fixed_two ? total_nprobe : std::min<size_t>(round_len * 2, 64); };
     // the planning counters (and, at the end, the per-round history) into their page-locked mirrors: one kernel, or blits
@@ -2461,10 +2472,12 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
                 const bool thr_mode = round > 0 && !no_thr;
                 if (!planned) plan_round(round_len);
                 planned = false;
+                launch_due_fix();
                 enqueue_scan(thr_mode, nullptr, round);
                 enqueue_replay(thr_mode, (uint32_t)n, true, round);
                 round_len = next_round_len(round_len);
             }
+            launch_due_fix();
             if (fixed_complete) break;
             // Is anything left?  The selection of the last round counted the queries it left unfinished, the planning of that
             // round the ones it deferred: one look at those two numbers, and a search that has ended (the common case after
@@ -2588,6 +2601,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
                 continue;
             }
             enqueue_replay(thr_mode, nact, false, round);
+            launch_due_fix();
             if (dbg_timing())
                 fprintf(stderr, "[round/dev] active %u pairs %u groups %u: plan+readback %.0f us, launches %.0f us\n", nact, hc[CNT_PAIRS],
                         hc[CNT_GROUPS], t1 - t0, now_us() - t1);
@@ -2596,6 +2610,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             round_len = next_round_len(round_len);
         }
     }
+    launch_due_fix();
     if (fix_pending) HIP_CHECK(hipStreamWaitEvent(s, h->ev_fix[last_fix_round & 1], 0));  // the last round's tie_fix_kernel
     if (sorted_any && !eager_fix) {
         size_t t = h->timer.begin(CAT_TIE_FIX, s);
