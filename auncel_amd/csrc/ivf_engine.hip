@@ -2070,6 +2070,14 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     h->hinted_rounds = h->short_rounds = 0;
     h->filter_launches = 0;
     size_t planned_rounds = 0;  // plans launched so far (round r's counters reach history[r] when round r + 1 is planned)
+    // searches of this index that were running when this one started (the tie replay, the candidate lists and the scan's stream
+    // are chosen by it: alone, a search is the latency of its chain; among others, the sum of the work)
+    struct Active {
+        std::atomic<int>& c;
+        int before;
+        explicit Active(std::atomic<int>& cc) : c(cc), before(cc.fetch_add(1)) {}
+        ~Active() { c.fetch_sub(1); }
+    } active(I->active_searches);
     auto plan_round = [&](size_t round_len) {
         pa.round_len = (uint32_t)round_len;
         pa.dense_round = !(base.range || (planned_rounds > 0 && !no_thr));
@@ -2127,8 +2135,10 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             // the scan runs on a normal-priority side stream (see make_main_stream)
             // (a handful of queries: the launch is a few microseconds of work, the fork and join around it two event waits of
             // ~13 us each -- it stays on the search's own stream)
-            static const bool scan_on_main = getenv("AUNCEL_AMD_SCAN_ON_MAIN") != nullptr;  // (experiment: no side stream at all)
-            if (scan_on_main || n < 20) {
+            // (so does a search that has the index to itself: there is nobody whose selection the side stream's lower priority would
+            // let pass)
+            static const int scan_on_main = getenv("AUNCEL_AMD_SCAN_ON_MAIN") ? atoi(getenv("AUNCEL_AMD_SCAN_ON_MAIN")) : -1;  // (experiment: 1 always, 0 only below 20 queries)
+            if (scan_on_main > 0 || n < 20 || (scan_on_main < 0 && active.before == 0)) {
                 launch_scan_mfma(ma, s);
             } else {
                 ensure_aux(h, 3, 3);
@@ -2226,12 +2236,6 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     // when other searches are running on it (their kernels fill the GPU while it runs; more streams would only crowd the hardware
     // queues)
     const int fix_opt = (int)opt(h, OPT_TIE_FIX, -1);
-    struct Active {
-        std::atomic<int>& c;
-        int before;
-        explicit Active(std::atomic<int>& cc) : c(cc), before(cc.fetch_add(1)) {}
-        ~Active() { c.fetch_sub(1); }
-    } active(I->active_searches);
     // ... and only where equal distances are common (integer-valued data: a third of the bench workload's queries): replaying
     // every unfinished query's admissions after every round is then cheaper than replaying the flagged queries' whole logs at the
     // end.  Where they are rare (float data: a query in a few hundred) the end pass is a handful of waves and the per-round one
