@@ -28,6 +28,18 @@ def test_exports_match_header(capi):
     assert sorted(capi.SYMBOLS) == declared
 
 
+def test_option_table_matches_header():
+    """every key amd_ivf_set_option accepts (the engine's OPT_TABLE) is in the header's table, and nothing else is"""
+    hdr = open(os.path.join(ROOT, "include", "auncel_amd.h")).read()
+    block = hdr[hdr.index(" *   key "):hdr.index("amd_ivf_set_option(h, key, NAN)")]
+    documented = set(re.findall(r'"([a-z_]+)"', block))
+    eng = open(os.path.join(ROOT, "auncel_amd", "csrc", "ivf_engine.hip")).read()
+    table = eng[eng.index("const OptSpec OPT_TABLE[N_OPT] = {"):]
+    table = table[:table.index("};")]
+    accepted = set(re.findall(r'\{"([a-z_]+)", "AUNCEL_AMD_', table))
+    assert accepted and accepted == documented, (sorted(accepted - documented), sorted(documented - accepted))
+
+
 def test_no_cpu_fallback(capi):
     import torch
     if torch.cuda.is_available():
