@@ -344,7 +344,9 @@ struct amd_ivf {
     // AUNCEL_AMD_COARSE_TIES=redo: the rankings that may need the reference's heap order (first run of equal distances within
     // the window a query can read in its first two rounds) are set aside and re-ranked on a side stream WHILE the first pass
     // searches; the second pass takes its rankings from those slots instead of running the heap (2.75 ms at nlist 4096) itself
-    DevBuf w_spec_full, w_spec_dis, w_spec_keys, w_spec_count, w_spec_slot, w_spec_pick, w_redo_idx;
+    DevBuf w_spec_full, w_spec_dis, w_spec_keys, w_spec_count, w_spec_slot, w_spec_pick, w_redo_idx, w_spec_query, w_spec_scratch;
+    bool spec_inline = false;       // the heap's order was applied to the first pass itself (launch_tie_patch): only what it could not fix is searched again
+    uint32_t tie_patched_host = 0;  // rankings of the last first pass that the heap's order changed
     hipStream_t spec_stream = nullptr;
     hipEvent_t ev_spec_go = nullptr, ev_spec_done = nullptr;
     bool spec_wanted = false;  // set by adaptive_redo_ties around its first pass (small calls repeat as a whole: no slots)
@@ -430,6 +432,8 @@ struct amd_ivf {
     std::vector<uint32_t> round_hint;  // [round][16]
     uint64_t hint_sig = 0;
     uint64_t last_tie_redone = 0;  // queries the last adaptive call searched again for the coarse tie order (AUNCEL_AMD_COARSE_TIES=redo)
+    uint64_t last_tie_patched = 0;  // ... rankings whose order the heap changed while the call's one pass was under way
+    uint32_t row_align_now = 1024;  // run_rounds_device: what the rows of the search under way are padded to (the tie patch moves rows)
     // run_rounds_device: the selection kernels write (D, I) straight into the caller's buffers when those are page-locked and
     // device-visible (rows leave as their queries finish, under the later rounds; no copy at the end); null: w_D / w_I + a copy
     float* out_D = nullptr;
@@ -851,6 +855,12 @@ struct RoundSpec {
     // a call of a few queries: queues the caller's own read-backs (results, statistics, error word) so that the look after the first
     // round can bring them along -- three calls in four end there, and then end with that one synchronisation
     std::function<void()> spec_finish;
+    // AUNCEL_AMD_COARSE_TIES=redo with the heap's order arriving while the first round is scanned (adaptive_slice): enqueued between
+    // the scan and the selection of round 0 -- waits for the heap, patches the ranking and the round's rows (launch_tie_patch),
+    // then derives the stop rule's boundary distances from the patched ranking.  run_ties: rounds take whole runs of equal
+    // coarse distances (PlanArgs::run_dis).
+    std::function<void()> before_first_select;
+    bool run_ties = false;
 };
 
 static bool dbg_timing() {
@@ -1648,7 +1658,9 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
             h->c_seg_off.ensure(m * 8);
             h->c_seg_list.ensure(m * 4);
             h->c_seg_count.ensure(m * 4);
-            h->w_misc.ensure(32);
+            // (throw-away statistics: one row per XCD as every selection launch adds to them, and the error word behind the rows)
+            constexpr size_t MISC_BYTES = STATS_ROWS * 4 * 8 + 8;
+            h->w_misc.ensure(MISC_BYTES);
             h->p_seg_off.ensure(m * 8);
             h->p_seg_list.ensure(m * 4);
             h->p_seg_count.ensure(m * 4);
@@ -1665,7 +1677,7 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
             HIP_CHECK(hipMemsetAsync(h->c_stage.p, 0, m * 4, s));
             HIP_CHECK(hipMemsetAsync(h->c_nscan.p, 0, m * 8, s));
             HIP_CHECK(hipMemsetAsync(h->c_done.p, 0, m * 4, s));
-            HIP_CHECK(hipMemsetAsync(h->w_misc.p, 0, 32, s));
+            HIP_CHECK(hipMemsetAsync(h->w_misc.p, 0, MISC_BYTES, s));
             ReplayArgs ra{};
             ra.metric = h->metric;
             ra.k = (int)k;
@@ -1686,7 +1698,7 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
             ra.D = d_out_dis + c0 * nprobe;
             ra.I = d_out_keys + c0 * nprobe;
             ra.stats = h->w_misc.as<unsigned long long>();
-            ra.error = reinterpret_cast<uint32_t*>(h->w_misc.as<unsigned long long>() + 3);
+            ra.error = reinterpret_cast<uint32_t*>(h->w_misc.as<unsigned long long>() + STATS_ROWS * 4);
             launch_replay(ra, s);
         } else {
             launch_sort_rows(h->w_dist.as<float>(), (uint32_t)m, (uint32_t)nlist, (uint32_t)nprobe, h->metric,
@@ -1993,6 +2005,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     pa.need = h->w_pl_need.as<unsigned long long>();
     pa.pad = h->w_pl_pad.as<uint32_t>();
     pa.row_align = sorted_ok ? 1024 : 64;  // (select_sorted_kernel reads dense rows in groups of four blocks of 256 candidates)
+    h->row_align_now = pa.row_align;
     pa.qblock = scan_qblock(base.bytes);
     pa.mfma_qblock = MFMA_QBLOCK;
     static const int item_order_env = getenv("AUNCEL_AMD_ITEM_ORDER") ? atoi(getenv("AUNCEL_AMD_ITEM_ORDER")) : 0;
@@ -2095,6 +2108,8 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         }
         pa.history = chained && planned_rounds >= 1 && planned_rounds <= MAX_HIST ? h->w_pl_hist.as<uint32_t>() + (planned_rounds - 1) * 16 : nullptr;
         pa.first_plan = planned_rounds == 0;
+        // (only while the ranking can still change: the rows of round 0 are reordered in place, later rounds are planned on the patched keys)
+        pa.run_dis = base.run_ties && planned_rounds == 0 ? base.d_cdis : nullptr;
         size_t t = h->timer.begin(CAT_PLAN, s);
         launch_plan(pa, s);
         h->timer.end(t, s);
@@ -2478,6 +2493,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
                 planned = false;
                 launch_due_fix();
                 enqueue_scan(thr_mode, nullptr, round);
+                if (round == 0 && base.before_first_select) base.before_first_select();
                 enqueue_replay(thr_mode, (uint32_t)n, true, round);
                 round_len = next_round_len(round_len);
             }
@@ -2604,6 +2620,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
                 HIP_CHECK(stream_sync(s));
                 continue;
             }
+            if (round == 0 && base.before_first_select) base.before_first_select();
             enqueue_replay(thr_mode, nact, false, round);
             launch_due_fix();
             if (dbg_timing())
@@ -3461,8 +3478,9 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
             L->w_spec_full.ensure((size_t)SPEC_CAP * nlist * 4);
             L->w_spec_dis.ensure((size_t)SPEC_CAP * nlist * 4);
             L->w_spec_keys.ensure((size_t)SPEC_CAP * nlist * 8);
-            L->w_spec_count.ensure(16);  // count | - | rows the heap re-ranked (not reported: most are never used)
+            L->w_spec_count.ensure(32);  // count | rankings the patch changed | rows the heap re-ranked (u64; not reported: most are never used) | scratch cursor (u64)
             L->w_spec_slot.ensure(n * 4);
+            L->w_spec_query.ensure((size_t)SPEC_CAP * 4);
             if (!L->spec_stream) {
                 L->spec_stream = make_background_stream();
                 HIP_CHECK(hipEventCreateWithFlags(&L->ev_spec_go, hipEventDisableTiming));
@@ -3470,13 +3488,13 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
             } else {
                 HIP_CHECK(hipStreamWaitEvent(L->stream, L->ev_spec_done, 0));  // (the previous search's slots are no longer being written)
             }
-            HIP_CHECK(hipMemsetAsync(L->w_spec_count.p, 0, 16, L->stream));
+            HIP_CHECK(hipMemsetAsync(L->w_spec_count.p, 0, 32, L->stream));
             // (slots go to the nearest runs first: a query that stops in round 0 -- most do -- reads 2 x 12 + 14 entries)
             for (uint32_t lo = 0, hi = SPEC_NEAR; lo < SPEC_WINDOW; lo = hi, hi = SPEC_WINDOW)
                 launch_spec_collect(L->w_first_tie.as<uint32_t>(), (uint32_t)n, lo, hi, SPEC_CAP, (uint32_t)nlist, (uint32_t)ncopy,
                                     L->w_dist.as<float>(), L->w_cdis.as<float>(), L->w_ckeys.as<int64_t>(), L->w_spec_count.as<uint32_t>(),
                                     L->w_spec_slot.as<int32_t>(), L->w_spec_full.as<float>(), L->w_spec_dis.as<float>(),
-                                    L->w_spec_keys.as<int64_t>(), L->stream);
+                                    L->w_spec_keys.as<int64_t>(), L->stream, L->w_spec_query.as<uint32_t>());
             HIP_CHECK(hipEventRecord(L->ev_spec_go, L->stream));
             HIP_CHECK(hipStreamWaitEvent(L->spec_stream, L->ev_spec_go, 0));
             launch_heap_tie_order(L->w_spec_full.as<float>(), SPEC_CAP, (uint32_t)nlist, (uint32_t)nlist, (uint32_t)ncopy, L->metric,
@@ -3486,8 +3504,16 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
             HIP_CHECK(hipEventRecord(L->ev_spec_done, L->spec_stream));
             L->spec_valid = true;
             L->spec_ncopy = ncopy;
+            // The heap's order can be applied to THIS pass when it arrives before anything has read the order inside a run of equal
+            // distances: that is the selection of round 0 (the stop rule's boundary distances and the probe order; the planner
+            // takes whole runs into a round, so the scan does not depend on it).  With the level-parallel filling and the pipelined
+            // heap sort (nlist a power of two) the heap takes ~1.5 ms a row, about what coarse ranking -> planning -> scan of
+            // round 0 take among other searches; the literal heap (12 ms a row) stays under the pass and feeds a second one.
+            static const bool no_patch = getenv("AUNCEL_AMD_NO_TIE_PATCH") != nullptr;
+            L->spec_inline = !no_patch && (nlist & (nlist - 1)) == 0 && nlist >= 64;
         }
     }
+    const bool tie_inline = L->want_first_tie && L->spec_valid && L->spec_inline;
     struct FuseScope {  // (init_state and byte_queries record their launches while this is alive)
         amd_ivf* h;
         bool on;
@@ -3500,10 +3526,47 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
         ~FuseScope() { h->fuse.active = false; }
     } fuse_scope(L, fuse_small);
     init_state(L, n, K, true);
-    if (!fuse_small)
+    auto set_online = [L, nlist, n, np_row]() {
         launch_set_online(L->metric, (uint32_t)nlist, (uint32_t)n, L->w_cdis.as<float>(), L->w_ckeys.as<int64_t>(), (uint32_t)np_row,
                           ix(L)->d_interdis.as<float>(), ix(L)->d_arcos.as<float>(), L->w_dtb.as<float>(), L->w_error.as<uint32_t>(), L->stream);
+    };
+    if (!fuse_small && !tie_inline) set_online();
     RoundSpec base;
+    if (tie_inline) {
+        // room for the rows the patch moves: a round's rows of every slot if that is not beyond reason (a query that finds no room is
+        // searched again)
+        size_t maxlist = 0;
+        for (size_t l = 0; l < nlist; l++) maxlist = std::max<size_t>(maxlist, ix(L)->h_list_off[l + 1] - ix(L)->h_list_off[l]);
+        const size_t SCRATCH_FLOATS = std::min<size_t>((size_t)64 << 20, std::max<size_t>((size_t)8 << 20, (size_t)512 * 16 * ((maxlist + 1023) & ~(size_t)1023)));
+        L->w_spec_scratch.ensure(SCRATCH_FLOATS * 4);
+        base.run_ties = true;
+        base.before_first_select = [L, nlist, set_online, SCRATCH_FLOATS]() {
+            HIP_CHECK(hipStreamWaitEvent(L->stream, L->ev_spec_done, 0));
+            TiePatchArgs ta{};
+            ta.count = L->w_spec_count.as<uint32_t>();
+            ta.cap = 512;
+            ta.nlist = (uint32_t)nlist;
+            ta.ncopy = (uint32_t)L->spec_ncopy;
+            ta.key_stride = (uint32_t)nlist;
+            ta.slot_query = L->w_spec_query.as<uint32_t>();
+            ta.slot_of = L->w_spec_slot.as<int32_t>();
+            ta.s_keys = L->w_spec_keys.as<int64_t>();
+            ta.ckeys = L->w_ckeys.as<int64_t>();
+            ta.seg_count = L->w_pl_cnt.as<uint32_t>();
+            ta.seg_begin = L->w_seg_begin.as<uint32_t>();
+            ta.seg_list = L->w_seg_list.as<int32_t>();
+            ta.seg_off = L->w_seg_off.as<uint64_t>();
+            ta.list_off = ix(L)->d_list_off.as<uint64_t>();
+            ta.dist = L->w_dist.as<float>();
+            ta.row_align = L->row_align_now;
+            ta.scratch = L->w_spec_scratch.as<float>();
+            ta.scratch_floats = SCRATCH_FLOATS;
+            ta.cursor = reinterpret_cast<unsigned long long*>(L->w_spec_count.as<uint32_t>() + 4);
+            ta.patched = L->w_spec_count.as<uint32_t>() + 1;
+            launch_tie_patch(ta, L->stream);
+            set_online();
+        };
+    }
     base.fused = ix(L)->allow_fused && ix(L)->db_range.fusable_with(qr, L->metric);
     base.bytes = byte_queries(L, ix(L), d_x, n, qr);
     if (fuse_small) {
@@ -3664,6 +3727,8 @@ static void adaptive_core_once(amd_ivf_t* h, const float* d_x, size_t start, siz
             if (h->spec_valid && nl == 1) {
                 h->spec_slot_host.assign(n, -1);
                 d2h_small(h, h->spec_slot_host.data(), h->w_spec_slot.p, n * 4, h->stream);
+                h->tie_patched_host = 0;
+                if (h->spec_inline) d2h_small(h, &h->tie_patched_host, h->w_spec_count.as<uint32_t>() + 1, 4, h->stream);
             } else {
                 h->spec_valid = false;
             }
@@ -3752,11 +3817,16 @@ static void adaptive_redo_ties(amd_ivf_t* h, const float* d_x, size_t start, siz
     h->want_first_tie = false;
     h->spec_wanted = false;
     std::vector<uint32_t> again;
+    // (with the heap's order applied to the pass itself -- launch_tie_patch -- a query whose ranking had a slot is done: the order it
+    // read was the reference's; left are the queries without a slot, the ones the patch gave up on (-2) and reads past what was ranked)
+    const bool patched = h->spec_inline && h->spec_valid && h->spec_slot_host.size() == n;
     for (size_t i = 0; i < n; i++) {
         const uint64_t bound = 2 * my_nprobe[start + i] + 14;
-        if (h->first_tie_host[i] < bound || bound + 1 >= nreal) again.push_back((uint32_t)i);
+        const bool in_order = patched && h->spec_slot_host[i] >= 0 && bound <= h->spec_ncopy;
+        if ((h->first_tie_host[i] < bound && !in_order) || bound + 1 >= nreal) again.push_back((uint32_t)i);
     }
     h->last_tie_redone = again.size();
+    h->last_tie_patched = patched ? h->tie_patched_host : 0;
     if (again.empty()) return;
     const size_t m = again.size();
     // what the first pass counted for these queries leaves the statistics (the device arrays are about to be reused)
@@ -3769,6 +3839,7 @@ static void adaptive_redo_ties(amd_ivf_t* h, const float* d_x, size_t start, siz
     std::vector<int32_t> pick(m, -1);
     for (size_t j = 0; j < m && spec; j++) {
         pick[j] = h->spec_slot_host[again[j]];
+        if (pick[j] <= -2) pick[j] = -2 - pick[j];  // (a slot whose order the first pass could not take over: launch_tie_patch)
         spec = pick[j] >= 0;
     }
     if (getenv("AUNCEL_AMD_DEBUG_REDO")) {
@@ -4304,6 +4375,11 @@ int amd_ivf_last_round_hints(amd_ivf_t* h, uint64_t out[2]) {
 
 int amd_ivf_last_tie_redone(amd_ivf_t* h, uint64_t* queries) {
     *queries = h->last_tie_redone;
+    return 0;
+}
+
+int amd_ivf_last_tie_patched(amd_ivf_t* h, uint64_t* rankings) {
+    *rankings = h->last_tie_patched;
     return 0;
 }
 

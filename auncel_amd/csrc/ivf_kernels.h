@@ -477,6 +477,9 @@ struct PlanArgs {
     double* min_bytes_thr;           // the same for the threshold rounds alone (null: not kept)
     uint32_t row_bytes;
     int dense_round;
+    // null or the sorted coarse distances [nq][key_stride]: a round never ends inside a run of exactly equal distances (the order
+    // inside a run may still change -- launch_tie_patch -- and a round's rows can be reordered, not exchanged with the next round's)
+    const float* run_dis;
 };
 
 constexpr uint32_t PLAN_MAX_ROUNDS = 64;
@@ -513,7 +516,33 @@ size_t heap_tie_order_lds(uint32_t nlist, uint32_t nprobe);  // LDS bytes of one
 // slot_of[q] = its slot or -1.  launch_heap_tie_order(dev_nq = count) then re-ranks the slots on a side stream.
 void launch_spec_collect(const uint32_t* first, uint32_t nq, uint32_t lo, uint32_t window, uint32_t cap, uint32_t nlist, uint32_t ncopy,
                          const float* full, const float* cdis, const int64_t* ckeys, uint32_t* count, int32_t* slot_of, float* s_full,
-                         float* s_dis, int64_t* s_keys, hipStream_t s);
+                         float* s_dis, int64_t* s_keys, hipStream_t s, uint32_t* slot_query = nullptr);
+// The heap's order of the slots' rankings applied to the search that set them aside, between the scan and the selection of its
+// first round (nothing before the selection reads the order inside a run of equal distances: the planner takes whole runs into
+// the round, PlanArgs::run_dis).  Per slot: the ranking's keys are overwritten with the heap's (same distances in the same places);
+// where that changes the order of rows the round has scanned, the rows and their table entries are put in the new order (through
+// `scratch`).  slot_of[q] = -2 - slot where that is not possible (more than 64 rows, a run across the end of the round, scratch full): the
+// caller searches those queries again.  *patched counts the rankings that changed.
+struct TiePatchArgs {
+    const uint32_t* count;       // slots handed out (may exceed cap)
+    uint32_t cap, nlist, ncopy, key_stride;
+    const uint32_t* slot_query;  // [cap]
+    int32_t* slot_of;            // [nq]
+    const int64_t* s_keys;       // [cap][nlist] the heap's order
+    int64_t* ckeys;              // [nq][key_stride] the search's ranking
+    const uint32_t* seg_count;   // [nq] rows of the query in the round
+    const uint32_t* seg_begin;   // [nq]
+    int32_t* seg_list;
+    uint64_t* seg_off;
+    const uint64_t* list_off;
+    float* dist;
+    uint32_t row_align;
+    float* scratch;
+    unsigned long long scratch_floats;
+    unsigned long long* cursor;  // zeroed by the caller
+    uint32_t* patched;
+};
+void launch_tie_patch(const TiePatchArgs& a, hipStream_t s);
 // rows of a second search from those slots: ranking row j <- slot slots[j] (ncopy leading entries, rows of nlist entries)
 void launch_spec_gather(const int32_t* slots, uint32_t m, uint32_t nlist, uint32_t ncopy, const float* s_dis, const int64_t* s_keys,
                         float* cdis, int64_t* ckeys, hipStream_t s);

@@ -2070,42 +2070,72 @@ template <bool IsMax> __device__ inline void floyd_fill_pow2(HeapEnt* a, const f
     wave_sync();
 }
 
+// One step of a walk: the hole takes the better child (the right one between equals) unless the entry the walk carries beats it, in
+// which case that entry lands in the hole and the walk ends.  A lane without a walk steps on slot 0 (unused) instead of being masked
+// off, and an address past the heap is read but not used: nothing is clamped.
+struct HeapWalk {
+    uint32_t hole, s, lvl, Lid;  // slot the walk stands on (0: none), heap size of its pop, depth of hole, id it carries
+    float Lv;
+};
+template <bool IsMax> __device__ __forceinline__ void heap_walk_step(HeapEnt* a, HeapWalk& w, const uint4 ch) {
+    const uint32_t j1 = w.hole << 1;
+    const float c1v = __uint_as_float(ch.x), c2v = __uint_as_float(ch.z);
+    const bool left = j1 == w.s || hcmp<IsMax>(c1v, c2v);  // a single child, or the better one (the right one between equals)
+    const float cv = left ? c1v : c2v;
+    const uint32_t cid = left ? ch.y : ch.w;
+    const bool done = j1 > w.s || hcmp<IsMax>(w.Lv, cv);
+    reinterpret_cast<uint2*>(a)[w.hole] = make_uint2(__float_as_uint(done ? w.Lv : cv), done ? w.Lid : cid);
+    const uint32_t nh = left ? j1 : j1 + 1;
+    w.hole = done ? 0u : nh;
+    w.lvl++;
+}
+
+// Two kinds of tick (round 5; the one-kind loop it replaces issued ~85 instructions a tick and was bound by that, not by the LDS
+// round trip: 1490 cycles per pop, now 870; scratch/ubench/heap_sort.hip).  A pop can start at most every other tick, so the tick
+// behind a start is a plain step of the walks in flight (children -> two compares -> store) and only the other ticks carry the
+// start logic; walks sit on a ring of lanes by pop number (at most one per two levels is alive).
 template <bool IsMax> __device__ inline void heapsort_pipelined(HeapEnt* a, uint32_t n, uint32_t* out_id, int lane) {
-    // one walk per lane: hole = slot the walk stands on (0: lane free), s = heap size of its pop, lvl = depth of hole,
-    // (Lv, Lid) = the entry it carries.  Every lane runs the same straight-line tick: free lanes read slot 0 and store nothing.
-    uint32_t hole = 0, s = 0, lvl = 0, Lid = 0;
-    float Lv = 0.f;
-    uint32_t t = 0, since = 2;  // pops started; ticks since the last start
+    HeapWalk w{0u, 0xffffffffu, 0u, 0u, 0.f};
+    uint32_t t = 0;  // pops started
     const uint4* a4 = reinterpret_cast<const uint4*>(a);
     const uint2* a2 = reinterpret_cast<const uint2*>(a);
     while (true) {
-        const unsigned long long act = __ballot(hole != 0);
-        if (t == n && !act) break;
-        const uint32_t sc = n - t, dsc = 31 - __builtin_clz(sc | 1);
-        const bool above = hole != 0 && lvl <= dsc && (sc >> ((dsc - lvl) & 31)) == hole;
-        const bool create = t < n && since >= 2 && !__ballot(above);
-        const bool mine = create && lane == __builtin_ctzll(~act);
-        hole = mine ? 1u : hole;
-        s = mine ? sc : s;
-        lvl = mine ? 0u : lvl;
-        const uint32_t i1 = hole << 1;
-        const uint4 ch = a4[(i1 < n ? i1 : n) >> 1];  // both children (a has n + 2 slots)
-        const uint2 ls = a2[mine ? sc : 0u];
-        const uint32_t top_id = a2[1].y;
-        if (mine) out_id[sc - 1] = top_id;  // heap_reorder: the top goes behind the shrinking heap
-        Lv = mine ? __uint_as_float(ls.x) : Lv;
-        Lid = mine ? ls.y : Lid;
-        const float c1v = __uint_as_float(ch.x), c2v = __uint_as_float(ch.z);
-        const bool left = i1 == s || hcmp<IsMax>(c1v, c2v);  // a single child, or the better one (the right one between equals)
-        const float cv = left ? c1v : c2v;
-        const uint32_t cid = left ? ch.y : ch.w;
-        const bool done = i1 > s || hcmp<IsMax>(Lv, cv);
-        if (hole != 0) a[hole] = HeapEnt{done ? Lv : cv, done ? Lid : cid};
-        hole = hole != 0 && !done ? (left ? i1 : i1 + 1) : 0u;
-        lvl++;
-        t += create ? 1u : 0u;
-        since = create ? 1u : since + 1;
+        // ---- a tick that may start pop t: it takes the entry of slot n - t and walks it down from the root
+        const uint32_t sc = n - t;
+        const uint4 ch_own = a4[w.hole];
+        const unsigned long long act = __ballot(w.hole != 0);
+        if (t == n) {
+            if (!act) break;
+            heap_walk_step<IsMax>(a, w, ch_own);
+            wave_sync();
+            continue;
+        }
+        // (no start while a walk in flight is above slot n - t: it could still change the entry the pop is about to take)
+        const uint32_t dsc = 31 - __builtin_clz(sc);
+        const bool above = w.hole != 0 && w.lvl <= dsc && (sc >> ((dsc - w.lvl) & 31)) == w.hole;
+        const bool create = !__ballot(above);
+        const bool mine = create && (uint32_t)lane == (t & 31u);
+        uint4 ch = ch_own;
+        if (mine) {
+            const uint4 r01 = a4[0];  // entry 1: the root
+            ch = a4[1];               // its children
+            const uint2 ls = a2[sc];
+            out_id[sc - 1] = r01.w;   // heap_reorder: the top goes behind the shrinking heap
+            w.hole = 1u;
+            w.s = sc;
+            w.lvl = 0u;
+            w.Lv = __uint_as_float(ls.x);
+            w.Lid = ls.y;
+        }
+        heap_walk_step<IsMax>(a, w, ch);
         wave_sync();
+        if (create) {
+            t++;
+            // ---- the tick behind a start: a plain step
+            const uint4 c2 = a4[w.hole];
+            heap_walk_step<IsMax>(a, w, c2);
+            wave_sync();
+        }
     }
 }
 
@@ -2115,6 +2145,7 @@ __global__ __launch_bounds__(64) void heap_tie_order_kernel(const float* dis, ui
                                                             const uint32_t* dev_nq) {
     extern __shared__ __align__(16) unsigned char smem[];
     if (dev_nq && blockIdx.x >= *dev_nq) return;  // (rows set aside on the device: launch_spec_collect)
+    __builtin_amdgcn_s_setprio(3);  // (one wave's dependent chain of a few thousand steps, beside other searches' kernels)
     HeapEnt* h = reinterpret_cast<HeapEnt*>(smem);                           // nprobe + 2 entries, [0] unused
     float* row = reinterpret_cast<float*>(smem + (size_t)(nprobe + 2) * 8);  // nlist
     const uint32_t q = blockIdx.x, lane = threadIdx.x;
@@ -2201,7 +2232,7 @@ void launch_first_tie(const float* sorted_dis, uint32_t nq, uint32_t stride, uin
 
 __global__ __launch_bounds__(64) void spec_collect_kernel(const uint32_t* first, uint32_t lo, uint32_t window, uint32_t cap, uint32_t nlist, uint32_t ncopy,
                                                           const float* full, const float* cdis, const int64_t* ckeys, uint32_t* count,
-                                                          int32_t* slot_of, float* s_full, float* s_dis, int64_t* s_keys) {
+                                                          int32_t* slot_of, float* s_full, float* s_dis, int64_t* s_keys, uint32_t* slot_query) {
     const uint32_t q = blockIdx.x, lane = threadIdx.x;
     uint32_t slot = 0xffffffffu;
     if (first[q] < lo) return;  // (dealt with by the launch for the nearer runs)
@@ -2211,7 +2242,10 @@ __global__ __launch_bounds__(64) void spec_collect_kernel(const uint32_t* first,
         if (lane == 0) slot_of[q] = -1;
         return;
     }
-    if (lane == 0) slot_of[q] = (int32_t)slot;
+    if (lane == 0) {
+        slot_of[q] = (int32_t)slot;
+        if (slot_query) slot_query[slot] = q;
+    }
     const float* fr = full + (size_t)q * nlist;
     float* fo = s_full + (size_t)slot * nlist;
     for (uint32_t j = lane; j < nlist; j += 64) fo[j] = fr[j];
@@ -2223,8 +2257,92 @@ __global__ __launch_bounds__(64) void spec_collect_kernel(const uint32_t* first,
 
 void launch_spec_collect(const uint32_t* first, uint32_t nq, uint32_t lo, uint32_t window, uint32_t cap, uint32_t nlist, uint32_t ncopy,
                          const float* full, const float* cdis, const int64_t* ckeys, uint32_t* count, int32_t* slot_of, float* s_full,
-                         float* s_dis, int64_t* s_keys, hipStream_t s) {
-    if (nq) LAUNCH(spec_collect_kernel, dim3(nq), dim3(64), 0, s, first, lo, window, cap, nlist, ncopy, full, cdis, ckeys, count, slot_of, s_full, s_dis, s_keys);
+                         float* s_dis, int64_t* s_keys, hipStream_t s, uint32_t* slot_query) {
+    if (nq)
+        LAUNCH(spec_collect_kernel, dim3(nq), dim3(64), 0, s, first, lo, window, cap, nlist, ncopy, full, cdis, ckeys, count, slot_of, s_full, s_dis, s_keys,
+               slot_query);
+}
+
+// The heap's order of the slots' rankings, applied to the search that is under way (TiePatchArgs, ivf_kernels.h).  One wave per slot.
+__global__ __launch_bounds__(64) void tie_patch_kernel(TiePatchArgs a) {
+    const uint32_t slot = blockIdx.x, lane = threadIdx.x;
+    const uint32_t nslots = *a.count < a.cap ? *a.count : a.cap;
+    if (slot >= nslots) return;
+    const uint32_t q = a.slot_query[slot];
+    const int64_t* nk = a.s_keys + (size_t)slot * a.nlist;
+    int64_t* ok = a.ckeys + (size_t)q * a.key_stride;
+    const uint32_t cnt0 = a.seg_count[q];
+    bool changed = false, in_round = false;
+    for (uint32_t j = lane; j < a.ncopy; j += 64) {
+        const int64_t want = nk[j];
+        if (ok[j] != want) {
+            ok[j] = want;
+            changed = true;
+            in_round = in_round || j < cnt0;
+        }
+    }
+    if (!__ballot(changed)) return;
+    if (lane == 0) atomicAdd(a.patched, 1u);
+    if (!__ballot(in_round)) return;
+    // ---- the rows the round has scanned already are in the old order: put them (and their table entries) in the new one
+    auto give_up = [&]() {
+        if (lane == 0) a.slot_of[q] = -2 - (int32_t)slot;  // (this query is searched again, its ranking taken from the slot: adaptive_redo_ties)
+    };
+    if (cnt0 > 64) return give_up();
+    const uint32_t seg0 = a.seg_begin[q];
+    const bool in = lane < cnt0;
+    const int32_t oldkey = in ? a.seg_list[seg0 + lane] : -1;
+    const int32_t newkey = in ? (int32_t)nk[lane] : -1;
+    const unsigned long long off_old = in ? a.seg_off[seg0 + lane] : 0ull;
+    unsigned long long psz = 0;
+    if (in && oldkey >= 0 && (uint32_t)oldkey < a.nlist) {
+        const unsigned long long sz = a.list_off[oldkey + 1] - a.list_off[oldkey], ra = a.row_align - 1;
+        psz = (sz + ra) & ~ra;
+    }
+    // where the row that belongs at place `lane` is now
+    int src = -1;
+    for (uint32_t p = 0; p < cnt0; p++)
+        if (rl_i(oldkey, (int)p) == newkey) src = (int)p;
+    if (__ballot(in && (src < 0 || newkey < 0)) != 0) return give_up();  // (a run that crosses the end of the round's rows)
+    const unsigned long long moved = __ballot(in && src != (int)lane);
+    if (!moved) return;
+    const int lo = __builtin_ctzll(moved), hi = 63 - __builtin_clzll(moved);
+    // sizes in the new order, new offsets inside [lo, hi]: exclusive prefix sums
+    const uint32_t my_psz = (uint32_t)psz;
+    uint32_t new_psz = (uint32_t)__shfl((int)my_psz, src < 0 ? 0 : src);
+    const bool span = (int)lane >= lo && (int)lane <= hi;
+    uint32_t incl = span ? new_psz : 0u;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
+        if ((int)lane >= off) incl += o;
+    }
+    const uint32_t total = (uint32_t)__shfl((int)incl, hi);
+    const unsigned long long base = ((unsigned long long)rl_u((uint32_t)(off_old >> 32), lo) << 32) | rl_u((uint32_t)off_old, lo);
+    const unsigned long long off_new = base + (incl - (span ? new_psz : 0u));
+    // room in the scratch buffer
+    unsigned long long at = 0;
+    if (lane == 0) at = atomicAdd(a.cursor, (unsigned long long)total);
+    at = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(at >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)at);
+    if (at + total > a.scratch_floats) return give_up();
+    float* sc = a.scratch + at;
+    for (uint32_t i = lane; i < total; i += 64) sc[i] = a.dist[base + i];
+    __threadfence();
+    wave_sync();
+    for (int p = lo; p <= hi; p++) {
+        const int sp = rl_i(src, p);
+        const unsigned long long from = (((unsigned long long)rl_u((uint32_t)(off_old >> 32), sp) << 32) | rl_u((uint32_t)off_old, sp)) - base;
+        const unsigned long long to = ((unsigned long long)rl_u((uint32_t)(off_new >> 32), p) << 32) | rl_u((uint32_t)off_new, p);
+        const uint32_t len = rl_u(new_psz, p);
+        for (uint32_t i = lane; i < len; i += 64) a.dist[to + i] = sc[from + i];
+    }
+    if (span) {
+        a.seg_list[seg0 + lane] = newkey;
+        a.seg_off[seg0 + lane] = off_new;
+    }
+}
+
+void launch_tie_patch(const TiePatchArgs& a, hipStream_t s) {
+    if (a.cap) LAUNCH(tie_patch_kernel, dim3(a.cap), dim3(64), 0, s, a);
 }
 
 __global__ __launch_bounds__(64) void spec_gather_kernel(const int32_t* slots, uint32_t nlist, uint32_t ncopy, const float* s_dis,

@@ -64,6 +64,12 @@ __device__ __forceinline__ void plan_counts_query(const PlanArgs& a, uint32_t i,
             }
         }
         if (target > a.total_nprobe) target = a.total_nprobe;
+        if (a.run_dis && target > stage) {
+            // (entries behind what was ranked are all (neutral, -1): not a run)
+            const float* dq = a.run_dis + (size_t)i * a.key_stride;
+            const int64_t* ka = a.keys + (size_t)i * a.key_stride;
+            while (target < a.total_nprobe && dq[target - 1] == dq[target] && ka[target] >= 0) target++;
+        }
         if (a.limit && lane == 0) a.limit[i] = last ? (uint32_t)target : a.total_nprobe;
         if (target <= stage) target = stage + 1 < a.total_nprobe ? stage + 1 : a.total_nprobe;
         cnt = (uint32_t)(target - stage);

@@ -1167,10 +1167,14 @@ __global__ __launch_bounds__(256) void compact_rows_kernel(CompactArgs a) {
             uint2* ent = a.cl_ent + (size_t)(s0 + r) * CL_CAP;
             uint32_t report = total;
             if (total > CL_CAP) {
-                uint32_t start = 0;
-                if (lane == 0) start = xcd_local_add(&a.cursor[32u * xcc_id()], total);
+                // (a place is asked for only while the cursor is inside the arena and the list could fit at all: a cursor that kept
+                // growing with every overflowing row could wrap around and hand out places that other rows own)
+                uint32_t start = a.arena_per_xcd;
+                if (lane == 0 && total <= a.arena_per_xcd &&
+                    __hip_atomic_load(&a.cursor[32u * xcc_id()], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < a.arena_per_xcd)
+                    start = xcd_local_add(&a.cursor[32u * xcc_id()], total);
                 start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
-                if (start + total > a.arena_per_xcd) {
+                if (start >= a.arena_per_xcd || total > a.arena_per_xcd - start) {
                     if (lane == 0) a.cl_cnt[s0 + r] = CL_WALK;
                     continue;
                 }

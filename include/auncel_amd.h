@@ -248,13 +248,18 @@ int amd_ivf_last_scan_min_bytes(amd_ivf_t* h, double* bytes);
  *     repeated with the heap's order -- same results as always re-running, at a hundredth of the cost.  Time-bounded
  *     search: centroid-number order (the clock decides the depth);
  *   larger calls: centroid-number order (the reference ranks sgemm output there);
- *   AUNCEL_AMD_COARSE_TIES=heap: always re-run; =id: never; =redo (adaptive calls of >= 20 queries): search the whole call with
- *     centroid-number order, then search again -- one small call with the heap's order -- exactly the queries whose first run
- *     starts below 2 my_nprobe + 14: the exact-distance result for every query at the price of a second, short call
- *     (amd_ivf_last_tie_redone: how many queries that was).
+ *   AUNCEL_AMD_COARSE_TIES=heap: always re-run; =id: never; =redo (adaptive calls of >= 20 queries): the exact-distance result
+ *     for every query of the call.  The rankings whose first run starts inside what the first two rounds can read are re-run
+ *     through the heap on a side stream WHILE the call's first round is planned and scanned (the planner takes whole runs into a
+ *     round, so nothing before the first selection depends on the order inside a run); the heap's order is then written over
+ *     those rankings and, where it changes the order of rows already scanned, over the rows (amd_ivf_last_tie_patched: rankings
+ *     changed) -- one pass, the reference's order.  What that cannot cover (no slot left, a ranking read past what was re-run,
+ *     nlist not a power of two: the level-parallel heap does not apply) is searched again as one small call with the heap's
+ *     order (amd_ivf_last_tie_redone: how many queries that was).
  * *rows = rankings re-run so far on this handle. */
 int amd_ivf_coarse_tie_rows(amd_ivf_t* h, uint64_t* rows);
 int amd_ivf_last_tie_redone(amd_ivf_t* h, uint64_t* queries);
+int amd_ivf_last_tie_patched(amd_ivf_t* h, uint64_t* rankings);
 /* Launch sizing of the last search.  The device-planned rounds are enqueued without reading anything back, so a scan's grid is
  * sized from what the same round of the previous search of this shape needed (+ 12 %); its workgroups stride over the item
  * count the planner left on the device, so a round that needs more is still complete -- it just runs on fewer workgroups than it

@@ -1,0 +1,256 @@
+// Pipelined heap sort of one row per wave (the second half of heap_tie_order_kernel, auncel_amd/csrc/ivf_kernels.hip): how fast can
+// a tick be made?  Checked against the literal heap sort (pops with the "right child between equals" rule) on rows with runs of
+// equal values.
+//   hipcc --offload-arch=gfx950 -O3 scratch/ubench/heap_sort.hip -o scratch/ubench/heap_sort && scratch/ubench/heap_sort
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+struct HeapEnt { float v; uint32_t id; };
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---- the form in the product at the start of round 5
+__device__ inline void heapsort_v1(HeapEnt* a, uint32_t n, uint32_t* out_id, int lane) {
+    uint32_t hole = 0, s = 0, lvl = 0, Lid = 0;
+    float Lv = 0.f;
+    uint32_t t = 0, since = 2;
+    const uint4* a4 = reinterpret_cast<const uint4*>(a);
+    const uint2* a2 = reinterpret_cast<const uint2*>(a);
+    while (true) {
+        const unsigned long long act = __ballot(hole != 0);
+        if (t == n && !act) break;
+        const uint32_t sc = n - t, dsc = 31 - __builtin_clz(sc | 1);
+        const bool above = hole != 0 && lvl <= dsc && (sc >> ((dsc - lvl) & 31)) == hole;
+        const bool create = t < n && since >= 2 && !__ballot(above);
+        const bool mine = create && lane == __builtin_ctzll(~act);
+        hole = mine ? 1u : hole;
+        s = mine ? sc : s;
+        lvl = mine ? 0u : lvl;
+        const uint32_t i1 = hole << 1;
+        const uint4 ch = a4[(i1 < n ? i1 : n) >> 1];
+        const uint2 ls = a2[mine ? sc : 0u];
+        const uint32_t top_id = a2[1].y;
+        if (mine) out_id[sc - 1] = top_id;
+        Lv = mine ? __uint_as_float(ls.x) : Lv;
+        Lid = mine ? ls.y : Lid;
+        const float c1v = __uint_as_float(ch.x), c2v = __uint_as_float(ch.z);
+        const bool left = i1 == s || c1v > c2v;
+        const float cv = left ? c1v : c2v;
+        const uint32_t cid = left ? ch.y : ch.w;
+        const bool done = i1 > s || Lv > cv;
+        if (hole != 0) a[hole] = HeapEnt{done ? Lv : cv, done ? Lid : cid};
+        hole = hole != 0 && !done ? (left ? i1 : i1 + 1) : 0u;
+        lvl++;
+        t += create ? 1u : 0u;
+        since = create ? 1u : since + 1;
+        wave_sync();
+    }
+}
+
+// ---- v2: the loads of a tick do not wait for the decision whether a pop starts (the root's children, the last entry and the root
+// itself are requested by every lane next to the lane's own walk), walks sit on a ring of lanes by pop number, and the bookkeeping
+// that needs no memory runs while the loads are in flight
+__device__ inline void heapsort_v2(HeapEnt* a, uint32_t n, uint32_t* out_id, int lane) {
+    uint32_t hole = 0, s = 0, lvl = 0, Lid = 0;
+    float Lv = 0.f;
+    uint32_t t = 0, since = 2;
+    const uint4* a4 = reinterpret_cast<const uint4*>(a);
+    const uint2* a2 = reinterpret_cast<const uint2*>(a);
+    const uint32_t lim = n >> 1;
+    while (true) {
+        const uint32_t sc = n - t;
+        // requests: own children | root + its children | the entry the next pop would take
+        const uint32_t i1 = hole << 1;
+        const uint4 ch_own = a4[hole < lim ? hole : lim];
+        const uint4 r01 = a4[0];  // entries 0 (unused), 1 (root)
+        const uint4 r23 = a4[1];  // the root's children
+        const uint2 ls = a2[sc];
+        // meanwhile
+        const unsigned long long act = __ballot(hole != 0);
+        if (t == n && !act) break;
+        const uint32_t dsc = 31 - __builtin_clz(sc | 1);
+        const bool above = hole != 0 && lvl <= dsc && (sc >> ((dsc - lvl) & 31)) == hole;
+        const bool create = t < n && since >= 2 && !__ballot(above);
+        const bool mine = create && (uint32_t)lane == (t & 15u);
+        // the walk's step
+        const uint32_t h = mine ? 1u : hole;
+        const uint32_t ss = mine ? sc : s;
+        const uint32_t j1 = mine ? 2u : i1;
+        const uint4 ch = mine ? r23 : ch_own;
+        if (mine) out_id[sc - 1] = r01.w;
+        Lv = mine ? __uint_as_float(ls.x) : Lv;
+        Lid = mine ? ls.y : Lid;
+        const float c1v = __uint_as_float(ch.x), c2v = __uint_as_float(ch.z);
+        const bool left = j1 == ss || c1v > c2v;
+        const float cv = left ? c1v : c2v;
+        const uint32_t cid = left ? ch.y : ch.w;
+        const bool done = j1 > ss || Lv > cv;
+        if (h != 0) a[h] = HeapEnt{done ? Lv : cv, done ? Lid : cid};
+        hole = h != 0 && !done ? (left ? j1 : j1 + 1) : 0u;
+        s = ss;
+        lvl = mine ? 1u : lvl + 1;
+        t += create ? 1u : 0u;
+        since = create ? 1u : since + 1;
+        wave_sync();
+    }
+}
+
+
+// ---- v3: two kinds of tick.  A pop can start at most every other tick, so the tick after a start is a plain step of the walks in
+// flight (children -> compare -> store), and only the other ticks carry the start logic.  Lanes without a walk step on slot 0
+// (unused) instead of being masked off; nothing is clamped (an address past the heap is read but its result is not used).
+struct Walk {
+    uint32_t hole, s, lvl, Lid;
+    float Lv;
+};
+__device__ __forceinline__ void walk_step(HeapEnt* a, Walk& w, const uint4 ch) {
+    const uint32_t j1 = w.hole << 1;
+    const float c1v = __uint_as_float(ch.x), c2v = __uint_as_float(ch.z);
+    const bool left = j1 == w.s || c1v > c2v;
+    const float cv = left ? c1v : c2v;
+    const uint32_t cid = left ? ch.y : ch.w;
+    const bool done = j1 > w.s || w.Lv > cv;
+    reinterpret_cast<uint2*>(a)[w.hole] = make_uint2(__float_as_uint(done ? w.Lv : cv), done ? w.Lid : cid);  // (hole 0: the unused slot)
+    const uint32_t nh = left ? j1 : j1 + 1;
+    w.hole = done ? 0u : nh;
+    w.lvl++;
+}
+__device__ inline void heapsort_v3(HeapEnt* a, uint32_t n, uint32_t* out_id, int lane) {
+    Walk w{0u, 0xffffffffu, 0u, 0u, 0.f};
+    uint32_t t = 0;
+    const uint4* a4 = reinterpret_cast<const uint4*>(a);
+    const uint2* a2 = reinterpret_cast<const uint2*>(a);
+    while (true) {
+        // ---- a tick that may start pop t
+        const uint32_t sc = n - t;
+        const uint4 ch_own = a4[w.hole];
+        const uint4 r01 = a4[0];
+        const uint4 r23 = a4[1];
+        const uint2 ls = a2[sc];
+        const unsigned long long act = __ballot(w.hole != 0);
+        if (t == n) {
+            if (!act) break;
+            walk_step(a, w, ch_own);
+            wave_sync();
+            continue;
+        }
+        const uint32_t dsc = 31 - __builtin_clz(sc);
+        const bool above = w.hole != 0 && w.lvl <= dsc && (sc >> ((dsc - w.lvl) & 31)) == w.hole;
+        const bool create = !__ballot(above);
+        const bool mine = create && (uint32_t)lane == (t & 15u);
+        if (mine) out_id[sc - 1] = r01.w;
+        w.hole = mine ? 1u : w.hole;
+        w.s = mine ? sc : w.s;
+        w.lvl = mine ? 0u : w.lvl;
+        w.Lv = mine ? __uint_as_float(ls.x) : w.Lv;
+        w.Lid = mine ? ls.y : w.Lid;
+        uint4 ch;
+        ch.x = mine ? r23.x : ch_own.x;
+        ch.y = mine ? r23.y : ch_own.y;
+        ch.z = mine ? r23.z : ch_own.z;
+        ch.w = mine ? r23.w : ch_own.w;
+        walk_step(a, w, ch);
+        wave_sync();
+        if (create) {
+            t++;
+            // ---- the tick after a start: a plain step
+            const uint4 c2 = a4[w.hole];
+            walk_step(a, w, c2);
+            wave_sync();
+        }
+    }
+}
+
+template <int V> __global__ __launch_bounds__(64) void sort_rows(const float* heaps, uint32_t n, uint32_t* out, unsigned long long* cycles) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    HeapEnt* a = reinterpret_cast<HeapEnt*>(smem);
+    uint32_t* out_id = reinterpret_cast<uint32_t*>(smem + (size_t)(n + 2) * 8);
+    const int lane = threadIdx.x;
+    __builtin_amdgcn_s_setprio(3);
+    // the row is a valid max-heap already (built on the host); ids = original slot
+    for (uint32_t i = lane; i < n + 2; i += 64) a[i] = HeapEnt{i >= 1 && i <= n ? heaps[(size_t)blockIdx.x * n + i - 1] : 3.0e38f, i - 1};
+    wave_sync();
+    const unsigned long long c0 = __builtin_readcyclecounter();
+    if (V == 1) heapsort_v1(a, n, out_id, lane);
+    else if (V == 2) heapsort_v2(a, n, out_id, lane);
+    else heapsort_v3(a, n, out_id, lane);
+    const unsigned long long c1 = __builtin_readcyclecounter();
+    wave_sync();
+    for (uint32_t i = lane; i < n; i += 64) out[(size_t)blockIdx.x * n + i] = out_id[i];
+    if (lane == 0) cycles[blockIdx.x] = c1 - c0;
+}
+
+// the literal heap sort (pop: Heap.h:88-118 restated)
+static void ref_sort(std::vector<float> v, std::vector<uint32_t>& out) {
+    const size_t n = v.size();
+    std::vector<uint32_t> id(n + 2);
+    std::vector<float> a(n + 2, 0.f);
+    for (size_t i = 1; i <= n; i++) a[i] = v[i - 1], id[i] = (uint32_t)(i - 1);
+    out.assign(n, 0);
+    for (size_t t = 0; t < n; t++) {
+        const size_t k = n - t;
+        const uint32_t top = id[1];
+        const float val = a[k];
+        const uint32_t vid = id[k];
+        size_t i = 1;
+        while (true) {
+            const size_t i1 = 2 * i, i2 = i1 + 1;
+            if (i1 > k) break;
+            if (i2 == k + 1 || a[i1] > a[i2]) {
+                if (val > a[i1]) break;
+                a[i] = a[i1]; id[i] = id[i1]; i = i1;
+            } else {
+                if (val > a[i2]) break;
+                a[i] = a[i2]; id[i] = id[i2]; i = i2;
+            }
+        }
+        a[i] = val; id[i] = vid;
+        out[k - 1] = top;
+    }
+}
+
+int main(int argc, char** argv) {
+    const uint32_t n = argc > 1 ? atoi(argv[1]) : 4096, rows = argc > 2 ? atoi(argv[2]) : 64;
+    std::vector<float> h((size_t)rows * n);
+    srand(7);
+    for (uint32_t r = 0; r < rows; r++) {
+        float* x = h.data() + (size_t)r * n;
+        for (uint32_t i = 0; i < n; i++) x[i] = (float)(rand() % (r % 2 ? 3000 : 100000));  // runs of equal values
+        std::make_heap(x, x + n);  // any valid max-heap will do as the start
+    }
+    float* dh; uint32_t* dout; unsigned long long* dcyc;
+    CK(hipMalloc(&dh, h.size() * 4)); CK(hipMalloc(&dout, h.size() * 4)); CK(hipMalloc(&dcyc, rows * 8));
+    CK(hipMemcpy(dh, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    const size_t shmem = (size_t)(n + 2) * 8 + (size_t)n * 4;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int ver = 1; ver <= 3; ver++) {
+        auto kern = ver == 1 ? sort_rows<1> : ver == 2 ? sort_rows<2> : sort_rows<3>;
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        float best = 1e9f;
+        for (int rep = 0; rep < 3; rep++) {
+            CK(hipEventRecord(e0));
+            kern<<<rows, 64, shmem>>>(dh, n, dout, dcyc);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms);
+        }
+        std::vector<uint32_t> out(h.size()); std::vector<unsigned long long> cyc(rows);
+        CK(hipMemcpy(out.data(), dout, out.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(cyc.data(), dcyc, rows * 8, hipMemcpyDeviceToHost));
+        size_t bad = 0;
+        for (uint32_t r = 0; r < rows; r++) {
+            std::vector<uint32_t> want;
+            ref_sort(std::vector<float>(h.begin() + (size_t)r * n, h.begin() + (size_t)(r + 1) * n), want);
+            for (uint32_t i = 0; i < n; i++) bad += want[i] != out[(size_t)r * n + i];
+        }
+        double mc = 0; for (auto c : cyc) mc += c; mc /= rows;
+        printf("v%d: n %u, %u rows: %.3f ms per launch, %.0f cycle-counter ticks per row (%.1f per pop), wrong entries %zu\n", ver, n, rows, best, mc, mc / n, bad);
+    }
+    return 0;
+}
