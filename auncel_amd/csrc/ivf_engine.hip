@@ -347,7 +347,7 @@ struct amd_ivf {
     DevBuf w_spec_full, w_spec_dis, w_spec_keys, w_spec_count, w_spec_slot, w_spec_pick, w_redo_idx, w_spec_query, w_spec_scratch;
     bool spec_inline = false;       // the heap's order was applied to the first pass itself (launch_tie_patch): only what it could not fix is searched again
     uint32_t tie_patched_host = 0;  // rankings of the last first pass that the heap's order changed
-    hipStream_t spec_stream = nullptr;
+    hipStream_t spec_stream = nullptr;  // (= bg_stream)
     hipEvent_t ev_spec_go = nullptr, ev_spec_done = nullptr;
     bool spec_wanted = false;  // set by adaptive_redo_ties around its first pass (small calls repeat as a whole: no slots)
     bool spec_done = false;   // run_rounds_device: the search ended at its first look and the caller's read-backs came with it
@@ -423,7 +423,8 @@ struct amd_ivf {
     DevBuf w_qstat;     // per query: lists scanned, heap updates (what a query searched again takes out of the statistics)
     DevBuf w_redo_x;    // rows of the queries searched again with the reference's coarse tie order (adaptive_core)
     DevBuf w_log_snap, w_fin_round, w_fix_pos, w_fix_val, w_fix_ref;  // tie_fix_kernel: per-round log counts, heaps replayed so far
-    hipStream_t fix_stream = nullptr;            // tie_fix_kernel runs here, under the next round
+    hipStream_t fix_stream = nullptr;            // tie_fix_kernel runs here, under the next round (= bg_stream)
+    hipStream_t bg_stream = nullptr;             // the context's background stream: tie replay beside the next round, the heap order of coarse ties
     hipEvent_t ev_sel = nullptr, ev_fix[2] = {nullptr, nullptr};
     size_t last_state_n = 0;                     // queries of the last search (amd_ivf_last_tie_fixed reads their flags)
     // chained rounds: the planning counters of every round of the last search (grid hints for the next one of the same shape)
@@ -490,8 +491,7 @@ struct amd_ivf {
             if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
         }
         if (ev_fork) (void)hipEventDestroy(ev_fork);
-        if (fix_stream) (void)hipStreamDestroy(fix_stream);
-        if (spec_stream) (void)hipStreamDestroy(spec_stream);
+        if (bg_stream) (void)hipStreamDestroy(bg_stream);
         if (ev_spec_go) (void)hipEventDestroy(ev_spec_go);
         if (ev_spec_done) (void)hipEventDestroy(ev_spec_done);
         if (ev_sel) (void)hipEventDestroy(ev_sel);
@@ -560,16 +560,53 @@ hipStream_t make_background_stream() {
     return s;
 }
 
+// The streams of a search context, all of them when the context is made and always in the same order: main (made by the caller),
+// scan, background.  The runtime hands a new stream the least used hardware queue of its priority class (GPU_MAX_HW_QUEUES per
+// class, the first of equals), so which streams share a queue follows from the order in which contexts are created and from
+// nothing else -- created on first use (round 4) it followed from which search happened to need which stream first, and the
+// figures of a leg moved by a factor of two with the legs run before it.  With the 8 queues the engine asks for (below) the scan
+// and background streams of four contexts have a queue each; from the fifth context on like shares with like (scan with scan).
+void ensure_context_streams(amd_ivf* h) {
+    if (h->bg_stream) return;
+    static const char* scan_prio = getenv("AUNCEL_AMD_SCAN_PRIO");  // (experiment: "low" = the scan stream at the lowest priority)
+    if (!h->ev_fork) {
+        HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        for (int i = 0; i < 4; i++) HIP_CHECK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+    }
+    int lo = 0, hi = 0;
+    if (scan_prio && !strcmp(scan_prio, "low") && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo) {
+        HIP_CHECK(hipStreamCreateWithPriority(&h->aux[3], hipStreamNonBlocking, lo));
+    } else {
+        HIP_CHECK(hipStreamCreateWithFlags(&h->aux[3], hipStreamNonBlocking));
+    }
+    static const char* bg_prio = getenv("AUNCEL_AMD_BG_PRIO");  // (experiment: "high" = the background stream at the main streams' priority)
+    if (bg_prio && !strcmp(bg_prio, "high") && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo) {
+        HIP_CHECK(hipStreamCreateWithPriority(&h->bg_stream, hipStreamNonBlocking, hi));
+    } else {
+        h->bg_stream = make_background_stream();
+    }
+    h->fix_stream = h->spec_stream = h->bg_stream;
+    HIP_CHECK(hipEventCreateWithFlags(&h->ev_sel, hipEventDisableTiming));
+    for (int i = 0; i < 2; i++) HIP_CHECK(hipEventCreateWithFlags(&h->ev_fix[i], hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&h->ev_spec_go, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&h->ev_spec_done, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(h->ev_spec_done, h->bg_stream));  // (a search waits for the previous search's heap: nothing to wait for yet)
+}
+
+// The engine's streams are laid out for 8 hardware queues per priority class (ROCm's default is 4): with 4, the scan and background
+// streams of four searches in flight share queues two by two, and a scan queued behind another context's 1.5 ms heap waits for it.
+// Read by the HIP runtime when it starts: set here, when the library is loaded, unless the process has chosen a value itself.
+struct HwQueues {
+    HwQueues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+} g_hw_queues;
+
 // Side streams of a context, created one by one on first use.  The runtime attaches a new stream to the hardware queue with the
 // fewest streams (GPU_MAX_HW_QUEUES of them): a context that creates its four side streams together puts stream i on queue i, so
 // the stream the byte-code scans use -- aux[3] -- of EVERY context lands on the same hardware queue, where the scans of four
 // searches in flight wait for each other (the dense launch's event span swung between 1.1 and 5 ms from run to run).  Created on
 // demand, a byte-code context has one side stream, and four contexts spread over four queues.
 void ensure_aux(amd_ivf* h, int lo, int hi) {
-    if (!h->ev_fork) {
-        HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-        for (int i = 0; i < 4; i++) HIP_CHECK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
-    }
+    ensure_context_streams(h);
     for (int i = lo; i <= hi; i++)
         if (!h->aux[i]) HIP_CHECK(hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
 }
@@ -2395,11 +2432,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         if (!fix_due) return;
         fix_due = false;
         const size_t round = fix_due_round;
-        if (!h->fix_stream) {
-            h->fix_stream = make_background_stream();
-            HIP_CHECK(hipEventCreateWithFlags(&h->ev_sel, hipEventDisableTiming));
-            for (int i = 0; i < 2; i++) HIP_CHECK(hipEventCreateWithFlags(&h->ev_fix[i], hipEventDisableTiming));
-        }
+        ensure_context_streams(h);
         TieFixArgs ta = tie_fix_args((uint32_t)round, 0);
         HIP_CHECK(hipEventRecord(h->ev_sel, s));
         HIP_CHECK(hipStreamWaitEvent(h->fix_stream, h->ev_sel, 0));
@@ -2770,6 +2803,7 @@ int amd_ivf_create(int d, size_t nlist, int metric, int device, amd_ivf_t** out)
     h->device = device;
     HIP_CHECK(hipSetDevice(device));
     h->stream = make_main_stream();
+    ensure_context_streams(h.get());
     h->h_codes.resize(nlist);
     h->h_ids.resize(nlist);
     h->h_list_off.assign(nlist + 1, 0);
@@ -2800,6 +2834,7 @@ int amd_ivf_clone(amd_ivf_t* h, amd_ivf_t** out) {
     c->allow_fused = owner->allow_fused;
     c->allow_bytes = owner->allow_bytes;
     c->stream = make_main_stream();
+    ensure_context_streams(c.get());
     owner->live_contexts.fetch_add(1);
     *out = c.release();
     API_END
@@ -3481,13 +3516,8 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
             L->w_spec_count.ensure(32);  // count | rankings the patch changed | rows the heap re-ranked (u64; not reported: most are never used) | scratch cursor (u64)
             L->w_spec_slot.ensure(n * 4);
             L->w_spec_query.ensure((size_t)SPEC_CAP * 4);
-            if (!L->spec_stream) {
-                L->spec_stream = make_background_stream();
-                HIP_CHECK(hipEventCreateWithFlags(&L->ev_spec_go, hipEventDisableTiming));
-                HIP_CHECK(hipEventCreateWithFlags(&L->ev_spec_done, hipEventDisableTiming));
-            } else {
-                HIP_CHECK(hipStreamWaitEvent(L->stream, L->ev_spec_done, 0));  // (the previous search's slots are no longer being written)
-            }
+            ensure_context_streams(L);
+            HIP_CHECK(hipStreamWaitEvent(L->stream, L->ev_spec_done, 0));  // (the previous search's slots are no longer being written)
             HIP_CHECK(hipMemsetAsync(L->w_spec_count.p, 0, 32, L->stream));
             // (slots go to the nearest runs first: a query that stops in round 0 -- most do -- reads 2 x 12 + 14 entries)
             for (uint32_t lo = 0, hi = SPEC_NEAR; lo < SPEC_WINDOW; lo = hi, hi = SPEC_WINDOW)

@@ -1113,9 +1113,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
 // After every probe the stop rule is evaluated exactly as IndexIVF.cpp:551-638 does (tune mode); a probe that admitted
 // nothing costs a handful of scalar instructions.
 __host__ __device__ inline size_t select_wave_bytes(int k, bool tune, bool dense, uint32_t trace_cap) {
+    // srt | dwin | trace x,z | cur_num_par terms.  Dense rounds rank the first k candidates of a search at once (keys, value bits,
+    // positions | sorted keys, positions: 5 x 128 words): that happens before the first probe's stop rule loads a trace, so in tune
+    // mode the two share their room (a workgroup's LDS: 28 -> 18 KB at k = 100, which is what lets a 49 KB workgroup -- the heap
+    // order of coarse ties -- start on a CU that holds five of these)
+    const size_t fill = 5 * 128 * 4;
     size_t b = 0;
-    if (tune) b += (size_t)k * 4 + 16 * 4 + (size_t)trace_cap * 8 + CURNUM_PAR_MAXK * 15 * 4 + 8;  // srt | dwin | trace x,z | cur_num_par terms
-    if (dense) b += 5 * 128 * 4;  // the first k candidates of a search, ranked at once: keys, value bits, positions | sorted keys, positions
+    if (tune) {
+        const size_t trace = (size_t)trace_cap * 8;
+        b += (size_t)k * 4 + 16 * 4 + (dense && trace < fill ? fill : trace) + CURNUM_PAR_MAXK * 15 * 4 + 8;
+    } else if (dense) {
+        b += fill;
+    }
     return (b + 15) & ~(size_t)15;
 }
 
@@ -1244,8 +1253,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 
     float* srt = reinterpret_cast<float*>(wbase);       // tune: the k values best first, as the rule reads them
     float* dwin = srt + k;                              // 16 boundary distances of the current stage
     float* trc = dwin + 16;                             // x | z of the cached trace, trace_cap each
-    float* terms = trc + 2 * a.trace_cap;               // cur_num_par scratch
-    uint32_t* fill = reinterpret_cast<uint32_t*>(wbase + select_wave_bytes(k, TUNE, false, a.trace_cap));  // dense rounds: 5 x 128 words
+    float* terms = trc + (!MASKED && 2 * a.trace_cap < 640u ? 640u : 2 * a.trace_cap);  // cur_num_par scratch (behind the trace's room: select_wave_bytes)
+    uint32_t* fill = reinterpret_cast<uint32_t*>(TUNE ? reinterpret_cast<unsigned char*>(trc) : wbase);  // dense rounds: 5 x 128 words (tune: in the trace's room)
     const float* gdtb = TUNE ? a.dtb + (size_t)qi * max_num : nullptr;
 
     // ---- state

@@ -317,7 +317,7 @@ def main():
     ap.add_argument("--kmeans", choices=["engine", "torch"], default="engine",
                     help="coarse centroids: the engine's Clustering::train restatement (amd_ivf_kmeans, the reference's IVF "
                          "training: 25 iterations, 256 points per centroid) or a 4-step torch Lloyd")
-    ap.add_argument("--stagger-ms", type=float, default=0.4,
+    ap.add_argument("--stagger-ms", type=float, default=0.0,
                     help="context j issues its first step j x this many ms after context 0 (inside the timed region): out of phase, the "
                          "scan of one batch runs under the selection of another; started together they tend to stay in step")
     ap.add_argument("--pinned-out", type=int, default=1, help="1: result buffers in page-locked host memory, 0: pageable")
@@ -331,7 +331,7 @@ def main():
     ap.add_argument("--runner", choices=["async", "threads"], default="threads",
                     help="how --in-flight batches are kept in flight: async = ONE caller thread through amd_ivf_submit_adaptive / "
                          "amd_ivf_wait (the engine's internal contexts), threads = one host thread + amd_ivf_clone context per batch")
-    ap.add_argument("--in-flight", type=int, default=4,
+    ap.add_argument("--in-flight", type=int, default=6,
                     help="batches kept in flight per GPU, each from its own host thread on its own search context "
                          "(amd_ivf_clone); 1 = one batch at a time")
     args = ap.parse_args()
@@ -354,9 +354,10 @@ def main():
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         log(f"--gpus {args.gpus} without a launcher: starting {' '.join(cmd[1:8])} ...")
         sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
-    # hardware queues the HIP runtime maps its streams onto (ROCm's default, pinned here because the figure is sensitive to it:
-    # with 8 queues four batches in flight lose 8 % and six collapse, profiles/r01_in_flight_sweep.txt); must precede HIP start-up
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
+    # hardware queues the HIP runtime maps its streams onto: the engine lays its streams out for 8 per priority class and asks for
+    # them itself when its library is loaded (auncel_amd/csrc/ivf_engine.hip: HwQueues); said here as well because it has to be in
+    # the environment before HIP starts, whichever of torch and the engine touches the GPU first
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     import torch
     import torch.distributed as dist
