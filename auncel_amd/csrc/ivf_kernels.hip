@@ -2044,7 +2044,7 @@ template <bool IsMax> __device__ inline void lds_heap_push(HeapEnt* h, uint32_t 
 // still change the entry the pop is about to take).  2.4 ticks per pop instead of one walk of m levels (measured, nlist
 // 4096: 2.8 ms a row against 12.4 ms for the plain walk below; the filling takes 0.06 ms of that).
 // (tests/heap_tie_model.py is the model both halves were checked with, entry for entry, against the literal heap.)
-template <bool IsMax> __device__ inline void floyd_fill_pow2(HeapEnt* a, const float* row, uint32_t n, int lane) {
+template <bool IsMax> __device__ inline void floyd_fill_pow2(HeapEnt* a, const float* __restrict__ row, uint32_t n, int lane) {
     const int m = 31 - __builtin_clz(n);
     const uint32_t F = n >> 1;
     for (int dp = m - 1; dp >= 1; dp--) {
@@ -2072,7 +2072,7 @@ template <bool IsMax> __device__ inline void floyd_fill_pow2(HeapEnt* a, const f
 
 // One step of a walk: the hole takes the better child (the right one between equals) unless the entry the walk carries beats it, in
 // which case that entry lands in the hole and the walk ends.  A lane without a walk steps on slot 0 (unused) instead of being masked
-// off, and an address past the heap is read but not used: nothing is clamped.
+// off; a hole without children reads the heap's last pair (not used).
 struct HeapWalk {
     uint32_t hole, s, lvl, Lid;  // slot the walk stands on (0: none), heap size of its pop, depth of hole, id it carries
     float Lv;
@@ -2094,7 +2094,7 @@ template <bool IsMax> __device__ __forceinline__ void heap_walk_step(HeapEnt* a,
 // round trip: 1490 cycles per pop, now 870; scratch/ubench/heap_sort.hip).  A pop can start at most every other tick, so the tick
 // behind a start is a plain step of the walks in flight (children -> two compares -> store) and only the other ticks carry the
 // start logic; walks sit on a ring of lanes by pop number (at most one per two levels is alive).
-template <bool IsMax> __device__ inline void heapsort_pipelined(HeapEnt* a, uint32_t n, uint32_t* out_id, int lane) {
+template <bool IsMax> __device__ inline void heapsort_pipelined(HeapEnt* a, uint32_t n, int64_t* out_keys, uint32_t nout, int lane) {
     HeapWalk w{0u, 0xffffffffu, 0u, 0u, 0.f};
     uint32_t t = 0;  // pops started
     const uint4* a4 = reinterpret_cast<const uint4*>(a);
@@ -2102,7 +2102,8 @@ template <bool IsMax> __device__ inline void heapsort_pipelined(HeapEnt* a, uint
     while (true) {
         // ---- a tick that may start pop t: it takes the entry of slot n - t and walks it down from the root
         const uint32_t sc = n - t;
-        const uint4 ch_own = a4[w.hole];
+        const uint32_t lim = n >> 1;  // (a has n + 2 slots: pair n / 2 is its last)
+        const uint4 ch_own = a4[w.hole < lim ? w.hole : lim];
         const unsigned long long act = __ballot(w.hole != 0);
         if (t == n) {
             if (!act) break;
@@ -2120,7 +2121,7 @@ template <bool IsMax> __device__ inline void heapsort_pipelined(HeapEnt* a, uint
             const uint4 r01 = a4[0];  // entry 1: the root
             ch = a4[1];               // its children
             const uint2 ls = a2[sc];
-            out_id[sc - 1] = r01.w;   // heap_reorder: the top goes behind the shrinking heap
+            if (sc - 1 < nout) out_keys[sc - 1] = (int64_t)r01.w;  // heap_reorder: the top goes behind the shrinking heap (the places that are read)
             w.hole = 1u;
             w.s = sc;
             w.lvl = 0u;
@@ -2132,7 +2133,7 @@ template <bool IsMax> __device__ inline void heapsort_pipelined(HeapEnt* a, uint
         if (create) {
             t++;
             // ---- the tick behind a start: a plain step
-            const uint4 c2 = a4[w.hole];
+            const uint4 c2 = a4[w.hole < lim ? w.hole : lim];
             heap_walk_step<IsMax>(a, w, c2);
             wave_sync();
         }
@@ -2147,7 +2148,10 @@ __global__ __launch_bounds__(64) void heap_tie_order_kernel(const float* dis, ui
     if (dev_nq && blockIdx.x >= *dev_nq) return;  // (rows set aside on the device: launch_spec_collect)
     __builtin_amdgcn_s_setprio(3);  // (one wave's dependent chain of a few thousand steps, beside other searches' kernels)
     HeapEnt* h = reinterpret_cast<HeapEnt*>(smem);                           // nprobe + 2 entries, [0] unused
-    float* row = reinterpret_cast<float*>(smem + (size_t)(nprobe + 2) * 8);  // nlist
+    // (the distance row stays in global memory -- every entry is read once or twice -- and the sorted ids go straight to the ranking:
+    // 33 KB of LDS a row instead of 49, with half a thousand rows of four searches resident at a time)
+    const bool fast = nprobe == nlist && (nlist & (nlist - 1)) == 0 && nlist >= 64;
+    float* row = fast ? nullptr : reinterpret_cast<float*>(smem + (size_t)(nprobe + 2) * 8);  // nlist (the literal heap only)
     const uint32_t q = blockIdx.x, lane = threadIdx.x;
     const float* grow = dis + (size_t)q * nlist;
     float* od = out_dis + (size_t)q * nprobe;
@@ -2170,19 +2174,20 @@ __global__ __launch_bounds__(64) void heap_tie_order_kernel(const float* dis, ui
     bool enters = true;  // every centroid beats the initial entries (utils.cpp:478: "if (disij < simi[0])")
     for (uint32_t j = lane; j < nlist; j += 64) {
         const float v = grow[j];
-        row[j] = v;
+        if (row) row[j] = v;
         enters &= hcmp<IsMax>(neutral, v);
     }
     for (uint32_t i = lane; i < nprobe + 2; i += 64) h[i] = HeapEnt{neutral, 0xffffffffu};  // heap_heapify, no input
     wave_sync();
     if (lane == 0) atomicAdd(nrows, 1ull);
-    if (nprobe == nlist && (nlist & (nlist - 1)) == 0 && nlist >= 64 && !__ballot(!enters)) {
-        floyd_fill_pow2<IsMax>(h, row, nlist, (int)lane);
-        uint32_t* out_id = reinterpret_cast<uint32_t*>(row);  // the distances are not needed any more
-        heapsort_pipelined<IsMax>(h, nlist, out_id, (int)lane);
+    if (fast && !__ballot(!enters)) {
+        floyd_fill_pow2<IsMax>(h, grow, nlist, (int)lane);
         // same distances in the same places, only centroid numbers inside runs of equal distances move
-        for (uint32_t i = lane; i < nout && i < nprobe; i += 64) ok[i] = (int64_t)out_id[i];
+        heapsort_pipelined<IsMax>(h, nlist, ok, nout < nprobe ? nout : nprobe, (int)lane);
         return;
+    }
+    if (!row) {  // (a row that holds a value the empty heap would not admit: the literal heap, from the row in global memory)
+        row = const_cast<float*>(grow);
     }
     uint32_t nvalid = 0;
     if (lane == 0) {
@@ -2370,7 +2375,10 @@ void launch_gather_rows(const float* x, const uint32_t* idx, uint32_t m, uint32_
     if (m) LAUNCH(gather_rows_kernel, dim3(m), dim3(64), 0, s, x, idx, dpad, out);
 }
 
-size_t heap_tie_order_lds(uint32_t nlist, uint32_t nprobe) { return (size_t)(nprobe + 2) * 8 + (size_t)nlist * 4; }
+size_t heap_tie_order_lds(uint32_t nlist, uint32_t nprobe) {
+    const bool fast = nprobe == nlist && (nlist & (nlist - 1)) == 0 && nlist >= 64;
+    return (size_t)(nprobe + 2) * 8 + (fast ? 0 : (size_t)nlist * 4);
+}
 
 // nout: leading entries of each ranking the caller reads (<= nprobe); rows without a run of equal distances there are left
 // as they are.  Returns false (nothing launched) when heap and row do not fit one workgroup's LDS.

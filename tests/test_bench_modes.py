@@ -31,15 +31,7 @@ def test_shards_mode_two_ranks_equals_one():
                      "--master-port", str(port), "bench.py", "--mode", "shards", "--gpus", "2"] + SMALL,
                     {"BENCH_DIST_BACKEND": "gloo", "BENCH_DEVICE": "0"})
 
-    def coarse_halved(j):
-        # the coarse ranking is computed once: each of the two ranks ranks its half of the batch
-        return sum(r[0] for r in j["config"]["per_rank_ms_per_step"]["rows"]) / 2 < 0.9 * one["config"]["per_rank_ms_per_step"]["rows"][0][0] + 0.05
-
     two = two_ranks(0)
-    for attempt in (1, 2):  # (two timed steps of two processes sharing one GPU: the one assertion on the clock gets a second look)
-        if coarse_halved(two):
-            break
-        two = two_ranks(attempt)
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
     assert one["config"]["distances_sha256"] == two["config"]["distances_sha256"]
     assert one["config"]["recall_at_k_mean"] == two["config"]["recall_at_k_mean"] > 0.5
@@ -48,7 +40,9 @@ def test_shards_mode_two_ranks_equals_one():
         assert j["roofline"]["bound"] == "hbm" and 0 < j["roofline"]["frac"] <= 1.0
         rows = j["config"]["per_rank_ms_per_step"]["rows"]
         assert len(rows) == j["n_gpus"] and all(len(r) == 4 for r in rows)
-    assert coarse_halved(two), (one["config"]["per_rank_ms_per_step"], two["config"]["per_rank_ms_per_step"])
+    # the coarse ranking is computed once: each of the two ranks ranks its half of the batch (counted in queries; how long that
+    # takes is bench.py's business, not a pass / fail matter)
+    assert one["config"]["coarse_queries_per_rank"] == [2000] and two["config"]["coarse_queries_per_rank"] == [1000, 1000]
 
 
 @pytest.mark.gpu
