@@ -24,7 +24,7 @@ SYMBOLS = [
     "amd_ivf_set_tuner", "amd_ivf_search_adaptive", "amd_ivf_search_adaptive_x", "amd_ivf_search_adaptive_pre", "amd_ivf_search_timed", "amd_ivf_search_timed_x",
     "amd_ivf_train_samples",
     "amd_ivf_train_samples_x", "amd_ivf_train_samples_pre", "amd_ivf_trace_sb", "amd_ivf_arcos_table", "amd_ivf_merge_tables",
-    "amd_ivf_last_timing", "amd_ivf_last_timing_detail", "amd_ivf_last_scan_min_bytes", "amd_ivf_coarse_tie_rows", "amd_ivf_last_tie_fixed", "amd_ivf_last_filter", "amd_ivf_last_direct_out", "amd_ivf_last_coarse_pick", "amd_ivf_set_async_depth", "amd_ivf_submit_adaptive", "amd_ivf_submit_search_resident", "amd_ivf_wait", "amd_ivf_last_tie_redone", "amd_ivf_last_tie_patched", "amd_ivf_last_round_hints", "amd_ivf_set_byte_codes", "amd_ivf_set_option", "amd_ivf_get_option",
+    "amd_ivf_last_timing", "amd_ivf_last_timing_detail", "amd_ivf_last_scan_min_bytes", "amd_ivf_coarse_tie_rows", "amd_ivf_last_tie_fixed", "amd_ivf_last_filter", "amd_ivf_last_direct_out", "amd_ivf_last_coarse_pick", "amd_ivf_set_async_depth", "amd_ivf_submit_adaptive", "amd_ivf_submit_search_resident", "amd_ivf_wait", "amd_ivf_last_tie_redone", "amd_ivf_last_tie_patched", "amd_ivf_self_check", "amd_ivf_last_round_hints", "amd_ivf_set_byte_codes", "amd_ivf_set_option", "amd_ivf_get_option",
     "amd_ivf_kmeans",
     "amd_ivf_range_search_preassigned", "amd_ivf_range_search", "amd_ivf_range_results",
     "amd_ivf_scan_arith",
@@ -78,6 +78,13 @@ def device_count():
     n = C.c_int(0)
     _chk(lib().amd_ivf_device_count(C.byref(n)))
     return n.value
+
+
+def self_check(device=0):
+    """include/auncel_amd.h: amd_ivf_self_check -> dict(adds, counted, wrong, xcd_mask)"""
+    v = (C.c_uint64 * 4)()
+    _chk(lib().amd_ivf_self_check(int(device), v))
+    return {"adds": int(v[0]), "counted": int(v[1]), "wrong": int(v[2]), "xcd_mask": int(v[3])}
 
 
 def kmeans(metric, x, k, niter=25, seed=1234, max_points_per_centroid=256, spherical=False, int_centroids=False, coarse_mode=0,

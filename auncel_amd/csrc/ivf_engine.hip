@@ -98,13 +98,16 @@ const OptSpec OPT_TABLE[N_OPT] = {
     {"row_lists", "AUNCEL_AMD_ROW_LISTS", nullptr},
 };
 struct Options {
-    double v[N_OPT];
+    // (atomic: amd_ivf_set_option on the owner may run while search contexts cloned from it are searching; a search reads the
+    // options that shape its launches ONCE -- run_rounds_device's snapshot -- so a change takes effect with the next search)
+    std::atomic<double> v[N_OPT];
     Options() {
-        for (double& x : v) x = OPT_UNSET;
+        for (auto& x : v) x.store(OPT_UNSET, std::memory_order_relaxed);
     }
     // the value set through the ABI, else the environment's (read per call: the tests flip it inside one process), else `dflt`
     double get(OptId id, double dflt) const {
-        if (v[id] != OPT_UNSET) return v[id];
+        const double set = v[id].load(std::memory_order_relaxed);
+        if (set != OPT_UNSET) return set;
         const char* e = getenv(OPT_TABLE[id].env);
         if (!e || !*e) return dflt;
         if (const char* w = OPT_TABLE[id].words) {
@@ -120,7 +123,9 @@ struct Options {
         }
         return atof(e);
     }
-    bool is_set(OptId id) const { return v[id] != OPT_UNSET || (getenv(OPT_TABLE[id].env) && *getenv(OPT_TABLE[id].env)); }
+    bool is_set(OptId id) const {
+        return v[id].load(std::memory_order_relaxed) != OPT_UNSET || (getenv(OPT_TABLE[id].env) && *getenv(OPT_TABLE[id].env));
+    }
 };
 
 // Range of a set of fp32 values when all of them are integers (else ok = false).  When every operand of a
@@ -560,15 +565,21 @@ hipStream_t make_background_stream() {
     return s;
 }
 
-// The streams of a search context, all of them when the context is made and always in the same order: main (made by the caller),
-// scan, background.  The runtime hands a new stream the least used hardware queue of its priority class (GPU_MAX_HW_QUEUES per
-// class, the first of equals), so which streams share a queue follows from the order in which contexts are created and from
-// nothing else -- created on first use (round 4) it followed from which search happened to need which stream first, and the
-// figures of a leg moved by a factor of two with the legs run before it.  With the 8 queues the engine asks for (below) the scan
-// and background streams of four contexts have a queue each; from the fifth context on like shares with like (scan with scan).
+// The streams of a search context, all of them when the context is made: main (made by the caller; high priority), scan (low),
+// background (normal).  The runtime keeps GPU_MAX_HW_QUEUES hardware queues per priority class and hands a new stream the least
+// used one of its class: with the three kinds of stream in three classes and the 8 queues per class the engine asks for (below),
+// every stream of up to eight contexts has a hardware queue to itself, whatever was created before -- no kernel ever waits behind
+// another stream's kernel in a shared queue.  (Round 4 created side streams on first use, all in the normal class: which stream
+// shared a queue with which followed from which search happened to need what first, a scan queued behind another context's
+// 1.5 ms heap waited for it, and the figures of a bench leg moved by a factor of two with the legs run before it.)  The classes
+// are also the order the work should be dispatched in when the chip is full: the latency-bound chain (planning, selection) first,
+// the background kernels the chain will wait for next, the bandwidth-bound scans -- grids of thousands of workgroups -- with
+// whatever is left.  Measured (profiles/r05_streams.txt): the same throughput as scans in the normal class, without the
+// dependence on creation order.
 void ensure_context_streams(amd_ivf* h) {
     if (h->bg_stream) return;
-    static const char* scan_prio = getenv("AUNCEL_AMD_SCAN_PRIO");  // (experiment: "low" = the scan stream at the lowest priority)
+    static const char* scan_prio_env = getenv("AUNCEL_AMD_SCAN_PRIO");  // ("normal": the scan stream in the background streams' class)
+    static const char* scan_prio = scan_prio_env ? scan_prio_env : "low";
     if (!h->ev_fork) {
         HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         for (int i = 0; i < 4; i++) HIP_CHECK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
@@ -1349,6 +1360,31 @@ static void throw_device_error(uint32_t err) {
     if (err) throw EngineError("device-side error " + std::to_string(err));
 }
 
+// Per-handle state of a call that must not outlive it when the call is left by an exception: the phase timers' switch, scatter
+// entries still pending in the host-to-device staging (they name device buffers the next call may have reallocated), the staging
+// cursor, epilogues queued behind a synchronisation that will not happen, and -- results going straight into the caller's
+// page-locked buffers -- kernels that may still be writing there (the selection on the main stream, the tie replay on the
+// background stream): the caller gets its buffers back with the error only once they are quiet.
+struct CallScope {
+    amd_ivf* h;
+    int entered;
+    explicit CallScope(amd_ivf* hh) : h(hh), entered(std::uncaught_exceptions()) {}
+    ~CallScope() {
+        h->timer.off = false;
+        if (std::uncaught_exceptions() > entered) {
+            h->h2d_pending.n = 0;
+            h->stage_used = 0;
+            h->small.clear();
+            h->small_used = 0;
+            h->after_flush.clear();
+            if (h->last_direct_out) {
+                (void)hipStreamSynchronize(h->stream);
+                if (h->bg_stream) (void)hipStreamSynchronize(h->bg_stream);
+            }
+        }
+    }
+};
+
 // copies queued with d2h_small name caller memory (often stack variables): if the sequence is left by an exception before
 // its sync_and_flush, they must not stay pending for the next call's flush
 struct SmallCopies {
@@ -1779,6 +1815,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
 // nprobe 32: 1.1 vs 1.3).
 void search_fixed_device(amd_ivf* h, const float* d_x, size_t n, size_t k, size_t nprobe, const int64_t* d_keys, float* D,
                          int64_t* I, int store_pairs, size_t max_codes, const IntRange& qr) {
+    CallScope call_scope(h);
     upload_lists(h);
     init_state(h, n, k, false);
     RoundSpec base;
@@ -2128,12 +2165,14 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         explicit Active(std::atomic<int>& cc) : c(cc), before(cc.fetch_add(1)) {}
         ~Active() { c.fetch_sub(1); }
     } active(I->active_searches);
+    // the form of the byte-code scan shapes the planner's items (queries per item) AND picks the kernel that walks them: read once
+    const int scan_pipelined = (int)opt(h, OPT_SCAN_PIPELINED, 7);
     auto plan_round = [&](size_t round_len) {
         pa.round_len = (uint32_t)round_len;
         pa.dense_round = !(base.range || (planned_rounds > 0 && !no_thr));
         if (base.bytes) {
             pa.mfma_chunk = pa.dense_round || base.range ? mfma_chunk() : mfma_chunk_thr();
-            pa.mfma_qblock = pa.dense_round ? MFMA_QBLOCK : mfma_thr_qblock(h->d, (int)opt(h, OPT_SCAN_PIPELINED, 7), base.range);
+            pa.mfma_qblock = pa.dense_round ? MFMA_QBLOCK : mfma_thr_qblock(h->d, scan_pipelined, base.range);
         }
         if (filter_ok) {  // threshold rounds of an fp32 search: items in the matrix-core form (a chunk x a block of 32 queries)
             const bool mf = !pa.dense_round;
@@ -2176,7 +2215,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             ma.nitems = counts ? counts[CNT_QG8] : 0;
             ma.dev_nitems = counts ? nullptr : dcnt + CNT_QG8;
             ma.hint_nitems = hint_of(round, CNT_QG8);
-            ma.pipelined = (int)opt(h, OPT_SCAN_PIPELINED, 7);
+            ma.pipelined = scan_pipelined;
             static const int scan_debug = getenv("AUNCEL_AMD_SCAN_DEBUG") ? atoi(getenv("AUNCEL_AMD_SCAN_DEBUG")) : 0;
             ma.debug = scan_debug;
             if (thr_mode) {
@@ -2788,6 +2827,47 @@ int amd_ivf_device_count(int* count) {
     API_END
 }
 
+// The per-XCD counters under contention (ivf_plan.hip: xcd_check_kernel).  out[0] adds made, out[1] sum of the counters, out[2]
+// (XCD, address) pairs whose returned values are not exactly 0 .. count - 1, out[3] mask of the XCD numbers seen.
+int amd_ivf_self_check(int device, uint64_t out[4]) {
+    API_BEGIN
+    HIP_CHECK(hipSetDevice(device));
+    const uint32_t n = 1u << 20, nkeys = 1024;
+    DevBuf c, sl, xo;
+    c.ensure((size_t)8 * nkeys * 4);
+    sl.ensure((size_t)n * 4);
+    xo.ensure((size_t)n * 4);
+    HIP_CHECK(hipMemset(c.p, 0, (size_t)8 * nkeys * 4));
+    launch_xcd_check(c.as<uint32_t>(), nkeys, sl.as<uint32_t>(), xo.as<uint32_t>(), n, nullptr);
+    std::vector<uint32_t> hs(n), hx(n), hc((size_t)8 * nkeys);
+    HIP_CHECK(hipMemcpy(hs.data(), sl.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(hx.data(), xo.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(hc.data(), c.p, hc.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<std::vector<uint32_t>> got((size_t)8 * nkeys);
+    uint64_t mask = 0, bad = 0, total = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        mask |= 1ull << hx[i];
+        if (hx[i] >= 8) {
+            bad++;
+            continue;
+        }
+        got[(size_t)hx[i] * nkeys + (i * 2654435761u) % nkeys].push_back(hs[i]);
+    }
+    for (size_t k = 0; k < got.size(); k++) {
+        auto& v = got[k];
+        std::sort(v.begin(), v.end());
+        total += hc[k];
+        bool ok = v.size() == hc[k];
+        for (size_t j = 0; ok && j < v.size(); j++) ok = v[j] == j;
+        bad += ok ? 0 : 1;
+    }
+    out[0] = n;
+    out[1] = total;
+    out[2] = bad;
+    out[3] = mask;
+    API_END
+}
+
 int amd_ivf_create(int d, size_t nlist, int metric, int device, amd_ivf_t** out) {
     API_BEGIN
     if (d <= 0 || nlist == 0) throw EngineError("bad dimension / nlist");
@@ -2802,6 +2882,19 @@ int amd_ivf_create(int d, size_t nlist, int metric, int device, amd_ivf_t** out)
     h->metric = metric;
     h->device = device;
     HIP_CHECK(hipSetDevice(device));
+    {
+        // once per device and process: the per-XCD counters the searches end on (xcd_local_add) behave as assumed -- 8 XCDs at most,
+        // adds exact under contention -- or the engine refuses to run rather than end a search early
+        static std::mutex mu;
+        static std::map<int, bool> checked;
+        std::lock_guard<std::mutex> lock(mu);
+        if (!checked.count(device)) {
+            uint64_t r[4] = {0, 0, 0, 0};
+            if (amd_ivf_self_check(device, r) != 0) throw std::runtime_error(std::string("self-check of the per-XCD counters: ") + g_last_error);
+            checked[device] = r[1] == r[0] && r[2] == 0 && (r[3] >> 8) == 0;
+        }
+        if (!checked[device]) throw std::runtime_error("per-XCD counters are not exact on this device (amd_ivf_self_check): the engine's round planning relies on them");
+    }
     h->stream = make_main_stream();
     ensure_context_streams(h.get());
     h->h_codes.resize(nlist);
@@ -3671,6 +3764,7 @@ static void adaptive_core_once(amd_ivf_t* h, const float* d_x, size_t start, siz
                             const float* require_acc, const float* gt_D, int profile, int coarse_mode,
                             uint64_t* my_nprobe, float* t_recalls, float* D, int64_t* I, const IntRange& qr) {
     use_device(h);
+    CallScope call_scope(h);
     const amd_ivf* owner = ix(h);
     if (!owner->have_tuner || !owner->have_interdis)
         throw EngineError("Search tune start can't start without IVF_pro init and training");
@@ -4377,7 +4471,7 @@ static double opt_default(OptId id) {
 int amd_ivf_set_option(amd_ivf_t* h, const char* key, double value) {
     API_BEGIN
     if (!h) throw EngineError("null handle");
-    ix(h)->opt.v[opt_id(key)] = std::isnan(value) ? OPT_UNSET : value;
+    ix(h)->opt.v[opt_id(key)].store(std::isnan(value) ? OPT_UNSET : value, std::memory_order_relaxed);
     API_END
 }
 int amd_ivf_get_option(amd_ivf_t* h, const char* key, double* value) {

@@ -583,7 +583,10 @@ template <int METRIC, int NJ, bool HALF> __global__ __launch_bounds__(256) void 
 // instead of once per query block and the query rows once per chunk instead of once per wave: PMC on the GIST-like
 // configuration (d = 960, 71 queries per list): 16 GB fetched per pass over 3.84 GB of lists before.
 constexpr int FILTER_WIDE_QB = FILTER_WIDE_QUERIES / 32;
-constexpr int FILTER_WIDE_SP = 8;
+#ifndef AUNCEL_FILTER_WIDE_SP
+#define AUNCEL_FILTER_WIDE_SP 6  // (8 pieces: 376 registers where two waves per SIMD leave 256 -- 120 of them spilled, 6 GB of scratch traffic a pass)
+#endif
+constexpr int FILTER_WIDE_SP = AUNCEL_FILTER_WIDE_SP;
 constexpr size_t FILTER_WIDE_STAGE_FLOATS = (size_t)FILTER_WIDE_QB * FILTER_WIDE_SP * 256;
 constexpr size_t FILTER_WIDE_LDS = 2 * FILTER_WIDE_STAGE_FLOATS * sizeof(float) + 4 * FILTER_WIDE_QUERIES * sizeof(float);
 static_assert(FILTER_WIDE_VECTORS == 128, "one 32-vector block per wave of the workgroup");

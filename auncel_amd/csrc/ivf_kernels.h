@@ -482,6 +482,9 @@ struct PlanArgs {
     const float* run_dis;
 };
 
+// self-check of the per-XCD counters (ivf_plan.hip: xcd_check_kernel): counters [8][nkeys] zeroed by the caller
+void launch_xcd_check(uint32_t* counters, uint32_t nkeys, uint32_t* slot, uint32_t* xcc_of, uint32_t n, hipStream_t s);
+
 constexpr uint32_t PLAN_MAX_ROUNDS = 64;
 // Counters that every wave of a selection adds to (statistics, queries left unfinished) exist once per XCD and are added to with
 // workgroup-scope atomics, which that XCD's L2 serves: thousands of adds on ONE word from all eight XCDs are served one after the

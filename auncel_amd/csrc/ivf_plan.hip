@@ -735,4 +735,24 @@ void launch_plan(const PlanArgs& a, hipStream_t s) {
     LAUNCH(plan_scatter_items_kernel, dim3(gq + gl), dim3(256), 0, s, a, (uint32_t)gq);
 }
 
+
+// ---------------------------------------------------------------------------- self-check of the per-XCD counters
+// xcd_local_add (ivf_dev.h) adds at workgroup scope from different workgroups: that is exact only because every global atomic of an
+// XCD is executed in that XCD's L2 and the tables it is used on are private to an XCD (row xcc_id()).  Search termination depends
+// on it (the per-XCD `unfinished` counts), so the assumption is checked where it can fail: every thread adds 1 to counter
+// [xcc][key] under contention and keeps the value returned; per (xcc, key) the returned values must be exactly 0 .. count - 1.
+__global__ void xcd_check_kernel(uint32_t* counters, uint32_t nkeys, uint32_t* slot, uint32_t* xcc_of, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t key = (i * 2654435761u) % nkeys;
+    uint32_t x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    x &= 0xfu;  // (unmasked beyond 8: the check reports an XCD number the engine's 8-row tables do not have)
+    slot[i] = x < 8 ? xcd_local_add(&counters[x * nkeys + key], 1u) : 0u;
+    xcc_of[i] = x;
+}
+void launch_xcd_check(uint32_t* counters, uint32_t nkeys, uint32_t* slot, uint32_t* xcc_of, uint32_t n, hipStream_t s) {
+    LAUNCH(xcd_check_kernel, dim3((n + 255) / 256), dim3(256), 0, s, counters, nkeys, slot, xcc_of, n);
+}
+
 }  // namespace amdivf

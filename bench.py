@@ -205,7 +205,8 @@ def run_shards(args, torch, dist, capi, rank, world, local, dev, red_dev):
     h.set_centroids(cen)
     keep = mine >= 0
     h.add(xb[keep], xids=np.nonzero(keep)[0].astype(np.int64), precomputed_idx=mine[keep])
-    del xb
+    if not (world > 1 and rank == 0):
+        del xb  # (rank 0 of a sharded run searches the undivided index once at the end: the result the shards must reproduce)
     h.set_queries(xq)
     log(f"shards: data, k-means, assignment, {int(keep.sum())} of {args.nb} vectors on rank 0: {time.time() - t0:.1f}s")
 
@@ -253,6 +254,18 @@ def run_shards(args, torch, dist, capi, rank, world, local, dev, red_dev):
     else:
         per_rank = [mine]
     line = None
+    single_sha = None
+    if rank == 0 and world > 1:
+        # the same search over the undivided index, on this rank: what IndexShards over N sub-indexes must give (IndexShards.cpp:261-311)
+        _, ckf = h.coarse_resident(0, nq, args.nprobe, mode=0, want_dis=False)
+        hf = capi.Handle(d, nlist, capi.METRIC_L2, local)
+        hf.set_centroids(cen)
+        hf.add(xb, precomputed_idx=assign)
+        del xb
+        hf.set_queries(xq)
+        Df, _ = hf.search_resident_preassigned(0, nq, k, ckf)
+        single_sha = __import__("hashlib").sha256(np.ascontiguousarray(Df).tobytes()).hexdigest()
+        del hf
     if rank == 0:
         D, I = out
         rec = recall_dist(D[:nvalid], gtD, k)
@@ -275,6 +288,7 @@ def run_shards(args, torch, dist, capi, rank, world, local, dev, red_dev):
                        # distances of the merged result (sorted rows: identical for any number of shards, whatever the order
                        # the merge gives equal distances)
                        "distances_sha256": __import__("hashlib").sha256(np.ascontiguousarray(D).tobytes()).hexdigest(),
+                       "single_index_distances_sha256": single_sha,  # (N > 1: recomputed on rank 0 over the undivided index)
                        "shard_bytes_max_over_min": float(load.max() / max(load.min(), 1))},
             "roofline": {"bound": "hbm", "kernel": "scan_mfma_thr_kernel + scan_mfma_pair_kernel" if h.scan_arith() == 2 else "scan_tiles_kernel", "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0 if achieved else None, "traffic": None,
@@ -307,6 +321,11 @@ def run_shards(args, torch, dist, capi, rank, world, local, dev, red_dev):
                                     "gpu_matches_cpu_on_sample": bool(np.array_equal(oI, I[:S]) and np.array_equal(oD, D[:S]))}
     del h
     torch.cuda.empty_cache()
+    if line is not None and single_sha is not None and single_sha != line["config"]["distances_sha256"]:
+        log("SHARDS MISMATCH: the merged distances of", world, "shards differ from the single index's")
+        line["config"]["shards_equal_single_index"] = False
+    elif line is not None and single_sha is not None:
+        line["config"]["shards_equal_single_index"] = True
     return line
 
 
@@ -430,6 +449,8 @@ def main():
             print(json.dumps(line), flush=True)
         if world > 1:
             dist.destroy_process_group()
+        if rank == 0 and line["config"].get("shards_equal_single_index") is False:
+            sys.exit(3)  # (a sharded result that is not the single index's is not a measurement)
         return
 
     d, nlist, K, topk, ts, ses = args.d, args.nlist, args.maxtopk, args.topk, args.train, args.test
@@ -683,8 +704,12 @@ def main():
     run_steps(args.steps, acc)
     barrier()
     elapsed = time.perf_counter() - t0
+    per_rank_value = [ses * args.steps / elapsed]
     if world > 1:
         t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank_value = [ses * args.steps / float(v.item()) for v in allt]  # every rank's own clock over its own replica
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = {}
@@ -907,6 +932,7 @@ def main():
             "workload": workload,
             "query_slices": nsl, "queries_per_slice": ses,
             "ranks_seen": args.ranks_seen, "collective_backend": backend if world > 1 else None,
+            "per_rank_value": per_rank_value,  # (value = all ranks' queries / the slowest rank's time)
             # scan grids of the device-chained rounds are sized from the previous search's counts (+ 12 %); a round that needs
             # more runs on fewer workgroups than it would have been given (it is still complete: the workgroups stride)
             "round_hint": {"launches_sized_by_a_hint": int(acc.get("hinted_launches", 0)), "hint_too_small": int(acc.get("short_hints", 0))},
@@ -1168,6 +1194,8 @@ def main():
         sl = run_shards(sargs, torch, dist, capi, rank, world, local, dev, red_dev)
         if rank == 0 and sl is not None:
             out["shards"] = {"metric": sl["metric"], "value": sl["value"], "unit": sl["unit"], "ms_per_step": sl["ms_per_step"],
+                             "single_index_distances_sha256": sl["config"].get("single_index_distances_sha256"),
+                             "shards_equal_single_index": sl["config"].get("shards_equal_single_index"),
                              "scaling": sl["scaling"], "n_gpus": sl["n_gpus"], "nprobe": sargs.nprobe, "batch": sargs.test,
                              "distances_sha256": sl["config"]["distances_sha256"], "recall_at_k_mean": sl["config"]["recall_at_k_mean"],
                              "ranks_seen": sl["config"]["ranks_seen"],
@@ -1177,6 +1205,8 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if rank == 0 and world > 1 and out.get("shards", {}).get("shards_equal_single_index") is False:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

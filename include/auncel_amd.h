@@ -36,6 +36,14 @@ int amd_ivf_device_count(int* count);
 
 /* ---- index lifetime and contents ------------------------------------------------------ */
 
+/* Self-check of an assumption the engine's device-side bookkeeping rests on: counters that exist once per XCD (statistics,
+ * queries left unfinished by a round, pairs per list) are added to with workgroup-scope atomics, which the issuing XCD's L2
+ * executes -- exact as long as no other XCD touches the row, and an XCD has a number below 8.  Runs the adds under contention
+ * (2^20 returning adds on 8 x 1024 addresses).  out[0] adds made, out[1] sum of the counters (must equal out[0]), out[2] (XCD,
+ * address) pairs whose returned values are not exactly 0 .. count - 1 (must be 0), out[3] bit mask of the XCD numbers seen.
+ * amd_ivf_create runs it once per device and refuses to create an index where it fails.  (No reference counterpart: diagnostics.) */
+int amd_ivf_self_check(int device, uint64_t out[4]);
+
 /* IndexIVFFlat(quantizer, d, nlist, metric)  [IndexIVFFlat.cpp:28-33, IndexIVF.cpp:146-170] */
 int amd_ivf_create(int d, size_t nlist, int metric, int device, amd_ivf_t** out);
 int amd_ivf_destroy(amd_ivf_t* h);
@@ -353,7 +361,8 @@ int amd_ivf_set_byte_codes(amd_ivf_t* h, int enable);
  *   "pinned_io"       per-call inputs / outputs through one page-locked block (1) or copies (0)                 1
  *   "row_lists"       threshold rounds of calls of >= 256 queries: 1 the rows' marked candidates are compacted    unset (-1): 1 when no other
  *                     into short lists before the selection (compact_rows_kernel), 0 the selection walks the masks  search of the index is running
- * amd_ivf_set_option(h, key, NAN) returns the key to "unset". */
+ * amd_ivf_set_option(h, key, NAN) returns the key to "unset".  May be called while search contexts of the index are searching: a
+ * search reads what shapes its launches once, when it starts, so the change takes effect with the searches that start after it. */
 int amd_ivf_set_option(amd_ivf_t* h, const char* key, double value);
 int amd_ivf_get_option(amd_ivf_t* h, const char* key, double* value);
 

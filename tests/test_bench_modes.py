@@ -53,7 +53,9 @@ def test_gpus_n_without_a_launcher_starts_the_ranks_itself():
     one = _run([sys.executable, "bench.py", "--mode", "shards", "--gpus", "1"] + SMALL, {})
     two = _run([sys.executable, "bench.py", "--mode", "shards", "--gpus", "2"] + SMALL, {"BENCH_DIST_BACKEND": "gloo", "BENCH_DEVICE": "0"})
     assert two["n_gpus"] == 2 and two["config"]["ranks_seen"] == 2 and two["config"]["collective_backend"] == "gloo"
-    assert one["config"]["ranks_seen"] == 1
+    assert one["config"]["ranks_seen"] == 1 and one["config"]["single_index_distances_sha256"] is None
+    # rank 0 searched the undivided index as well: the shards' merged distances are that result (else the run exits non-zero)
+    assert two["config"]["shards_equal_single_index"] is True and two["config"]["single_index_distances_sha256"] == two["config"]["distances_sha256"]
     assert one["config"]["distances_sha256"] == two["config"]["distances_sha256"]
 
 
@@ -79,8 +81,10 @@ def test_default_mode_two_ranks_records_both_splits(tmp_path):
                 "--master-port", str(port), "bench.py", "--gpus", "2"] + small, {"BENCH_DIST_BACKEND": "gloo", "BENCH_DEVICE": "0"})
     assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["data"] == "synthetic"
     assert two["config"]["query_slices"] == 4 and "round_hint" in two["config"]
+    assert len(two["config"]["per_rank_value"]) == 2 and two["config"]["ranks_seen"] == 2 and two["config"]["collective_backend"] == "gloo"
     sh = two["shards"]
     assert sh["n_gpus"] == 2 and sh["scaling"] == "strong" and sh["value"] > 0 and len(sh["distances_sha256"]) == 64
+    assert sh["shards_equal_single_index"] is True
     assert len(sh["per_rank_ms_per_step"]["rows"]) == 2 and sh["roofline"]["bound"] == "hbm"
 
 

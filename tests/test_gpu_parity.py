@@ -743,3 +743,11 @@ def test_options_through_the_abi(capi, monkeypatch):
         h.set_option("select", sel)
         D, I = h.search_preassigned(case["xq"], k, gold["coarse_keys_sse"], gold["coarse_dis_sse"])
         assert np.array_equal(I, gold[f"I_k{k}"]) and np.array_equal(bits(D), bits(gold[f"D_k{k}"]))
+
+
+def test_per_xcd_counters_are_exact(capi):
+    """the workgroup-scope adds on per-XCD rows that the round planning, the statistics and the end of a search rest on
+    (ivf_dev.h: xcd_local_add): under contention every add is counted and every returned value is handed out exactly once"""
+    r = capi.self_check(0)
+    assert r["counted"] == r["adds"] == 1 << 20 and r["wrong"] == 0
+    assert 0 < r["xcd_mask"] < 256  # XCD numbers 0..7 only: the tables have eight rows

@@ -203,3 +203,49 @@ def test_gist_like_d960_2000_queries(setup):
     oD, oI, _ = orc.search_preassigned(lists, xq[:S], k, ck, cd, nthreads=8)
     assert np.array_equal(I[:S], oI) and np.array_equal(D[:S].view(np.uint32), oD.view(np.uint32))
     assert np.all(np.diff(D, axis=1) >= 0)
+
+
+def _full_size_case(setup, kind, nb, nq, metric, k, nprobe, nlist=4096, S=64):
+    """a BASELINE configuration at its own index size (IVF4096, >= 1M vectors, a batch of thousands of queries: the regime of the
+    matrix-core coarse ranking, the fp16 filter passes and the large-call planner), 64 sampled queries against the pinned oracle"""
+    import os
+    import sys
+    import torch
+    capi, orc = setup["capi"], setup["orc"]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    import bench_configs
+    dev = torch.device("cuda", 0)
+    xb_t, xq_t = bench_configs.gen(torch, dev, kind, nb, nq)
+    d = xb_t.shape[1]
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    cen = xb_t[torch.randperm(nb, generator=g, device=dev)[:nlist]].cpu().numpy().copy()  # (distinct rows of the data as centroids)
+    xb, xq = xb_t.cpu().numpy(), xq_t.cpu().numpy()
+    del xb_t, xq_t
+    torch.cuda.empty_cache()
+    h = capi.Handle(d, nlist, metric, 0)
+    h.set_centroids(cen)
+    h.add(xb)
+    del xb
+    h.set_queries(xq)
+    D, I = h.search_resident(0, nq, k, nprobe)
+    assert h.scan_arith() != 2  # float data: the fp32 lists (reference order) + the filter's copies
+    lists = _oracle_lists(orc, h, metric, cen, nlist, d)
+    pick = np.linspace(0, nq - 1, S).astype(np.int64)  # spread over the batch: first and last query blocks included
+    cd, ck = orc.knn(metric, xq[pick], cen, nprobe, nthreads=8)
+    oD, oI, _ = orc.search_preassigned(lists, xq[pick], k, ck, cd, nthreads=8)
+    assert np.array_equal(I[pick], oI) and np.array_equal(D[pick].view(np.uint32), oD.view(np.uint32))
+    srt = np.diff(D, axis=1)
+    assert np.all(srt <= 0) if metric == 0 else np.all(srt >= 0)
+    h.close()
+
+
+def test_config3_full_size_ip_k100(setup):
+    """BASELINE config 3 at IVF4096 over 1M x 96 (DEEP-like, inner product, k = 100, nprobe 32), 5000 queries per call"""
+    _full_size_case(setup, "deep", 1_000_000, 5000, 0, 100, 32)
+
+
+def test_config5_full_size_d960(setup):
+    """BASELINE config 5 at its own size: 1M x 960 (GIST-like), IVF4096, k = 10, nprobe 32, 5000 queries per call"""
+    _full_size_case(setup, "gist", 1_000_000, 5000, 1, 10, 32)
