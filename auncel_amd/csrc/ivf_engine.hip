@@ -2228,8 +2228,13 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             // ~13 us each -- it stays on the search's own stream)
             // (so does a search that has the index to itself: there is nobody whose selection the side stream's lower priority would
             // let pass)
-            static const int scan_on_main = getenv("AUNCEL_AMD_SCAN_ON_MAIN") ? atoi(getenv("AUNCEL_AMD_SCAN_ON_MAIN")) : -1;  // (experiment: 1 always, 0 only below 20 queries)
-            if (scan_on_main > 0 || n < 20 || (scan_on_main < 0 && active.before == 0)) {
+            // Round 5: on the search's own stream always.  With six searches in flight through the engine's own contexts, every stream
+            // on a hardware queue of its own and the background work (heap order of coarse ties) beside them, the fork and join around
+            // a side stream cost more than letting other searches' selections pass the scans bought: 2.7 -> 3.05 M q/s in the exact
+            // tie regime, 3.2 -> 3.5 with runs in centroid-number order (profiles/r05_streams.txt).  AUNCEL_AMD_SCAN_ON_MAIN=0: the
+            // side stream (low priority class) for calls of 20 queries and more.
+            static const int scan_on_main = getenv("AUNCEL_AMD_SCAN_ON_MAIN") ? atoi(getenv("AUNCEL_AMD_SCAN_ON_MAIN")) : 1;
+            if (scan_on_main > 0 || n < 20) {
                 launch_scan_mfma(ma, s);
             } else {
                 ensure_aux(h, 3, 3);
