@@ -3595,8 +3595,6 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
     const bool fuse_small = n <= 4 && !L->spec_wanted;
     if (L->want_first_tie) {
         L->w_first_tie.ensure(n * 4);
-        if (!fuse_small)
-            launch_first_tie(L->w_cdis.as<float>(), (uint32_t)n, (uint32_t)nlist, (uint32_t)L->first_tie_nreal, L->w_first_tie.as<uint32_t>(), L->stream);
         // Which queries will have to be searched again is known only when this pass ends (first run < 2 my_nprobe + 14), but the
         // expensive part of searching them again -- the reference's heap over all nlist centroids, a serial 4096-element heap
         // sort per query -- needs nothing from this pass.  Every query that could qualify with the probes of the first two
@@ -3605,8 +3603,11 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
         static const bool no_spec = getenv("AUNCEL_AMD_NO_TIE_SPECULATION") != nullptr;
         constexpr uint32_t SPEC_CAP = 512, SPEC_NEAR = 64, SPEC_WINDOW = 2 * (12 + 144) + 14;
         L->spec_valid = false;
-        if (!no_spec && L->spec_wanted && !L->given_keys && np_row == nlist && n <= L->dist_budget_floats / std::max<size_t>(nlist, 1) &&
-            heap_tie_order_lds((uint32_t)nlist, (uint32_t)nlist) <= 160 * 1024) {
+        const bool can_spec = !no_spec && L->spec_wanted && !L->given_keys && np_row == nlist && n <= L->dist_budget_floats / std::max<size_t>(nlist, 1) &&
+                              heap_tie_order_lds((uint32_t)nlist, (uint32_t)nlist) <= 160 * 1024;
+        if (!can_spec && !fuse_small)
+            launch_first_tie(L->w_cdis.as<float>(), (uint32_t)n, (uint32_t)nlist, (uint32_t)L->first_tie_nreal, L->w_first_tie.as<uint32_t>(), L->stream);
+        if (can_spec) {
             const size_t ncopy = std::min(L->first_tie_nreal, nlist);
             L->w_spec_full.ensure((size_t)SPEC_CAP * nlist * 4);
             L->w_spec_dis.ensure((size_t)SPEC_CAP * nlist * 4);
@@ -3617,12 +3618,13 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
             ensure_context_streams(L);
             HIP_CHECK(hipStreamWaitEvent(L->stream, L->ev_spec_done, 0));  // (the previous search's slots are no longer being written)
             HIP_CHECK(hipMemsetAsync(L->w_spec_count.p, 0, 32, L->stream));
-            // (slots go to the nearest runs first: a query that stops in round 0 -- most do -- reads 2 x 12 + 14 entries)
-            for (uint32_t lo = 0, hi = SPEC_NEAR; lo < SPEC_WINDOW; lo = hi, hi = SPEC_WINDOW)
-                launch_spec_collect(L->w_first_tie.as<uint32_t>(), (uint32_t)n, lo, hi, SPEC_CAP, (uint32_t)nlist, (uint32_t)ncopy,
-                                    L->w_dist.as<float>(), L->w_cdis.as<float>(), L->w_ckeys.as<int64_t>(), L->w_spec_count.as<uint32_t>(),
-                                    L->w_spec_slot.as<int32_t>(), L->w_spec_full.as<float>(), L->w_spec_dis.as<float>(),
-                                    L->w_spec_keys.as<int64_t>(), L->stream, L->w_spec_query.as<uint32_t>());
+            // (the first run of every ranking and the slots of the rankings to re-rank in one launch: the heap starts right behind the
+            // coarse ranking; slots go to the waves in the order they arrive -- a ranking that finds none is searched again at the end)
+            (void)SPEC_NEAR;
+            launch_tie_collect(L->w_cdis.as<float>(), (uint32_t)n, (uint32_t)L->first_tie_nreal, SPEC_WINDOW, SPEC_CAP, (uint32_t)nlist, (uint32_t)ncopy,
+                               L->w_dist.as<float>(), L->w_ckeys.as<int64_t>(), L->w_first_tie.as<uint32_t>(), L->w_spec_count.as<uint32_t>(),
+                               L->w_spec_slot.as<int32_t>(), L->w_spec_full.as<float>(), L->w_spec_dis.as<float>(), L->w_spec_keys.as<int64_t>(),
+                               L->w_spec_query.as<uint32_t>(), L->stream);
             HIP_CHECK(hipEventRecord(L->ev_spec_go, L->stream));
             HIP_CHECK(hipStreamWaitEvent(L->spec_stream, L->ev_spec_go, 0));
             launch_heap_tie_order(L->w_spec_full.as<float>(), SPEC_CAP, (uint32_t)nlist, (uint32_t)nlist, (uint32_t)ncopy, L->metric,

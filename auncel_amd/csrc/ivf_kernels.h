@@ -546,6 +546,11 @@ struct TiePatchArgs {
     uint32_t* patched;
 };
 void launch_tie_patch(const TiePatchArgs& a, hipStream_t s);
+// launch_first_tie + launch_spec_collect in one launch (sorted rankings of row stride nlist): first_out[q] as launch_first_tie
+// leaves it, slots handed out in the order the waves arrive
+void launch_tie_collect(const float* sorted_dis, uint32_t nq, uint32_t nreal, uint32_t window, uint32_t cap, uint32_t nlist, uint32_t ncopy,
+                        const float* full, const int64_t* ckeys, uint32_t* first_out, uint32_t* count, int32_t* slot_of, float* s_full, float* s_dis,
+                        int64_t* s_keys, uint32_t* slot_query, hipStream_t s);
 // rows of a second search from those slots: ranking row j <- slot slots[j] (ncopy leading entries, rows of nlist entries)
 void launch_spec_gather(const int32_t* slots, uint32_t m, uint32_t nlist, uint32_t ncopy, const float* s_dis, const int64_t* s_keys,
                         float* cdis, int64_t* ckeys, hipStream_t s);

@@ -2231,6 +2231,50 @@ __global__ __launch_bounds__(64) void first_tie_kernel(const float* sorted_dis, 
     if (threadIdx.x == 0) out[blockIdx.x] = first;
 }
 
+// first_tie_kernel and spec_collect_kernel in one launch (one wave per ranking): the rankings whose first run starts below `window`
+// are set aside for the heap right where the run is found -- three launches fewer between the coarse ranking and the start of the
+// heap, whose end the first selection waits for
+__global__ __launch_bounds__(64) void tie_collect_kernel(const float* sorted_dis, uint32_t nreal, uint32_t window, uint32_t cap, uint32_t nlist,
+                                                         uint32_t ncopy, const float* full, const int64_t* ckeys, uint32_t* first_out, uint32_t* count,
+                                                         int32_t* slot_of, float* s_full, float* s_dis, int64_t* s_keys, uint32_t* slot_query) {
+    const uint32_t q = blockIdx.x, lane = threadIdx.x;
+    const float* od = sorted_dis + (size_t)q * nlist;
+    uint32_t first = 0xffffffffu;
+    for (uint32_t i = lane; i + 1 < nreal; i += 64)
+        if (od[i] == od[i + 1] && i < first) first = i;
+    for (int off = 32; off; off >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)first, off);
+        first = o < first ? o : first;
+    }
+    if (lane == 0) first_out[q] = first;
+    uint32_t slot = 0xffffffffu;
+    if (lane == 0 && first < window) slot = atomicAdd(count, 1u);
+    slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
+    if (slot >= cap) {
+        if (lane == 0) slot_of[q] = -1;
+        return;
+    }
+    if (lane == 0) {
+        slot_of[q] = (int32_t)slot;
+        slot_query[slot] = q;
+    }
+    const float* fr = full + (size_t)q * nlist;
+    float* fo = s_full + (size_t)slot * nlist;
+    for (uint32_t j = lane; j < nlist; j += 64) fo[j] = fr[j];
+    for (uint32_t j = lane; j < ncopy; j += 64) {
+        s_dis[(size_t)slot * nlist + j] = od[j];
+        s_keys[(size_t)slot * nlist + j] = ckeys[(size_t)q * nlist + j];
+    }
+}
+
+void launch_tie_collect(const float* sorted_dis, uint32_t nq, uint32_t nreal, uint32_t window, uint32_t cap, uint32_t nlist, uint32_t ncopy,
+                        const float* full, const int64_t* ckeys, uint32_t* first_out, uint32_t* count, int32_t* slot_of, float* s_full, float* s_dis,
+                        int64_t* s_keys, uint32_t* slot_query, hipStream_t s) {
+    if (nq)
+        LAUNCH(tie_collect_kernel, dim3(nq), dim3(64), 0, s, sorted_dis, nreal, window, cap, nlist, ncopy, full, ckeys, first_out, count, slot_of, s_full,
+               s_dis, s_keys, slot_query);
+}
+
 void launch_first_tie(const float* sorted_dis, uint32_t nq, uint32_t stride, uint32_t nreal, uint32_t* out, hipStream_t s) {
     if (nq) LAUNCH(first_tie_kernel, dim3(nq), dim3(64), 0, s, sorted_dis, stride, nreal, out);
 }

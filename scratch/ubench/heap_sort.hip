@@ -168,6 +168,64 @@ __device__ inline void heapsort_v3(HeapEnt* a, uint32_t n, uint32_t* out_id, int
     }
 }
 
+
+// ---- v4: v3 without branches inside a tick: the starting pop's loads are unconditional (uniform addresses), every update is a
+// select, the id of the popped root goes to a dummy place when no pop starts; depth from the hole itself (no lvl register)
+__device__ __forceinline__ void walk_step4(HeapEnt* a, uint32_t& hole, uint32_t s, float Lv, uint32_t Lid, const uint4 ch) {
+    const uint32_t j1 = hole << 1;
+    const float c1v = __uint_as_float(ch.x), c2v = __uint_as_float(ch.z);
+    const bool left = j1 == s || c1v > c2v;
+    const float cv = left ? c1v : c2v;
+    const uint32_t cid = left ? ch.y : ch.w;
+    const bool done = j1 > s || Lv > cv;
+    reinterpret_cast<uint2*>(a)[hole] = make_uint2(__float_as_uint(done ? Lv : cv), done ? Lid : cid);
+    const uint32_t nh = left ? j1 : j1 + 1;
+    hole = done ? 0u : nh;
+}
+__device__ inline void heapsort_v4(HeapEnt* a, uint32_t n, uint32_t* out_id, int lane) {
+    uint32_t hole = 0, s = 0xffffffffu, Lid = 0;
+    float Lv = 0.f;
+    uint32_t t = 0;
+    const uint4* a4 = reinterpret_cast<const uint4*>(a);
+    const uint2* a2 = reinterpret_cast<const uint2*>(a);
+    const uint32_t lim = n >> 1;
+    while (t < n) {
+        const uint32_t sc = n - t;
+        const uint4 ch_own = a4[hole < lim ? hole : lim];
+        const uint4 r01 = a4[0];
+        const uint4 r23 = a4[1];
+        const uint2 ls = a2[sc];
+        // a walk above slot sc?  depth(hole) = 31 - clz(hole); hole is an ancestor-or-self of sc iff sc >> (depth(sc) - depth(hole)) == hole
+        const uint32_t sh = (uint32_t)__builtin_clz(hole | 1u) - (uint32_t)__builtin_clz(sc);  // (hole 0: clz 31 -> a shift that cannot match a non-zero... see below)
+        const bool above = hole != 0 && sh < 32u && (sc >> sh) == hole;
+        const bool create = !__ballot(above);
+        const bool mine = create && (uint32_t)lane == (t & 31u);
+        out_id[mine ? sc - 1 : n] = r01.w;  // (slot n: scratch)
+        hole = mine ? 1u : hole;
+        s = mine ? sc : s;
+        Lv = mine ? __uint_as_float(ls.x) : Lv;
+        Lid = mine ? ls.y : Lid;
+        uint4 ch;
+        ch.x = mine ? r23.x : ch_own.x;
+        ch.y = mine ? r23.y : ch_own.y;
+        ch.z = mine ? r23.z : ch_own.z;
+        ch.w = mine ? r23.w : ch_own.w;
+        walk_step4(a, hole, s, Lv, Lid, ch);
+        wave_sync();
+        t += create ? 1u : 0u;
+        if (create) {
+            const uint4 c2 = a4[hole < lim ? hole : lim];
+            walk_step4(a, hole, s, Lv, Lid, c2);
+            wave_sync();
+        }
+    }
+    while (__ballot(hole != 0)) {
+        const uint4 c2 = a4[hole < lim ? hole : lim];
+        walk_step4(a, hole, s, Lv, Lid, c2);
+        wave_sync();
+    }
+}
+
 template <int V> __global__ __launch_bounds__(64) void sort_rows(const float* heaps, uint32_t n, uint32_t* out, unsigned long long* cycles) {
     extern __shared__ __align__(16) unsigned char smem[];
     HeapEnt* a = reinterpret_cast<HeapEnt*>(smem);
@@ -180,7 +238,8 @@ template <int V> __global__ __launch_bounds__(64) void sort_rows(const float* he
     const unsigned long long c0 = __builtin_readcyclecounter();
     if (V == 1) heapsort_v1(a, n, out_id, lane);
     else if (V == 2) heapsort_v2(a, n, out_id, lane);
-    else heapsort_v3(a, n, out_id, lane);
+    else if (V == 3) heapsort_v3(a, n, out_id, lane);
+    else heapsort_v4(a, n, out_id, lane);
     const unsigned long long c1 = __builtin_readcyclecounter();
     wave_sync();
     for (uint32_t i = lane; i < n; i += 64) out[(size_t)blockIdx.x * n + i] = out_id[i];
@@ -228,10 +287,10 @@ int main(int argc, char** argv) {
     float* dh; uint32_t* dout; unsigned long long* dcyc;
     CK(hipMalloc(&dh, h.size() * 4)); CK(hipMalloc(&dout, h.size() * 4)); CK(hipMalloc(&dcyc, rows * 8));
     CK(hipMemcpy(dh, h.data(), h.size() * 4, hipMemcpyHostToDevice));
-    const size_t shmem = (size_t)(n + 2) * 8 + (size_t)n * 4;
+    const size_t shmem = (size_t)(n + 2) * 8 + (size_t)(n + 1) * 4;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int ver = 1; ver <= 3; ver++) {
-        auto kern = ver == 1 ? sort_rows<1> : ver == 2 ? sort_rows<2> : sort_rows<3>;
+    for (int ver = 1; ver <= 4; ver++) {
+        auto kern = ver == 1 ? sort_rows<1> : ver == 2 ? sort_rows<2> : ver == 3 ? sort_rows<3> : sort_rows<4>;
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         float best = 1e9f;
         for (int rep = 0; rep < 3; rep++) {
