@@ -1112,13 +1112,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
 //                 words per step with the next step's words in flight; the few marked chunks of a step are fetched together.
 // After every probe the stop rule is evaluated exactly as IndexIVF.cpp:551-638 does (tune mode); a probe that admitted
 // nothing costs a handful of scalar instructions.
+#ifndef AUNCEL_SEL_BATCH
+#define AUNCEL_SEL_BATCH 1  // admissions in batches of up to 64 (flush) instead of one sorted insert each (0: the round-4 form)
+#endif
+constexpr size_t SEL_MERGE_BYTES = AUNCEL_SEL_BATCH ? 2 * 128 * 4 : 0;
 __host__ __device__ inline size_t select_wave_bytes(int k, bool tune, bool dense, uint32_t trace_cap) {
     // srt | dwin | trace x,z | cur_num_par terms.  Dense rounds rank the first k candidates of a search at once (keys, value bits,
     // positions | sorted keys, positions: 5 x 128 words): that happens before the first probe's stop rule loads a trace, so in tune
     // mode the two share their room (a workgroup's LDS: 28 -> 18 KB at k = 100, which is what lets a 49 KB workgroup -- the heap
     // order of coarse ties -- start on a CU that holds five of these)
     const size_t fill = 5 * 128 * 4;
-    size_t b = 0;
+    size_t b = SEL_MERGE_BYTES;  // keys | positions of the array a batch of admissions is merged into (select_sorted_kernel: flush)
     if (tune) {
         const size_t trace = (size_t)trace_cap * 8;
         b += (size_t)k * 4 + 16 * 4 + (dense && trace < fill ? fill : trace) + CURNUM_PAR_MAXK * 15 * 4 + 8;
@@ -1250,11 +1254,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 
     if (a.done[qi]) return;
 
     unsigned char* wbase = smem + (TUNE ? 2000 : 0) + (size_t)wave * select_wave_bytes(k, TUNE, !MASKED, a.trace_cap);
-    float* srt = reinterpret_cast<float*>(wbase);       // tune: the k values best first, as the rule reads them
+    uint32_t* mk = reinterpret_cast<uint32_t*>(wbase);  // batch merge: keys | positions (SEL_MERGE_BYTES)
+    uint32_t* mg = mk + 128;
+    float* srt = reinterpret_cast<float*>(wbase + SEL_MERGE_BYTES);  // tune: the k values best first, as the rule reads them
     float* dwin = srt + k;                              // 16 boundary distances of the current stage
     float* trc = dwin + 16;                             // x | z of the cached trace, trace_cap each
     float* terms = trc + (!MASKED && 2 * a.trace_cap < 640u ? 640u : 2 * a.trace_cap);  // cur_num_par scratch (behind the trace's room: select_wave_bytes)
-    uint32_t* fill = reinterpret_cast<uint32_t*>(TUNE ? reinterpret_cast<unsigned char*>(trc) : wbase);  // dense rounds: 5 x 128 words (tune: in the trace's room)
+    uint32_t* fill = reinterpret_cast<uint32_t*>(TUNE ? reinterpret_cast<unsigned char*>(trc) : wbase + SEL_MERGE_BYTES);  // dense rounds: 5 x 128 words (tune: in the trace's room)
     const float* gdtb = TUNE ? a.dtb + (size_t)qi * max_num : nullptr;
 
     // ---- state
@@ -1271,7 +1277,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 
     uint32_t logn = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.log_cnt[qi]);
     uint2* const qlog = a.log + (size_t)qi * a.log_cap;
     uint32_t log_v = 0, log_g = 0;
-    if ((uint32_t)lane < (logn & 63u)) {  // the open block of the log comes back into the staging registers
+    if (!AUNCEL_SEL_BATCH && (uint32_t)lane < (logn & 63u)) {  // the open block of the log comes back into the staging registers
         const uint2 e = qlog[(logn & ~63u) + lane];
         log_v = e.x;
         log_g = e.y;
@@ -1326,6 +1332,91 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 
 
     // ---- one admission (the candidate beats the worst of the k): IndexIVFFlat.cpp:125-135 on the sorted array
     int ins_min = 128;       // best position taken during the current probe
+#if AUNCEL_SEL_BATCH
+    // Round 5: admissions in batches.  A candidate that beats the worst of the k *as last known* is set aside (one per lane, in scan
+    // order); a batch -- 64 of them, or what a probe's row leaves -- is merged into the array at once (flush).  Candidate j is admitted
+    // iff fewer than k values seen before it are <= it: #{array entries <= b_j} + #{earlier candidates of the batch <= b_j} < k (values
+    // that left the array are >= its worst and so > b_j; a candidate set aside under a threshold that has moved on since fails the
+    // count) -- exactly the reference's "dis < simi[0]" at its turn, so the admissions, their order in the log, nheap_updates and the
+    // array after the batch are the one-by-one result; what it costs is ~20 instructions a candidate instead of ~75 an admission.
+    uint32_t B_k = 0, B_g = 0;  // lane j: order key and global position of the j-th candidate set aside
+    uint32_t bn = 0;
+    auto flush = [&]() {
+        if (bn == 0) return;
+        const bool cand = (uint32_t)lane < bn;
+        const uint32_t myk = cand ? B_k : 0xffffffffu;
+        uint32_t pa = 0, w = 0, later = 0, sh0 = 0, sh1 = 0;
+        for (uint32_t i = 0; i < bn; i++) {
+            const uint32_t ki = rl_u(B_k, (int)i);
+            uint32_t p = (uint32_t)__builtin_popcountll(__ballot(sr.k0 <= ki));
+            if (TWO) p += (uint32_t)__builtin_popcountll(__ballot(sr.k1 <= ki));
+            wl_u(pa, (uint32_t)__builtin_amdgcn_readfirstlane((int)p), __builtin_amdgcn_readfirstlane((int)i));
+            w += (ki <= myk && (uint32_t)lane > i) ? 1u : 0u;
+            later += (ki < myk && (uint32_t)lane < i) ? 1u : 0u;
+            sh0 += ki < sr.k0 ? 1u : 0u;
+            if (TWO) sh1 += ki < sr.k1 ? 1u : 0u;
+        }
+        const bool adm = cand && pa + w < (uint32_t)k;
+        const unsigned long long am = __ballot(adm);
+        const uint32_t nadm = (uint32_t)__builtin_popcountll(am);
+        if (nadm) {
+            const uint32_t rank = pa + w + later;  // place of an admitted candidate among (array + admitted), by (value, arrival)
+            const uint32_t r0 = (uint32_t)lane + sh0, r1 = 64u + (uint32_t)lane + sh1;  // ... of the array's own entries
+            wave_sync();
+            if ((int)lane < k && r0 < (uint32_t)k) {
+                mk[r0] = sr.k0;
+                mg[r0] = sr.g0;
+            }
+            if (TWO && (int)lane + 64 < k && r1 < (uint32_t)k) {
+                mk[r1] = sr.k1;
+                mg[r1] = sr.g1;
+            }
+            if (adm && rank < (uint32_t)k) {
+                mk[rank] = B_k;
+                mg[rank] = B_g;
+            }
+            // the admission log: the admitted candidates in scan order
+            if (logn + nadm > a.log_cap) {
+                err = ERR_LOG_OVERFLOW;
+            } else if (adm) {
+                const uint32_t at = logn + (uint32_t)__builtin_popcountll(am & ((1ull << lane) - 1ull));
+                qlog[at] = make_uint2(__float_as_uint(okey_inv<IsMax>(B_k)), B_g);
+            }
+            logn += logn + nadm > a.log_cap ? 0u : nadm;
+            st_nheap += nadm;
+            const unsigned long long top_in = __ballot(adm && rank < query_k);
+            if (top_in) ins_min = 0;  // (an admitted value among the first query_k: the rule's inputs changed)
+            wave_sync();
+            const bool l0 = (int)lane < k, l1 = TWO && (int)lane + 64 < k;
+            // what left: an array entry or an admitted candidate whose place is k or beyond
+            const uint32_t wk = mk[k - 1];
+            const bool out0 = l0 && r0 >= (uint32_t)k && sr.k0 == wk, out1 = l1 && r1 >= (uint32_t)k && sr.k1 == wk;
+            const bool outc = adm && rank >= (uint32_t)k && B_k == wk;
+            if (l0) {
+                sr.k0 = mk[lane];
+                sr.g0 = mg[lane];
+            }
+            if (l1) {
+                sr.k1 = mk[64 + lane];
+                sr.g1 = mg[64 + lane];
+            }
+            // a value of which a copy left while this one stays: the new worst equals something that left (the new values are
+            // strictly better than the old worst, so only then can equal worst values have been split)
+            if (wk != SKEY_SENT && __ballot(out0 || out1 || outc) != 0) amb = wk;
+            topk = wk;
+            top = okey_inv<IsMax>(wk);
+        }
+        bn = 0;
+    };
+    auto admit = [&](float val, uint32_t ckey, uint32_t gp) {
+        (void)val;
+        gp = (uint32_t)__builtin_amdgcn_readfirstlane((int)gp);
+        wl2_u(B_k, (uint32_t)__builtin_amdgcn_readfirstlane((int)ckey), B_g, gp, __builtin_amdgcn_readfirstlane((int)bn));
+        bn++;
+        if (bn == 64u) flush();
+    };
+#else
+    auto flush = [&]() {};
     auto admit = [&](float val, uint32_t ckey, uint32_t gp) {
         const uint32_t evicted = topk;
         gp = (uint32_t)__builtin_amdgcn_readfirstlane((int)gp);
@@ -1346,6 +1437,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 
         topk = wk;
         top = okey_inv<IsMax>(wk);
     };
+#endif
 
     // ---- probe table: a window of 64 probes, one per lane (list number, list length)
     uint32_t win0 = 0;
@@ -1655,6 +1747,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 
                 st_ndis += n;
             }
         }
+        flush();  // (the probe's last candidates: the rule below reads the array as the probe leaves it)
         if (TUNE && st_nheap != nheap0) {
             wave_sync();
             srt_from_regs();
@@ -1783,7 +1876,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 
         if (finished || a.finalize_all || err) a.fin_round[qi] = a.round;
     }
     // the open block of the admission log
-    if ((uint32_t)lane < (logn & 63u)) qlog[(logn & ~63u) + lane] = make_uint2(log_v, log_g);
+    if (!AUNCEL_SEL_BATCH && (uint32_t)lane < (logn & 63u)) qlog[(logn & ~63u) + lane] = make_uint2(log_v, log_g);
     const bool in0 = lane < k, in1 = TWO && lane + 64 < k;
     if (finished || a.finalize_all || err) {
         // equal values among the k (their order is the heap's), or a value of which a copy was evicted while this one stayed

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything the round's committed numbers come from, in one gpurun call:
-#   gpurun --timeout 2700 -- 'bash scripts/refresh_round.sh r04'
-tag=${1:-r04}
+#   gpurun --timeout 2700 -- 'bash scripts/refresh_round.sh r05'
+tag=${1:-r05}
 bash profiles/collect.sh $tag > gpurun_out/collect_$tag.log 2>&1
 # (bench.py takes roofline.traffic from the newest profiles/r*_pmc.json: the one this run just measured)
 cp gpurun_out/summary_$tag/${tag}_pmc.json profiles/ 2>/dev/null
@@ -15,5 +15,6 @@ python scratch/bw_probe.py > gpurun_out/bw_probe_$tag.txt 2> gpurun_out/bw_probe
 bash scripts/timelines.sh $tag > gpurun_out/timelines_$tag.log 2>&1
 bash scripts/busy.sh > gpurun_out/in_flight_busy_$tag.txt 2>&1
 python bench.py --steps 20 --warmup 5 --no-cpu --no-legs > gpurun_out/bench_driver_flags_$tag.json 2> /dev/null
+python bench.py --runner threads --no-cpu --no-other > gpurun_out/bench_threads_$tag.json 2> /dev/null
 timeout 1500 python -m pytest tests -m gpu -q -rf 2>&1 | tail -15 > gpurun_out/gpu_tests_$tag.txt
 tail -3 gpurun_out/bench_$tag.log; cat gpurun_out/effect_time_$tag.jsonl; du -sh gpurun_out
