@@ -574,7 +574,7 @@ hipStream_t make_background_stream() {
 // 1.5 ms heap waited for it, and the figures of a bench leg moved by a factor of two with the legs run before it.)  The classes
 // are also the order the work should be dispatched in when the chip is full: the latency-bound chain (planning, selection) first,
 // the background kernels the chain will wait for next, the bandwidth-bound scans -- grids of thousands of workgroups -- with
-// whatever is left.  Measured (profiles/r05_streams.txt): the same throughput as scans in the normal class, without the
+// whatever is left.  Measured (profiles/r05_experiments.txt): the same throughput as scans in the normal class, without the
 // dependence on creation order.
 void ensure_context_streams(amd_ivf* h) {
     if (h->bg_stream) return;
@@ -2231,7 +2231,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             // Round 5: on the search's own stream always.  With six searches in flight through the engine's own contexts, every stream
             // on a hardware queue of its own and the background work (heap order of coarse ties) beside them, the fork and join around
             // a side stream cost more than letting other searches' selections pass the scans bought: 2.7 -> 3.05 M q/s in the exact
-            // tie regime, 3.2 -> 3.5 with runs in centroid-number order (profiles/r05_streams.txt).  AUNCEL_AMD_SCAN_ON_MAIN=0: the
+            // tie regime, 3.2 -> 3.5 with runs in centroid-number order (profiles/r05_experiments.txt).  AUNCEL_AMD_SCAN_ON_MAIN=0: the
             // side stream (low priority class) for calls of 20 queries and more.
             static const int scan_on_main = getenv("AUNCEL_AMD_SCAN_ON_MAIN") ? atoi(getenv("AUNCEL_AMD_SCAN_ON_MAIN")) : 1;
             if (scan_on_main > 0 || n < 20) {

@@ -1112,8 +1112,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
 //                 words per step with the next step's words in flight; the few marked chunks of a step are fetched together.
 // After every probe the stop rule is evaluated exactly as IndexIVF.cpp:551-638 does (tune mode); a probe that admitted
 // nothing costs a handful of scalar instructions.
+// Admissions in batches of up to 64 (flush, below) instead of one sorted insert each: built and measured in round 5 -- every parity
+// suite passes with it, and it is NOT faster: round 0 of the bench workload, per wave, 590 k cycles against 535 k one by one (mean;
+// slowest wave 1.23 M against 1.15 M), because an admission costs ~50 issue slots, not the 75 instructions it was counted at, and a
+// candidate of a batch costs ~20 + its extraction.  Kept behind the switch (-DAUNCEL_SEL_BATCH=1) with its derivation; off.
 #ifndef AUNCEL_SEL_BATCH
-#define AUNCEL_SEL_BATCH 1  // admissions in batches of up to 64 (flush) instead of one sorted insert each (0: the round-4 form)
+#define AUNCEL_SEL_BATCH 0
 #endif
 constexpr size_t SEL_MERGE_BYTES = AUNCEL_SEL_BATCH ? 2 * 128 * 4 : 0;
 __host__ __device__ inline size_t select_wave_bytes(int k, bool tune, bool dense, uint32_t trace_cap) {
