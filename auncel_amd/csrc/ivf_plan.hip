@@ -114,7 +114,9 @@ __global__ __launch_bounds__(256) void plan_counts_kernel(PlanArgs a) {
 // were 18 of the ~35 barriers of a planning pass)
 template <int N> __device__ __forceinline__ void block_scan_1024_n(const uint32_t (&v)[N], uint32_t (&excl)[N], uint32_t (&total)[N],
                                                                     uint32_t (*s_wave)[N]) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // (the workgroup's own size: 1024 threads in the one-workgroup planner of small calls, 256 in the kernels of large ones -- a
+    // workgroup of 16 waves waits for a CU with 16 free wave slots, which among other searches' kernels takes longer than its work)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
     uint32_t incl[N];
 #pragma unroll
     for (int k = 0; k < N; k++) incl[k] = v[k];
@@ -133,14 +135,14 @@ template <int N> __device__ __forceinline__ void block_scan_1024_n(const uint32_
     if (w == 0) {
 #pragma unroll
         for (int k = 0; k < N; k++) {
-            const uint32_t x = lane < 16 ? s_wave[lane][k] : 0u;
+            const uint32_t x = lane < nw ? s_wave[lane][k] : 0u;
             uint32_t inc = x;
             for (int off = 1; off < 16; off <<= 1) {
                 const uint32_t o = (uint32_t)__shfl_up((int)inc, off);
                 if (lane >= off) inc += o;
             }
-            if (lane < 16) s_wave[lane][k] = inc - x;
-            if (lane == 15) s_wave[16][k] = inc;
+            if (lane < nw) s_wave[lane][k] = inc - x;
+            if (lane == nw - 1) s_wave[16][k] = inc;
         }
     }
     __syncthreads();
@@ -158,7 +160,8 @@ __device__ __forceinline__ void plan_prefix_body(const PlanArgs& a) {
     __shared__ uint32_t cut;
     const uint32_t t = threadIdx.x;
     if (t == 0) cut = 0xffffffffu;
-    const uint32_t per = (a.nq + 1023) / 1024, q0 = t * per, q1 = q0 + per < a.nq ? q0 + per : a.nq;
+    const uint32_t nt = blockDim.x;
+    const uint32_t per = (a.nq + nt - 1) / nt, q0 = t * per < a.nq ? t * per : a.nq, q1 = q0 + per < a.nq ? q0 + per : a.nq;
     unsigned long long my_need = 0;
     uint32_t my_cnt = 0, my_act = 0;
     for (uint32_t i = q0; i < q1; i++) {
@@ -211,7 +214,7 @@ __device__ __forceinline__ void plan_prefix_body(const PlanArgs& a) {
         s_ndist = 0;
     }
     __syncthreads();
-    for (uint32_t i = t; i < a.nq; i += 1024) {
+    for (uint32_t i = t; i < a.nq; i += nt) {
         uint32_t c = a.cnt[i];
         const uint32_t pm = a.pad[i], pad = pm & 0x7fffffffu;
         if (pm >> 31) a.pad[i] = pad;
@@ -348,7 +351,8 @@ __device__ __forceinline__ void plan_lists_body(const PlanArgs& a) {
             slots += (unsigned long long)((rem + SCAN_RQ - 1) / SCAN_RQ * SCAN_RQ) * ((sz + tv - 1) / tv) * tv;
         }
     };
-    const uint32_t per = (a.nlist + 1023) / 1024, l0 = t * per, l1 = l0 + per < a.nlist ? l0 + per : a.nlist;
+    const uint32_t nt = blockDim.x;
+    const uint32_t per = (a.nlist + nt - 1) / nt, l0 = t * per < a.nlist ? t * per : a.nlist, l1 = l0 + per < a.nlist ? l0 + per : a.nlist;
     uint32_t mine[6] = {0, 0, 0, 0, 0, 0};
     double list_bytes = 0;
     unsigned long long my_slots = 0, my_useful = 0;
@@ -728,10 +732,19 @@ void launch_plan(const PlanArgs& a, hipStream_t s) {
         return;
     }
     const unsigned gq = (a.nq + 3) / 4 /* one wave per query */, gl = (a.nlist + 3) / 4 /* one wave per list */;
+    // threads of the two one-workgroup kernels (prefix sums over the queries, per-list offsets; AUNCEL_AMD_PLAN_THREADS: 64 ... 1024, a
+    // multiple of 64).  A workgroup of sixteen waves waits for a CU with sixteen free wave slots, so 256 threads were tried (round 5,
+    // profiles/r05_experiments.txt U): with six searches in flight the same within the spread (3.11-3.14 against 3.09-3.14 M q/s),
+    // a search alone 0.08 ms slower (2.60 against 2.52 ms: four times the queries per thread) -- 1024 stays.
+    static const unsigned plan_threads = [] {
+        const char* e = getenv("AUNCEL_AMD_PLAN_THREADS");
+        const int v = e ? atoi(e) : 1024;
+        return (unsigned)(v >= 64 && v <= 1024 && v % 64 == 0 ? v : 1024);
+    }();
     LAUNCH(plan_counts_kernel, dim3(gq), dim3(256), 0, s, a);
-    LAUNCH(plan_prefix_kernel, dim3(1), dim3(1024), 0, s, a);
+    LAUNCH(plan_prefix_kernel, dim3(1), dim3(plan_threads), 0, s, a);
     LAUNCH(plan_segments_kernel, dim3(gq), dim3(256), 0, s, a);
-    LAUNCH(plan_lists_kernel, dim3(1), dim3(1024), 0, s, a);
+    LAUNCH(plan_lists_kernel, dim3(1), dim3(plan_threads), 0, s, a);
     LAUNCH(plan_scatter_items_kernel, dim3(gq + gl), dim3(256), 0, s, a, (uint32_t)gq);
 }
 
