@@ -574,8 +574,13 @@ hipStream_t make_background_stream() {
 // 1.5 ms heap waited for it, and the figures of a bench leg moved by a factor of two with the legs run before it.)  The classes
 // are also the order the work should be dispatched in when the chip is full: the latency-bound chain (planning, selection) first,
 // the background kernels the chain will wait for next, the bandwidth-bound scans -- grids of thousands of workgroups -- with
-// whatever is left.  Measured (profiles/r05_experiments.txt): the same throughput as scans in the normal class, without the
-// dependence on creation order.
+// whatever is left.  Measured (profiles/r05_experiments.txt I, K, V): the byte-code scans have since moved to the main stream, so for
+// them this stream carries nothing -- and its mere presence is worth 8 % of the headline (3.11-3.17 against 2.81-2.92 M q/s, twice on
+// one box: with queues in all three classes the hardware's arbitration between the high-priority main queues and the rest
+// changes, and the runtime offers no other handle on it).  Making it on first use and in the normal class instead was tried: the
+// headline lost those 8 %, and four fp32 searches in flight -- five normal-class streams each then, twenty on eight queues, with
+// fork / join events between streams that share a queue -- collapsed to 25 ms a step.  The fp32 paths keep it as the stream of the
+// widest tile shape and of the filter passes, where it starts behind the other shapes (cfg 5: DESIGN.md 3.2b).
 void ensure_context_streams(amd_ivf* h) {
     if (h->bg_stream) return;
     static const char* scan_prio_env = getenv("AUNCEL_AMD_SCAN_PRIO");  // ("normal": the scan stream in the background streams' class)

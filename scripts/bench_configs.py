@@ -18,6 +18,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (before anything starts the HIP runtime: auncel_amd/__init__.py)
 import bench  # noqa: E402
 
 
