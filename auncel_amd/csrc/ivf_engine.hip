@@ -596,8 +596,8 @@ void ensure_context_streams(amd_ivf* h) {
         HIP_CHECK(hipStreamCreateWithFlags(&h->aux[3], hipStreamNonBlocking));
     }
     static const char* bg_prio = getenv("AUNCEL_AMD_BG_PRIO");  // (experiment: "high" = the background stream at the main streams' priority)
-    if (bg_prio && !strcmp(bg_prio, "high") && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo) {
-        HIP_CHECK(hipStreamCreateWithPriority(&h->bg_stream, hipStreamNonBlocking, hi));
+    if (bg_prio && (!strcmp(bg_prio, "high") || !strcmp(bg_prio, "low")) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo) {
+        HIP_CHECK(hipStreamCreateWithPriority(&h->bg_stream, hipStreamNonBlocking, !strcmp(bg_prio, "high") ? hi : lo));
     } else {
         h->bg_stream = make_background_stream();
     }
