@@ -2146,7 +2146,10 @@ __global__ __launch_bounds__(64) void heap_tie_order_kernel(const float* dis, ui
                                                             const uint32_t* dev_nq) {
     extern __shared__ __align__(16) unsigned char smem[];
     if (dev_nq && blockIdx.x >= *dev_nq) return;  // (rows set aside on the device: launch_spec_collect)
-    __builtin_amdgcn_s_setprio(3);  // (one wave's dependent chain of a few thousand steps, beside other searches' kernels)
+#ifndef AUNCEL_HEAP_WAVE_PRIO
+#define AUNCEL_HEAP_WAVE_PRIO 3
+#endif
+    __builtin_amdgcn_s_setprio(AUNCEL_HEAP_WAVE_PRIO);  // (one wave's dependent chain of a few thousand steps, beside other searches' kernels)
     HeapEnt* h = reinterpret_cast<HeapEnt*>(smem);                           // nprobe + 2 entries, [0] unused
     // (the distance row stays in global memory -- every entry is read once or twice -- and the sorted ids go straight to the ranking:
     // 33 KB of LDS a row instead of 49, with half a thousand rows of four searches resident at a time)
