@@ -162,6 +162,25 @@ def run_config(torch, capi, dev, c, nprobes=None, sample=64, ref_sample=2000, lo
             if det[ph][1] and det[ph][0] > 0:
                 roof["per_launch"].append({"phase": ph, "launches": det[ph][1], "ms": det[ph][0] / det[ph][1], "min_bytes": mb / det[ph][1],
                                            "GBps": mb / 1e9 / (det[ph][0] / 1e3), "frac": mb / 1e9 / (det[ph][0] / 1e3) / 8000.0})
+        # HBM traffic by the committed counter profile of this configuration (profiles/collect_cfg.sh -> profiles/r*_pmc_cfg<c>.json: the
+        # kernels' FETCH_SIZE x 2 + WRITE_SIZE over one search of this batch at nprobe 32), per phase
+        try:
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_cfg{c}.json")))
+            if cands and nprobe == 32:
+                pj = json.load(open(cands[-1]))
+                dense_b = sum(e["hbm_read_bytes_x2"] + e["hbm_write_bytes"] for k_, e in pj.items()
+                              if isinstance(e, dict) and k_.startswith("scan_tiles_kernel"))
+                thr_b = sum(e["hbm_read_bytes_x2"] + e["hbm_write_bytes"] for k_, e in pj.items()
+                            if isinstance(e, dict) and (k_.startswith("scan_filter") or k_.startswith("rescore_kernel")))
+                for pl in roof["per_launch"]:
+                    tb = dense_b if pl["phase"] == "scan_dense" else thr_b
+                    pl["traffic"] = tb / max(pl["launches"], 1)
+                    pl["traffic_frac"] = tb / 1e9 / (pl["ms"] * pl["launches"] / 1e3) / 8000.0 if pl["ms"] else None
+                roof["traffic"] = (dense_b + thr_b) / max(sum(pl["launches"] for pl in roof["per_launch"]), 1)
+                roof["traffic_source"] = os.path.relpath(cands[-1], ROOT) + " (PMC, per search; divided by the launches of the phase)"
+        except Exception:  # noqa: BLE001 -- no profile: traffic stays null
+            pass
         tot_ms = det["scan_dense"][0] + det["scan_thr"][0]
         tot_b = det["min_bytes_dense"] + det["min_bytes_thr"]
         roof["achieved"] = tot_b / 1e9 / (tot_ms / 1e3) if tot_ms > 0 else None

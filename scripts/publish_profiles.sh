@@ -2,6 +2,8 @@
 # copy what scripts/refresh_round.sh brought back under gpurun_out/ into the tracked profiles/ directory
 tag=${1:-r05}
 cp gpurun_out/summary_$tag/${tag}_summary.md gpurun_out/summary_$tag/${tag}_pmc.json gpurun_out/summary_$tag/${tag}_kernel_stats.csv profiles/
+cp gpurun_out/summary_$tag/${tag}_pmc_cfg5.json gpurun_out/summary_$tag/${tag}_pmc_cfg3.json profiles/ 2>/dev/null
+cp gpurun_out/bench_threads_$tag.json profiles/${tag}_bench_line_threads_runner.json 2>/dev/null
 cp gpurun_out/bench_$tag.json profiles/${tag}_bench_line.json
 cp gpurun_out/perf_scan_$tag.txt profiles/${tag}_fixed_nprobe.txt
 cp gpurun_out/configs_$tag.jsonl profiles/${tag}_other_configs.jsonl

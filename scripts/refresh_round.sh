@@ -3,6 +3,8 @@
 #   gpurun --timeout 2700 -- 'bash scripts/refresh_round.sh r05'
 tag=${1:-r05}
 bash profiles/collect.sh $tag > gpurun_out/collect_$tag.log 2>&1
+bash profiles/collect_cfg.sh $tag > gpurun_out/collect_cfg_$tag.log 2>&1
+cp gpurun_out/summary_$tag/${tag}_pmc_cfg5.json gpurun_out/summary_$tag/${tag}_pmc_cfg3.json profiles/ 2>/dev/null
 # (bench.py takes roofline.traffic from the newest profiles/r*_pmc.json: the one this run just measured)
 cp gpurun_out/summary_$tag/${tag}_pmc.json profiles/ 2>/dev/null
 python bench.py > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.log
