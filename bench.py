@@ -869,6 +869,8 @@ def main():
     # whichever leg is put behind it instead loses as much: measured in every order)
     single_caller = None
     if nfl > 1 and not args.no_legs and not use_async:
+        while len(ctxs) > 1:  # (the caller threads' contexts go first: their streams would share hardware queues with the engine's own)
+            ctxs.pop().close()
         h.set_async_depth(nfl)
         async_outs = result_buffers(2 * nfl)
         run_steps_async(max(2 * nfl, 8), {})

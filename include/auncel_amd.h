@@ -230,6 +230,12 @@ int amd_ivf_range_results(amd_ivf_t* h, int64_t* labels, float* distances);
 /* ---- environment ----------------------------------------------------------------------------------
  * AUNCEL_AMD_BLOCKING_SYNC=1   host threads wait for the device on blocking events (sleep until the interrupt) instead of
  *                              hipStreamSynchronize's spinning: for hosts where the calling threads outnumber their cores
+ * GPU_MAX_HW_QUEUES (the HIP runtime's own variable): hardware queues per stream-priority class.  The engine's streams -- a
+ *                              high-priority main stream, a background stream and a low-priority side stream per search context --
+ *                              are laid out for 8 (ROCm's default is 4, with which the background streams of several searches in
+ *                              flight share queues and wait for each other's kernels); the library sets 8 when it is loaded unless
+ *                              the process has chosen a value, which only takes effect if the HIP runtime has not started yet: a
+ *                              process that touches the GPU before loading the library sets it itself (bench.py does)
  * The other AUNCEL_AMD_* variables the sources read are measurement switches (DESIGN.md names the ones it quotes). */
 
 /* ---- measurement hooks (bench.py): time of the kernels of the last search call, from HIP events
@@ -307,8 +313,9 @@ int amd_ivf_last_coarse_pick(amd_ivf_t* h, uint64_t* rankings);
  * call; amd_ivf_last_error() then holds its message); timing (amd_ivf_last_timing's 8 doubles + amd_ivf_last_scan_min_bytes) and diag (launches sized by a
  * hint, hints too small, queries searched again for the tie order, 1 if (D, I) were written directly) may be null.  Every
  * buffer passed to submit must stay valid, and the index and its resident queries unchanged, until the ticket has been waited
- * for; every ticket must be waited for exactly once.  One caller thread that keeps four 5000-query batches in flight this way
- * reaches what four threads with a context each reach (the reference's callers would use threads: IndexShards.cpp:48-120). */
+ * for; every ticket must be waited for exactly once.  One caller thread that keeps six 5000-query searches running this way (twelve
+ * tickets out: bench.py's headline) reaches what six threads with a context each reach (the reference's callers would use
+ * threads: IndexShards.cpp:48-120). */
 int amd_ivf_set_async_depth(amd_ivf_t* h, int depth);
 int amd_ivf_submit_adaptive(amd_ivf_t* h, size_t start, size_t n, size_t query_topk, float multipler, float std_m,
                             const float* require_acc, const float* gt_D, int profile, int coarse_mode, uint64_t* my_nprobe,
