@@ -182,6 +182,213 @@ done:
     rh_set(h, i, v, sv);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same heap for a small compile-time k, in SCALAR registers: node i is the pair (key[i], slot[i]) of named SGPRs, and the
+// walks are decision trees over compile-time node numbers -- a level is one s_max/s_min, two compares and a branch, with no
+// trip through v_readlane / v_writelane / M0 (each of those is a vector-to-scalar hand-off the lone wave waits out: the lane-
+// resident heap above spends ~1.3 k cycles an admission at k = 10).  S = the heap's current size (heap_reorder pops sizes K..1).
+template <int K> struct SHeap {
+    uint32_t key[K + 1], slot[K + 1];  // 1-based, Heap.h numbering
+};
+constexpr int SH_K = 10;  // the k that gets this form (the reference's harnesses ask for 10)
+
+// Heap.h:88-118 from node I down, (v, sv) = the pair of node S being re-placed (node S still takes part in the comparisons)
+template <bool IsMax, int K, int S, int I> __device__ __forceinline__ void sh_down(SHeap<K>& h, uint32_t v, uint32_t sv) {
+    constexpr int i1 = 2 * I, i2 = i1 + 1;
+    if constexpr (i1 > S) {
+        h.key[I] = v;
+        h.slot[I] = sv;
+    } else if constexpr (i2 == S + 1) {  // the left child only
+        if (kcmp<IsMax>(v, h.key[i1])) {
+            h.key[I] = v;
+            h.slot[I] = sv;
+        } else {
+            h.key[I] = h.key[i1];
+            h.slot[I] = h.slot[i1];
+            sh_down<IsMax, K, S, i1>(h, v, sv);
+        }
+    } else {
+        if (kcmp<IsMax>(h.key[i1], h.key[i2])) {
+            if (kcmp<IsMax>(v, h.key[i1])) {
+                h.key[I] = v;
+                h.slot[I] = sv;
+            } else {
+                h.key[I] = h.key[i1];
+                h.slot[I] = h.slot[i1];
+                sh_down<IsMax, K, S, i1>(h, v, sv);
+            }
+        } else {
+            if (kcmp<IsMax>(v, h.key[i2])) {
+                h.key[I] = v;
+                h.slot[I] = sv;
+            } else {
+                h.key[I] = h.key[i2];
+                h.slot[I] = h.slot[i2];
+                sh_down<IsMax, K, S, i2>(h, v, sv);
+            }
+        }
+    }
+}
+template <bool IsMax, int K, int S> __device__ __forceinline__ void sh_pop(SHeap<K>& h) { sh_down<IsMax, K, S, 1>(h, h.key[S], h.slot[S]); }
+
+// Heap.h:125-142 from node I up
+template <bool IsMax, int K, int I> __device__ __forceinline__ void sh_up(SHeap<K>& h, uint32_t v, uint32_t sv) {
+    if constexpr (I > 1) {
+        constexpr int F = I >> 1;
+        if (kcmp<IsMax>(v, h.key[F])) {
+            h.key[I] = h.key[F];
+            h.slot[I] = h.slot[F];
+            sh_up<IsMax, K, F>(h, v, sv);
+            return;
+        }
+    }
+    h.key[I] = v;
+    h.slot[I] = sv;
+}
+template <bool IsMax, int K> __device__ __forceinline__ void sh_push(SHeap<K>& h, uint32_t v, uint32_t sv) { sh_up<IsMax, K, K>(h, v, sv); }
+
+// LDS heap arrays (node order) -> scalar registers, by way of one lane per node
+template <int K> __device__ __forceinline__ void sh_load(SHeap<K>& h, const float* hval, int lane) {
+    const uint32_t kv = (lane >= 1 && lane <= K) ? fkey(hval[lane - 1]) : 0u;
+    h.key[0] = h.slot[0] = 0;
+#pragma unroll
+    for (int i = 1; i <= K; i++) {
+        h.key[i] = rl_u(kv, i);
+        h.slot[i] = (uint32_t)(i - 1);
+    }
+}
+// ... and back (lane i <- node i), in the form rh_store takes
+template <int K> __device__ __forceinline__ void sh_to_lanes(const SHeap<K>& h, int lane, uint32_t& v0, uint32_t& s0) {
+    v0 = 0;
+    s0 = 0;
+#pragma unroll
+    for (int i = 1; i <= K; i++) {
+        v0 = lane == i ? h.key[i] : v0;
+        s0 = lane == i ? h.slot[i] : s0;
+    }
+}
+
+// heap_reorder's pops (Heap.h:295-322), sizes S = K .. 1: the popped root goes to lane `ii` of (out_key, out_slot) unless its id is -1
+template <bool IsMax, int K, int S> __device__ __forceinline__ void sh_drain(SHeap<K>& h, const int64_t* href, uint32_t& out_key, uint32_t& out_slot, int& ii) {
+    if constexpr (S >= 1) {
+        const uint32_t rk = h.key[1], rs = h.slot[1];
+        const int64_t id = href[rs];
+        const bool valid = __builtin_amdgcn_readfirstlane((int)(id != -1)) != 0;
+        sh_pop<IsMax, K, S>(h);
+        if (valid) {
+            wl2_u(out_key, (uint32_t)__builtin_amdgcn_readfirstlane((int)rk), out_slot, (uint32_t)__builtin_amdgcn_readfirstlane((int)rs), ii);
+            ii++;
+        }
+        sh_drain<IsMax, K, S - 1>(h, href, out_key, out_slot, ii);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ... and for k = 100: the keys of nodes 1 .. NS - 1 (the upper levels, which every walk crosses) in scalar registers, the rest
+// and all id slots in lanes as in RegHeap (node i: lane i & 63 of register i >> 6) -- but every node number in the walk is a
+// compile-time constant, so a lane access is one v_readlane / v_writelane with an immediate lane (no M0, no index arithmetic)
+// and a step between scalar-resident levels is three scalar compares and a move.
+template <int K, int NS> struct THeap {
+    uint32_t top[NS];  // [0] unused
+    RegHeap r;         // keys of nodes >= NS; slots of every node
+};
+template <int N, int K, int NS> __device__ __forceinline__ uint32_t th_key(const THeap<K, NS>& h) {
+    if constexpr (N < NS) return h.top[N];
+    else if constexpr (N < 64) return rl_u(h.r.v0, N);
+    else return rl_u(h.r.v1, N - 64);
+}
+template <int L> __device__ __forceinline__ uint32_t wl_imm(uint32_t reg, uint32_t val) {  // reg[lane L] = val (wave-uniform)
+    asm("v_writelane_b32 %[r], %[v], %[l]" : [r] "+v"(reg) : [v] "s"((uint32_t)__builtin_amdgcn_readfirstlane((int)val)), [l] "n"(L));
+    return reg;
+}
+template <int N, int K, int NS> __device__ __forceinline__ void th_set_key(THeap<K, NS>& h, uint32_t x) {
+    if constexpr (N < NS) h.top[N] = x;
+    else if constexpr (N < 64) h.r.v0 = wl_imm<N>(h.r.v0, x);
+    else h.r.v1 = wl_imm<N - 64>(h.r.v1, x);
+}
+template <int N, int K, int NS> __device__ __forceinline__ uint32_t th_slot(const THeap<K, NS>& h) {
+    if constexpr (N < 64) return rl_u(h.r.s0, N);
+    else return rl_u(h.r.s1, N - 64);
+}
+template <int N, int K, int NS> __device__ __forceinline__ void th_set_slot(THeap<K, NS>& h, uint32_t x) {
+    if constexpr (N < 64) h.r.s0 = wl_imm<N>(h.r.s0, x);
+    else h.r.s1 = wl_imm<N - 64>(h.r.s1, x);
+}
+template <int N, int C, int K, int NS> __device__ __forceinline__ void th_move_up(THeap<K, NS>& h, uint32_t ckey) {  // node N <- child C
+    th_set_key<N>(h, ckey);
+    th_set_slot<N>(h, th_slot<C>(h));
+}
+// Heap.h:88-118 from node I down (see sh_down)
+template <bool IsMax, int K, int NS, int I> __device__ __forceinline__ void th_down(THeap<K, NS>& h, uint32_t v, uint32_t sv) {
+    constexpr int i1 = 2 * I, i2 = i1 + 1;
+    if constexpr (i1 > K) {
+        th_set_key<I>(h, v);
+        th_set_slot<I>(h, sv);
+    } else if constexpr (i2 == K + 1) {
+        const uint32_t k1 = th_key<i1>(h);
+        if (kcmp<IsMax>(v, k1)) {
+            th_set_key<I>(h, v);
+            th_set_slot<I>(h, sv);
+        } else {
+            th_move_up<I, i1>(h, k1);
+            th_down<IsMax, K, NS, i1>(h, v, sv);
+        }
+    } else {
+        const uint32_t k1 = th_key<i1>(h), k2 = th_key<i2>(h);
+        if (kcmp<IsMax>(k1, k2)) {
+            if (kcmp<IsMax>(v, k1)) {
+                th_set_key<I>(h, v);
+                th_set_slot<I>(h, sv);
+            } else {
+                th_move_up<I, i1>(h, k1);
+                th_down<IsMax, K, NS, i1>(h, v, sv);
+            }
+        } else {
+            if (kcmp<IsMax>(v, k2)) {
+                th_set_key<I>(h, v);
+                th_set_slot<I>(h, sv);
+            } else {
+                th_move_up<I, i2>(h, k2);
+                th_down<IsMax, K, NS, i2>(h, v, sv);
+            }
+        }
+    }
+}
+template <bool IsMax, int K, int NS> __device__ __forceinline__ void th_pop(THeap<K, NS>& h) {
+    th_down<IsMax, K, NS, 1>(h, th_key<K>(h), th_slot<K>(h));
+}
+// Heap.h:125-142 from node I up
+template <bool IsMax, int K, int NS, int I> __device__ __forceinline__ void th_up(THeap<K, NS>& h, uint32_t v, uint32_t sv) {
+    if constexpr (I > 1) {
+        constexpr int F = I >> 1;
+        const uint32_t fk = th_key<F>(h);
+        if (kcmp<IsMax>(v, fk)) {
+            th_move_up<I, F>(h, fk);  // (node I <- its father)
+            th_up<IsMax, K, NS, F>(h, v, sv);
+            return;
+        }
+    }
+    th_set_key<I>(h, v);
+    th_set_slot<I>(h, sv);
+}
+template <bool IsMax, int K, int NS> __device__ __forceinline__ void th_push(THeap<K, NS>& h, uint32_t v, uint32_t sv) { th_up<IsMax, K, NS, K>(h, v, sv); }
+template <int K, int NS, int I = 1> __device__ __forceinline__ void th_tops_from_lanes(THeap<K, NS>& h) {
+    if constexpr (I < NS) {
+        h.top[I] = rl_u(h.r.v0, I);
+        th_tops_from_lanes<K, NS, I + 1>(h);
+    }
+}
+template <int K, int NS, int I = 1> __device__ __forceinline__ void th_tops_to_lanes(THeap<K, NS>& h) {
+    if constexpr (I < NS) {
+        h.r.v0 = wl_imm<I>(h.r.v0, h.top[I]);
+        th_tops_to_lanes<K, NS, I + 1>(h);
+    }
+}
+#ifndef AUNCEL_TH_NS
+#define AUNCEL_TH_NS 32
+#endif
+constexpr int TH_K = 100, TH_NS = AUNCEL_TH_NS > 1 ? AUNCEL_TH_NS : 2;  // (AUNCEL_TH_NS 0: the lane-resident heap, for comparison)
+
 // LDS heap arrays (node order) -> registers; slot j holds the id of node j + 1
 __device__ __forceinline__ void rh_load(RegHeap& h, const float* hval, int k, int lane) {
     h.v0 = (lane >= 1 && lane <= k) ? fkey(hval[lane - 1]) : 0u;
@@ -1426,13 +1633,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 
         gp = (uint32_t)__builtin_amdgcn_readfirstlane((int)gp);
         const int at = sr_insert<TWO>(sr, ckey, gp, lane);
         ins_min = at < ins_min ? at : ins_min;
-        if (logn >= a.log_cap) {
+        const uint32_t ln = (uint32_t)__builtin_amdgcn_readfirstlane((int)logn);
+        if (ln >= a.log_cap) {
             err = ERR_LOG_OVERFLOW;
         } else {
-            wl2_u(log_v, (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(val)), log_g, gp,
-                  __builtin_amdgcn_readfirstlane((int)(logn & 63u)));
-            if ((logn & 63u) == 63u) qlog[(logn & ~63u) + lane] = make_uint2(log_v, log_g);
-            logn++;
+            const bool me = (uint32_t)lane == (ln & 63u);  // (a compare and two selects: a v_writelane pair through M0 is six instructions)
+            log_v = me ? __float_as_uint(val) : log_v;
+            log_g = me ? gp : log_g;
+            if ((ln & 63u) == 63u) qlog[(ln & ~63u) + lane] = make_uint2(log_v, log_g);
+            logn = ln + 1;
         }
         st_nheap++;
         // the entry that left was one of several equal worst values iff the new worst equals it (the new value is strictly better)
@@ -1481,7 +1690,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 
 
     // ---- the candidate stream
     // dense: R0..R3 hold blocks bpos .. bpos + 3 (in ring order starting at `slot`)
-    const f4* region4 = reinterpret_cast<const f4*>(a.dist + region_off) + lane;  // block b: region4[b * 64]
+    // A block of 256 candidates comes in with four 4-byte loads a lane -- component c of lane l is candidate 64 c + l -- so that the
+    // ballot of a component lists its candidates in scan order and a candidate is reached with one ctz and one v_readlane (with one
+    // 16-byte load a lane, candidate 4 l + c, the four ballots had to be interleaved lane by lane: ~30 scalar instructions a hit).
+    const float* regionf = a.dist + region_off + lane;  // block b, component c: regionf[b * 256 + c * 64]
+    auto load_block = [&](const float* p) {
+        f4 r;
+        r.x = __builtin_nontemporal_load(p);
+        r.y = __builtin_nontemporal_load(p + 64);
+        r.z = __builtin_nontemporal_load(p + 128);
+        r.w = __builtin_nontemporal_load(p + 192);
+        return r;
+    };
     f4 R0, R1, R2, R3;
     uint32_t gpos = 0;  // group of four blocks held in R0..R3
     // masked: W = the mask words of step `step` (word step * 64 + lane of the region), Wn = the next step's
@@ -1490,43 +1710,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 
     unsigned long long W = 0, Wn = 0;
     uint32_t wstep = 0;           // words [wstep * 64, wstep * 64 + 64) are in W
     if (!MASKED) {
-        R0 = __builtin_nontemporal_load(region4);
-        R1 = __builtin_nontemporal_load(region4 + 64);
-        R2 = __builtin_nontemporal_load(region4 + 128);
-        R3 = __builtin_nontemporal_load(region4 + 192);
+        R0 = load_block(regionf);
+        R1 = load_block(regionf + 256);
+        R2 = load_block(regionf + 512);
+        R3 = load_block(regionf + 768);
     } else if (!lists) {
         W = __builtin_nontemporal_load(rmask);
         Wn = __builtin_nontemporal_load(rmask + 64);
     }
     uint32_t wpos = 0;  // masked: first word of the current row (region word index)
 
-    // a block of 256 candidates (lane l: candidates 4l .. 4l + 3, the block's first is number c0 of its list) in which
+    // a block of 256 candidates (component c of lane l: candidate 64 c + l; the block's first is number c0 of its list) in which
     // something may beat the worst of the k, or that holds the padding behind the row's end
     auto dense_block = [&](const f4 x, uint32_t c0, uint32_t n, uint32_t lbase, uint32_t taken) {
         const uint32_t valid = n > c0 ? n - c0 : 0u;  // candidates of the row in this block (>= 256: all)
         const uint32_t skip = taken > c0 ? taken - c0 : 0u;  // ... of which the first `skip` are in the array already (fill_first_k)
-        const uint32_t p4 = 4u * lane;
-        const unsigned long long h0 = __ballot(hcmp<IsMax>(top, x.x) && p4 < valid && p4 >= skip);
-        const unsigned long long h1 = __ballot(hcmp<IsMax>(top, x.y) && p4 + 1 < valid && p4 + 1 >= skip);
-        const unsigned long long h2 = __ballot(hcmp<IsMax>(top, x.z) && p4 + 2 < valid && p4 + 2 >= skip);
-        const unsigned long long h3 = __ballot(hcmp<IsMax>(top, x.w) && p4 + 3 < valid && p4 + 3 >= skip);
-        unsigned long long any = h0 | h1 | h2 | h3;
-        while (any) {
-            const int l = __builtin_ctzll(any);
-            any &= any - 1;
-            const uint32_t g0 = lbase + c0 + 4u * (uint32_t)l;
-            // the lane's candidates in position order; one admission site
-            uint32_t nib = (uint32_t)((h0 >> l) & 1) | ((uint32_t)((h1 >> l) & 1) << 1) | ((uint32_t)((h2 >> l) & 1) << 2) |
-                           ((uint32_t)((h3 >> l) & 1) << 3);
-            const float v0 = rl_f(x.x, l), v1 = rl_f(x.y, l), v2 = rl_f(x.z, l), v3 = rl_f(x.w, l);
-            while (nib) {
-                const int sidx = __builtin_ctz(nib);
-                nib &= nib - 1;
-                const float val = sidx == 0 ? v0 : sidx == 1 ? v1 : sidx == 2 ? v2 : v3;
+        const uint32_t p0 = (uint32_t)lane, p1 = 64u + lane, p2 = 128u + lane, p3 = 192u + lane;
+        const unsigned long long h0 = __ballot(hcmp<IsMax>(top, x.x) && p0 < valid && p0 >= skip);
+        const unsigned long long h1 = __ballot(hcmp<IsMax>(top, x.y) && p1 < valid && p1 >= skip);
+        const unsigned long long h2 = __ballot(hcmp<IsMax>(top, x.z) && p2 < valid && p2 >= skip);
+        const unsigned long long h3 = __ballot(hcmp<IsMax>(top, x.w) && p3 < valid && p3 >= skip);
+        auto walk = [&](unsigned long long h, const float xc, uint32_t g0) {  // one component's hits, in scan order
+            while (h) {
+                const int l = __builtin_ctzll(h);
+                h &= h - 1;
+                const float val = rl_f(xc, l);
                 const uint32_t ck = okey<IsMax>(val);  // (it beat an earlier worst in the vector compare: not a NaN)
-                if (ck < topk) admit(val, ck, g0 + (uint32_t)sidx);
+                if (ck < topk) admit(val, ck, g0 + (uint32_t)l);
             }
-        }
+        };
+        const uint32_t g0 = lbase + c0;
+        walk(h0, x.x, g0);
+        walk(h1, x.y, g0 + 64u);
+        walk(h2, x.z, g0 + 128u);
+        walk(h3, x.w, g0 + 192u);
     };
 
     // The first min(k, n) candidates of a search all enter (the array is empty): ranked against each other at once instead of
@@ -1541,11 +1758,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 
         // taken here and the block goes through the one-by-one admission like any other.
         bool bad = false;
 #pragma unroll
-        for (int c = 0; c < 4; c++) bad = bad || (4u * lane + c < m && okey<IsMax>(xs[c]) >= SKEY_SENT);
+        for (int c = 0; c < 4; c++) bad = bad || (64u * c + lane < m && okey<IsMax>(xs[c]) >= SKEY_SENT);
         if (__ballot(bad) != 0) return 0u;
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            const uint32_t j = 4u * lane + c;
+            const uint32_t j = 64u * c + lane;
             if (j < m) {
                 fk[j] = okey<IsMax>(xs[c]);
                 fv[j] = __float_as_uint(xs[c]);
@@ -1624,11 +1841,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 
                         fresh = false;
                     }
                     for (uint32_t g = 0; g < ngrp; g++) {
-                        const f4* nxt = region4 + (size_t)(gpos + 1) * 256;
+                        const float* nxt = regionf + (size_t)(gpos + 1) * 1024;
 #define SEL_BLOCK(R, U)                                                                                                       \
     {                                                                                                                         \
         const f4 x = R;                                                                                                       \
-        R = __builtin_nontemporal_load(nxt + (U) * 64);                                                                       \
+        R = load_block(nxt + (U) * 256);                                                                                      \
         const float best = IsMax ? fminf(fminf(fminf(x.x, x.y), x.z), x.w) : fmaxf(fmaxf(fmaxf(x.x, x.y), x.z), x.w);         \
         if (__ballot(hcmp<IsMax>(top, best)) != 0) dense_block(x, g * 1024u + (U) * 256u, n, lbase, taken);                   \
     }
@@ -2034,7 +2251,16 @@ __global__ __launch_bounds__(256) void tie_fix_kernel(TieFixArgs a) {
     }
     wave_sync();
     RegHeap rh{};
-    if (RH) rh_load(rh, hval, k, lane);
+    constexpr bool SH = RH && KC == SH_K;  // the heap in scalar registers
+    constexpr bool TH = RH && KC == TH_K && AUNCEL_TH_NS > 1;  // ... its upper levels
+    SHeap<SH_K> sh;
+    THeap<TH_K, TH_NS> th;
+    if (SH) sh_load<SH_K>(sh, hval, lane);
+    else if (RH) rh_load(rh, hval, k, lane);
+    if constexpr (TH) {
+        th.r = rh;
+        th_tops_from_lanes(th);
+    }
     const uint2* qlog = a.log + (size_t)qi * a.log_cap;
     uint2 e = pos + lane < n ? qlog[pos + lane] : make_uint2(0u, 0u);
     for (uint32_t b = pos; b < n; b += 64) {
@@ -2044,7 +2270,17 @@ __global__ __launch_bounds__(256) void tie_fix_kernel(TieFixArgs a) {
         for (uint32_t l = 0; l < cnt; l++) {
             const float val = __uint_as_float(rl_u(cur.x, (int)l));
             const int64_t g = (int64_t)rl_u(cur.y, (int)l);
-            if (RH) {
+            if constexpr (SH) {
+                const uint32_t sr = sh.slot[1];
+                if (lane == 0) href[sr] = g;
+                sh_pop<IsMax, SH_K, SH_K>(sh);
+                sh_push<IsMax, SH_K>(sh, fkey(val), sr);
+            } else if constexpr (TH) {
+                const uint32_t sr = th_slot<1>(th);
+                if (lane == 0) href[sr] = g;
+                th_pop<IsMax>(th);
+                th_push<IsMax>(th, fkey(val), sr);
+            } else if (RH) {
                 const uint32_t sr = rl_u(rh.s0, 1);
                 if (lane == 0) href[sr] = g;
                 if (KC == 100) rh_pop_k100<IsMax>(rh);
@@ -2057,8 +2293,13 @@ __global__ __launch_bounds__(256) void tie_fix_kernel(TieFixArgs a) {
             }
         }
     }
+    if constexpr (TH) {
+        th_tops_to_lanes(th);
+        rh = th.r;
+    }
     wave_sync();
     if (!fin) {
+        if (SH) sh_to_lanes<SH_K>(sh, lane, rh.v0, rh.s0);
         if (RH) rh_store(rh, hval, href, k, lane, true);
         for (int i = lane; i < k; i += 64) {
             a.fix_val[(size_t)qi * k + i] = hval[i];
@@ -2073,7 +2314,8 @@ __global__ __launch_bounds__(256) void tie_fix_kernel(TieFixArgs a) {
         // (in registers: the popped root's value and id slot go to a staging pair, one lane per output position)
         uint32_t out_key = 0, out_slot = 0;  // lane j <-> output position k - 1 - j (and k - 65 - j in the second pair)
         uint32_t out_key2 = 0, out_slot2 = 0;
-        for (int i = 0; i < k; i++) {
+        if (SH) sh_drain<IsMax, SH_K, SH_K>(sh, href, out_key, out_slot, ii);
+        else for (int i = 0; i < k; i++) {
             const uint32_t rk = rl_u(rh.v0, 1), rs = rl_u(rh.s0, 1);
             const int64_t id = href[rs];  // (uniform LDS read)
             rh_pop<IsMax, 0>(rh, k - i);
