@@ -747,27 +747,39 @@ __device__ __forceinline__ uint32_t wave_shr1(uint32_t x, uint32_t carry) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
 
-__device__ __forceinline__ uint32_t sr_key(const SortedRegs& r, int i) { return i < 64 ? rl_u(r.k0, i) : rl_u(r.k1, i - 64); }
+// Two registers (k > 64) hold the array INTERLEAVED: entry i is lane i >> 1 of register i & 1.  An insertion moves every worse
+// entry one place down: an odd entry takes its even neighbour's place-mate of the same lane (no lane crossing at all), an even entry
+// takes the odd entry of the lane to its left -- one wave shift per payload register instead of two shifts, two carries between the
+// registers (v_readlane + v_mov each) and an early-out branch.  One register (k <= 64): entry i is lane i.
+template <bool TWO> __device__ __forceinline__ uint32_t sr_key(const SortedRegs& r, int i) {
+    if (!TWO) return rl_u(r.k0, i);
+    const uint32_t a = rl_u(r.k0, i >> 1), b = rl_u(r.k1, i >> 1);
+    return (i & 1) ? b : a;
+}
+template <bool TWO> __device__ __forceinline__ int sr_e0(int lane) { return TWO ? 2 * lane : lane; }      // entry held in k0 / g0
+template <bool TWO> __device__ __forceinline__ int sr_e1(int lane) { return TWO ? 2 * lane + 1 : 128; }   // ... in k1 / g1
 
 // insert (key, gpos) behind the entries that are <= key; everything worse moves down one place (the old entry k - 1 is
-// thereby evicted: it slides into the unused tail).  Returns the position taken.  Lane i takes the new entry iff its own key
-// is worse and its left neighbour's is not; the lanes to its right take their left neighbour's entry.
+// thereby evicted: it slides into the unused tail).  Returns the position taken.  An entry takes the new one iff its own key
+// is worse and its predecessor's is not; the entries behind it take their predecessor's.
 template <bool TWO> __device__ __forceinline__ int sr_insert(SortedRegs& r, uint32_t key, uint32_t gpos, int lane) {
     (void)lane;
     const bool w0 = r.k0 > key;
-    const unsigned long long m0 = __ballot(w0);
-    int at = 128 - __builtin_popcountll(m0);
     if (TWO) {
         const bool w1 = r.k1 > key;
-        at -= __builtin_popcountll(__ballot(w1));
-        const uint32_t t1 = wave_shr1(r.k1, rl_u(r.k0, 63)), u1 = wave_shr1(r.g1, rl_u(r.g0, 63));
-        const bool p1 = t1 > key;  // the left neighbour moves too: take its entry, else this is the gap
-        r.k1 = w1 ? (p1 ? t1 : key) : r.k1;
-        r.g1 = w1 ? (p1 ? u1 : gpos) : r.g1;
-        if (m0 == 0) return at;
-    } else {
-        at -= 64;
+        const int at = 128 - __builtin_popcountll(__ballot(w0)) - __builtin_popcountll(__ballot(w1));
+        // entry 2l: predecessor = entry 2l - 1 = lane l - 1 of register 1 (entry 0: none -- nothing is better than key 0)
+        const uint32_t t0 = wave_shr1(r.k1, 0u), u0 = wave_shr1(r.g1, 0u);
+        const bool p0 = t0 > key;
+        // entry 2l + 1: predecessor = entry 2l = this lane's k0, and "it moves too" is w0
+        const uint32_t n1k = w0 ? r.k0 : key, n1g = w0 ? r.g0 : gpos;
+        r.k1 = w1 ? n1k : r.k1;
+        r.g1 = w1 ? n1g : r.g1;
+        r.k0 = w0 ? (p0 ? t0 : key) : r.k0;
+        r.g0 = w0 ? (p0 ? u0 : gpos) : r.g0;
+        return at;
     }
+    const int at = 64 - __builtin_popcountll(__ballot(w0));
     const uint32_t t0 = wave_shr1(r.k0, 0u), u0 = wave_shr1(r.g0, 0u);  // (lane 0's left neighbour: nothing is better than key 0)
     const bool p0 = t0 > key;
     r.k0 = w0 ? (p0 ? t0 : key) : r.k0;
@@ -1476,13 +1488,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 
 
     // ---- state
     SortedRegs sr{0xffffffffu, 0xffffffffu, SPOS_NONE, SPOS_NONE};
-    if (lane < k) {
-        sr.k0 = okey<IsMax>(a.heap_val[(size_t)qi * k + lane]);
-        sr.g0 = (uint32_t)a.heap_ref[(size_t)qi * k + lane];
+    const int e0 = sr_e0<TWO>(lane), e1 = sr_e1<TWO>(lane);  // the array entries this lane holds (in k0 / g0 and k1 / g1)
+    if (e0 < k) {
+        sr.k0 = okey<IsMax>(a.heap_val[(size_t)qi * k + e0]);
+        sr.g0 = (uint32_t)a.heap_ref[(size_t)qi * k + e0];
     }
-    if (TWO && lane + 64 < k) {
-        sr.k1 = okey<IsMax>(a.heap_val[(size_t)qi * k + lane + 64]);
-        sr.g1 = (uint32_t)a.heap_ref[(size_t)qi * k + lane + 64];
+    if (TWO && e1 < k) {
+        sr.k1 = okey<IsMax>(a.heap_val[(size_t)qi * k + e1]);
+        sr.g1 = (uint32_t)a.heap_ref[(size_t)qi * k + e1];
     }
     uint32_t amb = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.amb[qi]);
     uint32_t logn = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.log_cnt[qi]);
@@ -1493,12 +1506,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 
         log_v = e.x;
         log_g = e.y;
     }
-    auto worst_key = [&]() { return sr_key(sr, k - 1); };
+    auto worst_key = [&]() { return sr_key<TWO>(sr, k - 1); };
     uint32_t topk = worst_key();          // the worst of the k: what a candidate has to beat (as an order key, for the scalar unit,
     float top = okey_inv<IsMax>(topk);    // and as the float the vector compares take)
     auto srt_from_regs = [&]() {
-        if (lane < k) srt[lane] = okey_inv<IsMax>(sr.k0);
-        if (TWO && lane + 64 < k) srt[lane + 64] = okey_inv<IsMax>(sr.k1);
+        if (e0 < k) srt[e0] = okey_inv<IsMax>(sr.k0);
+        if (TWO && e1 < k) srt[e1] = okey_inv<IsMax>(sr.k1);
     };
     if (TUNE) {
         srt_from_regs();
@@ -1572,13 +1585,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 
         const uint32_t nadm = (uint32_t)__builtin_popcountll(am);
         if (nadm) {
             const uint32_t rank = pa + w + later;  // place of an admitted candidate among (array + admitted), by (value, arrival)
-            const uint32_t r0 = (uint32_t)lane + sh0, r1 = 64u + (uint32_t)lane + sh1;  // ... of the array's own entries
+            const uint32_t r0 = (uint32_t)e0 + sh0, r1 = (uint32_t)e1 + sh1;  // ... of the array's own entries
             wave_sync();
-            if ((int)lane < k && r0 < (uint32_t)k) {
+            if (e0 < k && r0 < (uint32_t)k) {
                 mk[r0] = sr.k0;
                 mg[r0] = sr.g0;
             }
-            if (TWO && (int)lane + 64 < k && r1 < (uint32_t)k) {
+            if (TWO && e1 < k && r1 < (uint32_t)k) {
                 mk[r1] = sr.k1;
                 mg[r1] = sr.g1;
             }
@@ -1598,18 +1611,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 
             const unsigned long long top_in = __ballot(adm && rank < query_k);
             if (top_in) ins_min = 0;  // (an admitted value among the first query_k: the rule's inputs changed)
             wave_sync();
-            const bool l0 = (int)lane < k, l1 = TWO && (int)lane + 64 < k;
+            const bool l0 = e0 < k, l1 = TWO && e1 < k;
             // what left: an array entry or an admitted candidate whose place is k or beyond
             const uint32_t wk = mk[k - 1];
             const bool out0 = l0 && r0 >= (uint32_t)k && sr.k0 == wk, out1 = l1 && r1 >= (uint32_t)k && sr.k1 == wk;
             const bool outc = adm && rank >= (uint32_t)k && B_k == wk;
             if (l0) {
-                sr.k0 = mk[lane];
-                sr.g0 = mg[lane];
+                sr.k0 = mk[e0];
+                sr.g0 = mg[e0];
             }
             if (l1) {
-                sr.k1 = mk[64 + lane];
-                sr.g1 = mg[64 + lane];
+                sr.k1 = mk[e1];
+                sr.g1 = mg[e1];
             }
             // a value of which a copy left while this one stays: the new worst equals something that left (the new values are
             // strictly better than the old worst, so only then can equal worst values have been split)
@@ -1788,13 +1801,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 
             sg[r1] = fg[j1];
         }
         wave_sync();
-        if (j0 < m) {
-            sr.k0 = sk[j0];
-            sr.g0 = sg[j0];
+        if ((uint32_t)e0 < m) {
+            sr.k0 = sk[e0];
+            sr.g0 = sg[e0];
         }
-        if (TWO && j1 < m) {
-            sr.k1 = sk[j1];
-            sr.g1 = sg[j1];
+        if (TWO && (uint32_t)e1 < m) {
+            sr.k1 = sk[e1];
+            sr.g1 = sg[e1];
         }
         // the admission log holds them in arrival order; its open block goes to the staging registers
         logn = m;
@@ -1809,7 +1822,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 
         wave_sync();
         return m;
     };
-    bool fresh = !MASKED && logn == 0 && sr_key(sr, 0) == SKEY_SENT;  // nothing admitted yet in this search
+    bool fresh = !MASKED && logn == 0 && sr_key<TWO>(sr, 0) == SKEY_SENT;  // nothing admitted yet in this search
 
     bool finished = false;
     uint32_t consumed = 0;
@@ -2098,10 +2111,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 
     }
     // the open block of the admission log
     if (!AUNCEL_SEL_BATCH && (uint32_t)lane < (logn & 63u)) qlog[(logn & ~63u) + lane] = make_uint2(log_v, log_g);
-    const bool in0 = lane < k, in1 = TWO && lane + 64 < k;
+    const bool in0 = e0 < k, in1 = TWO && e1 < k;
     if (finished || a.finalize_all || err) {
         // equal values among the k (their order is the heap's), or a value of which a copy was evicted while this one stayed
-        const uint32_t p0 = wave_shr1(sr.k0, 0xfffffffeu), p1 = TWO ? wave_shr1(sr.k1, rl_u(sr.k0, 63)) : 0u;
+        // (an entry's predecessor: one register -- the lane to the left; two -- see sr_insert)
+        const uint32_t p0 = wave_shr1(TWO ? sr.k1 : sr.k0, 0xfffffffeu), p1 = sr.k0;
         const bool dup = (in0 && lane >= 1 && sr.k0 == p0 && sr.k0 != SKEY_SENT) || (in1 && sr.k1 == p1 && sr.k1 != SKEY_SENT);
         const bool tainted = __ballot(dup) != 0 || worst_key() == amb;
         if (tainted && !err) {
@@ -2117,18 +2131,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MASKED ? 4 
                 a.D[(size_t)qi * k + i] = empty ? hneutral<IsMax>() : okey_inv<IsMax>(key);
                 a.I[(size_t)qi * k + i] = id;
             };
-            if (in0) put(lane, sr.k0, sr.g0);
-            if (in1) put(lane + 64, sr.k1, sr.g1);
+            if (in0) put(e0, sr.k0, sr.g0);
+            if (in1) put(e1, sr.k1, sr.g1);
         }
         if (lane == 0) a.done[qi] = 1;
     } else {
         if (in0) {
-            a.heap_val[(size_t)qi * k + lane] = okey_inv<IsMax>(sr.k0);
-            a.heap_ref[(size_t)qi * k + lane] = sr.g0 == SPOS_NONE ? -1 : (int64_t)sr.g0;
+            a.heap_val[(size_t)qi * k + e0] = okey_inv<IsMax>(sr.k0);
+            a.heap_ref[(size_t)qi * k + e0] = sr.g0 == SPOS_NONE ? -1 : (int64_t)sr.g0;
         }
         if (in1) {
-            a.heap_val[(size_t)qi * k + lane + 64] = okey_inv<IsMax>(sr.k1);
-            a.heap_ref[(size_t)qi * k + lane + 64] = sr.g1 == SPOS_NONE ? -1 : (int64_t)sr.g1;
+            a.heap_val[(size_t)qi * k + e1] = okey_inv<IsMax>(sr.k1);
+            a.heap_ref[(size_t)qi * k + e1] = sr.g1 == SPOS_NONE ? -1 : (int64_t)sr.g1;
         }
         if (lane == 0) {
             a.amb[qi] = amb;
