@@ -73,6 +73,8 @@ enum OptId {
     OPT_ROW_LISTS,      // threshold rounds of calls of >= 256 queries: the rows' marked candidates compacted into short lists before the
                         // selection (1, compact_rows_kernel) or found by the selection itself in the masks (0); unset: lists when no
                         // other search of the index is running
+    OPT_LANES,          // fp32 dense rounds from a lane-ordered copy of the lists (1, scan_lanes_kernel: one coalesced KiB per 64 vectors and
+                        // step, no LDS staging) or from the rows (0, scan_tiles_kernel); the copy costs the lists' bytes once more
     N_OPT
 };
 struct OptSpec {
@@ -96,6 +98,7 @@ const OptSpec OPT_TABLE[N_OPT] = {
     {"phase_timing", "AUNCEL_AMD_PHASE_TIMING", nullptr},
     {"pinned_io", "AUNCEL_AMD_PINNED_IO", nullptr},
     {"row_lists", "AUNCEL_AMD_ROW_LISTS", nullptr},
+    {"lanes", "AUNCEL_AMD_LANES", nullptr},
 };
 struct Options {
     // (atomic: amd_ivf_set_option on the owner may run while search contexts cloned from it are searching; a search reads the
@@ -380,6 +383,9 @@ struct amd_ivf {
     // fp32 copy of the lists in fragment order + |y|^2 / |y| per slot (ivf_filter.hip), kept when the data does not qualify for
     // byte codes: threshold rounds run as a matrix-core filter over it, the exact distance only for what the filter keeps
     DevBuf d_frag32, d_yn;
+    double probed_len = 0;                 // expected length of the list a query probes: sum(len^2) / sum(len) (upload_lists)
+    DevBuf d_lanes;                        // the fp32 lists in lane order (ScanArgs::lanes), built by the first fp32 dense round
+    std::atomic<int> lanes_state{0};       // 0 not tried, 1 there, -1 not possible
     std::atomic<bool> have_frag32{false};  // (read without the lock by search contexts: ensure_frag32's double-checked creation)
     bool frag32_possible = false;
     // the fp16 form of the filter's list copy (ivf_filter.hip): scaled halves in fragment order + the range they were scaled by
@@ -655,8 +661,20 @@ void upload_lists(amd_ivf* h) {
     // that wants it: ensure_frag16 / ensure_frag32)
     h->have_frag32 = false;
     h->frag16_state = 0;
+    h->lanes_state = 0;
     h->frag32_possible = h->allow_filter && nt > 0 && nt < 0xffffffffull;
-    if (h->have_codes8 || h->frag32_possible) {
+    {
+        double s1 = 0, s2 = 0;
+        for (size_t l = 0; l < h->nlist; l++) {
+            const double len = (double)h->h_ids[l].size();
+            s1 += len;
+            s2 += len * len;
+        }
+        h->probed_len = s1 > 0 ? s2 / s1 : 0.0;
+    }
+    h->h_block_off.clear();
+    h->d_lanes.release();
+    if (nt > 0) {  // (the block table of every padded copy: byte codes, the filter's fragments, the dense rounds' lane order)
         h->h_block_off.assign(h->nlist + 1, 0);
         for (size_t l = 0; l < h->nlist; l++) h->h_block_off[l + 1] = h->h_block_off[l] + mfma_list_blocks(h->h_ids[l].size());
         h->d_block_off.ensure((h->nlist + 1) * sizeof(uint64_t));
@@ -751,12 +769,44 @@ void ensure_frag32(amd_ivf* index) {
     HIP_CHECK(stream_sync(index->stream));
     index->have_frag32 = true;
 }
+// the lane-ordered copy for the dense rounds of an fp32 search (option "lanes"); null where the block table is missing or the block
+// numbers do not fit an item's upper bits (scan_vec_base)
+const float* ensure_lanes(amd_ivf* index) {
+    if (index->opt.get(OPT_LANES, 1) == 0) return nullptr;
+    int st = index->lanes_state.load(std::memory_order_acquire);
+    if (st == 0) {
+        std::lock_guard<std::mutex> lock(index->upload_mu);
+        st = index->lanes_state.load(std::memory_order_acquire);
+        if (st == 0) {
+            const uint64_t nt = index->h_list_off[index->nlist];
+            const uint64_t nblk64 = index->h_block_off.empty() ? 0 : index->h_block_off[index->nlist] / 2;
+            if (nblk64 == 0 || nblk64 >= (1ull << (64 - SCAN_VB_BITS)) || nt >= (1ull << SCAN_VB_BITS)) {
+                st = -1;
+            } else {
+                use_device(index);
+                index->d_lanes.ensure(nblk64 * (uint64_t)index->dpad * 64 * sizeof(float));
+                launch_lanes_from_f32(index->d_codes.as<float>(), index->d_list_off.as<uint64_t>(), index->d_block_off.as<uint64_t>(), (uint32_t)index->nlist,
+                                      nblk64, index->dpad, index->d_lanes.as<float>(), index->stream);
+                HIP_CHECK(stream_sync(index->stream));
+                st = 1;
+            }
+            index->lanes_state.store(st, std::memory_order_release);
+        }
+    }
+    return st > 0 ? index->d_lanes.as<float>() : nullptr;
+}
 // Dense probes ahead of the filter: the k-th best of the first f lists is the threshold everything else is filtered with, and
-// about k / (f x mean list length) of the later candidates get under it; f is chosen to keep that near 1.5 % (the survivors are
-// rescored one lane each)
+// about k / (f x length of a probed list) of the later candidates get under it; f is chosen to keep that near 3 % (the survivors are
+// rescored one lane each; measured at nprobe 32 -- cfg 5: f = 1 / 2 / 3 / 4 -> 2.10 / 2.03 / 1.90 / 1.65 M queries/s, cfg 3:
+// 2.31 / 2.38 / 2.35-2.47 / 2.27 -- a dense probe costs exact arithmetic per distance, a filtered one its list's bytes)
 size_t filter_first_probes(const amd_ivf* index, size_t k, size_t nprobe) {
-    const double mean_len = std::max<double>(1.0, (double)index->h_list_off[index->nlist] / (double)std::max<size_t>(index->nlist, 1));
-    const size_t f = (size_t)std::ceil((double)k / (0.015 * mean_len));
+    // (the length of a list a query lands in: queries fall like the data, so a list is probed in proportion to its length and the
+    // expected length of a probed list is sum(len^2) / sum(len) -- the plain mean where lists are even, three times it on cfg 5's
+    // blobs, whose dense round then computed three times the distances the rule meant it to)
+    const double mean_len = std::max<double>(1.0, index->probed_len);
+    if (const char* e = getenv("AUNCEL_AMD_FILTER_FIRST"))  // (experiments: the dense probes of an fp32 search, whatever the rule says)
+        if (*e) return std::max<size_t>(1, std::min<size_t>((size_t)atoi(e), nprobe));
+    const size_t f = (size_t)std::ceil((double)k / (0.03 * mean_len));
     return std::max<size_t>(1, std::min<size_t>(f, std::max<size_t>(1, nprobe / 4)));
 }
 
@@ -1114,7 +1164,7 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
                 size_t& ni = cur[scan_qg_class(qg)];
                 for (uint32_t vb = 0; vb < sz; vb += tv) {
                     ScanItem& it = items[ni++];
-                    it.vec_base = off[l] + vb;
+                    it.vec_base = scan_vec_base(off[l] + vb, ix(h)->h_block_off.empty() ? 0ull : ix(h)->h_block_off[l], vb);
                     it.nvec = std::min(tv, sz - vb);
                     it.vec_off = vb;
                     it.pair_begin = lcount[l] + qb;
@@ -1155,6 +1205,7 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
         ScanArgs sa{};
         sa.qtile = h->w_qtile.as<float>();
         sa.codes = ix(h)->d_codes.as<float>();
+        sa.lanes = r.bytes ? nullptr : ensure_lanes(ix(h));
         sa.queries = r.d_x;
         sa.items = h->w_items.as<ScanItem>();
         sa.pair_query = h->w_pair_query.as<uint32_t>();
@@ -1957,6 +2008,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     const bool filter_ok = filter_available(h, I, base.bytes) && !base.range;
     const bool filter_half = filter_ok && ensure_frag16(I);
     if (filter_ok && !filter_half) ensure_frag32(I);
+    const float* lanes = base.bytes ? nullptr : ensure_lanes(I);  // (fp32 tiles: scan_lanes_kernel over the lane-ordered copy)
     if (filter_ok && base.tuner.enabled) first_round = filter_first_probes(I, (size_t)base.k, 64);
     // (byte codes: a round is bound by its one pass over the lists, x 12; the fp32 filter's rounds are bound by matrix-core issue
     // from ~50 queries per list on, so what a round scans past the queries' stop points is paid for: x 6 measured best --
@@ -2089,6 +2141,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     pa.mfma_qblock = MFMA_QBLOCK;
     static const int item_order_env = getenv("AUNCEL_AMD_ITEM_ORDER") ? atoi(getenv("AUNCEL_AMD_ITEM_ORDER")) : 0;
     pa.item_order = item_order_env;
+    pa.lane_block_off = lanes ? I->d_block_off.as<uint64_t>() : nullptr;
     if (base.bytes) {
         pa.mfma_chunk = mfma_chunk();
         pa.block_off = I->d_block_off.as<uint64_t>();
@@ -2291,6 +2344,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             ScanArgs sa{};
             sa.qtile = h->w_qtile.as<float>();
             sa.codes = I->d_codes.as<float>();
+            sa.lanes = lanes;
             sa.queries = base.d_x;
             sa.items = h->w_items.as<ScanItem>();
             sa.pair_query = h->w_pair_query.as<uint32_t>();
@@ -2529,6 +2583,13 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         if (chained) {
             h->round_hint.assign(h->p_hist.as<uint32_t>(), h->p_hist.as<uint32_t>() + nh * 16);
             h->round_hint.insert(h->round_hint.end(), hc, hc + 16);  // the last planned round
+            static const bool dbg_rounds = getenv("AUNCEL_AMD_DEBUG_ROUNDS") != nullptr;  // what every round of the search planned
+            if (dbg_rounds)
+                for (size_t r = 0; (r + 1) * 16 <= h->round_hint.size(); r++) {
+                    const uint32_t* c = &h->round_hint[r * 16];
+                    fprintf(stderr, "[rounds] %zu: queries %u segments %u pairs %u groups %u items qg1 %u qg2 %u qg4 %u qg8 %u\n", r, c[CNT_ACTIVE],
+                            c[CNT_SEGMENTS], c[CNT_PAIRS], c[CNT_GROUPS], c[CNT_QG1], c[CNT_QG2], c[CNT_QG4], c[CNT_QG8]);
+                }
             // a scan grid is its hint + 12 %; a round that needed more still covers its items (the workgroups stride over the
             // device-side count), only with fewer workgroups than it would have been given
             for (size_t r = 0; (r + 1) * 16 <= hints_used.size() && (r + 1) * 16 <= h->round_hint.size(); r++)

@@ -48,8 +48,16 @@ constexpr int SCAN_RV = 2;    // vectors per lane
 constexpr int SCAN_DC = AUNCEL_SCAN_DC;   // dimensions staged through LDS per step
 constexpr int SCAN_WAVE_VECS = 64 * SCAN_RV;
 
+// fp32 tiles: vec_base carries two numbers -- bits 0..39 the global index of the tile's first vector (into `codes`), bits 40..63
+// the tile's first 64-vector block in the lane-ordered copy of the lists (ScanArgs::lanes; 0 where there is none)
+constexpr int SCAN_VB_BITS = 40;
+constexpr uint64_t SCAN_VB_MASK = (1ull << SCAN_VB_BITS) - 1;
+inline __host__ __device__ uint64_t scan_vec_base(uint64_t first_vector, uint64_t first_block32_of_list, uint32_t pos_in_list) {
+    return first_vector | (((first_block32_of_list >> 1) + pos_in_list / 64u) << SCAN_VB_BITS);
+}
+
 struct ScanItem {
-    uint64_t vec_base;   // global index (into codes) of the tile's first vector
+    uint64_t vec_base;   // global index (into codes) of the tile's first vector (fp32 tiles: see scan_vec_base)
     uint32_t nvec;       // vectors in the tile
     uint32_t vec_off;    // position of the tile's first vector inside its list
     uint32_t pair_begin; // first entry of this tile in the pair arrays
@@ -82,12 +90,19 @@ struct ScanArgs {
     // correctness -- workgroups stride over the true count -- and a right-sized grid lets the dispatcher interleave the
     // workgroups of several search contexts where resident grids would run one context's launch to its end first.
     uint32_t hint_qg[4];
+    // the lists once more in LANE ORDER (launch_lanes_from_f32), or null: 64-vector blocks (lists padded like the fragment copies:
+    // block_off / 2), block b = d/4 pieces of 1 KiB, piece s = lane l's elements 4s .. 4s+3 of vector 64 b + l.  A wave streams a
+    // block with one fully coalesced 16-byte-a-lane load per piece: scan_lanes_kernel needs no LDS staging and no barrier.
+    const float* lanes;
 };
 
 // items grouped by qg (1, then 2, 4, 8); n_qg = item count of each group
 // the shapes are independent: s2 / s1 / s4 (optional) let the qg 2 / 1 / 4 launches run beside the qg 8 one
 void launch_scan(const ScanArgs& a, const size_t n_qg[4], hipStream_t s, hipStream_t s2 = nullptr, hipStream_t s1 = nullptr,
                  hipStream_t s4 = nullptr);
+// fp32 lists (CSR rows, row stride dpad) -> lane order; nblocks64 = block_off[nlist] / 2
+void launch_lanes_from_f32(const float* codes, const uint64_t* list_off, const uint64_t* block_off, uint32_t nlist, uint64_t nblocks64, int dpad,
+                           float* out, hipStream_t s);
 // counters of PlanArgs that the chained launches read
 constexpr int CNT_ACTIVE = 0, CNT_SEGMENTS = 1, CNT_PAIRS = 2, CNT_GROUPS = 3, CNT_QG1 = 4, CNT_QG2 = 5, CNT_QG4 = 8, CNT_QG8 = 9;
 unsigned resident_grid(unsigned workgroups_per_cu);  // CUs of the current device x workgroups_per_cu
@@ -443,6 +458,7 @@ struct PlanArgs {
     uint32_t mfma_qblock;            // queries per item in that form (MFMA_QBLOCK: one tile)
     int item_order;                  // ... items of a list: 0 chunk major (a chunk's query blocks are neighbours), 1 query block major
     const uint64_t* block_off;       // mfma: first 32-vector block of every list in the fragment-order storage
+    const uint64_t* lane_block_off;  // fp32 tiles over the lane-ordered copy (ScanArgs::lanes): the same array, else null
     uint32_t* seg_begin;             // [nq]
     unsigned long long* dist_base;   // [nq]
     uint32_t* qsel;                  // active slots, compacted

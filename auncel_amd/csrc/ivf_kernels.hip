@@ -32,6 +32,9 @@ namespace amdivf {
 // its rows with conflict-free ds_read_b128 (row stride 36 dwords).  The SCAN_RQ query operands of
 // a wave are wave-uniform: they are fetched with scalar loads and used as SGPR operands, so a
 // query value costs neither LDS bandwidth nor VGPRs.
+#ifndef AUNCEL_SCAN_PF
+#define AUNCEL_SCAN_PF 2   // chunks fetched ahead of the compute (register staging)
+#endif
 typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int LDS_ROW = SCAN_DC + 4;                 // dwords per staged row (pad = one 16-B slot)
 
@@ -52,6 +55,53 @@ template <int QG> struct ScanShape {
     static constexpr int tile_vecs = vg * SCAN_WAVE_VECS;
     static constexpr int lds_floats = tile_vecs * LDS_ROW;
 };
+
+// What a wave does with its finished sums (both scan kernels): distance rows, and in threshold mode the masks.
+template <int METRIC>
+__device__ __forceinline__ void scan_tile_store(const ScanArgs& a, const ScanItem& it, f2 (&acc)[SCAN_RQ][SCAN_RV][2], bool has_queries, int qgi, int vgi,
+                                                int lane, unsigned long long e_row, float e_thr) {
+    const bool masked = a.thr != nullptr;
+    // With thresholds (a.thr: the heap top each query had when the round was planned) only the distances that can
+    // still enter the heap are stored, and every 64-candidate chunk of a row gets a bit mask of those positions:
+    // the replay kernel then reads 1 bit per candidate instead of 4 bytes, and the rest of the row never
+    // leaves the chip.  Rows start on multiples of 64 floats in that mode.
+    if (!has_queries) return;
+    // threshold mode: the 64-bit masks of the wave's SCAN_RQ x SCAN_RV chunks are parked in lanes r * SCAN_RV + v and
+    // stored by one instruction at the end (a predicated store per chunk costs more scalar work than the chunk's test)
+    uint32_t mk_lo = 0, mk_hi = 0;
+#pragma unroll
+    for (int r = 0; r < SCAN_RQ; r++) {
+        uint32_t local = (uint32_t)(qgi * SCAN_RQ + r);
+        if (local < it.npair) {
+            const unsigned long long row = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(e_row >> 32), r) << 32) |
+                                           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e_row, r);
+            float* out = a.dist + row;
+            const float thr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e_thr), r));
+#pragma unroll
+            for (int v = 0; v < SCAN_RV; v++) {
+                const int lv0 = vgi * SCAN_WAVE_VECS + v * 64;
+                const int lv = lv0 + lane;
+                const float res = (acc[r][v][0].x + acc[r][v][0].y) + (acc[r][v][1].x + acc[r][v][1].y);
+                bool keep = lv < (int)it.nvec;
+                if (masked) {
+                    keep = keep && (METRIC == METRIC_L2 ? thr > res : thr < res);
+                    const unsigned long long m = __ballot(keep);
+                    const bool mine = lane == r * SCAN_RV + v;
+                    mk_lo = mine ? (uint32_t)m : mk_lo;
+                    mk_hi = mine ? (uint32_t)(m >> 32) : mk_hi;
+                }
+                if (keep) out[lv] = res;
+            }
+        }
+    }
+    if (masked && lane < SCAN_RQ * SCAN_RV) {
+        const int r = lane / SCAN_RV, v = lane % SCAN_RV;
+        const int lv0 = vgi * SCAN_WAVE_VECS + v * 64;
+        const unsigned long long row = __shfl(e_row, r);  // lane r holds the row offset of query r
+        if ((uint32_t)(qgi * SCAN_RQ + r) < it.npair && lv0 < (int)it.nvec)
+            a.mask[(row + lv0) >> 6] = ((unsigned long long)mk_hi << 32) | mk_lo;
+    }
+}
 
 // one tile; every wave of the workgroup takes part in all of its barriers
 template <int METRIC, int QG, int ARITH>
@@ -94,7 +144,7 @@ __device__ __forceinline__ void scan_tile_one(const ScanArgs& a, const ScanItem 
 #pragma unroll
         for (int v = 0; v < SCAN_RV; v++) acc[r][v][0] = acc[r][v][1] = f2{0.f, 0.f};
 
-    const float* tile_base = a.codes + (size_t)it.vec_base * (size_t)d;
+    const float* tile_base = a.codes + (size_t)(it.vec_base & SCAN_VB_MASK) * (size_t)d;
     const bool has_queries = (uint32_t)(qgi * SCAN_RQ) < it.npair;
 
     // What the epilogue needs per query -- row offset of its distances, |x|^2, threshold -- is fetched now by lane r
@@ -113,7 +163,7 @@ __device__ __forceinline__ void scan_tile_one(const ScanArgs& a, const ScanItem 
 
     // fetches run two chunks ahead of the compute (register staging, PF sets): at 4 steps per chunk one chunk
     // of lead does not cover an HBM round trip under load
-    constexpr int PF = 2;
+    constexpr int PF = AUNCEL_SCAN_PF;
     float4 pre[PF][NLD];
     auto fetch = [&](int c0, float4 (&dst)[NLD]) {
         const int nslot = (d - c0 >= SCAN_DC ? SCAN_DC : d - c0) >> 2;
@@ -127,8 +177,8 @@ __device__ __forceinline__ void scan_tile_one(const ScanArgs& a, const ScanItem 
         }
     };
 
-    fetch(0, pre[0]);
-    fetch(SCAN_DC, pre[1]);
+#pragma unroll
+    for (int i = 0; i < PF; i++) fetch(i * SCAN_DC, pre[i]);
     int buf = 0;
     // the chunk loop is unrolled by PF so that the staging registers are indexed statically
     for (int c0 = 0; c0 < d; c0 += PF * SCAN_DC) {
@@ -199,46 +249,7 @@ __device__ __forceinline__ void scan_tile_one(const ScanArgs& a, const ScanItem 
       }
     }
 
-    // With thresholds (a.thr: the heap top each query had when the round was planned) only the distances that can
-    // still enter the heap are stored, and every 64-candidate chunk of a row gets a bit mask of those positions:
-    // the replay kernel then reads 1 bit per candidate instead of 4 bytes, and the rest of the row never
-    // leaves the chip.  Rows start on multiples of 64 floats in that mode.
-    if (!has_queries) return;
-    // threshold mode: the 64-bit masks of the wave's SCAN_RQ x SCAN_RV chunks are parked in lanes r * SCAN_RV + v and
-    // stored by one instruction at the end (a predicated store per chunk costs more scalar work than the chunk's test)
-    uint32_t mk_lo = 0, mk_hi = 0;
-#pragma unroll
-    for (int r = 0; r < SCAN_RQ; r++) {
-        uint32_t local = (uint32_t)(qgi * SCAN_RQ + r);
-        if (local < it.npair) {
-            const unsigned long long row = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(e_row >> 32), r) << 32) |
-                                           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e_row, r);
-            float* out = a.dist + row;
-            const float thr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e_thr), r));
-#pragma unroll
-            for (int v = 0; v < SCAN_RV; v++) {
-                const int lv0 = vgi * SCAN_WAVE_VECS + v * 64;
-                const int lv = lv0 + lane;
-                const float res = (acc[r][v][0].x + acc[r][v][0].y) + (acc[r][v][1].x + acc[r][v][1].y);
-                bool keep = lv < (int)it.nvec;
-                if (masked) {
-                    keep = keep && (METRIC == METRIC_L2 ? thr > res : thr < res);
-                    const unsigned long long m = __ballot(keep);
-                    const bool mine = lane == r * SCAN_RV + v;
-                    mk_lo = mine ? (uint32_t)m : mk_lo;
-                    mk_hi = mine ? (uint32_t)(m >> 32) : mk_hi;
-                }
-                if (keep) out[lv] = res;
-            }
-        }
-    }
-    if (masked && lane < SCAN_RQ * SCAN_RV) {
-        const int r = lane / SCAN_RV, v = lane % SCAN_RV;
-        const int lv0 = vgi * SCAN_WAVE_VECS + v * 64;
-        const unsigned long long row = __shfl(e_row, r);  // lane r holds the row offset of query r
-        if ((uint32_t)(qgi * SCAN_RQ + r) < it.npair && lv0 < (int)it.nvec)
-            a.mask[(row + lv0) >> 6] = ((unsigned long long)mk_hi << 32) | mk_lo;
-    }
+    scan_tile_store<METRIC>(a, it, acc, has_queries, qgi, vgi, lane, e_row, e_thr);
 }
 
 template <int METRIC, int QG, int ARITH>
@@ -258,6 +269,165 @@ __global__ __launch_bounds__(ScanShape<QG>::NT) void scan_tiles_kernel(ScanArgs 
         scan_tile_one<METRIC, QG, ARITH>(a, items[i], lds);
         __syncthreads();  // the staging buffers are reused by the next tile
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same tiles from the lane-ordered copy of the lists (ScanArgs::lanes).  With rows of d floats a staged chunk of a tile is 64
+// bytes out of every row: at d = 960 that is half a cache line from each of 128 rows 3840 bytes apart, fetched again for the other
+// half a chunk later -- the dense round of cfg 5 moved 2x its bytes and ran at a quarter of the kernel's own rate.  Here a wave's
+// operand of one 4-dimension step is ONE contiguous KiB per 64-vector block (lane l: vector l), consecutive steps are consecutive
+// KiB: no LDS, no barrier, nothing shared between the waves of a workgroup but the L2 lines they both read.  A wave keeps
+// SCAN_LANE_AHEAD steps of its two blocks in flight in registers.  Arithmetic, operand order and the epilogue are scan_tile_one's.
+#ifndef AUNCEL_SCAN_LANE_AHEAD
+#define AUNCEL_SCAN_LANE_AHEAD 6
+#endif
+constexpr int SCAN_LANE_AHEAD = AUNCEL_SCAN_LANE_AHEAD;
+
+template <int METRIC, int QG, int ARITH>
+__device__ __forceinline__ void scan_lanes_one(const ScanArgs& a, const ScanItem it) {
+    constexpr bool FUSED = ARITH == 1;
+    constexpr int qg = QG;
+    constexpr int D = SCAN_LANE_AHEAD;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qgi = wave & (qg - 1);
+    const int vgi = wave / qg;
+    const int nsteps = a.d >> 2;
+    const bool has_queries = (uint32_t)(qgi * SCAN_RQ) < it.npair;
+    if (!has_queries) return;  // (nothing to wait for: the waves of a workgroup share no staging)
+    const uint32_t v0 = (uint32_t)vgi * SCAN_WAVE_VECS;  // the wave's first vector inside the tile
+    if (v0 >= it.nvec) return;
+    const bool two = v0 + 64u < it.nvec;                 // its second block holds vectors of the tile
+
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef const v4f __attribute__((address_space(4)))* const_f4p;
+    typedef const v4f __attribute__((address_space(1)))* glob_f4p;
+    const const_f4p qtile = (const_f4p)(uintptr_t)(a.qtile + (size_t)(it.qgroup + qgi) * (size_t)a.d * SCAN_RQ);
+    auto qload = [](const_f4p p) {
+        const v4f t = *p;
+        return make_float4(t.x, t.y, t.z, t.w);
+    };
+    const uint64_t blk = (it.vec_base >> SCAN_VB_BITS) + (uint64_t)(v0 >> 6);
+    const glob_f4p pa = (glob_f4p)(uintptr_t)(a.lanes + (blk * (uint64_t)nsteps) * 256u) + lane;  // piece s: pa[s * 64]
+    const glob_f4p pb = pa + (size_t)nsteps * 64;
+
+    f2 acc[SCAN_RQ][SCAN_RV][2];
+#pragma unroll
+    for (int r = 0; r < SCAN_RQ; r++)
+#pragma unroll
+        for (int v = 0; v < SCAN_RV; v++) acc[r][v][0] = acc[r][v][1] = f2{0.f, 0.f};
+    static_assert(SCAN_RV == 2, "two blocks a wave");
+
+    unsigned long long e_row = 0;
+    float e_thr = 0.f;
+    {
+        const uint32_t local = (uint32_t)(qgi * SCAN_RQ + lane);
+        if (lane < SCAN_RQ && local < it.npair) {
+            e_row = a.pair_out[it.pair_begin + local] + it.vec_off;
+            if (a.thr != nullptr) e_thr = a.thr[a.pair_query[it.pair_begin + local]];
+        }
+    }
+
+    v4f ring[D][SCAN_RV];
+#pragma unroll
+    for (int j = 0; j < D; j++) {
+        ring[j][0] = ring[j][1] = v4f{0.f, 0.f, 0.f, 0.f};
+        if (j < nsteps) {
+            ring[j][0] = __builtin_nontemporal_load(pa + (size_t)j * 64);
+            if (two) ring[j][1] = __builtin_nontemporal_load(pb + (size_t)j * 64);
+        }
+    }
+    float4 qn[SCAN_RQ];
+#pragma unroll
+    for (int r = 0; r < SCAN_RQ; r++) qn[r] = qload(qtile + r);
+    for (int s0 = 0; s0 < nsteps; s0 += D) {
+#pragma unroll
+        for (int j = 0; j < D; j++) {
+            const int s = s0 + j;
+            if (s >= nsteps) break;  // (wave-uniform)
+            const v4f ya4 = ring[j][0], yb4 = ring[j][1];
+            if (s + D < nsteps) {
+                ring[j][0] = __builtin_nontemporal_load(pa + (size_t)(s + D) * 64);
+                if (two) ring[j][1] = __builtin_nontemporal_load(pb + (size_t)(s + D) * 64);
+            }
+            float4 qc[SCAN_RQ];
+#pragma unroll
+            for (int r = 0; r < SCAN_RQ; r++) qc[r] = qn[r];
+            if (s + 1 < nsteps) {
+#pragma unroll
+#ifdef AUNCEL_SCAN_QHACK  // (experiment: operands of steps 0..3 over and over -- wrong distances, the scalar cache always hits)
+                for (int r = 0; r < SCAN_RQ; r++) qn[r] = qload(qtile + (size_t)((s + 1) & 3) * SCAN_RQ + r);
+#else
+                for (int r = 0; r < SCAN_RQ; r++) qn[r] = qload(qtile + (size_t)(s + 1) * SCAN_RQ + r);
+#endif
+            }
+            const f2 ya[SCAN_RV] = {f2{ya4.x, ya4.y}, f2{yb4.x, yb4.y}};  // elements (0,1) of the step: sums 0,1
+            const f2 yb[SCAN_RV] = {f2{ya4.z, ya4.w}, f2{yb4.z, yb4.w}};  // elements (2,3): sums 2,3
+#pragma unroll
+            for (int r = 0; r < SCAN_RQ; r++) {
+                const f2 qa = f2{qc[r].x, qc[r].y}, qb = f2{qc[r].z, qc[r].w};
+#pragma unroll
+                for (int v = 0; v < SCAN_RV; v++) {
+                    if (METRIC == METRIC_L2) {
+                        const f2 ta = ya[v] - qa, tb = yb[v] - qb;
+                        if (FUSED) {
+                            acc[r][v][0] = __builtin_elementwise_fma(ta, ta, acc[r][v][0]);
+                            acc[r][v][1] = __builtin_elementwise_fma(tb, tb, acc[r][v][1]);
+                        } else {
+                            acc[r][v][0] += ta * ta;
+                            acc[r][v][1] += tb * tb;
+                        }
+                    } else if (FUSED) {
+                        acc[r][v][0] = __builtin_elementwise_fma(ya[v], qa, acc[r][v][0]);
+                        acc[r][v][1] = __builtin_elementwise_fma(yb[v], qb, acc[r][v][1]);
+                    } else {
+                        acc[r][v][0] += ya[v] * qa;
+                        acc[r][v][1] += yb[v] * qb;
+                    }
+                }
+            }
+        }
+    }
+    scan_tile_store<METRIC>(a, it, acc, true, qgi, vgi, lane, e_row, e_thr);
+}
+
+template <int METRIC, int QG, int ARITH>
+__global__ __launch_bounds__(ScanShape<QG>::NT) void scan_lanes_kernel(ScanArgs a) {
+    uint32_t n = a.nitems;
+    const ScanItem* items = a.items;
+    if (a.dev_counts) {
+        const uint32_t n1 = a.dev_counts[CNT_QG1], n2 = a.dev_counts[CNT_QG2], n4 = a.dev_counts[CNT_QG4], n8 = a.dev_counts[CNT_QG8];
+        n = QG == 1 ? n1 : QG == 2 ? n2 : QG == 4 ? n4 : n8;
+        items += QG == 1 ? 0 : QG == 2 ? n1 : QG == 4 ? n1 + n2 : n1 + n2 + n4;
+    }
+    ItemWalk w(n, a.xcd_chunks);
+    for (uint32_t i = w.cur; i < w.end; i += w.step) scan_lanes_one<METRIC, QG, ARITH>(a, items[i]);
+}
+
+// one wave per (64-vector block, run of pieces): lane l copies vector 64 b + l's elements, 16 bytes a piece
+__global__ __launch_bounds__(64) void lanes_from_f32_kernel(const float* codes, const uint64_t* list_off, const uint64_t* block_off, uint32_t nlist,
+                                                            int dpad, float* out) {
+    const uint64_t blk = blockIdx.x;
+    const int lane = threadIdx.x;
+    uint32_t lo = 0, hi = nlist;  // largest l with block_off[l] / 2 <= blk
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if ((block_off[mid] >> 1) <= blk) lo = mid;
+        else hi = mid;
+    }
+    const uint64_t pos = (blk - (block_off[lo] >> 1)) * 64 + lane, size = list_off[lo + 1] - list_off[lo];
+    const bool ok = pos < size;
+    const float4* src = reinterpret_cast<const float4*>(codes + (list_off[lo] + (ok ? pos : 0)) * (uint64_t)dpad);
+    const int nsteps = dpad >> 2;
+    float4* dst = reinterpret_cast<float4*>(out) + blk * (uint64_t)nsteps * 64 + lane;
+    for (int s = 0; s < nsteps; s++) dst[(size_t)s * 64] = ok ? src[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+void launch_lanes_from_f32(const float* codes, const uint64_t* list_off, const uint64_t* block_off, uint32_t nlist, uint64_t nblocks64, int dpad,
+                           float* out, hipStream_t s) {
+    if (nblocks64 == 0) return;
+    LAUNCH(lanes_from_f32_kernel, dim3((unsigned)nblocks64), dim3(64), 0, s, codes, list_off, block_off, nlist, dpad, out);
 }
 
 __global__ __launch_bounds__(256) void pack_queries_kernel(const float* queries, const uint32_t* pair_query, const uint32_t* group_p0,
@@ -314,7 +484,15 @@ template <int QG> static void launch_scan_qg(ScanArgs a, size_t first, size_t n,
         const dim3 grid((unsigned)(a.dev_counts ? (hint ? hinted : resident_grid(per_cu)) : a.xcd_chunks ? ((n + 7) / 8) * 8 : n)), block(threads);
         LAUNCH(kern, grid, block, 0, s, a);
     };
-    if (a.metric == METRIC_L2) {
+    if (a.lanes) {
+        if (a.metric == METRIC_L2) {
+            if (a.fused) go(scan_lanes_kernel<METRIC_L2, QG, 1>);
+            else go(scan_lanes_kernel<METRIC_L2, QG, 0>);
+        } else {
+            if (a.fused) go(scan_lanes_kernel<METRIC_IP, QG, 1>);
+            else go(scan_lanes_kernel<METRIC_IP, QG, 0>);
+        }
+    } else if (a.metric == METRIC_L2) {
         if (a.fused) go(scan_tiles_kernel<METRIC_L2, QG, 1>);
         else go(scan_tiles_kernel<METRIC_L2, QG, 0>);
     } else {

@@ -444,6 +444,7 @@ __device__ inline void items_of_list(const PlanArgs& a, uint32_t l, uint32_t c) 
                        n1 + n2 + n4 + a.ibase[3 * a.nlist + l]};
     const uint32_t sz = (uint32_t)(a.list_off[l + 1] - a.list_off[l]);
     const uint64_t vb0 = a.list_off[l];
+    const uint64_t lb0 = a.lane_block_off ? a.lane_block_off[l] : 0ull;  // (the lane-ordered copy's blocks: scan_vec_base)
     if (a.mfma_chunk) {
         // items of one chunk are consecutive (its query blocks): they run close together on one XCD (scan_mfma_kernel's
         // item order), so a chunk fetched for one query block is still in that L2 for the next
@@ -476,7 +477,7 @@ __device__ inline void items_of_list(const PlanArgs& a, uint32_t l, uint32_t c) 
         uint32_t& ni = cur[scan_qg_class(qg)];
         for (uint32_t vb = 0; vb < sz; vb += tv) {
             ScanItem it;
-            it.vec_base = vb0 + vb;
+            it.vec_base = scan_vec_base(vb0 + vb, lb0, vb);
             it.nvec = sz - vb < tv ? sz - vb : tv;
             it.vec_off = vb;
             it.pair_begin = p0 + qb;
@@ -511,6 +512,7 @@ __device__ inline void items_of_list_wave(const PlanArgs& a, uint32_t l, uint32_
                              n1 + n2 + n4 + a.ibase[3 * a.nlist + l]};
     const uint32_t sz = (uint32_t)(a.list_off[l + 1] - a.list_off[l]);
     const uint64_t vb0 = a.list_off[l];
+    const uint64_t lb0 = a.lane_block_off ? a.lane_block_off[l] : 0ull;  // (the lane-ordered copy's blocks: scan_vec_base)
     if (a.mfma_chunk) {
         const uint64_t b0 = a.block_off[l];
         const uint32_t nvb = (sz + a.mfma_chunk - 1) / a.mfma_chunk, nqb = (c + a.mfma_qblock - 1) / a.mfma_qblock;
@@ -535,7 +537,7 @@ __device__ inline void items_of_list_wave(const PlanArgs& a, uint32_t l, uint32_
     for (uint32_t o = lane; o < full * nt_f; o += 64) {
         const uint32_t qb = (o / nt_f) * a.qblock, vb = (o % nt_f) * tv_f;
         ScanItem it;
-        it.vec_base = vb0 + vb;
+        it.vec_base = scan_vec_base(vb0 + vb, lb0, vb);
         it.nvec = sz - vb < tv_f ? sz - vb : tv_f;
         it.vec_off = vb;
         it.pair_begin = p0 + qb;
@@ -551,7 +553,7 @@ __device__ inline void items_of_list_wave(const PlanArgs& a, uint32_t l, uint32_
         for (uint32_t o = lane; o < nt_r; o += 64) {
             const uint32_t vb = o * tv_r;
             ScanItem it;
-            it.vec_base = vb0 + vb;
+            it.vec_base = scan_vec_base(vb0 + vb, lb0, vb);
             it.nvec = sz - vb < tv_r ? sz - vb : tv_r;
             it.vec_off = vb;
             it.pair_begin = p0 + qb;
@@ -679,7 +681,7 @@ __global__ __launch_bounds__(64) void plan_one_kernel(PlanArgs a) {
             for (uint32_t o = 0; o < n_it; o++) {
                 const uint32_t vb = o * tile;
                 ScanItem it;
-                it.vec_base = a.mfma_chunk ? b0 + vb / MFMA_BLOCK : vb0 + vb;
+                it.vec_base = a.mfma_chunk ? b0 + vb / MFMA_BLOCK : scan_vec_base(vb0 + vb, a.lane_block_off ? a.lane_block_off[key] : 0ull, vb);
                 it.nvec = sz - vb < tile ? sz - vb : tile;
                 it.vec_off = vb;
                 it.pair_begin = pidx;

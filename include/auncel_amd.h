@@ -368,6 +368,9 @@ int amd_ivf_set_byte_codes(amd_ivf_t* h, int enable);
  *   "pinned_io"       per-call inputs / outputs through one page-locked block (1) or copies (0)                 1
  *   "row_lists"       threshold rounds of calls of >= 256 queries: 1 the rows' marked candidates are compacted    unset (-1): 1 when no other
  *                     into short lists before the selection (compact_rows_kernel), 0 the selection walks the masks  search of the index is running
+ *   "lanes"           dense rounds of fp32 searches: 1 from a lane-ordered copy of the lists (one coalesced KiB per    1
+ *                     64 vectors and 4 dimensions, no staging; the copy costs the lists' bytes once more, built by the
+ *                     first fp32 search), 0 from the rows
  * amd_ivf_set_option(h, key, NAN) returns the key to "unset".  May be called while search contexts of the index are searching: a
  * search reads what shapes its launches once, when it starts, so the change takes effect with the searches that start after it. */
 int amd_ivf_set_option(amd_ivf_t* h, const char* key, double value);
