@@ -75,6 +75,8 @@ enum OptId {
                         // other search of the index is running
     OPT_LANES,          // fp32 dense rounds from a lane-ordered copy of the lists (1, scan_lanes_kernel: one coalesced KiB per 64 vectors and
                         // step, no LDS staging) or from the rows (0, scan_tiles_kernel); the copy costs the lists' bytes once more
+    OPT_FP32_IN_FLIGHT, // large fp32 searches of one index that run at a time (4): each keeps five streams busy, and from the fifth on they
+                        // queue behind each other in the hardware queues (measured: 4 at a time 1.35 M queries/s, 6 at a time 0.78); others wait
     N_OPT
 };
 struct OptSpec {
@@ -99,6 +101,7 @@ const OptSpec OPT_TABLE[N_OPT] = {
     {"pinned_io", "AUNCEL_AMD_PINNED_IO", nullptr},
     {"row_lists", "AUNCEL_AMD_ROW_LISTS", nullptr},
     {"lanes", "AUNCEL_AMD_LANES", nullptr},
+    {"fp32_in_flight", "AUNCEL_AMD_FP32_IN_FLIGHT", nullptr},
 };
 struct Options {
     // (atomic: amd_ivf_set_option on the owner may run while search contexts cloned from it are searching; a search reads the
@@ -383,6 +386,9 @@ struct amd_ivf {
     // fp32 copy of the lists in fragment order + |y|^2 / |y| per slot (ivf_filter.hip), kept when the data does not qualify for
     // byte codes: threshold rounds run as a matrix-core filter over it, the exact distance only for what the filter keeps
     DevBuf d_frag32, d_yn;
+    std::mutex fp32_gate_mu;               // large fp32 searches running on this index (option fp32_in_flight)
+    std::condition_variable fp32_gate_cv;
+    int fp32_running = 0;
     double probed_len = 0;                 // expected length of the list a query probes: sum(len^2) / sum(len) (upload_lists)
     DevBuf d_lanes;                        // the fp32 lists in lane order (ScanArgs::lanes), built by the first fp32 dense round
     std::atomic<int> lanes_state{0};       // 0 not tried, 1 there, -1 not possible
@@ -799,14 +805,14 @@ const float* ensure_lanes(amd_ivf* index) {
 // about k / (f x length of a probed list) of the later candidates get under it; f is chosen to keep that near 3 % (the survivors are
 // rescored one lane each; measured at nprobe 32 -- cfg 5: f = 1 / 2 / 3 / 4 -> 2.10 / 2.03 / 1.90 / 1.65 M queries/s, cfg 3:
 // 2.31 / 2.38 / 2.35-2.47 / 2.27 -- a dense probe costs exact arithmetic per distance, a filtered one its list's bytes)
-size_t filter_first_probes(const amd_ivf* index, size_t k, size_t nprobe) {
+size_t filter_first_probes(const amd_ivf* index, size_t k, size_t nprobe, double survivors = 0.03) {
     // (the length of a list a query lands in: queries fall like the data, so a list is probed in proportion to its length and the
     // expected length of a probed list is sum(len^2) / sum(len) -- the plain mean where lists are even, three times it on cfg 5's
     // blobs, whose dense round then computed three times the distances the rule meant it to)
     const double mean_len = std::max<double>(1.0, index->probed_len);
     if (const char* e = getenv("AUNCEL_AMD_FILTER_FIRST"))  // (experiments: the dense probes of an fp32 search, whatever the rule says)
         if (*e) return std::max<size_t>(1, std::min<size_t>((size_t)atoi(e), nprobe));
-    const size_t f = (size_t)std::ceil((double)k / (0.03 * mean_len));
+    const size_t f = (size_t)std::ceil((double)k / (survivors * mean_len));
     return std::max<size_t>(1, std::min<size_t>(f, std::max<size_t>(1, nprobe / 4)));
 }
 
@@ -2009,7 +2015,30 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     const bool filter_half = filter_ok && ensure_frag16(I);
     if (filter_ok && !filter_half) ensure_frag32(I);
     const float* lanes = base.bytes ? nullptr : ensure_lanes(I);  // (fp32 tiles: scan_lanes_kernel over the lane-ordered copy)
-    if (filter_ok && base.tuner.enabled) first_round = filter_first_probes(I, (size_t)base.k, 64);
+    // the engine's own limit on fp32 searches that share the device (callers may have any number of searches in flight)
+    struct Fp32Gate {
+        amd_ivf* ix;
+        bool held;
+        Fp32Gate(amd_ivf* index, bool wanted) : ix(index), held(false) {
+            const int limit = (int)index->opt.get(OPT_FP32_IN_FLIGHT, 4);
+            if (!wanted || limit <= 0) return;
+            std::unique_lock<std::mutex> lk(ix->fp32_gate_mu);
+            ix->fp32_gate_cv.wait(lk, [&] { return ix->fp32_running < limit; });
+            ix->fp32_running++;
+            held = true;
+        }
+        ~Fp32Gate() {
+            if (!held) return;
+            {
+                std::lock_guard<std::mutex> lk(ix->fp32_gate_mu);
+                ix->fp32_running--;
+            }
+            ix->fp32_gate_cv.notify_one();
+        }
+    } fp32_gate(I, !base.bytes && n >= 256);
+    // (an adaptive search ends most queries in its first rounds: a first round of 2 probes instead of 3 sent more of them through the
+    // threshold rounds and cost the bench workload's fp32 form 9 % -- it keeps the 1.5 % rule)
+    if (filter_ok && base.tuner.enabled) first_round = filter_first_probes(I, (size_t)base.k, 64, 0.015);
     // (byte codes: a round is bound by its one pass over the lists, x 12; the fp32 filter's rounds are bound by matrix-core issue
     // from ~50 queries per list on, so what a round scans past the queries' stop points is paid for: x 6 measured best --
     // fp32_path 0.69 / 0.88 / 0.90 / 0.84 M q/s at x 12 / 8 / 6 / 4)
