@@ -183,211 +183,120 @@ done:
 }
 
 // ---------------------------------------------------------------------------------------------
-// The same heap for a small compile-time k, in SCALAR registers: node i is the pair (key[i], slot[i]) of named SGPRs, and the
-// walks are decision trees over compile-time node numbers -- a level is one s_max/s_min, two compares and a branch, with no
-// trip through v_readlane / v_writelane / M0 (each of those is a vector-to-scalar hand-off the lone wave waits out: the lane-
-// resident heap above spends ~1.3 k cycles an admission at k = 10).  S = the heap's current size (heap_reorder pops sizes K..1).
-template <int K> struct SHeap {
-    uint32_t key[K + 1], slot[K + 1];  // 1-based, Heap.h numbering
+// The same heap as VECTOR work without a branch (k <= 127): tie_fix_kernel's replay.  A walk down the lane-resident heap above is a
+// chain of scalar decisions -- two v_readlane, a compare and a taken branch per level, ~520 ns a pop + push at k = 100 on a wave
+// that runs alone on its SIMD (scratch/ubench/tie_fix.hip, issue_cost.hip: ~2.5 ns an instruction, ~11 ns a taken branch).  Here a
+// pop is one pass of all lanes over all nodes:
+//   1. every node compares itself with its sibling (one DPP): w(i) = "i is the child its parent would pick" (Heap.h:100: the left
+//      one iff it is strictly worse-ranked than the right; absent nodes hold key 0 and never win);
+//   2. a node is on the root's path iff w holds for it and all its ancestors: the ballots of w against per-lane constant masks;
+//   3. the value v being re-placed stops above the first path node that is better than it (Heap.h:102,109: "if cmp(val, child)
+//      break"); keys fall along the path, so the nodes that move up are the path's prefix with key >= v: each path node whose picked
+//      child is one of them takes that child's entry (the pair winners gathered to their parents with ds_bpermute), and v lands in
+//      the deepest of them (or the root).
+// Keys are stored so that the heap is always a max-heap (L2: fkey, IP: ~fkey); payloads are 32-bit global positions (0xffffffff: an
+// empty entry, id -1).  Node i: lane i & 63 of register i >> 6.
+struct VHeap {
+    uint32_t k0, k1, p0, p1;
 };
-constexpr int SH_K = 10;  // the k that gets this form (the reference's harnesses ask for 10)
-
-// Heap.h:88-118 from node I down, (v, sv) = the pair of node S being re-placed (node S still takes part in the comparisons)
-template <bool IsMax, int K, int S, int I> __device__ __forceinline__ void sh_down(SHeap<K>& h, uint32_t v, uint32_t sv) {
-    constexpr int i1 = 2 * I, i2 = i1 + 1;
-    if constexpr (i1 > S) {
-        h.key[I] = v;
-        h.slot[I] = sv;
-    } else if constexpr (i2 == S + 1) {  // the left child only
-        if (kcmp<IsMax>(v, h.key[i1])) {
-            h.key[I] = v;
-            h.slot[I] = sv;
-        } else {
-            h.key[I] = h.key[i1];
-            h.slot[I] = h.slot[i1];
-            sh_down<IsMax, K, S, i1>(h, v, sv);
-        }
-    } else {
-        if (kcmp<IsMax>(h.key[i1], h.key[i2])) {
-            if (kcmp<IsMax>(v, h.key[i1])) {
-                h.key[I] = v;
-                h.slot[I] = sv;
-            } else {
-                h.key[I] = h.key[i1];
-                h.slot[I] = h.slot[i1];
-                sh_down<IsMax, K, S, i1>(h, v, sv);
-            }
-        } else {
-            if (kcmp<IsMax>(v, h.key[i2])) {
-                h.key[I] = v;
-                h.slot[I] = sv;
-            } else {
-                h.key[I] = h.key[i2];
-                h.slot[I] = h.slot[i2];
-                sh_down<IsMax, K, S, i2>(h, v, sv);
-            }
-        }
-    }
-}
-template <bool IsMax, int K, int S> __device__ __forceinline__ void sh_pop(SHeap<K>& h) { sh_down<IsMax, K, S, 1>(h, h.key[S], h.slot[S]); }
-
-// Heap.h:125-142 from node I up
-template <bool IsMax, int K, int I> __device__ __forceinline__ void sh_up(SHeap<K>& h, uint32_t v, uint32_t sv) {
-    if constexpr (I > 1) {
-        constexpr int F = I >> 1;
-        if (kcmp<IsMax>(v, h.key[F])) {
-            h.key[I] = h.key[F];
-            h.slot[I] = h.slot[F];
-            sh_up<IsMax, K, F>(h, v, sv);
-            return;
-        }
-    }
-    h.key[I] = v;
-    h.slot[I] = sv;
-}
-template <bool IsMax, int K> __device__ __forceinline__ void sh_push(SHeap<K>& h, uint32_t v, uint32_t sv) { sh_up<IsMax, K, K>(h, v, sv); }
-
-// LDS heap arrays (node order) -> scalar registers, by way of one lane per node
-template <int K> __device__ __forceinline__ void sh_load(SHeap<K>& h, const float* hval, int lane) {
-    const uint32_t kv = (lane >= 1 && lane <= K) ? fkey(hval[lane - 1]) : 0u;
-    h.key[0] = h.slot[0] = 0;
-#pragma unroll
-    for (int i = 1; i <= K; i++) {
-        h.key[i] = rl_u(kv, i);
-        h.slot[i] = (uint32_t)(i - 1);
-    }
-}
-// ... and back (lane i <- node i), in the form rh_store takes
-template <int K> __device__ __forceinline__ void sh_to_lanes(const SHeap<K>& h, int lane, uint32_t& v0, uint32_t& s0) {
-    v0 = 0;
-    s0 = 0;
-#pragma unroll
-    for (int i = 1; i <= K; i++) {
-        v0 = lane == i ? h.key[i] : v0;
-        s0 = lane == i ? h.slot[i] : s0;
-    }
-}
-
-// heap_reorder's pops (Heap.h:295-322), sizes S = K .. 1: the popped root goes to lane `ii` of (out_key, out_slot) unless its id is -1
-template <bool IsMax, int K, int S> __device__ __forceinline__ void sh_drain(SHeap<K>& h, const int64_t* href, uint32_t& out_key, uint32_t& out_slot, int& ii) {
-    if constexpr (S >= 1) {
-        const uint32_t rk = h.key[1], rs = h.slot[1];
-        const int64_t id = href[rs];
-        const bool valid = __builtin_amdgcn_readfirstlane((int)(id != -1)) != 0;
-        sh_pop<IsMax, K, S>(h);
-        if (valid) {
-            wl2_u(out_key, (uint32_t)__builtin_amdgcn_readfirstlane((int)rk), out_slot, (uint32_t)__builtin_amdgcn_readfirstlane((int)rs), ii);
-            ii++;
-        }
-        sh_drain<IsMax, K, S - 1>(h, href, out_key, out_slot, ii);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// ... and for k = 100: the keys of nodes 1 .. NS - 1 (the upper levels, which every walk crosses) in scalar registers, the rest
-// and all id slots in lanes as in RegHeap (node i: lane i & 63 of register i >> 6) -- but every node number in the walk is a
-// compile-time constant, so a lane access is one v_readlane / v_writelane with an immediate lane (no M0, no index arithmetic)
-// and a step between scalar-resident levels is three scalar compares and a move.
-template <int K, int NS> struct THeap {
-    uint32_t top[NS];  // [0] unused
-    RegHeap r;         // keys of nodes >= NS; slots of every node
+struct VHeapLane {        // per-lane constants
+    uint32_t a0lo, a0hi;  // node `lane`: its ancestors and itself, root excluded, as bits over nodes 0..63
+    uint32_t a1lo, a1hi;  // node 64 + lane: its ancestors (all below 64)
+    uint32_t caddr;       // ds_bpermute address of the lane holding this node's left child (register by lane < 32)
+    uint32_t paddr0, paddr1;  // ... of the lane holding the parent of node `lane` / of node 64 + lane
 };
-template <int N, int K, int NS> __device__ __forceinline__ uint32_t th_key(const THeap<K, NS>& h) {
-    if constexpr (N < NS) return h.top[N];
-    else if constexpr (N < 64) return rl_u(h.r.v0, N);
-    else return rl_u(h.r.v1, N - 64);
+__device__ __forceinline__ VHeapLane vh_lane(int lane) {
+    VHeapLane c;
+    unsigned long long a0 = lane == 0 ? 1ull : 0ull, a1 = 0ull;
+    for (int i = lane; i > 1; i >>= 1) a0 |= 1ull << i;
+    for (int i = (64 + lane) >> 1; i > 1; i >>= 1) a1 |= 1ull << i;
+    c.a0lo = (uint32_t)a0, c.a0hi = (uint32_t)(a0 >> 32), c.a1lo = (uint32_t)a1, c.a1hi = (uint32_t)(a1 >> 32);
+    c.caddr = (uint32_t)((2 * lane) & 63) * 4u;
+    c.paddr0 = (uint32_t)(lane >> 1) * 4u;
+    c.paddr1 = (uint32_t)(32 + (lane >> 1)) * 4u;
+    return c;
 }
-template <int L> __device__ __forceinline__ uint32_t wl_imm(uint32_t reg, uint32_t val) {  // reg[lane L] = val (wave-uniform)
-    asm("v_writelane_b32 %[r], %[v], %[l]" : [r] "+v"(reg) : [v] "s"((uint32_t)__builtin_amdgcn_readfirstlane((int)val)), [l] "n"(L));
-    return reg;
+__device__ __forceinline__ uint32_t vh_sel(unsigned long long mask, uint32_t yes, uint32_t no) {  // per lane: mask bit ? yes : no
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(no), "v"(yes), "s"(mask));
+    return r;
 }
-template <int N, int K, int NS> __device__ __forceinline__ void th_set_key(THeap<K, NS>& h, uint32_t x) {
-    if constexpr (N < NS) h.top[N] = x;
-    else if constexpr (N < 64) h.r.v0 = wl_imm<N>(h.r.v0, x);
-    else h.r.v1 = wl_imm<N - 64>(h.r.v1, x);
+__device__ __forceinline__ uint32_t vh_sib(uint32_t x) {  // the value of lane ^ 1
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false);  // (every lane has a source: `old` is never used)
 }
-template <int N, int K, int NS> __device__ __forceinline__ uint32_t th_slot(const THeap<K, NS>& h) {
-    if constexpr (N < 64) return rl_u(h.r.s0, N);
-    else return rl_u(h.r.s1, N - 64);
+template <bool TWO> __device__ __forceinline__ uint32_t vh_key_at(const VHeap& h, int node) {
+    if (!TWO) return rl_u(h.k0, node);
+    const uint32_t a = rl_u(h.k0, node & 63), b = rl_u(h.k1, node & 63);
+    return node < 64 ? a : b;
 }
-template <int N, int K, int NS> __device__ __forceinline__ void th_set_slot(THeap<K, NS>& h, uint32_t x) {
-    if constexpr (N < 64) h.r.s0 = wl_imm<N>(h.r.s0, x);
-    else h.r.s1 = wl_imm<N - 64>(h.r.s1, x);
+template <bool TWO> __device__ __forceinline__ uint32_t vh_pay_at(const VHeap& h, int node) {
+    if (!TWO) return rl_u(h.p0, node);
+    const uint32_t a = rl_u(h.p0, node & 63), b = rl_u(h.p1, node & 63);
+    return node < 64 ? a : b;
 }
-template <int N, int C, int K, int NS> __device__ __forceinline__ void th_move_up(THeap<K, NS>& h, uint32_t ckey) {  // node N <- child C
-    th_set_key<N>(h, ckey);
-    th_set_slot<N>(h, th_slot<C>(h));
-}
-// Heap.h:88-118 from node I down (see sh_down)
-template <bool IsMax, int K, int NS, int I> __device__ __forceinline__ void th_down(THeap<K, NS>& h, uint32_t v, uint32_t sv) {
-    constexpr int i1 = 2 * I, i2 = i1 + 1;
-    if constexpr (i1 > K) {
-        th_set_key<I>(h, v);
-        th_set_slot<I>(h, sv);
-    } else if constexpr (i2 == K + 1) {
-        const uint32_t k1 = th_key<i1>(h);
-        if (kcmp<IsMax>(v, k1)) {
-            th_set_key<I>(h, v);
-            th_set_slot<I>(h, sv);
-        } else {
-            th_move_up<I, i1>(h, k1);
-            th_down<IsMax, K, NS, i1>(h, v, sv);
-        }
+// Heap.h:88-118: the entry (v, pv) of the last node is re-placed from the root down (the last node itself still takes part, as there)
+template <bool TWO> __device__ __forceinline__ void vh_pop(VHeap& h, const VHeapLane& c, int lane, uint32_t v, uint32_t pv) {
+    constexpr unsigned long long EVEN = 0x5555555555555555ull;
+    const uint32_t s0 = vh_sib(h.k0), sp0 = vh_sib(h.p0);
+    const unsigned long long w0 = (__ballot(h.k0 > s0) & EVEN) | (__ballot(h.k0 >= s0) & ~EVEN);
+    const uint32_t t0 = vh_sel(w0, h.k0, s0), tp0 = vh_sel(w0, h.p0, sp0);  // the pair's winner, in both its lanes
+    uint32_t gk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)c.caddr, (int)t0);
+    uint32_t gp = (uint32_t)__builtin_amdgcn_ds_bpermute((int)c.caddr, (int)tp0);
+    unsigned long long w1 = 0, path1 = 0;
+    const unsigned long long low32 = 0xffffffffull;
+    if (TWO) {
+        const uint32_t s1 = vh_sib(h.k1), sp1 = vh_sib(h.p1);
+        w1 = (__ballot(h.k1 > s1) & EVEN) | (__ballot(h.k1 >= s1) & ~EVEN);
+        const uint32_t t1 = vh_sel(w1, h.k1, s1), tp1 = vh_sel(w1, h.p1, sp1);
+        const uint32_t gk1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)c.caddr, (int)t1);
+        const uint32_t gp1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)c.caddr, (int)tp1);
+        gk = vh_sel(low32, gk, gk1);  // nodes 0..31: children in register 0; 32..63: in register 1
+        gp = vh_sel(low32, gp, gp1);
     } else {
-        const uint32_t k1 = th_key<i1>(h), k2 = th_key<i2>(h);
-        if (kcmp<IsMax>(k1, k2)) {
-            if (kcmp<IsMax>(v, k1)) {
-                th_set_key<I>(h, v);
-                th_set_slot<I>(h, sv);
-            } else {
-                th_move_up<I, i1>(h, k1);
-                th_down<IsMax, K, NS, i1>(h, v, sv);
-            }
-        } else {
-            if (kcmp<IsMax>(v, k2)) {
-                th_set_key<I>(h, v);
-                th_set_slot<I>(h, sv);
-            } else {
-                th_move_up<I, i2>(h, k2);
-                th_down<IsMax, K, NS, i2>(h, v, sv);
-            }
+        gk = vh_sel(low32, gk, 0u);   // (nodes 32..63 have no children below 64)
+    }
+    const uint32_t nlo = ~(uint32_t)w0, nhi = ~(uint32_t)(w0 >> 32);  // on the path <=> none of the node's ancestor bits is missing from w
+    const unsigned long long path0 = __ballot(((nlo & c.a0lo) | (nhi & c.a0hi)) == 0u);
+    if (TWO) path1 = __ballot(((nlo & c.a1lo) | (nhi & c.a1hi)) == 0u) & w1;
+    const unsigned long long recv = path0 & __ballot(gk >= v);              // its picked child moves up into it
+    const unsigned long long land0 = path0 & ~recv & (__ballot(h.k0 >= v) | 2ull);
+    h.k0 = vh_sel(land0, v, vh_sel(recv, gk, h.k0));
+    h.p0 = vh_sel(land0, pv, vh_sel(recv, gp, h.p0));
+    if (TWO) {
+        const unsigned long long land1 = path1 & __ballot(h.k1 >= v);
+        h.k1 = vh_sel(land1, v, h.k1);
+        h.p1 = vh_sel(land1, pv, h.p1);
+    }
+}
+// Heap.h:125-142: (nv, np) enters at node k and climbs while it is worse than its father.  chain0 / chain1: node k and its ancestors
+// as lane masks of the two registers (wave-uniform constants of the kernel)
+template <bool TWO> __device__ __forceinline__ void vh_push(VHeap& h, const VHeapLane& c, int k, unsigned long long chain0, unsigned long long chain1,
+                                                             uint32_t nv, uint32_t np) {
+    const unsigned long long kbit0 = k < 64 ? 1ull << k : 0ull, kbit1 = k >= 64 ? 1ull << (k - 64) : 0ull;
+    if (!(nv > vh_key_at<false>(h, k >> 1)) || k == 1) {  // (the father of node k is below 64) -- the common case: it stays at node k
+        h.k0 = vh_sel(kbit0, nv, h.k0);
+        h.p0 = vh_sel(kbit0, np, h.p0);
+        if (TWO) {
+            h.k1 = vh_sel(kbit1, nv, h.k1);
+            h.p1 = vh_sel(kbit1, np, h.p1);
         }
+        return;
     }
-}
-template <bool IsMax, int K, int NS> __device__ __forceinline__ void th_pop(THeap<K, NS>& h) {
-    th_down<IsMax, K, NS, 1>(h, th_key<K>(h), th_slot<K>(h));
-}
-// Heap.h:125-142 from node I up
-template <bool IsMax, int K, int NS, int I> __device__ __forceinline__ void th_up(THeap<K, NS>& h, uint32_t v, uint32_t sv) {
-    if constexpr (I > 1) {
-        constexpr int F = I >> 1;
-        const uint32_t fk = th_key<F>(h);
-        if (kcmp<IsMax>(v, fk)) {
-            th_move_up<I, F>(h, fk);  // (node I <- its father)
-            th_up<IsMax, K, NS, F>(h, v, sv);
-            return;
-        }
+    const uint32_t f0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)c.paddr0, (int)h.k0);  // the father's entry, per node
+    const uint32_t fp0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)c.paddr0, (int)h.p0);
+    const unsigned long long down0 = chain0 & ~2ull & __ballot(f0 < nv);       // the father comes down into this node
+    const unsigned long long land0 = chain0 & (__ballot(h.k0 < nv) | kbit0) & ~down0;
+    if (TWO) {
+        const uint32_t f1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)c.paddr1, (int)h.k0);
+        const uint32_t fp1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)c.paddr1, (int)h.p0);
+        const unsigned long long down1 = chain1 & __ballot(f1 < nv);
+        const unsigned long long land1 = chain1 & (__ballot(h.k1 < nv) | kbit1) & ~down1;
+        h.k1 = vh_sel(land1, nv, vh_sel(down1, f1, h.k1));
+        h.p1 = vh_sel(land1, np, vh_sel(down1, fp1, h.p1));
     }
-    th_set_key<I>(h, v);
-    th_set_slot<I>(h, sv);
+    h.k0 = vh_sel(land0, nv, vh_sel(down0, f0, h.k0));
+    h.p0 = vh_sel(land0, np, vh_sel(down0, fp0, h.p0));
 }
-template <bool IsMax, int K, int NS> __device__ __forceinline__ void th_push(THeap<K, NS>& h, uint32_t v, uint32_t sv) { th_up<IsMax, K, NS, K>(h, v, sv); }
-template <int K, int NS, int I = 1> __device__ __forceinline__ void th_tops_from_lanes(THeap<K, NS>& h) {
-    if constexpr (I < NS) {
-        h.top[I] = rl_u(h.r.v0, I);
-        th_tops_from_lanes<K, NS, I + 1>(h);
-    }
-}
-template <int K, int NS, int I = 1> __device__ __forceinline__ void th_tops_to_lanes(THeap<K, NS>& h) {
-    if constexpr (I < NS) {
-        h.r.v0 = wl_imm<I>(h.r.v0, h.top[I]);
-        th_tops_to_lanes<K, NS, I + 1>(h);
-    }
-}
-#ifndef AUNCEL_TH_NS
-#define AUNCEL_TH_NS 32
-#endif
-constexpr int TH_K = 100, TH_NS = AUNCEL_TH_NS > 1 ? AUNCEL_TH_NS : 2;  // (AUNCEL_TH_NS 0: the lane-resident heap, for comparison)
 
 // LDS heap arrays (node order) -> registers; slot j holds the id of node j + 1
 __device__ __forceinline__ void rh_load(RegHeap& h, const float* hval, int k, int lane) {
@@ -2264,16 +2173,26 @@ __global__ __launch_bounds__(256) void tie_fix_kernel(TieFixArgs a) {
         href[i] = a.fix_ref[(size_t)qi * k + i];
     }
     wave_sync();
-    RegHeap rh{};
-    constexpr bool SH = RH && KC == SH_K;  // the heap in scalar registers
-    constexpr bool TH = RH && KC == TH_K && AUNCEL_TH_NS > 1;  // ... its upper levels
-    SHeap<SH_K> sh;
-    THeap<TH_K, TH_NS> th;
-    if (SH) sh_load<SH_K>(sh, hval, lane);
-    else if (RH) rh_load(rh, hval, k, lane);
-    if constexpr (TH) {
-        th.r = rh;
-        th_tops_from_lanes(th);
+    // RH (k <= 127): the heap in lanes, walked as vector work (VHeap); else in LDS, walked by every lane redundantly
+    constexpr bool TWO = KC == 0 || KC > 63;
+    auto stored = [](float x) { return IsMax ? fkey(x) : ~fkey(x); };
+    auto unstored = [](uint32_t sk) { return fkey_inv(IsMax ? sk : ~sk); };
+    VHeap vh{0u, 0u, 0xffffffffu, 0xffffffffu};
+    const VHeapLane vc = vh_lane(lane);
+    unsigned long long chain0 = 0, chain1 = 0;
+    if (RH) {
+        if (lane >= 1 && lane <= k) {
+            vh.k0 = stored(hval[lane - 1]);
+            vh.p0 = (uint32_t)href[lane - 1];
+        }
+        if (TWO && lane + 64 <= k) {
+            vh.k1 = stored(hval[lane + 63]);
+            vh.p1 = (uint32_t)href[lane + 63];
+        }
+        for (int i = k; i >= 1; i >>= 1) {
+            if (i < 64) chain0 |= 1ull << i;
+            else chain1 |= 1ull << (i - 64);
+        }
     }
     const uint2* qlog = a.log + (size_t)qi * a.log_cap;
     uint2 e = pos + lane < n ? qlog[pos + lane] : make_uint2(0u, 0u);
@@ -2283,38 +2202,29 @@ __global__ __launch_bounds__(256) void tie_fix_kernel(TieFixArgs a) {
         const uint32_t cnt = n - b < 64u ? n - b : 64u;
         for (uint32_t l = 0; l < cnt; l++) {
             const float val = __uint_as_float(rl_u(cur.x, (int)l));
-            const int64_t g = (int64_t)rl_u(cur.y, (int)l);
-            if constexpr (SH) {
-                const uint32_t sr = sh.slot[1];
-                if (lane == 0) href[sr] = g;
-                sh_pop<IsMax, SH_K, SH_K>(sh);
-                sh_push<IsMax, SH_K>(sh, fkey(val), sr);
-            } else if constexpr (TH) {
-                const uint32_t sr = th_slot<1>(th);
-                if (lane == 0) href[sr] = g;
-                th_pop<IsMax>(th);
-                th_push<IsMax>(th, fkey(val), sr);
-            } else if (RH) {
-                const uint32_t sr = rl_u(rh.s0, 1);
-                if (lane == 0) href[sr] = g;
-                if (KC == 100) rh_pop_k100<IsMax>(rh);
-                else rh_pop<IsMax, KC>(rh, k);
-                if (KC == 100) rh_push_k100<IsMax>(rh, fkey(val), sr);
-                else rh_push<IsMax, KC>(rh, k, fkey(val), sr);
+            const uint32_t g32 = rl_u(cur.y, (int)l);
+            if (RH) {
+                vh_pop<TWO>(vh, vc, lane, vh_key_at<TWO>(vh, k), vh_pay_at<TWO>(vh, k));
+                vh_push<TWO>(vh, vc, k, chain0, chain1, stored(val), g32);
             } else {
                 heap_pop<IsMax>(k, hval, href);
-                heap_push<IsMax>(k, hval, href, val, g);
+                heap_push<IsMax>(k, hval, href, val, (int64_t)g32);
             }
         }
     }
-    if constexpr (TH) {
-        th_tops_to_lanes(th);
-        rh = th.r;
-    }
     wave_sync();
     if (!fin) {
-        if (SH) sh_to_lanes<SH_K>(sh, lane, rh.v0, rh.s0);
-        if (RH) rh_store(rh, hval, href, k, lane, true);
+        if (RH) {  // the heap in node order
+            if (lane >= 1 && lane <= k) {
+                hval[lane - 1] = unstored(vh.k0);
+                href[lane - 1] = vh.p0 == 0xffffffffu ? -1 : (int64_t)vh.p0;
+            }
+            if (TWO && lane + 64 <= k) {
+                hval[lane + 63] = unstored(vh.k1);
+                href[lane + 63] = vh.p1 == 0xffffffffu ? -1 : (int64_t)vh.p1;
+            }
+            wave_sync();
+        }
         for (int i = lane; i < k; i += 64) {
             a.fix_val[(size_t)qi * k + i] = hval[i];
             a.fix_ref[(size_t)qi * k + i] = href[i];
@@ -2325,35 +2235,30 @@ __global__ __launch_bounds__(256) void tie_fix_kernel(TieFixArgs a) {
     // heap_reorder (Heap.h:295-322): pop everything, worst first, filling the row from its end; empty entries are dropped
     int ii = 0;
     if (RH) {
-        // (in registers: the popped root's value and id slot go to a staging pair, one lane per output position)
-        uint32_t out_key = 0, out_slot = 0;  // lane j <-> output position k - 1 - j (and k - 65 - j in the second pair)
-        uint32_t out_key2 = 0, out_slot2 = 0;
-        if (SH) sh_drain<IsMax, SH_K, SH_K>(sh, href, out_key, out_slot, ii);
-        else for (int i = 0; i < k; i++) {
-            const uint32_t rk = rl_u(rh.v0, 1), rs = rl_u(rh.s0, 1);
-            const int64_t id = href[rs];  // (uniform LDS read)
-            rh_pop<IsMax, 0>(rh, k - i);
-            if (id != -1) {
-                if (ii < 64) wl2_u(out_key, rk, out_slot, rs, ii);
-                else wl2_u(out_key2, rk, out_slot2, rs, ii - 64);
+        // (the popped root's value and position go to a staging pair, one lane per output position)
+        uint32_t out_key = 0, out_pay = 0;  // lane j <-> output position k - 1 - j (and k - 65 - j in the second pair)
+        uint32_t out_key2 = 0, out_pay2 = 0;
+        for (int sz = k; sz >= 1; sz--) {
+            const uint32_t rk = rl_u(vh.k0, 1), rp = rl_u(vh.p0, 1);
+            vh_pop<TWO>(vh, vc, lane, vh_key_at<TWO>(vh, sz), vh_pay_at<TWO>(vh, sz));
+            // the heap is one node shorter: node sz is no node any more
+            vh.k0 = lane == sz ? 0u : vh.k0;
+            if (TWO) vh.k1 = lane + 64 == sz ? 0u : vh.k1;
+            if (rp != 0xffffffffu) {
+                if (ii < 64) wl2_u(out_key, rk, out_pay, rp, ii);
+                else wl2_u(out_key2, rk, out_pay2, rp, ii - 64);
                 ii++;
             }
         }
         // the j-th valid entry popped belongs at position k - 1 - j (the valid ones end up in [k - ii, k), best first)
         wave_sync();
-        float* pv = hval;            // reuse: the register heap no longer needs its LDS image
-        int64_t* pr = href;
-        int64_t r_a = -1, r_b = -1;
-        if (lane < ii && lane < 64) r_a = href[out_slot];
-        if (lane + 64 < ii) r_b = href[out_slot2];
-        wave_sync();
         if (lane < ii && lane < 64) {
-            pv[k - 1 - lane] = fkey_inv(out_key);
-            pr[k - 1 - lane] = r_a;
+            hval[k - 1 - lane] = unstored(out_key);
+            href[k - 1 - lane] = (int64_t)out_pay;
         }
         if (lane + 64 < ii) {
-            pv[k - 65 - lane] = fkey_inv(out_key2);
-            pr[k - 65 - lane] = r_b;
+            hval[k - 65 - lane] = unstored(out_key2);
+            href[k - 65 - lane] = (int64_t)out_pay2;
         }
     } else {
         for (int i = 0; i < k; i++) {
