@@ -2098,7 +2098,8 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     // and the lists take 0.06 ms off it; among others it is the sum of the work, to which compact_rows_kernel adds: -2 % at four
     // batches in flight.  Decided below, where the searches are counted.)
     const int row_lists_opt = (int)opt(h, OPT_ROW_LISTS, ROW_LISTS_DEFAULT);
-    const bool row_lists = row_lists_opt != 0 && n >= 256;
+    static const size_t row_lists_min = getenv("AUNCEL_AMD_ROW_LISTS_MIN") ? (size_t)atoi(getenv("AUNCEL_AMD_ROW_LISTS_MIN")) : 256;
+    const bool row_lists = row_lists_opt != 0 && n >= row_lists_min;
     if (row_lists) {
         h->w_cl_cnt.ensure(seg_cap * 4);
         h->w_cl_ent.ensure((seg_cap + 64) * CL_CAP * sizeof(uint2));  // (+ a probe window's worth behind a query's last row)

@@ -290,7 +290,7 @@ def run_shards(args, torch, dist, capi, rank, world, local, dev, red_dev):
                        "distances_sha256": __import__("hashlib").sha256(np.ascontiguousarray(D).tobytes()).hexdigest(),
                        "single_index_distances_sha256": single_sha,  # (N > 1: recomputed on rank 0 over the undivided index)
                        "shard_bytes_max_over_min": float(load.max() / max(load.min(), 1))},
-            "roofline": {"bound": "hbm", "kernel": "scan_mfma_thr_kernel + scan_mfma_pair_kernel" if h.scan_arith() == 2 else "scan_tiles_kernel", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "scan_mfma_thr_kernel + scan_mfma_pair_kernel" if h.scan_arith() == 2 else "scan_lanes_kernel", "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0 if achieved else None, "traffic": None,
                          "traffic_source": "engine's lower bound (every probed list once per round + rows written), rank 0's shard",
                          "min_bytes_per_launch": per_launch, "avg_launch_ms": acc["scan_ms"] / launches, "launches_per_step": launches / args.steps,
@@ -783,7 +783,7 @@ def main():
         nst_r = max(4, nst // 2)
         fr = {"bound": "hbm", "peak": 8000.0, "unit": "GB/s", "measured": "one batch at a time, same run", "per_launch": []}
         tot_b = tot_ms = 0.0
-        for key, what in (("scan_dense", "dense round: scan_tiles_kernel (vector ALU, reference order)"),
+        for key, what in (("scan_dense", "dense round: scan_lanes_kernel (vector ALU, reference order, lists in lane order)"),
                           ("scan_thr", "threshold rounds: scan_filter_kernel (matrix cores over the fp16 copy of the lists; option filter = 1: the "
                                        "fp32 copy) + rescore_kernel (exact recomputation of what it keeps)")):
             ms_l, n_l = ph.get(key, (0.0, 0.0))
@@ -895,7 +895,7 @@ def main():
     # IndexIVF.cpp:676,733) x d x 4; `scan_bytes` (distances the tiles computed, incl. the probes a round
     # ran past a query's stop point) is reported beside it as computed_over_algorithmic
     alg_bytes = float(st["ndis"]) * d * 4.0
-    scan_kernel = "scan_mfma_thr_kernel (dense round) + scan_mfma_pair_kernel (threshold round): see per_launch" if arith == 2 else "scan_tiles_kernel"
+    scan_kernel = "scan_mfma_thr_kernel (dense round) + scan_mfma_pair_kernel (threshold round): see per_launch" if arith == 2 else "scan_lanes_kernel"
     min_bytes = acc["scan_min_bytes"]
     # HBM traffic of the scan per launch.  PMC counters cannot be read from inside this process: the measured figure comes
     # from the committed rocprofv3 --pmc passes over this same command (profiles/collect.sh -> summarize.py; FETCH_SIZE
@@ -911,7 +911,7 @@ def main():
             pj = json.load(open(cands[-1]))
             if pj.get("_workload") == workload:
                 # (average over the scan launches of a step: dense and threshold rounds; roofline.per_launch has them apart)
-                ks_ = [k for k in pj if k.startswith(("scan_mfma", "scan_tiles_kernel")) and not k.endswith("[coarse]")]
+                ks_ = [k for k in pj if k.startswith(("scan_mfma", "scan_tiles_kernel", "scan_lanes_kernel")) and not k.endswith("[coarse]")]
                 nd_ = sum(pj[k]["dispatches"] for k in ks_)
                 if nd_:
                     traffic = sum(pj[k]["hbm_bytes_per_dispatch"] * pj[k]["dispatches"] for k in ks_) / nd_
@@ -1006,7 +1006,7 @@ def main():
     # was taken on this workload, else the engine's lower bound for the round (every probed list once + rows / mask bits written)
     pipe = int(h.get_option("scan_pipelined")) if arith == 2 else 0
     ksn = (d + 31) // 32
-    knames = {"scan_dense": (f"scan_mfma_thr_kernel<1, {ksn}, true>" if pipe & 1 else f"scan_mfma_kernel<1, false, {ksn}>") if arith == 2 else "scan_tiles_kernel",
+    knames = {"scan_dense": (f"scan_mfma_thr_kernel<1, {ksn}, true>" if pipe & 1 else f"scan_mfma_kernel<1, false, {ksn}>") if arith == 2 else "scan_lanes_kernel",
               "scan_thr": (f"scan_mfma_pair_kernel<1, {ksn}>" if pipe & 4 else f"scan_mfma_thr_kernel<1, {ksn}, false>" if pipe & 2
                            else f"scan_mfma_kernel<1, true, {ksn}>") if arith == 2 else "scan_filter_kernel"}
     prof = {}

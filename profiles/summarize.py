@@ -143,7 +143,7 @@ step_bytes = 0.0
 def wide_reader(k):
     """kernels whose reads are 16-byte-per-lane coalesced streams (FETCH_SIZE counts those at half their bytes on gfx950,
     MI355X_MICROARCH.md HBM): the scans, the fp32 filter, the selection of a dense round (rows of distances)"""
-    return k.startswith(("scan_tiles_kernel", "scan_mfma", "scan_filter")) or k.startswith("select_sorted_kernel<true, false") \
+    return k.startswith(("scan_tiles_kernel", "scan_lanes_kernel", "scan_mfma", "scan_filter")) or k.startswith("select_sorted_kernel<true, false") \
         or k.startswith("select_sorted_kernel<false, false")
 
 

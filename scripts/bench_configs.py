@@ -170,7 +170,7 @@ def run_config(torch, capi, dev, c, nprobes=None, sample=64, ref_sample=2000, lo
             if cands and nprobe == 32:
                 pj = json.load(open(cands[-1]))
                 dense_b = sum(e["hbm_read_bytes_x2"] + e["hbm_write_bytes"] for k_, e in pj.items()
-                              if isinstance(e, dict) and k_.startswith("scan_tiles_kernel"))
+                              if isinstance(e, dict) and k_.startswith(("scan_tiles_kernel", "scan_lanes_kernel")))
                 thr_b = sum(e["hbm_read_bytes_x2"] + e["hbm_write_bytes"] for k_, e in pj.items()
                             if isinstance(e, dict) and (k_.startswith("scan_filter") or k_.startswith("rescore_kernel")))
                 for pl in roof["per_launch"]:
