@@ -19,14 +19,11 @@ namespace amdivf {
 // K-replay: ordered selection + Auncel stop rule + training samples
 // =============================================================================================
 // ---------------------------------------------------------------------------------------------
-// The same heap, resident in registers (k <= 127): node i (1-based, Heap.h numbering) lives in lane
-// i & 63 of register i >> 6, so levels 0-5 (nodes 1..63) are in register 0 and level 6 in register 1.
-// A wave replays one query, so every index below is wave-uniform: nodes are read with v_readlane and written
-// with v_writelane, and the sift loops run on the scalar unit.  For that the registers hold order keys, not
-// floats: key(x) is an unsigned integer with key(a) < key(b) <=> a < b (gfx950 has no scalar float compare),
-// and the float comes back bit for bit from the key.  Each node carries the slot (0..k-1) of its 64-bit id in
-// an LDS table, so ids never move.  (Keys order -0.0 below +0.0 where floats call them equal; distances from
-// the scan kernels are never -0.0.  NaN never enters: admission is tested on the floats.)
+// The reference's heap resident in registers (k <= 127): node i (1-based, Heap.h numbering) lives in lane i & 63 of register
+// i >> 6, as an order key -- key(x) is an unsigned integer with key(a) < key(b) <=> a < b, and the float comes back bit for bit
+// from the key -- next to the slot (0..k-1) of its 64-bit id in an LDS table, so ids never move.  (Keys order -0.0 below +0.0
+// where floats call them equal; distances from the scan kernels are never -0.0.  NaN never enters: admission is tested on the
+// floats.)  This is the form in which a heap is handed between kernels' phases (rh_store); the walks themselves are VHeap's.
 struct RegHeap {
     uint32_t v0, v1;  // keys
     uint32_t s0, s1;  // id slots
@@ -51,142 +48,12 @@ __device__ __forceinline__ void wl2_u(uint32_t& r0, uint32_t v0, uint32_t& r1, u
         : [v0] "s"(v0), [v1] "s"(v1), [l] "s"(l));
 }
 
-__device__ __forceinline__ uint32_t rh_key(const RegHeap& h, int node) {
-    const uint32_t a = rl_u(h.v0, node & 63), b = rl_u(h.v1, node & 63);
-    return node < 64 ? a : b;
-}
-__device__ __forceinline__ uint32_t rh_slot(const RegHeap& h, int node) {
-    const uint32_t a = rl_u(h.s0, node & 63), b = rl_u(h.s1, node & 63);
-    return node < 64 ? a : b;
-}
-// node <- (key, slot); the register is picked by one branch (in C++ the compiler copies both registers around it)
-__device__ __forceinline__ void rh_set(RegHeap& h, int node, uint32_t key, uint32_t slot) {
-    uint32_t m0s;
-    asm volatile(
-        "s_mov_b32 %[m], m0\n\t"
-        "s_cmp_gt_u32 %[n], 63\n\ts_cbranch_scc1 1f\n\t"
-        "s_mov_b32 m0, %[n]\n\ts_nop 0\n\tv_writelane_b32 %[v0], %[k], m0\n\tv_writelane_b32 %[s0], %[s], m0\n\ts_branch 2f\n"
-        "1:\n\ts_sub_u32 m0, %[n], 64\n\ts_nop 0\n\tv_writelane_b32 %[v1], %[k], m0\n\tv_writelane_b32 %[s1], %[s], m0\n"
-        "2:\n\ts_mov_b32 m0, %[m]\n\t"
-        : [v0] "+v"(h.v0), [s0] "+v"(h.s0), [v1] "+v"(h.v1), [s1] "+v"(h.s1), [m] "=&s"(m0s)
-        : [n] "s"(node), [k] "s"(key), [s] "s"(slot)
-        : "scc");
-}
-
-// Heap.h:88-118 (the node being removed, k, still takes part in the child comparisons, as there).
-// KC != 0: k is the compile-time constant KC and the bounds tests of complete levels fold away.
-template <bool IsMax, int KC> __device__ __forceinline__ void rh_pop(RegHeap& h, int krt) {
-    const int k = KC ? KC : krt;
-    const uint32_t v = rh_key(h, k);
-    const uint32_t sv = rh_slot(h, k);
-    int i = 1;
-#pragma unroll
-    for (int lvl = 0; lvl < 6; lvl++) {  // parent on level lvl (node < 64: register 0), children on level lvl + 1
-        const bool absent = KC && (2 << lvl) > KC;      // the whole child level lies beyond k
-        const bool full = KC && (4 << lvl) - 1 <= KC;   // every node of the child level exists
-        if (absent) break;
-        const int i1 = i << 1, i2 = i1 + 1;
-        if (!full && i1 > k) break;
-        const bool only_left = !full && i2 == k + 1;
-        const int j2 = only_left ? i1 : i2;
-        const uint32_t c1 = lvl < 5 ? rl_u(h.v0, i1) : rl_u(h.v1, i1 - 64);
-        const uint32_t c2 = lvl < 5 ? rl_u(h.v0, j2) : rl_u(h.v1, j2 - 64);
-        const bool left = only_left || kcmp<IsMax>(c1, c2);
-        const uint32_t c = left ? c1 : c2;
-        if (kcmp<IsMax>(v, c)) break;
-        const int ci = left ? i1 : i2;
-        const uint32_t cs = lvl < 5 ? rl_u(h.s0, ci) : rl_u(h.s1, ci - 64);
-        wl2_u(h.v0, c, h.s0, cs, i);
-        i = ci;
-    }
-    rh_set(h, i, v, sv);
-}
-
-// The same walk for k = 100, written out in assembly: the compiler's structured control flow spends five scalar
-// instructions per level on exit flags; here a level is 9 scalar + 5 vector instructions and one branch.  Levels 0-4
-// (children in register 0, all present), then level 5 (children 64..100 in register 1; node 50 has the left child only,
-// which the equal-keys case of the selection handles: both reads name the same lane and the "right" pick is that lane).
-#define RH_ASM_LEVEL(MAXOP, CMPOP)                                                                                      \
-    "s_lshl_b32 %[a], %[i], 1\n\ts_or_b32 %[b], %[a], 1\n\tv_readlane_b32 %[k1], %[v0], %[a]\n\tv_readlane_b32 %[k2], %[v0], %[b]\n\t" \
-    MAXOP " %[c], %[k1], %[k2]\n\t" CMPOP " %[v], %[c]\n\ts_cbranch_scc1 9f\n\t" CMPOP " %[k1], %[k2]\n\ts_cselect_b32 %[a], %[a], %[b]\n\t" \
-    "v_readlane_b32 %[cs], %[s0], %[a]\n\ts_mov_b32 m0, %[i]\n\ts_nop 0\n\tv_writelane_b32 %[v0], %[c], m0\n\t"                       \
-    "v_writelane_b32 %[s0], %[cs], m0\n\ts_mov_b32 %[i], %[a]\n\t"
-#define RH_ASM_LAST(MAXOP, CMPOP)                                                                                       \
-    "s_cmp_gt_u32 %[i], 50\n\ts_cbranch_scc1 9f\n\ts_lshl_b32 %[a], %[i], 1\n\ts_sub_u32 %[a], %[a], 64\n\ts_or_b32 %[b], %[a], 1\n\t"     \
-    "s_cmp_eq_u32 %[i], 50\n\ts_cselect_b32 %[b], %[a], %[b]\n\tv_readlane_b32 %[k1], %[v1], %[a]\n\tv_readlane_b32 %[k2], %[v1], %[b]\n\t" \
-    MAXOP " %[c], %[k1], %[k2]\n\t" CMPOP " %[v], %[c]\n\ts_cbranch_scc1 9f\n\t" CMPOP " %[k1], %[k2]\n\ts_cselect_b32 %[a], %[a], %[b]\n\t" \
-    "v_readlane_b32 %[cs], %[s1], %[a]\n\ts_mov_b32 m0, %[i]\n\ts_nop 0\n\tv_writelane_b32 %[v0], %[c], m0\n\t"                       \
-    "v_writelane_b32 %[s0], %[cs], m0\n\ts_add_u32 %[i], %[a], 64\n\t"                                                 \
-    "9:\n\t"
-template <bool IsMax> __device__ __forceinline__ void rh_pop_k100(RegHeap& h) {
-    const uint32_t v = rl_u(h.v1, 100 - 64);
-    const uint32_t sv = rl_u(h.s1, 100 - 64);
-    int i = 1;
-    uint32_t a, b, k1, k2, c, cs, m0s;
-    if (IsMax) {
-        asm volatile("s_mov_b32 %[m], m0\n\t" RH_ASM_LEVEL("s_max_u32", "s_cmp_gt_u32") RH_ASM_LEVEL("s_max_u32", "s_cmp_gt_u32") RH_ASM_LEVEL("s_max_u32", "s_cmp_gt_u32")
-                         RH_ASM_LEVEL("s_max_u32", "s_cmp_gt_u32") RH_ASM_LEVEL("s_max_u32", "s_cmp_gt_u32") RH_ASM_LAST("s_max_u32", "s_cmp_gt_u32")
-                     "s_mov_b32 m0, %[m]\n\t"
-                     : [i] "+s"(i), [v0] "+v"(h.v0), [s0] "+v"(h.s0), [a] "=&s"(a), [b] "=&s"(b), [k1] "=&s"(k1), [k2] "=&s"(k2),
-                       [c] "=&s"(c), [cs] "=&s"(cs), [m] "=&s"(m0s)
-                     : [v] "s"(v), [v1] "v"(h.v1), [s1] "v"(h.s1)
-                     : "scc");
-    } else {
-        asm volatile("s_mov_b32 %[m], m0\n\t" RH_ASM_LEVEL("s_min_u32", "s_cmp_lt_u32") RH_ASM_LEVEL("s_min_u32", "s_cmp_lt_u32") RH_ASM_LEVEL("s_min_u32", "s_cmp_lt_u32")
-                         RH_ASM_LEVEL("s_min_u32", "s_cmp_lt_u32") RH_ASM_LEVEL("s_min_u32", "s_cmp_lt_u32") RH_ASM_LAST("s_min_u32", "s_cmp_lt_u32")
-                     "s_mov_b32 m0, %[m]\n\t"
-                     : [i] "+s"(i), [v0] "+v"(h.v0), [s0] "+v"(h.s0), [a] "=&s"(a), [b] "=&s"(b), [k1] "=&s"(k1), [k2] "=&s"(k2),
-                       [c] "=&s"(c), [cs] "=&s"(cs), [m] "=&s"(m0s)
-                     : [v] "s"(v), [v1] "v"(h.v1), [s1] "v"(h.s1)
-                     : "scc");
-    }
-    rh_set(h, i, v, sv);
-}
-#undef RH_ASM_LEVEL
-#undef RH_ASM_LAST
-
-// Heap.h:125-142
-template <bool IsMax, int KC> __device__ __forceinline__ void rh_push(RegHeap& h, int krt, uint32_t v, uint32_t sv) {
-    int i = KC ? KC : krt;
-    while (i > 1) {
-        const int f = i >> 1;  // < 64
-        const uint32_t fv = rl_u(h.v0, f);
-        if (!kcmp<IsMax>(v, fv)) break;
-        const uint32_t fs = rl_u(h.s0, f);
-        rh_set(h, i, fv, fs);
-        i = f;
-    }
-    rh_set(h, i, v, sv);
-}
-
-// Heap.h:125-142 for k = 100: the ancestors of node 100 are fixed (50, 25, 12, 6, 3, 1), a new value rarely climbs
-// past the first
-template <bool IsMax> __device__ __forceinline__ void rh_push_k100(RegHeap& h, uint32_t v, uint32_t sv) {
-    int i = 100;
-#define RH_PUSH_STEP(F)                         \
-    {                                           \
-        const uint32_t fv = rl_u(h.v0, F);      \
-        if (!kcmp<IsMax>(v, fv)) goto done;     \
-        const uint32_t fs = rl_u(h.s0, F);      \
-        rh_set(h, i, fv, fs);                   \
-        i = F;                                  \
-    }
-    RH_PUSH_STEP(50)
-    RH_PUSH_STEP(25)
-    RH_PUSH_STEP(12)
-    RH_PUSH_STEP(6)
-    RH_PUSH_STEP(3)
-    RH_PUSH_STEP(1)
-#undef RH_PUSH_STEP
-done:
-    rh_set(h, i, v, sv);
-}
-
 // ---------------------------------------------------------------------------------------------
-// The same heap as VECTOR work without a branch (k <= 127): tie_fix_kernel's replay.  A walk down the lane-resident heap above is a
-// chain of scalar decisions -- two v_readlane, a compare and a taken branch per level, ~520 ns a pop + push at k = 100 on a wave
-// that runs alone on its SIMD (scratch/ubench/tie_fix.hip, issue_cost.hip: ~2.5 ns an instruction, ~11 ns a taken branch).  Here a
-// pop is one pass of all lanes over all nodes:
+// The heap's walks as VECTOR work without a branch (k <= 127): tie_fix_kernel's replay and replay_kernel's admissions.  Walked
+// node by node (rounds 2-4: v_readlane / v_writelane on wave-uniform indices, the sift loops on the scalar unit) a level is two
+// lane reads, a compare and a taken branch: ~520 ns a pop + push at k = 100 on a wave that runs alone on its SIMD
+// (scratch/ubench/tie_fix.hip; issue_cost.hip: ~2.5 ns an instruction, ~11 ns a taken branch); this form takes 290.  Here a pop
+// is one pass of all lanes over all nodes:
 //   1. every node compares itself with its sibling (one DPP): w(i) = "i is the child its parent would pick" (Heap.h:100: the left
 //      one iff it is strictly worse-ranked than the right; absent nodes hold key 0 and never win);
 //   2. a node is on the root's path iff w holds for it and all its ancestors: the ballots of w against per-lane constant masks;
@@ -296,14 +163,6 @@ template <bool TWO> __device__ __forceinline__ void vh_push(VHeap& h, const VHea
     }
     h.k0 = vh_sel(land0, nv, vh_sel(down0, f0, h.k0));
     h.p0 = vh_sel(land0, np, vh_sel(down0, fp0, h.p0));
-}
-
-// LDS heap arrays (node order) -> registers; slot j holds the id of node j + 1
-__device__ __forceinline__ void rh_load(RegHeap& h, const float* hval, int k, int lane) {
-    h.v0 = (lane >= 1 && lane <= k) ? fkey(hval[lane - 1]) : 0u;
-    h.s0 = (uint32_t)(lane - 1);
-    h.v1 = (lane + 64 <= k) ? fkey(hval[lane + 63]) : 0u;
-    h.s1 = (uint32_t)(lane + 63);
 }
 
 // registers -> LDS heap arrays in node order (ids permuted through registers)
@@ -775,9 +634,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
     uint32_t stoped = a.stoped ? a.stoped[qi] : 0u;
     unsigned long long st_nlist = 0, st_nheap = 0, st_ndis = 0;
 
-    constexpr bool asm_off = false;  // true: the C++ walk for k = 100 too
-    RegHeap rh{};
-    if (RH) rh_load(rh, hval, k, lane);
+    // RH: the heap in lanes, walked as vector work (VHeap); a node's payload is the slot of its 64-bit id in href[], so ids never move
+    constexpr bool VTWO = KC == 0 || KC > 63;
+    auto stored = [](float x) { return IsMax ? fkey(x) : ~fkey(x); };
+    auto unstored = [](uint32_t sk) { return fkey_inv(IsMax ? sk : ~sk); };
+    VHeap vh{0u, 0u, 0u, 0u};
+    const VHeapLane vc = vh_lane(lane);
+    unsigned long long chain0 = 0, chain1 = 0;
+    if (RH) {
+        if (lane >= 1 && lane <= k) vh.k0 = stored(hval[lane - 1]);
+        if (VTWO && lane + 64 <= k) vh.k1 = stored(hval[lane + 63]);
+        vh.p0 = (uint32_t)(lane - 1);
+        vh.p1 = (uint32_t)(lane + 63);
+        for (int i = k; i >= 1; i >>= 1) {
+            if (i < 64) chain0 |= 1ull << i;
+            else chain1 |= 1ull << (i - 64);
+        }
+    }
+    // registers -> LDS heap arrays in node order (rh_store's form)
+    auto vh_store = [&](bool with_refs) {
+        RegHeap rh{IsMax ? vh.k0 : ~vh.k0, IsMax ? vh.k1 : ~vh.k1, vh.p0, vh.p1};
+        rh_store(rh, hval, href, k, lane, with_refs);
+    };
 
     int win_start = -1;
     if (geo) {
@@ -949,7 +827,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
                         if (b0 >= n) break;
                         fetch(nv);
                     }
-                    float top = RH ? fkey_inv(rl_u(rh.v0, 1)) : hval[0];  // heap top, kept in a register between admissions
+                    float top = RH ? unstored(rl_u(vh.k0, 1)) : hval[0];  // heap top, kept in a register between admissions
                     // chunks (64 candidates) holding at least one value that beats the top as it is now
                     uint32_t umask = 0;
 #pragma unroll
@@ -975,13 +853,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
                             if (hcmp<IsMax>(top, val)) {
                                 const int64_t nref = refbase | (int64_t)(cbase + l);
                                 if (RH) {
-                                    const uint32_t sr = rl_u(rh.s0, 1);  // the evicted root's id slot passes to the new entry
+                                    const uint32_t sr = rl_u(vh.p0, 1);  // the evicted root's id slot passes to the new entry
                                     if (lane == 0) href[sr] = nref;
-                                    if (KC == 100 && !asm_off) rh_pop_k100<IsMax>(rh);
-                                    else rh_pop<IsMax, KC>(rh, k);
-                                    if (KC == 100 && !asm_off) rh_push_k100<IsMax>(rh, fkey(val), sr);
-                                    else rh_push<IsMax, KC>(rh, k, fkey(val), sr);
-                                    top = fkey_inv(rl_u(rh.v0, 1));
+                                    vh_pop<VTWO>(vh, vc, lane, vh_key_at<VTWO>(vh, k), vh_pay_at<VTWO>(vh, k));
+                                    vh_push<VTWO>(vh, vc, k, chain0, chain1, stored(val), sr);
+                                    top = unstored(rl_u(vh.k0, 1));
                                 } else {
                                     heap_pop<IsMax>(k, hval, href);
                                     heap_push<IsMax>(k, hval, href, val, nref);
@@ -1009,7 +885,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
                         for (uint32_t u = 0; u < npend; u++)
                             if (sorted_replace_worst<IsMax>(srt, k, pend[u], lane) < (int)query_k) top_changed = true;
                     } else {
-                        if (RH) rh_store(rh, hval, href, k, lane, false);
+                        if (RH) vh_store(false);
                         rank_sort_best_first<IsMax>(hval, srt, k, lane);
                         wave_sync();
                         top_changed = true;
@@ -1093,7 +969,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
                 if (stage >= nlist / 8) finished = true;
             } else if (np != 0 && np <= stage) {
                 if (a.tuner.profile) {
-                    if (RH) rh_store(rh, hval, href, k, lane, false);
+                    if (RH) vh_store(false);
                     uint32_t hits = 0;
                     for (int i = lane; i < k; i += 64) {
                         const float s = hval[i];
@@ -1175,8 +1051,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
     }
 
     wave_sync();
-    if (a.thr && lane == 0) a.thr[qi] = RH ? fkey_inv(rl_u(rh.v0, 1)) : hval[0];  // next round's scan stores only what beats this
-    if (RH) rh_store(rh, hval, href, k, lane, true);  // back to the node-ordered LDS layout
+    if (a.thr && lane == 0) a.thr[qi] = RH ? unstored(rl_u(vh.k0, 1)) : hval[0];  // next round's scan stores only what beats this
+    if (RH) vh_store(true);  // back to the node-ordered LDS layout
     if (finished || a.finalize_all || err) {
         if (a.raw_heap_out) {
             for (int i = lane; i < k; i += 64) {
