@@ -11,6 +11,7 @@ cp gpurun_out/shards_$tag.json profiles/${tag}_shards_one_gpu.json
 cp gpurun_out/effect_time_$tag.jsonl profiles/${tag}_effect_time.jsonl
 cp gpurun_out/latency1_$tag.txt profiles/${tag}_latency_batch1.txt
 cp gpurun_out/bw_probe_$tag.txt profiles/${tag}_bw_probe.txt
+cp gpurun_out/latency1_calls_summary_$tag.txt profiles/${tag}_latency_batch1_calls.txt 2>/dev/null
 cp gpurun_out/gpu_tests_$tag.txt profiles/${tag}_gpu_tests.txt
 grep -v "rocprofv3\|^W2026\|^E2026" gpurun_out/in_flight_busy_$tag.txt > profiles/${tag}_in_flight_busy.txt
 cp gpurun_out/bench_driver_flags_$tag.json profiles/${tag}_bench_line_driver_flags.json

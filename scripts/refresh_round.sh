@@ -14,6 +14,8 @@ python bench.py --mode shards --test 10000 > gpurun_out/shards_$tag.json 2> gpur
 python scripts/effect_time.py > gpurun_out/effect_time_$tag.jsonl 2> gpurun_out/effect_time_$tag.log
 python scratch/latency1.py > gpurun_out/latency1_$tag.txt 2> gpurun_out/latency1_$tag.log
 python scratch/bw_probe.py > gpurun_out/bw_probe_$tag.txt 2> gpurun_out/bw_probe_$tag.log
+bash scripts/latency1_calls.sh $tag > gpurun_out/latency1_calls_$tag.log 2>&1
+python3 scripts/latency1_summary.py gpurun_out/latency1_calls_$tag.txt > gpurun_out/latency1_calls_summary_$tag.txt 2>&1
 bash scripts/timelines.sh $tag > gpurun_out/timelines_$tag.log 2>&1
 bash scripts/busy.sh > gpurun_out/in_flight_busy_$tag.txt 2>&1
 python bench.py --steps 20 --warmup 5 --no-cpu --no-legs > gpurun_out/bench_driver_flags_$tag.json 2> /dev/null
