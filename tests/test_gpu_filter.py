@@ -161,3 +161,67 @@ def test_fp16_form_without_a_usable_scale(capi, oracle, form):
         xb2 = xb.copy()
         xb2[123] *= np.float32(factor if factor < 1 else 2.0 ** 40)
         run_and_compare(capi, oracle, 1, cen, assign, xb2, xq, k=10, nprobe=8)
+
+
+@pytest.mark.parametrize("metric", [1, 0])
+@pytest.mark.parametrize("d", [20, 96, 128, 960])
+def test_dense_rounds_from_rows_and_from_the_lane_ordered_copy(capi, oracle, d, metric):
+    """option "lanes": scan_lanes_kernel (the lists in the order a wave consumes them) and scan_tiles_kernel (rows staged through
+    LDS) are the same arithmetic in the same order -- ids, distances and statistics equal each other and the oracle's in every
+    tile shape (1 .. 64 queries on a list, ragged lists, a list of a few vectors, an empty one)"""
+    rs = np.random.RandomState(7300 + d + metric)
+    for nlist, nq in ((64, 100), (16, 260), (4, 300)):
+        cen, assign, xb, xq = clustered(rs, 3000, nq, d, nlist)
+        assign[:5] = nlist - 1  # (some vectors in the last list whatever the draw)
+        lists = oracle.Lists(metric, cen, xb, assign)
+        cd, ck = oracle.knn(metric, xq, cen, min(8, nlist))
+        eD, eI, est = oracle.search_preassigned(lists, xq, 10, ck, cd)
+        got = []
+        for lanes in (1, 0):
+            h = capi.Handle(d, nlist, metric, 0)
+            h.set_centroids(cen)
+            h.set_lists_from_assign(xb, assign)
+            h.set_option("lanes", lanes)
+            h.stats(reset=True)
+            D, I = h.search_preassigned(xq, 10, ck, cd)
+            st = h.stats()
+            assert np.array_equal(I, eI) and np.array_equal(bits(D), bits(eD)), (lanes, nlist)
+            assert [st["nlist"], st["ndis"], st["nheap_updates"]] == list(est)
+            got.append((D, I))
+            h.close()
+        assert np.array_equal(got[0][1], got[1][1]) and np.array_equal(bits(got[0][0]), bits(got[1][0]))
+
+
+def test_large_fp32_searches_wait_for_each_other(capi, oracle):
+    """option "fp32_in_flight": with room for one, three threads' searches of >= 256 queries run one after the other and every one
+    returns the oracle's result"""
+    import threading
+    rs = np.random.RandomState(7400)
+    cen, assign, xb, xq = clustered(rs, 4000, 300, 64, 16)
+    lists = oracle.Lists(1, cen, xb, assign)
+    cd, ck = oracle.knn(1, xq, cen, 8)
+    eD, eI, _ = oracle.search_preassigned(lists, xq, 10, ck, cd)
+    h = capi.Handle(64, 16, 1, 0)
+    h.set_centroids(cen)
+    h.set_lists_from_assign(xb, assign)
+    h.set_option("fp32_in_flight", 1)
+    ctxs = [h.clone() for _ in range(3)]
+    out, errs = [None] * 3, []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                out[i] = ctxs[i].search_preassigned(xq, 10, ck, cd)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert not errs and all(not t.is_alive() for t in ts)
+    for D, I in out:
+        assert np.array_equal(I, eI) and np.array_equal(bits(D), bits(eD))
+    for c in ctxs:
+        c.close()
+    h.close()
