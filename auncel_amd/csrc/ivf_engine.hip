@@ -648,6 +648,8 @@ void upload_lists(amd_ivf* h) {
     h->h_list_off.assign(h->nlist + 1, 0);
     for (size_t l = 0; l < h->nlist; l++) h->h_list_off[l + 1] = h->h_list_off[l] + h->h_ids[l].size();
     size_t nt = h->h_list_off[h->nlist];
+    // (a tile's first vector travels in the low SCAN_VB_BITS bits of ScanItem::vec_base: scan_vec_base)
+    if ((uint64_t)nt >= (1ull << SCAN_VB_BITS)) throw EngineError("too many vectors for one index");
     h->d_codes.ensure(std::max<size_t>(nt, 1) * h->dpad * sizeof(float));
     h->d_ids.ensure(std::max<size_t>(nt, 1) * sizeof(int64_t));
     h->d_list_off.ensure((h->nlist + 1) * sizeof(uint64_t));
