@@ -2391,6 +2391,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
             sa.hint_qg[1] = hint_of(round, CNT_QG2);
             sa.hint_qg[2] = hint_of(round, CNT_QG4);
             sa.hint_qg[3] = hint_of(round, CNT_QG8);
+            sa.hint_valid = chained && (round + 1) * 16 <= h->round_hint.size();
             if (thr_mode) {
                 sa.thr = h->w_thr.as<float>();
                 sa.mask = h->w_mask.as<unsigned long long>();

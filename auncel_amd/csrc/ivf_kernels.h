@@ -90,6 +90,7 @@ struct ScanArgs {
     // correctness -- workgroups stride over the true count -- and a right-sized grid lets the dispatcher interleave the
     // workgroups of several search contexts where resident grids would run one context's launch to its end first.
     uint32_t hint_qg[4];
+    int hint_valid;     // hint_qg is what the same round of the previous search needed (a 0 there: probably no item of the shape again)
     // the lists once more in LANE ORDER (launch_lanes_from_f32), or null: 64-vector blocks (lists padded like the fragment copies:
     // block_off / 2), block b = d/4 pieces of 1 KiB, piece s = lane l's elements 4s .. 4s+3 of vector 64 b + l.  A wave streams a
     // block with one fully coalesced 16-byte-a-lane load per piece: scan_lanes_kernel needs no LDS staging and no barrier.

@@ -481,7 +481,9 @@ template <int QG> static void launch_scan_qg(ScanArgs a, size_t first, size_t n,
     auto go = [&](auto kern) {
         static const unsigned per_cu = blocks_per_cu(kern, threads);
         const unsigned hinted = ((unsigned)((size_t)hint + hint / 8 + 7) / 8) * 8 + 8;  // last time's count + 12 %
-        const dim3 grid((unsigned)(a.dev_counts ? (hint ? hinted : resident_grid(per_cu)) : a.xcd_chunks ? ((n + 7) / 8) * 8 : n)), block(threads);
+        // (a shape the same round of the previous search had no item of gets one workgroup a CU: a fully resident grid that finds nothing to do
+        // still has to be placed on the chip behind the other shapes' workgroups, and the round's join waits for it)
+        const dim3 grid((unsigned)(a.dev_counts ? (hint ? hinted : a.hint_valid ? resident_grid(1) : resident_grid(per_cu)) : a.xcd_chunks ? ((n + 7) / 8) * 8 : n)), block(threads);
         LAUNCH(kern, grid, block, 0, s, a);
     };
     if (a.lanes) {
