@@ -1643,9 +1643,11 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
         size_t t = h->timer.begin(CAT_COARSE, s);
         h->w_xnorms.ensure(n * sizeof(float));
         h->w_dist.ensure(n * nlist * sizeof(float));
-        h->c_pick_flag.ensure((n + 1) * 4);
+        static const bool dbg_pick = getenv("AUNCEL_AMD_DEBUG_PICK") != nullptr;  // why rankings are flagged (five counters behind the list)
+        h->c_pick_flag.ensure((n + 1 + 8) * 4);
         h->p_pick.ensure((n + 1) * 4);
         HIP_CHECK(hipMemsetAsync(h->c_pick_flag.p, 0, 4, s));
+        if (dbg_pick) HIP_CHECK(hipMemsetAsync(h->c_pick_flag.as<uint32_t>() + n + 1, 0, 32, s));
         launch_row_norms(d_x, n, h->dpad, h->w_xnorms.as<float>(), s);
         const FilterParams* prm = nullptr;
         if (opt(h, OPT_COARSE_PICK, 2) >= 2 && ix(h)->d_cinfo.p) {
@@ -1666,7 +1668,7 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
         }
         launch_coarse_pick(h->metric, h->w_dist.as<float>(), d_x, ix(h)->d_centroids.as<float>(), h->w_xnorms.as<float>(), ix(h)->centroid_norm_max,
                            (uint32_t)n, (uint32_t)nlist, (uint32_t)nprobe, h->dpad, d_out_dis, d_out_keys, h->c_pick_flag.as<uint32_t>(),
-                           h->c_pick_flag.as<uint32_t>() + 1, s, prm);
+                           h->c_pick_flag.as<uint32_t>() + 1, s, prm, dbg_pick ? h->c_pick_flag.as<uint32_t>() + n + 1 : nullptr);
         h->timer.end(t, s);
         // (the flagged queries: how many, which)
         CopySegs c{};
@@ -1677,6 +1679,12 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
         launch_copy_segs(c, s);
         HIP_CHECK(stream_sync(s));
         const uint32_t m = h->p_pick.as<uint32_t>()[0];
+        if (dbg_pick) {
+            uint32_t why[5];
+            HIP_CHECK(hipMemcpy(why, h->c_pick_flag.as<uint32_t>() + n + 1, sizeof(why), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[pick] %u of %zu rankings flagged: threshold/scale %u, too many candidates %u, too few %u, not finite %u, equal distances %u\n", m, n,
+                    why[0], why[1], why[2], why[3], why[4]);
+        }
         if (m) {
             h->c_pick_x.ensure((size_t)m * h->dpad * sizeof(float));
             h->c_pick_dis.ensure((size_t)m * nprobe * 4);

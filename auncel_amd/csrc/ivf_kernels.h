@@ -592,7 +592,7 @@ void launch_coarse_gemm(int metric, const float* X, const float* Y, const float*
 // flagged[] and left to the caller
 void launch_coarse_pick(int metric, const float* approx, const float* x, const float* centroids, const float* xn, float cmax, uint32_t n,
                         uint32_t nlist, uint32_t nprobe, int dpad, float* out_dis, int64_t* out_keys, uint32_t* nflag, uint32_t* flagged,
-                        hipStream_t s, const FilterParams* params = nullptr);  // params: the approximate distances came from launch_coarse_gemm16
+                        hipStream_t s, const FilterParams* params = nullptr, uint32_t* why = nullptr);  // params: the approximate distances came from launch_coarse_gemm16
 void launch_scatter_rows(const void* in, const uint32_t* idx, uint32_t m, uint32_t words, void* out, hipStream_t s);
 
 // packed upper triangle (IVF_pro.cpp:21-39 layout) of a full nlist x nlist distance matrix

@@ -1960,6 +1960,8 @@ struct CoarsePickArgs {
     int64_t* out_keys;
     uint32_t* nflag;          // += 1 per flagged query
     uint32_t* flagged;        // [n] their numbers
+    uint32_t* why;            // [5] (debugging, or null): flagged because of 0 the threshold / scale, 1 too many candidates, 2 too few,
+                              // 3 a distance that is not finite, 4 equal distances among the first nprobe + 1
 };
 constexpr uint32_t PICK_CAP = 1024;
 template <int METRIC>
@@ -2008,6 +2010,7 @@ __global__ __launch_bounds__(256) void coarse_pick_kernel(CoarsePickArgs a) {
     const float eps = METRIC == METRIC_L2 ? Cb * (xn + a.cmax) : Cb * sqrtf(xn) * sqrtf(a.cmax);
     const float Tw = Ascending ? Tv + 2.f * eps : Tv - 2.f * eps;
     bool bad = !(fabsf(Tw) < 3.0e38f) || Cb < 0.f;  // (NaN, infinities, no usable fp16 scale: the caller's exact path deals with them)
+    uint32_t why = bad ? 1u : 0u;
     const uint32_t kw = Ascending ? fkey(Tw) : ~fkey(Tw);
     __syncthreads();
 #pragma unroll
@@ -2023,7 +2026,7 @@ __global__ __launch_bounds__(256) void coarse_pick_kernel(CoarsePickArgs a) {
     }
     __syncthreads();
     const uint32_t C = s_cnt;
-    if (C > PICK_CAP || C < a.nprobe) bad = true;
+    if (C > PICK_CAP || C < a.nprobe) bad = true, why |= C > PICK_CAP ? 2u : 4u;
     const uint32_t n = C < PICK_CAP ? C : PICK_CAP;
     uint32_t S = 64;
     while (S < n) S <<= 1;
@@ -2077,7 +2080,7 @@ __global__ __launch_bounds__(256) void coarse_pick_kernel(CoarsePickArgs a) {
         if (sub == 0) {
             unsigned long long e = ~0ull;
             if (have) {
-                if (!(fabsf(ex) < 3.0e38f)) bad = true;
+                if (!(fabsf(ex) < 3.0e38f)) bad = true, why |= 8u;
                 e = ((unsigned long long)(Ascending ? fkey(ex) : ~fkey(ex)) << 32) | i;
             }
             buf[c] = e;
@@ -2100,11 +2103,16 @@ __global__ __launch_bounds__(256) void coarse_pick_kernel(CoarsePickArgs a) {
     }
     // equal neighbours among the first nprobe + 1: the reference's order there is its heap's
     for (uint32_t i = tid; i < a.nprobe && i + 1 < n; i += 256)
-        if ((uint32_t)(buf[i] >> 32) == (uint32_t)(buf[i + 1] >> 32)) bad = true;
-    if (bad) atomicOr(&s_bad, 1u);
+        if ((uint32_t)(buf[i] >> 32) == (uint32_t)(buf[i + 1] >> 32)) bad = true, why |= 16u;
+    if (bad) atomicOr(&s_bad, why ? why : 1u);
     __syncthreads();
     if (s_bad) {
-        if (tid == 0) a.flagged[atomicAdd(a.nflag, 1u)] = q;
+        if (tid == 0) {
+            a.flagged[atomicAdd(a.nflag, 1u)] = q;
+            if (a.why)
+                for (int r = 0; r < 5; r++)
+                    if (s_bad & (1u << r)) atomicAdd(&a.why[r], 1u);
+        }
         return;
     }
     for (uint32_t i = tid; i < a.nprobe; i += 256) {
@@ -2116,9 +2124,9 @@ __global__ __launch_bounds__(256) void coarse_pick_kernel(CoarsePickArgs a) {
 }
 void launch_coarse_pick(int metric, const float* approx, const float* x, const float* centroids, const float* xn, float cmax, uint32_t n,
                         uint32_t nlist, uint32_t nprobe, int dpad, float* out_dis, int64_t* out_keys, uint32_t* nflag, uint32_t* flagged,
-                        hipStream_t s, const FilterParams* params) {
+                        hipStream_t s, const FilterParams* params, uint32_t* why) {
     if (n == 0) return;
-    CoarsePickArgs a{approx, x, centroids, xn, cmax, (2.f * (float)dpad + 32.f) * 5.9604645e-8f, params, nlist, nprobe, dpad, out_dis, out_keys, nflag, flagged};
+    CoarsePickArgs a{approx, x, centroids, xn, cmax, (2.f * (float)dpad + 32.f) * 5.9604645e-8f, params, nlist, nprobe, dpad, out_dis, out_keys, nflag, flagged, why};
     if (metric == METRIC_L2) LAUNCH(coarse_pick_kernel<METRIC_L2>, dim3(n), dim3(256), 0, s, a);
     else LAUNCH(coarse_pick_kernel<METRIC_IP>, dim3(n), dim3(256), 0, s, a);
 }
