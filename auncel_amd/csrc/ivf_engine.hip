@@ -75,8 +75,8 @@ enum OptId {
                         // other search of the index is running
     OPT_LANES,          // fp32 dense rounds from a lane-ordered copy of the lists (1, scan_lanes_kernel: one coalesced KiB per 64 vectors and
                         // step, no LDS staging) or from the rows (0, scan_tiles_kernel); the copy costs the lists' bytes once more
-    OPT_FP32_IN_FLIGHT, // large fp32 searches of one index that run at a time (4): each keeps five streams busy, and from the fifth on they
-                        // queue behind each other in the hardware queues (measured: 4 at a time 1.35 M queries/s, 6 at a time 0.78); others wait
+    OPT_FP32_IN_FLIGHT, // large fp32 searches of one index that run at a time (4, the measured optimum: 1.43 / 1.42 / 1.37 / 1.33 M queries/s
+                        // at 4 / 5 / 6 / 8 at a time); the others wait inside their calls
     N_OPT
 };
 struct OptSpec {
@@ -1239,17 +1239,15 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
             launch_scan_mfma(ma, s);
             h->timer.end(t, s);
         } else if (nitems) {
-            ensure_aux(h, 0, 3);
+            ensure_aux(h, 3, 3);
             size_t t = h->timer.begin(CAT_SCAN, s);
-            const bool fork = true;  // every shape on a side stream (see make_main_stream)
+            const bool fork = true;  // the shapes on the side stream (see make_main_stream; one stream: run_rounds_device's note)
             if (fork) {
                 HIP_CHECK(hipEventRecord(h->ev_fork, s));
-                for (int i = 0; i < 4; i++) HIP_CHECK(hipStreamWaitEvent(h->aux[i], h->ev_fork, 0));
-                launch_scan(sa, n_qg, h->aux[3], h->aux[0], h->aux[1], h->aux[2]);
-                for (int i = 0; i < 4; i++) {
-                    HIP_CHECK(hipEventRecord(h->ev_join[i], h->aux[i]));
-                    HIP_CHECK(hipStreamWaitEvent(s, h->ev_join[i], 0));
-                }
+                HIP_CHECK(hipStreamWaitEvent(h->aux[3], h->ev_fork, 0));
+                launch_scan(sa, n_qg, h->aux[3], h->aux[3], h->aux[3], h->aux[3]);
+                HIP_CHECK(hipEventRecord(h->ev_join[3], h->aux[3]));
+                HIP_CHECK(hipStreamWaitEvent(s, h->ev_join[3], 0));
             } else {
                 launch_scan(sa, n_qg, s);
             }
@@ -2290,7 +2288,12 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         planned_rounds++;
     };
     static const bool xcd_off = getenv("AUNCEL_AMD_NO_XCD_CHUNKS") != nullptr;
-    static const int nstreams = getenv("AUNCEL_AMD_SCAN_STREAMS") ? atoi(getenv("AUNCEL_AMD_SCAN_STREAMS")) : 4;
+    // side streams of an fp32 round's tile shapes.  Round 4 gave every shape its own (each filled the chip's LDS by itself); the
+    // lane-ordered kernel holds no LDS, the shapes share the chip from one stream just as well (cfg 3 / 5 and a lone fp32 batch: the
+    // same within a run's spread at 4 / 2 / 1) -- and with four low-class streams a search, the fifth fp32 search in flight pushed
+    // them three to a hardware queue: 0.31 M q/s at five at a time, 0.20 with a round growth of 5, against 1.41 and 1.42 with one
+    // (profiles/r05_experiments.txt Y2)
+    static const int nstreams = getenv("AUNCEL_AMD_SCAN_STREAMS") ? atoi(getenv("AUNCEL_AMD_SCAN_STREAMS")) : 1;
 
     // ---- the scan of a planned round.  counts == nullptr: sizes on the device (chained); else the counters read back.
     auto enqueue_scan = [&](bool thr_mode, const uint32_t* counts, size_t round) {
@@ -2411,17 +2414,20 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
                 n_qg[2] = counts[CNT_QG4];
                 n_qg[3] = counts[CNT_QG8];
             }
-            // every shape on a side stream (see make_main_stream)
-            ensure_aux(h, 0, 3);
+            // the shapes on the side stream(s) (see make_main_stream); streams that carry nothing are not made at all
+            const bool use_aux[4] = {nstreams >= 2, nstreams >= 3, nstreams >= 3, true};
+            ensure_aux(h, nstreams >= 2 ? 0 : 3, 3);
             HIP_CHECK(hipEventRecord(h->ev_fork, s));
-            for (int i = 0; i < 4; i++) HIP_CHECK(hipStreamWaitEvent(h->aux[i], h->ev_fork, 0));
-            if (nstreams == 1) launch_scan(sa, n_qg, h->aux[3], h->aux[3], h->aux[3], h->aux[3]);
+            for (int i = 0; i < 4; i++)
+                if (use_aux[i]) HIP_CHECK(hipStreamWaitEvent(h->aux[i], h->ev_fork, 0));
+            if (nstreams <= 1) launch_scan(sa, n_qg, h->aux[3], h->aux[3], h->aux[3], h->aux[3]);
             else if (nstreams == 2) launch_scan(sa, n_qg, h->aux[3], h->aux[0], h->aux[0], h->aux[3]);  // 8,4 | 2,1
             else launch_scan(sa, n_qg, h->aux[3], h->aux[0], h->aux[1], h->aux[2]);
-            for (int i = 0; i < 4; i++) {
-                HIP_CHECK(hipEventRecord(h->ev_join[i], h->aux[i]));
-                HIP_CHECK(hipStreamWaitEvent(s, h->ev_join[i], 0));
-            }
+            for (int i = 0; i < 4; i++)
+                if (use_aux[i]) {
+                    HIP_CHECK(hipEventRecord(h->ev_join[i], h->aux[i]));
+                    HIP_CHECK(hipStreamWaitEvent(s, h->ev_join[i], 0));
+                }
         }
         h->timer.end(t, s);
     };

@@ -372,7 +372,7 @@ int amd_ivf_set_byte_codes(amd_ivf_t* h, int enable);
  *                     64 vectors and 4 dimensions, no staging; the copy costs the lists' bytes once more, built by the
  *                     first fp32 search), 0 from the rows
  *   "fp32_in_flight"  searches of >= 256 queries in fp32 arithmetic that run on the index at a time; further ones      4
- *                     wait inside the call (each keeps five streams busy; 0: no limit)
+ *                     wait inside the call (four is the measured optimum; 0: no limit)
  * amd_ivf_set_option(h, key, NAN) returns the key to "unset".  May be called while search contexts of the index are searching: a
  * search reads what shapes its launches once, when it starts, so the change takes effect with the searches that start after it. */
 int amd_ivf_set_option(amd_ivf_t* h, const char* key, double value);
