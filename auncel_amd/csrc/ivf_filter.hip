@@ -11,7 +11,7 @@
 //                           bit and an entry in the survivor list (slots handed out per wave in chunks: SurvChunk).  Beyond
 //                           128 dimensions a workgroup shares one chunk of the list among up to 128 queries (operand
 //                           through LDS), so that the list is read once however many queries probe it.
-//   2. rescore_kernel       one lane per survivor: the reference's own rounding sequence on the two fp32 rows; the exact
+//   2. rescore_kernel       four lanes per survivor: the reference's own rounding sequence on the two fp32 rows; the exact
 //                           distance goes into the distance row.  A survivor whose exact distance does not beat the threshold
 //                           keeps its mask bit: the selection re-tests every candidate against the query's current worst
 //                           value anyway, so it costs a comparison, never a wrong result.
@@ -298,13 +298,50 @@ void launch_filter_queries16(const float* x, size_t n, int d, int dpad, int metr
 }
 
 // ---------------------------------------------------------------------------------------------
-// one lane per survivor of the filter: exact distance into the distance row
+// The survivors of the filter: exact distance into the distance row, in the reference's sequence (utils_simd.cpp:391-443) -- four
+// running sums over the elements 4 i + l, each accumulated in order, then (s0 + s1) + (s2 + s3).  The four sums are independent
+// chains, so FOUR neighbouring lanes take one survivor (lane l its sum l: the same rounding sequence, as in coarse_pick_kernel)
+// and request sixteen steps of their chain together: a survivor's chain of d / 4 steps is what the kernel's time is (a few
+// survivors per query, far fewer than lanes) -- with one lane a survivor and four steps a trip cfg 5 (d = 960) took 60 trips to
+// memory, 0.26 ms; now 15.
 template <int METRIC> __global__ __launch_bounds__(256) void rescore_kernel(FilterScanArgs a) {
     const uint32_t n = *a.surv_count < a.surv_cap ? *a.surv_count : a.surv_cap;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const uint32_t sub = threadIdx.x & 3;
+    for (uint32_t i = (blockIdx.x * 256 + threadIdx.x) >> 2; i < n; i += gridDim.x * 64) {
         const uint4 e = a.surv[i];  // (distance row position, query row, vector, -)
-        if (e.x == 0xffffffffu) continue;  // (an unused slot of a wave's chunk)
-        a.dist[e.x] = exact_distance<METRIC>(a.queries + (size_t)e.y * a.dpad, a.codes + (size_t)e.z * a.dpad, a.dpad);
+        if (e.x == 0xffffffffu) continue;  // (an unused slot of a wave's chunk; the same for the four lanes of a survivor)
+        const float* x = a.queries + (size_t)e.y * a.dpad;
+        const float* y = a.codes + (size_t)e.z * a.dpad;
+        float sl = 0.f;
+        int c = (int)sub;
+        for (; c + 60 < a.dpad; c += 64) {
+            float xv[16], yv[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                xv[u] = x[c + 4 * u];
+                yv[u] = y[c + 4 * u];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                if (METRIC == METRIC_L2) {
+                    const float t = yv[u] - xv[u];
+                    sl += t * t;
+                } else {
+                    sl += yv[u] * xv[u];
+                }
+            }
+        }
+        for (; c < a.dpad; c += 4) {
+            if (METRIC == METRIC_L2) {
+                const float t = y[c] - x[c];
+                sl += t * t;
+            } else {
+                sl += y[c] * x[c];
+            }
+        }
+        const float pair = sl + __shfl_xor(sl, 1);         // lanes 0/1: s0 + s1, lanes 2/3: s2 + s3 (the sum is commutative bit for bit)
+        const float ex = pair + __shfl_xor(pair, 2);       // (s0 + s1) + (s2 + s3)
+        if (sub == 0) a.dist[e.x] = ex;
     }
 }
 
