@@ -38,12 +38,39 @@ class EngineError(RuntimeError):
         self.code = code
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64.  A process that loads torch first runs this library on
+    that runtime too (its hip* symbols bind to the copy already in the global scope); a process that creates an index first gets
+    ROCm's copy for the library and torch's for torch -- and the second runtime to start finds no device ("No HIP GPUs are
+    available").  So where torch is installed but not yet imported, its runtime is loaded first, globally, and both orders behave
+    like the first.  (C and C++ callers link one runtime and have no such choice to make.)"""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("AUNCEL_AMD_OWN_HIP_RUNTIME"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    d = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        p = os.path.join(d, name)
+        if os.path.exists(p):
+            try:
+                C.CDLL(p, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def lib():
     global _LIB
     if _LIB is None:
         if not os.path.exists(_build.LIB):
             raise ImportError(f"{_build.LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950).  auncel_amd has no CPU fallback.")
+        _share_torch_hip_runtime()
         L = C.CDLL(os.environ.get("AUNCEL_AMD_LIB", _build.LIB))  # AUNCEL_AMD_LIB: a differently built engine (kernel experiments)
         L.amd_ivf_last_error.restype = C.c_char_p
         for s in SYMBOLS[1:]:

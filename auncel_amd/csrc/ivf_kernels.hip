@@ -2044,18 +2044,18 @@ __global__ __launch_bounds__(256) void coarse_pick_kernel(CoarsePickArgs a) {
         const float* y = a.centroids + (size_t)i * a.dpad;
         float sl = 0.f;
         if (have) {
-            // (eight steps of the chain per trip: their loads are requested together, the sums still run in order -- one step at a
-            // time the loop paid a trip to L2 per step of a chain d / 4 steps long)
+            // (sixteen steps of the chain per trip: their loads are requested together, the sums still run in order -- one step at a
+            // time the loop paid a trip to L2 per step of a chain d / 4 steps long; eight a trip: 30 trips at d = 960)
             int e = (int)sub;
-            for (; e + 28 < a.dpad; e += 32) {
-                float yv[8], xv[8];
+            for (; e + 60 < a.dpad; e += 64) {
+                float yv[16], xv[16];
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
+                for (int u = 0; u < 16; u++) {
                     yv[u] = y[e + 4 * u];
                     xv[u] = xq[e + 4 * u];
                 }
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
+                for (int u = 0; u < 16; u++) {
                     if (METRIC == METRIC_L2) {
                         const float t = yv[u] - xv[u];
                         sl += t * t;
