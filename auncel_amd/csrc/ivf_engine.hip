@@ -1642,10 +1642,10 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
         h->w_xnorms.ensure(n * sizeof(float));
         h->w_dist.ensure(n * nlist * sizeof(float));
         static const bool dbg_pick = getenv("AUNCEL_AMD_DEBUG_PICK") != nullptr;  // why rankings are flagged (five counters behind the list)
-        h->c_pick_flag.ensure((n + 1 + 8) * 4);
-        h->p_pick.ensure((n + 1) * 4);
+        h->c_pick_flag.ensure((n + 1 + 8 + 8) * 4);  // (+ the padding of the flagged list, + the debugging counters)
+        h->p_pick.ensure((n + 1 + 8) * 4);
         HIP_CHECK(hipMemsetAsync(h->c_pick_flag.p, 0, 4, s));
-        if (dbg_pick) HIP_CHECK(hipMemsetAsync(h->c_pick_flag.as<uint32_t>() + n + 1, 0, 32, s));
+        if (dbg_pick) HIP_CHECK(hipMemsetAsync(h->c_pick_flag.as<uint32_t>() + n + 1 + 8, 0, 32, s));
         launch_row_norms(d_x, n, h->dpad, h->w_xnorms.as<float>(), s);
         const FilterParams* prm = nullptr;
         if (opt(h, OPT_COARSE_PICK, 2) >= 2 && ix(h)->d_cinfo.p) {
@@ -1666,7 +1666,7 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
         }
         launch_coarse_pick(h->metric, h->w_dist.as<float>(), d_x, ix(h)->d_centroids.as<float>(), h->w_xnorms.as<float>(), ix(h)->centroid_norm_max,
                            (uint32_t)n, (uint32_t)nlist, (uint32_t)nprobe, h->dpad, d_out_dis, d_out_keys, h->c_pick_flag.as<uint32_t>(),
-                           h->c_pick_flag.as<uint32_t>() + 1, s, prm, dbg_pick ? h->c_pick_flag.as<uint32_t>() + n + 1 : nullptr);
+                           h->c_pick_flag.as<uint32_t>() + 1, s, prm, dbg_pick ? h->c_pick_flag.as<uint32_t>() + n + 1 + 8 : nullptr);
         h->timer.end(t, s);
         // (the flagged queries: how many, which)
         CopySegs c{};
@@ -1679,11 +1679,20 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
         const uint32_t m = h->p_pick.as<uint32_t>()[0];
         if (dbg_pick) {
             uint32_t why[5];
-            HIP_CHECK(hipMemcpy(why, h->c_pick_flag.as<uint32_t>() + n + 1, sizeof(why), hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(why, h->c_pick_flag.as<uint32_t>() + n + 1 + 8, sizeof(why), hipMemcpyDeviceToHost));
             fprintf(stderr, "[pick] %u of %zu rankings flagged: threshold/scale %u, too many candidates %u, too few %u, not finite %u, equal distances %u\n", m, n,
                     why[0], why[1], why[2], why[3], why[4]);
         }
-        if (m) {
+        if (const uint32_t m_flagged = m) {
+            // The flagged rankings go the exact way as a call of their own, whose work list is cached by its size (coarse_dev below):
+            // a handful of them -- 3, 7, 5 from one batch to the next -- would upload a new list every time.  They are padded to a
+            // multiple of eight (one query group: the same waves) with copies of the first, which are ranked and scattered twice.
+            const uint32_t m = (m_flagged + 7u) & ~7u;
+            if (m != m_flagged) {
+                uint32_t* list = h->p_pick.as<uint32_t>() + 1;
+                for (uint32_t i = m_flagged; i < m; i++) list[i] = list[0];
+                HIP_CHECK(hipMemcpyAsync(h->c_pick_flag.as<uint32_t>() + 1 + m_flagged, list + m_flagged, (m - m_flagged) * 4, hipMemcpyHostToDevice, s));
+            }
             h->c_pick_x.ensure((size_t)m * h->dpad * sizeof(float));
             h->c_pick_dis.ensure((size_t)m * nprobe * 4);
             h->c_pick_keys.ensure((size_t)m * nprobe * 8);
@@ -1720,7 +1729,7 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
         // only: it lives in buffers of its own (the rounds' planning kernels write the w_* ones) and is uploaded when that
         // signature changes -- a caller that searches batch after batch of one size pays for it once (it was five blits and,
         // for the staging buffers' sake, a host synchronisation per call).
-        const uint64_t csig = ((uint64_t)c0 << 40) ^ ((uint64_t)m << 20) ^ (uint64_t)nlist ^ ((uint64_t)qg << 60);
+        const uint64_t csig = ((uint64_t)c0 << 40) ^ ((uint64_t)m << 20) ^ (uint64_t)nlist ^ ((uint64_t)qg << 60) ^ (use_heap ? 1ull << 59 : 0ull);
         const size_t ng = (m + SCAN_RQ - 1) / SCAN_RQ;
         const bool cached = h->coarse_sig_valid && h->coarse_sig == csig;
         if (!cached) {
@@ -1804,17 +1813,19 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
             // (throw-away statistics: one row per XCD as every selection launch adds to them, and the error word behind the rows)
             constexpr size_t MISC_BYTES = STATS_ROWS * 4 * 8 + 8;
             h->w_misc.ensure(MISC_BYTES);
-            h->p_seg_off.ensure(m * 8);
-            h->p_seg_list.ensure(m * 4);
-            h->p_seg_count.ensure(m * 4);
-            for (size_t i = 0; i < m; i++) {
-                h->p_seg_off.as<uint64_t>()[i] = (uint64_t)i * nlist;
-                h->p_seg_list.as<int32_t>()[i] = 0;
-                h->p_seg_count.as<uint32_t>()[i] = 1;
+            if (!cached) {  // (the heap form's one-row-a-query segment table is part of the cached work list)
+                h->p_seg_off.ensure(m * 8);
+                h->p_seg_list.ensure(m * 4);
+                h->p_seg_count.ensure(m * 4);
+                for (size_t i = 0; i < m; i++) {
+                    h->p_seg_off.as<uint64_t>()[i] = (uint64_t)i * nlist;
+                    h->p_seg_list.as<int32_t>()[i] = 0;
+                    h->p_seg_count.as<uint32_t>()[i] = 1;
+                }
+                HIP_CHECK(hipMemcpyAsync(h->c_seg_off.p, h->p_seg_off.p, m * 8, hipMemcpyHostToDevice, s));
+                HIP_CHECK(hipMemcpyAsync(h->c_seg_list.p, h->p_seg_list.p, m * 4, hipMemcpyHostToDevice, s));
+                HIP_CHECK(hipMemcpyAsync(h->c_seg_count.p, h->p_seg_count.p, m * 4, hipMemcpyHostToDevice, s));
             }
-            HIP_CHECK(hipMemcpyAsync(h->c_seg_off.p, h->p_seg_off.p, m * 8, hipMemcpyHostToDevice, s));
-            HIP_CHECK(hipMemcpyAsync(h->c_seg_list.p, h->p_seg_list.p, m * 4, hipMemcpyHostToDevice, s));
-            HIP_CHECK(hipMemcpyAsync(h->c_seg_count.p, h->p_seg_count.p, m * 4, hipMemcpyHostToDevice, s));
             launch_fill_f32(h->c_heap_val.as<float>(), m * k, h->metric == METRIC_L2 ? FLT_MAX : -FLT_MAX, s);
             launch_fill_i64(h->c_heap_ref.as<int64_t>(), m * k, -1, s);
             HIP_CHECK(hipMemsetAsync(h->c_stage.p, 0, m * 4, s));
@@ -1864,9 +1875,9 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
         h->timer.end(t, s);
         // (the staging buffers of this chunk are rewritten by the next chunk / call unless the work list is the cached one; the
         // heap form also stages per call)
-        if (!cached || use_heap || c0 + m < n) {
+        if (!cached || c0 + m < n) {
             HIP_CHECK(stream_sync(s));
-            if (!use_heap && c0 == 0 && m == n) {
+            if (c0 == 0 && m == n) {
                 h->coarse_sig = csig;
                 h->coarse_sig_valid = true;
             }

@@ -1960,6 +1960,9 @@ struct CoarsePickArgs {
     int64_t* out_keys;
     uint32_t* nflag;          // += 1 per flagged query
     uint32_t* flagged;        // [n] their numbers
+    uint32_t pick_slack;      // the bisection stops at a threshold with nprobe .. nprobe + pick_slack approximate distances under it
+                              // (every candidate under the widened threshold costs a gathered row of d floats: cfg 5, d = 960,
+                              // nprobe 32 -- slack 48 / 16 / 8 / 2: 1.07 / 0.93 / 0.89 / 0.87 ms of coarse ranking)
     uint32_t* why;            // [5] (debugging, or null): flagged because of 0 the threshold / scale, 1 too many candidates, 2 too few,
                               // 3 a distance that is not finite, 4 equal distances among the first nprobe + 1
 };
@@ -1992,14 +1995,14 @@ __global__ __launch_bounds__(256) void coarse_pick_kernel(CoarsePickArgs a) {
         par ^= 1;
         return tot;
     };
-    // a threshold with nprobe .. 2 nprobe + 16 approximate distances at or below it (any such T is >= the nprobe-th smallest)
+    // a threshold with nprobe .. nprobe + pick_slack approximate distances at or below it (any such T is >= the nprobe-th smallest)
     uint32_t lo = 0, hi = 0xffffffffu;
     while (lo < hi) {
         const uint32_t mid = lo + (hi - lo) / 2;
         const uint32_t c = block_count(mid);
         if (c >= a.nprobe) {
             hi = mid;
-            if (c <= 2 * a.nprobe + 16) break;
+            if (c <= a.nprobe + a.pick_slack) break;
         } else {
             lo = mid + 1;
         }
@@ -2126,7 +2129,8 @@ void launch_coarse_pick(int metric, const float* approx, const float* x, const f
                         uint32_t nlist, uint32_t nprobe, int dpad, float* out_dis, int64_t* out_keys, uint32_t* nflag, uint32_t* flagged,
                         hipStream_t s, const FilterParams* params, uint32_t* why) {
     if (n == 0) return;
-    CoarsePickArgs a{approx, x, centroids, xn, cmax, (2.f * (float)dpad + 32.f) * 5.9604645e-8f, params, nlist, nprobe, dpad, out_dis, out_keys, nflag, flagged, why};
+    CoarsePickArgs a{approx, x, centroids, xn, cmax, (2.f * (float)dpad + 32.f) * 5.9604645e-8f, params, nlist, nprobe, dpad, out_dis, out_keys, nflag, flagged,
+                     getenv("AUNCEL_AMD_PICK_SLACK") ? (uint32_t)atoi(getenv("AUNCEL_AMD_PICK_SLACK")) : nprobe / 8u + 2u, why};
     if (metric == METRIC_L2) LAUNCH(coarse_pick_kernel<METRIC_L2>, dim3(n), dim3(256), 0, s, a);
     else LAUNCH(coarse_pick_kernel<METRIC_IP>, dim3(n), dim3(256), 0, s, a);
 }
