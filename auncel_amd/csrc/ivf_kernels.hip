@@ -356,11 +356,7 @@ __device__ __forceinline__ void scan_lanes_one(const ScanArgs& a, const ScanItem
             for (int r = 0; r < SCAN_RQ; r++) qc[r] = qn[r];
             if (s + 1 < nsteps) {
 #pragma unroll
-#ifdef AUNCEL_SCAN_QHACK  // (experiment: operands of steps 0..3 over and over -- wrong distances, the scalar cache always hits)
-                for (int r = 0; r < SCAN_RQ; r++) qn[r] = qload(qtile + (size_t)((s + 1) & 3) * SCAN_RQ + r);
-#else
                 for (int r = 0; r < SCAN_RQ; r++) qn[r] = qload(qtile + (size_t)(s + 1) * SCAN_RQ + r);
-#endif
             }
             const f2 ya[SCAN_RV] = {f2{ya4.x, ya4.y}, f2{yb4.x, yb4.y}};  // elements (0,1) of the step: sums 0,1
             const f2 yb[SCAN_RV] = {f2{ya4.z, ya4.w}, f2{yb4.z, yb4.w}};  // elements (2,3): sums 2,3
