@@ -282,6 +282,10 @@ __global__ __launch_bounds__(ScanShape<QG>::NT) void scan_tiles_kernel(ScanArgs 
 #define AUNCEL_SCAN_LANE_AHEAD 6
 #endif
 constexpr int SCAN_LANE_AHEAD = AUNCEL_SCAN_LANE_AHEAD;
+#ifndef AUNCEL_LANES_NT
+#define AUNCEL_LANES_NT 2   // streaming hint on the block loads -- 1: always; 2: only where one wave reads the block (QG 1: the other shapes'
+                            // waves find it in L2); 0: never.  Measured the same within a run's spread (scripts/r05_lanes_nt.sh)
+#endif
 
 template <int METRIC, int QG, int ARITH>
 __device__ __forceinline__ void scan_lanes_one(const ScanArgs& a, const ScanItem it) {
@@ -329,13 +333,15 @@ __device__ __forceinline__ void scan_lanes_one(const ScanArgs& a, const ScanItem
         }
     }
 
+    constexpr bool STREAM = AUNCEL_LANES_NT == 1 || (AUNCEL_LANES_NT == 2 && QG == 1);
+#define LANE_LOAD(p) (STREAM ? __builtin_nontemporal_load(p) : *(p))
     v4f ring[D][SCAN_RV];
 #pragma unroll
     for (int j = 0; j < D; j++) {
         ring[j][0] = ring[j][1] = v4f{0.f, 0.f, 0.f, 0.f};
         if (j < nsteps) {
-            ring[j][0] = __builtin_nontemporal_load(pa + (size_t)j * 64);
-            if (two) ring[j][1] = __builtin_nontemporal_load(pb + (size_t)j * 64);
+            ring[j][0] = LANE_LOAD(pa + (size_t)j * 64);
+            if (two) ring[j][1] = LANE_LOAD(pb + (size_t)j * 64);
         }
     }
     float4 qn[SCAN_RQ];
@@ -348,8 +354,8 @@ __device__ __forceinline__ void scan_lanes_one(const ScanArgs& a, const ScanItem
             if (s >= nsteps) break;  // (wave-uniform)
             const v4f ya4 = ring[j][0], yb4 = ring[j][1];
             if (s + D < nsteps) {
-                ring[j][0] = __builtin_nontemporal_load(pa + (size_t)(s + D) * 64);
-                if (two) ring[j][1] = __builtin_nontemporal_load(pb + (size_t)(s + D) * 64);
+                ring[j][0] = LANE_LOAD(pa + (size_t)(s + D) * 64);
+                if (two) ring[j][1] = LANE_LOAD(pb + (size_t)(s + D) * 64);
             }
             float4 qc[SCAN_RQ];
 #pragma unroll
@@ -385,6 +391,7 @@ __device__ __forceinline__ void scan_lanes_one(const ScanArgs& a, const ScanItem
             }
         }
     }
+#undef LANE_LOAD
     scan_tile_store<METRIC>(a, it, acc, true, qgi, vgi, lane, e_row, e_thr);
 }
 
