@@ -59,9 +59,26 @@ def _share_torch_hip_runtime():
         p = os.path.join(d, name)
         if os.path.exists(p):
             try:
-                C.CDLL(p, mode=C.RTLD_GLOBAL)
+                _SHARED[name] = C.CDLL(p, mode=C.RTLD_GLOBAL)
             except OSError:
                 return
+
+
+_SHARED = {}
+
+
+def hip_runtime():
+    """a ctypes handle on the HIP runtime this process uses (hipHostMalloc for page-locked result buffers, ...): torch's bundled
+    copy where torch is loaded or was pre-loaded by lib(), else ROCm's -- never a second runtime beside the first"""
+    import sys
+    lib()
+    if "libamdhip64.so" in _SHARED:
+        return _SHARED["libamdhip64.so"]
+    if "torch" in sys.modules:
+        p = os.path.join(os.path.dirname(sys.modules["torch"].__file__), "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            return C.CDLL(p)
+    return C.CDLL("libamdhip64.so")
 
 
 def lib():

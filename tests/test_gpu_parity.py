@@ -570,7 +570,7 @@ def test_results_written_straight_into_page_locked_buffers(capi, monkeypatch, na
     h.set_interdis(None)
     h.set_tuner(K, traces_from_gold(gold), gold["arcos_list"])
     h.set_queries(case["xq"])
-    hip = ctypes.CDLL("libamdhip64.so")
+    hip = capi.hip_runtime()  # (the runtime the library itself runs on: a second one in the process would find no device)
 
     def pinned(shape, dtype):
         nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
