@@ -355,7 +355,7 @@ struct amd_ivf {
     // AUNCEL_AMD_COARSE_TIES=redo: the rankings that may need the reference's heap order (first run of equal distances within
     // the window a query can read in its first two rounds) are set aside and re-ranked on a side stream WHILE the first pass
     // searches; the second pass takes its rankings from those slots instead of running the heap (2.75 ms at nlist 4096) itself
-    DevBuf w_spec_full, w_spec_dis, w_spec_keys, w_spec_count, w_spec_slot, w_spec_pick, w_redo_idx, w_spec_query, w_spec_scratch;
+    DevBuf w_spec_full, w_spec_dis, w_spec_keys, w_spec_count, w_spec_slot, w_spec_pick, w_redo_idx, w_spec_query, w_spec_scratch, w_split;
     bool spec_inline = false;       // the heap's order was applied to the first pass itself (launch_tie_patch): only what it could not fix is searched again
     uint32_t tie_patched_host = 0;  // rankings of the last first pass that the heap's order changed
     hipStream_t spec_stream = nullptr;  // (= bg_stream)
@@ -972,6 +972,15 @@ struct RoundSpec {
     // coarse distances (PlanArgs::run_dis).
     std::function<void()> before_first_select;
     bool run_ties = false;
+    // ... and, in the chained rounds, the first selection in two launches: the queries whose ranking does not wait for the heap are
+    // selected while it still runs (split_prepare: the two query lists + the boundary distances of everybody), then the hook above
+    // (split_between: wait, patch, the boundary distances of the patched rankings again), then the waiting ones.  The heap takes
+    // 1.6 ms a row beside a dense round of 0.5: a lone batch stood idle for 1.07 ms of its 3.5 (profiles/r05_timeline_exact_ties.txt).
+    std::function<void()> split_prepare, split_between;
+    const uint32_t* split_free = nullptr;   // query lists and their counts (device)
+    const uint32_t* split_wait = nullptr;
+    const uint32_t* split_counts = nullptr; // [0] free, [1] waiting
+    uint32_t split_wait_cap = 0;
 };
 
 static bool dbg_timing() {
@@ -2484,15 +2493,16 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
         return ta;
     };
     // ---- ordered selection of a scanned round.  nact: active queries (sync) or the bound n with the count on the device.
-    auto enqueue_replay = [&](bool thr_mode, uint32_t nact, bool on_device, size_t round) {
+    auto enqueue_replay = [&](bool thr_mode, uint32_t nact, bool on_device, size_t round, const uint32_t* only = nullptr,
+                              const uint32_t* only_count = nullptr) {
         ReplayArgs ra{};
         ra.metric = h->metric;
         ra.k = base.k;
         ra.nlist = (uint32_t)nlist;
         ra.nq = nact;
-        ra.nq_dev = on_device ? dcnt + CNT_ACTIVE : nullptr;
+        ra.nq_dev = only ? only_count : on_device ? dcnt + CNT_ACTIVE : nullptr;
         ra.nq_hint = on_device && round > 0 ? std::max<uint32_t>(1, nact / 3) : nact;
-        ra.qsel = h->w_qsel.as<uint32_t>();
+        ra.qsel = only ? only : h->w_qsel.as<uint32_t>();  // (only: a part of the round's queries -- RoundSpec::split_*)
         ra.total_nprobe = (uint32_t)total_nprobe;
         ra.round_probes = 0;
         ra.id_offset = base.id_offset;
@@ -2694,8 +2704,17 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
                 planned = false;
                 launch_due_fix();
                 enqueue_scan(thr_mode, nullptr, round);
-                if (round == 0 && base.before_first_select) base.before_first_select();
-                enqueue_replay(thr_mode, (uint32_t)n, true, round);
+                // (alone on the index only: 3.50 -> 3.36 ms a lone batch; among five other searches the two extra launches and the
+                // second pass over the boundary distances cost more than the wait they fill: 3.40 -> 3.30 M q/s)
+                if (round == 0 && base.split_prepare && !thr_mode && active.before == 0) {
+                    base.split_prepare();
+                    enqueue_replay(thr_mode, (uint32_t)n, true, round, base.split_free, base.split_counts);
+                    base.split_between();
+                    enqueue_replay(thr_mode, base.split_wait_cap, true, round, base.split_wait, base.split_counts + 1);
+                } else {
+                    if (round == 0 && base.before_first_select) base.before_first_select();
+                    enqueue_replay(thr_mode, (uint32_t)n, true, round);
+                }
                 round_len = next_round_len(round_len);
             }
             launch_due_fix();
@@ -3780,9 +3799,10 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
         ~FuseScope() { h->fuse.active = false; }
     } fuse_scope(L, fuse_small);
     init_state(L, n, K, true);
-    auto set_online = [L, nlist, n, np_row]() {
-        launch_set_online(L->metric, (uint32_t)nlist, (uint32_t)n, L->w_cdis.as<float>(), L->w_ckeys.as<int64_t>(), (uint32_t)np_row,
-                          ix(L)->d_interdis.as<float>(), ix(L)->d_arcos.as<float>(), L->w_dtb.as<float>(), L->w_error.as<uint32_t>(), L->stream);
+    auto set_online = [L, nlist, n, np_row](const uint32_t* only = nullptr, const uint32_t* only_count = nullptr, uint32_t cap = 0) {
+        launch_set_online(L->metric, (uint32_t)nlist, only ? cap : (uint32_t)n, L->w_cdis.as<float>(), L->w_ckeys.as<int64_t>(), (uint32_t)np_row,
+                          ix(L)->d_interdis.as<float>(), ix(L)->d_arcos.as<float>(), L->w_dtb.as<float>(), L->w_error.as<uint32_t>(), L->stream,
+                          only, only_count);
     };
     if (!fuse_small && !tie_inline) set_online();
     RoundSpec base;
@@ -3820,6 +3840,31 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
             launch_tie_patch(ta, L->stream);
             set_online();
         };
+        // the first selection in two launches (chained rounds; AUNCEL_AMD_NO_SPLIT_SELECT: in one, behind the heap)
+        static const bool no_split = getenv("AUNCEL_AMD_NO_SPLIT_SELECT") != nullptr;
+        if (!no_split && n >= 256) {
+            L->w_split.ensure((2 * n + 8) * 4);
+            uint32_t* counts = L->w_split.as<uint32_t>();
+            uint32_t* q_free = counts + 8;
+            uint32_t* q_wait = q_free + n;
+            const auto patch_hook = base.before_first_select;
+            const uint32_t wait_cap = (uint32_t)std::min<size_t>(n, 512);  // (tie_collect_kernel hands out at most 512 slots)
+            base.split_free = q_free;
+            base.split_wait = q_wait;
+            base.split_counts = counts;
+            base.split_wait_cap = wait_cap;
+            base.split_prepare = [L, n, counts, q_free, q_wait, set_online]() {
+                HIP_CHECK(hipMemsetAsync(counts, 0, 8, L->stream));
+                // (round 0 of an adaptive search: every query of the call is active, in order)
+                launch_partition_qsel(nullptr, nullptr, (uint32_t)n, L->w_spec_slot.as<int32_t>(), q_free, q_wait, counts, L->stream);
+                set_online();
+            };
+            base.split_between = [L, patch_hook, counts, q_wait, wait_cap, set_online]() {
+                (void)set_online;
+                patch_hook();  // (waits for the heap, patches, and derives the boundary distances again -- of every query: the patched
+                               // rankings are a tenth of them and the launch is 0.045 ms)
+            };
+        }
     }
     base.fused = ix(L)->allow_fused && ix(L)->db_range.fusable_with(qr, L->metric);
     base.bytes = byte_queries(L, ix(L), d_x, n, qr);

@@ -421,7 +421,10 @@ void launch_range_fill(const RangeArgs& a, hipStream_t s);
 
 // error_pro::set_online for nq queries: dtb[q][nlist/8+20] from the full coarse ranking (before round 0)
 void launch_set_online(int metric, uint32_t nlist, uint32_t nq, const float* coarse_dis, const int64_t* coarse_keys,
-                       uint32_t coarse_stride, const float* interdis, const float* arcos, float* dtb, uint32_t* error, hipStream_t s);
+                       uint32_t coarse_stride, const float* interdis, const float* arcos, float* dtb, uint32_t* error, hipStream_t s,
+                       const uint32_t* qsel = nullptr, const uint32_t* nq_dev = nullptr);  // (optional: a subset of the queries, count on the device)
+void launch_partition_qsel(const uint32_t* qsel, const uint32_t* nq_dev, uint32_t nq, const int32_t* slot_of, uint32_t* q_free, uint32_t* q_wait,
+                           uint32_t* counts, hipStream_t s);
 
 // ---------------------------------------------------------------------------- device-side round planning
 struct PlanArgs {

@@ -255,13 +255,15 @@ __device__ inline void set_online_dev(int metric, uint32_t nlist, const float* c
 // one wave per query: disToBoundary rows for a batch of queries (run once, before the first round)
 __global__ __launch_bounds__(256) void set_online_kernel(int metric, uint32_t nlist, uint32_t nq, const float* coarse_dis,
                                                          const int64_t* coarse_keys, uint32_t coarse_stride, const float* interdis,
-                                                         const float* arcos, float* dtb, uint32_t* error) {
+                                                         const float* arcos, float* dtb, uint32_t* error, const uint32_t* qsel,
+                                                         const uint32_t* nq_dev) {
     __shared__ float lut[500];
     for (int i = threadIdx.x; i < 500; i += 256) lut[i] = arcos[i];
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const uint32_t qi = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (qi >= nq) return;
+    const uint32_t li = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (li >= (nq_dev ? *nq_dev : nq)) return;
+    const uint32_t qi = qsel ? qsel[li] : li;  // (a subset of the call's queries: the rankings the tie patch rewrote)
     uint32_t err = 0;
     set_online_dev(metric, nlist, coarse_dis + (size_t)qi * coarse_stride, coarse_keys + (size_t)qi * coarse_stride, interdis, lut,
                    dtb + (size_t)qi * (nlist / 8 + 20), lane, &err);
@@ -270,9 +272,42 @@ __global__ __launch_bounds__(256) void set_online_kernel(int metric, uint32_t nl
 }
 
 void launch_set_online(int metric, uint32_t nlist, uint32_t nq, const float* coarse_dis, const int64_t* coarse_keys,
-                       uint32_t coarse_stride, const float* interdis, const float* arcos, float* dtb, uint32_t* error, hipStream_t s) {
+                       uint32_t coarse_stride, const float* interdis, const float* arcos, float* dtb, uint32_t* error, hipStream_t s,
+                       const uint32_t* qsel, const uint32_t* nq_dev) {
     if (nq) LAUNCH(set_online_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, metric, nlist, nq, coarse_dis, coarse_keys,
-                               coarse_stride, interdis, arcos, dtb, error);
+                               coarse_stride, interdis, arcos, dtb, error, qsel, nq_dev);
+}
+
+// The active queries of a round in two lists: those whose coarse ranking waits for the reference's heap order (slot_of >= 0) and the
+// others, which need not wait (run_rounds_device: the first selection in two launches).  counts[0 / 1]: others / waiting (zeroed by
+// the caller's memset on the same stream).
+__global__ __launch_bounds__(256) void partition_qsel_kernel(const uint32_t* qsel, const uint32_t* nq_dev, uint32_t nq, const int32_t* slot_of,
+                                                             uint32_t* q_free, uint32_t* q_wait, uint32_t* counts) {
+    const uint32_t n = nq_dev ? *nq_dev : nq;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t i0 = (blockIdx.x * 256 + threadIdx.x) & ~63u; i0 < n; i0 += gridDim.x * 256) {
+        const uint32_t i = i0 + lane;
+        const bool in = i < n;
+        const uint32_t q = in ? (qsel ? qsel[i] : i) : 0u;
+        const bool wait = in && slot_of[q] >= 0;
+        const unsigned long long mw = __ballot(wait), mf = __ballot(in && !wait);
+        uint32_t bw = 0, bf = 0;
+        if (lane == 0) {
+            if (mw) bw = atomicAdd(&counts[1], (uint32_t)__builtin_popcountll(mw));
+            if (mf) bf = atomicAdd(&counts[0], (uint32_t)__builtin_popcountll(mf));
+        }
+        bw = (uint32_t)__builtin_amdgcn_readfirstlane((int)bw);
+        bf = (uint32_t)__builtin_amdgcn_readfirstlane((int)bf);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (wait) q_wait[bw + __builtin_popcountll(mw & below)] = q;
+        else if (in) q_free[bf + __builtin_popcountll(mf & below)] = q;
+    }
+}
+void launch_partition_qsel(const uint32_t* qsel, const uint32_t* nq_dev, uint32_t nq, const int32_t* slot_of, uint32_t* q_free, uint32_t* q_wait,
+                           uint32_t* counts, hipStream_t s) {
+    if (!nq) return;
+    const unsigned grid = std::min<unsigned>((nq + 255) / 256, 1024u);
+    LAUNCH(partition_qsel_kernel, dim3(grid), dim3(256), 0, s, qsel, nq_dev, nq, slot_of, q_free, q_wait, counts);
 }
 
 // init_state_kernel + set_online_kernel + first_tie_kernel + sbytes_from_f32_kernel for at most four queries (SmallStateArgs)
