@@ -19,7 +19,8 @@ _LIB = None
 SYMBOLS = [
     "amd_ivf_last_error", "amd_ivf_device_count", "amd_ivf_create", "amd_ivf_clone", "amd_ivf_destroy", "amd_ivf_set_centroids",
     "amd_ivf_set_lists", "amd_ivf_add", "amd_ivf_ntotal", "amd_ivf_list_size", "amd_ivf_get_list", "amd_ivf_coarse",
-    "amd_ivf_search_preassigned", "amd_ivf_search", "amd_ivf_scan_codes", "amd_ivf_distance_to_code", "amd_ivf_stats",
+    "amd_ivf_search_preassigned", "amd_ivf_search", "amd_ivf_scan_codes", "amd_ivf_scan_codes_at", "amd_ivf_scan_codes_range",
+    "amd_ivf_scan_codes_range_results", "amd_ivf_distance_to_code", "amd_ivf_stats",
     "amd_ivf_set_queries", "amd_ivf_search_resident", "amd_ivf_search_resident_preassigned", "amd_ivf_coarse_resident", "amd_ivf_set_interdis", "amd_ivf_get_interdis",
     "amd_ivf_set_tuner", "amd_ivf_search_adaptive", "amd_ivf_search_adaptive_x", "amd_ivf_search_adaptive_pre", "amd_ivf_search_timed", "amd_ivf_search_timed_x",
     "amd_ivf_train_samples",
@@ -341,6 +342,26 @@ class Handle:
         _chk(lib().amd_ivf_scan_codes(self._h, _f(query), C.c_size_t(list_no), int(store_pairs), C.c_size_t(simi.shape[0]),
                                       _f(simi), _i(idxi), C.byref(nup)))
         return nup.value
+
+    def scan_codes_at(self, query, list_no, offset, n, simi, idxi, store_pairs=False):
+        """InvertedListScanner::scan_codes over vectors [offset, offset + n) of the list"""
+        query = f32(query)
+        nup = C.c_size_t(0)
+        _chk(lib().amd_ivf_scan_codes_at(self._h, _f(query), C.c_size_t(list_no), C.c_size_t(offset), C.c_size_t(n), int(store_pairs),
+                                         C.c_size_t(simi.shape[0]), _f(simi), _i(idxi), C.byref(nup)))
+        return nup.value
+
+    def scan_codes_range(self, query, list_no, offset, n, radius):
+        """InvertedListScanner::scan_codes_range over the same kind of run: (positions counted from offset, distances), in order"""
+        query = f32(query)
+        cnt = C.c_size_t(0)
+        _chk(lib().amd_ivf_scan_codes_range(self._h, _f(query), C.c_size_t(list_no), C.c_size_t(offset), C.c_size_t(n), C.c_float(radius),
+                                            C.byref(cnt)))
+        pos = np.empty(cnt.value, np.uint32)
+        dis = np.empty(cnt.value, np.float32)
+        if cnt.value:
+            _chk(lib().amd_ivf_scan_codes_range_results(self._h, pos.ctypes.data_as(C.POINTER(C.c_uint32)), _f(dis)))
+        return pos, dis
 
     def distance_to_code(self, query, list_no, offset):
         query = f32(query)

@@ -74,6 +74,17 @@ template <bool S> inline size_t heap_reorder_t(size_t k, float* v, long* id) {
     return n;
 }
 
+/// n candidates against the heap, each admitted on strict improvement over the top (Heap.h:246-264); null labels: the position
+template <bool S> inline void heap_addn_t(size_t k, float* v, long* id, const float* x, const long* labels, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        if (!HeapOrder<S>::cmp(v[0], x[i])) continue;
+        heap_pop_t<S>(k, v, id);
+        heap_push_t<S>(k, v, id, x[i], labels ? labels[i] : (long)i);
+    }
+}
+inline void maxheap_addn(size_t k, float* v, long* id, const float* x, const long* labels, size_t n) { heap_addn_t<true>(k, v, id, x, labels, n); }
+inline void minheap_addn(size_t k, float* v, long* id, const float* x, const long* labels, size_t n) { heap_addn_t<false>(k, v, id, x, labels, n); }
+
 inline void maxheap_heapify(size_t k, float* v, long* id) { heap_heapify_t<true>(k, v, id); }
 inline void minheap_heapify(size_t k, float* v, long* id) { heap_heapify_t<false>(k, v, id); }
 inline size_t maxheap_reorder(size_t k, float* v, long* id) { return heap_reorder_t<true>(k, v, id); }

@@ -34,6 +34,7 @@ struct IVFSearchParameters {
 };
 
 struct InvertedListScanner;
+struct RangeQueryResult;
 
 struct IndexIVF : Index, Level1Quantizer {
     InvertedLists* invlists;
@@ -127,8 +128,12 @@ struct InvertedListScanner {
     virtual void set_query(const float* query_vector) = 0;
     virtual void set_list(idx_t list_no, float coarse_dis) = 0;
     virtual float distance_to_code(const uint8_t* code) const = 0;
+    /// `codes` may point at any code of the current list, `n` codes are scanned from there (IndexIVFFlat.cpp:117-137)
     virtual size_t scan_codes(size_t n, const uint8_t* codes, const idx_t* ids, float* distances, idx_t* labels,
                               size_t k) const = 0;
+    /// results within `radius`, reported to `result` in the order of the codes (IndexIVF.h:349-354; the default fails, as the
+    /// reference's: IndexIVF.cpp:949-955)
+    virtual void scan_codes_range(size_t n, const uint8_t* codes, const idx_t* ids, float radius, RangeQueryResult& result) const;
     virtual ~InvertedListScanner() {}
 };
 

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <fstream>
 #include <iostream>
 #include <random>
@@ -725,7 +726,14 @@ RangeSearchResult::RangeSearchResult(idx_t nq, bool alloc_lims) : nq((size_t)nq)
     }
 }
 void RangeSearchResult::do_allocation() {
-    const size_t ofs = lims[nq];
+    // lims holds one COUNT per query on entry and the offsets on return (AuxIndexStructures.cpp:40-50)
+    size_t ofs = 0;
+    for (size_t i = 0; i < nq; i++) {
+        const size_t c = lims[i];
+        lims[i] = ofs;
+        ofs += c;
+    }
+    lims[nq] = ofs;
     labels = new idx_t[ofs];
     distances = new float[ofs];
 }
@@ -743,6 +751,7 @@ void IndexIVF::range_search_preassigned(idx_t nx, const float* x, float radius, 
                                         RangeSearchResult* result) const {
     sync_engine(false);
     AMD(amd_ivf_range_search_preassigned(gpu_, (size_t)nx, x, radius, nprobe, i64(keys), result->lims));
+    for (idx_t i = 0; i < nx; i++) result->lims[i] = result->lims[i + 1] - result->lims[i];  // (the engine's offsets -> counts)
     result->do_allocation();
     AMD(amd_ivf_range_results(gpu_, i64(result->labels), result->distances));
     fold_stats();
@@ -751,37 +760,171 @@ void IndexIVF::range_search_preassigned(idx_t nx, const float* x, float radius, 
 void IndexIVF::range_search(idx_t nx, const float* x, float radius, RangeSearchResult* result) const {
     sync_engine(false);
     AMD(amd_ivf_range_search(gpu_, (size_t)nx, x, radius, nprobe, coarse_mode, result->lims));
+    for (idx_t i = 0; i < nx; i++) result->lims[i] = result->lims[i + 1] - result->lims[i];
     result->do_allocation();
     AMD(amd_ivf_range_results(gpu_, i64(result->labels), result->distances));
     fold_stats();
 }
 
+// ---- the scanners' range results (Auncel/AuxIndexStructures.cpp:65-215): host-side bookkeeping, blocks that never move
+BufferList::BufferList(size_t buffer_size) : buffer_size(buffer_size), wp(buffer_size) {}
+BufferList::~BufferList() {
+    for (Buffer& b : buffers) {
+        delete[] b.ids;
+        delete[] b.dis;
+    }
+}
+void BufferList::append_buffer() {
+    buffers.push_back(Buffer{new idx_t[buffer_size], new float[buffer_size]});
+    wp = 0;
+}
+void BufferList::add(idx_t id, float dis) {
+    if (wp == buffer_size) append_buffer();
+    buffers.back().ids[wp] = id;
+    buffers.back().dis[wp] = dis;
+    wp++;
+}
+void BufferList::copy_range(size_t ofs, size_t n, idx_t* dest_ids, float* dest_dis) {
+    for (size_t b = ofs / buffer_size, at = ofs % buffer_size; n > 0; b++, at = 0) {
+        const size_t take = std::min(n, buffer_size - at);
+        memcpy(dest_ids, buffers[b].ids + at, take * sizeof(idx_t));
+        memcpy(dest_dis, buffers[b].dis + at, take * sizeof(float));
+        dest_ids += take;
+        dest_dis += take;
+        n -= take;
+    }
+}
+void RangeQueryResult::add(float dis, idx_t id) {
+    nres++;
+    pres->add(id, dis);
+}
+RangeSearchPartialResult::RangeSearchPartialResult(RangeSearchResult* res_in) : BufferList(res_in->buffer_size), res(res_in) {}
+RangeQueryResult& RangeSearchPartialResult::new_result(idx_t qno) {
+    queries.push_back(RangeQueryResult{qno, 0, this});
+    return queries.back();
+}
+void RangeSearchPartialResult::set_lims() {
+    for (const RangeQueryResult& q : queries) res->lims[q.qno] = q.nres;
+}
+void RangeSearchPartialResult::copy_result(bool incremental) {
+    size_t ofs = 0;
+    for (const RangeQueryResult& q : queries) {
+        copy_range(ofs, q.nres, res->labels + res->lims[q.qno], res->distances + res->lims[q.qno]);
+        if (incremental) res->lims[q.qno] += q.nres;
+        ofs += q.nres;
+    }
+}
+void RangeSearchPartialResult::finalize() {
+    // (the reference runs this inside an OpenMP team, with barriers around the one allocation: AuxIndexStructures.cpp:145-155)
+    set_lims();
+    res->do_allocation();
+    copy_result();
+}
+void RangeSearchPartialResult::merge(std::vector<RangeSearchPartialResult*>& partial_results, bool do_delete) {
+    if (partial_results.empty()) return;
+    RangeSearchResult* result = partial_results[0]->res;
+    const size_t nx = result->nq;
+    for (const RangeSearchPartialResult* p : partial_results)
+        if (p)
+            for (const RangeQueryResult& q : p->queries) result->lims[q.qno] += q.nres;
+    // (AuxIndexStructures.cpp:194-215: counts -> offsets by do_allocation, entries copied with incremental = true -- which leaves
+    // every offset one query ahead -- and the table shifted back)
+    result->do_allocation();
+    for (RangeSearchPartialResult*& p : partial_results) {
+        if (!p) continue;
+        p->copy_result(true);
+        if (do_delete) {
+            delete p;
+            p = nullptr;
+        }
+    }
+    for (size_t i = nx; i > 0; i--) result->lims[i] = result->lims[i - 1];
+    result->lims[0] = 0;
+}
+
+void InvertedListScanner::scan_codes_range(size_t, const uint8_t*, const idx_t*, float, RangeQueryResult&) const {
+    FAISS_THROW_MSG("scan_codes_range not implemented");
+}
+
+/// The scanner of IndexIVFFlat over the engine (IVFFlatScanner, Auncel/IndexIVFFlat.cpp:95-158).  The codes it is handed live in HBM
+/// already, so a `codes` pointer only NAMES a run of the current list -- [offset, offset + n), anywhere inside it.  Every scanner
+/// searches on a context of its own (amd_ivf_clone), so scanners of one index may run in different threads, as the reference's
+/// do ("distance_to_code and scan_codes can be called in multiple threads", IndexIVF.h:312-315; tests/test_lowlevel_ivf.cpp:426-564).
 struct EngineScanner : InvertedListScanner {
     const IndexIVF* ix;
     bool store_pairs;
     std::vector<float> q;
     idx_t list_no = -1;
+    mutable amd_ivf* ctx = nullptr;
+    mutable size_t ctx_version = (size_t)-1;
     EngineScanner(const IndexIVF* ix, bool sp) : ix(ix), store_pairs(sp) {}
+    ~EngineScanner() override {
+        if (ctx) amd_ivf_destroy(ctx);
+    }
     void set_query(const float* query) override { q.assign(query, query + ix->d); }
     void set_list(idx_t l, float) override { list_no = l; }
-    float distance_to_code(const uint8_t* code) const override {
+    /// this scanner's search context over the index as it is now
+    amd_ivf* context() const {
+        static std::mutex mu;  // (the index's own handle is brought up to date by one scanner at a time)
+        std::lock_guard<std::mutex> lock(mu);
+        ix->sync_engine(false);
+        if (ctx && ctx_version != ix->invlists->version) {
+            amd_ivf_destroy(ctx);
+            ctx = nullptr;
+        }
+        if (!ctx) {
+            AMD(amd_ivf_clone(ix->gpu_, &ctx));
+            ctx_version = ix->invlists->version;
+        }
+        return ctx;
+    }
+    /// where in the current list the n codes at `codes` are
+    size_t offset_of(size_t n, const uint8_t* codes) const {
         FAISS_THROW_IF_NOT_MSG(list_no >= 0, "set_list first");
         const uint8_t* base = ix->invlists->get_codes(list_no);
-        const size_t n = ix->invlists->list_size(list_no);
-        FAISS_THROW_IF_NOT_MSG(code >= base && code < base + n * ix->code_size, "code must point into the current list");
+        const size_t sz = ix->invlists->list_size(list_no);
+        FAISS_THROW_IF_NOT_MSG(n == 0 || (codes >= base && codes < base + sz * ix->code_size && (size_t)(codes - base) % ix->code_size == 0),
+                               "codes must point at a code of the current list (the lists live in HBM)");
+        const size_t offset = n ? (size_t)(codes - base) / ix->code_size : 0;
+        FAISS_THROW_IF_NOT_MSG(offset + n <= sz, "codes run past the end of the current list");
+        return offset;
+    }
+    float distance_to_code(const uint8_t* code) const override {
+        const size_t offset = offset_of(1, code);
         float dis = 0;
-        ix->sync_engine(false);
-        AMD(amd_ivf_distance_to_code(ix->gpu_, q.data(), (size_t)list_no, (size_t)(code - base) / ix->code_size, &dis));
+        AMD(amd_ivf_distance_to_code(context(), q.data(), (size_t)list_no, offset, &dis));
         return dis;
     }
-    size_t scan_codes(size_t n, const uint8_t* codes, const idx_t*, float* simi, idx_t* idxi, size_t k) const override {
-        FAISS_THROW_IF_NOT_MSG(list_no >= 0, "set_list first");
-        FAISS_THROW_IF_NOT_MSG(codes == ix->invlists->get_codes(list_no) && n == ix->invlists->list_size(list_no),
-                               "scan_codes scans the list named by set_list (its codes live in HBM)");
+    size_t scan_codes(size_t n, const uint8_t* codes, const idx_t* ids, float* simi, idx_t* idxi, size_t k) const override {
+        const size_t offset = offset_of(n, codes);
+        if (n == 0) return 0;
         size_t nup = 0;
-        ix->sync_engine(false);
-        AMD(amd_ivf_scan_codes(ix->gpu_, q.data(), (size_t)list_no, store_pairs ? 1 : 0, k, simi, i64(idxi), &nup));
+        const idx_t* own = ix->invlists->get_ids(list_no);
+        if (store_pairs || ids == own + offset) {
+            // labels straight from the engine: list_no << 32 | j (j from `codes`), or the ids stored with those vectors
+            AMD(amd_ivf_scan_codes_at(context(), q.data(), (size_t)list_no, offset, n, store_pairs ? 1 : 0, k, simi, i64(idxi), &nup));
+            return nup;
+        }
+        // the caller's own id array (the reference reads ids[j], whatever it is handed): the entries already in the heap travel as
+        // tags, the admitted ones come back as positions
+        std::vector<idx_t> lab(k);
+        for (size_t i = 0; i < k; i++) lab[i] = -(idx_t)i - 2;
+        AMD(amd_ivf_scan_codes_at(context(), q.data(), (size_t)list_no, offset, n, 1, k, simi, i64(lab.data()), &nup));
+        std::vector<idx_t> old(idxi, idxi + k);
+        for (size_t i = 0; i < k; i++) idxi[i] = lab[i] < 0 ? old[(size_t)(-lab[i] - 2)] : ids[lab[i] & 0xffffffffll];
         return nup;
+    }
+    void scan_codes_range(size_t n, const uint8_t* codes, const idx_t* ids, float radius, RangeQueryResult& res) const override {
+        const size_t offset = offset_of(n, codes);
+        if (n == 0) return;
+        size_t count = 0;
+        amd_ivf* c = context();
+        AMD(amd_ivf_scan_codes_range(c, q.data(), (size_t)list_no, offset, n, radius, &count));
+        if (!count) return;
+        std::vector<uint32_t> pos(count);
+        std::vector<float> dis(count);
+        AMD(amd_ivf_scan_codes_range_results(c, pos.data(), dis.data()));
+        for (size_t i = 0; i < count; i++) res.add(dis[i], store_pairs ? (idx_t)((idx_t)list_no << 32 | (idx_t)pos[i]) : ids[pos[i]]);
     }
 };
 

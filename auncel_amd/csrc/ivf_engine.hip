@@ -419,11 +419,13 @@ struct amd_ivf {
     DevBuf w_rcount, w_roff, w_rlab, w_rdis;  // range search: per-query counts / output offsets / results of a round
     std::vector<size_t> r_lims;              // results of the last range search (amd_ivf_range_results)
     std::vector<int64_t> r_labels;
+    std::vector<uint32_t> r_part_pos;  // amd_ivf_scan_codes_range: positions / distances of the last call
+    std::vector<float> r_part_dis;
     std::vector<float> r_dist;
     DevBuf w_thr, w_mask, w_pl_pad, w_cl_cnt, w_cl_ent, w_cl_arena, w_cl_cursor;  // threshold mode of the device-planned rounds: heap tops, candidate bit masks
     DevBuf w_x, w_dist, w_items, w_pair_query, w_pair_out, w_seg_off, w_seg_list, w_seg_count, w_qsel;
     DevBuf w_heap_val, w_heap_ref, w_stage, w_nscan, w_done, w_pre_val, w_stoped, w_dtb, w_D, w_I;
-    DevBuf w_cdis, w_ckeys, w_stats, w_error, w_misc, w_misc2, w_misc3, w_rawptrs;
+    DevBuf w_cdis, w_ckeys, w_stats, w_error, w_misc, w_misc2, w_misc3, w_rawptrs, w_sub_off;
     DevBuf c_heap_val, c_heap_ref, c_stage, c_nscan, c_done, c_seg_off, c_seg_list, c_seg_count;
     float centroid_norm_max = 0.f;  // max |c|^2 over the centroids, rounded up
     DevBuf d_cinfo;                 // range of the centroid table (launch_amax): the fp16 form of the approximate coarse ranking
@@ -791,12 +793,33 @@ const float* ensure_lanes(amd_ivf* index) {
             if (nblk64 == 0 || nblk64 >= (1ull << (64 - SCAN_VB_BITS)) || nt >= (1ull << SCAN_VB_BITS)) {
                 st = -1;
             } else {
+                // The copy is the fp32 lists once more.  An index that fits without it must keep searching (scan_tiles_kernel reads
+                // the rows): the copy is made only where it leaves a quarter of itself + 1 GiB free for the searches' workspaces,
+                // and a failed allocation means "no copy" for good (lanes_state -1), not a search that throws every time.
                 use_device(index);
-                index->d_lanes.ensure(nblk64 * (uint64_t)index->dpad * 64 * sizeof(float));
-                launch_lanes_from_f32(index->d_codes.as<float>(), index->d_list_off.as<uint64_t>(), index->d_block_off.as<uint64_t>(), (uint32_t)index->nlist,
-                                      nblk64, index->dpad, index->d_lanes.as<float>(), index->stream);
-                HIP_CHECK(stream_sync(index->stream));
-                st = 1;
+                const uint64_t bytes = nblk64 * (uint64_t)index->dpad * 64 * sizeof(float);
+                const uint64_t want = bytes + bytes / 8 + 256;  // (DevBuf's slack)
+                size_t free_b = 0, total_b = 0;
+                const bool fits = hipMemGetInfo(&free_b, &total_b) == hipSuccess && (uint64_t)free_b >= want + want / 4 + (1ull << 30) &&
+                                  !getenv("AUNCEL_AMD_LANES_NOFIT");  // (tests: the search of an index whose copy does not fit)
+                st = -1;
+                if (fits) {
+                    try {
+                        index->d_lanes.ensure(bytes);
+                        launch_lanes_from_f32(index->d_codes.as<float>(), index->d_list_off.as<uint64_t>(), index->d_block_off.as<uint64_t>(),
+                                              (uint32_t)index->nlist, nblk64, index->dpad, index->d_lanes.as<float>(), index->stream);
+                        HIP_CHECK(stream_sync(index->stream));
+                        st = 1;
+                    } catch (const std::exception&) {
+                        index->d_lanes.release();
+                        (void)hipGetLastError();  // (the sticky error of the failed allocation)
+                    }
+                } else {
+                    (void)hipGetLastError();
+                }
+                if (st < 0 && getenv("AUNCEL_AMD_VERBOSE"))
+                    fprintf(stderr, "[auncel_amd] no lane-ordered copy of the lists (%.1f GiB wanted, %.1f GiB free): dense fp32 rounds read the rows\n",
+                            want / 1073741824.0, free_b / 1073741824.0);
             }
             index->lanes_state.store(st, std::memory_order_release);
         }
@@ -959,6 +982,15 @@ struct RoundSpec {
     uint32_t coarse_stride = 0;
     int raw_heap_out = 0;
     int fused = 0;
+    // scanner API over a part of a list (amd_ivf_scan_codes_at / _range; exec_round only, one query, one probe, key 0): the round sees
+    // an index of ONE list whose vectors are [sub_base, sub_base + sub_n) of the packed matrix -- positions count from sub_base, as
+    // the reference's scanner counts from the pointer it is handed (IndexIVFFlat.cpp:117-137)
+    uint64_t sub_base = 0;
+    size_t sub_n = (size_t)-1;
+    long long pair_list = -1;  // store_pairs labels of a list part carry this list number
+    // ... and, instead of the heap replay, the row's entries inside `collect_radius` in position order (scan_codes_range)
+    bool collect = false;
+    float collect_radius = 0.f;
     // time-bounded search: budgets in ms (device, by absolute id) and the host clock (us) the budgets count from
     const float* d_budget_ms = nullptr;
     double t_start_us = 0;
@@ -1029,8 +1061,15 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
     if (m == 0) return;
     const uint32_t qblock = scan_qblock(r.bytes);
     const double t_enter = now_us();
-    const size_t nlist = h->nlist;
-    const std::vector<uint64_t>& off = ix(h)->h_list_off;
+    const bool sub = r.sub_n != (size_t)-1;
+    const std::vector<uint64_t> sub_off{r.sub_base, r.sub_base + (sub ? r.sub_n : 0)};
+    const size_t nlist = sub ? 1 : h->nlist;
+    const std::vector<uint64_t>& off = sub ? sub_off : ix(h)->h_list_off;
+    if (sub) {
+        if (m != 1 || r.cnt[0] != 1 || r.bytes) throw EngineError("a list part is scanned for one query, in fp32");
+        h->w_sub_off.ensure(32);  // (two offsets; the third word: scan_codes_range's count)
+        HIP_CHECK(hipMemcpyAsync(h->w_sub_off.p, sub_off.data(), 16, hipMemcpyHostToDevice, h->stream));
+    }
     size_t q0 = 0;
     std::vector<uint32_t> lcount(nlist + 1);
     while (q0 < m) {
@@ -1181,7 +1220,8 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
                 size_t& ni = cur[scan_qg_class(qg)];
                 for (uint32_t vb = 0; vb < sz; vb += tv) {
                     ScanItem& it = items[ni++];
-                    it.vec_base = scan_vec_base(off[l] + vb, ix(h)->h_block_off.empty() ? 0ull : ix(h)->h_block_off[l], vb);
+                    // (a list part starts anywhere: no block of the lane-ordered copy belongs to it, the tiles read the rows)
+                    it.vec_base = sub ? off[l] + vb : scan_vec_base(off[l] + vb, ix(h)->h_block_off.empty() ? 0ull : ix(h)->h_block_off[l], vb);
                     it.nvec = std::min(tv, sz - vb);
                     it.vec_off = vb;
                     it.pair_begin = lcount[l] + qb;
@@ -1222,7 +1262,7 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
         ScanArgs sa{};
         sa.qtile = h->w_qtile.as<float>();
         sa.codes = ix(h)->d_codes.as<float>();
-        sa.lanes = r.bytes ? nullptr : ensure_lanes(ix(h));
+        sa.lanes = r.bytes || sub ? nullptr : ensure_lanes(ix(h));
         sa.queries = r.d_x;
         sa.items = h->w_items.as<ScanItem>();
         sa.pair_query = h->w_pair_query.as<uint32_t>();
@@ -1262,6 +1302,17 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
             }
             h->timer.end(t, s);
         }
+        if (r.collect) {
+            // scan_codes_range: the row's entries inside the radius, in position order (count, positions, distances: w_D / w_I hold them)
+            h->w_D.ensure(std::max<uint64_t>(cursor, 1) * sizeof(float));
+            h->w_I.ensure(std::max<uint64_t>(cursor, 1) * sizeof(uint32_t));
+            if (!sub) throw EngineError("collect is the scanner API's (a list part)");
+            launch_range_collect(h->w_dist.as<float>(), (uint32_t)cursor, r.collect_radius, h->metric, h->w_sub_off.as<uint32_t>() + 4,
+                                 h->w_I.as<uint32_t>(), h->w_D.as<float>(), s);
+            HIP_CHECK(stream_sync(s));
+            q0 = q1;
+            continue;
+        }
         ReplayArgs ra{};
         ra.metric = h->metric;
         ra.k = r.k;
@@ -1276,7 +1327,7 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
         ra.seg_off = h->w_seg_off.as<uint64_t>();
         ra.seg_list = h->w_seg_list.as<int32_t>();
         ra.seg_count = h->w_seg_count.as<uint32_t>();
-        ra.list_off = ix(h)->d_list_off.as<uint64_t>();
+        ra.list_off = sub ? h->w_sub_off.as<uint64_t>() : ix(h)->d_list_off.as<uint64_t>();
         ra.ids = ix(h)->d_ids.as<int64_t>();
         ra.store_pairs = r.store_pairs;
         ra.identity_ids = 0;
@@ -1299,6 +1350,7 @@ void exec_round(amd_ivf* h, const RoundSpec& r) {
         ra.stats = h->w_stats.as<unsigned long long>();
         ra.error = h->w_error.as<uint32_t>();
         ra.raw_heap_out = r.raw_heap_out;
+        ra.pair_list = r.pair_list;
         ra.tuner = r.tuner;
         ra.train = r.train;
         static const bool dbg_replay = getenv("AUNCEL_AMD_DEBUG_REPLAY") != nullptr;
@@ -3546,30 +3598,122 @@ int amd_ivf_scan_codes(amd_ivf_t* h, const float* query, size_t list_no, int sto
 
 int amd_ivf_distance_to_code(amd_ivf_t* h, const float* query, size_t list_no, size_t offset, float* dis) {
     API_BEGIN
-    OWNER_ONLY(h);
     use_device(h);
     if (list_no >= h->nlist) throw EngineError("Invalid key");
     upload_lists(h);
-    if (offset >= h->h_list_off[list_no + 1] - h->h_list_off[list_no]) throw EngineError("offset beyond list size");
+    const std::vector<uint64_t>& loff = ix(h)->h_list_off;
+    if (offset >= loff[list_no + 1] - loff[list_no]) throw EngineError("offset beyond list size");
     h->w_x.ensure(h->dpad * sizeof(float));
     upload_rows(h, h->w_x.as<float>(), query, 1);
     h->w_dist.ensure(4);
     h->w_items.ensure(sizeof(ScanItem));
     h->w_pair_query.ensure(4);
     h->w_pair_out.ensure(8);
-    ScanItem it{h->h_list_off[list_no] + offset, 1, 0, 0, 1, 1, 0};  // qgroup 0
+    ScanItem it{loff[list_no] + offset, 1, 0, 0, 1, 1, 0};  // qgroup 0
     uint32_t pq = 0;
     uint64_t po = 0;
     HIP_CHECK(hipMemcpyAsync(h->w_items.p, &it, sizeof(it), hipMemcpyHostToDevice, h->stream));
     HIP_CHECK(hipMemcpyAsync(h->w_pair_query.p, &pq, 4, hipMemcpyHostToDevice, h->stream));
     HIP_CHECK(hipMemcpyAsync(h->w_pair_out.p, &po, 8, hipMemcpyHostToDevice, h->stream));
     pack_query_tiles(h, h->w_x.as<float>(), {{0u, 1u}});
-    ScanArgs sa{h->d_codes.as<float>(), h->w_x.as<float>(), h->w_items.as<ScanItem>(), h->w_pair_query.as<uint32_t>(),
+    ScanArgs sa{ix(h)->d_codes.as<float>(), h->w_x.as<float>(), h->w_items.as<ScanItem>(), h->w_pair_query.as<uint32_t>(),
                 h->w_pair_out.as<uint64_t>(), h->w_dist.as<float>(), h->w_qtile.as<float>(), h->dpad, h->metric, 0};
     const size_t one_qg1[4] = {1, 0, 0, 0};
     launch_scan(sa, one_qg1, h->stream);
     HIP_CHECK(hipMemcpyAsync(dis, h->w_dist.p, 4, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(stream_sync(h->stream));
+    API_END
+}
+
+// one query against vectors [offset, offset + n) of a list: the round of exec_round over that part
+static RoundSpec list_part_round(amd_ivf* h, const float* query, size_t list_no, size_t offset, size_t n, const int64_t* key0) {
+    if (list_no >= h->nlist) throw EngineError("Invalid key");
+    upload_lists(h);
+    const std::vector<uint64_t>& off = ix(h)->h_list_off;
+    if (offset + n > off[list_no + 1] - off[list_no]) throw EngineError("codes beyond the end of the list");
+    h->w_x.ensure(h->dpad * sizeof(float));
+    upload_rows(h, h->w_x.as<float>(), query, 1);
+    RoundSpec r;
+    r.slot = {0};
+    r.p0 = {0};
+    r.cnt = {1};
+    r.keys = key0;
+    r.key_stride = 1;
+    r.finalize_all = 1;
+    r.d_x = h->w_x.as<float>();
+    r.sub_base = off[list_no] + offset;
+    r.sub_n = n;
+    IntRange qr;
+    qr.add(query, (size_t)h->d);
+    r.fused = h->allow_fused && ix(h)->db_range.fusable_with(qr, h->metric);
+    return r;
+}
+
+int amd_ivf_scan_codes_at(amd_ivf_t* h, const float* query, size_t list_no, size_t offset, size_t n, int store_pairs, size_t k, float* simi,
+                          int64_t* idxi, size_t* nup) {
+    API_BEGIN
+    use_device(h);
+    if (nup) *nup = 0;
+    const int64_t key0 = 0;
+    RoundSpec r = list_part_round(h, query, list_no, offset, n, &key0);
+    if (n == 0 || k == 0) return 0;
+    init_state(h, 1, k, false);
+    HIP_CHECK(hipMemcpyAsync(h->w_heap_val.p, simi, k * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_CHECK(hipMemcpyAsync(h->w_heap_ref.p, idxi, k * 8, hipMemcpyHostToDevice, h->stream));
+    r.k = (int)k;
+    r.store_pairs = store_pairs;
+    r.pair_list = (long long)list_no;
+    r.raw_heap_out = 1;
+    exec_round(h, r);
+    check_device_error(h);
+    HIP_CHECK(hipMemcpyAsync(simi, h->w_D.p, k * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipMemcpyAsync(idxi, h->w_I.p, k * 8, hipMemcpyDeviceToHost, h->stream));
+    unsigned long long rows[4 * STATS_ROWS], st[4];
+    HIP_CHECK(hipMemcpyAsync(rows, h->w_stats.p, sizeof rows, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(stream_sync(h->stream));
+    sum_stat_rows(rows, st);
+    if (nup) *nup = st[2];
+    double ms[NCAT], ln[NCAT];
+    h->timer.collect(ms, NCAT, ln);
+    API_END
+}
+
+int amd_ivf_scan_codes_range(amd_ivf_t* h, const float* query, size_t list_no, size_t offset, size_t n, float radius, size_t* count) {
+    API_BEGIN
+    use_device(h);
+    *count = 0;
+    h->r_part_pos.clear();
+    h->r_part_dis.clear();
+    const int64_t key0 = 0;
+    RoundSpec r = list_part_round(h, query, list_no, offset, n, &key0);
+    if (n == 0) return 0;
+    init_state(h, 1, 1, false);
+    r.k = 1;
+    r.collect = true;
+    r.collect_radius = radius;
+    exec_round(h, r);
+    uint32_t cnt = 0;
+    HIP_CHECK(hipMemcpyAsync(&cnt, h->w_sub_off.as<uint32_t>() + 4, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(stream_sync(h->stream));
+    if (cnt) {
+        h->r_part_pos.resize(cnt);
+        h->r_part_dis.resize(cnt);
+        HIP_CHECK(hipMemcpyAsync(h->r_part_pos.data(), h->w_I.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(hipMemcpyAsync(h->r_part_dis.data(), h->w_D.p, (size_t)cnt * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_CHECK(stream_sync(h->stream));
+    }
+    *count = cnt;
+    double ms[NCAT], ln[NCAT];
+    h->timer.collect(ms, NCAT, ln);
+    API_END
+}
+
+int amd_ivf_scan_codes_range_results(amd_ivf_t* h, uint32_t* positions, float* distances) {
+    API_BEGIN
+    if (!h->r_part_pos.empty()) {
+        memcpy(positions, h->r_part_pos.data(), h->r_part_pos.size() * sizeof(uint32_t));
+        memcpy(distances, h->r_part_dis.data(), h->r_part_dis.size() * sizeof(float));
+    }
     API_END
 }
 
@@ -3782,7 +3926,9 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
             // takes whole runs into a round, so the scan does not depend on it).  With the level-parallel filling and the pipelined
             // heap sort (nlist a power of two) the heap takes ~1.5 ms a row, about what coarse ranking -> planning -> scan of
             // round 0 take among other searches; the literal heap (12 ms a row) stays under the pass and feeds a second one.
-            static const bool no_patch = getenv("AUNCEL_AMD_NO_TIE_PATCH") != nullptr;
+            // (only run_rounds_device calls RoundSpec::before_first_select: with the host-planned rounds of AUNCEL_AMD_HOST_PLAN the
+            // heap's order feeds the second pass instead, as for an nlist that is not a power of two)
+            static const bool no_patch = getenv("AUNCEL_AMD_NO_TIE_PATCH") != nullptr || getenv("AUNCEL_AMD_HOST_PLAN") != nullptr;
             L->spec_inline = !no_patch && (nlist & (nlist - 1)) == 0 && nlist >= 64;
         }
     }

@@ -311,6 +311,7 @@ struct ReplayArgs {
     unsigned long long* stats; // {nlist, ndis, nheap, ties} x 8: one row per XCD (added with L2-local atomics: STATS_ROWS below)
     uint32_t* error;           // != 0: the reference would have thrown (code)
     int raw_heap_out;          // scanner API: leave the heap un-reordered in D/I
+    long long pair_list = -1;  // scanner API over a list part (store_pairs): the list number new labels carry (< 0: the segment's own)
     unsigned long long* dbg;   // optional [nq][8]: wave cycles, heap updates, candidates, stages evaluated, cycles in the
                                // candidate stream, cycles in the stop rule, masked chunks fetched, probes consumed
     TunerDev tuner;
@@ -665,6 +666,7 @@ struct SmallStateArgs {
     int32_t* bcx;
 };
 void launch_small_state(const SmallStateArgs& a, hipStream_t s);
+void launch_range_collect(const float* dist, uint32_t n, float radius, int metric, uint32_t* count, uint32_t* out_pos, float* out_dis, hipStream_t s);
 void launch_fill_f32(float* p, size_t n, float v, hipStream_t s);
 void launch_fill_i64(int64_t* p, size_t n, int64_t v, hipStream_t s);
 

@@ -2718,6 +2718,43 @@ void launch_init_state(const InitStateArgs& a, hipStream_t s) {
     LAUNCH(init_state_kernel, dim3(grid), dim3(256), 0, s, a);
 }
 
+// InvertedListScanner::scan_codes_range (Auncel/IndexIVFFlat.cpp:139-155) over one row of n distances: the entries with
+// C::cmp(radius, dis) -- dis < radius for L2, dis > radius for inner product -- in position order, as RangeQueryResult::add receives
+// them.  One workgroup of 256 threads walks the row 256 candidates at a time; a chunk's survivors keep their order through the
+// waves' ballots (rank inside the wave) and the four waves' counts (LDS).  out_pos / out_dis hold `*count` entries afterwards.
+__global__ __launch_bounds__(256) void range_collect_kernel(const float* __restrict__ dist, uint32_t n, float radius, int metric, uint32_t* __restrict__ count,
+                                                            uint32_t* __restrict__ out_pos, float* __restrict__ out_dis) {
+    __shared__ uint32_t wave_cnt[4];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t base = 0;
+    for (uint32_t c0 = 0; c0 < n; c0 += 256) {
+        const uint32_t j = c0 + threadIdx.x;
+        const float v = j < n ? dist[j] : 0.f;
+        const bool keep = j < n && (metric == METRIC_L2 ? radius > v : radius < v);
+        const unsigned long long b = __ballot(keep);
+        if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(b);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (uint32_t w = 0; w < 4; w++) {
+            const uint32_t cw = wave_cnt[w];
+            before += w < wave ? cw : 0u;
+            total += cw;
+        }
+        if (keep) {
+            const uint32_t o = base + before + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+            out_pos[o] = j;
+            out_dis[o] = v;
+        }
+        base += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count = base;
+}
+
+void launch_range_collect(const float* dist, uint32_t n, float radius, int metric, uint32_t* count, uint32_t* out_pos, float* out_dis, hipStream_t s) {
+    LAUNCH(range_collect_kernel, dim3(1), dim3(256), 0, s, dist, n, radius, metric, count, out_pos, out_dis);
+}
+
 void launch_fill_f32(float* p, size_t n, float v, hipStream_t s) {
     if (n) LAUNCH(fill_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, v);
 }

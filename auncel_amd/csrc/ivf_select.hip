@@ -1095,6 +1095,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NLD == 16 ?
                 if (ref >= 0 && (ref & REF_TAG)) {
                     ref &= ~REF_TAG;
                     if (!a.store_pairs) ref = a.ids[a.list_off[ref >> 32] + (uint64_t)(ref & 0xffffffffll)];
+                    else if (a.pair_list >= 0) ref = ((int64_t)a.pair_list << 32) | (ref & 0xffffffffll);
                 }
                 a.D[(size_t)qi * k + i] = hval[i];
                 a.I[(size_t)qi * k + i] = ref;

@@ -168,6 +168,54 @@ def recall_dist(D, gtD, topk):
     return (D[:, :topk] <= thr).sum(1) / float(topk)
 
 
+class StepResults:
+    """(D, I, my_nprobe) of EVERY step of a timed region, for the parity check after the clock has stopped: each step writes into a
+    result buffer of its own (nothing is copied or compared while the clock runs), `collect` then folds steps over the same slice
+    that returned identical bytes into one stored variant with a count, and `check` compares every variant with the reference's
+    result for its slice.  What is compared is therefore what the timed searches themselves returned -- six in flight, whatever
+    kernels the engine picks under that concurrency -- not a re-run."""
+    KEEP = 128  # result buffers (6 MB each at the headline shape): of a longer region the last KEEP steps are checked
+
+    def __init__(self):
+        self.pending, self.variants, self.steps, self.unchecked = [], {}, 0, 0
+
+    def note(self, sn, start, buf, np_):
+        self.pending.append((sn, start, buf, np_))
+
+    def collect(self, nbuf, ses):
+        last = max(sn for sn, _, _, _ in self.pending) if self.pending else -1
+        for sn, start, (D, I), np_ in self.pending:
+            if sn + nbuf <= last:  # (its buffer was written again by a later step)
+                self.unchecked += 1
+                continue
+            self.steps += 1
+            npq = None if np_ is None else np_[start:start + ses]
+            for v in self.variants.setdefault(start, []):
+                if np.array_equal(v["D"].view(np.uint32), D.view(np.uint32)) and np.array_equal(v["I"], I) and (npq is None or np.array_equal(v["np"], npq)):
+                    v["count"] += 1
+                    break
+            else:
+                self.variants[start].append({"D": D.copy(), "I": I.copy(), "np": None if npq is None else npq.copy(), "count": 1})
+        self.pending = []
+        return self
+
+    def check(self, ref):
+        """ref(start) -> (D, I, my_nprobe or None) of the reference for the slice that starts at `start` (columns as the steps')"""
+        bad = bad_q = 0
+        for start, vs in self.variants.items():
+            rD, rI, rnp = ref(start)
+            for v in vs:
+                diff = (v["I"] != rI).any(1) | (v["D"].view(np.uint32) != np.ascontiguousarray(rD).view(np.uint32)).any(1)
+                if rnp is not None and v["np"] is not None:
+                    diff |= v["np"] != rnp
+                if diff.any():
+                    bad += v["count"]
+                    bad_q += int(diff.sum()) * v["count"]
+        return {"timed_steps_checked": self.steps, "timed_steps_differing": bad, "queries_differing_over_those_steps": bad_q,
+                "steps_not_kept": self.unchecked, "slices": len(self.variants),
+                "distinct_results_per_slice_max": max([len(v) for v in self.variants.values()] or [0])}
+
+
 def run_shards(args, torch, dist, capi, rank, world, local, dev, red_dev):
     """BASELINE configs[3]: SIFT-10M-like, IVF4096,Flat, k = topk, fixed nprobe; the inverted lists are sharded by list id over
     the ranks (the reference's IndexShards over sub-indexes that share one coarse quantizer, Auncel/IndexShards.cpp:261-311;
@@ -600,16 +648,21 @@ def main():
 
     outs = result_buffers(nslots)  # one pair per batch in flight (or queued)
     async_outs = outs if use_async else None  # (the single-caller leg of a threads run makes its own)
+    # ... and one pair per TIMED step (StepResults): what the timed searches return is what the parity leg checks
+    step_bufs = result_buffers(max(min(args.steps, StepResults.KEEP), min(args.steps, nslots))) if args.pinned_out else None
 
     hyper = {"mult": chosen, "std_m": chosen_std}
 
-    def step(ctx, stepno, slot=0):
+    def step(ctx, stepno, slot=0, keep=None):
         """step s searches slice s mod nsl of the resident queries: consecutive steps never see the same batch"""
         # (stepno // nfl: with as many slices as contexts, stepno % nsl alone would hand a context the same slice every time)
         start = ts + ((stepno + stepno // nfl) % nsl) * ses
         np_ = np.zeros(nall, dtype=np.uint64)
         tr_ = np.zeros(nall, dtype=np.float32)
-        D, I = ctx.search_adaptive(start, ses, topk, hyper["mult"], hyper["std_m"], req, np_, tr_, out=outs[slot])
+        buf = step_bufs[stepno % len(step_bufs)] if keep is not None and step_bufs else outs[slot]
+        D, I = ctx.search_adaptive(start, ses, topk, hyper["mult"], hyper["std_m"], req, np_, tr_, out=buf)
+        if keep is not None and step_bufs:
+            keep.note(stepno, start, buf, np_)
         return D, I, np_, start
 
     def barrier():
@@ -634,15 +687,20 @@ def main():
         acc["slot_eff"] = acc.get("slot_eff", 0.0) + tm["slot_efficiency"]
         acc["last"] = res
 
-    def run_steps_async(nsteps, acc):
-        """one caller thread keeps up to nfl steps in flight: submit step s, and once nfl are out wait for the oldest first"""
+    def run_steps_async(nsteps, acc, keep=None):
+        """one caller thread keeps up to nfl steps in flight: submit step s, and once nfl are out wait for the oldest first.
+        keep (a StepResults): every step returns into a result buffer of its own and is noted for the parity check"""
         pending = []
+        # (a buffer must not come round again while its step is still out: at most len(async_outs) are)
+        kept_bufs = step_bufs if keep is not None and step_bufs and len(step_bufs) >= min(nsteps, len(async_outs)) else None
 
         def finish():
-            ticket, np_, start = pending.pop(0)
+            ticket, np_, start, sn, buf = pending.pop(0)
             D, I, tm, dg = h.wait(ticket)
             if os.environ.get("AUNCEL_BENCH_TRACE_ASYNC"):
                 log(f"async step done at {1e3 * (time.perf_counter() - t_async0):.2f} ms: engine wall {tm['total_ms']:.2f} ms")
+            if kept_bufs is not None:
+                keep.note(sn, start, buf, np_)
             account(acc, tm, dg["hinted_launches"], dg["short_hints"], dg["tie_redone"], (D, I, np_, start))
 
         aslots = len(async_outs)
@@ -655,15 +713,15 @@ def main():
             start = ts + (sn % nsl) * ses
             np_ = np.zeros(nall, dtype=np.uint64)
             tr_ = np.zeros(nall, dtype=np.float32)
-            pending.append((h.submit_adaptive(start, ses, topk, hyper["mult"], hyper["std_m"], req, np_, tr_, out=async_outs[sn % aslots]),
-                            np_, start))
+            buf = kept_bufs[sn % len(kept_bufs)] if kept_bufs is not None else async_outs[sn % aslots]
+            pending.append((h.submit_adaptive(start, ses, topk, hyper["mult"], hyper["std_m"], req, np_, tr_, out=buf), np_, start, sn, buf))
         while pending:
             finish()
 
-    def run_steps(nsteps, acc):
+    def run_steps(nsteps, acc, keep=None):
         """steps j, j + nfl, ... on context j; acc collects per-step kernel timings and the last result"""
         if use_async and nfl > 1:
-            return run_steps_async(nsteps, acc)
+            return run_steps_async(nsteps, acc, keep)
         errs = []
 
         def worker(j):
@@ -674,7 +732,7 @@ def main():
                 # having searched at all, and its first search -- workspaces, streams -- lands in the timed region: 2.4-2.5 vs
                 # 2.7 M q/s at --steps 20 --warmup 5)
                 for sn in range(j, nsteps, nfl):
-                    res = step(ctxs[j], sn, j)
+                    res = step(ctxs[j], sn, j, keep)
                     tm = ctxs[j].last_timing()
                     hints = ctxs[j].last_round_hints()
                     det = ctxs[j].last_timing_detail()
@@ -699,11 +757,13 @@ def main():
     for c in ctxs:
         c.stats(reset=True)
     acc = {}
+    kept_timed = StepResults()
     barrier()
     t0 = time.perf_counter()
-    run_steps(args.steps, acc)
+    run_steps(args.steps, acc, kept_timed)
     barrier()
     elapsed = time.perf_counter() - t0
+    kept_timed.collect(len(step_bufs) if step_bufs else 1, ses)  # (after the clock: copies of the distinct results, the buffers are free again)
     per_rank_value = [ses * args.steps / elapsed]
     if world > 1:
         t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
@@ -727,11 +787,13 @@ def main():
         """nsteps more steps with the current settings, after the timed region (never part of `value`)"""
         leg = {}
         run_steps(min(nsteps, max(nfl, 2)), {})
+        kept = StepResults()
         barrier()
         tl = time.perf_counter()
-        run_steps(nsteps, leg)
+        run_steps(nsteps, leg, kept)
         barrier()
         leg["elapsed"] = time.perf_counter() - tl
+        leg["kept"] = kept.collect(len(step_bufs) if step_bufs else 1, ses)
         return leg
 
     # the same steps one batch at a time (after the timed region, not part of `value`): per-launch kernel figures without
@@ -748,11 +810,13 @@ def main():
     # the same workload on the fp32 lists (byte codes switched off on every context): what the engine does on data that is
     # not uint8-valued, and a cross-check of the byte-code path (results must be identical)
     fp32 = None
+    kept_fp32 = kept_fixed = None
     arith = h.scan_arith()  # of the timed region
     if arith == 2 and not args.no_legs and "fp32" not in skip_legs:
         for c in ctxs:
             c.set_byte_codes(False)
         leg = timed_leg(max(4, args.steps // 3))
+        kept_fp32 = leg["kept"]
         fD, fI, f_np, f_start = leg["last"]
         nst = max(4, args.steps // 3)
         if f_start != q_start:  # the same slice as the timed region's last step, for the comparison
@@ -820,15 +884,20 @@ def main():
     fixed32 = None
     if not args.no_legs and "fixed" not in skip_legs:
         fnp, fk = 32, topk
-        fouts = [(np.empty((ses, fk), np.float32), np.empty((ses, fk), np.int64)) for _ in range(2 * nfl)]
+        nst = max(2 * nfl, args.steps // 2)
+        # (600 KB a step: every step of the leg keeps its own, for the parity check)
+        fouts = [(np.empty((ses, fk), np.float32), np.empty((ses, fk), np.int64)) for _ in range(max(2 * nfl, nst))]
 
-        def run_fixed(nsteps):
+        def run_fixed(nsteps, keep=None):
             pend, last = [], None
             for sn in range(nsteps):
-                if len(pend) == len(fouts):
+                if len(pend) == 2 * nfl:
                     last = h.wait(pend.pop(0)[0])
                 st0 = ts + (sn % nsl) * ses
-                pend.append((h.submit_search_resident(st0, ses, fk, fnp, out=fouts[sn % len(fouts)]), st0))
+                buf = fouts[sn % len(fouts)]
+                pend.append((h.submit_search_resident(st0, ses, fk, fnp, out=buf), st0))
+                if keep is not None:
+                    keep.note(sn, st0, buf, None)
             st_last = pend[-1][1]
             while pend:
                 last = h.wait(pend.pop(0)[0])
@@ -837,12 +906,13 @@ def main():
         if nfl > 1:
             h.set_async_depth(nfl)
         run_fixed(max(2 * nfl, 4))
+        kept_fixed = StepResults()
         barrier()
         tf0 = time.perf_counter()
-        nst = max(2 * nfl, args.steps // 2)
-        (fD, fI, _, _), f_st = run_fixed(nst)
+        (fD, fI, _, _), f_st = run_fixed(nst, kept_fixed)
         barrier()
         f_el = time.perf_counter() - tf0
+        kept_fixed.collect(len(fouts), ses)
         frec = recall_dist(fD, gtD[f_st:f_st + ses, :fk], fk)
         fixed32 = {"nprobe": fnp, "k": fk, "value": ses * nst / f_el, "unit": "queries/s", "ms_per_step": 1000.0 * f_el / nst,
                    "recall_at_k_mean": float(frec.mean()), "how": "amd_ivf_submit_search_resident / amd_ivf_wait on the same index and slices"}
@@ -1121,11 +1191,30 @@ def main():
         def differing(rD, rI, rnp):
             return int(((rI != gI).any(1) | (rD != gD).any(1) | (rnp != g_np)).sum())
 
-        port_diff = differing(oD, oI, tun.my_nprobe[ts:ts + S])
+        port_np = tun.my_nprobe[ts:ts + S].astype(np.uint64)
+        port_diff = differing(oD, oI, port_np)
+
+        def slices_of(rD, rI, rnp, cols=K):
+            return lambda start: (rD[start - ts:start - ts + ses, :cols], rI[start - ts:start - ts + ses, :cols],
+                                  None if rnp is None else rnp[start - ts:start - ts + ses])
+
+        # ... and what the TIMED searches themselves returned (six in flight: StepResults), step by step, against the same results
+        timed_par = dict(kept_timed.check(slices_of(oD, oI, port_np)), against="CPU restatement (pinned)")
+        fp32_par = dict(kept_fp32.check(slices_of(oD, oI, port_np)), against="CPU restatement (pinned)") if kept_fp32 is not None else None
+        fixed_par = None
+        if kept_fixed is not None:
+            fcd, fck = pyoracle.knn(pyoracle.METRIC_L2, xs, cen, fixed32["nprobe"], nthreads=cores)
+            pfD, pfI, _ = pyoracle.search_preassigned(lists, xs, fixed32["k"], fck, fcd, nthreads=cores)
+            fixed_par = dict(kept_fixed.check(slices_of(pfD, pfI, None, fixed32["k"])), against="CPU restatement (pinned)")
+            del fcd, fck
         parity = {"regime": {2: "coarse_ties = 2: the reference's order inside runs of bit-equal coarse distances for every query, the heap's order "
                                 "patched into the one pass (include/auncel_amd.h)", 1: "coarse_ties = 1", 0: "coarse_ties = 0 (centroid-number order)"}[ties_opt],
                   "queries": S, "slices": nsl,
-                  "rankings_the_heap_changed": int(patched), "queries_searched_again": int(redone)}
+                  "rankings_the_heap_changed": int(patched), "queries_searched_again": int(redone),
+                  # the results of the timed steps themselves (every step of the timed region: D, I and my_nprobe as the searches in flight
+                  # returned them) and of the legs' steps, against the reference's result for the slice each searched
+                  "timed_steps_checked": timed_par["timed_steps_checked"], "timed_steps_differing": timed_par["timed_steps_differing"],
+                  "timed_region": timed_par, "fp32_path_steps": fp32_par, "fixed_nprobe_32_steps": fixed_par}
         if port_diff:
             log("PARITY MISMATCH vs the CPU restatement:", port_diff, "of", S, "queries differ in I / D / my_nprobe")
         log(f"parity vs the CPU restatement on {S} queries ({nsl} slices): {port_diff} differ; {patched} rankings changed by the heap, {redone} queries searched again")
@@ -1155,6 +1244,16 @@ def main():
                                   single_thread_queries=S1, threads=cores)
                 rnp = ro["my_nprobe"].astype(np.uint64)
                 ref_diff = differing(ro["D"], ro["I"], rnp)
+                against = "compiled reference (oracle/_ref/ref_harness)"
+                timed_par = dict(kept_timed.check(slices_of(ro["D"], ro["I"], rnp)), against=against)
+                parity.update({"timed_steps_checked": timed_par["timed_steps_checked"], "timed_steps_differing": timed_par["timed_steps_differing"],
+                               "timed_region": timed_par})
+                if kept_fp32 is not None:
+                    parity["fp32_path_steps"] = dict(kept_fp32.check(slices_of(ro["D"], ro["I"], rnp)), against=against)
+                if kept_fixed is not None:
+                    rf_ = refbench.run_fixed(pyoracle.METRIC_L2, cen, lists.off, lists.codes, lists.ids, xs, fixed32["k"], fixed32["nprobe"], threads=cores)
+                    parity["fixed_nprobe_32_steps"] = dict(kept_fixed.check(slices_of(rf_["D"], rf_["I"], None, fixed32["k"])), against=against,
+                                                           reference_qps=S / rf_["seconds_all_threads"])
                 port = out["cpu_baseline"]
                 out["cpu_baseline"] = {
                     "value": S / ro["seconds_all_threads"], "unit": "queries/s", "cores": ro["threads"], "kind": "reference",
@@ -1166,6 +1265,7 @@ def main():
                                              "(eval/bound.cpp:380-386) -- what the shipped reference does"},
                     "port": {k: port[k] for k in ("value", "cores", "gpu_matches_cpu_on_sample", "queries_differing", "one_thread")},
                 }
+                log("timed steps against the reference:", json.dumps({k: parity[k] for k in ("timed_region", "fp32_path_steps", "fixed_nprobe_32_steps")}))
                 log(f"reference on the host: {S / ro['seconds_all_threads']:.1f} q/s on {ro['threads']} threads, "
                     f"{ro['queries_one_thread'] / ro['seconds_one_thread']:.1f} q/s on one ({time.time() - t0:.1f}s incl. hand-over); "
                     f"GPU == reference on all {S} queries: {ref_diff == 0} ({ref_diff} differ)")
@@ -1203,7 +1303,7 @@ def main():
             import guaranteed_workload
             t0 = time.time()
             gw = guaranteed_workload.run(torch, capi, dev, log, sigma=20.0, nb=args.nb, d=d, nlist=nlist, blobs=args.blobs, K=K, topk=topk, bound=0.9,
-                                         ts=ts, ses=ses, steps=max(12, args.steps // 2), in_flight=nfl)
+                                         ts=ts, ses=ses, steps=max(12, args.steps // 2), in_flight=nfl, check_parity=not args.no_cpu)
             out["guaranteed_bound_workload"] = gw
             log(f"guaranteed-bound workload: guaranteed {gw.get('bound_guaranteed')} at multipler {gw.get('multipler')}: {gw.get('value', 0) / 1e6:.3f} M q/s "
                 f"({time.time() - t0:.0f}s)")
@@ -1235,6 +1335,16 @@ def main():
         dist.destroy_process_group()
     if rank == 0 and world > 1 and out.get("shards", {}).get("shards_equal_single_index") is False:
         sys.exit(3)
+    # a timed step (or a leg's step) whose result is not the reference's is not a measurement
+    cb = out.get("cpu_baseline") or {}
+    par = cb.get("parity") or {}
+    bad = int(cb.get("queries_differing") or 0) + sum(int((par.get(k) or {}).get("timed_steps_differing") or 0)
+                                                        for k in ("timed_region", "fp32_path_steps", "fixed_nprobe_32_steps"))
+    gw = out.get("guaranteed_bound_workload") or {}
+    bad += int((gw.get("parity") or {}).get("timed_steps_differing") or 0)
+    if rank == 0 and bad:
+        log("PARITY FAILURE:", bad, "differences between the engine's results and the reference's (see cpu_baseline.parity)")
+        sys.exit(4)
 
 
 if __name__ == "__main__":

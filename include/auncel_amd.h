@@ -99,6 +99,18 @@ int amd_ivf_search(amd_ivf_t* h, size_t n, const float* x, size_t k, size_t npro
  * returns the number of heap updates in *nup  [IndexIVFFlat.cpp:101-137] */
 int amd_ivf_scan_codes(amd_ivf_t* h, const float* query, size_t list_no, int store_pairs, size_t k, float* simi,
                        int64_t* idxi, size_t* nup);
+/* ... scan_codes over ANY run of codes of the list: the reference's scanner scans the n codes at whatever pointer it is handed
+ * (IndexIVFFlat.cpp:117-137; tests/test_lowlevel_ivf.cpp:426-564 hands different parts of a list to different threads).  Here the
+ * codes live in HBM, so the run is named: vectors [offset, offset + n) of list `list_no`.  Labels of the entries this call admits:
+ * store_pairs = 0: the stored ids of those vectors; store_pairs = 1: list_no << 32 | j with j counted FROM `offset`, exactly what the
+ * reference computes for a `codes` pointer that starts there (IndexIVFFlat.cpp:131).  Labels already in the heap pass through. */
+int amd_ivf_scan_codes_at(amd_ivf_t* h, const float* query, size_t list_no, size_t offset, size_t n, int store_pairs, size_t k,
+                          float* simi, int64_t* idxi, size_t* nup);
+/* InvertedListScanner::scan_codes_range over the same kind of run  [IndexIVF.h:349-354, IndexIVFFlat.cpp:139-155]: the entries with
+ * C::cmp(radius, dis) -- dis < radius (L2) / dis > radius (IP) -- in position order, as RangeQueryResult::add receives them.  *count
+ * entries; amd_ivf_scan_codes_range_results copies their positions j (counted from `offset`) and distances out of the handle. */
+int amd_ivf_scan_codes_range(amd_ivf_t* h, const float* query, size_t list_no, size_t offset, size_t n, float radius, size_t* count);
+int amd_ivf_scan_codes_range_results(amd_ivf_t* h, uint32_t* positions, float* distances);
 /* InvertedListScanner::distance_to_code for vector `offset` of list `list_no`  [IndexIVFFlat.cpp:110-115] */
 int amd_ivf_distance_to_code(amd_ivf_t* h, const float* query, size_t list_no, size_t offset, float* dis);
 

@@ -19,8 +19,40 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 
+def parity_of(kept, h, cen, traces, xs, ts, ses, K, topk, bound, mult, sm, nlist, d, capi, log):
+    """every timed step's (D, I, my_nprobe) against the compiled reference (oracle/_ref/ref_harness; the pinned CPU restatement where
+    the harness is absent) on the same lists / centroids / traces: test infrastructure, after the clock"""
+    from oracle import pyoracle, refbench
+    codes, ids, off = [], [], np.zeros(nlist + 1, dtype=np.uintp)
+    for l in range(nlist):
+        c, i_ = h.get_list(l)
+        codes.append(c)
+        ids.append(i_)
+        off[l + 1] = off[l] + len(i_)
+    codes, ids = np.concatenate(codes), np.concatenate(ids)
+    S = len(xs)
+    if refbench.available():
+        ro = refbench.run(cen, off, codes, ids, traces, xs, ts, K, topk, bound, mult, sm, single_thread_queries=1, threads=bench.host_cores())
+        rD, rI, rnp, against = ro["D"], ro["I"], ro["my_nprobe"].astype(np.uint64), "compiled reference (oracle/_ref/ref_harness)"
+    else:
+        lists = pyoracle.Lists.__new__(pyoracle.Lists)
+        lists.metric, lists.centroids, lists.nlist, lists.d = pyoracle.METRIC_L2, cen, nlist, d
+        lists.off, lists.codes, lists.ids = off, codes, ids
+        lists.struct = pyoracle.OrcIndex(lists.metric, d, nlist, pyoracle._s(lists.off), pyoracle._f(lists.codes), pyoracle._i(lists.ids))
+        nall = ts + S
+        tun = pyoracle.Tuner(h.get_interdis(), traces, K, nall, arcos=capi.arcos_table())
+        stt = tun.struct(topk, np.full(nall, bound, dtype=np.float32), mult, sm)
+        cd, ck = pyoracle.knn(pyoracle.METRIC_L2, xs, cen, nlist, nthreads=bench.host_cores())
+        rD, rI, _ = pyoracle.search_preassigned(lists, xs, K, ck, cd, tuner=stt, offset=ts, nthreads=bench.host_cores())
+        rnp, against = tun.my_nprobe[ts:ts + S].astype(np.uint64), "CPU restatement (pinned)"
+    res = kept.check(lambda start: (rD[start - ts:start - ts + ses], rI[start - ts:start - ts + ses], rnp[start - ts:start - ts + ses]))
+    res["against"] = against
+    log("    guaranteed workload, timed steps against the reference:", json.dumps(res))
+    return res
+
+
 def run(torch, capi, dev, log, sigma=30.0, nb=10_000_000, d=128, nlist=4096, blobs=20000, K=100, topk=10, bound=0.9, ts=5000, ses=5000,
-        steps=24, in_flight=6, nsl=2):
+        steps=24, in_flight=6, nsl=2, check_parity=True):
     t0 = time.time()
     xb_t, _, draw = bench.gen_data(torch, dev, nb, 0, d, blobs, sigma, 4321)
     gq = torch.Generator(device=dev)
@@ -57,25 +89,37 @@ def run(torch, capi, dev, log, sigma=30.0, nb=10_000_000, d=128, nlist=4096, blo
     h.set_async_depth(in_flight)
     outs = [(np.empty((ses, K), np.float32), np.empty((ses, K), np.int64)) for _ in range(2 * in_flight)]
 
-    def run_steps(n, mult, sm):
-        """n steps over the timed slices, in_flight at a time; returns the per-query recall of EVERY timed slice's last search"""
+    step_outs = [(np.empty((ses, K), np.float32), np.empty((ses, K), np.int64)) for _ in range(max(steps, 2 * in_flight))]
+
+    def run_steps(n, mult, sm, keep=None):
+        """n steps over the timed slices, in_flight at a time; returns the per-query recall of EVERY timed slice's last search.
+        keep (bench.StepResults): every step returns into a buffer of its own and is noted for the parity check"""
         pend, recs, nps = [], {}, {}
 
         def finish():
-            tk, npq, st0 = pend.pop(0)
+            tk, npq, st0, sn, buf = pend.pop(0)
             D, _, _, _ = h.wait(tk)
-            recs[st0] = bench.recall_dist(D, gtD[st0:st0 + ses], topk)
-            nps[st0] = npq[st0:st0 + ses].copy()
+            if keep is not None:
+                keep.note(sn, st0, buf, npq)
+            else:
+                recs[st0] = bench.recall_dist(D, gtD[st0:st0 + ses], topk)
+                nps[st0] = npq[st0:st0 + ses].copy()
 
         for sn in range(n):
-            if len(pend) == len(outs):
+            if len(pend) == 2 * in_flight:
                 finish()
             st0 = ts + (sn % nsl) * ses
             np_ = np.zeros(nall, dtype=np.uint64)
             tr_ = np.zeros(nall, dtype=np.float32)
-            pend.append((h.submit_adaptive(st0, ses, topk, mult, sm, req, np_, tr_, out=outs[sn % len(outs)]), np_, st0))
+            buf = step_outs[sn % len(step_outs)] if keep is not None else outs[sn % len(outs)]
+            pend.append((h.submit_adaptive(st0, ses, topk, mult, sm, req, np_, tr_, out=buf), np_, st0, sn, buf))
         while pend:
             finish()
+        if keep is not None:  # (after the clock: recall of every slice's last search from the kept results)
+            for sn, st0, (D, _), npq in keep.pending:
+                recs[st0] = bench.recall_dist(D, gtD[st0:st0 + ses], topk)
+                nps[st0] = npq[st0:st0 + ses].copy()
+            keep.collect(len(step_outs), ses)
         return np.concatenate([recs[k] for k in sorted(recs)]), np.concatenate([nps[k] for k in sorted(nps)])
 
     for mult, sm in grid:
@@ -93,8 +137,9 @@ def run(torch, capi, dev, log, sigma=30.0, nb=10_000_000, d=128, nlist=4096, blo
         # made on the searched queries, with hand-tuned hyper-parameters -- hyperparameter.txt; a point that fails it is followed by the next)
         run_steps(2 * in_flight, mult, sm)
         torch.cuda.synchronize()
+        kept = bench.StepResults()
         t1 = time.perf_counter()
-        rec_t, np_t = run_steps(steps, mult, sm)
+        rec_t, np_t = run_steps(steps, mult, sm, kept)
         torch.cuda.synchronize()
         el = time.perf_counter() - t1
         row.update({"value": ses * steps / el, "timed_recall_min": float(rec_t.min()), "timed_recall_mean": float(rec_t.mean()), "timed_nprobe_mean": float(np_t.mean())})
@@ -103,6 +148,8 @@ def run(torch, capi, dev, log, sigma=30.0, nb=10_000_000, d=128, nlist=4096, blo
             out.update({"multipler": mult, "std_m": sm, "value": ses * steps / el, "unit": "queries/s", "ms_per_step": 1e3 * el / steps, "in_flight": in_flight,
                         "recall_min": float(rec_t.min()), "recall_mean": float(rec_t.mean()), "queries_checked": int(len(rec_t)), "bound_guaranteed": True,
                         "nprobe_mean": float(np_t.mean()), "coarse_ties": "redo (the exact regime, as the headline)"})
+            if check_parity:
+                out["parity"] = parity_of(kept, h, cen, traces, xq[ts:ts + nsl * ses], ts, ses, K, topk, bound, mult, sm, nlist, d, capi, log)
             break
     h.close()
     return out

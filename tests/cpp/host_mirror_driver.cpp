@@ -6,7 +6,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <memory>
+#include <thread>
 
 #include "../../auncel_amd/csrc/host/AutoTune.h"
 #include "../../auncel_amd/csrc/host/AuxIndexStructures.h"
@@ -94,6 +96,118 @@ static int run_fixed(const tb::Bundle& in) {
         }
     }
 
+    {   // tests/test_lowlevel_ivf.cpp:426-564 (ThreadedSearch): the probes of a query dealt to three threads, one scanner and one
+        // result heap per thread, heaps merged with heap_addn -- and, beyond the reference's test, every list handed over in two
+        // HALVES (scan_codes scans whatever run of codes it is handed, IndexIVFFlat.cpp:117-137)
+        const size_t k = ks.as<int64_t>()[0];
+        const int64_t* Iref = in.get("I_k" + std::to_string(k)).as<int64_t>();
+        const float* Dref = in.get("D_k" + std::to_string(k)).as<float>();
+        std::vector<float> cd(nq * nprobe);
+        std::vector<idx_t> ck(nq * nprobe);
+        ix->quantizer->search(nq, xq.as<float>(), nprobe, cd.data(), ck.data());
+        const int nproc = 3;
+        const bool l2 = mt == METRIC_L2;
+        for (size_t i = 0; i < std::min<size_t>(nq, 6); i++) {
+            std::vector<idx_t> I(k * nproc, -1);
+            std::vector<float> D(k * nproc, l2 ? HUGE_VALF : -HUGE_VALF);
+            auto work = [&](int rank) {
+                std::unique_ptr<InvertedListScanner> sc(ix->get_InvertedListScanner());
+                sc->set_query(xq.as<float>() + i * d);
+                for (size_t j = rank; j < nprobe; j += nproc) {
+                    const idx_t key = ck[i * nprobe + j];
+                    if (key < 0) continue;
+                    sc->set_list(key, cd[i * nprobe + j]);
+                    const size_t sz = ix->invlists->list_size(key), half = sz / 2;
+                    InvertedLists::ScopedCodes codes(ix->invlists, key);
+                    InvertedLists::ScopedIds ids(ix->invlists, key);
+                    sc->scan_codes(half, codes.get(), ids.get(), D.data() + rank * k, I.data() + rank * k, k);
+                    sc->scan_codes(sz - half, codes.get() + half * ix->code_size, ids.get() + half, D.data() + rank * k, I.data() + rank * k, k);
+                }
+            };
+            std::vector<std::thread> th;
+            for (int r = 0; r < nproc; r++) th.emplace_back(work, r);
+            for (int r = 0; r < nproc; r++) {
+                th[r].join();
+                if (r == 0) continue;
+                if (l2) maxheap_addn(k, D.data(), I.data(), D.data() + r * k, I.data() + r * k, k);
+                else minheap_addn(k, D.data(), I.data(), D.data() + r * k, I.data() + r * k, k);
+            }
+            if (l2) maxheap_reorder(k, D.data(), I.data()); else minheap_reorder(k, D.data(), I.data());
+            // (threads + merge order equal distances differently from the serial loop: the reference's test data has no ties either;
+            // compare the distances, and the ids where a distance is unique)
+            bool ok = same_f(D.data(), Dref + i * k, k);
+            for (size_t j = 0; j < k && ok; j++) {
+                const bool tie = (j > 0 && D[j] == D[j - 1]) || (j + 1 < k && D[j] == D[j + 1]);
+                if (!tie) ok = I[j] == Iref[i * k + j];
+            }
+            expect(ok, "threaded scanners over list halves == search, query " + std::to_string(i));
+        }
+        // one scanner, serial, lists in three parts of uneven length: the same heap as the whole lists give (ids AND order), through
+        // the list's own ids, through a caller-owned id array, and with store_pairs (j counts from the part's first code)
+        for (size_t i = 0; i < std::min<size_t>(nq, 3); i++) {
+            std::unique_ptr<InvertedListScanner> sc(ix->get_InvertedListScanner()), sp(ix->get_InvertedListScanner(true));
+            std::vector<float> s0(k), s1(k), s2(k);
+            std::vector<idx_t> i0(k), i1(k), i2(k);
+            auto heapify = [&](std::vector<float>& v, std::vector<idx_t>& l) { if (l2) maxheap_heapify(k, v.data(), l.data()); else minheap_heapify(k, v.data(), l.data()); };
+            heapify(s0, i0);
+            heapify(s1, i1);
+            heapify(s2, i2);
+            sc->set_query(xq.as<float>() + i * d);
+            sp->set_query(xq.as<float>() + i * d);
+            bool pairs_ok = true;
+            for (size_t p = 0; p < nprobe; p++) {
+                const idx_t key = ck[i * nprobe + p];
+                if (key < 0 || ix->invlists->list_size(key) == 0) continue;
+                sc->set_list(key, cd[i * nprobe + p]);
+                sp->set_list(key, cd[i * nprobe + p]);
+                const size_t sz = ix->invlists->list_size(key);
+                const size_t cut[4] = {0, sz / 5, sz / 5 + (sz - sz / 5) / 2, sz};
+                const uint8_t* codes = ix->invlists->get_codes(key);
+                const idx_t* ids = ix->invlists->get_ids(key);
+                std::vector<idx_t> mine(ids, ids + sz);
+                for (idx_t& v : mine) v += 1000000;
+                for (int part = 0; part < 3; part++) {
+                    const size_t a = cut[part], n = cut[part + 1] - cut[part];
+                    sc->scan_codes(n, codes + a * ix->code_size, ids + a, s0.data(), i0.data(), k);
+                    sc->scan_codes(n, codes + a * ix->code_size, mine.data() + a, s1.data(), i1.data(), k);
+                    std::vector<idx_t> before(i2);
+                    sp->scan_codes(n, codes + a * ix->code_size, nullptr, s2.data(), i2.data(), k);
+                    // what this part admitted carries key << 32 | j with j counted from the part's first code (IndexIVFFlat.cpp:131)
+                    for (size_t s = 0; s < k; s++) {
+                        const size_t j = (size_t)(i2[s] & 0xffffffffll);
+                        const bool here = s2[s] == s0[s] && i2[s] >= 0 && (i2[s] >> 32) == key && j < n && ids[j + a] == i0[s];
+                        const bool empty = i2[s] == -1 && i0[s] == -1;
+                        const bool earlier = std::find(before.begin(), before.end(), i2[s]) != before.end();  // (an earlier part or list)
+                        if (!(here || empty || earlier)) pairs_ok = false;
+                    }
+                }
+            }
+            if (l2) { maxheap_reorder(k, s0.data(), i0.data()); maxheap_reorder(k, s1.data(), i1.data()); }
+            else { minheap_reorder(k, s0.data(), i0.data()); minheap_reorder(k, s1.data(), i1.data()); }
+            expect(same_i(i0.data(), Iref + i * k, k) && same_f(s0.data(), Dref + i * k, k), "scanner over list parts == search, query " + std::to_string(i));
+            bool mine_ok = same_f(s1.data(), Dref + i * k, k);
+            for (size_t j = 0; j < k; j++) mine_ok &= i1[j] == (Iref[i * k + j] < 0 ? -1 : Iref[i * k + j] + 1000000);
+            expect(mine_ok, "scanner with the caller's own id array, query " + std::to_string(i));
+            expect(pairs_ok, "store_pairs labels count from the part's first code, query " + std::to_string(i));
+        }
+        // a code pointer that is not in the current list is refused (the lists live in HBM)
+        {
+            std::unique_ptr<InvertedListScanner> sc(ix->get_InvertedListScanner());
+            sc->set_query(xq.as<float>());
+            size_t l0 = 0;
+            while (l0 < nlist && ix->invlists->list_size(l0) == 0) l0++;
+            sc->set_list((idx_t)l0, 0.f);
+            std::vector<float> sv(k);
+            std::vector<idx_t> iv(k);
+            bool threw = false;
+            try { sc->scan_codes(1, reinterpret_cast<const uint8_t*>(xq.as<float>()), nullptr, sv.data(), iv.data(), k); } catch (const FaissException&) { threw = true; }
+            expect(threw, "foreign code pointer refused");
+            threw = false;
+            try { sc->scan_codes(ix->invlists->list_size(l0) + 1, ix->invlists->get_codes(l0), ix->invlists->get_ids(l0), sv.data(), iv.data(), k); } catch (const FaissException&) { threw = true; }
+            expect(threw, "run past the end of the list refused");
+        }
+    }
+
     {   // search_and_reconstruct / reconstruct_n / make_direct_map + reconstruct (IndexIVF.cpp:305-328,869-938)
         const size_t k = ks.as<int64_t>()[0];
         std::vector<float> D(nq * k), R(nq * k * d);
@@ -135,6 +249,78 @@ static int run_fixed(const tb::Bundle& in) {
         }
         const int64_t* st = in.get("range_stats").as<int64_t>();
         expect(indexIVF_stats.nlist == (size_t)st[0] && indexIVF_stats.ndis == (size_t)st[1], "range_search stats");
+    }
+
+    if (in.has("range_lims") && d % 4 == 0) {
+        // IndexIVF::range_search_preassigned as the reference writes it (IndexIVF.cpp:760-857): one RangeSearchPartialResult, a
+        // RangeQueryResult per query, InvertedListScanner::scan_codes_range per probed list -- here in two halves per list
+        const float radius = in.get("radius").as<float>()[0];
+        std::vector<float> cd(nq * nprobe);
+        std::vector<idx_t> ck(nq * nprobe);
+        ix->quantizer->search(nq, xq.as<float>(), nprobe, cd.data(), ck.data());
+        const size_t nsub = std::min<size_t>(nq, 8);
+        const int64_t* gl = in.get("range_lims").as<int64_t>();
+        for (int pairs = 0; pairs < 2; pairs++) {
+            RangeSearchResult res(nsub);
+            RangeSearchPartialResult pres(&res);
+            std::unique_ptr<InvertedListScanner> sc(ix->get_InvertedListScanner(pairs != 0));
+            std::vector<idx_t> expect_pairs;
+            for (size_t i = 0; i < nsub; i++) {
+                sc->set_query(xq.as<float>() + i * d);
+                RangeQueryResult& qres = pres.new_result((idx_t)i);
+                for (size_t p = 0; p < nprobe; p++) {
+                    const idx_t key = ck[i * nprobe + p];
+                    if (key < 0 || ix->invlists->list_size(key) == 0) continue;
+                    sc->set_list(key, cd[i * nprobe + p]);
+                    const size_t sz = ix->invlists->list_size(key), half = (sz + 1) / 2;
+                    const uint8_t* codes = ix->invlists->get_codes(key);
+                    const idx_t* ids = ix->invlists->get_ids(key);
+                    sc->scan_codes_range(half, codes, ids, radius, qres);
+                    sc->scan_codes_range(sz - half, codes + half * ix->code_size, ids + half, radius, qres);
+                }
+            }
+            pres.finalize();
+            bool ok = true;
+            for (size_t i = 0; i <= nsub; i++) ok &= (int64_t)res.lims[i] == gl[i];
+            expect(ok, std::string("scan_codes_range lims") + (pairs ? " (store_pairs)" : ""));
+            if (!ok) continue;
+            expect(same_f(res.distances, in.get("range_distances").as<float>(), res.lims[nsub]), std::string("scan_codes_range distances") + (pairs ? " (store_pairs)" : ""));
+            if (!pairs) {
+                expect(same_i(res.labels, in.get("range_labels").as<int64_t>(), res.lims[nsub]), "scan_codes_range labels");
+            } else {
+                // list << 32 | j, j from the half's first code: the stored id at that place is the golden label
+                const int64_t* glab = in.get("range_labels").as<int64_t>();
+                bool pok = true;
+                for (size_t e = 0; e < res.lims[nsub] && pok; e++) {
+                    const idx_t key = res.labels[e] >> 32, j = res.labels[e] & 0xffffffffll;
+                    const size_t sz = ix->invlists->list_size(key), half = (sz + 1) / 2;
+                    const idx_t* ids = ix->invlists->get_ids(key);
+                    pok = ((size_t)j < half && ids[j] == glab[e]) || ((size_t)j + half < sz && ids[j + half] == glab[e]);
+                }
+                expect(pok, "scan_codes_range store_pairs labels");
+            }
+        }
+        // RangeSearchPartialResult::merge over two partial results that split the queries (parallel_mode != 0's ending, IndexIVF.cpp:846-851)
+        {
+            RangeSearchResult res(nsub);
+            std::vector<RangeSearchPartialResult*> parts{new RangeSearchPartialResult(&res), new RangeSearchPartialResult(&res)};
+            std::unique_ptr<InvertedListScanner> sc(ix->get_InvertedListScanner());
+            for (size_t i = 0; i < nsub; i++) {
+                sc->set_query(xq.as<float>() + i * d);
+                RangeQueryResult& qres = parts[i & 1]->new_result((idx_t)i);
+                for (size_t p = 0; p < nprobe; p++) {
+                    const idx_t key = ck[i * nprobe + p];
+                    if (key < 0 || ix->invlists->list_size(key) == 0) continue;
+                    sc->set_list(key, cd[i * nprobe + p]);
+                    sc->scan_codes_range(ix->invlists->list_size(key), ix->invlists->get_codes(key), ix->invlists->get_ids(key), radius, qres);
+                }
+            }
+            RangeSearchPartialResult::merge(parts);
+            bool ok = true;
+            for (size_t i = 0; i <= nsub; i++) ok &= (int64_t)res.lims[i] == gl[i];
+            expect(ok && same_i(res.labels, in.get("range_labels").as<int64_t>(), res.lims[nsub]) &&
+                       same_f(res.distances, in.get("range_distances").as<float>(), res.lims[nsub]), "RangeSearchPartialResult::merge");
+        }
     }
 
     if (in.scalar_or<int>("dedup", 0) > 0) {  // IndexIVFFlatDedup against the compiled reference's (same two add() calls)

@@ -101,6 +101,64 @@ def test_scanner_api(capi, name):
         assert np.array_equal(idxi, gold["scan_heap_I"][i])
 
 
+@pytest.mark.parametrize("name", ["fixed_sift_l2", "fixed_gauss_l2_d96", "fixed_deep_ip_d96", "fixed_dups", "fixed_odd_d30"])
+def test_scanner_over_list_parts(capi, oracle, name):
+    """amd_ivf_scan_codes_at / amd_ivf_scan_codes_range: the reference's scanner scans the n codes at whatever pointer it is handed
+    (IndexIVFFlat.cpp:117-155).  A list handed over in parts of any length leaves the heap the whole list leaves (values, labels,
+    update counts: the goldens of the whole-list scan), store_pairs labels count from the part's first code, and the range scan
+    reports the entries inside the radius in position order with the reference's distance bits (oracle: its per-pair distance)"""
+    case, gold = load_case(name)
+    h = make_index(capi, case, gold)
+    k = int(case["ks"][0])
+    is_l2 = case["metric"] == 1
+    fmax = np.finfo(np.float32).max
+    rs = np.random.RandomState(5)
+    for i in range(min(3, gold["scan_heap_D"].shape[0])):
+        simi = np.full(k, fmax if is_l2 else -fmax, dtype=np.float32)
+        idxi = np.full(k, -1, dtype=np.int64)
+        simi_p, idxi_p = simi.copy(), idxi.copy()
+        for p in range(case["nprobe"]):
+            key = int(gold["coarse_keys_sse"][i, p])
+            sz = h.list_size(key) if key >= 0 else 0
+            if sz == 0:
+                continue
+            cuts = np.unique(np.concatenate([[0, sz], rs.randint(0, sz + 1, size=3)]))  # up to four parts, some may be one vector
+            nup = 0
+            _, ids = h.get_list(key)
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                nup += h.scan_codes_at(case["xq"][i], key, int(a), int(b - a), simi, idxi)
+                before = idxi_p.copy()
+                h.scan_codes_at(case["xq"][i], key, int(a), int(b - a), simi_p, idxi_p, store_pairs=True)
+                new = idxi_p != before
+                assert np.array_equal(bits(simi_p), bits(simi))
+                assert np.all((idxi_p[new] >> 32) == key) and np.all((idxi_p[new] & 0xffffffff) < b - a)
+                assert np.array_equal(ids[(idxi_p[new] & 0xffffffff) + a], idxi[new])
+            assert nup == gold["scan_nup"][i, p]
+            # an empty run and a run past the end
+            assert h.scan_codes_at(case["xq"][i], key, sz, 0, simi, idxi) == 0
+            with pytest.raises(capi.EngineError, match="beyond the end"):
+                h.scan_codes_at(case["xq"][i], key, 1, sz, simi, idxi)
+        assert np.array_equal(bits(simi), bits(gold["scan_heap_D"][i]))
+        assert np.array_equal(idxi, gold["scan_heap_I"][i])
+    # range scan of list parts: the per-pair distances of the pinned oracle, filtered at a radius that keeps about a third
+    for i in range(2):
+        key = int(gold["coarse_keys_sse"][i, 0])
+        sz = h.list_size(key)
+        if sz < 4:
+            continue
+        codes, _ = h.get_list(key)
+        # (fvec_L2sqr / fvec_inner_product are symmetric in their arguments, element by element: each code against the one query)
+        od = oracle.knn(case["metric"], codes, case["xq"][i][None, :], 1)[0][:, 0]
+        radius = float(np.sort(od)[sz // 3 if is_l2 else sz - sz // 3])
+        a, b = sz // 4, sz - 1
+        pos, dis = h.scan_codes_range(case["xq"][i], key, a, b - a, radius)
+        want = np.nonzero(od[a:b] < radius if is_l2 else od[a:b] > radius)[0]
+        assert np.array_equal(pos, want.astype(np.uint32))
+        assert np.array_equal(bits(dis), bits(od[a:b][want]))
+        pos0, _ = h.scan_codes_range(case["xq"][i], key, 0, 0, radius)
+        assert len(pos0) == 0
+
+
 @pytest.mark.parametrize("name", ["fixed_sift_l2", "fixed_ragged", "fixed_dups"])
 def test_add_builds_reference_lists(capi, name):
     """IndexIVFFlat::add_core: nearest-centroid assignment + append in input order"""

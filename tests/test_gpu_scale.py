@@ -249,3 +249,105 @@ def test_config3_full_size_ip_k100(setup):
 def test_config5_full_size_d960(setup):
     """BASELINE config 5 at its own size: 1M x 960 (GIST-like), IVF4096, k = 10, nprobe 32, 5000 queries per call"""
     _full_size_case(setup, "gist", 1_000_000, 5000, 1, 10, 32)
+
+
+@pytest.mark.parametrize("byte_codes", [True, False])
+@pytest.mark.parametrize("cen_step", [0.0, 0.25])
+def test_config2_shape_six_searches_in_flight(setup, byte_codes, cen_step):
+    """BASELINE config 2 -- the headline -- at its own shape and in the configuration bench.py times: 1M x 128 uint8-valued vectors,
+    IVF4096 (k-means on the device), four resident slices of 2000 queries, coarse_ties = 2, amd_ivf_set_async_depth(6) and 24
+    submits from one caller.  The engine picks other kernels for a search among others than for a search alone (row lists, eager tie
+    replay, split first selection: ivf_engine.hip active_searches), so EVERY in-flight result is compared with the synchronous (alone)
+    result of its slice, and both with the pinned oracle on 64 sampled queries.  cen_step 0.25: centroids rounded to quarters, so that
+    runs of bit-equal coarse distances -- the heap-order patch of the pass under way -- are common instead of rare."""
+    import os
+    import sys
+    import torch
+    capi, orc = setup["capi"], setup["orc"]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    dev = torch.device("cuda", 0)
+    nb, d, nlist, K, topk, ts, ses, nsl = 1_000_000, 128, 4096, 100, 10, 1000, 2000, 4
+    xb_t, _, draw = bench.gen_data(torch, dev, nb, 0, d, 2000, 38.0, 4242)
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    xq = draw(ts + nsl * ses, g).cpu().numpy()
+    xb = xb_t.cpu().numpy()
+    del xb_t
+    torch.cuda.empty_cache()
+    cen, _ = capi.kmeans(capi.METRIC_L2, xb, nlist, niter=10, coarse_mode=0, device=0)
+    if cen_step:
+        cen = (np.round(cen / cen_step) * cen_step).astype(np.float32)
+    h = capi.Handle(d, nlist, capi.METRIC_L2, 0)
+    h.set_centroids(cen)
+    h.add(xb)
+    del xb
+    h.set_interdis(None)
+    h.set_queries(xq)
+    h.set_option("coarse_ties", 2)
+    h.set_byte_codes(byte_codes)
+    nall = ts + nsl * ses
+    gt_all = np.zeros((nall, K), dtype=np.float32)
+    gt_all[:ts] = h.search(xq[:ts], K, nlist)[0]  # exhaustive = exact
+    ntr = 0
+    while (1 << ntr) <= nlist // 8:
+        ntr += 1
+    raw = [np.full((ts * (K // 4), 2), -1, dtype=np.float32) for _ in range(ntr)]
+    h.train_samples(0, ts, K, gt_all, ts, raw)
+    traces = [capi.trace_sb(r) for r in raw]
+    h.set_tuner(K, traces, capi.arcos_table())
+    req = np.full(nall, 0.95, dtype=np.float32)
+    mult, sm = 1.0, 0.5
+
+    # alone: one synchronous call per slice
+    alone, patched = {}, 0
+    for sl in range(nsl):
+        np_ = np.zeros(nall, dtype=np.uint64)
+        tr_ = np.zeros(nall, dtype=np.float32)
+        D, I = h.search_adaptive(ts + sl * ses, ses, topk, mult, sm, req, np_, tr_)
+        alone[sl] = (D.copy(), I.copy(), np_[ts + sl * ses:ts + (sl + 1) * ses].copy())
+        patched += h.last_tie_patched()
+    assert h.scan_arith() == (2 if byte_codes else 1)
+    # the pinned oracle on 16 queries of every slice (spread over it)
+    lists = _oracle_lists(orc, h, 1, cen, nlist, d)
+    tun = orc.Tuner(h.get_interdis(), traces, K, nall, arcos=capi.arcos_table())
+    st = tun.struct(topk, req, mult, sm)
+    for sl in range(nsl):
+        pick = np.linspace(0, ses - 1, 16).astype(np.int64)
+        for p in pick:  # (one query per oracle call: `offset` is the absolute id of the call's first query)
+            q = ts + sl * ses + int(p)
+            cd, ck = orc.knn(1, xq[q:q + 1], cen, nlist, nthreads=8)
+            oD, oI, _ = orc.search_preassigned(lists, xq[q:q + 1], K, ck, cd, tuner=st, offset=q, nthreads=1)
+            assert np.array_equal(alone[sl][1][p], oI[0]) and np.array_equal(alone[sl][0][p].view(np.uint32), oD[0].view(np.uint32)), (sl, p)
+            assert int(tun.my_nprobe[q]) == int(alone[sl][2][p]), (sl, p)
+    # six in flight, 24 submits, twelve tickets out (as bench.py's runner)
+    h.set_async_depth(6)
+    pend, checked = [], 0
+
+    def finish():
+        nonlocal checked
+        t, sl, np_ = pend.pop(0)
+        D, I, _, _ = h.wait(t)
+        aD, aI, anp = alone[sl]
+        assert np.array_equal(I, aI), f"slice {sl}: ids differ from the synchronous result"
+        assert np.array_equal(D.view(np.uint32), aD.view(np.uint32)), f"slice {sl}: distances differ"
+        assert np.array_equal(np_[ts + sl * ses:ts + (sl + 1) * ses], anp), f"slice {sl}: my_nprobe differs"
+        checked += 1
+
+    for sn in range(24):
+        if len(pend) == 12:
+            finish()
+        sl = sn % nsl
+        np_ = np.zeros(nall, dtype=np.uint64)
+        tr_ = np.zeros(nall, dtype=np.float32)
+        pend.append((h.submit_adaptive(ts + sl * ses, ses, topk, mult, sm, req, np_, tr_), sl, np_))
+    while pend:
+        finish()
+    assert checked == 24
+    print(f"config-2 shape, byte codes {byte_codes}, centroid step {cen_step}: rankings the heap changed (4 slices alone) {patched}, "
+          f"my_nprobe mean {np.mean([a[2].mean() for a in alone.values()]):.1f}")
+    if cen_step:
+        assert patched > 0  # (the tie path was exercised)
+    h.set_async_depth(0)
+    h.close()

@@ -18,7 +18,7 @@ def driver(tmp_path_factory):
     build.build_host()
     exe = str(tmp_path_factory.mktemp("drv") / "host_mirror_driver")
     subprocess.run(["g++", "-std=c++17", "-O1", DRIVER_SRC, "-o", exe, "-L" + build.LIBDIR, "-lfaiss_amd", "-launcel_amd",
-                    "-Wl,-rpath," + build.LIBDIR], check=True)
+                    "-Wl,-rpath," + build.LIBDIR, "-pthread"], check=True)
     return exe
 
 
@@ -89,7 +89,7 @@ def test_index_io_bytes(tmp_path, name):
     build.build_host()
     exe = str(tmp_path / "index_io_driver")
     subprocess.run(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "cpp", "index_io_driver.cpp"), "-o", exe, "-L" + build.LIBDIR,
-                    "-lfaiss_amd", "-launcel_amd", "-Wl,-rpath," + build.LIBDIR], check=True)
+                    "-lfaiss_amd", "-launcel_amd", "-Wl,-rpath," + build.LIBDIR, "-pthread"], check=True)
     case, gold = load_case(name)
     t = {k: v for k, v in case.items() if k != "kind"}
     t.update({k: v for k, v in gold.items() if k != "input_sha"})
