@@ -25,7 +25,8 @@ SYMBOLS = [
     "amd_ivf_set_tuner", "amd_ivf_search_adaptive", "amd_ivf_search_adaptive_x", "amd_ivf_search_adaptive_pre", "amd_ivf_search_timed", "amd_ivf_search_timed_x",
     "amd_ivf_train_samples",
     "amd_ivf_train_samples_x", "amd_ivf_train_samples_pre", "amd_ivf_trace_sb", "amd_ivf_arcos_table", "amd_ivf_merge_tables",
-    "amd_ivf_last_timing", "amd_ivf_last_timing_detail", "amd_ivf_last_scan_min_bytes", "amd_ivf_coarse_tie_rows", "amd_ivf_last_tie_fixed", "amd_ivf_last_filter", "amd_ivf_last_direct_out", "amd_ivf_last_coarse_pick", "amd_ivf_set_async_depth", "amd_ivf_submit_adaptive", "amd_ivf_submit_search_resident", "amd_ivf_wait", "amd_ivf_last_tie_redone", "amd_ivf_last_tie_patched", "amd_ivf_self_check", "amd_ivf_last_round_hints", "amd_ivf_set_byte_codes", "amd_ivf_set_option", "amd_ivf_get_option",
+    "amd_ivf_last_timing", "amd_ivf_last_timing_detail", "amd_ivf_last_scan_min_bytes", "amd_ivf_coarse_tie_rows", "amd_ivf_last_tie_fixed", "amd_ivf_last_filter", "amd_ivf_last_direct_out", "amd_ivf_last_coarse_pick", "amd_ivf_set_async_depth", "amd_ivf_submit_adaptive", "amd_ivf_submit_search_resident", "amd_ivf_submit_coarse_resident",
+    "amd_ivf_submit_search_resident_preassigned", "amd_ivf_wait", "amd_ivf_last_tie_redone", "amd_ivf_last_tie_patched", "amd_ivf_self_check", "amd_ivf_last_round_hints", "amd_ivf_set_byte_codes", "amd_ivf_set_option", "amd_ivf_get_option",
     "amd_ivf_kmeans",
     "amd_ivf_range_search_preassigned", "amd_ivf_range_search", "amd_ivf_range_results",
     "amd_ivf_scan_arith",
@@ -465,6 +466,35 @@ class Handle:
         if not hasattr(self, "_tickets"):
             self._tickets = {}
         self._tickets[int(t.value)] = (None, None, None, None, D, I)
+        return int(t.value)
+
+    def submit_coarse_resident(self, start, n, nprobe, mode=0, want_dis=False):
+        """asynchronous coarse_resident: wait() returns (coarse_dis or None, keys) in place of (D, I)"""
+        keys = np.empty((n, nprobe), np.int64)
+        dis = np.empty((n, nprobe), np.float32) if want_dis else None
+        t = C.c_uint64(0)
+        _chk(lib().amd_ivf_submit_coarse_resident(self._h, C.c_size_t(start), C.c_size_t(n), C.c_size_t(nprobe), _f(dis), _i(keys), mode,
+                                                  C.byref(t)))
+        if not hasattr(self, "_tickets"):
+            self._tickets = {}
+        self._tickets[int(t.value)] = (None, None, None, None, dis, keys)
+        return int(t.value)
+
+    def submit_search_resident_preassigned(self, start, n, k, keys, out=None):
+        """asynchronous search_resident_preassigned (keys: n x nprobe, kept alive until wait())"""
+        keys = i64(keys)
+        assert keys.shape[0] == n
+        if out is not None:
+            D, I = out
+        else:
+            D = np.empty((n, k), np.float32)
+            I = np.empty((n, k), np.int64)
+        t = C.c_uint64(0)
+        _chk(lib().amd_ivf_submit_search_resident_preassigned(self._h, C.c_size_t(start), C.c_size_t(n), C.c_size_t(k), C.c_size_t(keys.shape[1]),
+                                                              _i(keys), _f(D), _i(I), C.byref(t)))
+        if not hasattr(self, "_tickets"):
+            self._tickets = {}
+        self._tickets[int(t.value)] = (keys, None, None, None, D, I)
         return int(t.value)
 
     def wait(self, ticket):

@@ -1,6 +1,7 @@
 // faiss::RangeSearchResult as the Auncel tree declares it (Auncel/AuxIndexStructures.h:31-50).
 #pragma once
 #include <cstddef>
+#include <unordered_set>
 #include <vector>
 
 #include "Index.h"
@@ -25,6 +26,25 @@ struct RangeSearchResult {
     virtual void do_allocation();
 
     virtual ~RangeSearchResult();
+};
+
+/// which ids an operation applies to (Auncel/AuxIndexStructures.h:54-90): remove_ids takes one
+struct IDSelector {
+    typedef Index::idx_t idx_t;
+    virtual bool is_member(idx_t id) const = 0;
+    virtual ~IDSelector() {}
+};
+/// ids in [imin, imax)
+struct IDSelectorRange : IDSelector {
+    idx_t imin, imax;
+    IDSelectorRange(idx_t imin, idx_t imax) : imin(imin), imax(imax) {}
+    bool is_member(idx_t id) const override { return id >= imin && id < imax; }
+};
+/// ids of a set
+struct IDSelectorBatch : IDSelector {
+    std::unordered_set<idx_t> set;
+    IDSelectorBatch(long n, const idx_t* indices) : set(indices, indices + n) {}
+    bool is_member(idx_t id) const override { return set.count(id) != 0; }
 };
 
 /// Blocks of (id, distance) results that grow without moving (Auncel/AuxIndexStructures.h:104-132): what the scanners' range

@@ -16,6 +16,7 @@ enum MetricType { METRIC_INNER_PRODUCT = 0, METRIC_L2 = 1 };
 typedef enum IndexType { IVF, HNSW, OTHER } IndexType;
 
 struct RangeSearchResult;
+struct IDSelector;
 
 struct Index {
     using idx_t = long;
@@ -52,6 +53,8 @@ struct Index {
     /// all vectors within `radius` of each query (Index.h:106-117); only the IVF classes implement it here
     virtual void range_search(idx_t n, const float* x, float radius, RangeSearchResult* result) const;
     virtual void reset() = 0;
+    /// removes the ids the selector names, returns how many (Index.h:159-162); only the IVF classes implement it here
+    virtual long remove_ids(const IDSelector& sel);
     /// stored vector of one id / a range of ids, search + stored vectors of the results (Index.h:119-157); only the IVF
     /// classes implement them here
     virtual void reconstruct(idx_t key, float* recons) const;

@@ -97,6 +97,15 @@ struct IndexIVF : Index, Level1Quantizer {
 
     virtual InvertedListScanner* get_InvertedListScanner(bool store_pairs = false) const;
 
+    /// IndexIVF.cpp:955-987
+    long remove_ids(const IDSelector& sel) override;
+    /// A subset of the entries copied into `other` (same nlist and code size).  subset_type 0: ids in [a1, a2); 1: ids with
+    /// id % a1 == a2; 2: the a1-th to a2-th entry of ntotal, cut list by list (IndexIVF.cpp:1055-1117, what the reference's
+    /// GpuAutoTune shards an IVF index with: by VECTOR).  Two more cut by LIST, whole lists with their ids -- the shards north_star
+    /// names, every probed list on exactly one GPU: 3: lists with list_no % a1 == a2; 4: lists whose owner among a1 shards is a2,
+    /// owners balanced by list bytes (ivf_list_owners below).
+    void copy_subset_to(IndexIVF& other, int subset_type, idx_t a1, idx_t a2) const;
+
     size_t get_list_size(size_t list_no) const { return invlists->list_size(list_no); }
     void replace_invlists(InvertedLists* il, bool own = false);
 
@@ -136,6 +145,10 @@ struct InvertedListScanner {
     virtual void scan_codes_range(size_t n, const uint8_t* codes, const idx_t* ids, float radius, RangeQueryResult& result) const;
     virtual ~InvertedListScanner() {}
 };
+
+/// owner[l] in [0, nshard) for every list: longest list first onto the least loaded shard (deterministic; the rule
+/// auncel_amd/sharding.py:assign_owners and bench.py --mode shards use)
+std::vector<int> ivf_list_owners(const IndexIVF& index, int nshard);
 
 struct IndexIVFStats {
     size_t nq, nlist, ndis, nheap_updates;

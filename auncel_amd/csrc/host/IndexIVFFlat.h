@@ -17,8 +17,8 @@ struct IndexIVFFlat : IndexIVF {
 };
 
 /// faiss::IndexIVFFlatDedup (Auncel/IndexIVFFlat.h:62-107): equal vectors are stored once; `instances` maps the id that
-/// is stored to the ids of its copies, and search results are expanded from it on the host.  remove_ids / update_vectors /
-/// range_search / reconstruct_from_offset are not provided (the last three are "not implemented" in the reference too).
+/// is stored to the ids of its copies, and search results are expanded from it on the host.  update_vectors / range_search /
+/// reconstruct_from_offset are "not implemented" in the reference too.
 struct IndexIVFFlatDedup : IndexIVFFlat {
     std::unordered_multimap<idx_t, idx_t> instances;
 
@@ -32,6 +32,7 @@ struct IndexIVFFlatDedup : IndexIVFFlat {
                             idx_t* labels, bool store_pairs, const IVFSearchParameters* params = nullptr) const override;
     void range_search(idx_t n, const float* x, float radius, RangeSearchResult* result) const override;
     void reconstruct_from_offset(idx_t list_no, idx_t offset, float* recons) const override;
+    long remove_ids(const IDSelector& sel) override;  ///< IndexIVFFlat.cpp:381-448
 
    private:
     void expand_instances(idx_t n, idx_t k, float* distances, idx_t* labels) const;

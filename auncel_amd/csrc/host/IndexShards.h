@@ -23,4 +23,15 @@ struct IndexShards : Index {
     void reset() override;
 };
 
+struct IndexIVFFlat;
+/// `index` cut into `nshard` IndexIVFFlat sub-indexes BY LIST (IndexIVF::copy_subset_to type 4: byte-balanced owners) that share its
+/// quantizer and keep its ids, under an IndexShards(successive_ids = false) that owns them: the list-id shards of north_star /
+/// BASELINE config 4 for a C++ caller.  The reference's analogue cuts by vector (gpu/GpuAutoTune.cpp:201-221, copy_subset_to 1 / 2).
+/// Shard i goes to GPU i % (GPUs of the node) unless `devices` says otherwise.
+struct IndexShardsByList : IndexShards {
+    std::vector<IndexIVFFlat*> owned;
+    IndexShardsByList(const IndexIVFFlat& index, int nshard, bool threaded = true, const int* devices = nullptr);
+    ~IndexShardsByList() override;
+};
+
 }  // namespace faiss

@@ -24,6 +24,10 @@ struct InvertedLists {
     virtual size_t add_entries(size_t list_no, size_t n_entry, const idx_t* ids, const uint8_t* code) = 0;
     virtual size_t add_entry(size_t list_no, idx_t theid, const uint8_t* code) { return add_entries(list_no, 1, &theid, code); }
     virtual void resize(size_t list_no, size_t new_size) = 0;
+    /// one stored id / entries overwritten in place (InvertedLists.h:66,88-93)
+    virtual idx_t get_single_id(size_t list_no, size_t offset) const { return get_ids(list_no)[offset]; }
+    virtual void update_entries(size_t list_no, size_t offset, size_t n_entry, const idx_t* ids, const uint8_t* code) = 0;
+    virtual void update_entry(size_t list_no, size_t offset, idx_t id, const uint8_t* code) { update_entries(list_no, offset, 1, &id, code); }
     virtual void reset() {
         for (size_t i = 0; i < nlist; i++) resize(i, 0);
     }
@@ -60,6 +64,7 @@ struct ArrayInvertedLists : InvertedLists {
     const idx_t* get_ids(size_t list_no) const override { return ids[list_no].data(); }
     size_t add_entries(size_t list_no, size_t n_entry, const idx_t* ids_in, const uint8_t* code) override;
     void resize(size_t list_no, size_t new_size) override;
+    void update_entries(size_t list_no, size_t offset, size_t n_entry, const idx_t* ids_in, const uint8_t* code) override;
 };
 
 }  // namespace faiss

@@ -58,6 +58,7 @@ inline const int64_t* i64(const long* p) { return reinterpret_cast<const int64_t
 
 // ------------------------------------------------------------------------------------- Index
 void Index::add_with_ids(idx_t, const float*, const long*) { FAISS_THROW_MSG("add_with_ids not implemented for this type of index"); }
+long Index::remove_ids(const IDSelector&) { FAISS_THROW_MSG("remove_ids not implemented for this type of index"); }
 
 void Index::assign(idx_t n, const float* x, idx_t* labels, idx_t k) {
     std::vector<float> dis(n * k);
@@ -107,6 +108,13 @@ size_t ArrayInvertedLists::add_entries(size_t list_no, size_t n_entry, const idx
     codes[list_no].insert(codes[list_no].end(), code, code + n_entry * code_size);
     version++;
     return o;
+}
+
+void ArrayInvertedLists::update_entries(size_t list_no, size_t offset, size_t n_entry, const idx_t* ids_in, const uint8_t* code) {
+    FAISS_THROW_IF_NOT(list_no < nlist && offset + n_entry <= ids[list_no].size());
+    memcpy(ids[list_no].data() + offset, ids_in, n_entry * sizeof(idx_t));
+    memmove(codes[list_no].data() + offset * code_size, code, n_entry * code_size);  // (an entry may be moved within its own list)
+    version++;
 }
 
 void ArrayInvertedLists::resize(size_t list_no, size_t new_size) {
@@ -1060,6 +1068,146 @@ void IndexIVFFlatDedup::search_preassigned(idx_t n, const float* x, idx_t k, con
     FAISS_THROW_IF_NOT_MSG(!store_pairs, "store_pairs not supported in IVFDedup");
     IndexIVFFlat::search_preassigned(n, x, k, assign, centroid_dis, distances, labels, false, params);
     expand_instances(n, k & 0xffffffff, distances, labels);
+}
+
+// Removal (IndexIVF.cpp:955-987): a removed entry's place is taken by the list's last entry, list by list; the lists in HBM are
+// refreshed before the next search (the version counter of the inverted lists).
+long IndexIVF::remove_ids(const IDSelector& sel) {
+    FAISS_THROW_IF_NOT_MSG(!maintain_direct_map, "direct map remove not implemented");
+    long nremove = 0;
+    for (size_t l = 0; l < nlist; l++) {
+        size_t len = invlists->list_size(l), j = 0;
+        const size_t len0 = len;
+        while (j < len) {
+            if (sel.is_member(invlists->get_single_id(l, j))) {
+                len--;
+                invlists->update_entry(l, j, invlists->get_single_id(l, len), invlists->get_codes(l) + len * code_size);
+            } else {
+                j++;
+            }
+        }
+        if (len != len0) invlists->resize(l, len);
+        nremove += (long)(len0 - len);
+    }
+    ntotal -= nremove;
+    return nremove;
+}
+
+// IndexIVFFlat.cpp:381-448: a removed id that stands for copies hands its entry to the first surviving copy (and that copy's
+// remaining twins are re-keyed to it); only an entry without a surviving copy leaves its list
+long IndexIVFFlatDedup::remove_ids(const IDSelector& sel) {
+    std::unordered_map<idx_t, idx_t> heir;
+    std::vector<std::pair<idx_t, idx_t>> rekeyed;
+    for (auto it = instances.begin(); it != instances.end();) {
+        const bool head_goes = sel.is_member(it->first), copy_goes = sel.is_member(it->second);
+        if (head_goes && !copy_goes) {
+            auto h = heir.find(it->first);
+            if (h == heir.end()) heir[it->first] = it->second;
+            else rekeyed.emplace_back(h->second, it->second);
+        }
+        if (head_goes || copy_goes) it = instances.erase(it);
+        else ++it;
+    }
+    instances.insert(rekeyed.begin(), rekeyed.end());
+    FAISS_THROW_IF_NOT_MSG(!maintain_direct_map, "direct map remove not implemented");
+    long nremove = 0;
+    for (size_t l = 0; l < nlist; l++) {
+        size_t len = invlists->list_size(l), j = 0;
+        const size_t len0 = len;
+        while (j < len) {
+            const idx_t id = invlists->get_single_id(l, j);
+            if (!sel.is_member(id)) {
+                j++;
+                continue;
+            }
+            auto h = heir.find(id);
+            if (h == heir.end()) {
+                len--;
+                invlists->update_entry(l, j, invlists->get_single_id(l, len), invlists->get_codes(l) + len * code_size);
+            } else {
+                invlists->update_entry(l, j, h->second, invlists->get_codes(l) + j * code_size);
+                j++;
+            }
+        }
+        if (len != len0) invlists->resize(l, len);
+        nremove += (long)(len0 - len);
+    }
+    ntotal -= nremove;
+    return nremove;
+}
+
+std::vector<int> ivf_list_owners(const IndexIVF& index, int nshard) {
+    FAISS_THROW_IF_NOT(nshard > 0);
+    std::vector<size_t> order(index.nlist);
+    for (size_t l = 0; l < index.nlist; l++) order[l] = l;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return index.invlists->list_size(a) > index.invlists->list_size(b); });
+    std::vector<size_t> load((size_t)nshard, 0);
+    std::vector<int> owner(index.nlist, 0);
+    for (size_t l : order) {
+        const size_t r = (size_t)(std::min_element(load.begin(), load.end()) - load.begin());
+        owner[l] = (int)r;
+        load[r] += index.invlists->list_size(l);
+    }
+    return owner;
+}
+
+void IndexIVF::copy_subset_to(IndexIVF& other, int subset_type, idx_t a1, idx_t a2) const {
+    FAISS_THROW_IF_NOT(nlist == other.nlist);
+    FAISS_THROW_IF_NOT(code_size == other.code_size);
+    FAISS_THROW_IF_NOT(!other.maintain_direct_map);
+    FAISS_THROW_IF_NOT_FMT(subset_type >= 0 && subset_type <= 4, "subset type %d not implemented", subset_type);
+    std::vector<int> owner;
+    if (subset_type == 4) owner = ivf_list_owners(*this, (int)a1);
+    size_t seen = 0, cut1 = 0, cut2 = 0;  // (type 2: entries met so far, and how many of them lie before a1 / before a2)
+    for (size_t l = 0; l < nlist; l++) {
+        const size_t n = invlists->list_size(l);
+        const idx_t* ids = invlists->get_ids(l);
+        const uint8_t* codes = invlists->get_codes(l);
+        size_t i0 = 0, i1 = 0;  // a contiguous run of the list (types 2, 3, 4)
+        if (subset_type == 0 || subset_type == 1) {
+            for (size_t i = 0; i < n; i++) {
+                const bool take = subset_type == 0 ? (a1 <= ids[i] && ids[i] < a2) : (ids[i] % a1 == a2);
+                if (!take) continue;
+                other.invlists->add_entry(l, ids[i], codes + i * code_size);
+                other.ntotal++;
+            }
+        } else if (subset_type == 2) {
+            const size_t next = seen + n, n1 = next * (size_t)a1 / (size_t)ntotal, n2 = next * (size_t)a2 / (size_t)ntotal;
+            i0 = n1 - cut1;
+            i1 = n2 - cut2;
+            cut1 = n1;
+            cut2 = n2;
+        } else if (subset_type == 3 ? (idx_t)l % a1 == a2 : owner[l] == (int)a2) {
+            i1 = n;
+        }
+        if (i1 > i0) {
+            other.invlists->add_entries(l, i1 - i0, ids + i0, codes + i0 * code_size);
+            other.ntotal += (idx_t)(i1 - i0);
+        }
+        seen += n;
+    }
+    FAISS_THROW_IF_NOT(seen == (size_t)ntotal);
+}
+
+IndexShardsByList::IndexShardsByList(const IndexIVFFlat& index, int nshard, bool threaded_, const int* devices)
+    : IndexShards((idx_t)index.d, threaded_, false) {
+    FAISS_THROW_IF_NOT(nshard > 0 && index.is_trained);
+    for (int s = 0; s < nshard; s++) {
+        IndexIVFFlat* sub = new IndexIVFFlat(index.quantizer, (size_t)index.d, index.nlist, index.metric_type);
+        owned.push_back(sub);
+        sub->is_trained = true;
+        sub->nprobe = index.nprobe;
+        sub->max_codes = index.max_codes;
+        sub->coarse_mode = index.coarse_mode;
+        index.copy_subset_to(*sub, 4, nshard, s);
+        if (devices) sub->set_device(devices[s]);
+        add_shard(sub);
+    }
+    FAISS_THROW_IF_NOT(ntotal == index.ntotal);
+}
+
+IndexShardsByList::~IndexShardsByList() {
+    for (IndexIVFFlat* s : owned) delete s;
 }
 
 void IndexIVFFlatDedup::range_search(idx_t, const float*, float, RangeSearchResult*) const { FAISS_THROW_MSG("not implemented"); }

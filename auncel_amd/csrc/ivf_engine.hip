@@ -3289,15 +3289,17 @@ int amd_ivf_coarse(amd_ivf_t* h, size_t n, const float* x, size_t nprobe, float*
 int amd_ivf_coarse_resident(amd_ivf_t* h, size_t start, size_t n, size_t nprobe, float* coarse_dis, int64_t* keys, int mode) {
     API_BEGIN
     use_device(h);
-    if (start + n > h->n_resident) throw EngineError("resident query range out of bounds");
+    // (a search context without resident queries of its own ranks its owner's: amd_ivf_submit_coarse_resident's contexts)
+    const amd_ivf* src = h->is_clone && h->n_resident == 0 && h->parent ? h->parent : h;
+    if (start + n > src->n_resident) throw EngineError("resident query range out of bounds");
     if (n == 0) return 0;
     WallClock wc(h->stream);
     h->scan_bytes = h->scan_min_bytes = h->scan_min_bytes_thr = 0;
     h->scan_slots = h->scan_useful = 0;
     h->w_cdis.ensure(n * nprobe * 4);
     h->w_ckeys.ensure(n * nprobe * 8);
-    coarse_dev(h, h->d_resident.as<float>() + start * h->dpad, n, nprobe, mode, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>(),
-               h->allow_fused && ix(h)->centroid_range.fusable_with(h->resident_range, h->metric));
+    coarse_dev(h, src->d_resident.as<float>() + start * h->dpad, n, nprobe, mode, h->w_cdis.as<float>(), h->w_ckeys.as<int64_t>(),
+               h->allow_fused && ix(h)->centroid_range.fusable_with(src->resident_range, h->metric));
     if (coarse_dis) HIP_CHECK(hipMemcpyAsync(coarse_dis, h->w_cdis.p, n * nprobe * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipMemcpyAsync(keys, h->w_ckeys.p, n * nprobe * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(stream_sync(h->stream));
@@ -3450,7 +3452,8 @@ int amd_ivf_search_resident_preassigned(amd_ivf_t* h, size_t start, size_t n, si
                                         int64_t* I) {
     API_BEGIN
     use_device(h);
-    if (start + n > h->n_resident) throw EngineError("resident query range out of bounds");
+    const amd_ivf* src = h->is_clone && h->n_resident == 0 && h->parent ? h->parent : h;  // (as amd_ivf_search_resident)
+    if (start + n > src->n_resident) throw EngineError("resident query range out of bounds");
     if (n == 0 || k == 0) return 0;
     if (!keys) throw EngineError("keys are required");
     WallClock wc(h->stream);
@@ -3458,7 +3461,7 @@ int amd_ivf_search_resident_preassigned(amd_ivf_t* h, size_t start, size_t n, si
     h->scan_slots = h->scan_useful = 0;
     h->w_ckeys.ensure(n * nprobe * 8);
     HIP_CHECK(hipMemcpyAsync(h->w_ckeys.p, keys, n * nprobe * 8, hipMemcpyHostToDevice, h->stream));
-    search_fixed_device(h, h->d_resident.as<float>() + start * h->dpad, n, k, nprobe, h->w_ckeys.as<int64_t>(), D, I, 0, 0, h->resident_range);
+    search_fixed_device(h, src->d_resident.as<float>() + start * h->dpad, n, k, nprobe, h->w_ckeys.as<int64_t>(), D, I, 0, 0, src->resident_range);
     finish_timing(h, wc.stop());
     API_END
 }
@@ -5035,6 +5038,26 @@ int amd_ivf_submit_search_resident(amd_ivf_t* h, size_t start, size_t n, size_t 
     use_device(h);
     if (start + n > h->n_resident) throw EngineError("resident query range out of bounds");
     *ticket = async_enqueue(h, [=](amd_ivf_t* c) { return amd_ivf_search_resident(c, start, n, k, nprobe, coarse_mode, D, I); });
+    API_END
+}
+
+int amd_ivf_submit_coarse_resident(amd_ivf_t* h, size_t start, size_t n, size_t nprobe, float* coarse_dis, int64_t* keys, int mode,
+                                   uint64_t* ticket) {
+    API_BEGIN
+    OWNER_ONLY(h);
+    use_device(h);
+    if (start + n > h->n_resident) throw EngineError("resident query range out of bounds");
+    *ticket = async_enqueue(h, [=](amd_ivf_t* c) { return amd_ivf_coarse_resident(c, start, n, nprobe, coarse_dis, keys, mode); });
+    API_END
+}
+
+int amd_ivf_submit_search_resident_preassigned(amd_ivf_t* h, size_t start, size_t n, size_t k, size_t nprobe, const int64_t* keys,
+                                               float* D, int64_t* I, uint64_t* ticket) {
+    API_BEGIN
+    OWNER_ONLY(h);
+    use_device(h);
+    if (start + n > h->n_resident) throw EngineError("resident query range out of bounds");
+    *ticket = async_enqueue(h, [=](amd_ivf_t* c) { return amd_ivf_search_resident_preassigned(c, start, n, k, nprobe, keys, D, I); });
     API_END
 }
 

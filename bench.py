@@ -258,40 +258,50 @@ def run_shards(args, torch, dist, capi, rank, world, local, dev, red_dev):
     h.set_queries(xq)
     log(f"shards: data, k-means, assignment, {int(keep.sum())} of {args.nb} vectors on rank 0: {time.time() - t0:.1f}s")
 
-    acc = {}
     counts = [(r + 1) * nq // world - r * nq // world for r in range(world)]
-    q0 = rank * nq // world
-
-    def step():
-        _, ck = h.coarse_resident(q0, counts[rank], args.nprobe, mode=0, want_dis=False)
-        acc["coarse_ms"] = acc.get("coarse_ms", 0.0) + h.last_timing()["coarse_ms"]
-        tx = time.perf_counter()
-        keys = sharding.allgather_rows(ck, counts, dist if world > 1 else None)
-        acc["exchange_ms"] = acc.get("exchange_ms", 0.0) + (time.perf_counter() - tx) * 1e3
-        D, I = h.search_resident_preassigned(0, nq, k, keys)
-        tm = h.last_timing()
-        for key in ("scan_ms", "scan_launches", "scan_min_bytes", "select_ms"):
-            acc[key] = acc.get(key, 0.0) + tm[key]
-        return sharding.gather_and_merge(D, I, capi.METRIC_L2, capi.merge_tables, dist if world > 1 else None)
+    # steps in flight (sharding.run_pipelined): `lag` searches at a time on the engine's internal contexts, the coarse rankings of the
+    # next steps ahead of them, one thread issuing the two collectives in a fixed order, the merge on its own thread on rank 0
+    lag = max(1, args.shard_lag)
+    h.set_async_depth(min(16, lag + 2))
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    acc.clear()
+    def run(nsteps):
+        return sharding.run_pipelined(h, capi.METRIC_L2, capi.merge_tables, nq, k, args.nprobe, counts, rank, dist if world > 1 else None,
+                                      nsteps, lag=lag)
+
+    if args.warmup:
+        run(max(args.warmup, lag + 1))
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    out, acc = run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    h.set_async_depth(0)
     if world > 1:
         t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # the same step one at a time (after the clock, never part of `value`): the kernels alone on the chip -- what the roofline is
+    # quoted on, as in the headline -- and the serial form's step time next to the pipelined one
+    solo = {"coarse_ms": 0.0, "scan_ms": 0.0, "select_ms": 0.0, "scan_launches": 0.0, "scan_min_bytes": 0.0}
+    nsolo = max(2, min(4, args.steps))
+    barrier()
+    ts0 = time.perf_counter()
+    for _ in range(nsolo):
+        _, ck_ = h.coarse_resident(sum(counts[:rank]), counts[rank], args.nprobe, mode=0, want_dis=False)
+        solo["coarse_ms"] += h.last_timing()["coarse_ms"]
+        keys_ = sharding.allgather_rows(ck_, counts, dist if world > 1 else None)
+        Ds, Is = h.search_resident_preassigned(0, nq, k, keys_)
+        tm_ = h.last_timing()
+        for key in ("scan_ms", "scan_launches", "scan_min_bytes", "select_ms"):
+            solo[key] += tm_[key]
+        out_solo = sharding.gather_and_merge(Ds, Is, capi.METRIC_L2, capi.merge_tables, dist if world > 1 else None)
+    barrier()
+    solo_ms = 1e3 * (time.perf_counter() - ts0) / nsolo
     # per-rank kernel times of the timed region (ms per step): what divides by N and what does not
     mine = [acc.get(key, 0.0) / args.steps for key in ("coarse_ms", "exchange_ms", "scan_ms", "select_ms")]
     if world > 1:
@@ -318,9 +328,10 @@ def run_shards(args, torch, dist, capi, rank, world, local, dev, red_dev):
         D, I = out
         rec = recall_dist(D[:nvalid], gtD, k)
         load = np.bincount(owner, weights=sizes, minlength=world)
-        launches = max(acc["scan_launches"], 1)
-        per_launch = acc["scan_min_bytes"] / launches
-        achieved = (per_launch / 1e9) / (acc["scan_ms"] / launches / 1e3) if acc["scan_ms"] > 0 else None
+        launches = max(solo["scan_launches"], 1)
+        per_launch = solo["scan_min_bytes"] / launches
+        achieved = (per_launch / 1e9) / (solo["scan_ms"] / launches / 1e3) if solo["scan_ms"] > 0 else None
+        same_as_serial = bool(np.array_equal(out_solo[0].view(np.uint32), D.view(np.uint32)) and np.array_equal(out_solo[1], I))
         line = {
             "metric": "queries/sec, SIFT-10M d=128 IVF4096 k=10 fixed nprobe, IndexShards (lists sharded by list id, host top-k merge)",
             "value": nq * args.steps / elapsed, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -331,6 +342,9 @@ def run_shards(args, torch, dist, capi, rank, world, local, dev, red_dev):
                        "nb": args.nb, "sigma": args.sigma, "nprobe": args.nprobe, "recall_at_k_mean": float(rec.mean()),
                        "ranks_seen": getattr(args, "ranks_seen", world), "collective_backend": os.environ.get("BENCH_DIST_BACKEND", "nccl") if world > 1 else None,
                        "coarse_queries_per_rank": [int(c) for c in counts],
+                       "steps_in_flight": lag, "steps_merged": int(acc["steps_merged"]),
+                       "pipeline": "sharding.run_pipelined: amd_ivf_submit_coarse_resident / amd_ivf_submit_search_resident_preassigned tickets, one "
+                                   "thread issuing key all-gather and table gather in a fixed order, amd_ivf_merge_tables on its own thread on rank 0",
                        "per_rank_ms_per_step": {"columns": ["coarse (own share of the batch)", "all-gather of the key rows (host wall)", "scan", "select"],
                                                 "rows": per_rank},
                        # distances of the merged result (sorted rows: identical for any number of shards, whatever the order
@@ -341,8 +355,13 @@ def run_shards(args, torch, dist, capi, rank, world, local, dev, red_dev):
             "roofline": {"bound": "hbm", "kernel": "scan_mfma_thr_kernel + scan_mfma_pair_kernel" if h.scan_arith() == 2 else "scan_lanes_kernel", "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0 if achieved else None, "traffic": None,
                          "traffic_source": "engine's lower bound (every probed list once per round + rows written), rank 0's shard",
-                         "min_bytes_per_launch": per_launch, "avg_launch_ms": acc["scan_ms"] / launches, "launches_per_step": launches / args.steps,
-                         "other_kernels_ms_per_step": {"coarse": acc["coarse_ms"] / args.steps, "select": acc["select_ms"] / args.steps}},
+                         "measured": "one step at a time, same run, after the timed region",
+                         "min_bytes_per_launch": per_launch, "avg_launch_ms": solo["scan_ms"] / launches, "launches_per_step": launches / nsolo,
+                         "other_kernels_ms_per_step": {"coarse": solo["coarse_ms"] / nsolo, "select": solo["select_ms"] / nsolo},
+                         "in_flight": {"steps": lag, "avg_launch_ms": acc["scan_ms"] / max(acc["scan_launches"], 1),
+                                       "coarse_ms_per_step": acc["coarse_ms"] / args.steps, "select_ms_per_step": acc["select_ms"] / args.steps,
+                                       "merge_ms_per_step": acc["merge_ms"] / max(acc["steps_merged"], 1)}},
+            "one_step_at_a_time": {"ms_per_step": solo_ms, "value": nq / solo_ms * 1e3, "unit": "queries/s", "same_results_as_pipelined": same_as_serial},
         }
         if world == 1 and not args.no_cpu:
             # CPU side: the pinned restatement of IndexIVF::search (coarse + search_preassigned) on a bounded sample, all host cores
@@ -367,6 +386,20 @@ def run_shards(args, torch, dist, capi, rank, world, local, dev, red_dev):
             line["cpu_baseline"] = {"value": S / cpu_s, "unit": "queries/s", "cores": cores, "kind": "port",
                                     "sample": f"first {S} of the {nq} queries, same lists, coarse + search_preassigned, OpenMP over queries",
                                     "gpu_matches_cpu_on_sample": bool(np.array_equal(oI, I[:S]) and np.array_equal(oD, D[:S]))}
+            # the compiled reference itself where its harness travelled (oracle/_ref/ref_harness fixedbench: IndexIVF::search, one query per
+            # call, OpenMP over queries -- the same lists, centroids and queries)
+            from oracle import refbench
+            if refbench.available() and not args.no_ref:
+                try:
+                    ro = refbench.run_fixed(pyoracle.METRIC_L2, cen, lists.off, lists.codes, lists.ids, xq[:S], k, args.nprobe, threads=cores)
+                    port = line["cpu_baseline"]
+                    line["cpu_baseline"] = {"value": S / ro["seconds_all_threads"], "unit": "queries/s", "cores": ro["threads"], "kind": "reference",
+                                            "sample": f"first {S} of the {nq} queries: the compiled reference (Auncel/*.cpp, -O3 -msse4) on the engine's lists and "
+                                                      "centroids, IndexIVF::search(1, ...) per query at the same nprobe, OpenMP over queries",
+                                            "gpu_matches_cpu_on_sample": bool(np.array_equal(ro["I"], I[:S]) and np.array_equal(ro["D"].view(np.uint32), D[:S].view(np.uint32))),
+                                            "port": port}
+                except Exception as e:  # noqa: BLE001 -- the port's figures stay
+                    log("reference harness not usable here:", repr(e))
     del h
     torch.cuda.empty_cache()
     if line is not None and single_sha is not None and single_sha != line["config"]["distances_sha256"]:
@@ -398,6 +431,7 @@ def main():
                     help="adaptive: BASELINE config 2, the headline (replicas at N > 1).  shards: config 4 -- fixed nprobe, the inverted "
                          "lists sharded by list id over the N GPUs (IndexShards), per-GPU partial top-k merged on the host; strong scaling")
     ap.add_argument("--nprobe", type=int, default=32, help="--mode shards: probes per query")
+    ap.add_argument("--shard-lag", type=int, default=4, help="--mode shards: steps in flight (searches on the GPU while earlier steps' tables are gathered and merged)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-legs", action="store_true",
                     help="skip the untimed extra legs (one batch at a time, fp32 path, guaranteed-bound point): profiling runs")

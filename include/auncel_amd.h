@@ -335,6 +335,13 @@ int amd_ivf_submit_adaptive(amd_ivf_t* h, size_t start, size_t n, size_t query_t
 /* the same for amd_ivf_search_resident (IndexIVF::search with a fixed nprobe over resident queries [start, start + n)) */
 int amd_ivf_submit_search_resident(amd_ivf_t* h, size_t start, size_t n, size_t k, size_t nprobe, int coarse_mode, float* D, int64_t* I,
                                    uint64_t* ticket);
+/* ... and the two halves of a sharded search (IndexShards over sub-indexes that share one quantizer, IndexShards.cpp:261-311): the
+ * coarse ranking of a share of the resident queries, and search_preassigned of a resident range with keys that came from elsewhere
+ * (the other shards' ranks).  `keys` / `coarse_dis` / `D` / `I` must stay valid until amd_ivf_wait returns the ticket. */
+int amd_ivf_submit_coarse_resident(amd_ivf_t* h, size_t start, size_t n, size_t nprobe, float* coarse_dis, int64_t* keys, int mode,
+                                   uint64_t* ticket);
+int amd_ivf_submit_search_resident_preassigned(amd_ivf_t* h, size_t start, size_t n, size_t k, size_t nprobe, const int64_t* keys,
+                                               float* D, int64_t* I, uint64_t* ticket);
 int amd_ivf_wait(amd_ivf_t* h, uint64_t ticket, double timing[9], uint64_t diag[4]);
 
 /* Arithmetic the list scan of the last search ran in.  All three produce the reference's fp32 distance bit for

@@ -226,10 +226,80 @@ __device__ inline void heapsort_v4(HeapEnt* a, uint32_t n, uint32_t* out_id, int
     }
 }
 
+// ---- v5 (round 6): one kind of walker step without bounds tests, and the start decision taken a tick ahead.
+//  * Sentinels instead of bounds: every slot outside the heap holds -inf (the slot a pop takes its entry from is overwritten with it
+//    at once; slots n + 1 .. n + 3 hold it from the start), so "a single child", "no child" and "past the array" are what the value
+//    compares give by themselves: a missing child loses against any entry, and an entry that meets two missing children ends its walk.
+//    The children of a hole beyond n / 2 are read from the pair (n + 2, n + 3).
+//  * Lanes without a walk carry +inf on hole 0: they read pair 0, never move, and write slot 0 (unused).
+//  * Whether pop t + 1 may start is decided at the END of the tick before (the holes it depends on are final then), in the shadow of
+//    that tick's store, instead of between the tick's load and its use.
+//  * depth from the hole itself (no level register); the popped root's id is read a tick later from where the step left it.
+__device__ __forceinline__ void walk_step5(uint2* a2w, const uint4* a4, uint32_t& hole, float Lv, uint32_t Lid, uint32_t P) {
+    const uint32_t pr = hole < P ? hole : P;
+    const uint4 ch = a4[pr];
+    const float c1v = __uint_as_float(ch.x), c2v = __uint_as_float(ch.z);
+    const bool left = c1v > c2v;  // the right one between equals (Heap.h:100)
+    const float cv = left ? c1v : c2v;
+    const uint32_t cid = left ? ch.y : ch.w;
+    const bool done = Lv > cv;
+    a2w[hole] = make_uint2(__float_as_uint(done ? Lv : cv), done ? Lid : cid);
+    const uint32_t nh = (hole << 1) | (left ? 0u : 1u);
+    hole = done ? 0u : nh;
+}
+__device__ inline void heapsort_v5(HeapEnt* a, uint32_t n, uint32_t* out_id, int lane) {
+    const float NEG = -__builtin_inff(), POS = __builtin_inff();
+    uint2* a2w = reinterpret_cast<uint2*>(a);
+    const uint4* a4 = reinterpret_cast<const uint4*>(a);
+    const uint32_t P = (n >> 1) + 1;
+    if (lane < 3) a2w[n + 1 + lane] = make_uint2(__float_as_uint(NEG), 0xffffffffu);
+    if (lane == 0) a2w[0] = make_uint2(__float_as_uint(POS), 0xffffffffu);
+    wave_sync();
+    uint32_t hole = 0, Lid = 0;
+    float Lv = POS;
+    uint32_t t = 0;
+    bool create = true;  // (nothing in flight)
+    while (t < n) {
+        const uint32_t sc = n - t;
+        if (create) {
+            // ---- the tick that starts pop t: its lane takes the entry of slot sc and stands on the root
+            const bool mine = (uint32_t)lane == (t & 31u);
+            const uint2 ls = a2w[sc];
+            const uint2 root = a2w[1];
+            // (slot sc keeps its entry while its own walk is under way -- the walk may meet it as a child, Heap.h:97-107 -- and
+            // the slot the pop BEFORE took its entry from leaves the heap for good now: nothing in flight can reach it any more)
+            a2w[sc + 1] = make_uint2(__float_as_uint(NEG), 0xffffffffu);
+            if (lane == 0) out_id[sc - 1] = root.y;
+            hole = mine ? 1u : hole;
+            Lv = mine ? __uint_as_float(ls.x) : Lv;
+            Lid = mine ? ls.y : Lid;
+            // (sc == 1: the last entry is the root itself -- its walk finds no child and puts it back; nothing reads it again)
+            walk_step5(a2w, a4, hole, Lv, Lid, P);
+            wave_sync();
+            t++;
+        }
+        // ---- a plain tick, and the decision for the next one: no start while a walk stands on slot n - t or above it
+        walk_step5(a2w, a4, hole, Lv, Lid, P);
+        // (on or above slot n - t, whose entry the next pop takes, or slot n - t + 1, which it declares dead)
+        const uint32_t scn = n - t;  // (t == n: the loop ends)
+        const uint32_t ch_ = (uint32_t)__builtin_clz(hole | 1u);
+        const uint32_t sh0 = ch_ - (uint32_t)__builtin_clz(scn | 1u), sh1 = ch_ - (uint32_t)__builtin_clz(scn + 1u);
+        const bool above = (sh0 < 32u && (scn >> sh0) == hole) || (sh1 < 32u && ((scn + 1u) >> sh1) == hole);
+        create = !__ballot(above);
+        Lv = hole == 0 ? POS : Lv;
+        wave_sync();
+    }
+    while (__ballot(hole != 0)) {
+        walk_step5(a2w, a4, hole, Lv, Lid, P);
+        Lv = hole == 0 ? POS : Lv;
+        wave_sync();
+    }
+}
+
 template <int V> __global__ __launch_bounds__(64) void sort_rows(const float* heaps, uint32_t n, uint32_t* out, unsigned long long* cycles) {
     extern __shared__ __align__(16) unsigned char smem[];
     HeapEnt* a = reinterpret_cast<HeapEnt*>(smem);
-    uint32_t* out_id = reinterpret_cast<uint32_t*>(smem + (size_t)(n + 2) * 8);
+    uint32_t* out_id = reinterpret_cast<uint32_t*>(smem + (size_t)(n + 4) * 8);
     const int lane = threadIdx.x;
     __builtin_amdgcn_s_setprio(3);
     // the row is a valid max-heap already (built on the host); ids = original slot
@@ -239,7 +309,8 @@ template <int V> __global__ __launch_bounds__(64) void sort_rows(const float* he
     if (V == 1) heapsort_v1(a, n, out_id, lane);
     else if (V == 2) heapsort_v2(a, n, out_id, lane);
     else if (V == 3) heapsort_v3(a, n, out_id, lane);
-    else heapsort_v4(a, n, out_id, lane);
+    else if (V == 4) heapsort_v4(a, n, out_id, lane);
+    else heapsort_v5(a, n, out_id, lane);
     const unsigned long long c1 = __builtin_readcyclecounter();
     wave_sync();
     for (uint32_t i = lane; i < n; i += 64) out[(size_t)blockIdx.x * n + i] = out_id[i];
@@ -287,10 +358,10 @@ int main(int argc, char** argv) {
     float* dh; uint32_t* dout; unsigned long long* dcyc;
     CK(hipMalloc(&dh, h.size() * 4)); CK(hipMalloc(&dout, h.size() * 4)); CK(hipMalloc(&dcyc, rows * 8));
     CK(hipMemcpy(dh, h.data(), h.size() * 4, hipMemcpyHostToDevice));
-    const size_t shmem = (size_t)(n + 2) * 8 + (size_t)(n + 1) * 4;
+    const size_t shmem = (size_t)(n + 4) * 8 + (size_t)(n + 1) * 4;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int ver = 1; ver <= 4; ver++) {
-        auto kern = ver == 1 ? sort_rows<1> : ver == 2 ? sort_rows<2> : ver == 3 ? sort_rows<3> : sort_rows<4>;
+    for (int ver = 1; ver <= 5; ver++) {
+        auto kern = ver == 1 ? sort_rows<1> : ver == 2 ? sort_rows<2> : ver == 3 ? sort_rows<3> : ver == 4 ? sort_rows<4> : sort_rows<5>;
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         float best = 1e9f;
         for (int rep = 0; rep < 3; rep++) {

@@ -353,6 +353,57 @@ static int run_fixed(const tb::Bundle& in) {
         bool threw = false;
         try { dd.search_preassigned(1, xq.as<float>(), 1, keys.data(), cd.as<float>(), nullptr, nullptr, true); } catch (const FaissException&) { threw = true; }
         expect(threw, "dedup store_pairs throws");
+        // IndexIVFFlatDedup::remove_ids (IndexIVFFlat.cpp:381-448): the first half of the ids goes; a stored vector whose id goes
+        // lives on under a surviving copy's id.  Every result is a surviving id at its true distance, and the distances are those of
+        // an index that only ever held the survivors.
+        {
+            IDSelectorRange sel(0, (idx_t)half);
+            const idx_t before = dd.ntotal;
+            const long gone = dd.remove_ids(sel);
+            expect(dd.ntotal == before - gone && gone > 0, "dedup remove_ids count");
+            IndexIVFFlatDedup fresh(ix->quantizer, d, nlist, mt);
+            fresh.coarse_mode = 0;
+            fresh.nprobe = nprobe;
+            std::vector<long> keep(nb - half);
+            for (size_t i = half; i < nb; i++) keep[i - half] = (long)i;
+            fresh.add_with_ids((idx_t)(nb - half), xb.as<float>() + half * d, keep.data());
+            const size_t k = ks.as<int64_t>()[0];
+            std::vector<float> D(nq * k), Df(nq * k);
+            std::vector<idx_t> I(nq * k), If(nq * k);
+            dd.search(nq, xq.as<float>(), k, D.data(), I.data());
+            fresh.search(nq, xq.as<float>(), k, Df.data(), If.data());
+            bool ok = same_f(D.data(), Df.data(), nq * k);
+            for (size_t i = 0; i < nq * k && ok; i++) ok = I[i] < 0 ? If[i] < 0 : I[i] >= (idx_t)half && I[i] < (idx_t)nb;
+            expect(ok, "dedup search after remove_ids == an index of the survivors");
+        }
+    }
+
+    {   // IndexIVF::remove_ids (IndexIVF.cpp:955-987) + IDSelectorBatch: the lists in HBM follow the host lists
+        IndexIVFFlat work(ix->quantizer, d, nlist, mt), fresh(ix->quantizer, d, nlist, mt);
+        work.coarse_mode = fresh.coarse_mode = 0;
+        work.nprobe = fresh.nprobe = nprobe;
+        work.add(nb, xb.as<float>());
+        const size_t k = ks.as<int64_t>()[0];
+        std::vector<float> D(nq * k), Df(nq * k);
+        std::vector<idx_t> I(nq * k), If(nq * k);
+        work.search(nq, xq.as<float>(), k, D.data(), I.data());  // (the engine holds the full lists now)
+        std::vector<idx_t> drop;
+        std::vector<long> keep;
+        for (size_t i = 0; i < nb; i++) (i % 3 == 1 ? drop : keep).push_back((idx_t)i);
+        IDSelectorBatch sel((long)drop.size(), drop.data());
+        const long gone = work.remove_ids(sel);
+        expect(gone == (long)drop.size() && work.ntotal == (idx_t)keep.size(), "remove_ids count");
+        std::vector<float> xk(keep.size() * d);
+        for (size_t i = 0; i < keep.size(); i++) memcpy(&xk[i * d], xb.as<float>() + (size_t)keep[i] * d, d * sizeof(float));
+        fresh.add_with_ids((idx_t)keep.size(), xk.data(), keep.data());
+        work.search(nq, xq.as<float>(), k, D.data(), I.data());
+        fresh.search(nq, xq.as<float>(), k, Df.data(), If.data());
+        bool ok = same_f(D.data(), Df.data(), nq * k);
+        for (size_t i = 0; i < nq * k && ok; i++) {
+            const bool tie = (i % k > 0 && D[i] == D[i - 1]) || (i % k + 1 < k && D[i] == D[i + 1]);
+            ok = I[i] < 0 ? If[i] < 0 : (I[i] % 3 != 1 && (tie || I[i] == If[i]));  // (removal moves entries inside a list: order among equals may differ)
+        }
+        expect(ok, "search after remove_ids == an index of the survivors");
     }
 
     size_t nshard = in.scalar_or<size_t>("nshard", 0);
@@ -384,6 +435,48 @@ static int run_fixed(const tb::Bundle& in) {
                 const std::string tag = threaded ? " (threaded)" : "";
                 expect(same_i(I.data(), in.get("I_shards_k" + std::to_string(k)).as<int64_t>(), nq * k), "shards ids" + tag);
                 expect(same_f(D.data(), in.get("D_shards_k" + std::to_string(k)).as<float>(), nq * k), "shards distances" + tag);
+            }
+        }
+        // the same shards made by the mirror itself: IndexIVF::copy_subset_to type 3 (lists with l % nshard == s: the goldens' owner
+        // rule) under an IndexShards, and IndexShardsByList (type 4: byte-balanced owners) -- a C++ caller's way to the list-id shards
+        {
+            IndexIVFFlat* src = dynamic_cast<IndexIVFFlat*>(ix);
+            std::vector<std::unique_ptr<IndexIVFFlat>> cut;
+            IndexShards by_mod((idx_t)d, true, false);
+            for (size_t s = 0; s < nshard; s++) {
+                cut.emplace_back(new IndexIVFFlat(ix->quantizer, d, nlist, mt));
+                cut.back()->coarse_mode = 0;
+                cut.back()->nprobe = nprobe;
+                src->copy_subset_to(*cut.back(), 3, (idx_t)nshard, (idx_t)s);
+                by_mod.add_shard(cut.back().get());
+            }
+            expect(by_mod.ntotal == (idx_t)nb, "copy_subset_to type 3 keeps every vector once");
+            IndexShardsByList by_bytes(*src, (int)nshard, true);
+            std::vector<int> owner = ivf_list_owners(*src, (int)nshard);
+            std::vector<size_t> load(nshard, 0);
+            size_t longest = 0;
+            for (size_t l = 0; l < nlist; l++) load[owner[l]] += ix->invlists->list_size(l), longest = std::max(longest, ix->invlists->list_size(l));
+            expect(*std::max_element(load.begin(), load.end()) - *std::min_element(load.begin(), load.end()) <= longest, "list owners balanced by bytes");
+            for (size_t ki = 0; ki < ks.numel(); ki++) {
+                size_t k = ks.as<int64_t>()[ki];
+                std::vector<float> D(nq * k);
+                std::vector<idx_t> I(nq * k);
+                by_mod.search(nq, xq.as<float>(), k, D.data(), I.data());
+                expect(same_i(I.data(), in.get("I_shards_k" + std::to_string(k)).as<int64_t>(), nq * k) &&
+                           same_f(D.data(), in.get("D_shards_k" + std::to_string(k)).as<float>(), nq * k), "copy_subset_to(3) shards == the reference's IndexShards");
+                by_bytes.search(nq, xq.as<float>(), k, D.data(), I.data());
+                // (another owner rule: equal distances may come out in another order; the distances are the single index's)
+                expect(same_f(D.data(), in.get("D_k" + std::to_string(k)).as<float>(), nq * k), "IndexShardsByList distances == the single index's");
+            }
+            // the reference's own cuts: by id range, by id modulo, by position (IndexIVF.cpp:1055-1117)
+            for (int type = 0; type < 3; type++) {
+                IndexIVFFlat a(ix->quantizer, d, nlist, mt), b(ix->quantizer, d, nlist, mt);
+                if (type == 0) { src->copy_subset_to(a, 0, 0, (idx_t)(nb / 2)); src->copy_subset_to(b, 0, (idx_t)(nb / 2), (idx_t)nb); }
+                if (type == 1) { src->copy_subset_to(a, 1, 2, 0); src->copy_subset_to(b, 1, 2, 1); }
+                if (type == 2) { src->copy_subset_to(a, 2, 0, (idx_t)(nb / 2)); src->copy_subset_to(b, 2, (idx_t)(nb / 2), (idx_t)nb); }
+                bool ok = a.ntotal + b.ntotal == (idx_t)nb && (type != 2 || a.ntotal == (idx_t)(nb / 2));
+                for (size_t l = 0; l < nlist && ok; l++) ok = a.invlists->list_size(l) + b.invlists->list_size(l) == ix->invlists->list_size(l);
+                expect(ok, "copy_subset_to type " + std::to_string(type) + " splits the index in two");
             }
         }
         // IndexShards::add from one host thread per shard while the shards share one quantizer (IndexFlat::search is

@@ -45,6 +45,85 @@ def _worker(rank, world, port, name, q):
         dist.destroy_process_group()
 
 
+class _OracleHandle:
+    """stands in for capi.Handle in sharding.run_pipelined: tickets run on a small thread pool, the CPU oracle does the work"""
+
+    def __init__(self, pyoracle, case, gold, sub, k):
+        from concurrent.futures import ThreadPoolExecutor
+        self.orc, self.case, self.gold, self.sub, self.k = pyoracle, case, gold, sub, k
+        self.pool, self.jobs, self.next = ThreadPoolExecutor(3), {}, 1
+
+    def _submit(self, fn):
+        t, self.next = self.next, self.next + 1
+        self.jobs[t] = self.pool.submit(fn)
+        return t
+
+    def submit_coarse_resident(self, start, n, nprobe, mode=0, want_dis=False):
+        assert nprobe == self.case["nprobe"]
+        return self._submit(lambda: (None, self.gold["coarse_keys_sse"][start:start + n].copy()))
+
+    def submit_search_resident_preassigned(self, start, n, k, keys, out=None):
+        def run():
+            # (IVF-Flat ignores the coarse distances: IndexIVFFlat.cpp:106)
+            D, I, _ = self.orc.search_preassigned(self.sub, self.case["xq"][start:start + n], int(k), keys, self.gold["coarse_dis_sse"][start:start + n])
+            out[0][:], out[1][:] = D, I
+            return out
+        return self._submit(run)
+
+    def wait(self, t):
+        a, b = self.jobs.pop(t).result()
+        tm = {"coarse_ms": 0.0, "scan_ms": 0.0, "select_ms": 0.0, "scan_launches": 1.0, "scan_min_bytes": 0.0}
+        return a, b, tm, {}
+
+
+def _worker_pipelined(rank, world, port, name, q):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")]
+    import torch.distributed as dist
+    from util import load_case
+    from auncel_amd import capi, sharding
+    from oracle import pyoracle
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        case, gold = load_case(name)
+        owner = np.arange(case["nlist"]) % world
+        nq = case["xq"].shape[0]
+        counts = [(r + 1) * nq // world - r * nq // world for r in range(world)]
+        k = int(case["ks"][0])
+        sub = pyoracle.Lists(case["metric"], case["centroids"], case["xb"], sharding.local_assignment(gold["assign"], owner, rank))
+        h = _OracleHandle(pyoracle, case, gold, sub, k)
+        ok = True
+        for lag in (1, 3):
+            out, acc = sharding.run_pipelined(h, case["metric"], capi.merge_tables, nq, k, case["nprobe"], counts, rank, dist, 5, lag=lag)
+            if rank == 0:
+                ok &= acc["steps_merged"] == 5
+                ok &= np.array_equal(out[1], gold[f"I_shards_k{k}"]) and np.array_equal(out[0].view(np.uint32), gold[f"D_shards_k{k}"].view(np.uint32))
+            else:
+                ok &= out is None
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["fixed_gauss_l2_d96", "fixed_dups"])
+def test_two_rank_pipelined_steps(name):
+    """sharding.run_pipelined (what bench.py --mode shards times): several steps in flight, the two collectives of a step issued by one
+    thread in a fixed order, the merge on its own thread -- two gloo ranks, the CPU oracle in the engine's place; every step's merged
+    table is the reference's IndexShards output"""
+    from auncel_amd import build
+    build.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 250)
+    procs = [ctx.Process(target=_worker_pipelined, args=(r, 2, port, name, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True), (1, True)]
+
+
 @pytest.mark.parametrize("name", ["fixed_gauss_l2_d96", "fixed_deep_ip_d96", "fixed_dups"])
 def test_two_rank_shards(name):
     from auncel_amd import build
