@@ -11,6 +11,9 @@ SOURCES = ["ivf_kernels.hip", "ivf_select.hip", "ivf_filter.hip", "dataset_io.cp
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result"]
 
 
+LAST = {"compiled": [], "reused": 0}  # what the last build() call did (printed by __graft_entry__.build)
+
+
 def _deps(src):
     """a source and the headers next to it (plus the public header)"""
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
@@ -35,6 +38,7 @@ def build(force=False):
         stale = force or not same_flags or not os.path.exists(o) or any(os.path.getmtime(p) > os.path.getmtime(o) for p in _deps(s))
         if stale:
             todo.append([hipcc] + cflags + extra + ["-c", os.path.join(CSRC, s), "-o", o])
+    LAST["compiled"], LAST["reused"] = [os.path.basename(c[-3]) for c in todo], len(SOURCES) - len(todo)
     if not todo and os.path.exists(LIB) and same_flags:
         return LIB
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:

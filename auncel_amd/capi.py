@@ -57,13 +57,19 @@ def _share_torch_hip_runtime():
     if spec is None or not spec.origin:
         return
     d = os.path.join(os.path.dirname(spec.origin), "lib")
-    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
-        p = os.path.join(d, name)
-        if os.path.exists(p):
-            try:
-                _SHARED[name] = C.CDLL(p, mode=C.RTLD_GLOBAL)
-            except OSError:
-                return
+    names = ("libhsa-runtime64.so", "libamdhip64.so")
+    if not all(os.path.exists(os.path.join(d, n)) for n in names):
+        return  # (a torch build without a bundled runtime: it uses ROCm's, like the engine)
+    for name in names:
+        try:
+            _SHARED[name] = C.CDLL(os.path.join(d, name), mode=C.RTLD_GLOBAL)
+        except OSError as e:
+            # half a runtime (torch's HSA under ROCm's HIP) is worse than either: say so instead of going on
+            raise ImportError(f"auncel_amd: torch's bundled {name} could not be loaded next to {sorted(_SHARED)} ({e}); set "
+                              "AUNCEL_AMD_OWN_HIP_RUNTIME=1 to run the engine on ROCm's own runtime (and do not use torch's GPU "
+                              "side in the same process)") from e
+    if os.environ.get("AUNCEL_AMD_VERBOSE"):
+        print(f"[auncel_amd] running on torch's bundled HIP runtime ({d}); AUNCEL_AMD_OWN_HIP_RUNTIME=1 keeps ROCm's", file=sys.stderr)
 
 
 _SHARED = {}

@@ -389,6 +389,7 @@ struct amd_ivf {
     std::mutex fp32_gate_mu;               // large fp32 searches running on this index (option fp32_in_flight)
     std::condition_variable fp32_gate_cv;
     int fp32_running = 0;
+    uint64_t fp32_gate_next = 0, fp32_gate_serving = 0;  // (first come, first served)
     double probed_len = 0;                 // expected length of the list a query probes: sum(len^2) / sum(len) (upload_lists)
     DevBuf d_lanes;                        // the fp32 lists in lane order (ScanArgs::lanes), built by the first fp32 dense round
     std::atomic<int> lanes_state{0};       // 0 not tried, 1 there, -1 not possible
@@ -626,9 +627,15 @@ void ensure_context_streams(amd_ivf* h) {
 // The engine's streams are laid out for 8 hardware queues per priority class (ROCm's default is 4): with 4, the scan and background
 // streams of four searches in flight share queues two by two, and a scan queued behind another context's 1.5 ms heap waits for it.
 // Read by the HIP runtime when it starts: set here, when the library is loaded, unless the process has chosen a value itself.
-struct HwQueues {
-    HwQueues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
-} g_hw_queues;
+// The library does NOT touch the environment (a constructor that called setenv changed the host application's and torch's runtime
+// behind their backs, and was without effect anyway once HIP had started): the process that wants several searches in flight
+// exports GPU_MAX_HW_QUEUES=8 before anything starts the HIP runtime (bench.py, tests/conftest.py).  What the engine
+// does itself is not run more searches at a time than there are queues in a class (async_running_limit below).
+static int hw_queues_per_class() {
+    const char* e = getenv("GPU_MAX_HW_QUEUES");
+    const int v = e && *e ? atoi(e) : 4;  // (ROCm's default)
+    return v > 0 ? v : 4;
+}
 
 // Side streams of a context, created one by one on first use.  The runtime attaches a new stream to the hardware queue with the
 // fewest streams (GPU_MAX_HW_QUEUES of them): a context that creates its four side streams together puts stream i on queue i, so
@@ -2099,13 +2106,22 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
     struct Fp32Gate {
         amd_ivf* ix;
         bool held;
+        // (Callers with threads of their own may block here on other callers' searches, in the order they arrive; the limit is read
+        // again whenever a waiter is woken, so changing the option while searches wait takes effect.  The handle's own asynchronous
+        // searches never park here: the pool does not start more fp32 searches than the limit, async_running_limit.)
         Fp32Gate(amd_ivf* index, bool wanted) : ix(index), held(false) {
-            const int limit = (int)index->opt.get(OPT_FP32_IN_FLIGHT, 4);
-            if (!wanted || limit <= 0) return;
+            if (!wanted || (int)index->opt.get(OPT_FP32_IN_FLIGHT, 4) <= 0) return;
             std::unique_lock<std::mutex> lk(ix->fp32_gate_mu);
-            ix->fp32_gate_cv.wait(lk, [&] { return ix->fp32_running < limit; });
+            const uint64_t mine = ix->fp32_gate_next++;
+            ix->fp32_gate_cv.wait(lk, [&] {
+                const int limit = (int)ix->opt.get(OPT_FP32_IN_FLIGHT, 4);
+                return mine == ix->fp32_gate_serving && (limit <= 0 || ix->fp32_running < limit);
+            });
+            ix->fp32_gate_serving++;
             ix->fp32_running++;
             held = true;
+            lk.unlock();
+            ix->fp32_gate_cv.notify_all();  // (the next in line may fit as well)
         }
         ~Fp32Gate() {
             if (!held) return;
@@ -2113,7 +2129,7 @@ void run_rounds_device(amd_ivf* h, const RoundSpec& base, size_t n, size_t first
                 std::lock_guard<std::mutex> lk(ix->fp32_gate_mu);
                 ix->fp32_running--;
             }
-            ix->fp32_gate_cv.notify_one();
+            ix->fp32_gate_cv.notify_all();
         }
     } fp32_gate(I, !base.bytes && n >= 256);
     // (an adaptive search ends most queries in its first rounds: a first round of 2 probes instead of 3 sent more of them through the
@@ -4911,6 +4927,8 @@ struct AsyncJob {
 struct AsyncPool {
     std::mutex mu;
     std::condition_variable cv_job, cv_done;
+    int running = 0, running_limit = 0;  // searches at a time: never more than the hardware queues of a priority class
+    const struct amd_ivf* owner = nullptr;
     std::deque<AsyncJob*> queue;
     std::map<uint64_t, std::unique_ptr<AsyncJob>> jobs;
     std::vector<std::thread> workers;
@@ -4919,15 +4937,28 @@ struct AsyncPool {
     bool stop = false;
 };
 
+// searches the pool runs at a time: its depth, cut to the hardware queues of a class (async_pool) and -- where the owner's lists have
+// no byte codes, i.e. its large searches are fp32 searches -- to the option fp32_in_flight, so that no worker parks inside a search
+static int async_running_limit(const AsyncPool* p) {
+    int lim = p->running_limit;
+    const amd_ivf* o = p->owner;
+    if (o && !o->lists_dirty && !(o->have_codes8 && o->allow_bytes)) {
+        const int f = (int)o->opt.get(OPT_FP32_IN_FLIGHT, 4);
+        if (f > 0) lim = std::min(lim, f);
+    }
+    return std::max(lim, 1);
+}
+
 static void async_worker(AsyncPool* p, size_t i) {
     for (;;) {
         AsyncJob* j = nullptr;
         {
             std::unique_lock<std::mutex> lk(p->mu);
-            p->cv_job.wait(lk, [&] { return p->stop || !p->queue.empty(); });
+            p->cv_job.wait(lk, [&] { return p->stop || (!p->queue.empty() && p->running < async_running_limit(p)); });
             if (p->stop || p->queue.empty()) return;  // (the handle is going away: searches not yet started are dropped)
             j = p->queue.front();
             p->queue.pop_front();
+            p->running++;
         }
         amd_ivf_t* c = p->ctx[i];
         const int rc = j->run(c);
@@ -4942,8 +4973,10 @@ static void async_worker(AsyncPool* p, size_t i) {
             j->error = std::move(err);
             j->rc = rc;
             j->done = true;
+            p->running--;
         }
         p->cv_done.notify_all();
+        p->cv_job.notify_one();
     }
 }
 
@@ -4954,6 +4987,16 @@ static AsyncPool* async_pool(amd_ivf* h) {
     if (h->async) return h->async;
     std::unique_ptr<AsyncPool> p(new AsyncPool);
     const int depth = std::min(std::max(h->async_depth, 1), 16);
+    // Every search context has one stream in each priority class and wants a hardware queue to itself in each (ensure_context_streams):
+    // where the runtime was started with fewer queues a class than searches asked for, two searches' kernels would wait for each other
+    // in a shared queue (2.0 instead of 3.0 M q/s, by luck of the order).  Then only as many run at a time as there are queues; the
+    // other tickets wait their turn, the caller's code is the same.
+    const int hwq = hw_queues_per_class();
+    p->owner = h;
+    p->running_limit = std::min(depth, std::max(hwq, 1));
+    if (p->running_limit < depth && !getenv("AUNCEL_AMD_QUIET"))
+        fprintf(stderr, "[auncel_amd] %d searches in flight asked for, the HIP runtime has %d hardware queues a priority class: %d run at a time "
+                        "(export GPU_MAX_HW_QUEUES=8 before the first GPU call: include/auncel_amd.h)\n", depth, hwq, p->running_limit);
     for (int i = 0; i < depth; i++) {
         amd_ivf_t* c = nullptr;
         if (amd_ivf_clone(h, &c) != 0) {

@@ -431,7 +431,7 @@ def main():
                     help="adaptive: BASELINE config 2, the headline (replicas at N > 1).  shards: config 4 -- fixed nprobe, the inverted "
                          "lists sharded by list id over the N GPUs (IndexShards), per-GPU partial top-k merged on the host; strong scaling")
     ap.add_argument("--nprobe", type=int, default=32, help="--mode shards: probes per query")
-    ap.add_argument("--shard-lag", type=int, default=4, help="--mode shards: steps in flight (searches on the GPU while earlier steps' tables are gathered and merged)")
+    ap.add_argument("--shard-lag", type=int, default=2, help="--mode shards: steps in flight (searches on the GPU while earlier steps' tables are gathered and merged)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-legs", action="store_true",
                     help="skip the untimed extra legs (one batch at a time, fp32 path, guaranteed-bound point): profiling runs")
@@ -485,9 +485,8 @@ def main():
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         log(f"--gpus {args.gpus} without a launcher: starting {' '.join(cmd[1:8])} ...")
         sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
-    # hardware queues the HIP runtime maps its streams onto: the engine lays its streams out for 8 per priority class and asks for
-    # them itself when its library is loaded (auncel_amd/csrc/ivf_engine.hip: HwQueues); said here as well because it has to be in
-    # the environment before HIP starts, whichever of torch and the engine touches the GPU first
+    # hardware queues the HIP runtime maps its streams onto: the engine lays its streams out for 8 per priority class; the library does
+    # not touch the environment, so it is said here, before HIP starts, whichever of torch and the engine touches the GPU first
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     import torch

@@ -245,9 +245,11 @@ int amd_ivf_range_results(amd_ivf_t* h, int64_t* labels, float* distances);
  * GPU_MAX_HW_QUEUES (the HIP runtime's own variable): hardware queues per stream-priority class.  The engine's streams -- a
  *                              high-priority main stream, a background stream and a low-priority side stream per search context --
  *                              are laid out for 8 (ROCm's default is 4, with which the background streams of several searches in
- *                              flight share queues and wait for each other's kernels); the library sets 8 when it is loaded unless
- *                              the process has chosen a value, which only takes effect if the HIP runtime has not started yet: a
- *                              process that touches the GPU before loading the library sets it itself (bench.py does)
+ *                              flight share queues and wait for each other's kernels).  The library never changes the environment:
+ *                              a process that wants more than 4 searches in flight (amd_ivf_set_async_depth, or threads of its own on
+ *                              amd_ivf_clone contexts) exports GPU_MAX_HW_QUEUES=8 before anything -- torch included -- starts the HIP
+ *                              runtime (bench.py and the tests do).  With fewer queues the asynchronous entry points run only as
+ *                              many searches at a time as there are queues in a class and say so once on stderr (AUNCEL_AMD_QUIET)
  * The other AUNCEL_AMD_* variables the sources read are measurement switches (DESIGN.md names the ones it quotes). */
 
 /* ---- measurement hooks (bench.py): time of the kernels of the last search call, from HIP events

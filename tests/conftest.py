@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# hardware queues per stream-priority class: the engine's streams are laid out for 8 (include/auncel_amd.h, environment); said before
+# anything starts the HIP runtime -- the library itself never changes the environment
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
     if p not in sys.path:

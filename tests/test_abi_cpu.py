@@ -79,3 +79,15 @@ def test_trace_sb_host(capi, name):
     assert i == 8
     # numpy arccos vs the reference's LUT (std::acos on float)
     assert np.array_equal(capi.arcos_table().view(np.uint32), gold["arcos_list"].view(np.uint32))
+
+
+def test_loading_the_library_leaves_the_environment_alone():
+    """the HIP runtime's GPU_MAX_HW_QUEUES is the process's business: neither the package nor the library's static constructors set it"""
+    import subprocess
+    import sys
+    code = ("import os; os.environ.pop('GPU_MAX_HW_QUEUES', None); import auncel_amd; from auncel_amd import capi; capi.lib(); "
+            "import ctypes; libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p; "
+            "print('ENV', os.environ.get('GPU_MAX_HW_QUEUES'), libc.getenv(b'GPU_MAX_HW_QUEUES'))")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "ENV None None" in r.stdout, r.stdout
