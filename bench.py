@@ -951,6 +951,35 @@ def main():
                    "recall_at_k_mean": float(frec.mean()), "how": "amd_ivf_submit_search_resident / amd_ivf_wait on the same index and slices"}
         if not use_async:
             h.set_async_depth(0)
+    # one query per call: the reference's own evaluation protocol (eval/bound.cpp:391-396 issues Error_sys::search(D, I, i, 1) for every
+    # test query).  Wall time of the call through the C ABI (ctypes), and the time inside the entry point; results kept and compared
+    # with the reference's below (parity leg).
+    lat1 = None
+    lat_keep = None
+    if not args.no_legs and "latency1" not in skip_legs:
+        ncall = min(400, nsl * ses)
+        stride = (nsl * ses) // ncall  # (spread over every resident slice)
+        ids1 = ts + np.arange(ncall) * stride
+        np1 = np.zeros(nall, dtype=np.uint64)
+        tr1 = np.zeros(nall, dtype=np.float32)
+        lD = np.empty((ncall, K), np.float32)
+        lI = np.empty((ncall, K), np.int64)
+        for i in range(20):
+            h.search_adaptive(int(ids1[i]), 1, topk, chosen, chosen_std, req, np1, tr1)
+        wall, inside = np.zeros(ncall), np.zeros(ncall)
+        for i in range(ncall):
+            q = int(ids1[i])
+            np1[q] = 0
+            tq = time.perf_counter()
+            D1, I1 = h.search_adaptive(q, 1, topk, chosen, chosen_std, req, np1, tr1)
+            wall[i] = (time.perf_counter() - tq) * 1e3
+            inside[i] = h.last_timing()["total_ms"]
+            lD[i], lI[i] = D1[0], I1[0]
+        lat_keep = (ids1, lD, lI, np1[ids1].copy())
+        lat1 = {"what": "amd_ivf_search_adaptive over ONE resident query per call, the reference's protocol (eval/bound.cpp:391-396)", "calls": int(ncall),
+                "ms_median": float(np.median(wall)), "ms_p90": float(np.percentile(wall, 90)), "ms_p99": float(np.percentile(wall, 99)), "ms_min": float(wall.min()),
+                "inside_the_entry_point": {"ms_median": float(np.median(inside)), "ms_p90": float(np.percentile(inside, 90))},
+                "queries_per_s_one_caller": float(1e3 / wall.mean()), "my_nprobe_mean": float(np1[ids1].mean())}
     # the reference's acceptance check at the operating point chosen for it on the training half
     guar = {"validation_min_recall_best": best_min[0], "validation_best_point": best_min[1]}
     if guaranteed is not None and not args.no_legs:
@@ -1156,8 +1185,13 @@ def main():
         }
     if single_caller is not None:
         out["single_caller_async"] = single_caller
+    if lat1 is not None:
+        out["latency_batch1"] = lat1
     if fp32 is not None:
         out["fp32_path"] = fp32
+        # the reference's own arithmetic as first-class fields: the same workload with byte codes off (what float data gets)
+        out["value_fp32"] = fp32["value"]
+        out["roofline_fp32"] = fp32.get("roofline")
     if id_ties is not None:
         out["centroid_number_tie_order"] = id_ties
     if fixed32 is not None:
@@ -1227,6 +1261,15 @@ def main():
         port_np = tun.my_nprobe[ts:ts + S].astype(np.uint64)
         port_diff = differing(oD, oI, port_np)
 
+        def lat_check(rD, rI, rnp):
+            """the one-query-per-call results against the reference's for the same queries"""
+            if lat_keep is None:
+                return None
+            ids_, lD_, lI_, lnp_ = lat_keep
+            rows = ids_ - ts
+            bad = (lI_ != rI[rows]).any(1) | (lD_.view(np.uint32) != np.ascontiguousarray(rD[rows]).view(np.uint32)).any(1) | (lnp_ != rnp[rows])
+            return {"calls_checked": int(len(ids_)), "calls_differing": int(bad.sum())}
+
         def slices_of(rD, rI, rnp, cols=K):
             return lambda start: (rD[start - ts:start - ts + ses, :cols], rI[start - ts:start - ts + ses, :cols],
                                   None if rnp is None else rnp[start - ts:start - ts + ses])
@@ -1247,7 +1290,8 @@ def main():
                   # the results of the timed steps themselves (every step of the timed region: D, I and my_nprobe as the searches in flight
                   # returned them) and of the legs' steps, against the reference's result for the slice each searched
                   "timed_steps_checked": timed_par["timed_steps_checked"], "timed_steps_differing": timed_par["timed_steps_differing"],
-                  "timed_region": timed_par, "fp32_path_steps": fp32_par, "fixed_nprobe_32_steps": fixed_par}
+                  "timed_region": timed_par, "fp32_path_steps": fp32_par, "fixed_nprobe_32_steps": fixed_par,
+                  "latency_batch1_calls": lat_check(oD, oI, port_np)}
         if port_diff:
             log("PARITY MISMATCH vs the CPU restatement:", port_diff, "of", S, "queries differ in I / D / my_nprobe")
         log(f"parity vs the CPU restatement on {S} queries ({nsl} slices): {port_diff} differ; {patched} rankings changed by the heap, {redone} queries searched again")
@@ -1281,6 +1325,7 @@ def main():
                 timed_par = dict(kept_timed.check(slices_of(ro["D"], ro["I"], rnp)), against=against)
                 parity.update({"timed_steps_checked": timed_par["timed_steps_checked"], "timed_steps_differing": timed_par["timed_steps_differing"],
                                "timed_region": timed_par})
+                parity["latency_batch1_calls"] = lat_check(ro["D"], ro["I"], rnp)
                 if kept_fp32 is not None:
                     parity["fp32_path_steps"] = dict(kept_fp32.check(slices_of(ro["D"], ro["I"], rnp)), against=against)
                 if kept_fixed is not None:
@@ -1373,6 +1418,7 @@ def main():
     par = cb.get("parity") or {}
     bad = int(cb.get("queries_differing") or 0) + sum(int((par.get(k) or {}).get("timed_steps_differing") or 0)
                                                         for k in ("timed_region", "fp32_path_steps", "fixed_nprobe_32_steps"))
+    bad += int((par.get("latency_batch1_calls") or {}).get("calls_differing") or 0)
     gw = out.get("guaranteed_bound_workload") or {}
     bad += int((gw.get("parity") or {}).get("timed_steps_differing") or 0)
     if rank == 0 and bad:

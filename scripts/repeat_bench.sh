@@ -1,15 +1,22 @@
 #!/bin/bash
-# three plain `python bench.py --steps 20 --warmup 5` runs (the driver's flags) back to back on one box -> gpurun_out/bench_lines_repeat_<tag>.jsonl
-tag=${1:-r04}
-: > gpurun_out/bench_lines_repeat_$tag.jsonl
-for i in 1 2 3; do
-  python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 >> gpurun_out/bench_lines_repeat_$tag.jsonl
+# N plain `python bench.py --steps 20 --warmup 5` runs (the driver's flags) back to back on one box -> gpurun_out/bench_lines_repeat_<tag>.jsonl
+# (the first with every leg, the others with the fixed_nprobe_32 leg only: the timed region is the same code either way)
+tag=${1:-r06}; n=${2:-10}
+out=gpurun_out/bench_lines_repeat_$tag.jsonl
+: > $out
+python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 >> $out
+for i in $(seq 2 $n); do
+  AUNCEL_BENCH_SKIP_LEGS=one_batch,fp32,id_ties,latency1 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-other 2>/dev/null | tail -1 >> $out
 done
 python - <<PY
-import json
-for l in open("gpurun_out/bench_lines_repeat_$tag.jsonl"):
+import json, statistics
+v, f = [], []
+for l in open("$out"):
     d = json.loads(l)
-    print(round(d["value"]), d["ms_per_step"], "one-batch", d["one_batch_at_a_time"]["ms_per_step"], "fp32", round(d["fp32_path"]["value"]),
-          "async", round(d["single_caller_async"]["value"]), "cfgs", [round(c["value"]) for c in d["other_configs"]],
-          "parity", d["cpu_baseline"]["gpu_matches_cpu_on_sample"], d["cpu_baseline"]["parity"]["timed_configuration_queries_differing"])
+    v.append(d["value"]); f.append((d.get("fixed_nprobe_32") or {}).get("value"))
+    print(round(d["value"]), round(d["ms_per_step"], 3), "fixed32", f[-1] and round(f[-1]))
+f = [x for x in f if x]
+for name, a in (("headline", v), ("fixed_nprobe_32", f)):
+    a = sorted(a)
+    print(name, "min", round(a[0]), "median", round(statistics.median(a)), "max", round(a[-1]), "p10/median", round(a[max(0, len(a) // 10)] / statistics.median(a), 3))
 PY
