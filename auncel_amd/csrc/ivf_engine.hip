@@ -4942,7 +4942,8 @@ struct AsyncPool {
 static int async_running_limit(const AsyncPool* p) {
     int lim = p->running_limit;
     const amd_ivf* o = p->owner;
-    if (o && !o->lists_dirty && !(o->have_codes8 && o->allow_bytes)) {
+    static const bool no_cap = getenv("AUNCEL_AMD_NO_POOL_FP32_CAP") != nullptr;  // (experiments: the gate inside the searches only)
+    if (!no_cap && o && !o->lists_dirty && !(o->have_codes8 && o->allow_bytes)) {
         const int f = (int)o->opt.get(OPT_FP32_IN_FLIGHT, 4);
         if (f > 0) lim = std::min(lim, f);
     }

@@ -449,6 +449,9 @@ template <bool HALF> __device__ __forceinline__ void filter_mac(v16f& acc, const
         for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc, 0, 0, 0);
     }
 }
+// (Occupancy is not what bounds this kernel: at NJ = 8 the compiler's free choice is 155 registers + 16 accumulators, two waves a SIMD;
+// asked for three it fits 153 without spilling, for four it spills 24 -- measured on the bench workload's fp32 form, threshold passes
+// per step: 1.78 / 1.78 / 2.18 ms at 2 / 3 / 4 waves, cfg 3 (NJ = 6) 0.88 / 0.88 / 0.95: profiles/r06_experiments.txt A.)
 template <int METRIC, int NJ, bool HALF> __global__ __launch_bounds__(256) void scan_filter_kernel(FilterScanArgs a) {
     __shared__ float s_u[4][32];
     __shared__ float s_c[4][32];

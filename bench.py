@@ -848,10 +848,11 @@ def main():
     if arith == 2 and not args.no_legs and "fp32" not in skip_legs:
         for c in ctxs:
             c.set_byte_codes(False)
-        leg = timed_leg(max(4, args.steps // 3))
+        # (at least two rounds of the searches in flight: six steps were a third of the leg's own spread)
+        nst = int(os.environ.get("AUNCEL_BENCH_FP32_STEPS", max(2 * nfl, args.steps // 2)))
+        leg = timed_leg(nst)
         kept_fp32 = leg["kept"]
         fD, fI, f_np, f_start = leg["last"]
-        nst = max(4, args.steps // 3)
         if f_start != q_start:  # the same slice as the timed region's last step, for the comparison
             fD, fI, f_np, f_start = step(ctxs[0], (q_start - ts) // ses)
             fD, fI = fD.copy(), fI.copy()
