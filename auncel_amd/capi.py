@@ -26,7 +26,7 @@ SYMBOLS = [
     "amd_ivf_train_samples",
     "amd_ivf_train_samples_x", "amd_ivf_train_samples_pre", "amd_ivf_trace_sb", "amd_ivf_arcos_table", "amd_ivf_merge_tables",
     "amd_ivf_last_timing", "amd_ivf_last_timing_detail", "amd_ivf_last_scan_min_bytes", "amd_ivf_coarse_tie_rows", "amd_ivf_last_tie_fixed", "amd_ivf_last_filter", "amd_ivf_last_direct_out", "amd_ivf_last_coarse_pick", "amd_ivf_set_async_depth", "amd_ivf_submit_adaptive", "amd_ivf_submit_search_resident", "amd_ivf_submit_coarse_resident",
-    "amd_ivf_submit_search_resident_preassigned", "amd_ivf_wait", "amd_ivf_last_tie_redone", "amd_ivf_last_tie_patched", "amd_ivf_self_check", "amd_ivf_last_round_hints", "amd_ivf_set_byte_codes", "amd_ivf_set_option", "amd_ivf_get_option",
+    "amd_ivf_submit_search_resident_preassigned", "amd_ivf_wait", "amd_ivf_async_counts", "amd_ivf_last_tie_redone", "amd_ivf_last_tie_patched", "amd_ivf_self_check", "amd_ivf_last_round_hints", "amd_ivf_set_byte_codes", "amd_ivf_set_option", "amd_ivf_get_option",
     "amd_ivf_kmeans",
     "amd_ivf_range_search_preassigned", "amd_ivf_range_search", "amd_ivf_range_results",
     "amd_ivf_scan_arith",
@@ -502,6 +502,12 @@ class Handle:
             self._tickets = {}
         self._tickets[int(t.value)] = (keys, None, None, None, D, I)
         return int(t.value)
+
+    def async_counts(self):
+        """(tickets served by the asynchronous entry points, passes that served them)"""
+        out = (C.c_uint64 * 2)()
+        _chk(lib().amd_ivf_async_counts(self._h, out))
+        return int(out[0]), int(out[1])
 
     def wait(self, ticket):
         """blocks until the search of `ticket` has ended; returns (D, I, timing dict, diag dict); raises as the synchronous call"""

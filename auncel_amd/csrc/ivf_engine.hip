@@ -77,6 +77,8 @@ enum OptId {
                         // step, no LDS staging) or from the rows (0, scan_tiles_kernel); the copy costs the lists' bytes once more
     OPT_FP32_IN_FLIGHT, // large fp32 searches of one index that run at a time (4, the measured optimum: 1.43 / 1.42 / 1.37 / 1.33 M queries/s
                         // at 4 / 5 / 6 / 8 at a time); the others wait inside their calls
+    OPT_COALESCE,       // asynchronous adaptive searches: queued tickets over adjacent resident ranges (same parameters, adjacent result
+                        // buffers) that one pass over the lists may serve together (1: every ticket its own pass)
     N_OPT
 };
 struct OptSpec {
@@ -102,6 +104,7 @@ const OptSpec OPT_TABLE[N_OPT] = {
     {"row_lists", "AUNCEL_AMD_ROW_LISTS", nullptr},
     {"lanes", "AUNCEL_AMD_LANES", nullptr},
     {"fp32_in_flight", "AUNCEL_AMD_FP32_IN_FLIGHT", nullptr},
+    {"coalesce", "AUNCEL_AMD_COALESCE", nullptr},
 };
 struct Options {
     // (atomic: amd_ivf_set_option on the owner may run while search contexts cloned from it are searching; a search reads the
@@ -356,6 +359,7 @@ struct amd_ivf {
     // the window a query can read in its first two rounds) are set aside and re-ranked on a side stream WHILE the first pass
     // searches; the second pass takes its rankings from those slots instead of running the heap (2.75 ms at nlist 4096) itself
     DevBuf w_spec_full, w_spec_dis, w_spec_keys, w_spec_count, w_spec_slot, w_spec_pick, w_redo_idx, w_spec_query, w_spec_scratch, w_split;
+    uint32_t spec_cap = 512;        // slots of this search (adaptive_slice)
     bool spec_inline = false;       // the heap's order was applied to the first pass itself (launch_tie_patch): only what it could not fix is searched again
     uint32_t tie_patched_host = 0;  // rankings of the last first pass that the heap's order changed
     hipStream_t spec_stream = nullptr;  // (= bg_stream)
@@ -390,6 +394,7 @@ struct amd_ivf {
     std::condition_variable fp32_gate_cv;
     int fp32_running = 0;
     uint64_t fp32_gate_next = 0, fp32_gate_serving = 0;  // (first come, first served)
+    uint64_t async_served[2] = {0, 0};  // tickets / passes of asynchronous pools that were shut down (amd_ivf_async_counts)
     double probed_len = 0;                 // expected length of the list a query probes: sum(len^2) / sum(len) (upload_lists)
     DevBuf d_lanes;                        // the fp32 lists in lane order (ScanArgs::lanes), built by the first fp32 dense round
     std::atomic<int> lanes_state{0};       // 0 not tried, 1 there, -1 not possible
@@ -3907,7 +3912,12 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
         // rounds gets its rows set aside now (the distance table lives in w_dist, which round 0 overwrites) and the heap runs on
         // a side stream under this pass.
         static const bool no_spec = getenv("AUNCEL_AMD_NO_TIE_SPECULATION") != nullptr;
-        constexpr uint32_t SPEC_CAP = 512, SPEC_NEAR = 64, SPEC_WINDOW = 2 * (12 + 144) + 14;
+        // (slots for the rankings whose first run is in reach: 512 for calls of up to 5000 queries -- about 400 of the bench workload's
+        // 5000 rankings take one -- and an eighth of the call beyond, so that larger calls, e.g. queued tickets served together, do not
+        // send what overflows through the second pass)
+        const uint32_t SPEC_CAP = n <= 5120 ? 512u : (uint32_t)(((n / 8 + 63) / 64) * 64);
+        constexpr uint32_t SPEC_NEAR = 64, SPEC_WINDOW = 2 * (12 + 144) + 14;
+        L->spec_cap = SPEC_CAP;
         L->spec_valid = false;
         const bool can_spec = !no_spec && L->spec_wanted && !L->given_keys && np_row == nlist && n <= L->dist_budget_floats / std::max<size_t>(nlist, 1) &&
                               heap_tie_order_lds((uint32_t)nlist, (uint32_t)nlist) <= 160 * 1024;
@@ -3976,14 +3986,14 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
         // searched again)
         size_t maxlist = 0;
         for (size_t l = 0; l < nlist; l++) maxlist = std::max<size_t>(maxlist, ix(L)->h_list_off[l + 1] - ix(L)->h_list_off[l]);
-        const size_t SCRATCH_FLOATS = std::min<size_t>((size_t)64 << 20, std::max<size_t>((size_t)8 << 20, (size_t)512 * 16 * ((maxlist + 1023) & ~(size_t)1023)));
+        const size_t SCRATCH_FLOATS = std::min<size_t>((size_t)64 << 20, std::max<size_t>((size_t)8 << 20, (size_t)L->spec_cap * 16 * ((maxlist + 1023) & ~(size_t)1023)));
         L->w_spec_scratch.ensure(SCRATCH_FLOATS * 4);
         base.run_ties = true;
         base.before_first_select = [L, nlist, set_online, SCRATCH_FLOATS]() {
             HIP_CHECK(hipStreamWaitEvent(L->stream, L->ev_spec_done, 0));
             TiePatchArgs ta{};
             ta.count = L->w_spec_count.as<uint32_t>();
-            ta.cap = 512;
+            ta.cap = L->spec_cap;
             ta.nlist = (uint32_t)nlist;
             ta.ncopy = (uint32_t)L->spec_ncopy;
             ta.key_stride = (uint32_t)nlist;
@@ -4013,7 +4023,7 @@ static void adaptive_slice(amd_ivf_t* L, const float* d_x, size_t id0, size_t n,
             uint32_t* q_free = counts + 8;
             uint32_t* q_wait = q_free + n;
             const auto patch_hook = base.before_first_select;
-            const uint32_t wait_cap = (uint32_t)std::min<size_t>(n, 512);  // (tie_collect_kernel hands out at most 512 slots)
+            const uint32_t wait_cap = (uint32_t)std::min<size_t>(n, L->spec_cap);  // (tie_collect_kernel hands out at most that many slots)
             base.split_free = q_free;
             base.split_wait = q_wait;
             base.split_counts = counts;
@@ -4916,8 +4926,24 @@ int amd_ivf_last_direct_out(amd_ivf_t* h);
 // workload).  A caller with more than one batch at hand gets that without threads of its own: submit returns a ticket at
 // once, the search runs on one of the handle's internal contexts (amd_ivf_clone: own stream and workspaces, the owner's index
 // data and resident queries), wait returns its status.  At most `depth` searches run at a time; further tickets queue.
+// what amd_ivf_submit_adaptive was asked for, kept next to the job so that a worker can see whether the ticket behind it in the queue
+// continues it (async_take_group)
+struct AdaptiveSpec {
+    size_t start = 0, n = 0, query_topk = 0;
+    float multipler = 0.f, std_m = 0.f;
+    const float* require_acc = nullptr;
+    const float* gt_D = nullptr;
+    int profile = 0, coarse_mode = 0;
+    uint64_t* my_nprobe = nullptr;
+    float* t_recalls = nullptr;
+    float* D = nullptr;
+    int64_t* I = nullptr;
+};
 struct AsyncJob {
     std::function<int(amd_ivf_t*)> run;
+    bool adaptive = false;
+    AdaptiveSpec spec;
+    uint32_t coalesced = 1;  // tickets the pass that served this one served
     int rc = 0;
     bool done = false;
     std::string error;
@@ -4928,6 +4954,7 @@ struct AsyncPool {
     std::mutex mu;
     std::condition_variable cv_job, cv_done;
     int running = 0, running_limit = 0;  // searches at a time: never more than the hardware queues of a priority class
+    uint64_t served_tickets = 0, served_passes = 0;
     const struct amd_ivf* owner = nullptr;
     std::deque<AsyncJob*> queue;
     std::map<uint64_t, std::unique_ptr<AsyncJob>> jobs;
@@ -4950,31 +4977,88 @@ static int async_running_limit(const AsyncPool* p) {
     return std::max(lim, 1);
 }
 
+// Tickets of amd_ivf_submit_adaptive that ONE pass can serve: the queue's next ticket continues the group when it asks for the same
+// search (parameters, require_acc / ground-truth arrays) over the resident queries right behind the group's, and its result buffers
+// lie right behind the group's in memory -- the group then is one search of the joined range into one buffer.  A pass over the
+// lists costs its bytes whatever the number of queries probing them (the scans are bound by the list stream), so two queued batches
+// of 5000 cost little more than one; every query's result is the reference's whatever batch it travels in (the parity suites).
+// Option "coalesce": tickets a group may hold (1: off).  The queue is only looked at, never waited on: a ticket without a
+// successor in the queue runs alone.
+static bool continues_group(const AdaptiveSpec& g, size_t g_n, const AdaptiveSpec& s, size_t K) {
+    return s.query_topk == g.query_topk && s.multipler == g.multipler && s.std_m == g.std_m && s.require_acc == g.require_acc &&
+           s.gt_D == g.gt_D && s.profile == g.profile && s.coarse_mode == g.coarse_mode && s.n == g.n && s.start == g.start + g_n &&
+           s.D == g.D + g_n * K && s.I == g.I + g_n * K && s.my_nprobe && s.t_recalls && g.my_nprobe && g.t_recalls;
+}
+static int run_adaptive_group(amd_ivf_t* c, const std::vector<AsyncJob*>& group) {
+    const AdaptiveSpec& g = group[0]->spec;
+    if (group.size() == 1)
+        return amd_ivf_search_adaptive(c, g.start, g.n, g.query_topk, g.multipler, g.std_m, g.require_acc, g.gt_D, g.profile, g.coarse_mode, g.my_nprobe,
+                                       g.t_recalls, g.D, g.I);
+    // my_nprobe / t_recalls are per-ticket arrays indexed by absolute query id: the joined search reads and writes a scratch pair that
+    // holds every ticket's own entries of its own range, and each ticket gets its range back
+    const size_t total = g.n * group.size(), end = g.start + total;
+    std::vector<uint64_t> np(end, 0);
+    std::vector<float> tr(end, 0.f);
+    for (const AsyncJob* j : group) {
+        std::copy(j->spec.my_nprobe + j->spec.start, j->spec.my_nprobe + j->spec.start + j->spec.n, np.begin() + j->spec.start);
+        std::copy(j->spec.t_recalls + j->spec.start, j->spec.t_recalls + j->spec.start + j->spec.n, tr.begin() + j->spec.start);
+    }
+    const int rc = amd_ivf_search_adaptive(c, g.start, total, g.query_topk, g.multipler, g.std_m, g.require_acc, g.gt_D, g.profile, g.coarse_mode, np.data(),
+                                           tr.data(), g.D, g.I);
+    for (const AsyncJob* j : group) {
+        std::copy(np.begin() + j->spec.start, np.begin() + j->spec.start + j->spec.n, j->spec.my_nprobe + j->spec.start);
+        std::copy(tr.begin() + j->spec.start, tr.begin() + j->spec.start + j->spec.n, j->spec.t_recalls + j->spec.start);
+    }
+    return rc;
+}
+
 static void async_worker(AsyncPool* p, size_t i) {
     for (;;) {
-        AsyncJob* j = nullptr;
+        std::vector<AsyncJob*> group;
         {
             std::unique_lock<std::mutex> lk(p->mu);
             p->cv_job.wait(lk, [&] { return p->stop || (!p->queue.empty() && p->running < async_running_limit(p)); });
             if (p->stop || p->queue.empty()) return;  // (the handle is going away: searches not yet started are dropped)
-            j = p->queue.front();
+            group.push_back(p->queue.front());
             p->queue.pop_front();
+            if (group[0]->adaptive && p->owner) {
+                const size_t limit = (size_t)std::max(1.0, p->owner->opt.get(OPT_COALESCE, 1));
+                const size_t K = p->owner->tuner_max_topk;
+                while (group.size() < limit && !p->queue.empty() && p->queue.front()->adaptive &&
+                       continues_group(group[0]->spec, group[0]->spec.n * group.size(), p->queue.front()->spec, K)) {
+                    group.push_back(p->queue.front());
+                    p->queue.pop_front();
+                }
+            }
             p->running++;
         }
         amd_ivf_t* c = p->ctx[i];
-        const int rc = j->run(c);
+        const int rc = group[0]->adaptive ? run_adaptive_group(c, group) : group[0]->run(c);
         std::string err = rc ? std::string(amd_ivf_last_error()) : std::string();
-        amd_ivf_last_timing(c, j->timing);
-        amd_ivf_last_scan_min_bytes(c, &j->timing[8]);
-        amd_ivf_last_round_hints(c, j->diag);
-        amd_ivf_last_tie_redone(c, &j->diag[2]);
-        j->diag[3] = (uint64_t)amd_ivf_last_direct_out(c);
+        double timing[9];
+        uint64_t diag[4];
+        amd_ivf_last_timing(c, timing);
+        amd_ivf_last_scan_min_bytes(c, &timing[8]);
+        amd_ivf_last_round_hints(c, diag);
+        amd_ivf_last_tie_redone(c, &diag[2]);
+        diag[3] = (uint64_t)amd_ivf_last_direct_out(c);
+        // (the pass's kernel times, bytes and launch counts are shared out evenly among the tickets it served -- sums over tickets stay
+        // sums over passes; its wall time, slot efficiency and round count are every ticket's)
+        const double share = 1.0 / (double)group.size();
         {
             std::lock_guard<std::mutex> lk(p->mu);
-            j->error = std::move(err);
-            j->rc = rc;
-            j->done = true;
+            for (size_t t = 0; t < group.size(); t++) {
+                AsyncJob* j = group[t];
+                for (int f = 0; f < 9; f++) j->timing[f] = (f == 3 || f == 6 || f == 7) ? timing[f] : timing[f] * share;
+                for (int f = 0; f < 4; f++) j->diag[f] = f == 3 ? diag[f] : (t == 0 ? diag[f] : 0);
+                j->coalesced = (uint32_t)group.size();
+                j->error = err;
+                j->rc = rc;
+                j->done = true;
+            }
             p->running--;
+            p->served_tickets += group.size();
+            p->served_passes++;
         }
         p->cv_done.notify_all();
         p->cv_job.notify_one();
@@ -5015,6 +5099,7 @@ static AsyncPool* async_pool(amd_ivf* h) {
 static void async_shutdown(amd_ivf* h) {
     AsyncPool* p = h->async;
     if (!p) return;
+    h->async_served[0] += p->served_tickets, h->async_served[1] += p->served_passes;
     h->async = nullptr;
     h->async_ctx.clear();
     {
@@ -5027,10 +5112,14 @@ static void async_shutdown(amd_ivf* h) {
     delete p;
 }
 
-static uint64_t async_enqueue(amd_ivf* h, std::function<int(amd_ivf_t*)> run) {
+static uint64_t async_enqueue(amd_ivf* h, std::function<int(amd_ivf_t*)> run, const AdaptiveSpec* spec = nullptr) {
     AsyncPool* p = async_pool(h);
     std::unique_ptr<AsyncJob> j(new AsyncJob);
     j->run = std::move(run);
+    if (spec) {
+        j->adaptive = true;
+        j->spec = *spec;
+    }
     uint64_t id;
     {
         std::lock_guard<std::mutex> lk(p->mu);
@@ -5068,10 +5157,11 @@ int amd_ivf_submit_adaptive(amd_ivf_t* h, size_t start, size_t n, size_t query_t
     OWNER_ONLY(h);
     use_device(h);
     if (start + n > h->n_resident) throw EngineError("resident query range out of bounds");
-    *ticket = async_enqueue(h, [=](amd_ivf_t* c) {
-        return amd_ivf_search_adaptive(c, start, n, query_topk, multipler, std_m, require_acc, gt_D, profile, coarse_mode, my_nprobe,
-                                       t_recalls, D, I);
-    });
+    AdaptiveSpec spec;
+    spec.start = start, spec.n = n, spec.query_topk = query_topk, spec.multipler = multipler, spec.std_m = std_m;
+    spec.require_acc = require_acc, spec.gt_D = gt_D, spec.profile = profile, spec.coarse_mode = coarse_mode;
+    spec.my_nprobe = my_nprobe, spec.t_recalls = t_recalls, spec.D = D, spec.I = I;
+    *ticket = async_enqueue(h, nullptr, &spec);
     API_END
 }
 
@@ -5103,6 +5193,18 @@ int amd_ivf_submit_search_resident_preassigned(amd_ivf_t* h, size_t start, size_
     if (start + n > h->n_resident) throw EngineError("resident query range out of bounds");
     *ticket = async_enqueue(h, [=](amd_ivf_t* c) { return amd_ivf_search_resident_preassigned(c, start, n, k, nprobe, keys, D, I); });
     API_END
+}
+
+int amd_ivf_async_counts(amd_ivf_t* h, uint64_t out[2]) {
+    out[0] = out[1] = 0;
+    if (h && h->async) {
+        std::lock_guard<std::mutex> lk(h->async->mu);
+        out[0] = h->async->served_tickets + h->async_served[0];
+        out[1] = h->async->served_passes + h->async_served[1];
+    } else if (h) {
+        out[0] = h->async_served[0], out[1] = h->async_served[1];
+    }
+    return 0;
 }
 
 int amd_ivf_wait(amd_ivf_t* h, uint64_t ticket, double timing[9], uint64_t diag[4]) {

@@ -460,6 +460,9 @@ def main():
     ap.add_argument("--runner", choices=["async", "threads"], default="async",
                     help="how --in-flight batches are kept in flight: async = ONE caller thread through amd_ivf_submit_adaptive / "
                          "amd_ivf_wait (the engine's internal contexts), threads = one host thread + amd_ivf_clone context per batch")
+    ap.add_argument("--coalesce", type=int, default=1,
+                    help="async runner: queued steps over adjacent resident slices that the engine may serve in ONE pass over the lists "
+                         "(option \"coalesce\" of include/auncel_amd.h; every step stays one amd_ivf_submit_adaptive call with its own result)")
     ap.add_argument("--in-flight", type=int, default=6,
                     help="batches kept in flight per GPU, each from its own host thread on its own search context "
                          "(amd_ivf_clone); 1 = one batch at a time")
@@ -667,17 +670,19 @@ def main():
     # the 6 MB of (D, I) of a step come back by direct DMA instead of through the runtime's staging copies
     # (async: as many tickets again as searches run at a time wait in the engine's queue, so that a context that finishes out of
     # order finds its next search there instead of idling until the caller has collected the oldest)
-    nslots = 2 * nfl if use_async else nfl
+    coalesce = max(1, args.coalesce) if use_async else 1
+    if "AUNCEL_AMD_COALESCE" not in os.environ:
+        h.set_option("coalesce", coalesce)
+    nslots = 2 * nfl * coalesce if use_async else nfl
 
     def result_buffers(count):
-        bufs = []
-        for _ in range(count):
-            if args.pinned_out:
-                bufs.append((torch.empty((ses, K), dtype=torch.float32).pin_memory().numpy(),
-                             torch.empty((ses, K), dtype=torch.int64).pin_memory().numpy()))
-            else:
-                bufs.append(None)
-        return bufs
+        """`count` (D, I) pairs cut from ONE page-locked block each, so that the buffers of consecutive steps follow each other in
+        memory: what lets the engine serve queued tickets over adjacent query ranges in one pass (option "coalesce")"""
+        if not args.pinned_out:
+            return [None] * count
+        Dall = torch.empty((count, ses, K), dtype=torch.float32).pin_memory().numpy()
+        Iall = torch.empty((count, ses, K), dtype=torch.int64).pin_memory().numpy()
+        return [(Dall[i], Iall[i]) for i in range(count)]
 
     outs = result_buffers(nslots)  # one pair per batch in flight (or queued)
     async_outs = outs if use_async else None  # (the single-caller leg of a threads run makes its own)
@@ -792,10 +797,12 @@ def main():
     acc = {}
     kept_timed = StepResults()
     barrier()
+    counts0 = h.async_counts()
     t0 = time.perf_counter()
     run_steps(args.steps, acc, kept_timed)
     barrier()
     elapsed = time.perf_counter() - t0
+    counts1 = h.async_counts()
     kept_timed.collect(len(step_bufs) if step_bufs else 1, ses)  # (after the clock: copies of the distinct results, the buffers are free again)
     per_rank_value = [ses * args.steps / elapsed]
     if world > 1:
@@ -1083,7 +1090,9 @@ def main():
             # scan grids of the device-chained rounds are sized from the previous search's counts (+ 12 %); a round that needs
             # more runs on fewer workgroups than it would have been given (it is still complete: the workgroups stride)
             "round_hint": {"launches_sized_by_a_hint": int(acc.get("hinted_launches", 0)), "hint_too_small": int(acc.get("short_hints", 0))},
-            "in_flight": nfl,
+            "in_flight": nfl, "coalesce": coalesce, "queries_searched_again_in_timed_region": int(acc.get("tie_redone", 0)),
+            # (timed region: steps submitted, and the passes over the lists that served them)
+            "tickets_and_passes": {"tickets": counts1[0] - counts0[0], "passes": counts1[1] - counts0[1]} if use_async else None,
             "runner": ("one caller thread: amd_ivf_submit_adaptive / amd_ivf_wait, the engine's internal contexts" if use_async
                        else "one host thread and one amd_ivf_clone context per batch in flight" if nfl > 1 else "one synchronous call at a time"),
             "host_wait": "blocking events" if os.environ.get("AUNCEL_AMD_BLOCKING_SYNC", "0") not in ("", "0") else "spin", "host_cores": host_cores(), "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "stagger_ms": stagger_s * 1e3,

@@ -345,6 +345,9 @@ int amd_ivf_submit_coarse_resident(amd_ivf_t* h, size_t start, size_t n, size_t 
 int amd_ivf_submit_search_resident_preassigned(amd_ivf_t* h, size_t start, size_t n, size_t k, size_t nprobe, const int64_t* keys,
                                                float* D, int64_t* I, uint64_t* ticket);
 int amd_ivf_wait(amd_ivf_t* h, uint64_t ticket, double timing[9], uint64_t diag[4]);
+/* tickets the asynchronous entry points have served since the handle was made, and the passes that served them (fewer where
+ * option "coalesce" joined queued tickets) */
+int amd_ivf_async_counts(amd_ivf_t* h, uint64_t out[2]);
 
 /* Arithmetic the list scan of the last search ran in.  All three produce the reference's fp32 distance bit for
  * bit (utils_simd.cpp:391-443 order); the engine picks the cheapest one the data allows:
@@ -394,6 +397,12 @@ int amd_ivf_set_byte_codes(amd_ivf_t* h, int enable);
  *                     first fp32 search), 0 from the rows
  *   "fp32_in_flight"  searches of >= 256 queries in fp32 arithmetic that run on the index at a time; further ones      4
  *                     wait inside the call (four is the measured optimum; 0: no limit)
+ *   "coalesce"        amd_ivf_submit_adaptive: how many QUEUED tickets one pass over the lists may serve together --   1
+ *                     tickets that ask for the same search (parameters, require_acc / ground-truth arrays) over resident
+ *                     ranges that follow each other, with result buffers that follow each other in memory.  A pass is
+ *                     bound by the list stream, not by the queries probing it, so two queued 5000-query batches cost
+ *                     little more than one; every query's result is what its own call would have returned.  Only
+ *                     tickets already waiting are joined: a ticket alone in the queue runs alone
  * amd_ivf_set_option(h, key, NAN) returns the key to "unset".  May be called while search contexts of the index are searching: a
  * search reads what shapes its launches once, when it starts, so the change takes effect with the searches that start after it. */
 int amd_ivf_set_option(amd_ivf_t* h, const char* key, double value);
