@@ -345,6 +345,24 @@ def test_config2_shape_six_searches_in_flight(setup, byte_codes, cen_step):
     while pend:
         finish()
     assert checked == 24
+    # option "coalesce": queued tickets over adjacent slices with adjacent result buffers are served by one pass over the lists --
+    # every ticket still gets exactly its own call's result
+    h.set_option("coalesce", 2)
+    Dall = np.empty((8, ses, K), np.float32)
+    Iall = np.empty((8, ses, K), np.int64)
+    t0, p0 = h.async_counts()
+    for sn in range(16):
+        if len(pend) == 8:
+            finish()
+        sl = sn % nsl
+        np_ = np.zeros(nall, dtype=np.uint64)
+        tr_ = np.zeros(nall, dtype=np.float32)
+        pend.append((h.submit_adaptive(ts + sl * ses, ses, topk, mult, sm, req, np_, tr_, out=(Dall[sn % 8], Iall[sn % 8])), sl, np_))
+    while pend:
+        finish()
+    t1, p1 = h.async_counts()
+    assert checked == 40 and t1 - t0 == 16 and p1 - p0 < 16  # (some tickets travelled together)
+    h.set_option("coalesce", 1)
     allnp = np.concatenate([a[2] for a in alone.values()])
     print(f"config-2 shape, byte codes {byte_codes}, centroid step {cen_step}: rankings the heap changed (4 slices alone) {patched}, "
           f"my_nprobe mean {allnp.mean():.1f}, share beyond round 0 (> 12) {float((allnp > 12).mean()):.3f}, max {int(allnp.max())}")
