@@ -210,7 +210,9 @@ struct WantHistory {
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    uint64_t touch = 0;  // calls of ensure(): every writer of a workspace sizes it first (coarse_dev's tail book-keeping)
     void ensure(size_t bytes) {
+        touch++;
         if (bytes <= cap) return;
         if (p) (void)hipFree(p);
         p = nullptr;
@@ -432,6 +434,14 @@ struct amd_ivf {
     DevBuf w_x, w_dist, w_items, w_pair_query, w_pair_out, w_seg_off, w_seg_list, w_seg_count, w_qsel;
     DevBuf w_heap_val, w_heap_ref, w_stage, w_nscan, w_done, w_pre_val, w_stoped, w_dtb, w_D, w_I;
     DevBuf w_cdis, w_ckeys, w_stats, w_error, w_misc, w_misc2, w_misc3, w_rawptrs, w_sub_off;
+    struct CoarseTail {  // what the last prefix ranking left behind the prefix of every row of w_cdis / w_ckeys (coarse_dev)
+        bool valid = false;
+        const void* dis = nullptr;
+        const void* keys = nullptr;
+        size_t prefix = 0, nprobe = 0, rows = 0;
+        int metric = 0;
+        uint64_t touch_dis = 0, touch_keys = 0;
+    } coarse_tail;
     DevBuf c_heap_val, c_heap_ref, c_stage, c_nscan, c_done, c_seg_off, c_seg_list, c_seg_count;
     float centroid_norm_max = 0.f;  // max |c|^2 over the centroids, rounded up
     DevBuf d_cinfo;                 // range of the centroid table (launch_amax): the fp16 form of the approximate coarse ranking
@@ -1928,8 +1938,22 @@ void coarse_dev(amd_ivf* h, const float* d_x, size_t n, size_t nprobe, int mode,
             ra.error = reinterpret_cast<uint32_t*>(h->w_misc.as<unsigned long long>() + STATS_ROWS * 4);
             launch_replay(ra, s);
         } else {
+            // The entries behind the prefix come out as (neutral, -1) -- and stay so: when the ranking of the search before went into
+            // the same buffers with the same prefix and nothing else has sized (i.e. may have written) them since, they are not written
+            // again.  (Writers inside the prefix -- the heap's order, the patch -- do not matter.)
+            bool tail_neutral = false;
+            if (sort_rows_ranks_a_prefix((uint32_t)nlist, (uint32_t)nprobe, (uint32_t)prefix) && c0 == 0 && m == n && d_out_dis == h->w_cdis.p &&
+                d_out_keys == h->w_ckeys.p) {
+                amd_ivf::CoarseTail& ct = h->coarse_tail;
+                tail_neutral = ct.valid && ct.dis == d_out_dis && ct.keys == d_out_keys && ct.prefix == prefix && ct.nprobe == nprobe && ct.rows >= n &&
+                               ct.metric == h->metric && ct.touch_dis + 1 == h->w_cdis.touch && ct.touch_keys + 1 == h->w_ckeys.touch &&
+                               !getenv("AUNCEL_AMD_WRITE_TAILS");
+                ct = amd_ivf::CoarseTail{true, d_out_dis, d_out_keys, prefix, nprobe, tail_neutral ? ct.rows : n, h->metric, h->w_cdis.touch, h->w_ckeys.touch};
+            } else {
+                h->coarse_tail.valid = false;
+            }
             launch_sort_rows(h->w_dist.as<float>(), (uint32_t)m, (uint32_t)nlist, (uint32_t)nprobe, h->metric,
-                             d_out_dis + c0 * nprobe, d_out_keys + c0 * nprobe, s, (uint32_t)prefix);
+                             d_out_dis + c0 * nprobe, d_out_keys + c0 * nprobe, s, (uint32_t)prefix, tail_neutral);
             if (heap_ties) {
                 if (!h->w_tie_rows.p) {
                     h->w_tie_rows.ensure(8);

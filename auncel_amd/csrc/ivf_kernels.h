@@ -523,8 +523,9 @@ constexpr uint32_t ERR_LOG_OVERFLOW = 5;  // a query admitted more candidates th
 // ---------------------------------------------------------------------------- coarse helpers
 // full ascending/descending sort of each row of `dis` (nlist entries) keeping the first nprobe
 // prefix != 0: only the first `prefix` entries are needed in order; the rest may come out as (neutral, -1)
+bool sort_rows_ranks_a_prefix(uint32_t nlist, uint32_t nprobe, uint32_t prefix);
 void launch_sort_rows(const float* dis, uint32_t nq, uint32_t nlist, uint32_t nprobe, int metric, float* out_dis,
-                      int64_t* out_keys, hipStream_t s, uint32_t prefix = 0);
+                      int64_t* out_keys, hipStream_t s, uint32_t prefix = 0, bool tail_is_neutral = false);
 
 // Rows whose first `nout` entries hold (or end inside) a run of exactly equal distances are re-ranked by the reference's
 // own heap (utils.cpp:417-490, Heap.h:88-142,295-322), whose order inside such a run depends on its history; *nrows

@@ -1849,7 +1849,7 @@ __device__ __forceinline__ void bitonic_sort_wg(unsigned long long* buf, uint32_
 // sort_rows_kernel; entries [prefix, nprobe) come out as (neutral distance, -1).
 template <bool Ascending>
 __global__ __launch_bounds__(256) void sort_prefix_kernel(const float* dis, uint32_t nlist, uint32_t nprobe, uint32_t prefix, uint32_t S,
-                                                           float* out_dis, int64_t* out_keys) {
+                                                           float* out_dis, int64_t* out_keys, uint32_t write_end) {
     __shared__ unsigned long long buf[2048];
     __shared__ uint32_t red[2][4];
     __shared__ uint32_t s_cnt;
@@ -1920,7 +1920,9 @@ __global__ __launch_bounds__(256) void sort_prefix_kernel(const float* dis, uint
     if (S == 512) bitonic_sort_wg<2>(buf, tid);
     else if (S == 1024) bitonic_sort_wg<4>(buf, tid);
     else bitonic_sort_wg<8>(buf, tid);
-    for (uint32_t i = tid; i < nprobe; i += 256) {
+    // (write_end < nprobe: the entries behind it hold (neutral, -1) already -- left by the ranking of the search before, which had the
+    // same prefix: 36 of the 48 KB a ranking of 4096 takes, 245 MB per 5000 rankings that nothing reads)
+    for (uint32_t i = tid; i < write_end; i += 256) {
         float dv = Ascending ? FLT_MAX : -FLT_MAX;
         int64_t id = -1;
         if (i < prefix && i < C) {
@@ -2148,13 +2150,18 @@ void launch_scatter_rows(const void* in, const uint32_t* idx, uint32_t m, uint32
 }
 
 // prefix: 0 = rank all nprobe entries; else only the first `prefix` are needed (see sort_prefix_kernel)
+bool sort_rows_ranks_a_prefix(uint32_t nlist, uint32_t nprobe, uint32_t prefix) {
+    return prefix && prefix < nprobe && prefix <= 2048 && prefix <= nlist && nlist <= 4096;
+}
+// tail_is_neutral: the entries [prefix, nprobe) of every row are (neutral, -1) already (the caller's book-keeping: coarse_dev)
 void launch_sort_rows(const float* dis, uint32_t nq, uint32_t nlist, uint32_t nprobe, int metric, float* out_dis,
-                      int64_t* out_keys, hipStream_t s, uint32_t prefix) {
+                      int64_t* out_keys, hipStream_t s, uint32_t prefix, bool tail_is_neutral) {
     if (nq == 0) return;
-    if (prefix && prefix < nprobe && prefix <= 2048 && prefix <= nlist && nlist <= 4096) {
+    if (sort_rows_ranks_a_prefix(nlist, nprobe, prefix)) {
         const uint32_t S = prefix <= 384 ? 512u : prefix <= 1024 ? 1024u : 2048u;  // (slots sorted: >= prefix, with room for the bisection to stop early)
-        if (metric == METRIC_L2) LAUNCH(sort_prefix_kernel<true>, dim3(nq), dim3(256), 0, s, dis, nlist, nprobe, prefix, S, out_dis, out_keys);
-        else LAUNCH(sort_prefix_kernel<false>, dim3(nq), dim3(256), 0, s, dis, nlist, nprobe, prefix, S, out_dis, out_keys);
+        const uint32_t write_end = tail_is_neutral ? prefix : nprobe;
+        if (metric == METRIC_L2) LAUNCH(sort_prefix_kernel<true>, dim3(nq), dim3(256), 0, s, dis, nlist, nprobe, prefix, S, out_dis, out_keys, write_end);
+        else LAUNCH(sort_prefix_kernel<false>, dim3(nq), dim3(256), 0, s, dis, nlist, nprobe, prefix, S, out_dis, out_keys, write_end);
         return;
     }
     uint32_t npow2 = 2;
