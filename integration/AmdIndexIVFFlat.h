@@ -16,6 +16,7 @@
 #include <string>
 #include <vector>
 
+#include "../AuxIndexStructures.h"
 #include "../IndexFlat.h"
 #include "../IndexIVFFlat.h"
 #include "../FaissAssert.h"
@@ -108,6 +109,68 @@ struct AmdIndexIVFFlat : IndexIVFFlat {
         indexIVF_stats.ndis += st[2];
         indexIVF_stats.nheap_updates += st[3];
     }
+
+    // The reference's second override point (IndexIVF.h:228-229): a scanner with all five virtuals of IndexIVF.h:316-358.  The
+    // reference's own scans the codes at whatever pointer it is handed (IndexIVFFlat.cpp:117-155); the codes live in HBM here, so the
+    // pointer names a run of the current list -- any run: tests/test_lowlevel_ivf.cpp:426-564 deals lists (and the mirror's driver
+    // halves of lists) to threads.  Every call leases a search context for its duration, as search_preassigned does.
+    struct Scanner : InvertedListScanner {
+        const AmdIndexIVFFlat* ix;
+        bool store_pairs;
+        std::vector<float> q;
+        idx_t list_no;
+        Scanner(const AmdIndexIVFFlat* ix_, bool sp) : ix(ix_), store_pairs(sp), list_no(-1) {}
+        void set_query(const float* query) override { q.assign(query, query + ix->d); }
+        void set_list(idx_t l, float) override { list_no = l; }
+        size_t offset_of(size_t n, const uint8_t* codes) const {
+            FAISS_THROW_IF_NOT_MSG(list_no >= 0, "set_list first");
+            const uint8_t* base = ix->invlists->get_codes(list_no);
+            const size_t sz = ix->invlists->list_size(list_no);
+            FAISS_THROW_IF_NOT_MSG(n == 0 || (codes >= base && codes < base + sz * ix->code_size && (size_t)(codes - base) % ix->code_size == 0),
+                                   "codes must point at a code of the current list");
+            const size_t offset = n ? (size_t)(codes - base) / ix->code_size : 0;
+            FAISS_THROW_IF_NOT_MSG(offset + n <= sz, "codes run past the end of the current list");
+            return offset;
+        }
+        float distance_to_code(const uint8_t* code) const override {
+            const size_t offset = offset_of(1, code);
+            Lease lease(ix, false, false);
+            float dis = 0;
+            check(amd_ivf_distance_to_code(lease.ctx, q.data(), (size_t)list_no, offset, &dis));
+            return dis;
+        }
+        size_t scan_codes(size_t n, const uint8_t* codes, const idx_t* ids, float* simi, idx_t* idxi, size_t k) const override {
+            const size_t offset = offset_of(n, codes);
+            if (n == 0) return 0;
+            size_t nup = 0;
+            Lease lease(ix, false, false);
+            if (store_pairs || ids == ix->invlists->get_ids(list_no) + offset) {
+                check(amd_ivf_scan_codes_at(lease.ctx, q.data(), (size_t)list_no, offset, n, store_pairs ? 1 : 0, k, simi,
+                                            reinterpret_cast<int64_t*>(idxi), &nup));
+                return nup;
+            }
+            // a caller-owned id array: the heap's entries travel as tags, the admitted ones come back as positions (ids[j])
+            std::vector<int64_t> lab(k);
+            for (size_t i = 0; i < k; i++) lab[i] = -(int64_t)i - 2;
+            check(amd_ivf_scan_codes_at(lease.ctx, q.data(), (size_t)list_no, offset, n, 1, k, simi, lab.data(), &nup));
+            std::vector<idx_t> old(idxi, idxi + k);
+            for (size_t i = 0; i < k; i++) idxi[i] = lab[i] < 0 ? old[(size_t)(-lab[i] - 2)] : ids[lab[i] & 0xffffffffll];
+            return nup;
+        }
+        void scan_codes_range(size_t n, const uint8_t* codes, const idx_t* ids, float radius, RangeQueryResult& res) const override {
+            const size_t offset = offset_of(n, codes);
+            if (n == 0) return;
+            size_t count = 0;
+            Lease lease(ix, false, false);
+            check(amd_ivf_scan_codes_range(lease.ctx, q.data(), (size_t)list_no, offset, n, radius, &count));
+            if (!count) return;
+            std::vector<uint32_t> pos(count);
+            std::vector<float> dis(count);
+            check(amd_ivf_scan_codes_range_results(lease.ctx, pos.data(), dis.data()));
+            for (size_t i = 0; i < count; i++) res.add(dis[i], store_pairs ? (idx_t)((idx_t)list_no << 32 | (idx_t)pos[i]) : ids[pos[i]]);
+        }
+    };
+    InvertedListScanner* get_InvertedListScanner(bool store_pairs = false) const override { return new Scanner(this, store_pairs); }
 
    private:
     // Device state.  search_preassigned is const and re-entrant like the reference's.  Everything below is guarded by `mu`.

@@ -6,6 +6,7 @@
 //   * Error_sys::sys_train (the training branch, traces after Trace::SB),
 //   * Error_sys::search, one query per call as eval/bound.cpp:380-386 does (tune branch: D, I, my_nprobe, t_recalls).
 // Built by oracle/Makefile (target subclass) in the container that has the reference; the binary travels to the GPU box.
+#include <memory>
 #include "Auncel/gpu_amd/AmdIndexIVFFlat.h"
 
 #include <cstdio>
@@ -93,6 +94,62 @@ int main(int argc, char** argv) {
         ref.search_preassigned(nq, xq.data(), 10, ck.data(), cd.data(), D1.data(), I1.data(), true);
         amd.search_preassigned(nq, xq.data(), 10, ck.data(), cd.data(), D2.data(), I2.data(), true);
         expect(same(D1, D2) && same(I1, I2), "search_preassigned, store_pairs");
+    }
+
+    // ---- get_InvertedListScanner, the second override point: the subclass's scanner next to the reference's own IVFFlatScanner on
+    // the same lists -- whole lists, lists in two halves, single codes, the range scan (tests/test_lowlevel_ivf.cpp:82-220,426-564)
+    {
+        const size_t k = 10, np = 8;
+        std::vector<float> cd(nq * np);
+        std::vector<idx_t> ck(nq * np);
+        q1.search(nq, xq.data(), np, cd.data(), ck.data());
+        bool heaps = true, pairs = true, single = true, ranges = true;
+        for (int sp = 0; sp < 2; sp++) {
+            std::unique_ptr<InvertedListScanner> a(ref.get_InvertedListScanner(sp != 0)), b(amd.get_InvertedListScanner(sp != 0));
+            for (size_t i = 0; i < 6; i++) {
+                std::vector<float> s1(k), s2(k);
+                std::vector<idx_t> l1(k), l2(k);
+                maxheap_heapify(k, s1.data(), l1.data());
+                maxheap_heapify(k, s2.data(), l2.data());
+                a->set_query(xq.data() + i * d);
+                b->set_query(xq.data() + i * d);
+                RangeSearchResult r1(1), r2(1);
+                RangeSearchPartialResult p1(&r1), p2(&r2);
+                RangeQueryResult& qr1 = p1.new_result(0);
+                RangeQueryResult& qr2 = p2.new_result(0);
+                float radius = 0;
+                for (size_t p = 0; p < np; p++) {
+                    const idx_t key = ck[i * np + p];
+                    const size_t sz = key < 0 ? 0 : ref.invlists->list_size(key);
+                    if (!sz) continue;
+                    a->set_list(key, cd[i * np + p]);
+                    b->set_list(key, cd[i * np + p]);
+                    const size_t half = sz / 2;
+                    size_t u1 = 0, u2 = 0;
+                    // (the reference's lists and the subclass's hold the same codes in the same order: same adds)
+                    u1 += a->scan_codes(half, ref.invlists->get_codes(key), ref.invlists->get_ids(key), s1.data(), l1.data(), k);
+                    u1 += a->scan_codes(sz - half, ref.invlists->get_codes(key) + half * ref.code_size, ref.invlists->get_ids(key) + half, s1.data(), l1.data(), k);
+                    u2 += b->scan_codes(half, amd.invlists->get_codes(key), amd.invlists->get_ids(key), s2.data(), l2.data(), k);
+                    u2 += b->scan_codes(sz - half, amd.invlists->get_codes(key) + half * amd.code_size, amd.invlists->get_ids(key) + half, s2.data(), l2.data(), k);
+                    (sp ? pairs : heaps) &= u1 == u2 && same(s1, s2) && same(l1, l2);
+                    single &= a->distance_to_code(ref.invlists->get_codes(key) + (sz - 1) * ref.code_size) ==
+                              b->distance_to_code(amd.invlists->get_codes(key) + (sz - 1) * amd.code_size);
+                    if (p == 0) radius = s1[0];  // (the worst of the best ten so far: keeps a handful per list)
+                    a->scan_codes_range(half, ref.invlists->get_codes(key), ref.invlists->get_ids(key), radius, qr1);
+                    a->scan_codes_range(sz - half, ref.invlists->get_codes(key) + half * ref.code_size, ref.invlists->get_ids(key) + half, radius, qr1);
+                    b->scan_codes_range(half, amd.invlists->get_codes(key), amd.invlists->get_ids(key), radius, qr2);
+                    b->scan_codes_range(sz - half, amd.invlists->get_codes(key) + half * amd.code_size, amd.invlists->get_ids(key) + half, radius, qr2);
+                }
+                p1.finalize();
+                p2.finalize();
+                ranges &= r1.lims[1] == r2.lims[1] && std::memcmp(r1.labels, r2.labels, r1.lims[1] * sizeof(idx_t)) == 0 &&
+                          std::memcmp(r1.distances, r2.distances, r1.lims[1] * sizeof(float)) == 0;
+            }
+        }
+        expect(heaps, "scanner: scan_codes over list halves, heaps and update counts as the reference's scanner");
+        expect(pairs, "scanner: the same with store_pairs (labels count from the half's first code)");
+        expect(single, "scanner: distance_to_code");
+        expect(ranges, "scanner: scan_codes_range over list halves, results in the reference's order");
     }
 
     // ---- the reference's IndexShards (threaded: one WorkerThread per shard, IndexShards.cpp:261-311) over two shards that split the
