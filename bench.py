@@ -1377,7 +1377,8 @@ def main():
                 t0 = time.time()
                 for line in bench_configs.run_config(torch, capi, dev, c, npb, 64, 0 if args.no_cpu or args.no_ref else 2000, log):
                     oc.append(line)
-                    log(f"other config {c} nprobe {line['nprobe']}: {line['value'] / 1e6:.3f} M q/s, {line['ms_per_batch']:.2f} ms per batch of {line['batch']}, "
+                    log(f"other config {c} nprobe {line['nprobe']}: {line['value'] / 1e6:.3f} M q/s one call at a time ({(line.get('in_flight') or {}).get('value', 0) / 1e6:.3f} with "
+                        f"{(line.get('in_flight') or {}).get('searches_at_a_time')} at a time), {line['ms_per_batch']:.2f} ms per batch of {line['batch']}, "
                         f"recall@{line['k']} {line['recall_at_k']:.4f}, == reference: {line['gpu_equals_reference']}, == CPU restatement: "
                         f"{line['gpu_equals_cpu_on_sample']} ({time.time() - t0:.0f}s)")
             out["other_configs"] = oc

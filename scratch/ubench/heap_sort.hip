@@ -296,6 +296,75 @@ __device__ inline void heapsort_v5(HeapEnt* a, uint32_t n, uint32_t* out_id, int
     }
 }
 
+// ---- v6: v5 with the ticks ordered by the LDS pipeline alone: a wave's LDS instructions execute in the order they were issued, so a
+// later tick's reads see an earlier tick's writes of any lane without waiting for the writes to complete -- only the compiler has to
+// keep the order (no fence, no s_waitcnt behind the stores)
+__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
+__device__ unsigned long long g_ticks6;
+__device__ __forceinline__ void walk_step6(uint2* a2w, const uint4* a4, uint32_t& hole, float Lv, uint32_t Lid, uint32_t P) {
+    const uint32_t pr = hole < P ? hole : P;
+    const uint4 ch = a4[pr];
+    const float c1v = __uint_as_float(ch.x), c2v = __uint_as_float(ch.z);
+    const bool left = c1v > c2v;  // the right one between equals (Heap.h:100)
+    const float cv = left ? c1v : c2v;
+    const uint32_t cid = left ? ch.y : ch.w;
+    const bool done = Lv > cv;
+    a2w[hole] = make_uint2(__float_as_uint(done ? Lv : cv), done ? Lid : cid);
+    const uint32_t nh = (hole << 1) | (left ? 0u : 1u);
+    hole = done ? 0u : nh;
+}
+__device__ inline void heapsort_v6(HeapEnt* a, uint32_t n, uint32_t* out_id, int lane) {
+    const float NEG = -__builtin_inff(), POS = __builtin_inff();
+    uint2* a2w = reinterpret_cast<uint2*>(a);
+    const uint4* a4 = reinterpret_cast<const uint4*>(a);
+    const uint32_t P = (n >> 1) + 1;
+    if (lane < 3) a2w[n + 1 + lane] = make_uint2(__float_as_uint(NEG), 0xffffffffu);
+    if (lane == 0) a2w[0] = make_uint2(__float_as_uint(POS), 0xffffffffu);
+    lds_order();
+    uint32_t hole = 0, Lid = 0;
+    float Lv = POS;
+    uint32_t t = 0, nticks = 0;
+    bool create = true;  // (nothing in flight)
+    while (t < n) {
+        const uint32_t sc = n - t;
+        if (create) {
+            // ---- the tick that starts pop t: its lane takes the entry of slot sc and stands on the root
+            const bool mine = (uint32_t)lane == (t & 31u);
+            const uint2 ls = a2w[sc];
+            const uint2 root = a2w[1];
+            // (slot sc keeps its entry while its own walk is under way -- the walk may meet it as a child, Heap.h:97-107 -- and
+            // the slot the pop BEFORE took its entry from leaves the heap for good now: nothing in flight can reach it any more)
+            a2w[sc + 1] = make_uint2(__float_as_uint(NEG), 0xffffffffu);
+            if (lane == 0) out_id[sc - 1] = root.y;
+            hole = mine ? 1u : hole;
+            Lv = mine ? __uint_as_float(ls.x) : Lv;
+            Lid = mine ? ls.y : Lid;
+            // (sc == 1: the last entry is the root itself -- its walk finds no child and puts it back; nothing reads it again)
+            walk_step6(a2w, a4, hole, Lv, Lid, P);
+            lds_order();
+            t++;
+            nticks++;
+        }
+        // ---- a plain tick, and the decision for the next one: no start while a walk stands on slot n - t or above it
+        walk_step6(a2w, a4, hole, Lv, Lid, P);
+        // (on or above slot n - t, whose entry the next pop takes, or slot n - t + 1, which it declares dead)
+        const uint32_t scn = n - t;  // (t == n: the loop ends)
+        const uint32_t ch_ = (uint32_t)__builtin_clz(hole | 1u);
+        const uint32_t sh0 = ch_ - (uint32_t)__builtin_clz(scn | 1u), sh1 = ch_ - (uint32_t)__builtin_clz(scn + 1u);
+        const bool above = (sh0 < 32u && (scn >> sh0) == hole) || (sh1 < 32u && ((scn + 1u) >> sh1) == hole);
+        create = !__ballot(above);
+        Lv = hole == 0 ? POS : Lv;
+        lds_order();
+        nticks++;
+    }
+    if (lane == 0 && blockIdx.x == 0) g_ticks6 = nticks;
+    while (__ballot(hole != 0)) {
+        walk_step6(a2w, a4, hole, Lv, Lid, P);
+        Lv = hole == 0 ? POS : Lv;
+        lds_order();
+    }
+}
+
 template <int V> __global__ __launch_bounds__(64) void sort_rows(const float* heaps, uint32_t n, uint32_t* out, unsigned long long* cycles) {
     extern __shared__ __align__(16) unsigned char smem[];
     HeapEnt* a = reinterpret_cast<HeapEnt*>(smem);
@@ -310,7 +379,8 @@ template <int V> __global__ __launch_bounds__(64) void sort_rows(const float* he
     else if (V == 2) heapsort_v2(a, n, out_id, lane);
     else if (V == 3) heapsort_v3(a, n, out_id, lane);
     else if (V == 4) heapsort_v4(a, n, out_id, lane);
-    else heapsort_v5(a, n, out_id, lane);
+    else if (V == 5) heapsort_v5(a, n, out_id, lane);
+    else heapsort_v6(a, n, out_id, lane);
     const unsigned long long c1 = __builtin_readcyclecounter();
     wave_sync();
     for (uint32_t i = lane; i < n; i += 64) out[(size_t)blockIdx.x * n + i] = out_id[i];
@@ -360,8 +430,8 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dh, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     const size_t shmem = (size_t)(n + 4) * 8 + (size_t)(n + 1) * 4;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int ver = 1; ver <= 5; ver++) {
-        auto kern = ver == 1 ? sort_rows<1> : ver == 2 ? sort_rows<2> : ver == 3 ? sort_rows<3> : ver == 4 ? sort_rows<4> : sort_rows<5>;
+    for (int ver = 3; ver <= 6; ver++) {
+        auto kern = ver == 3 ? sort_rows<3> : ver == 4 ? sort_rows<4> : ver == 5 ? sort_rows<5> : sort_rows<6>;
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         float best = 1e9f;
         for (int rep = 0; rep < 3; rep++) {
@@ -380,6 +450,7 @@ int main(int argc, char** argv) {
             for (uint32_t i = 0; i < n; i++) bad += want[i] != out[(size_t)r * n + i];
         }
         double mc = 0; for (auto c : cyc) mc += c; mc /= rows;
+        if (ver == 6) { unsigned long long tk = 0; CK(hipMemcpyFromSymbol(&tk, HIP_SYMBOL(g_ticks6), 8)); printf("   v6 row 0: %llu ticks for %u pops = %.2f ticks per pop\n", tk, n, (double)tk / n); }
         printf("v%d: n %u, %u rows: %.3f ms per launch, %.0f cycle-counter ticks per row (%.1f per pop), wrong entries %zu\n", ver, n, rows, best, mc, mc / n, bad);
     }
     return 0;

@@ -88,7 +88,7 @@ CFGS = {"1": ("sift", 1_000_000, 10000, 1024, 10, (8,), 1),
         "5": ("gist", 1_000_000, 10000, 4096, 10, (32, 64), 1)}
 
 
-def run_config(torch, capi, dev, c, nprobes=None, sample=64, ref_sample=2000, log=None):
+def run_config(torch, capi, dev, c, nprobes=None, sample=64, ref_sample=2000, log=None, in_flight=3):
     """one BASELINE config (build + timed fixed-nprobe searches + parity against the pinned oracle and, where its harness is
     present, the compiled reference): yields one dict per nprobe"""
     from oracle import pyoracle, refbench
@@ -133,6 +133,34 @@ def run_config(torch, capi, dev, c, nprobes=None, sample=64, ref_sample=2000, lo
             if best is None or dt < best[0]:
                 best = (dt, h.last_timing(), h.stats(), h.last_timing_detail())
         dt, tm, st, det = best
+        # ... and with searches in flight, as the headline is measured: the same batch submitted again and again through the asynchronous
+        # entry points (amd_ivf_submit_search_resident / amd_ivf_wait), `lag` searches at a time, results of every call compared with the
+        # synchronous call's
+        flight = None
+        if in_flight > 1:
+            h.set_async_depth(in_flight)
+            nrun = 4 * in_flight
+            bufs = [(np.empty((nq, k), np.float32), np.empty((nq, k), np.int64)) for _ in range(2 * in_flight)]
+
+            def run(nsteps):
+                pend, same_all = [], True
+                for sn in range(nsteps):
+                    if len(pend) == len(bufs):
+                        Dp, Ip, _, _ = h.wait(pend.pop(0))
+                        same_all &= bool(np.array_equal(Ip, I) and np.array_equal(Dp.view(np.uint32), D.view(np.uint32)))
+                    pend.append(h.submit_search_resident(0, nq, k, nprobe, out=bufs[sn % len(bufs)]))
+                while pend:
+                    Dp, Ip, _, _ = h.wait(pend.pop(0))
+                    same_all &= bool(np.array_equal(Ip, I) and np.array_equal(Dp.view(np.uint32), D.view(np.uint32)))
+                return same_all
+
+            run(2 * in_flight)
+            t0 = time.perf_counter()
+            ok = run(nrun)
+            el = time.perf_counter() - t0
+            flight = {"searches_at_a_time": in_flight, "value": nq * nrun / el, "unit": "queries/s", "ms_per_batch": 1e3 * el / nrun,
+                      "same_results_as_the_synchronous_call": ok}
+            h.set_async_depth(0)
         recall = np.mean([len(set(I[i]) & set(gtI[i])) / k for i in range(0, nq, 10)])
         S = sample
         cores = bench.host_cores()
@@ -192,6 +220,7 @@ def run_config(torch, capi, dev, c, nprobes=None, sample=64, ref_sample=2000, lo
                "coarse_rankings_from_matrix_core_distances": int(h.last_coarse_pick()),
                "scan_ms": tm["scan_ms"], "select_ms": tm["select_ms"], "coarse_ms": tm["coarse_ms"], "phases": phases, "roofline": roof,
                "scan_algorithmic_GBps": alg / 1e6 / max(tm["scan_ms"], 1e-9), "tile_slot_efficiency": tm["slot_efficiency"],
+               "in_flight": flight,
                "cpu_oracle_qps": cpu, "cpu_threads": cores, "gpu_equals_cpu_on_sample": same, "reference": ref,
                "gpu_equals_reference": (ref or {}).get("gpu_equals_reference")}
     h.close()
@@ -204,13 +233,14 @@ def main():
     ap.add_argument("--sample", type=int, default=64)
     ap.add_argument("--ref-sample", type=int, default=2000, help="queries the compiled reference runs (oracle/_ref/ref_harness fixedbench)")
     ap.add_argument("--nprobes", default="", help="comma list: only these nprobe values")
+    ap.add_argument("--in-flight", type=int, default=3, help="searches at a time in the in_flight block (1: skip it)")
     args = ap.parse_args()
     import torch
     from auncel_amd import capi
     dev = torch.device("cuda", 0)
     for c in args.cfg.split(","):
         nprobes = tuple(int(v) for v in args.nprobes.split(",")) if args.nprobes else None
-        for line in run_config(torch, capi, dev, c, nprobes, args.sample, args.ref_sample):
+        for line in run_config(torch, capi, dev, c, nprobes, args.sample, args.ref_sample, in_flight=args.in_flight):
             print(json.dumps(line), flush=True)
 
 
