@@ -972,6 +972,11 @@ def main():
         tr1 = np.zeros(nall, dtype=np.float32)
         lD = np.empty((ncall, K), np.float32)
         lI = np.empty((ncall, K), np.int64)
+        # (calls of fewer than 20 queries: the engine's own policy for runs of equal coarse distances -- centroid-number order first, the
+        # call repeated with the reference's heap order only if a run lies where the query read -- gives the reference's result as well
+        # and does not send every ranking with a run in reach through the 1.6 ms heap: the option is left unset for this leg)
+        if "AUNCEL_AMD_COARSE_TIES" not in os.environ:
+            h.set_option("coarse_ties", float("nan"))
         for i in range(20):
             h.search_adaptive(int(ids1[i]), 1, topk, chosen, chosen_std, req, np1, tr1)
         wall, inside = np.zeros(ncall), np.zeros(ncall)
@@ -983,6 +988,8 @@ def main():
             wall[i] = (time.perf_counter() - tq) * 1e3
             inside[i] = h.last_timing()["total_ms"]
             lD[i], lI[i] = D1[0], I1[0]
+        if "AUNCEL_AMD_COARSE_TIES" not in os.environ:
+            h.set_option("coarse_ties", ties_opt)
         lat_keep = (ids1, lD, lI, np1[ids1].copy())
         lat1 = {"what": "amd_ivf_search_adaptive over ONE resident query per call, the reference's protocol (eval/bound.cpp:391-396)", "calls": int(ncall),
                 "ms_median": float(np.median(wall)), "ms_p90": float(np.percentile(wall, 90)), "ms_p99": float(np.percentile(wall, 99)), "ms_min": float(wall.min()),

@@ -1,21 +1,17 @@
 #!/bin/bash
 # copy what scripts/refresh_round.sh brought back under gpurun_out/ into the tracked profiles/ directory
-tag=${1:-r05}
+tag=${1:-r06}
 cp gpurun_out/summary_$tag/${tag}_summary.md gpurun_out/summary_$tag/${tag}_pmc.json gpurun_out/summary_$tag/${tag}_kernel_stats.csv profiles/
 cp gpurun_out/summary_$tag/${tag}_pmc_cfg5.json gpurun_out/summary_$tag/${tag}_pmc_cfg3.json profiles/ 2>/dev/null
-cp gpurun_out/bench_threads_$tag.json profiles/${tag}_bench_line_threads_runner.json 2>/dev/null
 cp gpurun_out/bench_$tag.json profiles/${tag}_bench_line.json
-cp gpurun_out/perf_scan_$tag.txt profiles/${tag}_fixed_nprobe.txt
 cp gpurun_out/configs_$tag.jsonl profiles/${tag}_other_configs.jsonl
 cp gpurun_out/shards_$tag.json profiles/${tag}_shards_one_gpu.json
 cp gpurun_out/effect_time_$tag.jsonl profiles/${tag}_effect_time.jsonl
 cp gpurun_out/latency1_$tag.txt profiles/${tag}_latency_batch1.txt
-cp gpurun_out/bw_probe_$tag.txt profiles/${tag}_bw_probe.txt
-cp gpurun_out/latency1_calls_summary_$tag.txt profiles/${tag}_latency_batch1_calls.txt 2>/dev/null
 cp gpurun_out/gpu_tests_$tag.txt profiles/${tag}_gpu_tests.txt
 grep -v "rocprofv3\|^W2026\|^E2026" gpurun_out/in_flight_busy_$tag.txt > profiles/${tag}_in_flight_busy.txt
-cp gpurun_out/bench_driver_flags_$tag.json profiles/${tag}_bench_line_driver_flags.json
+cp gpurun_out/chain_$tag.txt profiles/${tag}_chain.txt
+cp gpurun_out/bench_lines_repeat_$tag.jsonl profiles/${tag}_bench_lines_repeat.jsonl
+cp gpurun_out/repeat_$tag.txt profiles/${tag}_bench_lines_repeat_summary.txt
 for n in fp32_path exact_ties id_ties cfg5; do cp gpurun_out/timeline_${n}_$tag.txt profiles/${tag}_timeline_$n.txt; done
-cp gpurun_out/timeline_batch1_$tag.txt profiles/${tag}_timeline_batch1.txt 2>/dev/null
-cp gpurun_out/scan_prof_$tag.txt profiles/${tag}_scan_wave_cycles.txt 2>/dev/null
 true
