@@ -4676,9 +4676,13 @@ int amd_ivf_merge_tables(int metric, size_t n, size_t k, size_t nshard, const fl
     const bool smallest_first = metric == METRIC_L2;
     auto before = [&](float a, float b) { return smallest_first ? a < b : a > b; };  // C::cmp
     const size_t stride = n * k;
+    // (queries are independent: the reference runs this loop under "#pragma omp parallel for", IndexShards.cpp:56; here a few host
+    // threads take ranges of queries when the tables are large -- eight shards x 10 000 queries are 1.5 ms on one thread, which
+    // would be the slowest stage of the pipelined shards mode)
+    auto merge_range = [&](size_t i_begin, size_t i_end) {
     std::vector<int> pointer(nshard), sid(nshard);
     std::vector<float> hv(nshard);
-    for (size_t i = 0; i < n; i++) {
+    for (size_t i = i_begin; i < i_end; i++) {
         const float* Din = all_D + i * k;
         const int64_t* Iin = all_I + i * k;
         size_t hs = 0;
@@ -4734,6 +4738,17 @@ int amd_ivf_merge_tables(int metric, size_t n, size_t k, size_t nshard, const fl
                 if ((size_t)p < k && Iin[stride * s + p] >= 0) push(Din[stride * s + p], s);
             }
         }
+    }
+    };
+    const size_t work = n * nshard * k;
+    size_t nthreads = work >= ((size_t)1 << 18) ? std::min<size_t>(8, std::max<size_t>(1, std::thread::hardware_concurrency() / 2)) : 1;
+    if (const char* e = getenv("AUNCEL_AMD_MERGE_THREADS")) nthreads = std::max(1, atoi(e));
+    if (nthreads <= 1) {
+        merge_range(0, n);
+    } else {
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nthreads; t++) th.emplace_back(merge_range, n * t / nthreads, n * (t + 1) / nthreads);
+        for (auto& t : th) t.join();
     }
     API_END
 }
