@@ -5024,7 +5024,7 @@ static int async_running_limit(const AsyncPool* p) {
 // Option "coalesce": tickets a group may hold (1: off).  The queue is only looked at, never waited on: a ticket without a
 // successor in the queue runs alone.
 static bool continues_group(const AdaptiveSpec& g, size_t g_n, const AdaptiveSpec& s, size_t K) {
-    return s.query_topk == g.query_topk && s.multipler == g.multipler && s.std_m == g.std_m && s.require_acc == g.require_acc &&
+    return K > 0 && g.n > 0 && s.query_topk == g.query_topk && s.multipler == g.multipler && s.std_m == g.std_m && s.require_acc == g.require_acc &&
            s.gt_D == g.gt_D && s.profile == g.profile && s.coarse_mode == g.coarse_mode && s.n == g.n && s.start == g.start + g_n &&
            s.D == g.D + g_n * K && s.I == g.I + g_n * K && s.my_nprobe && s.t_recalls && g.my_nprobe && g.t_recalls;
 }

@@ -192,6 +192,26 @@ def test_dense_rounds_from_rows_and_from_the_lane_ordered_copy(capi, oracle, d, 
         assert np.array_equal(got[0][1], got[1][1]) and np.array_equal(bits(got[0][0]), bits(got[1][0]))
 
 
+def test_an_index_whose_lane_ordered_copy_does_not_fit_still_searches(capi, oracle, monkeypatch):
+    """the lane-ordered copy is the fp32 lists once more: where it does not fit beside them (here: AUNCEL_AMD_LANES_NOFIT, the
+    hipMemGetInfo check answered "no") the search must not fail -- the dense rounds read the rows (scan_tiles_kernel), the state is
+    remembered (no second attempt), results are the oracle's"""
+    monkeypatch.setenv("AUNCEL_AMD_LANES_NOFIT", "1")
+    rs = np.random.RandomState(7350)
+    cen, assign, xb, xq = clustered(rs, 3000, 260, 96, 16)
+    lists = oracle.Lists(1, cen, xb, assign)
+    cd, ck = oracle.knn(1, xq, cen, 8)
+    eD, eI, est = oracle.search_preassigned(lists, xq, 10, ck, cd)
+    h = capi.Handle(96, 16, 1, 0)
+    h.set_centroids(cen)
+    h.set_lists_from_assign(xb, assign)
+    assert h.get_option("lanes") == 1  # (the option is on: it is the copy that is missing)
+    for _ in range(2):
+        D, I = h.search_preassigned(xq, 10, ck, cd)
+        assert np.array_equal(I, eI) and np.array_equal(bits(D), bits(eD))
+    h.close()
+
+
 def test_large_fp32_searches_wait_for_each_other(capi, oracle):
     """option "fp32_in_flight": with room for one, three threads' searches of >= 256 queries run one after the other and every one
     returns the oracle's result"""
