@@ -284,7 +284,7 @@ __global__ __launch_bounds__(ScanShape<QG>::NT) void scan_tiles_kernel(ScanArgs 
 constexpr int SCAN_LANE_AHEAD = AUNCEL_SCAN_LANE_AHEAD;
 #ifndef AUNCEL_LANES_NT
 #define AUNCEL_LANES_NT 2   // streaming hint on the block loads -- 1: always; 2: only where one wave reads the block (QG 1: the other shapes'
-                            // waves find it in L2); 0: never.  Measured the same within a run's spread (scripts/r05_lanes_nt.sh)
+                            // waves find it in L2); 0: never.  Measured the same within a run's spread (round 5)
 #endif
 
 template <int METRIC, int QG, int ARITH>
