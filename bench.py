@@ -925,7 +925,8 @@ def main():
     fixed32 = None
     if not args.no_legs and "fixed" not in skip_legs:
         fnp, fk = 32, topk
-        nst = max(2 * nfl, args.steps // 2)
+        # (a step is 1 ms: twelve of them were a window that one hiccup moved by a third -- 2.9 to 5.2 M q/s on one box)
+        nst = max(6 * nfl, 2 * args.steps)
         # (600 KB a step: every step of the leg keeps its own, for the parity check)
         fouts = [(np.empty((ses, fk), np.float32), np.empty((ses, fk), np.int64)) for _ in range(max(2 * nfl, nst))]
 
