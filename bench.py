@@ -856,7 +856,7 @@ def main():
         for c in ctxs:
             c.set_byte_codes(False)
         # (at least two rounds of the searches in flight: six steps were a third of the leg's own spread)
-        nst = int(os.environ.get("AUNCEL_BENCH_FP32_STEPS", max(2 * nfl, args.steps // 2)))
+        nst = int(os.environ.get("AUNCEL_BENCH_FP32_STEPS", max(4 * nfl, args.steps)))  # (12 steps still read 0.9 once where 24 read 1.4-1.5)
         leg = timed_leg(nst)
         kept_fp32 = leg["kept"]
         fD, fI, f_np, f_start = leg["last"]
