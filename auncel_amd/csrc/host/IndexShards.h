@@ -32,6 +32,8 @@ struct IndexShardsByList : IndexShards {
     std::vector<IndexIVFFlat*> owned;
     IndexShardsByList(const IndexIVFFlat& index, int nshard, bool threaded = true, const int* devices = nullptr);
     ~IndexShardsByList() override;
+    IndexShardsByList(const IndexShardsByList&) = delete;
+    IndexShardsByList& operator=(const IndexShardsByList&) = delete;
 };
 
 }  // namespace faiss

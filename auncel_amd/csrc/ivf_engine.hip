@@ -5072,8 +5072,15 @@ static void async_worker(AsyncPool* p, size_t i) {
             p->running++;
         }
         amd_ivf_t* c = p->ctx[i];
-        const int rc = group[0]->adaptive ? run_adaptive_group(c, group) : group[0]->run(c);
-        std::string err = rc ? std::string(amd_ivf_last_error()) : std::string();
+        int rc;
+        std::string err;
+        try {
+            rc = group[0]->adaptive ? run_adaptive_group(c, group) : group[0]->run(c);
+            if (rc) err = amd_ivf_last_error();
+        } catch (const std::exception& e) {  // (the entry points catch their own: this is the group's scratch memory)
+            rc = -4;
+            err = e.what();
+        }
         double timing[9];
         uint64_t diag[4];
         amd_ivf_last_timing(c, timing);
